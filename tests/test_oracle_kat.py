@@ -1,0 +1,63 @@
+"""Pins the CPU oracle against the reference's own reproducible known answers."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import kat_inputs as K
+
+
+def _printed_equal(v, expected, decimals):
+    """R prints a vector with a common number of decimals (7 significant digits for the
+    element that needs the most): equal iff every value rounds to the printed one."""
+    return np.all(np.abs(np.asarray(v) - np.asarray(expected)) <= 0.5 * 10.0 ** (-decimals) * (1 + 1e-9))
+
+
+def test_kat1_loglik_lasso_mcp(doc_kats):
+    x, y = K.kat1()
+    fit = orc.fit_dense(x, y, penalty=["lasso", "mcp"], compute_loss=True)
+    k = doc_kats["kat1"]
+    assert _printed_equal(K.loglik(fit["loss"][0], 2000), k["loglik_lasso"], 3)
+    assert _printed_equal(K.loglik(fit["loss"][1], 2000), k["loglik_mcp"], 3)
+    assert fit["niter"][0][0] == 1 and np.all(fit["beta"][0][1:, 0] == 0)       # Q13
+
+
+def test_kat1b_cv_full_fit_25_lambda(doc_kats):
+    x, y = K.kat1()
+    fit = orc.fit_dense(x, y, penalty=["lasso", "mcp"], compute_loss=True, nlambda=25)
+    k = doc_kats["kat1b"]
+    assert _printed_equal(K.loglik(fit["loss"][0], 2000), k["loglik_lasso"], 3)
+    assert _printed_equal(K.loglik(fit["loss"][1], 2000), k["loglik_mcp"], 3)
+
+
+def test_kat2_predict_mse_lasso_grp_lasso(doc_kats):
+    x, y, xt, yt = K.kat2()
+    groups = np.repeat(np.arange(1, 11), 10)
+    fit = orc.fit_dense(x, y, penalty=["lasso", "grp.lasso"], groups=groups, unique_groups=np.arange(1, 11),
+                        nlambda=10)
+    k = doc_kats["kat2"]
+    for m, key in enumerate(["mse_lasso", "mse_grp_lasso"]):
+        pred = fit["beta"][m][0][None, :] + xt @ fit["beta"][m][1:]
+        mse = ((yt[:, None] - pred) ** 2).mean(0)
+        assert _printed_equal(mse, k[key], 6), key
+
+
+def test_kat3_big_vs_dense(doc_kats):
+    x, y = K.kat3()
+    groups = np.repeat(np.arange(1, 21), 5)
+    dense = orc.fit_dense(x, y, penalty=["lasso", "grp.lasso"], groups=groups, unique_groups=np.arange(1, 21))
+    # R/big_oem.R:226-259: intercept => groups gets a leading 0, unique.groups gains 0
+    big = orc.fit_big(x, y, penalty=["lasso", "grp.lasso"], groups=np.concatenate([[0], groups]),
+                      unique_groups=np.arange(0, 21))
+    diff = np.abs(big["beta"][0] - dense["beta"][0]).max()
+    assert float(f"{diff:.7g}") == doc_kats["kat3"]["max_abs_big_minus_dense_lasso"]
+
+
+def test_prop_dense_equals_xtx(doc_kats):
+    """R/oem_xtx.R:78-103: oem(standardize=F, intercept=F) == oem.xtx(crossprod(x)/n, crossprod(x,y)/n)."""
+    x, y = K.kat1()
+    n = x.shape[0]
+    a = orc.fit_dense(x, y, penalty=["lasso", "mcp"], standardize=False, intercept=False)
+    b = orc.fit_xtx(x.T @ x / n, x.T @ y / n, penalty=["lasso", "mcp"])
+    for m in range(2):
+        assert np.abs(a["beta"][m][1:] - b["beta"][m]).max() < 1e-13
+        assert np.all(a["beta"][m][0] == 0)
