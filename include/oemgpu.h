@@ -1,0 +1,174 @@
+/*
+ * oemgpu.h -- C ABI of the MI355X-native Orthogonalizing-EM solver (liboemgpu.so).
+ *
+ * Drop-in boundary for the dense Gaussian hot path of jaredhuling/oem (reference @ 2024_08_07):
+ * the three entry points below are what the reference's `.Call` targets would bind instead of
+ * their RcppEigen bodies (INTEGRATION.md shows the R-side shim).  Plain pointers and sizes only;
+ * everything is IEEE fp64, matrices are column-major, outputs are caller-allocated, inputs are
+ * never written.  All "ref:" citations are paths under the reference tree.
+ *
+ * Return value: 0 on success, <0 on error; oemgpu_last_error() gives the message
+ * (thread-local).  There is NO CPU fallback: without a gfx950 device every compute entry
+ * point fails with OEMGPU_ERR_NO_DEVICE.
+ */
+#ifndef OEMGPU_H
+#define OEMGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OEMGPU_OK              0
+#define OEMGPU_ERR_ARG        -1   /* invalid argument (the R front ends stop() on these: ref R/oem.R:215-431) */
+#define OEMGPU_ERR_NO_DEVICE  -2
+#define OEMGPU_ERR_HIP        -3   /* a HIP runtime call failed */
+#define OEMGPU_ERR_UNSUPPORTED -4  /* outside the restated path (e.g. p >= n branch, ref src/oem_dense.h:363-366) */
+#define OEMGPU_ERR_INTERNAL   -5
+
+/* penalty codes = position in the R default vector (ref R/oem.R:165-173) */
+enum {
+    OEMGPU_ELASTIC_NET = 0, OEMGPU_LASSO = 1, OEMGPU_OLS = 2, OEMGPU_MCP = 3, OEMGPU_SCAD = 4,
+    OEMGPU_MCP_NET = 5, OEMGPU_SCAD_NET = 6, OEMGPU_GRP_LASSO = 7, OEMGPU_GRP_LASSO_NET = 8,
+    OEMGPU_GRP_MCP = 9, OEMGPU_GRP_SCAD = 10, OEMGPU_GRP_MCP_NET = 11, OEMGPU_GRP_SCAD_NET = 12,
+    OEMGPU_SPARSE_GRP_LASSO = 13, OEMGPU_NPENALTIES = 14
+};
+
+/* Arguments shared by the three entry points: the scalar/vector arguments of
+ * oem_fit_dense (ref src/oem_dense.cpp:30-48), oem_xtx (ref src/oem_xtx.cpp:29-44) and
+ * oem_fit_big (ref src/oem_big.cpp:30-48) after R's coercions (ref R/oem.R:411-445). */
+typedef struct oemgpu_opts {
+    int32_t        npen;             /* length(penalty) >= 1 */
+    const int32_t *penalty;          /* npen codes */
+    int32_t        nlambda;          /* nlambda_, used when no lambda is supplied */
+    double         lambda_min_ratio; /* lmin_ratio_ */
+    const double  *lambda_user;      /* lambda_: npen x nlambda_user, one row per penalty, each sorted
+                                        decreasing (ref R/oem.R:366-404); NULL => generated grid */
+    int32_t        nlambda_user;
+    double         alpha, gamma, tau;
+    double         tol;              /* opts$tol */
+    int32_t        maxit;            /* opts$maxit */
+    int32_t        accelerate;       /* opts$accelerate (dense only, ref src/oem_dense.h:633-651) */
+    int32_t        compute_loss;     /* compute_loss_ (dense only) */
+    const double  *penalty_factor;   /* p values */
+    const int32_t *groups;           /* ngroupvars values or NULL; big.oem with intercept passes p+1
+                                        values with a leading 0 (ref R/big_oem.R:254-257) */
+    int32_t        ngroupvars;
+    const int32_t *unique_groups;    /* ngroups values, sorted (ref R/oem.R:292) */
+    int32_t        ngroups;
+    const double  *group_weights;    /* n_group_weights values; 0 => sqrt(group size) (ref src/oem_dense.h:447-454) */
+    int32_t        n_group_weights;
+    int32_t        device;           /* HIP device ordinal; -1 => current device */
+} oemgpu_opts;
+
+/* -------------------------------------------------------------------------------------------
+ * Drop-in entry points (host buffers in, host buffers out; exactly the data the .Call carries).
+ *
+ * nl below = nlambda_user if lambda_user != NULL else nlambda.
+ * beta:       npen * nl * (p+1) doubles; beta[(k*nl + i)*(p+1) + j] = coefficient j (0 = intercept)
+ *             of penalty k at lambda i, i.e. each penalty's block is the reference's (p+1) x nl
+ *             column-major matrix (ref src/oem_dense.cpp:194,252-254).  For "ols" only i = 0 is
+ *             meaningful (ref :208-211,282-288).  oemgpu_fit_xtx: p rows, no intercept row
+ *             (ref src/oem_xtx.cpp:129).
+ * lambda_out: npen * nl, the unscaled lambda actually used (ref src/oem_dense.cpp:278)
+ * niter:      npen * nl (maxit+1 when the loop ran out, ref src/oem_base.h:94-109)
+ * loss:       npen * nl, 1e99 unless compute_loss (ref src/oem_dense.cpp:229-230,256-260)
+ * d:          1.005 * lambda_max(X'X/n) (ref src/oem_dense.h:498)
+ * ------------------------------------------------------------------------------------------- */
+
+/* replaces oem_fit_dense, ref src/oem_dense.cpp:30-309 (family "gaussian", weights empty) */
+int oemgpu_fit_dense(const double *x, int64_t n, int32_t p, const double *y,
+                     int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                     double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
+
+/* replaces oem_xtx, ref src/oem_xtx.cpp:29-219.  scale_factor: p values or NULL. */
+int oemgpu_fit_xtx(const double *xtx, const double *xty, int32_t p, const double *scale_factor,
+                   const oemgpu_opts *o,
+                   double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
+
+/* replaces oem_fit_big / oem_fit_fb_big, ref src/oem_big.cpp:30-258, src/oem_fb_big.cpp:30-258.
+ * The big.matrix is handed over as row shards (the reference itself slices rows,
+ * ref src/oem_big.h:319-361): shard s holds n_shard[s] rows, column-major with leading
+ * dimension n_shard[s].  One shard of n rows is the plain big.matrix buffer. */
+int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_t nshards, int32_t p,
+                   const double *const *y_shards,
+                   int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                   double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
+
+/* -------------------------------------------------------------------------------------------
+ * Device-resident / staged interface.  Used when X already lives in HBM (bench.py, repeated
+ * solves) and by the one-process-per-GPU row-sharded driver (oem_amd/distributed.py), which
+ * all-reduces the moment buffer between oemgpu_moments_dev and oemgpu_solve_moments_dev.
+ * All *_dev pointers are device pointers on the context's device.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct oemgpu_ctx oemgpu_ctx;
+
+/* stream: a hipStream_t to run on, or NULL for a stream owned by the context */
+oemgpu_ctx *oemgpu_create(int32_t device, void *stream);
+void        oemgpu_destroy(oemgpu_ctx *ctx);
+int         oemgpu_synchronize(oemgpu_ctx *ctx);
+
+/* Moment buffer of the augmented, shifted data Z = [X - 1 c_x' | y - c_y | 1]:
+ * q = p + 2; M is q x q column-major, lower triangle valid:
+ *   M[i,j] (i>=j, i,j<p) = sum_r (x_ri - c_i)(x_rj - c_j)      M[p,j]   = sum_r (y_r - c_y)(x_rj - c_j)
+ *   M[p,p] = sum_r (y_r - c_y)^2     M[p+1,j] = sum_r (x_rj - c_j)     M[p+1,p] = sum_r (y_r - c_y)
+ *   M[p+1,p+1] = number of rows.
+ * Moments add over row shards that use the same shift, which is what the RCCL all-reduce sums. */
+static inline int64_t oemgpu_moments_len(int32_t p) { return (int64_t)(p + 2) * (p + 2); }
+
+/* Sample sums for the provisional shift: sums_dev[0..p-1] = sum over the sampled rows of x_j,
+ * sums_dev[p] = same for y, sums_dev[p+1] = number of sampled rows.  (all-reduce these, then
+ * c = sums / count). */
+int oemgpu_shift_sums_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64_t ld, int32_t p,
+                          const double *y_dev, double *sums_dev);
+
+/* moments_dev <- moments of rows [0,n) about shift c (shift_dev: p+1 values = c_x, c_y; NULL => zeros).
+ * Replaces DataStd's passes + X'Y + XtX (ref src/DataStd.h:203-265, src/oem_dense.h:318-361,704-707;
+ * src/oem_big.h:743-841) with ONE pass over X. */
+int oemgpu_moments_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64_t ld, int32_t p,
+                       const double *y_dev, const double *shift_dev, double *moments_dev);
+
+/* semantics selector for oemgpu_solve_moments_dev */
+#define OEMGPU_SEM_DENSE 0   /* DataStd + oemDense (ref src/DataStd.h, src/oem_dense.h) */
+#define OEMGPU_SEM_BIG   1   /* oemBig: (n-1)-scaling, intercept as Gram row/column (ref src/oem_big.h:731-842,469-566) */
+
+/* From (all-reduced) moments to the full result: standardisation constants, XX, XY, d, lambda grid,
+ * penalty x lambda loops, recover.  Outputs are HOST buffers as in oemgpu_fit_dense. */
+int oemgpu_solve_moments_dev(oemgpu_ctx *ctx, const double *moments_dev, const double *shift_dev, int32_t p,
+                             int32_t semantics, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                             double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
+
+/* oemgpu_fit_dense with X (n x p, leading dimension ld >= n) and y already on the device. */
+int oemgpu_fit_dense_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
+                         int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                         double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
+
+/* oemgpu_fit_xtx with xtx (p x p) / xty on the device. */
+int oemgpu_fit_xtx_dev(oemgpu_ctx *ctx, const double *xtx_dev, const double *xty_dev, int32_t p,
+                       const double *scale_factor, const oemgpu_opts *o,
+                       double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
+
+/* lambda_max of a symmetric p x p device matrix (the Spectra call of ref src/oem_dense.h:485-498). */
+int oemgpu_eig_max_dev(oemgpu_ctx *ctx, const double *a_dev, int32_t p, double *lambda_max);
+
+/* Time of the most recent kernels on this context, measured with HIP events on the context's
+ * stream (milliseconds; 0 if that stage has not run).  Stages: */
+#define OEMGPU_T_SHIFT   0
+#define OEMGPU_T_MOMENTS 1   /* Gram/moment build (the MFMA kernel + its partial reduction) */
+#define OEMGPU_T_FINAL   2   /* moments -> XX, XY, standardisation constants */
+#define OEMGPU_T_EIGPATH 3   /* eigenvalue + penalty x lambda loops */
+#define OEMGPU_T_GRAMK   4   /* the MFMA Gram kernel alone */
+#define OEMGPU_NTIMERS   8
+int oemgpu_last_timings(oemgpu_ctx *ctx, double *ms /* OEMGPU_NTIMERS */);
+/* enable (1) / disable (0) event timing of the stages (off by default: events cost a few us) */
+int oemgpu_set_timing(oemgpu_ctx *ctx, int32_t on);
+
+const char *oemgpu_last_error(void);
+const char *oemgpu_version(void);
+int         oemgpu_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OEMGPU_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of liboemgpu.so (include/oemgpu.h).  No torch types cross this boundary."""
+import ctypes as C
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "liboemgpu.so"
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+PENALTIES = ["elastic.net", "lasso", "ols", "mcp", "scad", "mcp.net", "scad.net",
+             "grp.lasso", "grp.lasso.net", "grp.mcp", "grp.scad", "grp.mcp.net",
+             "grp.scad.net", "sparse.grp.lasso"]          # R/oem.R:165-173; index = C penalty code
+
+OEMGPU_SEM_DENSE, OEMGPU_SEM_BIG = 0, 1
+NTIMERS = 8
+T_SHIFT, T_MOMENTS, T_FINAL, T_EIGPATH, T_GRAMK = 0, 1, 2, 3, 4
+
+
+class OemgpuOpts(C.Structure):
+    _fields_ = [
+        ("npen", C.c_int32), ("penalty", _ip),
+        ("nlambda", C.c_int32), ("lambda_min_ratio", C.c_double),
+        ("lambda_user", _dp), ("nlambda_user", C.c_int32),
+        ("alpha", C.c_double), ("gamma", C.c_double), ("tau", C.c_double), ("tol", C.c_double),
+        ("maxit", C.c_int32), ("accelerate", C.c_int32), ("compute_loss", C.c_int32),
+        ("penalty_factor", _dp),
+        ("groups", _ip), ("ngroupvars", C.c_int32),
+        ("unique_groups", _ip), ("ngroups", C.c_int32),
+        ("group_weights", _dp), ("n_group_weights", C.c_int32),
+        ("device", C.c_int32),
+    ]
+
+
+class OemgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"liboemgpu error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+_OUT = [_dp, _dp, _ip, _dp, _dp]           # beta, lambda_out, niter, loss, d
+_SIGS = {
+    "oemgpu_fit_dense": (C.c_int, [_dp, C.c_int64, C.c_int32, _dp, C.c_int32, C.c_int32, C.POINTER(OemgpuOpts)] + _OUT),
+    "oemgpu_fit_xtx": (C.c_int, [_dp, _dp, C.c_int32, _dp, C.POINTER(OemgpuOpts)] + _OUT),
+    "oemgpu_fit_big": (C.c_int, [C.POINTER(_dp), C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.POINTER(_dp), C.c_int32,
+                                 C.c_int32, C.POINTER(OemgpuOpts)] + _OUT),
+    "oemgpu_create": (C.c_void_p, [C.c_int32, C.c_void_p]),
+    "oemgpu_destroy": (None, [C.c_void_p]),
+    "oemgpu_synchronize": (C.c_int, [C.c_void_p]),
+    "oemgpu_shift_sums_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "oemgpu_moments_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "oemgpu_solve_moments_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.POINTER(OemgpuOpts)] + _OUT),
+    "oemgpu_fit_dense_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int32,
+                                       C.c_int32, C.POINTER(OemgpuOpts)] + _OUT),
+    "oemgpu_fit_xtx_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, _dp, C.POINTER(OemgpuOpts)] + _OUT),
+    "oemgpu_eig_max_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, _dp]),
+    "oemgpu_last_timings": (C.c_int, [C.c_void_p, _dp]),
+    "oemgpu_set_timing": (C.c_int, [C.c_void_p, C.c_int32]),
+    "oemgpu_last_error": (C.c_char_p, []),
+    "oemgpu_version": (C.c_char_p, []),
+    "oemgpu_device_count": (C.c_int, []),
+}
+EXPORTS = sorted(_SIGS)
+
+
+def lib():
+    """Loads liboemgpu.so.  There is no fallback: a missing library is an error."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise OSError(f"{LIB_PATH} is missing: build it with `python -m oem_amd.build` "
+                          "(oem_amd has no CPU fallback)")
+        L = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise OemgpuError(rc, lib().oemgpu_last_error().decode())

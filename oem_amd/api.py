@@ -1,0 +1,431 @@
+"""Host-side mirror of the reference's R front ends for the dense Gaussian path.
+
+    oem()      <-> R/oem.R:162-507      (.Call("oem_fit_dense", ...)  R/oem.R:556-575)
+    oem_xtx()  <-> R/oem_xtx.R:109-360  (.Call("oem_xtx", ...)        R/oem_xtx.R:389-406)
+    big_oem()  <-> R/big_oem.R:121-441  (.Call("oem_fit_big", ...)    R/big_oem.R:447-491)
+
+Same argument names (dots become underscores, `lambda` is `lambda_`), same defaults, same
+validation messages, same result structure (`beta` / `lambda` / `niter` / `loss` lists, one entry
+per penalty, plus `d`, `nobs`, `nvars`, `penalty`, `family`, `varnames`, `nzero`).  All numerics run
+in liboemgpu.so (HIP kernels); there is no CPU fallback.
+
+x may be a numpy array (host: the drop-in entry points upload it) or a CUDA/HIP torch tensor
+(device resident: the *_dev entry points are used and X is never copied to the host).
+"""
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _lib as L
+
+PENALTIES = L.PENALTIES
+
+
+class OemFit(dict):
+    """The list returned by oem()/oem.xtx()/big.oem() (classes "oemfit_gaussian", "oem")."""
+
+    r_class = ("oemfit_gaussian", "oem")
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+# ------------------------------------------------------------------------------------------ helpers
+def _match_penalty(penalty):
+    """match.arg(penalty, several.ok=TRUE) (R/oem.R:202-208): default is the first choice only."""
+    if penalty is None:
+        return [PENALTIES[0]]
+    if isinstance(penalty, str):
+        penalty = [penalty]
+    out = []
+    for q in penalty:
+        hits = [c for c in PENALTIES if c == q] or [c for c in PENALTIES if c.startswith(q)]
+        if len(hits) != 1:
+            raise ValueError("'arg' should be one of " + ", ".join(f"'{c}'" for c in PENALTIES))
+        out.append(hits[0])
+    return out
+
+
+def _is_torch_cuda(x):
+    return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
+
+
+def _dptr(a):
+    return a.ctypes.data_as(L._dp) if a is not None and a.size > 0 else L._dp()
+
+
+def _iptr(a):
+    return a.ctypes.data_as(L._ip) if a is not None and a.size > 0 else L._ip()
+
+
+class _Args:
+    """Builds oemgpu_opts and keeps the numpy buffers alive."""
+
+    def __init__(self, penalty, lam_list, nlambda, lambda_min_ratio, alpha, gamma, tau, tol, maxit, accelerate,
+                 compute_loss, penalty_factor, groups, unique_groups, group_weights, device=-1):
+        self.pen = np.array([PENALTIES.index(q) for q in penalty], dtype=np.int32)
+        self.pf = np.ascontiguousarray(penalty_factor, dtype=np.float64)
+        nlu = len(lam_list[0]) if lam_list else 0
+        self.lam = np.ascontiguousarray(np.stack(lam_list), dtype=np.float64) if nlu > 0 else None
+        self.groups = np.ascontiguousarray(groups, dtype=np.int32)
+        self.ug = np.ascontiguousarray(unique_groups, dtype=np.int32)
+        self.gw = np.ascontiguousarray(group_weights, dtype=np.float64)
+        o = L.OemgpuOpts()
+        o.npen = len(self.pen); o.penalty = _iptr(self.pen)
+        o.nlambda = int(nlambda); o.lambda_min_ratio = float(lambda_min_ratio)
+        o.lambda_user = _dptr(self.lam); o.nlambda_user = nlu
+        o.alpha, o.gamma, o.tau, o.tol = float(alpha), float(gamma), float(tau), float(tol)
+        o.maxit, o.accelerate, o.compute_loss = int(maxit), int(bool(accelerate)), int(bool(compute_loss))
+        o.penalty_factor = _dptr(self.pf)
+        o.groups = _iptr(self.groups); o.ngroupvars = self.groups.size
+        o.unique_groups = _iptr(self.ug); o.ngroups = self.ug.size
+        o.group_weights = _dptr(self.gw); o.n_group_weights = self.gw.size
+        o.device = int(device)
+        self.c = o
+        self.nl = nlu if nlu > 0 else int(nlambda)
+        self.npen = len(self.pen)
+
+    def outputs(self, rows):
+        self.beta = np.zeros((self.npen, self.nl, rows))
+        self.lam_out = np.zeros((self.npen, self.nl))
+        self.niter = np.zeros((self.npen, self.nl), dtype=np.int32)
+        self.loss = np.zeros((self.npen, self.nl))
+        self.d = C.c_double(0.0)
+        return [_dptr(self.beta), _dptr(self.lam_out), _iptr(self.niter), _dptr(self.loss), C.byref(self.d)]
+
+
+def _lambda_list(lambda_, npen):
+    """R/oem.R:366-404"""
+    if isinstance(lambda_, (list, tuple)) and len(lambda_) > 0 and np.ndim(lambda_[0]) > 0:
+        if len(lambda_) != npen:
+            raise ValueError("If list of lambda vectors is provided, it must be \n"
+                             "                  the same length as the number of penalties fit")
+        n0 = len(lambda_[0])
+        out = []
+        for l in lambda_:
+            if l is None or len(l) < 1:
+                raise ValueError("Provided lambda vector must have at least one value")
+            if len(l) != n0:
+                raise ValueError("All provided lambda vectors must have same length")
+            out.append(np.sort(np.asarray(l, dtype=np.float64))[::-1].copy())
+        return out
+    lam = np.sort(np.asarray(lambda_, dtype=np.float64).ravel())[::-1].copy()
+    return [lam.copy() for _ in range(npen)]
+
+
+def _group_setup(penalty, groups, group_weights, p, intercept_adds_zero_group):
+    """R/oem.R:287-338 (dense gaussian: the intercept never adds a group) and R/big_oem.R:226-259."""
+    if any("grp" in q for q in penalty):
+        groups = np.asarray(groups).ravel()
+        if len(groups) != p:
+            raise ValueError("If any group penalty is used groups must have same length as number of columns in x")
+        unique_groups = np.sort(np.unique(groups))
+        has_zero = bool(np.any(unique_groups == 0))
+        if group_weights is not None:
+            group_weights = np.asarray(group_weights, dtype=np.float64).ravel().copy()
+            # `group.weights[zero.idx] <- 0` indexes with the VALUE 0, a no-op in R: kept as is
+            if not has_zero and intercept_adds_zero_group:
+                unique_groups = np.concatenate([[0], unique_groups])
+                group_weights = np.concatenate([[0.0], group_weights])
+            if len(group_weights) != len(unique_groups):
+                raise ValueError("group.weights must have same length as the number of groups")
+        else:
+            group_weights = np.zeros(0)
+            if not has_zero and intercept_adds_zero_group:
+                unique_groups = np.sort(np.concatenate([[0], unique_groups]))
+        if intercept_adds_zero_group:
+            groups = np.concatenate([[0], groups])
+        return groups.astype(np.int32), unique_groups.astype(np.int32), group_weights
+    return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0)
+
+
+def _common_checks(nlambda, lambda_min_ratio, maxit, irls_maxit, tol, irls_tol):
+    if lambda_min_ratio >= 1 or lambda_min_ratio <= 0:
+        raise ValueError("lambda.min.ratio must be between 0 and 1")
+    if int(np.ravel(nlambda)[0]) <= 0:
+        raise ValueError("nlambda must be a positive integer")
+    if maxit <= 0 or irls_maxit <= 0:
+        raise ValueError("maxit and irls.maxit should be positive")
+    if tol < 0 or irls_tol < 0:
+        raise ValueError("tol and irls.tol should be nonnegative")
+
+
+def _nonzero_lists(beta, zero_first_row=True):
+    """predict.oem(type="nonzero") (R/methods.R:93-100): row 1 is always treated as the intercept (quirk Q16)."""
+    b = np.array(beta, copy=True)
+    if zero_first_row:
+        b[0, :] = 0
+    return [np.nonzero(np.abs(b[:, j]) > 0)[0] + 1 if np.any(np.abs(b[:, j]) > 0) else None for j in range(b.shape[1])]
+
+
+def _decorate(a, penalty, varnames, intercept_row, n, p, family="gaussian"):
+    """R/oem.R:487-507"""
+    res = OemFit()
+    res["beta"], res["lambda"], res["niter"], res["loss"] = [], [], [], []
+    for k, name in enumerate(penalty):
+        b = a.beta[k].T.copy()                       # rows x nl
+        if name == "ols":                            # quirk Q9: vector reshaped to a 1-column matrix
+            res["beta"].append(b[:, :1]); res["niter"].append(int(a.niter[k, 0])); res["loss"].append(float(a.loss[k, 0]))
+        else:
+            res["beta"].append(b); res["niter"].append(a.niter[k].copy()); res["loss"].append(a.loss[k].copy())
+        res["lambda"].append(a.lam_out[k].copy())
+    res["d"] = a.d.value
+    res["rownames"] = (["(Intercept)"] if intercept_row else []) + list(varnames)
+    res["nzero"] = [[0 if v is None else len(v) for v in _nonzero_lists(b)] for b in res["beta"]]
+    if n is not None:
+        res["nobs"] = n
+    res["nvars"] = p
+    res["penalty"] = list(penalty)
+    res["family"] = family
+    res["varnames"] = list(varnames)
+    return res
+
+
+def _device_matrix(x):
+    """(data_ptr, n, p, ld, keepalive) of a torch device matrix in column-major order."""
+    import torch
+    if x.dtype != torch.float64:
+        x = x.to(torch.float64)
+    n, p = x.shape
+    if x.stride(0) == 1 and x.stride(1) >= n:           # already column-major
+        return x.data_ptr(), n, p, x.stride(1), x
+    xt = x.t().contiguous()                              # (p, n) row-major == (n, p) column-major
+    return xt.data_ptr(), n, p, n, xt
+
+
+_ctx_cache = {}
+
+
+def context(device=None, stream=None):
+    """A cached oemgpu_ctx per (device, stream).  stream: a torch.cuda.Stream or None (own stream)."""
+    import torch
+    if device is None:
+        device = torch.cuda.current_device()
+    sptr = None if stream is None else int(stream.cuda_stream)
+    key = (int(device), sptr)
+    if key not in _ctx_cache:
+        h = L.lib().oemgpu_create(int(device), C.c_void_p(sptr) if sptr else None)
+        if not h:
+            raise L.OemgpuError(-2, L.lib().oemgpu_last_error().decode())
+        _ctx_cache[key] = h
+    return _ctx_cache[key]
+
+
+# ------------------------------------------------------------------------------------------ oem()
+def oem(x, y, family="gaussian", penalty=None, weights=(), lambda_=(), nlambda=100, lambda_min_ratio=None,
+        alpha=1.0, gamma=3.0, tau=0.5, groups=(), penalty_factor=None, group_weights=None, standardize=True,
+        intercept=True, maxit=500, tol=1e-7, irls_maxit=100, irls_tol=1e-3, accelerate=False, ncores=-1,
+        compute_loss=False, hessian_type="upper.bound", varnames=None):
+    """oem(): R/oem.R:162-507, dense gaussian branch."""
+    if family not in ("gaussian", "binomial"):
+        raise ValueError("'arg' should be one of 'gaussian', 'binomial'")
+    penalty = _match_penalty(penalty)
+    if getattr(x, "ndim", 0) != 2:
+        raise ValueError("x must have at least two columns")
+    n, p = x.shape
+    if p > n:
+        warnings.warn("oem() is optimized for n >> p settings and may be very slow when p > n")
+    if p < 2:
+        raise ValueError("x must have at least two columns")
+    if type(x).__module__.startswith("scipy.sparse"):
+        raise NotImplementedError("sparse x is outside the dense Gaussian hot path (ref src/oem_sparse.cpp)")
+    if len(weights) > 0:
+        raise ValueError("weights not implemented yet.")
+    ylen = y.shape[0] if hasattr(y, "shape") else len(y)
+    if ylen != n:
+        raise ValueError("x and y lengths do not match")
+    if family == "binomial":
+        raise NotImplementedError("family='binomial' is outside the dense Gaussian hot path (ref src/oem_logistic_dense.cpp)")
+    if penalty_factor is None:
+        penalty_factor = np.ones(p)
+    penalty_factor = np.asarray(penalty_factor, dtype=np.float64).ravel()
+    if varnames is None:
+        varnames = [f"V{i + 1}" for i in range(p)]
+    if len(penalty_factor) != p:
+        raise ValueError("penalty.factor must have same length as number of columns in x")
+    groups, unique_groups, group_weights = _group_setup(penalty, groups, group_weights, p, False)
+    if lambda_min_ratio is None:
+        lambda_min_ratio = 0.01 if n < p else 0.0001
+    _common_checks(nlambda, float(lambda_min_ratio), maxit, irls_maxit, tol, irls_tol)
+    lam_list = _lambda_list(lambda_, len(penalty))
+    a = _Args(penalty, lam_list, int(np.ravel(nlambda)[0]), lambda_min_ratio, alpha, gamma, tau, tol, maxit, accelerate,
+              compute_loss, penalty_factor, groups, unique_groups, group_weights)
+    lib = L.lib()
+    if _is_torch_cuda(x):
+        import torch
+        xp, n_, p_, ld, keep = _device_matrix(x)
+        yd = y if _is_torch_cuda(y) else torch.as_tensor(np.asarray(y, dtype=np.float64), device=x.device)
+        yd = yd.to(torch.float64).contiguous().reshape(-1)
+        ctx = context(x.device.index)
+        torch.cuda.current_stream(x.device).synchronize()
+        L.check(lib.oemgpu_fit_dense_dev(ctx, xp, n, ld, p, yd.data_ptr(), int(bool(standardize)), int(bool(intercept)),
+                                         C.byref(a.c), *a.outputs(p + 1)))
+        del keep
+    else:
+        xh = np.asfortranarray(x, dtype=np.float64)
+        yh = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+        L.check(lib.oemgpu_fit_dense(_dptr(xh), n, p, _dptr(yh), int(bool(standardize)), int(bool(intercept)),
+                                     C.byref(a.c), *a.outputs(p + 1)))
+    return _decorate(a, penalty, varnames, True, n, p)
+
+
+# ------------------------------------------------------------------------------------------ oem.xtx()
+def oem_xtx(xtx, xty, family="gaussian", penalty=None, lambda_=(), nlambda=100, lambda_min_ratio=None, alpha=1.0,
+            gamma=3.0, tau=0.5, groups=(), scale_factor=(), penalty_factor=None, group_weights=None, maxit=500,
+            tol=1e-7, irls_maxit=100, irls_tol=1e-3, varnames=None):
+    """oem.xtx(): R/oem_xtx.R:109-360."""
+    penalty = _match_penalty(penalty)
+    if getattr(xtx, "ndim", 0) != 2:
+        raise ValueError("xtx must be a matrix")
+    if xtx.shape[0] != xtx.shape[1]:
+        raise ValueError("xtx must be a square matrix equal to X'X. do NOT provide design matrix")
+    p = xtx.shape[1]
+    xlen = xty.shape[0] if hasattr(xty, "shape") else len(xty)
+    if p != xlen:
+        raise ValueError("xty must have length equal to the number of columns and rows of xtx. do NOT provide response vector")
+    if p < 2:
+        raise ValueError("xtx must have at least two columns")
+    if family == "binomial":
+        raise ValueError("binomial not implemented yet")
+    if penalty_factor is None:
+        penalty_factor = np.ones(p)
+    penalty_factor = np.asarray(penalty_factor, dtype=np.float64).ravel()
+    if varnames is None:
+        varnames = [f"V{i + 1}" for i in range(p)]
+    if len(penalty_factor) != p:
+        raise ValueError("penalty.factor must have same length as number of columns in x")
+    if any("grp" in q for q in penalty) and len(np.ravel(groups)) != p:
+        raise ValueError("groups must have same length as number of columns in x")
+    groups, unique_groups, group_weights = _group_setup(penalty, groups, group_weights, p, False)
+    if lambda_min_ratio is None:
+        lambda_min_ratio = 0.0001
+    _common_checks(nlambda, float(lambda_min_ratio), maxit, irls_maxit, tol, irls_tol)
+    lam_list = _lambda_list(lambda_, len(penalty))
+    sf = np.asarray(scale_factor, dtype=np.float64).ravel()
+    if sf.size > 0 and sf.size != p:
+        raise ValueError("scale.factor must be same length as xty (nvars)")
+    a = _Args(penalty, lam_list, int(np.ravel(nlambda)[0]), lambda_min_ratio, alpha, gamma, tau, tol, maxit, False,
+              False, penalty_factor, groups, unique_groups, group_weights)
+    lib = L.lib()
+    if _is_torch_cuda(xtx):
+        import torch
+        xp, _, _, ld, keep = _device_matrix(xtx)
+        if ld != p:
+            keep = xtx.t().contiguous(); xp = keep.data_ptr()
+        yd = xty if _is_torch_cuda(xty) else torch.as_tensor(np.asarray(xty, dtype=np.float64), device=xtx.device)
+        yd = yd.to(torch.float64).contiguous().reshape(-1)
+        ctx = context(xtx.device.index)
+        torch.cuda.current_stream(xtx.device).synchronize()
+        L.check(lib.oemgpu_fit_xtx_dev(ctx, xp, yd.data_ptr(), p, _dptr(sf), C.byref(a.c), *a.outputs(p)))
+        del keep
+    else:
+        xh = np.asfortranarray(xtx, dtype=np.float64)
+        yh = np.ascontiguousarray(np.asarray(xty, dtype=np.float64).reshape(-1))
+        L.check(lib.oemgpu_fit_xtx(_dptr(xh), _dptr(yh), p, _dptr(sf), C.byref(a.c), *a.outputs(p)))
+    return _decorate(a, penalty, varnames, False, None, p)
+
+
+# ------------------------------------------------------------------------------------------ big.oem()
+def big_oem(x, y, family="gaussian", penalty=None, weights=(), lambda_=(), nlambda=100, lambda_min_ratio=None,
+            alpha=1.0, gamma=3.0, tau=0.5, groups=(), penalty_factor=None, group_weights=None, standardize=True,
+            intercept=True, maxit=500, tol=1e-7, irls_maxit=100, irls_tol=1e-3, compute_loss=False, gigs=4.0,
+            hessian_type="full", varnames=None):
+    """big.oem(): R/big_oem.R:121-441.  x: a (host) matrix or a list of row shards (the big.matrix stand-in);
+    y: a vector or the matching list of shards."""
+    penalty = PENALTIES if penalty is None else _match_penalty(penalty)      # match.arg(several.ok=TRUE), no default narrowing
+    shards = list(x) if isinstance(x, (list, tuple)) else [x]
+    yshards = list(y) if isinstance(y, (list, tuple)) else [y]
+    if family == "binomial":
+        raise ValueError("binomial case not implemented yet")
+    if any(getattr(s, "ndim", 0) != 2 for s in shards):
+        raise ValueError("x must have at least two columns")
+    p = shards[0].shape[1]
+    n = sum(s.shape[0] for s in shards)
+    if p < 2:
+        raise ValueError("x must have at least two columns")
+    if len(weights) > 0:
+        raise ValueError("weights not implemented yet.")
+    if len(yshards) != len(shards) or sum(len(v) for v in yshards) != n:
+        raise ValueError("x and y lengths do not match")
+    if penalty_factor is None:
+        penalty_factor = np.ones(p)
+    penalty_factor = np.asarray(penalty_factor, dtype=np.float64).ravel()
+    if varnames is None:
+        varnames = [f"V{i + 1}" for i in range(p)]
+    if len(penalty_factor) != p:
+        raise ValueError("penalty.factor must have same length as number of columns in x")
+    if any("grp" in q for q in penalty) and len(np.ravel(groups)) != p:
+        raise ValueError("groups must have same length as number of columns in x")
+    groups, unique_groups, group_weights = _group_setup(penalty, groups, group_weights, p, bool(intercept))
+    if lambda_min_ratio is None:
+        lambda_min_ratio = 0.01 if n < p else 0.0001
+    _common_checks(nlambda, float(lambda_min_ratio), maxit, irls_maxit, tol, irls_tol)
+    lam_list = _lambda_list(lambda_, len(penalty))
+    a = _Args(penalty, lam_list, int(np.ravel(nlambda)[0]), lambda_min_ratio, alpha, gamma, tau, tol, maxit, False,
+              compute_loss, penalty_factor, groups, unique_groups, group_weights)
+    xs = [np.asfortranarray(s, dtype=np.float64) for s in shards]
+    ys = [np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1)) for v in yshards]
+    ns = (C.c_int64 * len(xs))(*[s.shape[0] for s in xs])
+    xp = (L._dp * len(xs))(*[_dptr(s) for s in xs])
+    yp = (L._dp * len(ys))(*[_dptr(v) for v in ys])
+    L.check(L.lib().oemgpu_fit_big(xp, ns, len(xs), p, yp, int(bool(standardize)), int(bool(intercept)),
+                                   C.byref(a.c), *a.outputs(p + 1)))
+    return _decorate(a, penalty, varnames, True, n, p)
+
+
+# ------------------------------------------------------------------------------------------ consumers
+def predict(fit, newx=None, s=None, which_model=0, type="link"):
+    """predict.oem, R/methods.R:48-109 (which_model is 0-based or a penalty name)."""
+    if isinstance(which_model, str):
+        if which_model not in fit["penalty"]:
+            raise ValueError(f"Model {which_model} specified, but {which_model} not computed.")
+        which_model = fit["penalty"].index(which_model)
+    if which_model >= len(fit["beta"]):
+        raise ValueError(f"Model {which_model + 1} specified, but only {len(fit['beta'])} were computed.")
+    nbeta = np.array(fit["beta"][which_model])
+    if s is not None:
+        lam = np.asarray(fit["lambda"][which_model], dtype=np.float64)
+        left, right, frac = _lambda_interp(lam, np.atleast_1d(np.asarray(s, dtype=np.float64)))
+        nbeta = nbeta[:, left] * frac + nbeta[:, right] * (1 - frac)
+    if type == "coefficients":
+        return nbeta
+    if type == "nonzero":
+        return _nonzero_lists(nbeta)
+    if newx is None:
+        raise ValueError("A value for 'newx' must be supplied")
+    newx = np.asarray(newx, dtype=np.float64)
+    if newx.shape[1] < nbeta.shape[0]:
+        newx = np.column_stack([np.ones(newx.shape[0]), newx])
+    return newx @ nbeta
+
+
+def _lambda_interp(lam, s):
+    """lambda.interp, R/utils.R (glmnet's interpolation)."""
+    if len(lam) == 1:
+        z = np.zeros(len(s), dtype=int)
+        return z, z, np.ones(len(s))
+    s = np.clip(s, lam.min(), lam.max())
+    k = len(lam)
+    sfrac = (lam[0] - s) / (lam[0] - lam[k - 1])
+    lamn = (lam[0] - lam) / (lam[0] - lam[k - 1])
+    coord = np.interp(sfrac, lamn, np.arange(k))
+    left, right = np.floor(coord).astype(int), np.ceil(coord).astype(int)
+    den = lamn[left] - lamn[right]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sf = np.where(left == right, 1.0, (sfrac - lamn[right]) / den)
+    return left, right, sf
+
+
+def logLik(fit, which_model=0):
+    """logLik.oem, R/methods.R:431-482 (gaussian)."""
+    if isinstance(which_model, str):
+        which_model = fit["penalty"].index(which_model)
+    loss = np.atleast_1d(np.asarray(fit["loss"][which_model], dtype=np.float64))
+    if np.all(loss == 1e99):
+        raise ValueError("oem object needed compute.loss set to TRUE. logLik not returned")
+    n = float(fit["nobs"])
+    return -0.5 * n * (np.log(2 * np.pi) - np.log(n) + np.log(loss)) - 0.5 * n

@@ -1,0 +1,81 @@
+"""Builds liboemgpu.so (hipcc, gfx950 only) in-tree and audits the generated ISA.
+
+    python -m oem_amd.build [--force]
+
+The shared object lands in oem_amd/liboemgpu.so (git-ignored, but it travels with the repo
+snapshot to the GPU box).  hipcc cross-compiles without a GPU.
+"""
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+OUT = HERE / "liboemgpu.so"
+SOURCES = ["api.hip", "gram.hip", "path_small.hip", "path_large.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(a, b):
+    return (not b.exists()) or a.stat().st_mtime > b.stat().st_mtime
+
+
+def _deps():
+    return [CSRC / s for s in SOURCES] + [CSRC / "common.hpp", CSRC / "gen" / "acc_tiles.inc",
+                                          HERE.parent / "include" / "oemgpu.h"]
+
+
+def audit_gram_isa(asm_text):
+    """The Gram kernels own AGPRs a0..a223 through literal register names in inline asm
+    (csrc/gen/acc_tiles.inc).  That is only sound if hipcc itself never touches the accumulator
+    file and never spills in those kernels: check both in the emitted ISA."""
+    problems = []
+    for m in re.finditer(r"^(_ZN6oemgpu15gram_(?:tri|blk)_kernel\w+):\n(.*?)\n\s*s_endpgm", asm_text, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        in_asm = False
+        for line in body.splitlines():
+            if "#ASMSTART" in line:
+                in_asm = True
+            elif "#ASMEND" in line:
+                in_asm = False
+            elif not in_asm and "v_accvgpr" in line:
+                problems.append(f"{name}: compiler-emitted {line.strip()}")
+            if "scratch_" in line:
+                problems.append(f"{name}: scratch access {line.strip()}")
+            if "flat_load" in line:
+                problems.append(f"{name}: flat_load (drains the prefetch) {line.strip()}")
+    return problems
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    gen = CSRC / "gen" / "acc_tiles.inc"
+    if force or _newer(CSRC / "gen" / "gen_acc_tiles.py", gen):
+        subprocess.run([sys.executable, str(CSRC / "gen" / "gen_acc_tiles.py")], check=True, stdout=subprocess.DEVNULL)
+    if not force and OUT.exists() and all(not _newer(d, OUT) for d in _deps()):
+        return OUT
+    objs = []
+    bdir = HERE / "_build"
+    bdir.mkdir(exist_ok=True)
+    for s in SOURCES:
+        o = bdir / (s + ".o")
+        if force or _newer(CSRC / s, o) or any(_newer(d, o) for d in _deps()[len(SOURCES):]):
+            cmd = [hipcc, *FLAGS, "-c", str(CSRC / s), "-o", str(o)]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+        objs.append(str(o))
+    # ISA audit of the asm-owned-accumulator kernels
+    asm = subprocess.run([hipcc, *FLAGS, "-S", "--cuda-device-only", "-o", "-", str(CSRC / "gram.hip")],
+                         check=True, capture_output=True, text=True).stdout
+    problems = audit_gram_isa(asm)
+    if problems:
+        raise RuntimeError("gram.hip ISA audit failed:\n  " + "\n  ".join(problems[:20]))
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(OUT), *objs], check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

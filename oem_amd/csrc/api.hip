@@ -1,0 +1,655 @@
+// api.hip -- C ABI of liboemgpu: contexts, workspace, argument checks, and the host-side driver that the
+// reference keeps in src/oem_dense.cpp:30-309, src/oem_xtx.cpp:29-219 and src/oem_big.cpp:30-258
+// (lambda bookkeeping, result packing, DataStd::recover).  All arithmetic of the hot path runs in the HIP
+// kernels of gram.hip / path_small.hip / path_large.hip; there is no CPU fallback.
+#include "common.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace oemgpu {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace oemgpu
+
+using namespace oemgpu;
+
+struct oemgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+    char *ws = nullptr;          // device workspace (grow-only)
+    size_t ws_bytes = 0;
+    char *pinned = nullptr;      // pinned host staging for the results
+    size_t pinned_bytes = 0;
+    bool timing = false;
+    hipEvent_t ev[2 * OEMGPU_NTIMERS];
+    bool ev_made = false;
+    bool ev_used[OEMGPU_NTIMERS];
+    double ms[OEMGPU_NTIMERS];
+};
+
+namespace {
+
+struct Bump {           // carve-out of the context workspace, 256-byte granules
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; }
+};
+
+int ctx_reserve(oemgpu_ctx *c, size_t bytes)
+{
+    if (bytes <= c->ws_bytes) return 0;
+    if (c->ws) { OEM_HIP(hipStreamSynchronize(c->stream)); OEM_HIP(hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
+    bytes = bytes + bytes / 8 + (1 << 20);
+    OEM_HIP(hipMalloc((void **)&c->ws, bytes));
+    c->ws_bytes = bytes;
+    return 0;
+}
+int ctx_pinned(oemgpu_ctx *c, size_t bytes)
+{
+    if (bytes <= c->pinned_bytes) return 0;
+    if (c->pinned) { OEM_HIP(hipStreamSynchronize(c->stream)); OEM_HIP(hipHostFree(c->pinned)); c->pinned = nullptr; c->pinned_bytes = 0; }
+    bytes = bytes + bytes / 8 + 4096;
+    OEM_HIP(hipHostMalloc((void **)&c->pinned, bytes, hipHostMallocDefault));
+    c->pinned_bytes = bytes;
+    return 0;
+}
+
+struct Timer {
+    oemgpu_ctx *c; int id;
+    Timer(oemgpu_ctx *c_, int id_) : c(c_), id(id_)
+    {
+        if (c->timing) { (void)hipEventRecord(c->ev[2 * id], c->stream); c->ev_used[id] = true; }
+    }
+    ~Timer() { if (c->timing) (void)hipEventRecord(c->ev[2 * id + 1], c->stream); }
+};
+
+int set_device(const oemgpu_ctx *c) { OEM_HIP(hipSetDevice(c->device)); return 0; }
+
+// ---------------------------------------------------------------- argument checks (the R front ends stop() on these)
+int nl_of(const oemgpu_opts *o) { return (o->lambda_user && o->nlambda_user > 0) ? o->nlambda_user : o->nlambda; }
+
+int check_opts(const oemgpu_opts *o, int p, int ngroupvars_expected)
+{
+    if (!o) { set_error("opts is NULL"); return OEMGPU_ERR_ARG; }
+    if (o->npen < 1 || !o->penalty) { set_error("at least one penalty is required"); return OEMGPU_ERR_ARG; }
+    bool any_grp = false;
+    for (int k = 0; k < o->npen; ++k) {
+        if (o->penalty[k] < 0 || o->penalty[k] >= OEMGPU_NPENALTIES) { set_error("unknown penalty code %d", o->penalty[k]); return OEMGPU_ERR_ARG; }
+        any_grp |= pen_is_grp(o->penalty[k]);
+    }
+    if (p < 2) { set_error("x must have at least two columns"); return OEMGPU_ERR_ARG; }                 // ref R/oem.R:226-229
+    if (nl_of(o) < 1) { set_error("nlambda must be a positive integer"); return OEMGPU_ERR_ARG; }       // ref R/oem.R:361-364
+    if (!(o->lambda_user && o->nlambda_user > 0) && !(o->lambda_min_ratio > 0.0 && o->lambda_min_ratio < 1.0)) {
+        set_error("lambda.min.ratio must be between 0 and 1"); return OEMGPU_ERR_ARG;                    // ref R/oem.R:356-359
+    }
+    if (o->maxit <= 0) { set_error("maxit and irls.maxit should be positive"); return OEMGPU_ERR_ARG; }  // ref R/oem.R:427-430
+    if (o->tol < 0) { set_error("tol and irls.tol should be nonnegative"); return OEMGPU_ERR_ARG; }
+    if (!o->penalty_factor) { set_error("penalty.factor must have same length as number of columns in x"); return OEMGPU_ERR_ARG; }
+    if (any_grp) {
+        if (!o->groups || o->ngroupvars != ngroupvars_expected) {
+            set_error("If any group penalty is used groups must have same length as number of columns in x");   // ref R/oem.R:288-290
+            return OEMGPU_ERR_ARG;
+        }
+        if (!o->unique_groups || o->ngroups < 1) { set_error("unique_groups is empty"); return OEMGPU_ERR_ARG; }
+        if (o->n_group_weights > 0 && o->n_group_weights != o->ngroups) {
+            set_error("group.weights must have same length as the number of groups"); return OEMGPU_ERR_ARG;   // ref R/oem.R:313-315
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- host-built parameter blob
+struct Blob {
+    std::vector<char> h;
+    size_t add(const void *src, size_t bytes)
+    {
+        size_t o = (h.size() + 15) / 16 * 16;
+        h.resize(o + bytes);
+        if (bytes) memcpy(h.data() + o, src, bytes);
+        return o;
+    }
+};
+
+// group bookkeeping of get_group_indexes (ref src/oem_dense.h:421-456).  q = dimension of beta;
+// nscan = number of leading beta positions whose group entry is looked at (oemBig: nvars of nvars+1, quirk Q17).
+struct Groups {
+    std::vector<int> gid, gstart, gidx, gzero;
+    std::vector<double> gw;
+};
+void build_groups(const oemgpu_opts *o, int q, int nscan, Groups &G)
+{
+    G.gid.assign(q, -1);
+    G.gstart.assign(o->ngroups + 1, 0);
+    G.gzero.assign(o->ngroups > 0 ? o->ngroups : 1, 0);
+    G.gw.assign(o->ngroups > 0 ? o->ngroups : 1, 0.0);
+    G.gidx.clear();
+    for (int g = 0; g < o->ngroups; ++g) {
+        G.gstart[g] = (int)G.gidx.size();
+        for (int v = 0; v < nscan && v < o->ngroupvars; ++v)
+            if (o->groups[v] == o->unique_groups[g]) { G.gidx.push_back(v); G.gid[v] = g; }
+        G.gzero[g] = o->unique_groups[g] == 0;
+    }
+    if (o->ngroups > 0) G.gstart[o->ngroups] = (int)G.gidx.size();
+    for (int g = 0; g < o->ngroups; ++g)
+        G.gw[g] = (o->n_group_weights < 1) ? std::sqrt((double)(G.gstart[g + 1] - G.gstart[g])) : o->group_weights[g];
+    if (G.gidx.empty()) G.gidx.push_back(0);
+}
+
+// ---------------------------------------------------------------- the driver behind all entry points
+// xx (q x q), xy (q), stats already on the device (in the workspace).  sem: OEMGPU_SEM_*, or 2 for oem.xtx.
+enum { SEM_XTX = 2 };
+
+int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const double *stats, int p, int q, int sem,
+              int standardize, int intercept, const oemgpu_opts *o, const double *scale_factor,
+              double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out)
+{
+    const int nl = nl_of(o), npen = o->npen;
+    const bool user = o->lambda_user && o->nlambda_user > 0;
+    bool any_grp = false;
+    for (int k = 0; k < npen; ++k) any_grp |= pen_is_grp(o->penalty[k]);
+
+    // ---- parameter blob
+    Blob bl;
+    std::vector<double> pf(q, 0.0), sinv;
+    const int off = (sem == OEMGPU_SEM_BIG && intercept) ? 1 : 0;       // leading 0 for the intercept, ref src/oem_big.cpp:105-113
+    for (int j = 0; j < p; ++j) pf[j + off] = o->penalty_factor[j];
+    if (scale_factor) { sinv.resize(q); for (int j = 0; j < q; ++j) sinv[j] = 1.0 / scale_factor[j]; }
+    Groups G;
+    oemgpu_opts og = *o;
+    if (!any_grp) og.ngroups = 0;
+    build_groups(&og, q, sem == OEMGPU_SEM_BIG ? p : q, G);
+    const size_t o_pen = bl.add(o->penalty, sizeof(int32_t) * npen);
+    const size_t o_lam = user ? bl.add(o->lambda_user, sizeof(double) * (size_t)npen * nl) : 0;
+    const size_t o_pf = bl.add(pf.data(), sizeof(double) * q);
+    const size_t o_sinv = scale_factor ? bl.add(sinv.data(), sizeof(double) * q) : 0;
+    const size_t o_gid = bl.add(G.gid.data(), sizeof(int) * q);
+    const size_t o_gst = bl.add(G.gstart.data(), sizeof(int) * G.gstart.size());
+    const size_t o_gix = bl.add(G.gidx.data(), sizeof(int) * G.gidx.size());
+    const size_t o_gz = bl.add(G.gzero.data(), sizeof(int) * G.gzero.size());
+    const size_t o_gw = bl.add(G.gw.data(), sizeof(double) * G.gw.size());
+
+    // ---- outputs region (device) : beta | lambda | loss | d[2] | niter | stats copy
+    const size_t nb = (size_t)npen * nl * q, nk = (size_t)npen * nl;
+    const size_t out_doubles = nb + 2 * nk + 2 + (size_t)stats_len(p);
+    const size_t out_bytes = out_doubles * sizeof(double) + nk * sizeof(int32_t);
+    const bool small = q <= SMALL_P_MAX;
+    int lan = q < 128 ? q : 128;
+    const size_t work_d = small ? 0 : path_large_work_doubles(q, lan);
+    const size_t a_blob = B.take(bl.h.size()), a_out = B.take(out_bytes), a_work = B.take(work_d * sizeof(double));
+    // the workspace may be re-allocated by ctx_reserve: xx/xy/stats are offsets into it, so recompute after
+    const size_t off_xx = (const char *)xx - c->ws, off_xy = (const char *)xy - c->ws, off_st = (const char *)stats - c->ws;
+    if (B.off > c->ws_bytes) { set_error("internal: workspace under-reserved (%zu > %zu)", B.off, c->ws_bytes); return OEMGPU_ERR_INTERNAL; }
+    xx = (const double *)(c->ws + off_xx); xy = (const double *)(c->ws + off_xy); stats = (const double *)(c->ws + off_st);
+    char *dblob = c->ws + a_blob;
+    double *dout = (double *)(c->ws + a_out);
+    OEM_HIP(hipMemcpyAsync(dblob, bl.h.data(), bl.h.size(), hipMemcpyHostToDevice, c->stream));
+    OEM_HIP(hipMemsetAsync(dout, 0, out_bytes, c->stream));
+
+    PathArgs a;
+    memset(&a, 0, sizeof a);
+    a.p = q; a.npen = npen; a.nl = nl; a.user_lambda = user; a.maxit = o->maxit;
+    a.accelerate = (sem == OEMGPU_SEM_DENSE) ? (o->accelerate != 0) : 0;           // only oemDense accelerates (quirk Q12)
+    a.compute_loss = (sem == OEMGPU_SEM_DENSE) ? (o->compute_loss != 0) : 0;
+    a.ngroups = og.ngroups; a.lanczos_steps = lan; a.yscale = (sem == OEMGPU_SEM_DENSE);
+    a.alpha = o->alpha; a.gamma = o->gamma; a.tau = o->tau; a.tol = o->tol; a.lambda_min_ratio = o->lambda_min_ratio;
+    a.xx = xx; a.xy = xy; a.stats = stats;
+    a.penalty = (const int *)(dblob + o_pen);
+    a.lambda_user = user ? (const double *)(dblob + o_lam) : nullptr;
+    a.pf = (const double *)(dblob + o_pf);
+    a.sinv = scale_factor ? (const double *)(dblob + o_sinv) : nullptr;
+    a.gid = (const int *)(dblob + o_gid); a.gstart = (const int *)(dblob + o_gst); a.gidx = (const int *)(dblob + o_gix);
+    a.gzero = (const int *)(dblob + o_gz); a.gw = (const double *)(dblob + o_gw);
+    a.beta = dout; a.lambda_out = dout + nb; a.loss = a.lambda_out + nk; a.d_out = a.loss + nk;
+    double *dstats = a.d_out + 2;
+    a.niter = (int *)(dstats + stats_len(p));
+    a.work = (double *)(c->ws + a_work);
+
+    if (ctx_pinned(c, out_bytes)) return OEMGPU_ERR_HIP;
+    {
+        Timer t(c, OEMGPU_T_EIGPATH);
+        int rc = small ? launch_path_small(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned);
+        if (rc) return rc;
+    }
+    OEM_HIP(hipMemcpyAsync(dstats, stats, sizeof(double) * stats_len(p), hipMemcpyDeviceToDevice, c->stream));
+    OEM_HIP(hipMemcpyAsync(c->pinned, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    OEM_HIP(hipStreamSynchronize(c->stream));
+
+    // ---- unpack (ref src/oem_dense.cpp:249-294, src/DataStd.h:269-293, src/oem_big.h:880-897, src/oem_big.cpp:213-220)
+    const double *hb = (const double *)c->pinned, *hl = hb + nb, *hloss = hl + nk, *hd = hloss + nk, *hs = hd + 2;
+    const int32_t *hn = (const int32_t *)(hs + stats_len(p));
+    *d_out = hd[0];
+    const double meany = hs[0], scaley = hs[1];
+    const double *meanx = hs + 4, *scalex = hs + 4 + p;
+    const int flag = (standardize ? 1 : 0) + 2 * (intercept ? 1 : 0);
+    const int rows = (sem == SEM_XTX) ? p : p + 1;
+    for (int k = 0; k < npen; ++k) {
+        const int nlam = (o->penalty[k] == OEMGPU_OLS) ? 1 : nl;
+        for (int i = 0; i < nl; ++i) {
+            const size_t ki = (size_t)k * nl + i;
+            lambda_out[ki] = hl[ki];
+            niter[ki] = (i < nlam) ? hn[ki] : 0;
+            loss[ki] = (i < nlam && a.compute_loss) ? hloss[ki] : 1e99;
+            double *ob = beta + ki * rows;
+            const double *b = hb + ki * q;
+            if (i >= nlam) { for (int j = 0; j < rows; ++j) ob[j] = 0.0; continue; }
+            if (sem == SEM_XTX) {
+                for (int j = 0; j < p; ++j) ob[j] = b[j];
+            } else if (sem == OEMGPU_SEM_BIG) {
+                ob[0] = intercept ? b[0] : 0.0;
+                for (int j = 0; j < p; ++j) ob[j + 1] = b[j + off] * (standardize ? scalex[j] : 1.0);
+            } else {
+                double s = 0.0;
+                for (int j = 0; j < p; ++j) {
+                    double cf = b[j];
+                    if (flag & 1) cf /= scalex[j];
+                    if (flag != 0) cf *= scaley;
+                    if (flag & 2) s += cf * meanx[j];
+                    ob[j + 1] = cf;
+                }
+                ob[0] = (flag & 2) ? meany - s : 0.0;
+            }
+        }
+    }
+    return 0;
+}
+
+size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o)
+{
+    const int nl = nl_of(o);
+    size_t b = 0;
+    b += (size_t)o->npen * 4 + (size_t)o->npen * nl * 8 + (size_t)q * (8 + 8 + 4) + (size_t)(o->ngroups + 2) * 16 +
+         (size_t)(o->ngroupvars + q + 2) * 4 + 4096;
+    b += ((size_t)o->npen * nl * (q + 3) + 2 + stats_len(p)) * 8 + 4096;
+    if (q > SMALL_P_MAX) b += path_large_work_doubles(q, 128) * 8 + 4096;
+    return b;
+}
+
+__global__ void accumulate_kernel(double *__restrict__ dst, const double *__restrict__ src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
+// moments of one device-resident shard into `moments` (overwrite) ; tpart/vpart scratch from the workspace
+int shard_moments(oemgpu_ctx *c, const GramPlan &pl, const double *x, int64_t n, int64_t ld, const double *y,
+                  const double *sums, double *tpart, double *vpart, double *moments)
+{
+    OEM_HIP(hipMemsetAsync(moments, 0, sizeof(double) * (size_t)oemgpu_moments_len(pl.p), c->stream));
+    {
+        Timer t(c, OEMGPU_T_GRAMK);
+        int rc = launch_gram(c->stream, pl, x, n, ld, y, sums, tpart, vpart);
+        if (rc) return rc;
+    }
+    return launch_moments_reduce(c->stream, pl, tpart, vpart, moments);
+}
+
+}  // namespace
+
+// =====================================================================================================
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char *oemgpu_last_error(void) { return g_err; }
+const char *oemgpu_version(void) { return "oemgpu 0.1 (gfx950)"; }
+
+int oemgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+oemgpu_ctx *oemgpu_create(int32_t device, void *stream)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { set_error("no HIP device available (liboemgpu has no CPU fallback)"); return nullptr; }
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= n) { set_error("device %d out of range (%d devices)", device, n); return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error("hipGetDeviceProperties failed"); return nullptr; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; liboemgpu is built for gfx950 only", device, prop.gcnArchName);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return nullptr; }
+    oemgpu_ctx *c = new oemgpu_ctx();
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
+        c->own_stream = true;
+    }
+    for (int i = 0; i < OEMGPU_NTIMERS; ++i) { c->ev_used[i] = false; c->ms[i] = 0.0; }
+    return c;
+}
+
+void oemgpu_destroy(oemgpu_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->ev_made) for (int i = 0; i < 2 * OEMGPU_NTIMERS; ++i) (void)hipEventDestroy(c->ev[i]);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int oemgpu_synchronize(oemgpu_ctx *c)
+{
+    if (!c) { set_error("ctx is NULL"); return OEMGPU_ERR_ARG; }
+    OEM_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int oemgpu_set_timing(oemgpu_ctx *c, int32_t on)
+{
+    if (!c) { set_error("ctx is NULL"); return OEMGPU_ERR_ARG; }
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    if (on && !c->ev_made) {
+        for (int i = 0; i < 2 * OEMGPU_NTIMERS; ++i) OEM_HIP(hipEventCreate(&c->ev[i]));
+        c->ev_made = true;
+    }
+    c->timing = on != 0;
+    return 0;
+}
+
+int oemgpu_last_timings(oemgpu_ctx *c, double *ms)
+{
+    if (!c || !ms) { set_error("NULL argument"); return OEMGPU_ERR_ARG; }
+    OEM_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < OEMGPU_NTIMERS; ++i) {
+        ms[i] = 0.0;
+        if (c->ev_made && c->ev_used[i]) {
+            float f = 0.f;
+            if (hipEventElapsedTime(&f, c->ev[2 * i], c->ev[2 * i + 1]) == hipSuccess) ms[i] = f;
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- staged interface
+int oemgpu_shift_sums_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
+                          double *sums_dev)
+{
+    if (!c || !x_dev || !y_dev || !sums_dev || n < 1 || p < 1 || ld < n) { set_error("shift_sums: bad argument"); return OEMGPU_ERR_ARG; }
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    Timer t(c, OEMGPU_T_SHIFT);
+    return launch_shift_sums(c->stream, x_dev, n, ld, p, y_dev, sums_dev);
+}
+
+int oemgpu_moments_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
+                       const double *sums_dev, double *moments_dev)
+{
+    if (!c || !x_dev || !y_dev || !moments_dev || n < 1 || p < 1 || ld < n) { set_error("moments: bad argument"); return OEMGPU_ERR_ARG; }
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    const GramPlan pl = gram_plan(n, p, c->num_cu);
+    Bump B;
+    const size_t a_t = B.take(pl.tpart_doubles * 8), a_v = B.take(pl.vpart_doubles * 8);
+    if (ctx_reserve(c, B.off)) return OEMGPU_ERR_HIP;
+    Timer t(c, OEMGPU_T_MOMENTS);
+    return shard_moments(c, pl, x_dev, n, ld, y_dev, sums_dev, (double *)(c->ws + a_t), (double *)(c->ws + a_v), moments_dev);
+}
+
+int oemgpu_solve_moments_dev(oemgpu_ctx *c, const double *moments_dev, const double *sums_dev, int32_t p,
+                             int32_t semantics, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                             double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    if (!c || !moments_dev || !beta || !lambda_out || !niter || !loss || !d) { set_error("solve_moments: NULL argument"); return OEMGPU_ERR_ARG; }
+    if (semantics != OEMGPU_SEM_DENSE && semantics != OEMGPU_SEM_BIG) { set_error("unknown semantics %d", semantics); return OEMGPU_ERR_ARG; }
+    const int q = p + ((semantics == OEMGPU_SEM_BIG && intercept) ? 1 : 0);
+    int rc = check_opts(o, p, q);
+    if (rc) return rc;
+    if (semantics == OEMGPU_SEM_BIG && o->compute_loss) {
+        set_error("compute.loss is not available for big.oem: the reference expression is ill-formed (src/oem_big.h:899-921)");
+        return OEMGPU_ERR_UNSUPPORTED;
+    }
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    Bump B;
+    const size_t a_xx = B.take((size_t)q * q * 8), a_xy = B.take((size_t)q * 8), a_st = B.take((size_t)stats_len(p) * 8);
+    // moments/sums may live in the workspace (fit_dense_dev): keep them below this frame
+    size_t base = 0;
+    if ((const char *)moments_dev >= c->ws && (const char *)moments_dev < c->ws + c->ws_bytes)
+        base = ((const char *)moments_dev - c->ws) + (size_t)oemgpu_moments_len(p) * 8;
+    if (sums_dev && (const char *)sums_dev >= c->ws && (const char *)sums_dev < c->ws + c->ws_bytes) {
+        size_t e = ((const char *)sums_dev - c->ws) + (size_t)(p + 2) * 8;
+        if (e > base) base = e;
+    }
+    base = (base + 255) / 256 * 256;
+    const size_t need = base + B.off + paths_ws_bytes(p, q, o) + 4096;
+    if (need > c->ws_bytes) {
+        if (base != 0) { set_error("internal: workspace frame too small"); return OEMGPU_ERR_INTERNAL; }
+        if (ctx_reserve(c, need)) return OEMGPU_ERR_HIP;
+    }
+    Bump B2; B2.off = base + B.off;
+    double *xx = (double *)(c->ws + base + a_xx), *xy = (double *)(c->ws + base + a_xy), *st = (double *)(c->ws + base + a_st);
+    {
+        Timer t(c, OEMGPU_T_FINAL);
+        rc = launch_finalize(c->stream, moments_dev, sums_dev, p, semantics, standardize, intercept, xx, xy, st);
+        if (rc) return rc;
+    }
+    return run_paths(c, B2, xx, xy, st, p, q, semantics, standardize, intercept, o, nullptr, beta, lambda_out, niter, loss, d);
+}
+
+int oemgpu_fit_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
+                         int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                         double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    if (!c || !x_dev || !y_dev) { set_error("fit_dense: NULL argument"); return OEMGPU_ERR_ARG; }
+    int rc = check_opts(o, p, p);
+    if (rc) return rc;
+    if (n < 1 || ld < n) { set_error("fit_dense: bad n / ld"); return OEMGPU_ERR_ARG; }
+    if (n <= p) { set_error("p >= n: the XXt branch (ref src/oem_dense.h:363-366,513-521) is not part of this path"); return OEMGPU_ERR_UNSUPPORTED; }
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    const GramPlan pl = gram_plan(n, p, c->num_cu);
+    Bump B;
+    const size_t a_sums = B.take((size_t)(p + 2) * 8), a_mom = B.take((size_t)oemgpu_moments_len(p) * 8);
+    const size_t frame = B.off;
+    const size_t a_t = B.take(pl.tpart_doubles * 8), a_v = B.take(pl.vpart_doubles * 8);
+    size_t need = B.off;
+    const size_t need2 = frame + ((size_t)p * p + p + stats_len(p)) * 8 + 1024 + paths_ws_bytes(p, p, o) + 4096;
+    if (need2 > need) need = need2;
+    if (ctx_reserve(c, need)) return OEMGPU_ERR_HIP;
+    double *sums = (double *)(c->ws + a_sums), *mom = (double *)(c->ws + a_mom);
+    {
+        Timer t(c, OEMGPU_T_SHIFT);
+        rc = launch_shift_sums(c->stream, x_dev, n, ld, p, y_dev, sums);
+        if (rc) return rc;
+    }
+    {
+        Timer t(c, OEMGPU_T_MOMENTS);
+        rc = shard_moments(c, pl, x_dev, n, ld, y_dev, sums, (double *)(c->ws + a_t), (double *)(c->ws + a_v), mom);
+        if (rc) return rc;
+    }
+    return oemgpu_solve_moments_dev(c, mom, sums, p, OEMGPU_SEM_DENSE, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+}
+
+int oemgpu_fit_xtx_dev(oemgpu_ctx *c, const double *xtx_dev, const double *xty_dev, int32_t p, const double *scale_factor,
+                       const oemgpu_opts *o, double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    if (!c || !xtx_dev || !xty_dev || !beta || !lambda_out || !niter || !loss || !d) { set_error("fit_xtx: NULL argument"); return OEMGPU_ERR_ARG; }
+    int rc = check_opts(o, p, p);
+    if (rc) return rc;
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    Bump B;
+    const size_t a_xx = B.take((size_t)p * p * 8), a_xy = B.take((size_t)p * 8), a_st = B.take((size_t)stats_len(p) * 8),
+                 a_sf = B.take((size_t)p * 8);
+    if (ctx_reserve(c, B.off + paths_ws_bytes(p, p, o) + 4096)) return OEMGPU_ERR_HIP;
+    double *xx = (double *)(c->ws + a_xx), *xy = (double *)(c->ws + a_xy), *st = (double *)(c->ws + a_st), *sf = (double *)(c->ws + a_sf);
+    std::vector<double> sinv;
+    if (scale_factor) {
+        sinv.resize(p);
+        for (int j = 0; j < p; ++j) sinv[j] = 1 / scale_factor[j];                // ref src/oem_xtx.h:527-529
+        OEM_HIP(hipMemcpyAsync(sf, sinv.data(), sizeof(double) * p, hipMemcpyHostToDevice, c->stream));
+        OEM_HIP(hipStreamSynchronize(c->stream));
+    }
+    {
+        Timer t(c, OEMGPU_T_FINAL);
+        rc = launch_xtx_prepare(c->stream, xtx_dev, xty_dev, scale_factor ? sf : nullptr, p, xx, xy, st);
+        if (rc) return rc;
+    }
+    return run_paths(c, B, xx, xy, st, p, p, SEM_XTX, 0, 0, o, scale_factor, beta, lambda_out, niter, loss, d);
+}
+
+int oemgpu_eig_max_dev(oemgpu_ctx *c, const double *a_dev, int32_t p, double *lambda_max)
+{
+    if (!c || !a_dev || !lambda_max || p < 1) { set_error("eig_max: bad argument"); return OEMGPU_ERR_ARG; }
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    // run the engines with zero penalties: they stop after the eigenvalue step
+    Bump B;
+    const size_t a_z = B.take((size_t)(p + 8) * 8), a_o = B.take(64);
+    const int lan = p < 128 ? p : 128;
+    const size_t work_d = p <= SMALL_P_MAX ? 0 : path_large_work_doubles(p, lan);
+    const size_t a_w = B.take(work_d * 8);
+    if (ctx_reserve(c, B.off)) return OEMGPU_ERR_HIP;
+    if (ctx_pinned(c, 4096)) return OEMGPU_ERR_HIP;
+    OEM_HIP(hipMemsetAsync(c->ws + a_z, 0, (size_t)(p + 8) * 8, c->stream));
+    PathArgs a;
+    memset(&a, 0, sizeof a);
+    a.p = p; a.npen = 0; a.nl = 1; a.maxit = 1; a.lanczos_steps = lan; a.lambda_min_ratio = 0.5;
+    a.xx = a_dev; a.xy = (const double *)(c->ws + a_z); a.pf = a.xy; a.stats = a.xy;
+    a.d_out = (double *)(c->ws + a_o);
+    a.work = (double *)(c->ws + a_w);
+    int rc = p <= SMALL_P_MAX ? launch_path_small(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned);
+    if (rc) return rc;
+    double h[2];
+    OEM_HIP(hipMemcpyAsync(h, a.d_out, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    OEM_HIP(hipStreamSynchronize(c->stream));
+    *lambda_max = h[1];
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- drop-in entry points
+static int upload_matrix(oemgpu_ctx *c, const double *x, int64_t n, int32_t p, double **xd, int64_t *ld)
+{
+    *ld = (n + 1) / 2 * 2;                       // even leading dimension: every column 16-byte aligned
+    OEM_HIP(hipMalloc((void **)xd, sizeof(double) * (size_t)(*ld) * p));
+    if (*ld == n) OEM_HIP(hipMemcpyAsync(*xd, x, sizeof(double) * (size_t)n * p, hipMemcpyHostToDevice, c->stream));
+    else OEM_HIP(hipMemcpy2DAsync(*xd, sizeof(double) * (size_t)(*ld), x, sizeof(double) * (size_t)n, sizeof(double) * (size_t)n, p,
+                                  hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int oemgpu_fit_dense(const double *x, int64_t n, int32_t p, const double *y, int32_t standardize, int32_t intercept,
+                     const oemgpu_opts *o, double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    if (!x || !y || !o) { set_error("fit_dense: NULL argument"); return OEMGPU_ERR_ARG; }
+    int rc = check_opts(o, p, p);
+    if (rc) return rc;
+    if (n <= p) { set_error("p >= n: the XXt branch (ref src/oem_dense.h:363-366,513-521) is not part of this path"); return OEMGPU_ERR_UNSUPPORTED; }
+    oemgpu_ctx *c = oemgpu_create(o->device, nullptr);
+    if (!c) return OEMGPU_ERR_NO_DEVICE;
+    double *xd = nullptr, *yd = nullptr;
+    int64_t ld = 0;
+    rc = upload_matrix(c, x, n, p, &xd, &ld);
+    if (!rc) {
+        hipError_t e = hipMalloc((void **)&yd, sizeof(double) * (size_t)(n + 2));
+        if (e == hipSuccess) e = hipMemcpyAsync(yd, y, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { set_error("upload of y failed: %s", hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; }
+    }
+    if (!rc) rc = oemgpu_fit_dense_dev(c, xd, n, ld, p, yd, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+    (void)hipStreamSynchronize(c->stream);
+    if (xd) (void)hipFree(xd);
+    if (yd) (void)hipFree(yd);
+    oemgpu_destroy(c);
+    return rc;
+}
+
+int oemgpu_fit_xtx(const double *xtx, const double *xty, int32_t p, const double *scale_factor, const oemgpu_opts *o,
+                   double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    if (!xtx || !xty || !o) { set_error("fit_xtx: NULL argument"); return OEMGPU_ERR_ARG; }
+    int rc = check_opts(o, p, p);
+    if (rc) return rc;
+    oemgpu_ctx *c = oemgpu_create(o->device, nullptr);
+    if (!c) return OEMGPU_ERR_NO_DEVICE;
+    double *ad = nullptr, *bd = nullptr;
+    hipError_t e = hipMalloc((void **)&ad, sizeof(double) * (size_t)p * p);
+    if (e == hipSuccess) e = hipMalloc((void **)&bd, sizeof(double) * (size_t)p);
+    if (e == hipSuccess) e = hipMemcpyAsync(ad, xtx, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(bd, xty, sizeof(double) * (size_t)p, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { set_error("upload of xtx failed: %s", hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; }
+    if (!rc) rc = oemgpu_fit_xtx_dev(c, ad, bd, p, scale_factor, o, beta, lambda_out, niter, loss, d);
+    (void)hipStreamSynchronize(c->stream);
+    if (ad) (void)hipFree(ad);
+    if (bd) (void)hipFree(bd);
+    oemgpu_destroy(c);
+    return rc;
+}
+
+int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_t nshards, int32_t p,
+                   const double *const *y_shards, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                   double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    if (!x_shards || !n_shard || !y_shards || !o || nshards < 1) { set_error("fit_big: bad argument"); return OEMGPU_ERR_ARG; }
+    const int q = p + (intercept ? 1 : 0);
+    int rc = check_opts(o, p, q);
+    if (rc) return rc;
+    int64_t n = 0, nmax = 0;
+    for (int s = 0; s < nshards; ++s) {
+        if (n_shard[s] < 0 || !x_shards[s] || !y_shards[s]) { set_error("fit_big: bad shard %d", s); return OEMGPU_ERR_ARG; }
+        n += n_shard[s];
+        if (n_shard[s] > nmax) nmax = n_shard[s];
+    }
+    if (n <= q) { set_error("p >= n: the XXt branch (ref src/oem_big.h:547-551) is not part of this path"); return OEMGPU_ERR_UNSUPPORTED; }
+    oemgpu_ctx *c = oemgpu_create(o->device, nullptr);
+    if (!c) return OEMGPU_ERR_NO_DEVICE;
+    // The reference walks row slices serially (ref src/oem_big.h:329-358).  Here: stream the shards through one
+    // device buffer twice (sample sums for the common shift, then the moments) and add the shard moments.
+    double *xd = nullptr, *yd = nullptr, *acc = nullptr;
+    const int64_t ldmax = (nmax + 1) / 2 * 2;
+    const size_t mlen = (size_t)oemgpu_moments_len(p);
+    hipError_t e = hipMalloc((void **)&xd, sizeof(double) * (size_t)ldmax * p);
+    if (e == hipSuccess) e = hipMalloc((void **)&yd, sizeof(double) * (size_t)(ldmax + 2));
+    if (e == hipSuccess) e = hipMalloc((void **)&acc, sizeof(double) * (2 * mlen + 2 * (size_t)(p + 2)));
+    if (e != hipSuccess) { set_error("fit_big: device allocation failed: %s", hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; }
+    double *msum = acc, *mtmp = acc + mlen, *ssum = acc + 2 * mlen, *stmp = ssum + (p + 2);
+    if (!rc) {
+        e = hipMemsetAsync(acc, 0, sizeof(double) * (2 * mlen + 2 * (size_t)(p + 2)), c->stream);
+        if (e != hipSuccess) { set_error("memset failed"); rc = OEMGPU_ERR_HIP; }
+    }
+    for (int pass = 0; pass < 2 && !rc; ++pass) {
+        for (int s = 0; s < nshards && !rc; ++s) {
+            const int64_t ns = n_shard[s];
+            if (ns == 0) continue;
+            const int64_t ld = (ns + 1) / 2 * 2;
+            if (ld == ns) e = hipMemcpyAsync(xd, x_shards[s], sizeof(double) * (size_t)ns * p, hipMemcpyHostToDevice, c->stream);
+            else e = hipMemcpy2DAsync(xd, sizeof(double) * (size_t)ld, x_shards[s], sizeof(double) * (size_t)ns,
+                                      sizeof(double) * (size_t)ns, p, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(yd, y_shards[s], sizeof(double) * (size_t)ns, hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) { set_error("fit_big: upload of shard %d failed: %s", s, hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; break; }
+            if (pass == 0) {
+                rc = oemgpu_shift_sums_dev(c, xd, ns, ld, p, yd, stmp);
+                if (!rc) hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(256), 0, c->stream, ssum, stmp, (size_t)(p + 2));
+            } else {
+                rc = oemgpu_moments_dev(c, xd, ns, ld, p, yd, ssum, mtmp);
+                if (!rc) hipLaunchKernelGGL(accumulate_kernel, dim3(64), dim3(256), 0, c->stream, msum, mtmp, mlen);
+            }
+            if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("fit_big: shard %d failed on the device", s); rc = OEMGPU_ERR_HIP; }
+        }
+    }
+    if (!rc) rc = oemgpu_solve_moments_dev(c, msum, ssum, p, OEMGPU_SEM_BIG, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+    (void)hipStreamSynchronize(c->stream);
+    if (xd) (void)hipFree(xd);
+    if (yd) (void)hipFree(yd);
+    if (acc) (void)hipFree(acc);
+    oemgpu_destroy(c);
+    return rc;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

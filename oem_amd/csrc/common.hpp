@@ -1,0 +1,97 @@
+// common.hpp -- shared declarations of liboemgpu (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/oemgpu.h"
+
+namespace oemgpu {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------ error plumbing
+void set_error(const char *fmt, ...);
+#define OEM_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            oemgpu::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return OEMGPU_ERR_HIP;                                                            \
+        }                                                                                     \
+    } while (0)
+
+// ------------------------------------------------------------------ Gram / moments (gram.hip)
+// Tiles are 16x16 (one v_mfma_f64_16x16x4_f64 accumulator); only tiles I >= J are built.
+struct GramPlan {
+    int p;          // columns of X
+    int ntc;        // tile columns = ceil(p/16)
+    int ntile;      // ntc*(ntc+1)/2
+    int tri;        // 1: one wave holds the whole lower triangle (ntc <= 7); 0: 4x4 tile blocks
+    int nblk;       // tile blocks per row chunk (1 when tri)
+    int nchunk;     // row chunks (workgroups along rows)
+    int steps;      // 64-row steps per chunk
+    size_t tpart_doubles;   // nchunk * ntile * 256
+    size_t vpart_doubles;   // nchunk * (2*16*ntc + 4)
+};
+GramPlan gram_plan(int64_t n, int p, int num_cu);
+
+int launch_shift_sums(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, double *sums);
+int launch_gram(hipStream_t s, const GramPlan &pl, const double *x, int64_t n, int64_t ld, const double *y,
+                const double *sums /* p+2 or null */, double *tpart, double *vpart);
+int launch_moments_reduce(hipStream_t s, const GramPlan &pl, const double *tpart, const double *vpart, double *moments);
+
+// stats layout written by finalize (doubles): [0] meanY [1] scaleY [2] yy (sum of squared standardised y)
+// [3] nobs [4..4+p) meanX [4+p..4+2p) scaleX (dense) or colsq_inv (big)
+static inline int stats_len(int p) { return 4 + 2 * p; }
+int launch_finalize(hipStream_t s, const double *moments, const double *sums, int p, int sem, int standardize,
+                    int intercept, double *xx /* q x q */, double *xy /* q */, double *stats);
+int launch_xtx_prepare(hipStream_t s, const double *xtx, const double *xty, const double *sf_inv /* or null */, int p,
+                       double *xx, double *xy, double *stats);
+
+// ------------------------------------------------------------------ eigen + path
+struct PathArgs {
+    int p;                   // dimension of beta (q)
+    int npen, nl, user_lambda, maxit, accelerate, compute_loss;
+    int ngroups;             // 0 when no group data
+    int lanczos_steps;       // eigen step: number of Lanczos steps (<= p)
+    int yscale;              // 1: ilambda = lambda / scaleY and lmax *= scaleY (dense); 0: xtx / big
+    double alpha, gamma, tau, tol, lambda_min_ratio;
+    const double *xx;        // q x q col-major, ld = q
+    const double *xy;        // q
+    const double *stats;     // see stats layout
+    const int *penalty;      // npen
+    const double *lambda_user;   // npen * nl or null
+    const double *pf;        // q penalty factors
+    const double *sinv;      // q: oemXTX::get_beta in-place rescale (ref src/oem_xtx.h:576-581) or null
+    const int *gid;          // q: index of the column's group in unique_groups, -1 if none
+    const int *gstart;       // ngroups+1
+    const int *gidx;         // members by group, increasing
+    const double *gw;        // ngroups weights
+    const int *gzero;        // ngroups: unique_groups[g] == 0
+    // outputs (device)
+    double *beta;            // npen * nl * q (standardised scale)
+    double *lambda_out;      // npen * nl (unscaled lambda actually used)
+    int *niter;              // npen * nl
+    double *loss;            // npen * nl
+    double *d_out;           // [0] = d, [1] = lambda_max
+    // workspace for the large-p engine
+    double *work;
+};
+
+static const int SMALL_P_MAX = 192;
+int launch_path_small(hipStream_t s, const PathArgs &a);          // p <= SMALL_P_MAX: one fused launch
+int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch);   // any p: multi-launch engine
+size_t path_large_work_doubles(int p, int nsteps);
+
+int launch_eig_small(hipStream_t s, const double *a, int p, int steps, double *out /* [d, lambda_max] */);
+
+__host__ __device__ static inline bool pen_is_net(int pen)
+{
+    return pen == OEMGPU_ELASTIC_NET || pen == OEMGPU_MCP_NET || pen == OEMGPU_SCAD_NET ||
+           pen == OEMGPU_GRP_LASSO_NET || pen == OEMGPU_GRP_MCP_NET || pen == OEMGPU_GRP_SCAD_NET;
+}
+__host__ __device__ static inline bool pen_is_grp(int pen) { return pen >= OEMGPU_GRP_LASSO; }
+
+}  // namespace oemgpu

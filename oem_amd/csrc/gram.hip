@@ -1,0 +1,660 @@
+// gram.hip -- one-pass moment build for tall column-major X on gfx950 (CDNA4).
+//
+// Replaces, with ONE streaming pass over X:
+//   DataStd::standardize   ref src/DataStd.h:203-265   (column means / scales, never materialised)
+//   XY = X'Y / n           ref src/oem_dense.h:699-707
+//   XtX()                  ref src/oem_dense.h:318-361  (lower rank-n update), row slices ref src/oem_big.h:319-361
+//   per-column sums        ref src/oem_big.h:743-841
+//
+// Layout trick (no LDS, no transpose): v_mfma_f64_16x16x4_f64 takes A[i][k] from lane i+16k and
+// B[k][j] from lane j+16k, one f64 per lane.  For a Gram tile G[I][J] = sum_rows x[:,16I+i] x[:,16J+j]
+// the SAME register fragment f_T(lane) = x[row(k)][16T + (lane&15)] serves as the A operand of every
+// tile in tile-row T and the B operand of every tile in tile-column T, and the identity of the four
+// rows occupying the k slots of one MFMA is irrelevant as long as all fragments of that step agree.
+// So lane (i, q=lane>>4) loads 16 B = rows {r0+2q, r0+2q+1} of column 16T+i: the four q-lanes of a
+// column read 64 contiguous bytes, every fetched byte is used, and the two halves of the dwordx4
+// feed two consecutive MFMA k-steps.  Each 4-wave workgroup walks 64-row steps (16 rows per wave, so
+// a workgroup touches 512 contiguous bytes of every column per step).
+//
+// Centring: data are shifted by a provisional mean c (from a strided row sample) while loading, and the
+// exact centred moments follow from  C_ij = M_ij - s_i s_j / n  (M, s = shifted moments / sums).  The
+// correction is O(sample error^2), so there is no cancellation even when |mean| >> sd.
+#include "common.hpp"
+
+#include <type_traits>
+
+namespace oemgpu {
+
+// ------------------------------------------------------------------------------------------------
+// provisional shift: sums over <= 256 evenly spaced 16-row chunks (all rows when n <= 4096)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shift_sums_kernel(const double *__restrict__ x, int64_t n, int64_t ld, int p,
+                                                          const double *__restrict__ y, double *__restrict__ sums)
+{
+    __shared__ double sh[256];
+    const int j = blockIdx.x;
+    const double *col = (j < p) ? x + (size_t)j * ld : y;
+    const int64_t nch = (n + 15) / 16;
+    const int64_t nsamp = nch < 256 ? nch : 256;
+    const int k = threadIdx.x;
+    double s = 0.0, cnt = 0.0;
+    if (k < nsamp) {
+        const int64_t c = (nsamp > 1) ? ((int64_t)k * (nch - 1)) / (nsamp - 1) : 0;
+        const int64_t r0 = c * 16, r1 = (r0 + 16 < n) ? r0 + 16 : n;
+        for (int64_t r = r0; r < r1; ++r) { s += col[r]; cnt += 1.0; }
+    }
+    sh[k] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (k < w) sh[k] += sh[k + w];
+        __syncthreads();
+    }
+    if (k == 0) sums[j] = sh[0];
+    if (j == 0) {
+        __syncthreads();
+        sh[k] = cnt;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (k < w) sh[k] += sh[k + w];
+            __syncthreads();
+        }
+        if (k == 0) sums[p + 1] = sh[0];
+    }
+}
+
+int launch_shift_sums(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, double *sums)
+{
+    hipLaunchKernelGGL(shift_sums_kernel, dim3(p + 1), dim3(256), 0, s, x, n, ld, p, y, sums);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA Gram body
+// ------------------------------------------------------------------------------------------------
+#include "gen/acc_tiles.inc"
+
+template <int N, typename F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// Explicit global address space: through the per-fragment pointer arrays hipcc otherwise falls back to flat_load,
+// whose out-of-order return makes it wait vmcnt(0) + lgkmcnt(0) and drains the prefetch pipeline.
+typedef const double __attribute__((address_space(1))) *gptr_t;
+typedef const v2d __attribute__((address_space(1))) *gptr2_t;
+
+// One 8-row slab of one wave: lane (i, q) holds rows r+2q, r+2q+1 of each fragment's column.
+template <int NF> struct Slab {
+    v2d v[NF];
+    v2d y;
+};
+
+template <int NF, bool ALIGNED, bool MASKED, bool LOADY>
+__device__ __forceinline__ void load_slab(Slab<NF> &s, const gptr_t (&ptr)[NF], gptr_t y, int64_t r, int64_t n)
+{
+    if (!MASKED) {
+        if (ALIGNED) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) s.v[f] = *(gptr2_t)(ptr[f] + r);
+            if (LOADY) s.y = *(gptr2_t)(y + r);
+        } else {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) { s.v[f].x = ptr[f][r]; s.v[f].y = ptr[f][r + 1]; }
+            if (LOADY) { s.y.x = y[r]; s.y.y = y[r + 1]; }
+        }
+    } else {
+        const int64_t r0 = r < n ? r : n - 1, r1 = r + 1 < n ? r + 1 : n - 1;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) { s.v[f].x = ptr[f][r0]; s.v[f].y = ptr[f][r1]; }
+        if (LOADY) { s.y.x = y[r0]; s.y.y = y[r1]; }
+    }
+}
+
+// VALU-side accumulators (block kernel only; the triangle kernel gets X'y and the column sums from the MFMAs
+// by treating y and a column of ones as columns p and p+1 of the matrix).
+template <int NF> struct VecAcc {
+    double sx[NF], sxy[NF];
+    double sy, syy;
+};
+
+// Per-lane load-time transform: v = x * m + o.  Ordinary column: m = 1, o = -c (exact x - c).
+// Ones column (AUG, col == p+1): m = 0, o = 1.
+template <int NF> struct LaneXf {
+    double c[NF];       // shift of the fragment's column (0 for y/ones handled through m_last/o_last)
+    double m_last, o_last;
+};
+
+// Columns beyond the last valid one need no masking: a fragment lane only feeds the tile rows / columns of
+// its own column index, and entries outside the matrix are dropped by moments_reduce_kernel.
+template <int NR, int NC, bool DIAG, bool MASKED, bool VEC, bool AUG>
+__device__ __forceinline__ void consume_slab(VecAcc<DIAG ? NR : NR + NC> &V, Slab<DIAG ? NR : NR + NC> &s,
+                                             const LaneXf<DIAG ? NR : NR + NC> &X, double cy, int64_t r, int64_t n)
+{
+    constexpr int NF = DIAG ? NR : NR + NC;
+    double m0 = 1.0, m1 = 1.0;
+    if (MASKED) {
+        m0 = (r < n) ? 1.0 : 0.0;
+        m1 = (r + 1 < n) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        if (AUG && f == NF - 1) {
+            s.v[f].x = fma(s.v[f].x, X.m_last, X.o_last);
+            s.v[f].y = fma(s.v[f].y, X.m_last, X.o_last);
+        } else {
+            s.v[f].x -= X.c[f];
+            s.v[f].y -= X.c[f];
+        }
+        if (MASKED) { s.v[f].x *= m0; s.v[f].y *= m1; }
+    }
+    if (VEC) {
+        double y0 = s.y.x - cy, y1 = s.y.y - cy;
+        if (MASKED) { y0 *= m0; y1 *= m1; }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            V.sx[f] = (V.sx[f] + s.v[f].x) + s.v[f].y;
+            V.sxy[f] = fma(s.v[f].x, y0, V.sxy[f]);
+            V.sxy[f] = fma(s.v[f].y, y1, V.sxy[f]);
+        }
+        V.sy = (V.sy + y0) + y1;
+        V.syy = fma(y0, y0, V.syy);
+        V.syy = fma(y1, y1, V.syy);
+    }
+    // All VALU writes of MFMA operands are above this point.  The MFMAs are inline asm on asm-owned AGPR tiles
+    // (gen/acc_tiles.inc); hipcc pads no hazards for asm, so the VALU-write -> MFMA-read wait states are explicit.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 3" ::: "memory");
+    static_for<2>([&](auto E) {
+        constexpr int e = decltype(E)::value;
+        if constexpr (DIAG) {
+            static_for<NR>([&](auto I_) {
+                constexpr int I = decltype(I_)::value;
+                static_for<I + 1>([&](auto J_) {
+                    constexpr int J = decltype(J_)::value;
+                    AccTile<I *(I + 1) / 2 + J>::mfma(s.v[I][e], s.v[J][e]);
+                });
+            });
+        } else {
+            static_for<NR>([&](auto I_) {
+                constexpr int I = decltype(I_)::value;
+                static_for<NC>([&](auto J_) {
+                    constexpr int J = decltype(J_)::value;
+                    AccTile<I * NC + J>::mfma(s.v[I][e], s.v[NR + J][e]);
+                });
+            });
+        }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int m)
+{
+    return __shfl_xor(v, m, 64);
+}
+
+// One workgroup (4 waves) builds the tiles {(I0+a, J0+b)} over `steps` 64-row steps starting at row_begin.
+// AUG: the matrix is Z = [X | y | 1] (p+2 columns); otherwise X only, with X'y / sums on the VALU (VEC).
+// tdst: this chunk's tile partials [ntile_total][256]; vdst: this chunk's vector partials.
+template <int NR, int NC, bool DIAG, bool ALIGNED, bool VEC, bool AUG>
+__device__ __forceinline__ void gram_body(const double *__restrict__ x, int64_t n, int64_t ld, int p,
+                                          const double *__restrict__ y, const double *__restrict__ sums, int ntc,
+                                          int I0, int J0, int64_t row_begin, int steps, bool do_scalar,
+                                          double *__restrict__ tdst, double *__restrict__ vdst, double *lds)
+{
+    constexpr int NF = DIAG ? NR : NR + NC;
+    constexpr int NTILES = DIAG ? NR * (NR + 1) / 2 : NR * NC;
+    // w must be provably wave-uniform or every loop below turns into exec-masked vector control flow
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, q = lane >> 4;
+
+    const gptr_t xg = (gptr_t)x, yg = (gptr_t)y;
+    gptr_t ptr[NF];
+    LaneXf<NF> X;
+    X.m_last = 1.0; X.o_last = 0.0;
+    const double inv_cnt = sums ? 1.0 / sums[p + 1] : 0.0;
+    const double cy = sums ? sums[p] * inv_cnt : 0.0;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int T = (DIAG || f < NR) ? I0 + f : J0 + (f - NR);
+        const int col = 16 * T + i;
+        double cf;
+        if (AUG) {
+            if (col < p) { ptr[f] = xg + (size_t)col * ld; cf = sums ? sums[col] * inv_cnt : 0.0; }
+            else { ptr[f] = yg; cf = cy; }
+            if (f == NF - 1) {
+                X.m_last = (col == p + 1) ? 0.0 : 1.0;
+                X.o_last = (col == p + 1) ? 1.0 : -cf;
+            }
+        } else {
+            const int cc = col < p ? col : p - 1;
+            ptr[f] = xg + (size_t)cc * ld;
+            cf = sums ? sums[cc] * inv_cnt : 0.0;
+        }
+        X.c[f] = cf;
+    }
+
+    VecAcc<NF> V;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) { V.sx[f] = 0.0; V.sxy[f] = 0.0; }
+    V.sy = 0.0; V.syy = 0.0;
+    static_for<NTILES>([&](auto T_) { AccTile<decltype(T_)::value>::zero(); });
+    asm volatile("s_nop 7" ::: "memory");
+
+    // Row ownership: the workgroup walks 32-row steps; wave w owns the 8-row slab 8 w of each, so a workgroup
+    // touches 256 contiguous bytes of every column per step and a wave's slabs are evenly strided (32 rows):
+    // one pointer bump per three slabs, everything else is an immediate offset.
+    // Full slabs (row + 8 <= n) form a prefix; at most one ragged slab follows.
+    const int nslab = 2 * steps;
+    const int64_t w0 = row_begin + 8 * w;
+    int ns = 0;
+    if (w0 + 8 <= n) {
+        int64_t k = (n - w0 - 8) / 32 + 1;
+        ns = k < nslab ? (int)k : nslab;
+    }
+    gptr_t cur[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) cur[f] = ptr[f] + w0 + 2 * q;
+    gptr_t ycur = yg + w0 + 2 * q;
+    Slab<NF> s0, s1, s2;
+    int k = 0;
+    if (ns > 0) load_slab<NF, ALIGNED, false, VEC>(s0, cur, ycur, 0, n);
+    if (ns > 1) load_slab<NF, ALIGNED, false, VEC>(s1, cur, ycur, 32, n);
+    __builtin_amdgcn_sched_barrier(0);
+    while (k + 3 <= ns) {
+        load_slab<NF, ALIGNED, false, VEC>(s2, cur, ycur, 64, n);
+        __builtin_amdgcn_sched_barrier(0);
+        consume_slab<NR, NC, DIAG, false, VEC, AUG>(V, s0, X, cy, 0, n);
+        if (k + 3 < ns) load_slab<NF, ALIGNED, false, VEC>(s0, cur, ycur, 96, n);
+        __builtin_amdgcn_sched_barrier(0);
+        consume_slab<NR, NC, DIAG, false, VEC, AUG>(V, s1, X, cy, 0, n);
+        if (k + 4 < ns) load_slab<NF, ALIGNED, false, VEC>(s1, cur, ycur, 128, n);
+        __builtin_amdgcn_sched_barrier(0);
+        consume_slab<NR, NC, DIAG, false, VEC, AUG>(V, s2, X, cy, 0, n);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) cur[f] += 96;
+        ycur += 96;
+        k += 3;
+    }
+    if (k < ns) consume_slab<NR, NC, DIAG, false, VEC, AUG>(V, s0, X, cy, 0, n);
+    if (k + 1 < ns) consume_slab<NR, NC, DIAG, false, VEC, AUG>(V, s1, X, cy, 0, n);
+    if (ns < nslab && w0 + 32 * (int64_t)ns < n) {
+        const int64_t r = w0 + 32 * (int64_t)ns + 2 * q;
+        load_slab<NF, false, true, VEC>(s0, ptr, yg, r, n);
+        consume_slab<NR, NC, DIAG, true, VEC, AUG>(V, s0, X, cy, r, n);
+    }
+
+    // MFMA result -> any other reader: the 16-pass DGEMM needs up to 18 wait states, invisible to hipcc (asm)
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    // ---- vector partials: reduce over the 4 q-lanes of a column, then over the 4 waves (fixed order)
+    if (VEC) {
+        constexpr int VW = 2 * 16 * NF + 4;     // doubles per wave
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            V.sx[f] += shfl_xor_d(V.sx[f], 16);  V.sx[f] += shfl_xor_d(V.sx[f], 32);
+            V.sxy[f] += shfl_xor_d(V.sxy[f], 16); V.sxy[f] += shfl_xor_d(V.sxy[f], 32);
+        }
+        V.sy += shfl_xor_d(V.sy, 16);   V.sy += shfl_xor_d(V.sy, 32);
+        V.syy += shfl_xor_d(V.syy, 16); V.syy += shfl_xor_d(V.syy, 32);
+        if (q == 0) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                lds[w * VW + f * 16 + i] = V.sx[f];
+                lds[w * VW + 16 * NF + f * 16 + i] = V.sxy[f];
+            }
+            if (i == 0) { lds[w * VW + 32 * NF] = V.sy; lds[w * VW + 32 * NF + 1] = V.syy; }
+        }
+        __syncthreads();
+        if (w == 0 && q == 0) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int T = I0 + f;
+                if (T < ntc) {
+                    double a = 0.0, b = 0.0;
+                    for (int ww = 0; ww < 4; ++ww) { a += lds[ww * VW + f * 16 + i]; b += lds[ww * VW + 16 * NF + f * 16 + i]; }
+                    vdst[16 * T + i] = a;
+                    vdst[16 * ntc + 16 * T + i] = b;
+                }
+            }
+            if (i == 0 && do_scalar) {
+                double a = 0.0, b = 0.0;
+                for (int ww = 0; ww < 4; ++ww) { a += lds[ww * VW + 32 * NF]; b += lds[ww * VW + 32 * NF + 1]; }
+                int64_t rows = n - row_begin;
+                if (rows < 0) rows = 0;
+                if (rows > (int64_t)steps * 64) rows = (int64_t)steps * 64;
+                vdst[32 * ntc] = a; vdst[32 * ntc + 1] = b; vdst[32 * ntc + 2] = (double)rows; vdst[32 * ntc + 3] = 0.0;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- tile partials: ((w3 + w2) + w1) + w0, summed in place in LDS, then one coalesced store per register
+    if (w == 3) {
+        static_for<NTILES>([&](auto T_) {
+            constexpr int tt = decltype(T_)::value;
+            static_for<4>([&](auto R_) {
+                constexpr int r = decltype(R_)::value;
+                lds[(tt * 4 + r) * 64 + lane] = AccTile<tt>::template read<r>();
+            });
+        });
+    }
+    __syncthreads();
+    for (int src = 2; src >= 1; --src) {
+        if (w == src) {
+            static_for<NTILES>([&](auto T_) {
+                constexpr int tt = decltype(T_)::value;
+                static_for<4>([&](auto R_) {
+                    constexpr int r = decltype(R_)::value;
+                    lds[(tt * 4 + r) * 64 + lane] += AccTile<tt>::template read<r>();
+                });
+            });
+        }
+        __syncthreads();
+    }
+    if (w == 0) {
+        static_for<NR>([&](auto I_) {
+            constexpr int I = decltype(I_)::value;
+            static_for<(DIAG ? I + 1 : NC)>([&](auto J_) {
+                constexpr int J = decltype(J_)::value;
+                const int gi = I0 + I, gj = J0 + J;
+                if (gi < ntc && gj < ntc) {
+                    constexpr int tt = DIAG ? I * (I + 1) / 2 + J : I * NC + J;
+                    double *dst = tdst + (size_t)(gi * (gi + 1) / 2 + gj) * 256;
+                    static_for<4>([&](auto R_) {
+                        constexpr int r = decltype(R_)::value;
+                        dst[r * 64 + lane] = lds[(tt * 4 + r) * 64 + lane] + AccTile<tt>::template read<r>();
+                    });
+                }
+            });
+        });
+    }
+}
+
+// Pointers are separate kernel parameters (not struct members): only then does hipcc know they are global
+// and emit global_load (counted vmcnt) instead of flat_load (vmcnt(0) + lgkmcnt(0) drains the prefetch).
+struct GramDims {
+    int64_t n; int64_t ld; int p;
+    int ntc, ntile, nblk, nchunk, steps;
+};
+
+// whole lower triangle of Z = [X | y | 1] in one wave (p + 2 <= 112)
+template <int NT, bool ALIGNED>
+__global__ __launch_bounds__(256) void gram_tri_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                        const double *__restrict__ sums, double *__restrict__ tpart,
+                                                        double *__restrict__ vpart, GramDims a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int chunk = blockIdx.x;
+    gram_body<NT, NT, true, ALIGNED, false, true>(x, a.n, a.ld, a.p, y, sums, a.ntc, 0, 0,
+                                                  (int64_t)chunk * a.steps * 64, a.steps, true,
+                                                  tpart + (size_t)chunk * a.ntile * 256, vpart, lds);
+}
+
+// 4x4 tile blocks of X'X; blockIdx -> (row chunk, tile block) so that the tile blocks of one row chunk run
+// back to back on one XCD (blocks b and b+8 share an XCD) and re-read that chunk's rows from its L2.
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void gram_blk_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                        const double *__restrict__ sums, double *__restrict__ tpart,
+                                                        double *__restrict__ vpart, GramDims a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
+    const int tb = s % a.nblk, chunk = (s / a.nblk) * 8 + xcd;
+    int BI = (int)((sqrtf(8.0f * (float)tb + 1.0f) - 1.0f) * 0.5f);
+    while (BI * (BI + 1) / 2 > tb) --BI;
+    while ((BI + 1) * (BI + 2) / 2 <= tb) ++BI;
+    const int BJ = tb - BI * (BI + 1) / 2;
+    const int64_t row_begin = (int64_t)chunk * a.steps * 64;
+    double *tdst = tpart + (size_t)chunk * a.ntile * 256;
+    double *vdst = vpart + (size_t)chunk * (32 * a.ntc + 4);
+    if (BI == BJ)
+        gram_body<4, 4, true, ALIGNED, true, false>(x, a.n, a.ld, a.p, y, sums, a.ntc, 4 * BI, 4 * BI, row_begin,
+                                                    a.steps, BI == 0, tdst, vdst, lds);
+    else
+        gram_body<4, 4, false, ALIGNED, false, false>(x, a.n, a.ld, a.p, y, sums, a.ntc, 4 * BI, 4 * BJ,
+                                                      row_begin, a.steps, false, tdst, vdst, lds);
+}
+
+GramPlan gram_plan(int64_t n, int p, int num_cu)
+{
+    GramPlan pl;
+    pl.p = p;
+    pl.tri = (p + 2 + 15) / 16 <= 7;                     // Z = [X | y | 1] fits one wave's triangle
+    pl.ntc = pl.tri ? (p + 2 + 15) / 16 : (p + 15) / 16;
+    pl.ntile = pl.ntc * (pl.ntc + 1) / 2;
+    const int64_t nsteps = (n + 63) / 64;
+    if (pl.tri) {
+        pl.nblk = 1;
+        int64_t c = nsteps < num_cu ? nsteps : num_cu;
+        if (c < 1) c = 1;
+        pl.steps = (int)((nsteps + c - 1) / c);
+        if (pl.steps < 1) pl.steps = 1;
+        pl.nchunk = (int)((nsteps + pl.steps - 1) / pl.steps);
+        if (pl.nchunk < 1) pl.nchunk = 1;
+    } else {
+        const int nb = (pl.ntc + 3) / 4;
+        pl.nblk = nb * (nb + 1) / 2;
+        int64_t c = ((int64_t)num_cu * 8) / pl.nblk;          // ~8 rounds of one workgroup per CU
+        if (c > nsteps) c = nsteps;
+        if (c < 1) c = 1;
+        c = (c + 7) / 8 * 8;
+        pl.steps = (int)((nsteps + c - 1) / c);
+        if (pl.steps < 1) pl.steps = 1;
+        pl.nchunk = (int)c;
+    }
+    pl.tpart_doubles = (size_t)pl.nchunk * pl.ntile * 256;
+    pl.vpart_doubles = (size_t)pl.nchunk * (32 * pl.ntc + 4);
+    return pl;
+}
+
+template <bool ALIGNED>
+static int launch_gram_t(hipStream_t s, const GramPlan &pl, const double *x, const double *y, const double *sums,
+                         double *tpart, double *vpart, const GramDims &a)
+{
+    const size_t tile_bytes = 256 * sizeof(double);
+#define OEM_TRI(NT)                                                                                       \
+    case NT: {                                                                                            \
+        size_t sh = (size_t)(NT * (NT + 1) / 2) * tile_bytes;                                             \
+        size_t vb = (size_t)4 * (2 * 16 * NT + 4) * sizeof(double);                                       \
+        if (sh < vb) sh = vb;                                                                             \
+        hipLaunchKernelGGL((gram_tri_kernel<NT, ALIGNED>), dim3(pl.nchunk), dim3(256), sh, s, x, y, sums, tpart, vpart, a);          \
+        break;                                                                                            \
+    }
+    if (pl.tri) {
+        switch (pl.ntc) {
+            OEM_TRI(1) OEM_TRI(2) OEM_TRI(3) OEM_TRI(4) OEM_TRI(5) OEM_TRI(6) OEM_TRI(7)
+        default: set_error("gram: bad tile count %d", pl.ntc); return OEMGPU_ERR_INTERNAL;
+        }
+    } else {
+        size_t sh = 16 * tile_bytes;
+        size_t vb = (size_t)4 * (2 * 16 * 4 + 4) * sizeof(double);
+        if (sh < vb) sh = vb;
+        hipLaunchKernelGGL((gram_blk_kernel<ALIGNED>), dim3(pl.nchunk * pl.nblk), dim3(256), sh, s, x, y, sums, tpart, vpart, a);
+    }
+#undef OEM_TRI
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gram(hipStream_t s, const GramPlan &pl, const double *x, int64_t n, int64_t ld, const double *y,
+                const double *sums, double *tpart, double *vpart)
+{
+    GramDims a;
+    a.n = n; a.ld = ld; a.p = pl.p;
+    a.ntc = pl.ntc; a.ntile = pl.ntile; a.nblk = pl.nblk; a.nchunk = pl.nchunk; a.steps = pl.steps;
+    const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && (ld & 1) == 0;
+    return aligned ? launch_gram_t<true>(s, pl, x, y, sums, tpart, vpart, a)
+                   : launch_gram_t<false>(s, pl, x, y, sums, tpart, vpart, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// partial reduction: sums the per-chunk partials in chunk order (bitwise reproducible) and scatters the
+// MFMA accumulator layout (row = (lane>>4) + 4 reg, col = lane & 15) into the q x q moment buffer.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void moments_reduce_kernel(const double *__restrict__ tpart,
+                                                              const double *__restrict__ vpart, int p, int ntc,
+                                                              int ntile, int nchunk, int aug, double *__restrict__ M)
+{
+    const int q = p + 2;
+    const int lim = aug ? q : p;      // tiles cover Z = [X | y | 1] (aug) or X only
+    const int b = blockIdx.x, e = threadIdx.x;
+    if (b < ntile) {
+        int I = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
+        while (I * (I + 1) / 2 > b) --I;
+        while ((I + 1) * (I + 2) / 2 <= b) ++I;
+        const int J = b - I * (I + 1) / 2;
+        double s = 0.0;
+        const double *src = tpart + (size_t)b * 256 + e;
+        for (int c = 0; c < nchunk; ++c) s += src[(size_t)c * ntile * 256];
+        const int reg = e >> 6, lane = e & 63;
+        const int row = 16 * I + (lane >> 4) + 4 * reg, col = 16 * J + (lane & 15);
+        if (row < lim && col < lim && row >= col) {
+            M[(size_t)col * q + row] = s;
+            M[(size_t)row * q + col] = s;
+        }
+    } else if (!aug) {
+        const int vw = 32 * ntc + 4;
+        for (int j = e; j < p; j += 256) {
+            double a = 0.0, bb = 0.0;
+            for (int c = 0; c < nchunk; ++c) { a += vpart[(size_t)c * vw + j]; bb += vpart[(size_t)c * vw + 16 * ntc + j]; }
+            M[(size_t)j * q + (p + 1)] = a;  M[(size_t)(p + 1) * q + j] = a;
+            M[(size_t)j * q + p] = bb;       M[(size_t)p * q + j] = bb;
+        }
+        if (e == 0) {
+            double sy = 0.0, syy = 0.0, cnt = 0.0;
+            for (int c = 0; c < nchunk; ++c) {
+                sy += vpart[(size_t)c * vw + 32 * ntc]; syy += vpart[(size_t)c * vw + 32 * ntc + 1];
+                cnt += vpart[(size_t)c * vw + 32 * ntc + 2];
+            }
+            M[(size_t)p * q + p] = syy;
+            M[(size_t)p * q + (p + 1)] = sy;  M[(size_t)(p + 1) * q + p] = sy;
+            M[(size_t)(p + 1) * q + (p + 1)] = cnt;
+        }
+    }
+}
+
+int launch_moments_reduce(hipStream_t s, const GramPlan &pl, const double *tpart, const double *vpart, double *moments)
+{
+    hipLaunchKernelGGL(moments_reduce_kernel, dim3(pl.ntile + (pl.tri ? 0 : 1)), dim3(256), 0, s, tpart, vpart, pl.p,
+                       pl.ntc, pl.ntile, pl.nchunk, pl.tri, moments);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: shifted moments -> standardisation constants, XX, XY
+//   sem 0 (DataStd + oemDense): ref src/DataStd.h:94-267, src/oem_dense.h:483,704-707
+//   sem 1 (oemBig):             ref src/oem_big.h:731-842, 469-545
+// ------------------------------------------------------------------------------------------------
+struct Mom {
+    const double *M; const double *sums; int p, q; double n;
+    __device__ double c(int j) const { return sums ? sums[j] / sums[p + 1] : 0.0; }
+    __device__ double s(int j) const { return M[(size_t)j * q + (p + 1)]; }              // sum (z_j - c_j), j <= p
+    __device__ double mu(int j) const { return c(j) + s(j) / n; }
+    __device__ double cen(int i, int j) const { return M[(size_t)j * q + i] - s(i) * s(j) / n; }   // centred cross product
+    __device__ double raw(int i, int j) const { return cen(i, j) + n * mu(i) * mu(j); }            // sum z_i z_j
+};
+
+__global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict__ Mbuf, const double *__restrict__ sums,
+                                                        int p, int sem, int standardize, int intercept,
+                                                        double *__restrict__ xx, double *__restrict__ xy,
+                                                        double *__restrict__ stats)
+{
+    Mom m; m.M = Mbuf; m.sums = sums; m.p = p; m.q = p + 2; m.n = Mbuf[(size_t)(p + 1) * (p + 2) + (p + 1)];
+    const double n = m.n;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    if (sem == OEMGPU_SEM_DENSE) {
+        const int flag = (standardize ? 1 : 0) + 2 * (intercept ? 1 : 0);
+        // y
+        double meany = 0.0, scaley = 1.0, yy;
+        const double cyy = fmax(m.cen(p, p), 0.0);
+        if (flag == 1) { scaley = sqrt(cyy) / sqrt(n); yy = m.raw(p, p) / (scaley * scaley); }
+        else if (flag >= 2) { meany = m.mu(p); scaley = sqrt(cyy) * (1.0 / sqrt(n)); yy = cyy / (scaley * scaley); }
+        else yy = m.raw(p, p);
+        if (tid == 0) { stats[0] = meany; stats[1] = scaley; stats[2] = yy; stats[3] = n; }
+        for (int idx = tid; idx < p * p; idx += nth) {
+            const int i = idx % p, j = idx / p;
+            double si = 1.0, sj = 1.0;
+            if (flag & 1) {
+                si = (flag == 1) ? sqrt(fmax(m.cen(i, i), 0.0)) / sqrt(n) : sqrt(fmax(m.cen(i, i), 0.0)) * (1.0 / sqrt(n));
+                sj = (flag == 1) ? sqrt(fmax(m.cen(j, j), 0.0)) / sqrt(n) : sqrt(fmax(m.cen(j, j), 0.0)) * (1.0 / sqrt(n));
+                if (si == 0.0) si = 1.0;
+                if (sj == 0.0) sj = 1.0;
+            }
+            const double g = (flag >= 2) ? m.cen(i, j) : m.raw(i, j);
+            xx[(size_t)j * p + i] = g / (si * sj) / n;
+            if (i == 0) {
+                const double gy = (flag >= 2) ? m.cen(j, p) : m.raw(j, p);
+                xy[j] = gy / (sj * scaley) / n;
+                stats[4 + j] = (flag >= 2) ? m.mu(j) : 0.0;
+                stats[4 + p + j] = sj;
+            }
+        }
+    } else {
+        const int off = intercept ? 1 : 0, qq = p + off;
+        if (tid == 0) { stats[0] = 0.0; stats[1] = 1.0; stats[2] = m.raw(p, p); stats[3] = n; }
+        for (int idx = tid; idx < p * p; idx += nth) {
+            const int i = idx % p, j = idx / p;
+            double ci = 1.0, cj = 1.0;
+            if (standardize) {
+                double a = m.raw(i, i) / (n - 1.0), b = m.raw(j, j) / (n - 1.0);
+                if (a == 0.0) a = 1.0;
+                if (b == 0.0) b = 1.0;
+                ci = 1.0 / sqrt(a); cj = 1.0 / sqrt(b);
+            }
+            xx[(size_t)(j + off) * qq + (i + off)] = ci * m.raw(i, j) * cj / n;
+            if (i == 0) {
+                xy[j + off] = m.raw(j, p) * cj / n;
+                stats[4 + j] = 0.0;
+                stats[4 + p + j] = cj;
+                if (intercept) {
+                    const double cs = n * m.mu(j) * cj / n;     // colsums * colsq_inv / nobs
+                    xx[(size_t)(j + 1) * qq] = cs;
+                    xx[(size_t)(j + 1)] = cs;
+                }
+            }
+        }
+        if (tid == 0 && intercept) { xx[0] = 1.0; xy[0] = n * m.mu(p) / n; }
+    }
+}
+
+int launch_finalize(hipStream_t s, const double *moments, const double *sums, int p, int sem, int standardize,
+                    int intercept, double *xx, double *xy, double *stats)
+{
+    int blocks = (p * p + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, s, moments, sums, p, sem, standardize, intercept, xx,
+                       xy, stats);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+// oem.xtx: XY = xty / s, XX = S^-1 xtx S^-1  (ref src/oem_xtx.h:347-356, 520-531)
+__global__ __launch_bounds__(256) void xtx_prepare_kernel(const double *__restrict__ xtx, const double *__restrict__ xty,
+                                                           const double *__restrict__ sinv, int p,
+                                                           double *__restrict__ xx, double *__restrict__ xy,
+                                                           double *__restrict__ stats)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = tid; idx < (size_t)p * p; idx += nth) {
+        const int i = (int)(idx % p), j = (int)(idx / p);
+        xx[idx] = sinv ? sinv[i] * xtx[idx] * sinv[j] : xtx[idx];
+        if (i == 0) xy[j] = sinv ? xty[j] * sinv[j] : xty[j];
+    }
+    if (tid == 0) { stats[0] = 0.0; stats[1] = 1.0; stats[2] = 0.0; stats[3] = 1.0; }
+}
+
+int launch_xtx_prepare(hipStream_t s, const double *xtx, const double *xty, const double *sf_inv, int p, double *xx,
+                       double *xy, double *stats)
+{
+    size_t blocks = ((size_t)p * p + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(xtx_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xtx, xty, sf_inv, p, xx, xy, stats);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace oemgpu
