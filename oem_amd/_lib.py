@@ -70,6 +70,14 @@ def lib():
     """Loads liboemgpu.so.  There is no fallback: a missing library is an error."""
     global _lib
     if _lib is None:
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64, and device pointers / streams
+        # are only interchangeable with torch if liboemgpu binds to that same copy.  Loading torch first makes
+        # the dynamic loader resolve our DT_NEEDED libamdhip64.so.7 to the already-loaded one.  Without torch
+        # (e.g. under R) the system ROCm runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not LIB_PATH.exists():
             raise OSError(f"{LIB_PATH} is missing: build it with `python -m oem_amd.build` "
                           "(oem_amd has no CPU fallback)")
