@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- full-lambda-path solves/sec on BASELINE.json config 1 (the reference's README benchmark).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (README.md:44-66 of the reference): n = 1e6, p = 100, X ~ N(0, 3^2) iid, b = [U(0,1) x 25, 0 x 75],
+y = X b + N(0,1); oem(penalty="elastic.net", alpha=1) (= lasso), intercept, no standardisation, the 100 lambdas of
+a first default fit supplied back, tol = 1e-10.  Synthetic data, generated on the device, resident in HBM when
+the timed region starts.
+
+A "step" is one complete solve: shift sample -> one-pass MFMA moment build -> (N > 1: all-reduce) -> finalize ->
+eigenvalue -> 100-lambda path -> results on the host.  With N > 1 the n rows are split across the ranks (strong
+scaling: the total problem stays n = 1e6) and the (p+2)^2 moment buffer is summed with one RCCL all-reduce.
+
+Rank 0 prints ONE JSON line (see the repo README / DESIGN.md for the roofline and cpu_baseline fields).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix peak (AMD spec; 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
+README_SECONDS = 1.600241        # reference README.md:73, oem[lasso] mean over 5 runs, hardware unstated
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--p", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU baseline sample (0 = the full workload)")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import oem_amd
+    from oem_amd import _lib as L
+    from oem_amd import api
+    from oem_amd.distributed import HipBackend, oem_sharded, row_partition
+
+    n, p, m = a.n, a.p, 25
+    lo, hi = row_partition(n, world)[rank]
+    n_loc = hi - lo
+    # synthetic data of the README's shape, generated on the device (column-major: a (p, n_loc) row-major tensor)
+    g = torch.Generator(device=dev); g.manual_seed(123)
+    b = torch.cat([torch.rand(m, generator=g, device=dev, dtype=torch.float64), torch.zeros(p - m, device=dev, dtype=torch.float64)])
+    g.manual_seed(1000 + rank)
+    xt = torch.randn((p, n_loc), generator=g, device=dev, dtype=torch.float64) * 3.0
+    x = xt.t()                                   # (n_loc, p), stride (1, n_loc)
+    y = (x @ b + torch.randn(n_loc, generator=g, device=dev, dtype=torch.float64)).contiguous()
+    torch.cuda.synchronize()
+
+    kw = dict(penalty="elastic.net", alpha=1.0, intercept=True, standardize=False)
+    backend = HipBackend(local)
+    dd = dist if world > 1 else None
+
+    def solve_py(lam, tol):
+        return oem_sharded(x, y, backend=backend, dist=dd, lambda_=lam, tol=tol, **kw)
+
+    # the README first runs a default fit to obtain the lambda sequence, then times tol = 1e-10 fits on it
+    lambdas = solve_py((), 1e-7)["lambda"][0]
+
+    # The timed step is the C-ABI call sequence itself (what `.Call("oem_fit_dense")` is to the reference):
+    # arguments marshalled once, then per step: shift sample -> moments -> [all-reduce] -> solve (results on host).
+    args = api._Args(["elastic.net"], [np.asarray(lambdas)], 100, 1e-4, 1.0, 3.0, 0.5, 1e-10, 500, False, False,
+                     np.ones(p), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    sums = backend.new_buffer(p + 2)
+    mom = backend.new_buffer((p + 2) * (p + 2))
+
+    def solve(lam=None, tol=None):
+        backend.shift_sums(x, n_loc, n_loc, p, y, sums)
+        if dd is not None:
+            dd.all_reduce(sums)
+        backend.moments(x, n_loc, n_loc, p, y, sums, mom)
+        if dd is not None:
+            dd.all_reduce(mom)
+        backend.solve(mom, sums, p, L.OEMGPU_SEM_DENSE, False, True, args)
+        return args
+    for _ in range(a.warmup):
+        solve()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        solve()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the same through the Python mirror of the R front end (argument checks, result decoration): reported, not `value`
+    t1 = time.perf_counter()
+    for _ in range(20):
+        fit = solve_py(lambdas, 1e-10)
+    dt_py = (time.perf_counter() - t1) / 20
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel (the MFMA moment build), HIP events on the kernel's own stream
+    lib = L.lib()
+    L.check(lib.oemgpu_set_timing(backend.ctx, 1))
+    reps = max(10, min(50, a.steps))
+    acc = np.zeros(L.NTIMERS)
+    ms = (C.c_double * L.NTIMERS)()
+    for _ in range(reps):
+        solve()
+        L.check(lib.oemgpu_last_timings(backend.ctx, ms))
+        acc += np.array(list(ms))
+    L.check(lib.oemgpu_set_timing(backend.ctx, 0))
+    acc /= reps
+    gram_ms = acc[L.T_GRAMK]
+    flops = float(n_loc) * p * (p + 1) + 2.0 * n_loc * p            # lower-triangular syrk + X'y
+    bytes_alg = 8.0 * n_loc * p + 8.0 * n_loc
+    achieved_tf = flops / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else 0.0
+
+    out = None
+    if rank == 0:
+        niter_total = int(np.sum(fit["niter"][0]))
+        out = {
+            "metric": "full-lambda-path solves/sec (n=1e6 p=100 lasso, 100 lambdas, tol 1e-10)",
+            "value": a.steps / dt, "unit": "solves/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": (a.steps / dt) * README_SECONDS if (n == 1_000_000 and p == 100) else None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "config 1: oem() lasso (penalty='elastic.net', alpha=1), dense Gaussian X~N(0,9), "
+                                   "intercept, no standardize, 100-lambda path supplied, tol 1e-10 (README benchmark)",
+                       "n": n, "p": p, "nlambda": int(len(lambdas)), "rows_per_gpu": n_loc,
+                       "sharding": "rows/N + one all-reduce of the (p+2)^2 moment buffer" if world > 1 else "none",
+                       "oem_iterations_per_solve": niter_total},
+            "roofline": {"bound": "mfma", "kernel": "gram_tri_kernel<7> (v_mfma_f64_16x16x4_f64)",
+                         "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel_ms": gram_ms, "algorithmic_flops": flops, "algorithmic_bytes": bytes_alg,
+                         "hbm_GBps_algorithmic": bytes_alg / (gram_ms * 1e-3) / 1e9 if gram_ms > 0 else 0.0},
+            "stage_ms": {"shift_sample": acc[L.T_SHIFT], "moments_total": acc[L.T_MOMENTS], "finalize": acc[L.T_FINAL],
+                         "eigen_plus_path": acc[L.T_EIGPATH], "gram_kernel": gram_ms,
+                         "python_front_end_total": 1e3 * dt_py},
+            "path_kernel_clock_GHz": (acc[6] / acc[7] * 0.1) if acc[7] > 0 else None,
+            "path_kernel_cycles": acc[6],
+            "vs_baseline_note": "reference README: 1.600 s per solve on unstated CPU hardware",
+        }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # CPU baseline: the C restatement of the reference path (oracle/, -O3 -march=native build), 1 thread = the
+        # reference's effective default (R/oem.R:270-273), on a bounded sample of the same workload.
+        from oracle import oracle as orc
+        rows = n if a.cpu_rows <= 0 else min(n, a.cpu_rows)
+        xh = np.asfortranarray(x[:rows].cpu().numpy())
+        yh = y[:rows].cpu().numpy()
+        t0 = time.perf_counter()
+        ref = orc.fit_dense(xh, yh, native=True, lambda_=lambdas, tol=1e-10, **kw)
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / tc * (rows / n), "unit": "solves/s", "cores": 1, "kind": "port",
+                               "seconds": tc, "sample": f"{rows} of {n} rows, 1 solve (value scaled by rows/n)"
+                               if rows != n else "the full workload, 1 solve",
+                               "host_cpus": os.cpu_count()}
+        if rows == n:
+            out["max_abs_beta_err_vs_cpu"] = float(np.abs(fit["beta"][0] - ref["beta"][0]).max())
+            out["niter_equal_cpu"] = bool(np.array_equal(fit["niter"][0], ref["niter"][0]))
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,11 +123,12 @@ static inline int64_t oemgpu_moments_len(int32_t p) { return (int64_t)(p + 2) * 
 int oemgpu_shift_sums_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64_t ld, int32_t p,
                           const double *y_dev, double *sums_dev);
 
-/* moments_dev <- moments of rows [0,n) about shift c (shift_dev: p+1 values = c_x, c_y; NULL => zeros).
+/* moments_dev <- moments of rows [0,n) about the shift c = sums[0..p] / sums[p+1] (sums_dev: the (all-reduced)
+ * output of oemgpu_shift_sums_dev; NULL => c = 0).
  * Replaces DataStd's passes + X'Y + XtX (ref src/DataStd.h:203-265, src/oem_dense.h:318-361,704-707;
  * src/oem_big.h:743-841) with ONE pass over X. */
 int oemgpu_moments_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64_t ld, int32_t p,
-                       const double *y_dev, const double *shift_dev, double *moments_dev);
+                       const double *y_dev, const double *sums_dev, double *moments_dev);
 
 /* semantics selector for oemgpu_solve_moments_dev */
 #define OEMGPU_SEM_DENSE 0   /* DataStd + oemDense (ref src/DataStd.h, src/oem_dense.h) */
@@ -135,7 +136,7 @@ int oemgpu_moments_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64_t 
 
 /* From (all-reduced) moments to the full result: standardisation constants, XX, XY, d, lambda grid,
  * penalty x lambda loops, recover.  Outputs are HOST buffers as in oemgpu_fit_dense. */
-int oemgpu_solve_moments_dev(oemgpu_ctx *ctx, const double *moments_dev, const double *shift_dev, int32_t p,
+int oemgpu_solve_moments_dev(oemgpu_ctx *ctx, const double *moments_dev, const double *sums_dev, int32_t p,
                              int32_t semantics, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
                              double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
 
@@ -159,6 +160,8 @@ int oemgpu_eig_max_dev(oemgpu_ctx *ctx, const double *a_dev, int32_t p, double *
 #define OEMGPU_T_FINAL   2   /* moments -> XX, XY, standardisation constants */
 #define OEMGPU_T_EIGPATH 3   /* eigenvalue + penalty x lambda loops */
 #define OEMGPU_T_GRAMK   4   /* the MFMA Gram kernel alone */
+#define OEMGPU_T_PATHCYC 6   /* not a time: shader cycles of the last fused eigen+path kernel (p <= 192) */
+#define OEMGPU_T_PATHTICKS 7 /* not a time: the same span in 100 MHz ticks (cycles / ticks * 100 MHz = clock held) */
 #define OEMGPU_NTIMERS   8
 int oemgpu_last_timings(oemgpu_ctx *ctx, double *ms /* OEMGPU_NTIMERS */);
 /* enable (1) / disable (0) event timing of the stages (off by default: events cost a few us) */

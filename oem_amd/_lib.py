@@ -1,9 +1,10 @@
 """ctypes binding of liboemgpu.so (include/oemgpu.h).  No torch types cross this boundary."""
 import ctypes as C
+import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "liboemgpu.so"
+LIB_PATH = Path(os.environ.get("OEMGPU_LIB", _HERE / "liboemgpu.so"))   # OEMGPU_LIB: diagnostic builds only
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

@@ -175,7 +175,8 @@ def _decorate(a, penalty, varnames, intercept_row, n, p, family="gaussian"):
         res["lambda"].append(a.lam_out[k].copy())
     res["d"] = a.d.value
     res["rownames"] = (["(Intercept)"] if intercept_row else []) + list(varnames)
-    res["nzero"] = [[0 if v is None else len(v) for v in _nonzero_lists(b)] for b in res["beta"]]
+    # sapply(predict.oem(type = "nonzero"), length): row 1 is always dropped as "the intercept" (quirk Q16)
+    res["nzero"] = [(np.abs(np.asarray(b)[1:]) > 0).sum(axis=0) for b in res["beta"]]
     if n is not None:
         res["nobs"] = n
     res["nvars"] = p

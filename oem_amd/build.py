@@ -49,6 +49,14 @@ def audit_gram_isa(asm_text):
     return problems
 
 
+def build_diag():
+    """liboemgpu_diag.so: the same library with -DOEM_PATH_DIAG (stamped round segments); never the product."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = HERE / "liboemgpu_diag.so"
+    subprocess.run([hipcc, *FLAGS, "-DOEM_PATH_DIAG", "-shared", "-o", str(out)] + [str(CSRC / s) for s in SOURCES], check=True)
+    return out
+
+
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     gen = CSRC / "gen" / "acc_tiles.inc"
@@ -79,3 +87,5 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--diag" in sys.argv:
+        print(build_diag())

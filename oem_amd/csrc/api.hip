@@ -40,6 +40,7 @@ struct oemgpu_ctx {
     bool ev_made = false;
     bool ev_used[OEMGPU_NTIMERS];
     double ms[OEMGPU_NTIMERS];
+    double diag[2] = {0.0, 0.0};   // path kernel: shader cycles, 100 MHz ticks
 };
 
 namespace {
@@ -184,7 +185,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
 
     // ---- outputs region (device) : beta | lambda | loss | d[2] | niter | stats copy
     const size_t nb = (size_t)npen * nl * q, nk = (size_t)npen * nl;
-    const size_t out_doubles = nb + 2 * nk + 2 + (size_t)stats_len(p);
+    const size_t out_doubles = nb + 2 * nk + 4 + (size_t)stats_len(p);
     const size_t out_bytes = out_doubles * sizeof(double) + nk * sizeof(int32_t);
     const bool small = q <= SMALL_P_MAX;
     int lan = q < 128 ? q : 128;
@@ -214,11 +215,11 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     a.gid = (const int *)(dblob + o_gid); a.gstart = (const int *)(dblob + o_gst); a.gidx = (const int *)(dblob + o_gix);
     a.gzero = (const int *)(dblob + o_gz); a.gw = (const double *)(dblob + o_gw);
     a.beta = dout; a.lambda_out = dout + nb; a.loss = a.lambda_out + nk; a.d_out = a.loss + nk;
-    double *dstats = a.d_out + 2;
+    double *dstats = a.d_out + 4;
     a.niter = (int *)(dstats + stats_len(p));
     a.work = (double *)(c->ws + a_work);
 
-    if (ctx_pinned(c, out_bytes)) return OEMGPU_ERR_HIP;
+    if (ctx_pinned(c, out_bytes > 16384 ? out_bytes : 16384)) return OEMGPU_ERR_HIP;
     {
         Timer t(c, OEMGPU_T_EIGPATH);
         int rc = small ? launch_path_small(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned);
@@ -229,9 +230,10 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     OEM_HIP(hipStreamSynchronize(c->stream));
 
     // ---- unpack (ref src/oem_dense.cpp:249-294, src/DataStd.h:269-293, src/oem_big.h:880-897, src/oem_big.cpp:213-220)
-    const double *hb = (const double *)c->pinned, *hl = hb + nb, *hloss = hl + nk, *hd = hloss + nk, *hs = hd + 2;
+    const double *hb = (const double *)c->pinned, *hl = hb + nb, *hloss = hl + nk, *hd = hloss + nk, *hs = hd + 4;
     const int32_t *hn = (const int32_t *)(hs + stats_len(p));
     *d_out = hd[0];
+    c->diag[0] = hd[2]; c->diag[1] = hd[3];
     const double meany = hs[0], scaley = hs[1];
     const double *meanx = hs + 4, *scalex = hs + 4 + p;
     const int flag = (standardize ? 1 : 0) + 2 * (intercept ? 1 : 0);
@@ -273,7 +275,7 @@ size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o)
     size_t b = 0;
     b += (size_t)o->npen * 4 + (size_t)o->npen * nl * 8 + (size_t)q * (8 + 8 + 4) + (size_t)(o->ngroups + 2) * 16 +
          (size_t)(o->ngroupvars + q + 2) * 4 + 4096;
-    b += ((size_t)o->npen * nl * (q + 3) + 2 + stats_len(p)) * 8 + 4096;
+    b += ((size_t)o->npen * nl * (q + 3) + 4 + stats_len(p)) * 8 + 4096;
     if (q > SMALL_P_MAX) b += path_large_work_doubles(q, 128) * 8 + 4096;
     return b;
 }
@@ -379,6 +381,8 @@ int oemgpu_last_timings(oemgpu_ctx *c, double *ms)
             if (hipEventElapsedTime(&f, c->ev[2 * i], c->ev[2 * i + 1]) == hipSuccess) ms[i] = f;
         }
     }
+    ms[OEMGPU_T_PATHCYC] = c->diag[0];
+    ms[OEMGPU_T_PATHTICKS] = c->diag[1];
     return 0;
 }
 
@@ -511,12 +515,12 @@ int oemgpu_eig_max_dev(oemgpu_ctx *c, const double *a_dev, int32_t p, double *la
     if (set_device(c)) return OEMGPU_ERR_HIP;
     // run the engines with zero penalties: they stop after the eigenvalue step
     Bump B;
-    const size_t a_z = B.take((size_t)(p + 8) * 8), a_o = B.take(64);
+    const size_t a_z = B.take((size_t)(p + 8) * 8), a_o = B.take(256);
     const int lan = p < 128 ? p : 128;
     const size_t work_d = p <= SMALL_P_MAX ? 0 : path_large_work_doubles(p, lan);
     const size_t a_w = B.take(work_d * 8);
     if (ctx_reserve(c, B.off)) return OEMGPU_ERR_HIP;
-    if (ctx_pinned(c, 4096)) return OEMGPU_ERR_HIP;
+    if (ctx_pinned(c, 16384)) return OEMGPU_ERR_HIP;
     OEM_HIP(hipMemsetAsync(c->ws + a_z, 0, (size_t)(p + 8) * 8, c->stream));
     PathArgs a;
     memset(&a, 0, sizeof a);

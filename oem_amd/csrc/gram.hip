@@ -507,7 +507,16 @@ __global__ __launch_bounds__(256) void moments_reduce_kernel(const double *__res
         const int J = b - I * (I + 1) / 2;
         double s = 0.0;
         const double *src = tpart + (size_t)b * 256 + e;
-        for (int c = 0; c < nchunk; ++c) s += src[(size_t)c * ntile * 256];
+        const size_t stride = (size_t)ntile * 256;
+        int c = 0;
+        for (; c + 8 <= nchunk; c += 8) {                 // 8 independent loads in flight, summed in chunk order
+            double t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = src[(size_t)(c + k) * stride];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += t[k];
+        }
+        for (; c < nchunk; ++c) s += src[(size_t)c * stride];
         const int reg = e >> 6, lane = e & 63;
         const int row = 16 * I + (lane >> 4) + 4 * reg, col = 16 * J + (lane & 15);
         if (row < lim && col < lim && row >= col) {

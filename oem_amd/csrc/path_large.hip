@@ -1,15 +1,449 @@
-// path_large.hip -- eigenvalue + path engine for p > SMALL_P_MAX (multi-workgroup, multi-launch).
+// path_large.hip -- eigenvalue + penalty x lambda path for p > 192 (XX no longer fits one CU's registers).
+//
+// Same arithmetic as path_small.hip (ref src/oem_base.h:90-110, src/oem_dense.h:485-653, src/utils.cpp:537-549),
+// organised as a device-resident state machine driven by two kernels per OEM iteration:
+//   gemv_sym_kernel     g = XX beta        every CU streams rows of XX (HBM/L2-bound at p = 4096: 134 MB per pass)
+//   path_update_kernel  u = d beta - g + XY; beta = T(u); stop rule; lambda / penalty bookkeeping; outputs
+// The host only enqueues batches of these pairs and polls one "done" word per batch: convergence decisions,
+// warm starts and result packing never leave the device.  After "done" the remaining launches of a batch
+// return immediately.
+// The eigenvalue step is the same Lanczos recurrence as in the small engine with the GEMV as its own launch;
+// the (tiny) tridiagonal eigenproblem is bisected on the host every 32 steps, which is also the convergence test.
 #include "common.hpp"
+#include "penalty_ops.hpp"
+
+#include <cmath>
+#include <vector>
 
 namespace oemgpu {
 
-size_t path_large_work_doubles(int p, int nsteps) { (void)nsteps; return (size_t)p * 8 + 1024; }
+namespace {
 
+struct LState {
+    int pp, i, it, done;
+    int pending_loss;        // index k*nl+i whose loss is due from the next g = XX beta, or -1
+    int reset_next;          // the next update starts a penalty from beta = 0
+    int finish_after_loss;   // all lambdas done; stop once the pending loss is written
+    int pad;
+    double ak, d, theta, lmax;
+};
+static const int STATE_DBL = 16;
+static const int MAXL = 512;       // Lanczos steps kept
+
+// wave-uniform sum of v over the 64 lanes (same DPP scan as the small engine)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dppm(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int rlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int rhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(rhi, rlo);
+}
+__device__ __forceinline__ double wsum(double v)
+{
+    v += dppm<0x111, 0xf>(v); v += dppm<0x112, 0xf>(v); v += dppm<0x114, 0xf>(v); v += dppm<0x118, 0xf>(v);
+    v += dppm<0x142, 0xa>(v); v += dppm<0x143, 0xc>(v);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// deterministic block sum (1024 threads): per-wave DPP sums, then a fixed-order add of the 16 wave sums
+__device__ __forceinline__ double block_sum(double v, double *sh)
+{
+    const int w = threadIdx.x >> 6;
+    const double s = wsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = s;
+    __syncthreads();
+    double t = 0.0;
+    const int nw = blockDim.x >> 6;
+    for (int k = 0; k < nw; ++k) t += sh[k];
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// g = M vec for symmetric column-major M (q x q): row r is the contiguous column r.  One wave per row, the vector
+// held in registers (VPL doubles per lane), each row read with 1 KiB-coalesced dwordx4 loads.
+// ------------------------------------------------------------------------------------------------
+template <int VPL, bool ALIGNED>
+__global__ __launch_bounds__(256) void gemv_sym_kernel(const double *__restrict__ M, int q, const double *__restrict__ vec,
+                                                        double *__restrict__ out, const int *__restrict__ done)
+{
+    if (done && *done) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
+    double v[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL / 2; ++j) {
+        const int c = 2 * lane + 128 * j;
+        v[2 * j] = c < q ? vec[c] : 0.0;
+        v[2 * j + 1] = c + 1 < q ? vec[c + 1] : 0.0;
+    }
+    for (int r = wave; r < q; r += nwave) {
+        const double *row = M + (size_t)r * q;
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < VPL / 2; ++j) {
+            const int c = 2 * lane + 128 * j;
+            double m0 = 0.0, m1 = 0.0;
+            if (ALIGNED) {
+                if (c + 1 < q) { const v2d t = *reinterpret_cast<const v2d *>(row + c); m0 = t.x; m1 = t.y; }
+                else if (c < q) m0 = row[c];
+            } else {
+                if (c < q) m0 = row[c];
+                if (c + 1 < q) m1 = row[c + 1];
+            }
+            a0 = fma(m0, v[2 * j], a0);
+            a1 = fma(m1, v[2 * j + 1], a1);
+        }
+        const double s = wsum(a0 + a1);
+        if (lane == 0) out[r] = s;
+    }
+}
+
+// generic fallback (q > 4096): vector re-read from L1/L2
+__global__ __launch_bounds__(256) void gemv_sym_generic_kernel(const double *__restrict__ M, int q, const double *__restrict__ vec,
+                                                                double *__restrict__ out, const int *__restrict__ done)
+{
+    if (done && *done) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
+    for (int r = wave; r < q; r += nwave) {
+        const double *row = M + (size_t)r * q;
+        double a = 0.0;
+        for (int c = lane; c < q; c += 64) a = fma(row[c], vec[c], a);
+        const double s = wsum(a);
+        if (lane == 0) out[r] = s;
+    }
+}
+
+int launch_gemv(hipStream_t s, const double *M, int q, const double *vec, double *out, const int *done, int num_cu)
+{
+    int blocks = (q + 3) / 4;
+    if (blocks > num_cu * 4) blocks = num_cu * 4;
+    const bool al = (q % 2 == 0) && (((uintptr_t)M & 15) == 0);
+#define OEM_GEMV(V)                                                                                              \
+    do {                                                                                                         \
+        if (al) hipLaunchKernelGGL((gemv_sym_kernel<V, true>), dim3(blocks), dim3(256), 0, s, M, q, vec, out, done);   \
+        else hipLaunchKernelGGL((gemv_sym_kernel<V, false>), dim3(blocks), dim3(256), 0, s, M, q, vec, out, done);     \
+    } while (0)
+    if (q <= 512) OEM_GEMV(8);
+    else if (q <= 1024) OEM_GEMV(16);
+    else if (q <= 2048) OEM_GEMV(32);
+    else if (q <= 4096) OEM_GEMV(64);
+    else hipLaunchKernelGGL(gemv_sym_generic_kernel, dim3(blocks), dim3(256), 0, s, M, q, vec, out, done);
+#undef OEM_GEMV
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ Lanczos
+__global__ __launch_bounds__(1024) void lanczos_init_kernel(int q, double *__restrict__ v, double *__restrict__ vp)
+{
+    __shared__ double sh[16];
+    double nn = 0.0;
+    for (int j = threadIdx.x; j < q; j += blockDim.x) {
+        const unsigned h = (unsigned)j * 2654435761u + 12345u;
+        const double x = (double)(h >> 8) * (1.0 / 16777216.0) - 0.5;
+        v[j] = x; vp[j] = 0.0;
+        nn = fma(x, x, nn);
+    }
+    const double inv = 1.0 / sqrt(block_sum(nn, sh));
+    for (int j = threadIdx.x; j < q; j += blockDim.x) v[j] *= inv;
+}
+
+// w = M v is in `w`.  alpha_j = v.w ; w -= alpha v + beta_{j-1} v_prev ; beta_j = |w| ; v_prev = v ; v = w / beta_j
+__global__ __launch_bounds__(1024) void lanczos_update_kernel(int q, int j, double *__restrict__ v, double *__restrict__ vp,
+                                                               double *__restrict__ w, double *__restrict__ T)
+{
+    __shared__ double sh[16];
+    double *al = T, *be = T + MAXL;
+    if (j > 0 && !(be[j - 1] > 1e-13 * fabs(al[j - 1]))) {          // invariant subspace already reached
+        if (threadIdx.x == 0) { al[j] = al[j - 1]; be[j] = 0.0; }
+        return;
+    }
+    const double bprev = j > 0 ? be[j - 1] : 0.0;
+    double a = 0.0;
+    for (int k = threadIdx.x; k < q; k += blockDim.x) a = fma(v[k], w[k], a);
+    a = block_sum(a, sh);
+    double bb = 0.0;
+    for (int k = threadIdx.x; k < q; k += blockDim.x) {
+        const double t = (w[k] - a * v[k]) - bprev * vp[k];
+        w[k] = t;
+        bb = fma(t, t, bb);
+    }
+    bb = sqrt(block_sum(bb, sh));
+    if (threadIdx.x == 0) { al[j] = a; be[j] = bb; }
+    if (bb > 1e-13 * fabs(a)) {
+        const double ib = 1.0 / bb;
+        for (int k = threadIdx.x; k < q; k += blockDim.x) { vp[k] = v[k]; v[k] = w[k] * ib; }
+    }
+}
+
+// largest eigenvalue of the tridiagonal (host): bisection on the Sturm count; returns an upper bracket end
+double tridiag_max_host(const double *al, const double *be, int m)
+{
+    if (m == 1) return al[0];
+    double lo = -1e300, hi = -1e300;
+    for (int j = 0; j < m; ++j) {
+        const double bl = j > 0 ? std::fabs(be[j - 1]) : 0.0, br = j < m - 1 ? std::fabs(be[j]) : 0.0;
+        if (al[j] > lo) lo = al[j];
+        if (al[j] + bl + br > hi) hi = al[j] + bl + br;
+    }
+    for (int it = 0; it < 200 && hi - lo > 4e-16 * std::fabs(hi); ++it) {
+        const double th = 0.5 * (lo + hi);
+        if (th <= lo || th >= hi) break;
+        double qv = al[0] - th;
+        int neg = qv < 0.0;
+        for (int k = 1; k < m; ++k) {
+            if (qv == 0.0) qv = 1e-300;
+            qv = (al[k] - th) - be[k - 1] * be[k - 1] / qv;
+            neg += qv < 0.0;
+        }
+        if (neg < m) lo = th; else hi = th;
+    }
+    return hi;
+}
+
+// ------------------------------------------------------------------------------------------------ path
+__global__ __launch_bounds__(1024) void path_init_kernel(PathArgs A, LState *st, double *__restrict__ beta, double d, double theta)
+{
+    __shared__ double sh[16];
+    double m = 0.0;
+    for (int j = threadIdx.x; j < A.p; j += blockDim.x) { beta[j] = 0.0; m = fmax(m, fabs(A.xy[j])); }
+    // block max through the sum helper's layout: per-wave max, then 16-way
+    for (int s = 1; s < 64; s <<= 1) m = fmax(m, __shfl_xor(m, s, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double mm = 0.0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) mm = fmax(mm, sh[k]);
+        st->pp = 0; st->i = 0; st->it = 0; st->done = (A.npen == 0);
+        st->pending_loss = -1; st->reset_next = 1; st->finish_after_loss = 0; st->pad = 0;
+        st->ak = 1.0; st->d = d; st->theta = theta;
+        st->lmax = mm * (A.yscale ? A.stats[1] : 1.0);
+        A.d_out[0] = d; A.d_out[1] = theta; A.d_out[2] = 0.0; A.d_out[3] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void path_update_kernel(PathArgs A, LState *st, double *__restrict__ beta,
+                                                            const double *__restrict__ g)
+{
+    extern __shared__ __attribute__((aligned(16))) double dyn[];     // U[q] (group operand), F[ngroups]
+    __shared__ double sh[16];
+    if (st->done) return;
+    const int q = A.p, nl = A.nl, tid = threadIdx.x, nt = blockDim.x;
+    const int pp = st->pp, i = st->i;
+    int it = st->it;
+    const double d = st->d;
+    const double scaley = A.yscale ? A.stats[1] : 1.0;
+    const double yy = A.stats[2], nobs = A.stats[3];
+    double *U = dyn, *F = dyn + q;
+
+    // ---- loss of the lambda that converged in the previous update: g is XX beta_final (Gram identity, see path_small)
+    const int pl = st->pending_loss;
+    if (pl >= 0) {
+        double t = 0.0;
+        for (int j = tid; j < q; j += nt) t += beta[j] * (g[j] - 2.0 * A.xy[j]);
+        t = block_sum(t, sh);
+        if (tid == 0) A.loss[pl] = yy + nobs * t;
+    }
+    if (st->finish_after_loss) {
+        __syncthreads();
+        if (tid == 0) { st->pending_loss = -1; st->done = 1; }
+        return;
+    }
+    const bool reset = st->reset_next != 0;
+    const int pen = A.penalty[pp];
+    const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
+    const bool isnet = pen_is_net(pen);
+
+    // ---- lambda grid (ref src/oem_dense.cpp:175-227)
+    const double llo = log(st->lmax), lhi = log(A.lambda_min_ratio * st->lmax);
+    const double lstep = nl > 1 ? (lhi - llo) / (double)(nl - 1) : 0.0;
+    const bool lflip = fabs(lhi) < fabs(llo);
+    auto lambda_at = [&](int k) -> double {
+        if (A.user_lambda) return A.lambda_user[(size_t)pp * nl + k];
+        double lv;
+        if (nl == 1) lv = lhi;
+        else if (lflip) lv = (k == 0) ? llo : lhi - (double)(nl - 1 - k) * lstep;
+        else lv = (k == nl - 1) ? lhi : llo + (double)k * lstep;
+        const double l = exp(lv);
+        return isnet ? l / A.alpha : l;
+    };
+    if (reset)
+        for (int k = tid; k < nl; k += nt) A.lambda_out[(size_t)pp * nl + k] = lambda_at(k);
+    const double lam = lambda_at(i);
+    const PenK K = pen_consts(pen, lam / scaley, d, A.alpha, A.gamma, A.tau);
+    const double rD = 1.0 / K.D, gammad = K.gamma * K.D, dmg = K.D - 1.0 / K.gamma, rdmg = 1.0 / dmg;
+    const double gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0, rdsc = 1.0 / dsc;
+    const bool grp = K.kind >= K_GRP;
+    double ak = reset ? 1.0 : st->ak;
+
+    // ---- u and (for group operators) the group factors
+    if (grp) {
+        for (int j = tid; j < q; j += nt) {
+            const double bo = reset ? 0.0 : beta[j];
+            const double u = (d * bo - (reset ? 0.0 : g[j])) + A.xy[j];
+            U[j] = (K.kind == K_SGL) ? soft1(u, A.pf[j] * K.L1, 1.0) : u;
+        }
+        __syncthreads();
+        for (int gi = tid; gi < A.ngroups; gi += nt) {
+            double f = 1.0;
+            if (!A.gzero[gi]) {
+                double s = 0.0;
+                for (int m = A.gstart[gi]; m < A.gstart[gi + 1]; ++m) { const double x = U[A.gidx[m]]; s += x * x; }
+                s = sqrt(s);
+                const double pen_g = K.L * A.gw[gi];
+                if (K.kind == K_GRP || K.kind == K_SGL) { const double t = 1.0 - pen_g / s; f = (0.0 < t) ? t : 0.0; }
+                else if (K.kind == K_GRP_MCP) f = mcp_norm(s, pen_g, K.D, K.gamma);
+                else f = scad_norm(s, pen_g, K.D, K.gamma);
+            }
+            F[gi] = f;
+        }
+        __syncthreads();
+    }
+    // ---- beta = T(u), acceleration, stop rule.  Each thread owns its coordinates: it reads the old value, then writes.
+    bool bad = false;
+    double adp = 0.0;
+    const double akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak)), ratio = (ak - 1.0) / akn;
+    for (int j = tid; j < q; j += nt) {
+        const double bo = reset ? 0.0 : beta[j];
+        double bn;
+        if (grp) {
+            const int gi = A.gid[j];
+            const double f = gi >= 0 ? F[gi] : 0.0;
+            bn = (f != 0.0) ? U[j] * f / K.D : 0.0;
+        } else {
+            const double u = (d * bo - (reset ? 0.0 : g[j])) + A.xy[j];
+            const double tp = A.pf[j] * K.L;
+            if (K.kind == K_SOFT) bn = cdiv(shrink(u, tp), K.D, rD);
+            else if (K.kind == K_MCP) {
+                const bool big = fabs(u) > gammad * tp;
+                bn = cdiv(big ? u : shrink(u, tp), big ? K.D : dmg, big ? rD : rdmg);
+            } else if (K.kind == K_SCAD) {
+                const double au = fabs(u);
+                const bool big = au > gammad * tp, mid = !big && au > (K.D + 1.0) * tp;
+                const double num = big ? u : (mid ? shrink(gm1 * u, K.gamma * tp) : shrink(u, tp));
+                bn = cdiv(num, mid ? dsc : K.D, mid ? rdsc : rD);
+            } else bn = cdiv(u, d, 1.0 / d);
+        }
+        if (A.accelerate) {                                   // ref src/oem_dense.h:633-651
+            const double upd = bn, diff = upd - bo;
+            bn = upd + ratio * diff;
+            adp += (bn - upd) * diff;
+        }
+        const double c = fabs(bn), qo = fabs(bo);
+        const bool cn = c > 1e-13, qn = qo > 1e-13;
+        bad |= (cn != qn);
+        bad |= (cn && qn && fabs(bn - bo) > A.tol * qo);
+        beta[j] = bn;
+    }
+    if (A.accelerate) {
+        adp = block_sum(adp, sh);
+        ak = (adp > 0.0) ? 1.0 : akn;
+    }
+    const int anybad = __syncthreads_or(bad ? 1 : 0);
+    ++it;
+    const bool conv = !anybad;
+    if (conv || it >= A.maxit) {
+        const size_t ki = (size_t)pp * nl + i;
+        for (int j = tid; j < q; j += nt) {
+            double b = beta[j];
+            if (A.sinv) { b *= A.sinv[j]; beta[j] = b; }            // quirk Q5: the member itself is rescaled
+            A.beta[ki * q + j] = b;
+        }
+        if (tid == 0) {
+            A.niter[ki] = conv ? it : A.maxit + 1;                  // ref src/oem_base.h:94-109
+            if (!A.compute_loss) A.loss[ki] = 1e99;
+            st->pending_loss = A.compute_loss ? (int)ki : -1;
+            st->it = 0; st->ak = ak;
+            if (i + 1 < nlam) { st->i = i + 1; st->reset_next = 0; }
+            else if (pp + 1 < A.npen) { st->pp = pp + 1; st->i = 0; st->reset_next = 1; }
+            else {
+                st->reset_next = 0;
+                if (A.compute_loss) st->finish_after_loss = 1; else st->done = 1;
+            }
+        }
+    } else if (tid == 0) { st->it = it; st->ak = ak; st->reset_next = 0; st->pending_loss = -1; }
+}
+
+}  // namespace
+
+size_t path_large_work_doubles(int p, int nsteps)
+{
+    (void)nsteps;
+    return (size_t)STATE_DBL + 5 * (size_t)(p + 8) + 2 * MAXL + 64;
+}
+
+// host_scratch: pinned host memory (>= 8 KB)
 int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
 {
-    (void)s; (void)a; (void)host_scratch;
-    set_error("p = %d > %d: the large-p engine is not built yet", a.p, SMALL_P_MAX);
-    return OEMGPU_ERR_UNSUPPORTED;
+    const int q = a.p;
+    int dev = 0, num_cu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    LState *st = reinterpret_cast<LState *>(a.work);
+    static_assert(sizeof(LState) <= STATE_DBL * sizeof(double), "state block too small");
+    double *beta = a.work + STATE_DBL, *g = beta + (q + 8), *v = g + (q + 8), *vp = v + (q + 8), *w = vp + (q + 8);
+    double *T = w + (q + 8);
+    OEM_HIP(hipMemsetAsync(a.work, 0, sizeof(double) * path_large_work_doubles(q, 0), s));
+
+    // ---- eigenvalue step: Lanczos, checked every 32 steps on the host
+    hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, s, q, v, vp);
+    const int mmax = q < MAXL ? q : MAXL;
+    double theta = 0.0, theta_prev = -1.0;
+    double *hT = host_scratch;
+    int m = 0;
+    while (m < mmax) {
+        const int chunk = (mmax - m) < 32 ? (mmax - m) : 32;
+        for (int k = 0; k < chunk; ++k, ++m) {
+            int rc = launch_gemv(s, a.xx, q, v, w, nullptr, num_cu);
+            if (rc) return rc;
+            hipLaunchKernelGGL(lanczos_update_kernel, dim3(1), dim3(1024), 0, s, q, m, v, vp, w, T);
+        }
+        OEM_HIP(hipGetLastError());
+        OEM_HIP(hipMemcpyAsync(hT, T, sizeof(double) * 2 * MAXL, hipMemcpyDeviceToHost, s));
+        OEM_HIP(hipStreamSynchronize(s));
+        int mm = m;
+        for (int k = 0; k < m; ++k)
+            if (!(hT[MAXL + k] > 1e-13 * std::fabs(hT[k]))) { mm = k + 1; break; }     // breakdown: T is exact
+        theta = tridiag_max_host(hT, hT + MAXL, mm);
+        if (mm < m) break;
+        if (theta_prev > 0 && std::fabs(theta - theta_prev) <= 1e-12 * std::fabs(theta)) break;
+        theta_prev = theta;
+    }
+    const double d = theta * 1.005;                     // ref src/oem_dense.h:498
+
+    hipLaunchKernelGGL(path_init_kernel, dim3(1), dim3(1024), 0, s, a, st, beta, d, theta);
+    OEM_HIP(hipGetLastError());
+    if (a.npen == 0) return 0;
+
+    // ---- path: batches of (gemv, update) pairs; poll the done word once per batch
+    size_t sh = sizeof(double) * (size_t)(q + (a.ngroups > 0 ? a.ngroups : 0) + 8);
+    if (sh > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&path_update_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %zu): %s", sh, hipGetErrorString(e)); return OEMGPU_ERR_HIP; }
+    }
+    const long long max_updates = (long long)a.npen * a.nl * ((long long)a.maxit + 2) + 8;
+    long long launched = 0;
+    int *hdone = reinterpret_cast<int *>(host_scratch);
+    const int BATCH = 64;
+    for (;;) {
+        for (int k = 0; k < BATCH; ++k) {
+            int rc = launch_gemv(s, a.xx, q, beta, g, &st->done, num_cu);
+            if (rc) return rc;
+            hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), sh, s, a, st, beta, g);
+        }
+        OEM_HIP(hipGetLastError());
+        launched += BATCH;
+        OEM_HIP(hipMemcpyAsync(hdone, &st->done, sizeof(int), hipMemcpyDeviceToHost, s));
+        OEM_HIP(hipStreamSynchronize(s));
+        if (*hdone) break;
+        if (launched > max_updates) { set_error("large-p engine did not finish within %lld updates", max_updates); return OEMGPU_ERR_INTERNAL; }
+    }
+    return 0;
 }
 
 }  // namespace oemgpu

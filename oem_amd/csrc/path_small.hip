@@ -21,114 +21,74 @@
 // re-orthogonalisation: the top Ritz value still converges to lambda_max, Paige), followed by a 64-way
 // multisection of the tridiagonal Sturm count, all redundantly per wave.
 #include "common.hpp"
+#include "penalty_ops.hpp"
 
 namespace oemgpu {
 
 namespace {
 
+// -DOEM_PATH_DIAG: a diagnostic build that splits the round into stamped segments (cycles summed per wave 0).
+// Its fences forbid overlaps the real kernel has: read the SHARES, never the total.
+#ifdef OEM_PATH_DIAG
+__device__ unsigned long long g_diag[8];
+#define OEM_STAMP(slot)                                                                    \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        unsigned long long t__;                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        diag_acc[slot] += t__ - diag_last;                                                 \
+        diag_last = t__;                                                                   \
+    } while (0)
+#define OEM_DIAG_DECL unsigned long long diag_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, diag_last = __builtin_amdgcn_s_memtime();
+#define OEM_DIAG_ARGS , unsigned long long (&diag_acc)[8], unsigned long long &diag_last
+#define OEM_DIAG_PASS , diag_acc, diag_last
+#else
+#define OEM_STAMP(slot) do { } while (0)
+#define OEM_DIAG_DECL
+#define OEM_DIAG_ARGS
+#define OEM_DIAG_PASS
+#endif
+
+// Wave-wide reductions on the DPP network (no LDS round trips: __shfl_xor lowers to ds_bpermute, ~100 cycles per
+// step on this serial path).  Classic GFX9 scan: row_shr 1/2/4/8 inside each 16-lane row, then row_bcast15 and
+// row_bcast31 across rows; lane 63 holds the total, returned wave-uniform through an SGPR.  Every wave runs
+// the same instructions on the same data, so the result is bit-identical across waves.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double v, double identity)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int ilo = __double2loint(identity), ihi = __double2hiint(identity);
+    const int rlo = __builtin_amdgcn_update_dpp(ilo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int rhi = __builtin_amdgcn_update_dpp(ihi, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(rhi, rlo);
+}
+__device__ __forceinline__ double wave_uniform_lane63(double v)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);   // x+y == y+x: every lane ends with the same bits
-    return v;
+    v += dpp_mov<0x111, 0xf>(v, 0.0);      // row_shr:1
+    v += dpp_mov<0x112, 0xf>(v, 0.0);      // row_shr:2
+    v += dpp_mov<0x114, 0xf>(v, 0.0);      // row_shr:4
+    v += dpp_mov<0x118, 0xf>(v, 0.0);      // row_shr:8
+    v += dpp_mov<0x142, 0xa>(v, 0.0);      // row_bcast:15 -> rows 1, 3
+    v += dpp_mov<0x143, 0xc>(v, 0.0);      // row_bcast:31 -> rows 2, 3
+    return wave_uniform_lane63(v);
 }
 __device__ __forceinline__ double wave_max(double v)
 {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m, 64));
-    return v;
+    const double ninf = -__builtin_inf();
+    v = fmax(v, dpp_mov<0x111, 0xf>(v, ninf));
+    v = fmax(v, dpp_mov<0x112, 0xf>(v, ninf));
+    v = fmax(v, dpp_mov<0x114, 0xf>(v, ninf));
+    v = fmax(v, dpp_mov<0x118, 0xf>(v, ninf));
+    v = fmax(v, dpp_mov<0x142, 0xa>(v, ninf));
+    v = fmax(v, dpp_mov<0x143, 0xc>(v, ninf));
+    return wave_uniform_lane63(v);
 }
-
-// ---- element-wise operators, ref src/oem_dense.h:76-149 -------------------------------------------------
-__device__ __forceinline__ double soft1(double u, double tp, double d)
-{
-    if (u > tp) return (u - tp) / d;
-    if (u < -tp) return (u + tp) / d;
-    return 0.0;
-}
-__device__ __forceinline__ double mcp1(double u, double tp, double d, double gamma)
-{
-    const double gammad = gamma * d, dmg = d - 1.0 / gamma;
-    if (fabs(u) > gammad * tp) return u / d;
-    if (u > tp) return (u - tp) / dmg;
-    if (u < -tp) return (u + tp) / dmg;
-    return 0.0;
-}
-__device__ __forceinline__ double scad1(double u, double tp, double d, double gamma)
-{
-    const double gammad = gamma * d, gm1d = (gamma - 1.0) * d;
-    if (fabs(u) > gammad * tp) return u / d;
-    if (fabs(u) > (d + 1.0) * tp) {
-        const double gp = (gamma - 1.0) * u, gq = gamma * tp;
-        if (gp > gq) return (gp - gq) / (gm1d - 1.0);
-        if (gp < -gq) return (gp + gq) / (gm1d - 1.0);
-        return 0.0;
-    }
-    if (u > tp) return (u - tp) / d;
-    if (u < -tp) return (u + tp) / d;
-    return 0.0;
-}
-// ---- group factors, ref src/oem_dense.h:151-191, 277-315 --------------------------------------------------
-__device__ __forceinline__ double scad_norm(double b, double pen, double d, double gamma)
-{
-    const double gammad = gamma * d, gm1d = (gamma - 1.0) * d;
-    if (fabs(b) > gammad * pen) return 1.0;
-    if (fabs(b) > (d + 1.0) * pen) {
-        const double gp = gamma - 1.0, gq = gamma * pen / b;
-        if (gp > gq) return d * (gp - gq) / (gm1d - 1.0);
-        if (gp < -gq) return d * (gp + gq) / (gm1d - 1.0);
-        return 0.0;
-    }
-    if (b > pen) return 1.0 - pen / b;
-    if (b < -pen) return 1.0 + pen / b;
-    return 0.0;
-}
-__device__ __forceinline__ double mcp_norm(double b, double pen, double d, double gamma)
-{
-    const double gammad = gamma * d, dmg = d - 1.0 / gamma;
-    if (fabs(b) > gammad * pen) return 1.0;
-    if (b > pen) return d * (1.0 - pen / b) / dmg;
-    if (b < -pen) return d * (1.0 + pen / b) / dmg;
-    return 0.0;
-}
-
-enum { K_SOFT = 0, K_MCP = 1, K_SCAD = 2, K_OLS = 3, K_GRP = 4, K_GRP_MCP = 5, K_GRP_SCAD = 6, K_SGL = 7 };
-
-// per-lambda constants of next_beta's dispatch, ref src/oem_dense.h:527-628
-struct PenK {
-    int kind;
-    double L;      // lambda' multiplying penalty_factor / group weight
-    double D;      // denominator
-    double L1;     // sparse.grp.lasso: tau * lambda (soft threshold, denominator 1)
-    double gamma;
-};
-__device__ __forceinline__ PenK pen_consts(int pen, double lam, double d, double alpha, double gamma, double tau)
-{
-    PenK k; k.gamma = gamma; k.L1 = 0.0; k.L = lam; k.D = d; k.kind = K_SOFT;
-    const double Ln = lam * alpha, Dn = d + (1.0 - alpha) * lam;
-    switch (pen) {
-    case OEMGPU_LASSO: k.kind = K_SOFT; break;
-    case OEMGPU_OLS: k.kind = K_OLS; break;
-    case OEMGPU_ELASTIC_NET: k.kind = K_SOFT; k.L = Ln; k.D = Dn; break;
-    case OEMGPU_SCAD: k.kind = K_SCAD; break;
-    case OEMGPU_SCAD_NET:
-        k.kind = K_SCAD; k.L = Ln; k.D = Dn;
-        if (alpha == 0.0) { k.L = 0.0; k.D = d + lam; }
-        break;
-    case OEMGPU_MCP: k.kind = K_MCP; break;
-    case OEMGPU_MCP_NET: k.kind = K_MCP; k.L = Ln; k.D = Dn; break;
-    case OEMGPU_GRP_LASSO: k.kind = K_GRP; break;
-    case OEMGPU_GRP_LASSO_NET: k.kind = K_GRP; k.L = Ln; k.D = Dn; break;
-    case OEMGPU_GRP_MCP: k.kind = K_GRP_MCP; break;
-    case OEMGPU_GRP_SCAD: k.kind = K_GRP_SCAD; break;
-    case OEMGPU_GRP_MCP_NET: k.kind = K_GRP_MCP; k.L = Ln; k.D = Dn; break;
-    case OEMGPU_GRP_SCAD_NET: k.kind = K_GRP_SCAD; k.L = Ln; k.D = Dn; break;
-    case OEMGPU_SPARSE_GRP_LASSO: k.kind = K_SGL; k.L = (1.0 - tau) * lam; k.L1 = tau * lam; break;
-    default: break;
-    }
-    return k;
-}
-
 // largest eigenvalue of the symmetric tridiagonal (al[0..m), be[0..m-1)) by 64-way multisection of the Sturm
 // count; every lane of the wave returns the same value (an upper bracket end, so d never undershoots).
 __device__ double tridiag_max(const double *al, const double *be, int m, int lane)
@@ -179,36 +139,149 @@ template <int R, int NW, int CW> struct Cfg {
 // one GEMV round: out = M vec, M = the register-resident matrix.  One workgroup barrier.
 template <int R, int NW, int CW>
 __device__ __forceinline__ void gemv_round(const double (&a)[R][CW], const double (&vec)[R], double (&out)[R],
-                                           double *P, double *Uw, int w, int lane, int &buf)
+                                           double *P, double *Uw, int w, int lane, int &buf OEM_DIAG_ARGS)
 {
     constexpr int PR = 64 * R;
+    OEM_STAMP(0);                       // everything since the previous round's partial sums (threshold, stop rule)
 #pragma unroll
     for (int r = 0; r < R; ++r) Uw[lane + 64 * r] = vec[r];
+    // all CW/2 broadcast reads are issued before the first FMA: one LDS latency per round instead of CW/2
+    const v2d *bc = reinterpret_cast<const v2d *>(Uw + w * CW);     // same wave: DS ops execute in order
+    v2d b[CW / 2];
+#pragma unroll
+    for (int k = 0; k < CW / 2; ++k) b[k] = bc[k];                   // uniform address: LDS broadcast
     double acc0[R], acc1[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; }
-    const v2d *bc = reinterpret_cast<const v2d *>(Uw + w * CW);     // same wave: DS ops execute in order
 #pragma unroll
     for (int k = 0; k < CW; k += 2) {
-        const v2d b = bc[k >> 1];                                    // uniform address: LDS broadcast
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            acc0[r] = fma(a[r][k], b.x, acc0[r]);
-            acc1[r] = fma(a[r][k + 1], b.y, acc1[r]);
+            acc0[r] = fma(a[r][k], b[k >> 1].x, acc0[r]);
+            acc1[r] = fma(a[r][k + 1], b[k >> 1].y, acc1[r]);
         }
     }
+    OEM_STAMP(1);                       // strip write, broadcast reads, FMAs
     double *Pb = P + buf * NW * PR;
 #pragma unroll
     for (int r = 0; r < R; ++r) Pb[w * PR + lane + 64 * r] = acc0[r] + acc1[r];
     __syncthreads();
+    OEM_STAMP(2);                       // partial write + workgroup barrier
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        double s = Pb[lane + 64 * r];
+        double t[NW];
 #pragma unroll
-        for (int ww = 1; ww < NW; ++ww) s += Pb[ww * PR + lane + 64 * r];
-        out[r] = s;
+        for (int ww = 0; ww < NW; ++ww) t[ww] = Pb[ww * PR + lane + 64 * r];
+#pragma unroll
+        for (int h = 1; h < NW; h <<= 1)                       // fixed pairwise tree: short dependent chain
+#pragma unroll
+            for (int ww = 0; ww + h < NW; ww += 2 * h) t[ww] += t[ww + h];
+        out[r] = t[0];
     }
+    OEM_STAMP(3);                       // partial reads + adds
     buf ^= 1;
+}
+
+// The OEM iteration for one lambda (ref src/oem_base.h:90-110), specialised per operator so that the serial loop
+// carries only the arithmetic of the penalty in use.  KIND == K_GRP covers every group penalty (K.kind selects).
+template <int R, int NW, int CW, int KIND>
+__device__ __forceinline__ void iterate(const PathArgs &A, const PenK &K, double d, const double (&a)[R][CW],
+                                        const double (&xy)[R], const double (&pf)[R], const int (&gid)[R],
+                                        double (&beta)[R], double (&bold)[R], double (&ab)[R], double &ak, int &it,
+                                        int &conv, double *P, double *Uw, double *Fw, const int *gstart,
+                                        const int *gidx, const int *gzero, int ng, int w, int lane, int &buf OEM_DIAG_ARGS)
+{
+    double tp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) tp[r] = pf[r] * K.L;
+    const double D = K.D, rD = 1.0 / K.D;
+    const double gammad = K.gamma * D;
+    const double dmg = D - 1.0 / K.gamma, rdmg = 1.0 / dmg;                  // mcp
+    const double gm1 = K.gamma - 1.0, dsc = gm1 * D - 1.0, rdsc = 1.0 / dsc;  // scad
+    const double tol = A.tol;
+    double u[R];
+    for (;;) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { bold[r] = beta[r]; u[r] = ab[r] + xy[r]; }
+        if (KIND == K_SOFT) {                                   // ref src/oem_dense.h:76-92
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                beta[r] = cdiv(shrink(u[r], tp[r]), D, rD);
+            }
+        } else if (KIND == K_MCP) {                             // ref src/oem_dense.h:94-117
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool big = fabs(u[r]) > gammad * tp[r];
+                const double num = big ? u[r] : shrink(u[r], tp[r]);
+                beta[r] = cdiv(num, big ? D : dmg, big ? rD : rdmg);
+            }
+        } else if (KIND == K_SCAD) {                            // ref src/oem_dense.h:119-149
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double au = fabs(u[r]);
+                const bool big = au > gammad * tp[r], mid = !big && au > (D + 1.0) * tp[r];
+                const double gp = gm1 * u[r], gq = K.gamma * tp[r];
+                const double nmid = shrink(gp, gq);
+                const double nsoft = shrink(u[r], tp[r]);
+                const double num = big ? u[r] : (mid ? nmid : nsoft);
+                beta[r] = cdiv(num, mid ? dsc : D, mid ? rdsc : rD);
+            }
+        } else if (KIND == K_OLS) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) beta[r] = cdiv(u[r], d, 1.0 / d);
+        } else {                                                // group operators, ref src/oem_dense.h:193-315
+            double vv[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                vv[r] = (K.kind == K_SGL) ? soft1(u[r], pf[r] * K.L1, 1.0) : u[r];
+                Uw[lane + 64 * r] = vv[r];
+            }
+            for (int g = lane; g < ng; g += 64) {
+                double f = 1.0;
+                if (!gzero[g]) {
+                    double s = 0.0;
+                    for (int m = gstart[g]; m < gstart[g + 1]; ++m) { const double x = Uw[gidx[m]]; s += x * x; }
+                    s = sqrt(s);
+                    const double pen_g = K.L * A.gw[g];
+                    if (K.kind == K_GRP || K.kind == K_SGL) { const double t = 1.0 - pen_g / s; f = (0.0 < t) ? t : 0.0; }
+                    else if (K.kind == K_GRP_MCP) f = mcp_norm(s, pen_g, K.D, K.gamma);
+                    else f = scad_norm(s, pen_g, K.D, K.gamma);
+                }
+                Fw[g] = f;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double f = gid[r] >= 0 ? Fw[gid[r]] : 0.0;
+                beta[r] = (f != 0.0) ? vv[r] * f / K.D : 0.0;
+            }
+        }
+        if (A.accelerate) {                                        // ref src/oem_dense.h:633-651
+            const double akp = ak;
+            ak = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak));
+            const double ratio = (akp - 1.0) / ak;
+            double adp = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double upd = beta[r], diff = upd - bold[r];
+                beta[r] = upd + ratio * diff;
+                adp += (beta[r] - upd) * diff;
+            }
+            if (wave_sum(adp) > 0.0) ak = 1.0;
+        }
+        ++it;
+        // stopRule, ref src/utils.cpp:537-549; |(cur - prev) / prev| > tol written as |cur - prev| > tol |prev|
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double c = fabs(beta[r]), q = fabs(bold[r]);
+            const bool cn = c > 1e-13, qn = q > 1e-13;
+            bad |= (cn != qn);
+            bad |= (cn && qn && fabs(beta[r] - bold[r]) > tol * q);
+        }
+        conv = (__ballot(bad) == 0ull);
+        if (conv || it >= A.maxit) break;
+        gemv_round<R, NW, CW>(a, beta, ab, P, Uw, w, lane, buf OEM_DIAG_PASS);
+    }
 }
 
 template <int R, int NW, int CW>
@@ -219,6 +292,9 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int p = A.p;
+    // whole-kernel clock reading (shader cycles and 100 MHz ticks), stored beside d: a diagnostic of the clock the
+    // chip holds while a single CU runs the serial chain.  Not used by any result.
+    const unsigned long long t_cyc0 = __builtin_amdgcn_s_memtime(), t_rt0 = __builtin_amdgcn_s_memrealtime();
     double *P = lds + C::OFF_P;
     double *Uw = lds + C::OFF_U + w * PR;
     double *Fw = lds + C::OFF_F + w * PR;
@@ -256,6 +332,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
     }
     __syncthreads();
     int buf = 0;
+    OEM_DIAG_DECL
 
     // ---- eigenvalue step: m-step Lanczos on XX
     double v[R], vp[R], wv[R];
@@ -278,7 +355,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
     int nst = 0;
     double bprev = 0.0;
     for (int j = 0; j < msteps; ++j) {
-        gemv_round<R, NW, CW>(a, v, wv, P, Uw, w, lane, buf);
+        gemv_round<R, NW, CW>(a, v, wv, P, Uw, w, lane, buf OEM_DIAG_PASS);
         double al = 0.0;
 #pragma unroll
         for (int r = 0; r < R; ++r) al = fma(v[r], wv[r], al);
@@ -325,7 +402,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
     const double lstep = nl > 1 ? (lhi - llo) / (double)(nl - 1) : 0.0;
     const bool lflip = fabs(lhi) < fabs(llo);
 
-    double beta[R], bold[R], ab[R], u[R];
+    double beta[R], bold[R], ab[R];
     for (int pp = 0; pp < A.npen; ++pp) {
         const int pen = A.penalty[pp];
         const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
@@ -350,71 +427,12 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
             const double il = lam / scaley;                               // ref src/oem_dense.cpp:241
             const PenK K = pen_consts(pen, il, d, A.alpha, A.gamma, A.tau);
             int it = 0, conv = 0;
-            for (;;) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) { bold[r] = beta[r]; u[r] = ab[r] + xy[r]; }
-                // ---- beta = T(u)
-                if (K.kind <= K_OLS) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const double tp = pf[r] * K.L;
-                        beta[r] = K.kind == K_SOFT ? soft1(u[r], tp, K.D)
-                                : K.kind == K_MCP ? mcp1(u[r], tp, K.D, K.gamma)
-                                : K.kind == K_SCAD ? scad1(u[r], tp, K.D, K.gamma)
-                                                   : u[r] / d;
-                    }
-                } else {
-                    double vv[R];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        vv[r] = (K.kind == K_SGL) ? soft1(u[r], pf[r] * K.L1, 1.0) : u[r];
-                        Uw[lane + 64 * r] = vv[r];
-                    }
-                    for (int g = lane; g < ng; g += 64) {
-                        double f = 1.0;
-                        if (!gzero[g]) {
-                            double s = 0.0;
-                            for (int m = gstart[g]; m < gstart[g + 1]; ++m) { const double x = Uw[gidx[m]]; s += x * x; }
-                            s = sqrt(s);
-                            const double pen_g = K.L * A.gw[g];
-                            if (K.kind == K_GRP || K.kind == K_SGL) { const double t = 1.0 - pen_g / s; f = (0.0 < t) ? t : 0.0; }
-                            else if (K.kind == K_GRP_MCP) f = mcp_norm(s, pen_g, K.D, K.gamma);
-                            else f = scad_norm(s, pen_g, K.D, K.gamma);
-                        }
-                        Fw[g] = f;
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const double f = gid[r] >= 0 ? Fw[gid[r]] : 0.0;
-                        beta[r] = (f != 0.0) ? vv[r] * f / K.D : 0.0;
-                    }
-                }
-                if (A.accelerate) {                                        // ref src/oem_dense.h:633-651
-                    const double akp = ak;
-                    ak = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak));
-                    const double ratio = (akp - 1.0) / ak;
-                    double adp = 0.0;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const double upd = beta[r], diff = upd - bold[r];
-                        beta[r] = upd + ratio * diff;
-                        adp += (beta[r] - upd) * diff;
-                    }
-                    if (wave_sum(adp) > 0.0) ak = 1.0;
-                }
-                ++it;
-                // ---- stopRule, ref src/utils.cpp:537-549
-                bool bad = false;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const double c = fabs(beta[r]), q = fabs(bold[r]);
-                    const bool cn = c > 1e-13, qn = q > 1e-13;
-                    bad |= (cn != qn);
-                    bad |= (cn && qn && fabs((beta[r] - bold[r]) / bold[r]) > A.tol);
-                }
-                conv = (__ballot(bad) == 0ull);
-                if (conv || it >= A.maxit) break;
-                gemv_round<R, NW, CW>(a, beta, ab, P, Uw, w, lane, buf);
+            switch (K.kind) {
+            case K_SOFT: iterate<R, NW, CW, K_SOFT>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf OEM_DIAG_PASS); break;
+            case K_MCP: iterate<R, NW, CW, K_MCP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf OEM_DIAG_PASS); break;
+            case K_SCAD: iterate<R, NW, CW, K_SCAD>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf OEM_DIAG_PASS); break;
+            case K_OLS: iterate<R, NW, CW, K_OLS>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf OEM_DIAG_PASS); break;
+            default: iterate<R, NW, CW, K_GRP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf OEM_DIAG_PASS); break;
             }
             // oemXTX::get_beta rescales the member in place (ref src/oem_xtx.h:576-581, quirk Q5)
             if (A.sinv) {
@@ -431,7 +449,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
             }
             // warm start of the next lambda (and the loss) need A beta
             const bool last = (pp == A.npen - 1) && (i == nlam - 1);
-            if (!last || A.compute_loss) gemv_round<R, NW, CW>(a, beta, ab, P, Uw, w, lane, buf);
+            if (!last || A.compute_loss) gemv_round<R, NW, CW>(a, beta, ab, P, Uw, w, lane, buf OEM_DIAG_PASS);
             if (A.compute_loss) {
                 // sum (Y - X beta)^2 on the standardised data (ref src/oem_dense.h:759-770) through the Gram identity
                 // yy - 2 n beta'XY + n beta' XX beta, with XX beta = d beta - A beta
@@ -442,6 +460,13 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
                 if (tid == 0) A.loss[(size_t)pp * nl + i] = yy + nobs * t;
             } else if (tid == 0) A.loss[(size_t)pp * nl + i] = 1e99;
         }
+    }
+#ifdef OEM_PATH_DIAG
+    if (tid == 0) for (int k = 0; k < 8; ++k) g_diag[k] = diag_acc[k];
+#endif
+    if (tid == 0) {
+        A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
+        A.d_out[3] = (double)(__builtin_amdgcn_s_memrealtime() - t_rt0);
     }
 }
 
@@ -461,10 +486,23 @@ template <int R, int NW, int CW> int launch_cfg(hipStream_t s, const PathArgs &a
 
 }  // namespace
 
+#ifdef OEM_PATH_DIAG
+extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int launch_path_small(hipStream_t s, const PathArgs &a)
 {
+    // 4 waves (one per SIMD), CW = columns per wave rounded up to an even count: all CW/2 broadcast reads fit in
+    // registers next to the matrix slice, so a round exposes the LDS latency once.
+    if (a.p <= 32) return launch_cfg<1, 4, 8>(s, a);
     if (a.p <= 64) return launch_cfg<1, 4, 16>(s, a);
+    if (a.p <= 80) return launch_cfg<2, 4, 20>(s, a);
+    if (a.p <= 104) return launch_cfg<2, 4, 26>(s, a);
     if (a.p <= 128) return launch_cfg<2, 4, 32>(s, a);
+    if (a.p <= 160) return launch_cfg<3, 8, 20>(s, a);
     if (a.p <= 192) return launch_cfg<3, 8, 24>(s, a);
     set_error("path_small: p = %d exceeds %d", a.p, SMALL_P_MAX);
     return OEMGPU_ERR_INTERNAL;

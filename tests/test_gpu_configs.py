@@ -1,0 +1,117 @@
+"""BASELINE.json configs 2-5 through the HIP path: oracle comparisons at sizes the oracle finishes in seconds,
+plus size-independent properties (KKT conditions, shard invariance) at the full sizes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc
+
+TIGHT = 1e-9
+
+
+@pytest.fixture(scope="module")
+def oa():
+    import torch
+    assert torch.cuda.is_available()
+    import oem_amd
+    oem_amd.lib()
+    return oem_amd
+
+
+def _cmp(fit, ref, tol=TIGHT):
+    for k in range(len(ref["beta"])):
+        a, b = np.asarray(fit["beta"][k]), np.asarray(ref["beta"][k])
+        assert a.shape == b.shape
+        err = np.abs(a - b).max()
+        assert err <= tol, (fit["penalty"][k], err)
+        assert np.allclose(fit["lambda"][k], ref["lambda"][k], rtol=1e-12, atol=0)
+    assert abs(fit["d"] - ref["d"]) <= 1e-8 * abs(ref["d"])
+
+
+def test_config2_mcp_scad_p200(oa):
+    """README.md:100-141: n=5000, p=200, MCP gamma=2 / SCAD gamma=4, 200 lambdas, tol 1e-10 (large-p engine, 4x4 tile blocks)"""
+    rng = np.random.default_rng(123)
+    n, p, m = 5000, 200, 25
+    b = np.concatenate([rng.uniform(-0.5, 0.5, m), np.zeros(p - m)])
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 3.0)
+    y = x @ b + rng.normal(size=n)
+    for pen, gam in (("mcp", 2.0), ("scad", 4.0)):
+        kw = dict(penalty=pen, gamma=gam, nlambda=200, tol=1e-10, standardize=True, intercept=True)
+        fit, ref = oa.oem(x, y, **kw), orc.fit_dense(x, y, native=True, **kw)
+        _cmp(fit, ref)
+        assert np.abs(fit["niter"][0].astype(int) - ref["niter"][0]).max() <= 1
+    both = oa.oem(x, y, penalty=["mcp", "scad"], gamma=3.0, nlambda=50, tol=1e-10, compute_loss=True)
+    ref = orc.fit_dense(x, y, native=True, penalty=["mcp", "scad"], gamma=3.0, nlambda=50, tol=1e-10, compute_loss=True)
+    _cmp(both, ref)
+    for k in range(2):
+        assert np.allclose(both["loss"][k], ref["loss"][k], rtol=1e-9)
+
+
+def test_config3_group_lasso_p512_reduced_n(oa):
+    """config 3 shape at n = 20000: p=512, 64 groups of 8, grp.lasso, no intercept / standardize (README.md:207-213)"""
+    rng = np.random.default_rng(5)
+    n, p = 20000, 512
+    groups = np.repeat(np.arange(1, 65), 8)
+    b = np.zeros(p); b[:24] = rng.uniform(-0.5, 0.5, 24)
+    x = np.asfortranarray(rng.normal(size=(n, p)))
+    y = x @ b + rng.normal(size=n)
+    kw = dict(penalty="grp.lasso", nlambda=30, tol=1e-10, standardize=False, intercept=False)
+    fit = oa.oem(x, y, groups=groups, **kw)
+    ref = orc.fit_dense(x, y, native=True, groups=groups, unique_groups=np.arange(1, 65), **kw)
+    _cmp(fit, ref)
+    kw = dict(penalty=["grp.lasso", "grp.mcp", "sparse.grp.lasso"], nlambda=12, tol=1e-9)       # defaults: centred + scaled
+    _cmp(oa.oem(x, y, groups=groups, **kw), orc.fit_dense(x, y, native=True, groups=groups, unique_groups=np.arange(1, 65), **kw))
+
+
+def _xtx_problem(p, n, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=(n, p))
+    b = np.zeros(p); b[:25] = rng.uniform(-1, 1, 25)
+    y = x @ b + rng.normal(size=n)
+    return x.T @ x / n, x.T @ y / n
+
+
+def test_config4_xtx_p1024_against_oracle(oa):
+    xtx, xty = _xtx_problem(1024, 16384, 4)
+    kw = dict(penalty="lasso", nlambda=30, tol=1e-10)
+    fit = oa.oem_xtx(xtx, xty, **kw)
+    lam_max = np.linalg.eigvalsh(xtx)[-1]
+    assert abs(fit["d"] - 1.005 * lam_max) <= 1e-9 * lam_max
+    ref = orc.fit_xtx(xtx, xty, d_override=fit["d"], **kw)
+    _cmp(fit, ref)
+
+
+def test_config4_xtx_p4096_kkt(oa):
+    """config 4 at full size: p = 4096, 100-lambda lasso, tol 1e-10.  Checked through the lasso KKT conditions
+    |xty - xtx beta| <= lambda on zero coordinates, = lambda sign(beta) on the support."""
+    import torch
+    p = 4096
+    xtx, xty = _xtx_problem(p, 65536, 9)
+    fit = oa.oem_xtx(torch.as_tensor(xtx, device="cuda"), xty, penalty="lasso", nlambda=100, tol=1e-10)
+    beta, lam = fit["beta"][0], fit["lambda"][0]
+    assert beta.shape == (p, 100) and np.all(beta[:, 0] == 0) and fit["niter"][0][0] == 1
+    assert np.all(fit["niter"][0] <= 500)
+    grad = xty[:, None] - xtx @ beta
+    for i in (1, 10, 50, 99):
+        nz = beta[:, i] != 0
+        assert np.abs(grad[~nz, i]).max() <= lam[i] * (1 + 1e-7)
+        assert np.abs(grad[nz, i] - lam[i] * np.sign(beta[nz, i])).max() <= 1e-7 * max(1.0, lam[0])
+    lam_max = np.linalg.eigvalsh(xtx)[-1]
+    assert abs(fit["d"] - 1.005 * lam_max) <= 1e-8 * lam_max
+
+
+def test_config5_big_p256_reduced_n_and_shards(oa):
+    """config 5 semantics (big.oem: intercept column, (n-1) scaling) at n = 60000, p = 256; row shards == one block"""
+    rng = np.random.default_rng(8)
+    n, p = 60000, 256
+    x = np.asfortranarray(rng.normal(size=(n, p)) + 0.5)
+    b = np.zeros(p); b[:20] = rng.uniform(-1, 1, 20)
+    y = x @ b + rng.normal(size=n) + 2.0
+    kw = dict(penalty="lasso", nlambda=25, tol=1e-10)
+    ref = orc.fit_big(x, y, native=True, **kw)
+    _cmp(oa.big_oem(x, y, **kw), ref)
+    cuts = np.linspace(0, n, 9).astype(int)
+    xs = [x[cuts[i]:cuts[i + 1]] for i in range(8)]
+    ys = [y[cuts[i]:cuts[i + 1]] for i in range(8)]
+    _cmp(oa.big_oem(xs, ys, **kw), ref)
