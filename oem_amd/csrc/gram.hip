@@ -114,6 +114,46 @@ __device__ __forceinline__ void load_slab(Slab<NF> &s, const gptr_t (&ptr)[NF], 
     }
 }
 
+// Hot-loop loads as inline asm: hipcc then keeps no count of them, and the waits below are exact.  (With compiler
+// loads it folds every loop form tried back into one with conditional prefetches and then waits for all but the
+// newest slab, which halves the prefetch distance.)  Form (ii) of the guide's asm rules: "=v" loads, then one wait
+// statement naming every destination "+v" before the first consumer.
+template <int OFF> __device__ __forceinline__ void gload16(v2d &dst, gptr_t p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "i"(OFF * 8) : "memory");
+}
+template <int OFF> __device__ __forceinline__ double gload8(gptr_t p)
+{
+    double dst;
+    asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "i"(OFF * 8) : "memory");
+    return dst;
+}
+// loads issued per slab (for the vmcnt arithmetic)
+template <int NF, bool ALIGNED, bool LOADY> struct SlabLoads { static constexpr int N = (ALIGNED ? 1 : 2) * (NF + (LOADY ? 1 : 0)); };
+
+template <int NF, bool ALIGNED, bool LOADY, int OFF>
+__device__ __forceinline__ void load_slab_asm(Slab<NF> &s, const gptr_t (&ptr)[NF], gptr_t y)
+{
+    if (ALIGNED) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) gload16<OFF>(s.v[f], ptr[f]);
+        if (LOADY) gload16<OFF>(s.y, y);
+    } else {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) { s.v[f].x = gload8<OFF>(ptr[f]); s.v[f].y = gload8<OFF + 1>(ptr[f]); }
+        if (LOADY) { s.y.x = gload8<OFF>(y); s.y.y = gload8<OFF + 1>(y); }
+    }
+}
+// wait until at most PENDING younger loads are outstanding; ties the slab's registers to the wait
+template <int NF, int PENDING> __device__ __forceinline__ void wait_slab(Slab<NF> &s)
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PENDING) : "memory");
+#pragma unroll
+    for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(s.v[f]));
+    asm volatile("" : "+v"(s.y));
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // VALU-side accumulators (block kernel only; the triangle kernel gets X'y and the column sums from the MFMAs
 // by treating y and a column of ones as columns p and p+1 of the matrix).
 template <int NF> struct VecAcc {
@@ -259,27 +299,39 @@ __device__ __forceinline__ void gram_body(const double *__restrict__ x, int64_t 
     for (int f = 0; f < NF; ++f) cur[f] = ptr[f] + w0 + 2 * q;
     gptr_t ycur = yg + w0 + 2 * q;
     Slab<NF> s0, s1, s2;
+    s0.y = v2d{0.0, 0.0}; s1.y = s0.y; s2.y = s0.y;
+    constexpr int LPS = SlabLoads<NF, ALIGNED, VEC>::N;        // vmcnt units per slab
+    static_assert(2 * LPS <= 63, "vmcnt field is 6 bits");
     int k = 0;
-    if (ns > 0) load_slab<NF, ALIGNED, false, VEC>(s0, cur, ycur, 0, n);
-    if (ns > 1) load_slab<NF, ALIGNED, false, VEC>(s1, cur, ycur, 32, n);
-    __builtin_amdgcn_sched_barrier(0);
-    while (k + 3 <= ns) {
-        load_slab<NF, ALIGNED, false, VEC>(s2, cur, ycur, 64, n);
-        __builtin_amdgcn_sched_barrier(0);
+    if (ns > 0) load_slab_asm<NF, ALIGNED, VEC, 0>(s0, cur, ycur);
+    if (ns > 1) load_slab_asm<NF, ALIGNED, VEC, 32>(s1, cur, ycur);
+    // steady state: slab k is consumed with slabs k+1 and k+2 in flight (two slabs = 2 x 3584 MFMA cycles of cover)
+    while (k + 5 <= ns) {
+        load_slab_asm<NF, ALIGNED, VEC, 64>(s2, cur, ycur);
+        wait_slab<NF, 2 * LPS>(s0);
         consume_slab<NR, NC, DIAG, false, VEC, AUG>(V, s0, X, cy, 0, n);
-        if (k + 3 < ns) load_slab<NF, ALIGNED, false, VEC>(s0, cur, ycur, 96, n);
-        __builtin_amdgcn_sched_barrier(0);
+        load_slab_asm<NF, ALIGNED, VEC, 96>(s0, cur, ycur);
+        wait_slab<NF, 2 * LPS>(s1);
         consume_slab<NR, NC, DIAG, false, VEC, AUG>(V, s1, X, cy, 0, n);
-        if (k + 4 < ns) load_slab<NF, ALIGNED, false, VEC>(s1, cur, ycur, 128, n);
-        __builtin_amdgcn_sched_barrier(0);
+        load_slab_asm<NF, ALIGNED, VEC, 128>(s1, cur, ycur);
+        wait_slab<NF, 2 * LPS>(s2);
         consume_slab<NR, NC, DIAG, false, VEC, AUG>(V, s2, X, cy, 0, n);
 #pragma unroll
         for (int f = 0; f < NF; ++f) cur[f] += 96;
         ycur += 96;
         k += 3;
     }
-    if (k < ns) consume_slab<NR, NC, DIAG, false, VEC, AUG>(V, s0, X, cy, 0, n);
-    if (k + 1 < ns) consume_slab<NR, NC, DIAG, false, VEC, AUG>(V, s1, X, cy, 0, n);
+    // drain: s0 = slab k and s1 = slab k+1 are in flight (when they exist); at most two more follow
+    {
+        const int rem = ns - k;
+        if (rem >= 3) load_slab_asm<NF, ALIGNED, VEC, 64>(s2, cur, ycur);
+        if (rem >= 1) { wait_slab<NF, 0>(s0); consume_slab<NR, NC, DIAG, false, VEC, AUG>(V, s0, X, cy, 0, n); }
+        if (rem >= 4) load_slab_asm<NF, ALIGNED, VEC, 96>(s0, cur, ycur);
+        if (rem >= 2) { wait_slab<NF, 0>(s1); consume_slab<NR, NC, DIAG, false, VEC, AUG>(V, s1, X, cy, 0, n); }
+        if (rem >= 3) { wait_slab<NF, 0>(s2); consume_slab<NR, NC, DIAG, false, VEC, AUG>(V, s2, X, cy, 0, n); }
+        if (rem >= 4) { wait_slab<NF, 0>(s0); consume_slab<NR, NC, DIAG, false, VEC, AUG>(V, s0, X, cy, 0, n); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (ns < nslab && w0 + 32 * (int64_t)ns < n) {
         const int64_t r = w0 + 32 * (int64_t)ns + 2 * q;
         load_slab<NF, false, true, VEC>(s0, ptr, yg, r, n);

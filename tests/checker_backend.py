@@ -1,0 +1,64 @@
+"""A CPU stand-in for oem_amd.distributed.HipBackend, used ONLY to exercise the row-sharded driver under gloo.
+
+It is an independent restatement of the three local stages (numpy moments about the common shift; the
+moments -> (XX, XY, standardisation) algebra of finalize_kernel; the oracle's path on the resulting Gram), so
+the test also checks the moment algebra itself against the plain oracle fit on the unsharded data."""
+import numpy as np
+import torch
+
+from oracle import oracle as orc
+
+
+class CheckerBackend:
+    def new_buffer(self, n):
+        return torch.zeros(n, dtype=torch.float64)
+
+    def shift_sums(self, x, n, ld, p, y, out):
+        xn, yn = x.numpy(), y.numpy()
+        k = min(n, 64)                                   # any common sample works: the shift is only provisional
+        out[:p] = torch.from_numpy(xn[:k].sum(0)); out[p] = float(yn[:k].sum()); out[p + 1] = float(k)
+
+    def moments(self, x, n, ld, p, y, sums, out):
+        s = sums.numpy()
+        c = s[:p + 1] / s[p + 1]
+        z = np.column_stack([x.numpy() - c[:p], y.numpy() - c[p], np.ones(n)])
+        out.copy_(torch.from_numpy((z.T @ z).ravel()))
+
+    def solve(self, mom, sums, p, semantics, standardize, intercept, args):
+        assert semantics == 0
+        M = mom.numpy().reshape(p + 2, p + 2); s = sums.numpy()
+        n = M[p + 1, p + 1]; c = s[:p + 1] / s[p + 1]
+        sh = M[p + 1, :p + 1]
+        mu = c + sh / n
+        cen = M[:p + 1, :p + 1] - np.outer(sh, sh) / n
+        raw = cen + n * np.outer(mu, mu)
+        flag = int(bool(standardize)) + 2 * int(bool(intercept))
+        G = cen if flag >= 2 else raw
+        sx = np.ones(p)
+        if flag & 1:
+            sx = np.sqrt(np.maximum(np.diag(cen)[:p], 0) / n); sx[sx == 0] = 1.0
+        sy = 1.0 if flag == 0 else np.sqrt(cen[p, p] / n)
+        xx = G[:p, :p] / np.outer(sx, sx) / n
+        xy = G[p, :p] / (sx * sy) / n
+        d = orc.eig_max(xx) * 1.005
+        lmax = np.abs(xy).max() * sy
+        nl = args.nl
+        if args.lam is not None:
+            lam = args.lam.copy()
+        else:
+            base = np.exp(np.linspace(np.log(lmax), np.log(lmax * args.c.lambda_min_ratio), nl))
+            lam = np.tile(base, (args.npen, 1))
+        pens = [orc.PENALTIES[k] for k in args.pen]
+        beta, niter = orc.path(xx, xy, d, lam / sy, penalty=pens, tol=args.c.tol, maxit=args.c.maxit,
+                               alpha=args.c.alpha, gamma=args.c.gamma, tau=args.c.tau, penalty_factor=args.pf)
+        args.outputs(p + 1)
+        for k in range(args.npen):
+            for i in range(nl):
+                b = beta[k, i].copy()
+                if flag & 1:
+                    b = b / sx
+                if flag:
+                    b = b * sy
+                args.beta[k, i, 1:] = b
+                args.beta[k, i, 0] = (mu[p] - b @ mu[:p]) if flag & 2 else 0.0
+        args.lam_out[:] = lam; args.niter[:] = niter; args.loss[:] = 1e99; args.d.value = d

@@ -1,0 +1,79 @@
+"""The row-sharded driver (oem_amd/distributed.py) under gloo with world_size 2, on CPU: row partition, the
+two all-reduces (shift sample, moment buffer) and the replicated solve.  The local stages come from
+tests/checker_backend.py; on GPUs the same driver runs with HipBackend over RCCL (bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as orc
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _data(n=3001, p=12, seed=3):
+    rng = np.random.default_rng(seed)
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 2.0 + 1.0)
+    b = np.concatenate([rng.uniform(-1, 1, 4), np.zeros(p - 4)])
+    return x, x @ b + rng.normal(size=n) + 0.5
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oem_amd.distributed import oem_sharded, row_partition
+    from tests.checker_backend import CheckerBackend
+    x, y = _data()
+    lo, hi = row_partition(x.shape[0], world)[rank]
+    xl = torch.from_numpy(np.ascontiguousarray(x[lo:hi].T)).t()           # column-major local shard
+    yl = torch.from_numpy(y[lo:hi].copy())
+    out = {}
+    for std, icpt in ((True, True), (False, True), (False, False)):
+        fit = oem_sharded(xl, yl, backend=CheckerBackend(), dist=dist, penalty=["lasso", "mcp"], nlambda=12, tol=1e-10,
+                          standardize=std, intercept=icpt)
+        out[(std, icpt)] = (fit["beta"], fit["lambda"], fit["d"], fit["nobs"])
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_partition():
+    from oem_amd.distributed import row_partition
+    assert row_partition(10, 3) == [(0, 3), (3, 6), (6, 10)]              # remainder on the last (ref src/oem_dense.h:343)
+    assert row_partition(8, 1) == [(0, 8)]
+
+
+@pytest.mark.timeout(300)
+def test_sharded_equals_unsharded_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    x, y = _data()
+    for key in got[0]:
+        std, icpt = key
+        ref = orc.fit_dense(x, y, penalty=["lasso", "mcp"], nlambda=12, tol=1e-10, standardize=std, intercept=icpt)
+        for r in (0, 1):
+            beta, lam, d, nobs = got[r][key]
+            assert nobs == x.shape[0]
+            assert abs(d - ref["d"]) < 1e-10 * ref["d"]
+            for k in range(2):
+                assert np.abs(beta[k] - ref["beta"][k]).max() < 1e-9, (key, r, k)
+                assert np.allclose(lam[k], ref["lambda"][k], rtol=1e-12)
+        for k in range(2):                                                  # every rank returns the same bits
+            assert np.array_equal(got[0][key][0][k], got[1][key][0][k])

@@ -1,0 +1,103 @@
+"""Host-side logic of the Python mirror of the R front ends (no GPU): argument validation with the reference's
+messages, lambda / group preprocessing, result consumers."""
+import numpy as np
+import pytest
+
+from oem_amd import api
+
+
+def _xy(n=40, p=6, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=(n, p))
+    return x, x[:, 0] + rng.normal(size=n)
+
+
+@pytest.mark.parametrize("kw,msg", [
+    (dict(lambda_min_ratio=0.0), "lambda.min.ratio must be between 0 and 1"),
+    (dict(lambda_min_ratio=1.0), "lambda.min.ratio must be between 0 and 1"),
+    (dict(nlambda=0), "nlambda must be a positive integer"),
+    (dict(maxit=0), "maxit and irls.maxit should be positive"),
+    (dict(tol=-1.0), "tol and irls.tol should be nonnegative"),
+    (dict(weights=[1.0]), "weights not implemented yet."),
+    (dict(penalty_factor=[1.0, 2.0]), "penalty.factor must have same length as number of columns in x"),
+    (dict(penalty="grp.lasso", groups=[1, 2]), "groups must have same length as number of columns in x"),
+    (dict(penalty="grp.lasso", groups=[1, 1, 2, 2, 3, 3], group_weights=[1.0]), "group.weights must have same length as the number of groups"),
+    (dict(penalty=["lasso", "mcp"], lambda_=[[1.0, 0.5]]), "If list of lambda vectors is provided"),
+    (dict(penalty=["lasso", "mcp"], lambda_=[[1.0, 0.5], [1.0]]), "All provided lambda vectors must have same length"),
+    (dict(penalty="nope"), "'arg' should be one of"),
+])
+def test_oem_argument_errors(kw, msg):
+    x, y = _xy()
+    with pytest.raises(ValueError, match=msg.replace(".", r"\.").replace("(", r"\(")):
+        api.oem(x, y, **kw)
+
+
+def test_shape_errors():
+    x, y = _xy()
+    with pytest.raises(ValueError, match="x and y lengths do not match"):
+        api.oem(x, y[:-1])
+    with pytest.raises(ValueError, match="x must have at least two columns"):
+        api.oem(x[:, :1], y)
+    with pytest.raises(ValueError, match="x must have at least two columns"):
+        api.oem(y, y)
+    with pytest.raises(NotImplementedError):
+        api.oem(x, (y > 0).astype(float), family="binomial")
+    with pytest.raises(ValueError, match="xtx must be a square matrix"):
+        api.oem_xtx(x, y)
+    with pytest.raises(ValueError, match="xty must have length equal"):
+        api.oem_xtx(x.T @ x, y)
+    with pytest.raises(ValueError, match="scale.factor must be same length"):
+        api.oem_xtx(x.T @ x, x.T @ y, scale_factor=[1.0, 2.0])
+    with pytest.raises(ValueError, match="binomial case not implemented yet"):
+        api.big_oem(x, y, family="binomial")
+
+
+def test_penalty_matching_and_defaults():
+    assert api._match_penalty(None) == ["elastic.net"]                 # R/oem.R:202-208: default = first choice only
+    assert api._match_penalty("sparse") == ["sparse.grp.lasso"]         # partial matching like match.arg
+    assert api._match_penalty(["lasso", "grp.mcp.net"]) == ["lasso", "grp.mcp.net"]
+    with pytest.raises(ValueError):
+        api._match_penalty("grp")                                       # ambiguous
+
+
+def test_lambda_lists_are_sorted_decreasing():
+    lam = api._lambda_list([0.1, 1.0, 0.5], 2)
+    assert len(lam) == 2 and np.array_equal(lam[0], [1.0, 0.5, 0.1]) and np.array_equal(lam[1], lam[0])
+    lam = api._lambda_list([[0.1, 1.0], [3.0, 2.0]], 2)
+    assert np.array_equal(lam[0], [1.0, 0.1]) and np.array_equal(lam[1], [3.0, 2.0])
+    assert all(len(l) == 0 for l in api._lambda_list((), 3))
+
+
+def test_group_setup_dense_and_big():
+    g, ug, gw = api._group_setup(["grp.lasso"], [3, 3, 1, 1, 2, 2], None, 6, False)
+    assert np.array_equal(g, [3, 3, 1, 1, 2, 2]) and np.array_equal(ug, [1, 2, 3]) and gw.size == 0
+    # big.oem with intercept: groups gets a leading 0 and unique.groups gains 0 (R/big_oem.R:226-259)
+    g, ug, gw = api._group_setup(["grp.lasso"], [3, 3, 1, 1, 2, 2], None, 6, True)
+    assert np.array_equal(g, [0, 3, 3, 1, 1, 2, 2]) and np.array_equal(ug, [0, 1, 2, 3])
+    g, ug, gw = api._group_setup(["grp.lasso"], [1, 1, 2, 2, 3, 3], [1.0, 2.0, 3.0], 6, True)
+    assert np.array_equal(ug, [0, 1, 2, 3]) and np.array_equal(gw, [0.0, 1.0, 2.0, 3.0])
+    g, ug, gw = api._group_setup(["lasso"], [], None, 6, True)
+    assert g.size == 0 and ug.size == 0 and gw.size == 0
+
+
+def _fake_fit():
+    beta = np.array([[1.0, 1.0, 1.0], [0.0, 0.5, 0.7], [0.0, 0.0, -0.2]])
+    f = api.OemFit(beta=[beta], **{"lambda": [np.array([1.0, 0.5, 0.1])]}, loss=[np.array([10.0, 8.0, 7.0])],
+                   niter=[np.array([1, 3, 4])], penalty=["lasso"], nobs=20, nvars=2, family="gaussian")
+    return f
+
+
+def test_predict_and_loglik():
+    f = _fake_fit()
+    assert np.array_equal(api.predict(f, type="coefficients"), f["beta"][0])
+    nz = api.predict(f, type="nonzero")
+    assert nz[0] is None and np.array_equal(nz[1], [2]) and np.array_equal(nz[2], [2, 3])     # row 1 always dropped (Q16)
+    x = np.array([[1.0, 2.0], [0.0, 1.0]])
+    assert np.allclose(api.predict(f, x, type="response"), np.column_stack([np.ones(2), x]) @ f["beta"][0])
+    mid = api.predict(f, x, s=[0.75], type="response")
+    assert np.allclose(mid[:, 0], 0.5 * (api.predict(f, x)[:, 0] + api.predict(f, x)[:, 1]))
+    ll = api.logLik(f)
+    assert np.allclose(ll, -0.5 * 20 * (np.log(2 * np.pi) - np.log(20) + np.log(f["loss"][0])) - 10)
+    f["loss"] = [np.full(3, 1e99)]
+    with pytest.raises(ValueError, match="compute.loss"):
+        api.logLik(f)
