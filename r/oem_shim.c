@@ -1,0 +1,147 @@
+/*
+ * oem_shim.c -- the R-side binding a maintainer of jaredhuling/oem would add.
+ *
+ * Exports the SAME unmangled symbols with the SAME all-SEXP signatures as the reference's RcppExport entry
+ * points (ref src/oem_dense.cpp:30-48, src/oem_xtx.cpp:29-44), so the unchanged R front ends
+ * (R/oem.R:556-575, R/oem_xtx.R:389-406: `.Call("oem_fit_dense", ..., PACKAGE = "oem")`) resolve to it through
+ * the package's dynamic symbol lookup (ref src/oem_init.c:167-171).  R C API only (no Rcpp); all numerics are in
+ * liboemgpu.so behind include/oemgpu.h.
+ *
+ * Build (inside the package's src/, replacing oem_dense.cpp / oem_xtx.cpp):
+ *     PKG_CPPFLAGS = -I<repo>/include        PKG_LIBS = -L<repo>/oem_amd -loemgpu
+ * NOT compiled in this repository's image: there is no R installation.
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <string.h>
+
+#include "oemgpu.h"
+
+static const char *PENALTIES[OEMGPU_NPENALTIES] = {      /* ref R/oem.R:165-173 */
+    "elastic.net", "lasso", "ols", "mcp", "scad", "mcp.net", "scad.net", "grp.lasso", "grp.lasso.net",
+    "grp.mcp", "grp.scad", "grp.mcp.net", "grp.scad.net", "sparse.grp.lasso"};
+
+static SEXP list_elt(SEXP list, const char *name)
+{
+    SEXP names = Rf_getAttrib(list, R_NamesSymbol);
+    for (R_xlen_t i = 0; i < XLENGTH(list); i++)
+        if (strcmp(CHAR(STRING_ELT(names, i)), name) == 0) return VECTOR_ELT(list, i);
+    Rf_error("opts$%s is missing", name);
+    return R_NilValue;
+}
+
+/* fills o from the SEXP arguments; buffers that need a C layout are R_alloc'd (freed by R at the end of .Call) */
+static void fill_opts(oemgpu_opts *o, SEXP penalty_, SEXP groups_, SEXP unique_groups_, SEXP group_weights_,
+                      SEXP lambda_, SEXP nlambda_, SEXP lmin_ratio_, SEXP alpha_, SEXP gamma_, SEXP tau_,
+                      SEXP penalty_factor_, SEXP compute_loss_, SEXP opts_, int dense)
+{
+    memset(o, 0, sizeof *o);
+    o->npen = (int32_t)XLENGTH(penalty_);
+    int32_t *pen = (int32_t *)R_alloc(o->npen, sizeof(int32_t));
+    for (int k = 0; k < o->npen; k++) {
+        pen[k] = -1;
+        for (int c = 0; c < OEMGPU_NPENALTIES; c++)
+            if (strcmp(CHAR(STRING_ELT(penalty_, k)), PENALTIES[c]) == 0) pen[k] = c;
+        if (pen[k] < 0) Rf_error("unknown penalty '%s'", CHAR(STRING_ELT(penalty_, k)));
+    }
+    o->penalty = pen;
+    o->nlambda = Rf_asInteger(nlambda_);
+    o->lambda_min_ratio = Rf_asReal(lmin_ratio_);
+    /* lambda_: list of one numeric vector per penalty, possibly length 0 (ref R/oem.R:366-404) */
+    R_xlen_t nlu = XLENGTH(VECTOR_ELT(lambda_, 0));
+    if (nlu > 0) {
+        double *lam = (double *)R_alloc((size_t)o->npen * nlu, sizeof(double));
+        for (int k = 0; k < o->npen; k++) memcpy(lam + (size_t)k * nlu, REAL(VECTOR_ELT(lambda_, k)), sizeof(double) * nlu);
+        o->lambda_user = lam;
+        o->nlambda_user = (int32_t)nlu;
+    }
+    o->alpha = Rf_asReal(alpha_); o->gamma = Rf_asReal(gamma_); o->tau = Rf_asReal(tau_);
+    o->tol = Rf_asReal(list_elt(opts_, "tol"));
+    o->maxit = Rf_asInteger(list_elt(opts_, "maxit"));
+    o->accelerate = dense ? (Rf_asReal(list_elt(opts_, "accelerate")) != 0.0) : 0;     /* read as<double> (quirk Q12) */
+    o->compute_loss = compute_loss_ != R_NilValue ? Rf_asLogical(compute_loss_) : 0;
+    o->penalty_factor = REAL(penalty_factor_);
+    o->groups = XLENGTH(groups_) ? INTEGER(groups_) : NULL;            o->ngroupvars = (int32_t)XLENGTH(groups_);
+    o->unique_groups = XLENGTH(unique_groups_) ? INTEGER(unique_groups_) : NULL;   o->ngroups = (int32_t)XLENGTH(unique_groups_);
+    o->group_weights = XLENGTH(group_weights_) ? REAL(group_weights_) : NULL;      o->n_group_weights = (int32_t)XLENGTH(group_weights_);
+    o->device = -1;
+}
+
+/* List(beta = list(...), lambda = list(...), niter = list(...), loss = list(...), d = d)  (ref src/oem_dense.cpp:280-307) */
+static SEXP pack(const oemgpu_opts *o, int rows, int nl, const double *beta, const double *lam, const int32_t *niter,
+                 const double *loss, double d)
+{
+    SEXP res = PROTECT(Rf_allocVector(VECSXP, 5)), names = PROTECT(Rf_allocVector(STRSXP, 5));
+    const char *nm[5] = {"beta", "lambda", "niter", "loss", "d"};
+    for (int i = 0; i < 5; i++) SET_STRING_ELT(names, i, Rf_mkChar(nm[i]));
+    SEXP lb = PROTECT(Rf_allocVector(VECSXP, o->npen)), ll = PROTECT(Rf_allocVector(VECSXP, o->npen));
+    SEXP ln = PROTECT(Rf_allocVector(VECSXP, o->npen)), lo = PROTECT(Rf_allocVector(VECSXP, o->npen));
+    for (int k = 0; k < o->npen; k++) {
+        const int ols = o->penalty[k] == OEMGPU_OLS;                    /* vector / scalars for "ols" (ref :282-288) */
+        const int nlam = ols ? 1 : nl;
+        SEXP b = ols ? Rf_allocVector(REALSXP, rows) : Rf_allocMatrix(REALSXP, rows, nl);
+        SET_VECTOR_ELT(lb, k, b);
+        memcpy(REAL(b), beta + (size_t)k * nl * rows, sizeof(double) * (size_t)rows * nlam);
+        SEXP l = Rf_allocVector(REALSXP, nl);  SET_VECTOR_ELT(ll, k, l);  memcpy(REAL(l), lam + (size_t)k * nl, sizeof(double) * nl);
+        SEXP it = Rf_allocVector(INTSXP, nlam); SET_VECTOR_ELT(ln, k, it); memcpy(INTEGER(it), niter + (size_t)k * nl, sizeof(int) * nlam);
+        SEXP ls = Rf_allocVector(REALSXP, nlam); SET_VECTOR_ELT(lo, k, ls); memcpy(REAL(ls), loss + (size_t)k * nl, sizeof(double) * nlam);
+    }
+    SET_VECTOR_ELT(res, 0, lb); SET_VECTOR_ELT(res, 1, ll); SET_VECTOR_ELT(res, 2, ln); SET_VECTOR_ELT(res, 3, lo);
+    SET_VECTOR_ELT(res, 4, Rf_ScalarReal(d));
+    Rf_setAttrib(res, R_NamesSymbol, names);
+    UNPROTECT(6);
+    return res;
+}
+
+SEXP oem_fit_dense(SEXP x_, SEXP y_, SEXP family_, SEXP penalty_, SEXP weights_, SEXP groups_, SEXP unique_groups_,
+                   SEXP group_weights_, SEXP lambda_, SEXP nlambda_, SEXP lmin_ratio_, SEXP alpha_, SEXP gamma_,
+                   SEXP tau_, SEXP penalty_factor_, SEXP standardize_, SEXP intercept_, SEXP compute_loss_, SEXP opts_)
+{
+    if (strcmp(CHAR(STRING_ELT(family_, 0)), "gaussian") != 0)
+        Rf_error("binomial not available for oem_fit_dense, use oem_fit_logistic_dense");     /* ref src/oem_dense.cpp:168 */
+    if (XLENGTH(weights_) > 0) Rf_error("weights not implemented yet.");
+    SEXP dim = Rf_getAttrib(x_, R_DimSymbol);
+    const int64_t n = INTEGER(dim)[0];
+    const int p = INTEGER(dim)[1];
+    oemgpu_opts o;
+    fill_opts(&o, penalty_, groups_, unique_groups_, group_weights_, lambda_, nlambda_, lmin_ratio_, alpha_, gamma_, tau_,
+              penalty_factor_, compute_loss_, opts_, 1);
+    const int nl = o.nlambda_user > 0 ? o.nlambda_user : o.nlambda;
+    const size_t nk = (size_t)o.npen * nl;
+    double *beta = (double *)R_alloc(nk * (p + 1), sizeof(double)), *lam = (double *)R_alloc(nk, sizeof(double));
+    double *loss = (double *)R_alloc(nk, sizeof(double)), d = 0.0;
+    int32_t *niter = (int32_t *)R_alloc(nk, sizeof(int32_t));
+    /* x and y are read-only for the library: no copy (the reference copies, ref src/oem_dense.cpp:61-67) */
+    const int rc = oemgpu_fit_dense(REAL(x_), n, p, REAL(y_), Rf_asLogical(standardize_), Rf_asLogical(intercept_), &o,
+                                    beta, lam, niter, loss, &d);
+    if (rc != 0) Rf_error("%s", oemgpu_last_error());      /* device memory is already released inside the library */
+    return pack(&o, p + 1, nl, beta, lam, niter, loss, d);
+}
+
+SEXP oem_xtx(SEXP xtx_, SEXP xty_, SEXP family_, SEXP penalty_, SEXP groups_, SEXP unique_groups_, SEXP group_weights_,
+             SEXP lambda_, SEXP nlambda_, SEXP lmin_ratio_, SEXP alpha_, SEXP gamma_, SEXP tau_, SEXP scale_factor_,
+             SEXP penalty_factor_, SEXP opts_)
+{
+    if (strcmp(CHAR(STRING_ELT(family_, 0)), "gaussian") != 0)
+        Rf_error("binomial not available for oem_fit_dense, use oem_fit_logistic_dense");
+    const int p = INTEGER(Rf_getAttrib(xtx_, R_DimSymbol))[1];
+    oemgpu_opts o;
+    fill_opts(&o, penalty_, groups_, unique_groups_, group_weights_, lambda_, nlambda_, lmin_ratio_, alpha_, gamma_, tau_,
+              penalty_factor_, R_NilValue, opts_, 0);
+    const int nl = o.nlambda_user > 0 ? o.nlambda_user : o.nlambda;
+    const size_t nk = (size_t)o.npen * nl;
+    double *beta = (double *)R_alloc(nk * p, sizeof(double)), *lam = (double *)R_alloc(nk, sizeof(double));
+    double *loss = (double *)R_alloc(nk, sizeof(double)), d = 0.0;
+    int32_t *niter = (int32_t *)R_alloc(nk, sizeof(int32_t));
+    const int rc = oemgpu_fit_xtx(REAL(xtx_), REAL(xty_), p, XLENGTH(scale_factor_) ? REAL(scale_factor_) : NULL, &o,
+                                  beta, lam, niter, loss, &d);
+    if (rc != 0) Rf_error("%s", oemgpu_last_error());
+    return pack(&o, p, nl, beta, lam, niter, loss, d);
+}
+
+/* oem_fit_big / oem_fit_fb_big (ref src/oem_big.cpp:30, src/oem_fb_big.cpp:30): identical except that x_ is the
+ * big.matrix external pointer; with bigmemory's headers, in a C++ TU:
+ *     Rcpp::XPtr<BigMatrix> bm(x_);  const double *x = (const double *)bm->matrix();   // type 8 = double only (ref :57-62)
+ *     const double *xs[1] = {x}, *ys[1] = {REAL(y_)};  int64_t ns[1] = {bm->nrow()};
+ *     oemgpu_fit_big(xs, ns, 1, bm->ncol(), ys, standardize, intercept, &o, beta, lam, niter, loss, &d);
+ * groups_ arrives with its leading 0 for the intercept (ref R/big_oem.R:254-257) and is passed through unchanged. */
