@@ -32,7 +32,7 @@ def audit_gram_isa(asm_text):
     (csrc/gen/acc_tiles.inc).  That is only sound if hipcc itself never touches the accumulator
     file and never spills in those kernels: check both in the emitted ISA."""
     problems = []
-    for m in re.finditer(r"^(_ZN6oemgpu15gram_(?:tri|blk)_kernel\w+):\n(.*?)\n\s*s_endpgm", asm_text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN6oemgpu1[567]gram_(?:tri|blk|ring)_kernel\w+):\n(.*?)\n\s*s_endpgm", asm_text, re.S | re.M):
         name, body = m.group(1), m.group(2)
         in_asm = False
         for line in body.splitlines():
@@ -53,7 +53,7 @@ def build_diag():
     """liboemgpu_diag.so: the same library with -DOEM_PATH_DIAG (stamped round segments); never the product."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out = HERE / "liboemgpu_diag.so"
-    subprocess.run([hipcc, *FLAGS, "-DOEM_PATH_DIAG", "-shared", "-o", str(out)] + [str(CSRC / s) for s in SOURCES], check=True)
+    subprocess.run([hipcc, *FLAGS, "-DOEM_PATH_DIAG", "-DOEM_GRAM_DIAG", "-shared", "-o", str(out)] + [str(CSRC / s) for s in SOURCES], check=True)
     return out
 
 

@@ -154,6 +154,20 @@ template <int NF, int PENDING> __device__ __forceinline__ void wait_slab(Slab<NF
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// LDS-DMA (global_load_lds_dwordx4): 64 lanes x 16 B land at (wave-uniform LDS address) + 16 lane, with no VGPR
+// destination, so prefetch depth is bounded by LDS, not by registers.  M0 carries the LDS address; it is
+// compiler-reserved and not preserved around asm, so it is saved, set and restored inside the one statement.
+template <int OFF> __device__ __forceinline__ void glds16(gptr_t src, unsigned lds_byte_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_byte_addr), "i"(OFF * 8) : "memory");
+}
+template <int PENDING> __device__ __forceinline__ void wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PENDING) : "memory");
+}
+
 // VALU-side accumulators (block kernel only; the triangle kernel gets X'y and the column sums from the MFMAs
 // by treating y and a column of ones as columns p and p+1 of the matrix).
 template <int NF> struct VecAcc {
@@ -170,9 +184,14 @@ template <int NF> struct LaneXf {
 
 // Columns beyond the last valid one need no masking: a fragment lane only feeds the tile rows / columns of
 // its own column index, and entries outside the matrix are dropped by moments_reduce_kernel.
-template <int NR, int NC, bool DIAG, bool MASKED, bool VEC, bool AUG>
+struct NoHook { template <typename M> __device__ __forceinline__ void operator()(M) const {} };
+
+// hook(integral_constant<m>) runs right after the m-th MFMA of the slab (m = 0 .. 2 NTILES - 1): the place for
+// scalar / VMEM / LDS instructions, which issue for free in the 64-cycle shadow of an FP64 MFMA.
+template <int NR, int NC, bool DIAG, bool MASKED, bool VEC, bool AUG, typename Hook = NoHook>
 __device__ __forceinline__ void consume_slab(VecAcc<DIAG ? NR : NR + NC> &V, Slab<DIAG ? NR : NR + NC> &s,
-                                             const LaneXf<DIAG ? NR : NR + NC> &X, double cy, int64_t r, int64_t n)
+                                             const LaneXf<DIAG ? NR : NR + NC> &X, double cy, int64_t r, int64_t n,
+                                             Hook &&hook = NoHook())
 {
     constexpr int NF = DIAG ? NR : NR + NC;
     double m0 = 1.0, m1 = 1.0;
@@ -216,6 +235,7 @@ __device__ __forceinline__ void consume_slab(VecAcc<DIAG ? NR : NR + NC> &V, Sla
                 static_for<I + 1>([&](auto J_) {
                     constexpr int J = decltype(J_)::value;
                     AccTile<I *(I + 1) / 2 + J>::mfma(s.v[I][e], s.v[J][e]);
+                    hook(std::integral_constant<int, e * (NR * (NR + 1) / 2) + I * (I + 1) / 2 + J>{});
                 });
             });
         } else {
@@ -424,6 +444,182 @@ __device__ __forceinline__ void gram_body(const double *__restrict__ x, int64_t 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Triangle kernel, LDS-DMA ring form (the c1 path).  Measured on MI355X (tools/mfma_probe.hip): a bare stream of
+// v_mfma_f64_16x16x4_f64 issues every 64.00 cycles (77 TFLOP/s at the clock held), and EVERY interleaved v_fma_f64
+// costs 4.5-9 of those cycles: FP64 VALU and FP64 MFMA share the DP units.  So the kernel wants (a) as little FP64
+// VALU as possible -- moving the 6-column remainder strip of p = 100 to VALU FMAs gained nothing -- and (b) no cycle
+// of the MFMA stream spent waiting for memory.  (b): slabs arrive by LDS-DMA into a wave-private ring of NSLOT
+// slots (no VGPR destination, so depth is bounded by LDS: 4 slabs = 28 KiB per wave in flight), a slab is copied to
+// registers one slab ahead of its use, and the only waits are exact vmcnt counts.
+// ------------------------------------------------------------------------------------------------
+#ifdef OEM_GRAM_DIAG
+__device__ unsigned long long g_gram_diag[8];
+#define GSTAMP(slot)                                                                       \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        unsigned long long t__;                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        gd[slot] += t__ - gl;                                                              \
+        gl = t__;                                                                          \
+    } while (0)
+#else
+#define GSTAMP(slot) do { } while (0)
+#endif
+
+template <int NT, bool SHIFT>
+__device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x, int64_t n, int64_t ld, int p,
+                                                   const double *__restrict__ y, const double *__restrict__ sums,
+                                                   int64_t row_begin, int steps, double *__restrict__ tdst, double *lds)
+{
+    constexpr int NF = NT, NTILES = NT * (NT + 1) / 2;
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const gptr_t xg = (gptr_t)x, yg = (gptr_t)y;
+    gptr_t cur[NF];
+    LaneXf<NF> X;
+    X.m_last = 1.0; X.o_last = 0.0;
+    const double inv_cnt = (SHIFT && sums) ? 1.0 / sums[p + 1] : 0.0;
+    const double cy = (SHIFT && sums) ? sums[p] * inv_cnt : 0.0;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int col = 16 * f + i;
+        double cf;
+        if (col < p) { cur[f] = xg + (size_t)col * ld; cf = (SHIFT && sums) ? sums[col] * inv_cnt : 0.0; }
+        else { cur[f] = yg; cf = cy; }
+        if (f == NF - 1) {
+            X.m_last = (col == p + 1) ? 0.0 : 1.0;
+            X.o_last = (col == p + 1) ? 1.0 : -cf;
+        }
+        X.c[f] = cf;
+    }
+    VecAcc<NF> V;          // unused (AUG): kept for consume_slab's signature
+    V.sy = 0.0; V.syy = 0.0;
+    static_for<NTILES>([&](auto T_) { AccTile<decltype(T_)::value>::zero(); });
+    asm volatile("s_nop 7" ::: "memory");
+
+    const int nslab = 2 * steps;
+    const int64_t w0 = row_begin + 8 * w;
+    int ns = 0;
+    if (w0 + 8 <= n) {
+        int64_t k = (n - w0 - 8) / 32 + 1;
+        ns = k < nslab ? (int)k : nslab;
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) cur[f] += w0 + 2 * q;
+
+    constexpr int NSLOT = 5, SLOT_B = NF * 1024;
+    static_assert((NSLOT - 1) * NF <= 63, "vmcnt field is 6 bits");
+    const unsigned ring = (unsigned)(size_t)lds + (unsigned)w * (NSLOT * SLOT_B);     // LDS byte address of this wave's ring
+    const v2d *ring_rd = reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(lds) + w * (NSLOT * SLOT_B)) + lane;
+    auto issue = [&](int slot) {                                   // DMA the next slab into ring slot `slot`
+        const unsigned dst = ring + (unsigned)slot * SLOT_B;
+        static_for<NF>([&](auto F_) { constexpr int f = decltype(F_)::value; glds16<0>(cur[f], dst + f * 1024); });
+#pragma unroll
+        for (int f = 0; f < NF; ++f) cur[f] += 32;
+    };
+    auto fetch = [&](Slab<NF> &s, int slot) {                      // ring slot -> registers (a lane reads back its own 16 B)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) s.v[f] = ring_rd[(slot * SLOT_B + f * 1024) / 16];
+    };
+    auto next = [](int v) { return v + 1 == NSLOT ? 0 : v + 1; };
+    Slab<NF> sa, sb;
+    sa.y = v2d{0.0, 0.0}; sb.y = sa.y;
+#ifdef OEM_GRAM_DIAG
+    unsigned long long gd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gl = __builtin_amdgcn_s_memtime();
+#endif
+    // prologue: NSLOT-1 slabs in flight, slab 0 in registers
+    const int npre = ns < NSLOT - 1 ? ns : NSLOT - 1;
+    for (int j = 0; j < npre; ++j) issue(j);
+    int slot = 0, islot = npre % NSLOT, issued = npre, k = 0;
+    if (ns > 0) {
+        if (npre == NSLOT - 1) wait_vm<(NSLOT - 2) * NF>(); else wait_vm<0>();
+        fetch(sa, 0);
+        slot = next(slot);
+    }
+    // steady state, two slabs per trip (sa / sb alternate as "in registers" and "being fetched"):
+    //   issue slab k+NSLOT-1; wait until slab k+1 has landed; copy it to registers; MFMAs of slab k
+    GSTAMP(0);                                   // prologue
+    // steady state: while the MFMAs of slab k run, the hook (a) issues the DMA of slab k+NSLOT-1 after MFMAs 1..NF,
+    // (b) bumps the pointers, (c) waits for slab k+1 (exact vmcnt) and (d) copies it from the ring to the other
+    // register slab after MFMAs NF+2 .. 2NF+1.  None of it is FP64 VALU, so it rides in the MFMA shadows.
+    auto steady = [&](Slab<NF> &use, Slab<NF> &nxt) {
+        const unsigned dst = ring + (unsigned)islot * SLOT_B;
+        const v2d *src = ring_rd + (slot * SLOT_B) / 16;
+        consume_slab<NT, NT, true, false, false, true>(V, use, X, cy, 0, n, [&](auto M_) {
+            constexpr int m = decltype(M_)::value;
+            if constexpr (m >= 1 && m <= NF) glds16<0>(cur[m - 1], dst + (m - 1) * 1024);
+            if constexpr (m == NF + 1) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) cur[f] += 32;
+                wait_vm<(NSLOT - 2) * NF>();
+            }
+            if constexpr (m >= NF + 2 && m <= 2 * NF + 1) nxt.v[m - NF - 2] = src[((m - NF - 2) * 1024) / 16];
+        });
+        islot = next(islot); slot = next(slot);
+    };
+    static_assert(2 * NF + 1 < NT * (NT + 1), "not enough MFMAs per slab to carry the hooks");
+    while (k + NSLOT + 1 <= ns) {
+        steady(sa, sb);
+        GSTAMP(4);
+        steady(sb, sa);
+        GSTAMP(4);
+        issued += 2; k += 2;
+    }
+    // drain: slab k is in sa; issue what is left, then walk the ring with everything landed
+    while (issued < ns) { issue(islot); islot = next(islot); ++issued; }
+    wait_vm<0>();
+    for (; k < ns; ++k) {
+        if (k + 1 < ns) { fetch(sb, slot); slot = next(slot); }
+        consume_slab<NT, NT, true, false, false, true>(V, sa, X, cy, 0, n);
+        if (k + 1 < ns) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) sa.v[f] = sb.v[f];
+        }
+    }
+    GSTAMP(5);                                   // drain
+    __syncthreads();                                               // the ring memory is reused by the epilogue below
+    if (ns < nslab && w0 + 32 * (int64_t)ns < n) {
+        // ragged slab, addressed relative to the running pointers (cur = column base + w0 + 2q + 32 ns)
+        const int64_t r = w0 + 32 * (int64_t)ns + 2 * q;
+        const int64_t o0 = (r < n ? r : n - 1) - r, o1 = (r + 1 < n ? r + 1 : n - 1) - r;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) { sa.v[f].x = cur[f][o0]; sa.v[f].y = cur[f][o1]; }
+        consume_slab<NT, NT, true, true, false, true>(V, sa, X, cy, r, n);
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    // ---- tile partials: all four waves write their tiles to LDS at once (two passes of <= 14 tiles: 4 x 28 KiB),
+    //      then every wave sums a quarter of the pass ((w0 + w1) + (w2 + w3), fixed order) and stores it coalesced.
+    constexpr int TPP = (NTILES + 1) / 2;                                   // tiles per pass
+    static_for<2>([&](auto P_) {
+        constexpr int pass = decltype(P_)::value, t0 = pass * TPP, t1 = (t0 + TPP < NTILES) ? t0 + TPP : NTILES;
+        static_for<(t1 - t0)>([&](auto T_) {
+            constexpr int tt = t0 + decltype(T_)::value;
+            static_for<4>([&](auto R_) {
+                constexpr int r = decltype(R_)::value;
+                lds[(size_t)w * (TPP * 256) + ((tt - t0) * 4 + r) * 64 + lane] = AccTile<tt>::template read<r>();
+            });
+        });
+        __syncthreads();
+        for (int e = tid; e < (t1 - t0) * 256; e += 256) {
+            const double a0 = lds[e], a1 = lds[TPP * 256 + e], a2 = lds[2 * TPP * 256 + e], a3 = lds[3 * TPP * 256 + e];
+            tdst[(size_t)t0 * 256 + e] = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+    });
+#ifdef OEM_GRAM_DIAG
+    GSTAMP(6);                                   // epilogue
+    if (blockIdx.x == 7 && tid == 0) { gd[7] = (unsigned long long)ns; for (int j = 0; j < 8; ++j) g_gram_diag[j] = gd[j]; }
+#endif
+}
+
+#ifdef OEM_GRAM_DIAG
+extern "C" __attribute__((visibility("default"))) int oemgpu_gram_diag_read(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gram_diag), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // Pointers are separate kernel parameters (not struct members): only then does hipcc know they are global
 // and emit global_load (counted vmcnt) instead of flat_load (vmcnt(0) + lgkmcnt(0) drains the prefetch).
 struct GramDims {
@@ -442,6 +638,19 @@ __global__ __launch_bounds__(256) void gram_tri_kernel(const double *__restrict_
     gram_body<NT, NT, true, ALIGNED, false, true>(x, a.n, a.ld, a.p, y, sums, a.ntc, 0, 0,
                                                   (int64_t)chunk * a.steps * 64, a.steps, true,
                                                   tpart + (size_t)chunk * a.ntile * 256, vpart, lds);
+}
+
+// whole lower triangle of Z = [X | y | 1] in one wave, slabs through the LDS-DMA ring (16-byte aligned X)
+template <int NT>
+__global__ __launch_bounds__(256) void gram_ring_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                         const double *__restrict__ sums, double *__restrict__ tpart,
+                                                         double *__restrict__ vpart, GramDims a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    (void)vpart;
+    const int chunk = blockIdx.x;
+    gram_tri_ring_body<NT, true>(x, a.n, a.ld, a.p, y, sums, (int64_t)chunk * a.steps * 64, a.steps,
+                                 tpart + (size_t)chunk * a.ntile * 256, lds);
 }
 
 // 4x4 tile blocks of X'X; blockIdx -> (row chunk, tile block) so that the tile blocks of one row chunk run
@@ -513,6 +722,22 @@ static int launch_gram_t(hipStream_t s, const GramPlan &pl, const double *x, con
         if (sh < vb) sh = vb;                                                                             \
         hipLaunchKernelGGL((gram_tri_kernel<NT, ALIGNED>), dim3(pl.nchunk), dim3(256), sh, s, x, y, sums, tpart, vpart, a);          \
         break;                                                                                            \
+    }
+    // 16-byte aligned X with at least 4 tile columns: the LDS-DMA ring form
+    if (pl.tri && ALIGNED && pl.ntc >= 4) {
+        size_t sh = (size_t)pl.ntile * tile_bytes;
+        const size_t rb = (size_t)4 * 5 * pl.ntc * 1024;                         // 4 waves x NSLOT x NF KiB ring
+        if (sh < rb) sh = rb;
+#define OEM_RING(NT)                                                                                                   \
+    if (pl.ntc == NT) {                                                                                                \
+        if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_ring_kernel<NT>),         \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));        \
+        hipLaunchKernelGGL((gram_ring_kernel<NT>), dim3(pl.nchunk), dim3(256), sh, s, x, y, sums, tpart, vpart, a);   \
+        OEM_HIP(hipGetLastError());                                                                                    \
+        return 0;                                                                                                      \
+    }
+        OEM_RING(4) OEM_RING(5) OEM_RING(6) OEM_RING(7)
+#undef OEM_RING
     }
     if (pl.tri) {
         switch (pl.ntc) {

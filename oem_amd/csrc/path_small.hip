@@ -269,7 +269,9 @@ __device__ __forceinline__ void iterate(const PathArgs &A, const PenK &K, double
             if (wave_sum(adp) > 0.0) ak = 1.0;
         }
         ++it;
-        // stopRule, ref src/utils.cpp:537-549; |(cur - prev) / prev| > tol written as |cur - prev| > tol |prev|
+        // A beta is needed whatever the stop rule says (next iteration, or the warm start of the next lambda), so the
+        // GEMV round is issued first and the stop rule (ref src/utils.cpp:537-549; |(cur - prev) / prev| > tol written as
+        // |cur - prev| > tol |prev|) resolves in the shadow of its LDS exchange instead of ahead of it.
         bool bad = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -278,9 +280,9 @@ __device__ __forceinline__ void iterate(const PathArgs &A, const PenK &K, double
             bad |= (cn != qn);
             bad |= (cn && qn && fabs(beta[r] - bold[r]) > tol * q);
         }
+        gemv_round<R, NW, CW>(a, beta, ab, P, Uw, w, lane, buf OEM_DIAG_PASS);
         conv = (__ballot(bad) == 0ull);
         if (conv || it >= A.maxit) break;
-        gemv_round<R, NW, CW>(a, beta, ab, P, Uw, w, lane, buf OEM_DIAG_PASS);
     }
 }
 
@@ -375,6 +377,9 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
         for (int r = 0; r < R; ++r) { vp[r] = v[r]; v[r] = wv[r] * ib; }
         bprev = bb;
     }
+#ifdef OEM_PATH_DIAG
+    for (int k = 0; k < 4; ++k) diag_acc[4 + k] = diag_acc[k];      // Lanczos share of the four segments
+#endif
     const double theta = tridiag_max(Tal, Tbe, nst, lane);
     const double d = theta * 1.005;                       // ref src/oem_dense.h:498
     if (tid == 0) { A.d_out[0] = d; A.d_out[1] = theta; }
@@ -447,9 +452,9 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
                 }
                 if (lane == 0) A.niter[(size_t)pp * nl + i] = conv ? it : A.maxit + 1;   // ref src/oem_base.h:94-109
             }
-            // warm start of the next lambda (and the loss) need A beta
-            const bool last = (pp == A.npen - 1) && (i == nlam - 1);
-            if (!last || A.compute_loss) gemv_round<R, NW, CW>(a, beta, ab, P, Uw, w, lane, buf OEM_DIAG_PASS);
+            // ab = A beta (warm start of the next lambda, and the loss) is already there from the last round, unless
+            // beta has just been rescaled in place
+            if (A.sinv) gemv_round<R, NW, CW>(a, beta, ab, P, Uw, w, lane, buf OEM_DIAG_PASS);
             if (A.compute_loss) {
                 // sum (Y - X beta)^2 on the standardised data (ref src/oem_dense.h:759-770) through the Gram identity
                 // yy - 2 n beta'XY + n beta' XX beta, with XX beta = d beta - A beta
