@@ -189,7 +189,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const size_t out_bytes = out_doubles * sizeof(double) + nk * sizeof(int32_t);
     const bool small = q <= SMALL_P_MAX;
     int lan = q < 128 ? q : 128;
-    const size_t work_d = small ? 0 : path_large_work_doubles(q, lan);
+    const size_t work_d = small ? path_small_xchg_bytes() / 8 : path_large_work_doubles(q, lan);
     const size_t a_blob = B.take(bl.h.size()), a_out = B.take(out_bytes), a_work = B.take(work_d * sizeof(double));
     // the workspace may be re-allocated by ctx_reserve: xx/xy/stats are offsets into it, so recompute after
     const size_t off_xx = (const char *)xx - c->ws, off_xy = (const char *)xy - c->ws, off_st = (const char *)stats - c->ws;
@@ -233,6 +233,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const double *hb = (const double *)c->pinned, *hl = hb + nb, *hloss = hl + nk, *hd = hloss + nk, *hs = hd + 4;
     const int32_t *hn = (const int32_t *)(hs + stats_len(p));
     *d_out = hd[0];
+    if (hd[1] < 0.0) { set_error("cooperating workgroups lost each other (exchange timeout)"); return OEMGPU_ERR_INTERNAL; }
     c->diag[0] = hd[2]; c->diag[1] = hd[3];
     const double meany = hs[0], scaley = hs[1];
     const double *meanx = hs + 4, *scalex = hs + 4 + p;
@@ -276,7 +277,7 @@ size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o)
     b += (size_t)o->npen * 4 + (size_t)o->npen * nl * 8 + (size_t)q * (8 + 8 + 4) + (size_t)(o->ngroups + 2) * 16 +
          (size_t)(o->ngroupvars + q + 2) * 4 + 4096;
     b += ((size_t)o->npen * nl * (q + 3) + 4 + stats_len(p)) * 8 + 4096;
-    if (q > SMALL_P_MAX) b += path_large_work_doubles(q, 128) * 8 + 4096;
+    b += (q > SMALL_P_MAX ? path_large_work_doubles(q, 128) * 8 : path_small_xchg_bytes()) + 4096;
     return b;
 }
 
@@ -517,7 +518,7 @@ int oemgpu_eig_max_dev(oemgpu_ctx *c, const double *a_dev, int32_t p, double *la
     Bump B;
     const size_t a_z = B.take((size_t)(p + 8) * 8), a_o = B.take(256);
     const int lan = p < 128 ? p : 128;
-    const size_t work_d = p <= SMALL_P_MAX ? 0 : path_large_work_doubles(p, lan);
+    const size_t work_d = p <= SMALL_P_MAX ? path_small_xchg_bytes() / 8 : path_large_work_doubles(p, lan);
     const size_t a_w = B.take(work_d * 8);
     if (ctx_reserve(c, B.off)) return OEMGPU_ERR_HIP;
     if (ctx_pinned(c, 16384)) return OEMGPU_ERR_HIP;

@@ -80,7 +80,8 @@ struct PathArgs {
     double *work;
 };
 
-static const int SMALL_P_MAX = 192;
+static const int SMALL_P_MAX = 256;     // <= 192: one workgroup; 193..256: four cooperating workgroups
+size_t path_small_xchg_bytes();
 int launch_path_small(hipStream_t s, const PathArgs &a);          // p <= SMALL_P_MAX: one fused launch
 int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch);   // any p: multi-launch engine
 size_t path_large_work_doubles(int p, int nsteps);

@@ -13,6 +13,7 @@
 #include "penalty_ops.hpp"
 
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 namespace oemgpu {
@@ -152,10 +153,9 @@ __global__ __launch_bounds__(1024) void lanczos_init_kernel(int q, double *__res
 }
 
 // w = M v is in `w`.  alpha_j = v.w ; w -= alpha v + beta_{j-1} v_prev ; beta_j = |w| ; v_prev = v ; v = w / beta_j
-__global__ __launch_bounds__(1024) void lanczos_update_kernel(int q, int j, double *__restrict__ v, double *__restrict__ vp,
-                                                               double *__restrict__ w, double *__restrict__ T)
+__device__ __forceinline__ void lanczos_update(int q, int j, double *__restrict__ v, double *__restrict__ vp,
+                                               double *__restrict__ w, double *__restrict__ T, double *sh)
 {
-    __shared__ double sh[16];
     double *al = T, *be = T + MAXL;
     if (j > 0 && !(be[j - 1] > 1e-13 * fabs(al[j - 1]))) {          // invariant subspace already reached
         if (threadIdx.x == 0) { al[j] = al[j - 1]; be[j] = 0.0; }
@@ -226,11 +226,9 @@ __global__ __launch_bounds__(1024) void path_init_kernel(PathArgs A, LState *st,
     }
 }
 
-__global__ __launch_bounds__(1024) void path_update_kernel(PathArgs A, LState *st, double *__restrict__ beta,
-                                                            const double *__restrict__ g)
+__device__ __forceinline__ void path_update(const PathArgs &A, LState *st, double *__restrict__ beta,
+                                            const double *__restrict__ g, double *dyn, double *sh)
 {
-    extern __shared__ __attribute__((aligned(16))) double dyn[];     // U[q] (group operand), F[ngroups]
-    __shared__ double sh[16];
     if (st->done) return;
     const int q = A.p, nl = A.nl, tid = threadIdx.x, nt = blockDim.x;
     const int pp = st->pp, i = st->i;
@@ -368,6 +366,21 @@ __global__ __launch_bounds__(1024) void path_update_kernel(PathArgs A, LState *s
     } else if (tid == 0) { st->it = it; st->ak = ak; st->reset_next = 0; st->pending_loss = -1; }
 }
 
+__global__ __launch_bounds__(1024) void path_update_kernel(PathArgs A, LState *st, double *__restrict__ beta,
+                                                            const double *__restrict__ g)
+{
+    extern __shared__ __attribute__((aligned(16))) double dyn[];     // U[q] (group operand), F[ngroups]
+    __shared__ double sh[16];
+    path_update(A, st, beta, g, dyn, sh);
+}
+
+__global__ __launch_bounds__(1024) void lanczos_update_kernel(int q, int j, double *__restrict__ v, double *__restrict__ vp,
+                                                               double *__restrict__ w, double *__restrict__ T)
+{
+    __shared__ double sh[16];
+    lanczos_update(q, j, v, vp, w, T, sh);
+}
+
 }  // namespace
 
 size_t path_large_work_doubles(int p, int nsteps)
@@ -384,12 +397,13 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
     LState *st = reinterpret_cast<LState *>(a.work);
-    static_assert(sizeof(LState) <= STATE_DBL * sizeof(double), "state block too small");
+    static_assert(sizeof(LState) + 16 <= STATE_DBL * sizeof(double), "state block too small");
     double *beta = a.work + STATE_DBL, *g = beta + (q + 8), *v = g + (q + 8), *vp = v + (q + 8), *w = vp + (q + 8);
     double *T = w + (q + 8);
     OEM_HIP(hipMemsetAsync(a.work, 0, sizeof(double) * path_large_work_doubles(q, 0), s));
 
-    // ---- eigenvalue step: Lanczos, checked every 32 steps on the host
+    // ---- eigenvalue step: Lanczos (GEMV + single-workgroup vector update), checked every
+    //      32 steps on the host, which is also the convergence test
     hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, s, q, v, vp);
     const int mmax = q < MAXL ? q : MAXL;
     double theta = 0.0, theta_prev = -1.0;
@@ -419,31 +433,49 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     OEM_HIP(hipGetLastError());
     if (a.npen == 0) return 0;
 
-    // ---- path: batches of (gemv, update) pairs; poll the done word once per batch
+    // ---- path: (gemv, update) pairs replayed in batches from a hipGraph (eager launches are host-bound at ~3.5 us
+    //      each); the host polls the done word once per batch.  Fusing the pair into one launch with a last-arriver
+    //      hand-off was measured and is NOT faster: the agent-scope release + acquire cost what the boundary costs.
     size_t sh = sizeof(double) * (size_t)(q + (a.ngroups > 0 ? a.ngroups : 0) + 8);
     if (sh > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&path_update_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %zu): %s", sh, hipGetErrorString(e)); return OEMGPU_ERR_HIP; }
     }
+    auto enqueue = [&](int count) {
+        for (int k = 0; k < count; ++k) {
+            (void)launch_gemv(s, a.xx, q, beta, g, &st->done, num_cu);
+            hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), sh, s, a, st, beta, g);
+        }
+    };
+    const int BATCH = 128;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        enqueue(BATCH);
+        if (hipStreamEndCapture(s, &graph) != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            graph = nullptr; exec = nullptr;
+            (void)hipGetLastError();
+        }
+    } else (void)hipGetLastError();
     const long long max_updates = (long long)a.npen * a.nl * ((long long)a.maxit + 2) + 8;
     long long launched = 0;
     int *hdone = reinterpret_cast<int *>(host_scratch);
-    const int BATCH = 64;
+    int rc = 0;
     for (;;) {
-        for (int k = 0; k < BATCH; ++k) {
-            int rc = launch_gemv(s, a.xx, q, beta, g, &st->done, num_cu);
-            if (rc) return rc;
-            hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), sh, s, a, st, beta, g);
-        }
-        OEM_HIP(hipGetLastError());
+        if (exec) { if (hipGraphLaunch(exec, s) != hipSuccess) { set_error("hipGraphLaunch failed"); rc = OEMGPU_ERR_HIP; break; } }
+        else enqueue(BATCH);
+        if (hipGetLastError() != hipSuccess) { set_error("large-p engine: launch failed"); rc = OEMGPU_ERR_HIP; break; }
         launched += BATCH;
-        OEM_HIP(hipMemcpyAsync(hdone, &st->done, sizeof(int), hipMemcpyDeviceToHost, s));
-        OEM_HIP(hipStreamSynchronize(s));
+        if (hipMemcpyAsync(hdone, &st->done, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { set_error("large-p engine: device error"); rc = OEMGPU_ERR_HIP; break; }
         if (*hdone) break;
-        if (launched > max_updates) { set_error("large-p engine did not finish within %lld updates", max_updates); return OEMGPU_ERR_INTERNAL; }
+        if (launched > max_updates) { set_error("large-p engine did not finish within %lld updates", max_updates); rc = OEMGPU_ERR_INTERNAL; break; }
     }
-    return 0;
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
 }
 
 }  // namespace oemgpu

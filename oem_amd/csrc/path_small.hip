@@ -25,6 +25,9 @@
 
 namespace oemgpu {
 
+// granule exchange buffer of the cooperating-workgroup form: [2 parities][4 workgroups][256 rows][2 granules]
+size_t path_small_xchg_bytes() { return (size_t)2 * 4 * 256 * 2 * sizeof(unsigned long long); }
+
 namespace {
 
 // -DOEM_PATH_DIAG: a diagnostic build that splits the round into stamped segments (cycles summed per wave 0).
@@ -136,17 +139,92 @@ template <int R, int NW, int CW> struct Cfg {
     static constexpr int N_DBL = OFF_I + (3 * PR + 4) / 2 + 2;
 };
 
-// one GEMV round: out = M vec, M = the register-resident matrix.  One workgroup barrier.
-template <int R, int NW, int CW>
+// ---- cooperating workgroups (G > 1: 192 < p <= 256).  Each workgroup holds a column slice of the matrix and ends a
+// round with its partial sums of every row; the G partial vectors are exchanged through L2 as data-tagged 8-byte
+// granules {tag = round epoch, 32 value bits} (guide 6 G16, recipe R2: one aligned atomic store per granule, the data IS
+// the flag, no fence; polls are relaxed agent-scope loads that bypass L1).  Two buffers by round parity: a workgroup
+// can publish round t+1 while a slower one still reads round t, and cannot reach t+2 without that one's t+1.
+// Every spin is bounded; a timeout poisons the result (theta = -1) and lets every workgroup run out quickly.
+struct Xchg {
+    unsigned long long *buf;     // [2][G][PR][2] granules
+    unsigned epoch;              // round counter, never 0; identical in every workgroup (all decisions are replicated)
+    int gidx;                    // this workgroup's index
+    bool failed;
+};
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+template <int R, int G>
+__device__ __forceinline__ void exchange_partials(Xchg &X, double (&out)[R], double *scratch, int w, int lane)
+{
+    // wave 0 publishes this workgroup's partial sums; wave g (g < G, g != own) alone polls producer g -- one poller
+    // per producer keeps the L2 polling traffic an eighth of "every wave polls everyone" -- and drops its vector into
+    // LDS; after one workgroup barrier every wave adds the G vectors in producer order (identical bits everywhere).
+    constexpr int PR = 64 * R;
+    ++X.epoch;
+    gu64 *base = (gu64 *)X.buf + (size_t)(X.epoch & 1) * G * PR * 2;
+    if (w == 0) {
+        gu64 *mine = base + (size_t)X.gidx * PR * 2;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned lo = (unsigned)__double2loint(out[r]), hi = (unsigned)__double2hiint(out[r]);
+            const size_t o = (size_t)(lane + 64 * r) * 2;
+            __hip_atomic_store(mine + o, ((unsigned long long)X.epoch << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + o + 1, ((unsigned long long)X.epoch << 32) | hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (w < G) {
+        if (w == X.gidx) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) scratch[w * PR + lane + 64 * r] = out[r];
+        } else {
+            const gu64 *src = base + (size_t)w * PR * 2;
+            unsigned long long v[2 * R];
+            bool ok = false;
+            for (unsigned spins = 0; !ok; ++spins) {
+                bool all = true;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const size_t o = (size_t)(lane + 64 * r) * 2;
+                    v[2 * r] = __hip_atomic_load(src + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v[2 * r + 1] = __hip_atomic_load(src + o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    all &= ((unsigned)(v[2 * r] >> 32) == X.epoch) & ((unsigned)(v[2 * r + 1] >> 32) == X.epoch);
+                }
+                ok = __all(all);
+                if (!ok && spins > 1000000u) break;                 // ~1 s: the partner is gone
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                scratch[w * PR + lane + 64 * r] = ok ? __hiloint2double((int)(unsigned)v[2 * r + 1], (int)(unsigned)v[2 * r])
+                                                     : __builtin_nan("");   // poison: every wave sees the failure below
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) t += scratch[g * PR + lane + 64 * r];
+        out[r] = t;
+    }
+    // a timed-out poller wrote NaNs: detect them uniformly (rows beyond p are exact zeros, real data is finite)
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) bad |= (out[r] != out[r]);
+    if (__any(bad)) X.failed = true;
+}
+
+// one GEMV round: out = M vec, M = the register-resident matrix.  One workgroup barrier (plus, for G > 1, one
+// granule exchange between the cooperating workgroups).
+template <int R, int NW, int CW, int G>
 __device__ __forceinline__ void gemv_round(const double (&a)[R][CW], const double (&vec)[R], double (&out)[R],
-                                           double *P, double *Uw, int w, int lane, int &buf OEM_DIAG_ARGS)
+                                           double *P, double *Uw, int w, int lane, int &buf, Xchg &X OEM_DIAG_ARGS)
 {
     constexpr int PR = 64 * R;
     OEM_STAMP(0);                       // everything since the previous round's partial sums (threshold, stop rule)
 #pragma unroll
     for (int r = 0; r < R; ++r) Uw[lane + 64 * r] = vec[r];
     // all CW/2 broadcast reads are issued before the first FMA: one LDS latency per round instead of CW/2
-    const v2d *bc = reinterpret_cast<const v2d *>(Uw + w * CW);     // same wave: DS ops execute in order
+    const v2d *bc = reinterpret_cast<const v2d *>(Uw + (X.gidx * NW + w) * CW);     // same wave: DS ops execute in order
     v2d b[CW / 2];
 #pragma unroll
     for (int k = 0; k < CW / 2; ++k) b[k] = bc[k];                   // uniform address: LDS broadcast
@@ -178,18 +256,19 @@ __device__ __forceinline__ void gemv_round(const double (&a)[R][CW], const doubl
             for (int ww = 0; ww + h < NW; ww += 2 * h) t[ww] += t[ww + h];
         out[r] = t[0];
     }
-    OEM_STAMP(3);                       // partial reads + adds
+    if (G > 1) exchange_partials<R, G>(X, out, P + (buf ^ 1) * NW * PR, w, lane);   // the idle half of P as scratch
+    OEM_STAMP(3);                       // partial reads + adds (+ exchange)
     buf ^= 1;
 }
 
 // The OEM iteration for one lambda (ref src/oem_base.h:90-110), specialised per operator so that the serial loop
 // carries only the arithmetic of the penalty in use.  KIND == K_GRP covers every group penalty (K.kind selects).
-template <int R, int NW, int CW, int KIND>
+template <int R, int NW, int CW, int G, int KIND>
 __device__ __forceinline__ void iterate(const PathArgs &A, const PenK &K, double d, const double (&a)[R][CW],
                                         const double (&xy)[R], const double (&pf)[R], const int (&gid)[R],
                                         double (&beta)[R], double (&bold)[R], double (&ab)[R], double &ak, int &it,
                                         int &conv, double *P, double *Uw, double *Fw, const int *gstart,
-                                        const int *gidx, const int *gzero, int ng, int w, int lane, int &buf OEM_DIAG_ARGS)
+                                        const int *gidx, const int *gzero, int ng, int w, int lane, int &buf, Xchg &X OEM_DIAG_ARGS)
 {
     double tp[R];
 #pragma unroll
@@ -280,13 +359,13 @@ __device__ __forceinline__ void iterate(const PathArgs &A, const PenK &K, double
             bad |= (cn != qn);
             bad |= (cn && qn && fabs(beta[r] - bold[r]) > tol * q);
         }
-        gemv_round<R, NW, CW>(a, beta, ab, P, Uw, w, lane, buf OEM_DIAG_PASS);
+        gemv_round<R, NW, CW, G>(a, beta, ab, P, Uw, w, lane, buf, X OEM_DIAG_PASS);
         conv = (__ballot(bad) == 0ull);
         if (conv || it >= A.maxit) break;
     }
 }
 
-template <int R, int NW, int CW>
+template <int R, int NW, int CW, int G>
 __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
 {
     typedef Cfg<R, NW, CW> C;
@@ -310,7 +389,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
         const int row = lane + 64 * r;
 #pragma unroll
         for (int k = 0; k < CW; ++k) {
-            const int col = w * CW + k;
+            const int col = (blockIdx.x * NW + w) * CW + k;
             a[r][k] = (row < p && col < p) ? A.xx[(size_t)col * p + row] : 0.0;
         }
     }
@@ -334,6 +413,9 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
     }
     __syncthreads();
     int buf = 0;
+    Xchg X;
+    X.buf = reinterpret_cast<unsigned long long *>(A.work); X.epoch = 0; X.gidx = blockIdx.x; X.failed = false;
+    const bool writer = (blockIdx.x == 0);          // workgroup 0 writes the results (all hold identical copies)
     OEM_DIAG_DECL
 
     // ---- eigenvalue step: m-step Lanczos on XX
@@ -357,7 +439,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
     int nst = 0;
     double bprev = 0.0;
     for (int j = 0; j < msteps; ++j) {
-        gemv_round<R, NW, CW>(a, v, wv, P, Uw, w, lane, buf OEM_DIAG_PASS);
+        gemv_round<R, NW, CW, G>(a, v, wv, P, Uw, w, lane, buf, X OEM_DIAG_PASS);
         double al = 0.0;
 #pragma unroll
         for (int r = 0; r < R; ++r) al = fma(v[r], wv[r], al);
@@ -382,7 +464,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
 #endif
     const double theta = tridiag_max(Tal, Tbe, nst, lane);
     const double d = theta * 1.005;                       // ref src/oem_dense.h:498
-    if (tid == 0) { A.d_out[0] = d; A.d_out[1] = theta; }
+    if (tid == 0 && writer) { A.d_out[0] = d; A.d_out[1] = theta; }
 
     // ---- A = d I - XX   (ref src/oem_dense.h:501-505)
 #pragma unroll
@@ -390,7 +472,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
         const int row = lane + 64 * r;
 #pragma unroll
         for (int k = 0; k < CW; ++k) {
-            const int col = w * CW + k;
+            const int col = (blockIdx.x * NW + w) * CW + k;
             a[r][k] = ((row == col && row < p) ? d : 0.0) - a[r][k];
         }
     }
@@ -427,24 +509,24 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
                 lam = exp(lv);
                 if (isnet) lam = lam / A.alpha;
             }
-            if (tid == 0) A.lambda_out[(size_t)pp * nl + i] = lam;
+            if (tid == 0 && writer) A.lambda_out[(size_t)pp * nl + i] = lam;
             if (i >= nlam) continue;
             const double il = lam / scaley;                               // ref src/oem_dense.cpp:241
             const PenK K = pen_consts(pen, il, d, A.alpha, A.gamma, A.tau);
             int it = 0, conv = 0;
             switch (K.kind) {
-            case K_SOFT: iterate<R, NW, CW, K_SOFT>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf OEM_DIAG_PASS); break;
-            case K_MCP: iterate<R, NW, CW, K_MCP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf OEM_DIAG_PASS); break;
-            case K_SCAD: iterate<R, NW, CW, K_SCAD>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf OEM_DIAG_PASS); break;
-            case K_OLS: iterate<R, NW, CW, K_OLS>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf OEM_DIAG_PASS); break;
-            default: iterate<R, NW, CW, K_GRP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf OEM_DIAG_PASS); break;
+            case K_SOFT: iterate<R, NW, CW, G, K_SOFT>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
+            case K_MCP: iterate<R, NW, CW, G, K_MCP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
+            case K_SCAD: iterate<R, NW, CW, G, K_SCAD>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
+            case K_OLS: iterate<R, NW, CW, G, K_OLS>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
+            default: iterate<R, NW, CW, G, K_GRP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
             }
             // oemXTX::get_beta rescales the member in place (ref src/oem_xtx.h:576-581, quirk Q5)
             if (A.sinv) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) beta[r] *= sinv[r];
             }
-            if (w == 0) {
+            if (w == 0 && writer) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int row = lane + 64 * r;
@@ -454,7 +536,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
             }
             // ab = A beta (warm start of the next lambda, and the loss) is already there from the last round, unless
             // beta has just been rescaled in place
-            if (A.sinv) gemv_round<R, NW, CW>(a, beta, ab, P, Uw, w, lane, buf OEM_DIAG_PASS);
+            if (A.sinv) gemv_round<R, NW, CW, G>(a, beta, ab, P, Uw, w, lane, buf, X OEM_DIAG_PASS);
             if (A.compute_loss) {
                 // sum (Y - X beta)^2 on the standardised data (ref src/oem_dense.h:759-770) through the Gram identity
                 // yy - 2 n beta'XY + n beta' XX beta, with XX beta = d beta - A beta
@@ -462,29 +544,31 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
 #pragma unroll
                 for (int r = 0; r < R; ++r) t += beta[r] * ((d * beta[r] - ab[r]) - 2.0 * xy[r]);
                 t = wave_sum(t);
-                if (tid == 0) A.loss[(size_t)pp * nl + i] = yy + nobs * t;
-            } else if (tid == 0) A.loss[(size_t)pp * nl + i] = 1e99;
+                if (tid == 0 && writer) A.loss[(size_t)pp * nl + i] = yy + nobs * t;
+            } else if (tid == 0 && writer) A.loss[(size_t)pp * nl + i] = 1e99;
         }
     }
 #ifdef OEM_PATH_DIAG
     if (tid == 0) for (int k = 0; k < 8; ++k) g_diag[k] = diag_acc[k];
 #endif
-    if (tid == 0) {
+    if (tid == 0 && writer) {
         A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
         A.d_out[3] = (double)(__builtin_amdgcn_s_memrealtime() - t_rt0);
     }
+    if (X.failed && lane == 0) A.d_out[1] = -1.0;     // exchange timeout: poison (host turns it into an error)
 }
 
-template <int R, int NW, int CW> int launch_cfg(hipStream_t s, const PathArgs &a)
+template <int R, int NW, int CW, int G = 1> int launch_cfg(hipStream_t s, const PathArgs &a)
 {
     typedef Cfg<R, NW, CW> C;
     const size_t sh = (size_t)C::N_DBL * sizeof(double);
+    if (G > 1) OEM_HIP(hipMemsetAsync(a.work, 0, path_small_xchg_bytes(), s));      // granule tags must start at 0
     if (sh > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&path_small_kernel<R, NW, CW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&path_small_kernel<R, NW, CW, G>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %zu): %s", sh, hipGetErrorString(e)); return OEMGPU_ERR_HIP; }
     }
-    hipLaunchKernelGGL((path_small_kernel<R, NW, CW>), dim3(1), dim3(NW * 64), sh, s, a);
+    hipLaunchKernelGGL((path_small_kernel<R, NW, CW, G>), dim3(G), dim3(NW * 64), sh, s, a);
     OEM_HIP(hipGetLastError());
     return 0;
 }
@@ -509,6 +593,7 @@ int launch_path_small(hipStream_t s, const PathArgs &a)
     if (a.p <= 128) return launch_cfg<2, 4, 32>(s, a);
     if (a.p <= 160) return launch_cfg<3, 8, 20>(s, a);
     if (a.p <= 192) return launch_cfg<3, 8, 24>(s, a);
+    if (a.p <= 256) return launch_cfg<4, 8, 8, 4>(s, a);          // four cooperating workgroups, 64 columns each
     set_error("path_small: p = %d exceeds %d", a.p, SMALL_P_MAX);
     return OEMGPU_ERR_INTERNAL;
 }

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Times BASELINE.json configs 2-5 (and config 1 host-resident) on one MI355X next to the CPU oracle.
+Writes one JSON document (profiles/rNN_config_times.json is a copy of its output)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import oem_amd
+from oracle import oracle as orc
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+
+
+out = {}
+rng = np.random.default_rng(123)
+
+# config 2: n=5000, p=200, MCP gamma=2 / SCAD gamma=4, 200 lambdas, tol 1e-10, standardize + intercept
+n, p, m = 5000, 200, 25
+b = np.concatenate([rng.uniform(-0.5, 0.5, m), np.zeros(p - m)])
+x = np.asfortranarray(rng.normal(size=(n, p)) * 3.0); y = x @ b + rng.normal(size=n)
+xd = dev(x)
+for pen, gam in (("mcp", 2.0), ("scad", 4.0)):
+    kw = dict(penalty=pen, gamma=gam, nlambda=200, tol=1e-10)
+    t_gpu = timeit(lambda: oem_amd.oem(xd, y, **kw), 3)
+    t0 = time.perf_counter(); ref = orc.fit_dense(x, y, native=True, **kw); t_cpu = time.perf_counter() - t0
+    fit = oem_amd.oem(xd, y, **kw)
+    out[f"config2_{pen}"] = {"gpu_ms": 1e3 * t_gpu, "cpu_port_1thread_ms": 1e3 * t_cpu, "iterations": int(fit["niter"][0].sum()),
+                             "max_abs_err": float(np.abs(fit["beta"][0] - ref["beta"][0]).max()),
+                             "reference_readme_ms": 105.9 if pen == "mcp" else 80.2}
+
+# config 3: n=1e6, p=512, 64 groups of 8, grp.lasso, 100 lambdas, tol 1e-10, no intercept / standardize
+n, p = 1_000_000, 512
+g = torch.Generator(device="cuda"); g.manual_seed(3)
+xt = torch.randn((p, n), generator=g, device="cuda", dtype=torch.float64)
+bb = torch.zeros(p, dtype=torch.float64, device="cuda"); bb[:24] = torch.rand(24, generator=g, device="cuda", dtype=torch.float64) - 0.5
+yd = (xt.t() @ bb + torch.randn(n, generator=g, device="cuda", dtype=torch.float64)).contiguous()
+groups = np.repeat(np.arange(1, 65), 8)
+kw = dict(penalty="grp.lasso", groups=groups, nlambda=100, tol=1e-10, standardize=False, intercept=False)
+t_gpu = timeit(lambda: oem_amd.oem(xt.t(), yd, **kw), 2)
+fit = oem_amd.oem(xt.t(), yd, **kw)
+from oem_amd import _lib as L
+import ctypes as C
+ctx = oem_amd.context()
+L.check(L.lib().oemgpu_set_timing(ctx, 1)); oem_amd.oem(xt.t(), yd, **kw)
+ms = (C.c_double * L.NTIMERS)(); L.check(L.lib().oemgpu_last_timings(ctx, ms)); L.check(L.lib().oemgpu_set_timing(ctx, 0))
+flops = float(n) * p * (p + 1) + 2.0 * n * p
+out["config3_grp_lasso_p512"] = {"gpu_ms": 1e3 * t_gpu, "gram_kernel_ms": ms[L.T_GRAMK], "gram_TFLOPs": flops / (ms[L.T_GRAMK] * 1e-3) / 1e12,
+                                 "eigen_plus_path_ms": ms[L.T_EIGPATH], "iterations": int(fit["niter"][0].sum())}
+del xt, yd
+
+# config 4: oem.xtx p=4096, 100-lambda lasso, tol 1e-10
+p, n = 4096, 65536
+x = rng.normal(size=(n, p)); b = np.zeros(p); b[:25] = rng.uniform(-1, 1, 25); y = x @ b + rng.normal(size=n)
+xtx, xty = x.T @ x / n, x.T @ y / n
+xtxd = torch.as_tensor(xtx, device="cuda")
+kw = dict(penalty="lasso", nlambda=100, tol=1e-10)
+t_gpu = timeit(lambda: oem_amd.oem_xtx(xtxd, xty, **kw), 1)
+fit = oem_amd.oem_xtx(xtxd, xty, **kw)
+its = int(fit["niter"][0].sum())
+out["config4_xtx_p4096"] = {"gpu_ms": 1e3 * t_gpu, "iterations": its, "gemv_bytes_per_iteration": 8.0 * p * p + 24 * p,
+                            "note": "includes ~100+ Lanczos GEMVs; per-iteration = one 134 MB GEMV + one update kernel",
+                            "approx_GBps_over_all_gemvs": (its + 130) * (8.0 * p * p) / t_gpu / 1e9}
+del xtxd, x
+
+# config 5 semantics on one GPU: big.oem n=4e6 (of 1e8), p=256, lasso, device resident via the sharded driver
+from oem_amd.distributed import HipBackend, oem_sharded
+n, p = 4_000_000, 256
+g.manual_seed(5)
+xt = torch.randn((p, n), generator=g, device="cuda", dtype=torch.float64)
+bb = torch.zeros(p, dtype=torch.float64, device="cuda"); bb[:20] = torch.rand(20, generator=g, device="cuda", dtype=torch.float64)
+yd = (xt.t() @ bb + torch.randn(n, generator=g, device="cuda", dtype=torch.float64)).contiguous()
+be = HipBackend()
+t_gpu = timeit(lambda: oem_sharded(xt.t(), yd, backend=be, big=True, penalty="lasso", nlambda=100, tol=1e-10), 2)
+out["config5_big_p256_n4e6_one_gpu"] = {"gpu_ms": 1e3 * t_gpu, "rows": n, "note": "1/25 of the 1e8-row config; one rank's share at 8 GPUs is 1.25e7 rows"}
+del xt, yd
+
+# config 1, host-resident X through oemgpu_fit_dense (PCIe inclusive)
+n, p = 1_000_000, 100
+x = np.asfortranarray(rng.normal(size=(n, p)) * 3.0); b = np.concatenate([rng.uniform(size=25), np.zeros(75)]); y = x @ b + rng.normal(size=n)
+kw = dict(penalty="elastic.net", standardize=False, tol=1e-10)
+t = timeit(lambda: oem_amd.oem(x, y, **kw), 2)
+out["config1_host_resident"] = {"ms": 1e3 * t, "note": "800 MB pageable host->device copy + hipMalloc/hipFree per call"}
+print(json.dumps(out, indent=1))
