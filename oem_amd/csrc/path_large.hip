@@ -65,36 +65,47 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
 // g = M vec for symmetric column-major M (q x q): row r is the contiguous column r.  One wave per row, the vector
 // held in registers (VPL doubles per lane), each row read with 1 KiB-coalesced dwordx4 loads.
 // ------------------------------------------------------------------------------------------------
-template <int VPL, bool ALIGNED>
+// FULL: q == 64 VPL exactly and 16-byte aligned rows, so there is no bounds logic at all (q = 512, 1024, 2048, 4096).
+// Otherwise out-of-range columns read a clamped address and are multiplied by 0 (branch-free; hipcc turns
+// per-element guards into exec-mask branches around every load, which serialises the stream).
+template <int VPL, bool ALIGNED, bool FULL>
 __global__ __launch_bounds__(256) void gemv_sym_kernel(const double *__restrict__ M, int q, const double *__restrict__ vec,
                                                         double *__restrict__ out, const int *__restrict__ done)
 {
-    if (done && *done) return;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
-    double v[VPL];
+    const int dn = done ? *done : 0;                      // consumed only after the loads below are in flight
+    v2d v[VPL / 2];
+    int off[VPL / 2];
+    double msk0[FULL ? 1 : VPL / 2], msk1[FULL ? 1 : VPL / 2];
 #pragma unroll
     for (int j = 0; j < VPL / 2; ++j) {
         const int c = 2 * lane + 128 * j;
-        v[2 * j] = c < q ? vec[c] : 0.0;
-        v[2 * j + 1] = c + 1 < q ? vec[c + 1] : 0.0;
+        if (FULL) { off[j] = c; v[j] = *reinterpret_cast<const v2d *>(vec + c); }
+        else {
+            const int c0 = c < q ? c : q - 1, c1 = c + 1 < q ? c + 1 : q - 1;
+            msk0[j] = c < q ? 1.0 : 0.0; msk1[j] = c + 1 < q ? 1.0 : 0.0;
+            off[j] = (ALIGNED && c + 1 < q) ? c : c0;
+            v[j].x = vec[c0] * msk0[j]; v[j].y = vec[c1] * msk1[j];
+            if (!(ALIGNED && c + 1 < q)) { /* unaligned or edge pair: scalar loads below */ }
+        }
     }
+    if (dn) return;
     for (int r = wave; r < q; r += nwave) {
         const double *row = M + (size_t)r * q;
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int j = 0; j < VPL / 2; ++j) {
-            const int c = 2 * lane + 128 * j;
-            double m0 = 0.0, m1 = 0.0;
-            if (ALIGNED) {
-                if (c + 1 < q) { const v2d t = *reinterpret_cast<const v2d *>(row + c); m0 = t.x; m1 = t.y; }
-                else if (c < q) m0 = row[c];
+            if (FULL) {
+                const v2d t = *reinterpret_cast<const v2d *>(row + off[j]);
+                a0 = fma(t.x, v[j].x, a0);
+                a1 = fma(t.y, v[j].y, a1);
             } else {
-                if (c < q) m0 = row[c];
-                if (c + 1 < q) m1 = row[c + 1];
+                const int c = 2 * lane + 128 * j;
+                const int c0 = c < q ? c : q - 1, c1 = c + 1 < q ? c + 1 : q - 1;
+                a0 = fma(row[c0], v[j].x, a0);           // v is already 0 where the column does not exist
+                a1 = fma(row[c1], v[j].y, a1);
             }
-            a0 = fma(m0, v[2 * j], a0);
-            a1 = fma(m1, v[2 * j + 1], a1);
         }
         const double s = wsum(a0 + a1);
         if (lane == 0) out[r] = s;
@@ -120,12 +131,14 @@ __global__ __launch_bounds__(256) void gemv_sym_generic_kernel(const double *__r
 int launch_gemv(hipStream_t s, const double *M, int q, const double *vec, double *out, const int *done, int num_cu)
 {
     int blocks = (q + 3) / 4;
-    if (blocks > num_cu * 4) blocks = num_cu * 4;
+    if (blocks > num_cu * 2) blocks = num_cu * 2;       // two 4-wave workgroups per CU, >= 2 rows per wave at q = 4096
     const bool al = (q % 2 == 0) && (((uintptr_t)M & 15) == 0);
+    const bool vec_al = (((uintptr_t)vec & 15) == 0);
 #define OEM_GEMV(V)                                                                                              \
     do {                                                                                                         \
-        if (al) hipLaunchKernelGGL((gemv_sym_kernel<V, true>), dim3(blocks), dim3(256), 0, s, M, q, vec, out, done);   \
-        else hipLaunchKernelGGL((gemv_sym_kernel<V, false>), dim3(blocks), dim3(256), 0, s, M, q, vec, out, done);     \
+        if (al && vec_al && q == 64 * V)                                                                         \
+            hipLaunchKernelGGL((gemv_sym_kernel<V, true, true>), dim3(blocks), dim3(256), 0, s, M, q, vec, out, done); \
+        else hipLaunchKernelGGL((gemv_sym_kernel<V, false, false>), dim3(blocks), dim3(256), 0, s, M, q, vec, out, done); \
     } while (0)
     if (q <= 512) OEM_GEMV(8);
     else if (q <= 1024) OEM_GEMV(16);
@@ -223,6 +236,28 @@ __global__ __launch_bounds__(1024) void path_init_kernel(PathArgs A, LState *st,
         st->ak = 1.0; st->d = d; st->theta = theta;
         st->lmax = mm * (A.yscale ? A.stats[1] : 1.0);
         A.d_out[0] = d; A.d_out[1] = theta; A.d_out[2] = 0.0; A.d_out[3] = 0.0;
+        sh[0] = st->lmax;
+    }
+    __syncthreads();
+    // the whole lambda table once (ref src/oem_dense.cpp:175-227); the update kernel then only indexes it
+    const double lmax = sh[0];
+    const int nl = A.nl;
+    const double llo = log(lmax), lhi = log(A.lambda_min_ratio * lmax);
+    const double lstep = nl > 1 ? (lhi - llo) / (double)(nl - 1) : 0.0;
+    const bool lflip = fabs(lhi) < fabs(llo);
+    for (int idx = threadIdx.x; idx < A.npen * nl; idx += blockDim.x) {
+        const int pp = idx / nl, k = idx % nl;
+        double l;
+        if (A.user_lambda) l = A.lambda_user[idx];
+        else {
+            double lv;
+            if (nl == 1) lv = lhi;
+            else if (lflip) lv = (k == 0) ? llo : lhi - (double)(nl - 1 - k) * lstep;
+            else lv = (k == nl - 1) ? lhi : llo + (double)k * lstep;
+            l = exp(lv);
+            if (pen_is_net(A.penalty[pp])) l = l / A.alpha;
+        }
+        A.lambda_out[idx] = l;
     }
 }
 
@@ -254,24 +289,8 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
     const bool reset = st->reset_next != 0;
     const int pen = A.penalty[pp];
     const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
-    const bool isnet = pen_is_net(pen);
 
-    // ---- lambda grid (ref src/oem_dense.cpp:175-227)
-    const double llo = log(st->lmax), lhi = log(A.lambda_min_ratio * st->lmax);
-    const double lstep = nl > 1 ? (lhi - llo) / (double)(nl - 1) : 0.0;
-    const bool lflip = fabs(lhi) < fabs(llo);
-    auto lambda_at = [&](int k) -> double {
-        if (A.user_lambda) return A.lambda_user[(size_t)pp * nl + k];
-        double lv;
-        if (nl == 1) lv = lhi;
-        else if (lflip) lv = (k == 0) ? llo : lhi - (double)(nl - 1 - k) * lstep;
-        else lv = (k == nl - 1) ? lhi : llo + (double)k * lstep;
-        const double l = exp(lv);
-        return isnet ? l / A.alpha : l;
-    };
-    if (reset)
-        for (int k = tid; k < nl; k += nt) A.lambda_out[(size_t)pp * nl + k] = lambda_at(k);
-    const double lam = lambda_at(i);
+    const double lam = A.lambda_out[(size_t)pp * nl + i];          // table written by path_init_kernel
     const PenK K = pen_consts(pen, lam / scaley, d, A.alpha, A.gamma, A.tau);
     const double rD = 1.0 / K.D, gammad = K.gamma * K.D, dmg = K.D - 1.0 / K.gamma, rdmg = 1.0 / dmg;
     const double gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0, rdsc = 1.0 / dsc;
