@@ -87,8 +87,8 @@ def main():
     # arguments marshalled once, then per step: shift sample -> moments -> [all-reduce] -> solve (results on host).
     args = api._Args(["elastic.net"], [np.asarray(lambdas)], 100, 1e-4, 1.0, 3.0, 0.5, 1e-10, 500, False, False,
                      np.ones(p), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0))
-    sums = backend.new_buffer(p + 2)
-    mom = backend.new_buffer((p + 2) * (p + 2))
+    sums = backend.new_buffer(L.sums_len(p))
+    mom = backend.new_buffer(L.moments_len(p))
 
     def solve(lam=None, tol=None):
         backend.shift_sums(x, n_loc, n_loc, p, y, sums)

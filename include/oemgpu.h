@@ -117,13 +117,18 @@ int         oemgpu_synchronize(oemgpu_ctx *ctx);
  * Moments add over row shards that use the same shift, which is what the RCCL all-reduce sums. */
 static inline int64_t oemgpu_moments_len(int32_t p) { return (int64_t)(p + 2) * (p + 2); }
 
-/* Sample sums for the provisional shift: sums_dev[0..p-1] = sum over the sampled rows of x_j,
- * sums_dev[p] = same for y, sums_dev[p+1] = number of sampled rows.  (all-reduce these, then
- * c = sums / count). */
+/* Sample sums for the provisional shift (oemgpu_sums_len(p) doubles): sums_dev[0..p-1] = sum over the sampled
+ * rows of x_j, sums_dev[p] = same for y, sums_dev[p+1] = number of sampled rows, sums_dev[p+2 .. 2p+2] = the
+ * sampled sums of squares of the same p+1 columns, sums_dev[2p+3] = 0.  All-reduce the whole buffer across row
+ * shards.  The shift in effect is then a pure function of the buffer (identical in every kernel and rank):
+ *   c_j = sums[j] / sums[p+1]  if ANY column has mean_j^2 > 2^8 var_j (sample mean / variance), else c = 0
+ * -- un-shifted accumulation costs (mean/sd)^2 eps of relative accuracy on the centred moments, and is used when
+ * that is < 6e-14 because every x - c is an FP64 VALU op competing with the FP64 MFMA for the DP units. */
+static inline int64_t oemgpu_sums_len(int32_t p) { return 2 * (int64_t)(p + 1) + 2; }
 int oemgpu_shift_sums_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64_t ld, int32_t p,
                           const double *y_dev, double *sums_dev);
 
-/* moments_dev <- moments of rows [0,n) about the shift c = sums[0..p] / sums[p+1] (sums_dev: the (all-reduced)
+/* moments_dev <- moments of rows [0,n) about the shift c defined above (sums_dev: the (all-reduced)
  * output of oemgpu_shift_sums_dev; NULL => c = 0).
  * Replaces DataStd's passes + X'Y + XtX (ref src/DataStd.h:203-265, src/oem_dense.h:318-361,704-707;
  * src/oem_big.h:743-841) with ONE pass over X. */

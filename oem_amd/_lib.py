@@ -94,3 +94,13 @@ def lib():
 def check(rc):
     if rc != 0:
         raise OemgpuError(rc, lib().oemgpu_last_error().decode())
+
+
+def sums_len(p):
+    """include/oemgpu.h oemgpu_sums_len: sample sums, count, sample sums of squares, one reserved slot"""
+    return 2 * (p + 1) + 2
+
+
+def moments_len(p):
+    """include/oemgpu.h oemgpu_moments_len"""
+    return (p + 2) * (p + 2)

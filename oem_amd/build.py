@@ -32,8 +32,10 @@ def audit_gram_isa(asm_text):
     (csrc/gen/acc_tiles.inc).  That is only sound if hipcc itself never touches the accumulator
     file and never spills in those kernels: check both in the emitted ISA."""
     problems = []
-    for m in re.finditer(r"^(_ZN6oemgpu1[567]gram_(?:tri|blk|ring)_kernel\w+):\n(.*?)\n\s*s_endpgm", asm_text, re.S | re.M):
+    found = 0
+    for m in re.finditer(r"^(_ZN6oemgpu1[567]gram_(?:tri|blk|ring)_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end", asm_text, re.S | re.M):
         name, body = m.group(1), m.group(2)
+        found += 1
         in_asm = False
         for line in body.splitlines():
             if "#ASMSTART" in line:
@@ -46,6 +48,8 @@ def audit_gram_isa(asm_text):
                 problems.append(f"{name}: scratch access {line.strip()}")
             if "flat_load" in line:
                 problems.append(f"{name}: flat_load (drains the prefetch) {line.strip()}")
+    if found == 0:
+        problems.append("no Gram kernel found in the ISA listing (the audit pattern is stale)")
     return problems
 
 

@@ -431,7 +431,7 @@ int oemgpu_solve_moments_dev(oemgpu_ctx *c, const double *moments_dev, const dou
     if ((const char *)moments_dev >= c->ws && (const char *)moments_dev < c->ws + c->ws_bytes)
         base = ((const char *)moments_dev - c->ws) + (size_t)oemgpu_moments_len(p) * 8;
     if (sums_dev && (const char *)sums_dev >= c->ws && (const char *)sums_dev < c->ws + c->ws_bytes) {
-        size_t e = ((const char *)sums_dev - c->ws) + (size_t)(p + 2) * 8;
+        size_t e = ((const char *)sums_dev - c->ws) + (size_t)oemgpu_sums_len(p) * 8;
         if (e > base) base = e;
     }
     base = (base + 255) / 256 * 256;
@@ -462,7 +462,7 @@ int oemgpu_fit_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t 
     if (set_device(c)) return OEMGPU_ERR_HIP;
     const GramPlan pl = gram_plan(n, p, c->num_cu);
     Bump B;
-    const size_t a_sums = B.take((size_t)(p + 2) * 8), a_mom = B.take((size_t)oemgpu_moments_len(p) * 8);
+    const size_t a_sums = B.take((size_t)oemgpu_sums_len(p) * 8), a_mom = B.take((size_t)oemgpu_moments_len(p) * 8);
     const size_t frame = B.off;
     const size_t a_t = B.take(pl.tpart_doubles * 8), a_v = B.take(pl.vpart_doubles * 8);
     size_t need = B.off;
@@ -617,14 +617,14 @@ int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_
     // device buffer twice (sample sums for the common shift, then the moments) and add the shard moments.
     double *xd = nullptr, *yd = nullptr, *acc = nullptr;
     const int64_t ldmax = (nmax + 1) / 2 * 2;
-    const size_t mlen = (size_t)oemgpu_moments_len(p);
+    const size_t mlen = (size_t)oemgpu_moments_len(p), slen = (size_t)oemgpu_sums_len(p);
     hipError_t e = hipMalloc((void **)&xd, sizeof(double) * (size_t)ldmax * p);
     if (e == hipSuccess) e = hipMalloc((void **)&yd, sizeof(double) * (size_t)(ldmax + 2));
-    if (e == hipSuccess) e = hipMalloc((void **)&acc, sizeof(double) * (2 * mlen + 2 * (size_t)(p + 2)));
+    if (e == hipSuccess) e = hipMalloc((void **)&acc, sizeof(double) * (2 * mlen + 2 * slen));
     if (e != hipSuccess) { set_error("fit_big: device allocation failed: %s", hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; }
-    double *msum = acc, *mtmp = acc + mlen, *ssum = acc + 2 * mlen, *stmp = ssum + (p + 2);
+    double *msum = acc, *mtmp = acc + mlen, *ssum = acc + 2 * mlen, *stmp = ssum + slen;
     if (!rc) {
-        e = hipMemsetAsync(acc, 0, sizeof(double) * (2 * mlen + 2 * (size_t)(p + 2)), c->stream);
+        e = hipMemsetAsync(acc, 0, sizeof(double) * (2 * mlen + 2 * slen), c->stream);
         if (e != hipSuccess) { set_error("memset failed"); rc = OEMGPU_ERR_HIP; }
     }
     for (int pass = 0; pass < 2 && !rc; ++pass) {
@@ -639,7 +639,7 @@ int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_
             if (e != hipSuccess) { set_error("fit_big: upload of shard %d failed: %s", s, hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; break; }
             if (pass == 0) {
                 rc = oemgpu_shift_sums_dev(c, xd, ns, ld, p, yd, stmp);
-                if (!rc) hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(256), 0, c->stream, ssum, stmp, (size_t)(p + 2));
+                if (!rc) hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(256), 0, c->stream, ssum, stmp, slen);
             } else {
                 rc = oemgpu_moments_dev(c, xd, ns, ld, p, yd, ssum, mtmp);
                 if (!rc) hipLaunchKernelGGL(accumulate_kernel, dim3(64), dim3(256), 0, c->stream, msum, mtmp, mlen);

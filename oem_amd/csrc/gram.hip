@@ -37,11 +37,11 @@ __global__ __launch_bounds__(256) void shift_sums_kernel(const double *__restric
     const int64_t nch = (n + 15) / 16;
     const int64_t nsamp = nch < 256 ? nch : 256;
     const int k = threadIdx.x;
-    double s = 0.0, cnt = 0.0;
+    double s = 0.0, ss = 0.0, cnt = 0.0;
     if (k < nsamp) {
         const int64_t c = (nsamp > 1) ? ((int64_t)k * (nch - 1)) / (nsamp - 1) : 0;
         const int64_t r0 = c * 16, r1 = (r0 + 16 < n) ? r0 + 16 : n;
-        for (int64_t r = r0; r < r1; ++r) { s += col[r]; cnt += 1.0; }
+        for (int64_t r = r0; r < r1; ++r) { const double v = col[r]; s += v; ss = fma(v, v, ss); cnt += 1.0; }
     }
     sh[k] = s;
     __syncthreads();
@@ -50,6 +50,14 @@ __global__ __launch_bounds__(256) void shift_sums_kernel(const double *__restric
         __syncthreads();
     }
     if (k == 0) sums[j] = sh[0];
+    __syncthreads();
+    sh[k] = ss;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (k < w) sh[k] += sh[k + w];
+        __syncthreads();
+    }
+    if (k == 0) sums[p + 2 + j] = sh[0];
     if (j == 0) {
         __syncthreads();
         sh[k] = cnt;
@@ -58,7 +66,7 @@ __global__ __launch_bounds__(256) void shift_sums_kernel(const double *__restric
             if (k < w) sh[k] += sh[k + w];
             __syncthreads();
         }
-        if (k == 0) sums[p + 1] = sh[0];
+        if (k == 0) { sums[p + 1] = sh[0]; sums[2 * p + 3] = 0.0; }
     }
 }
 
@@ -67,6 +75,29 @@ int launch_shift_sums(hipStream_t s, const double *x, int64_t n, int64_t ld, int
     hipLaunchKernelGGL(shift_sums_kernel, dim3(p + 1), dim3(256), 0, s, x, n, ld, p, y, sums);
     OEM_HIP(hipGetLastError());
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Is the provisional shift worth its price?  Every x - c is an FP64 VALU op, and FP64 VALU shares the DP units with
+// the FP64 MFMA (tools/mfma_probe.hip: each v_fma_f64 between MFMAs costs 4.5-9 MFMA cycles).  Un-shifted
+// accumulation loses (mean/sd)^2 * eps of relative accuracy on the centred moments, so the shift is applied only
+// when some sampled column has |mean| / sd > 16 (worst un-shifted loss 2^8 eps ~ 6e-14: the level of the
+// summation rounding itself).  The decision is a pure function of the (all-reduced) sample sums, so every kernel, workgroup
+// and rank takes it identically.  sums layout: [0..p] sum z_j (x columns, then y), [p+1] sample count,
+// [p+2 .. 2p+2] sum z_j^2.
+__device__ __forceinline__ bool column_needs_shift(const double *__restrict__ sums, int p, int j)
+{
+    const double cnt = sums[p + 1], m = sums[j] / cnt;
+    double var = sums[p + 2 + j] / cnt - m * m;
+    if (!(var > 0.0)) var = 0.0;
+    return m * m > 256.0 * var;
+}
+__device__ __forceinline__ bool shift_needed_wave(const double *__restrict__ sums, int p)      // wave-uniform result
+{
+    if (!sums) return false;
+    bool need = false;
+    for (int j = threadIdx.x & 63; j <= p; j += 64) need |= column_needs_shift(sums, p, j);
+    return __any(need);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -188,7 +219,7 @@ struct NoHook { template <typename M> __device__ __forceinline__ void operator()
 
 // hook(integral_constant<m>) runs right after the m-th MFMA of the slab (m = 0 .. 2 NTILES - 1): the place for
 // scalar / VMEM / LDS instructions, which issue for free in the 64-cycle shadow of an FP64 MFMA.
-template <int NR, int NC, bool DIAG, bool MASKED, bool VEC, bool AUG, typename Hook = NoHook>
+template <int NR, int NC, bool DIAG, bool MASKED, bool VEC, bool AUG, bool XF = true, typename Hook = NoHook>
 __device__ __forceinline__ void consume_slab(VecAcc<DIAG ? NR : NR + NC> &V, Slab<DIAG ? NR : NR + NC> &s,
                                              const LaneXf<DIAG ? NR : NR + NC> &X, double cy, int64_t r, int64_t n,
                                              Hook &&hook = NoHook())
@@ -201,7 +232,9 @@ __device__ __forceinline__ void consume_slab(VecAcc<DIAG ? NR : NR + NC> &V, Sla
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        if (AUG && f == NF - 1) {
+        if (!XF) {
+            // un-shifted form: the operands are used as loaded (the ones column is read from a constant)
+        } else if (AUG && f == NF - 1) {
             s.v[f].x = fma(s.v[f].x, X.m_last, X.o_last);
             s.v[f].y = fma(s.v[f].y, X.m_last, X.o_last);
         } else {
@@ -210,6 +243,7 @@ __device__ __forceinline__ void consume_slab(VecAcc<DIAG ? NR : NR + NC> &V, Sla
         }
         if (MASKED) { s.v[f].x *= m0; s.v[f].y *= m1; }
     }
+    static_assert(XF || !VEC, "the VALU vector sums are only written for the shifted form");
     if (VEC) {
         double y0 = s.y.x - cy, y1 = s.y.y - cy;
         if (MASKED) { y0 *= m0; y1 *= m1; }
@@ -274,15 +308,16 @@ __device__ __forceinline__ void gram_body(const double *__restrict__ x, int64_t 
     gptr_t ptr[NF];
     LaneXf<NF> X;
     X.m_last = 1.0; X.o_last = 0.0;
-    const double inv_cnt = sums ? 1.0 / sums[p + 1] : 0.0;
-    const double cy = sums ? sums[p] * inv_cnt : 0.0;
+    const bool use_shift = shift_needed_wave(sums, p);
+    const double inv_cnt = use_shift ? 1.0 / sums[p + 1] : 0.0;
+    const double cy = use_shift ? sums[p] * inv_cnt : 0.0;
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         const int T = (DIAG || f < NR) ? I0 + f : J0 + (f - NR);
         const int col = 16 * T + i;
         double cf;
         if (AUG) {
-            if (col < p) { ptr[f] = xg + (size_t)col * ld; cf = sums ? sums[col] * inv_cnt : 0.0; }
+            if (col < p) { ptr[f] = xg + (size_t)col * ld; cf = use_shift ? sums[col] * inv_cnt : 0.0; }
             else { ptr[f] = yg; cf = cy; }
             if (f == NF - 1) {
                 X.m_last = (col == p + 1) ? 0.0 : 1.0;
@@ -291,7 +326,7 @@ __device__ __forceinline__ void gram_body(const double *__restrict__ x, int64_t 
         } else {
             const int cc = col < p ? col : p - 1;
             ptr[f] = xg + (size_t)cc * ld;
-            cf = sums ? sums[cc] * inv_cnt : 0.0;
+            cf = use_shift ? sums[cc] * inv_cnt : 0.0;
         }
         X.c[f] = cf;
     }
@@ -453,6 +488,8 @@ __device__ __forceinline__ void gram_body(const double *__restrict__ x, int64_t 
 // slots (no VGPR destination, so depth is bounded by LDS: 4 slabs = 28 KiB per wave in flight), a slab is copied to
 // registers one slab ahead of its use, and the only waits are exact vmcnt counts.
 // ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) const double g_ones[2] = {1.0, 1.0};
+
 #ifdef OEM_GRAM_DIAG
 __device__ unsigned long long g_gram_diag[8];
 #define GSTAMP(slot)                                                                       \
@@ -481,6 +518,10 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
     X.m_last = 1.0; X.o_last = 0.0;
     const double inv_cnt = (SHIFT && sums) ? 1.0 / sums[p + 1] : 0.0;
     const double cy = (SHIFT && sums) ? sums[p] * inv_cnt : 0.0;
+    // SHIFT: every operand is x - c (FP64 VALU) and the ones column is made by the same fma (m = 0, o = 1).
+    // !SHIFT: no FP64 VALU at all -- lanes of the ones column (and the padding lanes after it, whose tile entries
+    // are dropped) DMA a constant {1, 1} with a pointer stride of 0.
+    bool const_lane = false;
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         const int col = 16 * f + i;
@@ -490,9 +531,11 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
         if (f == NF - 1) {
             X.m_last = (col == p + 1) ? 0.0 : 1.0;
             X.o_last = (col == p + 1) ? 1.0 : -cf;
+            if (!SHIFT && col > p) { const_lane = true; cur[f] = (gptr_t)g_ones; }
         }
         X.c[f] = cf;
     }
+    const int64_t inc_last = const_lane ? 0 : 32;
     VecAcc<NF> V;          // unused (AUG): kept for consume_slab's signature
     V.sy = 0.0; V.syy = 0.0;
     static_for<NTILES>([&](auto T_) { AccTile<decltype(T_)::value>::zero(); });
@@ -506,7 +549,7 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
         ns = k < nslab ? (int)k : nslab;
     }
 #pragma unroll
-    for (int f = 0; f < NF; ++f) cur[f] += w0 + 2 * q;
+    for (int f = 0; f < NF; ++f) cur[f] += (f == NF - 1 && const_lane) ? 0 : w0 + 2 * q;
 
     constexpr int NSLOT = 5, SLOT_B = NF * 1024;
     static_assert((NSLOT - 1) * NF <= 63, "vmcnt field is 6 bits");
@@ -516,7 +559,7 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
         const unsigned dst = ring + (unsigned)slot * SLOT_B;
         static_for<NF>([&](auto F_) { constexpr int f = decltype(F_)::value; glds16<0>(cur[f], dst + f * 1024); });
 #pragma unroll
-        for (int f = 0; f < NF; ++f) cur[f] += 32;
+        for (int f = 0; f < NF; ++f) cur[f] += (f == NF - 1) ? inc_last : 32;
     };
     auto fetch = [&](Slab<NF> &s, int slot) {                      // ring slot -> registers (a lane reads back its own 16 B)
 #pragma unroll
@@ -546,12 +589,12 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
     auto steady = [&](Slab<NF> &use, Slab<NF> &nxt) {
         const unsigned dst = ring + (unsigned)islot * SLOT_B;
         const v2d *src = ring_rd + (slot * SLOT_B) / 16;
-        consume_slab<NT, NT, true, false, false, true>(V, use, X, cy, 0, n, [&](auto M_) {
+        consume_slab<NT, NT, true, false, false, true, SHIFT>(V, use, X, cy, 0, n, [&](auto M_) {
             constexpr int m = decltype(M_)::value;
             if constexpr (m >= 1 && m <= NF) glds16<0>(cur[m - 1], dst + (m - 1) * 1024);
             if constexpr (m == NF + 1) {
 #pragma unroll
-                for (int f = 0; f < NF; ++f) cur[f] += 32;
+                for (int f = 0; f < NF; ++f) cur[f] += (f == NF - 1) ? inc_last : 32;
                 wait_vm<(NSLOT - 2) * NF>();
             }
             if constexpr (m >= NF + 2 && m <= 2 * NF + 1) nxt.v[m - NF - 2] = src[((m - NF - 2) * 1024) / 16];
@@ -571,7 +614,7 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
     wait_vm<0>();
     for (; k < ns; ++k) {
         if (k + 1 < ns) { fetch(sb, slot); slot = next(slot); }
-        consume_slab<NT, NT, true, false, false, true>(V, sa, X, cy, 0, n);
+        consume_slab<NT, NT, true, false, false, true, SHIFT>(V, sa, X, cy, 0, n);
         if (k + 1 < ns) {
 #pragma unroll
             for (int f = 0; f < NF; ++f) sa.v[f] = sb.v[f];
@@ -584,8 +627,11 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
         const int64_t r = w0 + 32 * (int64_t)ns + 2 * q;
         const int64_t o0 = (r < n ? r : n - 1) - r, o1 = (r + 1 < n ? r + 1 : n - 1) - r;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) { sa.v[f].x = cur[f][o0]; sa.v[f].y = cur[f][o1]; }
-        consume_slab<NT, NT, true, true, false, true>(V, sa, X, cy, r, n);
+        for (int f = 0; f < NF; ++f) {
+            if (f == NF - 1 && const_lane) { sa.v[f] = v2d{1.0, 1.0}; continue; }
+            sa.v[f].x = cur[f][o0]; sa.v[f].y = cur[f][o1];
+        }
+        consume_slab<NT, NT, true, true, false, true, SHIFT>(V, sa, X, cy, r, n);
     }
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     // ---- tile partials: all four waves write their tiles to LDS at once (two passes of <= 14 tiles: 4 x 28 KiB),
@@ -649,8 +695,12 @@ __global__ __launch_bounds__(256) void gram_ring_kernel(const double *__restrict
     extern __shared__ __attribute__((aligned(16))) double lds[];
     (void)vpart;
     const int chunk = blockIdx.x;
-    gram_tri_ring_body<NT, true>(x, a.n, a.ld, a.p, y, sums, (int64_t)chunk * a.steps * 64, a.steps,
-                                 tpart + (size_t)chunk * a.ntile * 256, lds);
+    if (shift_needed_wave(sums, a.p))
+        gram_tri_ring_body<NT, true>(x, a.n, a.ld, a.p, y, sums, (int64_t)chunk * a.steps * 64, a.steps,
+                                     tpart + (size_t)chunk * a.ntile * 256, lds);
+    else
+        gram_tri_ring_body<NT, false>(x, a.n, a.ld, a.p, y, sums, (int64_t)chunk * a.steps * 64, a.steps,
+                                      tpart + (size_t)chunk * a.ntile * 256, lds);
 }
 
 // 4x4 tile blocks of X'X; blockIdx -> (row chunk, tile block) so that the tile blocks of one row chunk run
@@ -836,7 +886,8 @@ int launch_moments_reduce(hipStream_t s, const GramPlan &pl, const double *tpart
 // ------------------------------------------------------------------------------------------------
 struct Mom {
     const double *M; const double *sums; int p, q; double n;
-    __device__ double c(int j) const { return sums ? sums[j] / sums[p + 1] : 0.0; }
+    bool shift;
+    __device__ double c(int j) const { return shift ? sums[j] / sums[p + 1] : 0.0; }
     __device__ double s(int j) const { return M[(size_t)j * q + (p + 1)]; }              // sum (z_j - c_j), j <= p
     __device__ double mu(int j) const { return c(j) + s(j) / n; }
     __device__ double cen(int i, int j) const { return M[(size_t)j * q + i] - s(i) * s(j) / n; }   // centred cross product
@@ -849,6 +900,14 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict_
                                                         double *__restrict__ stats)
 {
     Mom m; m.M = Mbuf; m.sums = sums; m.p = p; m.q = p + 2; m.n = Mbuf[(size_t)(p + 1) * (p + 2) + (p + 1)];
+    {
+        __shared__ int need_sh;
+        if (threadIdx.x == 0) need_sh = 0;
+        __syncthreads();
+        if (sums) for (int j = threadIdx.x; j <= p; j += blockDim.x) if (column_needs_shift(sums, p, j)) need_sh = 1;
+        __syncthreads();
+        m.shift = need_sh != 0;
+    }
     const double n = m.n;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     if (sem == OEMGPU_SEM_DENSE) {

@@ -5,7 +5,7 @@ ref src/oem_dense.h:328-358, and across slices, ref src/oem_big.h:329-358).  Eac
 contiguous block of rows, builds the shifted moment buffer M_r of its block with the MFMA kernel,
 and the ranks sum them:
 
-    sums   <- all_reduce(sample sums)      (p+2 doubles: agree on the provisional shift c)
+    sums   <- all_reduce(sample sums)      (2p+4 doubles: agree on the provisional shift c, or on none)
     M      <- all_reduce(M_r)              ((p+2)^2 doubles; c5: 532 KB -> latency-bound, one collective)
     result <- solve_moments(M)             (replicated: the lambda path is a serial chain of tiny GEMVs)
 
@@ -78,8 +78,8 @@ def oem_sharded(x_local, y_local, backend=None, dist=None, group=None, big=False
     args = _api._Args(penalty, _api._lambda_list(lambda_, len(penalty)), int(nlambda), lambda_min_ratio, alpha, gamma,
                       tau, tol, maxit, accelerate and not big, compute_loss, np.asarray(penalty_factor, dtype=np.float64),
                       g, ug, gw)
-    sums = backend.new_buffer(p + 2)
-    mom = backend.new_buffer((p + 2) * (p + 2))
+    sums = backend.new_buffer(L.sums_len(p))
+    mom = backend.new_buffer(L.moments_len(p))
     backend.shift_sums(x_local, n_local, ld, p, y_local, sums)
     if dist is not None and dist.get_world_size(group) > 1:
         dist.all_reduce(sums, group=group)

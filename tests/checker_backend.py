@@ -9,6 +9,13 @@ import torch
 from oracle import oracle as orc
 
 
+def shift_in_effect(s, p):
+    """include/oemgpu.h, oemgpu_shift_sums_dev: c = sample mean if any column has mean^2 > 2^8 var, else 0"""
+    m = s[:p + 1] / s[p + 1]
+    var = np.maximum(s[p + 2:2 * p + 3] / s[p + 1] - m * m, 0.0)
+    return m if np.any(m * m > 256.0 * var) else np.zeros(p + 1)
+
+
 class CheckerBackend:
     def new_buffer(self, n):
         return torch.zeros(n, dtype=torch.float64)
@@ -17,17 +24,17 @@ class CheckerBackend:
         xn, yn = x.numpy(), y.numpy()
         k = min(n, 64)                                   # any common sample works: the shift is only provisional
         out[:p] = torch.from_numpy(xn[:k].sum(0)); out[p] = float(yn[:k].sum()); out[p + 1] = float(k)
+        out[p + 2:2 * p + 2] = torch.from_numpy((xn[:k] ** 2).sum(0)); out[2 * p + 2] = float((yn[:k] ** 2).sum())
 
     def moments(self, x, n, ld, p, y, sums, out):
-        s = sums.numpy()
-        c = s[:p + 1] / s[p + 1]
+        c = shift_in_effect(sums.numpy(), p)
         z = np.column_stack([x.numpy() - c[:p], y.numpy() - c[p], np.ones(n)])
         out.copy_(torch.from_numpy((z.T @ z).ravel()))
 
     def solve(self, mom, sums, p, semantics, standardize, intercept, args):
         assert semantics == 0
         M = mom.numpy().reshape(p + 2, p + 2); s = sums.numpy()
-        n = M[p + 1, p + 1]; c = s[:p + 1] / s[p + 1]
+        n = M[p + 1, p + 1]; c = shift_in_effect(s, p)
         sh = M[p + 1, :p + 1]
         mu = c + sh / n
         cen = M[:p + 1, :p + 1] - np.outer(sh, sh) / n

@@ -15,6 +15,7 @@ def _declared():
     h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
     names = set(re.findall(r"\b(oemgpu_[a-z_0-9]+)\s*\(", h))
     names.discard("oemgpu_moments_len")          # static inline
+    names.discard("oemgpu_sums_len")             # static inline
     return sorted(names)
 
 

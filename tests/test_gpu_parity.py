@@ -165,23 +165,25 @@ def test_xtx_matches_dense_and_oracle(oa, doc_kats):
          orc.fit_xtx(xtx, xty, penalty=["lasso", "scad"], scale_factor=sf, nlambda=20))
 
 
-def test_moments_kernel_against_numpy(oa):
-    """the MFMA moment build alone: M = Z'Z for Z = [X - c | y - c_y | 1]"""
+@pytest.mark.parametrize("mean,shifted", [(0.3, False), (100.0, True)])
+def test_moments_kernel_against_numpy(oa, mean, shifted):
+    """the MFMA moment build alone: M = Z'Z for Z = [X - c | y - c_y | 1]; c = 0 unless a column has |mean| > 16 sd"""
     import torch
     from oem_amd import _lib as L
+    from tests.checker_backend import shift_in_effect
     n, p = 10007, 100
-    x, y = _data(n, p, 21, mean=0.3)
+    x, y = _data(n, p, 21, mean=mean)
     xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda")
     yd = torch.as_tensor(y, device="cuda")
-    sums = torch.zeros(p + 2, dtype=torch.float64, device="cuda")
+    sums = torch.zeros(L.sums_len(p), dtype=torch.float64, device="cuda")
     M = torch.zeros((p + 2, p + 2), dtype=torch.float64, device="cuda")
     ctx = oa.context()
     torch.cuda.synchronize()
     L.check(L.lib().oemgpu_shift_sums_dev(ctx, xd.data_ptr(), n, n, p, yd.data_ptr(), sums.data_ptr()))
     L.check(L.lib().oemgpu_moments_dev(ctx, xd.data_ptr(), n, n, p, yd.data_ptr(), sums.data_ptr(), M.data_ptr()))
     L.check(L.lib().oemgpu_synchronize(ctx))
-    s = sums.cpu().numpy()
-    c = s[:p + 1] / s[p + 1]
+    c = shift_in_effect(sums.cpu().numpy(), p)
+    assert bool(np.any(c != 0)) == shifted
     z = np.column_stack([x - c[:p], y - c[p], np.ones(n)])
     want = z.T @ z
     got = M.cpu().numpy()
