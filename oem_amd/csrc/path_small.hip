@@ -33,7 +33,7 @@ namespace {
 // -DOEM_PATH_DIAG: a diagnostic build that splits the round into stamped segments (cycles summed per wave 0).
 // Its fences forbid overlaps the real kernel has: read the SHARES, never the total.
 #ifdef OEM_PATH_DIAG
-__device__ unsigned long long g_diag[8];
+__device__ unsigned long long g_diag[12];
 #define OEM_STAMP(slot)                                                                    \
     do {                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                 \
@@ -43,8 +43,8 @@ __device__ unsigned long long g_diag[8];
         diag_acc[slot] += t__ - diag_last;                                                 \
         diag_last = t__;                                                                   \
     } while (0)
-#define OEM_DIAG_DECL unsigned long long diag_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, diag_last = __builtin_amdgcn_s_memtime();
-#define OEM_DIAG_ARGS , unsigned long long (&diag_acc)[8], unsigned long long &diag_last
+#define OEM_DIAG_DECL unsigned long long diag_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, diag_last = __builtin_amdgcn_s_memtime();
+#define OEM_DIAG_ARGS , unsigned long long (&diag_acc)[12], unsigned long long &diag_last
 #define OEM_DIAG_PASS , diag_acc, diag_last
 #else
 #define OEM_STAMP(slot) do { } while (0)
@@ -92,35 +92,71 @@ __device__ __forceinline__ double wave_max(double v)
     v = fmax(v, dpp_mov<0x143, 0xc>(v, ninf));
     return wave_uniform_lane63(v);
 }
-// largest eigenvalue of the symmetric tridiagonal (al[0..m), be[0..m-1)) by 64-way multisection of the Sturm
-// count; every lane of the wave returns the same value (an upper bracket end, so d never undershoots).
-__device__ double tridiag_max(const double *al, const double *be, int m, int lane)
+// Largest eigenvalue of the symmetric tridiagonal (al[0..m), be[0..m-1)) by 64-way multisection of the Sturm count;
+// every lane returns the same value (an upper bracket end, so d never undershoots).  ONE wave runs it.
+//   * The count uses the determinant recurrence p_k = (a_k - t) p_{k-1} - b_{k-1}^2 p_{k-2} (sign agreements of
+//     consecutive p_k) on T scaled by 1/Gershgorin, renormalised by exponent every 4 steps: one dependent FMA per
+//     step.  The pivot form q_k = (a_k - t) - b^2 / q_{k-1} costs a ~200-cycle FP64 division per step, which made this
+//     routine (9 rounds x 100 steps) a fifth of config 1's whole path kernel.
+//   * sab: LDS scratch for the scaled, interleaved coefficients (2 (m + 4) doubles).
+//   * lo_hint: a known lower bound of the answer (the value at an earlier Lanczos step; Ritz values only grow), or
+//     -inf.  With a hint the first round places its 64 probes geometrically above it, so a nearly converged value is
+//     bracketed to a factor of two at once and two or three uniform rounds finish the job.
+__device__ __forceinline__ double tridiag_max(const double *al, const double *be, int m, int lane, double *sab, double lo_hint)
 {
     if (m == 1) return al[0];
-    double lo = -1e300, hi = -1e300;
+    double lo = -1e300, hi = -1e300, nrm = 0.0;
     for (int j = lane; j < m; j += 64) {
         const double bl = j > 0 ? fabs(be[j - 1]) : 0.0, br = j < m - 1 ? fabs(be[j]) : 0.0;
         lo = fmax(lo, al[j]);
         hi = fmax(hi, al[j] + bl + br);
+        nrm = fmax(nrm, fabs(al[j]) + bl + br);
     }
-    lo = wave_max(lo); hi = wave_max(hi);
-    const double tiny = 1e-300;
-    for (int round = 0; round < 12; ++round) {
+    lo = wave_max(lo); hi = wave_max(hi); nrm = wave_max(nrm);
+    const double sc = (nrm > 0.0 && nrm < 1e300) ? 1.0 / nrm : 1.0;
+    // scaled coefficients, interleaved {a_k, b_{k-1}^2}, padded to a multiple of four steps with identity steps
+    // (b^2 = 0 and a flagged diagonal that the loop replaces by t + 1, i.e. p_k = p_{k-1}: no sign change)
+    const int mp = 1 + (m - 1 + 3) / 4 * 4;
+    v2d *co = reinterpret_cast<v2d *>(sab);
+    for (int j = lane; j < mp; j += 64) {
+        const double b = (j > 0 && j < m) ? be[j - 1] * sc : 0.0;
+        co[j] = v2d{j < m ? al[j] * sc : 1e300, b * b};
+    }
+    const bool hinted = lo_hint > lo;
+    if (hinted) lo = lo_hint;
+    if (!(hi > lo)) return lo;                              // the hint already is the top of the bracket
+    for (int round = 0; round < 14; ++round) {
         const double w = hi - lo;
         if (!(w > 4.0e-16 * fabs(hi))) break;
-        const double th = lo + w * ((double)(lane + 1) / 65.0);
-        double qv = al[0] - th;
-        int neg = qv < 0.0;
-        for (int k = 1; k < m; ++k) {
-            if (qv == 0.0) qv = tiny;
-            const double b = be[k - 1];
-            qv = (al[k] - th) - b * b / qv;
-            neg += qv < 0.0;
+        const bool geo = hinted && round == 0;
+        // probe positions lo < th_0 < ... < th_63 < hi: uniform, or (first hinted round) lo + w 2^(lane - 64)
+        const double frac = geo ? ldexp(1.0, lane - 64) : (double)(lane + 1) / 65.0;
+        const double t = (lo + w * frac) * sc;
+        double pm2 = 1.0, pm1 = co[0].x - t;
+        int neg = (unsigned)__double2hiint(pm1) >> 31;
+        // four steps per trip; the next trip's coefficients are in flight while this one's dependent FMAs run
+        v2d c0 = co[1], c1 = co[2], c2 = co[3], c3 = co[4];
+        for (int k = 1; k < mp; k += 4) {
+            const v2d d0 = c0, d1 = c1, d2 = c2, d3 = c3;
+            if (k + 4 < mp) { c0 = co[k + 4]; c1 = co[k + 5]; c2 = co[k + 6]; c3 = co[k + 7]; }
+            auto step = [&](const v2d &cf) {
+                const double diag = cf.x > 1e299 ? 1.0 : cf.x - t;
+                const double pn = fma(diag, pm1, -(cf.y * pm2));
+                neg += (unsigned)(__double2hiint(pn) ^ __double2hiint(pm1)) >> 31;   // +0 counts as positive: see above
+                pm2 = pm1; pm1 = pn;
+            };
+            step(d0); step(d1); step(d2); step(d3);
+            // renormalise by exponent: sign counts are scale-free, and |a - t| <= 2, b^2 <= 1 after the scaling
+            const int e1 = (__double2hiint(pm1) >> 20) & 0x7ff, e2 = (__double2hiint(pm2) >> 20) & 0x7ff;
+            const int e = 1023 - (e1 > e2 ? e1 : e2);
+            pm1 = ldexp(pm1, e); pm2 = ldexp(pm2, e);
         }
         const int above = neg < m;                         // an eigenvalue >= th exists
         const int kk = __popcll(__ballot(above));          // monotone in the lane index
-        const double nlo = kk == 0 ? lo : lo + w * ((double)kk / 65.0);
-        const double nhi = kk == 64 ? hi : lo + w * ((double)(kk + 1) / 65.0);
+        const double flo = kk == 0 ? 0.0 : (geo ? ldexp(1.0, kk - 1 - 64) : (double)kk / 65.0);
+        const double fhi = kk == 64 ? 1.0 : (geo ? ldexp(1.0, kk - 64) : (double)(kk + 1) / 65.0);
+        const double nlo = kk == 0 ? lo : lo + w * flo;
+        const double nhi = kk == 64 ? hi : lo + w * fhi;
         lo = nlo; hi = nhi;
     }
     return hi;
@@ -136,7 +172,8 @@ template <int R, int NW, int CW> struct Cfg {
     static constexpr int OFF_F = OFF_U + NW * PR;           // wave-private group factors [NW][PR]
     static constexpr int OFF_T = OFF_F + NW * PR;           // wave-private Lanczos alpha/beta [NW][2][ML]
     static constexpr int OFF_I = OFF_T + NW * 2 * ML;       // ints: gstart[PR+1], gidx[PR], gzero[PR] (as int)
-    static constexpr int N_DBL = OFF_I + (3 * PR + 4) / 2 + 2;
+    static constexpr int OFF_X = (OFF_I + (3 * PR + 4) / 2 + 2 + 1) / 2 * 2;   // sliced form: flags / scalars, 16-byte aligned
+    static constexpr int N_DBL = OFF_X + 4 * NW;            // int flags [2][NW] | double aux [2][NW] | double sum [NW]
 };
 
 // ---- cooperating workgroups (G > 1: 192 < p <= 256).  Each workgroup holds a column slice of the matrix and ends a
@@ -259,6 +296,219 @@ __device__ __forceinline__ void gemv_round(const double (&a)[R][CW], const doubl
     if (G > 1) exchange_partials<R, G>(X, out, P + (buf ^ 1) * NW * PR, w, lane);   // the idle half of P as scratch
     OEM_STAMP(3);                       // partial reads + adds (+ exchange)
     buf ^= 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sliced form of the round (single workgroup, element-wise penalties).  Measured (tools/valu_probe.hip): with four
+// waves each broadcast-reading its CW vector entries, the LDS return path (128 B/clk per CU, a broadcast still returns
+// 64 x 16 B per ds_read_b128) costs ~400 cycles a round, on top of the strip's write->read round trip.  Here the
+// vector never passes through LDS: wave w keeps ONLY its own CW entries, NB = ceil(CW/16) per lane, replicated in
+// each of its four 16-lane rows (entry 16 j + (lane & 15) of the slice in register j), thresholds just those, and the
+// GEMV takes each entry straight from the neighbour lane with v_fmac_f64_dpp row_newbcast:k.  The partial sums
+// cross waves exactly as before (one LDS write, one barrier), and each lane reads back the NW partials of ITS
+// entries.  What used to be replicated per wave and now is not -- the stop rule -- rides along: every wave drops a
+// "some coefficient still moving" flag beside its partials and all waves OR the NW flags after the same barrier.
+// ------------------------------------------------------------------------------------------------
+template <int K> struct BcFma {
+    static __device__ __forceinline__ void fmac(double &acc, const double &b, const double &a)
+    {
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(a), "n"(K));
+    }
+};
+template <int R, int CW, int NCH, int C> struct SliceFma {
+    template <int NB>
+    static __device__ __forceinline__ void run(double (&acc)[R][NCH], const double (&B)[NB], const double (&a)[R][CW])
+    {
+        if constexpr (C < CW) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) BcFma<(C & 15)>::fmac(acc[r][C % NCH], B[C >> 4], a[r][C]);
+            SliceFma<R, CW, NCH, C + 1>::run(acc, B, a);
+        }
+    }
+};
+
+struct SliceLds {
+    double *P;          // partials [2][NW][PR]
+    int *flag;          // [2][NW]
+    double *aux;        // [2][NW]   (accelerate: partial inner products)
+    double *sum;        // [NW]      (cross-wave scalar sums outside the round)
+};
+
+// one round: ab[j] = (M beta)[e_j] for this lane's entries e_j; returns the OR over waves of `moving`.
+// aux (USE_AUX): a wave-uniform partial that is summed over the waves in fixed order and returned through aux.
+template <int R, int NW, int CW, int NB, bool USE_AUX>
+__device__ __forceinline__ bool gemv_sliced(const double (&a)[R][CW], const double (&B)[NB], double (&ab)[NB],
+                                            const int (&eoff)[NB], bool moving, double &aux, const SliceLds &S, int w,
+                                            int lane, int &buf OEM_DIAG_ARGS)
+{
+    constexpr int PR = 64 * R, NCH = (R >= 2) ? 2 : 4;
+    OEM_STAMP(0);
+    double acc[R][NCH];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[r][c] = 0.0;
+    asm volatile("s_nop 1" ::: "memory");                       // VALU write of B -> DPP read: 2 wait states
+    SliceFma<R, CW, NCH, 0>::run(acc, B, a);
+    OEM_STAMP(1);
+    double *Pb = S.P + buf * NW * PR;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        double t = acc[r][0];
+#pragma unroll
+        for (int c = 1; c < NCH; ++c) t += acc[r][c];
+        Pb[w * PR + lane + 64 * r] = t;
+    }
+    const bool any_mine = __ballot(moving) != 0ull;
+    if (lane == 0) {
+        S.flag[buf * NW + w] = any_mine ? 1 : 0;
+        if (USE_AUX) S.aux[buf * NW + w] = aux;
+    }
+    __syncthreads();
+    OEM_STAMP(2);
+    // flags first: the decision resolves while the partial sums are still being added
+    int f = 0;
+    {
+        const int4 *fp = reinterpret_cast<const int4 *>(S.flag + buf * NW);
+#pragma unroll
+        for (int k = 0; k < NW / 4; ++k) { const int4 v = fp[k]; f |= (v.x | v.y) | (v.z | v.w); }
+    }
+    double xs[NW];
+    if (USE_AUX) {
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) xs[ww] = S.aux[buf * NW + ww];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        double t[NW];
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) t[ww] = Pb[ww * PR + eoff[j]];
+#pragma unroll
+        for (int h = 1; h < NW; h <<= 1)
+#pragma unroll
+            for (int ww = 0; ww + h < NW; ww += 2 * h) t[ww] += t[ww + h];
+        ab[j] = t[0];
+    }
+    if (USE_AUX) {
+#pragma unroll
+        for (int h = 1; h < NW; h <<= 1)
+#pragma unroll
+            for (int ww = 0; ww + h < NW; ww += 2 * h) xs[ww] += xs[ww + h];
+        aux = xs[0];
+    }
+    OEM_STAMP(3);
+    buf ^= 1;
+    return __builtin_amdgcn_readfirstlane(f) != 0;
+}
+
+// sum over the waves of a wave-uniform value (outside the round: loss); fixed order, identical in every wave.
+// Safe to reuse S.sum on every call: consecutive calls are separated by at least one round barrier.
+template <int NW>
+__device__ __forceinline__ double cross_wave_sum(double v, const SliceLds &S, int w, int lane)
+{
+    if (lane == 0) S.sum[w] = v;
+    __syncthreads();
+    double t[NW];
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) t[ww] = S.sum[ww];
+#pragma unroll
+    for (int h = 1; h < NW; h <<= 1)
+#pragma unroll
+        for (int ww = 0; ww + h < NW; ww += 2 * h) t[ww] += t[ww + h];
+    return t[0];
+}
+
+// element-wise operators on N values per lane (ref src/oem_dense.h:76-149), branch-free
+struct ThrK {
+    double D, rD, gammad, dmg, rdmg, gm1, gamma, dsc, rdsc, d, rd;
+};
+template <int KIND>
+__device__ __forceinline__ ThrK thr_consts(const PenK &K, double d)
+{
+    // only the reciprocals the operator uses: each is a ~300-cycle dependent chain paid once per lambda
+    ThrK c = {};
+    c.D = K.D; c.gammad = K.gamma * K.D; c.gamma = K.gamma; c.gm1 = K.gamma - 1.0; c.d = d;
+    if (KIND != K_OLS) c.rD = 1.0 / K.D;
+    if (KIND == K_MCP) { c.dmg = K.D - 1.0 / K.gamma; c.rdmg = 1.0 / c.dmg; }
+    if (KIND == K_SCAD) { c.dsc = c.gm1 * K.D - 1.0; c.rdsc = 1.0 / c.dsc; }
+    if (KIND == K_OLS) c.rd = 1.0 / d;
+    return c;
+}
+template <int KIND>
+__device__ __forceinline__ double threshold1(double u, double tp, const ThrK &c)
+{
+    if (KIND == K_SOFT) return cdiv(shrink(u, tp), c.D, c.rD);                // ref src/oem_dense.h:76-92
+    if (KIND == K_MCP) {                                                      // ref src/oem_dense.h:94-117
+        const bool big = fabs(u) > c.gammad * tp;
+        const double num = big ? u : shrink(u, tp);
+        return cdiv(num, big ? c.D : c.dmg, big ? c.rD : c.rdmg);
+    }
+    if (KIND == K_SCAD) {                                                     // ref src/oem_dense.h:119-149
+        const double au = fabs(u);
+        const bool big = au > c.gammad * tp, mid = !big && au > (c.D + 1.0) * tp;
+        const double nmid = shrink(c.gm1 * u, c.gamma * tp);
+        const double nsoft = shrink(u, tp);
+        const double num = big ? u : (mid ? nmid : nsoft);
+        return cdiv(num, mid ? c.dsc : c.D, mid ? c.rdsc : c.rD);
+    }
+    return cdiv(u, c.d, c.rd);                                                // K_OLS
+}
+
+// The OEM iteration for one lambda in the sliced layout (same recurrence and stop rule as `iterate` below).
+template <int R, int NW, int CW, int NB, int KIND>
+__device__ __forceinline__ void iterate_sliced(const PathArgs &A, const PenK &K, double d, const double (&a)[R][CW],
+                                               const double (&xy)[NB], const double (&pf)[NB], const bool (&valid)[NB],
+                                               const int (&eoff)[NB], double (&beta)[NB], double (&bold)[NB],
+                                               double (&ab)[NB], double &ak, int &it, int &conv, const SliceLds &S,
+                                               int w, int lane, int &buf OEM_DIAG_ARGS)
+{
+    const ThrK c = thr_consts<KIND>(K, d);
+    double tp[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) tp[j] = pf[j] * K.L;
+    const double tol = A.tol;
+    const bool first_row = lane < 16;                               // the other three 16-lane rows hold replicas
+    OEM_STAMP(8);                       // per-lambda work since the last round (lambda, constants, stores)
+    for (;;) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            bold[j] = beta[j];
+            const double b = threshold1<KIND>(ab[j] + xy[j], tp[j], c);
+            beta[j] = valid[j] ? b : 0.0;
+        }
+        double aux = 0.0;
+        if (A.accelerate) {                                        // ref src/oem_dense.h:633-651
+            const double akp = ak;
+            ak = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak));
+            const double ratio = (akp - 1.0) / ak;
+            double adp = 0.0;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const double upd = beta[j], diff = upd - bold[j];
+                beta[j] = upd + ratio * diff;
+                adp += (beta[j] - upd) * diff;
+            }
+            aux = wave_sum(first_row ? adp : 0.0);
+        }
+        ++it;
+        // stop rule (ref src/utils.cpp:537-549; |(cur - prev) / prev| > tol written as |cur - prev| > tol |prev|)
+        bool moving = false;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const double cu = fabs(beta[j]), q = fabs(bold[j]);
+            const bool cn = cu > 1e-13, qn = q > 1e-13;
+            moving |= (cn != qn);
+            moving |= (cn && qn && fabs(beta[j] - bold[j]) > tol * q);
+        }
+        bool any;
+        if (A.accelerate) {
+            any = gemv_sliced<R, NW, CW, NB, true>(a, beta, ab, eoff, moving, aux, S, w, lane, buf OEM_DIAG_PASS);
+            if (aux > 0.0) ak = 1.0;
+        } else
+            any = gemv_sliced<R, NW, CW, NB, false>(a, beta, ab, eoff, moving, aux, S, w, lane, buf OEM_DIAG_PASS);
+        conv = !any;
+        if (conv || it >= A.maxit) break;
+    }
 }
 
 // The OEM iteration for one lambda (ref src/oem_base.h:90-110), specialised per operator so that the serial loop
@@ -438,6 +688,24 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
     if (msteps > p) msteps = p;
     int nst = 0;
     double bprev = 0.0;
+    // Wave 0 evaluates the top Ritz value (the other waves wait at the barrier and read it from LDS).  From step 16
+    // on it is checked every 8 steps and the recurrence stops once it has moved by less than 1e-14 (relative) over
+    // the last 8: the top Ritz value of a Gram matrix typically settles in 30-50 steps, and OEM needs d only as an
+    // upper bound of lambda_max that both sides compute alike (the fixed point does not depend on d).
+    double *theta_slot = lds + C::OFF_X + 3 * NW;                   // S.sum[0..1]: free until the path starts
+    auto top_ritz = [&](int m, double hint) {
+        if (w == 0) {
+            // scratch: the vector strips of all waves (only wave 0 is running; every round rewrites its strip)
+            const double th = tridiag_max(Tal, Tbe, m, lane, lds + C::OFF_U, hint);
+            if (lane == 0) theta_slot[0] = th;
+        }
+        __syncthreads();
+        const double th = theta_slot[0];
+        __syncthreads();                                            // the slot and the strips are reused
+        return th;
+    };
+    double theta = 0.0, theta_prev = -__builtin_inf();
+    bool have_theta = false;
     for (int j = 0; j < msteps; ++j) {
         gemv_round<R, NW, CW, G>(a, v, wv, P, Uw, w, lane, buf, X OEM_DIAG_PASS);
         double al = 0.0;
@@ -454,6 +722,13 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
         if (lane == 0) { Tal[j] = al; Tbe[j] = bb; }
         nst = j + 1;
         if (!(bb > 1e-13 * fabs(al))) break;            // invariant subspace reached: T is exact
+        if (nst >= 16 && (nst & 7) == 0 && nst < msteps) {
+            OEM_STAMP(10);
+            const double th = top_ritz(nst, theta_prev);
+            OEM_STAMP(9);
+            if (th - theta_prev <= 1e-14 * fabs(th)) { theta = th; have_theta = true; break; }
+            theta_prev = th;
+        }
         const double ib = 1.0 / bb;
 #pragma unroll
         for (int r = 0; r < R; ++r) { vp[r] = v[r]; v[r] = wv[r] * ib; }
@@ -462,7 +737,12 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
 #ifdef OEM_PATH_DIAG
     for (int k = 0; k < 4; ++k) diag_acc[4 + k] = diag_acc[k];      // Lanczos share of the four segments
 #endif
-    const double theta = tridiag_max(Tal, Tbe, nst, lane);
+    OEM_STAMP(10);
+    if (!have_theta) theta = top_ritz(nst, theta_prev);
+    OEM_STAMP(9);
+#ifdef OEM_PATH_DIAG
+    diag_acc[11] = (unsigned long long)nst;
+#endif
     const double d = theta * 1.005;                       // ref src/oem_dense.h:498
     if (tid == 0 && writer) { A.d_out[0] = d; A.d_out[1] = theta; }
 
@@ -489,19 +769,48 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
     const double lstep = nl > 1 ? (lhi - llo) / (double)(nl - 1) : 0.0;
     const bool lflip = fabs(lhi) < fabs(llo);
 
+    // ---- sliced layout (single workgroup): this lane's NB entries of the wave's column slice
+    constexpr bool CAN_SLICE = (G == 1);
+    constexpr int NB = (CW + 15) / 16;
+    int eoff[NB];
+    bool valid[NB];
+    double xyE[NB], pfE[NB], sinvE[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int loc = 16 * j + (lane & 15), e = w * CW + loc;
+        valid[j] = CAN_SLICE && loc < CW && e < p;
+        eoff[j] = valid[j] ? e : 0;
+        xyE[j] = valid[j] ? A.xy[e] : 0.0;
+        pfE[j] = valid[j] ? A.pf[e] : 0.0;
+        sinvE[j] = (valid[j] && A.sinv) ? A.sinv[e] : 1.0;
+    }
+    SliceLds S;
+    S.P = P;
+    S.flag = reinterpret_cast<int *>(lds + C::OFF_X);
+    S.aux = lds + C::OFF_X + NW;
+    S.sum = lds + C::OFF_X + 3 * NW;
+
     double beta[R], bold[R], ab[R];
+    double betaE[NB], boldE[NB], abE[NB];
     for (int pp = 0; pp < A.npen; ++pp) {
         const int pen = A.penalty[pp];
         const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
         const bool isnet = pen_is_net(pen);
+        const bool sliced = CAN_SLICE && pen_consts(pen, 1.0, d, A.alpha, A.gamma, A.tau).kind <= K_OLS;
 #pragma unroll
         for (int r = 0; r < R; ++r) { beta[r] = 0.0; ab[r] = 0.0; }     // cold start: A 0 = 0
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { betaE[j] = 0.0; abE[j] = 0.0; }
         double ak = 1.0;
+        // user-supplied lambdas are fetched one lambda ahead: a dependent global load costs 1-2 us on this serial chain
+        double lam_next = A.user_lambda ? A.lambda_user[(size_t)pp * nl] : 0.0;
         for (int i = 0; i < nl; ++i) {
             // lambda_i (Eigen's setLinSpaced incl. its "flip" form, then exp; *.net: / alpha)
             double lam;
-            if (A.user_lambda) lam = A.lambda_user[(size_t)pp * nl + i];
-            else {
+            if (A.user_lambda) {
+                lam = lam_next;
+                if (i + 1 < nl) lam_next = A.lambda_user[(size_t)pp * nl + i + 1];
+            } else {
                 double lv;
                 if (nl == 1) lv = lhi;
                 else if (lflip) lv = (i == 0) ? llo : lhi - (double)(nl - 1 - i) * lstep;
@@ -514,12 +823,53 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
             const double il = lam / scaley;                               // ref src/oem_dense.cpp:241
             const PenK K = pen_consts(pen, il, d, A.alpha, A.gamma, A.tau);
             int it = 0, conv = 0;
-            switch (K.kind) {
-            case K_SOFT: iterate<R, NW, CW, G, K_SOFT>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
-            case K_MCP: iterate<R, NW, CW, G, K_MCP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
-            case K_SCAD: iterate<R, NW, CW, G, K_SCAD>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
-            case K_OLS: iterate<R, NW, CW, G, K_OLS>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
-            default: iterate<R, NW, CW, G, K_GRP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
+            const size_t orow = ((size_t)pp * nl + i);
+            if constexpr (CAN_SLICE) {
+                if (sliced) {
+                    switch (K.kind) {
+                    case K_SOFT: iterate_sliced<R, NW, CW, NB, K_SOFT>(A, K, d, a, xyE, pfE, valid, eoff, betaE, boldE, abE, ak, it, conv, S, w, lane, buf OEM_DIAG_PASS); break;
+                    case K_MCP: iterate_sliced<R, NW, CW, NB, K_MCP>(A, K, d, a, xyE, pfE, valid, eoff, betaE, boldE, abE, ak, it, conv, S, w, lane, buf OEM_DIAG_PASS); break;
+                    case K_SCAD: iterate_sliced<R, NW, CW, NB, K_SCAD>(A, K, d, a, xyE, pfE, valid, eoff, betaE, boldE, abE, ak, it, conv, S, w, lane, buf OEM_DIAG_PASS); break;
+                    default: iterate_sliced<R, NW, CW, NB, K_OLS>(A, K, d, a, xyE, pfE, valid, eoff, betaE, boldE, abE, ak, it, conv, S, w, lane, buf OEM_DIAG_PASS); break;
+                    }
+                    // oemXTX::get_beta rescales the member in place (ref src/oem_xtx.h:576-581, quirk Q5)
+                    if (A.sinv) {
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) betaE[j] *= sinvE[j];
+                    }
+                    if (writer && lane < 16) {                      // every wave stores its own slice
+#pragma unroll
+                        for (int j = 0; j < NB; ++j)
+                            if (valid[j]) A.beta[orow * p + eoff[j]] = betaE[j];
+                    }
+                    if (tid == 0 && writer) A.niter[orow] = conv ? it : A.maxit + 1;   // ref src/oem_base.h:94-109
+                    if (A.sinv) {
+                        double none = 0.0;
+                        gemv_sliced<R, NW, CW, NB, false>(a, betaE, abE, eoff, false, none, S, w, lane, buf OEM_DIAG_PASS);
+                    }
+                    if (A.compute_loss) {
+                        // sum (Y - X beta)^2 through the Gram identity (ref src/oem_dense.h:759-770), see below
+                        double t = 0.0;
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) t += betaE[j] * ((d * betaE[j] - abE[j]) - 2.0 * xyE[j]);
+                        t = wave_sum(lane < 16 ? t : 0.0);
+                        t = cross_wave_sum<NW>(t, S, w, lane);
+                        if (tid == 0 && writer) A.loss[orow] = yy + nobs * t;
+                    } else if (tid == 0 && writer) A.loss[orow] = 1e99;
+                    continue;
+                }
+            }
+            if constexpr (CAN_SLICE) {
+                // only the group operators take the replicated-vector form in a single workgroup
+                iterate<R, NW, CW, G, K_GRP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS);
+            } else {
+                switch (K.kind) {
+                case K_SOFT: iterate<R, NW, CW, G, K_SOFT>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
+                case K_MCP: iterate<R, NW, CW, G, K_MCP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
+                case K_SCAD: iterate<R, NW, CW, G, K_SCAD>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
+                case K_OLS: iterate<R, NW, CW, G, K_OLS>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
+                default: iterate<R, NW, CW, G, K_GRP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
+                }
             }
             // oemXTX::get_beta rescales the member in place (ref src/oem_xtx.h:576-581, quirk Q5)
             if (A.sinv) {
@@ -530,9 +880,9 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int row = lane + 64 * r;
-                    if (row < p) A.beta[((size_t)pp * nl + i) * p + row] = beta[r];
+                    if (row < p) A.beta[orow * p + row] = beta[r];
                 }
-                if (lane == 0) A.niter[(size_t)pp * nl + i] = conv ? it : A.maxit + 1;   // ref src/oem_base.h:94-109
+                if (lane == 0) A.niter[orow] = conv ? it : A.maxit + 1;   // ref src/oem_base.h:94-109
             }
             // ab = A beta (warm start of the next lambda, and the loss) is already there from the last round, unless
             // beta has just been rescaled in place
@@ -544,12 +894,12 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
 #pragma unroll
                 for (int r = 0; r < R; ++r) t += beta[r] * ((d * beta[r] - ab[r]) - 2.0 * xy[r]);
                 t = wave_sum(t);
-                if (tid == 0 && writer) A.loss[(size_t)pp * nl + i] = yy + nobs * t;
-            } else if (tid == 0 && writer) A.loss[(size_t)pp * nl + i] = 1e99;
+                if (tid == 0 && writer) A.loss[orow] = yy + nobs * t;
+            } else if (tid == 0 && writer) A.loss[orow] = 1e99;
         }
     }
 #ifdef OEM_PATH_DIAG
-    if (tid == 0) for (int k = 0; k < 8; ++k) g_diag[k] = diag_acc[k];
+    if (tid == 0) for (int k = 0; k < 12; ++k) g_diag[k] = diag_acc[k];
 #endif
     if (tid == 0 && writer) {
         A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
@@ -578,7 +928,7 @@ template <int R, int NW, int CW, int G = 1> int launch_cfg(hipStream_t s, const 
 #ifdef OEM_PATH_DIAG
 extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read(unsigned long long *out)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 12) == hipSuccess ? 0 : -1;
 }
 #endif
 
