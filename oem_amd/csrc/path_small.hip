@@ -173,7 +173,7 @@ template <int R, int NW, int CW> struct Cfg {
     static constexpr int OFF_T = OFF_F + NW * PR;           // wave-private Lanczos alpha/beta [NW][2][ML]
     static constexpr int OFF_I = OFF_T + NW * 2 * ML;       // ints: gstart[PR+1], gidx[PR], gzero[PR] (as int)
     static constexpr int OFF_X = (OFF_I + (3 * PR + 4) / 2 + 2 + 1) / 2 * 2;   // sliced form: flags / scalars, 16-byte aligned
-    static constexpr int N_DBL = OFF_X + 4 * NW;            // int flags [2][NW] | double aux [2][NW] | double sum [NW]
+    static constexpr int N_DBL = OFF_X + 4 * NW + 64 * NW;  // (unused [NW]) | double aux [2][NW] | double sum [NW] | int flags [2][NW][64]
 };
 
 // ---- cooperating workgroups (G > 1: 192 < p <= 256).  Each workgroup holds a column slice of the matrix and ends a
@@ -329,7 +329,7 @@ template <int R, int CW, int NCH, int C> struct SliceFma {
 
 struct SliceLds {
     double *P;          // partials [2][NW][PR]
-    int *flag;          // [2][NW]
+    int *flag;          // [2][NW][64]: every lane of wave w stores the wave's flag in its own word
     double *aux;        // [2][NW]   (accelerate: partial inner products)
     double *sum;        // [NW]      (cross-wave scalar sums outside the round)
 };
@@ -343,6 +343,7 @@ __device__ __forceinline__ bool gemv_sliced(const double (&a)[R][CW], const doub
 {
     constexpr int PR = 64 * R, NCH = (R >= 2) ? 2 : 4;
     OEM_STAMP(0);
+    const int any_mine = (__ballot(moving) != 0ull) ? 1 : 0;      // resolved in the shadow of the FMAs
     double acc[R][NCH];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -359,35 +360,35 @@ __device__ __forceinline__ bool gemv_sliced(const double (&a)[R][CW], const doub
         for (int c = 1; c < NCH; ++c) t += acc[r][c];
         Pb[w * PR + lane + 64 * r] = t;
     }
-    const bool any_mine = __ballot(moving) != 0ull;
-    if (lane == 0) {
-        S.flag[buf * NW + w] = any_mine ? 1 : 0;
-        if (USE_AUX) S.aux[buf * NW + w] = aux;
-    }
+    // Stop flags ride beside the partials at (almost) no cost: every lane stores its wave's flag in a word of its
+    // own (no exec-masked branch), and after the barrier lane l reads ONE word of wave l mod NW -- a 256-byte read --
+    // and a wave-wide "any" replaces the OR of NW broadcast words.  (Measured, tools/valu_probe.hip: a lane-0 store
+    // plus a broadcast ds_read_b128 per lane cost 200-300 cycles a round.)
+    S.flag[(buf * NW + w) * 64 + lane] = any_mine;
+    if (USE_AUX && lane == 0) S.aux[buf * NW + w] = aux;
     __syncthreads();
     OEM_STAMP(2);
-    // flags first: the decision resolves while the partial sums are still being added
-    int f = 0;
-    {
-        const int4 *fp = reinterpret_cast<const int4 *>(S.flag + buf * NW);
-#pragma unroll
-        for (int k = 0; k < NW / 4; ++k) { const int4 v = fp[k]; f |= (v.x | v.y) | (v.z | v.w); }
-    }
+    const int f = S.flag[(buf * NW + (lane & (NW - 1))) * 64 + lane];
     double xs[NW];
     if (USE_AUX) {
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) xs[ww] = S.aux[buf * NW + ww];
     }
+    // every read is issued before the first add: left alone, the scheduler trades registers for four serial LDS
+    // round trips (read, wait, add, read, ...), ~300 cycles a round
+    double t[NB][NW];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) t[j][ww] = Pb[ww * PR + eoff[j]];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        double t[NW];
-#pragma unroll
-        for (int ww = 0; ww < NW; ++ww) t[ww] = Pb[ww * PR + eoff[j]];
 #pragma unroll
         for (int h = 1; h < NW; h <<= 1)
 #pragma unroll
-            for (int ww = 0; ww + h < NW; ww += 2 * h) t[ww] += t[ww + h];
-        ab[j] = t[0];
+            for (int ww = 0; ww + h < NW; ww += 2 * h) t[j][ww] += t[j][ww + h];
+        ab[j] = t[j][0];
     }
     if (USE_AUX) {
 #pragma unroll
@@ -398,7 +399,7 @@ __device__ __forceinline__ bool gemv_sliced(const double (&a)[R][CW], const doub
     }
     OEM_STAMP(3);
     buf ^= 1;
-    return __builtin_amdgcn_readfirstlane(f) != 0;
+    return __any(f != 0);
 }
 
 // sum over the waves of a wave-uniform value (outside the round: loss); fixed order, identical in every wave.
@@ -786,9 +787,9 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
     }
     SliceLds S;
     S.P = P;
-    S.flag = reinterpret_cast<int *>(lds + C::OFF_X);
     S.aux = lds + C::OFF_X + NW;
     S.sum = lds + C::OFF_X + 3 * NW;
+    S.flag = reinterpret_cast<int *>(lds + C::OFF_X + 4 * NW);
 
     double beta[R], bold[R], ab[R];
     double betaE[NB], boldE[NB], abE[NB];
