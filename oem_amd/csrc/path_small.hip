@@ -909,6 +909,343 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
     if (X.failed && lane == 0) A.d_out[1] = -1.0;     // exchange timeout: poison (host turns it into an error)
 }
 
+// ================================================================================================
+// Row-split form (64 < p <= 128, element-wise penalties): the fastest round for these sizes.
+//
+// Measured on MI355X (tools/valu_probe.hip, tools/path_cost.py): a round costs (FP64 VALU instructions of the
+// busiest SIMD) x ~5 cycles PLUS the exposed LDS exchange (write -> barrier -> read: ~190-260 cycles, ~25 more per
+// extra 8-byte read per lane), with no overlap between the two -- the chain is serial.  So the round that wins issues
+// the fewest instructions and moves the fewest words:
+//   * four waves, one per SIMD; wave w owns rows [w RWp, (w+1) RWp), RWp = ceil(p/4) <= 32;
+//   * the 16-lane row group g of every wave multiplies the column slice [g CGp, (g+1) CGp), CGp = ceil(p/4): lane
+//     (g, l) holds a[r][k] = M[row(l, r)][g CGp + k] for its two row slots r = 0, 1 -- 2 CG FMAs, each taking its
+//     beta entry from a neighbour lane (v_fmac_f64_dpp row_newbcast);
+//   * the four slice sums of a row meet WITHOUT LDS, and as a reduce-scatter: one v_permlane16_swap pair + add leaves
+//     slot 0's pair sums in even row groups and slot 1's in odd ones, one v_permlane32_swap pair + add finishes, so
+//     lane (g, l) ends with the full (M beta) of ONE row, 16 (g & 1) + l, (g0 + g1) + (g2 + g3) in every lane;
+//   * threshold, stop rule and warm start then touch ONE register per lane (rows replicated in groups 2, 3);
+//   * what crosses waves is the NEW beta, not partial sums: one 8-byte store per row, one barrier, two 8-byte reads
+//     per lane (the entries of its row group's slice).  Stop flags ride along as one 4-byte word per lane.
+// The eigenvalue step runs the same exchange; its two inner products per Lanczos step cross waves through per-lane
+// words and DPP butterflies (fixed order, identical in every lane).
+// ================================================================================================
+template <int CTRL> __device__ __forceinline__ double dpp_xchg(double v) { return dpp_mov<CTRL, 0xf>(v, 0.0); }
+// lane l holds the word of wave l mod 4: sum over aligned groups of 4 lanes, every lane gets the total
+__device__ __forceinline__ double quad_sum(double v)
+{
+    v += dpp_xchg<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_xchg<0x4E>(v);      // quad_perm [2,3,0,1]
+    return v;
+}
+// p0 / p1: this row group's slice sums of row slots 0 / 1.  Returns the sum over the four row groups of slot (g & 1).
+__device__ __forceinline__ double rowgroup_reduce_scatter(double p0, double p1)
+{
+    // v_permlane16_swap X, Y: rows 1, 3 of X <-> rows 0, 2 of Y.  X' + Y' = {p0(g0)+p0(g1), p1(g0)+p1(g1), p0(g2)+p0(g3), p1(g2)+p1(g3)}
+    auto l1 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(p0), (unsigned)__double2loint(p1), false, false);
+    auto h1 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(p0), (unsigned)__double2hiint(p1), false, false);
+    const double s = __hiloint2double((int)h1[0], (int)l1[0]) + __hiloint2double((int)h1[1], (int)l1[1]);
+    // v_permlane32_swap Z, W: rows 2, 3 of Z <-> rows 0, 1 of W
+    const unsigned lo = (unsigned)__double2loint(s), hi = (unsigned)__double2hiint(s);
+    auto l2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto h2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
+}
+template <int CG, int C> struct GroupFma {
+    template <int NBC>
+    static __device__ __forceinline__ void run(double (&acc)[2][2], const double (&B)[NBC], const double (&a)[2][CG])
+    {
+        if constexpr (C < CG) {
+            BcFma<(C & 15)>::fmac(acc[0][C & 1], B[C >> 4], a[0][C]);
+            BcFma<(C & 15)>::fmac(acc[1][C & 1], B[C >> 4], a[1][C]);
+            GroupFma<CG, C + 1>::run(acc, B, a);
+        }
+    }
+};
+
+template <int CG> struct RowsCfg {
+    static constexpr int NW = 4;
+    static constexpr int NBC = (CG + 15) / 16;
+    static constexpr int VS = 256;                        // vector words per buffer: 128 rows + one dummy word per lane
+    static constexpr int ML = 128;
+    // LDS carve (doubles)
+    static constexpr int OFF_V = 0;                       // exchanged vector [2][VS]
+    static constexpr int OFF_XA = OFF_V + 2 * VS;         // per-lane scalar words [2][NW][64] (aux / alpha)
+    static constexpr int OFF_XN = OFF_XA + 2 * NW * 64;   // per-lane scalar words [2][NW][64] (norms, sums)
+    static constexpr int OFF_F = OFF_XN + 2 * NW * 64;    // int flags [2][NW][64]
+    static constexpr int OFF_T = OFF_F + NW * 64;         // Lanczos alpha[ML], beta[ML]
+    static constexpr int OFF_S = OFF_T + 2 * ML;          // Sturm scratch 2 (ML + 4)
+    static constexpr int OFF_TH = OFF_S + 2 * (ML + 4);   // theta slot
+    static constexpr int N_DBL = OFF_TH + 2;
+};
+
+struct RowsLds {
+    double *V, *XA, *XN;
+    int *F;
+};
+
+// exchange + GEMV: every owner lane publishes `mine` (its row's entry), every lane picks up the entries of its
+// row group's column slice and returns (M vec)[own row].  flag / aux as in gemv_sliced.
+template <int CG, bool FLAGS, bool USE_AUX>
+__device__ __forceinline__ double gemv_rows(const double (&a)[2][CG], double mine, int wslot, const int (&ecol)[(CG + 15) / 16],
+                                            bool moving, bool &any, double &aux, const RowsLds &S, int w, int lane, int &buf)
+{
+    constexpr int NBC = (CG + 15) / 16, VS = RowsCfg<CG>::VS, NW = 4;
+    const int b = __builtin_amdgcn_readfirstlane(buf);              // provably uniform: addresses stay scalar + immediate
+    const int any_mine = FLAGS ? ((__ballot(moving) != 0ull) ? 1 : 0) : 0;
+    S.V[b * VS + wslot] = mine;
+    if (FLAGS) S.F[(b * NW + w) * 64 + lane] = any_mine;
+    if (USE_AUX) S.XA[(b * NW + w) * 64 + lane] = aux;
+    __syncthreads();
+    int f = 0;
+    if (FLAGS) f = S.F[(b * NW + (lane & (NW - 1))) * 64 + lane];
+    double xa = 0.0;
+    if (USE_AUX) xa = S.XA[(b * NW + (lane & (NW - 1))) * 64 + lane];
+    double B[NBC];
+#pragma unroll
+    for (int j = 0; j < NBC; ++j) B[j] = S.V[b * VS + ecol[j]];
+    __builtin_amdgcn_sched_barrier(0);
+    double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    asm volatile("s_nop 1" ::: "memory");                       // VALU write of B -> DPP read
+    GroupFma<CG, 0>::run(acc, B, a);
+    const double out = rowgroup_reduce_scatter(acc[0][0] + acc[0][1], acc[1][0] + acc[1][1]);
+    if (USE_AUX) aux = quad_sum(xa);
+    any = FLAGS ? __any(f != 0) : false;
+    buf = b ^ 1;
+    return out;
+}
+
+// sum over the waves of a per-wave value that every lane of the wave holds; own barrier, double-buffered by `par`
+__device__ __forceinline__ double waves_sum(double v, double *X, int &par, int w, int lane)
+{
+    const int b = __builtin_amdgcn_readfirstlane(par);
+    X[(b * 4 + w) * 64 + lane] = v;
+    __syncthreads();
+    const double x = X[(b * 4 + (lane & 3)) * 64 + lane];
+    par = b ^ 1;
+    return quad_sum(x);
+}
+
+template <int CG, int KIND>
+__device__ __forceinline__ void iterate_rows(const PathArgs &A, const PenK &K, double d, const double (&a)[2][CG], double xy,
+                                             double pf, bool rowok, bool owner, int wslot, const int (&ecol)[(CG + 15) / 16],
+                                             double &beta, double &ab, double &ak, int &it, int &conv, const RowsLds &S,
+                                             int w, int lane, int &buf)
+{
+    const ThrK c = thr_consts<KIND>(K, d);
+    const double tp = pf * K.L, tol = A.tol;
+    for (;;) {
+        const double bold = beta;
+        const double b = threshold1<KIND>(ab + xy, tp, c);
+        beta = rowok ? b : 0.0;
+        double aux = 0.0;
+        if (A.accelerate) {                                        // ref src/oem_dense.h:633-651
+            const double akp = ak;
+            ak = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak));
+            const double ratio = (akp - 1.0) / ak;
+            const double upd = beta, diff = upd - bold;
+            beta = upd + ratio * diff;
+            aux = wave_sum(owner ? (beta - upd) * diff : 0.0);      // this wave's rows
+        }
+        ++it;
+        // stop rule (ref src/utils.cpp:537-549)
+        const double cu = fabs(beta), q = fabs(bold);
+        const bool cn = cu > 1e-13, qn = q > 1e-13;
+        const bool moving = (cn != qn) || (cn && qn && fabs(beta - bold) > tol * q);
+        bool any;
+        if (A.accelerate) {
+            ab = gemv_rows<CG, true, true>(a, beta, wslot, ecol, moving, any, aux, S, w, lane, buf);
+            if (aux > 0.0) ak = 1.0;
+        } else
+            ab = gemv_rows<CG, true, false>(a, beta, wslot, ecol, moving, any, aux, S, w, lane, buf);
+        conv = !any;
+        if (conv || it >= A.maxit) break;
+    }
+}
+
+template <int CG>
+__global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
+{
+    typedef RowsCfg<CG> C;
+    constexpr int NBC = C::NBC, NW = 4;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l16 = lane & 15, g = lane >> 4;
+    const int p = A.p;
+    const unsigned long long t_cyc0 = __builtin_amdgcn_s_memtime(), t_rt0 = __builtin_amdgcn_s_memrealtime();
+    RowsLds S;
+    S.V = lds + C::OFF_V; S.XA = lds + C::OFF_XA; S.XN = lds + C::OFF_XN;
+    S.F = reinterpret_cast<int *>(lds + C::OFF_F);
+    double *Tal = lds + C::OFF_T, *Tbe = Tal + C::ML;
+
+    const int RWp = (p + 3) / 4, CGp = (p + 3) / 4;                 // rows per wave, columns per row group
+    // this lane's row after the reduce-scatter: slot g & 1 of the wave's rows; groups 2, 3 replicate groups 0, 1
+    const int rloc = 16 * (g & 1) + l16;
+    const bool rowok = rloc < RWp && w * RWp + rloc < p;
+    const int row = rowok ? w * RWp + rloc : 0;
+    const bool owner = rowok && g < 2;
+    const int wslot = owner ? row : 128 + lane;                     // replicas and padding lanes store a word of their own
+    int ecol[NBC];
+#pragma unroll
+    for (int j = 0; j < NBC; ++j) {
+        const int loc = 16 * j + l16, col = g * CGp + loc;
+        ecol[j] = (loc < CGp && col < p) ? col : 128 + lane;        // own dummy word: finite, meets zero columns only
+    }
+    double a[2][CG];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int lr = 16 * r + l16, grow = w * RWp + lr;
+        const bool rok = lr < RWp && grow < p;
+#pragma unroll
+        for (int k = 0; k < CG; ++k) {
+            const int col = g * CGp + k;
+            a[r][k] = (rok && k < CGp && col < p) ? A.xx[(size_t)col * p + grow] : 0.0;
+        }
+    }
+    const double xy = rowok ? A.xy[row] : 0.0, pf = rowok ? A.pf[row] : 0.0;
+    const double sinv = (rowok && A.sinv) ? A.sinv[row] : 1.0;
+    // dummy words must hold finite numbers before anyone reads them
+    for (int k = tid; k < 2 * C::VS; k += NW * 64) S.V[k] = 0.0;
+    __syncthreads();
+    int buf = 0, par = 0;
+    bool any_unused;
+    double aux_unused = 0.0;
+
+    // ---- eigenvalue step: Lanczos with the vector spread over the waves (one entry per owner lane)
+    int msteps = A.lanczos_steps < C::ML ? A.lanczos_steps : C::ML;
+    if (msteps > p) msteps = p;
+    double *theta_slot = lds + C::OFF_TH;
+    auto top_ritz = [&](int m, double hint) {
+        if (w == 0) {
+            const double th = tridiag_max(Tal, Tbe, m, lane, lds + C::OFF_S, hint);
+            if (lane == 0) theta_slot[0] = th;
+        }
+        __syncthreads();
+        const double th = theta_slot[0];
+        __syncthreads();
+        return th;
+    };
+    double v = 0.0, vp = 0.0, wn;                                    // wn: the unnormalised next vector
+    {
+        const unsigned h = (unsigned)row * 2654435761u + 12345u;     // deterministic non-structured start
+        wn = rowok ? ((double)(h >> 8) * (1.0 / 16777216.0) - 0.5) : 0.0;
+    }
+    int nst = 0;
+    double theta = 0.0, theta_prev = -__builtin_inf(), bb = 0.0;
+    bool have_theta = false;
+    for (int j = 0; j < msteps; ++j) {
+        // || wn ||: per-wave sums through per-lane words (the vector itself follows in gemv_rows' exchange)
+        const double nrm2 = waves_sum(wave_sum(owner ? wn * wn : 0.0), S.XN, par, w, lane);
+        const double nb = sqrt(nrm2);
+        if (j > 0) {
+            bb = nb;
+            if (tid == 0) Tbe[j - 1] = bb;
+            if (!(bb > 1e-13 * fabs(Tal[j - 1]))) break;             // invariant subspace reached: T is exact
+            if (nst >= 16 && (nst & 7) == 0) {
+                const double th = top_ritz(nst, theta_prev);
+                if (th - theta_prev <= 1e-14 * fabs(th)) { theta = th; have_theta = true; break; }
+                theta_prev = th;
+            }
+        }
+        const double ib = 1.0 / nb;
+        vp = v; v = wn * ib;
+        const double wv = gemv_rows<CG, false, false>(a, v, wslot, ecol, false, any_unused, aux_unused, S, w, lane, buf);
+        const double al = waves_sum(wave_sum(owner ? v * wv : 0.0), S.XA, par, w, lane);
+        if (tid == 0) Tal[j] = al;
+        nst = j + 1;
+        wn = (wv - al * v) - bb * vp;
+        __syncthreads();                                             // Tal[j] is read by every wave at the next trip
+    }
+    if (!have_theta) theta = top_ritz(nst, theta_prev);
+    const double d = theta * 1.005;                                  // ref src/oem_dense.h:498
+    if (tid == 0) { A.d_out[0] = d; A.d_out[1] = theta; }
+
+    // ---- A = d I - XX   (ref src/oem_dense.h:501-505)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int lr = 16 * r + l16, grow = w * RWp + lr;
+        const bool rok = lr < RWp && grow < p;
+#pragma unroll
+        for (int k = 0; k < CG; ++k) {
+            const int col = g * CGp + k;
+            a[r][k] = ((rok && k < CGp && col == grow) ? d : 0.0) - a[r][k];
+        }
+    }
+
+    // ---- lambda grid constants (ref src/oem_dense.cpp:175-192)
+    const double scaley = A.yscale ? A.stats[1] : 1.0;
+    const double yy = A.stats[2], nobs = A.stats[3];
+    double lmax;
+    {
+        // max |xy| over all rows: wave maxima through per-lane words, then a max over the four words
+        const double wm = wave_max(fabs(xy));
+        S.XN[(par * NW + w) * 64 + lane] = wm;
+        __syncthreads();
+        const double x = S.XN[(par * NW + (lane & (NW - 1))) * 64 + lane];
+        par ^= 1;
+        lmax = wave_max(x) * scaley;
+    }
+    const int nl = A.nl;
+    const double llo = log(lmax), lhi = log(A.lambda_min_ratio * lmax);
+    const double lstep = nl > 1 ? (lhi - llo) / (double)(nl - 1) : 0.0;
+    const bool lflip = fabs(lhi) < fabs(llo);
+
+    for (int pp = 0; pp < A.npen; ++pp) {
+        const int pen = A.penalty[pp];
+        const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
+        const bool isnet = pen_is_net(pen);
+        double beta = 0.0, ab = 0.0, ak = 1.0;                       // cold start: A 0 = 0
+        double lam_next = A.user_lambda ? A.lambda_user[(size_t)pp * nl] : 0.0;
+        for (int i = 0; i < nl; ++i) {
+            double lam;
+            if (A.user_lambda) {
+                lam = lam_next;
+                if (i + 1 < nl) lam_next = A.lambda_user[(size_t)pp * nl + i + 1];
+            } else {
+                double lv;
+                if (nl == 1) lv = lhi;
+                else if (lflip) lv = (i == 0) ? llo : lhi - (double)(nl - 1 - i) * lstep;
+                else lv = (i == nl - 1) ? lhi : llo + (double)i * lstep;
+                lam = exp(lv);
+                if (isnet) lam = lam / A.alpha;
+            }
+            const size_t orow = (size_t)pp * nl + i;
+            if (tid == 0) A.lambda_out[orow] = lam;
+            if (i >= nlam) continue;
+            const double il = lam / scaley;                               // ref src/oem_dense.cpp:241
+            const PenK K = pen_consts(pen, il, d, A.alpha, A.gamma, A.tau);
+            int it = 0, conv = 0;
+            switch (K.kind) {
+            case K_SOFT: iterate_rows<CG, K_SOFT>(A, K, d, a, xy, pf, rowok, owner, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf); break;
+            case K_MCP: iterate_rows<CG, K_MCP>(A, K, d, a, xy, pf, rowok, owner, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf); break;
+            case K_SCAD: iterate_rows<CG, K_SCAD>(A, K, d, a, xy, pf, rowok, owner, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf); break;
+            default: iterate_rows<CG, K_OLS>(A, K, d, a, xy, pf, rowok, owner, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf); break;
+            }
+            // oemXTX::get_beta rescales the member in place (ref src/oem_xtx.h:576-581, quirk Q5)
+            if (A.sinv) beta *= sinv;
+            if (owner) A.beta[orow * p + row] = beta;
+            if (tid == 0) A.niter[orow] = conv ? it : A.maxit + 1;        // ref src/oem_base.h:94-109
+            if (A.sinv) ab = gemv_rows<CG, false, false>(a, beta, wslot, ecol, false, any_unused, aux_unused, S, w, lane, buf);
+            if (A.compute_loss) {
+                // sum (Y - X beta)^2 through the Gram identity (ref src/oem_dense.h:759-770):
+                // yy - 2 n beta'XY + n beta' XX beta, with XX beta = d beta - A beta
+                const double t = waves_sum(wave_sum(owner ? beta * ((d * beta - ab) - 2.0 * xy) : 0.0), S.XN, par, w, lane);
+                if (tid == 0) A.loss[orow] = yy + nobs * t;
+            } else if (tid == 0) A.loss[orow] = 1e99;
+        }
+    }
+    if (tid == 0) {
+        A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
+        A.d_out[3] = (double)(__builtin_amdgcn_s_memrealtime() - t_rt0);
+    }
+}
+
+template <int CG> int launch_rows(hipStream_t s, const PathArgs &a)
+{
+    const size_t sh = (size_t)RowsCfg<CG>::N_DBL * sizeof(double);
+    hipLaunchKernelGGL((path_rows_kernel<CG>), dim3(1), dim3(256), sh, s, a);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int R, int NW, int CW, int G = 1> int launch_cfg(hipStream_t s, const PathArgs &a)
 {
     typedef Cfg<R, NW, CW> C;
@@ -935,6 +1272,12 @@ extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read(unsigned 
 
 int launch_path_small(hipStream_t s, const PathArgs &a)
 {
+    // element-wise penalties, 64 < p <= 128: the row-split form (beta all-gather, permlane reduce-scatter)
+    if (a.ngroups == 0 && a.p > 64 && a.p <= 128) {
+        if (a.p <= 80) return launch_rows<20>(s, a);
+        if (a.p <= 104) return launch_rows<26>(s, a);
+        return launch_rows<32>(s, a);
+    }
     // 4 waves (one per SIMD), CW = columns per wave rounded up to an even count: all CW/2 broadcast reads fit in
     // registers next to the matrix slice, so a round exposes the LDS latency once.
     if (a.p <= 32) return launch_cfg<1, 4, 8>(s, a);
