@@ -98,7 +98,7 @@ __device__ __forceinline__ double wave_max(double v)
 //     consecutive p_k) on T scaled by 1/Gershgorin, renormalised by exponent every 4 steps: one dependent FMA per
 //     step.  The pivot form q_k = (a_k - t) - b^2 / q_{k-1} costs a ~200-cycle FP64 division per step, which made this
 //     routine (9 rounds x 100 steps) a fifth of config 1's whole path kernel.
-//   * sab: LDS scratch for the scaled, interleaved coefficients (2 (m + 4) doubles).
+//   * sab: LDS scratch for the scaled, interleaved coefficients (2 (m + 8) doubles).
 //   * lo_hint: a known lower bound of the answer (the value at an earlier Lanczos step; Ritz values only grow), or
 //     -inf.  With a hint the first round places its 64 probes geometrically above it, so a nearly converged value is
 //     bracketed to a factor of two at once and two or three uniform rounds finish the job.
@@ -114,13 +114,13 @@ __device__ __forceinline__ double tridiag_max(const double *al, const double *be
     }
     lo = wave_max(lo); hi = wave_max(hi); nrm = wave_max(nrm);
     const double sc = (nrm > 0.0 && nrm < 1e300) ? 1.0 / nrm : 1.0;
-    // scaled coefficients, interleaved {a_k, b_{k-1}^2}, padded to a multiple of four steps with identity steps
-    // (b^2 = 0 and a flagged diagonal that the loop replaces by t + 1, i.e. p_k = p_{k-1}: no sign change)
-    const int mp = 1 + (m - 1 + 3) / 4 * 4;
+    // scaled coefficients, interleaved {a_k, b_{k-1}^2}, padded to a multiple of eight steps with identity steps
+    // (a_k = 2^100, b^2 = 0: p_k = 2^100 p_{k-1} keeps the sign of p_{k-1}; the renormalisation absorbs the factor)
+    const int mp = 1 + (m - 1 + 7) / 8 * 8;
     v2d *co = reinterpret_cast<v2d *>(sab);
     for (int j = lane; j < mp; j += 64) {
         const double b = (j > 0 && j < m) ? be[j - 1] * sc : 0.0;
-        co[j] = v2d{j < m ? al[j] * sc : 1e300, b * b};
+        co[j] = v2d{j < m ? al[j] * sc : 0x1p+100, b * b};
     }
     const bool hinted = lo_hint > lo;
     if (hinted) lo = lo_hint;
@@ -133,20 +133,31 @@ __device__ __forceinline__ double tridiag_max(const double *al, const double *be
         const double frac = geo ? ldexp(1.0, lane - 64) : (double)(lane + 1) / 65.0;
         const double t = (lo + w * frac) * sc;
         double pm2 = 1.0, pm1 = co[0].x - t;
-        int neg = (unsigned)__double2hiint(pm1) >> 31;
-        // four steps per trip; the next trip's coefficients are in flight while this one's dependent FMAs run
-        v2d c0 = co[1], c1 = co[2], c2 = co[3], c3 = co[4];
-        for (int k = 1; k < mp; k += 4) {
-            const v2d d0 = c0, d1 = c1, d2 = c2, d3 = c3;
-            if (k + 4 < mp) { c0 = co[k + 4]; c1 = co[k + 5]; c2 = co[k + 6]; c3 = co[k + 7]; }
-            auto step = [&](const v2d &cf) {
-                const double diag = cf.x > 1e299 ? 1.0 : cf.x - t;
-                const double pn = fma(diag, pm1, -(cf.y * pm2));
-                neg += (unsigned)(__double2hiint(pn) ^ __double2hiint(pm1)) >> 31;   // +0 counts as positive: see above
+        // sign history: one v_alignbit per step shifts the sign bit of p_k into a 32-bit register; sign changes are
+        // counted eight steps at a time with a popcount.  An exact zero counts as positive, which keeps the count
+        // right: p_k = +0 gives p_{k+1} = -b^2 p_{k-1}, one change over the two steps whichever sign p_{k-1} has.
+        unsigned hist = (unsigned)__double2hiint(pm1) >> 31;             // bit 0 = sign(p_1); sign(p_0) = 0
+        int neg = hist;
+        // eight steps per trip; the next trip's coefficients are in flight while this one's dependent FMAs run
+        v2d c[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c[q] = co[1 + q];
+        for (int k = 1; k < mp; k += 8) {
+            v2d dcur[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dcur[q] = c[q];
+            if (k + 8 < mp) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) c[q] = co[k + 8 + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double pn = fma(dcur[q].x - t, pm1, -(dcur[q].y * pm2));
+                hist = __builtin_amdgcn_alignbit(hist, (unsigned)__double2hiint(pn), 31);   // (hist << 1) | sign(pn)
                 pm2 = pm1; pm1 = pn;
-            };
-            step(d0); step(d1); step(d2); step(d3);
-            // renormalise by exponent: sign counts are scale-free, and |a - t| <= 2, b^2 <= 1 after the scaling
+            }
+            neg += __popc((hist ^ (hist >> 1)) & 0xffu);                // changes between p_{k-1} .. p_{k+7}
+            // renormalise by exponent: sign counts are scale-free; |a - t| <= 2 (2^100 in the padding), b^2 <= 1
             const int e1 = (__double2hiint(pm1) >> 20) & 0x7ff, e2 = (__double2hiint(pm2) >> 20) & 0x7ff;
             const int e = 1023 - (e1 > e2 ? e1 : e2);
             pm1 = ldexp(pm1, e); pm2 = ldexp(pm2, e);
@@ -690,8 +701,8 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
     int nst = 0;
     double bprev = 0.0;
     // Wave 0 evaluates the top Ritz value (the other waves wait at the barrier and read it from LDS).  From step 16
-    // on it is checked every 8 steps and the recurrence stops once it has moved by less than 1e-14 (relative) over
-    // the last 8: the top Ritz value of a Gram matrix typically settles in 30-50 steps, and OEM needs d only as an
+    // on it is checked every 8 steps and the recurrence stops once it has moved by less than 1e-14 (relative) since
+    // the previous check (steps 16, 32, 48, then every 8): the top Ritz value of a Gram matrix typically settles in 30-50 steps, and OEM needs d only as an
     // upper bound of lambda_max that both sides compute alike (the fixed point does not depend on d).
     double *theta_slot = lds + C::OFF_X + 3 * NW;                   // S.sum[0..1]: free until the path starts
     auto top_ritz = [&](int m, double hint) {
@@ -723,7 +734,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
         if (lane == 0) { Tal[j] = al; Tbe[j] = bb; }
         nst = j + 1;
         if (!(bb > 1e-13 * fabs(al))) break;            // invariant subspace reached: T is exact
-        if (nst >= 16 && (nst & 7) == 0 && nst < msteps) {
+        if (nst >= 16 && ((nst & 15) == 0 || (nst > 48 && (nst & 7) == 0)) && nst < msteps) {
             OEM_STAMP(10);
             const double th = top_ritz(nst, theta_prev);
             OEM_STAMP(9);
@@ -937,6 +948,37 @@ __device__ __forceinline__ double quad_sum(double v)
     v += dpp_xchg<0x4E>(v);      // quad_perm [2,3,0,1]
     return v;
 }
+// sum of a per-row value over the wave's rows (row groups 0, 1; groups 2, 3 hold replicas; padding lanes hold 0):
+// butterfly inside the 16-lane row, then one v_permlane16_swap pair joins the two groups.  Every lane gets the total.
+__device__ __forceinline__ double rows_sum(double v)
+{
+    v += dpp_xchg<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_xchg<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_xchg<0x141>(v);     // row_half_mirror
+    v += dpp_xchg<0x140>(v);     // row_mirror
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto l1 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto h1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)h1[0], (int)l1[0]) + __hiloint2double((int)h1[1], (int)l1[1]);
+}
+// s = sqrt(x), r = 1 / sqrt(x) for the Lanczos normalisation: v_rsq_f64 + two coupled Goldschmidt steps (~10
+// dependent FP64 ops; the library sqrt followed by a division is ~45).  Outside [1e-200, 1e200] the slow pair.
+__device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &r)
+{
+    if (x > 1e-200 && x < 1e200) {
+        const double y = __builtin_amdgcn_rsq(x);
+        double g = x * y, h = 0.5 * y;
+        double e = fma(-h, g, 0.5);
+        g = fma(g, e, g); h = fma(h, e, h);
+        e = fma(-h, g, 0.5);
+        g = fma(g, e, g); h = fma(h, e, h);
+        e = fma(-g, g, x);                                         // last correction of the root
+        g = fma(e, h, g);
+        s = g; r = 2.0 * h;
+    } else {
+        s = sqrt(x); r = 1.0 / s;
+    }
+}
 // p0 / p1: this row group's slice sums of row slots 0 / 1.  Returns the sum over the four row groups of slot (g & 1).
 __device__ __forceinline__ double rowgroup_reduce_scatter(double p0, double p1)
 {
@@ -973,8 +1015,8 @@ template <int CG> struct RowsCfg {
     static constexpr int OFF_XN = OFF_XA + 2 * NW * 64;   // per-lane scalar words [2][NW][64] (norms, sums)
     static constexpr int OFF_F = OFF_XN + 2 * NW * 64;    // int flags [2][NW][64]
     static constexpr int OFF_T = OFF_F + NW * 64;         // Lanczos alpha[ML], beta[ML]
-    static constexpr int OFF_S = OFF_T + 2 * ML;          // Sturm scratch 2 (ML + 4)
-    static constexpr int OFF_TH = OFF_S + 2 * (ML + 4);   // theta slot
+    static constexpr int OFF_S = OFF_T + 2 * ML;          // Sturm scratch 2 (ML + 8)
+    static constexpr int OFF_TH = OFF_S + 2 * (ML + 8);   // theta slot
     static constexpr int N_DBL = OFF_TH + 2;
 };
 
@@ -985,9 +1027,12 @@ struct RowsLds {
 
 // exchange + GEMV: every owner lane publishes `mine` (its row's entry), every lane picks up the entries of its
 // row group's column slice and returns (M vec)[own row].  flag / aux as in gemv_sliced.
-template <int CG, bool FLAGS, bool USE_AUX>
+// NORM (Lanczos): aux carries this wave's share of || vec ||^2; the gathered entries are divided by the norm before
+// the product, so the result is M (vec / || vec ||); aux returns the norm and scale its reciprocal.
+template <int CG, bool FLAGS, bool USE_AUX, bool NORM = false>
 __device__ __forceinline__ double gemv_rows(const double (&a)[2][CG], double mine, int wslot, const int (&ecol)[(CG + 15) / 16],
-                                            bool moving, bool &any, double &aux, const RowsLds &S, int w, int lane, int &buf)
+                                            bool moving, bool &any, double &aux, const RowsLds &S, int w, int lane, int &buf,
+                                            double *scale = nullptr)
 {
     constexpr int NBC = (CG + 15) / 16, VS = RowsCfg<CG>::VS, NW = 4;
     const int b = __builtin_amdgcn_readfirstlane(buf);              // provably uniform: addresses stay scalar + immediate
@@ -1004,11 +1049,18 @@ __device__ __forceinline__ double gemv_rows(const double (&a)[2][CG], double min
 #pragma unroll
     for (int j = 0; j < NBC; ++j) B[j] = S.V[b * VS + ecol[j]];
     __builtin_amdgcn_sched_barrier(0);
+    if (NORM) {
+        double nb, ib;
+        sqrt_rsqrt(quad_sum(xa), nb, ib);
+#pragma unroll
+        for (int j = 0; j < NBC; ++j) B[j] *= ib;
+        aux = nb; *scale = ib;
+    }
     double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
     asm volatile("s_nop 1" ::: "memory");                       // VALU write of B -> DPP read
     GroupFma<CG, 0>::run(acc, B, a);
     const double out = rowgroup_reduce_scatter(acc[0][0] + acc[0][1], acc[1][0] + acc[1][1]);
-    if (USE_AUX) aux = quad_sum(xa);
+    if (USE_AUX && !NORM) aux = quad_sum(xa);
     any = FLAGS ? __any(f != 0) : false;
     buf = b ^ 1;
     return out;
@@ -1035,8 +1087,7 @@ __device__ __forceinline__ void iterate_rows(const PathArgs &A, const PenK &K, d
     const double tp = pf * K.L, tol = A.tol;
     for (;;) {
         const double bold = beta;
-        const double b = threshold1<KIND>(ab + xy, tp, c);
-        beta = rowok ? b : 0.0;
+        beta = threshold1<KIND>(ab + xy, tp, c);                    // padding lanes: zero matrix rows, xy = 0 => stays 0
         double aux = 0.0;
         if (A.accelerate) {                                        // ref src/oem_dense.h:633-651
             const double akp = ak;
@@ -1044,7 +1095,7 @@ __device__ __forceinline__ void iterate_rows(const PathArgs &A, const PenK &K, d
             const double ratio = (akp - 1.0) / ak;
             const double upd = beta, diff = upd - bold;
             beta = upd + ratio * diff;
-            aux = wave_sum(owner ? (beta - upd) * diff : 0.0);      // this wave's rows
+            aux = rows_sum((beta - upd) * diff);                   // this wave's rows (padding lanes hold 0)
         }
         ++it;
         // stop rule (ref src/utils.cpp:537-549)
@@ -1131,28 +1182,27 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
     int nst = 0;
     double theta = 0.0, theta_prev = -__builtin_inf(), bb = 0.0;
     bool have_theta = false;
+    double al_prev = 0.0;
     for (int j = 0; j < msteps; ++j) {
-        // || wn ||: per-wave sums through per-lane words (the vector itself follows in gemv_rows' exchange)
-        const double nrm2 = waves_sum(wave_sum(owner ? wn * wn : 0.0), S.XN, par, w, lane);
-        const double nb = sqrt(nrm2);
+        // one exchange carries the unnormalised vector AND the per-wave shares of its squared norm
+        double nb = rows_sum(wn * wn), ib = 0.0;
+        const double wv = gemv_rows<CG, false, true, true>(a, wn, wslot, ecol, false, any_unused, nb, S, w, lane, buf, &ib);
         if (j > 0) {
             bb = nb;
             if (tid == 0) Tbe[j - 1] = bb;
-            if (!(bb > 1e-13 * fabs(Tal[j - 1]))) break;             // invariant subspace reached: T is exact
-            if (nst >= 16 && (nst & 7) == 0) {
+            if (!(bb > 1e-13 * fabs(al_prev))) break;                // invariant subspace reached: T is exact
+            if (nst >= 16 && ((nst & 15) == 0 || (nst > 48 && (nst & 7) == 0))) {
                 const double th = top_ritz(nst, theta_prev);
                 if (th - theta_prev <= 1e-14 * fabs(th)) { theta = th; have_theta = true; break; }
                 theta_prev = th;
             }
         }
-        const double ib = 1.0 / nb;
         vp = v; v = wn * ib;
-        const double wv = gemv_rows<CG, false, false>(a, v, wslot, ecol, false, any_unused, aux_unused, S, w, lane, buf);
-        const double al = waves_sum(wave_sum(owner ? v * wv : 0.0), S.XA, par, w, lane);
-        if (tid == 0) Tal[j] = al;
+        const double al = waves_sum(rows_sum(v * wv), S.XA, par, w, lane);
+        if (tid == 0) Tal[j] = al;                                   // read by wave 0 only (top_ritz)
+        al_prev = al;
         nst = j + 1;
         wn = (wv - al * v) - bb * vp;
-        __syncthreads();                                             // Tal[j] is read by every wave at the next trip
     }
     if (!have_theta) theta = top_ritz(nst, theta_prev);
     const double d = theta * 1.005;                                  // ref src/oem_dense.h:498
@@ -1227,7 +1277,7 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
             if (A.compute_loss) {
                 // sum (Y - X beta)^2 through the Gram identity (ref src/oem_dense.h:759-770):
                 // yy - 2 n beta'XY + n beta' XX beta, with XX beta = d beta - A beta
-                const double t = waves_sum(wave_sum(owner ? beta * ((d * beta - ab) - 2.0 * xy) : 0.0), S.XN, par, w, lane);
+                const double t = waves_sum(rows_sum(beta * ((d * beta - ab) - 2.0 * xy)), S.XN, par, w, lane);
                 if (tid == 0) A.loss[orow] = yy + nobs * t;
             } else if (tid == 0) A.loss[orow] = 1e99;
         }
