@@ -139,6 +139,14 @@ def main():
     flops = float(n_loc) * p * (p + 1) + 2.0 * n_loc * p            # lower-triangular syrk + X'y
     bytes_alg = 8.0 * n_loc * p + 8.0 * n_loc
     achieved_tf = flops / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else 0.0
+    # HBM traffic of that kernel: PMC counters cannot be read from inside this process, so the figure is the one the
+    # separate rocprofv3 --pmc passes of this same command measured (tools/round_artifacts.sh -> profiles/),
+    # FETCH_SIZE x2 + WRITE_SIZE as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950; null if it does not apply.
+    traffic, traffic_src = None, None
+    pmc = ROOT / "profiles" / "r1_pmc_gram.json"
+    if pmc.exists() and n == 1_000_000 and p == 100 and world == 1:
+        traffic = float(json.loads(pmc.read_text())["hbm_bytes_per_dispatch"])
+        traffic_src = "profiles/r1_pmc_gram.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
 
     out = None
     if rank == 0:
@@ -154,9 +162,10 @@ def main():
                        "n": n, "p": p, "nlambda": int(len(lambdas)), "rows_per_gpu": n_loc,
                        "sharding": "rows/N + one all-reduce of the (p+2)^2 moment buffer" if world > 1 else "none",
                        "oem_iterations_per_solve": niter_total},
-            "roofline": {"bound": "mfma", "kernel": "gram_tri_kernel<7> (v_mfma_f64_16x16x4_f64)",
+            "roofline": {"bound": "mfma", "kernel": "gram_ring_kernel<7> (v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src,
                          "kernel_ms": gram_ms, "algorithmic_flops": flops, "algorithmic_bytes": bytes_alg,
                          "hbm_GBps_algorithmic": bytes_alg / (gram_ms * 1e-3) / 1e9 if gram_ms > 0 else 0.0},
             "stage_ms": {"shift_sample": acc[L.T_SHIFT], "moments_total": acc[L.T_MOMENTS], "finalize": acc[L.T_FINAL],
