@@ -505,7 +505,41 @@ __device__ unsigned long long g_gram_diag[8];
 #define GSTAMP(slot) do { } while (0)
 #endif
 
-template <int NT, bool SHIFT>
+// The strip form (SB > 0; un-shifted variant only).  When the last tile row holds at most 4 SB <= 8 real columns
+// (p = 100: y, the ones and four x columns -- 6 of 16), its NT tiles cost a quarter of the MFMA work for 3/8 of a
+// tile row.  v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks, 16.5 cycles: the same FLOP per cycle) has the
+// k index on lane / 16 like the 16x16x4 and the block index on (lane % 16) / 4 (tools/mfma444_layout.hip), so a
+// column fragment already IS a valid B operand holding four 4-column sub-blocks; the A operand -- one 4-column
+// sub-block of the strip replicated into all four block slots -- is a second read of the ring slot with a permuted
+// lane address.  SB NT strip MFMAs replace the NT tile MFMAs of the last row: 3584 -> 3150 cycles per slab at p = 100.
+// The ragged last slab keeps the plain tiles; the epilogue adds both into the same partial tiles.
+template <int NT, int SB, typename Hook = NoHook>
+__device__ __forceinline__ void consume_ring_strip(Slab<NT> &s, const v2d (&ua)[SB > 0 ? SB : 1], Hook &&hook = NoHook())
+{
+    constexpr int NM16 = (NT - 1) * NT / 2;
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<2>([&](auto E) {
+        constexpr int e = decltype(E)::value;
+        static_for<NT - 1>([&](auto I_) {
+            constexpr int I = decltype(I_)::value;
+            static_for<I + 1>([&](auto J_) {
+                constexpr int J = decltype(J_)::value;
+                AccTile<I *(I + 1) / 2 + J>::mfma(s.v[I][e], s.v[J][e]);
+                hook(std::integral_constant<int, e * NM16 + I * (I + 1) / 2 + J>{});
+            });
+        });
+        static_for<SB>([&](auto A_) {
+            constexpr int a = decltype(A_)::value;
+            static_for<NT>([&](auto T_) {
+                constexpr int T = decltype(T_)::value;
+                AccStrip<a * NT + T>::mfma(ua[a][e], s.v[T][e]);
+            });
+        });
+    });
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NT, bool SHIFT, int SB = 0>
 __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x, int64_t n, int64_t ld, int p,
                                                    const double *__restrict__ y, const double *__restrict__ sums,
                                                    int64_t row_begin, int steps, double *__restrict__ tdst, double *lds)
@@ -538,7 +572,10 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
     const int64_t inc_last = const_lane ? 0 : 32;
     VecAcc<NF> V;          // unused (AUG): kept for consume_slab's signature
     V.sy = 0.0; V.syy = 0.0;
+    static_assert(SB == 0 || !SHIFT, "the strip form takes its operands straight from the ring");
+    static_assert(SB * NT <= 14, "strip accumulators");
     static_for<NTILES>([&](auto T_) { AccTile<decltype(T_)::value>::zero(); });
+    static_for<SB * NT>([&](auto S_) { AccStrip<decltype(S_)::value>::zero(); });
     asm volatile("s_nop 7" ::: "memory");
 
     const int nslab = 2 * steps;
@@ -561,12 +598,18 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
 #pragma unroll
         for (int f = 0; f < NF; ++f) cur[f] += (f == NF - 1) ? inc_last : 32;
     };
-    auto fetch = [&](Slab<NF> &s, int slot) {                      // ring slot -> registers (a lane reads back its own 16 B)
+    // strip A operands: lane (q, blk, x) reads the 16 B of lane (q, a, x) of the last fragment (both k halves)
+    const v2d *ring_rdA = reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(lds) + w * (NSLOT * SLOT_B)) +
+                          (NF - 1) * 64 + 16 * q + (lane & 3);
+    auto fetch = [&](Slab<NF> &s, v2d (&ua)[SB > 0 ? SB : 1], int slot) {   // ring slot -> registers (a lane reads back its own 16 B)
 #pragma unroll
         for (int f = 0; f < NF; ++f) s.v[f] = ring_rd[(slot * SLOT_B + f * 1024) / 16];
+#pragma unroll
+        for (int a = 0; a < SB; ++a) ua[a] = ring_rdA[(slot * SLOT_B) / 16 + 4 * a];
     };
     auto next = [](int v) { return v + 1 == NSLOT ? 0 : v + 1; };
     Slab<NF> sa, sb;
+    v2d ua[SB > 0 ? SB : 1], ub[SB > 0 ? SB : 1];
     sa.y = v2d{0.0, 0.0}; sb.y = sa.y;
 #ifdef OEM_GRAM_DIAG
     unsigned long long gd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gl = __builtin_amdgcn_s_memtime();
@@ -577,7 +620,7 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
     int slot = 0, islot = npre % NSLOT, issued = npre, k = 0;
     if (ns > 0) {
         if (npre == NSLOT - 1) wait_vm<(NSLOT - 2) * NF>(); else wait_vm<0>();
-        fetch(sa, 0);
+        fetch(sa, ua, 0);
         slot = next(slot);
     }
     // steady state, two slabs per trip (sa / sb alternate as "in registers" and "being fetched"):
@@ -586,10 +629,11 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
     // steady state: while the MFMAs of slab k run, the hook (a) issues the DMA of slab k+NSLOT-1 after MFMAs 1..NF,
     // (b) bumps the pointers, (c) waits for slab k+1 (exact vmcnt) and (d) copies it from the ring to the other
     // register slab after MFMAs NF+2 .. 2NF+1.  None of it is FP64 VALU, so it rides in the MFMA shadows.
-    auto steady = [&](Slab<NF> &use, Slab<NF> &nxt) {
+    auto steady = [&](Slab<NF> &use, Slab<NF> &nxt, v2d (&uuse)[SB > 0 ? SB : 1], v2d (&unxt)[SB > 0 ? SB : 1]) {
         const unsigned dst = ring + (unsigned)islot * SLOT_B;
         const v2d *src = ring_rd + (slot * SLOT_B) / 16;
-        consume_slab<NT, NT, true, false, false, true, SHIFT>(V, use, X, cy, 0, n, [&](auto M_) {
+        const v2d *srcA = ring_rdA + (slot * SLOT_B) / 16;
+        auto hook = [&](auto M_) {
             constexpr int m = decltype(M_)::value;
             if constexpr (m >= 1 && m <= NF) glds16<0>(cur[m - 1], dst + (m - 1) * 1024);
             if constexpr (m == NF + 1) {
@@ -598,14 +642,18 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
                 wait_vm<(NSLOT - 2) * NF>();
             }
             if constexpr (m >= NF + 2 && m <= 2 * NF + 1) nxt.v[m - NF - 2] = src[((m - NF - 2) * 1024) / 16];
-        });
+            if constexpr (SB > 0 && m >= 2 * NF + 2 && m < 2 * NF + 2 + SB) unxt[m - 2 * NF - 2] = srcA[4 * (m - 2 * NF - 2)];
+        };
+        if constexpr (SB > 0) consume_ring_strip<NT, SB>(use, uuse, hook);
+        else consume_slab<NT, NT, true, false, false, true, SHIFT>(V, use, X, cy, 0, n, hook);
         islot = next(islot); slot = next(slot);
     };
+    static_assert(SB == 0 || 2 * NF + 2 + SB <= (NT - 1) * NT, "not enough 16x16x4 MFMAs per slab to carry the hooks");
     static_assert(2 * NF + 1 < NT * (NT + 1), "not enough MFMAs per slab to carry the hooks");
     while (k + NSLOT + 1 <= ns) {
-        steady(sa, sb);
+        steady(sa, sb, ua, ub);
         GSTAMP(4);
-        steady(sb, sa);
+        steady(sb, sa, ub, ua);
         GSTAMP(4);
         issued += 2; k += 2;
     }
@@ -613,11 +661,14 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
     while (issued < ns) { issue(islot); islot = next(islot); ++issued; }
     wait_vm<0>();
     for (; k < ns; ++k) {
-        if (k + 1 < ns) { fetch(sb, slot); slot = next(slot); }
-        consume_slab<NT, NT, true, false, false, true, SHIFT>(V, sa, X, cy, 0, n);
+        if (k + 1 < ns) { fetch(sb, ub, slot); slot = next(slot); }
+        if constexpr (SB > 0) consume_ring_strip<NT, SB>(sa, ua);
+        else consume_slab<NT, NT, true, false, false, true, SHIFT>(V, sa, X, cy, 0, n);
         if (k + 1 < ns) {
 #pragma unroll
             for (int f = 0; f < NF; ++f) sa.v[f] = sb.v[f];
+#pragma unroll
+            for (int a = 0; a < SB; ++a) ua[a] = ub[a];
         }
     }
     GSTAMP(5);                                   // drain
@@ -645,6 +696,13 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
                 constexpr int r = decltype(R_)::value;
                 lds[(size_t)w * (TPP * 256) + ((tt - t0) * 4 + r) * 64 + lane] = AccTile<tt>::template read<r>();
             });
+        });
+        // strip accumulator (a, T): lane 16 i + c holds element (row 4 a + i, column c) of tile (NT-1, T); the 16x16x4
+        // layout keeps (row, c) in register row / 4 of lane 16 (row % 4) + c: register a of the same lane
+        static_for<SB * NT>([&](auto S_) {
+            constexpr int sidx = decltype(S_)::value, a = sidx / NT, T = sidx % NT, tt = (NT - 1) * NT / 2 + T;
+            if constexpr (tt >= t0 && tt < t1)
+                lds[(size_t)w * (TPP * 256) + ((tt - t0) * 4 + a) * 64 + lane] += AccStrip<sidx>::read();
         });
         __syncthreads();
         for (int e = tid; e < (t1 - t0) * 256; e += 256) {
@@ -687,7 +745,7 @@ __global__ __launch_bounds__(256) void gram_tri_kernel(const double *__restrict_
 }
 
 // whole lower triangle of Z = [X | y | 1] in one wave, slabs through the LDS-DMA ring (16-byte aligned X)
-template <int NT>
+template <int NT, int SB>
 __global__ __launch_bounds__(256) void gram_ring_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                          const double *__restrict__ sums, double *__restrict__ tpart,
                                                          double *__restrict__ vpart, GramDims a)
@@ -699,8 +757,8 @@ __global__ __launch_bounds__(256) void gram_ring_kernel(const double *__restrict
         gram_tri_ring_body<NT, true>(x, a.n, a.ld, a.p, y, sums, (int64_t)chunk * a.steps * 64, a.steps,
                                      tpart + (size_t)chunk * a.ntile * 256, lds);
     else
-        gram_tri_ring_body<NT, false>(x, a.n, a.ld, a.p, y, sums, (int64_t)chunk * a.steps * 64, a.steps,
-                                      tpart + (size_t)chunk * a.ntile * 256, lds);
+        gram_tri_ring_body<NT, false, SB>(x, a.n, a.ld, a.p, y, sums, (int64_t)chunk * a.steps * 64, a.steps,
+                                          tpart + (size_t)chunk * a.ntile * 256, lds);
 }
 
 // 4x4 tile blocks of X'X; blockIdx -> (row chunk, tile block) so that the tile blocks of one row chunk run
@@ -778,15 +836,20 @@ static int launch_gram_t(hipStream_t s, const GramPlan &pl, const double *x, con
         size_t sh = (size_t)pl.ntile * tile_bytes;
         const size_t rb = (size_t)4 * 5 * pl.ntc * 1024;                         // 4 waves x NSLOT x NF KiB ring
         if (sh < rb) sh = rb;
-#define OEM_RING(NT)                                                                                                   \
-    if (pl.ntc == NT) {                                                                                                \
-        if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_ring_kernel<NT>),         \
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));        \
-        hipLaunchKernelGGL((gram_ring_kernel<NT>), dim3(pl.nchunk), dim3(256), sh, s, x, y, sums, tpart, vpart, a);   \
-        OEM_HIP(hipGetLastError());                                                                                    \
-        return 0;                                                                                                      \
+        // real columns in the last tile row -> strip sub-blocks (0: the last row stays on 16x16x4 tiles)
+        const int rem = pl.p + 2 - 16 * (pl.ntc - 1);
+        const int sb = rem <= 4 ? 1 : (rem <= 8 ? 2 : 0);
+#define OEM_RING(NT, SB)                                                                                                   \
+    if (pl.ntc == NT && sb == SB) {                                                                                        \
+        if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_ring_kernel<NT, SB>),         \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));            \
+        hipLaunchKernelGGL((gram_ring_kernel<NT, SB>), dim3(pl.nchunk), dim3(256), sh, s, x, y, sums, tpart, vpart, a);   \
+        OEM_HIP(hipGetLastError());                                                                                        \
+        return 0;                                                                                                          \
     }
-        OEM_RING(4) OEM_RING(5) OEM_RING(6) OEM_RING(7)
+        OEM_RING(4, 0) OEM_RING(5, 0) OEM_RING(6, 0) OEM_RING(7, 0)
+        OEM_RING(4, 1) OEM_RING(5, 1) OEM_RING(6, 1) OEM_RING(7, 1)
+        OEM_RING(4, 2) OEM_RING(5, 2) OEM_RING(6, 2) OEM_RING(7, 2)
 #undef OEM_RING
     }
     if (pl.tri) {

@@ -151,6 +151,33 @@ def test_tile_count_boundaries(oa):
         _cmp(oa.oem(x, y, **kw), orc.fit_dense(x, y, **kw))
 
 
+@pytest.mark.parametrize("p", [46, 50, 54, 62, 66, 70, 82, 86, 94, 98, 102, 106])
+@pytest.mark.parametrize("n", [4096, 3001, 10007])
+def test_ring_strip_forms_of_the_moment_kernel(oa, p, n):
+    """LDS-DMA ring Gram kernel, every strip form (last tile row with <= 4 / <= 8 / more real columns: 4x4x4 MFMA
+    sub-blocks vs plain tiles), full and ragged slabs, against numpy"""
+    import torch
+    from oem_amd import _lib as L
+    x, y = _data(n, p, 100 + p, mean=0.2)
+    ld = n + (n & 1)
+    xd = torch.zeros((p, ld), dtype=torch.float64, device="cuda")
+    xd[:, :n] = torch.as_tensor(np.ascontiguousarray(x.T))
+    yd = torch.as_tensor(y, device="cuda")
+    sums = torch.zeros(L.sums_len(p), dtype=torch.float64, device="cuda")
+    M = torch.zeros((p + 2, p + 2), dtype=torch.float64, device="cuda")
+    ctx = oa.context()
+    torch.cuda.synchronize()
+    L.check(L.lib().oemgpu_shift_sums_dev(ctx, xd.data_ptr(), n, ld, p, yd.data_ptr(), sums.data_ptr()))
+    L.check(L.lib().oemgpu_moments_dev(ctx, xd.data_ptr(), n, ld, p, yd.data_ptr(), sums.data_ptr(), M.data_ptr()))
+    L.check(L.lib().oemgpu_synchronize(ctx))
+    z = np.column_stack([x, y, np.ones(n)])
+    want = np.tril(z.T @ z)
+    got = np.tril(M.cpu().numpy().T)          # column-major buffer, lower triangle valid
+    scale = np.sqrt(np.outer(np.diag(want), np.diag(want)))
+    assert np.abs((got - want) / scale).max() < 1e-12
+    assert got[p + 1, p + 1] == n
+
+
 def test_xtx_matches_dense_and_oracle(oa, doc_kats):
     x, y = K.kat1()
     n = x.shape[0]
