@@ -194,6 +194,21 @@ template <int OFF> __device__ __forceinline__ void glds16(gptr_t src, unsigned l
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(lds_byte_addr), "i"(OFF * 8) : "memory");
 }
+// Steady-state form: M0 is set ONCE per slab and the seven fragments are told apart by the instruction offset, which
+// (tools/ldsdma_offset_probe.hip) moves the global address AND the LDS destination by the same number of bytes -- so
+// the source pointer is pre-decremented by it.  The M0 save / set / restore dance per DMA cost 12 cycles each.
+__device__ __forceinline__ void set_m0(unsigned lds_byte_addr)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_byte_addr) : "memory");
+}
+template <int OFFB> __device__ __forceinline__ void glds_v(gptr_t src)               // 64-bit per-lane address
+{
+    asm volatile("global_load_lds_dwordx4 %0, off offset:%1" ::"v"(src), "i"(OFFB) : "memory");
+}
+template <int OFFB> __device__ __forceinline__ void glds_s(unsigned voff, gptr_t sbase)   // scalar base + 32-bit lane offset
+{
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(sbase), "i"(OFFB) : "memory");
+}
 template <int PENDING> __device__ __forceinline__ void wait_vm()
 {
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PENDING) : "memory");
@@ -539,7 +554,10 @@ __device__ __forceinline__ void consume_ring_strip(Slab<NT> &s, const v2d (&ua)[
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NT, bool SHIFT, int SB = 0>
+// SADDR: fragments 0 .. NT-2 (whole X columns) are addressed as one scalar base (advanced by a scalar add per slab) plus
+// a 32-bit per-lane offset; only the last fragment (y, ones, another allocation) keeps a 64-bit pointer per lane.
+// A 64-bit VALU add runs on the DP units the MFMAs need: seven pointer bumps cost 75 cycles per slab (measured).
+template <int NT, bool SHIFT, int SB = 0, bool SADDR = false>
 __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x, int64_t n, int64_t ld, int p,
                                                    const double *__restrict__ y, const double *__restrict__ sums,
                                                    int64_t row_begin, int steps, double *__restrict__ tdst, double *lds)
@@ -585,18 +603,37 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
         int64_t k = (n - w0 - 8) / 32 + 1;
         ns = k < nslab ? (int)k : nslab;
     }
+    // instruction offsets (f - CEN) KiB select the fragment's part of the ring slot; sources are pre-decremented
+    constexpr int CEN = NF / 2;
+    unsigned voff[NF];
+    gptr_t sbase = xg + w0;                                          // wave-uniform
 #pragma unroll
-    for (int f = 0; f < NF; ++f) cur[f] += (f == NF - 1 && const_lane) ? 0 : w0 + 2 * q;
+    for (int f = 0; f < NF; ++f) {
+        const int col = 16 * f + i;
+        voff[f] = (unsigned)(((int64_t)(col < p ? col : 0) * ld + 2 * q) * 8 - (f - CEN) * 1024);
+        cur[f] += ((f == NF - 1 && const_lane) ? 0 : w0 + 2 * q) - (f - CEN) * 128;
+    }
 
     constexpr int NSLOT = 5, SLOT_B = NF * 1024;
     static_assert((NSLOT - 1) * NF <= 63, "vmcnt field is 6 bits");
     const unsigned ring = (unsigned)(size_t)lds + (unsigned)w * (NSLOT * SLOT_B);     // LDS byte address of this wave's ring
     const v2d *ring_rd = reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(lds) + w * (NSLOT * SLOT_B)) + lane;
-    auto issue = [&](int slot) {                                   // DMA the next slab into ring slot `slot`
-        const unsigned dst = ring + (unsigned)slot * SLOT_B;
-        static_for<NF>([&](auto F_) { constexpr int f = decltype(F_)::value; glds16<0>(cur[f], dst + f * 1024); });
+    auto dma = [&](auto F_) {                                      // fragment f of the next slab (M0 set by the caller)
+        constexpr int f = decltype(F_)::value;
+        if constexpr (SADDR && f < NF - 1) glds_s<(f - CEN) * 1024>(voff[f], sbase);
+        else glds_v<(f - CEN) * 1024>(cur[f]);
+    };
+    auto bump = [&]() {
+        if constexpr (SADDR) { sbase += 32; cur[NF - 1] += inc_last; }
+        else {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) cur[f] += (f == NF - 1) ? inc_last : 32;
+            for (int f = 0; f < NF; ++f) cur[f] += (f == NF - 1) ? inc_last : 32;
+        }
+    };
+    auto issue = [&](int slot) {                                   // DMA the next slab into ring slot `slot`
+        set_m0(ring + (unsigned)slot * SLOT_B + CEN * 1024);
+        static_for<NF>(dma);
+        bump();
     };
     // strip A operands: lane (q, blk, x) reads the 16 B of lane (q, a, x) of the last fragment (both k halves)
     const v2d *ring_rdA = reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(lds) + w * (NSLOT * SLOT_B)) +
@@ -633,16 +670,21 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
         const unsigned dst = ring + (unsigned)islot * SLOT_B;
         const v2d *src = ring_rd + (slot * SLOT_B) / 16;
         const v2d *srcA = ring_rdA + (slot * SLOT_B) / 16;
+        // OEM_GRAM_EXP (timing experiments in diagnostic builds only; results are wrong): 1 = no DMA issue,
+        // 2 = no ring reads, 3 = no vmcnt wait, 4 = no pointer bumps
+#ifndef OEM_GRAM_EXP
+#define OEM_GRAM_EXP 0
+#endif
         auto hook = [&](auto M_) {
             constexpr int m = decltype(M_)::value;
-            if constexpr (m >= 1 && m <= NF) glds16<0>(cur[m - 1], dst + (m - 1) * 1024);
+            if constexpr (OEM_GRAM_EXP != 1 && m == 1) set_m0(dst + CEN * 1024);
+            if constexpr (OEM_GRAM_EXP != 1 && m >= 1 && m <= NF) dma(std::integral_constant<int, m - 1>{});
             if constexpr (m == NF + 1) {
-#pragma unroll
-                for (int f = 0; f < NF; ++f) cur[f] += (f == NF - 1) ? inc_last : 32;
-                wait_vm<(NSLOT - 2) * NF>();
+                if constexpr (OEM_GRAM_EXP != 4) bump();
+                if constexpr (OEM_GRAM_EXP != 3 && OEM_GRAM_EXP != 1) wait_vm<(NSLOT - 2) * NF>();
             }
-            if constexpr (m >= NF + 2 && m <= 2 * NF + 1) nxt.v[m - NF - 2] = src[((m - NF - 2) * 1024) / 16];
-            if constexpr (SB > 0 && m >= 2 * NF + 2 && m < 2 * NF + 2 + SB) unxt[m - 2 * NF - 2] = srcA[4 * (m - 2 * NF - 2)];
+            if constexpr (OEM_GRAM_EXP != 2 && m >= NF + 2 && m <= 2 * NF + 1) nxt.v[m - NF - 2] = src[((m - NF - 2) * 1024) / 16];
+            if constexpr (OEM_GRAM_EXP != 2 && SB > 0 && m >= 2 * NF + 2 && m < 2 * NF + 2 + SB) unxt[m - 2 * NF - 2] = srcA[4 * (m - 2 * NF - 2)];
         };
         if constexpr (SB > 0) consume_ring_strip<NT, SB>(use, uuse, hook);
         else consume_slab<NT, NT, true, false, false, true, SHIFT>(V, use, X, cy, 0, n, hook);
@@ -680,7 +722,11 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             if (f == NF - 1 && const_lane) { sa.v[f] = v2d{1.0, 1.0}; continue; }
-            sa.v[f].x = cur[f][o0]; sa.v[f].y = cur[f][o1];
+            // undo the pre-decrement; SADDR fragments are rebuilt from the scalar base and the lane offset
+            const gptr_t pf = (SADDR && f < NF - 1)
+                                  ? (gptr_t)((const char __attribute__((address_space(1))) *)sbase + voff[f]) + (f - CEN) * 128
+                                  : cur[f] + (f - CEN) * 128;
+            sa.v[f].x = pf[o0]; sa.v[f].y = pf[o1];
         }
         consume_slab<NT, NT, true, true, false, true, SHIFT>(V, sa, X, cy, r, n);
     }
@@ -745,7 +791,7 @@ __global__ __launch_bounds__(256) void gram_tri_kernel(const double *__restrict_
 }
 
 // whole lower triangle of Z = [X | y | 1] in one wave, slabs through the LDS-DMA ring (16-byte aligned X)
-template <int NT, int SB>
+template <int NT, int SB, bool SADDR>
 __global__ __launch_bounds__(256) void gram_ring_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                          const double *__restrict__ sums, double *__restrict__ tpart,
                                                          double *__restrict__ vpart, GramDims a)
@@ -754,11 +800,11 @@ __global__ __launch_bounds__(256) void gram_ring_kernel(const double *__restrict
     (void)vpart;
     const int chunk = blockIdx.x;
     if (shift_needed_wave(sums, a.p))
-        gram_tri_ring_body<NT, true>(x, a.n, a.ld, a.p, y, sums, (int64_t)chunk * a.steps * 64, a.steps,
-                                     tpart + (size_t)chunk * a.ntile * 256, lds);
+        gram_tri_ring_body<NT, true, 0, SADDR>(x, a.n, a.ld, a.p, y, sums, (int64_t)chunk * a.steps * 64, a.steps,
+                                               tpart + (size_t)chunk * a.ntile * 256, lds);
     else
-        gram_tri_ring_body<NT, false, SB>(x, a.n, a.ld, a.p, y, sums, (int64_t)chunk * a.steps * 64, a.steps,
-                                          tpart + (size_t)chunk * a.ntile * 256, lds);
+        gram_tri_ring_body<NT, false, SB, SADDR>(x, a.n, a.ld, a.p, y, sums, (int64_t)chunk * a.steps * 64, a.steps,
+                                                 tpart + (size_t)chunk * a.ntile * 256, lds);
 }
 
 // 4x4 tile blocks of X'X; blockIdx -> (row chunk, tile block) so that the tile blocks of one row chunk run
@@ -838,18 +884,21 @@ static int launch_gram_t(hipStream_t s, const GramPlan &pl, const double *x, con
         if (sh < rb) sh = rb;
         // real columns in the last tile row -> strip sub-blocks (0: the last row stays on 16x16x4 tiles)
         const int rem = pl.p + 2 - 16 * (pl.ntc - 1);
-        const int sb = rem <= 4 ? 1 : (rem <= 8 ? 2 : 0);
-#define OEM_RING(NT, SB)                                                                                                   \
-    if (pl.ntc == NT && sb == SB) {                                                                                        \
-        if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_ring_kernel<NT, SB>),         \
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));            \
-        hipLaunchKernelGGL((gram_ring_kernel<NT, SB>), dim3(pl.nchunk), dim3(256), sh, s, x, y, sums, tpart, vpart, a);   \
-        OEM_HIP(hipGetLastError());                                                                                        \
-        return 0;                                                                                                          \
+        // scalar-base addressing needs fragments 0 .. ntc-2 to be whole X columns and every lane offset to fit 32 bits
+        const bool saddr = pl.p >= 16 * (pl.ntc - 1) && (double)pl.p * (double)a.ld * 8.0 + 65536.0 < 4294967296.0;
+        const int sb = !saddr ? 0 : (rem <= 4 ? 1 : (rem <= 8 ? 2 : 0));
+#define OEM_RING(NT, SB, SA)                                                                                                   \
+    if (pl.ntc == NT && sb == SB && saddr == SA) {                                                                             \
+        if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_ring_kernel<NT, SB, SA>),         \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                \
+        hipLaunchKernelGGL((gram_ring_kernel<NT, SB, SA>), dim3(pl.nchunk), dim3(256), sh, s, x, y, sums, tpart, vpart, a);   \
+        OEM_HIP(hipGetLastError());                                                                                            \
+        return 0;                                                                                                              \
     }
-        OEM_RING(4, 0) OEM_RING(5, 0) OEM_RING(6, 0) OEM_RING(7, 0)
-        OEM_RING(4, 1) OEM_RING(5, 1) OEM_RING(6, 1) OEM_RING(7, 1)
-        OEM_RING(4, 2) OEM_RING(5, 2) OEM_RING(6, 2) OEM_RING(7, 2)
+        OEM_RING(4, 0, true) OEM_RING(5, 0, true) OEM_RING(6, 0, true) OEM_RING(7, 0, true)
+        OEM_RING(4, 1, true) OEM_RING(5, 1, true) OEM_RING(6, 1, true) OEM_RING(7, 1, true)
+        OEM_RING(4, 2, true) OEM_RING(5, 2, true) OEM_RING(6, 2, true) OEM_RING(7, 2, true)
+        OEM_RING(4, 0, false) OEM_RING(5, 0, false) OEM_RING(6, 0, false) OEM_RING(7, 0, false)
 #undef OEM_RING
     }
     if (pl.tri) {
