@@ -53,6 +53,44 @@ def audit_gram_isa(asm_text):
     return problems
 
 
+def audit_dpp_hazards(asm_text):
+    """path_small.hip issues v_fmac_f64_dpp from inline asm, for which hipcc pads no hazards: a VALU write of the DPP
+    source needs two wait states before the DPP instruction reads it.  dpp_hazard_fence() ties an s_nop to the
+    registers; this check proves it on the emitted ISA (every instruction is one wait state, s_nop N is N + 1)."""
+    problems, nfma = [], 0
+    lines = [l.strip() for l in asm_text.splitlines()]
+    ins = [l for l in lines if l and not l.startswith((";", ".", "#")) and not l.endswith(":")]
+
+    def regs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return {int(m.group(1))} if m else set()
+
+    for i, l in enumerate(ins):
+        if not l.startswith("v_fmac_f64_dpp"):
+            continue
+        nfma += 1
+        ops = [t.strip() for t in l.split(None, 1)[1].split(",")]
+        src = regs(ops[1])
+        waited, k = 0, i - 1
+        while k >= 0 and waited < 2:
+            p = ins[k]
+            if p.startswith("s_nop"):
+                waited += int(p.split()[1]) + 1
+            else:
+                if p.startswith("v_") and not p.startswith("v_fmac_f64_dpp"):
+                    dst = regs(p.split(None, 1)[1].split(",")[0].strip())
+                    if dst & src:
+                        problems.append(f"DPP hazard: '{p}' {waited} wait state(s) before '{l}'")
+                waited += 1
+            k -= 1
+    if nfma == 0:
+        problems.append("no v_fmac_f64_dpp found in path_small.hip (the audit pattern is stale)")
+    return problems
+
+
 def build_diag():
     """liboemgpu_diag.so: the same library with -DOEM_PATH_DIAG (stamped round segments); never the product."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -85,6 +123,11 @@ def build(force=False, verbose=False):
     problems = audit_gram_isa(asm)
     if problems:
         raise RuntimeError("gram.hip ISA audit failed:\n  " + "\n  ".join(problems[:20]))
+    asm = subprocess.run([hipcc, *FLAGS, "-S", "--cuda-device-only", "-o", "-", str(CSRC / "path_small.hip")],
+                         check=True, capture_output=True, text=True).stdout
+    problems = audit_dpp_hazards(asm)
+    if problems:
+        raise RuntimeError("path_small.hip ISA audit failed:\n  " + "\n  ".join(problems[:20]))
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(OUT), *objs], check=True)
     return OUT
 

@@ -320,6 +320,18 @@ __device__ __forceinline__ void gemv_round(const double (&a)[R][CW], const doubl
 // entries.  What used to be replicated per wave and now is not -- the stop rule -- rides along: every wave drops a
 // "some coefficient still moving" flag beside its partials and all waves OR the NW flags after the same barrier.
 // ------------------------------------------------------------------------------------------------
+// A VALU write of a VGPR needs two wait states before a DPP instruction reads it, and hipcc pads no hazards for
+// inline asm.  The nop must be TIED to the registers: a bare asm volatile("s_nop") only orders memory operations, so
+// the compiler may sink the producing VALU instruction below it, straight in front of the DPP read (seen as a
+// run-to-run varying eigenvalue in a diagnostic build).  The "+v" operands make the producers precede the nop and the
+// consumers follow it.
+template <int N> __device__ __forceinline__ void dpp_hazard_fence(double (&B)[N])
+{
+    if constexpr (N == 1) asm volatile("s_nop 1" : "+v"(B[0]));
+    else if constexpr (N == 2) asm volatile("s_nop 1" : "+v"(B[0]), "+v"(B[1]));
+    else if constexpr (N == 3) asm volatile("s_nop 1" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]));
+    else { static_assert(N == 4, "extend dpp_hazard_fence"); asm volatile("s_nop 1" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3])); }
+}
 template <int K> struct BcFma {
     static __device__ __forceinline__ void fmac(double &acc, const double &b, const double &a)
     {
@@ -360,8 +372,11 @@ __device__ __forceinline__ bool gemv_sliced(const double (&a)[R][CW], const doub
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc[r][c] = 0.0;
-    asm volatile("s_nop 1" ::: "memory");                       // VALU write of B -> DPP read: 2 wait states
-    SliceFma<R, CW, NCH, 0>::run(acc, B, a);
+    double Bf[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) Bf[j] = B[j];
+    dpp_hazard_fence(Bf);                                       // VALU write of B -> DPP read: 2 wait states
+    SliceFma<R, CW, NCH, 0>::run(acc, Bf, a);
     OEM_STAMP(1);
     double *Pb = S.P + buf * NW * PR;
 #pragma unroll
@@ -1017,7 +1032,9 @@ template <int CG> struct RowsCfg {
     static constexpr int OFF_T = OFF_F + NW * 64;         // Lanczos alpha[ML], beta[ML]
     static constexpr int OFF_S = OFF_T + 2 * ML;          // Sturm scratch 2 (ML + 8)
     static constexpr int OFF_TH = OFF_S + 2 * (ML + 8);   // theta slot
-    static constexpr int N_DBL = OFF_TH + 2;
+    static constexpr int LCH = 1024;                      // lambdas staged in LDS at a time
+    static constexpr int OFF_L = OFF_TH + 2 + 256;        // (+ one scratch word per lane before it)
+    static constexpr int N_DBL = OFF_L + LCH;
 };
 
 struct RowsLds {
@@ -1032,15 +1049,17 @@ struct RowsLds {
 template <int CG, bool FLAGS, bool USE_AUX, bool NORM = false>
 __device__ __forceinline__ double gemv_rows(const double (&a)[2][CG], double mine, int wslot, const int (&ecol)[(CG + 15) / 16],
                                             bool moving, bool &any, double &aux, const RowsLds &S, int w, int lane, int &buf,
-                                            double *scale = nullptr)
+                                            double *scale OEM_DIAG_ARGS)
 {
     constexpr int NBC = (CG + 15) / 16, VS = RowsCfg<CG>::VS, NW = 4;
     const int b = __builtin_amdgcn_readfirstlane(buf);              // provably uniform: addresses stay scalar + immediate
     const int any_mine = FLAGS ? ((__ballot(moving) != 0ull) ? 1 : 0) : 0;
+    OEM_STAMP(0);                       // threshold, stop rule, loop control since the previous round
     S.V[b * VS + wslot] = mine;
     if (FLAGS) S.F[(b * NW + w) * 64 + lane] = any_mine;
     if (USE_AUX) S.XA[(b * NW + w) * 64 + lane] = aux;
     __syncthreads();
+    OEM_STAMP(1);                       // stores + barrier
     int f = 0;
     if (FLAGS) f = S.F[(b * NW + (lane & (NW - 1))) * 64 + lane];
     double xa = 0.0;
@@ -1049,6 +1068,7 @@ __device__ __forceinline__ double gemv_rows(const double (&a)[2][CG], double min
 #pragma unroll
     for (int j = 0; j < NBC; ++j) B[j] = S.V[b * VS + ecol[j]];
     __builtin_amdgcn_sched_barrier(0);
+    OEM_STAMP(2);                       // reads (the stamp waits for them)
     if (NORM) {
         double nb, ib;
         sqrt_rsqrt(quad_sum(xa), nb, ib);
@@ -1057,12 +1077,17 @@ __device__ __forceinline__ double gemv_rows(const double (&a)[2][CG], double min
         aux = nb; *scale = ib;
     }
     double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-    asm volatile("s_nop 1" ::: "memory");                       // VALU write of B -> DPP read
+    dpp_hazard_fence(B);                                        // VALU write of B -> DPP read: 2 wait states
     GroupFma<CG, 0>::run(acc, B, a);
+    OEM_STAMP(3);                       // FMAs issued
     const double out = rowgroup_reduce_scatter(acc[0][0] + acc[0][1], acc[1][0] + acc[1][1]);
     if (USE_AUX && !NORM) aux = quad_sum(xa);
     any = FLAGS ? __any(f != 0) : false;
     buf = b ^ 1;
+#ifdef OEM_PATH_DIAG
+    { unsigned sink; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sink) : "v"(__double2loint(out))); diag_acc[11] += sink & 1; }   // results are in before the stamp
+#endif
+    OEM_STAMP(4);                       // chain adds + reduce-scatter
     return out;
 }
 
@@ -1077,19 +1102,22 @@ __device__ __forceinline__ double waves_sum(double v, double *X, int &par, int w
     return quad_sum(x);
 }
 
-template <int CG, int KIND>
-__device__ __forceinline__ void iterate_rows(const PathArgs &A, const PenK &K, double d, const double (&a)[2][CG], double xy,
-                                             double pf, bool rowok, bool owner, int wslot, const int (&ecol)[(CG + 15) / 16],
-                                             double &beta, double &ab, double &ak, int &it, int &conv, const RowsLds &S,
-                                             int w, int lane, int &buf)
+// ACC (the accelerate option) is a template parameter: as a run-time test it costs two taken scalar branches per round
+// on a chain where a fetch redirect is ~50 cycles.
+template <int CG, int KIND, bool ACC>
+__device__ __forceinline__ void iterate_rows_t(const PathArgs &A, const PenK &K, const ThrK &c, const double (&a)[2][CG], double xy,
+                                               double pf, int wslot, const int (&ecol)[(CG + 15) / 16],
+                                               double &beta, double &ab, double &ak, int &it, int &conv, const RowsLds &S,
+                                               int w, int lane, int &buf OEM_DIAG_ARGS)
 {
-    const ThrK c = thr_consts<KIND>(K, d);
     const double tp = pf * K.L, tol = A.tol;
-    for (;;) {
+    const int maxit = A.maxit;
+    OEM_STAMP(8);                       // per-lambda work since the last round
+    auto round = [&]() -> bool {
         const double bold = beta;
         beta = threshold1<KIND>(ab + xy, tp, c);                    // padding lanes: zero matrix rows, xy = 0 => stays 0
         double aux = 0.0;
-        if (A.accelerate) {                                        // ref src/oem_dense.h:633-651
+        if (ACC) {                                                 // ref src/oem_dense.h:633-651
             const double akp = ak;
             ak = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak));
             const double ratio = (akp - 1.0) / ak;
@@ -1103,16 +1131,17 @@ __device__ __forceinline__ void iterate_rows(const PathArgs &A, const PenK &K, d
         const bool cn = cu > 1e-13, qn = q > 1e-13;
         const bool moving = (cn != qn) || (cn && qn && fabs(beta - bold) > tol * q);
         bool any;
-        if (A.accelerate) {
-            ab = gemv_rows<CG, true, true>(a, beta, wslot, ecol, moving, any, aux, S, w, lane, buf);
-            if (aux > 0.0) ak = 1.0;
-        } else
-            ab = gemv_rows<CG, true, false>(a, beta, wslot, ecol, moving, any, aux, S, w, lane, buf);
+        ab = gemv_rows<CG, true, ACC>(a, beta, wslot, ecol, moving, any, aux, S, w, lane, buf, nullptr OEM_DIAG_PASS);
+        if (ACC && aux > 0.0) ak = 1.0;
         conv = !any;
-        if (conv || it >= A.maxit) break;
+        return conv || it >= maxit;
+    };
+    // two rounds per trip: a taken branch (fetch redirect) costs ~80 cycles on this chain, a fall-through one nothing
+    for (;;) {
+        if (round()) break;
+        if (round()) break;
     }
 }
-
 template <int CG>
 __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
 {
@@ -1125,7 +1154,7 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
     RowsLds S;
     S.V = lds + C::OFF_V; S.XA = lds + C::OFF_XA; S.XN = lds + C::OFF_XN;
     S.F = reinterpret_cast<int *>(lds + C::OFF_F);
-    double *Tal = lds + C::OFF_T, *Tbe = Tal + C::ML;
+    double *Tal = lds + C::OFF_T, *Tbe = Tal + C::ML, *LAM = lds + C::OFF_L;
 
     const int RWp = (p + 3) / 4, CGp = (p + 3) / 4;                 // rows per wave, columns per row group
     // this lane's row after the reduce-scatter: slot g & 1 of the wave's rows; groups 2, 3 replicate groups 0, 1
@@ -1159,11 +1188,13 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
     int buf = 0, par = 0;
     bool any_unused;
     double aux_unused = 0.0;
+    OEM_DIAG_DECL
 
     // ---- eigenvalue step: Lanczos with the vector spread over the waves (one entry per owner lane)
     int msteps = A.lanczos_steps < C::ML ? A.lanczos_steps : C::ML;
     if (msteps > p) msteps = p;
     double *theta_slot = lds + C::OFF_TH;
+    double *tsink = lds + C::OFF_TH + 2 + tid;                       // a scratch word per lane: stores without exec branches
     auto top_ritz = [&](int m, double hint) {
         if (w == 0) {
             const double th = tridiag_max(Tal, Tbe, m, lane, lds + C::OFF_S, hint);
@@ -1186,20 +1217,20 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
     for (int j = 0; j < msteps; ++j) {
         // one exchange carries the unnormalised vector AND the per-wave shares of its squared norm
         double nb = rows_sum(wn * wn), ib = 0.0;
-        const double wv = gemv_rows<CG, false, true, true>(a, wn, wslot, ecol, false, any_unused, nb, S, w, lane, buf, &ib);
+        const double wv = gemv_rows<CG, false, true, true>(a, wn, wslot, ecol, false, any_unused, nb, S, w, lane, buf, &ib OEM_DIAG_PASS);
         if (j > 0) {
             bb = nb;
-            if (tid == 0) Tbe[j - 1] = bb;
-            if (!(bb > 1e-13 * fabs(al_prev))) break;                // invariant subspace reached: T is exact
-            if (nst >= 16 && ((nst & 15) == 0 || (nst > 48 && (nst & 7) == 0))) {
+            *(tid == 0 ? &Tbe[j - 1] : tsink) = bb;
+            if (__builtin_expect(!(bb > 1e-13 * fabs(al_prev)), 0)) break;   // invariant subspace reached: T is exact
+            if (__builtin_expect(nst >= 16 && ((nst & 15) == 0 || (nst > 48 && (nst & 7) == 0)), 0)) {
                 const double th = top_ritz(nst, theta_prev);
                 if (th - theta_prev <= 1e-14 * fabs(th)) { theta = th; have_theta = true; break; }
                 theta_prev = th;
             }
         }
         vp = v; v = wn * ib;
-        const double al = waves_sum(rows_sum(v * wv), S.XA, par, w, lane);
-        if (tid == 0) Tal[j] = al;                                   // read by wave 0 only (top_ritz)
+        const double al = waves_sum(rows_sum(v * wv), S.XN, par, w, lane);   // XN: gemv_rows' exchange owns XA
+        *(tid == 0 ? &Tal[j] : tsink) = al;                          // read by wave 0 only (top_ritz)
         al_prev = al;
         nst = j + 1;
         wn = (wv - al * v) - bb * vp;
@@ -1207,6 +1238,12 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
     if (!have_theta) theta = top_ritz(nst, theta_prev);
     const double d = theta * 1.005;                                  // ref src/oem_dense.h:498
     if (tid == 0) { A.d_out[0] = d; A.d_out[1] = theta; }
+#ifdef OEM_PATH_DIAG
+    OEM_STAMP(9);                                                    // everything of the eigen step outside gemv_rows
+    unsigned long long lz[5];
+    for (int k = 0; k < 5; ++k) { lz[k] = diag_acc[k]; diag_acc[k] = 0; }
+    diag_acc[10] = lz[0] + lz[1] + lz[2] + lz[3] + lz[4];           // Lanczos gemv_rows total
+#endif
 
     // ---- A = d I - XX   (ref src/oem_dense.h:501-505)
 #pragma unroll
@@ -1238,50 +1275,96 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
     const double lstep = nl > 1 ? (lhi - llo) / (double)(nl - 1) : 0.0;
     const bool lflip = fabs(lhi) < fabs(llo);
 
-    for (int pp = 0; pp < A.npen; ++pp) {
-        const int pen = A.penalty[pp];
+    // Stores without exec-masked branches (a taken branch is ~80 cycles on this chain and three of the four waves would
+    // take every one of them): lanes that own nothing aim at a scratch word of their own in A.work.
+    double *sinkd = A.work + tid;                                    // [0, 256)
+    int *sinki = reinterpret_cast<int *>(A.work + 512) + tid;
+    const bool t0 = tid == 0;
+    // one lambda loop per (operator, accelerate) pair: the dispatch happens once per penalty, not once per lambda
+    auto lambda_loop = [&](auto KIND_, auto ACC_, int pp, int pen) {
+        constexpr int KIND = decltype(KIND_)::value;
+        constexpr bool ACC = decltype(ACC_)::value;
         const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
         const bool isnet = pen_is_net(pen);
         double beta = 0.0, ab = 0.0, ak = 1.0;                       // cold start: A 0 = 0
-        double lam_next = A.user_lambda ? A.lambda_user[(size_t)pp * nl] : 0.0;
-        for (int i = 0; i < nl; ++i) {
-            double lam;
-            if (A.user_lambda) {
-                lam = lam_next;
-                if (i + 1 < nl) lam_next = A.lambda_user[(size_t)pp * nl + i + 1];
-            } else {
-                double lv;
-                if (nl == 1) lv = lhi;
-                else if (lflip) lv = (i == 0) ? llo : lhi - (double)(nl - 1 - i) * lstep;
-                else lv = (i == nl - 1) ? lhi : llo + (double)i * lstep;
-                lam = exp(lv);
-                if (isnet) lam = lam / A.alpha;
+        // Per-lambda constants.  An FP64 division is a ~300-cycle dependent chain and a taken scalar branch ~80 cycles,
+        // so: lambda / scale(y) goes through the corrected reciprocal; the reciprocals of the operator's denominators
+        // are recomputed per lambda only if the penalty has a ridge part (otherwise the denominator is d); and the
+        // lambda values themselves (user-supplied, or exp of Eigen's setLinSpaced grid incl. its "flip" form, *.net:
+        // / alpha) are produced by a lane-parallel pre-pass into LDS, LCH at a time, so the serial loop only reads them.
+        const double rscaley = 1.0 / scaley;
+        const PenLin PL = pen_linear(pen, A.alpha, A.tau);
+        const bool ridge = PL.cD != 0.0;
+        ThrK c = thr_consts<KIND>(pen_from_linear(PL, 0.0, d, A.gamma), d);
+        for (int base = 0; base < nl; base += C::LCH) {
+            const int cnt = nl - base < C::LCH ? nl - base : C::LCH;
+            for (int k = tid; k < cnt; k += NW * 64) {
+                const int i = base + k;
+                double lam;
+                if (A.user_lambda) lam = A.lambda_user[(size_t)pp * nl + i];
+                else {
+                    double lv;
+                    if (nl == 1) lv = lhi;
+                    else if (lflip) lv = (i == 0) ? llo : lhi - (double)(nl - 1 - i) * lstep;
+                    else lv = (i == nl - 1) ? lhi : llo + (double)i * lstep;
+                    lam = exp(lv);
+                    if (isnet) lam = lam / A.alpha;
+                }
+                LAM[k] = lam;
+                A.lambda_out[(size_t)pp * nl + i] = lam;
             }
-            const size_t orow = (size_t)pp * nl + i;
-            if (tid == 0) A.lambda_out[orow] = lam;
-            if (i >= nlam) continue;
-            const double il = lam / scaley;                               // ref src/oem_dense.cpp:241
-            const PenK K = pen_consts(pen, il, d, A.alpha, A.gamma, A.tau);
-            int it = 0, conv = 0;
-            switch (K.kind) {
-            case K_SOFT: iterate_rows<CG, K_SOFT>(A, K, d, a, xy, pf, rowok, owner, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf); break;
-            case K_MCP: iterate_rows<CG, K_MCP>(A, K, d, a, xy, pf, rowok, owner, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf); break;
-            case K_SCAD: iterate_rows<CG, K_SCAD>(A, K, d, a, xy, pf, rowok, owner, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf); break;
-            default: iterate_rows<CG, K_OLS>(A, K, d, a, xy, pf, rowok, owner, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf); break;
+            __syncthreads();
+            const int kend = nlam - base < cnt ? nlam - base : cnt;
+            double lam_next = LAM[0];
+            for (int k = 0; k < kend; ++k) {
+                const double lam = lam_next;
+                lam_next = LAM[k + 1 < cnt ? k + 1 : k];
+                const size_t orow = (size_t)pp * nl + base + k;
+                const double il = cdiv(lam, scaley, rscaley);             // ref src/oem_dense.cpp:241
+                const PenK K = pen_from_linear(PL, il, d, A.gamma);
+                if (__builtin_expect(ridge, 0)) c = thr_consts<KIND>(K, d);
+                int it = 0, conv = 0;
+                iterate_rows_t<CG, KIND, ACC>(A, K, c, a, xy, pf, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf OEM_DIAG_PASS);
+                // oemXTX::get_beta rescales the member in place (ref src/oem_xtx.h:576-581, quirk Q5)
+                if (__builtin_expect(A.sinv != nullptr, 0)) beta *= sinv;
+                *(owner ? &A.beta[orow * p + row] : sinkd) = beta;
+                *(t0 ? &A.niter[orow] : sinki) = conv ? it : A.maxit + 1; // ref src/oem_base.h:94-109
+                if (__builtin_expect(A.sinv != nullptr, 0))
+                    ab = gemv_rows<CG, false, false>(a, beta, wslot, ecol, false, any_unused, aux_unused, S, w, lane, buf, nullptr OEM_DIAG_PASS);
+                double lossv = 1e99;
+                if (__builtin_expect(A.compute_loss != 0, 0)) {
+                    // sum (Y - X beta)^2 through the Gram identity (ref src/oem_dense.h:759-770):
+                    // yy - 2 n beta'XY + n beta' XX beta, with XX beta = d beta - A beta
+                    lossv = yy + nobs * waves_sum(rows_sum(beta * ((d * beta - ab) - 2.0 * xy)), S.XN, par, w, lane);
+                }
+                *(t0 ? &A.loss[orow] : sinkd + 256) = lossv;
             }
-            // oemXTX::get_beta rescales the member in place (ref src/oem_xtx.h:576-581, quirk Q5)
-            if (A.sinv) beta *= sinv;
-            if (owner) A.beta[orow * p + row] = beta;
-            if (tid == 0) A.niter[orow] = conv ? it : A.maxit + 1;        // ref src/oem_base.h:94-109
-            if (A.sinv) ab = gemv_rows<CG, false, false>(a, beta, wslot, ecol, false, any_unused, aux_unused, S, w, lane, buf);
-            if (A.compute_loss) {
-                // sum (Y - X beta)^2 through the Gram identity (ref src/oem_dense.h:759-770):
-                // yy - 2 n beta'XY + n beta' XX beta, with XX beta = d beta - A beta
-                const double t = waves_sum(rows_sum(beta * ((d * beta - ab) - 2.0 * xy)), S.XN, par, w, lane);
-                if (tid == 0) A.loss[orow] = yy + nobs * t;
-            } else if (tid == 0) A.loss[orow] = 1e99;
+            __syncthreads();                                             // LAM is rewritten by the next chunk
+        }
+    };
+    for (int pp = 0; pp < A.npen; ++pp) {
+        const int pen = A.penalty[pp];
+        const int kind = pen_consts(pen, 1.0, d, A.alpha, A.gamma, A.tau).kind;
+        using T = std::true_type; using F = std::false_type;
+        if (A.accelerate) {
+            switch (kind) {
+            case K_SOFT: lambda_loop(std::integral_constant<int, K_SOFT>{}, T{}, pp, pen); break;
+            case K_MCP: lambda_loop(std::integral_constant<int, K_MCP>{}, T{}, pp, pen); break;
+            case K_SCAD: lambda_loop(std::integral_constant<int, K_SCAD>{}, T{}, pp, pen); break;
+            default: lambda_loop(std::integral_constant<int, K_OLS>{}, T{}, pp, pen); break;
+            }
+        } else {
+            switch (kind) {
+            case K_SOFT: lambda_loop(std::integral_constant<int, K_SOFT>{}, F{}, pp, pen); break;
+            case K_MCP: lambda_loop(std::integral_constant<int, K_MCP>{}, F{}, pp, pen); break;
+            case K_SCAD: lambda_loop(std::integral_constant<int, K_SCAD>{}, F{}, pp, pen); break;
+            default: lambda_loop(std::integral_constant<int, K_OLS>{}, F{}, pp, pen); break;
+            }
         }
     }
+#ifdef OEM_PATH_DIAG
+    if (tid == 0) for (int k = 0; k < 12; ++k) g_diag[k] = diag_acc[k];
+#endif
     if (tid == 0) {
         A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
         A.d_out[3] = (double)(__builtin_amdgcn_s_memrealtime() - t_rt0);

@@ -111,4 +111,46 @@ __device__ __forceinline__ PenK pen_consts(int pen, double lam, double d, double
     return k;
 }
 
+// pen_consts is a 15-way switch: on the serial path kernels a taken scalar branch costs ~80 cycles, so the dispatch
+// is done once per penalty and the per-lambda constants follow from three coefficients with the SAME arithmetic:
+// L = cL * lam, D = d + cD * lam (d itself when cD == 0), L1 = cL1 * lam.
+struct PenLin {
+    int kind;
+    double cL, cD, cL1;
+};
+__device__ __forceinline__ PenLin pen_linear(int pen, double alpha, double tau)
+{
+    PenLin k; k.kind = K_SOFT; k.cL = 1.0; k.cD = 0.0; k.cL1 = 0.0;
+    switch (pen) {
+    case OEMGPU_LASSO: k.kind = K_SOFT; break;
+    case OEMGPU_OLS: k.kind = K_OLS; break;
+    case OEMGPU_ELASTIC_NET: k.kind = K_SOFT; k.cL = alpha; k.cD = 1.0 - alpha; break;
+    case OEMGPU_SCAD: k.kind = K_SCAD; break;
+    case OEMGPU_SCAD_NET:
+        k.kind = K_SCAD; k.cL = alpha; k.cD = 1.0 - alpha;
+        if (alpha == 0.0) { k.cL = 0.0; k.cD = 1.0; }
+        break;
+    case OEMGPU_MCP: k.kind = K_MCP; break;
+    case OEMGPU_MCP_NET: k.kind = K_MCP; k.cL = alpha; k.cD = 1.0 - alpha; break;
+    case OEMGPU_GRP_LASSO: k.kind = K_GRP; break;
+    case OEMGPU_GRP_LASSO_NET: k.kind = K_GRP; k.cL = alpha; k.cD = 1.0 - alpha; break;
+    case OEMGPU_GRP_MCP: k.kind = K_GRP_MCP; break;
+    case OEMGPU_GRP_SCAD: k.kind = K_GRP_SCAD; break;
+    case OEMGPU_GRP_MCP_NET: k.kind = K_GRP_MCP; k.cL = alpha; k.cD = 1.0 - alpha; break;
+    case OEMGPU_GRP_SCAD_NET: k.kind = K_GRP_SCAD; k.cL = alpha; k.cD = 1.0 - alpha; break;
+    case OEMGPU_SPARSE_GRP_LASSO: k.kind = K_SGL; k.cL = 1.0 - tau; k.cL1 = tau; break;
+    default: break;
+    }
+    return k;
+}
+__device__ __forceinline__ PenK pen_from_linear(const PenLin &c, double lam, double d, double gamma)
+{
+    PenK k;
+    k.kind = c.kind; k.gamma = gamma;
+    k.L = (c.cL == 1.0) ? lam : lam * c.cL;          // pen_consts: lam, lam * alpha, (1 - tau) * lam
+    k.D = (c.cD == 0.0) ? d : d + c.cD * lam;        // pen_consts: d, d + (1 - alpha) * lam
+    k.L1 = c.cL1 * lam;
+    return k;
+}
+
 }  // namespace oemgpu

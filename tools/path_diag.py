@@ -38,6 +38,12 @@ nit = int(np.sum(fit["niter"][0]))
 lz = d[4:8]; tot = d[0:4]; oem = tot - lz
 print('per-lambda overhead (slot 8):', int(d[8]), 'cycles total,', round(d[8] / max(1, len(fit['lambda'][0])), 1), 'per lambda')
 print(f"p={p}: OEM iterations {nit}; Lanczos steps {int(d[11])}; top_ritz calls total {int(d[9])} cycles; Lanczos vector work {int(d[10])} cycles")
+if p > 64 and p <= 128:
+    r = d[0:5]
+    print("row-split kernel, cycles per OEM round by segment [threshold+stop+loop | stores+barrier | reads | FMAs | adds+reduce]:")
+    print("   ", np.round(r / max(nit, 1), 1), "sum", round(r.sum() / max(nit, 1), 1))
+    print("    per-lambda (slot 8):", round(d[8] / len(fit["lambda"][0]), 1), " eigen step outside gemv (slot 9):", int(d[9]), " Lanczos gemv_rows total:", int(d[10]))
+    sys.exit(0)
 print("Lanczos cycles by segment:", lz.astype(int), "sum", int(lz.sum()))
 print("OEM cycles by segment    :", oem.astype(int), "sum", int(oem.sum()))
 print("per OEM round            :", np.round(oem / max(nit, 1), 1), "sum", round(oem.sum() / max(nit, 1), 1))
