@@ -980,7 +980,8 @@ __device__ __forceinline__ double rows_sum(double v)
 // dependent FP64 ops; the library sqrt followed by a division is ~45).  Outside [1e-200, 1e200] the slow pair.
 __device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &r)
 {
-    if (x > 1e-200 && x < 1e200) {
+    // x is the same in every lane; the test is made wave-uniform so that it is ONE untaken scalar branch
+    if (__builtin_expect(__all(x > 1e-200 && x < 1e200), 1)) {
         const double y = __builtin_amdgcn_rsq(x);
         double g = x * y, h = 0.5 * y;
         double e = fma(-h, g, 0.5);
@@ -1214,6 +1215,7 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
     double theta = 0.0, theta_prev = -__builtin_inf(), bb = 0.0;
     bool have_theta = false;
     double al_prev = 0.0;
+    OEM_STAMP(5);                                                    // prologue: matrix and vectors into registers
     for (int j = 0; j < msteps; ++j) {
         // one exchange carries the unnormalised vector AND the per-wave shares of its squared norm
         double nb = rows_sum(wn * wn), ib = 0.0;
@@ -1221,10 +1223,12 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
         if (j > 0) {
             bb = nb;
             *(tid == 0 ? &Tbe[j - 1] : tsink) = bb;
-            if (__builtin_expect(!(bb > 1e-13 * fabs(al_prev)), 0)) break;   // invariant subspace reached: T is exact
+            if (__builtin_expect(__any(!(bb > 1e-13 * fabs(al_prev))), 0)) break;   // invariant subspace reached: T is exact
             if (__builtin_expect(nst >= 16 && ((nst & 15) == 0 || (nst > 48 && (nst & 7) == 0)), 0)) {
+                OEM_STAMP(6);
                 const double th = top_ritz(nst, theta_prev);
-                if (th - theta_prev <= 1e-14 * fabs(th)) { theta = th; have_theta = true; break; }
+                OEM_STAMP(7);
+                if (__any(th - theta_prev <= 1e-14 * fabs(th))) { theta = th; have_theta = true; break; }
                 theta_prev = th;
             }
         }
@@ -1239,10 +1243,11 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
     const double d = theta * 1.005;                                  // ref src/oem_dense.h:498
     if (tid == 0) { A.d_out[0] = d; A.d_out[1] = theta; }
 #ifdef OEM_PATH_DIAG
-    OEM_STAMP(9);                                                    // everything of the eigen step outside gemv_rows
+    OEM_STAMP(7);                                                    // the final top_ritz (slot 7: all top_ritz calls)
     unsigned long long lz[5];
     for (int k = 0; k < 5; ++k) { lz[k] = diag_acc[k]; diag_acc[k] = 0; }
-    diag_acc[10] = lz[0] + lz[1] + lz[2] + lz[3] + lz[4];           // Lanczos gemv_rows total
+    diag_acc[10] = lz[0] + lz[1] + lz[2] + lz[3] + lz[4] + diag_acc[6];   // Lanczos steps: gemv_rows + vector work
+    diag_acc[9] = diag_acc[7]; diag_acc[6] = (unsigned long long)nst;
 #endif
 
     // ---- A = d I - XX   (ref src/oem_dense.h:501-505)

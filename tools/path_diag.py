@@ -42,7 +42,8 @@ if p > 64 and p <= 128:
     r = d[0:5]
     print("row-split kernel, cycles per OEM round by segment [threshold+stop+loop | stores+barrier | reads | FMAs | adds+reduce]:")
     print("   ", np.round(r / max(nit, 1), 1), "sum", round(r.sum() / max(nit, 1), 1))
-    print("    per-lambda (slot 8):", round(d[8] / len(fit["lambda"][0]), 1), " eigen step outside gemv (slot 9):", int(d[9]), " Lanczos gemv_rows total:", int(d[10]))
+    print("    per-lambda (slot 8):", round(d[8] / len(fit["lambda"][0]), 1), " prologue:", int(d[5]), " top_ritz calls total:", int(d[9]),
+          " Lanczos steps:", int(d[6]), "x", round(d[10] / max(d[6], 1), 1), "cycles (stamped)")
     sys.exit(0)
 print("Lanczos cycles by segment:", lz.astype(int), "sum", int(lz.sum()))
 print("OEM cycles by segment    :", oem.astype(int), "sum", int(oem.sum()))
