@@ -234,6 +234,9 @@ struct NoHook { template <typename M> __device__ __forceinline__ void operator()
 
 // hook(integral_constant<m>) runs right after the m-th MFMA of the slab (m = 0 .. 2 NTILES - 1): the place for
 // scalar / VMEM / LDS instructions, which issue for free in the 64-cycle shadow of an FP64 MFMA.
+#ifndef OEM_GRAM_EXP
+#define OEM_GRAM_EXP 0
+#endif
 template <int NR, int NC, bool DIAG, bool MASKED, bool VEC, bool AUG, bool XF = true, typename Hook = NoHook>
 __device__ __forceinline__ void consume_slab(VecAcc<DIAG ? NR : NR + NC> &V, Slab<DIAG ? NR : NR + NC> &s,
                                              const LaneXf<DIAG ? NR : NR + NC> &X, double cy, int64_t r, int64_t n,
@@ -247,7 +250,7 @@ __device__ __forceinline__ void consume_slab(VecAcc<DIAG ? NR : NR + NC> &V, Sla
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        if (!XF) {
+        if (!XF || OEM_GRAM_EXP == 5) {
             // un-shifted form: the operands are used as loaded (the ones column is read from a constant)
         } else if (AUG && f == NF - 1) {
             s.v[f].x = fma(s.v[f].x, X.m_last, X.o_last);
@@ -259,7 +262,7 @@ __device__ __forceinline__ void consume_slab(VecAcc<DIAG ? NR : NR + NC> &V, Sla
         if (MASKED) { s.v[f].x *= m0; s.v[f].y *= m1; }
     }
     static_assert(XF || !VEC, "the VALU vector sums are only written for the shifted form");
-    if (VEC) {
+    if (VEC && OEM_GRAM_EXP != 5) {
         double y0 = s.y.x - cy, y1 = s.y.y - cy;
         if (MASKED) { y0 *= m0; y1 *= m1; }
 #pragma unroll
@@ -671,10 +674,7 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
         const v2d *src = ring_rd + (slot * SLOT_B) / 16;
         const v2d *srcA = ring_rdA + (slot * SLOT_B) / 16;
         // OEM_GRAM_EXP (timing experiments in diagnostic builds only; results are wrong): 1 = no DMA issue,
-        // 2 = no ring reads, 3 = no vmcnt wait, 4 = no pointer bumps
-#ifndef OEM_GRAM_EXP
-#define OEM_GRAM_EXP 0
-#endif
+        // 2 = no ring reads, 3 = no vmcnt wait, 4 = no pointer bumps, 5 = block kernel without shift / VALU sums
         auto hook = [&](auto M_) {
             constexpr int m = decltype(M_)::value;
             if constexpr (OEM_GRAM_EXP != 1 && m == 1) set_m0(dst + CEN * 1024);

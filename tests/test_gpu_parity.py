@@ -123,6 +123,53 @@ def test_user_lambda_penalty_factor_accelerate_maxit(oa):
     assert f["niter"][0].max() == 4 and np.array_equal(f["niter"][0], r["niter"][0])
 
 
+@pytest.mark.parametrize("p", [72, 100, 128, 150, 200])
+def test_every_option_on_every_small_p_path_kernel(oa, p):
+    """the options of test_datastd_flags / test_user_lambda_... again at sizes that select the other single-launch path
+    kernels: row-split (64 < p <= 128), sliced with 8 waves (<= 192), four cooperating workgroups (<= 256)"""
+    x, y = _data(3 * p + 500, p, 40 + p, mean=0.5)
+    pens = ["elastic.net", "lasso", "ols", "mcp", "scad", "mcp.net", "scad.net"]
+    for std, icpt in ((True, True), (False, False)):
+        kw = dict(penalty=pens, standardize=std, intercept=icpt, alpha=0.6, nlambda=12, tol=1e-10, compute_loss=True)
+        f, r = oa.oem(x, y, **kw), orc.fit_dense(x, y, **kw)
+        _cmp(f, r)
+        for k in range(len(pens)):
+            # iteration counts: the GEMV is summed in another order than on the CPU, so a stop-rule comparison that
+            # lands within an ulp of tol may resolve one iteration apart (seen on the non-convex operators)
+            dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int))   # "ols": a scalar in R
+            assert dn.max() <= 1 and (dn != 0).mean() <= 0.2, (pens[k], dn)
+            assert np.allclose(np.ravel(f["loss"][k]), np.ravel(r["loss"][k]), rtol=1e-9, atol=1e-9), pens[k]
+    pf = np.linspace(0.0, 2.0, p)
+    lam = [np.geomspace(2.0, 0.01, 9), np.geomspace(1.0, 0.02, 9)]
+    kw = dict(penalty=["lasso", "scad"], penalty_factor=pf, tol=1e-9, gamma=4.0)
+    _cmp(oa.oem(x, y, lambda_=lam, **kw), orc.fit_dense(x, y, lambda_=lam, **kw))
+    kw = dict(penalty=["lasso", "mcp", "elastic.net"], accelerate=True, alpha=0.5, nlambda=10, tol=1e-9)
+    f, r = oa.oem(x, y, **kw), orc.fit_dense(x, y, **kw)
+    _cmp(f, r)
+    assert all(np.array_equal(f["niter"][k], r["niter"][k]) for k in range(3))
+    kw = dict(penalty=["lasso"], maxit=3, nlambda=8, tol=1e-12)                  # quirk Q2: niter = maxit + 1
+    f, r = oa.oem(x, y, **kw), orc.fit_dense(x, y, **kw)
+    _cmp(f, r)
+    assert f["niter"][0].max() == 4 and np.array_equal(f["niter"][0], r["niter"][0])
+    n = x.shape[0]
+    xtx, xty = x.T @ x / n, x.T @ y / n
+    sf = np.linspace(0.5, 2.0, p)                                                # quirk Q5: in-place rescaling
+    _cmp(oa.oem_xtx(xtx, xty, penalty=["lasso", "scad"], scale_factor=sf, nlambda=10),
+         orc.fit_xtx(xtx, xty, penalty=["lasso", "scad"], scale_factor=sf, nlambda=10))
+
+
+def test_more_lambdas_than_one_lds_chunk(oa):
+    """the row-split kernel stages lambdas in LDS 1024 at a time"""
+    x, y = _data(800, 72, 77)
+    kw = dict(penalty=["lasso"], nlambda=1100, tol=1e-7)
+    f, r = oa.oem(x, y, **kw), orc.fit_dense(x, y, **kw)
+    _cmp(f, r)
+    assert np.array_equal(f["niter"][0], r["niter"][0])
+    lam = np.geomspace(3.0, 0.003, 1030)
+    f, r = oa.oem(x, y, lambda_=[lam], penalty=["mcp"], tol=1e-7), orc.fit_dense(x, y, lambda_=[lam], penalty=["mcp"], tol=1e-7)
+    _cmp(f, r)
+
+
 @pytest.mark.parametrize("n", [129, 1000, 4097, 33331])
 def test_ragged_rows_and_alignment(oa, n):
     """row counts that are not multiples of 8 / 32 / 64; odd n exercises the 8-byte-aligned host path"""
