@@ -19,6 +19,7 @@
 // Centring: data are shifted by a provisional mean c (from a strided row sample) while loading, and the
 // exact centred moments follow from  C_ij = M_ij - s_i s_j / n  (M, s = shifted moments / sums).  The
 // correction is O(sample error^2), so there is no cancellation even when |mean| >> sd.
+#include <cstdlib>
 #include "common.hpp"
 
 #include <type_traits>
@@ -856,6 +857,10 @@ GramPlan gram_plan(int64_t n, int p, int num_cu)
         if (c < 1) c = 1;
         c = (c + 7) / 8 * 8;
         pl.steps = (int)((nsteps + c - 1) / c);
+        if (const char *e = getenv("OEM_BLK_STEPS")) {          // experiment knob: rows per chunk = 64 * steps
+            const int st = atoi(e);
+            if (st > 0 && st < pl.steps) { pl.steps = st; c = ((nsteps + st - 1) / st + 7) / 8 * 8; }
+        }
         if (pl.steps < 1) pl.steps = 1;
         pl.nchunk = (int)c;
     }
