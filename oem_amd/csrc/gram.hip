@@ -833,6 +833,205 @@ __global__ __launch_bounds__(256) void gram_blk_kernel(const double *__restrict_
                                                       row_begin, a.steps, false, tdst, vdst, lds);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Shared-slab kernel (p + 2 > 112, 16-byte aligned X).  profiles/r1_pmc_blk_p512.txt: gram_blk_kernel is bound by
+// RE-READS -- every 4x4 tile block streams its own 8 column fragments, 26.8 GB reach the fabric for 4.1 GB of X.  Here a
+// workgroup owns a SUPER-BLOCK of 2x2 tile blocks (8 x 8 tiles) over ALL rows of its chunk: the 16 (diagonal: 8)
+// column fragments of an 8-row slab are DMA'd ONCE into a workgroup-shared LDS ring (each wave issues a quarter of
+// them), and every wave multiplies a different 4x4 tile block from the same slab -- half the fragment traffic per tile.
+// One s_barrier per slab hands a slot over: a wave waits for its OWN DMAs of slab k+1 (exact vmcnt), the barrier then
+// makes everybody's visible; the slot of slab k-1 is refilled after that same barrier, by which time every wave has
+// consumed it.  Tiles are wave-private, so the epilogue stores accumulators straight to the partial buffer.
+// Diagonal super-blocks: wave 0 -> block (0,0) (10 tiles), wave 2 -> (1,0) (16 tiles), wave 3 -> (1,1) (10 tiles),
+// wave 1 only helps with the DMA; X'y and the column sums ride on the VALU of the two diagonal blocks as in
+// gram_blk_kernel, with y DMA'd beside the fragments.
+// ------------------------------------------------------------------------------------------------
+template <bool DIAGSB>
+__device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64_t n, int64_t ld, int p,
+                                             const double *__restrict__ y, const double *__restrict__ sums, int ntc, int SI,
+                                             int SJ, int64_t row_begin, int steps, double *__restrict__ tdst,
+                                             double *__restrict__ vdst, double *lds)
+{
+    constexpr int F = DIAGSB ? 8 : 16;                 // x fragments per slab
+    constexpr int DPW = DIAGSB ? 3 : 4;                // DMAs per wave per slab (diagonal: 2 fragments + its own copy of y)
+    constexpr int SLOT_B = (F + (DIAGSB ? 4 : 0)) * 1024, NSLOT = 6;
+    static_assert((NSLOT - 2) * DPW <= 63, "vmcnt field is 6 bits");
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const gptr_t xg = (gptr_t)x, yg = (gptr_t)y;
+    const bool use_shift = shift_needed_wave(sums, p);
+    const double inv_cnt = use_shift ? 1.0 / sums[p + 1] : 0.0;
+    const double cy = use_shift ? sums[p] * inv_cnt : 0.0;
+    // tile column of fragment f of this super-block
+    auto frag_tile = [&](int f) { return DIAGSB ? 8 * SI + f : (f < 8 ? 8 * SI + f : 8 * SJ + (f - 8)); };
+    auto frag_col = [&](int f) { const int col = 16 * frag_tile(f) + i; return col < p ? col : p - 1; };
+    // ---- this wave's DMA duty: fragments w, w + 4 (, w + 8, w + 12); the lane's source pointers
+    constexpr int NDMA = F / 4;
+    gptr_t dsrc[NDMA];
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) dsrc[k] = xg + (size_t)frag_col(w + 4 * k) * ld + row_begin + 2 * q;
+    gptr_t ysrc = yg + row_begin + 2 * q;
+    // ---- this wave's tile block: role 0 = diagonal block of tile rows rb.., 1 = rectangle rows rb.. x cols cb.., 2 = none
+    int role, rb, cb;                                  // rb / cb: first fragment of the block's row / column group
+    if (DIAGSB) { role = (w == 0 || w == 3) ? 0 : (w == 2 ? 1 : 2); rb = (w >= 2) ? 4 : 0; cb = 0; }
+    else { role = 1; rb = 4 * (w >> 1); cb = 8 + 4 * (w & 1); }
+    role = __builtin_amdgcn_readfirstlane(role); rb = __builtin_amdgcn_readfirstlane(rb); cb = __builtin_amdgcn_readfirstlane(cb);
+    LaneXf<8> X8; LaneXf<4> X4;
+    X8.m_last = 1.0; X8.o_last = 0.0; X4.m_last = 1.0; X4.o_last = 0.0;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        X8.c[f] = use_shift ? sums[frag_col(rb + f)] * inv_cnt : 0.0;
+        X8.c[4 + f] = use_shift ? sums[frag_col(cb + f)] * inv_cnt : 0.0;
+        X4.c[f] = X8.c[f];
+    }
+    VecAcc<4> V4; VecAcc<8> V8;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { V4.sx[f] = 0.0; V4.sxy[f] = 0.0; }
+    V4.sy = 0.0; V4.syy = 0.0; V8.sy = 0.0; V8.syy = 0.0;
+    static_for<16>([&](auto T_) { AccTile<decltype(T_)::value>::zero(); });
+    asm volatile("s_nop 7" ::: "memory");
+
+    // full slabs of this chunk (8 rows each; every wave walks all of them)
+    const int64_t rows_chunk = (int64_t)steps * 64;
+    int64_t rows = n - row_begin; if (rows > rows_chunk) rows = rows_chunk; if (rows < 0) rows = 0;
+    const int ns = (int)(rows / 8);
+    const unsigned ring = (unsigned)(size_t)lds;
+    const v2d *rd = reinterpret_cast<const v2d *>(lds) + lane;
+    auto issue = [&](int slot) {                                   // this wave's share of the next slab
+        const unsigned dst = ring + (unsigned)slot * SLOT_B;
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) { set_m0(dst + (unsigned)(w + 4 * k) * 1024); glds_v<0>(dsrc[k]); dsrc[k] += 8; }
+        if (DIAGSB) { set_m0(dst + (unsigned)(F + w) * 1024); glds_v<0>(ysrc); ysrc += 8; }
+    };
+    Slab<8> sa, sb;
+    auto fetch = [&](Slab<8> &s, int slot) {
+        const v2d *b = rd + (slot * SLOT_B) / 16;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { s.v[f] = b[(rb + f) * 64]; s.v[4 + f] = b[(cb + f) * 64]; }
+        if (DIAGSB) s.y = b[(F + w) * 64];
+    };
+    auto consume = [&](Slab<8> &s) {
+        if (role == 0) {
+            Slab<4> d;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) d.v[f] = s.v[f];
+            d.y = s.y;
+            consume_slab<4, 4, true, false, true, false>(V4, d, X4, cy, 0, n);
+        } else if (role == 1) consume_slab<4, 4, false, false, false, false>(V8, s, X8, cy, 0, n);
+    };
+    auto next = [](int v) { return v + 1 == NSLOT ? 0 : v + 1; };
+    // prologue: NSLOT - 2 slabs in flight (the slot two behind the newest is the one being read)
+    const int npre = ns < NSLOT - 2 ? ns : NSLOT - 2;
+    for (int j = 0; j < npre; ++j) issue(j);
+    int islot = npre % NSLOT, rslot = 0, issued = npre;
+    if (ns > 0) {
+        if (npre == NSLOT - 2) wait_vm<(NSLOT - 3) * DPW>(); else wait_vm<0>();
+        __syncthreads();
+        fetch(sa, 0);
+        rslot = 1;
+    }
+    // steady state: slab k in registers; own DMAs of slab k+1 landed -> barrier -> read slab k+1, refill the slot of
+    // slab k-1 with slab k+NSLOT-2, multiply slab k
+    int k = 0;
+    auto step = [&](Slab<8> &use, Slab<8> &nxt) {
+        if (k + 1 < ns) {          // slab k+1 must have landed; up to NSLOT-4 younger slabs of this wave may still fly
+            if (issued - (k + 2) >= NSLOT - 4) wait_vm<(NSLOT - 4) * DPW>(); else wait_vm<0>();
+        }
+        __syncthreads();
+        if (k + 1 < ns) { fetch(nxt, rslot); rslot = next(rslot); }
+        if (issued < ns) { issue(islot); islot = next(islot); ++issued; }
+        consume(use);
+        ++k;
+    };
+    while (k < ns) {
+        step(sa, sb);
+        if (k < ns) step(sb, sa);
+    }
+    wait_vm<0>();
+    // ragged tail of the data set (fewer than 8 rows left): masked loads straight from global memory
+    if (rows - 8 * (int64_t)ns > 0 && role != 2) {
+        const int64_t r = row_begin + 8 * (int64_t)ns + 2 * q;
+        const int64_t r0 = r < n ? r : n - 1, r1 = r + 1 < n ? r + 1 : n - 1;
+        Slab<8> t;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const gptr_t pr = xg + (size_t)frag_col(rb + f) * ld, pc = xg + (size_t)frag_col(cb + f) * ld;
+            t.v[f].x = pr[r0]; t.v[f].y = pr[r1];
+            t.v[4 + f].x = pc[r0]; t.v[4 + f].y = pc[r1];
+        }
+        t.y.x = yg[r0]; t.y.y = yg[r1];
+        if (role == 0) {
+            Slab<4> d;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) d.v[f] = t.v[f];
+            d.y = t.y;
+            consume_slab<4, 4, true, true, true, false>(V4, d, X4, cy, r, n);
+        } else consume_slab<4, 4, false, true, false, false>(V8, t, X8, cy, r, n);
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    // ---- results: tiles are wave-private -> straight to the partial buffer; vector sums of the diagonal blocks
+    const int BI = DIAGSB ? 2 * SI + (rb >> 2) : 2 * SI + (rb >> 2), BJ = DIAGSB ? 2 * SI + (cb >> 2) : 2 * SJ + ((cb - 8) >> 2);
+    if (role == 0) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            V4.sx[f] += shfl_xor_d(V4.sx[f], 16);  V4.sx[f] += shfl_xor_d(V4.sx[f], 32);
+            V4.sxy[f] += shfl_xor_d(V4.sxy[f], 16); V4.sxy[f] += shfl_xor_d(V4.sxy[f], 32);
+        }
+        V4.sy += shfl_xor_d(V4.sy, 16);   V4.sy += shfl_xor_d(V4.sy, 32);
+        V4.syy += shfl_xor_d(V4.syy, 16); V4.syy += shfl_xor_d(V4.syy, 32);
+        if (q == 0) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int T = 4 * BI + f;
+                if (T < ntc) { vdst[16 * T + i] = V4.sx[f]; vdst[16 * ntc + 16 * T + i] = V4.sxy[f]; }
+            }
+            if (i == 0 && BI == 0) {
+                vdst[32 * ntc] = V4.sy; vdst[32 * ntc + 1] = V4.syy; vdst[32 * ntc + 2] = (double)rows; vdst[32 * ntc + 3] = 0.0;
+            }
+        }
+        static_for<4>([&](auto I_) {
+            constexpr int I = decltype(I_)::value;
+            static_for<I + 1>([&](auto J_) {
+                constexpr int J = decltype(J_)::value;
+                const int gi = 4 * BI + I, gj = 4 * BI + J;
+                if (gi < ntc && gj < ntc) {
+                    double *dst = tdst + (size_t)(gi * (gi + 1) / 2 + gj) * 256;
+                    static_for<4>([&](auto R_) { constexpr int r = decltype(R_)::value; dst[r * 64 + lane] = AccTile<I *(I + 1) / 2 + J>::template read<r>(); });
+                }
+            });
+        });
+    } else if (role == 1) {
+        static_for<4>([&](auto I_) {
+            constexpr int I = decltype(I_)::value;
+            static_for<4>([&](auto J_) {
+                constexpr int J = decltype(J_)::value;
+                const int gi = 4 * BI + I, gj = 4 * BJ + J;
+                if (gi < ntc && gj < ntc) {
+                    double *dst = tdst + (size_t)(gi * (gi + 1) / 2 + gj) * 256;
+                    static_for<4>([&](auto R_) { constexpr int r = decltype(R_)::value; dst[r * 64 + lane] = AccTile<I * 4 + J>::template read<r>(); });
+                }
+            });
+        });
+    }
+}
+
+__global__ __launch_bounds__(256) void gram_sb_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                       const double *__restrict__ sums, double *__restrict__ tpart,
+                                                       double *__restrict__ vpart, GramDims a, int nsblk)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
+    const int sbk = s % nsblk, chunk = (s / nsblk) * 8 + xcd;
+    int SI = (int)((sqrtf(8.0f * (float)sbk + 1.0f) - 1.0f) * 0.5f);
+    while (SI * (SI + 1) / 2 > sbk) --SI;
+    while ((SI + 1) * (SI + 2) / 2 <= sbk) ++SI;
+    const int SJ = sbk - SI * (SI + 1) / 2;
+    const int64_t row_begin = (int64_t)chunk * a.steps * 64;
+    double *tdst = tpart + (size_t)chunk * a.ntile * 256;
+    double *vdst = vpart + (size_t)chunk * (32 * a.ntc + 4);
+    if (SI == SJ) gram_sb_body<true>(x, a.n, a.ld, a.p, y, sums, a.ntc, SI, SJ, row_begin, a.steps, tdst, vdst, lds);
+    else gram_sb_body<false>(x, a.n, a.ld, a.p, y, sums, a.ntc, SI, SJ, row_begin, a.steps, tdst, vdst, lds);
+}
+
 GramPlan gram_plan(int64_t n, int p, int num_cu)
 {
     GramPlan pl;
@@ -852,7 +1051,8 @@ GramPlan gram_plan(int64_t n, int p, int num_cu)
     } else {
         const int nb = (pl.ntc + 3) / 4;
         pl.nblk = nb * (nb + 1) / 2;
-        int64_t c = ((int64_t)num_cu * 8) / pl.nblk;          // ~8 rounds of one workgroup per CU
+        const int nsb = (pl.ntc + 7) / 8, nsblk = nsb * (nsb + 1) / 2;   // the shared-slab kernel's super-blocks
+        int64_t c = ((int64_t)num_cu * 8) / nsblk;            // ~8 rounds of one workgroup per CU
         if (c > nsteps) c = nsteps;
         if (c < 1) c = 1;
         c = (c + 7) / 8 * 8;
@@ -912,6 +1112,14 @@ static int launch_gram_t(hipStream_t s, const GramPlan &pl, const double *x, con
         default: set_error("gram: bad tile count %d", pl.ntc); return OEMGPU_ERR_INTERNAL;
         }
     } else {
+        if (ALIGNED && !getenv("OEM_GRAM_BLK")) {
+            const int nsb = (pl.ntc + 7) / 8, nsblk = nsb * (nsb + 1) / 2;
+            const size_t shb = (size_t)6 * 16 * 1024;                       // NSLOT x 16 KiB slots
+            OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+            hipLaunchKernelGGL(gram_sb_kernel, dim3(pl.nchunk * nsblk), dim3(256), shb, s, x, y, sums, tpart, vpart, a, nsblk);
+            OEM_HIP(hipGetLastError());
+            return 0;
+        }
         size_t sh = 16 * tile_bytes;
         size_t vb = (size_t)4 * (2 * 16 * 4 + 4) * sizeof(double);
         if (sh < vb) sh = vb;

@@ -225,6 +225,36 @@ def test_ring_strip_forms_of_the_moment_kernel(oa, p, n):
     assert got[p + 1, p + 1] == n
 
 
+@pytest.mark.parametrize("p", [120, 200, 256, 300, 520])
+@pytest.mark.parametrize("n", [4096, 3001, 1000, 10010])
+def test_shared_slab_moment_kernel(oa, p, n):
+    """the workgroup-shared-slab Gram kernel (p + 2 > 112, aligned X): diagonal and off-diagonal super-blocks, partial
+    super-blocks (tile count not a multiple of 8), ragged row tails; shifted and un-shifted accumulation"""
+    import torch
+    from oem_amd import _lib as L
+    from tests.checker_backend import shift_in_effect
+    for mean in (0.2, 60.0):
+        x, y = _data(n, p, 200 + p, mean=mean)
+        ld = n + (n & 1)
+        xd = torch.zeros((p, ld), dtype=torch.float64, device="cuda")
+        xd[:, :n] = torch.as_tensor(np.ascontiguousarray(x.T))
+        yd = torch.as_tensor(y, device="cuda")
+        sums = torch.zeros(L.sums_len(p), dtype=torch.float64, device="cuda")
+        M = torch.zeros((p + 2, p + 2), dtype=torch.float64, device="cuda")
+        ctx = oa.context()
+        torch.cuda.synchronize()
+        L.check(L.lib().oemgpu_shift_sums_dev(ctx, xd.data_ptr(), n, ld, p, yd.data_ptr(), sums.data_ptr()))
+        L.check(L.lib().oemgpu_moments_dev(ctx, xd.data_ptr(), n, ld, p, yd.data_ptr(), sums.data_ptr(), M.data_ptr()))
+        L.check(L.lib().oemgpu_synchronize(ctx))
+        c = shift_in_effect(sums.cpu().numpy(), p)
+        z = np.column_stack([x - c[:p], y - c[p], np.ones(n)])
+        want = z.T @ z
+        got = M.cpu().numpy()
+        scale = np.sqrt(np.outer(np.diag(want), np.diag(want))) + 1e-300
+        assert np.abs((got - want) / scale).max() < 1e-11, (mean,)
+        assert got[p + 1, p + 1] == n
+
+
 def test_xtx_matches_dense_and_oracle(oa, doc_kats):
     x, y = K.kat1()
     n = x.shape[0]

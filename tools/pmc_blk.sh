@@ -13,7 +13,7 @@ import csv, sys
 from collections import defaultdict
 acc = defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if "gram_blk" in r["Kernel_Name"]:
+    if "gram_blk" in r["Kernel_Name"] or "gram_sb" in r["Kernel_Name"]:
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in acc.items():
     print(k, "mean per dispatch", sum(v) / len(v), "dispatches", len(v))
