@@ -262,7 +262,6 @@ __device__ __forceinline__ void consume_slab(VecAcc<DIAG ? NR : NR + NC> &V, Sla
         }
         if (MASKED) { s.v[f].x *= m0; s.v[f].y *= m1; }
     }
-    static_assert(XF || !VEC, "the VALU vector sums are only written for the shifted form");
     if (VEC && OEM_GRAM_EXP != 5) {
         double y0 = s.y.x - cy, y1 = s.y.y - cy;
         if (MASKED) { y0 *= m0; y1 *= m1; }
@@ -297,6 +296,7 @@ __device__ __forceinline__ void consume_slab(VecAcc<DIAG ? NR : NR + NC> &V, Sla
                 static_for<NC>([&](auto J_) {
                     constexpr int J = decltype(J_)::value;
                     AccTile<I * NC + J>::mfma(s.v[I][e], s.v[NR + J][e]);
+                    hook(std::integral_constant<int, e * (NR * NC) + I * NC + J>{});
                 });
             });
         }
@@ -846,7 +846,63 @@ __global__ __launch_bounds__(256) void gram_blk_kernel(const double *__restrict_
 // wave 1 only helps with the DMA; X'y and the column sums ride on the VALU of the two diagonal blocks as in
 // gram_blk_kernel, with y DMA'd beside the fragments.
 // ------------------------------------------------------------------------------------------------
-template <bool DIAGSB>
+#ifndef OEM_SB_NSLOT
+#define OEM_SB_NSLOT 9
+#endif
+constexpr int SB_NSLOT = OEM_SB_NSLOT;           // ring depth: the prefetch distance is (NSLOT - 3) slabs
+
+// row of the lower triangle that holds row-major index tt (tt = I (I + 1) / 2 + J, J <= I)
+constexpr int tri_row(int tt) { int I = 0; while ((I + 1) * (I + 2) / 2 <= tt) ++I; return I; }
+
+// One slab of one wave of a super-block.  Eight fragments in registers.
+//   off-diagonal super-block: s.v[0..3] = the block's tile rows, s.v[4..7] = its tile columns, 16 tiles (I, J);
+//   diagonal super-block (8 x 8 tile triangle = 36 tiles): s.v[f] = fragment f, wave W multiplies tiles 9 W .. 9 W + 8 of
+//   the row-major triangle (9 each: balanced), and carries X'y / column sums of fragments 2 W, 2 W + 1 on the VALU.
+template <bool DIAGSB, int W, bool XF, bool MASKED, typename Hook = NoHook>
+__device__ __forceinline__ void sb_consume(Slab<8> &s, const double (&c)[8], double cy, double (&sx)[2], double (&sxy)[2],
+                                           double &sy, double &syy, int64_t r, int64_t n, Hook &&hook = NoHook())
+{
+    double m0 = 1.0, m1 = 1.0;
+    if (MASKED) { m0 = (r < n) ? 1.0 : 0.0; m1 = (r + 1 < n) ? 1.0 : 0.0; }
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+        if (XF) { s.v[f].x -= c[f]; s.v[f].y -= c[f]; }
+        if (MASKED) { s.v[f].x *= m0; s.v[f].y *= m1; }
+    }
+    if (DIAGSB) {
+        double y0 = s.y.x - cy, y1 = s.y.y - cy;
+        if (MASKED) { y0 *= m0; y1 *= m1; }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const v2d v = s.v[2 * W + k];
+            sx[k] = (sx[k] + v.x) + v.y;
+            sxy[k] = fma(v.x, y0, sxy[k]);
+            sxy[k] = fma(v.y, y1, sxy[k]);
+        }
+        if (W == 0) { sy = (sy + y0) + y1; syy = fma(y0, y0, syy); syy = fma(y1, y1, syy); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 3" ::: "memory");                          // VALU write -> MFMA read (hipcc pads nothing for asm)
+    static_for<2>([&](auto E) {
+        constexpr int e = decltype(E)::value;
+        if constexpr (DIAGSB) {
+            static_for<9>([&](auto T_) {
+                constexpr int t = decltype(T_)::value, tt = 9 * W + t, I = tri_row(tt), J = tt - I * (I + 1) / 2;
+                AccTile<t>::mfma(s.v[I][e], s.v[J][e]);
+                hook(std::integral_constant<int, e * 9 + t>{});
+            });
+        } else {
+            static_for<16>([&](auto T_) {
+                constexpr int t = decltype(T_)::value;
+                AccTile<t>::mfma(s.v[t / 4][e], s.v[4 + t % 4][e]);
+                hook(std::integral_constant<int, e * 16 + t>{});
+            });
+        }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool DIAGSB, int W, bool XF>
 __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64_t n, int64_t ld, int p,
                                              const double *__restrict__ y, const double *__restrict__ sums, int ntc, int SI,
                                              int SJ, int64_t row_begin, int steps, double *__restrict__ tdst,
@@ -854,39 +910,41 @@ __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64
 {
     constexpr int F = DIAGSB ? 8 : 16;                 // x fragments per slab
     constexpr int DPW = DIAGSB ? 3 : 4;                // DMAs per wave per slab (diagonal: 2 fragments + its own copy of y)
-    constexpr int SLOT_B = (F + (DIAGSB ? 4 : 0)) * 1024, NSLOT = 6;
+    constexpr int NFETCH = DIAGSB ? 9 : 8;             // ring reads per wave per slab
+    constexpr int NMFMA = DIAGSB ? 18 : 32;
+    constexpr int SLOT_B = (F + (DIAGSB ? 4 : 0)) * 1024, NSLOT = SB_NSLOT;
     static_assert((NSLOT - 2) * DPW <= 63, "vmcnt field is 6 bits");
+    static_assert(1 + NFETCH + DPW <= NMFMA, "not enough MFMAs per slab to carry the hooks");
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, q = lane >> 4;
     const gptr_t xg = (gptr_t)x, yg = (gptr_t)y;
-    const bool use_shift = shift_needed_wave(sums, p);
-    const double inv_cnt = use_shift ? 1.0 / sums[p + 1] : 0.0;
-    const double cy = use_shift ? sums[p] * inv_cnt : 0.0;
+    const double inv_cnt = XF ? 1.0 / sums[p + 1] : 0.0;
+    const double cy = XF ? sums[p] * inv_cnt : 0.0;
     // tile column of fragment f of this super-block
     auto frag_tile = [&](int f) { return DIAGSB ? 8 * SI + f : (f < 8 ? 8 * SI + f : 8 * SJ + (f - 8)); };
     auto frag_col = [&](int f) { const int col = 16 * frag_tile(f) + i; return col < p ? col : p - 1; };
-    // ---- this wave's DMA duty: fragments w, w + 4 (, w + 8, w + 12); the lane's source pointers
+    // ---- DMA duty of this wave: fragments w, w + 4 (, w + 8, w + 12) (+ its own copy of y in a diagonal super-block).
+    // Addressing: one scalar base per fragment (first column of its tile at the chunk's first row, bumped by a scalar
+    // add per slab) + a 32-bit lane offset (column within the tile, row pair) -- 64-bit VALU adds run on the DP units.
     constexpr int NDMA = F / 4;
-    gptr_t dsrc[NDMA];
+    gptr_t dbase[NDMA];
+    unsigned doff[NDMA];
 #pragma unroll
-    for (int k = 0; k < NDMA; ++k) dsrc[k] = xg + (size_t)frag_col(w + 4 * k) * ld + row_begin + 2 * q;
-    gptr_t ysrc = yg + row_begin + 2 * q;
-    // ---- this wave's tile block: role 0 = diagonal block of tile rows rb.., 1 = rectangle rows rb.. x cols cb.., 2 = none
-    int role, rb, cb;                                  // rb / cb: first fragment of the block's row / column group
-    if (DIAGSB) { role = (w == 0 || w == 3) ? 0 : (w == 2 ? 1 : 2); rb = (w >= 2) ? 4 : 0; cb = 0; }
-    else { role = 1; rb = 4 * (w >> 1); cb = 8 + 4 * (w & 1); }
-    role = __builtin_amdgcn_readfirstlane(role); rb = __builtin_amdgcn_readfirstlane(rb); cb = __builtin_amdgcn_readfirstlane(cb);
-    LaneXf<8> X8; LaneXf<4> X4;
-    X8.m_last = 1.0; X8.o_last = 0.0; X4.m_last = 1.0; X4.o_last = 0.0;
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        X8.c[f] = use_shift ? sums[frag_col(rb + f)] * inv_cnt : 0.0;
-        X8.c[4 + f] = use_shift ? sums[frag_col(cb + f)] * inv_cnt : 0.0;
-        X4.c[f] = X8.c[f];
+    for (int k = 0; k < NDMA; ++k) {
+        int t0 = 16 * frag_tile(w + 4 * k);                       // wave-uniform
+        if (t0 > p - 1) t0 = p - 1;
+        dbase[k] = xg + (size_t)t0 * ld + row_begin;
+        doff[k] = (unsigned)(((int64_t)(frag_col(w + 4 * k) - t0) * ld + 2 * q) * 8);
     }
-    VecAcc<4> V4; VecAcc<8> V8;
+    gptr_t ybase = yg + row_begin;
+    const unsigned yoff = (unsigned)(2 * q * 8);
+    // ---- the fragments this wave multiplies: registers 0..7 <- ring fragments rf[0..7]
+    int rb = 0, cb = 0;                                            // off-diagonal: first fragment of the row / column group
+    if (!DIAGSB) { rb = __builtin_amdgcn_readfirstlane(4 * (w >> 1)); cb = __builtin_amdgcn_readfirstlane(8 + 4 * (w & 1)); }
+    auto reg_frag = [&](int f) { return DIAGSB ? f : (f < 4 ? rb + f : cb + f - 4); };
+    double c[8];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) { V4.sx[f] = 0.0; V4.sxy[f] = 0.0; }
-    V4.sy = 0.0; V4.syy = 0.0; V8.sy = 0.0; V8.syy = 0.0;
+    for (int f = 0; f < 8; ++f) c[f] = XF ? sums[frag_col(reg_frag(f))] * inv_cnt : 0.0;
+    double sx[2] = {0.0, 0.0}, sxy[2] = {0.0, 0.0}, sy = 0.0, syy = 0.0;
     static_for<16>([&](auto T_) { AccTile<decltype(T_)::value>::zero(); });
     asm volatile("s_nop 7" ::: "memory");
 
@@ -896,30 +954,24 @@ __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64
     const int ns = (int)(rows / 8);
     const unsigned ring = (unsigned)(size_t)lds;
     const v2d *rd = reinterpret_cast<const v2d *>(lds) + lane;
-    auto issue = [&](int slot) {                                   // this wave's share of the next slab
+    auto issue1 = [&](int slot, auto K_) {                         // one DMA of this wave's share of the next slab
+        constexpr int k = decltype(K_)::value;
         const unsigned dst = ring + (unsigned)slot * SLOT_B;
-#pragma unroll
-        for (int k = 0; k < NDMA; ++k) { set_m0(dst + (unsigned)(w + 4 * k) * 1024); glds_v<0>(dsrc[k]); dsrc[k] += 8; }
-        if (DIAGSB) { set_m0(dst + (unsigned)(F + w) * 1024); glds_v<0>(ysrc); ysrc += 8; }
+        if constexpr (k < NDMA) { set_m0(dst + (unsigned)(w + 4 * k) * 1024); glds_s<0>(doff[k], dbase[k]); dbase[k] += 8; }
+        else { set_m0(dst + (unsigned)(F + w) * 1024); glds_s<0>(yoff, ybase); ybase += 8; }
     };
+    auto issue = [&](int slot) { static_for<DPW>([&](auto K_) { issue1(slot, K_); }); };
     Slab<8> sa, sb;
-    auto fetch = [&](Slab<8> &s, int slot) {
+    sa.y = v2d{0.0, 0.0}; sb.y = sa.y;
+    auto fetch1 = [&](Slab<8> &s, int slot, auto J_) {
+        constexpr int j = decltype(J_)::value;
         const v2d *b = rd + (slot * SLOT_B) / 16;
-#pragma unroll
-        for (int f = 0; f < 4; ++f) { s.v[f] = b[(rb + f) * 64]; s.v[4 + f] = b[(cb + f) * 64]; }
-        if (DIAGSB) s.y = b[(F + w) * 64];
+        if constexpr (j < 8) s.v[j] = b[reg_frag(j) * 64];
+        else s.y = b[(F + w) * 64];
     };
-    auto consume = [&](Slab<8> &s) {
-        if (role == 0) {
-            Slab<4> d;
-#pragma unroll
-            for (int f = 0; f < 4; ++f) d.v[f] = s.v[f];
-            d.y = s.y;
-            consume_slab<4, 4, true, false, true, false>(V4, d, X4, cy, 0, n);
-        } else if (role == 1) consume_slab<4, 4, false, false, false, false>(V8, s, X8, cy, 0, n);
-    };
+    auto fetch = [&](Slab<8> &s, int slot) { static_for<NFETCH>([&](auto J_) { fetch1(s, slot, J_); }); };
     auto next = [](int v) { return v + 1 == NSLOT ? 0 : v + 1; };
-    // prologue: NSLOT - 2 slabs in flight (the slot two behind the newest is the one being read)
+    // prologue: NSLOT - 2 slabs in flight
     const int npre = ns < NSLOT - 2 ? ns : NSLOT - 2;
     for (int j = 0; j < npre; ++j) issue(j);
     int islot = npre % NSLOT, rslot = 0, issued = npre;
@@ -929,17 +981,35 @@ __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64
         fetch(sa, 0);
         rslot = 1;
     }
-    // steady state: slab k in registers; own DMAs of slab k+1 landed -> barrier -> read slab k+1, refill the slot of
-    // slab k-1 with slab k+NSLOT-2, multiply slab k
+    // Steady state, two slabs per trip and not a single conditional inside.  The hand-over (exact vmcnt wait: this
+    // wave's DMAs of slab k+1 have landed; barrier: everybody's have, and everybody is done with slab k-1), the ring
+    // reads of slab k+1 and this wave's DMAs of slab k+NSLOT-2 (into the slot of slab k-2) sit BETWEEN the MFMAs of
+    // slab k (hook after MFMA m), where scalar, LDS and VMEM instructions issue for free.
     int k = 0;
+    auto steady = [&](Slab<8> &use, Slab<8> &nxt) {
+        const int rs = rslot, is = islot;
+        sb_consume<DIAGSB, W, XF, false>(use, c, cy, sx, sxy, sy, syy, 0, n, [&](auto M_) {
+            constexpr int m = decltype(M_)::value;
+            if constexpr (m == 0) { wait_vm<(NSLOT - 4) * DPW>(); __syncthreads(); }
+            if constexpr (m >= 1 && m <= NFETCH) fetch1(nxt, rs, std::integral_constant<int, m - 1>{});
+            if constexpr (m > NFETCH && m <= NFETCH + DPW) issue1(is, std::integral_constant<int, m - NFETCH - 1>{});
+        });
+        rslot = next(rslot); islot = next(islot);
+    };
+    while (issued + 2 <= ns) {
+        steady(sa, sb);
+        steady(sb, sa);
+        issued += 2; k += 2;
+    }
+    // drain
     auto step = [&](Slab<8> &use, Slab<8> &nxt) {
-        if (k + 1 < ns) {          // slab k+1 must have landed; up to NSLOT-4 younger slabs of this wave may still fly
+        if (k + 1 < ns) {
             if (issued - (k + 2) >= NSLOT - 4) wait_vm<(NSLOT - 4) * DPW>(); else wait_vm<0>();
         }
         __syncthreads();
         if (k + 1 < ns) { fetch(nxt, rslot); rslot = next(rslot); }
         if (issued < ns) { issue(islot); islot = next(islot); ++issued; }
-        consume(use);
+        sb_consume<DIAGSB, W, XF, false>(use, c, cy, sx, sxy, sy, syy, 0, n);
         ++k;
     };
     while (k < ns) {
@@ -948,68 +1018,55 @@ __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64
     }
     wait_vm<0>();
     // ragged tail of the data set (fewer than 8 rows left): masked loads straight from global memory
-    if (rows - 8 * (int64_t)ns > 0 && role != 2) {
+    if (rows - 8 * (int64_t)ns > 0) {
         const int64_t r = row_begin + 8 * (int64_t)ns + 2 * q;
         const int64_t r0 = r < n ? r : n - 1, r1 = r + 1 < n ? r + 1 : n - 1;
         Slab<8> t;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const gptr_t pr = xg + (size_t)frag_col(rb + f) * ld, pc = xg + (size_t)frag_col(cb + f) * ld;
-            t.v[f].x = pr[r0]; t.v[f].y = pr[r1];
-            t.v[4 + f].x = pc[r0]; t.v[4 + f].y = pc[r1];
+        for (int f = 0; f < 8; ++f) {
+            const gptr_t pf = xg + (size_t)frag_col(reg_frag(f)) * ld;
+            t.v[f].x = pf[r0]; t.v[f].y = pf[r1];
         }
         t.y.x = yg[r0]; t.y.y = yg[r1];
-        if (role == 0) {
-            Slab<4> d;
-#pragma unroll
-            for (int f = 0; f < 4; ++f) d.v[f] = t.v[f];
-            d.y = t.y;
-            consume_slab<4, 4, true, true, true, false>(V4, d, X4, cy, r, n);
-        } else consume_slab<4, 4, false, true, false, false>(V8, t, X8, cy, r, n);
+        sb_consume<DIAGSB, W, XF, true>(t, c, cy, sx, sxy, sy, syy, r, n);
     }
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-    // ---- results: tiles are wave-private -> straight to the partial buffer; vector sums of the diagonal blocks
-    const int BI = DIAGSB ? 2 * SI + (rb >> 2) : 2 * SI + (rb >> 2), BJ = DIAGSB ? 2 * SI + (cb >> 2) : 2 * SJ + ((cb - 8) >> 2);
-    if (role == 0) {
+    // ---- results: tiles are wave-private -> straight to the partial buffer; vector sums of the diagonal super-blocks
+    if constexpr (DIAGSB) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            V4.sx[f] += shfl_xor_d(V4.sx[f], 16);  V4.sx[f] += shfl_xor_d(V4.sx[f], 32);
-            V4.sxy[f] += shfl_xor_d(V4.sxy[f], 16); V4.sxy[f] += shfl_xor_d(V4.sxy[f], 32);
+        for (int k2 = 0; k2 < 2; ++k2) {
+            sx[k2] += shfl_xor_d(sx[k2], 16);  sx[k2] += shfl_xor_d(sx[k2], 32);
+            sxy[k2] += shfl_xor_d(sxy[k2], 16); sxy[k2] += shfl_xor_d(sxy[k2], 32);
         }
-        V4.sy += shfl_xor_d(V4.sy, 16);   V4.sy += shfl_xor_d(V4.sy, 32);
-        V4.syy += shfl_xor_d(V4.syy, 16); V4.syy += shfl_xor_d(V4.syy, 32);
+        sy += shfl_xor_d(sy, 16);   sy += shfl_xor_d(sy, 32);
+        syy += shfl_xor_d(syy, 16); syy += shfl_xor_d(syy, 32);
         if (q == 0) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const int T = 4 * BI + f;
-                if (T < ntc) { vdst[16 * T + i] = V4.sx[f]; vdst[16 * ntc + 16 * T + i] = V4.sxy[f]; }
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int T = 8 * SI + 2 * W + k2;
+                if (T < ntc) { vdst[16 * T + i] = sx[k2]; vdst[16 * ntc + 16 * T + i] = sxy[k2]; }
             }
-            if (i == 0 && BI == 0) {
-                vdst[32 * ntc] = V4.sy; vdst[32 * ntc + 1] = V4.syy; vdst[32 * ntc + 2] = (double)rows; vdst[32 * ntc + 3] = 0.0;
+            if (W == 0 && i == 0 && SI == 0) {
+                vdst[32 * ntc] = sy; vdst[32 * ntc + 1] = syy; vdst[32 * ntc + 2] = (double)rows; vdst[32 * ntc + 3] = 0.0;
             }
         }
-        static_for<4>([&](auto I_) {
-            constexpr int I = decltype(I_)::value;
-            static_for<I + 1>([&](auto J_) {
-                constexpr int J = decltype(J_)::value;
-                const int gi = 4 * BI + I, gj = 4 * BI + J;
-                if (gi < ntc && gj < ntc) {
-                    double *dst = tdst + (size_t)(gi * (gi + 1) / 2 + gj) * 256;
-                    static_for<4>([&](auto R_) { constexpr int r = decltype(R_)::value; dst[r * 64 + lane] = AccTile<I *(I + 1) / 2 + J>::template read<r>(); });
-                }
-            });
+        static_for<9>([&](auto T_) {
+            constexpr int t = decltype(T_)::value, tt = 9 * W + t, I = tri_row(tt), J = tt - I * (I + 1) / 2;
+            const int gi = 8 * SI + I, gj = 8 * SI + J;
+            if (gi < ntc && gj < ntc) {
+                double *dst = tdst + (size_t)(gi * (gi + 1) / 2 + gj) * 256;
+                static_for<4>([&](auto R_) { constexpr int r = decltype(R_)::value; dst[r * 64 + lane] = AccTile<t>::template read<r>(); });
+            }
         });
-    } else if (role == 1) {
-        static_for<4>([&](auto I_) {
-            constexpr int I = decltype(I_)::value;
-            static_for<4>([&](auto J_) {
-                constexpr int J = decltype(J_)::value;
-                const int gi = 4 * BI + I, gj = 4 * BJ + J;
-                if (gi < ntc && gj < ntc) {
-                    double *dst = tdst + (size_t)(gi * (gi + 1) / 2 + gj) * 256;
-                    static_for<4>([&](auto R_) { constexpr int r = decltype(R_)::value; dst[r * 64 + lane] = AccTile<I * 4 + J>::template read<r>(); });
-                }
-            });
+    } else {
+        const int BI = 2 * SI + (w >> 1), BJ = 2 * SJ + (w & 1);
+        static_for<16>([&](auto T_) {
+            constexpr int t = decltype(T_)::value;
+            const int gi = 4 * BI + t / 4, gj = 4 * BJ + t % 4;
+            if (gi < ntc && gj < ntc) {
+                double *dst = tdst + (size_t)(gi * (gi + 1) / 2 + gj) * 256;
+                static_for<4>([&](auto R_) { constexpr int r = decltype(R_)::value; dst[r * 64 + lane] = AccTile<t>::template read<r>(); });
+            }
         });
     }
 }
@@ -1028,8 +1085,20 @@ __global__ __launch_bounds__(256) void gram_sb_kernel(const double *__restrict__
     const int64_t row_begin = (int64_t)chunk * a.steps * 64;
     double *tdst = tpart + (size_t)chunk * a.ntile * 256;
     double *vdst = vpart + (size_t)chunk * (32 * a.ntc + 4);
-    if (SI == SJ) gram_sb_body<true>(x, a.n, a.ld, a.p, y, sums, a.ntc, SI, SJ, row_begin, a.steps, tdst, vdst, lds);
-    else gram_sb_body<false>(x, a.n, a.ld, a.p, y, sums, a.ntc, SI, SJ, row_begin, a.steps, tdst, vdst, lds);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // every (kind of super-block, wave, shift) combination is its own straight-line body: a taken scalar branch per slab
+    // costs ~80 cycles (measured on the path kernels), a 4-way dispatch up here costs nothing
+#define OEM_SB(D, W, XF) gram_sb_body<D, W, XF>(x, a.n, a.ld, a.p, y, sums, a.ntc, SI, SJ, row_begin, a.steps, tdst, vdst, lds)
+    if (shift_needed_wave(sums, a.p)) {
+        if (SI != SJ) OEM_SB(false, 0, true);
+        else if (w == 0) OEM_SB(true, 0, true); else if (w == 1) OEM_SB(true, 1, true);
+        else if (w == 2) OEM_SB(true, 2, true); else OEM_SB(true, 3, true);
+    } else {
+        if (SI != SJ) OEM_SB(false, 0, false);
+        else if (w == 0) OEM_SB(true, 0, false); else if (w == 1) OEM_SB(true, 1, false);
+        else if (w == 2) OEM_SB(true, 2, false); else OEM_SB(true, 3, false);
+    }
+#undef OEM_SB
 }
 
 GramPlan gram_plan(int64_t n, int p, int num_cu)
@@ -1112,9 +1181,9 @@ static int launch_gram_t(hipStream_t s, const GramPlan &pl, const double *x, con
         default: set_error("gram: bad tile count %d", pl.ntc); return OEMGPU_ERR_INTERNAL;
         }
     } else {
-        if (ALIGNED && !getenv("OEM_GRAM_BLK")) {
+        if (ALIGNED && !getenv("OEM_GRAM_BLK") && (double)a.ld * 16.0 * 8.0 < 4294967296.0) {   // 32-bit lane offsets within a tile
             const int nsb = (pl.ntc + 7) / 8, nsblk = nsb * (nsb + 1) / 2;
-            const size_t shb = (size_t)6 * 16 * 1024;                       // NSLOT x 16 KiB slots
+            const size_t shb = (size_t)SB_NSLOT * 16 * 1024;                // NSLOT x 16 KiB slots
             OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
             hipLaunchKernelGGL(gram_sb_kernel, dim3(pl.nchunk * nsblk), dim3(256), shb, s, x, y, sums, tpart, vpart, a, nsblk);
             OEM_HIP(hipGetLastError());
