@@ -13,6 +13,7 @@
 #include "penalty_ops.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -402,10 +403,118 @@ __global__ __launch_bounds__(1024) void lanczos_update_kernel(int q, int j, doub
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// Fused iteration (element-wise penalties, q = 512 / 1024 / 2048 / 4096, no accelerate / loss / scale.factor):
+// ONE kernel per OEM iteration -- g = XX beta streamed exactly like gemv_sym_kernel, and the wave that finishes row r
+// thresholds coordinate r on the spot (the operator is row-local).  What is not row-local is the stop rule and the
+// lambda / penalty bookkeeping.  Instead of a second kernel (7.4 us + a launch boundary per iteration at p = 4096) or a
+// last-arriver fence (measured: no faster), the bookkeeping is REPLICATED one launch later: every workgroup of launch
+// k+1 ORs the per-workgroup "still moving" words that launch k left behind, and takes the same state transition
+// (converged -> store this lambda's beta, move to the next lambda or penalty).  State, beta and flags are double-buffered
+// by launch parity, which is a kernel argument of the graph node.  u = d beta - g + XY does not depend on lambda, so the
+// launch that detects convergence of lambda_i already performs the first iteration of lambda_{i+1}.
+// ------------------------------------------------------------------------------------------------
+struct FState {
+    int pp, i, it, done, fresh, pad0, pad1, pad2;
+};
+static const int FMAXB = 1024;          // flag words per parity
+
+template <int VPL>
+__global__ __launch_bounds__(256) void oem_fused_kernel(PathArgs A, FState *__restrict__ S, double *__restrict__ B,
+                                                         int *__restrict__ flags, int *__restrict__ fdone, int par, double d)
+{
+    const int q = A.p, nl = A.nl, tid = threadIdx.x, lane = tid & 63;
+    const int wave = blockIdx.x * 4 + (tid >> 6), nwave = gridDim.x * 4;
+    const FState st = S[par];
+    if (st.done) {                                                  // the launch after the last one: make both copies agree
+        if (blockIdx.x == 0 && tid == 0) { S[par ^ 1].done = 1; *fdone = 1; }
+        return;
+    }
+    const double *__restrict__ bin = B + (size_t)par * (q + 8);
+    double *__restrict__ bout = B + (size_t)(par ^ 1) * (q + 8);
+    v2d v[VPL / 2];
+#pragma unroll
+    for (int j = 0; j < VPL / 2; ++j) v[j] = *reinterpret_cast<const v2d *>(bin + 2 * lane + 128 * j);
+    int f = 0;
+    for (int t = tid; t < (int)gridDim.x; t += 256) f |= flags[par * FMAXB + t];
+    const int any = __syncthreads_or(f);
+    // ---- the replicated state transition
+    int pp = st.pp, i = st.i, it = st.it;
+    bool fresh = st.fresh != 0, finalize = false, done_now = false;
+    size_t kfin = 0;
+    int niter_fin = 0;
+    if (!fresh) {
+        const bool conv = !any;
+        if (conv || it >= A.maxit) {
+            finalize = true; kfin = (size_t)pp * nl + i; niter_fin = conv ? it : A.maxit + 1;     // ref src/oem_base.h:94-109
+            const int nlam = (A.penalty[pp] == OEMGPU_OLS) ? 1 : nl;
+            if (i + 1 < nlam) i = i + 1;
+            else if (pp + 1 < A.npen) { pp = pp + 1; i = 0; fresh = true; }
+            else done_now = true;
+            it = 0;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        FState nx; nx.pp = pp; nx.i = i; nx.it = it + 1; nx.done = done_now ? 1 : 0; nx.fresh = 0; nx.pad0 = nx.pad1 = nx.pad2 = 0;
+        S[par ^ 1] = nx;
+        if (finalize) { A.niter[kfin] = niter_fin; A.loss[kfin] = 1e99; }
+    }
+    if (done_now) {                                                 // only the last lambda's coefficients are left to store
+        for (int r = wave * 64 + lane; r < q; r += nwave * 64) A.beta[kfin * q + r] = bin[r];
+        return;
+    }
+    // ---- constants of the (possibly new) lambda
+    const int pen = A.penalty[pp];
+    const double scaley = A.yscale ? A.stats[1] : 1.0;
+    const PenK K = pen_consts(pen, A.lambda_out[(size_t)pp * nl + i] / scaley, d, A.alpha, A.gamma, A.tau);
+    const double rD = 1.0 / K.D, gammad = K.gamma * K.D, dmg = K.D - 1.0 / K.gamma, rdmg = 1.0 / dmg;
+    const double gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0, rdsc = 1.0 / dsc, rd = 1.0 / d, tol = A.tol;
+    bool moving = false;
+    for (int r = wave; r < q; r += nwave) {
+        const double bo = bin[r], xyr = A.xy[r], tp = A.pf[r] * K.L;        // in flight while the row streams
+        const double *row = A.xx + (size_t)r * q;
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < VPL / 2; ++j) {
+            const v2d t = *reinterpret_cast<const v2d *>(row + 2 * lane + 128 * j);
+            a0 = fma(t.x, v[j].x, a0);
+            a1 = fma(t.y, v[j].y, a1);
+        }
+        const double g = wsum(a0 + a1);
+        if (finalize && lane == 0) A.beta[kfin * q + r] = bo;
+        const double b0 = fresh ? 0.0 : bo;
+        const double u = (d * b0 - (fresh ? 0.0 : g)) + xyr;
+        double bn;
+        if (K.kind == K_SOFT) bn = cdiv(shrink(u, tp), K.D, rD);
+        else if (K.kind == K_MCP) {
+            const bool big = fabs(u) > gammad * tp;
+            bn = cdiv(big ? u : shrink(u, tp), big ? K.D : dmg, big ? rD : rdmg);
+        } else if (K.kind == K_SCAD) {
+            const double au = fabs(u);
+            const bool big = au > gammad * tp, mid = !big && au > (K.D + 1.0) * tp;
+            const double num = big ? u : (mid ? shrink(gm1 * u, K.gamma * tp) : shrink(u, tp));
+            bn = cdiv(num, mid ? dsc : K.D, mid ? rdsc : rD);
+        } else bn = cdiv(u, d, rd);
+        const double c = fabs(bn), qo = fabs(b0);
+        const bool cn = c > 1e-13, qn = qo > 1e-13;
+        moving |= (cn != qn) || (cn && qn && fabs(bn - b0) > tol * qo);
+        if (lane == 0) bout[r] = bn;
+    }
+    const int mv = __syncthreads_or(moving ? 1 : 0);
+    if (tid == 0) flags[(par ^ 1) * FMAXB + blockIdx.x] = mv;
+}
+
+__global__ void fused_init_kernel(FState *S, int npen)
+{
+    FState z; z.pp = 0; z.i = 0; z.it = 0; z.done = (npen == 0) ? 1 : 0; z.fresh = 1; z.pad0 = z.pad1 = z.pad2 = 0;
+    S[0] = z; S[1] = z; S[1].done = 0;
+}
+
 size_t path_large_work_doubles(int p, int nsteps)
 {
     (void)nsteps;
-    return (size_t)STATE_DBL + 5 * (size_t)(p + 8) + 2 * MAXL + 64;
+    // + fused engine: FState[2] (8 doubles), done word, beta[2][p+8], flags[2][FMAXB] ints
+    return (size_t)STATE_DBL + 5 * (size_t)(p + 8) + 2 * MAXL + 64 + 16 + 2 * (size_t)(p + 8) + FMAXB;
 }
 
 // host_scratch: pinned host memory (>= 8 KB)
@@ -451,6 +560,58 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     hipLaunchKernelGGL(path_init_kernel, dim3(1), dim3(1024), 0, s, a, st, beta, d, theta);
     OEM_HIP(hipGetLastError());
     if (a.npen == 0) return 0;
+
+    // ---- fused engine when the operators are row-local and nothing needs a global sum per iteration
+    const bool fused_ok = a.ngroups == 0 && !a.accelerate && !a.compute_loss && !a.sinv && (q == 512 || q == 1024 || q == 2048 || q == 4096) &&
+                          (((uintptr_t)a.xx) & 15) == 0 && !getenv("OEM_NO_FUSED");
+    if (fused_ok) {
+        double *fbase = T + 2 * MAXL + 64;
+        FState *S = reinterpret_cast<FState *>(fbase);
+        int *fdone = reinterpret_cast<int *>(fbase + 8);
+        double *Bv = fbase + 16;
+        int *flags = reinterpret_cast<int *>(Bv + 2 * (size_t)(q + 8));
+        int blocks = (q + 3) / 4;
+        if (blocks > num_cu * 2) blocks = num_cu * 2;
+        if (blocks > FMAXB) blocks = FMAXB;
+        hipLaunchKernelGGL(fused_init_kernel, dim3(1), dim3(1), 0, s, S, a.npen);
+        auto enq = [&](int count) {
+            for (int k = 0; k < count; ++k) {
+                const int par = k & 1;
+                if (q == 512) hipLaunchKernelGGL((oem_fused_kernel<8>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);
+                else if (q == 1024) hipLaunchKernelGGL((oem_fused_kernel<16>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);
+                else if (q == 2048) hipLaunchKernelGGL((oem_fused_kernel<32>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);
+                else hipLaunchKernelGGL((oem_fused_kernel<64>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);
+            }
+        };
+        const int FB = 128;                                          // even: every batch starts at parity 0
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            enq(FB);
+            if (hipStreamEndCapture(s, &graph) != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+                if (graph) (void)hipGraphDestroy(graph);
+                graph = nullptr; exec = nullptr;
+                (void)hipGetLastError();
+            }
+        } else (void)hipGetLastError();
+        const long long max_it = (long long)a.npen * a.nl * ((long long)a.maxit + 2) + 8;
+        long long launched = 0;
+        int *hdone = reinterpret_cast<int *>(host_scratch);
+        int rc = 0;
+        for (;;) {
+            if (exec) { if (hipGraphLaunch(exec, s) != hipSuccess) { set_error("hipGraphLaunch failed"); rc = OEMGPU_ERR_HIP; break; } }
+            else enq(FB);
+            if (hipGetLastError() != hipSuccess) { set_error("fused engine: launch failed"); rc = OEMGPU_ERR_HIP; break; }
+            launched += FB;
+            if (hipMemcpyAsync(hdone, fdone, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess) { set_error("fused engine: device error"); rc = OEMGPU_ERR_HIP; break; }
+            if (*hdone) break;
+            if (launched > max_it) { set_error("fused engine did not finish within %lld iterations", max_it); rc = OEMGPU_ERR_INTERNAL; break; }
+        }
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
 
     // ---- path: (gemv, update) pairs replayed in batches from a hipGraph (eager launches are host-bound at ~3.5 us
     //      each); the host polls the done word once per batch.  Fusing the pair into one launch with a last-arriver

@@ -115,3 +115,32 @@ def test_config5_big_p256_reduced_n_and_shards(oa):
     xs = [x[cuts[i]:cuts[i + 1]] for i in range(8)]
     ys = [y[cuts[i]:cuts[i + 1]] for i in range(8)]
     _cmp(oa.big_oem(xs, ys, **kw), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [512, 1024])
+def test_fused_iteration_engine(oa, p):
+    """p = 512 / 1024 / 2048 / 4096 with row-local operators: one fused kernel per OEM iteration (GEMV + threshold, the
+    stop rule and lambda bookkeeping replicated one launch later).  Against the oracle, and against the two-kernel engine."""
+    import os
+    rng = np.random.default_rng(p)
+    n = 3 * p
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 2.0 + 0.3)
+    b = np.concatenate([rng.uniform(-0.5, 0.5, 12), np.zeros(p - 12)])
+    y = x @ b + rng.normal(size=n)
+    pens = ["lasso", "elastic.net", "mcp", "scad", "ols", "scad.net"]
+    kw = dict(penalty=pens, alpha=0.7, nlambda=8, tol=1e-8, maxit=400)
+    fit, ref = oa.oem(x, y, **kw), orc.fit_dense(x, y, native=True, **kw)
+    os.environ["OEM_NO_FUSED"] = "1"
+    try:
+        two = oa.oem(x, y, **kw)
+    finally:
+        del os.environ["OEM_NO_FUSED"]
+    for k in range(len(pens)):
+        assert np.abs(np.asarray(fit["beta"][k]) - np.asarray(ref["beta"][k])).max() < 1e-9, pens[k]
+        assert np.array_equal(np.asarray(fit["beta"][k]), np.asarray(two["beta"][k])), pens[k]      # same arithmetic, bit for bit
+        assert np.array_equal(np.ravel(fit["niter"][k]), np.ravel(two["niter"][k])), pens[k]
+    kw = dict(penalty=["lasso"], nlambda=6, tol=1e-12, maxit=3)                                       # exhaustion: maxit + 1
+    fit, ref = oa.oem(x, y, **kw), orc.fit_dense(x, y, native=True, **kw)
+    assert np.array_equal(fit["niter"][0], ref["niter"][0]) and fit["niter"][0].max() == 4
+    assert np.abs(fit["beta"][0] - ref["beta"][0]).max() < 1e-9
