@@ -504,6 +504,173 @@ __global__ __launch_bounds__(256) void oem_fused_kernel(PathArgs A, FState *__re
     if (tid == 0) flags[(par ^ 1) * FMAXB + blockIdx.x] = mv;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused iteration, replicated-update form (group penalties, accelerate, compute.loss, scale.factor; same q): what crosses
+// launches is u = d beta - XX beta + XY.  EVERY workgroup thresholds the whole u itself (q <= 4096 coordinates: a few
+// hundred nanoseconds, identical in every workgroup), applies the stop rule, takes the state transition at once, puts
+// beta into registers and streams its rows of XX; workgroup 0 also leaves beta behind for the next stop rule.  One launch
+// per iteration instead of two; at p = 512 the iteration is launch-latency bound, so that halves it.
+// ------------------------------------------------------------------------------------------------
+struct GState {
+    int pp, i, it, done, fresh, pending_loss, finish_after_loss, pad;
+    double ak;
+};
+
+template <int VPL>
+__global__ __launch_bounds__(256) void oem_fused_rep_kernel(PathArgs A, GState *__restrict__ S, double *__restrict__ Ubuf,
+                                                             double *__restrict__ Bbuf, int *__restrict__ fdone, int par, double d)
+{
+    extern __shared__ __attribute__((aligned(16))) double dyn[];     // Ush[q] | Bsh[q] | F[ngroups]
+    __shared__ double sh[16];
+    const int q = A.p, nl = A.nl, tid = threadIdx.x, nt = 256, lane = tid & 63;
+    const int wave = blockIdx.x * 4 + (tid >> 6), nwave = gridDim.x * 4;
+    const GState st = S[par];
+    if (st.done) {
+        if (blockIdx.x == 0 && tid == 0) { S[par ^ 1].done = 1; *fdone = 1; }
+        return;
+    }
+    const bool b0 = blockIdx.x == 0;
+    double *Ush = dyn, *Bsh = dyn + q, *F = dyn + 2 * q;
+    const double *__restrict__ uin = Ubuf + (size_t)par * (q + 8), *__restrict__ bprev = Bbuf + (size_t)par * (q + 8);
+    double *__restrict__ uout = Ubuf + (size_t)(par ^ 1) * (q + 8), *__restrict__ bkeep = Bbuf + (size_t)(par ^ 1) * (q + 8);
+    const double scaley = A.yscale ? A.stats[1] : 1.0;
+    const double yy = A.stats[2], nobs = A.stats[3];
+    const bool fresh = st.fresh != 0;
+    // ---- loss of the lambda that converged in the previous launch: XX beta_final = d beta_final - u + XY
+    if (st.pending_loss >= 0) {
+        double t = 0.0;
+        for (int j = tid; j < q; j += nt) { const double b = bprev[j], g = (d * b - uin[j]) + A.xy[j]; t += b * (g - 2.0 * A.xy[j]); }
+        t = block_sum(t, sh);
+        if (b0 && tid == 0) A.loss[st.pending_loss] = yy + nobs * t;
+    }
+    if (st.finish_after_loss) {
+        if (b0 && tid == 0) { GState nx = st; nx.done = 1; nx.pending_loss = -1; S[par ^ 1] = nx; }
+        return;
+    }
+    const int pp = st.pp, i = st.i;
+    const int pen = A.penalty[pp];
+    const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
+    const PenK K = pen_consts(pen, A.lambda_out[(size_t)pp * nl + i] / scaley, d, A.alpha, A.gamma, A.tau);
+    const double rD = 1.0 / K.D, gammad = K.gamma * K.D, dmg = K.D - 1.0 / K.gamma, rdmg = 1.0 / dmg;
+    const double gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0, rdsc = 1.0 / dsc;
+    const bool grp = K.kind >= K_GRP;
+    double ak = fresh ? 1.0 : st.ak;
+    // ---- u (a fresh penalty starts from beta = 0: u = XY) and, for the group operators, the group factors
+    for (int j = tid; j < q; j += nt) {
+        const double u = fresh ? A.xy[j] : uin[j];
+        Ush[j] = (grp && K.kind == K_SGL) ? soft1(u, A.pf[j] * K.L1, 1.0) : u;
+    }
+    __syncthreads();
+    if (grp) {
+        for (int gi = tid; gi < A.ngroups; gi += nt) {
+            double f = 1.0;
+            if (!A.gzero[gi]) {
+                double s2 = 0.0;
+                for (int m = A.gstart[gi]; m < A.gstart[gi + 1]; ++m) { const double x = Ush[A.gidx[m]]; s2 += x * x; }
+                s2 = sqrt(s2);
+                const double pen_g = K.L * A.gw[gi];
+                if (K.kind == K_GRP || K.kind == K_SGL) { const double t = 1.0 - pen_g / s2; f = (0.0 < t) ? t : 0.0; }
+                else if (K.kind == K_GRP_MCP) f = mcp_norm(s2, pen_g, K.D, K.gamma);
+                else f = scad_norm(s2, pen_g, K.D, K.gamma);
+            }
+            F[gi] = f;
+        }
+        __syncthreads();
+    }
+    // ---- beta = T(u), acceleration, stop rule (every workgroup, identically)
+    bool bad = false;
+    double adp = 0.0;
+    const double akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak)), ratio = (ak - 1.0) / akn;
+    for (int j = tid; j < q; j += nt) {
+        const double bo = fresh ? 0.0 : bprev[j];
+        const double u = Ush[j];
+        double bn;
+        if (grp) {
+            const int gi = A.gid[j];
+            const double f = gi >= 0 ? F[gi] : 0.0;
+            bn = (f != 0.0) ? u * f / K.D : 0.0;
+        } else {
+            const double tp = A.pf[j] * K.L;
+            if (K.kind == K_SOFT) bn = cdiv(shrink(u, tp), K.D, rD);
+            else if (K.kind == K_MCP) {
+                const bool big = fabs(u) > gammad * tp;
+                bn = cdiv(big ? u : shrink(u, tp), big ? K.D : dmg, big ? rD : rdmg);
+            } else if (K.kind == K_SCAD) {
+                const double au = fabs(u);
+                const bool big = au > gammad * tp, mid = !big && au > (K.D + 1.0) * tp;
+                const double num = big ? u : (mid ? shrink(gm1 * u, K.gamma * tp) : shrink(u, tp));
+                bn = cdiv(num, mid ? dsc : K.D, mid ? rdsc : rD);
+            } else bn = cdiv(u, d, 1.0 / d);
+        }
+        if (A.accelerate) {                                   // ref src/oem_dense.h:633-651
+            const double upd = bn, diff = upd - bo;
+            bn = upd + ratio * diff;
+            adp += (bn - upd) * diff;
+        }
+        const double c = fabs(bn), qo = fabs(bo);
+        const bool cn = c > 1e-13, qn = qo > 1e-13;
+        bad |= (cn != qn);
+        bad |= (cn && qn && fabs(bn - bo) > A.tol * qo);
+        Bsh[j] = bn;
+    }
+    if (A.accelerate) {
+        adp = block_sum(adp, sh);
+        ak = (adp > 0.0) ? 1.0 : akn;
+    }
+    const int anybad = __syncthreads_or(bad ? 1 : 0);
+    const int it = st.it + 1;
+    const bool conv = !anybad;
+    GState nx = st;
+    nx.fresh = 0; nx.pending_loss = -1; nx.ak = ak; nx.it = it;
+    bool done_now = false;
+    if (conv || it >= A.maxit) {
+        const size_t ki = (size_t)pp * nl + i;
+        if (A.sinv) {                                           // quirk Q5: the member itself is rescaled
+            for (int j = tid; j < q; j += nt) Bsh[j] *= A.sinv[j];
+            __syncthreads();
+        }
+        for (int j = wave * 64 + lane; j < q; j += nwave * 64) A.beta[ki * q + j] = Bsh[j];
+        if (b0 && tid == 0) {
+            A.niter[ki] = conv ? it : A.maxit + 1;                  // ref src/oem_base.h:94-109
+            if (!A.compute_loss) A.loss[ki] = 1e99;
+        }
+        nx.pending_loss = A.compute_loss ? (int)ki : -1;
+        nx.it = 0;
+        if (i + 1 < nlam) nx.i = i + 1;
+        else if (pp + 1 < A.npen) { nx.pp = pp + 1; nx.i = 0; nx.fresh = 1; }
+        else if (A.compute_loss) nx.finish_after_loss = 1;
+        else { nx.done = 1; done_now = true; }
+    }
+    if (b0) {
+        if (tid == 0) S[par ^ 1] = nx;
+        for (int j = tid; j < q; j += nt) bkeep[j] = Bsh[j];       // beta_t for the next launch's stop rule / loss
+    }
+    if (done_now) return;
+    // ---- g = XX beta for this workgroup's rows, u' = d beta - g + XY
+    v2d v[VPL / 2];
+#pragma unroll
+    for (int j = 0; j < VPL / 2; ++j) v[j] = *reinterpret_cast<const v2d *>(Bsh + 2 * lane + 128 * j);
+    for (int r = wave; r < q; r += nwave) {
+        const double br = Bsh[r], xyr = A.xy[r];
+        const double *row = A.xx + (size_t)r * q;
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < VPL / 2; ++j) {
+            const v2d t = *reinterpret_cast<const v2d *>(row + 2 * lane + 128 * j);
+            a0 = fma(t.x, v[j].x, a0);
+            a1 = fma(t.y, v[j].y, a1);
+        }
+        const double g = wsum(a0 + a1);
+        if (lane == 0) uout[r] = (d * br - g) + xyr;
+    }
+}
+
+__global__ void fused_rep_init_kernel(GState *S, int npen)
+{
+    GState z; z.pp = 0; z.i = 0; z.it = 0; z.done = (npen == 0) ? 1 : 0; z.fresh = 1; z.pending_loss = -1; z.finish_after_loss = 0; z.pad = 0; z.ak = 1.0;
+    S[0] = z; S[1] = z; S[1].done = 0;
+}
+
 __global__ void fused_init_kernel(FState *S, int npen)
 {
     FState z; z.pp = 0; z.i = 0; z.it = 0; z.done = (npen == 0) ? 1 : 0; z.fresh = 1; z.pad0 = z.pad1 = z.pad2 = 0;
@@ -514,7 +681,8 @@ size_t path_large_work_doubles(int p, int nsteps)
 {
     (void)nsteps;
     // + fused engine: FState[2] (8 doubles), done word, beta[2][p+8], flags[2][FMAXB] ints
-    return (size_t)STATE_DBL + 5 * (size_t)(p + 8) + 2 * MAXL + 64 + 16 + 2 * (size_t)(p + 8) + FMAXB;
+    // + replicated-update engine: GState[2] (16 doubles), u[2][p+8] (beta[2] shared with the fused engine)
+    return (size_t)STATE_DBL + 5 * (size_t)(p + 8) + 2 * MAXL + 64 + 16 + 2 * (size_t)(p + 8) + FMAXB + 16 + 2 * (size_t)(p + 8);
 }
 
 // host_scratch: pinned host memory (>= 8 KB)
@@ -595,6 +763,63 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
             }
         } else (void)hipGetLastError();
         const long long max_it = (long long)a.npen * a.nl * ((long long)a.maxit + 2) + 8;
+        long long launched = 0;
+        int *hdone = reinterpret_cast<int *>(host_scratch);
+        int rc = 0;
+        for (;;) {
+            if (exec) { if (hipGraphLaunch(exec, s) != hipSuccess) { set_error("hipGraphLaunch failed"); rc = OEMGPU_ERR_HIP; break; } }
+            else enq(FB);
+            if (hipGetLastError() != hipSuccess) { set_error("fused engine: launch failed"); rc = OEMGPU_ERR_HIP; break; }
+            launched += FB;
+            if (hipMemcpyAsync(hdone, fdone, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess) { set_error("fused engine: device error"); rc = OEMGPU_ERR_HIP; break; }
+            if (*hdone) break;
+            if (launched > max_it) { set_error("fused engine did not finish within %lld iterations", max_it); rc = OEMGPU_ERR_INTERNAL; break; }
+        }
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+
+    // ---- replicated-update fused engine: everything else at the same sizes
+    const bool rep_ok = (q == 512 || q == 1024 || q == 2048 || q == 4096) && (((uintptr_t)a.xx) & 15) == 0 && !getenv("OEM_NO_FUSED");
+    if (rep_ok) {
+        double *fbase = T + 2 * MAXL + 64;
+        int *fdone = reinterpret_cast<int *>(fbase + 8);
+        double *Bv = fbase + 16;
+        double *gbase = Bv + 2 * (size_t)(q + 8) + FMAXB;
+        GState *S = reinterpret_cast<GState *>(gbase);
+        double *Uv = gbase + 16;
+        int blocks = (q + 3) / 4;
+        if (blocks > num_cu * 2) blocks = num_cu * 2;
+        const size_t shb = sizeof(double) * (size_t)(2 * q + (a.ngroups > 0 ? a.ngroups : 0) + 8);
+#define OEM_REP_ATTR(V)                                                                                                      \
+    if (shb > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&oem_fused_rep_kernel<V>),                \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+        if (q == 512) { OEM_REP_ATTR(8) } else if (q == 1024) { OEM_REP_ATTR(16) } else if (q == 2048) { OEM_REP_ATTR(32) } else { OEM_REP_ATTR(64) }
+#undef OEM_REP_ATTR
+        hipLaunchKernelGGL(fused_rep_init_kernel, dim3(1), dim3(1), 0, s, S, a.npen);
+        auto enq = [&](int count) {
+            for (int k = 0; k < count; ++k) {
+                const int par = k & 1;
+                if (q == 512) hipLaunchKernelGGL((oem_fused_rep_kernel<8>), dim3(blocks), dim3(256), shb, s, a, S, Uv, Bv, fdone, par, d);
+                else if (q == 1024) hipLaunchKernelGGL((oem_fused_rep_kernel<16>), dim3(blocks), dim3(256), shb, s, a, S, Uv, Bv, fdone, par, d);
+                else if (q == 2048) hipLaunchKernelGGL((oem_fused_rep_kernel<32>), dim3(blocks), dim3(256), shb, s, a, S, Uv, Bv, fdone, par, d);
+                else hipLaunchKernelGGL((oem_fused_rep_kernel<64>), dim3(blocks), dim3(256), shb, s, a, S, Uv, Bv, fdone, par, d);
+            }
+        };
+        const int FB = 128;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            enq(FB);
+            if (hipStreamEndCapture(s, &graph) != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+                if (graph) (void)hipGraphDestroy(graph);
+                graph = nullptr; exec = nullptr;
+                (void)hipGetLastError();
+            }
+        } else (void)hipGetLastError();
+        const long long max_it = (long long)a.npen * a.nl * ((long long)a.maxit + 3) + 8;
         long long launched = 0;
         int *hdone = reinterpret_cast<int *>(host_scratch);
         int rc = 0;

@@ -144,3 +144,49 @@ def test_fused_iteration_engine(oa, p):
     fit, ref = oa.oem(x, y, **kw), orc.fit_dense(x, y, native=True, **kw)
     assert np.array_equal(fit["niter"][0], ref["niter"][0]) and fit["niter"][0].max() == 4
     assert np.abs(fit["beta"][0] - ref["beta"][0]).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_replicated_update_fused_engine(oa):
+    """p = 512 with group penalties / accelerate / compute.loss / scale.factor: one fused kernel per iteration in which every
+    workgroup thresholds the whole vector itself.  Against the oracle and, bit for bit, against the two-kernel engine."""
+    import os
+    p = 512
+    rng = np.random.default_rng(5)
+    n = 3 * p
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 2.0 + 0.3)
+    b = np.concatenate([rng.uniform(-0.5, 0.5, 12), np.zeros(p - 12)])
+    y = x @ b + rng.normal(size=n)
+    groups = np.repeat(np.arange(1, 65), 8)
+
+    def both(f):
+        a = f()
+        os.environ["OEM_NO_FUSED"] = "1"
+        try:
+            t = f()
+        finally:
+            del os.environ["OEM_NO_FUSED"]
+        return a, t
+
+    pens = ["grp.lasso", "grp.mcp", "grp.scad", "sparse.grp.lasso", "grp.lasso.net"]
+    kw = dict(penalty=pens, groups=groups, alpha=0.7, tau=0.4, gamma=3.5, nlambda=7, tol=1e-8)
+    fit, two = both(lambda: oa.oem(x, y, **kw))
+    ref = orc.fit_dense(x, y, native=True, unique_groups=np.unique(groups), **kw)
+    for k in range(len(pens)):
+        assert np.abs(fit["beta"][k] - ref["beta"][k]).max() < 1e-9, pens[k]
+        assert np.array_equal(fit["beta"][k], two["beta"][k]) and np.array_equal(fit["niter"][k], two["niter"][k]), pens[k]
+    kw = dict(penalty=["lasso", "mcp"], accelerate=True, compute_loss=True, nlambda=7, tol=1e-8)
+    fit, two = both(lambda: oa.oem(x, y, **kw))
+    ref = orc.fit_dense(x, y, native=True, **kw)
+    for k in range(2):
+        assert np.abs(fit["beta"][k] - ref["beta"][k]).max() < 1e-9
+        assert np.allclose(fit["loss"][k], ref["loss"][k], rtol=1e-9)
+        assert np.array_equal(fit["beta"][k], two["beta"][k]) and np.array_equal(fit["niter"][k], two["niter"][k])
+        assert np.allclose(fit["loss"][k], two["loss"][k], rtol=1e-12)
+    xtx, xty = x.T @ x / n, x.T @ y / n
+    sf = np.linspace(0.5, 2.0, p)
+    fit, two = both(lambda: oa.oem_xtx(xtx, xty, penalty=["lasso", "scad"], scale_factor=sf, nlambda=7))
+    ref = orc.fit_xtx(xtx, xty, penalty=["lasso", "scad"], scale_factor=sf, nlambda=7)
+    for k in range(2):
+        assert np.abs(fit["beta"][k] - ref["beta"][k]).max() < 1e-9
+        assert np.array_equal(fit["beta"][k], two["beta"][k])
