@@ -109,25 +109,30 @@ def build(force=False, verbose=False):
     objs = []
     bdir = HERE / "_build"
     bdir.mkdir(exist_ok=True)
-    for s in SOURCES:
-        o = bdir / (s + ".o")
-        if force or _newer(CSRC / s, o) or any(_newer(d, o) for d in _deps()[len(SOURCES):]):
-            cmd = [hipcc, *FLAGS, "-c", str(CSRC / s), "-o", str(o)]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.run(cmd, check=True)
-        objs.append(str(o))
-    # ISA audit of the asm-owned-accumulator kernels
-    asm = subprocess.run([hipcc, *FLAGS, "-S", "--cuda-device-only", "-o", "-", str(CSRC / "gram.hip")],
-                         check=True, capture_output=True, text=True).stdout
-    problems = audit_gram_isa(asm)
-    if problems:
-        raise RuntimeError("gram.hip ISA audit failed:\n  " + "\n  ".join(problems[:20]))
-    asm = subprocess.run([hipcc, *FLAGS, "-S", "--cuda-device-only", "-o", "-", str(CSRC / "path_small.hip")],
-                         check=True, capture_output=True, text=True).stdout
-    problems = audit_dpp_hazards(asm)
-    if problems:
-        raise RuntimeError("path_small.hip ISA audit failed:\n  " + "\n  ".join(problems[:20]))
+    # the four objects and the two ISA listings are independent hipcc runs: do them side by side (a cold build is
+    # ~1.5 minutes of wall clock instead of ~5)
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = []
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("OEM_BUILD_JOBS", "6"))) as ex:
+        for s in SOURCES:
+            o = bdir / (s + ".o")
+            if force or _newer(CSRC / s, o) or any(_newer(d, o) for d in _deps()[len(SOURCES):]):
+                cmd = [hipcc, *FLAGS, "-c", str(CSRC / s), "-o", str(o)]
+                if verbose:
+                    print(" ".join(cmd))
+                jobs.append(ex.submit(subprocess.run, cmd, check=True))
+            objs.append(str(o))
+        # ISA audits: asm-owned accumulators (gram.hip), DPP hazards of the inline-asm FMAs (path_small.hip)
+        listing = {src: ex.submit(subprocess.run, [hipcc, *FLAGS, "-S", "--cuda-device-only", "-o", "-", str(CSRC / src)],
+                                  check=True, capture_output=True, text=True) for src in ("gram.hip", "path_small.hip")}
+        for j in jobs:
+            j.result()
+        problems = audit_gram_isa(listing["gram.hip"].result().stdout)
+        if problems:
+            raise RuntimeError("gram.hip ISA audit failed:\n  " + "\n  ".join(problems[:20]))
+        problems = audit_dpp_hazards(listing["path_small.hip"].result().stdout)
+        if problems:
+            raise RuntimeError("path_small.hip ISA audit failed:\n  " + "\n  ".join(problems[:20]))
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(OUT), *objs], check=True)
     return OUT
 
