@@ -20,6 +20,7 @@
 // The eigenvalue step is an m-step Lanczos recurrence on the same register-resident matrix (no
 // re-orthogonalisation: the top Ritz value still converges to lambda_max, Paige), followed by a 64-way
 // multisection of the tridiagonal Sturm count, all redundantly per wave.
+#include <cstdlib>
 #include "common.hpp"
 #include "penalty_ops.hpp"
 
@@ -956,11 +957,12 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
 // words and DPP butterflies (fixed order, identical in every lane).
 // ================================================================================================
 template <int CTRL> __device__ __forceinline__ double dpp_xchg(double v) { return dpp_mov<CTRL, 0xf>(v, 0.0); }
-// lane l holds the word of wave l mod 4: sum over aligned groups of 4 lanes, every lane gets the total
-__device__ __forceinline__ double quad_sum(double v)
+// lane l holds the word of wave l mod NW (NW = 4 or 8): sum over aligned groups of NW lanes, every lane gets the total
+template <int NW> __device__ __forceinline__ double lanes_sum(double v)
 {
     v += dpp_xchg<0xB1>(v);      // quad_perm [1,0,3,2]
     v += dpp_xchg<0x4E>(v);      // quad_perm [2,3,0,1]
+    if (NW == 8) v += dpp_xchg<0x141>(v);     // row_half_mirror
     return v;
 }
 // sum of a per-row value over the wave's rows (row groups 0, 1; groups 2, 3 hold replicas; padding lanes hold 0):
@@ -1020,10 +1022,36 @@ template <int CG, int C> struct GroupFma {
     }
 };
 
-template <int CG> struct RowsCfg {
-    static constexpr int NW = 4;
-    static constexpr int NBC = (CG + 15) / 16;
-    static constexpr int VS = 256;                        // vector words per buffer: 128 rows + one dummy word per lane
+// CG columns of the lane's slice sit in registers, CGL more in LDS (one word per lane and coefficient, read back in the
+// shadow of the exchange): at two waves per SIMD a wave has 256 VGPRs, a[2][44] is what fits next to the rest.
+// The LDS-resident columns are streamed two at a time (four coefficients per lane), the next pair in flight while the
+// current one is multiplied: all of them in registers at once is exactly the pressure that put them in LDS.
+template <int CG, int CGL, int NWT, int J> struct LdsFma {
+    template <int NBC>
+    static __device__ __forceinline__ void run(double (&acc)[2][2], const double (&B)[NBC], const double *aL, double (&t)[2][2])
+    {
+        if constexpr (2 * J < CGL) {
+            double u[2][2];
+            if constexpr (2 * (J + 1) < CGL) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) u[c][r] = aL[(2 * (2 * (J + 1) + c) + r) * NWT];
+            }
+            constexpr int C0 = CG + 2 * J, C1 = C0 + 1;
+            BcFma<(C0 & 15)>::fmac(acc[0][C0 & 1], B[C0 >> 4], t[0][0]);
+            BcFma<(C0 & 15)>::fmac(acc[1][C0 & 1], B[C0 >> 4], t[0][1]);
+            BcFma<(C1 & 15)>::fmac(acc[0][C1 & 1], B[C1 >> 4], t[1][0]);
+            BcFma<(C1 & 15)>::fmac(acc[1][C1 & 1], B[C1 >> 4], t[1][1]);
+            if constexpr (2 * (J + 1) < CGL) LdsFma<CG, CGL, NWT, J + 1>::run(acc, B, aL, u);
+        }
+    }
+};
+
+template <int NW_, int CG, int CGL> struct RowsCfg {
+    static constexpr int NW = NW_;
+    static constexpr int NBC = (CG + CGL + 15) / 16;
+    static constexpr int VS = 64 * NW;                    // vector words per buffer: 32 NW rows + one dummy word per lane
     static constexpr int ML = 128;
     // LDS carve (doubles)
     static constexpr int OFF_V = 0;                       // exchanged vector [2][VS]
@@ -1034,8 +1062,9 @@ template <int CG> struct RowsCfg {
     static constexpr int OFF_S = OFF_T + 2 * ML;          // Sturm scratch 2 (ML + 8)
     static constexpr int OFF_TH = OFF_S + 2 * (ML + 8);   // theta slot
     static constexpr int LCH = 1024;                      // lambdas staged in LDS at a time
-    static constexpr int OFF_L = OFF_TH + 2 + 256;        // (+ one scratch word per lane before it)
-    static constexpr int N_DBL = OFF_L + LCH;
+    static constexpr int OFF_L = OFF_TH + 2 + 64 * NW;    // (+ one scratch word per lane before it)
+    static constexpr int OFF_A = OFF_L + LCH;             // LDS-resident matrix columns [CGL][2][NW * 64]
+    static constexpr int N_DBL = OFF_A + 2 * CGL * NW * 64;
 };
 
 struct RowsLds {
@@ -1047,15 +1076,24 @@ struct RowsLds {
 // row group's column slice and returns (M vec)[own row].  flag / aux as in gemv_sliced.
 // NORM (Lanczos): aux carries this wave's share of || vec ||^2; the gathered entries are divided by the norm before
 // the product, so the result is M (vec / || vec ||); aux returns the norm and scale its reciprocal.
-template <int CG, bool FLAGS, bool USE_AUX, bool NORM = false>
-__device__ __forceinline__ double gemv_rows(const double (&a)[2][CG], double mine, int wslot, const int (&ecol)[(CG + 15) / 16],
+template <int NW, int CG, int CGL, bool FLAGS, bool USE_AUX, bool NORM = false>
+__device__ __forceinline__ double gemv_rows(const double (&a)[2][CG], const double *aL, double mine, int wslot,
+                                            const int (&ecol)[(CG + CGL + 15) / 16],
                                             bool moving, bool &any, double &aux, const RowsLds &S, int w, int lane, int &buf,
                                             double *scale OEM_DIAG_ARGS)
 {
-    constexpr int NBC = (CG + 15) / 16, VS = RowsCfg<CG>::VS, NW = 4;
+    constexpr int NBC = (CG + CGL + 15) / 16, VS = RowsCfg<NW, CG, CGL>::VS;
     const int b = __builtin_amdgcn_readfirstlane(buf);              // provably uniform: addresses stay scalar + immediate
     const int any_mine = FLAGS ? ((__ballot(moving) != 0ull) ? 1 : 0) : 0;
     OEM_STAMP(0);                       // threshold, stop rule, loop control since the previous round
+    static_assert(CGL % 2 == 0, "LDS-resident columns are streamed in pairs");
+    double tl[2][2];                    // first pair of LDS-resident coefficients [column][row slot]: independent of the
+    if (CGL > 0) {                      // vector, so it is fetched before the barrier and lands in its shadow
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) tl[c][r] = aL[(2 * c + r) * NW * 64];
+    }
     S.V[b * VS + wslot] = mine;
     if (FLAGS) S.F[(b * NW + w) * 64 + lane] = any_mine;
     if (USE_AUX) S.XA[(b * NW + w) * 64 + lane] = aux;
@@ -1072,7 +1110,7 @@ __device__ __forceinline__ double gemv_rows(const double (&a)[2][CG], double min
     OEM_STAMP(2);                       // reads (the stamp waits for them)
     if (NORM) {
         double nb, ib;
-        sqrt_rsqrt(quad_sum(xa), nb, ib);
+        sqrt_rsqrt(lanes_sum<NW>(xa), nb, ib);
 #pragma unroll
         for (int j = 0; j < NBC; ++j) B[j] *= ib;
         aux = nb; *scale = ib;
@@ -1080,9 +1118,10 @@ __device__ __forceinline__ double gemv_rows(const double (&a)[2][CG], double min
     double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
     dpp_hazard_fence(B);                                        // VALU write of B -> DPP read: 2 wait states
     GroupFma<CG, 0>::run(acc, B, a);
+    LdsFma<CG, CGL, NW * 64, 0>::run(acc, B, aL, tl);
     OEM_STAMP(3);                       // FMAs issued
     const double out = rowgroup_reduce_scatter(acc[0][0] + acc[0][1], acc[1][0] + acc[1][1]);
-    if (USE_AUX && !NORM) aux = quad_sum(xa);
+    if (USE_AUX && !NORM) aux = lanes_sum<NW>(xa);
     any = FLAGS ? __any(f != 0) : false;
     buf = b ^ 1;
 #ifdef OEM_PATH_DIAG
@@ -1093,21 +1132,23 @@ __device__ __forceinline__ double gemv_rows(const double (&a)[2][CG], double min
 }
 
 // sum over the waves of a per-wave value that every lane of the wave holds; own barrier, double-buffered by `par`
+template <int NW>
 __device__ __forceinline__ double waves_sum(double v, double *X, int &par, int w, int lane)
 {
     const int b = __builtin_amdgcn_readfirstlane(par);
-    X[(b * 4 + w) * 64 + lane] = v;
+    X[(b * NW + w) * 64 + lane] = v;
     __syncthreads();
-    const double x = X[(b * 4 + (lane & 3)) * 64 + lane];
+    const double x = X[(b * NW + (lane & (NW - 1))) * 64 + lane];
     par = b ^ 1;
-    return quad_sum(x);
+    return lanes_sum<NW>(x);
 }
 
 // ACC (the accelerate option) is a template parameter: as a run-time test it costs two taken scalar branches per round
 // on a chain where a fetch redirect is ~50 cycles.
-template <int CG, int KIND, bool ACC>
-__device__ __forceinline__ void iterate_rows_t(const PathArgs &A, const PenK &K, const ThrK &c, const double (&a)[2][CG], double xy,
-                                               double pf, int wslot, const int (&ecol)[(CG + 15) / 16],
+template <int NW, int CG, int CGL, int KIND, bool ACC>
+__device__ __forceinline__ void iterate_rows_t(const PathArgs &A, const PenK &K, const ThrK &c, const double (&a)[2][CG],
+                                               const double *aL, double xy, double pf, int wslot,
+                                               const int (&ecol)[(CG + CGL + 15) / 16],
                                                double &beta, double &ab, double &ak, int &it, int &conv, const RowsLds &S,
                                                int w, int lane, int &buf OEM_DIAG_ARGS)
 {
@@ -1132,7 +1173,7 @@ __device__ __forceinline__ void iterate_rows_t(const PathArgs &A, const PenK &K,
         const bool cn = cu > 1e-13, qn = q > 1e-13;
         const bool moving = (cn != qn) || (cn && qn && fabs(beta - bold) > tol * q);
         bool any;
-        ab = gemv_rows<CG, true, ACC>(a, beta, wslot, ecol, moving, any, aux, S, w, lane, buf, nullptr OEM_DIAG_PASS);
+        ab = gemv_rows<NW, CG, CGL, true, ACC>(a, aL, beta, wslot, ecol, moving, any, aux, S, w, lane, buf, nullptr OEM_DIAG_PASS);
         if (ACC && aux > 0.0) ak = 1.0;
         conv = !any;
         return conv || it >= maxit;
@@ -1143,11 +1184,11 @@ __device__ __forceinline__ void iterate_rows_t(const PathArgs &A, const PenK &K,
         if (round()) break;
     }
 }
-template <int CG>
-__global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
+template <int NW, int CG, int CGL>
+__global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A)
 {
-    typedef RowsCfg<CG> C;
-    constexpr int NBC = C::NBC, NW = 4;
+    typedef RowsCfg<NW, CG, CGL> C;
+    constexpr int NBC = C::NBC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l16 = lane & 15, g = lane >> 4;
     const int p = A.p;
@@ -1157,18 +1198,18 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
     S.F = reinterpret_cast<int *>(lds + C::OFF_F);
     double *Tal = lds + C::OFF_T, *Tbe = Tal + C::ML, *LAM = lds + C::OFF_L;
 
-    const int RWp = (p + 3) / 4, CGp = (p + 3) / 4;                 // rows per wave, columns per row group
+    const int RWp = (p + NW - 1) / NW, CGp = (p + 3) / 4;           // rows per wave, columns per row group
     // this lane's row after the reduce-scatter: slot g & 1 of the wave's rows; groups 2, 3 replicate groups 0, 1
     const int rloc = 16 * (g & 1) + l16;
     const bool rowok = rloc < RWp && w * RWp + rloc < p;
     const int row = rowok ? w * RWp + rloc : 0;
     const bool owner = rowok && g < 2;
-    const int wslot = owner ? row : 128 + lane;                     // replicas and padding lanes store a word of their own
+    const int wslot = owner ? row : 32 * NW + lane;                 // replicas and padding lanes store a word of their own
     int ecol[NBC];
 #pragma unroll
     for (int j = 0; j < NBC; ++j) {
         const int loc = 16 * j + l16, col = g * CGp + loc;
-        ecol[j] = (loc < CGp && col < p) ? col : 128 + lane;        // own dummy word: finite, meets zero columns only
+        ecol[j] = (loc < CGp && col < p) ? col : 32 * NW + lane;    // own dummy word: finite, meets zero columns only
     }
     double a[2][CG];
 #pragma unroll
@@ -1179,6 +1220,17 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
         for (int k = 0; k < CG; ++k) {
             const int col = g * CGp + k;
             a[r][k] = (rok && k < CGp && col < p) ? A.xx[(size_t)col * p + grow] : 0.0;
+        }
+    }
+    double *aL = lds + C::OFF_A + tid;                               // [k][r] at (2 k + r) * NW * 64: conflict-free, lane-private
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int lr = 16 * r + l16, grow = w * RWp + lr;
+        const bool rok = lr < RWp && grow < p;
+#pragma unroll
+        for (int k = 0; k < CGL; ++k) {
+            const int col = g * CGp + CG + k;
+            aL[(2 * k + r) * NW * 64] = (rok && CG + k < CGp && col < p) ? A.xx[(size_t)col * p + grow] : 0.0;
         }
     }
     const double xy = rowok ? A.xy[row] : 0.0, pf = rowok ? A.pf[row] : 0.0;
@@ -1219,7 +1271,7 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
     for (int j = 0; j < msteps; ++j) {
         // one exchange carries the unnormalised vector AND the per-wave shares of its squared norm
         double nb = rows_sum(wn * wn), ib = 0.0;
-        const double wv = gemv_rows<CG, false, true, true>(a, wn, wslot, ecol, false, any_unused, nb, S, w, lane, buf, &ib OEM_DIAG_PASS);
+        const double wv = gemv_rows<NW, CG, CGL, false, true, true>(a, aL, wn, wslot, ecol, false, any_unused, nb, S, w, lane, buf, &ib OEM_DIAG_PASS);
         if (j > 0) {
             bb = nb;
             *(tid == 0 ? &Tbe[j - 1] : tsink) = bb;
@@ -1233,7 +1285,7 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
             }
         }
         vp = v; v = wn * ib;
-        const double al = waves_sum(rows_sum(v * wv), S.XN, par, w, lane);   // XN: gemv_rows' exchange owns XA
+        const double al = waves_sum<NW>(rows_sum(v * wv), S.XN, par, w, lane);   // XN: gemv_rows' exchange owns XA
         *(tid == 0 ? &Tal[j] : tsink) = al;                          // read by wave 0 only (top_ritz)
         al_prev = al;
         nst = j + 1;
@@ -1259,6 +1311,11 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
         for (int k = 0; k < CG; ++k) {
             const int col = g * CGp + k;
             a[r][k] = ((rok && k < CGp && col == grow) ? d : 0.0) - a[r][k];
+        }
+#pragma unroll
+        for (int k = 0; k < CGL; ++k) {
+            const int col = g * CGp + CG + k;
+            aL[(2 * k + r) * NW * 64] = ((rok && CG + k < CGp && col == grow) ? d : 0.0) - aL[(2 * k + r) * NW * 64];
         }
     }
 
@@ -1329,18 +1386,18 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
                 const PenK K = pen_from_linear(PL, il, d, A.gamma);
                 if (__builtin_expect(ridge, 0)) c = thr_consts<KIND>(K, d);
                 int it = 0, conv = 0;
-                iterate_rows_t<CG, KIND, ACC>(A, K, c, a, xy, pf, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf OEM_DIAG_PASS);
+                iterate_rows_t<NW, CG, CGL, KIND, ACC>(A, K, c, a, aL, xy, pf, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf OEM_DIAG_PASS);
                 // oemXTX::get_beta rescales the member in place (ref src/oem_xtx.h:576-581, quirk Q5)
                 if (__builtin_expect(A.sinv != nullptr, 0)) beta *= sinv;
                 *(owner ? &A.beta[orow * p + row] : sinkd) = beta;
                 *(t0 ? &A.niter[orow] : sinki) = conv ? it : A.maxit + 1; // ref src/oem_base.h:94-109
                 if (__builtin_expect(A.sinv != nullptr, 0))
-                    ab = gemv_rows<CG, false, false>(a, beta, wslot, ecol, false, any_unused, aux_unused, S, w, lane, buf, nullptr OEM_DIAG_PASS);
+                    ab = gemv_rows<NW, CG, CGL, false, false>(a, aL, beta, wslot, ecol, false, any_unused, aux_unused, S, w, lane, buf, nullptr OEM_DIAG_PASS);
                 double lossv = 1e99;
                 if (__builtin_expect(A.compute_loss != 0, 0)) {
                     // sum (Y - X beta)^2 through the Gram identity (ref src/oem_dense.h:759-770):
                     // yy - 2 n beta'XY + n beta' XX beta, with XX beta = d beta - A beta
-                    lossv = yy + nobs * waves_sum(rows_sum(beta * ((d * beta - ab) - 2.0 * xy)), S.XN, par, w, lane);
+                    lossv = yy + nobs * waves_sum<NW>(rows_sum(beta * ((d * beta - ab) - 2.0 * xy)), S.XN, par, w, lane);
                 }
                 *(t0 ? &A.loss[orow] : sinkd + 256) = lossv;
             }
@@ -1376,10 +1433,12 @@ __global__ __launch_bounds__(256) void path_rows_kernel(PathArgs A)
     }
 }
 
-template <int CG> int launch_rows(hipStream_t s, const PathArgs &a)
+template <int NW, int CG, int CGL = 0> int launch_rows(hipStream_t s, const PathArgs &a)
 {
-    const size_t sh = (size_t)RowsCfg<CG>::N_DBL * sizeof(double);
-    hipLaunchKernelGGL((path_rows_kernel<CG>), dim3(1), dim3(256), sh, s, a);
+    const size_t sh = (size_t)RowsCfg<NW, CG, CGL>::N_DBL * sizeof(double);
+    if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_rows_kernel<NW, CG, CGL>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL((path_rows_kernel<NW, CG, CGL>), dim3(1), dim3(NW * 64), sh, s, a);
     OEM_HIP(hipGetLastError());
     return 0;
 }
@@ -1410,11 +1469,17 @@ extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read(unsigned 
 
 int launch_path_small(hipStream_t s, const PathArgs &a)
 {
-    // element-wise penalties, 64 < p <= 128: the row-split form (beta all-gather, permlane reduce-scatter)
-    if (a.ngroups == 0 && a.p > 64 && a.p <= 128) {
-        if (a.p <= 80) return launch_rows<20>(s, a);
-        if (a.p <= 104) return launch_rows<26>(s, a);
-        return launch_rows<32>(s, a);
+    // element-wise penalties, 64 < p <= 208: the row-split form (beta all-gather, permlane reduce-scatter); four waves
+    // up to p = 128, eight (two per SIMD, 256 VGPRs each: a[2][CG] must leave room) beyond
+    if (a.ngroups == 0 && a.p > 64 && a.p <= 208 && !(a.p > 128 && getenv("OEM_NO_ROWS8"))) {
+        if (a.p <= 80) return launch_rows<4, 20>(s, a);
+        if (a.p <= 104) return launch_rows<4, 26>(s, a);
+        if (a.p <= 128) return launch_rows<4, 32>(s, a);
+        if (a.p <= 160) return launch_rows<8, 40>(s, a);
+        // a[2][44] = 176 of the 256 VGPRs a wave has at two waves per SIMD (46+ spills into the loop); the slice's
+        // remaining columns live in LDS (config 2: p = 200 -> 6 of 50 columns)
+        if (a.p <= 176) return launch_rows<8, 44>(s, a);
+        return launch_rows<8, 44, 8>(s, a);
     }
     // 4 waves (one per SIMD), CW = columns per wave rounded up to an even count: all CW/2 broadcast reads fit in
     // registers next to the matrix slice, so a round exposes the LDS latency once.
