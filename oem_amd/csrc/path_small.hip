@@ -1469,9 +1469,11 @@ extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read(unsigned 
 
 int launch_path_small(hipStream_t s, const PathArgs &a)
 {
-    // element-wise penalties, 64 < p <= 208: the row-split form (beta all-gather, permlane reduce-scatter); four waves
+    // element-wise penalties, p <= 208: the row-split form (beta all-gather, permlane reduce-scatter); four waves
     // up to p = 128, eight (two per SIMD, 256 VGPRs each: a[2][CG] must leave room) beyond
-    if (a.ngroups == 0 && a.p > 64 && a.p <= 208 && !(a.p > 128 && getenv("OEM_NO_ROWS8"))) {
+    if (a.ngroups == 0 && a.p <= 208 && !(a.p > 128 && getenv("OEM_NO_ROWS8"))) {
+        if (a.p <= 32) return launch_rows<4, 8>(s, a);
+        if (a.p <= 64) return launch_rows<4, 16>(s, a);
         if (a.p <= 80) return launch_rows<4, 20>(s, a);
         if (a.p <= 104) return launch_rows<4, 26>(s, a);
         if (a.p <= 128) return launch_rows<4, 32>(s, a);

@@ -107,6 +107,19 @@ def test_group_penalties(oa):
     _cmp(fit, ref)
 
 
+@pytest.mark.parametrize("p", [40, 96, 150, 230])
+def test_mixed_group_and_elementwise_penalties(oa, p):
+    """a call with group AND element-wise penalties stays in the replicated-vector kernel, whose element-wise
+    operators take the sliced form (p <= 192) or the four-workgroup form"""
+    x, y = _data(3 * p + 300, p, 300 + p)
+    groups = np.arange(p) // 5 + 1
+    pens = ["lasso", "grp.lasso", "mcp", "grp.scad", "ols"]
+    kw = dict(penalty=pens, groups=groups, gamma=3.5, nlambda=9, tol=1e-9)
+    fit = oa.oem(x, y, **kw)
+    ref = orc.fit_dense(x, y, unique_groups=np.unique(groups), **kw)
+    _cmp(fit, ref)
+
+
 def test_user_lambda_penalty_factor_accelerate_maxit(oa):
     x, y = _data(2500, 30, 9)
     pf = np.linspace(0.0, 2.0, 30)
