@@ -516,7 +516,9 @@ struct GState {
     double ak;
 };
 
-template <int VPL>
+// FULL: q == 64 VPL and 16-byte aligned rows (no bounds logic); otherwise any q <= 64 VPL: columns past q read a clamped
+// address and meet a zero vector entry (branch-free, as in gemv_sym_kernel).
+template <int VPL, bool FULL>
 __global__ __launch_bounds__(256) void oem_fused_rep_kernel(PathArgs A, GState *__restrict__ S, double *__restrict__ Ubuf,
                                                              double *__restrict__ Bbuf, int *__restrict__ fdone, int par, double d)
 {
@@ -648,17 +650,30 @@ __global__ __launch_bounds__(256) void oem_fused_rep_kernel(PathArgs A, GState *
     if (done_now) return;
     // ---- g = XX beta for this workgroup's rows, u' = d beta - g + XY
     v2d v[VPL / 2];
+    int c0[FULL ? 1 : VPL / 2], c1[FULL ? 1 : VPL / 2];
 #pragma unroll
-    for (int j = 0; j < VPL / 2; ++j) v[j] = *reinterpret_cast<const v2d *>(Bsh + 2 * lane + 128 * j);
+    for (int j = 0; j < VPL / 2; ++j) {
+        const int c = 2 * lane + 128 * j;
+        if (FULL) v[j] = *reinterpret_cast<const v2d *>(Bsh + c);
+        else {
+            c0[j] = c < q ? c : q - 1; c1[j] = c + 1 < q ? c + 1 : q - 1;
+            v[j].x = c < q ? Bsh[c0[j]] : 0.0; v[j].y = c + 1 < q ? Bsh[c1[j]] : 0.0;
+        }
+    }
     for (int r = wave; r < q; r += nwave) {
         const double br = Bsh[r], xyr = A.xy[r];
         const double *row = A.xx + (size_t)r * q;
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int j = 0; j < VPL / 2; ++j) {
-            const v2d t = *reinterpret_cast<const v2d *>(row + 2 * lane + 128 * j);
-            a0 = fma(t.x, v[j].x, a0);
-            a1 = fma(t.y, v[j].y, a1);
+            if (FULL) {
+                const v2d t = *reinterpret_cast<const v2d *>(row + 2 * lane + 128 * j);
+                a0 = fma(t.x, v[j].x, a0);
+                a1 = fma(t.y, v[j].y, a1);
+            } else {
+                a0 = fma(row[c0[j]], v[j].x, a0);
+                a1 = fma(row[c1[j]], v[j].y, a1);
+            }
         }
         const double g = wsum(a0 + a1);
         if (lane == 0) uout[r] = (d * br - g) + xyr;
@@ -782,7 +797,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     }
 
     // ---- replicated-update fused engine: everything else at the same sizes
-    const bool rep_ok = (q == 512 || q == 1024 || q == 2048 || q == 4096) && (((uintptr_t)a.xx) & 15) == 0 && !getenv("OEM_NO_FUSED");
+    const bool rep_ok = q <= 4096 && !getenv("OEM_NO_FUSED");
     if (rep_ok) {
         double *fbase = T + 2 * MAXL + 64;
         int *fdone = reinterpret_cast<int *>(fbase + 8);
@@ -793,20 +808,17 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         int blocks = (q + 3) / 4;
         if (blocks > num_cu * 2) blocks = num_cu * 2;
         const size_t shb = sizeof(double) * (size_t)(2 * q + (a.ngroups > 0 ? a.ngroups : 0) + 8);
-#define OEM_REP_ATTR(V)                                                                                                      \
-    if (shb > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&oem_fused_rep_kernel<V>),                \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
-        if (q == 512) { OEM_REP_ATTR(8) } else if (q == 1024) { OEM_REP_ATTR(16) } else if (q == 2048) { OEM_REP_ATTR(32) } else { OEM_REP_ATTR(64) }
-#undef OEM_REP_ATTR
+        const bool full = (q == 512 || q == 1024 || q == 2048 || q == 4096) && (((uintptr_t)a.xx) & 15) == 0;
+        // kernel for this q: VPL = 8, 16, 32 or 64 columns per lane
+        void (*kern)(PathArgs, GState *, double *, double *, int *, int, double);
+        if (q <= 512) kern = full ? oem_fused_rep_kernel<8, true> : oem_fused_rep_kernel<8, false>;
+        else if (q <= 1024) kern = full ? oem_fused_rep_kernel<16, true> : oem_fused_rep_kernel<16, false>;
+        else if (q <= 2048) kern = full ? oem_fused_rep_kernel<32, true> : oem_fused_rep_kernel<32, false>;
+        else kern = full ? oem_fused_rep_kernel<64, true> : oem_fused_rep_kernel<64, false>;
+        if (shb > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
         hipLaunchKernelGGL(fused_rep_init_kernel, dim3(1), dim3(1), 0, s, S, a.npen);
         auto enq = [&](int count) {
-            for (int k = 0; k < count; ++k) {
-                const int par = k & 1;
-                if (q == 512) hipLaunchKernelGGL((oem_fused_rep_kernel<8>), dim3(blocks), dim3(256), shb, s, a, S, Uv, Bv, fdone, par, d);
-                else if (q == 1024) hipLaunchKernelGGL((oem_fused_rep_kernel<16>), dim3(blocks), dim3(256), shb, s, a, S, Uv, Bv, fdone, par, d);
-                else if (q == 2048) hipLaunchKernelGGL((oem_fused_rep_kernel<32>), dim3(blocks), dim3(256), shb, s, a, S, Uv, Bv, fdone, par, d);
-                else hipLaunchKernelGGL((oem_fused_rep_kernel<64>), dim3(blocks), dim3(256), shb, s, a, S, Uv, Bv, fdone, par, d);
-            }
+            for (int k = 0; k < count; ++k) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shb, s, a, S, Uv, Bv, fdone, k & 1, d);
         };
         const int FB = 128;
         hipGraph_t graph = nullptr;

@@ -147,17 +147,18 @@ def test_fused_iteration_engine(oa, p):
 
 
 @pytest.mark.gpu
-def test_replicated_update_fused_engine(oa):
-    """p = 512 with group penalties / accelerate / compute.loss / scale.factor: one fused kernel per iteration in which every
-    workgroup thresholds the whole vector itself.  Against the oracle and, bit for bit, against the two-kernel engine."""
+@pytest.mark.parametrize("p", [512, 300, 257])
+def test_replicated_update_fused_engine(oa, p):
+    """p > 256 with group penalties / accelerate / compute.loss / scale.factor (and any p that is not 512 / 1024 / 2048 / 4096):
+    one fused kernel per iteration in which every workgroup thresholds the whole vector itself.  Against the oracle and,
+    bit for bit, against the two-kernel engine."""
     import os
-    p = 512
     rng = np.random.default_rng(5)
     n = 3 * p
     x = np.asfortranarray(rng.normal(size=(n, p)) * 2.0 + 0.3)
     b = np.concatenate([rng.uniform(-0.5, 0.5, 12), np.zeros(p - 12)])
     y = x @ b + rng.normal(size=n)
-    groups = np.repeat(np.arange(1, 65), 8)
+    groups = np.arange(p) // 8 + 1
 
     def both(f):
         a = f()
