@@ -120,6 +120,17 @@ def test_mixed_group_and_elementwise_penalties(oa, p):
     _cmp(fit, ref)
 
 
+@pytest.mark.parametrize("p", [32, 33, 64, 65, 80, 81, 104, 105, 128, 129, 160, 161, 176, 177, 208, 209, 256, 257, 260])
+def test_path_kernel_size_boundaries(oa, p):
+    """both sides of every size at which another path kernel / configuration takes over"""
+    x, y = _data(2 * p + 400, p, 500 + p, mean=0.4)
+    kw = dict(penalty=["lasso", "scad"], nlambda=8, tol=1e-9)
+    f, r = oa.oem(x, y, **kw), orc.fit_dense(x, y, **kw)
+    _cmp(f, r)
+    n = x.shape[0]
+    _cmp(oa.oem_xtx(x.T @ x / n, x.T @ y / n, penalty=["mcp"], nlambda=6), orc.fit_xtx(x.T @ x / n, x.T @ y / n, penalty=["mcp"], nlambda=6))
+
+
 def test_user_lambda_penalty_factor_accelerate_maxit(oa):
     x, y = _data(2500, 30, 9)
     pf = np.linspace(0.0, 2.0, 30)
