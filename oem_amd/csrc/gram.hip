@@ -186,15 +186,8 @@ template <int NF, int PENDING> __device__ __forceinline__ void wait_slab(Slab<NF
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// LDS-DMA (global_load_lds_dwordx4): 64 lanes x 16 B land at (wave-uniform LDS address) + 16 lane, with no VGPR
-// destination, so prefetch depth is bounded by LDS, not by registers.  M0 carries the LDS address; it is
-// compiler-reserved and not preserved around asm, so it is saved, set and restored inside the one statement.
-template <int OFF> __device__ __forceinline__ void glds16(gptr_t src, unsigned lds_byte_addr)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds_byte_addr), "i"(OFF * 8) : "memory");
-}
+// LDS-DMA (global_load_lds_dwordx4): 64 lanes x 16 B land at (wave-uniform LDS address in M0) + 16 lane, with no VGPR
+// destination, so prefetch depth is bounded by LDS, not by registers.
 // Steady-state form: M0 is set ONCE per slab and the seven fragments are told apart by the instruction offset, which
 // (tools/ldsdma_offset_probe.hip) moves the global address AND the LDS destination by the same number of bytes -- so
 // the source pointer is pre-decremented by it.  The M0 save / set / restore dance per DMA cost 12 cycles each.
