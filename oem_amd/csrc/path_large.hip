@@ -193,6 +193,86 @@ __device__ __forceinline__ void lanczos_update(int q, int j, double *__restrict_
     }
 }
 
+// Fused Lanczos step (q <= 4096): one launch per step.  Launch j receives w = M v_j from its predecessor; EVERY workgroup
+// forms alpha_j, w - alpha v - beta v_prev, beta_j and v_{j+1} itself (identical everywhere: two block reductions over q
+// numbers), then streams its rows of M against v_{j+1}; workgroup 0 leaves v_{j+1}, v_j and T[j] behind.  Same arithmetic
+// and the same breakdown rule as lanczos_update.
+template <int VPL, bool FULL>
+__global__ __launch_bounds__(256) void lanczos_fused_kernel(const double *__restrict__ M, int q, int j, double *__restrict__ Vc,
+                                                             double *__restrict__ Vp, double *__restrict__ Wb,
+                                                             double *__restrict__ T, int par)
+{
+    extern __shared__ __attribute__((aligned(16))) double dyn[];     // v_{j+1} [q]
+    __shared__ double sh[16];
+    const int tid = threadIdx.x, nt = 256, lane = tid & 63;
+    const int wave = blockIdx.x * 4 + (tid >> 6), nwave = gridDim.x * 4;
+    const bool b0 = blockIdx.x == 0;
+    double *al = T, *be = T + MAXL;
+    const double *__restrict__ v = Vc + (size_t)par * (q + 8), *__restrict__ vp = Vp + (size_t)par * (q + 8);
+    const double *__restrict__ w = Wb + (size_t)par * (q + 8);
+    double *__restrict__ vn = Vc + (size_t)(par ^ 1) * (q + 8), *__restrict__ vpn = Vp + (size_t)(par ^ 1) * (q + 8);
+    double *__restrict__ wn = Wb + (size_t)(par ^ 1) * (q + 8);
+    const bool broken = j > 0 && !(be[j - 1] > 1e-13 * fabs(al[j - 1]));     // invariant subspace already reached
+    if (broken) {
+        if (b0) {
+            if (tid == 0) { al[j] = al[j - 1]; be[j] = 0.0; }
+            for (int k = tid; k < q; k += nt) { vn[k] = v[k]; vpn[k] = vp[k]; wn[k] = w[k]; }
+        }
+        return;
+    }
+    const double bprev = j > 0 ? be[j - 1] : 0.0;
+    double a = 0.0;
+    for (int k = tid; k < q; k += nt) a = fma(v[k], w[k], a);
+    a = block_sum(a, sh);
+    double bb = 0.0;
+    for (int k = tid; k < q; k += nt) {
+        const double t = (w[k] - a * v[k]) - bprev * vp[k];
+        dyn[k] = t;
+        bb = fma(t, t, bb);
+    }
+    bb = sqrt(block_sum(bb, sh));
+    if (b0 && tid == 0) { al[j] = a; be[j] = bb; }
+    if (!(bb > 1e-13 * fabs(a))) {                                  // breakdown now: T is exact, the vectors stay
+        if (b0) for (int k = tid; k < q; k += nt) { vn[k] = v[k]; vpn[k] = vp[k]; wn[k] = w[k]; }
+        return;
+    }
+    const double ib = 1.0 / bb;
+    for (int k = tid; k < q; k += nt) {
+        const double x = dyn[k] * ib;
+        dyn[k] = x;
+        if (b0) { vn[k] = x; vpn[k] = v[k]; }
+    }
+    __syncthreads();
+    v2d vv[VPL / 2];
+    int c0[FULL ? 1 : VPL / 2], c1[FULL ? 1 : VPL / 2];
+#pragma unroll
+    for (int jj = 0; jj < VPL / 2; ++jj) {
+        const int c = 2 * lane + 128 * jj;
+        if (FULL) vv[jj] = *reinterpret_cast<const v2d *>(dyn + c);
+        else {
+            c0[jj] = c < q ? c : q - 1; c1[jj] = c + 1 < q ? c + 1 : q - 1;
+            vv[jj].x = c < q ? dyn[c0[jj]] : 0.0; vv[jj].y = c + 1 < q ? dyn[c1[jj]] : 0.0;
+        }
+    }
+    for (int r = wave; r < q; r += nwave) {
+        const double *row = M + (size_t)r * q;
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < VPL / 2; ++jj) {
+            if (FULL) {
+                const v2d t = *reinterpret_cast<const v2d *>(row + 2 * lane + 128 * jj);
+                a0 = fma(t.x, vv[jj].x, a0);
+                a1 = fma(t.y, vv[jj].y, a1);
+            } else {
+                a0 = fma(row[c0[jj]], vv[jj].x, a0);
+                a1 = fma(row[c1[jj]], vv[jj].y, a1);
+            }
+        }
+        const double g = wsum(a0 + a1);
+        if (lane == 0) wn[r] = g;
+    }
+}
+
 // largest eigenvalue of the tridiagonal (host): bisection on the Sturm count; returns an upper bracket end
 double tridiag_max_host(const double *al, const double *be, int m)
 {
@@ -697,7 +777,8 @@ size_t path_large_work_doubles(int p, int nsteps)
     (void)nsteps;
     // + fused engine: FState[2] (8 doubles), done word, beta[2][p+8], flags[2][FMAXB] ints
     // + replicated-update engine: GState[2] (16 doubles), u[2][p+8] (beta[2] shared with the fused engine)
-    return (size_t)STATE_DBL + 5 * (size_t)(p + 8) + 2 * MAXL + 64 + 16 + 2 * (size_t)(p + 8) + FMAXB + 16 + 2 * (size_t)(p + 8);
+    // + fused Lanczos: two copies each of v, v_prev, w
+    return (size_t)STATE_DBL + 5 * (size_t)(p + 8) + 2 * MAXL + 64 + 16 + 2 * (size_t)(p + 8) + FMAXB + 16 + 2 * (size_t)(p + 8) + 6 * (size_t)(p + 8);
 }
 
 // host_scratch: pinned host memory (>= 8 KB)
@@ -715,17 +796,39 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
 
     // ---- eigenvalue step: Lanczos (GEMV + single-workgroup vector update), checked every
     //      32 steps on the host, which is also the convergence test
-    hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, s, q, v, vp);
     const int mmax = q < MAXL ? q : MAXL;
     double theta = 0.0, theta_prev = -1.0;
     double *hT = host_scratch;
     int m = 0;
+    // fused steps (one launch each) ping-pong between two copies of (v, v_prev, w) kept in their own area
+    const bool lz_fused = q <= 4096 && !getenv("OEM_NO_FUSED");
+    const bool lz_full = (q == 512 || q == 1024 || q == 2048 || q == 4096) && (((uintptr_t)a.xx) & 15) == 0;
+    double *LZ = T + 2 * MAXL + 64 + 16 + 2 * (size_t)(q + 8) + FMAXB + 16 + 2 * (size_t)(q + 8);
+    double *Vc = LZ, *Vp = LZ + 2 * (size_t)(q + 8), *Wb = LZ + 4 * (size_t)(q + 8);
+    void (*lzk)(const double *, int, int, double *, double *, double *, double *, int) = nullptr;
+    if (lz_fused) {
+        if (q <= 512) lzk = lz_full ? lanczos_fused_kernel<8, true> : lanczos_fused_kernel<8, false>;
+        else if (q <= 1024) lzk = lz_full ? lanczos_fused_kernel<16, true> : lanczos_fused_kernel<16, false>;
+        else if (q <= 2048) lzk = lz_full ? lanczos_fused_kernel<32, true> : lanczos_fused_kernel<32, false>;
+        else lzk = lz_full ? lanczos_fused_kernel<64, true> : lanczos_fused_kernel<64, false>;
+    }
+    int lblocks = (q + 3) / 4;
+    if (lblocks > num_cu * 2) lblocks = num_cu * 2;
+    const size_t lsh = sizeof(double) * (size_t)(q + 8);
+    if (lz_fused) {
+        hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, s, q, Vc, Vp);
+        int rc = launch_gemv(s, a.xx, q, Vc, Wb, nullptr, num_cu);           // w_0 = M v_0; every later product is fused
+        if (rc) return rc;
+    } else hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, s, q, v, vp);
     while (m < mmax) {
         const int chunk = (mmax - m) < 32 ? (mmax - m) : 32;
         for (int k = 0; k < chunk; ++k, ++m) {
-            int rc = launch_gemv(s, a.xx, q, v, w, nullptr, num_cu);
-            if (rc) return rc;
-            hipLaunchKernelGGL(lanczos_update_kernel, dim3(1), dim3(1024), 0, s, q, m, v, vp, w, T);
+            if (lz_fused) hipLaunchKernelGGL(lzk, dim3(lblocks), dim3(256), lsh, s, a.xx, q, m, Vc, Vp, Wb, T, m & 1);
+            else {
+                int rc = launch_gemv(s, a.xx, q, v, w, nullptr, num_cu);
+                if (rc) return rc;
+                hipLaunchKernelGGL(lanczos_update_kernel, dim3(1), dim3(1024), 0, s, q, m, v, vp, w, T);
+            }
         }
         OEM_HIP(hipGetLastError());
         OEM_HIP(hipMemcpyAsync(hT, T, sizeof(double) * 2 * MAXL, hipMemcpyDeviceToHost, s));
