@@ -99,7 +99,7 @@ __device__ __forceinline__ double wave_max(double v)
 //     consecutive p_k) on T scaled by 1/Gershgorin, renormalised by exponent every 4 steps: one dependent FMA per
 //     step.  The pivot form q_k = (a_k - t) - b^2 / q_{k-1} costs a ~200-cycle FP64 division per step, which made this
 //     routine (9 rounds x 100 steps) a fifth of config 1's whole path kernel.
-//   * sab: LDS scratch for the scaled, interleaved coefficients (2 (m + 8) doubles).
+//   * sab: LDS scratch for the scaled, interleaved coefficients (2 (m + 16) doubles).
 //   * lo_hint: a known lower bound of the answer (the value at an earlier Lanczos step; Ritz values only grow), or
 //     -inf.  With a hint the first round places its 64 probes geometrically above it, so a nearly converged value is
 //     bracketed to a factor of two at once and two or three uniform rounds finish the job.
@@ -115,9 +115,9 @@ __device__ __forceinline__ double tridiag_max(const double *al, const double *be
     }
     lo = wave_max(lo); hi = wave_max(hi); nrm = wave_max(nrm);
     const double sc = (nrm > 0.0 && nrm < 1e300) ? 1.0 / nrm : 1.0;
-    // scaled coefficients, interleaved {a_k, b_{k-1}^2}, padded to a multiple of eight steps with identity steps
+    // scaled coefficients, interleaved {a_k, b_{k-1}^2}, padded to a multiple of sixteen steps with identity steps
     // (a_k = 2^100, b^2 = 0: p_k = 2^100 p_{k-1} keeps the sign of p_{k-1}; the renormalisation absorbs the factor)
-    const int mp = 1 + (m - 1 + 7) / 8 * 8;
+    const int mp = 1 + (m - 1 + 15) / 16 * 16;
     v2d *co = reinterpret_cast<v2d *>(sab);
     for (int j = lane; j < mp; j += 64) {
         const double b = (j > 0 && j < m) ? be[j - 1] * sc : 0.0;
@@ -139,21 +139,10 @@ __device__ __forceinline__ double tridiag_max(const double *al, const double *be
         // right: p_k = +0 gives p_{k+1} = -b^2 p_{k-1}, one change over the two steps whichever sign p_{k-1} has.
         unsigned hist = (unsigned)__double2hiint(pm1) >> 31;             // bit 0 = sign(p_1); sign(p_0) = 0
         int neg = hist;
-        // eight steps per trip; the next trip's coefficients are in flight while this one's dependent FMAs run
-        v2d c[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) c[q] = co[1 + q];
-        for (int k = 1; k < mp; k += 8) {
-            v2d dcur[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) dcur[q] = c[q];
-            if (k + 8 < mp) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) c[q] = co[k + 8 + q];
-            }
+        auto eight = [&](const v2d (&c)[8]) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const double pn = fma(dcur[q].x - t, pm1, -(dcur[q].y * pm2));
+                const double pn = fma(c[q].x - t, pm1, -(c[q].y * pm2));
                 hist = __builtin_amdgcn_alignbit(hist, (unsigned)__double2hiint(pn), 31);   // (hist << 1) | sign(pn)
                 pm2 = pm1; pm1 = pn;
             }
@@ -162,6 +151,21 @@ __device__ __forceinline__ double tridiag_max(const double *al, const double *be
             const int e1 = (__double2hiint(pm1) >> 20) & 0x7ff, e2 = (__double2hiint(pm2) >> 20) & 0x7ff;
             const int e = 1023 - (e1 > e2 ? e1 : e2);
             pm1 = ldexp(pm1, e); pm2 = ldexp(pm2, e);
+        };
+        // sixteen steps per trip on two register sets that take turns: the other set's coefficients are in flight while
+        // this one's dependent FMAs run, and nothing is copied (one taken branch per sixteen steps)
+        v2d ca[8], cb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ca[q] = co[1 + q];
+        for (int k = 1; k < mp; k += 16) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cb[q] = co[k + 8 + q];
+            eight(ca);
+            if (k + 16 < mp) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ca[q] = co[k + 16 + q];
+            }
+            eight(cb);
         }
         const int above = neg < m;                         // an eigenvalue >= th exists
         const int kk = __popcll(__ballot(above));          // monotone in the lane index
