@@ -35,6 +35,8 @@ struct oemgpu_ctx {
     size_t ws_bytes = 0;
     char *pinned = nullptr;      // pinned host staging for the results
     size_t pinned_bytes = 0;
+    char *pinned_in = nullptr;   // pinned host staging for the parameter blob (a pageable source makes the copy block the host)
+    size_t pinned_in_bytes = 0;
     bool timing = false;
     hipEvent_t ev[2 * OEMGPU_NTIMERS];
     bool ev_made = false;
@@ -59,6 +61,16 @@ int ctx_reserve(oemgpu_ctx *c, size_t bytes)
     c->ws_bytes = bytes;
     return 0;
 }
+int ctx_pinned_in(oemgpu_ctx *c, size_t bytes)
+{
+    if (bytes <= c->pinned_in_bytes) return 0;
+    if (c->pinned_in) { OEM_HIP(hipStreamSynchronize(c->stream)); OEM_HIP(hipHostFree(c->pinned_in)); c->pinned_in = nullptr; c->pinned_in_bytes = 0; }
+    bytes = (bytes + 4095) / 4096 * 4096;
+    OEM_HIP(hipHostMalloc((void **)&c->pinned_in, bytes, hipHostMallocDefault));
+    c->pinned_in_bytes = bytes;
+    return 0;
+}
+
 int ctx_pinned(oemgpu_ctx *c, size_t bytes)
 {
     if (bytes <= c->pinned_bytes) return 0;
@@ -197,7 +209,9 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     xx = (const double *)(c->ws + off_xx); xy = (const double *)(c->ws + off_xy); stats = (const double *)(c->ws + off_st);
     char *dblob = c->ws + a_blob;
     double *dout = (double *)(c->ws + a_out);
-    OEM_HIP(hipMemcpyAsync(dblob, bl.h.data(), bl.h.size(), hipMemcpyHostToDevice, c->stream));
+    if (ctx_pinned_in(c, bl.h.size())) return OEMGPU_ERR_HIP;       // the previous call ended with a stream sync: the buffer is free
+    memcpy(c->pinned_in, bl.h.data(), bl.h.size());
+    OEM_HIP(hipMemcpyAsync(dblob, c->pinned_in, bl.h.size(), hipMemcpyHostToDevice, c->stream));
     OEM_HIP(hipMemsetAsync(dout, 0, out_bytes, c->stream));
 
     PathArgs a;
@@ -347,6 +361,7 @@ void oemgpu_destroy(oemgpu_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     if (c->ws) (void)hipFree(c->ws);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pinned_in) (void)hipHostFree(c->pinned_in);
     if (c->ev_made) for (int i = 0; i < 2 * OEMGPU_NTIMERS; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
