@@ -1207,13 +1207,17 @@ int launch_gram(hipStream_t s, const GramPlan &pl, const double *x, int64_t n, i
 // partial reduction: sums the per-chunk partials in chunk order (bitwise reproducible) and scatters the
 // MFMA accumulator layout (row = (lane>>4) + 4 reg, col = lane & 15) into the q x q moment buffer.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void moments_reduce_kernel(const double *__restrict__ tpart,
-                                                              const double *__restrict__ vpart, int p, int ntc,
-                                                              int ntile, int nchunk, int aug, double *__restrict__ M)
+// A tile's chunk partials are summed by four thread groups (chunks c = g mod 4, each in ascending order, eight loads in
+// flight) and combined as (g0 + g1) + (g2 + g3): a fixed order, so the result is reproducible; with one group the
+// kernel was a 15 us latency chain of 253 dependent steps on 28 workgroups.
+__global__ __launch_bounds__(1024) void moments_reduce_kernel(const double *__restrict__ tpart,
+                                                               const double *__restrict__ vpart, int p, int ntc,
+                                                               int ntile, int nchunk, int aug, double *__restrict__ M)
 {
+    __shared__ double part[4][256];
     const int q = p + 2;
     const int lim = aug ? q : p;      // tiles cover Z = [X | y | 1] (aug) or X only
-    const int b = blockIdx.x, e = threadIdx.x;
+    const int b = blockIdx.x, e = threadIdx.x & 255, grp = threadIdx.x >> 8;
     if (b < ntile) {
         int I = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
         while (I * (I + 1) / 2 > b) --I;
@@ -1222,22 +1226,25 @@ __global__ __launch_bounds__(256) void moments_reduce_kernel(const double *__res
         double s = 0.0;
         const double *src = tpart + (size_t)b * 256 + e;
         const size_t stride = (size_t)ntile * 256;
-        int c = 0;
-        for (; c + 8 <= nchunk; c += 8) {                 // 8 independent loads in flight, summed in chunk order
+        int c = grp;
+        for (; c + 28 < nchunk; c += 32) {                // 8 independent loads in flight, summed in chunk order
             double t[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = src[(size_t)(c + k) * stride];
+            for (int k = 0; k < 8; ++k) t[k] = src[(size_t)(c + 4 * k) * stride];
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += t[k];
         }
-        for (; c < nchunk; ++c) s += src[(size_t)c * stride];
+        for (; c < nchunk; c += 4) s += src[(size_t)c * stride];
+        part[grp][e] = s;
+        __syncthreads();
+        s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
         const int reg = e >> 6, lane = e & 63;
         const int row = 16 * I + (lane >> 4) + 4 * reg, col = 16 * J + (lane & 15);
-        if (row < lim && col < lim && row >= col) {
+        if (grp == 0 && row < lim && col < lim && row >= col) {
             M[(size_t)col * q + row] = s;
             M[(size_t)row * q + col] = s;
         }
-    } else if (!aug) {
+    } else if (!aug && grp == 0) {
         const int vw = 32 * ntc + 4;
         for (int j = e; j < p; j += 256) {
             double a = 0.0, bb = 0.0;
@@ -1260,7 +1267,7 @@ __global__ __launch_bounds__(256) void moments_reduce_kernel(const double *__res
 
 int launch_moments_reduce(hipStream_t s, const GramPlan &pl, const double *tpart, const double *vpart, double *moments)
 {
-    hipLaunchKernelGGL(moments_reduce_kernel, dim3(pl.ntile + (pl.tri ? 0 : 1)), dim3(256), 0, s, tpart, vpart, pl.p,
+    hipLaunchKernelGGL(moments_reduce_kernel, dim3(pl.ntile + (pl.tri ? 0 : 1)), dim3(1024), 0, s, tpart, vpart, pl.p,
                        pl.ntc, pl.ntile, pl.nchunk, pl.tri, moments);
     OEM_HIP(hipGetLastError());
     return 0;
