@@ -32,7 +32,9 @@ namespace oemgpu {
 __global__ __launch_bounds__(256) void shift_sums_kernel(const double *__restrict__ x, int64_t n, int64_t ld, int p,
                                                           const double *__restrict__ y, double *__restrict__ sums)
 {
-    __shared__ double sh[256];
+    // one workgroup per column: 256 threads x 16 consecutive rows (a full chunk is two 64-byte loads per thread, all in
+    // flight at once), then ONE fixed-order tree for the three sums together (sum, sum of squares, count)
+    __shared__ double sh[3][256];
     const int j = blockIdx.x;
     const double *col = (j < p) ? x + (size_t)j * ld : y;
     const int64_t nch = (n + 15) / 16;
@@ -41,33 +43,28 @@ __global__ __launch_bounds__(256) void shift_sums_kernel(const double *__restric
     double s = 0.0, ss = 0.0, cnt = 0.0;
     if (k < nsamp) {
         const int64_t c = (nsamp > 1) ? ((int64_t)k * (nch - 1)) / (nsamp - 1) : 0;
-        const int64_t r0 = c * 16, r1 = (r0 + 16 < n) ? r0 + 16 : n;
-        for (int64_t r = r0; r < r1; ++r) { const double v = col[r]; s += v; ss = fma(v, v, ss); cnt += 1.0; }
-    }
-    sh[k] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if (k < w) sh[k] += sh[k + w];
-        __syncthreads();
-    }
-    if (k == 0) sums[j] = sh[0];
-    __syncthreads();
-    sh[k] = ss;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if (k < w) sh[k] += sh[k + w];
-        __syncthreads();
-    }
-    if (k == 0) sums[p + 2 + j] = sh[0];
-    if (j == 0) {
-        __syncthreads();
-        sh[k] = cnt;
-        __syncthreads();
-        for (int w = 128; w > 0; w >>= 1) {
-            if (k < w) sh[k] += sh[k + w];
-            __syncthreads();
+        const int64_t r0 = c * 16;
+        if (r0 + 16 <= n) {
+            double v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = col[r0 + r];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s += v[r]; ss = fma(v[r], v[r], ss); }
+            cnt = 16.0;
+        } else {
+            for (int64_t r = r0; r < n; ++r) { const double v = col[r]; s += v; ss = fma(v, v, ss); cnt += 1.0; }
         }
-        if (k == 0) { sums[p + 1] = sh[0]; sums[2 * p + 3] = 0.0; }
+    }
+    sh[0][k] = s; sh[1][k] = ss; sh[2][k] = cnt;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (k < w) { sh[0][k] += sh[0][k + w]; sh[1][k] += sh[1][k + w]; sh[2][k] += sh[2][k + w]; }
+        __syncthreads();
+    }
+    if (k == 0) {
+        sums[j] = sh[0][0];
+        sums[p + 2 + j] = sh[1][0];
+        if (j == 0) { sums[p + 1] = sh[2][0]; sums[2 * p + 3] = 0.0; }
     }
 }
 
