@@ -50,11 +50,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    # OEM_BENCH_ONE_DEVICE=1: a functional check of the N > 1 code path on a one-GPU box (all ranks on device 0, gloo
+    # instead of RCCL, which refuses two ranks on one device); never a measurement
+    one_dev = os.environ.get("OEM_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import oem_amd
     from oem_amd import _lib as L
@@ -64,13 +72,27 @@ def main():
     n, p, m = a.n, a.p, 25
     lo, hi = row_partition(n, world)[rank]
     n_loc = hi - lo
-    # synthetic data of the README's shape, generated on the device (column-major: a (p, n_loc) row-major tensor)
+    # Synthetic data of the README's shape, generated on the device (column-major: a (p, n_loc) row-major tensor).
+    # The SAME n x p problem for every N in {1, 2, 4, 8}: the rows come in 8 blocks, block k from its own seed, and a rank
+    # generates exactly the blocks of its row range -- so iteration counts (and the path's share of the time) do not move with N.
     g = torch.Generator(device=dev); g.manual_seed(123)
     b = torch.cat([torch.rand(m, generator=g, device=dev, dtype=torch.float64), torch.zeros(p - m, device=dev, dtype=torch.float64)])
-    g.manual_seed(1000 + rank)
-    xt = torch.randn((p, n_loc), generator=g, device=dev, dtype=torch.float64) * 3.0
+    xt = torch.empty((p, n_loc), device=dev, dtype=torch.float64)
+    y = torch.empty(n_loc, device=dev, dtype=torch.float64)
+    NBLK = 8
+    if n % NBLK == 0 and NBLK % world == 0:
+        blk = n // NBLK
+        for k in range(lo // blk, hi // blk):
+            g.manual_seed(1000 + k)
+            c0 = k * blk - lo
+            xt[:, c0:c0 + blk] = torch.randn((p, blk), generator=g, device=dev, dtype=torch.float64) * 3.0
+            y[c0:c0 + blk] = torch.randn(blk, generator=g, device=dev, dtype=torch.float64)
+    else:
+        g.manual_seed(1000 + rank)
+        xt.copy_(torch.randn((p, n_loc), generator=g, device=dev, dtype=torch.float64) * 3.0)
+        y.copy_(torch.randn(n_loc, generator=g, device=dev, dtype=torch.float64))
     x = xt.t()                                   # (n_loc, p), stride (1, n_loc)
-    y = (x @ b + torch.randn(n_loc, generator=g, device=dev, dtype=torch.float64)).contiguous()
+    y += x @ b
     torch.cuda.synchronize()
 
     kw = dict(penalty="elastic.net", alpha=1.0, intercept=True, standardize=False)
@@ -91,13 +113,14 @@ def main():
     mom = backend.new_buffer(L.moments_len(p))
 
     def solve(lam=None, tol=None):
-        backend.shift_sums(x, n_loc, n_loc, p, y, sums)
-        if dd is not None:
-            dd.all_reduce(sums)
-        backend.moments(x, n_loc, n_loc, p, y, sums, mom)
-        if dd is not None:
-            dd.all_reduce(mom)
-        backend.solve(mom, sums, p, L.OEMGPU_SEM_DENSE, False, True, args)
+        with backend.section():                   # kernels and RCCL collectives stream-ordered on the backend's stream
+            backend.shift_sums(x, n_loc, n_loc, p, y, sums)
+            if dd is not None:
+                dd.all_reduce(sums)
+            backend.moments(x, n_loc, n_loc, p, y, sums, mom)
+            if dd is not None:
+                dd.all_reduce(mom)
+            backend.solve(mom, sums, p, L.OEMGPU_SEM_DENSE, False, True, args)
         return args
     for _ in range(a.warmup):
         solve()

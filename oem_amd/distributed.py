@@ -28,13 +28,25 @@ class HipBackend:
         import torch
         self.torch = torch
         self.device = torch.cuda.current_device() if device is None else device
-        # run on torch's current stream so that kernels and RCCL collectives are ordered without host syncs
-        self.stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        # Kernels (launched by liboemgpu on the context's stream) and RCCL collectives (ordered by torch against its
+        # CURRENT stream) must share one stream, or an all-reduce can start before the kernel that feeds it has finished.
+        # torch's default stream has handle 0, which the C ABI reads as "create your own": so the backend always owns an
+        # explicit side stream, and `section()` makes it torch's current stream around kernels AND collectives.
+        self.stream = torch.cuda.Stream(device=self.device) if stream is None else stream
+        if int(self.stream.cuda_stream) == 0:
+            raise ValueError("HipBackend needs an explicit (non-default) torch.cuda.Stream")
         self.ctx = _api.context(self.device, self.stream)
         self.lib = L.lib()
 
+    def section(self):
+        """`with backend.section():` -- the work inside (local stages and torch.distributed collectives) is stream-ordered on
+        the backend's stream; inputs produced on the caller's stream are waited for on the device, not on the host."""
+        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
+        return self.torch.cuda.stream(self.stream)
+
     def new_buffer(self, n):
-        return self.torch.zeros(n, dtype=self.torch.float64, device=f"cuda:{self.device}")
+        with self.torch.cuda.stream(self.stream):
+            return self.torch.zeros(n, dtype=self.torch.float64, device=f"cuda:{self.device}")
 
     def shift_sums(self, x, n, ld, p, y, out):
         L.check(self.lib.oemgpu_shift_sums_dev(self.ctx, x.data_ptr(), n, ld, p, y.data_ptr(), out.data_ptr()))
@@ -78,16 +90,17 @@ def oem_sharded(x_local, y_local, backend=None, dist=None, group=None, big=False
     args = _api._Args(penalty, _api._lambda_list(lambda_, len(penalty)), int(nlambda), lambda_min_ratio, alpha, gamma,
                       tau, tol, maxit, accelerate and not big, compute_loss, np.asarray(penalty_factor, dtype=np.float64),
                       g, ug, gw)
-    sums = backend.new_buffer(L.sums_len(p))
-    mom = backend.new_buffer(L.moments_len(p))
-    backend.shift_sums(x_local, n_local, ld, p, y_local, sums)
-    if dist is not None and dist.get_world_size(group) > 1:
-        dist.all_reduce(sums, group=group)
-    backend.moments(x_local, n_local, ld, p, y_local, sums, mom)
-    if dist is not None and dist.get_world_size(group) > 1:
-        dist.all_reduce(mom, group=group)          # the single Gram all-reduce of the north star
-    backend.solve(mom, sums, p, L.OEMGPU_SEM_BIG if big else L.OEMGPU_SEM_DENSE, standardize, intercept, args)
-    n_total = int(round(float(mom.reshape(p + 2, p + 2)[p + 1, p + 1])))
+    with backend.section():                        # kernels and collectives on one stream (see HipBackend)
+        sums = backend.new_buffer(L.sums_len(p))
+        mom = backend.new_buffer(L.moments_len(p))
+        backend.shift_sums(x_local, n_local, ld, p, y_local, sums)
+        if dist is not None and dist.get_world_size(group) > 1:
+            dist.all_reduce(sums, group=group)
+        backend.moments(x_local, n_local, ld, p, y_local, sums, mom)
+        if dist is not None and dist.get_world_size(group) > 1:
+            dist.all_reduce(mom, group=group)      # the single Gram all-reduce of the north star
+        backend.solve(mom, sums, p, L.OEMGPU_SEM_BIG if big else L.OEMGPU_SEM_DENSE, standardize, intercept, args)
+        n_total = int(round(float(mom.reshape(p + 2, p + 2)[p + 1, p + 1])))
     if varnames is None:
         varnames = [f"V{i + 1}" for i in range(p)]
     return _api._decorate(args, penalty, varnames, True, n_total, p)

@@ -17,6 +17,10 @@ def shift_in_effect(s, p):
 
 
 class CheckerBackend:
+    def section(self):
+        import contextlib
+        return contextlib.nullcontext()
+
     def new_buffer(self, n):
         return torch.zeros(n, dtype=torch.float64)
 
