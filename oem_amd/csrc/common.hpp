@@ -80,7 +80,7 @@ struct PathArgs {
     double *work;
 };
 
-static const int SMALL_P_MAX = 256;     // <= 192: one workgroup; 193..256: four cooperating workgroups
+static const int SMALL_P_MAX = 288;     // one workgroup where the matrix fits its registers (+ LDS); else four cooperating workgroups (big.oem's p + 1 = 257 included)
 size_t path_small_xchg_bytes();
 int launch_path_small(hipStream_t s, const PathArgs &a);          // p <= SMALL_P_MAX: one fused launch
 int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch);   // any p: multi-launch engine

@@ -26,8 +26,8 @@
 
 namespace oemgpu {
 
-// granule exchange buffer of the cooperating-workgroup form: [2 parities][4 workgroups][256 rows][2 granules]
-size_t path_small_xchg_bytes() { return (size_t)2 * 4 * 256 * 2 * sizeof(unsigned long long); }
+// granule exchange buffer of the cooperating-workgroup form: [2 parities][4 workgroups][<= 320 rows][2 granules]
+size_t path_small_xchg_bytes() { return (size_t)2 * 4 * 320 * 2 * sizeof(unsigned long long); }
 
 namespace {
 
@@ -650,6 +650,7 @@ __device__ __forceinline__ void iterate(const PathArgs &A, const PenK &K, double
 template <int R, int NW, int CW, int G>
 __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
 {
+    static_assert(CW % 2 == 0, "the broadcast strip is read in pairs");
     typedef Cfg<R, NW, CW> C;
     constexpr int PR = C::PR;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1497,6 +1498,7 @@ int launch_path_small(hipStream_t s, const PathArgs &a)
     if (a.p <= 160) return launch_cfg<3, 8, 20>(s, a);
     if (a.p <= 192) return launch_cfg<3, 8, 24>(s, a);
     if (a.p <= 256) return launch_cfg<4, 8, 8, 4>(s, a);          // four cooperating workgroups, 64 columns each
+    if (a.p <= 288) return launch_cfg<5, 8, 10, 4>(s, a);         // ... 80 column slots each (CW must be even): big.oem's p = 256 + intercept lands here
     set_error("path_small: p = %d exceeds %d", a.p, SMALL_P_MAX);
     return OEMGPU_ERR_INTERNAL;
 }
