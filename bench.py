@@ -112,25 +112,27 @@ def main():
     sums = backend.new_buffer(L.sums_len(p))
     mom = backend.new_buffer(L.moments_len(p))
 
-    def solve(lam=None, tol=None):
-        with backend.section():                   # kernels and RCCL collectives stream-ordered on the backend's stream
-            backend.shift_sums(x, n_loc, n_loc, p, y, sums)
-            if dd is not None:
-                dd.all_reduce(sums)
-            backend.moments(x, n_loc, n_loc, p, y, sums, mom)
-            if dd is not None:
-                dd.all_reduce(mom)
-            backend.solve(mom, sums, p, L.OEMGPU_SEM_DENSE, False, True, args)
+    def solve(lam=None, tol=None):              # call inside `with backend.section():`
+        backend.shift_sums(x, n_loc, n_loc, p, y, sums)
+        if dd is not None:
+            dd.all_reduce(sums)
+        backend.moments(x, n_loc, n_loc, p, y, sums, mom)
+        if dd is not None:
+            dd.all_reduce(mom)
+        backend.solve(mom, sums, p, L.OEMGPU_SEM_DENSE, False, True, args)
         return args
-    for _ in range(a.warmup):
-        solve()
+    # kernels and RCCL collectives are stream-ordered on the backend's stream: one section around each loop
+    with backend.section():
+        for _ in range(a.warmup):
+            solve()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        solve()
+    with backend.section():
+        for _ in range(a.steps):
+            solve()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -152,10 +154,11 @@ def main():
     reps = max(10, min(50, a.steps))
     acc = np.zeros(L.NTIMERS)
     ms = (C.c_double * L.NTIMERS)()
-    for _ in range(reps):
-        solve()
-        L.check(lib.oemgpu_last_timings(backend.ctx, ms))
-        acc += np.array(list(ms))
+    with backend.section():
+        for _ in range(reps):
+            solve()
+            L.check(lib.oemgpu_last_timings(backend.ctx, ms))
+            acc += np.array(list(ms))
     L.check(lib.oemgpu_set_timing(backend.ctx, 0))
     acc /= reps
     gram_ms = acc[L.T_GRAMK]

@@ -202,7 +202,9 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const bool small = q <= SMALL_P_MAX;
     int lan = q < 128 ? q : 128;
     const size_t work_d = small ? path_small_xchg_bytes() / 8 : path_large_work_doubles(q, lan);
-    const size_t a_blob = B.take(bl.h.size()), a_out = B.take(out_bytes), a_work = B.take(work_d * sizeof(double));
+    // the outputs come first: when the caller's frame ends with `stats` (both callers), stats | outputs is one
+    // contiguous range and one device-to-host copy returns both
+    const size_t a_out = B.take(out_bytes), a_blob = B.take(bl.h.size()), a_work = B.take(work_d * sizeof(double));
     // the workspace may be re-allocated by ctx_reserve: xx/xy/stats are offsets into it, so recompute after
     const size_t off_xx = (const char *)xx - c->ws, off_xy = (const char *)xy - c->ws, off_st = (const char *)stats - c->ws;
     if (B.off > c->ws_bytes) { set_error("internal: workspace under-reserved (%zu > %zu)", B.off, c->ws_bytes); return OEMGPU_ERR_INTERNAL; }
@@ -212,7 +214,10 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     if (ctx_pinned_in(c, bl.h.size())) return OEMGPU_ERR_HIP;       // the previous call ended with a stream sync: the buffer is free
     memcpy(c->pinned_in, bl.h.data(), bl.h.size());
     OEM_HIP(hipMemcpyAsync(dblob, c->pinned_in, bl.h.size(), hipMemcpyHostToDevice, c->stream));
-    OEM_HIP(hipMemsetAsync(dout, 0, out_bytes, c->stream));
+    // Every output the host reads below is written by the path kernels, so the region is not cleared.  OEM_POISON_OUT=1
+    // fills it with NaN bit patterns first: the GPU suite run that way proves nothing depends on stale contents.
+    static const bool poison = getenv("OEM_POISON_OUT") != nullptr;
+    if (poison) OEM_HIP(hipMemsetAsync(dout, 0xFF, out_bytes, c->stream));
 
     PathArgs a;
     memset(&a, 0, sizeof a);
@@ -233,19 +238,23 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     a.niter = (int *)(dstats + stats_len(p));
     a.work = (double *)(c->ws + a_work);
 
-    if (ctx_pinned(c, out_bytes > 16384 ? out_bytes : 16384)) return OEMGPU_ERR_HIP;
+    const size_t st_gap = (size_t)((const char *)dout - (const char *)stats);
+    const bool joined = (const char *)stats < (const char *)dout && st_gap == ((size_t)stats_len(p) * 8 + 255) / 256 * 256;
+    const size_t back_bytes = out_bytes + (joined ? st_gap : 0);
+    if (ctx_pinned(c, back_bytes > 16384 ? back_bytes : 16384)) return OEMGPU_ERR_HIP;
     {
         Timer t(c, OEMGPU_T_EIGPATH);
         int rc = small ? launch_path_small(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned);
         if (rc) return rc;
     }
-    OEM_HIP(hipMemcpyAsync(dstats, stats, sizeof(double) * stats_len(p), hipMemcpyDeviceToDevice, c->stream));
-    OEM_HIP(hipMemcpyAsync(c->pinned, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (!joined) OEM_HIP(hipMemcpyAsync(dstats, stats, sizeof(double) * stats_len(p), hipMemcpyDeviceToDevice, c->stream));
+    OEM_HIP(hipMemcpyAsync(c->pinned, joined ? (const void *)stats : (const void *)dout, back_bytes, hipMemcpyDeviceToHost, c->stream));
     OEM_HIP(hipStreamSynchronize(c->stream));
 
     // ---- unpack (ref src/oem_dense.cpp:249-294, src/DataStd.h:269-293, src/oem_big.h:880-897, src/oem_big.cpp:213-220)
-    const double *hb = (const double *)c->pinned, *hl = hb + nb, *hloss = hl + nk, *hd = hloss + nk, *hs = hd + 4;
-    const int32_t *hn = (const int32_t *)(hs + stats_len(p));
+    const double *hb = (const double *)((const char *)c->pinned + (joined ? st_gap : 0)), *hl = hb + nb, *hloss = hl + nk,
+                 *hd = hloss + nk, *hs = joined ? (const double *)c->pinned : hd + 4;
+    const int32_t *hn = (const int32_t *)(hd + 4 + stats_len(p));
     *d_out = hd[0];
     if (hd[1] < 0.0) { set_error("cooperating workgroups lost each other (exchange timeout)"); return OEMGPU_ERR_INTERNAL; }
     c->diag[0] = hd[2]; c->diag[1] = hd[3];
@@ -304,8 +313,7 @@ __global__ void accumulate_kernel(double *__restrict__ dst, const double *__rest
 int shard_moments(oemgpu_ctx *c, const GramPlan &pl, const double *x, int64_t n, int64_t ld, const double *y,
                   const double *sums, double *tpart, double *vpart, double *moments)
 {
-    OEM_HIP(hipMemsetAsync(moments, 0, sizeof(double) * (size_t)oemgpu_moments_len(pl.p), c->stream));
-    {
+    {                       // no clear: moments_reduce_kernel writes all (p+2)^2 entries
         Timer t(c, OEMGPU_T_GRAMK);
         int rc = launch_gram(c->stream, pl, x, n, ld, y, sums, tpart, vpart);
         if (rc) return rc;
@@ -506,8 +514,8 @@ int oemgpu_fit_xtx_dev(oemgpu_ctx *c, const double *xtx_dev, const double *xty_d
     if (rc) return rc;
     if (set_device(c)) return OEMGPU_ERR_HIP;
     Bump B;
-    const size_t a_xx = B.take((size_t)p * p * 8), a_xy = B.take((size_t)p * 8), a_st = B.take((size_t)stats_len(p) * 8),
-                 a_sf = B.take((size_t)p * 8);
+    const size_t a_xx = B.take((size_t)p * p * 8), a_xy = B.take((size_t)p * 8), a_sf = B.take((size_t)p * 8),
+                 a_st = B.take((size_t)stats_len(p) * 8);      // stats last: run_paths returns it with the outputs
     if (ctx_reserve(c, B.off + paths_ws_bytes(p, p, o) + 4096)) return OEMGPU_ERR_HIP;
     double *xx = (double *)(c->ws + a_xx), *xy = (double *)(c->ws + a_xy), *st = (double *)(c->ws + a_st), *sf = (double *)(c->ws + a_sf);
     std::vector<double> sinv;
