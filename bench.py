@@ -12,7 +12,8 @@ the timed region starts.
 
 A "step" is one complete solve: shift sample -> one-pass MFMA moment build -> (N > 1: all-reduce) -> finalize ->
 eigenvalue -> 100-lambda path -> results on the host.  With N > 1 the n rows are split across the ranks (strong
-scaling: the total problem stays n = 1e6) and the (p+2)^2 moment buffer is summed with one RCCL all-reduce.
+scaling: the total problem stays n = 1e6) and the sample sums + (p+2)^2 moment buffer are summed with one RCCL all-reduce
+(oem_amd/distributed.py: solve_row_shards).
 
 Rank 0 prints ONE JSON line (see the repo README / DESIGN.md for the roofline and cpu_baseline fields).
 """
@@ -67,7 +68,7 @@ def main():
     import oem_amd
     from oem_amd import _lib as L
     from oem_amd import api
-    from oem_amd.distributed import HipBackend, oem_sharded, row_partition
+    from oem_amd.distributed import HipBackend, oem_sharded, row_partition, sharded_buffers, solve_row_shards
 
     n, p, m = a.n, a.p, 25
     lo, hi = row_partition(n, world)[rank]
@@ -109,17 +110,10 @@ def main():
     # arguments marshalled once, then per step: shift sample -> moments -> [all-reduce] -> solve (results on host).
     args = api._Args(["elastic.net"], [np.asarray(lambdas)], 100, 1e-4, 1.0, 3.0, 0.5, 1e-10, 500, False, False,
                      np.ones(p), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0))
-    sums = backend.new_buffer(L.sums_len(p))
-    mom = backend.new_buffer(L.moments_len(p))
+    bufs = sharded_buffers(backend, p)
 
     def solve(lam=None, tol=None):              # call inside `with backend.section():`
-        backend.shift_sums(x, n_loc, n_loc, p, y, sums)
-        if dd is not None:
-            dd.all_reduce(sums)
-        backend.moments(x, n_loc, n_loc, p, y, sums, mom)
-        if dd is not None:
-            dd.all_reduce(mom)
-        backend.solve(mom, sums, p, L.OEMGPU_SEM_DENSE, False, True, args)
+        solve_row_shards(backend, dd, None, x, n_loc, n_loc, p, y, bufs, L.OEMGPU_SEM_DENSE, False, True, args)
         return args
     # kernels and RCCL collectives are stream-ordered on the backend's stream: one section around each loop
     with backend.section():

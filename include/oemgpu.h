@@ -155,6 +155,12 @@ int oemgpu_fit_xtx_dev(oemgpu_ctx *ctx, const double *xtx_dev, const double *xty
                        const double *scale_factor, const oemgpu_opts *o,
                        double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
 
+/* 1 if the most recent oemgpu_solve_moments_dev on this context found the shift predicate above true for its
+ * sums_dev (and so read moments_dev as accumulated about c), 0 if not, -1 for a NULL context.  The row-sharded
+ * driver builds its moments about c = 0 BEFORE the sums are all-reduced (one collective for sums and moments
+ * together) and uses this to detect the rare case in which that guess was wrong and the pass must be redone. */
+int oemgpu_last_shift_in_effect(oemgpu_ctx *ctx);
+
 /* lambda_max of a symmetric p x p device matrix (the Spectra call of ref src/oem_dense.h:485-498). */
 int oemgpu_eig_max_dev(oemgpu_ctx *ctx, const double *a_dev, int32_t p, double *lambda_max);
 

@@ -43,6 +43,7 @@ struct oemgpu_ctx {
     bool ev_used[OEMGPU_NTIMERS];
     double ms[OEMGPU_NTIMERS];
     double diag[2] = {0.0, 0.0};   // path kernel: shader cycles, 100 MHz ticks
+    int shifted = 0;               // the last solve read its moments as accumulated about the provisional shift
 };
 
 namespace {
@@ -258,6 +259,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     *d_out = hd[0];
     if (hd[1] < 0.0) { set_error("cooperating workgroups lost each other (exchange timeout)"); return OEMGPU_ERR_INTERNAL; }
     c->diag[0] = hd[2]; c->diag[1] = hd[3];
+    c->shifted = hs[stats_shift_flag(p)] != 0.0;
     const double meany = hs[0], scaley = hs[1];
     const double *meanx = hs + 4, *scalex = hs + 4 + p;
     const int flag = (standardize ? 1 : 0) + 2 * (intercept ? 1 : 0);
@@ -532,6 +534,8 @@ int oemgpu_fit_xtx_dev(oemgpu_ctx *c, const double *xtx_dev, const double *xty_d
     }
     return run_paths(c, B, xx, xy, st, p, p, SEM_XTX, 0, 0, o, scale_factor, beta, lambda_out, niter, loss, d);
 }
+
+int oemgpu_last_shift_in_effect(oemgpu_ctx *c) { return c ? c->shifted : -1; }
 
 int oemgpu_eig_max_dev(oemgpu_ctx *c, const double *a_dev, int32_t p, double *lambda_max)
 {

@@ -1301,6 +1301,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict_
     }
     const double n = m.n;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    if (tid == 0) { stats[stats_shift_flag(p)] = m.shift ? 1.0 : 0.0; stats[stats_shift_flag(p) + 1] = 0.0; }
     if (sem == OEMGPU_SEM_DENSE) {
         const int flag = (standardize ? 1 : 0) + 2 * (intercept ? 1 : 0);
         // y
@@ -1380,7 +1381,7 @@ __global__ __launch_bounds__(256) void xtx_prepare_kernel(const double *__restri
         xx[idx] = sinv ? sinv[i] * xtx[idx] * sinv[j] : xtx[idx];
         if (i == 0) xy[j] = sinv ? xty[j] * sinv[j] : xty[j];
     }
-    if (tid == 0) { stats[0] = 0.0; stats[1] = 1.0; stats[2] = 0.0; stats[3] = 1.0; }
+    if (tid == 0) { stats[0] = 0.0; stats[1] = 1.0; stats[2] = 0.0; stats[3] = 1.0; stats[stats_shift_flag(p)] = 0.0; stats[stats_shift_flag(p) + 1] = 0.0; }
 }
 
 int launch_xtx_prepare(hipStream_t s, const double *xtx, const double *xty, const double *sf_inv, int p, double *xx,

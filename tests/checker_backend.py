@@ -21,6 +21,9 @@ class CheckerBackend:
         import contextlib
         return contextlib.nullcontext()
 
+    def shift_in_effect(self):
+        return self.shifted
+
     def new_buffer(self, n):
         return torch.zeros(n, dtype=torch.float64)
 
@@ -30,8 +33,11 @@ class CheckerBackend:
         out[:p] = torch.from_numpy(xn[:k].sum(0)); out[p] = float(yn[:k].sum()); out[p + 1] = float(k)
         out[p + 2:2 * p + 2] = torch.from_numpy((xn[:k] ** 2).sum(0)); out[2 * p + 2] = float((yn[:k] ** 2).sum())
 
+    passes = 0
+
     def moments(self, x, n, ld, p, y, sums, out):
-        c = shift_in_effect(sums.numpy(), p)
+        self.passes += 1
+        c = np.zeros(p + 1) if sums is None else shift_in_effect(sums.numpy(), p)
         z = np.column_stack([x.numpy() - c[:p], y.numpy() - c[p], np.ones(n)])
         out.copy_(torch.from_numpy((z.T @ z).ravel()))
 
@@ -39,6 +45,7 @@ class CheckerBackend:
         assert semantics == 0
         M = mom.numpy().reshape(p + 2, p + 2); s = sums.numpy()
         n = M[p + 1, p + 1]; c = shift_in_effect(s, p)
+        self.shifted = bool(np.any(c != 0.0))
         sh = M[p + 1, :p + 1]
         mu = c + sh / n
         cen = M[:p + 1, :p + 1] - np.outer(sh, sh) / n

@@ -1,5 +1,6 @@
-"""The row-sharded driver (oem_amd/distributed.py) under gloo with world_size 2, on CPU: row partition, the
-two all-reduces (shift sample, moment buffer) and the replicated solve.  The local stages come from
+"""The row-sharded driver (oem_amd/distributed.py) under gloo with world_size 2, on CPU: row partition, the single
+all-reduce of [sample sums | moments about 0], the redo about the agreed shift when the reduced sums call for one
+(columns with |mean| >> sd), and the replicated solve.  The local stages come from
 tests/checker_backend.py; on GPUs the same driver runs with HipBackend over RCCL (bench.py --gpus N)."""
 import os
 import socket
@@ -19,9 +20,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _data(n=3001, p=12, seed=3):
+def _data(n=3001, p=12, seed=3, offset=1.0):
     rng = np.random.default_rng(seed)
-    x = np.asfortranarray(rng.normal(size=(n, p)) * 2.0 + 1.0)
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 2.0 + offset)
     b = np.concatenate([rng.uniform(-1, 1, 4), np.zeros(p - 4)])
     return x, x @ b + rng.normal(size=n) + 0.5
 
@@ -32,18 +33,23 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oem_amd.distributed import oem_sharded, row_partition
     from tests.checker_backend import CheckerBackend
-    x, y = _data()
-    lo, hi = row_partition(x.shape[0], world)[rank]
-    xl = torch.from_numpy(np.ascontiguousarray(x[lo:hi].T)).t()           # column-major local shard
-    yl = torch.from_numpy(y[lo:hi].copy())
     out = {}
-    for std, icpt in ((True, True), (False, True), (False, False)):
-        fit = oem_sharded(xl, yl, backend=CheckerBackend(), dist=dist, penalty=["lasso", "mcp"], nlambda=12, tol=1e-10,
-                          standardize=std, intercept=icpt)
-        out[(std, icpt)] = (fit["beta"], fit["lambda"], fit["d"], fit["nobs"])
+    for offset in OFFSETS:
+        x, y = _data(offset=offset)
+        lo, hi = row_partition(x.shape[0], world)[rank]
+        xl = torch.from_numpy(np.ascontiguousarray(x[lo:hi].T)).t()           # column-major local shard
+        yl = torch.from_numpy(y[lo:hi].copy())
+        for std, icpt in ((True, True), (False, True), (False, False)):
+            backend = CheckerBackend()
+            fit = oem_sharded(xl, yl, backend=backend, dist=dist, penalty=["lasso", "mcp"], nlambda=12, tol=1e-10,
+                              standardize=std, intercept=icpt)
+            out[(offset, std, icpt)] = (fit["beta"], fit["lambda"], fit["d"], fit["nobs"], backend.shifted, backend.passes)
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
+
+
+OFFSETS = (1.0, 500.0)          # |mean| = 0.5 sd: no shift, one collective;  250 sd: shift, the pass is redone
 
 
 def test_row_partition():
@@ -64,16 +70,17 @@ def test_sharded_equals_unsharded_world2():
     for pr in procs:
         pr.join(timeout=60)
         assert pr.exitcode == 0
-    x, y = _data()
     for key in got[0]:
-        std, icpt = key
+        offset, std, icpt = key
+        x, y = _data(offset=offset)
         ref = orc.fit_dense(x, y, penalty=["lasso", "mcp"], nlambda=12, tol=1e-10, standardize=std, intercept=icpt)
         for r in (0, 1):
-            beta, lam, d, nobs = got[r][key]
+            beta, lam, d, nobs, shifted, passes = got[r][key]
             assert nobs == x.shape[0]
-            assert abs(d - ref["d"]) < 1e-10 * ref["d"]
+            assert shifted == (offset > 100.0) and passes == (2 if shifted else 1), (key, shifted, passes)
+            assert abs(d - ref["d"]) < 1e-9 * ref["d"]
             for k in range(2):
-                assert np.abs(beta[k] - ref["beta"][k]).max() < 1e-9, (key, r, k)
-                assert np.allclose(lam[k], ref["lambda"][k], rtol=1e-12)
+                assert np.abs(beta[k] - ref["beta"][k]).max() < 1e-8 * max(1.0, np.abs(ref["beta"][k]).max()), (key, r, k)
+                assert np.allclose(lam[k], ref["lambda"][k], rtol=1e-10)
         for k in range(2):                                                  # every rank returns the same bits
             assert np.array_equal(got[0][key][0][k], got[1][key][0][k])
