@@ -24,7 +24,7 @@ extern "C" {
 #define OEMGPU_ERR_ARG        -1   /* invalid argument (the R front ends stop() on these: ref R/oem.R:215-431) */
 #define OEMGPU_ERR_NO_DEVICE  -2
 #define OEMGPU_ERR_HIP        -3   /* a HIP runtime call failed */
-#define OEMGPU_ERR_UNSUPPORTED -4  /* outside the restated path (e.g. p >= n branch, ref src/oem_dense.h:363-366) */
+#define OEMGPU_ERR_UNSUPPORTED -4  /* outside the restated path (e.g. big.oem with p >= n, ref src/oem_big.h:547-551) */
 #define OEMGPU_ERR_INTERNAL   -5
 
 /* penalty codes = position in the R default vector (ref R/oem.R:165-173) */
@@ -77,7 +77,9 @@ typedef struct oemgpu_opts {
  * d:          1.005 * lambda_max(X'X/n) (ref src/oem_dense.h:498)
  * ------------------------------------------------------------------------------------------- */
 
-/* replaces oem_fit_dense, ref src/oem_dense.cpp:30-309 (family "gaussian", weights empty) */
+/* replaces oem_fit_dense, ref src/oem_dense.cpp:30-309 (family "gaussian", weights empty).
+ * Both branches of ref src/oem_dense.h:476-482: n > p, and p >= n, where the reference iterates through X twice
+ * (u = X'(Y - X b)/n + d b, d from XXt/n) -- the same iteration written on the Gram, which is how it is run here. */
 int oemgpu_fit_dense(const double *x, int64_t n, int32_t p, const double *y,
                      int32_t standardize, int32_t intercept, const oemgpu_opts *o,
                      double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);

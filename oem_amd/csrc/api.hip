@@ -483,7 +483,8 @@ int oemgpu_fit_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t 
     int rc = check_opts(o, p, p);
     if (rc) return rc;
     if (n < 1 || ld < n) { set_error("fit_dense: bad n / ld"); return OEMGPU_ERR_ARG; }
-    if (n <= p) { set_error("p >= n: the XXt branch (ref src/oem_dense.h:363-366,513-521) is not part of this path"); return OEMGPU_ERR_UNSUPPORTED; }
+    // p >= n (ref src/oem_dense.h:476-482,513-521: d from XXt / n, u = X'(Y - X b)/n + d b) is served by the same Gram
+    // form: the non-zero spectra of XXt and XtX coincide and X'(Y - X b)/n + d b = (dI - X'X/n) b + X'Y/n.
     if (set_device(c)) return OEMGPU_ERR_HIP;
     const GramPlan pl = gram_plan(n, p, c->num_cu);
     Bump B;
@@ -582,7 +583,8 @@ int oemgpu_fit_dense(const double *x, int64_t n, int32_t p, const double *y, int
     if (!x || !y || !o) { set_error("fit_dense: NULL argument"); return OEMGPU_ERR_ARG; }
     int rc = check_opts(o, p, p);
     if (rc) return rc;
-    if (n <= p) { set_error("p >= n: the XXt branch (ref src/oem_dense.h:363-366,513-521) is not part of this path"); return OEMGPU_ERR_UNSUPPORTED; }
+    // p >= n (ref src/oem_dense.h:476-482,513-521: d from XXt / n, u = X'(Y - X b)/n + d b) is served by the same Gram
+    // form: the non-zero spectra of XXt and XtX coincide and X'(Y - X b)/n + d b = (dI - X'X/n) b + X'Y/n.
     oemgpu_ctx *c = oemgpu_create(o->device, nullptr);
     if (!c) return OEMGPU_ERR_NO_DEVICE;
     double *xd = nullptr, *yd = nullptr;

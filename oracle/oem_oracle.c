@@ -500,6 +500,10 @@ typedef struct {
     const double *XY;
     double d;
     double *u, *beta, *beta_prev, *tmp, *beta_last;
+    /* p >= n branch (ref: src/oem_dense.h:513-521): A is not formed, next_u goes through X twice */
+    const double *X, *Y;   /* standardised X (n x p col-major), Y (n); NULL on the n > p branch */
+    int64_t n;
+    double *resid;         /* n */
 } core_t;
 
 static int solve_one(core_t *s, int pen, double lambda, const orc_opts *o, const double *pf, const grp_t *g,
@@ -508,6 +512,22 @@ static int solve_one(core_t *s, int pen, double lambda, const orc_opts *o, const
     int p = s->p, i;
     for (i = 0; i < o->maxit; ++i) {
         memcpy(s->beta_prev, s->beta, sizeof(double) * (size_t)p);
+        if (s->X) {
+            /* next_u: u = X'(Y - X beta_prev) / n + d beta_prev  (ref: src/oem_dense.h:520) */
+            memcpy(s->resid, s->Y, sizeof(double) * (size_t)s->n);
+            for (int c = 0; c < p; c++) {
+                double b = s->beta_prev[c];
+                if (b == 0.0) continue;
+                const double *col = s->X + (size_t)c * s->n;
+                for (int64_t k = 0; k < s->n; k++) s->resid[k] -= col[k] * b;
+            }
+            for (int c = 0; c < p; c++) {
+                const double *col = s->X + (size_t)c * s->n;
+                double t = 0.0;
+                for (int64_t k = 0; k < s->n; k++) t += col[k] * s->resid[k];
+                s->u[c] = t / (double)s->n + s->d * s->beta_prev[c];
+            }
+        } else {
         /* next_u: u = A * beta_prev + XY  (ref: src/oem_dense.h:512) */
         for (int r = 0; r < p; r++) s->u[r] = 0.0;
         for (int c = 0; c < p; c++) {
@@ -517,6 +537,7 @@ static int solve_one(core_t *s, int pen, double lambda, const orc_opts *o, const
             for (int r = 0; r < p; r++) s->u[r] += col[r] * b;
         }
         for (int r = 0; r < p; r++) s->u[r] += s->XY[r];
+        }
         if (o->accelerate) memcpy(s->beta_last, s->beta, sizeof(double) * (size_t)p);
         next_beta(pen, s->beta, s->u, p, lambda, s->d, o->alpha, o->gamma, o->tau, pf, g, s->tmp);
         if (o->accelerate) {
@@ -574,15 +595,22 @@ static void lambda_grid(const orc_opts *o, double lmax, double *lam)
         }
 }
 
-int orc_path(const double *xx, const double *xy, int32_t p, double d, const orc_opts *o,
-             const double *lambda_scaled, int32_t nl, const double *scale_factor_inv,
-             double *beta_std, int32_t *niter)
+/* xx != NULL: the n > p branch on the Gram;  xx == NULL: the p >= n branch on the standardised (X, Y) */
+static int path_run(const double *xx, const double *xy, int32_t p, double d, const orc_opts *o,
+                    const double *lambda_scaled, int32_t nl, const double *scale_factor_inv,
+                    double *beta_std, int32_t *niter, const double *X, const double *Y, int64_t n)
 {
     core_t s; memset(&s, 0, sizeof s);
     if (core_alloc(&s, p)) return -1;
-    double *A = (double *)malloc(sizeof(double) * (size_t)p * p);
-    for (size_t k = 0; k < (size_t)p * p; k++) A[k] = -xx[k];
-    for (int j = 0; j < p; j++) A[(size_t)j * p + j] += d;
+    double *A = NULL;
+    if (xx) {
+        A = (double *)malloc(sizeof(double) * (size_t)p * p);
+        for (size_t k = 0; k < (size_t)p * p; k++) A[k] = -xx[k];
+        for (int j = 0; j < p; j++) A[(size_t)j * p + j] += d;
+    } else {
+        s.X = X; s.Y = Y; s.n = n;
+        s.resid = (double *)malloc(sizeof(double) * (size_t)n);
+    }
     s.A = A; s.XY = xy; s.d = d;
     grp_t g; memset(&g, 0, sizeof g);
     int have_g = 0;
@@ -603,8 +631,26 @@ int orc_path(const double *xx, const double *xy, int32_t p, double d, const orc_
         }
     }
     if (have_g) free_groups(&g);
-    free(A); free(s.u);
+    free(A); free(s.u); free(s.resid);
     return 0;
+}
+
+int orc_path(const double *xx, const double *xy, int32_t p, double d, const orc_opts *o,
+             const double *lambda_scaled, int32_t nl, const double *scale_factor_inv,
+             double *beta_std, int32_t *niter)
+{
+    return path_run(xx, xy, p, d, o, lambda_scaled, nl, scale_factor_inv, beta_std, niter, NULL, NULL, 0);
+}
+
+/* XXt / n: the n x n row Gram of the p >= n branch (ref: src/oem_dense.h:363-366, 483) */
+static void xxt_over_n(const double *x, int64_t n, int32_t p, double *g)
+{
+    for (int64_t a = 0; a < n; a++)
+        for (int64_t b = 0; b <= a; b++) {
+            double t = 0.0;
+            for (int j = 0; j < p; j++) t += x[(size_t)j * n + a] * x[(size_t)j * n + b];
+            g[(size_t)b * n + a] = g[(size_t)a * n + b] = t / (double)n;
+        }
 }
 
 /* ------------------------------------------------------------------ */
@@ -612,7 +658,8 @@ int orc_fit_dense(const double *x_in, int64_t n, int32_t p, const double *y_in,
                   int32_t standardize, int32_t intercept, const orc_opts *o,
                   double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out)
 {
-    if (n <= p) return fail("oracle: only the n > p branch is restated (ref: src/oem_dense.h:476)");
+    const int wide = n <= p;          /* the XXt branch (ref: src/oem_dense.h:476-482) */
+    if (wide && n > 8192) return fail("oracle: the p >= n branch is restated for n <= 8192 only (dense n x n eigen-solve)");
     int flag = (standardize ? 1 : 0) + 2 * (intercept ? 1 : 0);
     int nl = nl_of(o);
     /* copy (ref: src/oem_dense.cpp:61-67) */
@@ -629,8 +676,24 @@ int orc_fit_dense(const double *x_in, int64_t n, int32_t p, const double *y_in,
     double meany, scaley;
     orc_standardize(X, n, p, Y, standardize, intercept, meanx, scalex, &meany, &scaley);
     int ncores = o->ncores < 1 ? 1 : o->ncores;
-    orc_gram(X, n, p, Y, ncores, XX, XY);
-    double d = (o->d_override > 0) ? o->d_override : orc_eig_max(XX, p) * 1.005;
+    double d;
+    if (!wide) {
+        orc_gram(X, n, p, Y, ncores, XX, XY);
+        d = (o->d_override > 0) ? o->d_override : orc_eig_max(XX, p) * 1.005;
+    } else {
+        /* XY = X'Y / n (ref: :704-707);  d from XXt / n (ref: :480-498) */
+        for (int j = 0; j < p; j++) {
+            const double *c = X + (size_t)j * n;
+            double t = 0.0;
+            for (int64_t i = 0; i < n; i++) t += c[i] * Y[i];
+            XY[j] = t / (double)n;
+        }
+        double *G = (double *)malloc(sizeof(double) * (size_t)n * n);
+        if (!G) return fail("oracle: out of memory");
+        xxt_over_n(X, n, p, G);
+        d = (o->d_override > 0) ? o->d_override : orc_eig_max(G, (int32_t)n) * 1.005;
+        free(G);
+    }
     *d_out = d;
     double lmax = 0.0;
     for (int j = 0; j < p; j++) if (fabs(XY[j]) > lmax) lmax = fabs(XY[j]);
@@ -640,7 +703,7 @@ int orc_fit_dense(const double *x_in, int64_t n, int32_t p, const double *y_in,
     /* ilambda = lambda / scaleY (ref: src/oem_dense.cpp:241) */
     double *lams = (double *)malloc(sizeof(double) * (size_t)o->npen * nl);
     for (size_t k = 0; k < (size_t)o->npen * nl; k++) lams[k] = lam[k] / scaley;
-    int rc = orc_path(XX, XY, p, d, o, lams, nl, NULL, bstd, niter);
+    int rc = path_run(wide ? NULL : XX, XY, p, d, o, lams, nl, NULL, bstd, niter, X, Y, n);
     if (rc == 0) {
         for (int pp = 0; pp < o->npen; pp++) {
             int nlam = (o->penalty[pp] == ORC_OLS) ? 1 : nl;

@@ -1,6 +1,7 @@
 """Parity of the HIP path (through the C ABI) against the CPU oracle and the reference's doc KATs.
 Tolerance contract (BASELINE.json north_star): coefficients <= 1e-7 max-abs; observed ~1e-12."""
 import ctypes as C
+import warnings
 
 import numpy as np
 import pytest
@@ -356,4 +357,28 @@ def test_errors_are_the_references(oa):
     with pytest.raises(ValueError, match="groups must have same length"):
         oa.oem(x, y, penalty="grp.lasso", groups=[1, 2])
     with pytest.raises(oa.OemgpuError):
-        oa.oem(x[:4], y[:4])                                                     # p >= n branch is out of the path
+        oa.big_oem(x[:4], y[:4], penalty="lasso")                                #  big.oem's p >= n branch is out of the path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,p", [(40, 100), (64, 64), (3, 5), (120, 200), (200, 260), (150, 300)])
+@pytest.mark.parametrize("std,icpt", [(True, True), (False, False)])
+def test_wide_branch(oa, n, p, std, icpt):
+    """p >= n (ref src/oem_dense.h:476-482,513-521): the reference takes d from XXt/n and iterates through X twice; the
+    library runs the same iteration on the Gram.  Checked against the oracle's restatement of the reference's form."""
+    x, y = _data(n, p, 21, nnz=min(6, p))
+    groups = np.arange(p) // 5 + 1
+    kw = dict(penalty=["lasso", "mcp", "grp.lasso"], groups=groups, nlambda=12, tol=1e-8, maxit=800,
+              standardize=std, intercept=icpt)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f = oa.oem(x, y, **kw)
+    # R/oem.R:348-354: lambda.min.ratio defaults to 0.01 when n < p
+    r = orc.fit_dense(x, y, lambda_min_ratio=0.01 if n < p else 0.0001, unique_groups=np.unique(groups), **kw)
+    assert abs(f["d"] - r["d"]) < 1e-11 * r["d"]
+    for k in range(3):
+        assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-11)
+        scale = max(1.0, float(np.abs(r["beta"][k]).max()))
+        assert np.abs(f["beta"][k] - r["beta"][k]).max() < 1e-7 * scale, (k, np.abs(f["beta"][k] - r["beta"][k]).max())
+        dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]))
+        assert np.mean(dn > 1) <= 0.2, dn

@@ -61,3 +61,25 @@ def test_prop_dense_equals_xtx(doc_kats):
     for m in range(2):
         assert np.abs(a["beta"][m][1:] - b["beta"][m]).max() < 1e-13
         assert np.all(a["beta"][m][0] == 0)
+
+
+@pytest.mark.parametrize("n,p", [(40, 100), (64, 64), (30, 31)])
+def test_prop_wide_branch_equals_gram_form(n, p):
+    """The p >= n branch (ref src/oem_dense.h:476-482,513-521: d from XXt/n, u = X'(Y - X b)/n + d b) is the same
+    iteration as the n > p one written on the Gram (u = (dI - X'X/n) b + X'Y/n): the non-zero spectra of XXt and XtX
+    coincide.  The reference holds no known answer for this branch; this ties it to the pinned n > p code."""
+    rng = np.random.default_rng(17)
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 1.5)
+    b = np.zeros(p); b[:6] = rng.uniform(1, 2, 6)
+    y = x @ b + 0.2 * rng.normal(size=n)
+    groups = np.arange(p) // 4 + 1
+    kw = dict(penalty=["lasso", "scad", "grp.lasso"], groups=groups, unique_groups=np.unique(groups), nlambda=15, lambda_min_ratio=0.01, tol=1e-9,
+              maxit=3000)
+    a = orc.fit_dense(x, y, standardize=False, intercept=False, **kw)
+    g = orc.fit_xtx(x.T @ x / n, x.T @ y / n, **kw)
+    assert abs(a["d"] - g["d"]) < 1e-12 * g["d"]
+    for m in range(3):
+        assert np.allclose(a["lambda"][m], g["lambda"][m], rtol=1e-13)
+        assert np.abs(a["beta"][m][1:] - g["beta"][m]).max() < 1e-9
+        assert np.abs(a["niter"][m].astype(int) - g["niter"][m]).max() <= 1
+        assert np.abs(g["beta"][m]).max() > 0.1
