@@ -878,3 +878,169 @@ int orc_fit_big(const double *x, int64_t n, int32_t p, const double *y,
     free(XtXm); free(XX); free(XY); free(colsums); free(pf); free(lam); free(bstd);
     return rc;
 }
+
+/* ------------------------------------------------------------------ */
+/* xval.oem: ref src/oem_xval_dense.cpp:31-482 + src/oem_xval_dense.h.
+ * Per-fold Grams once, K+1 fits on sums of them, per-observation CV error with Welford's update. */
+static int xval_paths(const double *XX, const double *XY, int q, double d, const orc_opts *oo, const double *pf,
+                      const double *lam, int nl, grp_t *g, int *have_g, double *bstd, int32_t *niter)
+{
+    core_t s; memset(&s, 0, sizeof s);
+    if (core_alloc(&s, q)) return -1;
+    double *A = (double *)malloc(sizeof(double) * (size_t)q * q);
+    if (!A) return fail("oracle: out of memory");
+    for (size_t k = 0; k < (size_t)q * q; k++) A[k] = -XX[k];          /* ref: oem_xval_dense.h:786-789, 845-848 */
+    for (int j = 0; j < q; j++) A[(size_t)j * q + j] += d;
+    s.A = A; s.XY = XY; s.d = d;
+    int rc = 0;
+    for (int pp = 0; pp < oo->npen && rc == 0; pp++) {
+        int pen = oo->penalty[pp];
+        int nlam = (pen == ORC_OLS) ? 1 : nl;
+        double ak = 1.0;
+        for (int i = 0; i < nlam; i++) {
+            if (i == 0) {                                                 /* init(): cold start, ref :1039-1058 */
+                memset(s.beta, 0, sizeof(double) * (size_t)q);
+                /* get_group_indexes scans nvars + intercept entries (ref :636), once per solver (found_grp_idx) */
+                if (!*have_g && pen_is_grp(pen)) { if (build_groups(g, oo, q)) { rc = -1; break; } *have_g = 1; }
+            }
+            orc_opts o2 = *oo; o2.accelerate = 0;
+            int it = solve_one(&s, pen, lam[(size_t)pp * nl + i], &o2, pf, g, &ak);
+            if (niter) niter[(size_t)pp * nl + i] = it;
+            memcpy(bstd + ((size_t)pp * nl + i) * q, s.beta, sizeof(double) * (size_t)q);
+        }
+    }
+    free(A); free(s.u);
+    return rc;
+}
+
+int orc_xval_dense(const double *x, int64_t n, int32_t p, const double *y, const int32_t *foldid, int32_t nfolds,
+                   int32_t standardize, int32_t intercept, int32_t type_measure, const orc_opts *o,
+                   double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out,
+                   double *cvm, double *cvsd)
+{
+    if (n <= p) return fail("dimension of x larger than number of observations");     /* ref: oem_xval_dense.h:690-731 */
+    const int off = intercept ? 1 : 0, q = p + off, K = nfolds;
+    const int nl = nl_of(o);
+    const size_t qq = (size_t)q * q;
+    double *fxx = (double *)calloc(qq * K, sizeof(double)), *fxy = (double *)calloc((size_t)q * K, sizeof(double));
+    double *fcs = (double *)calloc((size_t)p * K, sizeof(double));
+    int64_t *fn = (int64_t *)calloc((size_t)K, sizeof(int64_t));
+    double *XX = (double *)malloc(sizeof(double) * qq), *XY = (double *)malloc(sizeof(double) * (size_t)q);
+    double *colsq = (double *)malloc(sizeof(double) * (size_t)p * 2), *colsq_inv = colsq + p;
+    double *pf = (double *)calloc((size_t)q, sizeof(double));
+    double *lam = (double *)malloc(sizeof(double) * (size_t)o->npen * nl);
+    double *bstd = (double *)malloc(sizeof(double) * (size_t)o->npen * nl * q);
+    /* coefficients of every fold fit on the original scale: [fold][pen][lambda][p + 1] */
+    double *bf = (double *)calloc((size_t)K * o->npen * nl * (p + 1), sizeof(double));
+    if (!fxx || !fxy || !fcs || !fn || !XX || !XY || !colsq || !pf || !lam || !bstd || !bf) return fail("oracle: out of memory");
+    for (int j = 0; j < p; j++) pf[j + off] = o->penalty_factor[j];     /* ref: oem_xval_dense.cpp:139-146 */
+    /* per-fold pieces (ref: oem_xval_dense.h:358-484) */
+    for (int64_t i = 0; i < n; i++) {
+        int k = foldid[i] - 1;
+        if (k < 0 || k >= K) return fail("oracle: foldid out of range");
+        double *G = fxx + qq * k, *b = fxy + (size_t)q * k, *cs = fcs + (size_t)p * k;
+        fn[k]++;
+        if (intercept) { G[0] += 1.0; b[0] += y[i]; }
+        for (int c = 0; c < p; c++) {
+            double xc = x[(size_t)c * n + i];
+            b[c + off] += xc * y[i];
+            cs[c] += xc * xc;
+            if (intercept) { G[(size_t)(c + 1) * q] += xc; G[c + 1] += xc; }
+            for (int r = c; r < p; r++) G[(size_t)(c + off) * q + (r + off)] += x[(size_t)r * n + i] * xc;
+        }
+    }
+    for (int k = 0; k < K; k++) {
+        double *G = fxx + qq * k;
+        for (int c = 0; c < p; c++)
+            for (int r = c + 1; r < p; r++) G[(size_t)(r + off) * q + (c + off)] = G[(size_t)(c + off) * q + (r + off)];
+    }
+    grp_t g; memset(&g, 0, sizeof g); int have_g = 0;
+    orc_opts oo = *o; oo.penalty_factor = pf;
+    int rc = 0;
+    for (int ff = 0; ff <= K && rc == 0; ff++) {
+        /* ref: oem_xval_dense.h:733-784 (ff == 0) and :791-853 (update_xtx) */
+        memset(XX, 0, sizeof(double) * qq); memset(XY, 0, sizeof(double) * (size_t)q);
+        for (int j = 0; j < p; j++) colsq[j] = 0.0;
+        int64_t nobs = 0;
+        for (int k = 1; k <= K; k++) {
+            if (k == ff) continue;
+            const double *G = fxx + qq * (k - 1), *b = fxy + (size_t)q * (k - 1), *cs = fcs + (size_t)p * (k - 1);
+            for (size_t t = 0; t < qq; t++) XX[t] += G[t];
+            for (int j = 0; j < q; j++) XY[j] += b[j];
+            for (int j = 0; j < p; j++) colsq[j] += cs[j];
+            nobs += fn[k - 1];
+        }
+        if (nobs <= p) { rc = fail("dimension of x larger than number of observations"); break; }
+        for (int j = 0; j < p; j++) {
+            colsq[j] /= ((double)nobs - 1.0);
+            if (colsq[j] == 0.0) colsq[j] = 1.0;
+            colsq_inv[j] = 1.0 / sqrt(colsq[j]);
+        }
+        if (standardize) {
+            for (int c = 0; c < p; c++)
+                for (int r = 0; r < p; r++)
+                    XX[(size_t)(c + off) * q + (r + off)] = colsq_inv[r] * XX[(size_t)(c + off) * q + (r + off)] * colsq_inv[c];
+            if (intercept) for (int j = 0; j < p; j++) { XX[(size_t)(j + 1) * q] *= colsq_inv[j]; XX[j + 1] *= colsq_inv[j]; }
+            for (int j = 0; j < p; j++) XY[j + off] *= colsq_inv[j];
+        }
+        for (size_t t = 0; t < qq; t++) XX[t] /= (double)nobs;
+        for (int j = 0; j < q; j++) XY[j] /= (double)nobs;
+        double d = (o->d_override > 0) ? o->d_override : orc_eig_max(XX, q) * 1.005;
+        if (ff == 0) {
+            *d_out = d;
+            double lmax = 0.0;                 /* excludes the intercept slot (ref: oem_xval_dense.h:1025-1032) */
+            for (int j = off; j < q; j++) if (fabs(XY[j]) > lmax) lmax = fabs(XY[j]);
+            lambda_grid(o, lmax, lam);
+            for (size_t k = 0; k < (size_t)o->npen * nl; k++) { lambda_out[k] = lam[k]; loss[k] = 1e99; niter[k] = 0; }
+        }
+        rc = xval_paths(XX, XY, q, d, &oo, pf, lam, nl, &g, &have_g, bstd, ff == 0 ? niter : NULL);
+        if (rc) break;
+        for (int pp = 0; pp < o->npen; pp++) {
+            int nlam = (o->penalty[pp] == ORC_OLS) ? 1 : nl;
+            for (int i = 0; i < nl; i++) {
+                double *out = (ff == 0) ? beta + ((size_t)pp * nl + i) * (p + 1)
+                                        : bf + (((size_t)(ff - 1) * o->npen + pp) * nl + i) * (p + 1);
+                for (int j = 0; j <= p; j++) out[j] = 0.0;
+                if (i >= nlam) continue;
+                const double *b = bstd + ((size_t)pp * nl + i) * q;
+                if (intercept) out[0] = b[0];                                   /* get_beta, ref :1069-1086 */
+                for (int j = 0; j < p; j++) out[j + 1] = b[j + off] * (standardize ? colsq_inv[j] : 1.0);
+                if (ff == 0 && o->compute_loss) {                               /* get_loss, ref :1088-1117 */
+                    double l = 0.0;
+                    for (int64_t r = 0; r < n; r++) {
+                        double t = y[r];
+                        for (int j = 0; j < p; j++) t -= x[(size_t)j * n + r] * out[j + 1];
+                        t -= out[0];
+                        l += t * t;
+                    }
+                    loss[(size_t)pp * nl + i] = l;
+                }
+            }
+        }
+    }
+    /* CV error per observation, Welford over i (ref: oem_xval_dense.cpp:343-461) */
+    if (rc == 0)
+        for (int pp = 0; pp < o->npen; pp++) {
+            int nlam = (o->penalty[pp] == ORC_OLS) ? 1 : nl;
+            double *mean = cvm + (size_t)pp * nl, *ss = cvsd + (size_t)pp * nl;
+            for (int i = 0; i < nl; i++) { mean[i] = 0.0; ss[i] = 0.0; }
+            for (int64_t r = 0; r < n; r++) {
+                const double *B = bf + ((size_t)(foldid[r] - 1) * o->npen + pp) * nl * (p + 1);
+                for (int i = 0; i < nlam; i++) {
+                    const double *b = B + (size_t)i * (p + 1);
+                    double pred = 0.0;
+                    for (int j = 0; j < p; j++) pred += x[(size_t)j * n + r] * b[j + 1];
+                    pred += b[0];                                               /* 0 without an intercept */
+                    double res = y[r] - pred;
+                    double v = (type_measure == 1) ? fabs(res) : res * res;
+                    double delta = v - mean[i];
+                    mean[i] += delta / (double)(r + 1);
+                    ss[i] += delta * (v - mean[i]);
+                }
+            }
+            for (int i = 0; i < nlam; i++) ss[i] = sqrt(ss[i] / (double)(n - 1)) / sqrt((double)n);
+        }
+    if (have_g) free_groups(&g);
+    free(fxx); free(fxy); free(fcs); free(fn); free(XX); free(XY); free(colsq); free(pf); free(lam); free(bstd); free(bf);
+    return rc;
+}

@@ -154,6 +154,28 @@ def fit_big(x, y, penalty="elastic.net", standardize=True, intercept=True, nativ
                  C.c_int32(int(standardize)), C.c_int32(int(intercept)), native=native)
 
 
+def xval_dense(x, y, foldid, penalty="elastic.net", standardize=True, intercept=True, type_measure="mse", native=False, **kw):
+    """ref src/oem_xval_dense.cpp:31-482.  foldid: values 1..nfolds.  Adds cvm, cvsd (lists per penalty) to the fit."""
+    x = np.asfortranarray(x, dtype=np.float64); y = _d(y)
+    n, p = x.shape
+    fid = np.ascontiguousarray(foldid, dtype=np.int32)
+    o = _Opts(p, penalty, **kw)
+    L = lib(native)
+    npen, nl = len(o.names), o.nl
+    cvm = np.zeros((npen, nl)); cvsd = np.zeros((npen, nl))
+    beta = np.zeros((npen, nl * (p + 1))); lam = np.zeros((npen, nl))
+    niter = np.zeros((npen, nl), dtype=np.int32); loss = np.zeros((npen, nl)); d = C.c_double(0)
+    rc = L.orc_xval_dense(_ptr(x), C.c_int64(n), C.c_int32(p), _ptr(y), _ptr(fid, _ip), C.c_int32(int(fid.max())),
+                          C.c_int32(int(standardize)), C.c_int32(int(intercept)), C.c_int32({"mse": 0, "mae": 1}[type_measure]),
+                          C.byref(o.c), _ptr(beta), _ptr(lam), _ptr(niter, _ip), _ptr(loss), C.byref(d), _ptr(cvm), _ptr(cvsd))
+    if rc != 0:
+        raise RuntimeError(L.orc_last_error().decode())
+    out = _result(o, beta, lam, niter, loss, d, p + 1)
+    out["cvm"] = [cvm[k, :1].copy() if name == "ols" else cvm[k].copy() for k, name in enumerate(o.names)]
+    out["cvsd"] = [cvsd[k, :1].copy() if name == "ols" else cvsd[k].copy() for k, name in enumerate(o.names)]
+    return out
+
+
 def standardize(x, y, standardize=True, intercept=True):
     x = np.array(x, dtype=np.float64, order="F", copy=True); y = np.array(y, dtype=np.float64, copy=True)
     n, p = x.shape

@@ -56,3 +56,31 @@ class RRng:
             uu = np.floor(_BIG * u[0::2]) + u[1::2]
             out[s:s + m] = ndtri(uu / _BIG)
         return mean + sd * out
+
+    def _unif_index(self, dn):
+        """R_unif_index, sample.kind = "Rejection" (the default since R 3.6.0; RNG.c: rbits + rejection)"""
+        if dn <= 0:
+            return 0
+        bits = int(np.ceil(np.log2(dn)))
+        while True:
+            v = 0
+            for _ in range(0, bits + 1, 16):
+                v = 65536 * v + int(np.floor(self.unif_rand(1)[0] * 65536))
+            if bits < 64:
+                v &= (1 << bits) - 1
+            if v < dn:
+                return v
+
+    def sample(self, x):
+        """sample(x): a random permutation of x (do_sample without replacement, k = n)"""
+        x = np.asarray(x)
+        n = len(x)
+        idx = list(range(n))
+        out = np.empty(n, dtype=np.int64)
+        m = n
+        for i in range(n):
+            j = self._unif_index(m)
+            out[i] = idx[j]
+            m -= 1
+            idx[j] = idx[m]
+        return x[out]

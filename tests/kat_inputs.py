@@ -46,3 +46,18 @@ def kat3():
 def loglik(loss, n):
     """R/methods.R:465-466"""
     return -0.5 * n * (np.log(2 * np.pi) - np.log(n) + np.log(loss)) - 0.5 * n
+
+
+@functools.lru_cache(maxsize=None)
+def kat_xval():
+    """docs/reference/predict.xval.oem.html (source R/methods.R, predict.xval.oem example): the data of kat2, then the
+    fold assignment xval.oem draws itself, foldid = sample(rep(seq(nfolds), length = n)) (R/oem_xval.R:187-188)."""
+    r = RRng(123)
+    n, p, nt = 10000, 100, 1000
+    tb = np.concatenate([r.runif(15, -0.5, 0.5), np.zeros(p - 15)])
+    x = np.asfortranarray(r.rnorm(n * p).reshape(p, n).T)
+    y = r.rnorm(n, sd=3) + x @ tb
+    xt = np.asfortranarray(r.rnorm(nt * p).reshape(p, nt).T)
+    yt = r.rnorm(nt, sd=3) + xt @ tb
+    foldid = r.sample(np.resize(np.arange(1, 11), n)).astype(np.int32)
+    return x, y, xt, yt, foldid

@@ -83,3 +83,49 @@ def test_prop_wide_branch_equals_gram_form(n, p):
         assert np.abs(a["beta"][m][1:] - g["beta"][m]).max() < 1e-9
         assert np.abs(a["niter"][m].astype(int) - g["niter"][m]).max() <= 1
         assert np.abs(g["beta"][m]).max() > 0.1
+
+
+def test_kat4_xval_best_model_test_mse():
+    """docs/reference/predict.xval.oem.html: xval.oem(lasso, grp.lasso; groups rep(1:10, each = 10); nlambda = 10), then the
+    test-set MSE of the full-data fit at each model's lambda.min: 9.099371 (lasso), 9.091854 (grp.lasso = best.model)."""
+    x, y, xt, yt, foldid = K.kat_xval()
+    g = np.concatenate([[0], np.repeat(np.arange(1, 11), 10)])                   # R/oem_xval.R:279-283
+    f = orc.xval_dense(x, y, foldid, penalty=["lasso", "grp.lasso"], groups=g, unique_groups=np.arange(0, 11), nlambda=10,
+                       lambda_min_ratio=1e-4, tol=1e-7, maxit=500)
+    mse = []
+    for k in range(2):
+        b = f["beta"][k][:, int(np.argmin(f["cvm"][k]))]
+        mse.append(float(np.mean((yt - (xt @ b[1:] + b[0])) ** 2)))
+    assert "%.6f" % mse[0] == "9.099371" and "%.6f" % mse[1] == "9.091854"
+    assert np.min(f["cvm"][1]) < np.min(f["cvm"][0])                             # best.model is grp.lasso
+
+
+def test_xval_against_fold_by_fold_numpy():
+    """The restated xval against a direct numpy computation: every fold fit as its own problem (big.oem-style scaling of the
+    other folds' rows, ref src/oem_xval_dense.h:791-853), then mean / sd of the per-observation errors."""
+    rng = np.random.default_rng(4)
+    n, p, K_ = 600, 12, 4
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 2 + 0.5)
+    y = x[:, :3] @ np.array([1.0, -2.0, 0.5]) + rng.normal(size=n) + 1.0
+    foldid = rng.permutation(np.resize(np.arange(1, K_ + 1), n)).astype(np.int32)
+    f = orc.xval_dense(x, y, foldid, penalty=["lasso", "mcp"], nlambda=8, lambda_min_ratio=1e-3, tol=1e-10, maxit=2000,
+                       type_measure="mae")
+    err = np.zeros((2, n, 8))
+    for k in range(1, K_ + 1):
+        tr = foldid != k
+        xs, ys = x[tr], y[tr]; m = xs.shape[0]
+        sc = 1.0 / np.sqrt((xs ** 2).sum(0) / (m - 1))
+        z = np.column_stack([np.ones(m), xs * sc])
+        xx, xy = z.T @ z / m, z.T @ ys / m
+        d = orc.eig_max(xx) * 1.005
+        lam = np.stack([f["lambda"][0], f["lambda"][1]])
+        pf = np.concatenate([[0.0], np.ones(p)])
+        b, _ = orc.path(xx, xy, d, lam, penalty=["lasso", "mcp"], tol=1e-10, maxit=2000, penalty_factor=pf)
+        te = foldid == k
+        for m_ in range(2):
+            coef = b[m_].T if b[m_].shape[0] == 8 else b[m_]                     # (q, nl)
+            pred = x[te] @ (coef[1:] * sc[:, None]) + coef[0]
+            err[m_, te] = np.abs(y[te][:, None] - pred)
+    for m_ in range(2):
+        assert np.allclose(f["cvm"][m_], err[m_].mean(0), rtol=1e-9)
+        assert np.allclose(f["cvsd"][m_], err[m_].std(0, ddof=1) / np.sqrt(n), rtol=1e-8)
