@@ -98,6 +98,16 @@ int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_
                    int32_t standardize, int32_t intercept, const oemgpu_opts *o,
                    double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
 
+/* replaces oem_xval_dense, ref src/oem_xval_dense.cpp:31-482 (family "gaussian", weights empty): xval.oem's fast
+ * cross-validation.  foldid: n values in 1..nfolds.  type_measure: 0 "mse", 1 "mae" (ref :378-411).
+ * beta, lambda_out, niter, loss, d: the fit on ALL rows, laid out as in oemgpu_fit_dense (loss only if compute_loss,
+ * ref :296-301).  cvm, cvsd: npen * nl each -- mean over the n observations of the error of row i under the fit that
+ * left row i's fold out, and sqrt(sample variance / n) of the same (ref :452-461; 0 beyond the single "ols" entry). */
+int oemgpu_xval_dense(const double *x, int64_t n, int32_t p, const double *y, const int32_t *foldid, int32_t nfolds,
+                      int32_t standardize, int32_t intercept, int32_t type_measure, const oemgpu_opts *o,
+                      double *beta, double *lambda_out, int32_t *niter, double *loss, double *d,
+                      double *cvm, double *cvsd);
+
 /* -------------------------------------------------------------------------------------------
  * Device-resident / staged interface.  Used when X already lives in HBM (bench.py, repeated
  * solves) and by the one-process-per-GPU row-sharded driver (oem_amd/distributed.py), which
@@ -140,6 +150,8 @@ int oemgpu_moments_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64_t 
 /* semantics selector for oemgpu_solve_moments_dev */
 #define OEMGPU_SEM_DENSE 0   /* DataStd + oemDense (ref src/DataStd.h, src/oem_dense.h) */
 #define OEMGPU_SEM_BIG   1   /* oemBig: (n-1)-scaling, intercept as Gram row/column (ref src/oem_big.h:731-842,469-566) */
+#define OEMGPU_SEM_XVAL  3   /* oemXvalDense: oemBig's algebra (ref src/oem_xval_dense.h:745-789), lambda_zero without the intercept
+                              * slot (:1025-1032), groups scanned over all p + 1 slots (:636), compute_loss allowed (:1088-1117) */
 
 /* From (all-reduced) moments to the full result: standardisation constants, XX, XY, d, lambda grid,
  * penalty x lambda loops, recover.  Outputs are HOST buffers as in oemgpu_fit_dense. */
@@ -156,6 +168,13 @@ int oemgpu_fit_dense_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64_
 int oemgpu_fit_xtx_dev(oemgpu_ctx *ctx, const double *xtx_dev, const double *xty_dev, int32_t p,
                        const double *scale_factor, const oemgpu_opts *o,
                        double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
+
+/* oemgpu_xval_dense with X (n x p, leading dimension ld >= n), y and foldid already on the device. */
+int oemgpu_xval_dense_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
+                          const int32_t *foldid_dev, int32_t nfolds, int32_t standardize, int32_t intercept,
+                          int32_t type_measure, const oemgpu_opts *o,
+                          double *beta, double *lambda_out, int32_t *niter, double *loss, double *d,
+                          double *cvm, double *cvsd);
 
 /* 1 if the most recent oemgpu_solve_moments_dev on this context found the shift predicate above true for its
  * sums_dev (and so read moments_dev as accumulated about c), 0 if not, -1 for a NULL context.  The row-sharded

@@ -378,6 +378,121 @@ def big_oem(x, y, family="gaussian", penalty=None, weights=(), lambda_=(), nlamb
     return _decorate(a, penalty, varnames, True, n, p)
 
 
+
+# ------------------------------------------------------------------------------------------ xval.oem()
+def _getmin(lam, cvm, cvsd):
+    """R/utils.R:3-26 (getmin)"""
+    lmin_models, l1se_models, cv_models = [], [], []
+    for m in range(len(cvm)):
+        cvmin = np.min(cvm[m])
+        idmin = cvm[m] <= cvmin
+        lmin = np.max(lam[m][idmin])
+        cv_models.append(np.min(cvm[m][idmin]))
+        i0 = int(np.nonzero(lam[m] == lmin)[0][0])
+        semin = (cvm[m] + cvsd[m])[i0]
+        l1se_models.append(np.max(lam[m][cvm[m] < semin]))
+        lmin_models.append(lmin)
+    mmin = int(np.argmin(cv_models))
+    return {"lambda.min": lmin_models[mmin], "model.min": mmin + 1, "lambda.1se": l1se_models[mmin],
+            "lambda.min.models": np.array(lmin_models), "lambda.1se.models": np.array(l1se_models)}
+
+
+_TYPE_MEASURES = ("mse", "deviance", "class", "auc", "mae")
+
+
+def xval_oem(x, y, nfolds=10, foldid=None, type_measure=None, ncores=-1, family="gaussian", penalty=None, weights=(),
+             lambda_=(), nlambda=100, lambda_min_ratio=None, alpha=1.0, gamma=3.0, tau=0.5, groups=(), penalty_factor=None,
+             group_weights=None, standardize=True, intercept=True, maxit=500, tol=1e-7, irls_maxit=100, irls_tol=1e-3,
+             compute_loss=False, varnames=None, rng=None):
+    """xval.oem(): R/oem_xval.R:107-460 (gaussian, dense).  foldid: values 1..nfolds; drawn with `rng` (a numpy Generator)
+    as sample(rep(seq(nfolds), length = n)) when None."""
+    if family not in ("gaussian", "binomial"):
+        raise ValueError("'arg' should be one of 'gaussian', 'binomial'")
+    penalty = _match_penalty(penalty)
+    if type_measure is None:
+        type_measure = "default"
+    elif type_measure not in _TYPE_MEASURES:
+        raise ValueError("'arg' should be one of " + ", ".join("'%s'" % t for t in _TYPE_MEASURES))
+    if family == "binomial":
+        raise ValueError("binomial models not yet supported for xval, use cv.oem() instead")
+    if getattr(x, "ndim", 0) != 2:
+        raise ValueError("x must have at least two columns")
+    n, p = x.shape
+    if p >= n:
+        raise ValueError("number of observations must be greater than the number of variables\n"
+                         "             for xval, use cv.oem instead, or, preferably, use another package such as\n"
+                         "             glmnet for the lasso, ncvreg for MCP/SCAD, or grpreg or gglasso for group lasso.")
+    if p < 2:
+        raise ValueError("x must have at least two columns")
+    if foldid is None:
+        g = np.random.default_rng() if rng is None else rng
+        foldid = g.permutation(np.resize(np.arange(1, int(nfolds) + 1), n))
+    else:
+        foldid = np.asarray(foldid).ravel()
+        nfolds = int(foldid.max())
+    if nfolds < 3:
+        raise ValueError("nfolds must be bigger than 3; nfolds=10 recommended")
+    if type(x).__module__.startswith("scipy.sparse"):
+        raise ValueError("sparse matrices not supported yet")
+    ylen = y.shape[0] if hasattr(y, "shape") else len(y)
+    if ylen != n or len(foldid) != n:
+        raise ValueError("x and y lengths do not match")
+    if len(weights) > 0:
+        raise NotImplementedError("observation weights in xval.oem (ref src/oem_xval_dense.h:486-623) are outside the built path")
+    if penalty_factor is None:
+        penalty_factor = np.ones(p)
+    if varnames is None:
+        varnames = [f"V{i + 1}" for i in range(p)]
+    penalty_factor = np.asarray(penalty_factor, dtype=np.float64).ravel()
+    if len(penalty_factor) != p:
+        raise ValueError("penalty.factor must have same length as number of columns in x")
+    if any("grp" in q for q in penalty) and len(np.ravel(groups)) != p:
+        raise ValueError("groups must have same length as number of columns in x")
+    groups, unique_groups, group_weights = _group_setup(penalty, groups, group_weights, p, bool(intercept))
+    if lambda_min_ratio is None:
+        lambda_min_ratio = 0.01 if n < p else 0.0001
+    _common_checks(nlambda, float(lambda_min_ratio), maxit, irls_maxit, tol, irls_tol)
+    lam_list = _lambda_list(lambda_, len(penalty))
+    if type_measure in ("default", "deviance"):                  # R/oem_xval.R:488-497
+        type_measure = "mse"
+    if type_measure not in ("mse", "mae"):
+        warnings.warn("Only 'mse', 'deviance' or 'mae'  available for Gaussian models; 'mse' used")
+        type_measure = "mse"
+    a = _Args(penalty, lam_list, int(np.ravel(nlambda)[0]), lambda_min_ratio, alpha, gamma, tau, tol, maxit, False,
+              compute_loss, penalty_factor, groups, unique_groups, group_weights)
+    out = a.outputs(p + 1)
+    cvm = np.zeros((a.npen, a.nl)); cvsd = np.zeros((a.npen, a.nl))
+    fid = np.ascontiguousarray(foldid, dtype=np.int32)
+    tm = 1 if type_measure == "mae" else 0
+    lib = L.lib()
+    if _is_torch_cuda(x):
+        import torch
+        xp, n_, p_, ld, keep = _device_matrix(x)
+        yd = y if _is_torch_cuda(y) else torch.as_tensor(np.asarray(y, dtype=np.float64), device=x.device)
+        yd = yd.to(torch.float64).contiguous().reshape(-1)
+        fd = torch.as_tensor(fid, device=x.device)
+        ctx = context(x.device.index)
+        torch.cuda.current_stream(x.device).synchronize()
+        L.check(lib.oemgpu_xval_dense_dev(ctx, xp, n, ld, p, yd.data_ptr(), fd.data_ptr(), int(nfolds), int(bool(standardize)),
+                                          int(bool(intercept)), tm, C.byref(a.c), *out, _dptr(cvm), _dptr(cvsd)))
+        del keep
+    else:
+        xh = np.asfortranarray(x, dtype=np.float64)
+        yh = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+        L.check(lib.oemgpu_xval_dense(_dptr(xh), n, p, _dptr(yh), _iptr(fid), int(nfolds), int(bool(standardize)),
+                                      int(bool(intercept)), tm, C.byref(a.c), *out, _dptr(cvm), _dptr(cvsd)))
+    res = _decorate(a, penalty, varnames, True, n, p)
+    res["cvm"] = [cvm[k, :1].copy() if name == "ols" else cvm[k].copy() for k, name in enumerate(penalty)]
+    res["cvsd"] = [cvsd[k, :1].copy() if name == "ols" else cvsd[k].copy() for k, name in enumerate(penalty)]
+    res["name"] = {"mse": "Mean-Squared Error", "mae": "Mean Absolute Error"}[type_measure]
+    res["foldid"] = fid
+    res.update(_getmin([l[:len(c)] for l, c in zip(res["lambda"], res["cvm"])], res["cvm"], res["cvsd"]))
+    res["cvup"] = [m + s for m, s in zip(res["cvm"], res["cvsd"])]
+    res["cvlo"] = [m - s for m, s in zip(res["cvm"], res["cvsd"])]
+    res["best.model"] = penalty[res["model.min"] - 1]
+    return res
+
+
 # ------------------------------------------------------------------------------------------ consumers
 def predict(fit, newx=None, s=None, which_model=0, type="link"):
     """predict.oem, R/methods.R:48-109 (which_model is 0-based or a penalty name)."""

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace oemgpu {
@@ -44,6 +45,10 @@ struct oemgpu_ctx {
     double ms[OEMGPU_NTIMERS];
     double diag[2] = {0.0, 0.0};   // path kernel: shader cycles, 100 MHz ticks
     int shifted = 0;               // the last solve read its moments as accumulated about the provisional shift
+    char *aux = nullptr;           // xval.oem: fold-ordered copy of X, fold moments, fold coefficients (grow-only)
+    size_t aux_bytes = 0;
+    std::vector<oemgpu_ctx *> kids;   // xval.oem: one child context (stream, workspace, staging) per concurrent fold fit
+    hipEvent_t fork_ev = nullptr;
 };
 
 namespace {
@@ -165,11 +170,14 @@ void build_groups(const oemgpu_opts *o, int q, int nscan, Groups &G)
 
 // ---------------------------------------------------------------- the driver behind all entry points
 // xx (q x q), xy (q), stats already on the device (in the workspace).  sem: OEMGPU_SEM_*, or 2 for oem.xtx.
-enum { SEM_XTX = 2 };
+enum { SEM_XTX = 2 };        // OEMGPU_SEM_XVAL = 3 (oemgpu.h): oemBig's algebra with xval.oem's lambda_zero, groups and loss
 
+// nbatch > 1: that many independent problems (instance b at xx + b * bstride, ... ; outputs of instance b at beta + b * npen * nl *
+// rows, lambda_out / niter / loss + b * npen * nl, d_out[b]) solved by ONE launch, one workgroup (set) each; q <= SMALL_P_MAX only.
 int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const double *stats, int p, int q, int sem,
               int standardize, int intercept, const oemgpu_opts *o, const double *scale_factor,
-              double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out)
+              double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out,
+              int nbatch = 1, size_t bstride = 0)
 {
     const int nl = nl_of(o), npen = o->npen;
     const bool user = o->lambda_user && o->nlambda_user > 0;
@@ -179,13 +187,14 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     // ---- parameter blob
     Blob bl;
     std::vector<double> pf(q, 0.0), sinv;
-    const int off = (sem == OEMGPU_SEM_BIG && intercept) ? 1 : 0;       // leading 0 for the intercept, ref src/oem_big.cpp:105-113
+    const bool biglike = sem == OEMGPU_SEM_BIG || sem == OEMGPU_SEM_XVAL;
+    const int off = (biglike && intercept) ? 1 : 0;       // leading 0 for the intercept, ref src/oem_big.cpp:105-113, src/oem_xval_dense.cpp:139-146
     for (int j = 0; j < p; ++j) pf[j + off] = o->penalty_factor[j];
     if (scale_factor) { sinv.resize(q); for (int j = 0; j < q; ++j) sinv[j] = 1.0 / scale_factor[j]; }
     Groups G;
     oemgpu_opts og = *o;
     if (!any_grp) og.ngroups = 0;
-    build_groups(&og, q, sem == OEMGPU_SEM_BIG ? p : q, G);
+    build_groups(&og, q, sem == OEMGPU_SEM_BIG ? p : q, G);      // quirk Q17 is oemBig's alone (ref src/oem_xval_dense.h:636 scans nvars + intercept)
     const size_t o_pen = bl.add(o->penalty, sizeof(int32_t) * npen);
     const size_t o_lam = user ? bl.add(o->lambda_user, sizeof(double) * (size_t)npen * nl) : 0;
     const size_t o_pf = bl.add(pf.data(), sizeof(double) * q);
@@ -200,12 +209,14 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const size_t nb = (size_t)npen * nl * q, nk = (size_t)npen * nl;
     const size_t out_doubles = nb + 2 * nk + 4 + (size_t)stats_len(p);
     const size_t out_bytes = out_doubles * sizeof(double) + nk * sizeof(int32_t);
+    const size_t out_stride = (out_bytes + 255) / 256 * 256;
     const bool small = q <= SMALL_P_MAX;
+    if (nbatch > 1 && !small) { set_error("internal: batched paths need p <= %d", SMALL_P_MAX); return OEMGPU_ERR_INTERNAL; }
     int lan = q < 128 ? q : 128;
     const size_t work_d = small ? path_small_xchg_bytes() / 8 : path_large_work_doubles(q, lan);
     // the outputs come first: when the caller's frame ends with `stats` (both callers), stats | outputs is one
     // contiguous range and one device-to-host copy returns both
-    const size_t a_out = B.take(out_bytes), a_blob = B.take(bl.h.size()), a_work = B.take(work_d * sizeof(double));
+    const size_t a_out = B.take(out_stride * nbatch), a_blob = B.take(bl.h.size()), a_work = B.take(work_d * sizeof(double) * nbatch);
     // the workspace may be re-allocated by ctx_reserve: xx/xy/stats are offsets into it, so recompute after
     const size_t off_xx = (const char *)xx - c->ws, off_xy = (const char *)xy - c->ws, off_st = (const char *)stats - c->ws;
     if (B.off > c->ws_bytes) { set_error("internal: workspace under-reserved (%zu > %zu)", B.off, c->ws_bytes); return OEMGPU_ERR_INTERNAL; }
@@ -218,14 +229,15 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     // Every output the host reads below is written by the path kernels, so the region is not cleared.  OEM_POISON_OUT=1
     // fills it with NaN bit patterns first: the GPU suite run that way proves nothing depends on stale contents.
     static const bool poison = getenv("OEM_POISON_OUT") != nullptr;
-    if (poison) OEM_HIP(hipMemsetAsync(dout, 0xFF, out_bytes, c->stream));
+    if (poison) OEM_HIP(hipMemsetAsync(dout, 0xFF, out_stride * nbatch, c->stream));
 
     PathArgs a;
     memset(&a, 0, sizeof a);
     a.p = q; a.npen = npen; a.nl = nl; a.user_lambda = user; a.maxit = o->maxit;
     a.accelerate = (sem == OEMGPU_SEM_DENSE) ? (o->accelerate != 0) : 0;           // only oemDense accelerates (quirk Q12)
-    a.compute_loss = (sem == OEMGPU_SEM_DENSE) ? (o->compute_loss != 0) : 0;
+    a.compute_loss = (sem == OEMGPU_SEM_DENSE || sem == OEMGPU_SEM_XVAL) ? (o->compute_loss != 0) : 0;
     a.ngroups = og.ngroups; a.lanczos_steps = lan; a.yscale = (sem == OEMGPU_SEM_DENSE);
+    a.lmax_from = (sem == OEMGPU_SEM_XVAL) ? off : 0;              // ref src/oem_xval_dense.h:1025-1032
     a.alpha = o->alpha; a.gamma = o->gamma; a.tau = o->tau; a.tol = o->tol; a.lambda_min_ratio = o->lambda_min_ratio;
     a.xx = xx; a.xy = xy; a.stats = stats;
     a.penalty = (const int *)(dblob + o_pen);
@@ -238,66 +250,73 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     double *dstats = a.d_out + 4;
     a.niter = (int *)(dstats + stats_len(p));
     a.work = (double *)(c->ws + a_work);
+    a.nbatch = nbatch; a.bs_xx = a.bs_xy = a.bs_stats = (long long)bstride; a.bs_out = (long long)out_stride; a.bs_work = (long long)work_d;
 
     const size_t st_gap = (size_t)((const char *)dout - (const char *)stats);
-    const bool joined = (const char *)stats < (const char *)dout && st_gap == ((size_t)stats_len(p) * 8 + 255) / 256 * 256;
-    const size_t back_bytes = out_bytes + (joined ? st_gap : 0);
+    const bool joined = nbatch == 1 && (const char *)stats < (const char *)dout && st_gap == ((size_t)stats_len(p) * 8 + 255) / 256 * 256;
+    const size_t back_bytes = nbatch > 1 ? out_stride * nbatch : out_bytes + (joined ? st_gap : 0);
     if (ctx_pinned(c, back_bytes > 16384 ? back_bytes : 16384)) return OEMGPU_ERR_HIP;
     {
         Timer t(c, OEMGPU_T_EIGPATH);
         int rc = small ? launch_path_small(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned);
         if (rc) return rc;
     }
-    if (!joined) OEM_HIP(hipMemcpyAsync(dstats, stats, sizeof(double) * stats_len(p), hipMemcpyDeviceToDevice, c->stream));
+    if (!joined) OEM_HIP(hipMemcpy2DAsync(dstats, out_stride, stats, bstride * sizeof(double), sizeof(double) * stats_len(p), nbatch,
+                                          hipMemcpyDeviceToDevice, c->stream));
     OEM_HIP(hipMemcpyAsync(c->pinned, joined ? (const void *)stats : (const void *)dout, back_bytes, hipMemcpyDeviceToHost, c->stream));
     OEM_HIP(hipStreamSynchronize(c->stream));
 
     // ---- unpack (ref src/oem_dense.cpp:249-294, src/DataStd.h:269-293, src/oem_big.h:880-897, src/oem_big.cpp:213-220)
-    const double *hb = (const double *)((const char *)c->pinned + (joined ? st_gap : 0)), *hl = hb + nb, *hloss = hl + nk,
-                 *hd = hloss + nk, *hs = joined ? (const double *)c->pinned : hd + 4;
-    const int32_t *hn = (const int32_t *)(hd + 4 + stats_len(p));
-    *d_out = hd[0];
-    if (hd[1] < 0.0) { set_error("cooperating workgroups lost each other (exchange timeout)"); return OEMGPU_ERR_INTERNAL; }
-    c->diag[0] = hd[2]; c->diag[1] = hd[3];
-    c->shifted = hs[stats_shift_flag(p)] != 0.0;
-    const double meany = hs[0], scaley = hs[1];
-    const double *meanx = hs + 4, *scalex = hs + 4 + p;
     const int flag = (standardize ? 1 : 0) + 2 * (intercept ? 1 : 0);
     const int rows = (sem == SEM_XTX) ? p : p + 1;
-    for (int k = 0; k < npen; ++k) {
-        const int nlam = (o->penalty[k] == OEMGPU_OLS) ? 1 : nl;
-        for (int i = 0; i < nl; ++i) {
-            const size_t ki = (size_t)k * nl + i;
-            lambda_out[ki] = hl[ki];
-            niter[ki] = (i < nlam) ? hn[ki] : 0;
-            loss[ki] = (i < nlam && a.compute_loss) ? hloss[ki] : 1e99;
-            double *ob = beta + ki * rows;
-            const double *b = hb + ki * q;
-            if (i >= nlam) { for (int j = 0; j < rows; ++j) ob[j] = 0.0; continue; }
-            if (sem == SEM_XTX) {
-                for (int j = 0; j < p; ++j) ob[j] = b[j];
-            } else if (sem == OEMGPU_SEM_BIG) {
-                ob[0] = intercept ? b[0] : 0.0;
-                for (int j = 0; j < p; ++j) ob[j + 1] = b[j + off] * (standardize ? scalex[j] : 1.0);
-            } else {
-                double s = 0.0;
-                for (int j = 0; j < p; ++j) {
-                    double cf = b[j];
-                    if (flag & 1) cf /= scalex[j];
-                    if (flag != 0) cf *= scaley;
-                    if (flag & 2) s += cf * meanx[j];
-                    ob[j + 1] = cf;
+    for (int bi = 0; bi < nbatch; ++bi) {
+        const double *hb = (const double *)((const char *)c->pinned + (joined ? st_gap : 0) + (size_t)bi * out_stride), *hl = hb + nb,
+                     *hloss = hl + nk, *hd = hloss + nk, *hs = joined ? (const double *)c->pinned : hd + 4;
+        const int32_t *hn = (const int32_t *)(hd + 4 + stats_len(p));
+        double *beta_b = beta + (size_t)bi * nk * rows, *lambda_b = lambda_out + (size_t)bi * nk, *loss_b = loss + (size_t)bi * nk;
+        int32_t *niter_b = niter + (size_t)bi * nk;
+        d_out[bi] = hd[0];
+        if (hd[1] < 0.0) { set_error("cooperating workgroups lost each other (exchange timeout)"); return OEMGPU_ERR_INTERNAL; }
+        c->diag[0] = hd[2]; c->diag[1] = hd[3];
+        c->shifted = hs[stats_shift_flag(p)] != 0.0;
+        const double meany = hs[0], scaley = hs[1];
+        const double *meanx = hs + 4, *scalex = hs + 4 + p;
+        for (int k = 0; k < npen; ++k) {
+            const int nlam = (o->penalty[k] == OEMGPU_OLS) ? 1 : nl;
+            for (int i = 0; i < nl; ++i) {
+                const size_t ki = (size_t)k * nl + i;
+                lambda_b[ki] = hl[ki];
+                niter_b[ki] = (i < nlam) ? hn[ki] : 0;
+                loss_b[ki] = (i < nlam && a.compute_loss) ? hloss[ki] : 1e99;
+                double *ob = beta_b + ki * rows;
+                const double *b = hb + ki * q;
+                if (i >= nlam) { for (int j = 0; j < rows; ++j) ob[j] = 0.0; continue; }
+                if (sem == SEM_XTX) {
+                    for (int j = 0; j < p; ++j) ob[j] = b[j];
+                } else if (biglike) {
+                    ob[0] = intercept ? b[0] : 0.0;
+                    for (int j = 0; j < p; ++j) ob[j + 1] = b[j + off] * (standardize ? scalex[j] : 1.0);
+                } else {
+                    double s = 0.0;
+                    for (int j = 0; j < p; ++j) {
+                        double cf = b[j];
+                        if (flag & 1) cf /= scalex[j];
+                        if (flag != 0) cf *= scaley;
+                        if (flag & 2) s += cf * meanx[j];
+                        ob[j + 1] = cf;
+                    }
+                    ob[0] = (flag & 2) ? meany - s : 0.0;
                 }
-                ob[0] = (flag & 2) ? meany - s : 0.0;
             }
         }
     }
     return 0;
 }
 
-size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o)
+size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o, int nbatch = 1)
 {
     const int nl = nl_of(o);
+    if (nbatch > 1) return (size_t)nbatch * (paths_ws_bytes(p, q, o) + 1024);
     size_t b = 0;
     b += (size_t)o->npen * 4 + (size_t)o->npen * nl * 8 + (size_t)q * (8 + 8 + 4) + (size_t)(o->ngroups + 2) * 16 +
          (size_t)(o->ngroupvars + q + 2) * 4 + 4096;
@@ -372,6 +391,9 @@ void oemgpu_destroy(oemgpu_ctx *c)
     if (c->ws) (void)hipFree(c->ws);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned_in) (void)hipHostFree(c->pinned_in);
+    if (c->aux) (void)hipFree(c->aux);
+    for (oemgpu_ctx *k : c->kids) oemgpu_destroy(k);
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->ev_made) for (int i = 0; i < 2 * OEMGPU_NTIMERS; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -440,8 +462,8 @@ int oemgpu_solve_moments_dev(oemgpu_ctx *c, const double *moments_dev, const dou
                              double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
 {
     if (!c || !moments_dev || !beta || !lambda_out || !niter || !loss || !d) { set_error("solve_moments: NULL argument"); return OEMGPU_ERR_ARG; }
-    if (semantics != OEMGPU_SEM_DENSE && semantics != OEMGPU_SEM_BIG) { set_error("unknown semantics %d", semantics); return OEMGPU_ERR_ARG; }
-    const int q = p + ((semantics == OEMGPU_SEM_BIG && intercept) ? 1 : 0);
+    if (semantics != OEMGPU_SEM_DENSE && semantics != OEMGPU_SEM_BIG && semantics != OEMGPU_SEM_XVAL) { set_error("unknown semantics %d", semantics); return OEMGPU_ERR_ARG; }
+    const int q = p + ((semantics != OEMGPU_SEM_DENSE && intercept) ? 1 : 0);
     int rc = check_opts(o, p, q);
     if (rc) return rc;
     if (semantics == OEMGPU_SEM_BIG && o->compute_loss) {
@@ -681,6 +703,196 @@ int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_
     if (xd) (void)hipFree(xd);
     if (yd) (void)hipFree(yd);
     if (acc) (void)hipFree(acc);
+    oemgpu_destroy(c);
+    return rc;
+}
+
+// nbatch moment buffers (instance b at moments + b * mstride, all OUTSIDE the context workspace), one finalize each, then ONE
+// launch that walks all their paths side by side (q <= SMALL_P_MAX).  Outputs as in run_paths.
+static int solve_moments_batch(oemgpu_ctx *c, const double *moments, size_t mstride, int nbatch, int32_t p, int32_t semantics,
+                               int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                               double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    const int q = p + ((semantics != OEMGPU_SEM_DENSE && intercept) ? 1 : 0);
+    Bump B;
+    const size_t per = ((size_t)q * q * 8 + 255) / 256 * 256 + ((size_t)q * 8 + 255) / 256 * 256 + ((size_t)stats_len(p) * 8 + 255) / 256 * 256;
+    const size_t a_0 = B.take(per * nbatch);
+    if (ctx_reserve(c, B.off + paths_ws_bytes(p, q, o, nbatch) + 4096)) return OEMGPU_ERR_HIP;
+    const size_t o_xy = ((size_t)q * q * 8 + 255) / 256 * 256, o_st = o_xy + ((size_t)q * 8 + 255) / 256 * 256;
+    for (int b = 0; b < nbatch; ++b) {
+        char *f = c->ws + a_0 + per * b;
+        int rc = launch_finalize(c->stream, moments + mstride * b, nullptr, p, semantics, standardize, intercept, (double *)f,
+                                 (double *)(f + o_xy), (double *)(f + o_st));
+        if (rc) return rc;
+    }
+    char *f0 = c->ws + a_0;
+    return run_paths(c, B, (const double *)f0, (const double *)(f0 + o_xy), (const double *)(f0 + o_st), p, q, semantics, standardize,
+                     intercept, o, nullptr, beta, lambda_out, niter, loss, d, nbatch, per / 8);
+}
+
+// ---------------------------------------------------------------------------------------------- xval.oem
+static int ctx_aux(oemgpu_ctx *c, size_t bytes)
+{
+    if (bytes <= c->aux_bytes) return 0;
+    if (c->aux) { OEM_HIP(hipStreamSynchronize(c->stream)); OEM_HIP(hipFree(c->aux)); c->aux = nullptr; c->aux_bytes = 0; }
+    OEM_HIP(hipMalloc((void **)&c->aux, bytes));
+    c->aux_bytes = bytes;
+    return 0;
+}
+
+int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
+                          const int32_t *foldid_dev, int32_t nfolds, int32_t standardize, int32_t intercept,
+                          int32_t type_measure, const oemgpu_opts *o,
+                          double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, double *cvm, double *cvsd)
+{
+    if (!c || !x_dev || !y_dev || !foldid_dev || !beta || !lambda_out || !niter || !loss || !d || !cvm || !cvsd) {
+        set_error("xval_dense: NULL argument"); return OEMGPU_ERR_ARG;
+    }
+    const int K = nfolds, q = p + (intercept ? 1 : 0);
+    int rc = check_opts(o, p, q);
+    if (rc) return rc;
+    if (K < 2 || K > 1024) { set_error("xval_dense: nfolds must be in 2..1024"); return OEMGPU_ERR_ARG; }
+    if (type_measure != 0 && type_measure != 1) { set_error("xval_dense: type_measure must be 0 (mse) or 1 (mae)"); return OEMGPU_ERR_ARG; }
+    if (n < 1 || ld < n) { set_error("xval_dense: bad n / ld"); return OEMGPU_ERR_ARG; }
+    if (n <= p) { set_error("dimension of x larger than number of observations"); return OEMGPU_ERR_UNSUPPORTED; }   // ref src/oem_xval_dense.h:690-731
+    if (n + 16 * (int64_t)K >= (int64_t)1 << 31) { set_error("xval_dense: n too large for 32-bit row positions"); return OEMGPU_ERR_UNSUPPORTED; }
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    const int nl = nl_of(o), npen = o->npen;
+    const int64_t ldp = (n + 16 * (int64_t)K + 15) / 16 * 16;
+    const size_t mlen = (size_t)oemgpu_moments_len(p);
+    const int nwg = cv_wg_per_fold(n, K, npen, c->num_cu);
+    // the largest moment plan over the folds is bounded by the plan of all n rows
+    const GramPlan plmax = gram_plan(n, p, c->num_cu);
+    Bump A;
+    const size_t a_cnt = A.take(fold_layout_ints(n, K) * sizeof(int)), a_fn = A.take(sizeof(int64_t) * 2 * K), a_bad = A.take(256),
+                 a_pos = A.take(sizeof(int) * (size_t)n), a_xp = A.take(sizeof(double) * (size_t)ldp * p),
+                 a_yp = A.take(sizeof(double) * (size_t)ldp), a_mf = A.take(sizeof(double) * mlen * K),
+                 a_mc = A.take(sizeof(double) * mlen), a_ms = A.take(sizeof(double) * mlen * K), a_t = A.take(plmax.tpart_doubles * 8 * 2), a_v = A.take(plmax.vpart_doubles * 8 * 2),
+                 a_b = A.take(sizeof(double) * (size_t)K * npen * nl * (p + 1)),
+                 a_part = A.take(sizeof(double) * cv_part_doubles(nwg, K, npen, nl)), a_out = A.take(sizeof(double) * 2 * (size_t)npen * nl);
+    if (ctx_aux(c, A.off)) return OEMGPU_ERR_HIP;
+    char *ax = c->aux;
+    int *blockcnt = (int *)(ax + a_cnt), *bad = (int *)(ax + a_bad), *pos = (int *)(ax + a_pos);
+    int64_t *fold_n = (int64_t *)(ax + a_fn), *fold_start = fold_n + K;
+    double *xp = (double *)(ax + a_xp), *yp = (double *)(ax + a_yp), *mfold = (double *)(ax + a_mf), *mcur = (double *)(ax + a_mc);
+    double *bdev = (double *)(ax + a_b), *part = (double *)(ax + a_part), *cvout = (double *)(ax + a_out);
+
+    // ---- rows into fold order
+    rc = launch_fold_layout(c->stream, foldid_dev, n, K, blockcnt, fold_n, fold_start, pos, bad);
+    if (rc) return rc;
+    std::vector<int64_t> hf(2 * K);
+    int hbad = 0;
+    OEM_HIP(hipMemcpyAsync(hf.data(), fold_n, sizeof(int64_t) * 2 * K, hipMemcpyDeviceToHost, c->stream));
+    OEM_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    rc = launch_gather_rows(c->stream, x_dev, n, ld, p, y_dev, pos, xp, ldp, yp);
+    if (rc) return rc;
+    OEM_HIP(hipStreamSynchronize(c->stream));
+    if (hbad) { set_error("xval_dense: foldid must hold values in 1..nfolds"); return OEMGPU_ERR_ARG; }
+    // ---- per-fold moments about 0 (ref src/oem_xval_dense.h:358-484), one MFMA pass per fold segment
+    for (int k = 0; k < K; ++k) {
+        const int64_t nk = hf[k], st = hf[K + k];
+        if (n - nk <= p) { set_error("dimension of x larger than number of observations"); return OEMGPU_ERR_UNSUPPORTED; }  // ref :849-852
+        if (nk == 0) { OEM_HIP(hipMemsetAsync(mfold + mlen * k, 0, sizeof(double) * mlen, c->stream)); continue; }
+        const GramPlan pl = gram_plan(nk, p, c->num_cu);
+        if (pl.tpart_doubles > 2 * plmax.tpart_doubles || pl.vpart_doubles > 2 * plmax.vpart_doubles) {
+            set_error("internal: fold plan larger than its scratch"); return OEMGPU_ERR_INTERNAL;
+        }
+        rc = shard_moments(c, pl, xp + st, nk, ldp, yp + st, nullptr, (double *)(ax + a_t), (double *)(ax + a_v), mfold + mlen * k);
+        if (rc) return rc;
+    }
+    // ---- the full-data fit (ff = 0), then one fit per left-out fold on the lambdas of the first (ref src/oem_xval_dense.cpp:213-340)
+    rc = launch_fold_sum(c->stream, mfold, K, mlen, 0, mcur);
+    if (rc) return rc;
+    rc = oemgpu_solve_moments_dev(c, mcur, nullptr, p, OEMGPU_SEM_XVAL, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+    if (rc) return rc;
+    // The K fold fits are independent of each other (each a chain of tiny dependent steps on ONE workgroup): they run
+    // concurrently, one host thread + child context (own stream, workspace, staging buffers) per fold.
+    oemgpu_opts of = *o;
+    of.lambda_user = lambda_out; of.nlambda_user = nl; of.compute_loss = 0;
+    const size_t blen = (size_t)npen * nl * (p + 1), nk2 = (size_t)npen * nl;
+    std::vector<double> hb(blen * K), hl(nk2 * K), hloss(nk2 * K), hd(K);
+    std::vector<int32_t> hn(nk2 * K);
+    double *msum = (double *)(ax + a_ms);
+    for (int ff = 1; ff <= K; ++ff) {
+        rc = launch_fold_sum(c->stream, mfold, K, mlen, ff, msum + mlen * (ff - 1));
+        if (rc) return rc;
+    }
+    if (q <= SMALL_P_MAX) {
+        // one launch, one workgroup (set) per fold (hardware queues are few: K streams would run four at a time)
+        rc = solve_moments_batch(c, msum, mlen, K, p, OEMGPU_SEM_XVAL, standardize, intercept, &of, hb.data(), hl.data(), hn.data(),
+                                 hloss.data(), hd.data());
+        if (rc) return rc;
+    } else {
+        while ((int)c->kids.size() < K) {
+            oemgpu_ctx *kid = oemgpu_create(c->device, nullptr);
+            if (!kid) return OEMGPU_ERR_HIP;
+            c->kids.push_back(kid);
+        }
+        if (!c->fork_ev) OEM_HIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+        OEM_HIP(hipEventRecord(c->fork_ev, c->stream));
+        for (int ff = 1; ff <= K; ++ff) OEM_HIP(hipStreamWaitEvent(c->kids[ff - 1]->stream, c->fork_ev, 0));
+        {
+            std::vector<int> rcs(K, 0);
+            std::vector<std::string> errs(K);
+            std::vector<std::thread> th;
+            th.reserve(K);
+            for (int ff = 1; ff <= K; ++ff)
+                th.emplace_back([&, ff]() {
+                    const int i = ff - 1;
+                    rcs[i] = oemgpu_solve_moments_dev(c->kids[i], msum + mlen * i, nullptr, p, OEMGPU_SEM_XVAL, standardize, intercept, &of,
+                                                      hb.data() + blen * i, hl.data() + nk2 * i, hn.data() + nk2 * i, hloss.data() + nk2 * i,
+                                                      &hd[i]);
+                    if (rcs[i]) errs[i] = oemgpu_last_error();          // the message lives in this thread
+                });
+            for (auto &t : th) t.join();
+            for (int i = 0; i < K; ++i)
+                if (rcs[i]) { set_error("fold %d: %s", i + 1, errs[i].c_str()); return rcs[i]; }
+        }
+    }
+    // ---- per-observation error of every row under the fit that left its fold out (ref src/oem_xval_dense.cpp:343-461)
+    OEM_HIP(hipMemcpyAsync(bdev, hb.data(), sizeof(double) * blen * K, hipMemcpyHostToDevice, c->stream));
+    rc = launch_cv_error(c->stream, xp, ldp, yp, fold_start, fold_n, K, p, bdev, npen, nl, type_measure, nwg, (double)n, part, cvout);
+    if (rc) { if (rc == OEMGPU_ERR_UNSUPPORTED) set_error("xval_dense: p too large for the CV-error kernel's LDS tile"); return rc; }
+    std::vector<double> hc(2 * (size_t)npen * nl);
+    OEM_HIP(hipMemcpyAsync(hc.data(), cvout, sizeof(double) * hc.size(), hipMemcpyDeviceToHost, c->stream));
+    OEM_HIP(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < npen; ++k) {
+        const int nlam = (o->penalty[k] == OEMGPU_OLS) ? 1 : nl;
+        for (int i = 0; i < nl; ++i) {
+            const size_t ki = (size_t)k * nl + i;
+            cvm[ki] = i < nlam ? hc[2 * ki] : 0.0;
+            cvsd[ki] = i < nlam ? hc[2 * ki + 1] : 0.0;
+        }
+    }
+    return 0;
+}
+
+int oemgpu_xval_dense(const double *x, int64_t n, int32_t p, const double *y, const int32_t *foldid, int32_t nfolds,
+                      int32_t standardize, int32_t intercept, int32_t type_measure, const oemgpu_opts *o,
+                      double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, double *cvm, double *cvsd)
+{
+    if (!x || !y || !foldid || !o) { set_error("xval_dense: NULL argument"); return OEMGPU_ERR_ARG; }
+    int rc = check_opts(o, p, p + (intercept ? 1 : 0));
+    if (rc) return rc;
+    oemgpu_ctx *c = oemgpu_create(o->device, nullptr);
+    if (!c) return OEMGPU_ERR_NO_DEVICE;
+    double *xd = nullptr, *yd = nullptr;
+    int32_t *fd = nullptr;
+    int64_t ld = 0;
+    rc = upload_matrix(c, x, n, p, &xd, &ld);
+    if (!rc) {
+        hipError_t e = hipMalloc((void **)&yd, sizeof(double) * (size_t)(n + 2));
+        if (e == hipSuccess) e = hipMalloc((void **)&fd, sizeof(int32_t) * (size_t)n);
+        if (e == hipSuccess) e = hipMemcpyAsync(yd, y, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(fd, foldid, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { set_error("upload of y / foldid failed: %s", hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; }
+    }
+    if (!rc) rc = oemgpu_xval_dense_dev(c, xd, n, ld, p, yd, fd, nfolds, standardize, intercept, type_measure, o, beta, lambda_out,
+                                        niter, loss, d, cvm, cvsd);
+    (void)hipStreamSynchronize(c->stream);
+    if (xd) (void)hipFree(xd);
+    if (yd) (void)hipFree(yd);
+    if (fd) (void)hipFree(fd);
     oemgpu_destroy(c);
     return rc;
 }

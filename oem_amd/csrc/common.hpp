@@ -51,6 +51,18 @@ int launch_finalize(hipStream_t s, const double *moments, const double *sums, in
 int launch_xtx_prepare(hipStream_t s, const double *xtx, const double *xty, const double *sf_inv /* or null */, int p,
                        double *xx, double *xy, double *stats);
 
+// ------------------------------------------------------------------ xval.oem (xval.hip)
+size_t fold_layout_ints(int64_t n, int K);
+int launch_fold_layout(hipStream_t s, const int *foldid, int64_t n, int K, int *blockcnt, int64_t *fold_n, int64_t *fold_start,
+                       int *pos, int *bad);
+int launch_gather_rows(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, const int *pos,
+                       double *xo, int64_t ldo, double *yo);
+int launch_fold_sum(hipStream_t s, const double *M, int K, size_t len, int skip /* 1-based, 0: none */, double *out);
+int cv_wg_per_fold(int64_t n, int K, int npen, int num_cu);
+size_t cv_part_doubles(int nwg, int K, int npen, int nl);
+int launch_cv_error(hipStream_t s, const double *xp, int64_t ldp, const double *yp, const int64_t *fold_start, const int64_t *fold_n,
+                    int K, int p, const double *B, int npen, int nl, int mae, int nwg, double n, double *part, double *out);
+
 // ------------------------------------------------------------------ eigen + path
 struct PathArgs {
     int p;                   // dimension of beta (q)
@@ -58,6 +70,7 @@ struct PathArgs {
     int ngroups;             // 0 when no group data
     int lanczos_steps;       // eigen step: number of Lanczos steps (<= p)
     int yscale;              // 1: ilambda = lambda / scaleY and lmax *= scaleY (dense); 0: xtx / big
+    int lmax_from;           // lambda_zero = max |xy[j]| over j >= lmax_from (1: xval.oem leaves the intercept slot out, ref src/oem_xval_dense.h:1025-1032)
     double alpha, gamma, tau, tol, lambda_min_ratio;
     const double *xx;        // q x q col-major, ld = q
     const double *xy;        // q
@@ -79,7 +92,25 @@ struct PathArgs {
     double *d_out;           // [0] = d, [1] = lambda_max
     // workspace for the large-p engine
     double *work;
+    // nbatch > 1 (p <= SMALL_P_MAX only): blockIdx.y selects one of nbatch independent problems that share everything above
+    // except xx, xy, stats (element strides bs_xx, bs_xy, bs_stats), the outputs (byte stride bs_out) and work (bs_work)
+    int nbatch;
+    long long bs_xx, bs_xy, bs_stats, bs_out, bs_work;
 };
+
+// the problem instance of this workgroup (see PathArgs::nbatch); all scalar arithmetic
+__device__ __forceinline__ PathArgs path_instance(PathArgs A)
+{
+    if (A.nbatch > 1) {
+        const long long b = blockIdx.y;
+        A.xx += b * A.bs_xx; A.xy += b * A.bs_xy; A.stats += b * A.bs_stats; A.work += b * A.bs_work;
+        const long long ob = b * A.bs_out;
+        A.beta = (double *)((char *)A.beta + ob); A.lambda_out = (double *)((char *)A.lambda_out + ob);
+        A.loss = (double *)((char *)A.loss + ob); A.d_out = (double *)((char *)A.d_out + ob);
+        A.niter = (int *)((char *)A.niter + ob);
+    }
+    return A;
+}
 
 static const int SMALL_P_MAX = 288;     // one workgroup where the matrix fits its registers (+ LDS); else four cooperating workgroups (big.oem's p + 1 = 257 included)
 size_t path_small_xchg_bytes();

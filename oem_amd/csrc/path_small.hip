@@ -648,8 +648,9 @@ __device__ __forceinline__ void iterate(const PathArgs &A, const PenK &K, double
 }
 
 template <int R, int NW, int CW, int G>
-__global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
+__global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
 {
+    const PathArgs A = path_instance(A_);
     static_assert(CW % 2 == 0, "the broadcast strip is read in pairs");
     typedef Cfg<R, NW, CW> C;
     constexpr int PR = C::PR;
@@ -795,7 +796,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A)
     const double yy = A.stats[2], nobs = A.stats[3];
     double lmax = 0.0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) lmax = fmax(lmax, fabs(xy[r]));
+    for (int r = 0; r < R; ++r) lmax = fmax(lmax, (lane + 64 * r >= A.lmax_from) ? fabs(xy[r]) : 0.0);
     lmax = wave_max(lmax) * scaley;
     const int nl = A.nl;
     const double llo = log(lmax), lhi = log(A.lambda_min_ratio * lmax);
@@ -1190,8 +1191,9 @@ __device__ __forceinline__ void iterate_rows_t(const PathArgs &A, const PenK &K,
     }
 }
 template <int NW, int CG, int CGL>
-__global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A)
+__global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
 {
+    const PathArgs A = path_instance(A_);
     typedef RowsCfg<NW, CG, CGL> C;
     constexpr int NBC = C::NBC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1330,7 +1332,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A)
     double lmax;
     {
         // max |xy| over all rows: wave maxima through per-lane words, then a max over the four words
-        const double wm = wave_max(fabs(xy));
+        const double wm = wave_max(row >= A.lmax_from ? fabs(xy) : 0.0);      // padding lanes: xy = 0
         S.XN[(par * NW + w) * 64 + lane] = wm;
         __syncthreads();
         const double x = S.XN[(par * NW + (lane & (NW - 1))) * 64 + lane];
@@ -1443,7 +1445,7 @@ template <int NW, int CG, int CGL = 0> int launch_rows(hipStream_t s, const Path
     const size_t sh = (size_t)RowsCfg<NW, CG, CGL>::N_DBL * sizeof(double);
     if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_rows_kernel<NW, CG, CGL>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    hipLaunchKernelGGL((path_rows_kernel<NW, CG, CGL>), dim3(1), dim3(NW * 64), sh, s, a);
+    hipLaunchKernelGGL((path_rows_kernel<NW, CG, CGL>), dim3(1, a.nbatch > 1 ? a.nbatch : 1), dim3(NW * 64), sh, s, a);
     OEM_HIP(hipGetLastError());
     return 0;
 }
@@ -1452,13 +1454,17 @@ template <int R, int NW, int CW, int G = 1> int launch_cfg(hipStream_t s, const 
 {
     typedef Cfg<R, NW, CW> C;
     const size_t sh = (size_t)C::N_DBL * sizeof(double);
-    if (G > 1) OEM_HIP(hipMemsetAsync(a.work, 0, path_small_xchg_bytes(), s));      // granule tags must start at 0
+    const int nbatch = a.nbatch > 1 ? a.nbatch : 1;
+    if (G > 1) {                                                                    // granule tags must start at 0
+        if (nbatch > 1 && (size_t)a.bs_work * 8 != path_small_xchg_bytes()) { set_error("internal: batch work stride"); return OEMGPU_ERR_INTERNAL; }
+        OEM_HIP(hipMemsetAsync(a.work, 0, path_small_xchg_bytes() * nbatch, s));
+    }
     if (sh > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&path_small_kernel<R, NW, CW, G>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %zu): %s", sh, hipGetErrorString(e)); return OEMGPU_ERR_HIP; }
     }
-    hipLaunchKernelGGL((path_small_kernel<R, NW, CW, G>), dim3(G), dim3(NW * 64), sh, s, a);
+    hipLaunchKernelGGL((path_small_kernel<R, NW, CW, G>), dim3(G, nbatch), dim3(NW * 64), sh, s, a);
     OEM_HIP(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,338 @@
+// xval.hip -- the device side of xval.oem (ref src/oem_xval_dense.{h,cpp}).
+//
+// The reference builds one Gram per fold from a gathered copy of the fold's rows (ref src/oem_xval_dense.h:358-484), fits
+// K+1 models on sums of them (:733-853) and then walks the observations once more for the cross-validation error
+// (ref src/oem_xval_dense.cpp:343-461).  Here:
+//   * fold layout: rows are permuted ONCE into fold-contiguous order (stable inside a fold, so every run sums in the same
+//     order): block histograms -> per-fold scan -> stable ranks by wave ballots -> a gather pass (coalesced reads, K write
+//     streams).  Fold segments start on multiples of 16 rows, so each one meets the alignment the MFMA Gram kernels want;
+//   * per-fold moments: the one-pass moment kernels of gram.hip on each segment (launched from api.hip);
+//   * leave-one-fold-out sums: fold_sum_kernel, in fold order like the reference;
+//   * CV error: predictions of a fold's rows under that fold's K-th fit for ALL lambdas are an (n_k x p) x (p x nlambda)
+//     product -- as many flops as the Gram build -- so it runs on the FP64 MFMA pipe: a 16-row tile of X against 16-lambda
+//     tiles of the coefficient matrix held in LDS, the intercept riding along as one more column of ones.  The epilogue
+//     turns the accumulators into squared / absolute residuals and keeps per-lambda sums of the error and its square;
+//     workgroup partials are combined in a fixed order.
+#include "common.hpp"
+
+namespace oemgpu {
+namespace {
+
+constexpr int FB = 1024;                 // rows per layout block
+
+// ---------------------------------------------------------------------------------------- fold layout
+__global__ __launch_bounds__(FB) void fold_count_kernel(const int *__restrict__ foldid, int64_t n, int K,
+                                                        int *__restrict__ blockcnt, int *__restrict__ bad)
+{
+    extern __shared__ int hist[];
+    for (int k = threadIdx.x; k < K; k += FB) hist[k] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * FB + threadIdx.x;
+    if (i < n) {
+        const int f = foldid[i];
+        if (f < 1 || f > K) atomicOr(bad, 1);
+        else atomicAdd(&hist[f - 1], 1);              // integer: the order of the adds does not matter
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += FB) blockcnt[(size_t)blockIdx.x * K + k] = hist[k];
+}
+
+// one wave per fold: exclusive prefix of the fold's block counts, 64 blocks per step
+__global__ __launch_bounds__(64) void fold_scan_kernel(int *__restrict__ blockcnt, int nblk, int K, int64_t *__restrict__ fold_n)
+{
+    const int k = blockIdx.x, lane = threadIdx.x;
+    int64_t run = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 64) {
+        const int b = b0 + lane;
+        const int c = b < nblk ? blockcnt[(size_t)b * K + k] : 0;
+        int incl = c;
+        for (int s = 1; s < 64; s <<= 1) { const int t = __shfl_up(incl, s, 64); if (lane >= s) incl += t; }
+        if (b < nblk) blockcnt[(size_t)b * K + k] = (int)(run + incl - c);
+        run += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) fold_n[k] = run;
+}
+
+__global__ void fold_start_kernel(const int64_t *__restrict__ fold_n, int K, int64_t *__restrict__ fold_start)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int64_t s = 0;
+        for (int k = 0; k < K; ++k) { fold_start[k] = s; s += (fold_n[k] + 15) / 16 * 16; }
+    }
+}
+
+__global__ __launch_bounds__(FB) void fold_pos_kernel(const int *__restrict__ foldid, int64_t n, int K,
+                                                      const int *__restrict__ blockoff, const int64_t *__restrict__ fold_start,
+                                                      int *__restrict__ pos)
+{
+    extern __shared__ int wcnt[];                     // [16][K]
+    const int64_t i = (int64_t)blockIdx.x * FB + threadIdx.x;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int f = -1;
+    if (i < n) { f = foldid[i] - 1; if (f < 0 || f >= K) f = -1; }
+    int rank = 0;
+    for (int k = 0; k < K; ++k) {
+        const unsigned long long m = __ballot(f == k);
+        if (lane == 0) wcnt[w * K + k] = __popcll(m);
+        if (f == k) rank = __popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (f >= 0) {
+        int pre = 0;
+        for (int ww = 0; ww < w; ++ww) pre += wcnt[ww * K + f];
+        pos[i] = (int)(fold_start[f] + blockoff[(size_t)blockIdx.x * K + f] + pre + rank);
+    }
+}
+
+// rows into fold-contiguous order: reads coalesced along the rows of a column, writes in K streams
+constexpr int GCB = 8;                   // columns per gather block
+__global__ __launch_bounds__(256) void gather_rows_kernel(const double *__restrict__ x, int64_t n, int64_t ld, int p,
+                                                          const double *__restrict__ y, const int *__restrict__ pos,
+                                                          double *__restrict__ xo, int64_t ldo, double *__restrict__ yo)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t d = pos[i];
+    const int c0 = blockIdx.y * GCB;
+#pragma unroll
+    for (int c = 0; c < GCB; ++c)
+        if (c0 + c < p) xo[(size_t)(c0 + c) * ldo + d] = x[(size_t)(c0 + c) * ld + i];
+    if (blockIdx.y == 0) yo[d] = y[i];
+}
+
+// out = sum of the fold moments except fold `skip` (1-based; 0: none), in fold order (ref src/oem_xval_dense.h:733-742, 801-811)
+__global__ __launch_bounds__(256) void fold_sum_kernel(const double *__restrict__ M, int K, size_t len, int skip, double *__restrict__ out)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= len) return;
+    double s = 0.0;
+    for (int k = 1; k <= K; ++k) if (k != skip) s += M[(size_t)(k - 1) * len + t];
+    out[t] = s;
+}
+
+// ---------------------------------------------------------------------------------------- CV error
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// grid (workgroups per fold, K folds, npen); 512 threads = 2 waves per SIMD sharing one copy of the coefficients in LDS.
+// B: [K][npen][nl][p + 1], row 0 of each column the intercept.  part: [K * gridDim.x][npen][nl16][2] (sum of the error, of its square)
+// KC: k-steps (4 columns each) whose X fragments a lane holds at once (SINGLE: p + 1 <= 4 KC, one chunk per row tile).
+constexpr int CVW = 8;                   // waves per workgroup
+template <int LT, int KC, bool SINGLE>
+__global__ __launch_bounds__(64 * CVW) void cv_error_kernel(const double *__restrict__ xp, int64_t ldp, const double *__restrict__ yp,
+                                                            const int64_t *__restrict__ fold_start, const int64_t *__restrict__ fold_n,
+                                                            int p, const double *__restrict__ B, int nl, int mae,
+                                                            double *__restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int k = blockIdx.y, pen = blockIdx.z, npen = gridDim.z, nwg = gridDim.x, wg = blockIdx.x;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l16 = lane & 15, g = lane >> 4;
+    const int Kd = p + 1, K4 = (Kd + 3) & ~3, nl16 = (nl + 15) & ~15, ntile = nl16 >> 4;
+    constexpr int LW = 16 * LT;                       // lambdas per pass
+    double *Bl = lds;                                 // [K4][LW]
+    double *red = lds + (size_t)K4 * LW;              // [CVW][LW][2]
+    const int64_t start = fold_start[k], nk = fold_n[k];
+    const double *Bsrc = B + ((size_t)k * npen + pen) * nl * Kd;
+    const double *xk = xp + start, *yk = yp + start;
+    double *dst = part + (((size_t)k * nwg + wg) * npen + pen) * nl16 * 2;
+    const int64_t stride = (int64_t)nwg * CVW;
+
+    auto load_a = [&](double (&a)[KC], int64_t rt, int c0) {
+        const int64_t arow = rt * 16 + l16;
+        const bool avalid = arow < nk;
+#pragma unroll
+        for (int s_ = 0; s_ < KC; ++s_) {
+            const int kk = c0 + 4 * s_ + g;
+            double v = (kk == p) ? 1.0 : 0.0;
+            if (avalid && kk < p) v = xk[(size_t)kk * ldp + arow];
+            a[s_] = v;
+        }
+    };
+
+    for (int l0 = 0; l0 < ntile; l0 += LT) {
+        __syncthreads();
+        for (int idx = tid; idx < K4 * LW; idx += 64 * CVW) {
+            const int c = idx / LW, j = idx - c * LW, lam = l0 * 16 + j;
+            double v = 0.0;
+            if (lam < nl) {
+                if (c < p) v = Bsrc[(size_t)lam * Kd + c + 1];
+                else if (c == p) v = Bsrc[(size_t)lam * Kd];          // intercept: the column of ones
+            }
+            Bl[idx] = v;
+        }
+        __syncthreads();
+        double s1[LT], s2[LT];
+#pragma unroll
+        for (int t = 0; t < LT; ++t) { s1[t] = 0.0; s2[t] = 0.0; }
+        d4 acc[LT];
+        auto clear = [&]() {
+#pragma unroll
+            for (int t = 0; t < LT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+        };
+        auto mac = [&](const double (&a)[KC], int c0) {
+#pragma unroll
+            for (int s_ = 0; s_ < KC; ++s_) {
+                const int kk = c0 + 4 * s_ + g;
+                if (SINGLE || c0 + 4 * s_ < K4) {
+                    const double *bp = Bl + (size_t)(kk < K4 ? kk : 0) * LW + l16;
+                    const double av = (kk < K4) ? a[s_] : 0.0;
+#pragma unroll
+                    for (int t = 0; t < LT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[16 * t], acc[t], 0, 0, 0);
+                }
+            }
+        };
+        // accumulator layout: register r of lane (g, l16) is (row 4 r + g, lambda l16) of the tile
+        auto finish = [&](int64_t rt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = rt * 16 + 4 * r + g;
+                const bool ok = row < nk;
+                const double yv = ok ? yk[row] : 0.0;
+#pragma unroll
+                for (int t = 0; t < LT; ++t) {
+                    const double res = yv - acc[t][r];
+                    const double v = ok ? (mae ? fabs(res) : res * res) : 0.0;
+                    s1[t] += v; s2[t] += v * v;
+                }
+            }
+        };
+        // all fragments of a chunk are requested before its first MFMA; the second wave of the SIMD covers the wait
+        for (int64_t rt = (int64_t)wg * CVW + w; rt * 16 < nk; rt += stride) {
+            clear();
+            for (int c0 = 0; c0 < K4; c0 += 4 * KC) {
+                double a[KC];
+                load_a(a, rt, c0);
+                mac(a, c0);
+            }
+            finish(rt);
+        }
+        // the four row groups of a wave, then the waves
+#pragma unroll
+        for (int t = 0; t < LT; ++t) {
+            s1[t] += __shfl_xor(s1[t], 16, 64); s1[t] += __shfl_xor(s1[t], 32, 64);
+            s2[t] += __shfl_xor(s2[t], 16, 64); s2[t] += __shfl_xor(s2[t], 32, 64);
+            if (g == 0) { red[((size_t)w * LW + 16 * t + l16) * 2] = s1[t]; red[((size_t)w * LW + 16 * t + l16) * 2 + 1] = s2[t]; }
+        }
+        __syncthreads();
+        for (int j = tid; j < LW * 2; j += 64 * CVW) {
+            const int lam = l0 * 16 + (j >> 1);
+            double v = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < CVW; ++ww) v += red[(size_t)ww * LW * 2 + j];       // fixed order
+            if (lam < nl16) dst[(size_t)lam * 2 + (j & 1)] = v;
+        }
+    }
+}
+
+// cvm = mean error, cvsd = sqrt(sample variance / n)  (ref src/oem_xval_dense.cpp:452-461).  One wave per (penalty, lambda):
+// lanes stride over the workgroup partials, then a fixed butterfly -- reproducible.
+__global__ __launch_bounds__(64) void cv_finish_kernel(const double *__restrict__ part, int nparts, int npen, int nl, double n,
+                                                       double *__restrict__ out /* [npen][nl][2] */)
+{
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int pen = t / nl, lam = t - pen * nl, nl16 = (nl + 15) & ~15;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = lane; b < nparts; b += 64) {
+        const double *q = part + (((size_t)b * npen + pen) * nl16 + lam) * 2;
+        s1 += q[0]; s2 += q[1];
+    }
+    for (int s_ = 32; s_ > 0; s_ >>= 1) { s1 += __shfl_xor(s1, s_, 64); s2 += __shfl_xor(s2, s_, 64); }
+    if (lane == 0) {
+        const double mean = s1 / n;
+        double m2 = s2 - s1 * mean;                   // sum (v - mean)^2
+        if (m2 < 0.0) m2 = 0.0;
+        out[(size_t)t * 2] = mean;
+        out[(size_t)t * 2 + 1] = sqrt(m2 / (n - 1.0)) / sqrt(n);
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------- launchers
+size_t fold_layout_ints(int64_t n, int K) { return (size_t)((n + FB - 1) / FB) * K + 8; }
+
+int launch_fold_layout(hipStream_t s, const int *foldid, int64_t n, int K, int *blockcnt, int64_t *fold_n, int64_t *fold_start,
+                       int *pos, int *bad)
+{
+    const int nblk = (int)((n + FB - 1) / FB);
+    OEM_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
+    hipLaunchKernelGGL(fold_count_kernel, dim3(nblk), dim3(FB), sizeof(int) * K, s, foldid, n, K, blockcnt, bad);
+    hipLaunchKernelGGL(fold_scan_kernel, dim3(K), dim3(64), 0, s, blockcnt, nblk, K, fold_n);
+    hipLaunchKernelGGL(fold_start_kernel, dim3(1), dim3(64), 0, s, fold_n, K, fold_start);
+    hipLaunchKernelGGL(fold_pos_kernel, dim3(nblk), dim3(FB), sizeof(int) * 16 * K, s, foldid, n, K, blockcnt, fold_start, pos);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gather_rows(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, const int *pos,
+                       double *xo, int64_t ldo, double *yo)
+{
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256), (p + GCB - 1) / GCB), dim3(256), 0, s, x, n, ld, p,
+                       y, pos, xo, ldo, yo);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_fold_sum(hipStream_t s, const double *M, int K, size_t len, int skip, double *out)
+{
+    hipLaunchKernelGGL(fold_sum_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, M, K, len, skip, out);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+// workgroups per fold for the CV pass: about one (of 8 waves) per CU over all (fold, penalty) pairs, not more than the fold's row tiles
+int cv_wg_per_fold(int64_t n, int K, int npen, int num_cu)
+{
+    int nwg = (num_cu + K * npen - 1) / (K * npen);
+    const int64_t tiles = (n / K + 16 * CVW - 1) / (16 * CVW);
+    if (nwg > tiles) nwg = (int)tiles;
+    return nwg < 1 ? 1 : nwg;
+}
+size_t cv_part_doubles(int nwg, int K, int npen, int nl) { return (size_t)nwg * K * npen * ((nl + 15) & ~15) * 2; }
+
+template <int LT>
+static int launch_cv_lt(hipStream_t s, dim3 grid, size_t lds, int ksteps, const double *xp, int64_t ldp, const double *yp,
+                        const int64_t *fold_start, const int64_t *fold_n, int p, const double *B, int nl, int mae, double *part)
+{
+#define OEM_CVK(KC, SINGLE)                                                                                                          \
+    do {                                                                                                                             \
+        OEM_HIP(hipFuncSetAttribute((const void *)cv_error_kernel<LT, KC, SINGLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((cv_error_kernel<LT, KC, SINGLE>), grid, dim3(64 * CVW), lds, s, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); \
+    } while (0)
+    if (ksteps <= 14) OEM_CVK(14, true);
+    else OEM_CVK(14, false);          // 28 fragments at once spill next to 7 accumulator tiles
+#undef OEM_CVK
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_cv_error(hipStream_t s, const double *xp, int64_t ldp, const double *yp, const int64_t *fold_start, const int64_t *fold_n,
+                    int K, int p, const double *B, int npen, int nl, int mae, int nwg, double n, double *part, double *out)
+{
+    const int K4 = (p + 1 + 3) & ~3, ntile = (nl + 15) >> 4;
+    // lambdas per pass: as many 16-wide tiles as fit 140 KB of LDS next to the reduction scratch, at most 7 (accumulator registers);
+    // all of them in one pass whenever that fits, so that X is read once
+    auto bytes = [&](int lt) { return ((size_t)K4 * 16 * lt + (size_t)CVW * 16 * lt * 2) * sizeof(double); };
+    int lt = ntile < 7 ? ntile : 7;
+    while (lt > 1 && bytes(lt) > 140 * 1024) --lt;
+    if (bytes(lt) > 150 * 1024) return OEMGPU_ERR_UNSUPPORTED;
+    if (ntile > lt) lt = (ntile + (ntile + lt - 1) / lt - 1) / ((ntile + lt - 1) / lt);      // even passes
+    const size_t lds = bytes(lt);
+    dim3 grid(nwg, K, npen);
+    int rc;
+    switch (lt) {
+    case 1: rc = launch_cv_lt<1>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); break;
+    case 2: rc = launch_cv_lt<2>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); break;
+    case 3: rc = launch_cv_lt<3>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); break;
+    case 4: rc = launch_cv_lt<4>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); break;
+    case 5: rc = launch_cv_lt<5>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); break;
+    case 6: rc = launch_cv_lt<6>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); break;
+    case 7: rc = launch_cv_lt<7>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); break;
+    default: return OEMGPU_ERR_INTERNAL;
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(cv_finish_kernel, dim3(npen * nl), dim3(64), 0, s, part, nwg * K, npen, nl, n, out);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace oemgpu

@@ -1,0 +1,101 @@
+"""xval.oem on the GPU (oemgpu_xval_dense / oemgpu_xval_dense_dev) against the oracle's restatement of
+ref src/oem_xval_dense.{h,cpp} and the reference's documented known answer."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import kat_inputs as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oa():
+    import oem_amd
+    return oem_amd
+
+
+def _oracle(x, y, foldid, penalty, groups=None, intercept=True, **kw):
+    if groups is not None:
+        g = np.concatenate([[0], groups]) if intercept else np.asarray(groups)           # R/oem_xval.R:279-283
+        ug = np.unique(np.concatenate([[0], groups])) if intercept else np.unique(groups)
+        kw.update(groups=g, unique_groups=ug)
+    return orc.xval_dense(x, y, foldid, penalty=penalty, intercept=intercept, **kw)
+
+
+def _compare(f, r, npen, tol_b=1e-8, tol_cv=1e-9):
+    assert abs(f["d"] - r["d"]) < 1e-11 * r["d"]
+    for k in range(npen):
+        assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-11)
+        scale = max(1.0, float(np.abs(r["beta"][k]).max()))
+        assert np.abs(f["beta"][k] - r["beta"][k]).max() < tol_b * scale
+        assert np.allclose(f["cvm"][k], r["cvm"][k], rtol=tol_cv), (k, f["cvm"][k], r["cvm"][k])
+        assert np.allclose(f["cvsd"][k], r["cvsd"][k], rtol=10 * tol_cv)
+
+
+def test_kat4_doc_example(oa):
+    """docs/reference/predict.xval.oem.html: test-set MSE at lambda.min 9.099371 (lasso) / 9.091854 (grp.lasso, best.model)."""
+    x, y, xt, yt, foldid = K.kat_xval()
+    f = oa.xval_oem(x, y, foldid=foldid, penalty=["lasso", "grp.lasso"], groups=np.repeat(np.arange(1, 11), 10), nlambda=10)
+    assert f["best.model"] == "grp.lasso"
+    mse = []
+    for k in range(2):
+        i = int(np.nonzero(f["lambda"][k] == f["lambda.min.models"][k])[0][0])
+        b = f["beta"][k][:, i]
+        mse.append("%.6f" % float(np.mean((yt - (xt @ b[1:] + b[0])) ** 2)))
+    assert mse == ["9.099371", "9.091854"]
+    r = _oracle(x, y, foldid, ["lasso", "grp.lasso"], groups=np.repeat(np.arange(1, 11), 10), nlambda=10, lambda_min_ratio=1e-4)
+    _compare(f, r, 2)
+
+
+@pytest.mark.parametrize("std,icpt", [(True, True), (False, True), (True, False), (False, False)])
+@pytest.mark.parametrize("measure", ["mse", "mae"])
+def test_parity_small(oa, std, icpt, measure):
+    rng = np.random.default_rng(11)
+    n, p, nf = 3001, 23, 5                                       # ragged: folds of 601 / 600 rows, p + 1 not a multiple of 4
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 2 + 0.3)
+    y = x[:, :4] @ np.array([1.0, -1.5, 0.5, 2.0]) + rng.normal(size=n) + 0.4
+    foldid = rng.permutation(np.resize(np.arange(1, nf + 1), n))
+    groups = np.arange(p) // 4 + 1
+    pens = ["lasso", "mcp", "grp.lasso", "ols"]
+    kw = dict(nlambda=21, tol=1e-9, maxit=1000, standardize=std)
+    f = oa.xval_oem(x, y, foldid=foldid, penalty=pens, groups=groups, intercept=icpt, type_measure=measure, compute_loss=True, **kw)
+    r = _oracle(x, y, foldid, pens, groups=groups, intercept=icpt, type_measure=measure, compute_loss=True,
+                lambda_min_ratio=1e-4, **kw)
+    _compare(f, r, 4)
+    for k in range(4):
+        assert np.allclose(np.ravel(f["loss"][k]), np.ravel(r["loss"][k]), rtol=1e-9)
+        assert np.array_equal(np.ravel(f["niter"][k]), np.ravel(r["niter"][k]))
+
+
+def test_uneven_folds_and_user_lambda(oa):
+    rng = np.random.default_rng(12)
+    n, p = 5000, 40
+    x = np.asfortranarray(rng.normal(size=(n, p)))
+    y = x[:, :5] @ rng.uniform(0.5, 1.5, 5) + 2 * rng.normal(size=n)
+    foldid = np.concatenate([np.full(2500, 1), np.full(1700, 2), np.full(17, 3), np.full(783, 4)])    # contiguous, very uneven
+    lam = [np.geomspace(1.0, 1e-3, 37), np.geomspace(2.0, 1e-2, 37)]
+    f = oa.xval_oem(x, y, foldid=foldid, penalty=["elastic.net", "scad"], alpha=0.7, lambda_=lam, tol=1e-9)
+    r = _oracle(x, y, foldid, ["elastic.net", "scad"], alpha=0.7, lambda_=lam, tol=1e-9)
+    _compare(f, r, 2)
+    with pytest.raises(oa.OemgpuError, match="foldid must hold values"):
+        bad = foldid.copy(); bad[7] = 0
+        oa.xval_oem(x, y, foldid=bad, penalty="lasso")
+
+
+def test_device_resident_readme_shape(oa):
+    """n = 2e5, p = 100, 10 folds, 100 lambdas on a device-resident X: the shape of the benchmark (config 1) at a size the
+    oracle walks in seconds."""
+    import torch
+    rng = np.random.default_rng(13)
+    n, p = 200_000, 100
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 3.0)
+    b = np.concatenate([rng.uniform(size=25), np.zeros(75)])
+    y = x @ b + rng.normal(size=n)
+    foldid = rng.permutation(np.resize(np.arange(1, 11), n))
+    xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+    f = oa.xval_oem(xd, y, foldid=foldid, penalty="lasso", tol=1e-9)
+    r = _oracle(x, y, foldid, ["lasso"], nlambda=100, lambda_min_ratio=1e-4, tol=1e-9)
+    _compare(f, r, 1)
+    imin = int(np.argmin(r["cvm"][0]))
+    assert int(np.nonzero(f["lambda"][0] == f["lambda.min"])[0][0]) == imin
