@@ -177,7 +177,7 @@ enum { SEM_XTX = 2 };        // OEMGPU_SEM_XVAL = 3 (oemgpu.h): oemBig's algebra
 int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const double *stats, int p, int q, int sem,
               int standardize, int intercept, const oemgpu_opts *o, const double *scale_factor,
               double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out,
-              int nbatch = 1, size_t bstride = 0)
+              int nbatch = 1, size_t bstride = 0, bool shared_lmax = false)
 {
     const int nl = nl_of(o), npen = o->npen;
     const bool user = o->lambda_user && o->nlambda_user > 0;
@@ -250,6 +250,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     double *dstats = a.d_out + 4;
     a.niter = (int *)(dstats + stats_len(p));
     a.work = (double *)(c->ws + a_work);
+    a.lmax_xy = (nbatch > 1 && shared_lmax) ? xy : nullptr;        // instance 0's X'Y
     a.nbatch = nbatch; a.bs_xx = a.bs_xy = a.bs_stats = (long long)bstride; a.bs_out = (long long)out_stride; a.bs_work = (long long)work_d;
 
     const size_t st_gap = (size_t)((const char *)dout - (const char *)stats);
@@ -711,7 +712,7 @@ int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_
 // launch that walks all their paths side by side (q <= SMALL_P_MAX).  Outputs as in run_paths.
 static int solve_moments_batch(oemgpu_ctx *c, const double *moments, size_t mstride, int nbatch, int32_t p, int32_t semantics,
                                int32_t standardize, int32_t intercept, const oemgpu_opts *o,
-                               double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+                               double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, bool shared_lmax)
 {
     const int q = p + ((semantics != OEMGPU_SEM_DENSE && intercept) ? 1 : 0);
     Bump B;
@@ -727,7 +728,7 @@ static int solve_moments_batch(oemgpu_ctx *c, const double *moments, size_t mstr
     }
     char *f0 = c->ws + a_0;
     return run_paths(c, B, (const double *)f0, (const double *)(f0 + o_xy), (const double *)(f0 + o_st), p, q, semantics, standardize,
-                     intercept, o, nullptr, beta, lambda_out, niter, loss, d, nbatch, per / 8);
+                     intercept, o, nullptr, beta, lambda_out, niter, loss, d, nbatch, per / 8, shared_lmax);
 }
 
 // ---------------------------------------------------------------------------------------------- xval.oem
@@ -767,7 +768,7 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t
     const size_t a_cnt = A.take(fold_layout_ints(n, K) * sizeof(int)), a_fn = A.take(sizeof(int64_t) * 2 * K), a_bad = A.take(256),
                  a_pos = A.take(sizeof(int) * (size_t)n), a_xp = A.take(sizeof(double) * (size_t)ldp * p),
                  a_yp = A.take(sizeof(double) * (size_t)ldp), a_mf = A.take(sizeof(double) * mlen * K),
-                 a_mc = A.take(sizeof(double) * mlen), a_ms = A.take(sizeof(double) * mlen * K), a_t = A.take(plmax.tpart_doubles * 8 * 2), a_v = A.take(plmax.vpart_doubles * 8 * 2),
+                 a_mc = A.take(sizeof(double) * mlen), a_ms = A.take(sizeof(double) * mlen * (K + 1)), a_t = A.take(plmax.tpart_doubles * 8 * 2), a_v = A.take(plmax.vpart_doubles * 8 * 2),
                  a_b = A.take(sizeof(double) * (size_t)K * npen * nl * (p + 1)),
                  a_part = A.take(sizeof(double) * cv_part_doubles(nwg, K, npen, nl)), a_out = A.take(sizeof(double) * 2 * (size_t)npen * nl);
     if (ctx_aux(c, A.off)) return OEMGPU_ERR_HIP;
@@ -800,29 +801,37 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t
         rc = shard_moments(c, pl, xp + st, nk, ldp, yp + st, nullptr, (double *)(ax + a_t), (double *)(ax + a_v), mfold + mlen * k);
         if (rc) return rc;
     }
-    // ---- the full-data fit (ff = 0), then one fit per left-out fold on the lambdas of the first (ref src/oem_xval_dense.cpp:213-340)
-    rc = launch_fold_sum(c->stream, mfold, K, mlen, 0, mcur);
-    if (rc) return rc;
-    rc = oemgpu_solve_moments_dev(c, mcur, nullptr, p, OEMGPU_SEM_XVAL, standardize, intercept, o, beta, lambda_out, niter, loss, d);
-    if (rc) return rc;
-    // The K fold fits are independent of each other (each a chain of tiny dependent steps on ONE workgroup): they run
-    // concurrently, one host thread + child context (own stream, workspace, staging buffers) per fold.
-    oemgpu_opts of = *o;
-    of.lambda_user = lambda_out; of.nlambda_user = nl; of.compute_loss = 0;
+    // ---- the full-data fit (ff = 0) and one fit per left-out fold on the lambdas of the first (ref src/oem_xval_dense.cpp:213-340)
     const size_t blen = (size_t)npen * nl * (p + 1), nk2 = (size_t)npen * nl;
-    std::vector<double> hb(blen * K), hl(nk2 * K), hloss(nk2 * K), hd(K);
-    std::vector<int32_t> hn(nk2 * K);
-    double *msum = (double *)(ax + a_ms);
-    for (int ff = 1; ff <= K; ++ff) {
-        rc = launch_fold_sum(c->stream, mfold, K, mlen, ff, msum + mlen * (ff - 1));
+    std::vector<double> hb(blen * K);
+    double *msum = (double *)(ax + a_ms);                        // [K + 1]: all folds, then all but fold ff
+    for (int ff = 0; ff <= K; ++ff) {
+        rc = launch_fold_sum(c->stream, mfold, K, mlen, ff, msum + mlen * ff);
         if (rc) return rc;
     }
     if (q <= SMALL_P_MAX) {
-        // one launch, one workgroup (set) per fold (hardware queues are few: K streams would run four at a time)
-        rc = solve_moments_batch(c, msum, mlen, K, p, OEMGPU_SEM_XVAL, standardize, intercept, &of, hb.data(), hl.data(), hn.data(),
-                                 hloss.data(), hd.data());
+        // The K + 1 fits are independent chains of tiny dependent steps: ONE launch, one workgroup (set) per fit.  (K streams
+        // would run four at a time: the hardware queues are few.)  The folds' lambda grid is the full fit's, which a fold's
+        // kernel derives from the full-data X'Y itself (PathArgs::lmax_xy) instead of waiting for the full fit to end.
+        std::vector<double> ab(blen * (K + 1)), al(nk2 * (K + 1)), aloss(nk2 * (K + 1)), ad(K + 1);
+        std::vector<int32_t> an(nk2 * (K + 1));
+        rc = solve_moments_batch(c, msum, mlen, K + 1, p, OEMGPU_SEM_XVAL, standardize, intercept, o, ab.data(), al.data(), an.data(),
+                                 aloss.data(), ad.data(), true);
         if (rc) return rc;
+        memcpy(beta, ab.data(), sizeof(double) * blen);
+        memcpy(lambda_out, al.data(), sizeof(double) * nk2);
+        memcpy(niter, an.data(), sizeof(int32_t) * nk2);
+        memcpy(loss, aloss.data(), sizeof(double) * nk2);       // the reference reports the loss of the full fit only (ref :296-301)
+        *d = ad[0];
+        memcpy(hb.data(), ab.data() + blen, sizeof(double) * blen * K);
     } else {
+        rc = oemgpu_solve_moments_dev(c, msum, nullptr, p, OEMGPU_SEM_XVAL, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+        if (rc) return rc;
+        oemgpu_opts of = *o;
+        of.lambda_user = lambda_out; of.nlambda_user = nl; of.compute_loss = 0;
+        std::vector<double> hl(nk2 * K), hloss(nk2 * K), hd(K);
+        std::vector<int32_t> hn(nk2 * K);
+        msum += mlen;                                            // the folds' sums
         while ((int)c->kids.size() < K) {
             oemgpu_ctx *kid = oemgpu_create(c->device, nullptr);
             if (!kid) return OEMGPU_ERR_HIP;

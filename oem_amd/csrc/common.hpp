@@ -96,6 +96,7 @@ struct PathArgs {
     // except xx, xy, stats (element strides bs_xx, bs_xy, bs_stats), the outputs (byte stride bs_out) and work (bs_work)
     int nbatch;
     long long bs_xx, bs_xy, bs_stats, bs_out, bs_work;
+    const double *lmax_xy;   // not null: every instance takes lambda_zero from THIS xy (xval.oem: the grid of the full-data fit, ref src/oem_xval_dense.cpp:177-194)
 };
 
 // the problem instance of this workgroup (see PathArgs::nbatch); all scalar arithmetic

@@ -796,7 +796,11 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
     const double yy = A.stats[2], nobs = A.stats[3];
     double lmax = 0.0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) lmax = fmax(lmax, (lane + 64 * r >= A.lmax_from) ? fabs(xy[r]) : 0.0);
+    for (int r = 0; r < R; ++r) {
+        const int row = lane + 64 * r;
+        const double xl = (A.lmax_xy && row < p) ? A.lmax_xy[row] : xy[r];
+        lmax = fmax(lmax, (row >= A.lmax_from) ? fabs(xl) : 0.0);
+    }
     lmax = wave_max(lmax) * scaley;
     const int nl = A.nl;
     const double llo = log(lmax), lhi = log(A.lambda_min_ratio * lmax);
@@ -1332,7 +1336,8 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
     double lmax;
     {
         // max |xy| over all rows: wave maxima through per-lane words, then a max over the four words
-        const double wm = wave_max(row >= A.lmax_from ? fabs(xy) : 0.0);      // padding lanes: xy = 0
+        const double xl = (A.lmax_xy && rowok) ? A.lmax_xy[row] : xy;
+        const double wm = wave_max(row >= A.lmax_from ? fabs(xl) : 0.0);      // padding lanes: xy = 0
         S.XN[(par * NW + w) * 64 + lane] = wm;
         __syncthreads();
         const double x = S.XN[(par * NW + (lane & (NW - 1))) * 64 + lane];

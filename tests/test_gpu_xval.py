@@ -99,3 +99,16 @@ def test_device_resident_readme_shape(oa):
     _compare(f, r, 1)
     imin = int(np.argmin(r["cvm"][0]))
     assert int(np.nonzero(f["lambda"][0] == f["lambda.min"])[0][0]) == imin
+
+
+def test_large_p_takes_the_threaded_fold_fits(oa):
+    """p + 1 > 288: the fold fits run on the launch-per-iteration engine, one host thread and child context per fold."""
+    rng = np.random.default_rng(14)
+    n, p = 3000, 300
+    x = np.asfortranarray(rng.normal(size=(n, p)))
+    y = x[:, :6] @ rng.uniform(0.5, 1.5, 6) + rng.normal(size=n) + 1.0
+    foldid = rng.permutation(np.resize(np.arange(1, 4), n))
+    kw = dict(nlambda=8, tol=1e-8, maxit=400, lambda_min_ratio=1e-2)
+    f = oa.xval_oem(x, y, foldid=foldid, penalty=["lasso", "mcp"], **kw)
+    r = _oracle(x, y, foldid, ["lasso", "mcp"], **kw)
+    _compare(f, r, 2, tol_b=1e-7, tol_cv=1e-8)
