@@ -279,10 +279,11 @@ int launch_fold_sum(hipStream_t s, const double *M, int K, size_t len, int skip,
     return 0;
 }
 
-// workgroups per fold for the CV pass: about one (of 8 waves) per CU over all (fold, penalty) pairs, not more than the fold's row tiles
+// workgroups per fold for the CV pass.  One workgroup fills a CU (LDS), and all of them carry the same work: the grid must not
+// exceed the CU count by a few (260 workgroups on 256 CUs take two rounds), so round DOWN.
 int cv_wg_per_fold(int64_t n, int K, int npen, int num_cu)
 {
-    int nwg = (num_cu + K * npen - 1) / (K * npen);
+    int nwg = num_cu / (K * npen);
     const int64_t tiles = (n / K + 16 * CVW - 1) / (16 * CVW);
     if (nwg > tiles) nwg = (int)tiles;
     return nwg < 1 ? 1 : nwg;

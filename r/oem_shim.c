@@ -145,3 +145,47 @@ SEXP oem_xtx(SEXP xtx_, SEXP xty_, SEXP family_, SEXP penalty_, SEXP groups_, SE
  *     const double *xs[1] = {x}, *ys[1] = {REAL(y_)};  int64_t ns[1] = {bm->nrow()};
  *     oemgpu_fit_big(xs, ns, 1, bm->ncol(), ys, standardize, intercept, &o, beta, lam, niter, loss, &d);
  * groups_ arrives with its leading 0 for the intercept (ref R/big_oem.R:254-257) and is passed through unchanged. */
+
+/* oem_xval_dense (ref src/oem_xval_dense.cpp:31-52, called from R/oem_xval.R:497-521): the list of oem_fit_dense plus cvm and cvsd
+ * (ref :470-478).  R/oem_xval.R computes lambda.min, lambda.1se, model.min, cvup, cvlo, nzero from it, unchanged. */
+SEXP oem_xval_dense(SEXP x_, SEXP y_, SEXP family_, SEXP penalty_, SEXP weights_, SEXP groups_, SEXP unique_groups_,
+                    SEXP group_weights_, SEXP lambda_, SEXP nlambda_, SEXP lmin_ratio_, SEXP alpha_, SEXP gamma_,
+                    SEXP tau_, SEXP penalty_factor_, SEXP standardize_, SEXP intercept_, SEXP nfolds_, SEXP foldid_,
+                    SEXP compute_loss_, SEXP type_measure_, SEXP opts_)
+{
+    if (strcmp(CHAR(STRING_ELT(family_, 0)), "gaussian") != 0)
+        Rf_error("binomial not available for oem_xval_dense, use oem_xval_logistic_dense");    /* ref src/oem_xval_dense.cpp:157 */
+    if (XLENGTH(weights_) > 0) Rf_error("observation weights in xval.oem are outside the GPU path");
+    SEXP dim = Rf_getAttrib(x_, R_DimSymbol);
+    const int64_t n = INTEGER(dim)[0];
+    const int p = INTEGER(dim)[1];
+    oemgpu_opts o;
+    fill_opts(&o, penalty_, groups_, unique_groups_, group_weights_, lambda_, nlambda_, lmin_ratio_, alpha_, gamma_, tau_,
+              penalty_factor_, compute_loss_, opts_, 0);
+    const int nl = o.nlambda_user > 0 ? o.nlambda_user : o.nlambda;
+    const size_t nk = (size_t)o.npen * nl;
+    double *beta = (double *)R_alloc(nk * (p + 1), sizeof(double)), *lam = (double *)R_alloc(nk, sizeof(double));
+    double *loss = (double *)R_alloc(nk, sizeof(double)), *cvm = (double *)R_alloc(nk, sizeof(double)),
+           *cvsd = (double *)R_alloc(nk, sizeof(double)), d = 0.0;
+    int32_t *niter = (int32_t *)R_alloc(nk, sizeof(int32_t));
+    const int mae = strcmp(CHAR(STRING_ELT(type_measure_, 0)), "mae") == 0;                    /* ref :378-411 */
+    const int rc = oemgpu_xval_dense(REAL(x_), n, p, REAL(y_), INTEGER(foldid_), Rf_asInteger(nfolds_), Rf_asLogical(standardize_),
+                                     Rf_asLogical(intercept_), mae, &o, beta, lam, niter, loss, &d, cvm, cvsd);
+    if (rc != 0) Rf_error("%s", oemgpu_last_error());
+    SEXP base = PROTECT(pack(&o, p + 1, nl, beta, lam, niter, loss, d));
+    /* beta, lambda, niter, loss, cvm, cvsd, d */
+    SEXP res = PROTECT(Rf_allocVector(VECSXP, 7)), names = PROTECT(Rf_allocVector(STRSXP, 7));
+    const char *nm[7] = {"beta", "lambda", "niter", "loss", "cvm", "cvsd", "d"};
+    for (int i = 0; i < 7; i++) SET_STRING_ELT(names, i, Rf_mkChar(nm[i]));
+    for (int i = 0; i < 4; i++) SET_VECTOR_ELT(res, i, VECTOR_ELT(base, i));
+    SEXP lm = PROTECT(Rf_allocVector(VECSXP, o.npen)), ls = PROTECT(Rf_allocVector(VECSXP, o.npen));
+    for (int k = 0; k < o.npen; k++) {
+        const int nlam = (o.penalty[k] == OEMGPU_OLS) ? 1 : nl;
+        SEXP m = Rf_allocVector(REALSXP, nlam); SET_VECTOR_ELT(lm, k, m); memcpy(REAL(m), cvm + (size_t)k * nl, sizeof(double) * nlam);
+        SEXP s = Rf_allocVector(REALSXP, nlam); SET_VECTOR_ELT(ls, k, s); memcpy(REAL(s), cvsd + (size_t)k * nl, sizeof(double) * nlam);
+    }
+    SET_VECTOR_ELT(res, 4, lm); SET_VECTOR_ELT(res, 5, ls); SET_VECTOR_ELT(res, 6, VECTOR_ELT(base, 4));
+    Rf_setAttrib(res, R_NamesSymbol, names);
+    UNPROTECT(5);
+    return res;
+}
