@@ -493,6 +493,120 @@ def xval_oem(x, y, nfolds=10, foldid=None, type_measure=None, ncores=-1, family=
     return res
 
 
+
+# ------------------------------------------------------------------------------------------ cv.oem()
+def cv_oem(x, y, penalty=None, weights=(), lambda_=None, type_measure=None, nfolds=10, foldid=None, grouped=True, keep=False,
+           rng=None, **kw):
+    """cv.oem(): R/cv_oem.R:56-221 with cv.oemfit_gaussian (:349-423) and cvcompute (R/utils.R:128-144): K + 1 calls of oem(),
+    every fold on its own lambda sequence, errors interpolated onto the full fit's lambdas."""
+    penalty = _match_penalty(penalty)
+    if type_measure is None:
+        type_measure = "default"
+    elif type_measure not in _TYPE_MEASURES:
+        raise ValueError("'arg' should be one of " + ", ".join("'%s'" % t for t in _TYPE_MEASURES))
+    if lambda_ is not None and len(lambda_) < 2:
+        raise ValueError("Need more than one value of lambda for cv.oem")
+    if len(weights) > 0:
+        raise ValueError("weights not implemented yet.")
+    xh = np.asarray(x.cpu().numpy() if _is_torch_cuda(x) else x, dtype=np.float64)
+    yh = np.asarray(y.cpu().numpy() if _is_torch_cuda(y) else y, dtype=np.float64).reshape(-1)
+    n = xh.shape[0]
+    lam_arg = () if lambda_ is None else lambda_
+    fit0 = oem(x, y, penalty=penalty, lambda_=lam_arg, **kw)
+    nz = [np.array([0 if v is None else len(v) for v in predict(fit0, type="nonzero", which_model=m)]) for m in range(len(penalty))]
+    if foldid is None:
+        g = np.random.default_rng() if rng is None else rng
+        foldid = g.permutation(np.resize(np.arange(1, int(nfolds) + 1), n))
+    else:
+        foldid = np.asarray(foldid).ravel()
+        nfolds = int(foldid.max())
+    if nfolds < 3:
+        raise ValueError("nfolds must be bigger than 3; nfolds=10 recommended")
+    outlist = []
+    for i in range(1, nfolds + 1):
+        keep_rows = foldid != i
+        outlist.append(oem(np.asfortranarray(xh[keep_rows]), yh[keep_rows], penalty=penalty, lambda_=lam_arg, **kw))
+    # cv.oemfit_gaussian
+    if type_measure in ("default", "deviance"):
+        type_measure = "mse"
+    if type_measure not in ("mse", "mae"):
+        warnings.warn("Only 'mse', 'deviance' or 'mae'  available for Gaussian models; 'mse' used")
+        type_measure = "mse"
+    lam = [np.asarray(l, dtype=np.float64) for l in fit0["lambda"]]
+    nmodels = len(penalty)
+    which_lam = [lam[m] >= max(np.min(o["lambda"][m]) for o in outlist) for m in range(nmodels)]     # no extrapolation to smaller lambdas
+    predlist = [np.full((n, len(lam[0])), np.nan) for _ in range(nmodels)]
+    nlams = np.zeros(nfolds, dtype=int)
+    for i in range(1, nfolds + 1):
+        rows = foldid == i
+        for m in range(nmodels):
+            preds = predict(outlist[i - 1], xh[rows], s=lam[m][which_lam[m]], which_model=m)
+            nlami = int(which_lam[m].sum())
+            predlist[m][rows, :nlami] = preds
+        nlams[i - 1] = nlami
+    cvraw = [(yh[:, None] - pm) ** 2 if type_measure == "mse" else np.abs(yh[:, None] - pm) for pm in predlist]
+    if n / nfolds < 3 and grouped:
+        warnings.warn("Option grouped=FALSE enforced in cv.glmnet, since < 3 observations per fold")
+        grouped = False
+    w = [np.ones(n) for _ in range(nmodels)]
+    N = [n - np.isnan(pm).sum(axis=0) for pm in predlist]
+    if grouped:                                                   # cvcompute: fold means, weighted by fold size
+        wisum = np.array([np.sum(foldid == i) for i in range(1, nfolds + 1)], dtype=np.float64)
+        for m in range(nmodels):
+            out = np.full((nfolds, cvraw[m].shape[1]), np.nan)
+            good = np.zeros_like(out)
+            for i in range(nfolds):
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    out[i] = np.nanmean(cvraw[m][foldid == i + 1], axis=0)
+                good[i, :nlams[i]] = 1
+            cvraw[m], w[m], N[m] = out, wisum, good.sum(axis=0)
+
+    def wmean(a, wt):
+        ok = ~np.isnan(a)
+        return np.array([np.sum(a[ok[:, j], j] * wt[ok[:, j]]) / np.sum(wt[ok[:, j]]) if ok[:, j].any() else np.nan
+                         for j in range(a.shape[1])])
+    cvm = [wmean(cvraw[m], w[m]) for m in range(nmodels)]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        cvsd = [np.sqrt(wmean((cvraw[m] - cvm[m]) ** 2, w[m]) / (N[m] - 1)) for m in range(nmodels)]
+    nas = np.zeros(len(lam[0]), dtype=bool)
+    for m in range(nmodels):
+        nas |= np.isnan(cvsd[m])
+    if nas.any():
+        cvm = [c[~nas] for c in cvm]; cvsd = [c[~nas] for c in cvsd]
+        nz = [c[~nas] for c in nz]; lam = [l[~nas] for l in lam]
+    res = OemFit()
+    res.update({"lambda": lam, "cvm": cvm, "cvsd": cvsd, "cvup": [a + b for a, b in zip(cvm, cvsd)],
+                "cvlo": [a - b for a, b in zip(cvm, cvsd)], "nzero": nz,
+                "name": {"mse": "Mean-Squared Error", "mae": "Mean Absolute Error"}[type_measure], "oem.fit": fit0})
+    if keep:
+        res["fit.preval"] = predlist; res["foldid"] = foldid
+    res.update(_getmin(lam, cvm, cvsd))
+    res["best.model"] = penalty[res["model.min"] - 1]
+    res["penalty"] = list(penalty)
+    return res
+
+
+def predict_cv(fit, newx=None, which_model="best.model", s="lambda.min", **kw):
+    """predict.cv.oem, R/methods.R (same selection rules as predict.xval.oem, on the full-data fit `oem.fit`)."""
+    if isinstance(s, str):
+        if s not in ("lambda.min", "lambda.1se"):
+            raise ValueError("'arg' should be one of 'lambda.min', 'lambda.1se'")
+        lam = fit[s]
+    else:
+        lam = s
+    if isinstance(which_model, str):
+        if which_model == "best.model":
+            mod = fit["model.min"] - 1
+        else:
+            if which_model not in fit["penalty"]:
+                raise ValueError(f"Model {which_model} specified, but {which_model} not computed.")
+            mod = fit["penalty"].index(which_model)
+    else:
+        mod = int(which_model)
+    return predict(fit["oem.fit"], newx, s=lam, which_model=mod, **kw)
+
+
 # ------------------------------------------------------------------------------------------ consumers
 def predict(fit, newx=None, s=None, which_model=0, type="link"):
     """predict.oem, R/methods.R:48-109 (which_model is 0-based or a penalty name)."""
@@ -517,6 +631,30 @@ def predict(fit, newx=None, s=None, which_model=0, type="link"):
     if newx.shape[1] < nbeta.shape[0]:
         newx = np.column_stack([np.ones(newx.shape[0]), newx])
     return newx @ nbeta
+
+
+def predict_xval(fit, newx=None, which_model="best.model", s="lambda.min", **kw):
+    """predict.xval.oem, R/methods.R:765-807 (which_model: "best.model", a penalty name, or a 0-based index)."""
+    if isinstance(s, str):
+        if s not in ("lambda.min", "lambda.1se"):
+            raise ValueError("'arg' should be one of 'lambda.min', 'lambda.1se'")
+        lam = fit[s]
+    elif np.isscalar(s) or isinstance(s, (list, tuple, np.ndarray)):
+        lam = s
+    else:
+        raise ValueError("Invalid form for s")
+    if isinstance(which_model, str):
+        if which_model == "best.model":
+            mod = fit["model.min"] - 1
+        else:
+            if which_model not in fit["penalty"]:
+                raise ValueError(f"Model {which_model} specified, but {which_model} not computed.")
+            mod = fit["penalty"].index(which_model)
+    else:
+        mod = int(which_model)
+        if mod >= len(fit["cvm"]):
+            raise ValueError(f"Model {mod + 1} specified, but only {len(fit['cvm'])} were computed.")
+    return predict(fit, newx, s=lam, which_model=mod, **kw)
 
 
 def _lambda_interp(lam, s):

@@ -38,12 +38,10 @@ def test_kat4_doc_example(oa):
     x, y, xt, yt, foldid = K.kat_xval()
     f = oa.xval_oem(x, y, foldid=foldid, penalty=["lasso", "grp.lasso"], groups=np.repeat(np.arange(1, 11), 10), nlambda=10)
     assert f["best.model"] == "grp.lasso"
-    mse = []
-    for k in range(2):
-        i = int(np.nonzero(f["lambda"][k] == f["lambda.min.models"][k])[0][0])
-        b = f["beta"][k][:, i]
-        mse.append("%.6f" % float(np.mean((yt - (xt @ b[1:] + b[0])) ** 2)))
-    assert mse == ["9.099371", "9.091854"]
+    # the calls of the documentation example: which.model = "best.model", "grp.lasso", 1
+    mse = ["%.6f" % float(np.mean((yt - oa.predict_xval(f, xt, which_model=m, type="response")[:, 0]) ** 2))
+           for m in ("best.model", "grp.lasso", 0)]
+    assert mse == ["9.091854", "9.091854", "9.099371"]
     r = _oracle(x, y, foldid, ["lasso", "grp.lasso"], groups=np.repeat(np.arange(1, 11), 10), nlambda=10, lambda_min_ratio=1e-4)
     _compare(f, r, 2)
 
@@ -112,3 +110,15 @@ def test_large_p_takes_the_threaded_fold_fits(oa):
     f = oa.xval_oem(x, y, foldid=foldid, penalty=["lasso", "mcp"], **kw)
     r = _oracle(x, y, foldid, ["lasso", "mcp"], **kw)
     _compare(f, r, 2, tol_b=1e-7, tol_cv=1e-8)
+
+
+def test_kat5_cv_oem_doc_example(oa):
+    """docs/reference/predict.cv.oem.html: cv.oem(lasso, grp.lasso; groups rep(1:10, each = 10); nlambda = 10) with the folds R
+    draws itself (the same RNG position as in the xval example), then the test-set MSE of the full-data oem() fit at lambda.min:
+    9.091859 for "best.model" and "grp.lasso", 9.099376 for model 1."""
+    x, y, xt, yt, foldid = K.kat_xval()
+    cv = oa.cv_oem(x, y, penalty=["lasso", "grp.lasso"], groups=np.repeat(np.arange(1, 11), 10), nlambda=10, foldid=foldid)
+    assert cv["best.model"] == "grp.lasso"
+    mse = ["%.6f" % float(np.mean((yt - oa.predict_cv(cv, xt, which_model=m, type="response")[:, 0]) ** 2))
+           for m in ("best.model", "grp.lasso", 0)]
+    assert mse == ["9.091859", "9.091859", "9.099376"]
