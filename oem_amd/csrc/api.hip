@@ -752,7 +752,7 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t
     const int K = nfolds, q = p + (intercept ? 1 : 0);
     int rc = check_opts(o, p, q);
     if (rc) return rc;
-    if (K < 2 || K > 1024) { set_error("xval_dense: nfolds must be in 2..1024"); return OEMGPU_ERR_ARG; }
+    if (K < 2 || K > 512) { set_error("xval_dense: nfolds must be in 2..512"); return OEMGPU_ERR_ARG; }
     if (type_measure != 0 && type_measure != 1) { set_error("xval_dense: type_measure must be 0 (mse) or 1 (mae)"); return OEMGPU_ERR_ARG; }
     if (n < 1 || ld < n) { set_error("xval_dense: bad n / ld"); return OEMGPU_ERR_ARG; }
     if (n <= p) { set_error("dimension of x larger than number of observations"); return OEMGPU_ERR_UNSUPPORTED; }   // ref src/oem_xval_dense.h:690-731

@@ -122,3 +122,16 @@ def test_kat5_cv_oem_doc_example(oa):
     mse = ["%.6f" % float(np.mean((yt - oa.predict_cv(cv, xt, which_model=m, type="response")[:, 0]) ** 2))
            for m in ("best.model", "grp.lasso", 0)]
     assert mse == ["9.091859", "9.091859", "9.099376"]
+
+
+def test_many_small_folds_and_an_empty_one(oa):
+    """37 folds of ~54 rows (one of them empty: its id never occurs), n not a multiple of anything."""
+    rng = np.random.default_rng(15)
+    n, p, nf = 1999, 10, 37
+    x = np.asfortranarray(rng.normal(size=(n, p)) + 0.2)
+    y = x[:, :3] @ np.array([1.0, -1.0, 0.5]) + rng.normal(size=n)
+    foldid = rng.permutation(np.resize(np.arange(1, nf), n))          # ids 1..36 only: fold 37 is empty
+    foldid[0] = nf - 1
+    f = oa.xval_oem(x, y, foldid=np.where(foldid == 5, nf, foldid), penalty=["lasso", "scad"], nlambda=16, tol=1e-9)     # fold 5 empty instead
+    r = _oracle(x, y, np.where(foldid == 5, nf, foldid), ["lasso", "scad"], nlambda=16, lambda_min_ratio=1e-4, tol=1e-9)
+    _compare(f, r, 2)
