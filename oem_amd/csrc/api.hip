@@ -216,7 +216,9 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const size_t work_d = small ? path_small_xchg_bytes() / 8 : path_large_work_doubles(q, lan);
     // the outputs come first: when the caller's frame ends with `stats` (both callers), stats | outputs is one
     // contiguous range and one device-to-host copy returns both
-    const size_t a_out = B.take(out_stride * nbatch), a_blob = B.take(bl.h.size()), a_work = B.take(work_d * sizeof(double) * nbatch);
+    const bool pen_split = small && npen > 1;        // one workgroup (set) per penalty: they are independent cold starts
+    const size_t a_out = B.take(out_stride * nbatch), a_blob = B.take(bl.h.size()),
+                 a_work = B.take(work_d * sizeof(double) * nbatch * (pen_split ? npen : 1));
     // the workspace may be re-allocated by ctx_reserve: xx/xy/stats are offsets into it, so recompute after
     const size_t off_xx = (const char *)xx - c->ws, off_xy = (const char *)xy - c->ws, off_st = (const char *)stats - c->ws;
     if (B.off > c->ws_bytes) { set_error("internal: workspace under-reserved (%zu > %zu)", B.off, c->ws_bytes); return OEMGPU_ERR_INTERNAL; }
@@ -251,6 +253,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     a.niter = (int *)(dstats + stats_len(p));
     a.work = (double *)(c->ws + a_work);
     a.lmax_xy = (nbatch > 1 && shared_lmax) ? xy : nullptr;        // instance 0's X'Y
+    a.pen_split = pen_split; a.pen_lo = 0; a.pen_hi = npen;
     a.nbatch = nbatch; a.bs_xx = a.bs_xy = a.bs_stats = (long long)bstride; a.bs_out = (long long)out_stride; a.bs_work = (long long)work_d;
 
     const size_t st_gap = (size_t)((const char *)dout - (const char *)stats);
@@ -318,11 +321,12 @@ size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o, int nbatch = 1)
 {
     const int nl = nl_of(o);
     if (nbatch > 1) return (size_t)nbatch * (paths_ws_bytes(p, q, o) + 1024);
+    const size_t splits = (q <= SMALL_P_MAX && o->npen > 1) ? (size_t)o->npen : 1;
     size_t b = 0;
     b += (size_t)o->npen * 4 + (size_t)o->npen * nl * 8 + (size_t)q * (8 + 8 + 4) + (size_t)(o->ngroups + 2) * 16 +
          (size_t)(o->ngroupvars + q + 2) * 4 + 4096;
     b += ((size_t)o->npen * nl * (q + 3) + 4 + stats_len(p)) * 8 + 4096;
-    b += (q > SMALL_P_MAX ? path_large_work_doubles(q, 128) * 8 : path_small_xchg_bytes()) + 4096;
+    b += (q > SMALL_P_MAX ? path_large_work_doubles(q, 128) * 8 : path_small_xchg_bytes() * splits) + 4096;
     return b;
 }
 

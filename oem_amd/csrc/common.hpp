@@ -96,15 +96,23 @@ struct PathArgs {
     // except xx, xy, stats (element strides bs_xx, bs_xy, bs_stats), the outputs (byte stride bs_out) and work (bs_work)
     int nbatch;
     long long bs_xx, bs_xy, bs_stats, bs_out, bs_work;
+    // pen_split (p <= SMALL_P_MAX only): every penalty of every instance gets a workgroup (set) of its own -- penalties are
+    // independent cold starts (ref src/oem_dense.cpp:243-244) -- so blockIdx.y = instance + nbatch * penalty; pen_lo / pen_hi are
+    // the penalties this workgroup walks ([0, npen) without the split)
+    int pen_split, pen_lo, pen_hi;
     const double *lmax_xy;   // not null: every instance takes lambda_zero from THIS xy (xval.oem: the grid of the full-data fit, ref src/oem_xval_dense.cpp:177-194)
 };
 
 // the problem instance of this workgroup (see PathArgs::nbatch); all scalar arithmetic
 __device__ __forceinline__ PathArgs path_instance(PathArgs A)
 {
+    const int nb = A.nbatch > 1 ? A.nbatch : 1;
+    const long long y = blockIdx.y;
+    if (A.pen_split) { A.pen_lo = (int)(y / nb); A.pen_hi = A.pen_lo + 1; }
+    A.work += y * A.bs_work;                                   // exchange granules: one set per workgroup set
     if (A.nbatch > 1) {
-        const long long b = blockIdx.y;
-        A.xx += b * A.bs_xx; A.xy += b * A.bs_xy; A.stats += b * A.bs_stats; A.work += b * A.bs_work;
+        const long long b = y % nb;
+        A.xx += b * A.bs_xx; A.xy += b * A.bs_xy; A.stats += b * A.bs_stats;
         const long long ob = b * A.bs_out;
         A.beta = (double *)((char *)A.beta + ob); A.lambda_out = (double *)((char *)A.lambda_out + ob);
         A.loss = (double *)((char *)A.loss + ob); A.d_out = (double *)((char *)A.d_out + ob);

@@ -830,7 +830,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
 
     double beta[R], bold[R], ab[R];
     double betaE[NB], boldE[NB], abE[NB];
-    for (int pp = 0; pp < A.npen; ++pp) {
+    for (int pp = A.pen_lo; pp < A.pen_hi; ++pp) {
         const int pen = A.penalty[pp];
         const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
         const bool isnet = pen_is_net(pen);
@@ -1416,7 +1416,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
             __syncthreads();                                             // LAM is rewritten by the next chunk
         }
     };
-    for (int pp = 0; pp < A.npen; ++pp) {
+    for (int pp = A.pen_lo; pp < A.pen_hi; ++pp) {
         const int pen = A.penalty[pp];
         const int kind = pen_consts(pen, 1.0, d, A.alpha, A.gamma, A.tau).kind;
         using T = std::true_type; using F = std::false_type;
@@ -1445,12 +1445,15 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
     }
 }
 
+// workgroup sets of one launch: instances x (penalties, when split)
+static inline int path_grid_y(const PathArgs &a) { return (a.nbatch > 1 ? a.nbatch : 1) * (a.pen_split ? a.npen : 1); }
+
 template <int NW, int CG, int CGL = 0> int launch_rows(hipStream_t s, const PathArgs &a)
 {
     const size_t sh = (size_t)RowsCfg<NW, CG, CGL>::N_DBL * sizeof(double);
     if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_rows_kernel<NW, CG, CGL>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    hipLaunchKernelGGL((path_rows_kernel<NW, CG, CGL>), dim3(1, a.nbatch > 1 ? a.nbatch : 1), dim3(NW * 64), sh, s, a);
+    hipLaunchKernelGGL((path_rows_kernel<NW, CG, CGL>), dim3(1, path_grid_y(a)), dim3(NW * 64), sh, s, a);
     OEM_HIP(hipGetLastError());
     return 0;
 }
@@ -1459,7 +1462,7 @@ template <int R, int NW, int CW, int G = 1> int launch_cfg(hipStream_t s, const 
 {
     typedef Cfg<R, NW, CW> C;
     const size_t sh = (size_t)C::N_DBL * sizeof(double);
-    const int nbatch = a.nbatch > 1 ? a.nbatch : 1;
+    const int nbatch = path_grid_y(a);
     if (G > 1) {                                                                    // granule tags must start at 0
         if (nbatch > 1 && (size_t)a.bs_work * 8 != path_small_xchg_bytes()) { set_error("internal: batch work stride"); return OEMGPU_ERR_INTERNAL; }
         OEM_HIP(hipMemsetAsync(a.work, 0, path_small_xchg_bytes() * nbatch, s));
