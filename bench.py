@@ -10,9 +10,9 @@ y = X b + N(0,1); oem(penalty="elastic.net", alpha=1) (= lasso), intercept, no s
 a first default fit supplied back, tol = 1e-10.  Synthetic data, generated on the device, resident in HBM when
 the timed region starts.
 
-A "step" is one complete solve: shift sample -> one-pass MFMA moment build -> (N > 1: all-reduce) -> finalize ->
+A "step" is one complete solve: one-pass MFMA moment build (about 0; a shifted redo only if finalize asks) -> (N > 1: all-reduce) -> finalize ->
 eigenvalue -> 100-lambda path -> results on the host.  With N > 1 the n rows are split across the ranks (strong
-scaling: the total problem stays n = 1e6) and the sample sums + (p+2)^2 moment buffer are summed with one RCCL all-reduce
+scaling: the total problem stays n = 1e6) and the (p+2)^2 moment buffer is summed with one RCCL all-reduce
 (oem_amd/distributed.py: solve_row_shards).
 
 Rank 0 prints ONE JSON line (see the repo README / DESIGN.md for the roofline and cpu_baseline fields).
@@ -107,7 +107,7 @@ def main():
     lambdas = solve_py((), 1e-7)["lambda"][0]
 
     # The timed step is the C-ABI call sequence itself (what `.Call("oem_fit_dense")` is to the reference):
-    # arguments marshalled once, then per step: shift sample -> moments -> [all-reduce] -> solve (results on host).
+    # arguments marshalled once, then per step: moments -> [all-reduce] -> solve (results on host) [-> shifted redo if advised].
     args = api._Args(["elastic.net"], [np.asarray(lambdas)], 100, 1e-4, 1.0, 3.0, 0.5, 1e-10, 500, False, False,
                      np.ones(p), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0))
     bufs = sharded_buffers(backend, p)

@@ -169,6 +169,14 @@ int oemgpu_fit_xtx_dev(oemgpu_ctx *ctx, const double *xtx_dev, const double *xty
                        const double *scale_factor, const oemgpu_opts *o,
                        double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
 
+/* 1 if the most recent oemgpu_solve_moments_dev (OEMGPU_SEM_DENSE) on this context was given moments about 0
+ * (sums_dev == NULL) of data in which some column has mean^2 > 2^8 var -- the shift predicate above, evaluated on the
+ * full-data moments.  The coefficients just returned may then have lost (mean/sd)^2 eps of relative accuracy to
+ * cancellation: redo the pass about a shift (oemgpu_shift_sums_dev, oemgpu_moments_dev and this call with those sums).
+ * 0 otherwise, -1 for a NULL context.  oemgpu_fit_dense(_dev) and the row-sharded driver do exactly this, so that the
+ * usual data costs one pass and one collective, with no sample pass in front. */
+int oemgpu_last_shift_advised(oemgpu_ctx *ctx);
+
 /* oemgpu_xval_dense with X (n x p, leading dimension ld >= n), y and foldid already on the device. */
 int oemgpu_xval_dense_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
                           const int32_t *foldid_dev, int32_t nfolds, int32_t standardize, int32_t intercept,
@@ -177,9 +185,7 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64
                           double *cvm, double *cvsd);
 
 /* 1 if the most recent oemgpu_solve_moments_dev on this context found the shift predicate above true for its
- * sums_dev (and so read moments_dev as accumulated about c), 0 if not, -1 for a NULL context.  The row-sharded
- * driver builds its moments about c = 0 BEFORE the sums are all-reduced (one collective for sums and moments
- * together) and uses this to detect the rare case in which that guess was wrong and the pass must be redone. */
+ * sums_dev (and so read moments_dev as accumulated about c), 0 if not, -1 for a NULL context. */
 int oemgpu_last_shift_in_effect(oemgpu_ctx *ctx);
 
 /* lambda_max of a symmetric p x p device matrix (the Spectra call of ref src/oem_dense.h:485-498). */

@@ -45,6 +45,7 @@ struct oemgpu_ctx {
     double ms[OEMGPU_NTIMERS];
     double diag[2] = {0.0, 0.0};   // path kernel: shader cycles, 100 MHz ticks
     int shifted = 0;               // the last solve read its moments as accumulated about the provisional shift
+    int shift_advised = 0;         // the last solve was given moments about 0 whose columns have |mean| >> sd
     char *aux = nullptr;           // xval.oem: fold-ordered copy of X, fold moments, fold coefficients (grow-only)
     size_t aux_bytes = 0;
     std::vector<oemgpu_ctx *> kids;   // xval.oem: one child context (stream, workspace, staging) per concurrent fold fit
@@ -283,6 +284,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
         if (hd[1] < 0.0) { set_error("cooperating workgroups lost each other (exchange timeout)"); return OEMGPU_ERR_INTERNAL; }
         c->diag[0] = hd[2]; c->diag[1] = hd[3];
         c->shifted = hs[stats_shift_flag(p)] != 0.0;
+        c->shift_advised = hs[stats_shift_flag(p) + 1] != 0.0;
         const double meany = hs[0], scaley = hs[1];
         const double *meanx = hs + 4, *scalex = hs + 4 + p;
         for (int k = 0; k < npen; ++k) {
@@ -523,6 +525,15 @@ int oemgpu_fit_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t 
     if (need2 > need) need = need2;
     if (ctx_reserve(c, need)) return OEMGPU_ERR_HIP;
     double *sums = (double *)(c->ws + a_sums), *mom = (double *)(c->ws + a_mom);
+    // Moments about 0 first: that is what the shift predicate yields unless some column has |mean| > 16 sd, and finalize tells
+    // (from the full-data moments) when it was the wrong guess.  The sample pass and the shifted pass then run only for such data.
+    {
+        Timer t(c, OEMGPU_T_MOMENTS);
+        rc = shard_moments(c, pl, x_dev, n, ld, y_dev, nullptr, (double *)(c->ws + a_t), (double *)(c->ws + a_v), mom);
+        if (rc) return rc;
+    }
+    rc = oemgpu_solve_moments_dev(c, mom, nullptr, p, OEMGPU_SEM_DENSE, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+    if (rc || !c->shift_advised) return rc;
     {
         Timer t(c, OEMGPU_T_SHIFT);
         rc = launch_shift_sums(c->stream, x_dev, n, ld, p, y_dev, sums);
@@ -564,6 +575,7 @@ int oemgpu_fit_xtx_dev(oemgpu_ctx *c, const double *xtx_dev, const double *xty_d
 }
 
 int oemgpu_last_shift_in_effect(oemgpu_ctx *c) { return c ? c->shifted : -1; }
+int oemgpu_last_shift_advised(oemgpu_ctx *c) { return c ? c->shift_advised : -1; }
 
 int oemgpu_eig_max_dev(oemgpu_ctx *c, const double *a_dev, int32_t p, double *lambda_max)
 {
@@ -669,8 +681,9 @@ int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_
     if (n <= q) { set_error("p >= n: the XXt branch (ref src/oem_big.h:547-551) is not part of this path"); return OEMGPU_ERR_UNSUPPORTED; }
     oemgpu_ctx *c = oemgpu_create(o->device, nullptr);
     if (!c) return OEMGPU_ERR_NO_DEVICE;
-    // The reference walks row slices serially (ref src/oem_big.h:329-358).  Here: stream the shards through one
-    // device buffer twice (sample sums for the common shift, then the moments) and add the shard moments.
+    // The reference walks row slices serially (ref src/oem_big.h:329-358).  Here: stream the shards through one device buffer
+    // ONCE and add the shard moments.  They are taken about 0, like the reference's own sums: oemBig never centres
+    // (ref src/oem_big.h:757-763, 469-545), so there is no cancellation for a shift to prevent.
     double *xd = nullptr, *yd = nullptr, *acc = nullptr;
     const int64_t ldmax = (nmax + 1) / 2 * 2;
     const size_t mlen = (size_t)oemgpu_moments_len(p), slen = (size_t)oemgpu_sums_len(p);
@@ -678,12 +691,12 @@ int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_
     if (e == hipSuccess) e = hipMalloc((void **)&yd, sizeof(double) * (size_t)(ldmax + 2));
     if (e == hipSuccess) e = hipMalloc((void **)&acc, sizeof(double) * (2 * mlen + 2 * slen));
     if (e != hipSuccess) { set_error("fit_big: device allocation failed: %s", hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; }
-    double *msum = acc, *mtmp = acc + mlen, *ssum = acc + 2 * mlen, *stmp = ssum + slen;
+    double *msum = acc, *mtmp = acc + mlen;
     if (!rc) {
         e = hipMemsetAsync(acc, 0, sizeof(double) * (2 * mlen + 2 * slen), c->stream);
         if (e != hipSuccess) { set_error("memset failed"); rc = OEMGPU_ERR_HIP; }
     }
-    for (int pass = 0; pass < 2 && !rc; ++pass) {
+    {
         for (int s = 0; s < nshards && !rc; ++s) {
             const int64_t ns = n_shard[s];
             if (ns == 0) continue;
@@ -693,17 +706,12 @@ int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_
                                       sizeof(double) * (size_t)ns, p, hipMemcpyHostToDevice, c->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(yd, y_shards[s], sizeof(double) * (size_t)ns, hipMemcpyHostToDevice, c->stream);
             if (e != hipSuccess) { set_error("fit_big: upload of shard %d failed: %s", s, hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; break; }
-            if (pass == 0) {
-                rc = oemgpu_shift_sums_dev(c, xd, ns, ld, p, yd, stmp);
-                if (!rc) hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(256), 0, c->stream, ssum, stmp, slen);
-            } else {
-                rc = oemgpu_moments_dev(c, xd, ns, ld, p, yd, ssum, mtmp);
-                if (!rc) hipLaunchKernelGGL(accumulate_kernel, dim3(64), dim3(256), 0, c->stream, msum, mtmp, mlen);
-            }
+            rc = oemgpu_moments_dev(c, xd, ns, ld, p, yd, nullptr, mtmp);
+            if (!rc) hipLaunchKernelGGL(accumulate_kernel, dim3(64), dim3(256), 0, c->stream, msum, mtmp, mlen);
             if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("fit_big: shard %d failed on the device", s); rc = OEMGPU_ERR_HIP; }
         }
     }
-    if (!rc) rc = oemgpu_solve_moments_dev(c, msum, ssum, p, OEMGPU_SEM_BIG, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+    if (!rc) rc = oemgpu_solve_moments_dev(c, msum, nullptr, p, OEMGPU_SEM_BIG, standardize, intercept, o, beta, lambda_out, niter, loss, d);
     (void)hipStreamSynchronize(c->stream);
     if (xd) (void)hipFree(xd);
     if (yd) (void)hipFree(yd);

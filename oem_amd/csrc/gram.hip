@@ -1301,7 +1301,23 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict_
     }
     const double n = m.n;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
-    if (tid == 0) { stats[stats_shift_flag(p)] = m.shift ? 1.0 : 0.0; stats[stats_shift_flag(p) + 1] = 0.0; }
+    // Moments about 0 (no sums) that DataStd will centre: say so if some column has mean^2 > 2^8 var -- the predicate of
+    // oemgpu.h on the full data instead of a sample -- so that the caller can redo the pass about a shift.  oemBig / oemXvalDense
+    // use the raw moments themselves (the reference accumulates them about 0 too): nothing to advise.
+    __shared__ int advise;
+    if (threadIdx.x == 0) advise = 0;
+    __syncthreads();
+    if (!sums && sem == OEMGPU_SEM_DENSE && blockIdx.x == 0) {
+        const int q = p + 2;
+        for (int j = threadIdx.x; j <= p; j += blockDim.x) {
+            const double mean = Mbuf[(size_t)j * q + (p + 1)] / n;
+            double var = Mbuf[(size_t)j * q + j] / n - mean * mean;
+            if (!(var > 0.0)) var = 0.0;
+            if (mean * mean > 256.0 * var) advise = 1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { stats[stats_shift_flag(p)] = m.shift ? 1.0 : 0.0; stats[stats_shift_flag(p) + 1] = advise ? 1.0 : 0.0; }
     if (sem == OEMGPU_SEM_DENSE) {
         const int flag = (standardize ? 1 : 0) + 2 * (intercept ? 1 : 0);
         // y

@@ -5,15 +5,15 @@ ref src/oem_dense.h:328-358, and across slices, ref src/oem_big.h:329-358).  Eac
 contiguous block of rows, builds the shifted moment buffer M_r of its block with the MFMA kernel,
 and the ranks sum them:
 
-    [sums | M] <- all_reduce([sample sums_r | M_r])    (2p+4 + (p+2)^2 doubles in ONE buffer, one collective; c5: 532 KB)
-    result     <- solve_moments(M, sums)               (replicated: the lambda path is a serial chain of tiny GEMVs)
+    M      <- all_reduce(M_r)             ((p+2)^2 doubles about c = 0, ONE collective; c1: 83 KB, c5: 532 KB)
+    result <- solve_moments(M)            (replicated: the lambda path is a serial chain of tiny GEMVs)
 
-The shift c that the moments are accumulated about is a function of the ALL-REDUCED sample sums, which a rank does not
-have when it starts its Gram pass.  A second, earlier collective would cost more than the Gram pass itself at 8 GPUs
-(the whole step is latency-bound), so each rank builds M_r about c = 0 -- what the predicate yields unless some column
-has |mean| > 16 sd -- and ships its sample sums in the same buffer.  Every rank then sees the same reduced sums; if they
-do call for a shift (oemgpu_last_shift_in_effect), all ranks redo the pass about the agreed c with one more all-reduce.
-Either way the result is the one the two-collective protocol gives, bit for bit.
+The shift c that guards the centred moments against cancellation would be a function of ALL the data, which a rank does not
+have when it starts its Gram pass; an earlier collective for it would cost more than the Gram pass itself at 8 GPUs (the
+whole step is latency-bound).  So every rank builds M_r about c = 0 -- right unless some column has |mean| > 16 sd -- and
+the solve reports, from the reduced full-data moments, when that was the wrong guess (oemgpu_last_shift_advised).  Every rank
+sees the same reduced M, so all of them take the redo branch or none: sample sums, one all-reduce to agree on c, the pass
+about c, its all-reduce, the solve.  No sample pass and no second collective for the usual data.
 
 `backend` supplies the three local stages; the product backend is HipBackend (liboemgpu).  Tests run
 the same driver under gloo on CPU with a checker backend, which is how the N > 1 logic is covered
@@ -63,13 +63,17 @@ class HipBackend:
                                             None if sums is None else sums.data_ptr(), out.data_ptr()))
 
     def solve(self, moments, sums, p, semantics, standardize, intercept, args):
-        L.check(self.lib.oemgpu_solve_moments_dev(self.ctx, moments.data_ptr(), sums.data_ptr(), p, semantics,
+        L.check(self.lib.oemgpu_solve_moments_dev(self.ctx, moments.data_ptr(), None if sums is None else sums.data_ptr(), p, semantics,
                                                   int(bool(standardize)), int(bool(intercept)), C.byref(args.c),
                                                   *args.outputs(p + 1)))
 
     def shift_in_effect(self):
         """did the last solve() find that its sums call for a shift (and read the moments as shifted)?"""
         return self.lib.oemgpu_last_shift_in_effect(self.ctx) == 1
+
+    def shift_advised(self):
+        """was the last solve() given moments about 0 of columns with |mean| >> sd (redo about a shift)?"""
+        return self.lib.oemgpu_last_shift_advised(self.ctx) == 1
 
 
 def row_partition(n, world):
@@ -79,27 +83,26 @@ def row_partition(n, world):
 
 
 def sharded_buffers(backend, p):
-    """(joint, sums, moments): one allocation, so that sums and moments travel in one all-reduce"""
-    ns = L.sums_len(p)                              # even: the moment view stays 16-byte aligned
-    joint = backend.new_buffer(ns + L.moments_len(p))
-    return joint, joint[:ns], joint[ns:]
+    """(sums, moments) device buffers of one solve"""
+    return backend.new_buffer(L.sums_len(p)), backend.new_buffer(L.moments_len(p))
 
 
 def solve_row_shards(backend, dist, group, x, n_local, ld, p, y, bufs, semantics, standardize, intercept, args):
-    """The three local stages and the collective(s) between them (module docstring); call inside backend.section().
+    """The local stages and the collective between them (module docstring); call inside backend.section().
     Every rank ends with the full result in `args`."""
-    joint, sums, mom = bufs
-    backend.shift_sums(x, n_local, ld, p, y, sums)
-    if dist is None or dist.get_world_size(group) == 1:
+    sums, mom = bufs
+    many = dist is not None and dist.get_world_size(group) > 1
+    backend.moments(x, n_local, ld, p, y, None, mom)              # about c = 0: the usual verdict
+    if many:
+        dist.all_reduce(mom, group=group)                         # the single Gram all-reduce of the north star
+    backend.solve(mom, None, p, semantics, standardize, intercept, args)
+    if backend.shift_advised():                                   # same reduced moments on every rank: all redo or none
+        backend.shift_sums(x, n_local, ld, p, y, sums)
+        if many:
+            dist.all_reduce(sums, group=group)
         backend.moments(x, n_local, ld, p, y, sums, mom)
-        backend.solve(mom, sums, p, semantics, standardize, intercept, args)
-        return
-    backend.moments(x, n_local, ld, p, y, None, mom)          # about c = 0: the usual verdict of the reduced sums
-    dist.all_reduce(joint, group=group)                       # the single Gram all-reduce of the north star
-    backend.solve(mom, sums, p, semantics, standardize, intercept, args)
-    if backend.shift_in_effect():                             # same reduced sums on every rank: all take this branch or none
-        backend.moments(x, n_local, ld, p, y, sums, mom)
-        dist.all_reduce(mom, group=group)
+        if many:
+            dist.all_reduce(mom, group=group)
         backend.solve(mom, sums, p, semantics, standardize, intercept, args)
 
 
@@ -131,7 +134,7 @@ def oem_sharded(x_local, y_local, backend=None, dist=None, group=None, big=False
         bufs = sharded_buffers(backend, p)
         solve_row_shards(backend, dist, group, x_local, n_local, ld, p, y_local, bufs,
                          L.OEMGPU_SEM_BIG if big else L.OEMGPU_SEM_DENSE, standardize, intercept, args)
-        mom = bufs[2]
+        mom = bufs[1]
         n_total = int(round(float(mom.reshape(p + 2, p + 2)[p + 1, p + 1])))
     if varnames is None:
         varnames = [f"V{i + 1}" for i in range(p)]

@@ -41,10 +41,21 @@ class CheckerBackend:
         z = np.column_stack([x.numpy() - c[:p], y.numpy() - c[p], np.ones(n)])
         out.copy_(torch.from_numpy((z.T @ z).ravel()))
 
+    def shift_advised(self):
+        return self.advised
+
     def solve(self, mom, sums, p, semantics, standardize, intercept, args):
         assert semantics == 0
-        M = mom.numpy().reshape(p + 2, p + 2); s = sums.numpy()
-        n = M[p + 1, p + 1]; c = shift_in_effect(s, p)
+        M = mom.numpy().reshape(p + 2, p + 2)
+        n = M[p + 1, p + 1]
+        if sums is None:                                          # include/oemgpu.h, oemgpu_last_shift_advised
+            c = np.zeros(p + 1)
+            mean = M[p + 1, :p + 1] / n
+            var = np.maximum(np.diag(M)[:p + 1] / n - mean * mean, 0.0)
+            self.advised = bool(np.any(mean * mean > 256.0 * var))
+        else:
+            c = shift_in_effect(sums.numpy(), p)
+            self.advised = False
         self.shifted = bool(np.any(c != 0.0))
         sh = M[p + 1, :p + 1]
         mu = c + sh / n

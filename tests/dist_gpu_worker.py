@@ -33,7 +33,7 @@ for rep in range(6):                         # back to back, no host sync in bet
     for k in range(2):
         err = float(np.abs(fit["beta"][k] - ref["beta"][k]).max())
         ok &= err < 1e-9 and np.array_equal(fit["niter"][k], ref["niter"][k])
-ok &= not be.shift_in_effect()             # centred data: one collective, no redo
+ok &= not be.shift_advised() and not be.shift_in_effect()      # centred data: one collective, no redo
 # columns with |mean| = 67 sd: the reduced sums call for the shift, every rank redoes its pass about the agreed c
 xs = (xt[:, lo:hi] + 200.0).contiguous().t()
 whole = (xt + 200.0).t()

@@ -1,6 +1,6 @@
 """The row-sharded driver (oem_amd/distributed.py) under gloo with world_size 2, on CPU: row partition, the single
-all-reduce of [sample sums | moments about 0], the redo about the agreed shift when the reduced sums call for one
-(columns with |mean| >> sd), and the replicated solve.  The local stages come from
+all-reduce of the moments about 0, the redo about an agreed shift when the reduced moments call for one (columns with
+|mean| >> sd), and the replicated solve.  The local stages come from
 tests/checker_backend.py; on GPUs the same driver runs with HipBackend over RCCL (bench.py --gpus N)."""
 import os
 import socket
