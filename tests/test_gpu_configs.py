@@ -193,3 +193,72 @@ def test_replicated_update_fused_engine(oa, p):
     for k in range(2):
         assert np.abs(fit["beta"][k] - ref["beta"][k]).max() < 1e-9
         assert np.abs(fit["beta"][k] - two["beta"][k]).max() < 1e-12
+
+
+def _device_problem(n, p, nnz, seed, sd=1.0):
+    """Synthetic data generated on the device (column-major X as the transpose view of a (p, n) tensor)."""
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    xt = torch.empty((p, n), device="cuda", dtype=torch.float64)
+    for j0 in range(0, p, 64):                               # in slabs: randn's temporaries stay small next to a 25 GB X
+        j1 = min(p, j0 + 64)
+        xt[j0:j1] = torch.randn((j1 - j0, n), generator=g, device="cuda", dtype=torch.float64) * sd
+    b = torch.zeros(p, device="cuda", dtype=torch.float64)
+    b[:nnz] = torch.rand(nnz, generator=g, device="cuda", dtype=torch.float64) - 0.5
+    y = torch.randn(n, generator=g, device="cuda", dtype=torch.float64)
+    y += torch.mv(xt.t(), b)
+    return xt.t(), y
+
+
+def test_config3_full_size_group_lasso_kkt(oa):
+    """config 3 at full size (n = 1e6, p = 512, 64 groups of 8, 100 lambdas, tol 1e-10, no intercept / standardisation as in the
+    reference's README) through the group-lasso optimality conditions: with r = X'(y - X b)/n, a zero group has
+    ||r_g|| <= lambda w_g and an active one r_g = lambda w_g b_g / ||b_g||  (w_g = sqrt(8))."""
+    import torch
+    n, p = 1_000_000, 512
+    x, y = _device_problem(n, p, 40, 31, sd=1.0)
+    groups = np.repeat(np.arange(1, 65), 8)
+    fit = oa.oem(x, y, penalty="grp.lasso", groups=groups, intercept=False, standardize=False, tol=1e-10)
+    beta, lam = fit["beta"][0], fit["lambda"][0]
+    assert beta.shape == (p + 1, 100) and np.all(beta[:, 0] == 0) and np.all(beta[0] == 0)
+    assert np.all(fit["niter"][0] <= 500)
+    bd = torch.as_tensor(beta[1:], device="cuda")
+    wg = np.sqrt(8.0)
+    for i in (1, 20, 60, 99):
+        r = (torch.mv(x.t(), y - torch.mv(x, bd[:, i])) / n).cpu().numpy().reshape(64, 8)
+        bg = beta[1:, i].reshape(64, 8)
+        nb = np.linalg.norm(bg, axis=1)
+        act = nb > 0
+        assert act.any() or i < 5
+        assert np.all(np.linalg.norm(r[~act], axis=1) <= lam[i] * wg * (1 + 1e-6))
+        if act.any():
+            assert np.abs(r[act] - lam[i] * wg * bg[act] / nb[act, None]).max() <= 2e-7 * lam[0]
+
+
+def test_config5_one_gpu_share_full_size_kkt(oa):
+    """config 5: one rank's share of the 1e8 x 256 problem at 8 GPUs is 1.25e7 rows = 25.6 GB of X -- the largest single-GPU
+    input of BASELINE.json.  big.oem semantics through the row-sharded driver with one rank; checked through the lasso optimality
+    conditions on the standardised scale the solver works in (columns scaled by sqrt(sum x^2 / (n - 1)), unpenalised intercept)."""
+    import torch
+    from oem_amd.distributed import oem_sharded
+    n, p = 12_500_000, 256
+    x, y = _device_problem(n, p, 30, 32, sd=1.0)
+    y += 1.5
+    fit = oem_sharded(x, y, big=True, penalty="lasso", nlambda=20, tol=1e-10)
+    beta, lam = fit["beta"][0], fit["lambda"][0]
+    assert fit["nobs"] == n and beta.shape == (p + 1, 20)
+    assert np.all(fit["niter"][0] <= 500)
+    s = torch.sqrt((x * x).sum(0) / (n - 1.0))                        # ref src/oem_big.h:757-763
+    bd = torch.as_tensor(beta, device="cuda")
+    for i in (1, 10, 19):
+        res = y - torch.mv(x, bd[1:, i]) - bd[0, i]
+        assert abs(float(res.sum()) / n) <= 1e-9                      # the intercept is not penalised
+        g = (torch.mv(x.t(), res) / n / s).cpu().numpy()              # gradient in the standardised coordinates
+        bs = beta[1:, i] * s.cpu().numpy()
+        nz = bs != 0
+        assert np.abs(g[~nz]).max() <= lam[i] * (1 + 1e-6)
+        if nz.any():
+            assert np.abs(g[nz] - lam[i] * np.sign(bs[nz])).max() <= 2e-7 * lam[0]
+    assert (beta[1:, 19] != 0).sum() >= 30                            # lambda_zero counts the intercept slot (quirk Q10): the early lambdas select nothing
+    del x, y
+    torch.cuda.empty_cache()

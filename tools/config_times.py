@@ -90,6 +90,22 @@ be = HipBackend()
 t_gpu = timeit(lambda: oem_sharded(xt.t(), yd, backend=be, big=True, penalty="lasso", nlambda=100, tol=1e-10), 2)
 out["config5_big_p256_n4e6_one_gpu"] = {"gpu_ms": 1e3 * t_gpu, "rows": n, "note": "1/25 of the 1e8-row config; one rank's share at 8 GPUs is 1.25e7 rows"}
 del xt, yd
+# ... and the full share of one rank at 8 GPUs: 1.25e7 rows = 25.6 GB of X
+n = 12_500_000
+xt = torch.empty((p, n), device="cuda", dtype=torch.float64)
+for j0 in range(0, p, 64):
+    xt[j0:j0 + 64] = torch.randn((64, n), generator=g, device="cuda", dtype=torch.float64)
+yd = torch.randn(n, generator=g, device="cuda", dtype=torch.float64)
+yd += torch.mv(xt.t(), bb)
+lib_ = oem_amd.lib(); lib_.oemgpu_set_timing(be.ctx, 1)
+t_gpu = timeit(lambda: oem_sharded(xt.t(), yd, backend=be, big=True, penalty="lasso", nlambda=100, tol=1e-10), 2)
+import ctypes as C_
+ms_ = (C_.c_double * 8)(); lib_.oemgpu_last_timings(be.ctx, ms_); lib_.oemgpu_set_timing(be.ctx, 0)
+fl = float(n) * p * (p + 1) + 2.0 * n * p
+out["config5_big_p256_n1.25e7_one_rank_share"] = {"gpu_ms": 1e3 * t_gpu, "rows": n, "gram_kernel_ms": ms_[4],
+                                                  "gram_TFLOPs": fl / (ms_[4] * 1e-3) / 1e12 if ms_[4] > 0 else None,
+                                                  "note": "25.6 GB of X resident in HBM; at 8 GPUs add one 532 KB all-reduce"}
+del xt, yd
 
 # config 1, host-resident X through oemgpu_fit_dense (PCIe inclusive)
 n, p = 1_000_000, 100
