@@ -111,9 +111,11 @@ def main():
     args = api._Args(["elastic.net"], [np.asarray(lambdas)], 100, 1e-4, 1.0, 3.0, 0.5, 1e-10, 500, False, False,
                      np.ones(p), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0))
     bufs = sharded_buffers(backend, p)
+    outs = args.outputs(p + 1)                  # caller-allocated result buffers, written by every step
 
     def solve(lam=None, tol=None):              # call inside `with backend.section():`
-        solve_row_shards(backend, dd, None, x, n_loc, n_loc, p, y, bufs, L.OEMGPU_SEM_DENSE, False, True, args)
+        # N = 1: oemgpu_fit_dense_dev (the drop-in entry point); N > 1: moments -> all-reduce -> solve
+        solve_row_shards(backend, dd, None, x, n_loc, n_loc, p, y, bufs, L.OEMGPU_SEM_DENSE, False, True, args, outs)
         return args
     # kernels and RCCL collectives are stream-ordered on the backend's stream: one section around each loop
     with backend.section():

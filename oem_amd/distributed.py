@@ -27,6 +27,9 @@ from . import _lib as L
 from . import api as _api
 
 
+_STAGED_ALWAYS = bool(__import__("os").environ.get("OEM_STAGED_ALWAYS"))      # diagnostic: the N > 1 call sequence on one rank too
+
+
 class HipBackend:
     """Local stages on this rank's GPU through the C ABI (oemgpu_*_dev)."""
 
@@ -62,10 +65,16 @@ class HipBackend:
         L.check(self.lib.oemgpu_moments_dev(self.ctx, x.data_ptr(), n, ld, p, y.data_ptr(),
                                             None if sums is None else sums.data_ptr(), out.data_ptr()))
 
-    def solve(self, moments, sums, p, semantics, standardize, intercept, args):
+    def solve(self, moments, sums, p, semantics, standardize, intercept, args, outs=None):
+        """outs: the host result buffers of an earlier args.outputs(p + 1), to be written again (repeated solves)"""
         L.check(self.lib.oemgpu_solve_moments_dev(self.ctx, moments.data_ptr(), None if sums is None else sums.data_ptr(), p, semantics,
                                                   int(bool(standardize)), int(bool(intercept)), C.byref(args.c),
-                                                  *args.outputs(p + 1)))
+                                                  *(args.outputs(p + 1) if outs is None else outs)))
+
+    def fit_dense(self, x, n, ld, p, y, standardize, intercept, args, outs=None):
+        """oemgpu_fit_dense_dev: the whole single-GPU solve (moments, verdict on the shift, redo if advised, paths) in one call"""
+        L.check(self.lib.oemgpu_fit_dense_dev(self.ctx, x.data_ptr(), n, ld, p, y.data_ptr(), int(bool(standardize)),
+                                              int(bool(intercept)), C.byref(args.c), *(args.outputs(p + 1) if outs is None else outs)))
 
     def shift_in_effect(self):
         """did the last solve() find that its sums call for a shift (and read the moments as shifted)?"""
@@ -87,15 +96,18 @@ def sharded_buffers(backend, p):
     return backend.new_buffer(L.sums_len(p)), backend.new_buffer(L.moments_len(p))
 
 
-def solve_row_shards(backend, dist, group, x, n_local, ld, p, y, bufs, semantics, standardize, intercept, args):
+def solve_row_shards(backend, dist, group, x, n_local, ld, p, y, bufs, semantics, standardize, intercept, args, outs=None):
     """The local stages and the collective between them (module docstring); call inside backend.section().
     Every rank ends with the full result in `args`."""
     sums, mom = bufs
     many = dist is not None and dist.get_world_size(group) > 1
+    if not many and semantics == L.OEMGPU_SEM_DENSE and hasattr(backend, "fit_dense") and not _STAGED_ALWAYS:
+        backend.fit_dense(x, n_local, ld, p, y, standardize, intercept, args, outs)      # one rank: the drop-in entry point does it all
+        return
     backend.moments(x, n_local, ld, p, y, None, mom)              # about c = 0: the usual verdict
     if many:
         dist.all_reduce(mom, group=group)                         # the single Gram all-reduce of the north star
-    backend.solve(mom, None, p, semantics, standardize, intercept, args)
+    backend.solve(mom, None, p, semantics, standardize, intercept, args, outs)
     if backend.shift_advised():                                   # same reduced moments on every rank: all redo or none
         backend.shift_sums(x, n_local, ld, p, y, sums)
         if many:
@@ -103,7 +115,7 @@ def solve_row_shards(backend, dist, group, x, n_local, ld, p, y, bufs, semantics
         backend.moments(x, n_local, ld, p, y, sums, mom)
         if many:
             dist.all_reduce(mom, group=group)
-        backend.solve(mom, sums, p, semantics, standardize, intercept, args)
+        backend.solve(mom, sums, p, semantics, standardize, intercept, args, outs)
 
 
 def oem_sharded(x_local, y_local, backend=None, dist=None, group=None, big=False, penalty=None, lambda_=(),
@@ -134,8 +146,10 @@ def oem_sharded(x_local, y_local, backend=None, dist=None, group=None, big=False
         bufs = sharded_buffers(backend, p)
         solve_row_shards(backend, dist, group, x_local, n_local, ld, p, y_local, bufs,
                          L.OEMGPU_SEM_BIG if big else L.OEMGPU_SEM_DENSE, standardize, intercept, args)
-        mom = bufs[1]
-        n_total = int(round(float(mom.reshape(p + 2, p + 2)[p + 1, p + 1])))
+        if dist is not None and dist.get_world_size(group) > 1:
+            n_total = int(round(float(bufs[1].reshape(p + 2, p + 2)[p + 1, p + 1])))      # the reduced row count
+        else:
+            n_total = int(n_local)
     if varnames is None:
         varnames = [f"V{i + 1}" for i in range(p)]
     return _api._decorate(args, penalty, varnames, True, n_total, p)

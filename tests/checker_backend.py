@@ -44,7 +44,7 @@ class CheckerBackend:
     def shift_advised(self):
         return self.advised
 
-    def solve(self, mom, sums, p, semantics, standardize, intercept, args):
+    def solve(self, mom, sums, p, semantics, standardize, intercept, args, outs=None):
         assert semantics == 0
         M = mom.numpy().reshape(p + 2, p + 2)
         n = M[p + 1, p + 1]
