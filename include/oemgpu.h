@@ -98,6 +98,16 @@ int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_
                    int32_t standardize, int32_t intercept, const oemgpu_opts *o,
                    double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
 
+/* replaces oem_fit_sparse, ref src/oem_sparse.cpp:30-267 (family "gaussian", weights empty, n > p): oem() on a dgCMatrix.
+ * colptr[p + 1], rowidx[nnz], values[nnz]: the compressed sparse column slots @p, @i, @x (row indices increasing inside a
+ * column).  Outputs as oemgpu_fit_dense.  The semantics are oemSparse's, not oemDense's: no centring, columns scaled by
+ * sqrt(sum x^2 / (n - 1)), the intercept as a Gram column of value sqrt(mean diag / n) whose coefficient is rescaled in
+ * place after every lambda (ref src/oem_sparse.h:493-615, 897-917), lambda_zero without the intercept slot (:854-863).
+ * compute_loss is refused. */
+int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t *rowidx, const double *values, const double *y,
+                      int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                      double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
+
 /* replaces oem_xval_dense, ref src/oem_xval_dense.cpp:31-482 (family "gaussian", weights empty): xval.oem's fast
  * cross-validation.  foldid: n values in 1..nfolds.  type_measure: 0 "mse", 1 "mae" (ref :378-411).
  * beta, lambda_out, niter, loss, d: the fit on ALL rows, laid out as in oemgpu_fit_dense (loss only if compute_loss,

@@ -232,8 +232,7 @@ def oem(x, y, family="gaussian", penalty=None, weights=(), lambda_=(), nlambda=1
         warnings.warn("oem() is optimized for n >> p settings and may be very slow when p > n")
     if p < 2:
         raise ValueError("x must have at least two columns")
-    if type(x).__module__.startswith("scipy.sparse"):
-        raise NotImplementedError("sparse x is outside the dense Gaussian hot path (ref src/oem_sparse.cpp)")
+    is_sparse = type(x).__module__.startswith("scipy.sparse")         # R/oem.R:236-242: sparseMatrix -> dgCMatrix
     if len(weights) > 0:
         raise ValueError("weights not implemented yet.")
     ylen = y.shape[0] if hasattr(y, "shape") else len(y)
@@ -256,6 +255,16 @@ def oem(x, y, family="gaussian", penalty=None, weights=(), lambda_=(), nlambda=1
     a = _Args(penalty, lam_list, int(np.ravel(nlambda)[0]), lambda_min_ratio, alpha, gamma, tau, tol, maxit, accelerate,
               compute_loss, penalty_factor, groups, unique_groups, group_weights)
     lib = L.lib()
+    if is_sparse:                                                      # oem_fit_sparse (ref src/oem_sparse.cpp:30-267)
+        import scipy.sparse as sp
+        xc = sp.csc_matrix(x, dtype=np.float64); xc.sort_indices()
+        colptr = np.ascontiguousarray(xc.indptr, dtype=np.int64); rowidx = np.ascontiguousarray(xc.indices, dtype=np.int32)
+        vals = np.ascontiguousarray(xc.data, dtype=np.float64)
+        yh = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+        a.c.accelerate = 0                                             # oemSparse has no acceleration
+        L.check(lib.oemgpu_fit_sparse(n, p, colptr.ctypes.data, _iptr(rowidx), _dptr(vals), _dptr(yh), int(bool(standardize)),
+                                      int(bool(intercept)), C.byref(a.c), *a.outputs(p + 1)))
+        return _decorate(a, penalty, varnames, True, n, p)
     if _is_torch_cuda(x):
         import torch
         xp, n_, p_, ld, keep = _device_matrix(x)

@@ -1044,3 +1044,109 @@ int orc_xval_dense(const double *x, int64_t n, int32_t p, const double *y, const
     free(fxx); free(fxy); free(fcs); free(fn); free(XX); free(XY); free(colsq); free(pf); free(lam); free(bstd); free(bf);
     return rc;
 }
+
+/* ------------------------------------------------------------------ */
+/* oem() on a sparse X: ref src/oem_sparse.cpp:30-267 + src/oem_sparse.h (n > p branch, no observation weights).
+ * X in compressed sparse column form as a dgCMatrix holds it: colptr[p + 1], rowidx[nnz] (increasing inside a column), val[nnz].
+ * What differs from oemBig: the intercept column holds intval = sqrt(mean(diag(XX)) / n) instead of 1 (ref :577-593), the
+ * coefficient of that column is rescaled IN PLACE by get_beta after every lambda (ref :897-900) and so enters the next warm
+ * start rescaled, lambda_zero leaves the intercept slot out (ref :854-863), and the group vector is read against positions
+ * 0..p-1 of the (p + 1)-vector (ref :452-470: position 0 is the intercept). */
+int orc_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t *rowidx, const double *val, const double *y,
+                   int32_t standardize, int32_t intercept, const orc_opts *o,
+                   double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out)
+{
+    if (n <= p) return fail("oracle: only the n > p branch of oemSparse is restated (ref: src/oem_sparse.h:563)");
+    const int off = intercept ? 1 : 0, q = p + off, nl = nl_of(o);
+    const size_t qq = (size_t)q * q;
+    double *XX = (double *)calloc(qq, sizeof(double)), *XY = (double *)calloc((size_t)q, sizeof(double));
+    double *colsq_inv = (double *)malloc(sizeof(double) * (size_t)p), *colsums = (double *)calloc((size_t)p, sizeof(double));
+    double *dense = (double *)calloc((size_t)n, sizeof(double));
+    double *pf = (double *)calloc((size_t)q, sizeof(double));
+    double *lam = (double *)malloc(sizeof(double) * (size_t)o->npen * nl);
+    if (!XX || !XY || !colsq_inv || !colsums || !dense || !pf || !lam) return fail("oracle: out of memory");
+    for (int j = 0; j < p; j++) pf[j + off] = o->penalty_factor[j];       /* ref: src/oem_sparse.cpp:131-138 */
+    /* colsq (ref: src/oem_sparse.h:493-508) */
+    for (int j = 0; j < p; j++) {
+        double s = 0.0;
+        for (int64_t k = colptr[j]; k < colptr[j + 1]; k++) s += val[k] * val[k];
+        s /= ((double)n - 1.0);
+        if (s == 0.0) s = 1.0;
+        colsq_inv[j] = standardize ? 1.0 / sqrt(s) : 1.0;
+    }
+    /* X'X, X'Y, column sums */
+    double sumy = 0.0;
+    for (int64_t i = 0; i < n; i++) sumy += y[i];
+    for (int a = 0; a < p; a++) {
+        for (int64_t k = colptr[a]; k < colptr[a + 1]; k++) dense[rowidx[k]] = val[k];
+        for (int b = a; b < p; b++) {
+            double s = 0.0;
+            for (int64_t k = colptr[b]; k < colptr[b + 1]; k++) s += val[k] * dense[rowidx[k]];
+            s = colsq_inv[a] * s * colsq_inv[b];
+            XX[(size_t)(a + off) * q + (b + off)] = s; XX[(size_t)(b + off) * q + (a + off)] = s;
+        }
+        double sxy = 0.0, sx = 0.0;
+        for (int64_t k = colptr[a]; k < colptr[a + 1]; k++) { sxy += val[k] * y[rowidx[k]]; sx += val[k]; dense[rowidx[k]] = 0.0; }
+        XY[a + off] = sxy * colsq_inv[a];
+        colsums[a] = sx;
+    }
+    double intval = 1.0;
+    if (intercept) {
+        double xxdiag = 0.0;                                                 /* ref :577-593 */
+        for (int j = 0; j < p; j++) xxdiag += XX[(size_t)(j + 1) * q + (j + 1)];
+        xxdiag /= (double)p;
+        intval = sqrt(xxdiag / (double)n);
+        for (int j = 0; j < p; j++) {
+            double c = colsums[j] * intval * colsq_inv[j];
+            XX[(size_t)(j + 1) * q] = c; XX[j + 1] = c;
+        }
+        XX[0] = xxdiag;
+        XY[0] = sumy * intval;                                               /* ref :829-836 */
+    }
+    for (size_t t = 0; t < qq; t++) XX[t] /= (double)n;
+    for (int j = 0; j < q; j++) XY[j] /= (double)n;
+    double d = (o->d_override > 0) ? o->d_override : orc_eig_max(XX, q) * 1.005;
+    *d_out = d;
+    double lmax = 0.0;
+    for (int j = off; j < q; j++) if (fabs(XY[j]) > lmax) lmax = fabs(XY[j]);
+    lambda_grid(o, lmax, lam);
+    for (size_t k = 0; k < (size_t)o->npen * nl; k++) { lambda_out[k] = lam[k]; loss[k] = 1e99; niter[k] = 0; }
+    core_t s; memset(&s, 0, sizeof s);
+    if (core_alloc(&s, q)) return -1;
+    double *A = (double *)malloc(sizeof(double) * qq);
+    for (size_t t = 0; t < qq; t++) A[t] = -XX[t];
+    for (int j = 0; j < q; j++) A[(size_t)j * q + j] += d;
+    s.A = A; s.XY = XY; s.d = d;
+    grp_t g; memset(&g, 0, sizeof g); int have_g = 0, rc = 0;
+    orc_opts oo = *o; oo.penalty_factor = pf; oo.accelerate = 0;
+    for (int pp = 0; pp < o->npen && rc == 0; pp++) {
+        int pen = o->penalty[pp];
+        int nlam = (pen == ORC_OLS) ? 1 : nl;
+        double ak = 1.0;
+        for (int i = 0; i < nl; i++) {
+            double *out = beta + ((size_t)pp * nl + i) * (p + 1);
+            for (int j = 0; j <= p; j++) out[j] = 0.0;
+            if (i >= nlam) continue;
+            if (i == 0) {
+                memset(s.beta, 0, sizeof(double) * (size_t)q);
+                if (!have_g && pen_is_grp(pen)) { if (build_groups(&g, &oo, p)) { rc = -1; break; } have_g = 1; }   /* groups.size() = p */
+            }
+            niter[(size_t)pp * nl + i] = solve_one(&s, pen, lam[(size_t)pp * nl + i], &oo, pf, &g, &ak);
+            if (intercept) s.beta[0] *= intval;                              /* get_beta, in place (ref :897-900) */
+            if (intercept) out[0] = s.beta[0];
+            for (int j = 0; j < p; j++) out[j + 1] = s.beta[j + off] * colsq_inv[j];
+            if (o->compute_loss) {                                           /* get_loss after get_beta (ref :919-944) */
+                memcpy(dense, y, sizeof(double) * (size_t)n);
+                for (int j = 0; j < p; j++)
+                    for (int64_t k = colptr[j]; k < colptr[j + 1]; k++) dense[rowidx[k]] -= val[k] * out[j + 1];
+                double l = 0.0;
+                for (int64_t r = 0; r < n; r++) { double t = dense[r] - (intercept ? s.beta[0] : 0.0); l += t * t; }
+                loss[(size_t)pp * nl + i] = l;
+                memset(dense, 0, sizeof(double) * (size_t)n);
+            }
+        }
+    }
+    if (have_g) free_groups(&g);
+    free(A); free(s.u); free(XX); free(XY); free(colsq_inv); free(colsums); free(dense); free(pf); free(lam);
+    return rc;
+}

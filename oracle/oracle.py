@@ -176,6 +176,19 @@ def xval_dense(x, y, foldid, penalty="elastic.net", standardize=True, intercept=
     return out
 
 
+def fit_sparse(x, y, penalty="elastic.net", standardize=True, intercept=True, native=False, **kw):
+    """ref src/oem_sparse.cpp:30-267.  x: a scipy.sparse matrix (converted to CSC with sorted indices)."""
+    import scipy.sparse as sp
+    xc = sp.csc_matrix(x, dtype=np.float64); xc.sort_indices()
+    n, p = xc.shape
+    colptr = np.ascontiguousarray(xc.indptr, dtype=np.int64); rowidx = np.ascontiguousarray(xc.indices, dtype=np.int32)
+    val = np.ascontiguousarray(xc.data, dtype=np.float64); y = _d(y)
+    o = _Opts(p, penalty, **kw)
+    L = lib(native)
+    return _call(L.orc_fit_sparse, o, p + 1, C.c_int64(n), C.c_int32(p), colptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                 _ptr(rowidx, _ip), _ptr(val), _ptr(y), C.c_int32(int(standardize)), C.c_int32(int(intercept)), native=native)
+
+
 def standardize(x, y, standardize=True, intercept=True):
     x = np.array(x, dtype=np.float64, order="F", copy=True); y = np.array(y, dtype=np.float64, copy=True)
     n, p = x.shape

@@ -382,3 +382,34 @@ def test_wide_branch(oa, n, p, std, icpt):
         assert np.abs(f["beta"][k] - r["beta"][k]).max() < 1e-7 * scale, (k, np.abs(f["beta"][k] - r["beta"][k]).max())
         dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]))
         assert np.mean(dn > 1) <= 0.2, dn
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("std,icpt", [(True, True), (False, True), (True, False), (False, False)])
+def test_sparse_x(oa, std, icpt):
+    """oem() on a sparse x (ref src/oem_sparse.{h,cpp}, n > p): oemSparse's own standardisation and intercept handling (the
+    intercept as a Gram column of value sqrt(mean diag / n), rescaled in place after every lambda), against the oracle's
+    restatement; without intercept and standardisation it is the dense fit (the reference's doc example: 1.6e-15)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(41)
+    n, p = 6000, 57
+    x = sp.random(n, p, density=0.03, random_state=5, format="csc", data_rvs=lambda k: rng.normal(size=k) * 2.0)
+    b = np.zeros(p); b[:6] = [1.0, -1.0, 0.5, 2.0, -0.7, 0.3]
+    y = x @ b + rng.normal(size=n) * 0.5 + 0.8
+    groups = np.arange(p) // 4 + 1
+    pens = ["lasso", "mcp", "grp.lasso", "ols"]
+    kw = dict(penalty=pens, groups=groups, nlambda=15, tol=1e-9, maxit=1000, standardize=std, intercept=icpt)
+    f = oa.oem(x, y, **kw)
+    r = orc.fit_sparse(x, y, unique_groups=np.unique(groups), lambda_min_ratio=1e-4, **kw)
+    assert abs(f["d"] - r["d"]) < 1e-11 * r["d"]
+    for k in range(len(pens)):
+        assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-11)
+        assert np.abs(f["beta"][k] - r["beta"][k]).max() < 1e-8 * max(1.0, float(np.abs(r["beta"][k]).max())), pens[k]
+        dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]))
+        assert dn.max() <= 1, (pens[k], dn)
+    if not std and not icpt:
+        g = oa.oem(np.asfortranarray(x.toarray()), y, **kw)
+        for k in range(len(pens)):
+            assert np.abs(f["beta"][k] - g["beta"][k]).max() < 1e-12
+    with pytest.raises(oa.OemgpuError, match="compute.loss"):
+        oa.oem(x, y, penalty="lasso", compute_loss=True)

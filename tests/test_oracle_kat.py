@@ -129,3 +129,25 @@ def test_xval_against_fold_by_fold_numpy():
     for m_ in range(2):
         assert np.allclose(f["cvm"][m_], err[m_].mean(0), rtol=1e-9)
         assert np.allclose(f["cvsd"][m_], err[m_].std(0, ddof=1) / np.sqrt(n), rtol=1e-8)
+
+
+def test_prop_sparse_equals_dense_without_intercept_and_scaling():
+    """docs/reference/oem.html: max(abs(fit$beta[[1]] - fits$beta[[1]])) = 1.58e-15 for a dense and a sparse copy of x with
+    standardize = FALSE (intercept = FALSE there too: R/oem.R example); and with an intercept the converged sparse fit is the
+    optimum of big.oem's formulation (same column scaling, unpenalised intercept), reached along a different iteration."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(2)
+    n, p = 4000, 30
+    x = sp.random(n, p, density=0.05, random_state=3, format="csc", data_rvs=lambda k: rng.normal(size=k))
+    b = np.zeros(p); b[:5] = [1, -1, 0.5, 2, -0.7]
+    y = x @ b + rng.normal(size=n) * 0.5 + 0.3
+    xd = np.asfortranarray(x.toarray())
+    kw = dict(penalty=["lasso", "mcp"], nlambda=20, tol=1e-9)
+    a = orc.fit_sparse(x, y, standardize=False, intercept=False, **kw)
+    d = orc.fit_dense(xd, y, standardize=False, intercept=False, **kw)
+    for k in range(2):
+        assert np.abs(a["beta"][k] - d["beta"][k]).max() < 1e-13
+    lam = [a["lambda"][0] * 0.5]
+    g = orc.fit_big(xd, y, penalty=["lasso"], lambda_=lam, tol=1e-12, maxit=20000)
+    h = orc.fit_sparse(x, y, penalty=["lasso"], lambda_=lam, tol=1e-12, maxit=20000)
+    assert np.abs(g["beta"][0] - h["beta"][0]).max() < 1e-9
