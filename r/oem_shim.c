@@ -189,3 +189,32 @@ SEXP oem_xval_dense(SEXP x_, SEXP y_, SEXP family_, SEXP penalty_, SEXP weights_
     UNPROTECT(5);
     return res;
 }
+
+/* oem_fit_sparse (ref src/oem_sparse.cpp:30-50, called from R/oem.R:534-553): x_ is a dgCMatrix; its slots are the compressed
+ * sparse column arrays the library takes.  (The column pointers of a dgCMatrix are 32-bit: widened here.) */
+SEXP oem_fit_sparse(SEXP x_, SEXP y_, SEXP family_, SEXP penalty_, SEXP weights_, SEXP groups_, SEXP unique_groups_,
+                    SEXP group_weights_, SEXP lambda_, SEXP nlambda_, SEXP lmin_ratio_, SEXP alpha_, SEXP gamma_,
+                    SEXP tau_, SEXP penalty_factor_, SEXP standardize_, SEXP intercept_, SEXP compute_loss_, SEXP opts_)
+{
+    if (strcmp(CHAR(STRING_ELT(family_, 0)), "gaussian") != 0)
+        Rf_error("binomial not available for oem_fit_sparse, use oem_fit_logistic_sparse");    /* ref src/oem_sparse.cpp:150 */
+    if (XLENGTH(weights_) > 0) Rf_error("weights not implemented yet.");
+    SEXP dim = R_do_slot(x_, Rf_install("Dim")), ip = R_do_slot(x_, Rf_install("p")), ii = R_do_slot(x_, Rf_install("i")),
+         xv = R_do_slot(x_, Rf_install("x"));
+    const int64_t n = INTEGER(dim)[0];
+    const int p = INTEGER(dim)[1];
+    int64_t *colptr = (int64_t *)R_alloc((size_t)p + 1, sizeof(int64_t));
+    for (int j = 0; j <= p; j++) colptr[j] = INTEGER(ip)[j];
+    oemgpu_opts o;
+    fill_opts(&o, penalty_, groups_, unique_groups_, group_weights_, lambda_, nlambda_, lmin_ratio_, alpha_, gamma_, tau_,
+              penalty_factor_, compute_loss_, opts_, 0);
+    const int nl = o.nlambda_user > 0 ? o.nlambda_user : o.nlambda;
+    const size_t nk = (size_t)o.npen * nl;
+    double *beta = (double *)R_alloc(nk * (p + 1), sizeof(double)), *lam = (double *)R_alloc(nk, sizeof(double));
+    double *loss = (double *)R_alloc(nk, sizeof(double)), d = 0.0;
+    int32_t *niter = (int32_t *)R_alloc(nk, sizeof(int32_t));
+    const int rc = oemgpu_fit_sparse(n, p, colptr, INTEGER(ii), REAL(xv), REAL(y_), Rf_asLogical(standardize_),
+                                     Rf_asLogical(intercept_), &o, beta, lam, niter, loss, &d);
+    if (rc != 0) Rf_error("%s", oemgpu_last_error());
+    return pack(&o, p + 1, nl, beta, lam, niter, loss, d);
+}
