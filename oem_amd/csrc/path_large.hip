@@ -592,8 +592,8 @@ __global__ __launch_bounds__(256) void oem_fused_kernel(PathArgs A, FState *__re
 // per iteration instead of two; at p = 512 the iteration is launch-latency bound, so that halves it.
 // ------------------------------------------------------------------------------------------------
 struct GState {
-    int pp, i, it, done, fresh, pending_loss, finish_after_loss, pad;
-    double ak;
+    int pp, i, it, done, fresh, pending_loss, finish_after_loss, pen;     // pen = penalty[pp], lam = lambda_out[pp * nl + i]:
+    double ak, lam;                                                        // written by whoever advances (pp, i), so that a launch needs ONE dependent load
 };
 
 // FULL: q == 64 VPL and 16-byte aligned rows (no bounds logic); otherwise any q <= 64 VPL: columns past q read a clamped
@@ -606,14 +606,32 @@ __global__ __launch_bounds__(256) void oem_fused_rep_kernel(PathArgs A, GState *
     __shared__ double sh[16];
     const int q = A.p, nl = A.nl, tid = threadIdx.x, nt = 256, lane = tid & 63;
     const int wave = blockIdx.x * 4 + (tid >> 6), nwave = gridDim.x * 4;
+    // One dependent global load per launch: the state.  Everything else a launch reads is requested BEFORE the state is looked at
+    // (this thread's entries of u, beta_t, XY, the penalty factors, and the first matrix row of its wave), and the penalty code and
+    // lambda of (pp, i) travel inside the state: a launch is nothing but latency (6.4 us at q = 512 before this, 5.6 us after).
     const GState st = S[par];
+    const double *__restrict__ uin = Ubuf + (size_t)par * (q + 8), *__restrict__ bprev = Bbuf + (size_t)par * (q + 8);
+    constexpr int NPRE = 4;                                    // entries per thread covered by the prefetch: q <= 1024
+    double pre_u[NPRE], pre_xy[NPRE], pre_b[NPRE], pre_pf[NPRE];
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+        const int j = tid + k * nt;
+        const bool ok = j < q;
+        pre_u[k] = ok ? uin[j] : 0.0; pre_xy[k] = ok ? A.xy[j] : 0.0; pre_b[k] = ok ? bprev[j] : 0.0; pre_pf[k] = ok ? A.pf[j] : 0.0;
+    }
+    constexpr bool PREROW = FULL && VPL <= 16;                 // the first row of this wave (rows wave, wave + nwave, ...)
+    v2d prow[PREROW ? VPL / 2 : 1];
+    if (PREROW && wave < q) {
+        const double *row = A.xx + (size_t)wave * q;
+#pragma unroll
+        for (int j = 0; j < VPL / 2; ++j) prow[j] = *reinterpret_cast<const v2d *>(row + 2 * lane + 128 * j);
+    }
     if (st.done) {
         if (blockIdx.x == 0 && tid == 0) { S[par ^ 1].done = 1; *fdone = 1; }
         return;
     }
     const bool b0 = blockIdx.x == 0;
     double *Ush = dyn, *Bsh = dyn + q, *F = dyn + 2 * q;
-    const double *__restrict__ uin = Ubuf + (size_t)par * (q + 8), *__restrict__ bprev = Bbuf + (size_t)par * (q + 8);
     double *__restrict__ uout = Ubuf + (size_t)(par ^ 1) * (q + 8), *__restrict__ bkeep = Bbuf + (size_t)(par ^ 1) * (q + 8);
     const double scaley = A.yscale ? A.stats[1] : 1.0;
     const double yy = A.stats[2], nobs = A.stats[3];
@@ -630,18 +648,21 @@ __global__ __launch_bounds__(256) void oem_fused_rep_kernel(PathArgs A, GState *
         return;
     }
     const int pp = st.pp, i = st.i;
-    const int pen = A.penalty[pp];
+    const int pen = st.pen;
     const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
-    const PenK K = pen_consts(pen, A.lambda_out[(size_t)pp * nl + i] / scaley, d, A.alpha, A.gamma, A.tau);
+    const PenK K = pen_consts(pen, st.lam / scaley, d, A.alpha, A.gamma, A.tau);
     const double rD = 1.0 / K.D, gammad = K.gamma * K.D, dmg = K.D - 1.0 / K.gamma, rdmg = 1.0 / dmg;
     const double gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0, rdsc = 1.0 / dsc;
     const bool grp = K.kind >= K_GRP;
     double ak = fresh ? 1.0 : st.ak;
     // ---- u (a fresh penalty starts from beta = 0: u = XY) and, for the group operators, the group factors
-    for (int j = tid; j < q; j += nt) {
-        const double u = fresh ? A.xy[j] : uin[j];
-        Ush[j] = (grp && K.kind == K_SGL) ? soft1(u, A.pf[j] * K.L1, 1.0) : u;
+    auto put_u = [&](int j, double u, double pfj) { Ush[j] = (grp && K.kind == K_SGL) ? soft1(u, pfj * K.L1, 1.0) : u; };
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {                               // the prefetched entries: constant register indices
+        const int j = tid + k * nt;
+        if (j < q) put_u(j, fresh ? pre_xy[k] : pre_u[k], pre_pf[k]);
     }
+    for (int j = tid + NPRE * nt; j < q; j += nt) put_u(j, fresh ? A.xy[j] : uin[j], A.pf[j]);
     __syncthreads();
     if (grp) {
         for (int gi = tid; gi < A.ngroups; gi += nt) {
@@ -663,8 +684,8 @@ __global__ __launch_bounds__(256) void oem_fused_rep_kernel(PathArgs A, GState *
     bool bad = false;
     double adp = 0.0;
     const double akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak)), ratio = (ak - 1.0) / akn;
-    for (int j = tid; j < q; j += nt) {
-        const double bo = fresh ? 0.0 : bprev[j];
+    auto update = [&](int j, double bprev_j, double pf_j) {
+        const double bo = fresh ? 0.0 : bprev_j;
         const double u = Ush[j];
         double bn;
         if (grp) {
@@ -672,7 +693,7 @@ __global__ __launch_bounds__(256) void oem_fused_rep_kernel(PathArgs A, GState *
             const double f = gi >= 0 ? F[gi] : 0.0;
             bn = (f != 0.0) ? u * f / K.D : 0.0;
         } else {
-            const double tp = A.pf[j] * K.L;
+            const double tp = pf_j * K.L;
             if (K.kind == K_SOFT) bn = cdiv(shrink(u, tp), K.D, rD);
             else if (K.kind == K_MCP) {
                 const bool big = fabs(u) > gammad * tp;
@@ -694,7 +715,13 @@ __global__ __launch_bounds__(256) void oem_fused_rep_kernel(PathArgs A, GState *
         bad |= (cn != qn);
         bad |= (cn && qn && fabs(bn - bo) > A.tol * qo);
         Bsh[j] = bn;
+    };
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+        const int j = tid + k * nt;
+        if (j < q) update(j, pre_b[k], pre_pf[k]);
     }
+    for (int j = tid + NPRE * nt; j < q; j += nt) update(j, bprev[j], A.pf[j]);
     if (A.accelerate) {
         adp = block_sum(adp, sh);
         ak = (adp > 0.0) ? 1.0 : akn;
@@ -724,7 +751,10 @@ __global__ __launch_bounds__(256) void oem_fused_rep_kernel(PathArgs A, GState *
         else { nx.done = 1; done_now = true; }
     }
     if (b0) {
-        if (tid == 0) S[par ^ 1] = nx;
+        if (tid == 0) {
+            if (nx.pp != pp || nx.i != i) { nx.pen = A.penalty[nx.pp]; nx.lam = A.lambda_out[(size_t)nx.pp * nl + nx.i]; }   // off the other workgroups' path
+            S[par ^ 1] = nx;
+        }
         for (int j = tid; j < q; j += nt) bkeep[j] = Bsh[j];       // beta_t for the next launch's stop rule / loss
     }
     if (done_now) return;
@@ -747,7 +777,7 @@ __global__ __launch_bounds__(256) void oem_fused_rep_kernel(PathArgs A, GState *
 #pragma unroll
         for (int j = 0; j < VPL / 2; ++j) {
             if (FULL) {
-                const v2d t = *reinterpret_cast<const v2d *>(row + 2 * lane + 128 * j);
+                const v2d t = (PREROW && r == wave) ? prow[PREROW ? j : 0] : *reinterpret_cast<const v2d *>(row + 2 * lane + 128 * j);
                 a0 = fma(t.x, v[j].x, a0);
                 a1 = fma(t.y, v[j].y, a1);
             } else {
@@ -760,9 +790,10 @@ __global__ __launch_bounds__(256) void oem_fused_rep_kernel(PathArgs A, GState *
     }
 }
 
-__global__ void fused_rep_init_kernel(GState *S, int npen)
+__global__ void fused_rep_init_kernel(GState *S, int npen, const int *penalty, const double *lambda_out)
 {
-    GState z; z.pp = 0; z.i = 0; z.it = 0; z.done = (npen == 0) ? 1 : 0; z.fresh = 1; z.pending_loss = -1; z.finish_after_loss = 0; z.pad = 0; z.ak = 1.0;
+    GState z; z.pp = 0; z.i = 0; z.it = 0; z.done = (npen == 0) ? 1 : 0; z.fresh = 1; z.pending_loss = -1; z.finish_after_loss = 0; z.ak = 1.0;
+    z.pen = npen > 0 ? penalty[0] : 0; z.lam = npen > 0 ? lambda_out[0] : 0.0;
     S[0] = z; S[1] = z; S[1].done = 0;
 }
 
@@ -921,7 +952,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         else if (q <= 2048) kern = full ? oem_fused_rep_kernel<32, true> : oem_fused_rep_kernel<32, false>;
         else kern = full ? oem_fused_rep_kernel<64, true> : oem_fused_rep_kernel<64, false>;
         if (shb > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
-        hipLaunchKernelGGL(fused_rep_init_kernel, dim3(1), dim3(1), 0, s, S, a.npen);
+        hipLaunchKernelGGL(fused_rep_init_kernel, dim3(1), dim3(1), 0, s, S, a.npen, a.penalty, a.lambda_out);
         auto enq = [&](int count) {
             for (int k = 0; k < count; ++k) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shb, s, a, S, Uv, Bv, fdone, k & 1, d);
         };
