@@ -413,3 +413,22 @@ def test_sparse_x(oa, std, icpt):
             assert np.abs(f["beta"][k] - g["beta"][k]).max() < 1e-12
     with pytest.raises(oa.OemgpuError, match="compute.loss"):
         oa.oem(x, y, penalty="lasso", compute_loss=True)
+
+
+@pytest.mark.gpu
+def test_sparse_x_large_p_engine(oa):
+    """p + 1 = 301 > 288: the sparse fit on the launch-per-iteration engine (the in-place rescale of the intercept slot rides on
+    its scale.factor path)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(43)
+    n, p = 5000, 300
+    x = sp.random(n, p, density=0.04, random_state=9, format="csc", data_rvs=lambda k: rng.normal(size=k))
+    b = np.zeros(p); b[:8] = rng.uniform(0.5, 1.5, 8)
+    y = x @ b + rng.normal(size=n) * 0.3 + 1.2
+    kw = dict(penalty=["lasso", "scad"], nlambda=10, tol=1e-9, maxit=600)
+    f = oa.oem(x, y, **kw)
+    r = orc.fit_sparse(x, y, lambda_min_ratio=1e-4, **kw)
+    assert abs(f["d"] - r["d"]) < 1e-11 * r["d"]
+    for k in range(2):
+        assert np.abs(f["beta"][k] - r["beta"][k]).max() < 1e-8 * max(1.0, float(np.abs(r["beta"][k]).max()))
+        assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k])).max() <= 1
