@@ -732,12 +732,22 @@ static __global__ void scale_intercept_kernel(double *__restrict__ xx, double *_
     else { xx[(size_t)j * q] *= intval; xx[j] *= intval; }
 }
 
+// rows [r0, r1) of a compressed-column matrix into a zeroed dense column-major tile (row indices increase inside a column:
+// one lower_bound per workgroup finds where the tile's part of the column starts)
 static __global__ void csc_densify_kernel(const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx, const double *__restrict__ val,
-                                   int64_t ld, double *__restrict__ xd)
+                                          int64_t r0, int64_t r1, int64_t ld, double *__restrict__ xd)
 {
+    __shared__ int64_t first;
     const int j = blockIdx.y;
-    const int64_t k = colptr[j] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < colptr[j + 1]) xd[(size_t)j * ld + rowidx[k]] = val[k];
+    const int64_t lo0 = colptr[j], hi0 = colptr[j + 1];
+    if (threadIdx.x == 0) {
+        int64_t lo = lo0, hi = hi0;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rowidx[mid] < r0) lo = mid + 1; else hi = mid; }
+        first = lo;
+    }
+    __syncthreads();
+    const int64_t k = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < hi0) { const int64_t r = rowidx[k]; if (r < r1) xd[(size_t)j * ld + (r - r0)] = val[k]; }
 }
 
 // nbatch moment buffers (instance b at moments + b * mstride, all OUTSIDE the context workspace), one finalize each, then ONE
@@ -950,8 +960,12 @@ int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t
     if (o->compute_loss) { set_error("compute.loss with a sparse x is not built (the loss is taken after the in-place rescale of the intercept, ref src/oem_sparse.h:897-944)"); return OEMGPU_ERR_UNSUPPORTED; }
     const int64_t nnz = colptr[p];
     if (nnz < 0 || (nnz > 0 && (!rowidx || !values))) { set_error("fit_sparse: bad compressed-column arrays"); return OEMGPU_ERR_ARG; }
-    const int64_t ld = (n + 1) / 2 * 2;
-    if ((double)ld * p * 8.0 > 128e9) { set_error("fit_sparse: the dense staging copy of x would take %.0f GB", (double)ld * p * 8e-9); return OEMGPU_ERR_UNSUPPORTED; }
+    // rows per staging tile: the dense tile is capped at 2 GiB, whatever n is
+    int64_t rcrows = (int64_t)(2147483648.0 / (8.0 * p)) / 64 * 64;
+    if (const char *e = getenv("OEM_SPARSE_TILE_ROWS")) { const long long t = atoll(e) / 64 * 64; if (t >= 64) rcrows = t; }   // test knob: several tiles on small data
+    if (rcrows < 64) rcrows = 64;
+    if (rcrows > n) rcrows = n;
+    const int64_t ld = (rcrows + 1) / 2 * 2;
     // intval = sqrt(mean(diag(XX)) / n) with XX the (standardised) Gram before the division by n (ref src/oem_sparse.h:493-508, 577-578)
     double intval = 1.0;
     int64_t maxcol = 0;
@@ -985,20 +999,32 @@ int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t
     if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(rd, rowidx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(vd, values, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { set_error("fit_sparse: device staging failed: %s", hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; }
-    // The Gram of a sparse X through the dense FP64-MFMA pass: X is scattered once into a zeroed column-major buffer in HBM (one
-    // 8-byte store per non-zero) and read back by the moment kernels.  At the densities of the reference's examples (1 %) this is
-    // a few hundred MB and a fraction of a millisecond; a compressed-column Gram kernel is the next step for n p beyond HBM.
-    if (!rc && nnz > 0) {
-        hipLaunchKernelGGL(csc_densify_kernel, dim3((unsigned)((maxcol + 255) / 256), p), dim3(256), 0, c->stream, cd, rd, vd, ld, xd);
-        if (hipGetLastError() != hipSuccess) { set_error("fit_sparse: densify launch failed"); rc = OEMGPU_ERR_HIP; }
-    }
+    // The Gram of a sparse X through the dense FP64-MFMA pass: row tiles of at most 2 GiB are zeroed, filled with the tile's
+    // non-zeros (one 8-byte store each) and read back by the moment kernels; the tiles' moments are added in row order.  At the
+    // densities of the reference's examples (1 %) the whole x is one tile of a few hundred MB and a fraction of a millisecond.  The
+    // matrix pipe does not care about zeros: the cost is that of a dense n x p pass whatever the density, with no dense copy of x
+    // beyond one tile.  (A compressed-column Gram kernel would win below ~0.1 % density; it is not built.)
     if (!rc) {
-        const GramPlan pl = gram_plan(n, p, c->num_cu);
+        const GramPlan plmax = gram_plan(rcrows, p, c->num_cu);
         Bump B;
-        const size_t a_mom = B.take((size_t)oemgpu_moments_len(p) * 8), a_t = B.take(pl.tpart_doubles * 8), a_v = B.take(pl.vpart_doubles * 8);
+        const size_t mlen = (size_t)oemgpu_moments_len(p);
+        const size_t a_mom = B.take(mlen * 8), a_tmp = B.take(mlen * 8), a_t = B.take(plmax.tpart_doubles * 8 * 2), a_v = B.take(plmax.vpart_doubles * 8 * 2);
         const size_t a_xx = B.take((size_t)q * q * 8), a_xy = B.take((size_t)q * 8), a_st = B.take((size_t)stats_len(p) * 8);
         rc = ctx_reserve(c, B.off + paths_ws_bytes(p, q, o) + 4096) ? OEMGPU_ERR_HIP : 0;
-        if (!rc) rc = shard_moments(c, pl, xd, n, ld, yd, nullptr, (double *)(c->ws + a_t), (double *)(c->ws + a_v), (double *)(c->ws + a_mom));
+        double *mom = (double *)(c->ws + a_mom), *mtmp = (double *)(c->ws + a_tmp);
+        if (!rc && hipMemsetAsync(mom, 0, mlen * 8, c->stream) != hipSuccess) rc = OEMGPU_ERR_HIP;
+        for (int64_t r0 = 0; r0 < n && !rc; r0 += rcrows) {
+            const int64_t r1 = r0 + rcrows < n ? r0 + rcrows : n, nr = r1 - r0;
+            if (hipMemsetAsync(xd, 0, sizeof(double) * (size_t)ld * p, c->stream) != hipSuccess) { set_error("fit_sparse: memset failed"); rc = OEMGPU_ERR_HIP; break; }
+            if (nnz > 0) {
+                hipLaunchKernelGGL(csc_densify_kernel, dim3((unsigned)((maxcol + 255) / 256), p), dim3(256), 0, c->stream, cd, rd, vd, r0, r1, ld, xd);
+                if (hipGetLastError() != hipSuccess) { set_error("fit_sparse: densify launch failed"); rc = OEMGPU_ERR_HIP; break; }
+            }
+            const GramPlan pl = gram_plan(nr, p, c->num_cu);
+            if (pl.tpart_doubles > 2 * plmax.tpart_doubles || pl.vpart_doubles > 2 * plmax.vpart_doubles) { set_error("internal: tile plan larger than its scratch"); rc = OEMGPU_ERR_INTERNAL; break; }
+            rc = shard_moments(c, pl, xd, nr, ld, yd + r0, nullptr, (double *)(c->ws + a_t), (double *)(c->ws + a_v), mtmp);
+            if (!rc) hipLaunchKernelGGL(accumulate_kernel, dim3(64), dim3(256), 0, c->stream, mom, mtmp, mlen);
+        }
         double *xx = (double *)(c->ws + a_xx), *xy = (double *)(c->ws + a_xy), *st = (double *)(c->ws + a_st);
         if (!rc) rc = launch_finalize(c->stream, (double *)(c->ws + a_mom), nullptr, p, OEMGPU_SEM_BIG, standardize, intercept, xx, xy, st);
         std::vector<double> sf;

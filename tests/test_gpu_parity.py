@@ -432,3 +432,21 @@ def test_sparse_x_large_p_engine(oa):
     for k in range(2):
         assert np.abs(f["beta"][k] - r["beta"][k]).max() < 1e-8 * max(1.0, float(np.abs(r["beta"][k]).max()))
         assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k])).max() <= 1
+
+
+@pytest.mark.gpu
+def test_sparse_x_in_several_row_tiles(oa, monkeypatch):
+    """the dense staging tile of the sparse Gram is capped (2 GiB); OEM_SPARSE_TILE_ROWS forces several tiles, with a ragged last one"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(44)
+    n, p = 7001, 33
+    x = sp.random(n, p, density=0.05, random_state=11, format="csc", data_rvs=lambda k: rng.normal(size=k))
+    y = x[:, :4] @ np.array([1.0, -2.0, 0.5, 1.5]) + rng.normal(size=n) * 0.3 + 0.7
+    kw = dict(penalty=["lasso", "mcp"], nlambda=9, tol=1e-10)
+    one = oa.oem(x, y, **kw)
+    monkeypatch.setenv("OEM_SPARSE_TILE_ROWS", "1024")
+    many = oa.oem(x, y, **kw)
+    r = orc.fit_sparse(x, y, lambda_min_ratio=1e-4, **kw)
+    for k in range(2):
+        assert np.abs(one["beta"][k] - many["beta"][k]).max() < 1e-12
+        assert np.abs(many["beta"][k] - r["beta"][k]).max() < 1e-9
