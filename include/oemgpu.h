@@ -103,7 +103,7 @@ int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_
  * column).  Outputs as oemgpu_fit_dense.  The semantics are oemSparse's, not oemDense's: no centring, columns scaled by
  * sqrt(sum x^2 / (n - 1)), the intercept as a Gram column of value sqrt(mean diag / n) whose coefficient is rescaled in
  * place after every lambda (ref src/oem_sparse.h:493-615, 897-917), lambda_zero without the intercept slot (:854-863).
- * compute_loss is refused.  The Gram is built by the dense FP64-MFMA pass over zero-filled row tiles of x (<= 2 GiB each). */
+ * compute_loss (ref :919-944) for p + intercept <= 288.  The Gram is built by the dense FP64-MFMA pass over zero-filled row tiles of x (<= 2 GiB each). */
 int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t *rowidx, const double *values, const double *y,
                       int32_t standardize, int32_t intercept, const oemgpu_opts *o,
                       double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);

@@ -239,7 +239,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     memset(&a, 0, sizeof a);
     a.p = q; a.npen = npen; a.nl = nl; a.user_lambda = user; a.maxit = o->maxit;
     a.accelerate = (sem == OEMGPU_SEM_DENSE) ? (o->accelerate != 0) : 0;           // only oemDense accelerates (quirk Q12)
-    a.compute_loss = (sem == OEMGPU_SEM_DENSE || sem == OEMGPU_SEM_XVAL) ? (o->compute_loss != 0) : 0;
+    a.compute_loss = (sem == OEMGPU_SEM_DENSE || sem == OEMGPU_SEM_XVAL || sem == SEM_SPARSE) ? (o->compute_loss != 0) : 0;
     a.ngroups = og.ngroups; a.lanczos_steps = lan; a.yscale = (sem == OEMGPU_SEM_DENSE);
     a.lmax_from = (sem == OEMGPU_SEM_XVAL || sem == SEM_SPARSE) ? off : 0;              // ref src/oem_xval_dense.h:1025-1032
     a.alpha = o->alpha; a.gamma = o->gamma; a.tau = o->tau; a.tol = o->tol; a.lambda_min_ratio = o->lambda_min_ratio;
@@ -957,7 +957,7 @@ int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t
     int rc = check_opts(o, p, p);             // the group vector has p entries with or without an intercept (ref src/oem_sparse.h:452-470)
     if (rc) return rc;
     if (n <= p) { set_error("p >= n with a sparse x (the XXt branch, ref src/oem_sparse.h:607-612) is not part of this path"); return OEMGPU_ERR_UNSUPPORTED; }
-    if (o->compute_loss) { set_error("compute.loss with a sparse x is not built (the loss is taken after the in-place rescale of the intercept, ref src/oem_sparse.h:897-944)"); return OEMGPU_ERR_UNSUPPORTED; }
+    if (o->compute_loss && q > SMALL_P_MAX) { set_error("compute.loss with a sparse x is built for p + intercept <= %d only", SMALL_P_MAX); return OEMGPU_ERR_UNSUPPORTED; }
     const int64_t nnz = colptr[p];
     if (nnz < 0 || (nnz > 0 && (!rowidx || !values))) { set_error("fit_sparse: bad compressed-column arrays"); return OEMGPU_ERR_ARG; }
     // rows per staging tile: the dense tile is capped at 2 GiB, whatever n is

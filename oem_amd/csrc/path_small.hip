@@ -870,6 +870,16 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
                     case K_SCAD: iterate_sliced<R, NW, CW, NB, K_SCAD>(A, K, d, a, xyE, pfE, valid, eoff, betaE, boldE, abE, ak, it, conv, S, w, lane, buf OEM_DIAG_PASS); break;
                     default: iterate_sliced<R, NW, CW, NB, K_OLS>(A, K, d, a, xyE, pfE, valid, eoff, betaE, boldE, abE, ak, it, conv, S, w, lane, buf OEM_DIAG_PASS); break;
                     }
+                    // (the loss is taken in the coordinates of the iteration, before any in-place rescale)
+                    if (A.compute_loss) {
+                        // sum (Y - X beta)^2 through the Gram identity (ref src/oem_dense.h:759-770), see below
+                        double t = 0.0;
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) t += betaE[j] * ((d * betaE[j] - abE[j]) - 2.0 * xyE[j]);
+                        t = wave_sum(lane < 16 ? t : 0.0);
+                        t = cross_wave_sum<NW>(t, S, w, lane);
+                        if (tid == 0 && writer) A.loss[orow] = yy + nobs * t;
+                    } else if (tid == 0 && writer) A.loss[orow] = 1e99;
                     // oemXTX::get_beta rescales the member in place (ref src/oem_xtx.h:576-581, quirk Q5)
                     if (A.sinv) {
 #pragma unroll
@@ -885,15 +895,6 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
                         double none = 0.0;
                         gemv_sliced<R, NW, CW, NB, false>(a, betaE, abE, eoff, false, none, S, w, lane, buf OEM_DIAG_PASS);
                     }
-                    if (A.compute_loss) {
-                        // sum (Y - X beta)^2 through the Gram identity (ref src/oem_dense.h:759-770), see below
-                        double t = 0.0;
-#pragma unroll
-                        for (int j = 0; j < NB; ++j) t += betaE[j] * ((d * betaE[j] - abE[j]) - 2.0 * xyE[j]);
-                        t = wave_sum(lane < 16 ? t : 0.0);
-                        t = cross_wave_sum<NW>(t, S, w, lane);
-                        if (tid == 0 && writer) A.loss[orow] = yy + nobs * t;
-                    } else if (tid == 0 && writer) A.loss[orow] = 1e99;
                     continue;
                 }
             }
@@ -909,6 +910,17 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
                 default: iterate<R, NW, CW, G, K_GRP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
                 }
             }
+            // the loss belongs to the coordinates the iteration ran in: before any in-place rescale (oemSparse takes it after
+            // get_beta, where the rescaled intercept slot gives the same fitted values, ref src/oem_sparse.h:897-944)
+            if (A.compute_loss) {
+                // sum (Y - X beta)^2 on the standardised data (ref src/oem_dense.h:759-770) through the Gram identity
+                // yy - 2 n beta'XY + n beta' XX beta, with XX beta = d beta - A beta
+                double t = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) t += beta[r] * ((d * beta[r] - ab[r]) - 2.0 * xy[r]);
+                t = wave_sum(t);
+                if (tid == 0 && writer) A.loss[orow] = yy + nobs * t;
+            } else if (tid == 0 && writer) A.loss[orow] = 1e99;
             // oemXTX::get_beta rescales the member in place (ref src/oem_xtx.h:576-581, quirk Q5)
             if (A.sinv) {
 #pragma unroll
@@ -925,15 +937,6 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
             // ab = A beta (warm start of the next lambda, and the loss) is already there from the last round, unless
             // beta has just been rescaled in place
             if (A.sinv) gemv_round<R, NW, CW, G>(a, beta, ab, P, Uw, w, lane, buf, X OEM_DIAG_PASS);
-            if (A.compute_loss) {
-                // sum (Y - X beta)^2 on the standardised data (ref src/oem_dense.h:759-770) through the Gram identity
-                // yy - 2 n beta'XY + n beta' XX beta, with XX beta = d beta - A beta
-                double t = 0.0;
-#pragma unroll
-                for (int r = 0; r < R; ++r) t += beta[r] * ((d * beta[r] - ab[r]) - 2.0 * xy[r]);
-                t = wave_sum(t);
-                if (tid == 0 && writer) A.loss[orow] = yy + nobs * t;
-            } else if (tid == 0 && writer) A.loss[orow] = 1e99;
         }
     }
 #ifdef OEM_PATH_DIAG
@@ -1399,18 +1402,19 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
                 if (__builtin_expect(ridge, 0)) c = thr_consts<KIND>(K, d);
                 int it = 0, conv = 0;
                 iterate_rows_t<NW, CG, CGL, KIND, ACC>(A, K, c, a, aL, xy, pf, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf OEM_DIAG_PASS);
-                // oemXTX::get_beta rescales the member in place (ref src/oem_xtx.h:576-581, quirk Q5)
-                if (__builtin_expect(A.sinv != nullptr, 0)) beta *= sinv;
-                *(owner ? &A.beta[orow * p + row] : sinkd) = beta;
-                *(t0 ? &A.niter[orow] : sinki) = conv ? it : A.maxit + 1; // ref src/oem_base.h:94-109
-                if (__builtin_expect(A.sinv != nullptr, 0))
-                    ab = gemv_rows<NW, CG, CGL, false, false>(a, aL, beta, wslot, ecol, false, any_unused, aux_unused, S, w, lane, buf, nullptr OEM_DIAG_PASS);
+                // (the loss is taken in the coordinates of the iteration, before any in-place rescale)
                 double lossv = 1e99;
                 if (__builtin_expect(A.compute_loss != 0, 0)) {
                     // sum (Y - X beta)^2 through the Gram identity (ref src/oem_dense.h:759-770):
                     // yy - 2 n beta'XY + n beta' XX beta, with XX beta = d beta - A beta
                     lossv = yy + nobs * waves_sum<NW>(rows_sum(beta * ((d * beta - ab) - 2.0 * xy)), S.XN, par, w, lane);
                 }
+                // oemXTX::get_beta rescales the member in place (ref src/oem_xtx.h:576-581, quirk Q5)
+                if (__builtin_expect(A.sinv != nullptr, 0)) beta *= sinv;
+                *(owner ? &A.beta[orow * p + row] : sinkd) = beta;
+                *(t0 ? &A.niter[orow] : sinki) = conv ? it : A.maxit + 1; // ref src/oem_base.h:94-109
+                if (__builtin_expect(A.sinv != nullptr, 0))
+                    ab = gemv_rows<NW, CG, CGL, false, false>(a, aL, beta, wslot, ecol, false, any_unused, aux_unused, S, w, lane, buf, nullptr OEM_DIAG_PASS);
                 *(t0 ? &A.loss[orow] : sinkd + 256) = lossv;
             }
             __syncthreads();                                             // LAM is rewritten by the next chunk

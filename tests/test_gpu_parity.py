@@ -399,11 +399,12 @@ def test_sparse_x(oa, std, icpt):
     groups = np.arange(p) // 4 + 1
     pens = ["lasso", "mcp", "grp.lasso", "ols"]
     kw = dict(penalty=pens, groups=groups, nlambda=15, tol=1e-9, maxit=1000, standardize=std, intercept=icpt)
-    f = oa.oem(x, y, **kw)
-    r = orc.fit_sparse(x, y, unique_groups=np.unique(groups), lambda_min_ratio=1e-4, **kw)
+    f = oa.oem(x, y, compute_loss=True, **kw)
+    r = orc.fit_sparse(x, y, unique_groups=np.unique(groups), lambda_min_ratio=1e-4, compute_loss=True, **kw)
     assert abs(f["d"] - r["d"]) < 1e-11 * r["d"]
     for k in range(len(pens)):
         assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-11)
+        assert np.allclose(np.ravel(f["loss"][k]), np.ravel(r["loss"][k]), rtol=1e-9)
         assert np.abs(f["beta"][k] - r["beta"][k]).max() < 1e-8 * max(1.0, float(np.abs(r["beta"][k]).max())), pens[k]
         dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]))
         assert dn.max() <= 1, (pens[k], dn)
@@ -411,8 +412,6 @@ def test_sparse_x(oa, std, icpt):
         g = oa.oem(np.asfortranarray(x.toarray()), y, **kw)
         for k in range(len(pens)):
             assert np.abs(f["beta"][k] - g["beta"][k]).max() < 1e-12
-    with pytest.raises(oa.OemgpuError, match="compute.loss"):
-        oa.oem(x, y, penalty="lasso", compute_loss=True)
 
 
 @pytest.mark.gpu
