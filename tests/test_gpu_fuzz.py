@@ -1,0 +1,130 @@
+"""Randomised parity: seeded random shapes, option sets and entry points, GPU against the oracle.  Each case is small enough for
+the oracle to finish in well under a second; the point is the combinations (sizes that straddle the kernel dispatch limits,
+penalty mixes, flags) that the hand-written cases do not enumerate."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ELEMENTWISE = ["elastic.net", "lasso", "ols", "mcp", "scad", "mcp.net", "scad.net"]
+GROUPED = ["grp.lasso", "grp.lasso.net", "grp.mcp", "grp.scad", "grp.mcp.net", "grp.scad.net", "sparse.grp.lasso"]
+import os
+
+SCALE = int(os.environ.get("OEM_FUZZ_SCALE", "1"))        # OEM_FUZZ_SCALE=20: a bug hunt, not part of the regular run
+P_CHOICES = [2, 3, 7, 16, 17, 31, 33, 64, 65, 80, 81, 104, 105, 128, 129, 160, 176, 177, 192, 208, 209, 256, 257, 287, 288, 289, 300]
+
+
+@pytest.fixture(scope="module")
+def oa():
+    import oem_amd
+    return oem_amd
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    p = int(rng.choice(P_CHOICES))
+    n = int(p + 1 + rng.integers(1, 4 * p + 200))
+    x = np.asfortranarray(rng.normal(size=(n, p)) * rng.uniform(0.5, 3.0) + rng.uniform(-1, 1))
+    nnz = int(min(p, rng.integers(1, 8)))
+    b = np.zeros(p); b[rng.choice(p, nnz, replace=False)] = rng.uniform(-1.5, 1.5, nnz)
+    y = x @ b + rng.normal(size=n) * rng.uniform(0.3, 2.0) + rng.uniform(-1, 1)
+    npen = int(rng.integers(1, 4))
+    pool = ELEMENTWISE + (GROUPED if rng.random() < 0.6 else [])
+    pens = list(rng.choice(pool, npen, replace=False))
+    gsz = int(rng.integers(1, 6))
+    groups = np.arange(p) // gsz + (0 if rng.random() < 0.3 else 1)          # sometimes a group 0 (unpenalised)
+    pf = np.where(rng.random(p) < 0.1, 0.0, rng.uniform(0.5, 2.0, p))
+    kw = dict(penalty=pens, nlambda=int(rng.integers(1, 9)), alpha=float(rng.uniform(0.2, 1.0)), gamma=float(rng.uniform(2.1, 5.0)),
+              tau=float(rng.uniform(0.1, 0.9)), tol=float(10.0 ** rng.uniform(-10, -6)), maxit=int(rng.choice([30, 200, 500])),
+              penalty_factor=pf)
+    if any("grp" in q for q in pens):
+        kw["groups"] = groups
+    return rng, x, y, kw, pens, groups
+
+
+def _check(f, r, pens, tol=2e-7):
+    assert abs(f["d"] - r["d"]) <= 1e-10 * abs(r["d"])
+    for k, name in enumerate(pens):
+        fb, rb = np.asarray(f["beta"][k]), np.asarray(r["beta"][k])
+        assert fb.shape == rb.shape, (name, fb.shape, rb.shape)
+        assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-10)
+        assert np.abs(fb - rb).max() <= tol * max(1.0, float(np.abs(rb).max())), (name, float(np.abs(fb - rb).max()))
+        dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int))
+        assert np.mean(dn > 1) <= 0.25, (name, dn)
+
+
+@pytest.mark.parametrize("seed", list(range(36)) + list(range(10000, 10000 + 36 * (SCALE - 1))))
+def test_random_dense(oa, seed):
+    rng, x, y, kw, pens, groups = _case(seed)
+    std, icpt = bool(rng.integers(2)), bool(rng.integers(2))
+    extra = dict(standardize=std, intercept=icpt, accelerate=bool(rng.random() < 0.3), compute_loss=bool(rng.random() < 0.5))
+    okw = dict(kw); okw.pop("groups", None)
+    if "groups" in kw:
+        okw.update(groups=groups, unique_groups=np.unique(groups))
+    f = oa.oem(x, y, **kw, **extra)
+    r = orc.fit_dense(x, y, lambda_min_ratio=1e-4, **okw, **extra)
+    _check(f, r, pens)
+    if extra["compute_loss"]:
+        for k in range(len(pens)):
+            assert np.allclose(np.ravel(f["loss"][k]), np.ravel(r["loss"][k]), rtol=1e-7)
+
+
+@pytest.mark.parametrize("seed", list(range(36, 54)) + list(range(20000, 20000 + 18 * (SCALE - 1))))
+def test_random_big_and_xtx(oa, seed):
+    rng, x, y, kw, pens, groups = _case(seed)
+    n, p = x.shape
+    std, icpt = bool(rng.integers(2)), bool(rng.integers(2))
+    okw = dict(kw); okw.pop("groups", None)
+    if seed % 2 == 0:                                             # big.oem
+        if "groups" in kw:
+            g = np.concatenate([[0], groups]) if icpt else groups
+            ug = np.unique(np.concatenate([[0], groups])) if icpt else np.unique(groups)
+            okw.update(groups=g, unique_groups=ug)
+        f = oa.big_oem(x, y, standardize=std, intercept=icpt, **kw)
+        r = orc.fit_big(x, y, standardize=std, intercept=icpt, lambda_min_ratio=1e-4, **okw)
+    else:                                                         # oem.xtx, with a scale factor half of the time
+        sf = rng.uniform(0.5, 2.0, p) if rng.random() < 0.5 else None
+        if "groups" in kw:
+            okw.update(groups=groups, unique_groups=np.unique(groups))
+        xtx, xty = x.T @ x / n, x.T @ y / n
+        f = oa.oem_xtx(xtx, xty, scale_factor=() if sf is None else sf, **kw)
+        r = orc.fit_xtx(xtx, xty, scale_factor=sf, lambda_min_ratio=1e-4, **okw)
+    _check(f, r, pens)
+
+
+@pytest.mark.parametrize("seed", list(range(54, 66)) + list(range(30000, 30000 + 12 * (SCALE - 1))))
+def test_random_xval_and_sparse(oa, seed):
+    import scipy.sparse as sp
+    rng, x, y, kw, pens, groups = _case(seed)
+    n, p = x.shape
+    std, icpt = bool(rng.integers(2)), bool(rng.integers(2))
+    okw = dict(kw); okw.pop("groups", None)
+    if seed % 2 == 0:                                             # xval.oem
+        nf = int(rng.integers(3, 8))
+        if n - (n + nf - 1) // nf <= p + 1:
+            pytest.skip("a fold fit would have n <= p")
+        foldid = rng.permutation(np.resize(np.arange(1, nf + 1), n))
+        if "groups" in kw:
+            g = np.concatenate([[0], groups]) if icpt else groups
+            ug = np.unique(np.concatenate([[0], groups])) if icpt else np.unique(groups)
+            okw.update(groups=g, unique_groups=ug)
+        measure = "mae" if rng.random() < 0.5 else "mse"
+        f = oa.xval_oem(x, y, foldid=foldid, standardize=std, intercept=icpt, type_measure=measure, **kw)
+        r = orc.xval_dense(x, y, foldid, standardize=std, intercept=icpt, type_measure=measure, lambda_min_ratio=1e-4, **okw)
+        _check(f, r, pens)
+        for k in range(len(pens)):
+            assert np.allclose(f["cvm"][k], r["cvm"][k], rtol=1e-6), pens[k]
+            assert np.allclose(f["cvsd"][k], r["cvsd"][k], rtol=1e-5), pens[k]
+    else:                                                         # sparse x
+        xs = sp.csc_matrix(np.where(rng.random(x.shape) < 0.15, x, 0.0))
+        if "groups" in kw:
+            okw.update(groups=groups, unique_groups=np.unique(groups))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            f = oa.oem(xs, y, standardize=std, intercept=icpt, **kw)
+        r = orc.fit_sparse(xs, y, standardize=std, intercept=icpt, lambda_min_ratio=1e-4, **okw)
+        _check(f, r, pens)
