@@ -128,3 +128,46 @@ def test_random_xval_and_sparse(oa, seed):
             f = oa.oem(xs, y, standardize=std, intercept=icpt, **kw)
         r = orc.fit_sparse(xs, y, standardize=std, intercept=icpt, lambda_min_ratio=1e-4, **okw)
         _check(f, r, pens)
+
+
+@pytest.mark.parametrize("seed", list(range(66, 82)) + list(range(40000, 40000 + 16 * (SCALE - 1))))
+def test_random_large_p_wide_and_shifted(oa, seed):
+    """the launch-per-iteration engines (p > 288), the p >= n branch, and columns with |mean| >> sd (the shifted redo)"""
+    rng = np.random.default_rng(5000 + seed)
+    kind = seed % 4
+    if kind == 0:                                                 # large p, n > p
+        p = int(rng.choice([300, 320, 511, 512, 513, 700])); n = p + int(rng.integers(20, 400))
+    elif kind == 1:                                               # wide
+        p = int(rng.choice([20, 64, 100, 130, 300])); n = int(rng.integers(3, p + 1))
+    elif kind == 2:                                               # far-from-zero columns
+        p = int(rng.choice([5, 40, 100, 200])); n = 4 * p + int(rng.integers(50, 500))
+    else:                                                         # device-resident, row-major or padded leading dimension
+        p = int(rng.choice([10, 100, 150])); n = 3 * p + int(rng.integers(50, 2000))
+    x = rng.normal(size=(n, p)) * rng.uniform(0.5, 2.0)
+    if kind == 2:
+        x += rng.choice([0.0, 50.0, 1e3, -3e4], size=p)
+    x = np.asfortranarray(x)
+    b = np.zeros(p); b[:min(p, 5)] = rng.uniform(-1, 1, min(p, 5))
+    y = x @ b + rng.normal(size=n) + (rng.uniform(-100, 100) if kind == 2 else 0.5)
+    pens = list(rng.choice(["lasso", "mcp", "scad", "elastic.net", "grp.lasso"], int(rng.integers(1, 3)), replace=False))
+    groups = np.arange(p) // 3 + 1
+    std, icpt = bool(rng.integers(2)), bool(rng.integers(2))
+    kw = dict(penalty=pens, nlambda=int(rng.integers(2, 7)), alpha=0.8, gamma=3.0, tol=1e-8, maxit=int(rng.choice([50, 300])),
+              standardize=std, intercept=icpt)
+    okw = dict(kw)
+    if "grp.lasso" in pens:
+        kw["groups"] = groups; okw.update(groups=groups, unique_groups=np.unique(groups))
+    xin = x
+    if kind == 3:
+        import torch
+        if seed % 8 == 3:
+            xin = torch.as_tensor(np.ascontiguousarray(x), device="cuda")                       # row-major device matrix
+        else:
+            buf = torch.zeros((p, n + 6), device="cuda", dtype=torch.float64)                   # column-major, ld = n + 6
+            buf[:, :n] = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda")
+            xin = buf[:, :n].t()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f = oa.oem(xin, y, **kw)
+    r = orc.fit_dense(x, y, lambda_min_ratio=0.01 if n < p else 1e-4, **okw)
+    _check(f, r, pens, tol=5e-7)
