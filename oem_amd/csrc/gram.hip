@@ -1282,6 +1282,10 @@ struct Mom {
     __device__ double s(int j) const { return M[(size_t)j * q + (p + 1)]; }              // sum (z_j - c_j), j <= p
     __device__ double mu(int j) const { return c(j) + s(j) / n; }
     __device__ double cen(int i, int j) const { return M[(size_t)j * q + i] - s(i) * s(j) / n; }   // centred cross product
+    // A column whose entries are all the same value is EXACTLY zero once the reference has centred it (src/DataStd.h:219-262), and
+    // its scale then falls back to 1 (:237-240).  One-pass moments leave rounding noise instead: about the shift (which such a
+    // column always triggers) the noise is ~ n (eps mean)^2, far below anything a column that really varies can produce.
+    __device__ bool flat(int i) const { const double t = 32.0 * 2.220446049250313e-16 * fabs(mu(i)); return cen(i, i) <= n * t * t; }
     __device__ double raw(int i, int j) const { return cen(i, j) + n * mu(i) * mu(j); }            // sum z_i z_j
 };
 
@@ -1330,16 +1334,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict_
         for (int idx = tid; idx < p * p; idx += nth) {
             const int i = idx % p, j = idx / p;
             double si = 1.0, sj = 1.0;
+            const bool fi = m.flat(i), fj = m.flat(j);
             if (flag & 1) {
                 si = (flag == 1) ? sqrt(fmax(m.cen(i, i), 0.0)) / sqrt(n) : sqrt(fmax(m.cen(i, i), 0.0)) * (1.0 / sqrt(n));
                 sj = (flag == 1) ? sqrt(fmax(m.cen(j, j), 0.0)) / sqrt(n) : sqrt(fmax(m.cen(j, j), 0.0)) * (1.0 / sqrt(n));
-                if (si == 0.0) si = 1.0;
-                if (sj == 0.0) sj = 1.0;
+                if (si == 0.0 || fi) si = 1.0;
+                if (sj == 0.0 || fj) sj = 1.0;
             }
-            const double g = (flag >= 2) ? m.cen(i, j) : m.raw(i, j);
+            const double g = (flag >= 2) ? ((fi || fj) ? 0.0 : m.cen(i, j)) : m.raw(i, j);
             xx[(size_t)j * p + i] = g / (si * sj) / n;
             if (i == 0) {
-                const double gy = (flag >= 2) ? m.cen(j, p) : m.raw(j, p);
+                const double gy = (flag >= 2) ? (fj ? 0.0 : m.cen(j, p)) : m.raw(j, p);
                 xy[j] = gy / (sj * scaley) / n;
                 stats[4 + j] = (flag >= 2) ? m.mu(j) : 0.0;
                 stats[4 + p + j] = sj;

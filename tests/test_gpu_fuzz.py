@@ -171,3 +171,30 @@ def test_random_large_p_wide_and_shifted(oa, seed):
         f = oa.oem(xin, y, **kw)
     r = orc.fit_dense(x, y, lambda_min_ratio=0.01 if n < p else 1e-4, **okw)
     _check(f, r, pens, tol=5e-7)
+
+
+@pytest.mark.parametrize("seed", list(range(82, 94)) + list(range(50000, 50000 + 12 * (SCALE - 1))))
+def test_random_degenerate_inputs(oa, seed):
+    """constant and all-zero columns, exact duplicates, a constant response, n = p + 1: whatever the reference's arithmetic makes
+    of them (a zero scale becomes 1, src/DataStd.h:237-240), the GPU and the oracle must make the same"""
+    rng = np.random.default_rng(9000 + seed)
+    p = int(rng.choice([4, 20, 70, 150])); n = int(rng.choice([p + 1, 2 * p + 3, 500 + p]))
+    x = rng.normal(size=(n, p))
+    x[:, int(rng.integers(p))] = 0.0                               # an all-zero column
+    # a constant column.  The value is dyadic: a constant whose column mean is not exact leaves ~1e-17 of "centred" noise in the
+    # reference's two-pass arithmetic, which it then divides by its own ~1e-17 "standard deviation" (only an EXACT zero falls back
+    # to 1, src/DataStd.h:237-240) -- an accident of rounding that no other summation order reproduces.  (The library treats such
+    # a column as the constant it is: gram.hip, Mom::flat.)
+    x[:, int(rng.integers(p))] = float(rng.choice([-3.0, -1.5, 0.25, 0.5, 2.0]))
+    j, k = rng.choice(p, 2, replace=False); x[:, j] = x[:, k]      # duplicates
+    x = np.asfortranarray(x)
+    y = np.full(n, 2.5) if seed % 4 == 0 else x[:, :2] @ np.array([1.0, -1.0]) + rng.normal(size=n)
+    pens = list(rng.choice(["lasso", "mcp", "elastic.net", "ols"], 2, replace=False))
+    std, icpt = bool(rng.integers(2)), bool(rng.integers(2))
+    kw = dict(penalty=pens, nlambda=5, alpha=0.7, tol=1e-8, maxit=100, standardize=std, intercept=icpt)
+    f = oa.oem(x, y, **kw)
+    r = orc.fit_dense(x, y, lambda_min_ratio=1e-4, **kw)
+    ok = np.isfinite(r["d"]) and all(np.all(np.isfinite(bk)) for bk in r["beta"]) and all(np.all(np.isfinite(lk)) for lk in r["lambda"])
+    if not ok:                                                     # the reference arithmetic itself blows up (0 / 0): nothing to match
+        pytest.skip("the oracle's own result is not finite for this input")
+    _check(f, r, pens, tol=1e-6)
