@@ -198,3 +198,45 @@ def test_random_degenerate_inputs(oa, seed):
     if not ok:                                                     # the reference arithmetic itself blows up (0 / 0): nothing to match
         pytest.skip("the oracle's own result is not finite for this input")
     _check(f, r, pens, tol=1e-6)
+
+
+@pytest.mark.parametrize("seed", list(range(94, 106)) + list(range(60000, 60000 + 12 * (SCALE - 1))))
+def test_random_shards_and_device_entries(oa, seed):
+    """big.oem on ragged row-shard lists, the row-sharded driver with one rank (dense and big semantics) on device data, and a
+    device-resident oem.xtx"""
+    import torch
+    from oem_amd.distributed import oem_sharded
+    rng, x, y, kw, pens, groups = _case(seed + 500)
+    n, p = x.shape
+    std, icpt = bool(rng.integers(2)), bool(rng.integers(2))
+    okw = dict(kw); okw.pop("groups", None)
+    kind = seed % 3
+    if kind == 0:                                                 # shard lists
+        cuts = np.sort(rng.choice(np.arange(1, n), size=int(rng.integers(1, 5)), replace=False))
+        cuts = np.concatenate([[0], cuts, [n]])
+        xs = [np.asfortranarray(x[cuts[i]:cuts[i + 1]]) for i in range(len(cuts) - 1)]
+        ys = [y[cuts[i]:cuts[i + 1]] for i in range(len(cuts) - 1)]
+        if "groups" in kw:
+            g = np.concatenate([[0], groups]) if icpt else groups
+            okw.update(groups=g, unique_groups=np.unique(np.concatenate([[0], groups])) if icpt else np.unique(groups))
+        f = oa.big_oem(xs, ys, standardize=std, intercept=icpt, **kw)
+        r = orc.fit_big(x, y, standardize=std, intercept=icpt, lambda_min_ratio=1e-4, **okw)
+    elif kind == 1:                                               # one-rank sharded driver on device data
+        big = bool(rng.integers(2))
+        xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+        yd = torch.as_tensor(y, device="cuda")
+        if "groups" in kw:
+            if big:
+                g = np.concatenate([[0], groups]) if icpt else groups
+                okw.update(groups=g, unique_groups=np.unique(np.concatenate([[0], groups])) if icpt else np.unique(groups))
+            else:
+                okw.update(groups=groups, unique_groups=np.unique(groups))
+        f = oem_sharded(xd, yd, big=big, standardize=std, intercept=icpt, **kw)
+        r = (orc.fit_big if big else orc.fit_dense)(x, y, standardize=std, intercept=icpt, lambda_min_ratio=1e-4, **okw)
+    else:                                                         # device-resident Gram for oem.xtx
+        xtx, xty = x.T @ x / n, x.T @ y / n
+        if "groups" in kw:
+            okw.update(groups=groups, unique_groups=np.unique(groups))
+        f = oa.oem_xtx(torch.as_tensor(xtx, device="cuda"), torch.as_tensor(xty, device="cuda"), **kw)
+        r = orc.fit_xtx(xtx, xty, lambda_min_ratio=1e-4, **okw)
+    _check(f, r, pens)
