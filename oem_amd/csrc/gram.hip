@@ -1142,7 +1142,9 @@ static int launch_gram_t(hipStream_t s, const GramPlan &pl, const double *x, con
         break;                                                                                            \
     }
     // 16-byte aligned X with at least 4 tile columns: the LDS-DMA ring form
-    if (pl.tri && ALIGNED && pl.ntc >= 4) {
+    // (not for a handful of rows: the ring's pre-decremented 32-bit lane offsets assume 16 columns x ld x 8 bytes >= 1 KiB per
+    // fragment, i.e. ld >= 8 -- a 1-row shard with ld = 2 wrapped them around and read 4 GB away)
+    if (pl.tri && ALIGNED && pl.ntc >= 4 && a.n >= 64) {
         size_t sh = (size_t)pl.ntile * tile_bytes;
         const size_t rb = (size_t)4 * 5 * pl.ntc * 1024;                         // 4 waves x NSLOT x NF KiB ring
         if (sh < rb) sh = rb;
@@ -1171,7 +1173,7 @@ static int launch_gram_t(hipStream_t s, const GramPlan &pl, const double *x, con
         default: set_error("gram: bad tile count %d", pl.ntc); return OEMGPU_ERR_INTERNAL;
         }
     } else {
-        if (ALIGNED && !getenv("OEM_GRAM_BLK") && (double)a.ld * 16.0 * 8.0 < 4294967296.0) {   // 32-bit lane offsets within a tile
+        if (ALIGNED && a.n >= 64 && !getenv("OEM_GRAM_BLK") && (double)a.ld * 16.0 * 8.0 < 4294967296.0) {   // 32-bit lane offsets within a tile
             const int nsb = (pl.ntc + 7) / 8, nsblk = nsb * (nsb + 1) / 2;
             const size_t shb = (size_t)SB_NSLOT * 16 * 1024;                // NSLOT x 16 KiB slots
             OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));

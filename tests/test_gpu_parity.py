@@ -449,3 +449,30 @@ def test_sparse_x_in_several_row_tiles(oa, monkeypatch):
     for k in range(2):
         assert np.abs(one["beta"][k] - many["beta"][k]).max() < 1e-12
         assert np.abs(many["beta"][k] - r["beta"][k]).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [5, 65, 100, 111, 300])
+def test_moments_of_a_handful_of_rows(oa, p):
+    """1 .. 65 rows with garbage behind the last one (a 1-row shard of big.oem, a tiny fold): every moment kernel must stay inside
+    its input.  (The LDS-DMA ring's pre-decremented 32-bit lane offsets wrapped around at ld < 8 -- found by tests/test_gpu_fuzz.py --
+    so launches of fewer than 64 rows take the plain kernels.)"""
+    import torch
+    from oem_amd import _lib as L
+    from oem_amd.distributed import HipBackend
+    be = HipBackend(0)
+    rng = np.random.default_rng(p)
+    for n in (1, 2, 3, 7, 8, 9, 63, 64, 65):
+        for pad in (0, 2):
+            ld = (n + 1) // 2 * 2 + pad
+            x = rng.normal(size=(n, p)); y = rng.normal(size=n)
+            buf = torch.full((p, ld), 7.5, device="cuda", dtype=torch.float64)
+            buf[:, :n] = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda")
+            yd = torch.full((ld + 8,), -3.25, device="cuda", dtype=torch.float64); yd[:n] = torch.as_tensor(y, device="cuda")
+            with be.section():
+                mom = be.new_buffer(L.moments_len(p))
+                be.moments(buf[:, :n].t(), n, ld, p, yd, None, mom)
+            torch.cuda.synchronize()
+            z = np.column_stack([x, y, np.ones(n)])
+            ref = z.T @ z
+            assert np.abs(mom.cpu().numpy().reshape(p + 2, p + 2) - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), (n, ld)
