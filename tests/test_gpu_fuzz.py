@@ -240,3 +240,46 @@ def test_random_shards_and_device_entries(oa, seed):
         f = oa.oem_xtx(torch.as_tensor(xtx, device="cuda"), torch.as_tensor(xty, device="cuda"), **kw)
         r = orc.fit_xtx(xtx, xty, lambda_min_ratio=1e-4, **okw)
     _check(f, r, pens)
+
+
+@pytest.mark.parametrize("seed", list(range(106, 136)) + list(range(70000, 70000 + 30 * (SCALE - 1))))
+def test_random_moment_kernels(oa, seed):
+    """the moment buffer itself against numpy: row counts around the 64-row slab and chunk boundaries, every tile-count / strip
+    variant of the ring kernel (p + 2 around multiples of 16), the shared-slab and block kernels, padded leading dimensions,
+    8-byte-aligned (not 16) inputs, shifted and unshifted accumulation, garbage behind the last row"""
+    import torch
+    from oem_amd import _lib as L
+    from oem_amd.distributed import HipBackend
+    rng = np.random.default_rng(7000 + seed)
+    p = int(rng.choice([2, 13, 14, 15, 29, 30, 31, 46, 62, 63, 78, 94, 100, 105, 106, 109, 110, 111, 112, 126, 200, 254, 255, 256, 300, 511, 512]))
+    n = int(rng.choice([1, 63, 64, 65, 127, 128, 129, 191, 1000, 4095, 4096, 4097, 16383, 20001, 65537]))
+    pad = int(rng.choice([0, 0, 2, 6, 10]))
+    odd = bool(rng.random() < 0.25)                               # leading dimension odd and base 8-byte aligned only
+    ld = n + pad + (1 if odd and (n + pad) % 2 == 0 else 0) if odd else (n + 1) // 2 * 2 + pad
+    shift = bool(rng.random() < 0.4)
+    x = rng.normal(size=(n, p)) * rng.uniform(0.5, 2.0) + (rng.uniform(-50, 50, p) if shift else 0.0)
+    y = rng.normal(size=n) + (30.0 if shift else 0.0)
+    be = HipBackend(0)
+    off = 1 if odd else 0
+    flat = torch.full((p * ld + off + 16,), 7.5, device="cuda", dtype=torch.float64)
+    view = flat[off:off + p * ld].view(p, ld)
+    view[:, :n] = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda")
+    yflat = torch.full((n + off + 16,), -3.25, device="cuda", dtype=torch.float64)
+    yd = yflat[off:off + n]; yd[:] = torch.as_tensor(y, device="cuda")
+    with be.section():
+        mom = be.new_buffer(L.moments_len(p)); sums = be.new_buffer(L.sums_len(p))
+        if shift:
+            be.shift_sums(view[:, :n].t(), n, ld, p, yd, sums)
+        be.moments(view[:, :n].t(), n, ld, p, yd, sums if shift else None, mom)
+    torch.cuda.synchronize()
+    M = mom.cpu().numpy().reshape(p + 2, p + 2)
+    c = np.zeros(p + 1)
+    if shift:
+        sh = sums.cpu().numpy()
+        m = sh[:p + 1] / sh[p + 1]
+        var = np.maximum(sh[p + 2:2 * p + 3] / sh[p + 1] - m * m, 0.0)
+        c = m if np.any(m * m > 256.0 * var) else c
+    z = np.column_stack([x - c[:p], y - c[p], np.ones(n)])
+    ref = z.T @ z
+    scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref))) + 1e-300
+    assert np.abs(M - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), (p, n, ld, odd, shift, float(np.abs((M - ref) / scale).max()))
