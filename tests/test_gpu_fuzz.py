@@ -283,3 +283,29 @@ def test_random_moment_kernels(oa, seed):
     ref = z.T @ z
     scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref))) + 1e-300
     assert np.abs(M - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), (p, n, ld, odd, shift, float(np.abs((M - ref) / scale).max()))
+
+
+@pytest.mark.parametrize("seed", list(range(136, 148)) + list(range(80000, 80000 + 12 * (SCALE - 1))))
+def test_random_xval_fold_layouts(oa, seed):
+    """xval.oem with many folds of very uneven size, folds of a single row, ids that never occur, n at the 1024-row layout-block
+    boundaries"""
+    rng = np.random.default_rng(8000 + seed)
+    p = int(rng.choice([3, 10, 40, 100])); n = int(rng.choice([1023, 1024, 1025, 2047, 2049, 3000, 5000])) + 3 * p
+    nf = int(rng.choice([3, 7, 16, 37, 64, 130]))
+    w = rng.dirichlet(np.full(nf, 0.3))                           # very uneven fold sizes, some (nearly) empty
+    foldid = rng.choice(np.arange(1, nf + 1), size=n, p=w)
+    foldid[:1] = nf                                               # nfolds = max(foldid) as R/oem_xval.R:189 has it
+    x = np.asfortranarray(rng.normal(size=(n, p)) + rng.uniform(-0.5, 0.5))
+    y = x[:, :2] @ np.array([1.0, -0.5]) + rng.normal(size=n) + 0.3
+    if n - np.bincount(foldid, minlength=nf + 1).max() <= p + 2:
+        pytest.skip("a fold fit would have n <= p")
+    pens = list(rng.choice(["lasso", "mcp", "elastic.net", "ols"], 2, replace=False))
+    std, icpt = bool(rng.integers(2)), bool(rng.integers(2))
+    measure = "mae" if rng.random() < 0.5 else "mse"
+    kw = dict(penalty=pens, nlambda=int(rng.integers(2, 8)), alpha=0.6, tol=1e-8, maxit=400, standardize=std, intercept=icpt)
+    f = oa.xval_oem(x, y, foldid=foldid, type_measure=measure, **kw)
+    r = orc.xval_dense(x, y, foldid, type_measure=measure, lambda_min_ratio=1e-4, **kw)
+    _check(f, r, pens)
+    for k in range(len(pens)):
+        assert np.allclose(f["cvm"][k], r["cvm"][k], rtol=1e-7), pens[k]
+        assert np.allclose(f["cvsd"][k], r["cvsd"][k], rtol=1e-6), pens[k]
