@@ -309,3 +309,36 @@ def test_random_xval_fold_layouts(oa, seed):
     for k in range(len(pens)):
         assert np.allclose(f["cvm"][k], r["cvm"][k], rtol=1e-7), pens[k]
         assert np.allclose(f["cvsd"][k], r["cvsd"][k], rtol=1e-6), pens[k]
+
+
+@pytest.mark.parametrize("seed", list(range(148, 160)) + list(range(90000, 90000 + 12 * (SCALE - 1))))
+def test_random_large_q_engines(oa, seed):
+    """the launch-per-iteration engines through oem.xtx: q on both sides of 512 / 1024 (the fused kernels' exact sizes and their
+    prefetch limit), group / element-wise / mixed penalties, scale.factor, and the dense entry's accelerate + compute.loss"""
+    rng = np.random.default_rng(9500 + seed)
+    q = int(rng.choice([289, 300, 511, 512, 513, 700, 1023, 1024, 1025, 1100, 1500]))
+    n = q + int(rng.integers(50, 300))
+    x = rng.normal(size=(n, q)) * rng.uniform(0.5, 2.0)
+    b = np.zeros(q); b[:6] = rng.uniform(-1, 1, 6)
+    y = x @ b + rng.normal(size=n)
+    pens = list(rng.choice(["lasso", "mcp", "scad.net", "grp.lasso", "grp.mcp", "sparse.grp.lasso", "ols"], int(rng.integers(1, 3)), replace=False))
+    groups = np.arange(q) // int(rng.integers(2, 9)) + 1
+    kw = dict(penalty=pens, nlambda=int(rng.integers(2, 6)), alpha=0.7, gamma=3.0, tau=0.4, tol=1e-7, maxit=int(rng.choice([40, 150])))
+    okw = dict(kw)
+    if any("grp" in t for t in pens):
+        kw["groups"] = groups; okw.update(groups=groups, unique_groups=np.unique(groups))
+    if seed % 2 == 0:
+        xtx, xty = x.T @ x / n, x.T @ y / n
+        sf = rng.uniform(0.5, 2.0, q) if rng.random() < 0.5 else None
+        f = oa.oem_xtx(xtx, xty, scale_factor=() if sf is None else sf, **kw)
+        r = orc.fit_xtx(xtx, xty, scale_factor=sf, lambda_min_ratio=1e-4, d_override=f["d"] if q > 1100 else 0.0, **okw)
+    else:
+        extra = dict(standardize=bool(rng.integers(2)), intercept=bool(rng.integers(2)), accelerate=bool(rng.random() < 0.5),
+                     compute_loss=bool(rng.random() < 0.5))
+        xf = np.asfortranarray(x)
+        f = oa.oem(xf, y, **kw, **extra)
+        r = orc.fit_dense(xf, y, lambda_min_ratio=1e-4, d_override=f["d"] if q > 1100 else 0.0, **okw, **extra)
+        if extra["compute_loss"]:
+            for k in range(len(pens)):
+                assert np.allclose(np.ravel(f["loss"][k]), np.ravel(r["loss"][k]), rtol=1e-7)
+    _check(f, r, pens, tol=5e-7)
