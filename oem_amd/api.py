@@ -247,7 +247,7 @@ def oem(x, y, family="gaussian", penalty=None, weights=(), lambda_=(), nlambda=1
         varnames = [f"V{i + 1}" for i in range(p)]
     if len(penalty_factor) != p:
         raise ValueError("penalty.factor must have same length as number of columns in x")
-    groups, unique_groups, group_weights = _group_setup(penalty, groups, group_weights, p, False)
+    groups, unique_groups, group_weights = _group_setup(penalty, groups, group_weights, p, bool(intercept) and is_sparse)   # R/oem.R:296-338
     if lambda_min_ratio is None:
         lambda_min_ratio = 0.01 if n < p else 0.0001
     _common_checks(nlambda, float(lambda_min_ratio), maxit, irls_maxit, tol, irls_tol)

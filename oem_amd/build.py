@@ -23,8 +23,9 @@ def _newer(a, b):
 
 
 def _deps():
-    return [CSRC / s for s in SOURCES] + [CSRC / "common.hpp", CSRC / "gen" / "acc_tiles.inc",
-                                          HERE.parent / "include" / "oemgpu.h"]
+    # every header / include any source may pull in: an edited penalty_ops.hpp must rebuild path_*.hip
+    return [CSRC / s for s in SOURCES] + sorted(CSRC.glob("*.hpp")) + sorted((CSRC / "gen").glob("*.inc")) + \
+        [HERE.parent / "include" / "oemgpu.h"]
 
 
 def audit_gram_isa(asm_text):

@@ -172,7 +172,7 @@ void build_groups(const oemgpu_opts *o, int q, int nscan, Groups &G)
 // ---------------------------------------------------------------- the driver behind all entry points
 // xx (q x q), xy (q), stats already on the device (in the workspace).  sem: OEMGPU_SEM_*, or 2 for oem.xtx.
 enum { SEM_XTX = 2, SEM_SPARSE = 4 };        // OEMGPU_SEM_XVAL = 3 (oemgpu.h): oemBig's algebra with xval.oem's lambda_zero, groups and loss;
-                                              // SEM_SPARSE: oemSparse (the intercept slot rescaled in place through `scale_factor`, groups read against positions 0..p-1)
+                                              // SEM_SPARSE: oemSparse (the intercept slot rescaled in place through `scale_factor`, groups = q entries, slot 0 the intercept's group 0)
 
 // nbatch > 1: that many independent problems (instance b at xx + b * bstride, ... ; outputs of instance b at beta + b * npen * nl *
 // rows, lambda_out / niter / loss + b * npen * nl, d_out[b]) solved by ONE launch, one workgroup (set) each; q <= SMALL_P_MAX only.
@@ -196,7 +196,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     Groups G;
     oemgpu_opts og = *o;
     if (!any_grp) og.ngroups = 0;
-    build_groups(&og, q, (sem == OEMGPU_SEM_BIG || sem == SEM_SPARSE) ? p : q, G);      // quirk Q17 is oemBig's alone (ref src/oem_xval_dense.h:636 scans nvars + intercept)
+    build_groups(&og, q, sem == OEMGPU_SEM_BIG ? p : q, G);      // quirk Q17 is oemBig's alone (ref src/oem_xval_dense.h:636 and src/oem_sparse.h:465 scan all groups.size() slots)
     const size_t o_pen = bl.add(o->penalty, sizeof(int32_t) * npen);
     const size_t o_lam = user ? bl.add(o->lambda_user, sizeof(double) * (size_t)npen * nl) : 0;
     const size_t o_pf = bl.add(pf.data(), sizeof(double) * q);
@@ -954,7 +954,7 @@ int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t
 {
     if (!colptr || !y || !o || !beta || !lambda_out || !niter || !loss || !d) { set_error("fit_sparse: NULL argument"); return OEMGPU_ERR_ARG; }
     const int q = p + (intercept ? 1 : 0);
-    int rc = check_opts(o, p, p);             // the group vector has p entries with or without an intercept (ref src/oem_sparse.h:452-470)
+    int rc = check_opts(o, p, q);             // R prepends the unpenalised group 0 for the intercept slot (ref R/oem.R:296-338); oemSparse scans all groups.size() = q slots (ref src/oem_sparse.h:465)
     if (rc) return rc;
     if (n <= p) { set_error("p >= n with a sparse x (the XXt branch, ref src/oem_sparse.h:607-612) is not part of this path"); return OEMGPU_ERR_UNSUPPORTED; }
     if (o->compute_loss && q > SMALL_P_MAX) { set_error("compute.loss with a sparse x is built for p + intercept <= %d only", SMALL_P_MAX); return OEMGPU_ERR_UNSUPPORTED; }

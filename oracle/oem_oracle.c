@@ -1050,8 +1050,8 @@ int orc_xval_dense(const double *x, int64_t n, int32_t p, const double *y, const
  * X in compressed sparse column form as a dgCMatrix holds it: colptr[p + 1], rowidx[nnz] (increasing inside a column), val[nnz].
  * What differs from oemBig: the intercept column holds intval = sqrt(mean(diag(XX)) / n) instead of 1 (ref :577-593), the
  * coefficient of that column is rescaled IN PLACE by get_beta after every lambda (ref :897-900) and so enters the next warm
- * start rescaled, lambda_zero leaves the intercept slot out (ref :854-863), and the group vector is read against positions
- * 0..p-1 of the (p + 1)-vector (ref :452-470: position 0 is the intercept). */
+ * start rescaled, lambda_zero leaves the intercept slot out (ref :854-863), and the group vector has q = p + intercept entries
+ * (ref :452-470 scans all groups.size() slots; with an intercept R prepends the unpenalised group 0, ref R/oem.R:296-338). */
 int orc_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t *rowidx, const double *val, const double *y,
                    int32_t standardize, int32_t intercept, const orc_opts *o,
                    double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out)
@@ -1129,7 +1129,7 @@ int orc_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t *r
             if (i >= nlam) continue;
             if (i == 0) {
                 memset(s.beta, 0, sizeof(double) * (size_t)q);
-                if (!have_g && pen_is_grp(pen)) { if (build_groups(&g, &oo, p)) { rc = -1; break; } have_g = 1; }   /* groups.size() = p */
+                if (!have_g && pen_is_grp(pen)) { if (build_groups(&g, &oo, q)) { rc = -1; break; } have_g = 1; }   /* groups.size() = q: R prepends group 0 for the intercept (ref R/oem.R:296-338, src/oem_sparse.h:465) */
             }
             niter[(size_t)pp * nl + i] = solve_one(&s, pen, lam[(size_t)pp * nl + i], &oo, pf, &g, &ak);
             if (intercept) s.beta[0] *= intval;                              /* get_beta, in place (ref :897-900) */

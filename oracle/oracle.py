@@ -176,8 +176,21 @@ def xval_dense(x, y, foldid, penalty="elastic.net", standardize=True, intercept=
     return out
 
 
+def r_sparse_groups(groups, intercept):
+    """What R's oem() hands to oem_fit_sparse for a group penalty (ref R/oem.R:285-338, default group weights): with an
+    intercept the unpenalised group 0 is added to unique.groups and a 0 is prepended to groups (slot 0 = the intercept)."""
+    groups = np.asarray(groups).ravel()
+    ug = np.sort(np.unique(groups))
+    if intercept:
+        if not np.any(ug == 0):
+            ug = np.sort(np.concatenate([[0], ug]))
+        groups = np.concatenate([[0], groups])
+    return groups.astype(np.int32), ug.astype(np.int32)
+
+
 def fit_sparse(x, y, penalty="elastic.net", standardize=True, intercept=True, native=False, **kw):
-    """ref src/oem_sparse.cpp:30-267.  x: a scipy.sparse matrix (converted to CSC with sorted indices)."""
+    """ref src/oem_sparse.cpp:30-267.  x: a scipy.sparse matrix (converted to CSC with sorted indices).
+    groups / unique_groups are the arrays the C++ entry receives (see r_sparse_groups), p + intercept entries."""
     import scipy.sparse as sp
     xc = sp.csc_matrix(x, dtype=np.float64); xc.sort_indices()
     n, p = xc.shape

@@ -122,7 +122,8 @@ def test_random_xval_and_sparse(oa, seed):
     else:                                                         # sparse x
         xs = sp.csc_matrix(np.where(rng.random(x.shape) < 0.15, x, 0.0))
         if "groups" in kw:
-            okw.update(groups=groups, unique_groups=np.unique(groups))
+            rg, rug = orc.r_sparse_groups(groups, icpt)
+            okw.update(groups=rg, unique_groups=rug)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             f = oa.oem(xs, y, standardize=std, intercept=icpt, **kw)

@@ -400,7 +400,8 @@ def test_sparse_x(oa, std, icpt):
     pens = ["lasso", "mcp", "grp.lasso", "ols"]
     kw = dict(penalty=pens, groups=groups, nlambda=15, tol=1e-9, maxit=1000, standardize=std, intercept=icpt)
     f = oa.oem(x, y, compute_loss=True, **kw)
-    r = orc.fit_sparse(x, y, unique_groups=np.unique(groups), lambda_min_ratio=1e-4, compute_loss=True, **kw)
+    rg, rug = orc.r_sparse_groups(groups, icpt)
+    r = orc.fit_sparse(x, y, lambda_min_ratio=1e-4, compute_loss=True, **dict(kw, groups=rg, unique_groups=rug))
     assert abs(f["d"] - r["d"]) < 1e-11 * r["d"]
     for k in range(len(pens)):
         assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-11)
@@ -412,6 +413,30 @@ def test_sparse_x(oa, std, icpt):
         g = oa.oem(np.asfortranarray(x.toarray()), y, **kw)
         for k in range(len(pens)):
             assert np.abs(f["beta"][k] - g["beta"][k]).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_sparse_x_groups_follow_the_variables(oa):
+    """with an intercept the group vector of a sparse x has p + 1 entries, slot 0 the intercept's unpenalised group 0
+    (ref R/oem.R:296-338, src/oem_sparse.h:465).  The LAST variable sits in an active group here: one slot off, it would be in no
+    group and forced to 0.  Converged group-lasso fits of the sparse and the dense copy of x are the same optimum (standardize =
+    FALSE, unpenalised intercept on both sides)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(47)
+    n, p = 4000, 24
+    x = sp.random(n, p, density=0.2, random_state=3, format="csc", data_rvs=lambda k: rng.normal(size=k))
+    b = np.zeros(p); b[-4:] = [1.5, -1.0, 0.8, 2.0]; b[:4] = [0.5, 0.0, -0.6, 0.0]
+    y = x @ b + rng.normal(size=n) * 0.3 + 0.4
+    groups = np.arange(p) // 4 + 1
+    dense = oa.oem(np.asfortranarray(x.toarray()), y, penalty=["grp.lasso"], groups=groups, nlambda=8, standardize=False, tol=1e-13, maxit=100000)
+    lam = dense["lambda"][0]
+    f = oa.oem(x, y, penalty=["grp.lasso"], groups=groups, lambda_=lam, standardize=False, tol=1e-13, maxit=100000)
+    assert np.abs(f["beta"][0][-1, 1:]).min() > 0.5                      # the last variable is alive from the second lambda on
+    assert np.abs(f["beta"][0] - dense["beta"][0]).max() < 1e-7
+    rg, rug = orc.r_sparse_groups(groups, True)
+    assert rg.shape == (p + 1,) and rg[0] == 0 and rug[0] == 0
+    r = orc.fit_sparse(x, y, penalty=["grp.lasso"], groups=rg, unique_groups=rug, lambda_=lam, standardize=False, tol=1e-13, maxit=100000)
+    assert np.abs(f["beta"][0] - r["beta"][0]).max() < 1e-9
 
 
 @pytest.mark.gpu

@@ -151,3 +151,24 @@ def test_prop_sparse_equals_dense_without_intercept_and_scaling():
     g = orc.fit_big(xd, y, penalty=["lasso"], lambda_=lam, tol=1e-12, maxit=20000)
     h = orc.fit_sparse(x, y, penalty=["lasso"], lambda_=lam, tol=1e-12, maxit=20000)
     assert np.abs(g["beta"][0] - h["beta"][0]).max() < 1e-9
+
+
+def test_sparse_groups_have_an_intercept_slot():
+    """ref R/oem.R:296-338 + src/oem_sparse.h:465: with an intercept a sparse x gets p + 1 group entries (slot 0 = the
+    intercept's unpenalised group 0).  The converged grp.lasso fit then is the optimum the dense path reaches (standardize =
+    FALSE); one slot off, the last variable would be in no group and stay 0."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(47)
+    n, p = 3000, 16
+    x = sp.random(n, p, density=0.25, random_state=3, format="csc", data_rvs=lambda k: rng.normal(size=k))
+    b = np.zeros(p); b[-4:] = [1.5, -1.0, 0.8, 2.0]; b[:2] = [0.5, -0.6]
+    y = x @ b + rng.normal(size=n) * 0.3 + 0.4
+    groups = np.arange(p) // 4 + 1
+    dense = orc.fit_dense(np.asfortranarray(x.toarray()), y, penalty=["grp.lasso"], groups=groups, unique_groups=np.unique(groups),
+                          nlambda=6, standardize=False, tol=1e-13, maxit=100000)
+    rg, rug = orc.r_sparse_groups(groups, True)
+    assert len(rg) == p + 1 and rg[0] == 0 and list(rug[:2]) == [0, 1]
+    s = orc.fit_sparse(x, y, penalty=["grp.lasso"], groups=rg, unique_groups=rug, lambda_=dense["lambda"][0], standardize=False,
+                       tol=1e-13, maxit=100000)
+    assert np.abs(s["beta"][0][-1, 1:]).min() > 0.5
+    assert np.abs(s["beta"][0] - dense["beta"][0]).max() < 1e-7
