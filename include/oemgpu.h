@@ -26,6 +26,8 @@ extern "C" {
 #define OEMGPU_ERR_HIP        -3   /* a HIP runtime call failed */
 #define OEMGPU_ERR_UNSUPPORTED -4  /* outside the restated path (e.g. big.oem with p >= n, ref src/oem_big.h:547-551) */
 #define OEMGPU_ERR_INTERNAL   -5
+#define OEMGPU_ERR_INTERRUPTED -6  /* opts->interrupt asked to stop (the R shim then raises the pending user interrupt,
+                                     ref src/oem_dense.cpp:235-238 Rcpp::checkUserInterrupt); every buffer is already released */
 
 /* penalty codes = position in the R default vector (ref R/oem.R:165-173) */
 enum {
@@ -60,6 +62,16 @@ typedef struct oemgpu_opts {
     const double  *group_weights;    /* n_group_weights values; 0 => sqrt(group size) (ref src/oem_dense.h:447-454) */
     int32_t        n_group_weights;
     int32_t        device;           /* HIP device ordinal; -1 => current device */
+    /* ---- host-resident entry points only (oemgpu_fit_dense, oemgpu_fit_big); zero / NULL = the defaults ---- */
+    int32_t        ngpus;            /* G > 1: the rows are split over G devices inside the library, floor(n / G) rows each and
+                                        the remainder on the last (as the reference's row blocks, ref src/oem_dense.h:328,343,
+                                        src/oem_big.h:329-358); every device builds the moments of its rows and they are summed
+                                        in device order on the first one (peer copies over xGMI), which solves.  0 or 1: `device` */
+    const int32_t *devices;          /* ngpus ordinals, or NULL => device, device + 1, ... (device = -1 => 0, 1, ...) */
+    int32_t        upload_threads;   /* host staging threads per device (pageable rows -> pinned bounce slots -> H2D); 0 => 8 */
+    int          (*interrupt)(void *);   /* polled between row blocks and between penalties / batches of iterations;
+                                            non-zero => OEMGPU_ERR_INTERRUPTED after cleanup.  NULL => never polled */
+    void          *interrupt_arg;
 } oemgpu_opts;
 
 /* -------------------------------------------------------------------------------------------
@@ -214,6 +226,21 @@ int oemgpu_eig_max_dev(oemgpu_ctx *ctx, const double *a_dev, int32_t p, double *
 int oemgpu_last_timings(oemgpu_ctx *ctx, double *ms /* OEMGPU_NTIMERS */);
 /* enable (1) / disable (0) event timing of the stages (off by default: events cost a few us) */
 int oemgpu_set_timing(oemgpu_ctx *ctx, int32_t on);
+
+/* Row range [*r0, *r1) of device g of G for n rows: floor(n / G) each, the remainder on the last
+ * (ref src/oem_dense.h:328,343).  Pure host arithmetic. */
+void oemgpu_row_split(int64_t n, int32_t G, int32_t g, int64_t *r0, int64_t *r1);
+
+/* What the most recent host-resident call (oemgpu_fit_dense / oemgpu_fit_big) of THIS thread did, for bench.py and the tests:
+ * [0] wall milliseconds of the whole call  [1] of the upload + moment passes  [2] of the solve(s)  [3] bytes staged to the
+ * devices  [4] devices used  [5] row blocks streamed (all devices)  [6] 1 if the rows stayed resident in HBM, 0 if two block
+ * buffers were recycled  [7] hipMalloc / hipHostMalloc calls made inside the call (0 in the steady state of repeated calls). */
+#define OEMGPU_NHOSTSTATS 8
+int oemgpu_last_host_stats(double *out /* OEMGPU_NHOSTSTATS */);
+
+/* Frees every cached context (streams, workspaces, pinned staging).  The host-resident entry points keep theirs between
+ * calls; nothing else needs this.  Contexts in use by another thread are left alone. */
+void oemgpu_release_cache(void);
 
 const char *oemgpu_last_error(void);
 const char *oemgpu_version(void);

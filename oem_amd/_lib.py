@@ -14,6 +14,8 @@ PENALTIES = ["elastic.net", "lasso", "ols", "mcp", "scad", "mcp.net", "scad.net"
              "grp.scad.net", "sparse.grp.lasso"]          # R/oem.R:165-173; index = C penalty code
 
 OEMGPU_SEM_DENSE, OEMGPU_SEM_BIG = 0, 1
+ERR_INTERRUPTED = -6
+NHOSTSTATS = 8
 NTIMERS = 8
 T_SHIFT, T_MOMENTS, T_FINAL, T_EIGPATH, T_GRAMK = 0, 1, 2, 3, 4
 
@@ -30,6 +32,8 @@ class OemgpuOpts(C.Structure):
         ("unique_groups", _ip), ("ngroups", C.c_int32),
         ("group_weights", _dp), ("n_group_weights", C.c_int32),
         ("device", C.c_int32),
+        ("ngpus", C.c_int32), ("devices", _ip), ("upload_threads", C.c_int32),
+        ("interrupt", C.CFUNCTYPE(C.c_int, C.c_void_p)), ("interrupt_arg", C.c_void_p),
     ]
 
 
@@ -68,6 +72,9 @@ _SIGS = {
     "oemgpu_eig_max_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, _dp]),
     "oemgpu_last_timings": (C.c_int, [C.c_void_p, _dp]),
     "oemgpu_set_timing": (C.c_int, [C.c_void_p, C.c_int32]),
+    "oemgpu_row_split": (None, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "oemgpu_last_host_stats": (C.c_int, [_dp]),
+    "oemgpu_release_cache": (None, []),
     "oemgpu_last_error": (C.c_char_p, []),
     "oemgpu_version": (C.c_char_p, []),
     "oemgpu_device_count": (C.c_int, []),
@@ -102,6 +109,14 @@ def lib():
 def check(rc):
     if rc != 0:
         raise OemgpuError(rc, lib().oemgpu_last_error().decode())
+
+
+def host_stats():
+    """oemgpu_last_host_stats of this thread, as a dict"""
+    out = (C.c_double * NHOSTSTATS)()
+    check(lib().oemgpu_last_host_stats(out))
+    keys = ["call_ms", "upload_moments_ms", "solve_ms", "bytes_staged", "devices", "row_blocks", "resident", "allocations"]
+    return dict(zip(keys, list(out)))
 
 
 def sums_len(p):

@@ -66,7 +66,8 @@ class _Args:
     """Builds oemgpu_opts and keeps the numpy buffers alive."""
 
     def __init__(self, penalty, lam_list, nlambda, lambda_min_ratio, alpha, gamma, tau, tol, maxit, accelerate,
-                 compute_loss, penalty_factor, groups, unique_groups, group_weights, device=-1):
+                 compute_loss, penalty_factor, groups, unique_groups, group_weights, device=-1, ngpus=0, devices=None,
+                 upload_threads=0, interrupt=None):
         self.pen = np.array([PENALTIES.index(q) for q in penalty], dtype=np.int32)
         self.pf = np.ascontiguousarray(penalty_factor, dtype=np.float64)
         nlu = len(lam_list[0]) if lam_list else 0
@@ -85,6 +86,14 @@ class _Args:
         o.unique_groups = _iptr(self.ug); o.ngroups = self.ug.size
         o.group_weights = _dptr(self.gw); o.n_group_weights = self.gw.size
         o.device = int(device)
+        # host-resident entry points: rows over `ngpus` devices inside the library (include/oemgpu.h)
+        self.devices = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+        o.ngpus = int(ngpus) if self.devices is None else len(self.devices)
+        o.devices = _iptr(self.devices) if self.devices is not None else None
+        o.upload_threads = int(upload_threads)
+        if interrupt is not None:
+            self._cb = L.OemgpuOpts._fields_[-2][1](lambda _arg: int(bool(interrupt())))      # kept alive with the struct
+            o.interrupt = self._cb
         self.c = o
         self.nl = nlu if nlu > 0 else int(nlambda)
         self.npen = len(self.pen)
@@ -220,8 +229,10 @@ def context(device=None, stream=None):
 def oem(x, y, family="gaussian", penalty=None, weights=(), lambda_=(), nlambda=100, lambda_min_ratio=None,
         alpha=1.0, gamma=3.0, tau=0.5, groups=(), penalty_factor=None, group_weights=None, standardize=True,
         intercept=True, maxit=500, tol=1e-7, irls_maxit=100, irls_tol=1e-3, accelerate=False, ncores=-1,
-        compute_loss=False, hessian_type="upper.bound", varnames=None):
-    """oem(): R/oem.R:162-507, dense gaussian branch."""
+        compute_loss=False, hessian_type="upper.bound", varnames=None, ngpus=0, devices=None, upload_threads=0,
+        interrupt=None):
+    """oem(): R/oem.R:162-507, dense gaussian branch.  ngpus / devices / upload_threads / interrupt: the host-resident
+    options of include/oemgpu.h (`options` gains ngpus / device; absent => one GPU)."""
     if family not in ("gaussian", "binomial"):
         raise ValueError("'arg' should be one of 'gaussian', 'binomial'")
     penalty = _match_penalty(penalty)
@@ -253,7 +264,8 @@ def oem(x, y, family="gaussian", penalty=None, weights=(), lambda_=(), nlambda=1
     _common_checks(nlambda, float(lambda_min_ratio), maxit, irls_maxit, tol, irls_tol)
     lam_list = _lambda_list(lambda_, len(penalty))
     a = _Args(penalty, lam_list, int(np.ravel(nlambda)[0]), lambda_min_ratio, alpha, gamma, tau, tol, maxit, accelerate,
-              compute_loss, penalty_factor, groups, unique_groups, group_weights)
+              compute_loss, penalty_factor, groups, unique_groups, group_weights, ngpus=ngpus, devices=devices,
+              upload_threads=upload_threads, interrupt=interrupt)
     lib = L.lib()
     if is_sparse:                                                      # oem_fit_sparse (ref src/oem_sparse.cpp:30-267)
         import scipy.sparse as sp
@@ -343,7 +355,7 @@ def oem_xtx(xtx, xty, family="gaussian", penalty=None, lambda_=(), nlambda=100, 
 def big_oem(x, y, family="gaussian", penalty=None, weights=(), lambda_=(), nlambda=100, lambda_min_ratio=None,
             alpha=1.0, gamma=3.0, tau=0.5, groups=(), penalty_factor=None, group_weights=None, standardize=True,
             intercept=True, maxit=500, tol=1e-7, irls_maxit=100, irls_tol=1e-3, compute_loss=False, gigs=4.0,
-            hessian_type="full", varnames=None):
+            hessian_type="full", varnames=None, ngpus=0, devices=None, upload_threads=0, interrupt=None):
     """big.oem(): R/big_oem.R:121-441.  x: a (host) matrix or a list of row shards (the big.matrix stand-in);
     y: a vector or the matching list of shards."""
     penalty = PENALTIES if penalty is None else _match_penalty(penalty)      # match.arg(several.ok=TRUE), no default narrowing
@@ -376,7 +388,8 @@ def big_oem(x, y, family="gaussian", penalty=None, weights=(), lambda_=(), nlamb
     _common_checks(nlambda, float(lambda_min_ratio), maxit, irls_maxit, tol, irls_tol)
     lam_list = _lambda_list(lambda_, len(penalty))
     a = _Args(penalty, lam_list, int(np.ravel(nlambda)[0]), lambda_min_ratio, alpha, gamma, tau, tol, maxit, False,
-              compute_loss, penalty_factor, groups, unique_groups, group_weights)
+              compute_loss, penalty_factor, groups, unique_groups, group_weights, ngpus=ngpus, devices=devices,
+              upload_threads=upload_threads, interrupt=interrupt)
     xs = [np.asfortranarray(s, dtype=np.float64) for s in shards]
     ys = [np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1)) for v in yshards]
     ns = (C.c_int64 * len(xs))(*[s.shape[0] for s in xs])

@@ -2,12 +2,13 @@
 // reference keeps in src/oem_dense.cpp:30-309, src/oem_xtx.cpp:29-219 and src/oem_big.cpp:30-258
 // (lambda bookkeeping, result packing, DataStd::recover).  All arithmetic of the hot path runs in the HIP
 // kernels of gram.hip / path_small.hip / path_large.hip; there is no CPU fallback.
-#include "common.hpp"
+#include "ctx.hpp"
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -27,53 +28,66 @@ void set_error(const char *fmt, ...)
 
 using namespace oemgpu;
 
-struct oemgpu_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int num_cu = 256;
-    char *ws = nullptr;          // device workspace (grow-only)
-    size_t ws_bytes = 0;
-    char *pinned = nullptr;      // pinned host staging for the results
-    size_t pinned_bytes = 0;
-    char *pinned_in = nullptr;   // pinned host staging for the parameter blob (a pageable source makes the copy block the host)
-    size_t pinned_in_bytes = 0;
-    bool timing = false;
-    hipEvent_t ev[2 * OEMGPU_NTIMERS];
-    bool ev_made = false;
-    bool ev_used[OEMGPU_NTIMERS];
-    double ms[OEMGPU_NTIMERS];
-    double diag[2] = {0.0, 0.0};   // path kernel: shader cycles, 100 MHz ticks
-    int shifted = 0;               // the last solve read its moments as accumulated about the provisional shift
-    int shift_advised = 0;         // the last solve was given moments about 0 whose columns have |mean| >> sd
-    char *aux = nullptr;           // xval.oem: fold-ordered copy of X, fold moments, fold coefficients (grow-only)
-    size_t aux_bytes = 0;
-    std::vector<oemgpu_ctx *> kids;   // xval.oem: one child context (stream, workspace, staging) per concurrent fold fit
-    hipEvent_t fork_ev = nullptr;
-};
-
-namespace {
-
-struct Bump {           // carve-out of the context workspace, 256-byte granules
-    size_t off = 0;
-    size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; }
-};
+namespace oemgpu {
 
 int ctx_reserve(oemgpu_ctx *c, size_t bytes)
 {
     if (bytes <= c->ws_bytes) return 0;
     if (c->ws) { OEM_HIP(hipStreamSynchronize(c->stream)); OEM_HIP(hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
     bytes = bytes + bytes / 8 + (1 << 20);
-    OEM_HIP(hipMalloc((void **)&c->ws, bytes));
+    OEM_HIP(hipMalloc((void **)&c->ws, bytes)); ++g_alloc_count;
     c->ws_bytes = bytes;
     return 0;
 }
+
+int ctx_grow(oemgpu_ctx *c, char **buf, size_t *have, size_t bytes)
+{
+    if (bytes <= *have) return 0;
+    if (*buf) { OEM_HIP(hipStreamSynchronize(c->stream)); OEM_HIP(hipFree(*buf)); *buf = nullptr; *have = 0; }
+    OEM_HIP(hipMalloc((void **)buf, bytes)); ++g_alloc_count;
+    *have = bytes;
+    return 0;
+}
+
+int set_device(const oemgpu_ctx *c) { OEM_HIP(hipSetDevice(c->device)); return 0; }
+
+// ---------------------------------------------------------------- process-wide context cache
+static std::mutex g_cache_mu;
+static std::vector<oemgpu_ctx *> g_cache;
+
+oemgpu_ctx *ctx_acquire(int device)
+{
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (oemgpu_ctx *c : g_cache)
+            if (c->device == device && !c->busy) { c->busy = true; (void)hipSetDevice(device); return c; }
+    }
+    oemgpu_ctx *c = oemgpu_create(device, nullptr);
+    if (!c) return nullptr;
+    c->cached = true; c->busy = true;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_cache.push_back(c);
+    return c;
+}
+
+void ctx_release(oemgpu_ctx *c)
+{
+    if (!c) return;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    c->busy = false;
+}
+
+}  // namespace oemgpu
+
+namespace {
+
 int ctx_pinned_in(oemgpu_ctx *c, size_t bytes)
 {
     if (bytes <= c->pinned_in_bytes) return 0;
     if (c->pinned_in) { OEM_HIP(hipStreamSynchronize(c->stream)); OEM_HIP(hipHostFree(c->pinned_in)); c->pinned_in = nullptr; c->pinned_in_bytes = 0; }
     bytes = (bytes + 4095) / 4096 * 4096;
-    OEM_HIP(hipHostMalloc((void **)&c->pinned_in, bytes, hipHostMallocDefault));
+    OEM_HIP(hipHostMalloc((void **)&c->pinned_in, bytes, hipHostMallocDefault)); ++g_alloc_count;
     c->pinned_in_bytes = bytes;
     return 0;
 }
@@ -83,7 +97,7 @@ int ctx_pinned(oemgpu_ctx *c, size_t bytes)
     if (bytes <= c->pinned_bytes) return 0;
     if (c->pinned) { OEM_HIP(hipStreamSynchronize(c->stream)); OEM_HIP(hipHostFree(c->pinned)); c->pinned = nullptr; c->pinned_bytes = 0; }
     bytes = bytes + bytes / 8 + 4096;
-    OEM_HIP(hipHostMalloc((void **)&c->pinned, bytes, hipHostMallocDefault));
+    OEM_HIP(hipHostMalloc((void **)&c->pinned, bytes, hipHostMallocDefault)); ++g_alloc_count;
     c->pinned_bytes = bytes;
     return 0;
 }
@@ -96,8 +110,6 @@ struct Timer {
     }
     ~Timer() { if (c->timing) (void)hipEventRecord(c->ev[2 * id + 1], c->stream); }
 };
-
-int set_device(const oemgpu_ctx *c) { OEM_HIP(hipSetDevice(c->device)); return 0; }
 
 // ---------------------------------------------------------------- argument checks (the R front ends stop() on these)
 int nl_of(const oemgpu_opts *o) { return (o->lambda_user && o->nlambda_user > 0) ? o->nlambda_user : o->nlambda; }
@@ -385,7 +397,7 @@ oemgpu_ctx *oemgpu_create(int32_t device, void *stream)
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
-        c->own_stream = true;
+        c->own_stream = true; ++g_alloc_count;
     }
     for (int i = 0; i < OEMGPU_NTIMERS; ++i) { c->ev_used[i] = false; c->ms[i] = 0.0; }
     return c;
@@ -400,11 +412,35 @@ void oemgpu_destroy(oemgpu_ctx *c)
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned_in) (void)hipHostFree(c->pinned_in);
     if (c->aux) (void)hipFree(c->aux);
+    if (c->xres) (void)hipFree(c->xres);
+    if (c->acc) (void)hipFree(c->acc);
+    for (oemgpu_lane &l : c->lanes) {
+        for (int k = 0; k < 2; ++k) {
+            if (l.slot[k]) (void)hipHostFree(l.slot[k]);
+            if (l.slot_ev[k]) (void)hipEventDestroy(l.slot_ev[k]);
+            if (l.blk_ev[k]) (void)hipEventDestroy(l.blk_ev[k]);
+        }
+        if (l.s) (void)hipStreamDestroy(l.s);
+    }
+    for (int k = 0; k < 2; ++k) if (c->done_ev[k]) (void)hipEventDestroy(c->done_ev[k]);
+    if (c->xfer_ev) (void)hipEventDestroy(c->xfer_ev);
     for (oemgpu_ctx *k : c->kids) oemgpu_destroy(k);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->ev_made) for (int i = 0; i < 2 * OEMGPU_NTIMERS; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+void oemgpu_release_cache(void)
+{
+    std::vector<oemgpu_ctx *> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        std::vector<oemgpu_ctx *> keep;
+        for (oemgpu_ctx *c : g_cache) (c->busy ? keep : drop).push_back(c);
+        g_cache.swap(keep);
+    }
+    for (oemgpu_ctx *c : drop) oemgpu_destroy(c);
 }
 
 int oemgpu_synchronize(oemgpu_ctx *c)
@@ -607,40 +643,18 @@ int oemgpu_eig_max_dev(oemgpu_ctx *c, const double *a_dev, int32_t p, double *la
 }
 
 // ---------------------------------------------------------------------------------------------- drop-in entry points
-static int upload_matrix(oemgpu_ctx *c, const double *x, int64_t n, int32_t p, double **xd, int64_t *ld)
-{
-    *ld = (n + 1) / 2 * 2;                       // even leading dimension: every column 16-byte aligned
-    OEM_HIP(hipMalloc((void **)xd, sizeof(double) * (size_t)(*ld) * p));
-    if (*ld == n) OEM_HIP(hipMemcpyAsync(*xd, x, sizeof(double) * (size_t)n * p, hipMemcpyHostToDevice, c->stream));
-    else OEM_HIP(hipMemcpy2DAsync(*xd, sizeof(double) * (size_t)(*ld), x, sizeof(double) * (size_t)n, sizeof(double) * (size_t)n, p,
-                                  hipMemcpyHostToDevice, c->stream));
-    return 0;
-}
-
+// Host buffers in, host buffers out.  Contexts come from the process-wide cache and own every device / pinned buffer the
+// calls need (grow-only), so a repeated call creates no stream, allocates nothing and frees nothing.
 int oemgpu_fit_dense(const double *x, int64_t n, int32_t p, const double *y, int32_t standardize, int32_t intercept,
                      const oemgpu_opts *o, double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
 {
-    if (!x || !y || !o) { set_error("fit_dense: NULL argument"); return OEMGPU_ERR_ARG; }
+    if (!x || !y || !o || !beta || !lambda_out || !niter || !loss || !d) { set_error("fit_dense: NULL argument"); return OEMGPU_ERR_ARG; }
     int rc = check_opts(o, p, p);
     if (rc) return rc;
+    if (n < 1) { set_error("fit_dense: bad n"); return OEMGPU_ERR_ARG; }
     // p >= n (ref src/oem_dense.h:476-482,513-521: d from XXt / n, u = X'(Y - X b)/n + d b) is served by the same Gram
     // form: the non-zero spectra of XXt and XtX coincide and X'(Y - X b)/n + d b = (dI - X'X/n) b + X'Y/n.
-    oemgpu_ctx *c = oemgpu_create(o->device, nullptr);
-    if (!c) return OEMGPU_ERR_NO_DEVICE;
-    double *xd = nullptr, *yd = nullptr;
-    int64_t ld = 0;
-    rc = upload_matrix(c, x, n, p, &xd, &ld);
-    if (!rc) {
-        hipError_t e = hipMalloc((void **)&yd, sizeof(double) * (size_t)(n + 2));
-        if (e == hipSuccess) e = hipMemcpyAsync(yd, y, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) { set_error("upload of y failed: %s", hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; }
-    }
-    if (!rc) rc = oemgpu_fit_dense_dev(c, xd, n, ld, p, yd, standardize, intercept, o, beta, lambda_out, niter, loss, d);
-    (void)hipStreamSynchronize(c->stream);
-    if (xd) (void)hipFree(xd);
-    if (yd) (void)hipFree(yd);
-    oemgpu_destroy(c);
-    return rc;
+    return host_fit_dense(x, n, p, y, standardize, intercept, o, beta, lambda_out, niter, loss, d);
 }
 
 int oemgpu_fit_xtx(const double *xtx, const double *xty, int32_t p, const double *scale_factor, const oemgpu_opts *o,
@@ -649,19 +663,19 @@ int oemgpu_fit_xtx(const double *xtx, const double *xty, int32_t p, const double
     if (!xtx || !xty || !o) { set_error("fit_xtx: NULL argument"); return OEMGPU_ERR_ARG; }
     int rc = check_opts(o, p, p);
     if (rc) return rc;
-    oemgpu_ctx *c = oemgpu_create(o->device, nullptr);
+    oemgpu_ctx *c = ctx_acquire(o->device);
     if (!c) return OEMGPU_ERR_NO_DEVICE;
-    double *ad = nullptr, *bd = nullptr;
-    hipError_t e = hipMalloc((void **)&ad, sizeof(double) * (size_t)p * p);
-    if (e == hipSuccess) e = hipMalloc((void **)&bd, sizeof(double) * (size_t)p);
-    if (e == hipSuccess) e = hipMemcpyAsync(ad, xtx, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(bd, xty, sizeof(double) * (size_t)p, hipMemcpyHostToDevice, c->stream);
-    if (e != hipSuccess) { set_error("upload of xtx failed: %s", hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; }
+    const size_t nb = sizeof(double) * (size_t)p * p;
+    rc = ctx_grow(c, &c->xres, &c->xres_bytes, nb + sizeof(double) * (size_t)p + 256);
+    double *ad = (double *)c->xres, *bd = (double *)(c->xres + (nb + 255) / 256 * 256);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(ad, xtx, nb, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(bd, xty, sizeof(double) * (size_t)p, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { set_error("upload of xtx failed: %s", hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; }
+    }
     if (!rc) rc = oemgpu_fit_xtx_dev(c, ad, bd, p, scale_factor, o, beta, lambda_out, niter, loss, d);
     (void)hipStreamSynchronize(c->stream);
-    if (ad) (void)hipFree(ad);
-    if (bd) (void)hipFree(bd);
-    oemgpu_destroy(c);
+    ctx_release(c);
     return rc;
 }
 
@@ -669,56 +683,23 @@ int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_
                    const double *const *y_shards, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
                    double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
 {
-    if (!x_shards || !n_shard || !y_shards || !o || nshards < 1) { set_error("fit_big: bad argument"); return OEMGPU_ERR_ARG; }
+    if (!x_shards || !n_shard || !y_shards || !o || nshards < 1 || !beta || !lambda_out || !niter || !loss || !d) {
+        set_error("fit_big: bad argument"); return OEMGPU_ERR_ARG;
+    }
     const int q = p + (intercept ? 1 : 0);
     int rc = check_opts(o, p, q);
     if (rc) return rc;
-    int64_t n = 0, nmax = 0;
+    if (o->compute_loss) {
+        set_error("compute.loss is not available for big.oem: the reference expression is ill-formed (src/oem_big.h:899-921)");
+        return OEMGPU_ERR_UNSUPPORTED;
+    }
+    int64_t n = 0;
     for (int s = 0; s < nshards; ++s) {
-        if (n_shard[s] < 0 || !x_shards[s] || !y_shards[s]) { set_error("fit_big: bad shard %d", s); return OEMGPU_ERR_ARG; }
+        if (n_shard[s] < 0 || (n_shard[s] > 0 && (!x_shards[s] || !y_shards[s]))) { set_error("fit_big: bad shard %d", s); return OEMGPU_ERR_ARG; }
         n += n_shard[s];
-        if (n_shard[s] > nmax) nmax = n_shard[s];
     }
     if (n <= q) { set_error("p >= n: the XXt branch (ref src/oem_big.h:547-551) is not part of this path"); return OEMGPU_ERR_UNSUPPORTED; }
-    oemgpu_ctx *c = oemgpu_create(o->device, nullptr);
-    if (!c) return OEMGPU_ERR_NO_DEVICE;
-    // The reference walks row slices serially (ref src/oem_big.h:329-358).  Here: stream the shards through one device buffer
-    // ONCE and add the shard moments.  They are taken about 0, like the reference's own sums: oemBig never centres
-    // (ref src/oem_big.h:757-763, 469-545), so there is no cancellation for a shift to prevent.
-    double *xd = nullptr, *yd = nullptr, *acc = nullptr;
-    const int64_t ldmax = (nmax + 1) / 2 * 2;
-    const size_t mlen = (size_t)oemgpu_moments_len(p), slen = (size_t)oemgpu_sums_len(p);
-    hipError_t e = hipMalloc((void **)&xd, sizeof(double) * (size_t)ldmax * p);
-    if (e == hipSuccess) e = hipMalloc((void **)&yd, sizeof(double) * (size_t)(ldmax + 2));
-    if (e == hipSuccess) e = hipMalloc((void **)&acc, sizeof(double) * (2 * mlen + 2 * slen));
-    if (e != hipSuccess) { set_error("fit_big: device allocation failed: %s", hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; }
-    double *msum = acc, *mtmp = acc + mlen;
-    if (!rc) {
-        e = hipMemsetAsync(acc, 0, sizeof(double) * (2 * mlen + 2 * slen), c->stream);
-        if (e != hipSuccess) { set_error("memset failed"); rc = OEMGPU_ERR_HIP; }
-    }
-    {
-        for (int s = 0; s < nshards && !rc; ++s) {
-            const int64_t ns = n_shard[s];
-            if (ns == 0) continue;
-            const int64_t ld = (ns + 1) / 2 * 2;
-            if (ld == ns) e = hipMemcpyAsync(xd, x_shards[s], sizeof(double) * (size_t)ns * p, hipMemcpyHostToDevice, c->stream);
-            else e = hipMemcpy2DAsync(xd, sizeof(double) * (size_t)ld, x_shards[s], sizeof(double) * (size_t)ns,
-                                      sizeof(double) * (size_t)ns, p, hipMemcpyHostToDevice, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(yd, y_shards[s], sizeof(double) * (size_t)ns, hipMemcpyHostToDevice, c->stream);
-            if (e != hipSuccess) { set_error("fit_big: upload of shard %d failed: %s", s, hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; break; }
-            rc = oemgpu_moments_dev(c, xd, ns, ld, p, yd, nullptr, mtmp);
-            if (!rc) hipLaunchKernelGGL(accumulate_kernel, dim3(64), dim3(256), 0, c->stream, msum, mtmp, mlen);
-            if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("fit_big: shard %d failed on the device", s); rc = OEMGPU_ERR_HIP; }
-        }
-    }
-    if (!rc) rc = oemgpu_solve_moments_dev(c, msum, nullptr, p, OEMGPU_SEM_BIG, standardize, intercept, o, beta, lambda_out, niter, loss, d);
-    (void)hipStreamSynchronize(c->stream);
-    if (xd) (void)hipFree(xd);
-    if (yd) (void)hipFree(yd);
-    if (acc) (void)hipFree(acc);
-    oemgpu_destroy(c);
-    return rc;
+    return host_fit_big(x_shards, n_shard, nshards, p, y_shards, standardize, intercept, o, beta, lambda_out, niter, loss, d);
 }
 
 // ---------------------------------------------------------------------------------------------- oem() on a sparse X
@@ -778,7 +759,7 @@ static int ctx_aux(oemgpu_ctx *c, size_t bytes)
 {
     if (bytes <= c->aux_bytes) return 0;
     if (c->aux) { OEM_HIP(hipStreamSynchronize(c->stream)); OEM_HIP(hipFree(c->aux)); c->aux = nullptr; c->aux_bytes = 0; }
-    OEM_HIP(hipMalloc((void **)&c->aux, bytes));
+    OEM_HIP(hipMalloc((void **)&c->aux, bytes)); ++g_alloc_count;
     c->aux_bytes = bytes;
     return 0;
 }
@@ -925,26 +906,21 @@ int oemgpu_xval_dense(const double *x, int64_t n, int32_t p, const double *y, co
     if (!x || !y || !foldid || !o) { set_error("xval_dense: NULL argument"); return OEMGPU_ERR_ARG; }
     int rc = check_opts(o, p, p + (intercept ? 1 : 0));
     if (rc) return rc;
-    oemgpu_ctx *c = oemgpu_create(o->device, nullptr);
+    if (n < 1) { set_error("xval_dense: bad n"); return OEMGPU_ERR_ARG; }
+    oemgpu_ctx *c = ctx_acquire(o->device);
     if (!c) return OEMGPU_ERR_NO_DEVICE;
     double *xd = nullptr, *yd = nullptr;
-    int32_t *fd = nullptr;
     int64_t ld = 0;
-    rc = upload_matrix(c, x, n, p, &xd, &ld);
+    rc = host_upload_resident(c, x, n, p, y, o, &xd, &ld, &yd);      // staged through the pinned lanes, leaves room for foldid behind y
+    int32_t *fd = (int32_t *)(yd + ((n + 2 + 31) / 32 * 32));
     if (!rc) {
-        hipError_t e = hipMalloc((void **)&yd, sizeof(double) * (size_t)(n + 2));
-        if (e == hipSuccess) e = hipMalloc((void **)&fd, sizeof(int32_t) * (size_t)n);
-        if (e == hipSuccess) e = hipMemcpyAsync(yd, y, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(fd, foldid, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) { set_error("upload of y / foldid failed: %s", hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; }
+        hipError_t e = hipMemcpyAsync(fd, foldid, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { set_error("upload of foldid failed: %s", hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; }
     }
     if (!rc) rc = oemgpu_xval_dense_dev(c, xd, n, ld, p, yd, fd, nfolds, standardize, intercept, type_measure, o, beta, lambda_out,
                                         niter, loss, d, cvm, cvsd);
     (void)hipStreamSynchronize(c->stream);
-    if (xd) (void)hipFree(xd);
-    if (yd) (void)hipFree(yd);
-    if (fd) (void)hipFree(fd);
-    oemgpu_destroy(c);
+    ctx_release(c);
     return rc;
 }
 
@@ -983,16 +959,21 @@ int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t
         xxdiag /= (double)p;
         if (intercept) intval = std::sqrt(xxdiag / (double)n);
     }
-    oemgpu_ctx *c = oemgpu_create(o->device, nullptr);
+    oemgpu_ctx *c = ctx_acquire(o->device);
     if (!c) return OEMGPU_ERR_NO_DEVICE;
     double *xd = nullptr, *yd = nullptr, *vd = nullptr;
     int64_t *cd = nullptr;
     int32_t *rd = nullptr;
-    hipError_t e = hipMalloc((void **)&xd, sizeof(double) * (size_t)ld * p);
-    if (e == hipSuccess) e = hipMalloc((void **)&yd, sizeof(double) * (size_t)(n + 2));
-    if (e == hipSuccess) e = hipMalloc((void **)&cd, sizeof(int64_t) * (size_t)(p + 1));
-    if (e == hipSuccess && nnz > 0) e = hipMalloc((void **)&rd, sizeof(int32_t) * (size_t)nnz);
-    if (e == hipSuccess && nnz > 0) e = hipMalloc((void **)&vd, sizeof(double) * (size_t)nnz);
+    hipError_t e = hipSuccess;
+    {                                                       // every staging buffer out of the context's grow-only input buffer
+        Bump S;
+        const size_t a_x = S.take(sizeof(double) * (size_t)ld * p), a_y = S.take(sizeof(double) * (size_t)(n + 2)),
+                     a_c = S.take(sizeof(int64_t) * (size_t)(p + 1)), a_r = S.take(sizeof(int32_t) * (size_t)(nnz + 1)),
+                     a_v = S.take(sizeof(double) * (size_t)(nnz + 1));
+        if (ctx_grow(c, &c->xres, &c->xres_bytes, S.off)) { ctx_release(c); return OEMGPU_ERR_HIP; }
+        xd = (double *)(c->xres + a_x); yd = (double *)(c->xres + a_y); cd = (int64_t *)(c->xres + a_c);
+        rd = (int32_t *)(c->xres + a_r); vd = (double *)(c->xres + a_v);
+    }
     if (e == hipSuccess) e = hipMemsetAsync(xd, 0, sizeof(double) * (size_t)ld * p, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(yd, y, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(cd, colptr, sizeof(int64_t) * (size_t)(p + 1), hipMemcpyHostToDevice, c->stream);
@@ -1036,12 +1017,7 @@ int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t
                                 lambda_out, niter, loss, d);
     }
     (void)hipStreamSynchronize(c->stream);
-    if (xd) (void)hipFree(xd);
-    if (yd) (void)hipFree(yd);
-    if (cd) (void)hipFree(cd);
-    if (rd) (void)hipFree(rd);
-    if (vd) (void)hipFree(vd);
-    oemgpu_destroy(c);
+    ctx_release(c);
     return rc;
 }
 

@@ -60,3 +60,38 @@ def test_product_never_imports_the_oracle():
     for f in list((ROOT / "oem_amd").rglob("*.py")) + list((ROOT / "oem_amd" / "csrc").rglob("*.*")):
         txt = f.read_text(errors="ignore")
         assert "oracle" not in txt.replace("# oracle", ""), f
+
+
+def test_opts_struct_matches_the_header():
+    """the ctypes mirror of oemgpu_opts has the header's size and field offsets (checked with the C compiler)"""
+    import subprocess
+    import tempfile
+    from oem_amd import _lib as L
+    fields = [f[0] for f in L.OemgpuOpts._fields_]
+    prog = '#include <stddef.h>\n#include <stdio.h>\n#include "oemgpu.h"\nint main(void){printf("%zu", sizeof(oemgpu_opts));\n' + \
+        "".join(f'printf(" %zu", offsetof(oemgpu_opts, {f}));\n' for f in fields) + "return 0;}\n"
+    with tempfile.TemporaryDirectory() as td:
+        src = Path(td) / "t.c"
+        src.write_text(prog)
+        subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(Path(td) / "t")], check=True)
+        out = subprocess.run([str(Path(td) / "t")], capture_output=True, text=True, check=True).stdout.split()
+    assert int(out[0]) == C.sizeof(L.OemgpuOpts)
+    for f, off in zip(fields, out[1:]):
+        assert int(off) == getattr(L.OemgpuOpts, f).offset, f
+
+
+def test_row_split_is_the_references_block_rule():
+    """floor(n / G) rows per device, the remainder on the last (ref src/oem_dense.h:328,343) -- pure host arithmetic"""
+    import oem_amd
+    from oem_amd.distributed import row_partition
+    L = oem_amd.lib()
+    for n in (0, 1, 7, 8, 1000003, 10 ** 8):
+        for G in (1, 2, 3, 8):
+            got = []
+            for g in range(G):
+                a, b = C.c_int64(), C.c_int64()
+                L.oemgpu_row_split(n, G, g, C.byref(a), C.byref(b))
+                got.append((a.value, b.value))
+            assert got == row_partition(n, G)
+            assert got[0][0] == 0 and got[-1][1] == n and all(got[i][1] == got[i + 1][0] for i in range(G - 1))
+            assert all(b - a == n // G for a, b in got[:-1])

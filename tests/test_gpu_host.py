@@ -1,0 +1,190 @@
+"""The host-resident entry points (oemgpu_fit_dense / oemgpu_fit_big with pageable host rows): staged upload through pinned
+bounce slots, row blocks overlapped with the moment pass, rows over several devices inside the library (here: the same device
+several times -- this pool has one GPU per box), penalties dealt to devices, cached contexts, caller interrupts.
+All through the C ABI, against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc
+
+
+@pytest.fixture(scope="module")
+def oa():
+    import torch
+    assert torch.cuda.is_available()
+    import oem_amd
+    oem_amd.lib()
+    return oem_amd
+
+
+def _data(n, p, seed, mean=0.0, sd=2.0, nnz=8):
+    rng = np.random.default_rng(seed)
+    x = np.asfortranarray(rng.normal(size=(n, p)) * sd + mean)
+    b = np.concatenate([rng.uniform(-0.5, 0.5, nnz), np.zeros(p - nnz)])
+    y = x @ b + rng.normal(size=n) + 0.7
+    return x, y
+
+
+def _cmp(f, r, tol=1e-9):
+    assert abs(f["d"] - r["d"]) <= 1e-8 * abs(r["d"])
+    for k in range(len(r["beta"])):
+        assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-12)
+        assert np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max() <= tol, f["penalty"][k]
+        assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k])).max() <= 1
+
+
+@pytest.mark.parametrize("mode", ["default", "blocks", "recycled", "one_lane"])
+@pytest.mark.parametrize("n,p", [(20011, 37), (3000, 130), (64, 5)])
+def test_host_rows_in_blocks(oa, monkeypatch, mode, n, p):
+    """row blocks (several per call, ragged last one), bounce slots smaller than a column block, two recycled block buffers
+    instead of a resident slice, a single staging lane: all the same fit"""
+    from oem_amd import _lib as L
+    if mode != "default":
+        monkeypatch.setenv("OEMGPU_BLOCK_BYTES", str(8 * p * 1024))          # 1024-row blocks
+        monkeypatch.setenv("OEMGPU_SLOT_BYTES", str(64 * 1024))
+    if mode == "recycled":
+        monkeypatch.setenv("OEMGPU_RESIDENT_BYTES", "1")
+    x, y = _data(n, p, 100 + p)
+    kw = dict(penalty=["lasso", "mcp"], nlambda=12, tol=1e-10)
+    f = oa.oem(x, y, upload_threads=1 if mode == "one_lane" else 3, **kw)
+    st = L.host_stats()
+    r = orc.fit_dense(x, y, **kw)
+    _cmp(f, r)
+    assert st["bytes_staged"] == 8 * (n * p + n) and st["devices"] == 1
+    if mode != "default":
+        assert st["row_blocks"] == (n + 1023) // 1024
+    assert st["resident"] == (0.0 if mode == "recycled" else 1.0)
+
+
+@pytest.mark.parametrize("recycled", [False, True])
+def test_host_shifted_redo(oa, monkeypatch, recycled):
+    """|mean| >> sd: the speculative pass about 0 is redone about the sample mean -- from HBM when the rows stayed resident,
+    by streaming them again when they did not"""
+    from oem_amd import _lib as L
+    monkeypatch.setenv("OEMGPU_BLOCK_BYTES", str(8 * 20 * 2048))
+    if recycled:
+        monkeypatch.setenv("OEMGPU_RESIDENT_BYTES", "1")
+    n, p = 9000, 20
+    x, y = _data(n, p, 7, mean=1e4, sd=1.0)
+    kw = dict(penalty=["lasso"], nlambda=10, tol=1e-10)
+    f = oa.oem(x, y, **kw)
+    st = L.host_stats()
+    r = orc.fit_dense(x, y, **kw)
+    _cmp(f, r, tol=1e-8)
+    assert st["bytes_staged"] == (2 if recycled else 1) * 8 * (n * p + n)
+
+
+@pytest.mark.parametrize("devs", [[0, 0], [0, 0, 0]])
+def test_rows_over_several_devices(oa, devs):
+    """ngpus > 1 inside the library: floor(n / G) rows per device (remainder last), the moment buffers summed in device order on
+    the first.  One GPU per box here, so the devices are the same ordinal several times: two / three contexts, streams, lane
+    sets and accumulators, the peer hand-over degenerating to a device-to-device copy."""
+    from oem_amd import _lib as L
+    n, p = 30011, 45
+    x, y = _data(n, p, 3)
+    kw = dict(penalty=["lasso", "scad", "grp.lasso"], groups=np.arange(p) // 5 + 1, nlambda=10, tol=1e-10)
+    one = oa.oem(x, y, **kw)
+    many = oa.oem(x, y, devices=devs, **kw)
+    st = L.host_stats()
+    assert st["devices"] == len(devs) and st["bytes_staged"] == 8 * (n * p + n)
+    r = orc.fit_dense(x, y, unique_groups=np.unique(kw["groups"]), **kw)
+    _cmp(many, r)
+    for k in range(3):
+        assert np.abs(one["beta"][k] - many["beta"][k]).max() < 1e-11
+    # fewer rows than devices: the first devices get none
+    import warnings
+    xs, ys = np.asfortranarray(x[:2, :3]), y[:2]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tiny = oa.oem(xs, ys, devices=[0, 0, 0], penalty=["lasso"], nlambda=3)
+        tiny1 = oa.oem(xs, ys, penalty=["lasso"], nlambda=3)
+    assert np.all(np.isfinite(tiny["beta"][0])) and np.abs(tiny["beta"][0] - tiny1["beta"][0]).max() < 1e-12
+
+
+def test_rows_over_devices_with_shift(oa):
+    x, y = _data(12000, 30, 11, mean=5e3, sd=1.0)
+    kw = dict(penalty=["lasso", "mcp"], nlambda=8, tol=1e-10)
+    f = oa.oem(x, y, devices=[0, 0], **kw)
+    _cmp(f, orc.fit_dense(x, y, **kw), tol=1e-8)
+
+
+def test_penalties_dealt_to_devices(oa, monkeypatch):
+    """p > 288 (launch-per-iteration engines) and several penalties and several devices: penalty k is solved on device k mod G
+    from a copy of the summed moments (penalties are independent cold starts, ref src/oem_dense.cpp:206-246) -- the same
+    result as all penalties on one device"""
+    n, p = 2500, 300
+    x, y = _data(n, p, 5, sd=1.0)
+    groups = np.arange(p) // 6 + 1
+    lam = [np.geomspace(0.5, 0.01, 6) * s for s in (1.0, 0.9, 1.1)]
+    kw = dict(penalty=["lasso", "grp.lasso", "mcp"], groups=groups, lambda_=lam, tol=1e-9, maxit=2000)
+    split = oa.oem(x, y, devices=[0, 0], **kw)
+    monkeypatch.setenv("OEMGPU_NO_PENALTY_SPLIT", "1")
+    whole = oa.oem(x, y, devices=[0, 0], **kw)
+    r = orc.fit_dense(x, y, unique_groups=np.unique(groups), **kw)
+    _cmp(split, r)
+    for k in range(3):
+        assert np.array_equal(split["beta"][k], whole["beta"][k])
+        assert np.array_equal(split["niter"][k], whole["niter"][k])
+        assert np.array_equal(split["lambda"][k], whole["lambda"][k])
+
+
+@pytest.mark.parametrize("devs", [None, [0, 0]])
+def test_big_oem_host_shards(oa, devs):
+    """oemgpu_fit_big: shards of a big.matrix (ragged, one of a single row), ngpus = 1 and rows over two contexts; the row
+    ranges of the devices cut across the shards"""
+    n, p = 15003, 33
+    x, y = _data(n, p, 9, mean=2.0)
+    cuts = [0, 4000, 4001, 11000, n]
+    xs = [np.asfortranarray(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    ys = [y[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    kw = dict(penalty=["lasso", "mcp", "grp.lasso"], groups=np.arange(p) // 3 + 1, nlambda=10, tol=1e-10)
+    f = oa.big_oem(xs, ys, devices=devs, **kw)
+    g0, ug = np.concatenate([[0], kw["groups"]]), np.unique(np.concatenate([[0], kw["groups"]]))
+    r = orc.fit_big(x, y, **dict(kw, groups=g0, unique_groups=ug))
+    _cmp(f, r)
+
+
+def test_steady_state_allocates_nothing(oa):
+    """contexts, streams, events, pinned slots, block buffers and workspaces come from the process-wide cache: the second call
+    of the same shape makes no hipMalloc / hipHostMalloc / stream / event creation"""
+    from oem_amd import _lib as L
+    x, y = _data(50000, 40, 21)
+    kw = dict(penalty=["lasso"], nlambda=20, tol=1e-10)
+    a = oa.oem(x, y, **kw)
+    b = oa.oem(x, y, **kw)
+    st = L.host_stats()
+    assert st["allocations"] == 0, st
+    assert np.array_equal(a["beta"][0], b["beta"][0])                 # and the fit is bitwise reproducible
+    xs = [np.asfortranarray(x[:20000]), np.asfortranarray(x[20000:])]
+    ys = [y[:20000], y[20000:]]
+    oa.big_oem(xs, ys, **kw)
+    oa.big_oem(xs, ys, **kw)
+    assert L.host_stats()["allocations"] == 0
+    L.lib().oemgpu_release_cache()
+    c = oa.oem(x, y, **kw)
+    assert L.host_stats()["allocations"] > 0                          # rebuilt after the cache was dropped
+    assert np.array_equal(a["beta"][0], c["beta"][0])
+
+
+def test_caller_interrupt(oa, monkeypatch):
+    """opts->interrupt (R: R_CheckUserInterrupt under R_ToplevelExec, ref src/oem_dense.cpp:235-238): polled between row blocks
+    on the calling thread; a non-zero answer ends the call with OEMGPU_ERR_INTERRUPTED after cleanup, and the next call works"""
+    import threading
+    from oem_amd import _lib as L
+    monkeypatch.setenv("OEMGPU_BLOCK_BYTES", str(8 * 25 * 1024))
+    x, y = _data(20000, 25, 2)
+    calls, tids = [], set()
+
+    def stop_on_third():
+        calls.append(1)
+        tids.add(threading.get_ident())
+        return len(calls) >= 3
+    with pytest.raises(oa.OemgpuError) as e:
+        oa.oem(x, y, penalty=["lasso"], nlambda=5, interrupt=stop_on_third, devices=[0, 0])
+    assert e.value.code == L.ERR_INTERRUPTED
+    assert len(calls) == 3 and tids == {threading.get_ident()}       # only ever polled on the calling thread
+    calls.clear()
+    f = oa.oem(x, y, penalty=["lasso"], nlambda=5, interrupt=lambda: False)
+    _cmp(f, orc.fit_dense(x, y, penalty=["lasso"], nlambda=5))
