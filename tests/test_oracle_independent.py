@@ -1,0 +1,219 @@
+"""Every penalty code of the oracle against something that is NOT a restatement of the reference (SURVEY section 8c item 4,
+VERDICT r1 item 6): scikit-learn's coordinate-descent solvers for the convex element-wise penalties (quirk Q14's mapping for
+the elastic net), least squares for "ols", and first-order stationarity (KKT) conditions -- written from the penalty
+definitions, not from the threshold operators -- for MCP / SCAD / their .net forms, all group penalties and the sparse group
+lasso.  The doc KATs of tests/test_oracle_kat.py pin lasso, MCP (gamma = 3) and grp.lasso on reference-held numbers; this
+file covers the rest: SCAD, every *.net, grp.mcp / grp.scad (+ .net), sparse.grp.lasso, `accelerate`, `scale.factor`."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+TIGHT = dict(tol=1e-13, maxit=200000)
+
+
+def _data(n=400, p=24, seed=0, sd=1.0, rho=0.3):
+    rng = np.random.default_rng(seed)
+    z = rng.normal(size=(n, p))
+    x = np.asfortranarray((z + rho * z[:, [0]]) * sd)
+    b = np.zeros(p); b[:6] = [1.5, -1.0, 0.7, 0.0, 0.4, -2.0]; b[12:15] = [0.8, -0.5, 0.3]
+    y = x @ b + rng.normal(size=n)
+    return x, y
+
+
+# ------------------------------------------------------------------ penalty derivatives, from their definitions
+def _dmcp(t, lam, gamma):          # d/dt of MCP(t; lam, gamma), t >= 0 (Zhang 2010): (lam - t / gamma)_+
+    return np.maximum(lam - t / gamma, 0.0)
+
+
+def _dscad(t, lam, gamma):         # d/dt of SCAD(t; lam, gamma), t >= 0 (Fan & Li 2001)
+    return np.where(t <= lam, lam, np.maximum(gamma * lam - t, 0.0) / (gamma - 1.0))
+
+
+def _kkt_elementwise(g, beta, lam_j, dpen, ridge):
+    """max violation of  g_j + ridge * b_j + P'(|b_j|) sign(b_j) = 0  (b_j != 0),  |g_j| <= P'(0+) = lam_j  (b_j == 0)"""
+    nz = beta != 0
+    v = np.zeros_like(beta)
+    v[nz] = np.abs(g[nz] + ridge * beta[nz] + dpen(np.abs(beta[nz]), lam_j[nz]) * np.sign(beta[nz]))
+    v[~nz] = np.maximum(np.abs(g[~nz]) - lam_j[~nz], 0.0)
+    return v.max()
+
+
+def _kkt_group(g, beta, groups, lam_g, dpen, ridge, l1=0.0):
+    """group penalties P(||b_g||): g_g + ridge b_g + P'(||b_g||) b_g / ||b_g|| (+ l1 * subgradient of |.|_1) = 0 for b_g != 0;
+    || S(g_g, l1) || <= P'(0+) = lam_g for b_g == 0.  Group id 0 is unpenalised."""
+    worst = 0.0
+    for gid, lg in lam_g.items():
+        idx = np.where(groups == gid)[0]
+        bg, gg = beta[idx], g[idx]
+        if gid == 0:
+            worst = max(worst, np.abs(gg + ridge * bg).max()); continue
+        nb = np.linalg.norm(bg)
+        if nb > 0:
+            r = gg + ridge * bg + dpen(nb, lg) * bg / nb
+            nzj = bg != 0
+            r[nzj] += l1 * np.sign(bg[nzj])
+            r[~nzj] = np.maximum(np.abs(r[~nzj]) - l1, 0.0)
+            worst = max(worst, np.abs(r).max())
+        else:
+            s = np.sign(gg) * np.maximum(np.abs(gg) - l1, 0.0)
+            worst = max(worst, max(np.linalg.norm(s) - lg, 0.0))
+    return worst
+
+
+# ------------------------------------------------------------------ convex element-wise penalties vs scikit-learn
+@pytest.mark.parametrize("std", [False, True])
+def test_lasso_and_accelerate_against_sklearn(std):
+    from sklearn.linear_model import Lasso
+    x, y = _data(seed=1, sd=2.0)
+    lam = np.array([0.5, 0.2, 0.05, 0.01])
+    xs = x / x.std(0) if std else x
+    for acc in (False, True):
+        f = orc.fit_dense(x, y, penalty=["lasso"], lambda_=lam, standardize=std, intercept=True, accelerate=acc, **TIGHT)
+        for i, l in enumerate(lam):
+            m = Lasso(alpha=l, fit_intercept=True, tol=1e-15, max_iter=1000000).fit(xs, y)
+            coef = m.coef_ / x.std(0) if std else m.coef_
+            assert np.abs(f["beta"][0][1:, i] - coef).max() < 1e-9, (acc, l)
+            assert abs(f["beta"][0][0, i] - (y.mean() - x.mean(0) @ coef)) < 1e-9
+
+
+@pytest.mark.parametrize("alpha", [0.5, 0.9, 0.2])
+def test_elastic_net_against_sklearn_with_the_y_scaled_ridge(alpha):
+    """quirk Q14 (ref src/oem_dense.h:538-541, src/oem_dense.cpp:241): the ridge term lives on the y-scaled problem, so in
+    original units the fit is alpha*lam*|b|_1 + (1/2)(1 - alpha)(lam / sy)*|b|^2"""
+    from sklearn.linear_model import ElasticNet
+    x, y = _data(seed=2)
+    lam = np.array([0.6, 0.1, 0.02])
+    f = orc.fit_dense(x, y, penalty=["elastic.net"], lambda_=lam, alpha=alpha, standardize=False, intercept=True, **TIGHT)
+    sy = np.sqrt(np.mean((y - y.mean()) ** 2))
+    for i, l in enumerate(lam):
+        a_sk = alpha * l + (1 - alpha) * l / sy
+        m = ElasticNet(alpha=a_sk, l1_ratio=alpha * l / a_sk, fit_intercept=True, tol=1e-15, max_iter=1000000).fit(x, y)
+        assert np.abs(f["beta"][0][1:, i] - m.coef_).max() < 1e-9
+        naive = ElasticNet(alpha=l, l1_ratio=alpha, fit_intercept=True, tol=1e-15, max_iter=1000000).fit(x, y)
+        assert np.abs(f["beta"][0][1:, i] - naive.coef_).max() > 1e-4          # and NOT glmnet's parametrisation
+
+
+def test_ols_is_least_squares():
+    x, y = _data(seed=3)
+    f = orc.fit_dense(x, y, penalty=["ols"], standardize=True, intercept=True, **TIGHT)
+    xa = np.column_stack([np.ones(len(y)), x])
+    assert np.abs(np.ravel(f["beta"][0]) - np.linalg.lstsq(xa, y, rcond=None)[0]).max() < 1e-8
+
+
+def test_xtx_scale_factor_is_a_weighted_lasso():
+    """oem.xtx(scale.factor = s) (quirk Q5, ref src/oem_xtx.h:349-356,576-581): the lasso in the variables s_j b_j, i.e. the
+    columns x_j / s_j; its converged fit does not depend on the in-place rescaling of the warm starts"""
+    from sklearn.linear_model import Lasso
+    x, y = _data(seed=4)
+    n, p = x.shape
+    s = np.linspace(0.5, 2.0, p)
+    lam = np.array([0.4, 0.1, 0.03])
+    f = orc.fit_xtx(x.T @ x / n, x.T @ y / n, penalty=["lasso"], lambda_=lam, scale_factor=s, **TIGHT)
+    for i, l in enumerate(lam):
+        m = Lasso(alpha=l, fit_intercept=False, tol=1e-15, max_iter=1000000).fit(x / s, y)
+        assert np.abs(f["beta"][0][:, i] - m.coef_ / s).max() < 1e-9
+
+
+# ------------------------------------------------------------------ stationarity of everything else
+def _grad(x, y, beta):
+    return -x.T @ (y - x @ beta) / len(y)
+
+
+@pytest.mark.parametrize("pen,gamma,alpha", [("mcp", 3.0, 1.0), ("mcp", 1.6, 1.0), ("scad", 4.0, 1.0), ("scad", 2.7, 1.0),
+                                             ("mcp.net", 2.0, 0.6), ("scad.net", 3.7, 0.4), ("elastic.net", 3.0, 0.3),
+                                             ("lasso", 3.0, 1.0)])
+def test_elementwise_penalties_are_stationary(pen, gamma, alpha):
+    x, y = _data(seed=5)
+    p = x.shape[1]
+    pf = np.ones(p); pf[3] = 0.0; pf[7] = 2.5                                  # an unpenalised and a heavily penalised variable
+    lam = np.array([0.5, 0.25, 0.1, 0.04, 0.01])
+    f = orc.fit_dense(x, y, penalty=[pen], lambda_=lam, gamma=gamma, alpha=alpha, penalty_factor=pf, standardize=False,
+                      intercept=False, **TIGHT)
+    net = pen.endswith(".net")
+    for i, l in enumerate(lam):
+        beta = f["beta"][0][1:, i]
+        a = alpha if net else 1.0
+        lj = a * l * pf
+        if pen.startswith("mcp"):
+            dpen = lambda t, lt: _dmcp(t, lt, gamma)
+        elif pen.startswith("scad"):
+            dpen = lambda t, lt: _dscad(t, lt, gamma)
+        else:
+            dpen = lambda t, lt: lt
+        v = _kkt_elementwise(_grad(x, y, beta), beta, lj, dpen, (1 - a) * l if net else 0.0)
+        assert v < 1e-9 * max(1.0, l), (pen, l, v)
+        assert f["niter"][0][i] <= TIGHT["maxit"]
+    assert np.count_nonzero(f["beta"][0][1:, 0]) < np.count_nonzero(f["beta"][0][1:, -1])      # a real path, not all-zero
+
+
+@pytest.mark.parametrize("pen,gamma,alpha", [("grp.lasso", 3.0, 1.0), ("grp.lasso.net", 3.0, 0.5), ("grp.mcp", 3.0, 1.0),
+                                             ("grp.scad", 4.0, 1.0), ("grp.mcp.net", 2.5, 0.7), ("grp.scad.net", 3.7, 0.6)])
+@pytest.mark.parametrize("custom_weights", [False, True])
+def test_group_penalties_are_stationary(pen, gamma, alpha, custom_weights):
+    x, y = _data(seed=6)
+    p = x.shape[1]
+    groups = np.array([0, 0] + list(np.repeat(np.arange(1, 6), 4)) + [6, 6])     # group 0 unpenalised; sizes 4, 4, 4, 4, 4, 2
+    ug = np.unique(groups)
+    gw = np.array([0.0, 1.0, 2.0, 0.5, 1.5, 1.0, 3.0]) if custom_weights else None
+    lam = np.array([0.4, 0.15, 0.05, 0.015])
+    f = orc.fit_dense(x, y, penalty=[pen], lambda_=lam, gamma=gamma, alpha=alpha, groups=groups, unique_groups=ug,
+                      group_weights=gw, standardize=False, intercept=False, **TIGHT)
+    net = pen.endswith(".net")
+    w = {int(g): (gw[k] if custom_weights else np.sqrt(np.sum(groups == g))) for k, g in enumerate(ug)}
+    for i, l in enumerate(lam):
+        beta = f["beta"][0][1:, i]
+        a = alpha if net else 1.0
+        lam_g = {g: a * l * w[g] for g in w}
+        if "mcp" in pen:
+            dpen = lambda t, lt: _dmcp(t, lt, gamma)
+        elif "scad" in pen:
+            dpen = lambda t, lt: _dscad(t, lt, gamma)
+        else:
+            dpen = lambda t, lt: lt
+        v = _kkt_group(_grad(x, y, beta), beta, groups, lam_g, dpen, (1 - a) * l if net else 0.0)
+        assert v < 1e-9 * max(1.0, l), (pen, l, v)
+    assert np.count_nonzero(f["beta"][0][1:, 0]) < np.count_nonzero(f["beta"][0][1:, -1])
+
+
+@pytest.mark.parametrize("tau", [0.5, 0.2, 0.9])
+def test_sparse_group_lasso_is_stationary(tau):
+    """tau * lam * |b|_1 + (1 - tau) * lam * sum_g w_g ||b_g||  (ref src/oem_dense.h:615-628: soft threshold with denominator 1,
+    then the block threshold -- the exact prox of the sum)"""
+    x, y = _data(seed=7)
+    groups = np.repeat(np.arange(1, 7), 4)
+    lam = np.array([0.5, 0.2, 0.06, 0.02])
+    f = orc.fit_dense(x, y, penalty=["sparse.grp.lasso"], lambda_=lam, tau=tau, groups=groups, unique_groups=np.unique(groups),
+                      standardize=False, intercept=False, **TIGHT)
+    for i, l in enumerate(lam):
+        beta = f["beta"][0][1:, i]
+        lam_g = {g: (1 - tau) * l * 2.0 for g in range(1, 7)}
+        v = _kkt_group(_grad(x, y, beta), beta, groups, lam_g, lambda t, lt: lt, 0.0, l1=tau * l)
+        assert v < 1e-9, (l, v)
+    b = f["beta"][0][1:, 2]
+    inside = [np.any(b[groups == g] != 0) and np.any(b[groups == g] == 0) for g in range(1, 7)]
+    assert any(inside)                                                          # sparsity INSIDE an active group: the l1 part acts
+
+
+def test_sparse_fit_is_the_optimum_of_bigs_objective_along_a_path():
+    """the converged sparse-x fit (intercept as a scaled Gram column, rescaled in place every lambda) is the optimum big.oem's
+    formulation reaches, at every lambda of a path -- and that optimum is scikit-learn's lasso on the (n-1)-scaled columns"""
+    import scipy.sparse as sp
+    from sklearn.linear_model import Lasso
+    rng = np.random.default_rng(12)
+    n, p = 3000, 20
+    x = sp.random(n, p, density=0.1, random_state=5, format="csc", data_rvs=lambda k: rng.normal(size=k) * 1.5)
+    b = np.zeros(p); b[:5] = [1, -1, 0.5, 2, -0.7]
+    y = x @ b + rng.normal(size=n) * 0.5 + 0.3
+    xd = np.asfortranarray(x.toarray())
+    lam = np.array([0.3, 0.1, 0.03, 0.01, 0.003])
+    s = orc.fit_sparse(x, y, penalty=["lasso"], lambda_=lam, standardize=True, intercept=True, tol=1e-13, maxit=200000)
+    g = orc.fit_big(xd, y, penalty=["lasso"], lambda_=lam, standardize=True, intercept=True, tol=1e-13, maxit=200000)
+    assert np.abs(s["beta"][0] - g["beta"][0]).max() < 1e-9
+    sc = np.sqrt((xd ** 2).sum(0) / (n - 1))                                    # uncentred (n - 1) scaling (ref src/oem_big.h:757-763)
+    for i, l in enumerate(lam):
+        m = Lasso(alpha=l, fit_intercept=True, tol=1e-15, max_iter=1000000).fit(xd / sc, y)
+        assert np.abs(s["beta"][0][1:, i] - m.coef_ / sc).max() < 1e-8
+        assert abs(s["beta"][0][0, i] - m.intercept_) < 1e-8
