@@ -24,6 +24,14 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+static thread_local int (*g_poll)(void *) = nullptr;
+static thread_local void *g_poll_arg = nullptr;
+bool caller_interrupted() { return g_poll && g_poll(g_poll_arg) != 0; }
+struct PollScope {          // the engines poll the caller's interrupt between batches of iterations, on the calling thread only
+    PollScope(const oemgpu_opts *o) { g_poll = o->interrupt; g_poll_arg = o->interrupt_arg; }
+    ~PollScope() { g_poll = nullptr; g_poll_arg = nullptr; }
+};
+
 }  // namespace oemgpu
 
 using namespace oemgpu;
@@ -276,6 +284,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     if (ctx_pinned(c, back_bytes > 16384 ? back_bytes : 16384)) return OEMGPU_ERR_HIP;
     {
         Timer t(c, OEMGPU_T_EIGPATH);
+        PollScope poll(o);
         int rc = small ? launch_path_small(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned);
         if (rc) return rc;
     }

@@ -127,6 +127,9 @@ int launch_path_small(hipStream_t s, const PathArgs &a);          // p <= SMALL_
 int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch);   // any p: multi-launch engine
 size_t path_large_work_doubles(int p, int nsteps);
 
+// opts->interrupt of the call in progress on this thread (api.hip: run_paths sets it around the engines); false if none
+bool caller_interrupted();
+
 int launch_eig_small(hipStream_t s, const double *a, int p, int steps, double *out /* [d, lambda_max] */);
 
 __host__ __device__ static inline bool pen_is_net(int pen)

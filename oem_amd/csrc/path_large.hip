@@ -925,6 +925,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
             if (hipMemcpyAsync(hdone, fdone, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
                 hipStreamSynchronize(s) != hipSuccess) { set_error("fused engine: device error"); rc = OEMGPU_ERR_HIP; break; }
             if (*hdone) break;
+            if (caller_interrupted()) { set_error("interrupted by the caller"); rc = OEMGPU_ERR_INTERRUPTED; break; }
             if (launched > max_it) { set_error("fused engine did not finish within %lld iterations", max_it); rc = OEMGPU_ERR_INTERNAL; break; }
         }
         if (exec) (void)hipGraphExecDestroy(exec);
@@ -979,6 +980,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
             if (hipMemcpyAsync(hdone, fdone, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
                 hipStreamSynchronize(s) != hipSuccess) { set_error("fused engine: device error"); rc = OEMGPU_ERR_HIP; break; }
             if (*hdone) break;
+            if (caller_interrupted()) { set_error("interrupted by the caller"); rc = OEMGPU_ERR_INTERRUPTED; break; }
             if (launched > max_it) { set_error("fused engine did not finish within %lld iterations", max_it); rc = OEMGPU_ERR_INTERNAL; break; }
         }
         if (exec) (void)hipGraphExecDestroy(exec);
@@ -1024,6 +1026,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         if (hipMemcpyAsync(hdone, &st->done, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess) { set_error("large-p engine: device error"); rc = OEMGPU_ERR_HIP; break; }
         if (*hdone) break;
+        if (caller_interrupted()) { set_error("interrupted by the caller"); rc = OEMGPU_ERR_INTERRUPTED; break; }
         if (launched > max_updates) { set_error("large-p engine did not finish within %lld updates", max_updates); rc = OEMGPU_ERR_INTERNAL; break; }
     }
     if (exec) (void)hipGraphExecDestroy(exec);

@@ -13,6 +13,7 @@
  */
 #include <R.h>
 #include <Rinternals.h>
+#include <Rinterface.h>      /* Rf_onintr */
 #include <string.h>
 
 #include "oemgpu.h"
@@ -20,6 +21,22 @@
 static const char *PENALTIES[OEMGPU_NPENALTIES] = {      /* ref R/oem.R:165-173 */
     "elastic.net", "lasso", "ols", "mcp", "scad", "mcp.net", "scad.net", "grp.lasso", "grp.lasso.net",
     "grp.mcp", "grp.scad", "grp.mcp.net", "grp.scad.net", "sparse.grp.lasso"};
+
+/* User interrupts (ref src/oem_dense.cpp:235-238: Rcpp::checkUserInterrupt() every third lambda).  R_CheckUserInterrupt()
+ * longjmps out of the caller, which would leak whatever the library holds; under R_ToplevelExec the jump is caught, so the
+ * library's callback only learns "an interrupt is pending", unwinds itself (OEMGPU_ERR_INTERRUPTED after releasing every
+ * buffer) and the shim raises the condition once the call has returned.  Polled on the R main thread only. */
+static void shim_check_interrupt(void *unused) { (void)unused; R_CheckUserInterrupt(); }
+static int shim_interrupted(void *unused) { (void)unused; return R_ToplevelExec(shim_check_interrupt, NULL) == FALSE; }
+
+/* opts$name or R_NilValue (ngpus / devices are additions of this binding: absent => one GPU) */
+static SEXP list_opt(SEXP list, const char *name)
+{
+    SEXP names = Rf_getAttrib(list, R_NamesSymbol);
+    for (R_xlen_t i = 0; i < XLENGTH(list); i++)
+        if (strcmp(CHAR(STRING_ELT(names, i)), name) == 0) return VECTOR_ELT(list, i);
+    return R_NilValue;
+}
 
 static SEXP list_elt(SEXP list, const char *name)
 {
@@ -65,6 +82,25 @@ static void fill_opts(oemgpu_opts *o, SEXP penalty_, SEXP groups_, SEXP unique_g
     o->unique_groups = XLENGTH(unique_groups_) ? INTEGER(unique_groups_) : NULL;   o->ngroups = (int32_t)XLENGTH(unique_groups_);
     o->group_weights = XLENGTH(group_weights_) ? REAL(group_weights_) : NULL;      o->n_group_weights = (int32_t)XLENGTH(group_weights_);
     o->device = -1;
+    o->interrupt = shim_interrupted;
+    {                                            /* options(oem.ngpus = G) style additions, passed through opts */
+        SEXP g = list_opt(opts_, "ngpus"), dv = list_opt(opts_, "devices");
+        if (g != R_NilValue) o->ngpus = Rf_asInteger(g);
+        if (dv != R_NilValue && XLENGTH(dv) > 0) {
+            SEXP di = PROTECT(Rf_coerceVector(dv, INTSXP));
+            int32_t *d = (int32_t *)R_alloc(XLENGTH(di), sizeof(int32_t));
+            for (R_xlen_t i = 0; i < XLENGTH(di); i++) d[i] = INTEGER(di)[i];
+            o->devices = d; o->ngpus = (int32_t)XLENGTH(di);
+            UNPROTECT(1);
+        }
+    }
+}
+
+/* non-zero return of the library -> R condition (the library has already released what it held) */
+static void raise(int rc)
+{
+    if (rc == OEMGPU_ERR_INTERRUPTED) Rf_onintr();        /* the user's interrupt, re-raised outside the library */
+    Rf_error("%s", oemgpu_last_error());
 }
 
 /* List(beta = list(...), lambda = list(...), niter = list(...), loss = list(...), d = d)  (ref src/oem_dense.cpp:280-307) */
@@ -114,7 +150,7 @@ SEXP oem_fit_dense(SEXP x_, SEXP y_, SEXP family_, SEXP penalty_, SEXP weights_,
     /* x and y are read-only for the library: no copy (the reference copies, ref src/oem_dense.cpp:61-67) */
     const int rc = oemgpu_fit_dense(REAL(x_), n, p, REAL(y_), Rf_asLogical(standardize_), Rf_asLogical(intercept_), &o,
                                     beta, lam, niter, loss, &d);
-    if (rc != 0) Rf_error("%s", oemgpu_last_error());      /* device memory is already released inside the library */
+    if (rc != 0) raise(rc);
     return pack(&o, p + 1, nl, beta, lam, niter, loss, d);
 }
 
@@ -135,16 +171,37 @@ SEXP oem_xtx(SEXP xtx_, SEXP xty_, SEXP family_, SEXP penalty_, SEXP groups_, SE
     int32_t *niter = (int32_t *)R_alloc(nk, sizeof(int32_t));
     const int rc = oemgpu_fit_xtx(REAL(xtx_), REAL(xty_), p, XLENGTH(scale_factor_) ? REAL(scale_factor_) : NULL, &o,
                                   beta, lam, niter, loss, &d);
-    if (rc != 0) Rf_error("%s", oemgpu_last_error());
+    if (rc != 0) raise(rc);
     return pack(&o, p, nl, beta, lam, niter, loss, d);
 }
 
-/* oem_fit_big / oem_fit_fb_big (ref src/oem_big.cpp:30, src/oem_fb_big.cpp:30): identical except that x_ is the
- * big.matrix external pointer; with bigmemory's headers, in a C++ TU:
- *     Rcpp::XPtr<BigMatrix> bm(x_);  const double *x = (const double *)bm->matrix();   // type 8 = double only (ref :57-62)
- *     const double *xs[1] = {x}, *ys[1] = {REAL(y_)};  int64_t ns[1] = {bm->nrow()};
- *     oemgpu_fit_big(xs, ns, 1, bm->ncol(), ys, standardize, intercept, &o, beta, lam, niter, loss, &d);
- * groups_ arrives with its leading 0 for the intercept (ref R/big_oem.R:254-257) and is passed through unchanged. */
+/* oem_fit_big / oem_fit_fb_big (ref src/oem_big.cpp:30, src/oem_fb_big.cpp:30): x_ is the big.matrix external pointer, a C++
+ * object of the bigmemory package -- r/oem_shim_big.cpp (a C++ TU against bigmemory's BigMatrix.h, as the reference's own
+ * LinkingTo) unwraps it and calls oem_shim_fit_big below with the plain column-major buffer. */
+SEXP oem_shim_fit_big(const double *x, int64_t n, int p, SEXP y_, SEXP family_, SEXP penalty_, SEXP weights_, SEXP groups_,
+                      SEXP unique_groups_, SEXP group_weights_, SEXP lambda_, SEXP nlambda_, SEXP lmin_ratio_, SEXP alpha_,
+                      SEXP gamma_, SEXP tau_, SEXP penalty_factor_, SEXP standardize_, SEXP intercept_, SEXP compute_loss_, SEXP opts_)
+{
+    if (strcmp(CHAR(STRING_ELT(family_, 0)), "gaussian") != 0)
+        Rf_error("binomial not available for oem_fit_big");                                   /* ref src/oem_big.cpp:152 */
+    if (XLENGTH(weights_) > 0) Rf_error("weights not implemented yet.");
+    oemgpu_opts o;
+    /* groups_ arrives with its leading 0 for the intercept (ref R/big_oem.R:254-257) and is passed through unchanged;
+     * opts$gigs (the reference's row-slice size, ref src/oem_big.h:738-741) has no meaning here: the library cuts its own
+     * row blocks (oem_amd/csrc/hoststream.hip) */
+    fill_opts(&o, penalty_, groups_, unique_groups_, group_weights_, lambda_, nlambda_, lmin_ratio_, alpha_, gamma_, tau_,
+              penalty_factor_, compute_loss_, opts_, 0);
+    const int nl = o.nlambda_user > 0 ? o.nlambda_user : o.nlambda;
+    const size_t nk = (size_t)o.npen * nl;
+    double *beta = (double *)R_alloc(nk * (p + 1), sizeof(double)), *lam = (double *)R_alloc(nk, sizeof(double));
+    double *loss = (double *)R_alloc(nk, sizeof(double)), d = 0.0;
+    int32_t *niter = (int32_t *)R_alloc(nk, sizeof(int32_t));
+    const double *xs[1] = {x}, *ys[1] = {REAL(y_)};
+    const int64_t ns[1] = {n};
+    const int rc = oemgpu_fit_big(xs, ns, 1, p, ys, Rf_asLogical(standardize_), Rf_asLogical(intercept_), &o, beta, lam, niter, loss, &d);
+    if (rc != 0) raise(rc);
+    return pack(&o, p + 1, nl, beta, lam, niter, loss, d);
+}
 
 /* oem_xval_dense (ref src/oem_xval_dense.cpp:31-52, called from R/oem_xval.R:497-521): the list of oem_fit_dense plus cvm and cvsd
  * (ref :470-478).  R/oem_xval.R computes lambda.min, lambda.1se, model.min, cvup, cvlo, nzero from it, unchanged. */
@@ -171,7 +228,7 @@ SEXP oem_xval_dense(SEXP x_, SEXP y_, SEXP family_, SEXP penalty_, SEXP weights_
     const int mae = strcmp(CHAR(STRING_ELT(type_measure_, 0)), "mae") == 0;                    /* ref :378-411 */
     const int rc = oemgpu_xval_dense(REAL(x_), n, p, REAL(y_), INTEGER(foldid_), Rf_asInteger(nfolds_), Rf_asLogical(standardize_),
                                      Rf_asLogical(intercept_), mae, &o, beta, lam, niter, loss, &d, cvm, cvsd);
-    if (rc != 0) Rf_error("%s", oemgpu_last_error());
+    if (rc != 0) raise(rc);
     SEXP base = PROTECT(pack(&o, p + 1, nl, beta, lam, niter, loss, d));
     /* beta, lambda, niter, loss, cvm, cvsd, d */
     SEXP res = PROTECT(Rf_allocVector(VECSXP, 7)), names = PROTECT(Rf_allocVector(STRSXP, 7));
@@ -215,6 +272,6 @@ SEXP oem_fit_sparse(SEXP x_, SEXP y_, SEXP family_, SEXP penalty_, SEXP weights_
     int32_t *niter = (int32_t *)R_alloc(nk, sizeof(int32_t));
     const int rc = oemgpu_fit_sparse(n, p, colptr, INTEGER(ii), REAL(xv), REAL(y_), Rf_asLogical(standardize_),
                                      Rf_asLogical(intercept_), &o, beta, lam, niter, loss, &d);
-    if (rc != 0) Rf_error("%s", oemgpu_last_error());
+    if (rc != 0) raise(rc);
     return pack(&o, p + 1, nl, beta, lam, niter, loss, d);
 }

@@ -22,6 +22,7 @@ def oa():
 def _data(n, p, seed, mean=0.0, sd=2.0, nnz=8):
     rng = np.random.default_rng(seed)
     x = np.asfortranarray(rng.normal(size=(n, p)) * sd + mean)
+    nnz = min(nnz, p)
     b = np.concatenate([rng.uniform(-0.5, 0.5, nnz), np.zeros(p - nnz)])
     y = x @ b + rng.normal(size=n) + 0.7
     return x, y
