@@ -34,6 +34,103 @@ FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix peak (AMD spec; 32 FLOP/cl
 README_SECONDS = 1.600241        # reference README.md:73, oem[lasso] mean over 5 runs, hardware unstated
 
 
+def c5_weak(torch, dist, world, rank, dev, backend, rows, steps, warmup):
+    """BASELINE.json config 5 as its per-GPU share: big.oem() lasso, 100 lambdas, p = 256, `rows` rows on EVERY rank (weak
+    scaling: n = world * rows), X ~ N(0,1) generated on the device, one all-reduce of the (p+2)^2 moment buffer."""
+    import numpy as np
+    from oem_amd import _lib as L
+    from oem_amd import api
+    from oem_amd.distributed import sharded_buffers, solve_row_shards
+    p, m = 256, 25
+    g = torch.Generator(device=dev); g.manual_seed(4242)
+    b = torch.cat([torch.rand(m, generator=g, device=dev, dtype=torch.float64), torch.zeros(p - m, device=dev, dtype=torch.float64)])
+    g.manual_seed(5000 + rank)
+    xt = torch.empty((p, rows), device=dev, dtype=torch.float64)
+    for j0 in range(0, p, 32):                                         # 32 columns at a time: no second 25.6 GB temporary
+        xt[j0:j0 + 32].normal_(generator=g)
+    x = xt.t()
+    y = torch.randn(rows, generator=g, device=dev, dtype=torch.float64)
+    for j0 in range(0, m, 5):
+        y += x[:, j0:j0 + 5] @ b[j0:j0 + 5]
+    torch.cuda.synchronize()
+    q = p + 1
+    args = api._Args(["lasso"], [], 100, 1e-4, 1.0, 3.0, 0.5, 1e-7, 500, False, False, np.ones(p),
+                     np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    bufs = sharded_buffers(backend, p)
+    outs = args.outputs(q)
+    dd = dist if world > 1 else None
+
+    def solve():
+        solve_row_shards(backend, dd, None, x, rows, rows, p, y, bufs, L.OEMGPU_SEM_BIG, True, True, args, outs)
+    with backend.section():
+        for _ in range(warmup):
+            solve()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with backend.section():
+        for _ in range(steps):
+            solve()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    lib = L.lib()
+    L.check(lib.oemgpu_set_timing(backend.ctx, 1))
+    acc = np.zeros(L.NTIMERS)
+    ms = (C.c_double * L.NTIMERS)()
+    with backend.section():
+        for _ in range(5):
+            solve()
+            L.check(lib.oemgpu_last_timings(backend.ctx, ms))
+            acc += np.array(list(ms))
+    L.check(lib.oemgpu_set_timing(backend.ctx, 0))
+    acc /= 5
+    flops = float(rows) * p * (p + 1) + 2.0 * rows * p
+    nit = int(np.sum(args.niter))
+    del x, xt, y
+    torch.cuda.empty_cache()
+    return {"workload": "config 5 share: big.oem() lasso, p=256, 100 lambdas, tol 1e-7 (default), %d rows per GPU, n = %d" % (rows, rows * world),
+            "value": steps / dt, "unit": "solves/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "scaling": "weak",
+            "rows_per_gpu": rows, "n_total": rows * world, "rows_per_second": rows * world * steps / dt,
+            "stage_ms": {"moments_total": acc[L.T_MOMENTS], "gram_kernel": acc[L.T_GRAMK], "finalize": acc[L.T_FINAL],
+                         "eigen_plus_path": acc[L.T_EIGPATH]},
+            "gram_TFLOPs": flops / (acc[L.T_GRAMK] * 1e-3) / 1e12 if acc[L.T_GRAMK] > 0 else None,
+            "gram_frac_of_fp64_mfma_peak": flops / (acc[L.T_GRAMK] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if acc[L.T_GRAMK] > 0 else None,
+            "oem_iterations_per_solve": nit}
+
+
+def host_resident(xh, yh, args, p, calls=5):
+    """The drop-in level: oemgpu_fit_dense on PAGEABLE host x / y, exactly what `.Call("oem_fit_dense")` hands over
+    (staged upload through pinned lanes + moments + solve; contexts and buffers cached by the library).  Never `value`."""
+    import numpy as np
+    from oem_amd import _lib as L
+    from oem_amd import api
+    lib = L.lib()
+    n = xh.shape[0]
+    outs = args.outputs(p + 1)
+    ts, st = [], None
+    for k in range(calls + 1):
+        t0 = time.perf_counter()
+        L.check(lib.oemgpu_fit_dense(api._dptr(xh), n, p, api._dptr(yh), 0, 1, C.byref(args.c), *outs))
+        ts.append(1e3 * (time.perf_counter() - t0))
+        st = L.host_stats()
+    first, ts = ts[0], ts[1:]
+    gb = 8.0 * (n * p + n) / 1e9
+    return {"what": "oemgpu_fit_dense(host x, host y): pageable rows -> pinned bounce slots -> HBM, MFMA moments per row block, solve",
+            "first_call_ms": first, "min_ms": float(np.min(ts)), "median_ms": float(np.median(ts)), "calls": calls,
+            "GBps_at_median": gb / (float(np.median(ts)) * 1e-3), "upload_threads": 8,
+            "steady_state_allocations": st["allocations"], "row_blocks": st["row_blocks"],
+            "upload_plus_moments_ms": st["upload_moments_ms"], "solve_ms": st["solve_ms"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -41,6 +138,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--p", type=int, default=100)
+    ap.add_argument("--workload", choices=["c1", "c5"], default="c1",
+                    help="c1: BASELINE.json config 1, n fixed (strong scaling; the headline).  c5: config 5's per-GPU share, "
+                         "1.25e7 x 256 rows PER RANK, big.oem semantics (weak scaling)")
+    ap.add_argument("--no-c5", action="store_true", help="c1 run: skip the appended c5 weak-scaling measurement")
+    ap.add_argument("--c5-rows", type=int, default=12_500_000, help="rows per rank of the c5 workload")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-resident (drop-in .Call level) measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU baseline sample (0 = the full workload)")
     a = ap.parse_args()
@@ -69,6 +172,24 @@ def main():
     from oem_amd import _lib as L
     from oem_amd import api
     from oem_amd.distributed import HipBackend, oem_sharded, row_partition, sharded_buffers, solve_row_shards
+
+    if a.workload == "c5":
+        backend = HipBackend(local)
+        steps = a.steps if a.steps != 200 else 10
+        warm = a.warmup if a.warmup != 10 else 2
+        r = c5_weak(torch, dist, world, rank, dev, backend, a.c5_rows, steps, warm)
+        if rank == 0:
+            print(json.dumps({"metric": "full-lambda-path solves/sec (config 5 share: big.oem lasso, 1.25e7 x 256 rows per GPU)",
+                              "value": r["value"], "unit": "solves/s", "n_gpus": world, "steps": steps, "warmup": warm,
+                              "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "f64", "data": "synthetic", "config": {"workload": r["workload"], "rows_per_gpu": r["rows_per_gpu"]},
+                              "roofline": {"bound": "mfma", "kernel": "gram_sb_kernel (v_mfma_f64_16x16x4_f64)", "achieved": r["gram_TFLOPs"],
+                                           "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r["gram_frac_of_fp64_mfma_peak"],
+                                           "traffic": None},
+                              "detail": r}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     n, p, m = a.n, a.p, 25
     lo, hi = row_partition(n, world)[rank]
@@ -165,10 +286,11 @@ def main():
     # separate rocprofv3 --pmc passes of this same command measured (tools/round_artifacts.sh -> profiles/),
     # FETCH_SIZE x2 + WRITE_SIZE as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950; null if it does not apply.
     traffic, traffic_src = None, None
-    pmc = ROOT / "profiles" / "r1_pmc_gram.json"
-    if pmc.exists() and n == 1_000_000 and p == 100 and world == 1:
-        traffic = float(json.loads(pmc.read_text())["hbm_bytes_per_dispatch"])
-        traffic_src = "profiles/r1_pmc_gram.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+    pmcs = sorted((ROOT / "profiles").glob("r*_pmc_gram.json"))
+    if pmcs and n == 1_000_000 and p == 100 and world == 1:
+        traffic = float(json.loads(pmcs[-1].read_text())["hbm_bytes_per_dispatch"])
+        traffic_src = ("CONSTANT, not measured in this run: profiles/%s (the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                       "command, tools/round_artifacts.sh); counters cannot be read from inside the process" % pmcs[-1].name)
 
     out = None
     if rank == 0:
@@ -195,22 +317,50 @@ def main():
                          "python_front_end_total": 1e3 * dt_py},
             "path_kernel_clock_GHz": (acc[6] / acc[7] * 0.1) if acc[7] > 0 else None,
             "path_kernel_cycles": acc[6],
+            "path_kernel_cycles_per_oem_iteration": acc[6] / niter_total if niter_total > 0 else None,
+            "path_kernel_note": "eigenvalue (Lanczos) + 100-lambda path in ONE launch; cycles include the eigen step's fixed cost",
             "vs_baseline_note": "reference README: 1.600 s per solve on unstated CPU hardware",
         }
+    xh_full = yh_full = None
+    if rank == 0 and world == 1 and not (a.no_host and a.no_cpu_baseline):
+        xh_full = x.cpu().numpy()                  # (n, p) with strides (8, 8n): column-major, as R holds it
+        yh_full = y.cpu().numpy()
+        assert xh_full.flags.f_contiguous
+    if rank == 0 and world == 1 and not a.no_host:
+        # what the drop-in .Call delivers: the same solve from pageable host memory (never `value`)
+        out["host_resident_ms"] = {"c1": host_resident(xh_full, yh_full, args, p)}
+    # every rank takes part in the appended weak-scaling measurement (it has a collective)
+    if not a.no_c5 and n == 1_000_000 and p == 100:
+        try:
+            del x, xt
+            torch.cuda.empty_cache()
+            r5 = c5_weak(torch, dist, world, rank, dev, backend, a.c5_rows, 10, 2)
+            if rank == 0:
+                out["c5_weak"] = r5
+        except Exception as e:          # e.g. not enough free HBM on a shared device: the headline line must still print
+            if rank == 0:
+                out["c5_weak"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         # CPU baseline: the C restatement of the reference path (oracle/, -O3 -march=native build), 1 thread = the
         # reference's effective default (R/oem.R:270-273), on a bounded sample of the same workload.
         from oracle import oracle as orc
         rows = n if a.cpu_rows <= 0 else min(n, a.cpu_rows)
-        xh = np.asfortranarray(x[:rows].cpu().numpy())
-        yh = y[:rows].cpu().numpy()
+        xh = np.asfortranarray(xh_full[:rows])
+        yh = yh_full[:rows]
+        orc.lib(True)                              # builds the -march=native oracle ON THIS HOST if it was compiled elsewhere
         t0 = time.perf_counter()
         ref = orc.fit_dense(xh, yh, native=True, lambda_=lambdas, tol=1e-10, **kw)
         tc = time.perf_counter() - t0
+        sample = f"{rows} of {n} rows, 1 solve (value scaled by rows/n)" if rows != n else "the full workload, 1 solve"
         out["cpu_baseline"] = {"value": 1.0 / tc * (rows / n), "unit": "solves/s", "cores": 1, "kind": "port",
-                               "seconds": tc, "sample": f"{rows} of {n} rows, 1 solve (value scaled by rows/n)"
-                               if rows != n else "the full workload, 1 solve",
+                               "seconds": tc, "sample": sample, "flags": "-O3 -march=native (compiled on this host)",
                                "host_cpus": os.cpu_count()}
+        # R's default flags (-O2, no -march; ref src/Makevars:9-12): what an installed reference package is built with
+        t0 = time.perf_counter()
+        orc.fit_dense(xh, yh, native=False, lambda_=lambdas, tol=1e-10, **kw)
+        tc2 = time.perf_counter() - t0
+        out["cpu_baseline_O2"] = {"value": 1.0 / tc2 * (rows / n), "unit": "solves/s", "cores": 1, "kind": "port", "seconds": tc2,
+                                  "sample": sample, "flags": "-O2 (R's default build flags)"}
         if rows == n:
             out["max_abs_beta_err_vs_cpu"] = float(np.abs(fit["beta"][0] - ref["beta"][0]).max())
             out["niter_equal_cpu"] = bool(np.array_equal(fit["niter"][0], ref["niter"][0]))

@@ -46,10 +46,39 @@ def build(force=False):
 _libs = {}
 
 
+def _host_cpu():
+    """model name + ISA flags of this host: the -march=native build is only valid (and only a fair timing) on the CPU it
+    was compiled on, and oracle/_build/ travels to the GPU box prebuilt"""
+    import hashlib
+    try:
+        txt = open("/proc/cpuinfo").read()
+    except OSError:
+        return "unknown"
+    keep = sorted({l.split(":", 1)[1].strip() for l in txt.splitlines() if l.startswith(("model name", "flags"))})
+    return hashlib.sha1("|".join(keep).encode()).hexdigest()
+
+
+def build_native():
+    """(re)build liboem_oracle_native.so when it was compiled on another CPU (build it on the box it is timed on)"""
+    out = _HERE / "_build" / "liboem_oracle_native.so"
+    stamp = _HERE / "_build" / "native.cpu"
+    src = _HERE / "oem_oracle.c"
+    cpu = _host_cpu()
+    if out.exists() and stamp.exists() and stamp.read_text() == cpu and out.stat().st_mtime >= src.stat().st_mtime:
+        return out
+    (_HERE / "_build").mkdir(exist_ok=True)
+    subprocess.run(["gcc", "-O2", "-fPIC", "-std=gnu99", "-fopenmp", "-O3", "-march=native", "-ffp-contract=off", "-shared",
+                    "-o", str(out), str(src), "-lm"], check=True)
+    stamp.write_text(cpu)
+    return out
+
+
 def lib(native=False):
     key = bool(native)
     if key not in _libs:
         build()
+        if native:
+            build_native()
         name = "liboem_oracle_native.so" if native else "liboem_oracle.so"
         L = C.CDLL(str(_HERE / "_build" / name))
         L.orc_last_error.restype = C.c_char_p

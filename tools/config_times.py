@@ -74,6 +74,7 @@ kw = dict(penalty="lasso", nlambda=100, tol=1e-10)
 t_gpu = timeit(lambda: oem_amd.oem_xtx(xtxd, xty, **kw), 1)
 fit = oem_amd.oem_xtx(xtxd, xty, **kw)
 its = int(fit["niter"][0].sum())
+its_c4, fit_c4_lambda = its, fit["lambda"][0]
 out["config4_xtx_p4096"] = {"gpu_ms": 1e3 * t_gpu, "iterations": its, "gemv_bytes_per_iteration": 8.0 * p * p + 24 * p,
                             "note": "includes ~100+ Lanczos GEMVs; per-iteration = one 134 MB GEMV + one update kernel",
                             "approx_GBps_over_all_gemvs": (its + 130) * (8.0 * p * p) / t_gpu / 1e9}
@@ -112,7 +113,14 @@ n, p = 1_000_000, 100
 x = np.asfortranarray(rng.normal(size=(n, p)) * 3.0); b = np.concatenate([rng.uniform(size=25), np.zeros(75)]); y = x @ b + rng.normal(size=n)
 kw = dict(penalty="elastic.net", standardize=False, tol=1e-10)
 t = timeit(lambda: oem_amd.oem(x, y, **kw), 2)
-out["config1_host_resident"] = {"ms": 1e3 * t, "note": "800 MB pageable host->device copy + hipMalloc/hipFree per call"}
+from oem_amd import _lib as L_
+out["config1_host_resident"] = {"ms": 1e3 * t, "stats_last_call": L_.host_stats(),
+                                "note": "oemgpu_fit_dense on pageable host x: 8 staging lanes -> pinned slots -> HBM, block moments, solve; cached contexts"}
+for thr in (1, 2, 4, 8, 16):
+    tt = timeit(lambda: oem_amd.oem(x, y, upload_threads=thr, **kw), 2)
+    out["config1_host_resident"][f"ms_with_{thr}_lanes"] = 1e3 * tt
+tt = timeit(lambda: oem_amd.oem(x, y, devices=[0, 0], **kw), 2)
+out["config1_host_resident"]["ms_rows_over_two_contexts_of_one_device"] = 1e3 * tt
 
 # next rows: xval.oem (f-1) on the same device-resident data, and oem() with p >= n (f-3)
 xd = dev(x)
@@ -135,4 +143,46 @@ t = timeit(lambda: oem_amd.oem(xw, yw, **kw), 2)
 t0 = time.perf_counter(); orc.fit_dense(xw, yw, lambda_min_ratio=0.01, native=True, **kw); t_cpu = time.perf_counter() - t0
 out["wide_n500_p2000_lasso"] = {"gpu_ms": 1e3 * t, "cpu_port_1thread_ms": 1e3 * t_cpu,
                                 "note": "p >= n: the reference iterates through X twice; the library runs the Gram form"}
+
+# ---- CPU baselines for configs 3, 4, 5 (the oracle = the C restatement of the reference path, 1 thread = the reference's effective
+# default; -O3 -march=native built on this host).  The Gram pass is linear in n and the path does not depend on n, so configs 3 and 5
+# are timed at two sub-sampled n and extrapolated linearly, t(n) = a + b n; both points are reported.
+orc.lib(True)
+def cpu_two_points(make, fit, n_small, n_big, n_full):
+    ts = []
+    for nn in (n_small, n_big):
+        xs, ys = make(nn)
+        t0 = time.perf_counter(); fit(xs, ys); ts.append(time.perf_counter() - t0)
+    b_ = (ts[1] - ts[0]) / (n_big - n_small); a_ = ts[0] - b_ * n_small
+    return {"rows": [n_small, n_big], "seconds": ts, "extrapolated_full_seconds": a_ + b_ * n_full, "n_full": n_full,
+            "model": "t(n) = a + b n through the two points", "threads": 1}
+r3 = np.random.default_rng(33)
+def make3(nn):
+    xs = np.asfortranarray(r3.normal(size=(nn, 512))); bb_ = np.zeros(512); bb_[:24] = r3.uniform(-0.5, 0.5, 24)
+    return xs, xs @ bb_ + r3.normal(size=nn)
+g3 = np.repeat(np.arange(1, 65), 8)
+out["config3_cpu_port"] = cpu_two_points(make3, lambda xs, ys: orc.fit_dense(xs, ys, native=True, penalty=["grp.lasso"], groups=g3, unique_groups=np.unique(g3),
+                                                                            nlambda=100, tol=1e-10, standardize=False, intercept=False), 20000, 40000, 1_000_000)
+def make5(nn):
+    xs = np.asfortranarray(r3.normal(size=(nn, 256))); bb_ = np.zeros(256); bb_[:20] = r3.uniform(0, 1, 20)
+    return xs, xs @ bb_ + r3.normal(size=nn)
+out["config5_cpu_port"] = cpu_two_points(make5, lambda xs, ys: orc.fit_big(xs, ys, native=True, penalty=["lasso"], nlambda=100, tol=1e-7), 40000, 80000, 100_000_000)
+# config 4: the path is the whole cost and each iteration is one dense 4096 x 4096 GEMV: time the first 12 lambdas of the 100-lambda grid
+# and scale by the iteration counts the GPU fit reports for the full path
+lam12 = np.asarray(fit_c4_lambda)[:12]
+t0 = time.perf_counter(); r4 = orc.fit_xtx(xtx, xty, native=True, penalty=["lasso"], lambda_=lam12, tol=1e-10); t4 = time.perf_counter() - t0
+it12 = int(np.sum(r4["niter"][0]))
+out["config4_cpu_port"] = {"seconds_first_12_lambdas": t4, "iterations_first_12_lambdas": it12, "ms_per_iteration": 1e3 * t4 / max(it12, 1),
+                           "iterations_full_path": its_c4, "extrapolated_full_seconds": t4 / max(it12, 1) * its_c4, "threads": 1,
+                           "model": "ms per iteration (one 134 MB GEMV + threshold) x the full path's iteration count"}
+
+# ---- config 5's per-GPU share from HOST memory (oemgpu_fit_big, one device): a 2e6 x 256 sample (4.1 GB) of the 1.25e7 x 256 share (25.6 GB)
+n5 = 2_000_000
+x5, y5 = make5(n5)
+kw5 = dict(penalty="lasso", nlambda=100, tol=1e-7)
+t5 = timeit(lambda: oem_amd.big_oem(x5, y5, **kw5), 2)
+st5 = L_.host_stats()
+out["config5_share_host_resident"] = {"rows": n5, "ms": 1e3 * t5, "GBps": 8.0 * n5 * 257 / t5 / 1e9, "stats_last_call": st5,
+                                      "extrapolated_ms_for_1.25e7_rows": 1e3 * t5 * 12_500_000 / n5,
+                                      "note": "upload-bound: linear in rows; at 8 GPUs each device streams its own share over its own PCIe link"}
 print(json.dumps(out, indent=1))

@@ -1,22 +1,43 @@
 #!/bin/bash
 # Round artefacts on the GPU box: kernel-trace stats, PMC traffic passes (separate runs), config times, bench line.
-# usage: bash tools/round_artifacts.sh r1     (writes under gpurun_out/<tag>_*)
+# usage: bash tools/round_artifacts.sh r2 [quick]     (writes under gpurun_out/<tag>_*; copy what is to be judged into profiles/)
 set -u
-tag=${1:-r1}
+tag=${1:-r2}
+quick=${2:-}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 o=gpurun_out
 mkdir -p $o
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_trace -o ${tag} -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline > $o/${tag}_trace_bench.json 2> $o/${tag}_trace.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_fetch -o ${tag} -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $o/${tag}_pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_write -o ${tag} -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $o/${tag}_pmc_write.err
+B="--no-cpu-baseline --no-c5 --no-host"
+# ---- config 1 (the bench command): per-kernel stats, then FETCH_SIZE / WRITE_SIZE in their own passes
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_trace -o ${tag} -- python3 bench.py --steps 100 --warmup 10 $B > $o/${tag}_trace_bench.json 2> $o/${tag}_trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_fetch -o ${tag} -- python3 bench.py --steps 5 --warmup 2 $B > /dev/null 2> $o/${tag}_pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_write -o ${tag} -- python3 bench.py --steps 5 --warmup 2 $B > /dev/null 2> $o/${tag}_pmc_write.err
 f=$(find $o/${tag}_pmc_fetch -name "*counter_collection.csv" | head -1)
 w=$(find $o/${tag}_pmc_write -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_summary.py gram_ring_kernel $o/${tag}_pmc_gram.json "$f" "$w"
 s=$(find $o/${tag}_trace -name "*kernel_stats.csv" | head -1)
 cp "$s" $o/${tag}_kernel_stats.csv
-python3 tools/config_times.py > $o/${tag}_config_times.json 2> $o/${tag}_config_times.err
+if [ -z "$quick" ]; then
+  # ---- configs 3 and 5 (the shared-slab Gram kernel) and config 4 (the fused GEMV iteration): stats + traffic
+  for cfg in c3 c5; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_${cfg}_trace -o ${tag} -- python3 tools/run_c3.py $cfg 3 > $o/${tag}_${cfg}_trace.log 2>&1
+    cp "$(find $o/${tag}_${cfg}_trace -name '*kernel_stats.csv' | head -1)" $o/${tag}_${cfg}_kernel_stats.csv
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/${tag}_${cfg}_pmc_$c -o ${tag} -- python3 tools/run_c3.py $cfg 2 > /dev/null 2> $o/${tag}_${cfg}_pmc_$c.err
+    done
+    python3 tools/pmc_summary.py gram_sb_kernel $o/${tag}_${cfg}_pmc_gram_sb.json "$(find $o/${tag}_${cfg}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_${cfg}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
+  done
+  rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_c4_trace -o ${tag} -- python3 tools/run_c4.py > $o/${tag}_c4_trace.log 2>&1
+  cp "$(find $o/${tag}_c4_trace -name '*kernel_stats.csv' | head -1)" $o/${tag}_c4_kernel_stats.csv
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/${tag}_c4_pmc_$c -o ${tag} -- python3 tools/run_c4.py > /dev/null 2> $o/${tag}_c4_pmc_$c.err
+  done
+  python3 tools/pmc_summary.py oem_fused_kernel $o/${tag}_c4_pmc_fused.json "$(find $o/${tag}_c4_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_c4_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
+  python3 tools/config_times.py > $o/${tag}_config_times.json 2> $o/${tag}_config_times.err
+fi
 python3 bench.py > $o/${tag}_bench.json 2> $o/${tag}_bench.err
 tail -c 300 $o/${tag}_bench.err
 head -c 1500 $o/${tag}_kernel_stats.csv
-cat $o/${tag}_config_times.json | head -c 2500
+[ -z "$quick" ] && head -c 4000 $o/${tag}_config_times.json
+exit 0
