@@ -34,7 +34,7 @@ namespace {
 // -DOEM_PATH_DIAG: a diagnostic build that splits the round into stamped segments (cycles summed per wave 0).
 // Its fences forbid overlaps the real kernel has: read the SHARES, never the total.
 #ifdef OEM_PATH_DIAG
-__device__ unsigned long long g_diag[12];
+__device__ unsigned long long g_diag[24];
 #define OEM_STAMP(slot)                                                                    \
     do {                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                 \
@@ -44,8 +44,8 @@ __device__ unsigned long long g_diag[12];
         diag_acc[slot] += t__ - diag_last;                                                 \
         diag_last = t__;                                                                   \
     } while (0)
-#define OEM_DIAG_DECL unsigned long long diag_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, diag_last = __builtin_amdgcn_s_memtime();
-#define OEM_DIAG_ARGS , unsigned long long (&diag_acc)[12], unsigned long long &diag_last
+#define OEM_DIAG_DECL unsigned long long diag_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, diag_last = __builtin_amdgcn_s_memtime();
+#define OEM_DIAG_ARGS , unsigned long long (&diag_acc)[24], unsigned long long &diag_last
 #define OEM_DIAG_PASS , diag_acc, diag_last
 #else
 #define OEM_STAMP(slot) do { } while (0)
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
         }
     }
 #ifdef OEM_PATH_DIAG
-    if (tid == 0) for (int k = 0; k < 12; ++k) g_diag[k] = diag_acc[k];
+    if (tid == 0) for (int k = 0; k < 24; ++k) g_diag[k] = diag_acc[k];
 #endif
     if (tid == 0 && writer) {
         A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
@@ -1298,12 +1298,15 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
                 theta_prev = th;
             }
         }
+        OEM_STAMP(17);                                               // beta store, breakdown / check tests
         vp = v; v = wn * ib;
         const double al = waves_sum<NW>(rows_sum(v * wv), S.XN, par, w, lane);   // XN: gemv_rows' exchange owns XA
+        OEM_STAMP(18);                                               // alpha: rows_sum + second exchange
         *(tid == 0 ? &Tal[j] : tsink) = al;                          // read by wave 0 only (top_ritz)
         al_prev = al;
         nst = j + 1;
         wn = (wv - al * v) - bb * vp;
+        OEM_STAMP(19);                                               // alpha store, next vector
     }
     if (!have_theta) theta = top_ritz(nst, theta_prev);
     const double d = theta * 1.005;                                  // ref src/oem_dense.h:498
@@ -1311,7 +1314,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
 #ifdef OEM_PATH_DIAG
     OEM_STAMP(7);                                                    // the final top_ritz (slot 7: all top_ritz calls)
     unsigned long long lz[5];
-    for (int k = 0; k < 5; ++k) { lz[k] = diag_acc[k]; diag_acc[k] = 0; }
+    for (int k = 0; k < 5; ++k) { lz[k] = diag_acc[k]; diag_acc[12 + k] = lz[k]; diag_acc[k] = 0; }
     diag_acc[10] = lz[0] + lz[1] + lz[2] + lz[3] + lz[4] + diag_acc[6];   // Lanczos steps: gemv_rows + vector work
     diag_acc[9] = diag_acc[7]; diag_acc[6] = (unsigned long long)nst;
 #endif
@@ -1441,7 +1444,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
         }
     }
 #ifdef OEM_PATH_DIAG
-    if (tid == 0) for (int k = 0; k < 12; ++k) g_diag[k] = diag_acc[k];
+    if (tid == 0) for (int k = 0; k < 24; ++k) g_diag[k] = diag_acc[k];
 #endif
     if (tid == 0) {
         A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
@@ -1486,7 +1489,7 @@ template <int R, int NW, int CW, int G = 1> int launch_cfg(hipStream_t s, const 
 #ifdef OEM_PATH_DIAG
 extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read(unsigned long long *out)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 12) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 24) == hipSuccess ? 0 : -1;
 }
 #endif
 

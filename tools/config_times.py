@@ -29,6 +29,7 @@ def dev(x):
 
 
 out = {}
+orc.lib(True)      # builds the -march=native oracle on THIS host before anything is timed
 rng = np.random.default_rng(123)
 
 # config 2: n=5000, p=200, MCP gamma=2 / SCAD gamma=4, 200 lambdas, tol 1e-10, standardize + intercept

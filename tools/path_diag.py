@@ -31,7 +31,7 @@ fit = oa.oem(x, y, penalty="elastic.net", intercept=True, standardize=False, tol
 fit = oa.oem(x, y, penalty="elastic.net", intercept=True, standardize=False, tol=1e-10, lambda_=fit["lambda"][0])
 lib = L.lib()
 lib.oemgpu_diag_read.argtypes = [C.POINTER(C.c_ulonglong)]
-out = (C.c_ulonglong * 12)()
+out = (C.c_ulonglong * 24)()
 assert lib.oemgpu_diag_read(out) == 0
 d = np.array(list(out), dtype=np.float64)
 nit = int(np.sum(fit["niter"][0]))
@@ -44,6 +44,9 @@ if p > 64 and p <= 128:
     print("   ", np.round(r / max(nit, 1), 1), "sum", round(r.sum() / max(nit, 1), 1))
     print("    per-lambda (slot 8):", round(d[8] / len(fit["lambda"][0]), 1), " prologue:", int(d[5]), " top_ritz calls total:", int(d[9]),
           " Lanczos steps:", int(d[6]), "x", round(d[10] / max(d[6], 1), 1), "cycles (stamped)")
+    ns = max(d[6], 1)
+    print("    Lanczos step by segment [norm rows_sum etc | stores+barrier | reads | rsqrt+scale+FMAs | adds+reduce | beta store+tests | alpha rows_sum+exchange | alpha store+next vector]:")
+    print("   ", np.round(np.r_[d[12:17], d[17:20]] / ns, 1), "sum", round((d[12:17].sum() + d[17:20].sum()) / ns, 1))
     sys.exit(0)
 print("Lanczos cycles by segment:", lz.astype(int), "sum", int(lz.sum()))
 print("OEM cycles by segment    :", oem.astype(int), "sum", int(oem.sum()))
