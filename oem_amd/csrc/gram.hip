@@ -1211,7 +1211,7 @@ int launch_gram(hipStream_t s, const GramPlan &pl, const double *x, int64_t n, i
 // kernel was a 15 us latency chain of 253 dependent steps on 28 workgroups.
 __global__ __launch_bounds__(1024) void moments_reduce_kernel(const double *__restrict__ tpart,
                                                                const double *__restrict__ vpart, int p, int ntc,
-                                                               int ntile, int nchunk, int aug, double *__restrict__ M)
+                                                               int ntile, int nchunk, int nchunk_v, int aug, double *__restrict__ M)
 {
     __shared__ double part[4][256];
     const int q = p + 2;
@@ -1243,31 +1243,47 @@ __global__ __launch_bounds__(1024) void moments_reduce_kernel(const double *__re
             M[(size_t)col * q + row] = s;
             M[(size_t)row * q + col] = s;
         }
-    } else if (!aug && grp == 0) {
+    } else if (!aug) {
+        // vector partials (X'y, column sums, y sums, count: vw doubles per chunk), 256 elements per extra workgroup, summed
+        // like a tile: four thread groups over the chunks, eight loads in flight.  (One thread walking all chunks with
+        // dependent loads made this tail the whole kernel: 0.25 ms at p = 512, 0.4 ms at p = 256 with 688 chunks; a first stage
+        // over contiguous tile runs, tried on the theory that the 1 MB stride was the problem, made it slower: 76 vs 59 us.)
         const int vw = 32 * ntc + 4;
-        for (int j = e; j < p; j += 256) {
-            double a = 0.0, bb = 0.0;
-            for (int c = 0; c < nchunk; ++c) { a += vpart[(size_t)c * vw + j]; bb += vpart[(size_t)c * vw + 16 * ntc + j]; }
-            M[(size_t)j * q + (p + 1)] = a;  M[(size_t)(p + 1) * q + j] = a;
-            M[(size_t)j * q + p] = bb;       M[(size_t)p * q + j] = bb;
-        }
-        if (e == 0) {
-            double sy = 0.0, syy = 0.0, cnt = 0.0;
-            for (int c = 0; c < nchunk; ++c) {
-                sy += vpart[(size_t)c * vw + 32 * ntc]; syy += vpart[(size_t)c * vw + 32 * ntc + 1];
-                cnt += vpart[(size_t)c * vw + 32 * ntc + 2];
+        const int idx = (b - ntile) * 256 + e;
+        double s = 0.0;
+        if (idx < vw) {
+            const double *src = vpart + idx;
+            int c = grp;
+            for (; c + 28 < nchunk_v; c += 32) {
+                double t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = src[(size_t)(c + 4 * k) * vw];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += t[k];
             }
-            M[(size_t)p * q + p] = syy;
-            M[(size_t)p * q + (p + 1)] = sy;  M[(size_t)(p + 1) * q + p] = sy;
-            M[(size_t)(p + 1) * q + (p + 1)] = cnt;
+            for (; c < nchunk_v; c += 4) s += src[(size_t)c * vw];
+        }
+        part[grp][e] = s;
+        __syncthreads();
+        s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+        if (grp == 0 && idx < vw) {
+            if (idx < 16 * ntc) {                      // sum (x_j - c_j)
+                if (idx < p) { M[(size_t)idx * q + (p + 1)] = s; M[(size_t)(p + 1) * q + idx] = s; }
+            } else if (idx < 32 * ntc) {               // sum (x_j - c_j)(y - c_y)
+                const int j = idx - 16 * ntc;
+                if (j < p) { M[(size_t)j * q + p] = s; M[(size_t)p * q + j] = s; }
+            } else if (idx == 32 * ntc) { M[(size_t)p * q + (p + 1)] = s; M[(size_t)(p + 1) * q + p] = s; }      // sum (y - c_y)
+            else if (idx == 32 * ntc + 1) M[(size_t)p * q + p] = s;                                              // sum (y - c_y)^2
+            else if (idx == 32 * ntc + 2) M[(size_t)(p + 1) * q + (p + 1)] = s;                                  // rows
         }
     }
 }
 
 int launch_moments_reduce(hipStream_t s, const GramPlan &pl, const double *tpart, const double *vpart, double *moments)
 {
-    hipLaunchKernelGGL(moments_reduce_kernel, dim3(pl.ntile + (pl.tri ? 0 : 1)), dim3(1024), 0, s, tpart, vpart, pl.p,
-                       pl.ntc, pl.ntile, pl.nchunk, pl.tri, moments);
+    const int nvblk = pl.tri ? 0 : (32 * pl.ntc + 4 + 255) / 256;
+    hipLaunchKernelGGL(moments_reduce_kernel, dim3(pl.ntile + nvblk), dim3(1024), 0, s, tpart, vpart, pl.p,
+                       pl.ntc, pl.ntile, pl.nchunk, pl.nchunk, pl.tri, moments);
     OEM_HIP(hipGetLastError());
     return 0;
 }
