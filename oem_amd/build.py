@@ -14,7 +14,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "liboemgpu.so"
-SOURCES = ["api.hip", "hoststream.hip", "gram.hip", "path_small.hip", "path_large.hip", "xval.hip"]
+SOURCES = ["api.hip", "hoststream.hip", "gram.hip", "path_small.hip", "path_coop.hip", "path_large.hip", "xval.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
@@ -125,15 +125,16 @@ def build(force=False, verbose=False):
             objs.append(str(o))
         # ISA audits: asm-owned accumulators (gram.hip), DPP hazards of the inline-asm FMAs (path_small.hip)
         listing = {src: ex.submit(subprocess.run, [hipcc, *FLAGS, "-S", "--cuda-device-only", "-o", "-", str(CSRC / src)],
-                                  check=True, capture_output=True, text=True) for src in ("gram.hip", "path_small.hip")}
+                                  check=True, capture_output=True, text=True) for src in ("gram.hip", "path_small.hip", "path_coop.hip")}
         for j in jobs:
             j.result()
         problems = audit_gram_isa(listing["gram.hip"].result().stdout)
         if problems:
             raise RuntimeError("gram.hip ISA audit failed:\n  " + "\n  ".join(problems[:20]))
-        problems = audit_dpp_hazards(listing["path_small.hip"].result().stdout)
-        if problems:
-            raise RuntimeError("path_small.hip ISA audit failed:\n  " + "\n  ".join(problems[:20]))
+        for src in ("path_small.hip", "path_coop.hip"):
+            problems = audit_dpp_hazards(listing[src].result().stdout)
+            if problems:
+                raise RuntimeError(src + " ISA audit failed:\n  " + "\n  ".join(problems[:20]))
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(OUT), *objs], check=True)
     return OUT
 

@@ -233,12 +233,16 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const size_t out_bytes = out_doubles * sizeof(double) + nk * sizeof(int32_t);
     const size_t out_stride = (out_bytes + 255) / 256 * 256;
     const bool small = q <= SMALL_P_MAX;
+    const bool loss_on = (sem == OEMGPU_SEM_DENSE || sem == OEMGPU_SEM_XVAL || sem == SEM_SPARSE) && o->compute_loss != 0;
+    const bool coop = !small && path_coop_eligible(q, scale_factor != nullptr, loss_on, og.ngroups, nbatch);
     if (nbatch > 1 && !small) { set_error("internal: batched paths need p <= %d", SMALL_P_MAX); return OEMGPU_ERR_INTERNAL; }
     int lan = q < 128 ? q : 128;
-    const size_t work_d = small ? path_small_xchg_bytes() / 8 : path_large_work_doubles(q, lan);
+    size_t work_d = small ? path_small_xchg_bytes() / 8 : path_large_work_doubles(q, lan);
+    if (coop && work_d < path_coop_xchg_bytes() / 8) work_d = path_coop_xchg_bytes() / 8;
     // the outputs come first: when the caller's frame ends with `stats` (both callers), stats | outputs is one
     // contiguous range and one device-to-host copy returns both
-    const bool pen_split = small && npen > 1;        // one workgroup (set) per penalty: they are independent cold starts
+    // one workgroup (set) per penalty: they are independent cold starts (the cooperating sets must all be resident: <= half the CUs)
+    const bool pen_split = npen > 1 && (small || (coop && path_coop_workgroups(q) * npen <= c->num_cu / 2));
     const size_t a_out = B.take(out_stride * nbatch), a_blob = B.take(bl.h.size()),
                  a_work = B.take(work_d * sizeof(double) * nbatch * (pen_split ? npen : 1));
     // the workspace may be re-allocated by ctx_reserve: xx/xy/stats are offsets into it, so recompute after
@@ -285,7 +289,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     {
         Timer t(c, OEMGPU_T_EIGPATH);
         PollScope poll(o);
-        int rc = small ? launch_path_small(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned);
+        int rc = small ? launch_path_small(c->stream, a) : (coop ? launch_path_coop(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned));
         if (rc) return rc;
     }
     if (!joined) OEM_HIP(hipMemcpy2DAsync(dstats, out_stride, stats, bstride * sizeof(double), sizeof(double) * stats_len(p), nbatch,
@@ -345,12 +349,14 @@ size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o, int nbatch = 1)
 {
     const int nl = nl_of(o);
     if (nbatch > 1) return (size_t)nbatch * (paths_ws_bytes(p, q, o) + 1024);
-    const size_t splits = (q <= SMALL_P_MAX && o->npen > 1) ? (size_t)o->npen : 1;
+    const size_t splits = (q <= 1024 && o->npen > 1) ? (size_t)o->npen : 1;
     size_t b = 0;
     b += (size_t)o->npen * 4 + (size_t)o->npen * nl * 8 + (size_t)q * (8 + 8 + 4) + (size_t)(o->ngroups + 2) * 16 +
          (size_t)(o->ngroupvars + q + 2) * 4 + 4096;
     b += ((size_t)o->npen * nl * (q + 3) + 4 + stats_len(p)) * 8 + 4096;
-    b += (q > SMALL_P_MAX ? path_large_work_doubles(q, 128) * 8 : path_small_xchg_bytes() * splits) + 4096;
+    size_t wk = q > SMALL_P_MAX ? path_large_work_doubles(q, 128) * 8 : path_small_xchg_bytes();
+    if (q > SMALL_P_MAX && q <= 1024 && wk < path_coop_xchg_bytes()) wk = path_coop_xchg_bytes();
+    b += wk * splits + 4096;
     return b;
 }
 
@@ -631,7 +637,9 @@ int oemgpu_eig_max_dev(oemgpu_ctx *c, const double *a_dev, int32_t p, double *la
     Bump B;
     const size_t a_z = B.take((size_t)(p + 8) * 8), a_o = B.take(256);
     const int lan = p < 128 ? p : 128;
-    const size_t work_d = p <= SMALL_P_MAX ? path_small_xchg_bytes() / 8 : path_large_work_doubles(p, lan);
+    size_t work_d = p <= SMALL_P_MAX ? path_small_xchg_bytes() / 8 : path_large_work_doubles(p, lan);
+    const bool coop = path_coop_eligible(p, false, false, 0, 1);
+    if (coop && work_d < path_coop_xchg_bytes() / 8) work_d = path_coop_xchg_bytes() / 8;
     const size_t a_w = B.take(work_d * 8);
     if (ctx_reserve(c, B.off)) return OEMGPU_ERR_HIP;
     if (ctx_pinned(c, 16384)) return OEMGPU_ERR_HIP;
@@ -642,7 +650,8 @@ int oemgpu_eig_max_dev(oemgpu_ctx *c, const double *a_dev, int32_t p, double *la
     a.xx = a_dev; a.xy = (const double *)(c->ws + a_z); a.pf = a.xy; a.stats = a.xy;
     a.d_out = (double *)(c->ws + a_o);
     a.work = (double *)(c->ws + a_w);
-    int rc = p <= SMALL_P_MAX ? launch_path_small(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned);
+    a.pen_lo = 0; a.pen_hi = 0;
+    int rc = p <= SMALL_P_MAX ? launch_path_small(c->stream, a) : (coop ? launch_path_coop(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned));
     if (rc) return rc;
     double h[2];
     OEM_HIP(hipMemcpyAsync(h, a.d_out, sizeof h, hipMemcpyDeviceToHost, c->stream));

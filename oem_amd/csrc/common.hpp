@@ -126,6 +126,11 @@ size_t path_small_xchg_bytes();
 int launch_path_small(hipStream_t s, const PathArgs &a);          // p <= SMALL_P_MAX: one fused launch
 int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch);   // any p: multi-launch engine
 size_t path_large_work_doubles(int p, int nsteps);
+// 288 < p <= 1024: one persistent launch of cooperating workgroups (path_coop.hip)
+bool path_coop_eligible(int q, bool has_sinv, bool compute_loss, int ngroups, int nbatch);
+int path_coop_workgroups(int q);
+size_t path_coop_xchg_bytes();
+int launch_path_coop(hipStream_t s, const PathArgs &a);
 
 // opts->interrupt of the call in progress on this thread (api.hip: run_paths sets it around the engines); false if none
 bool caller_interrupted();

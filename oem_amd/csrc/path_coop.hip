@@ -1,0 +1,505 @@
+// path_coop.hip -- eigenvalue + penalty x lambda path for 288 < q <= 1024: ONE persistent launch of cooperating workgroups.
+//
+// Replaces, for these sizes, the launch-per-iteration engines of path_large.hip (config 3, p = 512: 873 OEM iterations at
+// 5.7 us per launch + ~2 ms of Lanczos launches = 6.0 ms of a 12 ms solve).  Same arithmetic as those engines
+// (ref src/oem_base.h:90-110, src/oem_dense.h:485-653, src/utils.cpp:537-549, src/oem_dense.cpp:206-297):
+//
+//   * XX stays in REGISTERS for the whole call, rows split over W = ceil(q / RW) workgroups, one per CU.  Inside a
+//     workgroup the rows are laid out as in path_small.hip's row-split kernel: the 16-lane row group g of a wave holds a
+//     slice of CG = 64 columns of 16 rows, multiplies it with v_fmac_f64_dpp row_newbcast (each lane supplies 4 vector
+//     entries to its row), and the four slices of a row meet through v_permlane16/32_swap -- no LDS in the product.
+//     A wave covers 256 columns; CH = 2 (q <= 512) or 4 (q <= 1024) waves share a row set and combine through LDS.
+//   * what crosses workgroups is the PRODUCT: u = d beta - XX beta + XY (or XX v during Lanczos), one all-gather per
+//     iteration through L2 as data-tagged 8-byte granules {epoch, 32 value bits} (guide recipe R2: one aligned atomic store
+//     per granule, the data is the flag, no fence; relaxed agent-scope polls; two buffers by parity).  Every workgroup
+//     then thresholds the WHOLE u itself (q / 256 coordinates per thread: group norms, Nesterov step, stop rule, the
+//     lambda / penalty state machine), identically everywhere, so no flag or scalar ever crosses workgroups.
+//   * u does not depend on lambda: the product that follows convergence at lambda_i is the warm start of lambda_{i+1} and
+//     carries the loss of lambda_i (Gram identity).
+//   * the eigenvalue step is Lanczos on the same registers with the same exchange (the vector updates and both inner
+//     products replicated per workgroup), the top Ritz value by the Sturm multisection of path_dev.hpp.
+// Every spin is bounded; a timeout poisons the result (theta = -1) and the host reports it.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.hpp"
+#include "penalty_ops.hpp"
+#include "path_dev.hpp"
+
+namespace oemgpu {
+
+namespace {
+
+constexpr int CG = 64;            // columns per 16-lane row group, in registers
+constexpr int NTH = 256;          // threads per workgroup (one wave per SIMD: 512 registers per lane, 256 of them VGPRs)
+constexpr int CML = 256;          // Lanczos steps kept
+typedef __attribute__((address_space(1))) unsigned long long cgu64;
+
+template <int CH> struct CoopCfg {
+    static constexpr int RW = 64 / CH;          // rows per workgroup (16 per row set, 4 / CH row sets)
+    static constexpr int QMAX = 256 * CH;       // columns covered: CH waves x 4 groups x CG
+    static constexpr int EPT = QMAX / NTH;      // coordinates per thread in the replicated vector work
+    // LDS carve (doubles)
+    static constexpr int OFF_U = 0;                         // gathered product / u [QMAX + 8]
+    static constexpr int OFF_B = OFF_U + QMAX + 8;          // vector going into the product (beta / Lanczos v) [QMAX + 8]
+    static constexpr int OFF_F = OFF_B + QMAX + 8;          // group factors [QMAX]
+    static constexpr int OFF_GW = OFF_F + QMAX;             // group weights [QMAX]
+    static constexpr int OFF_T = OFF_GW + QMAX;             // Lanczos alpha [CML], beta [CML]
+    static constexpr int OFF_S = OFF_T + 2 * CML;           // Sturm scratch 2 (CML + 16)
+    static constexpr int OFF_R = OFF_S + 2 * (CML + 16);    // block reductions [2][4], theta slot, ...
+    static constexpr int OFF_P = OFF_R + 16;                // partial products of the column parts [CH][16 * 4 / CH ... ] = [64]
+    static constexpr int OFF_I = OFF_P + 64;                // ints: gid[QMAX], gstart[QMAX + 1], gidx[QMAX], gzero[QMAX]
+    static constexpr int N_DBL = OFF_I + (4 * QMAX + 4) / 2 + 2;
+};
+
+struct CoopX {
+    cgu64 *buf;                   // [2 parities][QMAX rows][2 granules]
+    unsigned epoch;               // exchange counter, never 0; identical in every workgroup
+    int wg, qmax;
+    bool failed;
+};
+
+// sum over the 256 threads, identical in every thread and every workgroup (per-wave DPP sums, four words in fixed order)
+__device__ __forceinline__ double coop_block_sum(double v, double *red, int &rpar, int w, int lane)
+{
+    const double s = wave_sum(v);
+    double *r = red + 4 * rpar;
+    if (lane == 0) r[w] = s;
+    __syncthreads();
+    const double t = (r[0] + r[1]) + (r[2] + r[3]);
+    rpar ^= 1;                    // the next call writes the other half: no second barrier needed
+    return t;
+}
+
+template <int C> struct CoopFma {
+    static __device__ __forceinline__ void run(double (&acc)[4], const double (&B)[CG / 16], const double (&a)[CG])
+    {
+        if constexpr (C < CG) {
+            BcFma<(C & 15)>::fmac(acc[C & 3], B[C >> 4], a[C]);
+            CoopFma<C + 1>::run(acc, B, a);
+        }
+    }
+};
+
+// (M vec)[row of this lane] over this wave's 256 columns: every lane of the 16-lane column position gets the sum of the four groups
+__device__ __forceinline__ double coop_product(const double (&a)[CG], const double *Bsh, const int (&bidx)[CG / 16])
+{
+    double B[CG / 16];
+#pragma unroll
+    for (int j = 0; j < CG / 16; ++j) B[j] = Bsh[bidx[j]];
+    asm volatile("s_nop 1" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]));      // LDS/VALU write -> DPP read (path_dev.hpp)
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    CoopFma<0>::run(acc, B, a);
+    const double s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    // sum over the four row groups: v_permlane16_swap (rows 1, 3 <-> 0, 2), then v_permlane32_swap (rows 2, 3 <-> 0, 1)
+    const unsigned lo = (unsigned)__double2loint(s), hi = (unsigned)__double2hiint(s);
+    auto l1 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto h1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double t = __hiloint2double((int)h1[0], (int)l1[0]) + __hiloint2double((int)h1[1], (int)l1[1]);
+    const unsigned lo2 = (unsigned)__double2loint(t), hi2 = (unsigned)__double2hiint(t);
+    auto l2 = __builtin_amdgcn_permlane32_swap(lo2, lo2, false, false);
+    auto h2 = __builtin_amdgcn_permlane32_swap(hi2, hi2, false, false);
+    return __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
+}
+
+// One product + all-gather.  In: the vector in Bsh (complete, behind a barrier).  Out: Ush[j] for every j < q, behind a
+// barrier: OEM ? (d vec_j - (M vec)_j) + xy_j : (M vec)_j.
+template <int CH, bool OEM>
+__device__ __forceinline__ void coop_round(const double (&a)[CG], const int (&bidx)[CG / 16], double *Ush, const double *Bsh, double *Pc,
+                                           int q, int row, bool rowok, bool publisher, double d, double xyR, CoopX &X, int w, int lane, int tid)
+{
+    typedef CoopCfg<CH> C;
+    double g = coop_product(a, Bsh, bidx);
+    if (CH > 1) {                                               // the CH column parts of a row set meet in LDS
+        const int part = w % CH, rset = w / CH;                 // waves rset * CH .. rset * CH + CH - 1 share 16 rows
+        if (part != 0 && lane < 16) Pc[(rset * CH + part) * 16 + lane] = g;
+        __syncthreads();
+        if (part == 0) {
+#pragma unroll
+            for (int k = 1; k < CH; ++k) g += Pc[(rset * CH + k) * 16 + (lane & 15)];
+        }
+    }
+    ++X.epoch;
+    cgu64 *base = X.buf + (size_t)(X.epoch & 1) * X.qmax * 2;
+    if (publisher) {                                            // lanes 0..15 of the first wave of each row set
+        const double out = OEM ? (d * Bsh[row] - g) + xyR : g;
+        if (rowok) {
+            const unsigned lo = (unsigned)__double2loint(out), hi = (unsigned)__double2hiint(out);
+            __hip_atomic_store(base + (size_t)row * 2, ((unsigned long long)X.epoch << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(base + (size_t)row * 2 + 1, ((unsigned long long)X.epoch << 32) | hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            Ush[row] = out;
+        }
+    }
+    // gather the rows of the other workgroups: thread t polls rows t, t + 256, ...
+    unsigned long long v[2 * C::EPT];
+    bool need[C::EPT];
+#pragma unroll
+    for (int k = 0; k < C::EPT; ++k) {
+        const int j = tid + NTH * k;
+        need[k] = j < q && j / C::RW != X.wg;
+        v[2 * k] = v[2 * k + 1] = 0ull;
+    }
+    bool ok = false;
+    const unsigned limit = X.failed ? 0u : 2000000u;            // ~1 s: a partner is gone; after one timeout nobody waits again
+    for (unsigned spins = 0; !ok; ++spins) {
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < C::EPT; ++k) {
+            if (need[k]) {
+                const size_t o = (size_t)(tid + NTH * k) * 2;
+                v[2 * k] = __hip_atomic_load(base + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[2 * k + 1] = __hip_atomic_load(base + o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                all &= ((unsigned)(v[2 * k] >> 32) == X.epoch) & ((unsigned)(v[2 * k + 1] >> 32) == X.epoch);
+            }
+        }
+        ok = __all(all);
+        if (!ok && spins >= limit) break;
+    }
+    if (!ok) X.failed = true;
+#pragma unroll
+    for (int k = 0; k < C::EPT; ++k)
+        if (need[k]) Ush[tid + NTH * k] = ok ? __hiloint2double((int)(unsigned)v[2 * k + 1], (int)(unsigned)v[2 * k]) : 0.0;
+    __syncthreads();
+}
+
+template <int CH>
+__global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
+{
+    if (blockIdx.x % stride != 0) return;                       // stride 8: the working workgroups share one XCD (speed only)
+    const PathArgs A = path_instance(A_);
+    typedef CoopCfg<CH> C;
+    constexpr int EPT = C::EPT;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l16 = lane & 15, grp = lane >> 4;
+    const int q = A.p, wg = blockIdx.x / stride;
+    const unsigned long long t_cyc0 = __builtin_amdgcn_s_memtime(), t_rt0 = __builtin_amdgcn_s_memrealtime();
+    double *Ush = lds + C::OFF_U, *Bsh = lds + C::OFF_B, *F = lds + C::OFF_F, *GW = lds + C::OFF_GW;
+    double *Tal = lds + C::OFF_T, *Tbe = Tal + CML, *red = lds + C::OFF_R, *Pc = lds + C::OFF_P;
+    int *gid = reinterpret_cast<int *>(lds + C::OFF_I), *gstart = gid + C::QMAX, *gidx = gstart + C::QMAX + 1, *gzero = gidx + C::QMAX;
+    const bool writer = wg == 0;
+
+    // ---- this lane's part of the matrix: row set w / CH (16 rows), column part w % CH, group slice grp
+    const int part = w % CH, rset = w / CH;
+    const int row = wg * C::RW + rset * 16 + l16;
+    const bool rowok = rset * 16 + l16 < C::RW && row < q;
+    const int cbase = part * 256 + grp * CG;
+    double a[CG];
+#pragma unroll
+    for (int k = 0; k < CG; ++k) {
+        const int col = cbase + k;
+        a[k] = (rowok && col < q) ? A.xx[(size_t)col * q + row] : 0.0;
+    }
+    int bidx[CG / 16];
+#pragma unroll
+    for (int j = 0; j < CG / 16; ++j) {
+        const int col = cbase + 16 * j + l16;
+        bidx[j] = col < q ? col : C::QMAX + (lane & 7);         // a zero word behind the vector
+    }
+    const bool publisher = part == 0 && lane < 16;
+    const double xyR = rowok ? A.xy[row] : 0.0;
+    // ---- this thread's coordinates of the replicated vector work
+    double xyE[EPT], pfE[EPT], sinvE[EPT];
+    bool valid[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int j = tid + NTH * k;
+        valid[k] = j < q;
+        xyE[k] = valid[k] ? A.xy[j] : 0.0;
+        pfE[k] = valid[k] ? A.pf[j] : 0.0;
+        sinvE[k] = (valid[k] && A.sinv) ? A.sinv[j] : 1.0;
+    }
+    const int ng = A.ngroups;
+    for (int j = tid; j < C::QMAX + 8; j += NTH) { Ush[j] = 0.0; Bsh[j] = 0.0; }
+    for (int j = tid; j < q; j += NTH) gid[j] = ng > 0 ? A.gid[j] : -1;
+    if (ng > 0) {
+        for (int g = tid; g <= ng; g += NTH) gstart[g] = A.gstart[g];
+        for (int g = tid; g < ng; g += NTH) { gzero[g] = A.gzero[g]; GW[g] = A.gw[g]; }
+        const int nm = A.gstart[ng];
+        for (int m = tid; m < nm; m += NTH) gidx[m] = A.gidx[m];
+    }
+    __syncthreads();
+    CoopX X;
+    X.buf = (cgu64 *)reinterpret_cast<unsigned long long *>(A.work); X.epoch = 0; X.wg = wg; X.qmax = C::QMAX; X.failed = false;
+    int rpar = 0;
+
+    // ---- eigenvalue step: Lanczos on XX, the vector updates replicated per workgroup
+    double v[EPT], vp[EPT], wv[EPT];
+    {
+        double nn = 0.0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const unsigned j = tid + NTH * k;
+            const unsigned h = j * 2654435761u + 12345u;                 // deterministic non-structured start
+            v[k] = valid[k] ? ((double)(h >> 8) * (1.0 / 16777216.0) - 0.5) : 0.0;
+            vp[k] = 0.0;
+            nn = fma(v[k], v[k], nn);
+        }
+        nn = 1.0 / sqrt(coop_block_sum(nn, red, rpar, w, lane));
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) v[k] *= nn;
+    }
+    int msteps = A.lanczos_steps > CML ? CML : A.lanczos_steps;
+    if (q < CML) msteps = msteps < q ? msteps : q;
+    if (msteps < 1) msteps = 1;
+    double *theta_slot = red + 8;
+    auto top_ritz = [&](int m, double hint) {
+        if (w == 0) {
+            const double th = tridiag_max(Tal, Tbe, m, lane, lds + C::OFF_S, hint);
+            if (lane == 0) theta_slot[0] = th;
+        }
+        __syncthreads();
+        const double th = theta_slot[0];
+        __syncthreads();
+        return th;
+    };
+    int nst = 0;
+    double bprev = 0.0, theta = 0.0, theta_prev = -__builtin_inf();
+    bool have_theta = false;
+    for (int j = 0; j < msteps; ++j) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) if (valid[k]) Bsh[tid + NTH * k] = v[k];
+        __syncthreads();
+        coop_round<CH, false>(a, bidx, Ush, Bsh, Pc, q, row, rowok, publisher, 0.0, 0.0, X, w, lane, tid);
+        double al = 0.0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) { wv[k] = valid[k] ? Ush[tid + NTH * k] : 0.0; al = fma(v[k], wv[k], al); }
+        al = coop_block_sum(al, red, rpar, w, lane);
+        double bb = 0.0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            wv[k] = (wv[k] - al * v[k]) - bprev * vp[k];
+            bb = fma(wv[k], wv[k], bb);
+        }
+        bb = sqrt(coop_block_sum(bb, red, rpar, w, lane));
+        if (tid == 0) { Tal[j] = al; Tbe[j] = bb; }
+        nst = j + 1;
+        if (!(bb > 1e-13 * fabs(al))) break;                        // invariant subspace reached: T is exact
+        if (nst >= 16 && ((nst & 15) == 0 || (nst > 48 && (nst & 7) == 0)) && nst < msteps) {
+            const double th = top_ritz(nst, theta_prev);            // its first barrier publishes Tal / Tbe
+            if (th - theta_prev <= 1e-14 * fabs(th)) { theta = th; have_theta = true; break; }
+            theta_prev = th;
+        }
+        const double ib = 1.0 / bb;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) { vp[k] = v[k]; v[k] = wv[k] * ib; }
+        bprev = bb;
+    }
+    if (!have_theta) { __syncthreads(); theta = top_ritz(nst, theta_prev); }
+    const double d = theta * 1.005;                                  // ref src/oem_dense.h:498
+    if (tid == 0 && writer) { A.d_out[0] = d; A.d_out[1] = theta; }
+
+    // ---- lambda grid constants (ref src/oem_dense.cpp:175-192)
+    const double scaley = A.yscale ? A.stats[1] : 1.0;
+    const double yy = A.stats[2], nobs = A.stats[3];
+    const int nl = A.nl;
+    double lmax = 0.0;
+    {
+        double m = 0.0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int j = tid + NTH * k;
+            const double xl = (A.lmax_xy && valid[k]) ? A.lmax_xy[j] : xyE[k];
+            m = fmax(m, (valid[k] && j >= A.lmax_from) ? fabs(xl) : 0.0);
+        }
+        m = wave_max(m);
+        if (lane == 0) red[12 + w] = m;
+        __syncthreads();
+        lmax = fmax(fmax(red[12], red[13]), fmax(red[14], red[15])) * scaley;
+    }
+    const double llo = log(lmax), lhi = log(A.lambda_min_ratio * lmax);
+    const double lstep = nl > 1 ? (lhi - llo) / (double)(nl - 1) : 0.0;
+    const bool lflip = fabs(lhi) < fabs(llo);
+    const double tol = A.tol;
+
+    double beta[EPT], bold[EPT];
+    for (int pp = A.pen_lo; pp < A.pen_hi; ++pp) {
+        const int pen = A.penalty[pp];
+        const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
+        const bool isnet = pen_is_net(pen);
+        // cold start (ref src/oem_dense.cpp:243-244): beta = 0, so u = XY
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            beta[k] = 0.0;
+            if (valid[k]) { Ush[tid + NTH * k] = xyE[k]; Bsh[tid + NTH * k] = 0.0; }
+        }
+        __syncthreads();
+        double ak = 1.0;
+        double lam_next = A.user_lambda ? A.lambda_user[(size_t)pp * nl] : 0.0;
+        for (int i = 0; i < nl; ++i) {
+            double lam;
+            if (A.user_lambda) {
+                lam = lam_next;
+                if (i + 1 < nl) lam_next = A.lambda_user[(size_t)pp * nl + i + 1];
+            } else {
+                double lv;
+                if (nl == 1) lv = lhi;
+                else if (lflip) lv = (i == 0) ? llo : lhi - (double)(nl - 1 - i) * lstep;
+                else lv = (i == nl - 1) ? lhi : llo + (double)i * lstep;
+                lam = exp(lv);
+                if (isnet) lam = lam / A.alpha;
+            }
+            const size_t orow = (size_t)pp * nl + i;
+            if (tid == 0 && writer) A.lambda_out[orow] = lam;
+            if (i >= nlam) continue;
+            const PenK K = pen_consts(pen, lam / scaley, d, A.alpha, A.gamma, A.tau);       // ref src/oem_dense.cpp:241
+            const double rD = 1.0 / K.D, gammad = K.gamma * K.D, dmg = K.D - 1.0 / K.gamma, rdmg = 1.0 / dmg;
+            const double gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0, rdsc = 1.0 / dsc, rd = 1.0 / d;
+            const bool grpk = K.kind >= K_GRP;
+            int it = 0;
+            for (;;) {
+                // ---- beta = T(u) for every coordinate (replicated), acceleration, stop rule
+                double u[EPT];
+#pragma unroll
+                for (int k = 0; k < EPT; ++k) { bold[k] = beta[k]; u[k] = valid[k] ? Ush[tid + NTH * k] : 0.0; }
+                if (grpk) {                                         // group operators, ref src/oem_dense.h:193-315
+                    __syncthreads();                                // everybody has read u before it is overwritten
+#pragma unroll
+                    for (int k = 0; k < EPT; ++k) {
+                        if (K.kind == K_SGL) u[k] = soft1(u[k], pfE[k] * K.L1, 1.0);
+                        if (valid[k]) Ush[tid + NTH * k] = u[k];
+                    }
+                    __syncthreads();
+                    for (int gi = tid; gi < ng; gi += NTH) {
+                        double f = 1.0;
+                        if (!gzero[gi]) {
+                            double s2 = 0.0;
+                            for (int m = gstart[gi]; m < gstart[gi + 1]; ++m) { const double x = Ush[gidx[m]]; s2 += x * x; }
+                            s2 = sqrt(s2);
+                            const double pen_g = K.L * GW[gi];
+                            if (K.kind == K_GRP || K.kind == K_SGL) { const double t = 1.0 - pen_g / s2; f = (0.0 < t) ? t : 0.0; }
+                            else if (K.kind == K_GRP_MCP) f = mcp_norm(s2, pen_g, K.D, K.gamma);
+                            else f = scad_norm(s2, pen_g, K.D, K.gamma);
+                        }
+                        F[gi] = f;
+                    }
+                    __syncthreads();
+                }
+                bool bad = false;
+                double adp = 0.0;
+                const double akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak)), ratio = (ak - 1.0) / akn;
+#pragma unroll
+                for (int k = 0; k < EPT; ++k) {
+                    const int j = tid + NTH * k;
+                    double bn;
+                    if (grpk) {
+                        const int gi = valid[k] ? gid[j] : -1;
+                        const double f = gi >= 0 ? F[gi] : 0.0;
+                        bn = (f != 0.0) ? u[k] * f / K.D : 0.0;
+                    } else {
+                        const double tp = pfE[k] * K.L;
+                        if (K.kind == K_SOFT) bn = cdiv(shrink(u[k], tp), K.D, rD);
+                        else if (K.kind == K_MCP) {
+                            const bool big = fabs(u[k]) > gammad * tp;
+                            bn = cdiv(big ? u[k] : shrink(u[k], tp), big ? K.D : dmg, big ? rD : rdmg);
+                        } else if (K.kind == K_SCAD) {
+                            const double au = fabs(u[k]);
+                            const bool big = au > gammad * tp, mid = !big && au > (K.D + 1.0) * tp;
+                            const double num = big ? u[k] : (mid ? shrink(gm1 * u[k], K.gamma * tp) : shrink(u[k], tp));
+                            bn = cdiv(num, mid ? dsc : K.D, mid ? rdsc : rD);
+                        } else bn = cdiv(u[k], d, rd);
+                    }
+                    if (!valid[k]) bn = 0.0;
+                    if (A.accelerate) {                             // ref src/oem_dense.h:633-651
+                        const double upd = bn, diff = upd - bold[k];
+                        bn = upd + ratio * diff;
+                        adp += (bn - upd) * diff;
+                    }
+                    const double c = fabs(bn), qo = fabs(bold[k]);
+                    const bool cn = c > 1e-13, qn = qo > 1e-13;     // ref src/utils.cpp:537-549
+                    bad |= (cn != qn);
+                    bad |= (cn && qn && fabs(bn - bold[k]) > tol * qo);
+                    beta[k] = bn;
+                    if (valid[k]) Bsh[j] = bn;
+                }
+                if (A.accelerate) {
+                    adp = coop_block_sum(adp, red, rpar, w, lane);
+                    ak = (adp > 0.0) ? 1.0 : akn;
+                }
+                const int anybad = __syncthreads_or(bad ? 1 : 0);   // also: Bsh is complete
+                ++it;
+                const bool conv = !anybad;
+                const bool fin = conv || it >= A.maxit;
+                if (fin) {
+                    if (A.sinv) {                                   // oemXTX::get_beta rescales the member in place (quirk Q5)
+#pragma unroll
+                        for (int k = 0; k < EPT; ++k) { beta[k] *= sinvE[k]; if (valid[k]) Bsh[tid + NTH * k] = beta[k]; }
+                        __syncthreads();
+                    }
+                    if (writer) {
+#pragma unroll
+                        for (int k = 0; k < EPT; ++k) if (valid[k]) A.beta[orow * q + tid + NTH * k] = beta[k];
+                        if (tid == 0) {
+                            A.niter[orow] = conv ? it : A.maxit + 1;                    // ref src/oem_base.h:94-109
+                            if (!A.compute_loss) A.loss[orow] = 1e99;
+                        }
+                    }
+                }
+                // ---- u = d beta - XX beta + XY: the next iteration's input, or the warm start of the next lambda
+                coop_round<CH, true>(a, bidx, Ush, Bsh, Pc, q, row, rowok, publisher, d, xyR, X, w, lane, tid);
+                if (fin) {
+                    if (A.compute_loss) {
+                        // sum (Y - X beta)^2 through the Gram identity (ref src/oem_dense.h:759-770): XX beta = d beta - u + XY
+                        double t = 0.0;
+#pragma unroll
+                        for (int k = 0; k < EPT; ++k) {
+                            const double uu = valid[k] ? Ush[tid + NTH * k] : 0.0;
+                            const double gg = (d * beta[k] - uu) + xyE[k];
+                            t += beta[k] * (gg - 2.0 * xyE[k]);
+                        }
+                        t = coop_block_sum(t, red, rpar, w, lane);
+                        if (tid == 0 && writer) A.loss[orow] = yy + nobs * t;
+                    }
+                    break;
+                }
+            }
+        }
+    }
+    if (tid == 0 && writer) {
+        A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
+        A.d_out[3] = (double)(__builtin_amdgcn_s_memrealtime() - t_rt0);
+    }
+    if (X.failed && tid == 0) A.d_out[1] = -1.0;                     // exchange timeout: poison (the host turns it into an error)
+}
+
+}  // namespace
+
+size_t path_coop_xchg_bytes() { return (size_t)2 * 1024 * 2 * sizeof(unsigned long long); }
+
+bool path_coop_eligible(int q, bool has_sinv, bool compute_loss, int ngroups, int nbatch)
+{
+    if (getenv("OEM_NO_COOP") || q <= SMALL_P_MAX || q > 1024) return false;      // OEM_NO_COOP: the launch-per-iteration engines
+    if (has_sinv && compute_loss) return false;          // the loss of the un-rescaled member would need a product of its own
+    if (ngroups > (q <= 512 ? 512 : 1024)) return false;
+    if (nbatch > 1) return false;
+    return true;
+}
+
+int path_coop_workgroups(int q) { return q <= 512 ? (q + 31) / 32 : (q + 15) / 16; }
+
+int launch_path_coop(hipStream_t s, const PathArgs &a_)
+{
+    PathArgs a = a_;
+    const int q = a.p;
+    a.lanczos_steps = q < CML ? q : CML;
+    static const int stride = getenv("OEM_COOP_STRIDE") ? atoi(getenv("OEM_COOP_STRIDE")) : 1;
+    const int ninst = a.pen_split ? a.npen : 1;
+    OEM_HIP(hipMemsetAsync(a.work, 0, path_coop_xchg_bytes() * ninst, s));     // granule tags must start at 0
+    if (q <= 512) {
+        typedef CoopCfg<2> C;
+        const int W = (q + C::RW - 1) / C::RW;
+        const size_t sh = (size_t)C::N_DBL * sizeof(double);
+        if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_coop_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL((path_coop_kernel<2>), dim3(W * stride, ninst), dim3(NTH), sh, s, a, stride);
+    } else {
+        typedef CoopCfg<4> C;
+        const int W = (q + C::RW - 1) / C::RW;
+        const size_t sh = (size_t)C::N_DBL * sizeof(double);
+        if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_coop_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL((path_coop_kernel<4>), dim3(W * stride, ninst), dim3(NTH), sh, s, a, stride);
+    }
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace oemgpu

@@ -117,6 +117,24 @@ def test_config5_big_p256_reduced_n_and_shards(oa):
     _cmp(oa.big_oem(xs, ys, **kw), ref)
 
 
+def _engines(f):
+    """the same call on the three engines that serve 288 < p <= 1024: the persistent cooperating-workgroup kernel (default), the
+    fused launch-per-iteration kernels (OEM_NO_COOP) and the two-kernel engine (OEM_NO_COOP + OEM_NO_FUSED)"""
+    import os
+    coop = f()
+    os.environ["OEM_NO_COOP"] = "1"
+    try:
+        fused = f()
+        os.environ["OEM_NO_FUSED"] = "1"
+        try:
+            two = f()
+        finally:
+            del os.environ["OEM_NO_FUSED"]
+    finally:
+        del os.environ["OEM_NO_COOP"]
+    return coop, fused, two
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("p", [512, 1024])
 def test_fused_iteration_engine(oa, p):
@@ -130,21 +148,21 @@ def test_fused_iteration_engine(oa, p):
     y = x @ b + rng.normal(size=n)
     pens = ["lasso", "elastic.net", "mcp", "scad", "ols", "scad.net"]
     kw = dict(penalty=pens, alpha=0.7, nlambda=8, tol=1e-8, maxit=400)
-    fit, ref = oa.oem(x, y, **kw), orc.fit_dense(x, y, native=True, **kw)
-    os.environ["OEM_NO_FUSED"] = "1"
-    try:
-        two = oa.oem(x, y, **kw)
-    finally:
-        del os.environ["OEM_NO_FUSED"]
+    ref = orc.fit_dense(x, y, native=True, **kw)
+    coop, fit, two = _engines(lambda: oa.oem(x, y, **kw))
     for k in range(len(pens)):
+        assert np.abs(np.asarray(coop["beta"][k]) - np.asarray(ref["beta"][k])).max() < 1e-9, pens[k]
+        assert np.abs(np.ravel(coop["niter"][k]).astype(int) - np.ravel(ref["niter"][k]).astype(int)).max() <= 1, pens[k]
         assert np.abs(np.asarray(fit["beta"][k]) - np.asarray(ref["beta"][k])).max() < 1e-9, pens[k]
         # same iteration arithmetic; d may differ in its last bits (the fused Lanczos step sums in another order)
         assert np.abs(np.asarray(fit["beta"][k]) - np.asarray(two["beta"][k])).max() < 1e-12, pens[k]
         assert np.abs(np.ravel(fit["niter"][k]).astype(int) - np.ravel(two["niter"][k]).astype(int)).max() <= 1, pens[k]
+    assert abs(coop["d"] - ref["d"]) < 1e-9 * ref["d"]
     kw = dict(penalty=["lasso"], nlambda=6, tol=1e-12, maxit=3)                                       # exhaustion: maxit + 1
-    fit, ref = oa.oem(x, y, **kw), orc.fit_dense(x, y, native=True, **kw)
-    assert np.array_equal(fit["niter"][0], ref["niter"][0]) and fit["niter"][0].max() == 4
-    assert np.abs(fit["beta"][0] - ref["beta"][0]).max() < 1e-9
+    ref = orc.fit_dense(x, y, native=True, **kw)
+    for fit in _engines(lambda: oa.oem(x, y, **kw)):
+        assert np.array_equal(fit["niter"][0], ref["niter"][0]) and fit["niter"][0].max() == 4
+        assert np.abs(fit["beta"][0] - ref["beta"][0]).max() < 1e-9
 
 
 @pytest.mark.gpu
@@ -160,27 +178,22 @@ def test_replicated_update_fused_engine(oa, p):
     y = x @ b + rng.normal(size=n)
     groups = np.arange(p) // 8 + 1
 
-    def both(f):
-        a = f()
-        os.environ["OEM_NO_FUSED"] = "1"
-        try:
-            t = f()
-        finally:
-            del os.environ["OEM_NO_FUSED"]
-        return a, t
-
     pens = ["grp.lasso", "grp.mcp", "grp.scad", "sparse.grp.lasso", "grp.lasso.net"]
     kw = dict(penalty=pens, groups=groups, alpha=0.7, tau=0.4, gamma=3.5, nlambda=7, tol=1e-8)
-    fit, two = both(lambda: oa.oem(x, y, **kw))
+    coop, fit, two = _engines(lambda: oa.oem(x, y, **kw))
     ref = orc.fit_dense(x, y, native=True, unique_groups=np.unique(groups), **kw)
     for k in range(len(pens)):
+        assert np.abs(coop["beta"][k] - ref["beta"][k]).max() < 1e-9, pens[k]
+        assert np.abs(coop["niter"][k].astype(int) - ref["niter"][k].astype(int)).max() <= 1, pens[k]
         assert np.abs(fit["beta"][k] - ref["beta"][k]).max() < 1e-9, pens[k]
         assert np.abs(fit["beta"][k] - two["beta"][k]).max() < 1e-12, pens[k]
         assert np.abs(fit["niter"][k].astype(int) - two["niter"][k].astype(int)).max() <= 1, pens[k]
     kw = dict(penalty=["lasso", "mcp"], accelerate=True, compute_loss=True, nlambda=7, tol=1e-8)
-    fit, two = both(lambda: oa.oem(x, y, **kw))
+    coop, fit, two = _engines(lambda: oa.oem(x, y, **kw))
     ref = orc.fit_dense(x, y, native=True, **kw)
     for k in range(2):
+        assert np.abs(coop["beta"][k] - ref["beta"][k]).max() < 1e-9
+        assert np.allclose(coop["loss"][k], ref["loss"][k], rtol=1e-9)
         assert np.abs(fit["beta"][k] - ref["beta"][k]).max() < 1e-9
         assert np.allclose(fit["loss"][k], ref["loss"][k], rtol=1e-9)
         assert np.abs(fit["beta"][k] - two["beta"][k]).max() < 1e-12
@@ -188,9 +201,10 @@ def test_replicated_update_fused_engine(oa, p):
         assert np.allclose(fit["loss"][k], two["loss"][k], rtol=1e-10)
     xtx, xty = x.T @ x / n, x.T @ y / n
     sf = np.linspace(0.5, 2.0, p)
-    fit, two = both(lambda: oa.oem_xtx(xtx, xty, penalty=["lasso", "scad"], scale_factor=sf, nlambda=7))
+    coop, fit, two = _engines(lambda: oa.oem_xtx(xtx, xty, penalty=["lasso", "scad"], scale_factor=sf, nlambda=7))
     ref = orc.fit_xtx(xtx, xty, penalty=["lasso", "scad"], scale_factor=sf, nlambda=7)
     for k in range(2):
+        assert np.abs(coop["beta"][k] - ref["beta"][k]).max() < 1e-9
         assert np.abs(fit["beta"][k] - ref["beta"][k]).max() < 1e-9
         assert np.abs(fit["beta"][k] - two["beta"][k]).max() < 1e-12
 
