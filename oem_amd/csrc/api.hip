@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -23,6 +24,25 @@ void set_error(const char *fmt, ...)
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
 }
+
+// The cooperating-workgroup engine (path_coop.hip) spins on its partners, so every workgroup of every such kernel in flight must
+// be resident at once: concurrent callers (xval.oem's fold threads, user threads) queue here for CU slots.
+static std::mutex g_coop_mu;
+static std::condition_variable g_coop_cv;
+static int g_coop_in_flight = 0;
+struct CoopSlots {
+    int n = 0;
+    void take(int want, int capacity)
+    {
+        std::unique_lock<std::mutex> lk(g_coop_mu);
+        g_coop_cv.wait(lk, [&] { return g_coop_in_flight == 0 || g_coop_in_flight + want <= capacity; });
+        g_coop_in_flight += want; n = want;
+    }
+    ~CoopSlots()
+    {
+        if (n) { { std::lock_guard<std::mutex> lk(g_coop_mu); g_coop_in_flight -= n; } g_coop_cv.notify_all(); }
+    }
+};
 
 static thread_local int (*g_poll)(void *) = nullptr;
 static thread_local void *g_poll_arg = nullptr;
@@ -286,6 +306,8 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const bool joined = nbatch == 1 && (const char *)stats < (const char *)dout && st_gap == ((size_t)stats_len(p) * 8 + 255) / 256 * 256;
     const size_t back_bytes = nbatch > 1 ? out_stride * nbatch : out_bytes + (joined ? st_gap : 0);
     if (ctx_pinned(c, back_bytes > 16384 ? back_bytes : 16384)) return OEMGPU_ERR_HIP;
+    CoopSlots slots;                                  // held until the stream has been synchronised below
+    if (coop) slots.take(path_coop_workgroups(q) * (pen_split ? npen : 1), c->num_cu * 3 / 4);
     {
         Timer t(c, OEMGPU_T_EIGPATH);
         PollScope poll(o);
@@ -651,6 +673,8 @@ int oemgpu_eig_max_dev(oemgpu_ctx *c, const double *a_dev, int32_t p, double *la
     a.d_out = (double *)(c->ws + a_o);
     a.work = (double *)(c->ws + a_w);
     a.pen_lo = 0; a.pen_hi = 0;
+    CoopSlots slots;
+    if (coop) slots.take(path_coop_workgroups(p), c->num_cu * 3 / 4);
     int rc = p <= SMALL_P_MAX ? launch_path_small(c->stream, a) : (coop ? launch_path_coop(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned));
     if (rc) return rc;
     double h[2];

@@ -52,11 +52,30 @@ template <int CH> struct CoopCfg {
     static constexpr int N_DBL = OFF_I + (4 * QMAX + 4) / 2 + 2;
 };
 
+// -DOEM_PATH_DIAG: cycles of wave 0 of workgroup 0 by segment (fenced stamps: read the SHARES)
+#ifdef OEM_PATH_DIAG
+__device__ unsigned long long g_diag_coop[16];
+#define COOP_STAMP(slot)                                                                   \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        unsigned long long t__;                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        X.acc[slot] += t__ - X.last;                                                       \
+        X.last = t__;                                                                      \
+    } while (0)
+#else
+#define COOP_STAMP(slot) do { } while (0)
+#endif
+
 struct CoopX {
     cgu64 *buf;                   // [2 parities][QMAX rows][2 granules]
     unsigned epoch;               // exchange counter, never 0; identical in every workgroup
     int wg, qmax;
     bool failed;
+#ifdef OEM_PATH_DIAG
+    unsigned long long acc[16], last;
+#endif
 };
 
 // sum over the 256 threads, identical in every thread and every workgroup (per-wave DPP sums, four words in fixed order)
@@ -109,7 +128,9 @@ __device__ __forceinline__ void coop_round(const double (&a)[CG], const int (&bi
                                            int q, int row, bool rowok, bool publisher, double d, double xyR, CoopX &X, int w, int lane, int tid)
 {
     typedef CoopCfg<CH> C;
+    COOP_STAMP(0);                                              // everything between rounds (threshold, stop rule, Lanczos vector work)
     double g = coop_product(a, Bsh, bidx);
+    COOP_STAMP(1);                                              // vector reads, FMAs, row-group sum
     if (CH > 1) {                                               // the CH column parts of a row set meet in LDS
         const int part = w % CH, rset = w / CH;                 // waves rset * CH .. rset * CH + CH - 1 share 16 rows
         if (part != 0 && lane < 16) Pc[(rset * CH + part) * 16 + lane] = g;
@@ -119,6 +140,7 @@ __device__ __forceinline__ void coop_round(const double (&a)[CG], const int (&bi
             for (int k = 1; k < CH; ++k) g += Pc[(rset * CH + k) * 16 + (lane & 15)];
         }
     }
+    COOP_STAMP(2);                                              // column parts through LDS
     ++X.epoch;
     cgu64 *base = X.buf + (size_t)(X.epoch & 1) * X.qmax * 2;
     if (publisher) {                                            // lanes 0..15 of the first wave of each row set
@@ -130,8 +152,12 @@ __device__ __forceinline__ void coop_round(const double (&a)[CG], const int (&bi
             Ush[row] = out;
         }
     }
-    // gather the rows of the other workgroups: thread t polls rows t, t + 256, ...
-    unsigned long long v[2 * C::EPT];
+    COOP_STAMP(3);                                              // publish
+    // Gather the rows of the other workgroups: thread t polls rows t, t + 256, ...  THREE sweeps are kept in flight (a new one
+    // is issued whenever the oldest comes back without the data): a poll that leaves just before the stores land no longer costs
+    // a whole extra memory round trip, only a third of one.
+    constexpr int NPOLL = 3;
+    unsigned long long v[2 * C::EPT], pv[NPOLL][2 * C::EPT];
     bool need[C::EPT];
 #pragma unroll
     for (int k = 0; k < C::EPT; ++k) {
@@ -139,27 +165,82 @@ __device__ __forceinline__ void coop_round(const double (&a)[CG], const int (&bi
         need[k] = j < q && j / C::RW != X.wg;
         v[2 * k] = v[2 * k + 1] = 0ull;
     }
-    bool ok = false;
-    const unsigned limit = X.failed ? 0u : 2000000u;            // ~1 s: a partner is gone; after one timeout nobody waits again
-    for (unsigned spins = 0; !ok; ++spins) {
-        bool all = true;
+    auto issue = [&](auto R_) {
+        constexpr int R = decltype(R_)::value;
 #pragma unroll
         for (int k = 0; k < C::EPT; ++k) {
+            pv[R][2 * k] = pv[R][2 * k + 1] = 0ull;
             if (need[k]) {
                 const size_t o = (size_t)(tid + NTH * k) * 2;
-                v[2 * k] = __hip_atomic_load(base + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v[2 * k + 1] = __hip_atomic_load(base + o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                all &= ((unsigned)(v[2 * k] >> 32) == X.epoch) & ((unsigned)(v[2 * k + 1] >> 32) == X.epoch);
+                pv[R][2 * k] = __hip_atomic_load(base + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pv[R][2 * k + 1] = __hip_atomic_load(base + o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        ok = __all(all);
-        if (!ok && spins >= limit) break;
+    };
+    bool ok = false;
+    unsigned spins = 0;
+    const unsigned limit = X.failed ? 0u : 2000000u;            // ~1 s: a partner is gone; after one timeout nobody waits again
+    auto step = [&](auto R_) -> bool {                          // true: stop (data complete, or timed out)
+        constexpr int R = decltype(R_)::value;
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < C::EPT; ++k)
+            if (need[k]) all &= ((unsigned)(pv[R][2 * k] >> 32) == X.epoch) & ((unsigned)(pv[R][2 * k + 1] >> 32) == X.epoch);
+        if (__all(all)) {
+#pragma unroll
+            for (int k = 0; k < 2 * C::EPT; ++k) v[k] = pv[R][k];
+            ok = true;
+            return true;
+        }
+        if (++spins >= limit) return true;
+        issue(R_);
+        return false;
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    issue(I0{}); issue(I1{}); issue(I2{});
+    for (;;) {
+        if (step(I0{})) break;
+        if (step(I1{})) break;
+        if (step(I2{})) break;
     }
     if (!ok) X.failed = true;
+    COOP_STAMP(4);                                              // polling
+#ifdef OEM_PATH_DIAG
+    X.acc[8] += 1;
+#endif
 #pragma unroll
     for (int k = 0; k < C::EPT; ++k)
         if (need[k]) Ush[tid + NTH * k] = ok ? __hiloint2double((int)(unsigned)v[2 * k + 1], (int)(unsigned)v[2 * k]) : 0.0;
     __syncthreads();
+    COOP_STAMP(5);                                              // LDS stores + barrier (waits for the slowest wave's poll)
+}
+
+// element-wise operators (ref src/oem_dense.h:76-149), branch-free; only the reciprocals the operator uses
+struct ThrC { double D, rD, gammad, dmg, rdmg, gm1, gamma, dsc, rdsc, d, rd; };
+template <int KIND> __device__ __forceinline__ ThrC thr_c(const PenK &K, double d)
+{
+    ThrC c = {};
+    c.D = K.D; c.gammad = K.gamma * K.D; c.gamma = K.gamma; c.gm1 = K.gamma - 1.0; c.d = d;
+    if (KIND != K_OLS) c.rD = 1.0 / K.D;
+    if (KIND == K_MCP) { c.dmg = K.D - 1.0 / K.gamma; c.rdmg = 1.0 / c.dmg; }
+    if (KIND == K_SCAD) { c.dsc = c.gm1 * K.D - 1.0; c.rdsc = 1.0 / c.dsc; }
+    if (KIND == K_OLS) c.rd = 1.0 / d;
+    return c;
+}
+template <int KIND> __device__ __forceinline__ double thr1(double u, double tp, const ThrC &c)
+{
+    if (KIND == K_SOFT) return cdiv(shrink(u, tp), c.D, c.rD);
+    if (KIND == K_MCP) {
+        const bool big = fabs(u) > c.gammad * tp;
+        return cdiv(big ? u : shrink(u, tp), big ? c.D : c.dmg, big ? c.rD : c.rdmg);
+    }
+    if (KIND == K_SCAD) {
+        const double au = fabs(u);
+        const bool big = au > c.gammad * tp, mid = !big && au > (c.D + 1.0) * tp;
+        const double num = big ? u : (mid ? shrink(c.gm1 * u, c.gamma * tp) : shrink(u, tp));
+        return cdiv(num, mid ? c.dsc : c.D, mid ? c.rdsc : c.rD);
+    }
+    return cdiv(u, c.d, c.rd);
 }
 
 template <int CH>
@@ -218,8 +299,28 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
         for (int m = tid; m < nm; m += NTH) gidx[m] = A.gidx[m];
     }
     __syncthreads();
+    // this thread's group (tid < ng; groups beyond 256 take the LDS loop) with its first eight members, and the groups of its coordinates
+    int gm[8], gcnt = 0, gme = 0;
+    bool gz = true;
+    double gwt = 0.0;
+    if (tid < ng) {
+        const int m0 = gstart[tid];
+        gme = gstart[tid + 1]; gcnt = gme - m0; gz = gzero[tid] != 0; gwt = GW[tid];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gm[k] = (k < gcnt) ? gidx[m0 + k] : C::QMAX + k;       // zero words behind the vector
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gm[k] = C::QMAX + k;
+    }
+    int gidE[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) gidE[k] = valid[k] ? gid[tid + NTH * k] : -1;
     CoopX X;
     X.buf = (cgu64 *)reinterpret_cast<unsigned long long *>(A.work); X.epoch = 0; X.wg = wg; X.qmax = C::QMAX; X.failed = false;
+#ifdef OEM_PATH_DIAG
+    for (int k = 0; k < 16; ++k) X.acc[k] = 0;
+    X.last = __builtin_amdgcn_s_memtime();
+#endif
     int rpar = 0;
 
     // ---- eigenvalue step: Lanczos on XX, the vector updates replicated per workgroup
@@ -270,7 +371,8 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
             wv[k] = (wv[k] - al * v[k]) - bprev * vp[k];
             bb = fma(wv[k], wv[k], bb);
         }
-        bb = sqrt(coop_block_sum(bb, red, rpar, w, lane));
+        double ib;
+        sqrt_rsqrt(coop_block_sum(bb, red, rpar, w, lane), bb, ib);
         if (tid == 0) { Tal[j] = al; Tbe[j] = bb; }
         nst = j + 1;
         if (!(bb > 1e-13 * fabs(al))) break;                        // invariant subspace reached: T is exact
@@ -279,7 +381,6 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
             if (th - theta_prev <= 1e-14 * fabs(th)) { theta = th; have_theta = true; break; }
             theta_prev = th;
         }
-        const double ib = 1.0 / bb;
 #pragma unroll
         for (int k = 0; k < EPT; ++k) { vp[k] = v[k]; v[k] = wv[k] * ib; }
         bprev = bb;
@@ -287,6 +388,11 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
     if (!have_theta) { __syncthreads(); theta = top_ritz(nst, theta_prev); }
     const double d = theta * 1.005;                                  // ref src/oem_dense.h:498
     if (tid == 0 && writer) { A.d_out[0] = d; A.d_out[1] = theta; }
+#ifdef OEM_PATH_DIAG
+    COOP_STAMP(0);
+    if (tid == 0 && writer) { for (int k = 0; k < 6; ++k) { g_diag_coop[k] = X.acc[k]; } g_diag_coop[6] = X.acc[8]; g_diag_coop[7] = (unsigned long long)nst; }
+    for (int k = 0; k < 16; ++k) X.acc[k] = 0;
+#endif
 
     // ---- lambda grid constants (ref src/oem_dense.cpp:175-192)
     const double scaley = A.yscale ? A.stats[1] : 1.0;
@@ -311,11 +417,17 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
     const bool lflip = fabs(lhi) < fabs(llo);
     const double tol = A.tol;
 
-    double beta[EPT], bold[EPT];
-    for (int pp = A.pen_lo; pp < A.pen_hi; ++pp) {
-        const int pen = A.penalty[pp];
+    int *flagw = reinterpret_cast<int *>(red + 10);                 // "some coefficient still moving", one word per wave
+    // One lambda loop per (operator family, accelerate) pair: the dispatch happens once per penalty, the serial loop carries only
+    // the arithmetic of the operator in use.  KIND == K_GRP covers every group operator (K.kind selects inside).
+    auto lambda_loop = [&](auto KIND_, auto ACC_, int pp, int pen) {
+        constexpr int KIND = decltype(KIND_)::value;
+        constexpr bool ACC = decltype(ACC_)::value;
         const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
         const bool isnet = pen_is_net(pen);
+        const int maxit = A.maxit;
+        const bool want_loss = A.compute_loss != 0, has_sinv = A.sinv != nullptr;
+        double beta[EPT], bold[EPT];
         // cold start (ref src/oem_dense.cpp:243-244): beta = 0, so u = XY
         __syncthreads();
 #pragma unroll
@@ -343,85 +455,100 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
             if (tid == 0 && writer) A.lambda_out[orow] = lam;
             if (i >= nlam) continue;
             const PenK K = pen_consts(pen, lam / scaley, d, A.alpha, A.gamma, A.tau);       // ref src/oem_dense.cpp:241
-            const double rD = 1.0 / K.D, gammad = K.gamma * K.D, dmg = K.D - 1.0 / K.gamma, rdmg = 1.0 / dmg;
-            const double gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0, rdsc = 1.0 / dsc, rd = 1.0 / d;
-            const bool grpk = K.kind >= K_GRP;
+            const ThrC c = thr_c<KIND>(K, d);
+            double tp[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) tp[k] = pfE[k] * K.L;
             int it = 0;
             for (;;) {
                 // ---- beta = T(u) for every coordinate (replicated), acceleration, stop rule
                 double u[EPT];
 #pragma unroll
                 for (int k = 0; k < EPT; ++k) { bold[k] = beta[k]; u[k] = valid[k] ? Ush[tid + NTH * k] : 0.0; }
-                if (grpk) {                                         // group operators, ref src/oem_dense.h:193-315
-                    __syncthreads();                                // everybody has read u before it is overwritten
+                if constexpr (KIND == K_GRP) {                      // group operators, ref src/oem_dense.h:193-315
+                    if (K.kind == K_SGL) {                          // sparse group lasso: the soft-thresholded u feeds the norms
+                        __syncthreads();                            // everybody has read u before it is overwritten
 #pragma unroll
-                    for (int k = 0; k < EPT; ++k) {
-                        if (K.kind == K_SGL) u[k] = soft1(u[k], pfE[k] * K.L1, 1.0);
-                        if (valid[k]) Ush[tid + NTH * k] = u[k];
+                        for (int k = 0; k < EPT; ++k) {
+                            u[k] = soft1(u[k], pfE[k] * K.L1, 1.0);
+                            if (valid[k]) Ush[tid + NTH * k] = u[k];
+                        }
+                        __syncthreads();
                     }
-                    __syncthreads();
                     for (int gi = tid; gi < ng; gi += NTH) {
                         double f = 1.0;
-                        if (!gzero[gi]) {
+                        const bool first = gi == tid;               // this thread's cached group
+                        if (first ? !gz : !gzero[gi]) {
+                            // summed in member order like the reference; the first eight member indices sit in registers (eight
+                            // independent LDS reads: one latency), longer groups and groups beyond the 256th walk the LDS lists
                             double s2 = 0.0;
-                            for (int m = gstart[gi]; m < gstart[gi + 1]; ++m) { const double x = Ush[gidx[m]]; s2 += x * x; }
-                            s2 = sqrt(s2);
-                            const double pen_g = K.L * GW[gi];
-                            if (K.kind == K_GRP || K.kind == K_SGL) { const double t = 1.0 - pen_g / s2; f = (0.0 < t) ? t : 0.0; }
-                            else if (K.kind == K_GRP_MCP) f = mcp_norm(s2, pen_g, K.D, K.gamma);
-                            else f = scad_norm(s2, pen_g, K.D, K.gamma);
+                            int m, me;
+                            if (first) {
+                                double x[8];
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) x[k] = Ush[gm[k]];              // padding slots read zero words
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) s2 += x[k] * x[k];
+                                m = gme - gcnt + 8; me = gme;
+                            } else { m = gstart[gi]; me = gstart[gi + 1]; }
+                            for (; m < me; ++m) { const double x = Ush[gidx[m]]; s2 += x * x; }
+                            const double pen_g = K.L * (first ? gwt : GW[gi]);
+                            if (K.kind == K_GRP || K.kind == K_SGL) {
+                                // 1 - pen / ||u_g|| with the root and its reciprocal from v_rsq_f64 + Goldschmidt (~10 dependent
+                                // FP64 ops; sqrt followed by a division is ~60), the quotient refined like cdiv; ||u_g|| = 0 => f = 0 (quirk Q6)
+                                double nrm, rn;
+                                sqrt_rsqrt_lane(s2, nrm, rn);
+                                const double t = 1.0 - cdiv(pen_g, nrm, rn);
+                                f = (s2 > 0.0 && 0.0 < t) ? t : 0.0;
+                            } else {
+                                s2 = sqrt(s2);
+                                f = (K.kind == K_GRP_MCP) ? mcp_norm(s2, pen_g, K.D, K.gamma) : scad_norm(s2, pen_g, K.D, K.gamma);
+                            }
                         }
                         F[gi] = f;
                     }
                     __syncthreads();
                 }
+                COOP_STAMP(9);                                      // u read (+ group norms and factors)
                 bool bad = false;
-                double adp = 0.0;
-                const double akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak)), ratio = (ak - 1.0) / akn;
+                double adp = 0.0, akn = 1.0, ratio = 0.0;
+                if (ACC) { akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak)); ratio = (ak - 1.0) / akn; }     // ref src/oem_dense.h:633-651
 #pragma unroll
                 for (int k = 0; k < EPT; ++k) {
                     const int j = tid + NTH * k;
                     double bn;
-                    if (grpk) {
-                        const int gi = valid[k] ? gid[j] : -1;
-                        const double f = gi >= 0 ? F[gi] : 0.0;
-                        bn = (f != 0.0) ? u[k] * f / K.D : 0.0;
-                    } else {
-                        const double tp = pfE[k] * K.L;
-                        if (K.kind == K_SOFT) bn = cdiv(shrink(u[k], tp), K.D, rD);
-                        else if (K.kind == K_MCP) {
-                            const bool big = fabs(u[k]) > gammad * tp;
-                            bn = cdiv(big ? u[k] : shrink(u[k], tp), big ? K.D : dmg, big ? rD : rdmg);
-                        } else if (K.kind == K_SCAD) {
-                            const double au = fabs(u[k]);
-                            const bool big = au > gammad * tp, mid = !big && au > (K.D + 1.0) * tp;
-                            const double num = big ? u[k] : (mid ? shrink(gm1 * u[k], K.gamma * tp) : shrink(u[k], tp));
-                            bn = cdiv(num, mid ? dsc : K.D, mid ? rdsc : rD);
-                        } else bn = cdiv(u[k], d, rd);
-                    }
-                    if (!valid[k]) bn = 0.0;
-                    if (A.accelerate) {                             // ref src/oem_dense.h:633-651
+                    if constexpr (KIND == K_GRP) {
+                        const double f = gidE[k] >= 0 ? F[gidE[k]] : 0.0;
+                        bn = (f != 0.0) ? cdiv(u[k] * f, K.D, c.rD) : 0.0;
+                    } else bn = thr1<KIND>(u[k], tp[k], c);
+                    bn = valid[k] ? bn : 0.0;
+                    if (ACC) {
                         const double upd = bn, diff = upd - bold[k];
                         bn = upd + ratio * diff;
                         adp += (bn - upd) * diff;
                     }
-                    const double c = fabs(bn), qo = fabs(bold[k]);
-                    const bool cn = c > 1e-13, qn = qo > 1e-13;     // ref src/utils.cpp:537-549
-                    bad |= (cn != qn);
-                    bad |= (cn && qn && fabs(bn - bold[k]) > tol * qo);
+                    const double cu = fabs(bn), qo = fabs(bold[k]);
+                    const bool cn = cu > 1e-13, qn = qo > 1e-13;    // ref src/utils.cpp:537-549
+                    bad |= (cn != qn) | (cn & qn & (fabs(bn - bold[k]) > tol * qo));
                     beta[k] = bn;
                     if (valid[k]) Bsh[j] = bn;
                 }
-                if (A.accelerate) {
+                if (ACC) {
                     adp = coop_block_sum(adp, red, rpar, w, lane);
                     ak = (adp > 0.0) ? 1.0 : akn;
                 }
-                const int anybad = __syncthreads_or(bad ? 1 : 0);   // also: Bsh is complete
+                COOP_STAMP(10);                                     // threshold, stop rule
+                // one barrier: Bsh is complete, and every wave's "still moving" word is in place
+                const int mine = (__ballot(bad) != 0ull) ? 1 : 0;
+                if (lane == 0) flagw[w] = mine;
+                __syncthreads();
+                const int anybad = flagw[0] | flagw[1] | flagw[2] | flagw[3];
+                COOP_STAMP(11);                                     // the barrier
                 ++it;
                 const bool conv = !anybad;
-                const bool fin = conv || it >= A.maxit;
-                if (fin) {
-                    if (A.sinv) {                                   // oemXTX::get_beta rescales the member in place (quirk Q5)
+                const bool fin = conv || it >= maxit;
+                if (__builtin_expect(fin, 0)) {
+                    if (has_sinv) {                                 // oemXTX::get_beta rescales the member in place (quirk Q5)
 #pragma unroll
                         for (int k = 0; k < EPT; ++k) { beta[k] *= sinvE[k]; if (valid[k]) Bsh[tid + NTH * k] = beta[k]; }
                         __syncthreads();
@@ -430,15 +557,15 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
 #pragma unroll
                         for (int k = 0; k < EPT; ++k) if (valid[k]) A.beta[orow * q + tid + NTH * k] = beta[k];
                         if (tid == 0) {
-                            A.niter[orow] = conv ? it : A.maxit + 1;                    // ref src/oem_base.h:94-109
-                            if (!A.compute_loss) A.loss[orow] = 1e99;
+                            A.niter[orow] = conv ? it : maxit + 1;                      // ref src/oem_base.h:94-109
+                            if (!want_loss) A.loss[orow] = 1e99;
                         }
                     }
                 }
                 // ---- u = d beta - XX beta + XY: the next iteration's input, or the warm start of the next lambda
                 coop_round<CH, true>(a, bidx, Ush, Bsh, Pc, q, row, rowok, publisher, d, xyR, X, w, lane, tid);
-                if (fin) {
-                    if (A.compute_loss) {
+                if (__builtin_expect(fin, 0)) {
+                    if (want_loss) {
                         // sum (Y - X beta)^2 through the Gram identity (ref src/oem_dense.h:759-770): XX beta = d beta - u + XY
                         double t = 0.0;
 #pragma unroll
@@ -454,7 +581,36 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
                 }
             }
         }
+    };
+    for (int pp = A.pen_lo; pp < A.pen_hi; ++pp) {
+        const int pen = A.penalty[pp];
+        const int kind = pen_consts(pen, 1.0, d, A.alpha, A.gamma, A.tau).kind;
+        using T = std::true_type; using Fa = std::false_type;
+        if (A.accelerate) {
+            switch (kind) {
+            case K_SOFT: lambda_loop(std::integral_constant<int, K_SOFT>{}, T{}, pp, pen); break;
+            case K_MCP: lambda_loop(std::integral_constant<int, K_MCP>{}, T{}, pp, pen); break;
+            case K_SCAD: lambda_loop(std::integral_constant<int, K_SCAD>{}, T{}, pp, pen); break;
+            case K_OLS: lambda_loop(std::integral_constant<int, K_OLS>{}, T{}, pp, pen); break;
+            default: lambda_loop(std::integral_constant<int, K_GRP>{}, T{}, pp, pen); break;
+            }
+        } else {
+            switch (kind) {
+            case K_SOFT: lambda_loop(std::integral_constant<int, K_SOFT>{}, Fa{}, pp, pen); break;
+            case K_MCP: lambda_loop(std::integral_constant<int, K_MCP>{}, Fa{}, pp, pen); break;
+            case K_SCAD: lambda_loop(std::integral_constant<int, K_SCAD>{}, Fa{}, pp, pen); break;
+            case K_OLS: lambda_loop(std::integral_constant<int, K_OLS>{}, Fa{}, pp, pen); break;
+            default: lambda_loop(std::integral_constant<int, K_GRP>{}, Fa{}, pp, pen); break;
+            }
+        }
     }
+#ifdef OEM_PATH_DIAG
+    if (tid == 0 && writer) {
+        for (int k = 0; k < 6; ++k) g_diag_coop[8 + k] = X.acc[k];
+        g_diag_coop[14] = X.acc[8];
+        g_diag_coop[0] = X.acc[9]; g_diag_coop[1] = X.acc[10]; g_diag_coop[2] = X.acc[11];      // (overwrites the Lanczos slots 0..2)
+    }
+#endif
     if (tid == 0 && writer) {
         A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
         A.d_out[3] = (double)(__builtin_amdgcn_s_memrealtime() - t_rt0);
@@ -463,6 +619,13 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
 }
 
 }  // namespace
+
+#ifdef OEM_PATH_DIAG
+extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read_coop(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_coop), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 size_t path_coop_xchg_bytes() { return (size_t)2 * 1024 * 2 * sizeof(unsigned long long); }
 

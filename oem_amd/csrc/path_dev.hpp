@@ -149,5 +149,42 @@ template <int K> struct BcFma {
         asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(a), "n"(K));
     }
 };
+// s = sqrt(x), r = 1 / sqrt(x) for the Lanczos normalisation: v_rsq_f64 + two coupled Goldschmidt steps (~10
+// dependent FP64 ops; the library sqrt followed by a division is ~45).  Outside [1e-200, 1e200] the slow pair.
+__device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &r)
+{
+    // x is the same in every lane; the test is made wave-uniform so that it is ONE untaken scalar branch
+    if (__builtin_expect(__all(x > 1e-200 && x < 1e200), 1)) {
+        const double y = __builtin_amdgcn_rsq(x);
+        double g = x * y, h = 0.5 * y;
+        double e = fma(-h, g, 0.5);
+        g = fma(g, e, g); h = fma(h, e, h);
+        e = fma(-h, g, 0.5);
+        g = fma(g, e, g); h = fma(h, e, h);
+        e = fma(-g, g, x);                                         // last correction of the root
+        g = fma(e, h, g);
+        s = g; r = 2.0 * h;
+    } else {
+        s = sqrt(x); r = 1.0 / s;
+    }
+}
+// the same per lane (x differs between lanes: no wave-uniform fast-path test)
+__device__ __forceinline__ void sqrt_rsqrt_lane(double x, double &s, double &r)
+{
+    if (x > 1e-200 && x < 1e200) {
+        const double y = __builtin_amdgcn_rsq(x);
+        double g = x * y, h = 0.5 * y;
+        double e = fma(-h, g, 0.5);
+        g = fma(g, e, g); h = fma(h, e, h);
+        e = fma(-h, g, 0.5);
+        g = fma(g, e, g); h = fma(h, e, h);
+        e = fma(-g, g, x);
+        g = fma(e, h, g);
+        s = g; r = 2.0 * h;
+    } else {
+        s = sqrt(x); r = 1.0 / s;
+    }
+}
+
 }  // namespace
 }  // namespace oemgpu

@@ -850,25 +850,6 @@ __device__ __forceinline__ double rows_sum(double v)
     auto h1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
     return __hiloint2double((int)h1[0], (int)l1[0]) + __hiloint2double((int)h1[1], (int)l1[1]);
 }
-// s = sqrt(x), r = 1 / sqrt(x) for the Lanczos normalisation: v_rsq_f64 + two coupled Goldschmidt steps (~10
-// dependent FP64 ops; the library sqrt followed by a division is ~45).  Outside [1e-200, 1e200] the slow pair.
-__device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &r)
-{
-    // x is the same in every lane; the test is made wave-uniform so that it is ONE untaken scalar branch
-    if (__builtin_expect(__all(x > 1e-200 && x < 1e200), 1)) {
-        const double y = __builtin_amdgcn_rsq(x);
-        double g = x * y, h = 0.5 * y;
-        double e = fma(-h, g, 0.5);
-        g = fma(g, e, g); h = fma(h, e, h);
-        e = fma(-h, g, 0.5);
-        g = fma(g, e, g); h = fma(h, e, h);
-        e = fma(-g, g, x);                                         // last correction of the root
-        g = fma(e, h, g);
-        s = g; r = 2.0 * h;
-    } else {
-        s = sqrt(x); r = 1.0 / s;
-    }
-}
 // p0 / p1: this row group's slice sums of row slots 0 / 1.  Returns the sum over the four row groups of slot (g & 1).
 __device__ __forceinline__ double rowgroup_reduce_scatter(double p0, double p1)
 {
