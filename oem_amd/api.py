@@ -98,6 +98,15 @@ class _Args:
         self.nl = nlu if nlu > 0 else int(nlambda)
         self.npen = len(self.pen)
 
+    def subset(self, idx):
+        """the penalties idx of this call as a call of their own (penalties are independent cold starts,
+        ref src/oem_dense.cpp:206-246): same options, their rows of a user-supplied lambda"""
+        o = self.c
+        sub = _Args([PENALTIES[self.pen[k]] for k in idx], [] if self.lam is None else [self.lam[k] for k in idx], o.nlambda,
+                    o.lambda_min_ratio, o.alpha, o.gamma, o.tau, o.tol, o.maxit, o.accelerate, o.compute_loss, self.pf,
+                    self.groups, self.ug, self.gw, device=o.device)
+        return sub
+
     def outputs(self, rows):
         self.beta = np.zeros((self.npen, self.nl, rows))
         self.lam_out = np.zeros((self.npen, self.nl))

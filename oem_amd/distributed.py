@@ -96,18 +96,72 @@ def sharded_buffers(backend, p):
     return backend.new_buffer(L.sums_len(p)), backend.new_buffer(L.moments_len(p))
 
 
-def solve_row_shards(backend, dist, group, x, n_local, ld, p, y, bufs, semantics, standardize, intercept, args, outs=None):
+SMALL_P_MAX = 288          # csrc/common.hpp: up to here ONE launch walks all penalties side by side on one GPU
+
+
+def _split_solve(backend, dist, group, mom, sums, p, semantics, standardize, intercept, args, outs):
+    """Penalties dealt round-robin to the ranks ("lambda loop"): rank r solves penalties r, r + N, ... from the
+    reduced moments every rank holds, then ONE all-gather assembles the result on every rank.  Penalties are independent cold
+    starts (ref src/oem_dense.cpp:206-246), so nothing else crosses ranks.  A rank beyond the number of penalties repeats one
+    (its copy is dropped): every rank runs a solve and so sees the shift verdict of the reduced moments."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    npen, nl, rows = args.npen, args.nl, p + 1
+    mine = list(range(rank, npen, world)) if rank < npen else [rank % npen]
+    sub = args.subset(mine)
+    backend.solve(mom, sums, p, semantics, standardize, intercept, sub)
+    per = nl * rows + 3 * nl                                  # beta | lambda | niter | loss of one penalty
+    slots = (npen + world - 1) // world
+    buf = backend.new_buffer(slots * per + 1)
+    flat = np.zeros(slots * per + 1)
+    for s_, k in enumerate(mine if rank < npen else []):
+        o = s_ * per
+        flat[o:o + nl * rows] = sub.beta[s_].ravel()
+        flat[o + nl * rows:o + nl * rows + nl] = sub.lam_out[s_]
+        flat[o + nl * rows + nl:o + nl * rows + 2 * nl] = sub.niter[s_]
+        flat[o + nl * rows + 2 * nl:o + per] = sub.loss[s_]
+    flat[-1] = sub.d.value
+    import torch
+    buf.copy_(torch.from_numpy(flat))
+    parts = [backend.new_buffer(slots * per + 1) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    if outs is None:
+        args.outputs(rows)
+    for r in range(min(world, npen)):
+        got = parts[r].cpu().numpy()
+        for s_, k in enumerate(range(r, npen, world)):
+            o = s_ * per
+            args.beta[k] = got[o:o + nl * rows].reshape(nl, rows)
+            args.lam_out[k] = got[o + nl * rows:o + nl * rows + nl]
+            args.niter[k] = np.rint(got[o + nl * rows + nl:o + nl * rows + 2 * nl]).astype(np.int32)
+            args.loss[k] = got[o + nl * rows + 2 * nl:o + per]
+    args.d.value = float(parts[0].cpu().numpy()[-1])
+
+
+def solve_row_shards(backend, dist, group, x, n_local, ld, p, y, bufs, semantics, standardize, intercept, args, outs=None,
+                     split_penalties=None):
     """The local stages and the collective between them (module docstring); call inside backend.section().
-    Every rank ends with the full result in `args`."""
+    Every rank ends with the full result in `args`.
+    split_penalties: None = when it pays (several penalties on the engines that walk them one after the other: p + intercept
+    column > SMALL_P_MAX); True / False force it."""
     sums, mom = bufs
     many = dist is not None and dist.get_world_size(group) > 1
+    q = p + (1 if (semantics != L.OEMGPU_SEM_DENSE and intercept) else 0)
+    if split_penalties is None:
+        split_penalties = q > SMALL_P_MAX
+    split = many and args.npen > 1 and split_penalties
+
+    def solve(sm):
+        if split:
+            _split_solve(backend, dist, group, mom, sm, p, semantics, standardize, intercept, args, outs)
+        else:
+            backend.solve(mom, sm, p, semantics, standardize, intercept, args, outs)
     if not many and semantics == L.OEMGPU_SEM_DENSE and hasattr(backend, "fit_dense") and not _STAGED_ALWAYS:
         backend.fit_dense(x, n_local, ld, p, y, standardize, intercept, args, outs)      # one rank: the drop-in entry point does it all
         return
     backend.moments(x, n_local, ld, p, y, None, mom)              # about c = 0: the usual verdict
     if many:
         dist.all_reduce(mom, group=group)                         # the single Gram all-reduce of the north star
-    backend.solve(mom, None, p, semantics, standardize, intercept, args, outs)
+    solve(None)
     if backend.shift_advised():                                   # same reduced moments on every rank: all redo or none
         backend.shift_sums(x, n_local, ld, p, y, sums)
         if many:
@@ -115,14 +169,16 @@ def solve_row_shards(backend, dist, group, x, n_local, ld, p, y, bufs, semantics
         backend.moments(x, n_local, ld, p, y, sums, mom)
         if many:
             dist.all_reduce(mom, group=group)
-        backend.solve(mom, sums, p, semantics, standardize, intercept, args, outs)
+        solve(sums)
 
 
 def oem_sharded(x_local, y_local, backend=None, dist=None, group=None, big=False, penalty=None, lambda_=(),
                 nlambda=100, lambda_min_ratio=None, alpha=1.0, gamma=3.0, tau=0.5, groups=(), penalty_factor=None,
                 group_weights=None, standardize=True, intercept=True, maxit=500, tol=1e-7, accelerate=False,
-                compute_loss=False, varnames=None):
+                compute_loss=False, varnames=None, split_penalties=None, n_total=None):
     """oem() (big=False: DataStd + oemDense semantics) or big.oem() (big=True) on row shards.
+    n_total: the global number of rows if the caller knows it (the default lambda.min.ratio depends on n < p, R/oem.R:348-354);
+    otherwise one tiny all-reduce of the local row counts finds it.
 
     x_local: this rank's rows as a column-major device matrix (torch tensor of shape (n_local, p) with
     stride (1, ld)); y_local: its responses.  Every rank returns the full OemFit.
@@ -136,8 +192,19 @@ def oem_sharded(x_local, y_local, backend=None, dist=None, group=None, big=False
     if penalty_factor is None:
         penalty_factor = np.ones(p)
     g, ug, gw = _api._group_setup(penalty, groups, group_weights, p, bool(big and intercept))
+    many = dist is not None and dist.get_world_size(group) > 1
+    if n_total is None:
+        n_total = int(n_local)
+        if many and (lambda_min_ratio is None or big):           # the default grid and big.oem's n > p + intercept test need the GLOBAL n
+            t = backend.new_buffer(1)
+            t += float(n_local)
+            with backend.section():
+                dist.all_reduce(t, group=group)
+            n_total = int(round(float(t.cpu()[0])))
     if lambda_min_ratio is None:
-        lambda_min_ratio = 0.0001
+        lambda_min_ratio = 0.01 if n_total < p else 0.0001        # R/oem.R:348-354, R/big_oem.R:206-212
+    if big and n_total <= p + (1 if intercept else 0):
+        raise L.OemgpuError(-4, "p >= n: the XXt branch (ref src/oem_big.h:547-551) is not part of this path")
     _api._common_checks(nlambda, float(lambda_min_ratio), maxit, 1, tol, 0.0)
     args = _api._Args(penalty, _api._lambda_list(lambda_, len(penalty)), int(nlambda), lambda_min_ratio, alpha, gamma,
                       tau, tol, maxit, accelerate and not big, compute_loss, np.asarray(penalty_factor, dtype=np.float64),
@@ -145,11 +212,10 @@ def oem_sharded(x_local, y_local, backend=None, dist=None, group=None, big=False
     with backend.section():                        # kernels and collectives on one stream (see HipBackend)
         bufs = sharded_buffers(backend, p)
         solve_row_shards(backend, dist, group, x_local, n_local, ld, p, y_local, bufs,
-                         L.OEMGPU_SEM_BIG if big else L.OEMGPU_SEM_DENSE, standardize, intercept, args)
-        if dist is not None and dist.get_world_size(group) > 1:
+                         L.OEMGPU_SEM_BIG if big else L.OEMGPU_SEM_DENSE, standardize, intercept, args,
+                         split_penalties=split_penalties)
+        if many:
             n_total = int(round(float(bufs[1].reshape(p + 2, p + 2)[p + 1, p + 1])))      # the reduced row count
-        else:
-            n_total = int(n_local)
     if varnames is None:
         varnames = [f"V{i + 1}" for i in range(p)]
     return _api._decorate(args, penalty, varnames, True, n_total, p)

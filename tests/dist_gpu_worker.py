@@ -69,6 +69,20 @@ for case in range(14):
         ok &= err < 1e-8 * max(1.0, float(np.abs(ref2["beta"][k]).max()))
         ok &= bool(np.abs(np.ravel(fit2["niter"][k]).astype(int) - np.ravel(ref2["niter"][k]).astype(int)).max() <= 1)
     ok &= fit2["nobs"] == n2
+# p > 288 with several penalties: the penalties are dealt round-robin to the ranks (one all-gather assembles the fit) -- the
+# same numbers as every rank solving everything, and as the one-process fit
+p3, n3 = 320, 4000
+xh = rng.normal(size=(n3, p3)); yh = xh[:, :5] @ np.array([1.0, -1.0, 0.5, 2.0, -0.7]) + rng.normal(size=n3)
+kw3 = dict(penalty=["lasso", "grp.lasso", "mcp", "scad"], groups=np.arange(p3) // 4 + 1, nlambda=6, tol=1e-9, maxit=1000)
+xfull = torch.as_tensor(np.ascontiguousarray(xh.T), device="cuda"); yfull = torch.as_tensor(yh, device="cuda")
+lo3, hi3 = row_partition(n3, world)[rank]
+xl3, yl3 = xfull[:, lo3:hi3].contiguous().t(), yfull[lo3:hi3].contiguous()
+dealt = oem_sharded(xl3, yl3, backend=be, dist=dist, **kw3)
+whole3 = oem_sharded(xl3, yl3, backend=be, dist=dist, split_penalties=False, **kw3)
+ref3 = oem_amd.oem(np.asfortranarray(xh), yh, **kw3)
+for k in range(4):
+    ok &= bool(np.array_equal(dealt["beta"][k], whole3["beta"][k]) and np.array_equal(dealt["niter"][k], whole3["niter"][k]))
+    ok &= float(np.abs(dealt["beta"][k] - ref3["beta"][k]).max()) < 1e-8
 if rank == 0:
     print("DIST_GPU_OK" if ok else "DIST_GPU_MISMATCH", flush=True)
 dist.destroy_process_group()

@@ -44,6 +44,21 @@ def _worker(rank, world, port, q):
             fit = oem_sharded(xl, yl, backend=backend, dist=dist, penalty=["lasso", "mcp"], nlambda=12, tol=1e-10,
                               standardize=std, intercept=icpt)
             out[(offset, std, icpt)] = (fit["beta"], fit["lambda"], fit["d"], fit["nobs"], backend.shifted, backend.passes)
+    # penalties dealt round-robin to the ranks (forced: the CPU stand-in has no size at which it would pay), three penalties on
+    # two ranks -- and one penalty fewer than ranks would be the `rank >= npen` branch, covered with world 2 by npen = 1 + force
+    x, y = _data(offset=1.0)
+    lo, hi = row_partition(x.shape[0], world)[rank]
+    xl = torch.from_numpy(np.ascontiguousarray(x[lo:hi].T)).t()
+    yl = torch.from_numpy(y[lo:hi].copy())
+    lam = [np.geomspace(1.0, 0.01, 7) * s for s in (1.0, 0.8, 1.3)]
+    for key, pens, lams in (("split3", ["lasso", "mcp", "scad"], lam), ("split_default_grid", ["lasso", "elastic.net", "mcp"], ())):
+        res = []
+        for split in (True, False):
+            backend = CheckerBackend()
+            fit = oem_sharded(xl, yl, backend=backend, dist=dist, penalty=pens, lambda_=lams, nlambda=7, alpha=0.6, tol=1e-10,
+                              split_penalties=split)
+            res.append((fit["beta"], fit["lambda"], fit["niter"], fit["d"]))
+        out[key] = res
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -70,6 +85,12 @@ def test_sharded_equals_unsharded_world2():
     for pr in procs:
         pr.join(timeout=60)
         assert pr.exitcode == 0
+    for key in ("split3", "split_default_grid"):
+        for r in (0, 1):
+            (bs, ls, ns, ds), (bw, lw, nw, dw) = got[r].pop(key)
+            assert ds == dw
+            for k in range(3):                                              # dealt to the ranks == every rank solves everything
+                assert np.array_equal(bs[k], bw[k]) and np.array_equal(ls[k], lw[k]) and np.array_equal(ns[k], nw[k]), (key, r, k)
     for key in got[0]:
         offset, std, icpt = key
         x, y = _data(offset=offset)
