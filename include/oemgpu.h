@@ -125,7 +125,7 @@ int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t
  * beta, lambda_out, niter, loss, d: the fit on ALL rows, laid out as in oemgpu_fit_dense (loss only if compute_loss,
  * ref :296-301).  cvm, cvsd: npen * nl each -- mean over the n observations of the error of row i under the fit that
  * left row i's fold out, and sqrt(sample variance / n) of the same (ref :452-461; 0 beyond the single "ols" entry). */
-int oemgpu_xval_dense(const double *x, int64_t n, int32_t p, const double *y, const int32_t *foldid, int32_t nfolds,
+int oemgpu_xval_dense(const double *x, int64_t n, int32_t p, const double *y, const double *weights, const int32_t *foldid, int32_t nfolds,
                       int32_t standardize, int32_t intercept, int32_t type_measure, const oemgpu_opts *o,
                       double *beta, double *lambda_out, int32_t *niter, double *loss, double *d,
                       double *cvm, double *cvsd);
@@ -199,9 +199,9 @@ int oemgpu_fit_xtx_dev(oemgpu_ctx *ctx, const double *xtx_dev, const double *xty
  * usual data costs one pass and one collective, with no sample pass in front. */
 int oemgpu_last_shift_advised(oemgpu_ctx *ctx);
 
-/* oemgpu_xval_dense with X (n x p, leading dimension ld >= n), y and foldid already on the device. */
+/* oemgpu_xval_dense with X (n x p, leading dimension ld >= n), y, weights and foldid already on the device. */
 int oemgpu_xval_dense_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
-                          const int32_t *foldid_dev, int32_t nfolds, int32_t standardize, int32_t intercept,
+                          const double *weights_dev /* or NULL */, const int32_t *foldid_dev, int32_t nfolds, int32_t standardize, int32_t intercept,
                           int32_t type_measure, const oemgpu_opts *o,
                           double *beta, double *lambda_out, int32_t *niter, double *loss, double *d,
                           double *cvm, double *cvsd);

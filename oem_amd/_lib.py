@@ -65,9 +65,9 @@ _SIGS = {
     "oemgpu_last_shift_advised": (C.c_int, [C.c_void_p]),
     "oemgpu_fit_sparse": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                     C.POINTER(OemgpuOpts)] + _OUT),
-    "oemgpu_xval_dense": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+    "oemgpu_xval_dense": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.POINTER(OemgpuOpts)] + _OUT + [_dp, _dp]),
-    "oemgpu_xval_dense_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+    "oemgpu_xval_dense_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_int32, C.POINTER(OemgpuOpts)] + _OUT + [_dp, _dp]),
     "oemgpu_eig_max_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, _dp]),
     "oemgpu_last_timings": (C.c_int, [C.c_void_p, _dp]),

@@ -468,8 +468,11 @@ def xval_oem(x, y, nfolds=10, foldid=None, type_measure=None, ncores=-1, family=
     ylen = y.shape[0] if hasattr(y, "shape") else len(y)
     if ylen != n or len(foldid) != n:
         raise ValueError("x and y lengths do not match")
-    if len(weights) > 0:
-        raise NotImplementedError("observation weights in xval.oem (ref src/oem_xval_dense.h:486-623) are outside the built path")
+    wh = None
+    if len(weights) > 0:                                         # R/oem_xval.R:216-223
+        if len(weights) != n:
+            raise ValueError("length of weights not same as number of observations in x")
+        wh = np.ascontiguousarray(np.asarray(weights, dtype=np.float64).reshape(-1))
     if penalty_factor is None:
         penalty_factor = np.ones(p)
     if varnames is None:
@@ -502,15 +505,18 @@ def xval_oem(x, y, nfolds=10, foldid=None, type_measure=None, ncores=-1, family=
         yd = y if _is_torch_cuda(y) else torch.as_tensor(np.asarray(y, dtype=np.float64), device=x.device)
         yd = yd.to(torch.float64).contiguous().reshape(-1)
         fd = torch.as_tensor(fid, device=x.device)
+        wd = None if wh is None else torch.as_tensor(wh, device=x.device)
         ctx = context(x.device.index)
         torch.cuda.current_stream(x.device).synchronize()
-        L.check(lib.oemgpu_xval_dense_dev(ctx, xp, n, ld, p, yd.data_ptr(), fd.data_ptr(), int(nfolds), int(bool(standardize)),
+        L.check(lib.oemgpu_xval_dense_dev(ctx, xp, n, ld, p, yd.data_ptr(), None if wd is None else wd.data_ptr(), fd.data_ptr(),
+                                          int(nfolds), int(bool(standardize)),
                                           int(bool(intercept)), tm, C.byref(a.c), *out, _dptr(cvm), _dptr(cvsd)))
         del keep
     else:
         xh = np.asfortranarray(x, dtype=np.float64)
         yh = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
-        L.check(lib.oemgpu_xval_dense(_dptr(xh), n, p, _dptr(yh), _iptr(fid), int(nfolds), int(bool(standardize)),
+        L.check(lib.oemgpu_xval_dense(_dptr(xh), n, p, _dptr(yh), None if wh is None else _dptr(wh), _iptr(fid), int(nfolds),
+                                      int(bool(standardize)),
                                       int(bool(intercept)), tm, C.byref(a.c), *out, _dptr(cvm), _dptr(cvsd)))
     res = _decorate(a, penalty, varnames, True, n, p)
     res["cvm"] = [cvm[k, :1].copy() if name == "ols" else cvm[k].copy() for k, name in enumerate(penalty)]

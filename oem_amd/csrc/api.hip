@@ -775,9 +775,12 @@ static __global__ void csc_densify_kernel(const int64_t *__restrict__ colptr, co
 
 // nbatch moment buffers (instance b at moments + b * mstride, all OUTSIDE the context workspace), one finalize each, then ONE
 // launch that walks all their paths side by side (q <= SMALL_P_MAX).  Outputs as in run_paths.
+// cs != nullptr: observation weights -- the moments are those of the p + 1 data columns [sqrt(w) | sqrt(w) X] ((p + 3)^2 each) and
+// cs holds the unweighted column sums of squares and the row count of every instance (launch_finalize_weighted).
 static int solve_moments_batch(oemgpu_ctx *c, const double *moments, size_t mstride, int nbatch, int32_t p, int32_t semantics,
                                int32_t standardize, int32_t intercept, const oemgpu_opts *o,
-                               double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, bool shared_lmax)
+                               double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, bool shared_lmax,
+                               const double *cs = nullptr, size_t cstride = 0)
 {
     const int q = p + ((semantics != OEMGPU_SEM_DENSE && intercept) ? 1 : 0);
     Bump B;
@@ -787,8 +790,10 @@ static int solve_moments_batch(oemgpu_ctx *c, const double *moments, size_t mstr
     const size_t o_xy = ((size_t)q * q * 8 + 255) / 256 * 256, o_st = o_xy + ((size_t)q * 8 + 255) / 256 * 256;
     for (int b = 0; b < nbatch; ++b) {
         char *f = c->ws + a_0 + per * b;
-        int rc = launch_finalize(c->stream, moments + mstride * b, nullptr, p, semantics, standardize, intercept, (double *)f,
-                                 (double *)(f + o_xy), (double *)(f + o_st));
+        int rc = cs ? launch_finalize_weighted(c->stream, moments + mstride * b, cs + cstride * b, p, standardize, intercept, (double *)f,
+                                               (double *)(f + o_xy), (double *)(f + o_st))
+                    : launch_finalize(c->stream, moments + mstride * b, nullptr, p, semantics, standardize, intercept, (double *)f,
+                                      (double *)(f + o_xy), (double *)(f + o_st));
         if (rc) return rc;
     }
     char *f0 = c->ws + a_0;
@@ -807,7 +812,7 @@ static int ctx_aux(oemgpu_ctx *c, size_t bytes)
 }
 
 int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
-                          const int32_t *foldid_dev, int32_t nfolds, int32_t standardize, int32_t intercept,
+                          const double *w_dev, const int32_t *foldid_dev, int32_t nfolds, int32_t standardize, int32_t intercept,
                           int32_t type_measure, const oemgpu_opts *o,
                           double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, double *cvm, double *cvsd)
 {
@@ -822,16 +827,25 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t
     if (n < 1 || ld < n) { set_error("xval_dense: bad n / ld"); return OEMGPU_ERR_ARG; }
     if (n <= p) { set_error("dimension of x larger than number of observations"); return OEMGPU_ERR_UNSUPPORTED; }   // ref src/oem_xval_dense.h:690-731
     if (n + 16 * (int64_t)K >= (int64_t)1 << 31) { set_error("xval_dense: n too large for 32-bit row positions"); return OEMGPU_ERR_UNSUPPORTED; }
+    if (w_dev && o->compute_loss) {
+        set_error("compute.loss with observation weights: the reference's loss is the unweighted residual sum (src/oem_xval_dense.h:1122-1145), "
+                  "which the weighted Gram does not hold");
+        return OEMGPU_ERR_UNSUPPORTED;
+    }
     if (set_device(c)) return OEMGPU_ERR_HIP;
     const int nl = nl_of(o), npen = o->npen;
     const int64_t ldp = (n + 16 * (int64_t)K + 15) / 16 * 16;
-    const size_t mlen = (size_t)oemgpu_moments_len(p);
+    // observation weights: the fold-ordered copy gets a leading column sqrt(w) and everything is scaled by sqrt(w), so the moment
+    // kernels see pm = p + 1 data columns and their Gram IS X'WX with its intercept border (ref src/oem_xval_dense.h:486-623)
+    const int pm = p + (w_dev ? 1 : 0);
+    const size_t mlen = (size_t)oemgpu_moments_len(pm), cslen = (size_t)p + 1;
     const int nwg = cv_wg_per_fold(n, K, npen, c->num_cu);
     // the largest moment plan over the folds is bounded by the plan of all n rows
-    const GramPlan plmax = gram_plan(n, p, c->num_cu);
+    const GramPlan plmax = gram_plan(n, pm, c->num_cu);
     Bump A;
+    const size_t a_cs = A.take(sizeof(double) * cslen * (2 * (size_t)K + 1));      // per fold, then all folds / all but fold ff
     const size_t a_cnt = A.take(fold_layout_ints(n, K) * sizeof(int)), a_fn = A.take(sizeof(int64_t) * 2 * K), a_bad = A.take(256),
-                 a_pos = A.take(sizeof(int) * (size_t)n), a_xp = A.take(sizeof(double) * (size_t)ldp * p),
+                 a_pos = A.take(sizeof(int) * (size_t)n), a_xp = A.take(sizeof(double) * (size_t)ldp * pm),
                  a_yp = A.take(sizeof(double) * (size_t)ldp), a_mf = A.take(sizeof(double) * mlen * K),
                  a_mc = A.take(sizeof(double) * mlen), a_ms = A.take(sizeof(double) * mlen * (K + 1)), a_t = A.take(plmax.tpart_doubles * 8 * 2), a_v = A.take(plmax.vpart_doubles * 8 * 2),
                  a_b = A.take(sizeof(double) * (size_t)K * npen * nl * (p + 1)),
@@ -850,7 +864,12 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t
     int hbad = 0;
     OEM_HIP(hipMemcpyAsync(hf.data(), fold_n, sizeof(int64_t) * 2 * K, hipMemcpyDeviceToHost, c->stream));
     OEM_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    rc = launch_gather_rows(c->stream, x_dev, n, ld, p, y_dev, pos, xp, ldp, yp);
+    double *csq = (double *)(ax + a_cs), *cssum = csq + cslen * K;
+    if (w_dev) {
+        rc = launch_gather_rows(c->stream, w_dev, n, n, 1, y_dev, pos, xp, ldp, yp);               // column 0 <- w
+        if (!rc) rc = launch_gather_rows(c->stream, x_dev, n, ld, p, y_dev, pos, xp + ldp, ldp, yp);
+        if (!rc) rc = launch_weight_scale(c->stream, xp, ldp, yp, p, K, fold_start, fold_n, csq);
+    } else rc = launch_gather_rows(c->stream, x_dev, n, ld, p, y_dev, pos, xp, ldp, yp);
     if (rc) return rc;
     OEM_HIP(hipStreamSynchronize(c->stream));
     if (hbad) { set_error("xval_dense: foldid must hold values in 1..nfolds"); return OEMGPU_ERR_ARG; }
@@ -859,7 +878,7 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t
         const int64_t nk = hf[k], st = hf[K + k];
         if (n - nk <= p) { set_error("dimension of x larger than number of observations"); return OEMGPU_ERR_UNSUPPORTED; }  // ref :849-852
         if (nk == 0) { OEM_HIP(hipMemsetAsync(mfold + mlen * k, 0, sizeof(double) * mlen, c->stream)); continue; }
-        const GramPlan pl = gram_plan(nk, p, c->num_cu);
+        const GramPlan pl = gram_plan(nk, pm, c->num_cu);
         if (pl.tpart_doubles > 2 * plmax.tpart_doubles || pl.vpart_doubles > 2 * plmax.vpart_doubles) {
             set_error("internal: fold plan larger than its scratch"); return OEMGPU_ERR_INTERNAL;
         }
@@ -872,6 +891,7 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t
     double *msum = (double *)(ax + a_ms);                        // [K + 1]: all folds, then all but fold ff
     for (int ff = 0; ff <= K; ++ff) {
         rc = launch_fold_sum(c->stream, mfold, K, mlen, ff, msum + mlen * ff);
+        if (!rc && w_dev) rc = launch_fold_sum(c->stream, csq, K, cslen, ff, cssum + cslen * ff);
         if (rc) return rc;
     }
     if (q <= SMALL_P_MAX) {
@@ -881,7 +901,7 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t
         std::vector<double> ab(blen * (K + 1)), al(nk2 * (K + 1)), aloss(nk2 * (K + 1)), ad(K + 1);
         std::vector<int32_t> an(nk2 * (K + 1));
         rc = solve_moments_batch(c, msum, mlen, K + 1, p, OEMGPU_SEM_XVAL, standardize, intercept, o, ab.data(), al.data(), an.data(),
-                                 aloss.data(), ad.data(), true);
+                                 aloss.data(), ad.data(), true, w_dev ? cssum : nullptr, cslen);
         if (rc) return rc;
         memcpy(beta, ab.data(), sizeof(double) * blen);
         memcpy(lambda_out, al.data(), sizeof(double) * nk2);
@@ -889,6 +909,22 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t
         memcpy(loss, aloss.data(), sizeof(double) * nk2);       // the reference reports the loss of the full fit only (ref :296-301)
         *d = ad[0];
         memcpy(hb.data(), ab.data() + blen, sizeof(double) * blen * K);
+    } else if (w_dev) {
+        // weighted and beyond one launch's size: the K + 1 fits one after the other on this context (each a cooperating-workgroup
+        // or launch-per-iteration solve of its own), the folds on the full fit's lambdas
+        rc = solve_moments_batch(c, msum, mlen, 1, p, OEMGPU_SEM_XVAL, standardize, intercept, o, beta, lambda_out, niter, loss, d, false,
+                                 cssum, cslen);
+        if (rc) return rc;
+        oemgpu_opts of = *o;
+        of.lambda_user = lambda_out; of.nlambda_user = nl; of.compute_loss = 0;
+        std::vector<double> hl(nk2), hloss(nk2);
+        std::vector<int32_t> hn(nk2);
+        double hd = 0.0;
+        for (int ff = 1; ff <= K; ++ff) {
+            rc = solve_moments_batch(c, msum + mlen * ff, mlen, 1, p, OEMGPU_SEM_XVAL, standardize, intercept, &of, hb.data() + blen * (ff - 1),
+                                     hl.data(), hn.data(), hloss.data(), &hd, false, cssum + cslen * ff, cslen);
+            if (rc) return rc;
+        }
     } else {
         rc = oemgpu_solve_moments_dev(c, msum, nullptr, p, OEMGPU_SEM_XVAL, standardize, intercept, o, beta, lambda_out, niter, loss, d);
         if (rc) return rc;
@@ -925,7 +961,7 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t
     }
     // ---- per-observation error of every row under the fit that left its fold out (ref src/oem_xval_dense.cpp:343-461)
     OEM_HIP(hipMemcpyAsync(bdev, hb.data(), sizeof(double) * blen * K, hipMemcpyHostToDevice, c->stream));
-    rc = launch_cv_error(c->stream, xp, ldp, yp, fold_start, fold_n, K, p, bdev, npen, nl, type_measure, nwg, (double)n, part, cvout);
+    rc = launch_cv_error(c->stream, xp, ldp, yp, fold_start, fold_n, K, p, bdev, npen, nl, type_measure, w_dev ? 1 : 0, nwg, (double)n, part, cvout);
     if (rc) { if (rc == OEMGPU_ERR_UNSUPPORTED) set_error("xval_dense: p too large for the CV-error kernel's LDS tile"); return rc; }
     std::vector<double> hc(2 * (size_t)npen * nl);
     OEM_HIP(hipMemcpyAsync(hc.data(), cvout, sizeof(double) * hc.size(), hipMemcpyDeviceToHost, c->stream));
@@ -941,7 +977,7 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t
     return 0;
 }
 
-int oemgpu_xval_dense(const double *x, int64_t n, int32_t p, const double *y, const int32_t *foldid, int32_t nfolds,
+int oemgpu_xval_dense(const double *x, int64_t n, int32_t p, const double *y, const double *weights, const int32_t *foldid, int32_t nfolds,
                       int32_t standardize, int32_t intercept, int32_t type_measure, const oemgpu_opts *o,
                       double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, double *cvm, double *cvsd)
 {
@@ -955,11 +991,19 @@ int oemgpu_xval_dense(const double *x, int64_t n, int32_t p, const double *y, co
     int64_t ld = 0;
     rc = host_upload_resident(c, x, n, p, y, o, &xd, &ld, &yd);      // staged through the pinned lanes, leaves room for foldid behind y
     int32_t *fd = (int32_t *)(yd + ((n + 2 + 31) / 32 * 32));
+    double *wd = nullptr;
     if (!rc) {
         hipError_t e = hipMemcpyAsync(fd, foldid, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) { set_error("upload of foldid failed: %s", hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; }
     }
-    if (!rc) rc = oemgpu_xval_dense_dev(c, xd, n, ld, p, yd, fd, nfolds, standardize, intercept, type_measure, o, beta, lambda_out,
+    if (!rc && weights) {                                            // n doubles in the accumulator buffer of the host path (grow-only)
+        rc = ctx_grow(c, &c->acc, &c->acc_bytes, sizeof(double) * (size_t)(n + 2));
+        wd = (double *)c->acc;
+        if (!rc && hipMemcpyAsync(wd, weights, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+            set_error("upload of the weights failed"); rc = OEMGPU_ERR_HIP;
+        }
+    }
+    if (!rc) rc = oemgpu_xval_dense_dev(c, xd, n, ld, p, yd, wd, fd, nfolds, standardize, intercept, type_measure, o, beta, lambda_out,
                                         niter, loss, d, cvm, cvsd);
     (void)hipStreamSynchronize(c->stream);
     ctx_release(c);

@@ -110,6 +110,69 @@ __global__ __launch_bounds__(256) void fold_sum_kernel(const double *__restrict_
     out[t] = s;
 }
 
+// ---------------------------------------------------------------------------------------- observation weights
+// xp: the fold-ordered copy with p + 1 columns, column 0 = w (gathered), columns 1..p = x (gathered); yp = y (gathered).
+// Workgroup (j, k): column j (1..p: x_j; p + 1: y) over the rows of fold k -- the UNWEIGHTED sum of squares of an x column (the
+// reference does not standardise with respect to the weights, ref src/oem_xval_dense.h:533-535, 614) in a fixed order, then the
+// column times sqrt(w), in place.  csq: [K][p + 1], entry p of a fold = its number of rows (filled by the y workgroup).
+__global__ __launch_bounds__(256) void weight_scale_kernel(double *__restrict__ xp, int64_t ldp, double *__restrict__ yp, int p,
+                                                           const int64_t *__restrict__ fold_start, const int64_t *__restrict__ fold_n,
+                                                           double *__restrict__ csq)
+{
+    __shared__ double sh[256];
+    const int j = blockIdx.x + 1, k = blockIdx.y, tid = threadIdx.x;
+    const int64_t st = fold_start[k], nk = fold_n[k];
+    double *col = (j <= p) ? xp + (size_t)j * ldp + st : yp + st;
+    const double *wv = xp + st;
+    double s = 0.0;
+    for (int64_t r = tid; r < nk; r += 256) {
+        const double v = col[r];
+        s = fma(v, v, s);
+        col[r] = v * sqrt(wv[r]);
+    }
+    sh[tid] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) { if (tid < h) sh[tid] += sh[tid + h]; __syncthreads(); }
+    if (tid == 0) csq[(size_t)k * (p + 1) + (j <= p ? j - 1 : p)] = (j <= p) ? sh[0] : (double)nk;
+}
+// column 0 becomes sqrt(w) once every other column has used w
+__global__ __launch_bounds__(256) void weight_sqrt_kernel(double *__restrict__ xp, const int64_t *__restrict__ fold_start,
+                                                          const int64_t *__restrict__ fold_n)
+{
+    const int k = blockIdx.y;
+    const int64_t st = fold_start[k], nk = fold_n[k];
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < nk; r += (int64_t)gridDim.x * 256) xp[st + r] = sqrt(xp[st + r]);
+}
+
+// Weighted fold sums -> XX, XY of oemXvalDense (ref src/oem_xval_dense.h:733-784 with XtWX_xval(_int), :486-623): Mw = moments of
+// the p + 1 data columns [sqrt(w) | sqrt(w) X] and of sqrt(w) y ((p + 3)^2, lower triangle), cs = [sum x_j^2 (unweighted), rows].
+// q = p + intercept.  stats as launch_finalize's (colsq_inv in the scale slots).
+__global__ __launch_bounds__(256) void finalize_weighted_kernel(const double *__restrict__ Mw, const double *__restrict__ cs, int p,
+                                                                int standardize, int intercept, double *__restrict__ xx,
+                                                                double *__restrict__ xy, double *__restrict__ stats)
+{
+    const int q = p + (intercept ? 1 : 0), off = intercept ? 0 : 1, qm = p + 3;
+    const double nobs = cs[p];
+    auto cinv = [&](int c) -> double {                 // data column c of [sqrt(w) | X]: 1 for the intercept column
+        if (c == 0 || !standardize) return 1.0;
+        double v = cs[c - 1] / (nobs - 1.0);
+        if (v == 0.0) v = 1.0;
+        return 1.0 / sqrt(v);
+    };
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    for (int t = tid; t < q * q; t += nth) {
+        const int a = t % q + off, b = t / q + off;    // data columns
+        const int hi = a > b ? a : b, lo = a > b ? b : a;
+        xx[t] = cinv(a) * Mw[(size_t)lo * qm + hi] * cinv(b) / nobs;
+    }
+    for (int t = tid; t < q; t += nth) xy[t] = cinv(t + off) * Mw[(size_t)(t + off) * qm + (p + 1)] / nobs;
+    if (tid == 0) {
+        stats[0] = 0.0; stats[1] = 1.0; stats[2] = Mw[(size_t)(p + 1) * qm + (p + 1)]; stats[3] = nobs;
+        stats[stats_shift_flag(p)] = 0.0; stats[stats_shift_flag(p) + 1] = 0.0;
+    }
+    for (int t = tid; t < p; t += nth) { stats[4 + t] = 0.0; stats[4 + p + t] = cinv(t + 1); }
+}
+
 // ---------------------------------------------------------------------------------------- CV error
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -120,9 +183,11 @@ constexpr int CVW = 8;                   // waves per workgroup
 template <int LT, int KC, bool SINGLE>
 __global__ __launch_bounds__(64 * CVW) void cv_error_kernel(const double *__restrict__ xp, int64_t ldp, const double *__restrict__ yp,
                                                             const int64_t *__restrict__ fold_start, const int64_t *__restrict__ fold_n,
-                                                            int p, const double *__restrict__ B, int nl, int mae,
+                                                            int p, const double *__restrict__ B, int nl, int mae, int wmode,
                                                             double *__restrict__ part)
 {
+    // wmode (observation weights): xp has p + 1 data columns -- column 0 = sqrt(w), columns 1..p = sqrt(w) x -- and yp = sqrt(w) y, so
+    // the squared residual of the scaled row IS w (y - yhat)^2 (ref src/oem_xval_dense.cpp:389-437); |.| takes one more sqrt(w).
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int k = blockIdx.y, pen = blockIdx.z, npen = gridDim.z, nwg = gridDim.x, wg = blockIdx.x;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l16 = lane & 15, g = lane >> 4;
@@ -142,8 +207,8 @@ __global__ __launch_bounds__(64 * CVW) void cv_error_kernel(const double *__rest
 #pragma unroll
         for (int s_ = 0; s_ < KC; ++s_) {
             const int kk = c0 + 4 * s_ + g;
-            double v = (kk == p) ? 1.0 : 0.0;
-            if (avalid && kk < p) v = xk[(size_t)kk * ldp + arow];
+            double v = (!wmode && kk == p) ? 1.0 : 0.0;
+            if (avalid && (wmode ? kk <= p : kk < p)) v = xk[(size_t)kk * ldp + arow];
             a[s_] = v;
         }
     };
@@ -154,7 +219,8 @@ __global__ __launch_bounds__(64 * CVW) void cv_error_kernel(const double *__rest
             const int c = idx / LW, j = idx - c * LW, lam = l0 * 16 + j;
             double v = 0.0;
             if (lam < nl) {
-                if (c < p) v = Bsrc[(size_t)lam * Kd + c + 1];
+                if (wmode) { if (c <= p) v = Bsrc[(size_t)lam * Kd + c]; }      // column 0 (sqrt(w)) meets the intercept
+                else if (c < p) v = Bsrc[(size_t)lam * Kd + c + 1];
                 else if (c == p) v = Bsrc[(size_t)lam * Kd];          // intercept: the column of ones
             }
             Bl[idx] = v;
@@ -187,10 +253,11 @@ __global__ __launch_bounds__(64 * CVW) void cv_error_kernel(const double *__rest
                 const int64_t row = rt * 16 + 4 * r + g;
                 const bool ok = row < nk;
                 const double yv = ok ? yk[row] : 0.0;
+                const double sw = (ok && wmode && mae) ? xk[row] : 1.0;
 #pragma unroll
                 for (int t = 0; t < LT; ++t) {
                     const double res = yv - acc[t][r];
-                    const double v = ok ? (mae ? fabs(res) : res * res) : 0.0;
+                    const double v = ok ? (mae ? fabs(res) * sw : res * res) : 0.0;
                     s1[t] += v; s2[t] += v * v;
                 }
             }
@@ -272,6 +339,26 @@ int launch_gather_rows(hipStream_t s, const double *x, int64_t n, int64_t ld, in
     return 0;
 }
 
+int launch_weight_scale(hipStream_t s, double *xp, int64_t ldp, double *yp, int p, int K, const int64_t *fold_start, const int64_t *fold_n,
+                        double *csq)
+{
+    hipLaunchKernelGGL(weight_scale_kernel, dim3(p + 1, K), dim3(256), 0, s, xp, ldp, yp, p, fold_start, fold_n, csq);
+    hipLaunchKernelGGL(weight_sqrt_kernel, dim3(64, K), dim3(256), 0, s, xp, fold_start, fold_n);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_finalize_weighted(hipStream_t s, const double *Mw, const double *cs, int p, int standardize, int intercept, double *xx,
+                             double *xy, double *stats)
+{
+    const int q = p + (intercept ? 1 : 0);
+    int blocks = (q * q + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(finalize_weighted_kernel, dim3(blocks), dim3(256), 0, s, Mw, cs, p, standardize, intercept, xx, xy, stats);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_fold_sum(hipStream_t s, const double *M, int K, size_t len, int skip, double *out)
 {
     hipLaunchKernelGGL(fold_sum_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, M, K, len, skip, out);
@@ -292,12 +379,12 @@ size_t cv_part_doubles(int nwg, int K, int npen, int nl) { return (size_t)nwg * 
 
 template <int LT>
 static int launch_cv_lt(hipStream_t s, dim3 grid, size_t lds, int ksteps, const double *xp, int64_t ldp, const double *yp,
-                        const int64_t *fold_start, const int64_t *fold_n, int p, const double *B, int nl, int mae, double *part)
+                        const int64_t *fold_start, const int64_t *fold_n, int p, const double *B, int nl, int mae, int wmode, double *part)
 {
 #define OEM_CVK(KC, SINGLE)                                                                                                          \
     do {                                                                                                                             \
         OEM_HIP(hipFuncSetAttribute((const void *)cv_error_kernel<LT, KC, SINGLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((cv_error_kernel<LT, KC, SINGLE>), grid, dim3(64 * CVW), lds, s, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); \
+        hipLaunchKernelGGL((cv_error_kernel<LT, KC, SINGLE>), grid, dim3(64 * CVW), lds, s, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); \
     } while (0)
     if (ksteps <= 14) OEM_CVK(14, true);
     else OEM_CVK(14, false);          // 28 fragments at once spill next to 7 accumulator tiles
@@ -307,7 +394,7 @@ static int launch_cv_lt(hipStream_t s, dim3 grid, size_t lds, int ksteps, const 
 }
 
 int launch_cv_error(hipStream_t s, const double *xp, int64_t ldp, const double *yp, const int64_t *fold_start, const int64_t *fold_n,
-                    int K, int p, const double *B, int npen, int nl, int mae, int nwg, double n, double *part, double *out)
+                    int K, int p, const double *B, int npen, int nl, int mae, int wmode, int nwg, double n, double *part, double *out)
 {
     const int K4 = (p + 1 + 3) & ~3, ntile = (nl + 15) >> 4;
     // lambdas per pass: as many 16-wide tiles as fit 140 KB of LDS next to the reduction scratch, at most 7 (accumulator registers);
@@ -321,13 +408,13 @@ int launch_cv_error(hipStream_t s, const double *xp, int64_t ldp, const double *
     dim3 grid(nwg, K, npen);
     int rc;
     switch (lt) {
-    case 1: rc = launch_cv_lt<1>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); break;
-    case 2: rc = launch_cv_lt<2>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); break;
-    case 3: rc = launch_cv_lt<3>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); break;
-    case 4: rc = launch_cv_lt<4>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); break;
-    case 5: rc = launch_cv_lt<5>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); break;
-    case 6: rc = launch_cv_lt<6>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); break;
-    case 7: rc = launch_cv_lt<7>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, part); break;
+    case 1: rc = launch_cv_lt<1>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
+    case 2: rc = launch_cv_lt<2>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
+    case 3: rc = launch_cv_lt<3>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
+    case 4: rc = launch_cv_lt<4>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
+    case 5: rc = launch_cv_lt<5>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
+    case 6: rc = launch_cv_lt<6>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
+    case 7: rc = launch_cv_lt<7>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
     default: return OEMGPU_ERR_INTERNAL;
     }
     if (rc) return rc;

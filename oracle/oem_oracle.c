@@ -913,10 +913,25 @@ static int xval_paths(const double *XX, const double *XY, int q, double d, const
     return rc;
 }
 
+/* weights: n observation weights or NULL (ref src/oem_xval_dense.h:486-623 XtWX_xval / XtWX_xval_int: the fold Grams, X'y and
+ * the intercept border carry the weights; the column scales and the divisor nobs do NOT -- "we do not standardize with respect
+ * to weights", :533-535 -- and the CV error of row i is multiplied by w_i, ref src/oem_xval_dense.cpp:389-437). */
+int orc_xval_dense_w(const double *x, int64_t n, int32_t p, const double *y, const double *weights, const int32_t *foldid, int32_t nfolds,
+                     int32_t standardize, int32_t intercept, int32_t type_measure, const orc_opts *o,
+                     double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out,
+                     double *cvm, double *cvsd);
 int orc_xval_dense(const double *x, int64_t n, int32_t p, const double *y, const int32_t *foldid, int32_t nfolds,
                    int32_t standardize, int32_t intercept, int32_t type_measure, const orc_opts *o,
                    double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out,
                    double *cvm, double *cvsd)
+{
+    return orc_xval_dense_w(x, n, p, y, NULL, foldid, nfolds, standardize, intercept, type_measure, o, beta, lambda_out, niter, loss,
+                            d_out, cvm, cvsd);
+}
+int orc_xval_dense_w(const double *x, int64_t n, int32_t p, const double *y, const double *weights, const int32_t *foldid, int32_t nfolds,
+                     int32_t standardize, int32_t intercept, int32_t type_measure, const orc_opts *o,
+                     double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out,
+                     double *cvm, double *cvsd)
 {
     if (n <= p) return fail("dimension of x larger than number of observations");     /* ref: oem_xval_dense.h:690-731 */
     const int off = intercept ? 1 : 0, q = p + off, K = nfolds;
@@ -940,13 +955,14 @@ int orc_xval_dense(const double *x, int64_t n, int32_t p, const double *y, const
         if (k < 0 || k >= K) return fail("oracle: foldid out of range");
         double *G = fxx + qq * k, *b = fxy + (size_t)q * k, *cs = fcs + (size_t)p * k;
         fn[k]++;
-        if (intercept) { G[0] += 1.0; b[0] += y[i]; }
+        const double wi = weights ? weights[i] : 1.0;
+        if (intercept) { G[0] += wi; b[0] += wi * y[i]; }
         for (int c = 0; c < p; c++) {
             double xc = x[(size_t)c * n + i];
-            b[c + off] += xc * y[i];
-            cs[c] += xc * xc;
-            if (intercept) { G[(size_t)(c + 1) * q] += xc; G[c + 1] += xc; }
-            for (int r = c; r < p; r++) G[(size_t)(c + off) * q + (r + off)] += x[(size_t)r * n + i] * xc;
+            b[c + off] += xc * (y[i] * wi);
+            cs[c] += xc * xc;                                           /* never weighted (ref :533-535) */
+            if (intercept) { G[(size_t)(c + 1) * q] += wi * xc; G[c + 1] += wi * xc; }
+            for (int r = c; r < p; r++) G[(size_t)(c + off) * q + (r + off)] += x[(size_t)r * n + i] * (wi * xc);
         }
     }
     for (int k = 0; k < K; k++) {
@@ -1033,6 +1049,7 @@ int orc_xval_dense(const double *x, int64_t n, int32_t p, const double *y, const
                     pred += b[0];                                               /* 0 without an intercept */
                     double res = y[r] - pred;
                     double v = (type_measure == 1) ? fabs(res) : res * res;
+                    if (weights) v *= weights[r];                               /* ref: oem_xval_dense.cpp:389-437 */
                     double delta = v - mean[i];
                     mean[i] += delta / (double)(r + 1);
                     ss[i] += delta * (v - mean[i]);

@@ -183,9 +183,12 @@ def fit_big(x, y, penalty="elastic.net", standardize=True, intercept=True, nativ
                  C.c_int32(int(standardize)), C.c_int32(int(intercept)), native=native)
 
 
-def xval_dense(x, y, foldid, penalty="elastic.net", standardize=True, intercept=True, type_measure="mse", native=False, **kw):
-    """ref src/oem_xval_dense.cpp:31-482.  foldid: values 1..nfolds.  Adds cvm, cvsd (lists per penalty) to the fit."""
+def xval_dense(x, y, foldid, penalty="elastic.net", standardize=True, intercept=True, type_measure="mse", native=False,
+               weights=None, **kw):
+    """ref src/oem_xval_dense.cpp:31-482.  foldid: values 1..nfolds.  Adds cvm, cvsd (lists per penalty) to the fit.
+    weights: observation weights (ref src/oem_xval_dense.h:486-623) or None."""
     x = np.asfortranarray(x, dtype=np.float64); y = _d(y)
+    w = None if weights is None or len(weights) == 0 else _d(weights)
     n, p = x.shape
     fid = np.ascontiguousarray(foldid, dtype=np.int32)
     o = _Opts(p, penalty, **kw)
@@ -194,7 +197,7 @@ def xval_dense(x, y, foldid, penalty="elastic.net", standardize=True, intercept=
     cvm = np.zeros((npen, nl)); cvsd = np.zeros((npen, nl))
     beta = np.zeros((npen, nl * (p + 1))); lam = np.zeros((npen, nl))
     niter = np.zeros((npen, nl), dtype=np.int32); loss = np.zeros((npen, nl)); d = C.c_double(0)
-    rc = L.orc_xval_dense(_ptr(x), C.c_int64(n), C.c_int32(p), _ptr(y), _ptr(fid, _ip), C.c_int32(int(fid.max())),
+    rc = L.orc_xval_dense_w(_ptr(x), C.c_int64(n), C.c_int32(p), _ptr(y), _ptr(w), _ptr(fid, _ip), C.c_int32(int(fid.max())),
                           C.c_int32(int(standardize)), C.c_int32(int(intercept)), C.c_int32({"mse": 0, "mae": 1}[type_measure]),
                           C.byref(o.c), _ptr(beta), _ptr(lam), _ptr(niter, _ip), _ptr(loss), C.byref(d), _ptr(cvm), _ptr(cvsd))
     if rc != 0:

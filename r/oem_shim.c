@@ -212,7 +212,8 @@ SEXP oem_xval_dense(SEXP x_, SEXP y_, SEXP family_, SEXP penalty_, SEXP weights_
 {
     if (strcmp(CHAR(STRING_ELT(family_, 0)), "gaussian") != 0)
         Rf_error("binomial not available for oem_xval_dense, use oem_xval_logistic_dense");    /* ref src/oem_xval_dense.cpp:157 */
-    if (XLENGTH(weights_) > 0) Rf_error("observation weights in xval.oem are outside the GPU path");
+    if (XLENGTH(weights_) > 0 && Rf_asLogical(compute_loss_))
+        Rf_error("compute.loss with observation weights is outside the GPU path (the reference's loss is unweighted)");
     SEXP dim = Rf_getAttrib(x_, R_DimSymbol);
     const int64_t n = INTEGER(dim)[0];
     const int p = INTEGER(dim)[1];
@@ -226,7 +227,8 @@ SEXP oem_xval_dense(SEXP x_, SEXP y_, SEXP family_, SEXP penalty_, SEXP weights_
            *cvsd = (double *)R_alloc(nk, sizeof(double)), d = 0.0;
     int32_t *niter = (int32_t *)R_alloc(nk, sizeof(int32_t));
     const int mae = strcmp(CHAR(STRING_ELT(type_measure_, 0)), "mae") == 0;                    /* ref :378-411 */
-    const int rc = oemgpu_xval_dense(REAL(x_), n, p, REAL(y_), INTEGER(foldid_), Rf_asInteger(nfolds_), Rf_asLogical(standardize_),
+    const int rc = oemgpu_xval_dense(REAL(x_), n, p, REAL(y_), XLENGTH(weights_) > 0 ? REAL(weights_) : NULL, INTEGER(foldid_),
+                                     Rf_asInteger(nfolds_), Rf_asLogical(standardize_),
                                      Rf_asLogical(intercept_), mae, &o, beta, lam, niter, loss, &d, cvm, cvsd);
     if (rc != 0) raise(rc);
     SEXP base = PROTECT(pack(&o, p + 1, nl, beta, lam, niter, loss, d));

@@ -135,3 +135,47 @@ def test_many_small_folds_and_an_empty_one(oa):
     f = oa.xval_oem(x, y, foldid=np.where(foldid == 5, nf, foldid), penalty=["lasso", "scad"], nlambda=16, tol=1e-9)     # fold 5 empty instead
     r = _oracle(x, y, np.where(foldid == 5, nf, foldid), ["lasso", "scad"], nlambda=16, lambda_min_ratio=1e-4, tol=1e-9)
     _compare(f, r, 2)
+
+
+@pytest.mark.parametrize("std,icpt", [(True, True), (False, True), (True, False), (False, False)])
+@pytest.mark.parametrize("measure", ["mse", "mae"])
+def test_observation_weights(oa, std, icpt, measure):
+    """xval.oem(weights = w) (ref src/oem_xval_dense.h:486-623, src/oem_xval_dense.cpp:389-437): weighted fold Grams with the
+    intercept border carrying the weights, unweighted column scales and divisor, the error of row i times w_i -- device-resident
+    and host-resident x, against the oracle (which tests/test_oracle_independent.py holds against scikit-learn)."""
+    import torch
+    rng = np.random.default_rng(21)
+    n, p, nf = 4003, 19, 4
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 1.5 + 0.2)
+    y = x[:, :4] @ np.array([1.0, -1.5, 0.5, 2.0]) + rng.normal(size=n) + 0.4
+    w = rng.uniform(0.1, 4.0, n); w[:7] = 0.0                   # a few rows that only count in nobs and the column scales
+    foldid = rng.permutation(np.resize(np.arange(1, nf + 1), n))
+    groups = np.arange(p) // 4 + 1
+    pens = ["lasso", "scad", "grp.lasso", "ols"]
+    kw = dict(nlambda=15, tol=1e-9, maxit=2000, standardize=std)
+    r = _oracle(x, y, foldid, pens, groups=groups, intercept=icpt, type_measure=measure, weights=w, lambda_min_ratio=1e-4, **kw)
+    f = oa.xval_oem(x, y, foldid=foldid, penalty=pens, groups=groups, intercept=icpt, type_measure=measure, weights=w, **kw)
+    _compare(f, r, len(pens))
+    xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+    g = oa.xval_oem(xd, y, foldid=foldid, penalty=pens, groups=groups, intercept=icpt, type_measure=measure, weights=w, **kw)
+    _compare(g, r, len(pens))
+    # unit weights are no weights
+    a = oa.xval_oem(x, y, foldid=foldid, penalty=["lasso"], intercept=icpt, type_measure=measure, weights=np.ones(n), **kw)
+    b = oa.xval_oem(x, y, foldid=foldid, penalty=["lasso"], intercept=icpt, type_measure=measure, **kw)
+    assert np.abs(a["beta"][0] - b["beta"][0]).max() < 1e-10 and np.allclose(a["cvm"][0], b["cvm"][0], rtol=1e-10)
+    with pytest.raises(oa.OemgpuError):                          # the reference's loss is unweighted: refused, not faked
+        oa.xval_oem(x, y, foldid=foldid, penalty=["lasso"], weights=w, compute_loss=True, **kw)
+
+
+def test_observation_weights_large_p(oa):
+    """p + 1 > 288: the K + 1 weighted fits run one after the other on the cooperating-workgroup engine"""
+    rng = np.random.default_rng(22)
+    n, p, nf = 2400, 300, 3
+    x = np.asfortranarray(rng.normal(size=(n, p)))
+    y = x[:, :5] @ np.array([1.0, -1.5, 0.5, 2.0, -0.8]) + rng.normal(size=n) + 0.4
+    w = rng.uniform(0.5, 2.0, n)
+    foldid = rng.permutation(np.resize(np.arange(1, nf + 1), n))
+    kw = dict(nlambda=6, tol=1e-9, maxit=3000)
+    r = orc.xval_dense(x, y, foldid, penalty=["lasso", "mcp"], weights=w, lambda_min_ratio=1e-4, **kw)
+    f = oa.xval_oem(x, y, foldid=foldid, penalty=["lasso", "mcp"], weights=w, **kw)
+    _compare(f, r, 2, tol_b=1e-7, tol_cv=1e-7)

@@ -217,3 +217,34 @@ def test_sparse_fit_is_the_optimum_of_bigs_objective_along_a_path():
         m = Lasso(alpha=l, fit_intercept=True, tol=1e-15, max_iter=1000000).fit(xd / sc, y)
         assert np.abs(s["beta"][0][1:, i] - m.coef_ / sc).max() < 1e-8
         assert abs(s["beta"][0][0, i] - m.intercept_) < 1e-8
+
+
+def test_weighted_xval_against_sklearn_and_numpy():
+    """xval.oem with observation weights (ref src/oem_xval_dense.h:486-623): weighted Grams and X'y, UNWEIGHTED divisor nobs and
+    column scales.  With standardize = FALSE the full-data fit is scikit-learn's lasso with sample_weight at alpha = lambda n / sum w
+    (sklearn rescales the weights to sum n); the CV error is the mean over rows of w_i (y_i - prediction of the fit that left
+    row i's fold out)^2, recomputed here in numpy from per-fold sklearn fits."""
+    from sklearn.linear_model import Lasso
+    x, y = _data(n=600, p=24, seed=9)
+    n = len(y)
+    rng = np.random.default_rng(4)
+    w = rng.uniform(0.2, 3.0, n)
+    foldid = rng.permutation(np.resize(np.arange(1, 6), n))
+    lam = np.array([0.3, 0.1, 0.03])
+    f = orc.xval_dense(x, y, foldid, penalty=["lasso"], lambda_=lam, weights=w, standardize=False, intercept=True, **TIGHT)
+    cv = np.zeros((n, len(lam)))
+    for i, l in enumerate(lam):
+        m = Lasso(alpha=l * n / w.sum(), fit_intercept=True, tol=1e-15, max_iter=1000000).fit(x, y, sample_weight=w)
+        assert np.abs(f["beta"][0][1:, i] - m.coef_).max() < 1e-8
+        assert abs(f["beta"][0][0, i] - m.intercept_) < 1e-8
+        for k in range(1, 6):
+            tr = foldid != k
+            mk = Lasso(alpha=l * tr.sum() / w[tr].sum(), fit_intercept=True, tol=1e-15, max_iter=1000000).fit(x[tr], y[tr], sample_weight=w[tr])
+            cv[~tr, i] = w[~tr] * (y[~tr] - mk.predict(x[~tr])) ** 2
+    assert np.allclose(f["cvm"][0], cv.mean(0), rtol=1e-7)
+    assert np.allclose(f["cvsd"][0], cv.std(0, ddof=1) / np.sqrt(n), rtol=1e-7)
+    # unit weights are no weights
+    a = orc.xval_dense(x, y, foldid, penalty=["lasso", "mcp"], nlambda=8, weights=np.ones(n))
+    b = orc.xval_dense(x, y, foldid, penalty=["lasso", "mcp"], nlambda=8)
+    for k in range(2):
+        assert np.array_equal(a["beta"][k], b["beta"][k]) and np.allclose(a["cvm"][k], b["cvm"][k], rtol=1e-14)
