@@ -256,7 +256,9 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const bool loss_on = (sem == OEMGPU_SEM_DENSE || sem == OEMGPU_SEM_XVAL || sem == SEM_SPARSE) && o->compute_loss != 0;
     const bool coop = !small && path_coop_eligible(q, scale_factor != nullptr, loss_on, og.ngroups, nbatch);
     if (nbatch > 1 && !small) { set_error("internal: batched paths need p <= %d", SMALL_P_MAX); return OEMGPU_ERR_INTERNAL; }
-    int lan = q < 128 ? q : 128;
+    // Lanczos step cap: q up to 288 (the whole Krylov space: the recurrence stops by itself when the top Ritz value has settled, and
+    // a spectrum that needs more than 128 steps gets them -- ADVICE r1); the large-p engines keep their own caps (256 / 512)
+    int lan = q < 288 ? q : 288;
     size_t work_d = small ? path_small_xchg_bytes() / 8 : path_large_work_doubles(q, lan);
     if (coop && work_d < path_coop_xchg_bytes() / 8) work_d = path_coop_xchg_bytes() / 8;
     // the outputs come first: when the caller's frame ends with `stats` (both callers), stats | outputs is one
@@ -658,7 +660,7 @@ int oemgpu_eig_max_dev(oemgpu_ctx *c, const double *a_dev, int32_t p, double *la
     // run the engines with zero penalties: they stop after the eigenvalue step
     Bump B;
     const size_t a_z = B.take((size_t)(p + 8) * 8), a_o = B.take(256);
-    const int lan = p < 128 ? p : 128;
+    const int lan = p < 288 ? p : 288;
     size_t work_d = p <= SMALL_P_MAX ? path_small_xchg_bytes() / 8 : path_large_work_doubles(p, lan);
     const bool coop = path_coop_eligible(p, false, false, 0, 1);
     if (coop && work_d < path_coop_xchg_bytes() / 8) work_d = path_coop_xchg_bytes() / 8;

@@ -58,7 +58,7 @@ __device__ unsigned long long g_diag[24];
 template <int R, int NW, int CW> struct Cfg {
     static constexpr int PR = 64 * R;       // padded rows
     static constexpr int PC = NW * CW;      // padded columns
-    static constexpr int ML = 128;          // max Lanczos steps kept
+    static constexpr int ML = 288;          // max Lanczos steps kept: as many as the largest p served, so the Krylov space can be exhausted
     // LDS carve (doubles)
     static constexpr int OFF_P = 0;                         // partials [2][NW][PR]
     static constexpr int OFF_U = OFF_P + 2 * NW * PR;       // wave-private vector strip [NW][PR]
@@ -905,7 +905,7 @@ template <int NW_, int CG, int CGL> struct RowsCfg {
     static constexpr int NW = NW_;
     static constexpr int NBC = (CG + CGL + 15) / 16;
     static constexpr int VS = 64 * NW;                    // vector words per buffer: 32 NW rows + one dummy word per lane
-    static constexpr int ML = 128;
+    static constexpr int ML = 208;                        // as many Lanczos steps as the largest p this kernel serves
     // LDS carve (doubles)
     static constexpr int OFF_V = 0;                       // exchanged vector [2][VS]
     static constexpr int OFF_XA = OFF_V + 2 * VS;         // per-lane scalar words [2][NW][64] (aux / alpha)
