@@ -255,6 +255,38 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # Two callers at once (two host threads, two contexts / streams, the same resident X): the path kernel of one solve occupies ONE
+    # CU for 0.33 ms, so the moment pass of the other caller's solve runs beside it.  Reported as an extra, never as `value`: a
+    # solve is still 0.57 ms long, this is what the chip delivers when the solves are independent.
+    two_callers = None
+    if world == 1:
+        import threading
+        backs = [HipBackend(local), HipBackend(local)]
+        sets = []
+        for bk in backs:
+            ar = api._Args(["elastic.net"], [np.asarray(lambdas)], 100, 1e-4, 1.0, 3.0, 0.5, 1e-10, 500, False, False,
+                           np.ones(p), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0))
+            sets.append((bk, ar, sharded_buffers(bk, p), ar.outputs(p + 1)))
+        per = max(a.steps // 2, 1)
+
+        def caller(bk, ar, bf, ou):
+            with bk.section():
+                for _ in range(per):
+                    solve_row_shards(bk, None, None, x, n_loc, n_loc, p, y, bf, L.OEMGPU_SEM_DENSE, False, True, ar, ou)
+        for st_ in sets:
+            caller(*st_)                                  # warm both contexts
+        torch.cuda.synchronize()
+        th = [threading.Thread(target=caller, args=st_) for st_ in sets]
+        t2 = time.perf_counter()
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        same = bool(np.array_equal(sets[0][1].beta, args.beta) and np.array_equal(sets[1][1].beta, args.beta))
+        two_callers = {"solves_per_s": 2 * per / dt2, "callers": 2, "solves": 2 * per, "same_bits_as_the_single_caller": same,
+                       "note": "independent solves from two host threads on two contexts; NOT the headline value"}
     # the same through the Python mirror of the R front end (argument checks, result decoration): reported, not `value`
     t1 = time.perf_counter()
     for _ in range(20):
@@ -320,6 +352,7 @@ def main():
             "path_kernel_cycles_per_oem_iteration": acc[6] / niter_total if niter_total > 0 else None,
             "path_kernel_note": "eigenvalue (Lanczos) + 100-lambda path in ONE launch; cycles include the eigen step's fixed cost",
             "vs_baseline_note": "reference README: 1.600 s per solve on unstated CPU hardware",
+            "throughput_two_callers": two_callers,
         }
     xh_full = yh_full = None
     if rank == 0 and world == 1 and not (a.no_host and a.no_cpu_baseline):

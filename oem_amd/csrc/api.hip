@@ -271,15 +271,26 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const size_t off_xx = (const char *)xx - c->ws, off_xy = (const char *)xy - c->ws, off_st = (const char *)stats - c->ws;
     if (B.off > c->ws_bytes) { set_error("internal: workspace under-reserved (%zu > %zu)", B.off, c->ws_bytes); return OEMGPU_ERR_INTERNAL; }
     xx = (const double *)(c->ws + off_xx); xy = (const double *)(c->ws + off_xy); stats = (const double *)(c->ws + off_st);
-    char *dblob = c->ws + a_blob;
+    (void)a_blob;                                     // (the frame keeps its slot; the blob itself lives in a buffer of its own)
+    // its own grow-only buffer, not the workspace: the Gram partials of the NEXT call overlay this frame, and a blob that survives
+    // between calls is what lets run_paths skip an identical upload
+    if (bl.h.size() + 256 > c->blob_bytes) c->blob_dev = nullptr;      // a re-allocation may land on the old address
+    if (ctx_grow(c, &c->blob_buf, &c->blob_bytes, bl.h.size() + 256)) return OEMGPU_ERR_HIP;
+    char *dblob = c->blob_buf;
     double *dout = (double *)(c->ws + a_out);
     if (ctx_pinned_in(c, bl.h.size())) return OEMGPU_ERR_HIP;       // the previous call ended with a stream sync: the buffer is free
-    memcpy(c->pinned_in, bl.h.data(), bl.h.size());
-    OEM_HIP(hipMemcpyAsync(dblob, c->pinned_in, bl.h.size(), hipMemcpyHostToDevice, c->stream));
+    // Repeated solves with the same options (a lambda path re-fitted on new data, bench.py's loop) find the parameter blob already on
+    // the device: same bytes at the same workspace address as the last upload of this context => no copy (a 2 KB H2D copy is a
+    // 4 us node plus a boundary on a 570 us chain).
+    if (!(c->blob_dev == dblob && c->blob_len == bl.h.size() && memcmp(c->pinned_in, bl.h.data(), bl.h.size()) == 0)) {
+        memcpy(c->pinned_in, bl.h.data(), bl.h.size());
+        OEM_HIP(hipMemcpyAsync(dblob, c->pinned_in, bl.h.size(), hipMemcpyHostToDevice, c->stream));
+        c->blob_dev = dblob; c->blob_len = bl.h.size();
+    }
     // Every output the host reads below is written by the path kernels, so the region is not cleared.  OEM_POISON_OUT=1
     // fills it with NaN bit patterns first: the GPU suite run that way proves nothing depends on stale contents.
     static const bool poison = getenv("OEM_POISON_OUT") != nullptr;
-    if (poison) OEM_HIP(hipMemsetAsync(dout, 0xFF, out_stride * nbatch, c->stream));
+    if (poison) { OEM_HIP(hipMemsetAsync(dout, 0xFF, out_stride * nbatch, c->stream)); c->blob_dev = nullptr; }
 
     PathArgs a;
     memset(&a, 0, sizeof a);
@@ -452,6 +463,7 @@ void oemgpu_destroy(oemgpu_ctx *c)
     if (c->pinned_in) (void)hipHostFree(c->pinned_in);
     if (c->aux) (void)hipFree(c->aux);
     if (c->xres) (void)hipFree(c->xres);
+    if (c->blob_buf) (void)hipFree(c->blob_buf);
     if (c->acc) (void)hipFree(c->acc);
     for (oemgpu_lane &l : c->lanes) {
         for (int k = 0; k < 2; ++k) {

@@ -48,6 +48,10 @@ struct oemgpu_ctx {
     size_t slot_bytes = 0;
     hipEvent_t done_ev[2] = {nullptr, nullptr};   // "the moment pass over block buffer k has finished reading it"
     hipEvent_t xfer_ev = nullptr;                 // cross-device hand-over of the moment buffers
+    char *blob_buf = nullptr;      // the parameter blob of run_paths (grow-only, outside the workspace: it survives between calls)
+    size_t blob_bytes = 0;
+    const char *blob_dev = nullptr;   // where the last parameter blob was uploaded (run_paths skips an identical upload)
+    size_t blob_len = 0;
     bool cached = false;           // owned by the process-wide cache (oemgpu_release_cache frees it)
     bool busy = false;
 };
