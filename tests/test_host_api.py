@@ -101,3 +101,49 @@ def test_predict_and_loglik():
     f["loss"] = [np.full(3, 1e99)]
     with pytest.raises(ValueError, match="compute.loss"):
         api.logLik(f)
+
+
+def _oracle_fit():
+    """a fit dictionary as oem_amd.api._decorate builds it, from the CPU oracle (no GPU needed for the consumers)"""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(3)
+    n, p = 400, 12
+    x = np.asfortranarray(rng.normal(size=(n, p))); y = x[:, :3] @ np.array([1.0, -2.0, 0.5]) + rng.normal(size=n)
+    r = orc.fit_dense(x, y, penalty=["lasso", "mcp"], nlambda=15, compute_loss=True)
+    fit = {"beta": r["beta"], "lambda": r["lambda"], "loss": r["loss"], "penalty": ["lasso", "mcp"], "family": "gaussian",
+           "nobs": n, "nvars": p, "varnames": [f"V{j + 1}" for j in range(p)],
+           "nzero": [(np.abs(b[1:]) > 0).sum(axis=0) for b in r["beta"]]}
+    return fit
+
+
+def test_plot_and_summary_methods():
+    """plot.oem / plot.cv.oem / plot.xval.oem / summary.* (ref R/methods.R:143-330, 841-1056) over the fit dictionaries"""
+    import oem_amd as oa
+    fit = _oracle_fit()
+    for xvar in ("norm", "lambda", "loglambda", "dev"):
+        d = oa.plot_oem(fit, "mcp", xvar=xvar, show=False)
+        assert d["curves"].shape[1] == len(d["index"]) == 15 and len(d["labels"]) == d["curves"].shape[0] <= 12
+        assert d["reversed_x"] == (xvar in ("lambda", "loglambda")) and len(d["top_axis_at"]) == len(d["top_axis_df"])
+    assert np.allclose(oa.plot_oem(fit, 0, show=False)["index"], np.abs(fit["beta"][0][1:]).sum(0))
+    with pytest.raises(ValueError):
+        oa.plot_oem(fit, "scad", show=False)
+    with pytest.raises(ValueError):
+        oa.plot_oem(fit, 2, show=False)
+    drawn = oa.plot_oem(fit, 0, xvar="loglambda")                       # matplotlib (Agg) when it is there
+    # a cross-validation object on top of it
+    cvm = [np.linspace(3.0, 1.0, 15) ** 2, np.linspace(3.2, 1.1, 15) ** 2]
+    cv = dict(fit, cvm=cvm, cvsd=[0.1 * c for c in cvm], name="Mean-Squared Error")
+    cv["cvup"] = [a + b for a, b in zip(cv["cvm"], cv["cvsd"])]; cv["cvlo"] = [a - b for a, b in zip(cv["cvm"], cv["cvsd"])]
+    cv.update(api._getmin(fit["lambda"], cv["cvm"], cv["cvsd"]))
+    d = oa.plot_xval(cv, "lasso", show=False)
+    assert len(d["x"]) == 15 and np.allclose(d["x"], np.log(fit["lambda"][0])) and len(d["vlines"]) == 2
+    assert oa.plot_xval(cv, 1, type="coefficients", show=False)["main"] == "mcp"
+    s = oa.summary_xval(cv)
+    assert s["model"] == "linear" and s["n"] == 400 and s["p"] == 12 and np.allclose(s["sigma"][0], np.sqrt(cvm[0]))
+    txt = oa.format_summary(s)
+    assert txt.startswith("lasso-penalized linear regression with n=400, p=12") and "Scale estimate (sigma): 1.000" in txt
+    assert "<===============================================>" in txt and "mcp-penalized" in txt
+    cvo = {"oem.fit": fit, "cvm": cv["cvm"], "cvup": cv["cvup"], "cvlo": cv["cvlo"], "lambda": fit["lambda"], "nzero": fit["nzero"],
+           "name": cv["name"], "lambda.min.models": cv["lambda.min.models"], "lambda.1se.models": cv["lambda.1se.models"]}
+    assert np.allclose(oa.plot_cv(cvo, "mcp", sign_lambda=-1, show=False)["x"], -np.log(fit["lambda"][1]))
+    assert oa.format_summary(oa.summary_cv(cvo)) == txt
