@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void finalize_weighted_kernel(const double *__
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // grid (workgroups per fold, K folds, npen); 512 threads = 2 waves per SIMD sharing one copy of the coefficients in LDS.
-// B: [K][npen][nl][p + 1], row 0 of each column the intercept.  part: [K * gridDim.x][npen][nl16][2] (sum of the error, of its square)
+// B: [K][npen][nl][p + 1], row 0 of each column the intercept.  part: [K * gridDim.x * CVW][npen][nl16][4] per WAVE: rows, centre c, sum (v - c), sum (v - c)^2 -- merged by Chan's formula in cv_finish_kernel
 // KC: k-steps (4 columns each) whose X fragments a lane holds at once (SINGLE: p + 1 <= 4 KC, one chunk per row tile).
 constexpr int CVW = 8;                   // waves per workgroup
 template <int LT, int KC, bool SINGLE>
@@ -194,11 +194,10 @@ __global__ __launch_bounds__(64 * CVW) void cv_error_kernel(const double *__rest
     const int Kd = p + 1, K4 = (Kd + 3) & ~3, nl16 = (nl + 15) & ~15, ntile = nl16 >> 4;
     constexpr int LW = 16 * LT;                       // lambdas per pass
     double *Bl = lds;                                 // [K4][LW]
-    double *red = lds + (size_t)K4 * LW;              // [CVW][LW][2]
     const int64_t start = fold_start[k], nk = fold_n[k];
     const double *Bsrc = B + ((size_t)k * npen + pen) * nl * Kd;
     const double *xk = xp + start, *yk = yp + start;
-    double *dst = part + (((size_t)k * nwg + wg) * npen + pen) * nl16 * 2;
+    double *dst = part + ((((size_t)k * nwg + wg) * CVW + w) * npen + pen) * nl16 * 4;      // this wave's partial
     const int64_t stride = (int64_t)nwg * CVW;
 
     auto load_a = [&](double (&a)[KC], int64_t rt, int c0) {
@@ -226,9 +225,15 @@ __global__ __launch_bounds__(64 * CVW) void cv_error_kernel(const double *__rest
             Bl[idx] = v;
         }
         __syncthreads();
-        double s1[LT], s2[LT];
+        // The reference runs Welford's update over the observations (ref src/oem_xval_dense.cpp:420-422,452-461).  Here every wave
+        // accumulates sum (v - c) and sum (v - c)^2 about a centre c of its own -- the error of the FIRST row it meets, per lambda --
+        // so nothing cancels however small the spread of the errors is next to their mean, and the wave partials
+        // (rows, c, sums) are merged pairwise with Chan's formula.
+        double s1[LT], s2[LT], cen[LT];
+        double cnt = 0.0;
+        bool have_c = false;
 #pragma unroll
-        for (int t = 0; t < LT; ++t) { s1[t] = 0.0; s2[t] = 0.0; }
+        for (int t = 0; t < LT; ++t) { s1[t] = 0.0; s2[t] = 0.0; cen[t] = 0.0; }
         d4 acc[LT];
         auto clear = [&]() {
 #pragma unroll
@@ -247,18 +252,25 @@ __global__ __launch_bounds__(64 * CVW) void cv_error_kernel(const double *__rest
             }
         };
         // accumulator layout: register r of lane (g, l16) is (row 4 r + g, lambda l16) of the tile
+        auto err_of = [&](double yv, double a, double sw) { const double res = yv - a; return mae ? fabs(res) * sw : res * res; };
         auto finish = [&](int64_t rt) {
+            if (!have_c) {                                      // the tile's first row always exists (rt * 16 < nk): lanes g = 0, r = 0 hold it
+                const double y0 = yk[rt * 16], sw0 = (wmode && mae) ? xk[rt * 16] : 1.0;
+#pragma unroll
+                for (int t = 0; t < LT; ++t) cen[t] = __shfl(err_of(y0, acc[t][0], sw0), l16, 64);
+                have_c = true;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = rt * 16 + 4 * r + g;
                 const bool ok = row < nk;
                 const double yv = ok ? yk[row] : 0.0;
                 const double sw = (ok && wmode && mae) ? xk[row] : 1.0;
+                if (l16 == 0) cnt += ok ? 1.0 : 0.0;
 #pragma unroll
                 for (int t = 0; t < LT; ++t) {
-                    const double res = yv - acc[t][r];
-                    const double v = ok ? (mae ? fabs(res) * sw : res * res) : 0.0;
-                    s1[t] += v; s2[t] += v * v;
+                    const double dv = ok ? err_of(yv, acc[t][r], sw) - cen[t] : 0.0;
+                    s1[t] += dv; s2[t] = fma(dv, dv, s2[t]);
                 }
             }
         };
@@ -272,20 +284,18 @@ __global__ __launch_bounds__(64 * CVW) void cv_error_kernel(const double *__rest
             }
             finish(rt);
         }
-        // the four row groups of a wave, then the waves
+        // the four row groups of a wave (fixed order); every wave leaves its own partial
+        cnt += __shfl_xor(cnt, 16, 64); cnt += __shfl_xor(cnt, 32, 64);
+        const double rows = __shfl(cnt, 0, 64);
 #pragma unroll
         for (int t = 0; t < LT; ++t) {
             s1[t] += __shfl_xor(s1[t], 16, 64); s1[t] += __shfl_xor(s1[t], 32, 64);
             s2[t] += __shfl_xor(s2[t], 16, 64); s2[t] += __shfl_xor(s2[t], 32, 64);
-            if (g == 0) { red[((size_t)w * LW + 16 * t + l16) * 2] = s1[t]; red[((size_t)w * LW + 16 * t + l16) * 2 + 1] = s2[t]; }
-        }
-        __syncthreads();
-        for (int j = tid; j < LW * 2; j += 64 * CVW) {
-            const int lam = l0 * 16 + (j >> 1);
-            double v = 0.0;
-#pragma unroll
-            for (int ww = 0; ww < CVW; ++ww) v += red[(size_t)ww * LW * 2 + j];       // fixed order
-            if (lam < nl16) dst[(size_t)lam * 2 + (j & 1)] = v;
+            const int lam = l0 * 16 + 16 * t + l16;
+            if (g == 0 && lam < nl16) {
+                double *q = dst + (size_t)lam * 4;
+                q[0] = rows; q[1] = cen[t]; q[2] = s1[t]; q[3] = s2[t];
+            }
         }
     }
 }
@@ -297,18 +307,32 @@ __global__ __launch_bounds__(64) void cv_finish_kernel(const double *__restrict_
 {
     const int t = blockIdx.x, lane = threadIdx.x;
     const int pen = t / nl, lam = t - pen * nl, nl16 = (nl + 15) & ~15;
-    double s1 = 0.0, s2 = 0.0;
+    // (rows, mean, M2 = sum (v - mean)^2) of a set of observations; two sets merge by Chan, Golub & LeVeque's update
+    double na = 0.0, ma = 0.0, qa = 0.0;
+    auto merge = [&](double nb, double mb, double qb) {
+        if (nb > 0.0) {
+            if (na > 0.0) {
+                const double nn = na + nb, dl = mb - ma;
+                ma += dl * (nb / nn);
+                qa += qb + dl * dl * (na * nb / nn);
+                na = nn;
+            } else { na = nb; ma = mb; qa = qb; }
+        }
+    };
     for (int b = lane; b < nparts; b += 64) {
-        const double *q = part + (((size_t)b * npen + pen) * nl16 + lam) * 2;
-        s1 += q[0]; s2 += q[1];
+        const double *q = part + (((size_t)b * npen + pen) * nl16 + lam) * 4;
+        const double nb = q[0];
+        if (nb > 0.0) { const double m1 = q[2] / nb; merge(nb, q[1] + m1, q[3] - q[2] * m1); }
     }
-    for (int s_ = 32; s_ > 0; s_ >>= 1) { s1 += __shfl_xor(s1, s_, 64); s2 += __shfl_xor(s2, s_, 64); }
+    for (int s_ = 32; s_ > 0; s_ >>= 1) {                       // fixed butterfly: reproducible
+        const double nb = __shfl_xor(na, s_, 64), mb = __shfl_xor(ma, s_, 64), qb = __shfl_xor(qa, s_, 64);
+        // both partners must end with the same numbers: merge in lane order (lower lane's set first)
+        if (lane & s_) { const double n0 = na, m0 = ma, q0 = qa; na = nb; ma = mb; qa = qb; merge(n0, m0, q0); }
+        else merge(nb, mb, qb);
+    }
     if (lane == 0) {
-        const double mean = s1 / n;
-        double m2 = s2 - s1 * mean;                   // sum (v - mean)^2
-        if (m2 < 0.0) m2 = 0.0;
-        out[(size_t)t * 2] = mean;
-        out[(size_t)t * 2 + 1] = sqrt(m2 / (n - 1.0)) / sqrt(n);
+        out[(size_t)t * 2] = ma;                                // all n observations are in: the mean
+        out[(size_t)t * 2 + 1] = sqrt((qa < 0.0 ? 0.0 : qa) / (n - 1.0)) / sqrt(n);
     }
 }
 
@@ -375,7 +399,7 @@ int cv_wg_per_fold(int64_t n, int K, int npen, int num_cu)
     if (nwg > tiles) nwg = (int)tiles;
     return nwg < 1 ? 1 : nwg;
 }
-size_t cv_part_doubles(int nwg, int K, int npen, int nl) { return (size_t)nwg * K * npen * ((nl + 15) & ~15) * 2; }
+size_t cv_part_doubles(int nwg, int K, int npen, int nl) { return (size_t)nwg * K * CVW * npen * ((nl + 15) & ~15) * 4; }
 
 template <int LT>
 static int launch_cv_lt(hipStream_t s, dim3 grid, size_t lds, int ksteps, const double *xp, int64_t ldp, const double *yp,
@@ -418,7 +442,7 @@ int launch_cv_error(hipStream_t s, const double *xp, int64_t ldp, const double *
     default: return OEMGPU_ERR_INTERNAL;
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(cv_finish_kernel, dim3(npen * nl), dim3(64), 0, s, part, nwg * K, npen, nl, n, out);
+    hipLaunchKernelGGL(cv_finish_kernel, dim3(npen * nl), dim3(64), 0, s, part, nwg * K * CVW, npen, nl, n, out);
     OEM_HIP(hipGetLastError());
     return 0;
 }

@@ -179,3 +179,19 @@ def test_observation_weights_large_p(oa):
     r = orc.xval_dense(x, y, foldid, penalty=["lasso", "mcp"], weights=w, lambda_min_ratio=1e-4, **kw)
     f = oa.xval_oem(x, y, foldid=foldid, penalty=["lasso", "mcp"], weights=w, **kw)
     _compare(f, r, 2, tol_b=1e-7, tol_cv=1e-7)
+
+
+def test_cv_error_variance_with_a_tiny_spread(oa):
+    """when the per-row errors barely vary next to their mean (mae on responses far from the fit), a one-pass
+    sum v, sum v^2 loses the variance to cancellation; the kernel accumulates about a per-wave centre and merges by Chan's
+    formula, like the reference's Welford update (ref src/oem_xval_dense.cpp:420-461)"""
+    rng = np.random.default_rng(31)
+    n, p, nf = 6000, 8, 3
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 1e-3)
+    y = 1e4 + x @ rng.normal(size=p) + rng.normal(size=n) * 1e-4        # |y - yhat| ~ 1e4 +- 1e-4 without an intercept
+    foldid = rng.permutation(np.resize(np.arange(1, nf + 1), n))
+    kw = dict(penalty=["lasso"], nlambda=5, intercept=False, standardize=False, type_measure="mae")
+    f = oa.xval_oem(x, y, foldid=foldid, **kw)
+    r = orc.xval_dense(x, y, foldid, lambda_min_ratio=1e-4, **kw)
+    assert np.allclose(f["cvm"][0], r["cvm"][0], rtol=1e-12)
+    assert np.allclose(f["cvsd"][0], r["cvsd"][0], rtol=1e-6), (f["cvsd"][0], r["cvsd"][0])
