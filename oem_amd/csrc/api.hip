@@ -258,7 +258,9 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     if (nbatch > 1 && !small) { set_error("internal: batched paths need p <= %d", SMALL_P_MAX); return OEMGPU_ERR_INTERNAL; }
     // Lanczos step cap: q up to 288 (the whole Krylov space: the recurrence stops by itself when the top Ritz value has settled, and
     // a spectrum that needs more than 128 steps gets them -- ADVICE r1); the large-p engines keep their own caps (256 / 512)
-    int lan = q < 288 ? q : 288;
+    // (more steps than rows: without re-orthogonalisation a clustered spectrum does not exhaust the Krylov space in q steps -- a 9 x 9
+    // standardised sparse Gram was 1.1e-7 short after 9 -- but the top Ritz value keeps converging; the stagnation test ends it)
+    int lan = 2 * q < 32 ? 32 : (2 * q < 288 ? 2 * q : 288);
     size_t work_d = small ? path_small_xchg_bytes() / 8 : path_large_work_doubles(q, lan);
     if (coop && work_d < path_coop_xchg_bytes() / 8) work_d = path_coop_xchg_bytes() / 8;
     // the outputs come first: when the caller's frame ends with `stats` (both callers), stats | outputs is one
@@ -672,7 +674,7 @@ int oemgpu_eig_max_dev(oemgpu_ctx *c, const double *a_dev, int32_t p, double *la
     // run the engines with zero penalties: they stop after the eigenvalue step
     Bump B;
     const size_t a_z = B.take((size_t)(p + 8) * 8), a_o = B.take(256);
-    const int lan = p < 288 ? p : 288;
+    const int lan = 2 * p < 32 ? 32 : (2 * p < 288 ? 2 * p : 288);
     size_t work_d = p <= SMALL_P_MAX ? path_small_xchg_bytes() / 8 : path_large_work_doubles(p, lan);
     const bool coop = path_coop_eligible(p, false, false, 0, 1);
     if (coop && work_d < path_coop_xchg_bytes() / 8) work_d = path_coop_xchg_bytes() / 8;
@@ -1061,20 +1063,30 @@ int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t
     }
     oemgpu_ctx *c = ctx_acquire(o->device);
     if (!c) return OEMGPU_ERR_NO_DEVICE;
+    // Two ways to the moment buffer.  Compressed columns (sparse.hip): p * nnz / 2 LDS gathers, the cost follows the non-zeros --
+    // taken up to 2 % density, where it beats the dense pass (n p^2 MFMA flops whatever the density) several times over.
+    // Denser: zero-filled row tiles through the FP64-MFMA kernels.  OEM_SPARSE_GRAM=csc|dense forces one (tests compare them).
+    bool use_csc = csc_moments_fits(p) && (double)nnz <= 0.02 * (double)n * (double)p && n < ((int64_t)1 << 31);
+    if (const char *ev = getenv("OEM_SPARSE_GRAM")) {
+        if (!strcmp(ev, "csc") && csc_moments_fits(p)) use_csc = true;
+        if (!strcmp(ev, "dense")) use_csc = false;
+    }
     double *xd = nullptr, *yd = nullptr, *vd = nullptr;
     int64_t *cd = nullptr;
     int32_t *rd = nullptr;
+    void *cwork = nullptr;
     hipError_t e = hipSuccess;
     {                                                       // every staging buffer out of the context's grow-only input buffer
         Bump S;
-        const size_t a_x = S.take(sizeof(double) * (size_t)ld * p), a_y = S.take(sizeof(double) * (size_t)(n + 2)),
+        const size_t a_x = S.take(use_csc ? csc_moments_work_bytes(n, p) : sizeof(double) * (size_t)ld * p),
+                     a_y = S.take(sizeof(double) * (size_t)(n + 2)),
                      a_c = S.take(sizeof(int64_t) * (size_t)(p + 1)), a_r = S.take(sizeof(int32_t) * (size_t)(nnz + 1)),
                      a_v = S.take(sizeof(double) * (size_t)(nnz + 1));
         if (ctx_grow(c, &c->xres, &c->xres_bytes, S.off)) { ctx_release(c); return OEMGPU_ERR_HIP; }
-        xd = (double *)(c->xres + a_x); yd = (double *)(c->xres + a_y); cd = (int64_t *)(c->xres + a_c);
+        xd = (double *)(c->xres + a_x); cwork = c->xres + a_x; yd = (double *)(c->xres + a_y); cd = (int64_t *)(c->xres + a_c);
         rd = (int32_t *)(c->xres + a_r); vd = (double *)(c->xres + a_v);
     }
-    if (e == hipSuccess) e = hipMemsetAsync(xd, 0, sizeof(double) * (size_t)ld * p, c->stream);
+    if (e == hipSuccess && !use_csc) e = hipMemsetAsync(xd, 0, sizeof(double) * (size_t)ld * p, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(yd, y, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(cd, colptr, sizeof(int64_t) * (size_t)(p + 1), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(rd, rowidx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, c->stream);
@@ -1094,7 +1106,8 @@ int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t
         rc = ctx_reserve(c, B.off + paths_ws_bytes(p, q, o) + 4096) ? OEMGPU_ERR_HIP : 0;
         double *mom = (double *)(c->ws + a_mom), *mtmp = (double *)(c->ws + a_tmp);
         if (!rc && hipMemsetAsync(mom, 0, mlen * 8, c->stream) != hipSuccess) rc = OEMGPU_ERR_HIP;
-        for (int64_t r0 = 0; r0 < n && !rc; r0 += rcrows) {
+        if (!rc && use_csc) rc = launch_csc_moments(c->stream, cd, rd, vd, yd, n, p, cwork, mom);
+        for (int64_t r0 = 0; r0 < n && !rc && !use_csc; r0 += rcrows) {
             const int64_t r1 = r0 + rcrows < n ? r0 + rcrows : n, nr = r1 - r0;
             if (hipMemsetAsync(xd, 0, sizeof(double) * (size_t)ld * p, c->stream) != hipSuccess) { set_error("fit_sparse: memset failed"); rc = OEMGPU_ERR_HIP; break; }
             if (nnz > 0) {

@@ -51,6 +51,12 @@ int launch_finalize(hipStream_t s, const double *moments, const double *sums, in
 int launch_xtx_prepare(hipStream_t s, const double *xtx, const double *xty, const double *sf_inv /* or null */, int p,
                        double *xx, double *xy, double *stats);
 
+// ------------------------------------------------------------------ sparse x (sparse.hip): moments of a compressed-sparse-column matrix
+size_t csc_moments_work_bytes(int64_t n, int p);
+bool csc_moments_fits(int p);
+int launch_csc_moments(hipStream_t s, const int64_t *colptr, const int32_t *rowidx, const double *val, const double *y, int64_t n, int p,
+                       void *work, double *moments);
+
 // ------------------------------------------------------------------ xval.oem (xval.hip)
 size_t fold_layout_ints(int64_t n, int K);
 int launch_fold_layout(hipStream_t s, const int *foldid, int64_t n, int K, int *blockcnt, int64_t *fold_n, int64_t *fold_start,

@@ -578,7 +578,6 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
         for (int r = 0; r < R; ++r) v[r] *= nn;
     }
     int msteps = A.lanczos_steps < C::ML ? A.lanczos_steps : C::ML;
-    if (msteps > p) msteps = p;
     int nst = 0;
     double bprev = 0.0;
     // Wave 0 evaluates the top Ritz value (the other waves wait at the barrier and read it from LDS).  From step 16
@@ -1099,7 +1098,6 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
 
     // ---- eigenvalue step: Lanczos with the vector spread over the waves (one entry per owner lane)
     int msteps = A.lanczos_steps < C::ML ? A.lanczos_steps : C::ML;
-    if (msteps > p) msteps = p;
     double *theta_slot = lds + C::OFF_TH;
     double *tsink = lds + C::OFF_TH + 2 + tid;                       // a scratch word per lane: stores without exec branches
     auto top_ritz = [&](int m, double hint) {

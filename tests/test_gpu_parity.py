@@ -416,6 +416,32 @@ def test_sparse_x(oa, std, icpt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,p,dens", [(20000, 57, 0.01), (9000, 130, 0.03), (40000, 8, 0.2), (8193, 33, 0.002), (5000, 300, 0.01)])
+def test_sparse_x_compressed_column_gram(oa, monkeypatch, n, p, dens):
+    """the compressed-column moment kernel (sparse.hip: LDS copy of a row chunk of one column, the other columns gathered against it)
+    and the zero-filled tiles through the MFMA pass are two routes to the same moment buffer: same fits, both the oracle's"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(n + p)
+    x = sp.random(n, p, density=dens, random_state=3, format="csc", data_rvs=lambda k: rng.normal(size=k) * 1.5)
+    x = sp.csc_matrix(x); x[:, p - 1] = 0.0; x.eliminate_zeros()                 # an empty column on the way
+    b = np.zeros(p); b[:5] = [1.0, -1.0, 0.5, 2.0, -0.7]
+    y = x @ b + rng.normal(size=n) * 0.5 + 0.8
+    kw = dict(penalty=["lasso", "mcp"], nlambda=8, tol=1e-9, maxit=2000)
+    monkeypatch.setenv("OEM_SPARSE_GRAM", "csc")
+    a = oa.oem(x, y, **kw)
+    monkeypatch.setenv("OEM_SPARSE_GRAM", "dense")
+    d = oa.oem(x, y, **kw)
+    r = orc.fit_sparse(x, y, lambda_min_ratio=1e-4, **kw)
+    assert abs(a["d"] - r["d"]) < 1e-10 * r["d"]
+    for k in range(2):
+        assert np.abs(a["beta"][k] - d["beta"][k]).max() < 1e-9
+        assert np.abs(a["beta"][k] - r["beta"][k]).max() < 1e-8 * max(1.0, float(np.abs(r["beta"][k]).max()))
+    monkeypatch.setenv("OEM_SPARSE_GRAM", "csc")
+    a2 = oa.oem(x, y, **kw)
+    assert np.array_equal(a["beta"][0], a2["beta"][0])                            # fixed summation order: bitwise reproducible
+
+
+@pytest.mark.gpu
 def test_sparse_x_groups_follow_the_variables(oa):
     """with an intercept the group vector of a sparse x has p + 1 entries, slot 0 the intercept's unpenalised group 0
     (ref R/oem.R:296-338, src/oem_sparse.h:465).  The LAST variable sits in an active group here: one slot off, it would be in no

@@ -33,12 +33,30 @@ def timeit(fn, reps=3):
     return 1e3 * (time.perf_counter() - t0) / reps, r
 
 
+import os
 t_dense, fit = timeit(lambda: oem_amd.oem(xd, ys, **kw))
-t_sparse, fits = timeit(lambda: oem_amd.oem(xs, ys, lambda_=fit["lambda"], **kw))
+t_sparse, fits = timeit(lambda: oem_amd.oem(xs, ys, lambda_=fit["lambda"], **kw))           # density 1 %: the compressed-column Gram
+os.environ["OEM_SPARSE_GRAM"] = "dense"
+t_sparse_tiles, fitt = timeit(lambda: oem_amd.oem(xs, ys, lambda_=fit["lambda"], **kw))     # zero-filled tiles + MFMA pass
+del os.environ["OEM_SPARSE_GRAM"]
+other = {}
+for dens in (0.001, 0.05):                                                                  # both ways at other densities
+    xo = sp.random(n, p, density=dens, random_state=8, format="csc", data_rvs=lambda k: rng.normal(size=k))
+    yo = rng.normal(size=n) + xo @ tb
+    r = {}
+    for mode in ("csc", "dense"):
+        os.environ["OEM_SPARSE_GRAM"] = mode
+        r[mode + "_ms"], f_ = timeit(lambda: oem_amd.oem(xo, yo, **kw))
+        r[mode] = f_
+    del os.environ["OEM_SPARSE_GRAM"]
+    other[str(dens)] = {"csc_ms": r["csc_ms"], "dense_tiles_ms": r["dense_ms"],
+                        "max_abs_diff": float(max(np.abs(r["csc"]["beta"][k] - r["dense"]["beta"][k]).max() for k in range(2)))}
 t0 = time.perf_counter()
 ref = orc.fit_sparse(xs, ys, unique_groups=np.unique(groups), lambda_=fit["lambda"], native=True, **kw)
 t_cpu = 1e3 * (time.perf_counter() - t0)
 print(json.dumps({"n": n, "p": p, "nnz": int(xs.nnz), "gpu_dense_host_x_ms": t_dense, "gpu_sparse_host_x_ms": t_sparse,
+                  "gpu_sparse_host_x_dense_tiles_ms": t_sparse_tiles, "other_densities_host_x": other,
+                  "max_abs_csc_vs_tiles": [float(np.abs(fitt["beta"][k] - fits["beta"][k]).max()) for k in range(2)],
                   "cpu_oracle_sparse_1thread_ms": t_cpu,
                   "max_abs_dense_vs_sparse": [float(np.abs(fit["beta"][k] - fits["beta"][k]).max()) for k in range(2)],
                   "max_abs_sparse_vs_oracle": [float(np.abs(ref["beta"][k] - fits["beta"][k]).max()) for k in range(2)]}))
