@@ -254,8 +254,10 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const size_t out_stride = (out_bytes + 255) / 256 * 256;
     const bool small = q <= SMALL_P_MAX;
     const bool loss_on = (sem == OEMGPU_SEM_DENSE || sem == OEMGPU_SEM_XVAL || sem == SEM_SPARSE) && o->compute_loss != 0;
-    const bool coop = !small && path_coop_eligible(q, scale_factor != nullptr, loss_on, og.ngroups, nbatch);
-    if (nbatch > 1 && !small) { set_error("internal: batched paths need p <= %d", SMALL_P_MAX); return OEMGPU_ERR_INTERNAL; }
+    // several instances (xval.oem's K + 1 fits) on the cooperating engine: only if all their workgroup sets are resident at once
+    const bool coop = !small && path_coop_eligible(q, scale_factor != nullptr, loss_on, og.ngroups, nbatch) &&
+                      (nbatch == 1 || path_coop_workgroups(q) * nbatch <= c->num_cu * 3 / 4);
+    if (nbatch > 1 && !small && !coop) { set_error("internal: batched paths need p <= %d", SMALL_P_MAX); return OEMGPU_ERR_INTERNAL; }
     // Lanczos step cap: q up to 288 (the whole Krylov space: the recurrence stops by itself when the top Ritz value has settled, and
     // a spectrum that needs more than 128 steps gets them -- ADVICE r1); the large-p engines keep their own caps (256 / 512)
     // (more steps than rows: without re-orthogonalisation a clustered spectrum does not exhaust the Krylov space in q steps -- a 9 x 9
@@ -266,7 +268,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     // the outputs come first: when the caller's frame ends with `stats` (both callers), stats | outputs is one
     // contiguous range and one device-to-host copy returns both
     // one workgroup (set) per penalty: they are independent cold starts (the cooperating sets must all be resident: <= half the CUs)
-    const bool pen_split = npen > 1 && (small || (coop && path_coop_workgroups(q) * npen <= c->num_cu / 2));
+    const bool pen_split = npen > 1 && (small || (coop && path_coop_workgroups(q) * npen * nbatch <= c->num_cu / 2));
     const size_t a_out = B.take(out_stride * nbatch), a_blob = B.take(bl.h.size()),
                  a_work = B.take(work_d * sizeof(double) * nbatch * (pen_split ? npen : 1));
     // the workspace may be re-allocated by ctx_reserve: xx/xy/stats are offsets into it, so recompute after
@@ -322,7 +324,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const size_t back_bytes = nbatch > 1 ? out_stride * nbatch : out_bytes + (joined ? st_gap : 0);
     if (ctx_pinned(c, back_bytes > 16384 ? back_bytes : 16384)) return OEMGPU_ERR_HIP;
     CoopSlots slots;                                  // held until the stream has been synchronised below
-    if (coop) slots.take(path_coop_workgroups(q) * (pen_split ? npen : 1), c->num_cu * 3 / 4);
+    if (coop) slots.take(path_coop_workgroups(q) * (pen_split ? npen : 1) * nbatch, c->num_cu * 3 / 4);
     {
         Timer t(c, OEMGPU_T_EIGPATH);
         PollScope poll(o);
@@ -385,7 +387,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
 size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o, int nbatch = 1)
 {
     const int nl = nl_of(o);
-    if (nbatch > 1) return (size_t)nbatch * (paths_ws_bytes(p, q, o) + 1024);
+    if (nbatch > 1) return (size_t)nbatch * (paths_ws_bytes(p, q, o) + 1024) + (q > SMALL_P_MAX ? (size_t)nbatch * o->npen * path_coop_xchg_bytes() : 0);
     const size_t splits = (q <= 1024 && o->npen > 1) ? (size_t)o->npen : 1;
     size_t b = 0;
     b += (size_t)o->npen * 4 + (size_t)o->npen * nl * 8 + (size_t)q * (8 + 8 + 4) + (size_t)(o->ngroups + 2) * 16 +
@@ -818,6 +820,12 @@ static int solve_moments_batch(oemgpu_ctx *c, const double *moments, size_t mstr
 }
 
 // ---------------------------------------------------------------------------------------------- xval.oem
+static int any_grp_count(const oemgpu_opts *o)
+{
+    for (int k = 0; k < o->npen; ++k) if (pen_is_grp(o->penalty[k])) return o->ngroups;
+    return 0;
+}
+
 static int ctx_aux(oemgpu_ctx *c, size_t bytes)
 {
     if (bytes <= c->aux_bytes) return 0;
@@ -910,7 +918,9 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t
         if (!rc && w_dev) rc = launch_fold_sum(c->stream, csq, K, cslen, ff, cssum + cslen * ff);
         if (rc) return rc;
     }
-    if (q <= SMALL_P_MAX) {
+    const bool coop_batch = q > SMALL_P_MAX && path_coop_eligible(q, false, o->compute_loss != 0, any_grp_count(o), K + 1) &&
+                            path_coop_workgroups(q) * (K + 1) <= c->num_cu * 3 / 4;
+    if (q <= SMALL_P_MAX || coop_batch) {
         // The K + 1 fits are independent chains of tiny dependent steps: ONE launch, one workgroup (set) per fit.  (K streams
         // would run four at a time: the hardware queues are few.)  The folds' lambda grid is the full fit's, which a fold's
         // kernel derives from the full-data X'Y itself (PathArgs::lmax_xy) instead of waiting for the full fit to end.

@@ -634,7 +634,7 @@ bool path_coop_eligible(int q, bool has_sinv, bool compute_loss, int ngroups, in
     if (getenv("OEM_NO_COOP") || q <= SMALL_P_MAX || q > 1024) return false;      // OEM_NO_COOP: the launch-per-iteration engines
     if (has_sinv && compute_loss) return false;          // the loss of the un-rescaled member would need a product of its own
     if (ngroups > (q <= 512 ? 512 : 1024)) return false;
-    if (nbatch > 1) return false;
+    (void)nbatch;                                        // nbatch > 1: the caller checks that all workgroup sets fit (api.hip: run_paths)
     return true;
 }
 
@@ -646,8 +646,9 @@ int launch_path_coop(hipStream_t s, const PathArgs &a_)
     const int q = a.p;
     a.lanczos_steps = q < CML ? q : CML;
     static const int stride = getenv("OEM_COOP_STRIDE") ? atoi(getenv("OEM_COOP_STRIDE")) : 1;
-    const int ninst = a.pen_split ? a.npen : 1;
-    OEM_HIP(hipMemsetAsync(a.work, 0, path_coop_xchg_bytes() * ninst, s));     // granule tags must start at 0
+    const int ninst = (a.nbatch > 1 ? a.nbatch : 1) * (a.pen_split ? a.npen : 1);
+    if (ninst > 1 && (size_t)a.bs_work * 8 < path_coop_xchg_bytes()) { set_error("internal: coop work stride"); return OEMGPU_ERR_INTERNAL; }
+    OEM_HIP(hipMemsetAsync(a.work, 0, (ninst > 1 ? (size_t)a.bs_work * 8 : path_coop_xchg_bytes()) * ninst, s));     // granule tags must start at 0
     if (q <= 512) {
         typedef CoopCfg<2> C;
         const int W = (q + C::RW - 1) / C::RW;

@@ -99,8 +99,12 @@ def test_device_resident_readme_shape(oa):
     assert int(np.nonzero(f["lambda"][0] == f["lambda.min"])[0][0]) == imin
 
 
-def test_large_p_takes_the_threaded_fold_fits(oa):
-    """p + 1 > 288: the fold fits run on the launch-per-iteration engine, one host thread and child context per fold."""
+@pytest.mark.parametrize("route", ["one launch of cooperating workgroup sets", "a host thread and child context per fold"])
+def test_large_p_takes_the_threaded_fold_fits(oa, monkeypatch, route):
+    """p + 1 > 288: the K + 1 fits as workgroup sets of ONE cooperating-engine launch when they all fit the chip; otherwise (here:
+    forced with OEM_NO_COOP) one host thread and child context per fold on the launch-per-iteration engines."""
+    if route.startswith("a host thread"):
+        monkeypatch.setenv("OEM_NO_COOP", "1")
     rng = np.random.default_rng(14)
     n, p = 3000, 300
     x = np.asfortranarray(rng.normal(size=(n, p)))
