@@ -548,6 +548,54 @@ __device__ __forceinline__ void consume_ring_strip(Slab<NT> &s, const v2d (&ua)[
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Diagonal tiles as 4x4 sub-blocks (un-shifted ring form, NT >= 6).  A 16x16x4 MFMA on a diagonal tile computes 256 entries of which 136
+// are wanted.  The tile is a 4 x 4 grid of 4x4 sub-blocks; v_mfma_f64_4x4x4_4b_f64 multiplies four independent block pairs in a
+// quarter of the time, and with the B operand the plain column fragment (block slot b = columns 4b .. 4b + 3) and the A operand the
+// SAME fragment rotated left by 4 r lanes inside each 16-lane row (slot b then holds columns 4 ((b + r) mod 4) ...), rotation r yields
+// the sub-blocks ((b + r) mod 4, b): r = 0 the four diagonal ones, r = 1 (1,0) (2,1) (3,2) and (0,3) = (3,0) transposed, r = 2 (2,0)
+// (3,1) and two duplicates -- all ten lower sub-blocks in 3 x 16.5 cycles instead of 64.  The rotated operands are two more reads of
+// the ring slot with a permuted lane address; the three accumulators live in the tile's own AGPRs (a[8T .. 8T + 5]).  In the result
+// layout of the 16x16x4 tile (row = (lane >> 4) + 4 reg, column = lane & 15) the value of rotation r in lane L belongs to register
+// ((L & 15) / 4 + r) mod 4 of the SAME lane (the epilogue stores it there; the (0,3) block goes transposed into register 3).
+// p = 100: 3,141 -> 2,949 MFMA issue cycles per slab.
+template <int NT, int SB, bool LAST_PLAIN, typename Hook = NoHook>
+__device__ __forceinline__ void consume_ring_dg(Slab<NT> &s, const v2d (&ua)[SB > 0 ? SB : 1], const v2d (&r1)[NT - 1],
+                                                const v2d (&r2)[NT - 1], Hook &&hook = NoHook())
+{
+    constexpr int NM16 = (NT - 1) * NT / 2;
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<2>([&](auto E) {
+        constexpr int e = decltype(E)::value;
+        static_for<NT - 1>([&](auto I_) {
+            constexpr int I = decltype(I_)::value;
+            static_for<I>([&](auto J_) {
+                constexpr int J = decltype(J_)::value;
+                AccTile<I *(I + 1) / 2 + J>::mfma(s.v[I][e], s.v[J][e]);
+                hook(std::integral_constant<int, e * NM16 + I * (I + 1) / 2 + J>{});
+            });
+            AccTile<I *(I + 1) / 2 + I>::template mfma444<0>(s.v[I][e], s.v[I][e]);
+            AccTile<I *(I + 1) / 2 + I>::template mfma444<1>(r1[I][e], s.v[I][e]);
+            AccTile<I *(I + 1) / 2 + I>::template mfma444<2>(r2[I][e], s.v[I][e]);
+            hook(std::integral_constant<int, e * NM16 + I * (I + 1) / 2 + I>{});
+        });
+        if constexpr (LAST_PLAIN) {                             // the last tile row as plain tiles (ragged slab; SB == 0)
+            static_for<NT>([&](auto J_) {
+                constexpr int J = decltype(J_)::value;
+                AccTile<(NT - 1) * NT / 2 + J>::mfma(s.v[NT - 1][e], s.v[J][e]);
+            });
+        } else {
+            static_for<SB>([&](auto A_) {
+                constexpr int a = decltype(A_)::value;
+                static_for<NT>([&](auto T_) {
+                    constexpr int T = decltype(T_)::value;
+                    AccStrip<a * NT + T>::mfma(ua[a][e], s.v[T][e]);
+                });
+            });
+        }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // SADDR: fragments 0 .. NT-2 (whole X columns) are addressed as one scalar base (advanced by a scalar add per slab) plus
 // a 32-bit per-lane offset; only the last fragment (y, ones, another allocation) keeps a 64-bit pointer per lane.
 // A 64-bit VALU add runs on the DP units the MFMAs need: seven pointer bumps cost 75 cycles per slab (measured).
@@ -557,6 +605,7 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
                                                    int64_t row_begin, int steps, double *__restrict__ tdst, double *lds)
 {
     constexpr int NF = NT, NTILES = NT * (NT + 1) / 2;
+    constexpr bool DG = !SHIFT && NT >= 6;                          // diagonal tiles as rotated 4x4x4 sub-blocks (consume_ring_dg)
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, q = lane >> 4;
     const gptr_t xg = (gptr_t)x, yg = (gptr_t)y;
     gptr_t cur[NF];
@@ -632,15 +681,24 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
     // strip A operands: lane (q, blk, x) reads the 16 B of lane (q, a, x) of the last fragment (both k halves)
     const v2d *ring_rdA = reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(lds) + w * (NSLOT * SLOT_B)) +
                           (NF - 1) * 64 + 16 * q + (lane & 3);
-    auto fetch = [&](Slab<NF> &s, v2d (&ua)[SB > 0 ? SB : 1], int slot) {   // ring slot -> registers (a lane reads back its own 16 B)
+    // rotated A operands of the diagonal tiles: lane (q, i) reads the 16 B of lane (q, (i + 4 r) mod 16), r = 1, 2
+    const v2d *ring_rd1 = reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(lds) + w * (NSLOT * SLOT_B)) + (16 * q + ((i + 4) & 15));
+    const v2d *ring_rd2 = reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(lds) + w * (NSLOT * SLOT_B)) + (16 * q + ((i + 8) & 15));
+    constexpr int NR = DG ? NT - 1 : 1;
+    auto fetch = [&](Slab<NF> &s, v2d (&ua)[SB > 0 ? SB : 1], v2d (&r1)[NR], v2d (&r2)[NR], int slot) {   // ring slot -> registers (a lane reads back its own 16 B)
 #pragma unroll
         for (int f = 0; f < NF; ++f) s.v[f] = ring_rd[(slot * SLOT_B + f * 1024) / 16];
 #pragma unroll
         for (int a = 0; a < SB; ++a) ua[a] = ring_rdA[(slot * SLOT_B) / 16 + 4 * a];
+        if constexpr (DG) {
+#pragma unroll
+            for (int f = 0; f < NT - 1; ++f) { r1[f] = ring_rd1[(slot * SLOT_B + f * 1024) / 16]; r2[f] = ring_rd2[(slot * SLOT_B + f * 1024) / 16]; }
+        }
     };
     auto next = [](int v) { return v + 1 == NSLOT ? 0 : v + 1; };
     Slab<NF> sa, sb;
     v2d ua[SB > 0 ? SB : 1], ub[SB > 0 ? SB : 1];
+    v2d ra1[NR], ra2[NR], rb1[NR], rb2[NR];
     sa.y = v2d{0.0, 0.0}; sb.y = sa.y;
 #ifdef OEM_GRAM_DIAG
     unsigned long long gd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gl = __builtin_amdgcn_s_memtime();
@@ -651,7 +709,7 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
     int slot = 0, islot = npre % NSLOT, issued = npre, k = 0;
     if (ns > 0) {
         if (npre == NSLOT - 1) wait_vm<(NSLOT - 2) * NF>(); else wait_vm<0>();
-        fetch(sa, ua, 0);
+        fetch(sa, ua, ra1, ra2, 0);
         slot = next(slot);
     }
     // steady state, two slabs per trip (sa / sb alternate as "in registers" and "being fetched"):
@@ -660,10 +718,12 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
     // steady state: while the MFMAs of slab k run, the hook (a) issues the DMA of slab k+NSLOT-1 after MFMAs 1..NF,
     // (b) bumps the pointers, (c) waits for slab k+1 (exact vmcnt) and (d) copies it from the ring to the other
     // register slab after MFMAs NF+2 .. 2NF+1.  None of it is FP64 VALU, so it rides in the MFMA shadows.
-    auto steady = [&](Slab<NF> &use, Slab<NF> &nxt, v2d (&uuse)[SB > 0 ? SB : 1], v2d (&unxt)[SB > 0 ? SB : 1]) {
+    auto steady = [&](Slab<NF> &use, Slab<NF> &nxt, v2d (&uuse)[SB > 0 ? SB : 1], v2d (&unxt)[SB > 0 ? SB : 1],
+                      v2d (&r1use)[NR], v2d (&r2use)[NR], v2d (&r1nxt)[NR], v2d (&r2nxt)[NR]) {
         const unsigned dst = ring + (unsigned)islot * SLOT_B;
         const v2d *src = ring_rd + (slot * SLOT_B) / 16;
         const v2d *srcA = ring_rdA + (slot * SLOT_B) / 16;
+        const v2d *src1 = ring_rd1 + (slot * SLOT_B) / 16, *src2 = ring_rd2 + (slot * SLOT_B) / 16;
         // OEM_GRAM_EXP (timing experiments in diagnostic builds only; results are wrong): 1 = no DMA issue,
         // 2 = no ring reads, 3 = no vmcnt wait, 4 = no pointer bumps, 5 = block kernel without shift / VALU sums
         auto hook = [&](auto M_) {
@@ -676,17 +736,24 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
             }
             if constexpr (OEM_GRAM_EXP != 2 && m >= NF + 2 && m <= 2 * NF + 1) nxt.v[m - NF - 2] = src[((m - NF - 2) * 1024) / 16];
             if constexpr (OEM_GRAM_EXP != 2 && SB > 0 && m >= 2 * NF + 2 && m < 2 * NF + 2 + SB) unxt[m - 2 * NF - 2] = srcA[4 * (m - 2 * NF - 2)];
+            // rotated operands of the next slab's diagonal tiles: two reads per hook
+            if constexpr (DG && m >= 2 * NF + 2 + SB && m < 2 * NF + 2 + SB + (NT - 1)) {
+                constexpr int f = m - (2 * NF + 2 + SB);
+                r1nxt[DG ? f : 0] = src1[(f * 1024) / 16]; r2nxt[DG ? f : 0] = src2[(f * 1024) / 16];
+            }
         };
-        if constexpr (SB > 0) consume_ring_strip<NT, SB>(use, uuse, hook);
+        if constexpr (DG) consume_ring_dg<NT, SB, (SB == 0)>(use, uuse, r1use, r2use, hook);
+        else if constexpr (SB > 0) consume_ring_strip<NT, SB>(use, uuse, hook);
         else consume_slab<NT, NT, true, false, false, true, SHIFT>(V, use, X, cy, 0, n, hook);
         islot = next(islot); slot = next(slot);
     };
     static_assert(SB == 0 || 2 * NF + 2 + SB <= (NT - 1) * NT, "not enough 16x16x4 MFMAs per slab to carry the hooks");
     static_assert(2 * NF + 1 < NT * (NT + 1), "not enough MFMAs per slab to carry the hooks");
+    static_assert(!DG || 2 * NF + 2 + SB + (NT - 1) <= (NT - 1) * NT, "not enough hook slots per slab for the rotated reads");
     while (k + NSLOT + 1 <= ns) {
-        steady(sa, sb, ua, ub);
+        steady(sa, sb, ua, ub, ra1, ra2, rb1, rb2);
         GSTAMP(4);
-        steady(sb, sa, ub, ua);
+        steady(sb, sa, ub, ua, rb1, rb2, ra1, ra2);
         GSTAMP(4);
         issued += 2; k += 2;
     }
@@ -694,14 +761,19 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
     while (issued < ns) { issue(islot); islot = next(islot); ++issued; }
     wait_vm<0>();
     for (; k < ns; ++k) {
-        if (k + 1 < ns) { fetch(sb, ub, slot); slot = next(slot); }
-        if constexpr (SB > 0) consume_ring_strip<NT, SB>(sa, ua);
+        if (k + 1 < ns) { fetch(sb, ub, rb1, rb2, slot); slot = next(slot); }
+        if constexpr (DG) consume_ring_dg<NT, SB, (SB == 0)>(sa, ua, ra1, ra2);
+        else if constexpr (SB > 0) consume_ring_strip<NT, SB>(sa, ua);
         else consume_slab<NT, NT, true, false, false, true, SHIFT>(V, sa, X, cy, 0, n);
         if (k + 1 < ns) {
 #pragma unroll
             for (int f = 0; f < NF; ++f) sa.v[f] = sb.v[f];
 #pragma unroll
             for (int a = 0; a < SB; ++a) ua[a] = ub[a];
+            if constexpr (DG) {
+#pragma unroll
+                for (int f = 0; f < NT - 1; ++f) { ra1[f] = rb1[f]; ra2[f] = rb2[f]; }
+            }
         }
     }
     GSTAMP(5);                                   // drain
@@ -719,7 +791,21 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
                                   : cur[f] + (f - CEN) * 128;
             sa.v[f].x = pf[o0]; sa.v[f].y = pf[o1];
         }
-        consume_slab<NT, NT, true, true, false, true, SHIFT>(V, sa, X, cy, r, n);
+        if constexpr (DG) {
+            // the diagonal tiles' AGPRs hold 4x4x4 accumulators: the ragged slab takes the same form.  Rows past n are masked to
+            // zero, the fragments go through (free) ring slot 0 of this wave to come back rotated, the last tile row stays plain.
+            const double m0 = (r < n) ? 1.0 : 0.0, m1 = (r + 1 < n) ? 1.0 : 0.0;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) { sa.v[f].x *= m0; sa.v[f].y *= m1; }
+            v2d *ring_wr = reinterpret_cast<v2d *>(reinterpret_cast<char *>(lds) + w * (NSLOT * SLOT_B)) + lane;
+#pragma unroll
+            for (int f = 0; f < NT - 1; ++f) ring_wr[(f * 1024) / 16] = sa.v[f];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+            for (int f = 0; f < NT - 1; ++f) { ra1[f] = ring_rd1[(f * 1024) / 16]; ra2[f] = ring_rd2[(f * 1024) / 16]; }
+            asm volatile("s_nop 3" ::: "memory");
+            consume_ring_dg<NT, SB, true>(sa, ua, ra1, ra2);
+        } else consume_slab<NT, NT, true, true, false, true, SHIFT>(V, sa, X, cy, r, n);
     }
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     // ---- tile partials: all four waves write their tiles to LDS at once (two passes of <= 14 tiles: 4 x 28 KiB),
@@ -729,10 +815,25 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
         constexpr int pass = decltype(P_)::value, t0 = pass * TPP, t1 = (t0 + TPP < NTILES) ? t0 + TPP : NTILES;
         static_for<(t1 - t0)>([&](auto T_) {
             constexpr int tt = t0 + decltype(T_)::value;
-            static_for<4>([&](auto R_) {
-                constexpr int r = decltype(R_)::value;
-                lds[(size_t)w * (TPP * 256) + ((tt - t0) * 4 + r) * 64 + lane] = AccTile<tt>::template read<r>();
-            });
+            // is tt a diagonal tile (I, I) with I < NT - 1 ?  tt = I (I + 3) / 2
+            constexpr bool isdiag = DG && [] { for (int I = 0; I < NT - 1; ++I) if (I * (I + 3) / 2 == tt) return true; return false; }();
+            if constexpr (isdiag) {
+                double *tl = lds + (size_t)w * (TPP * 256) + (size_t)(tt - t0) * 256;
+                static_for<4>([&](auto R_) { tl[decltype(R_)::value * 64 + lane] = 0.0; });
+                const int b4 = i >> 2;
+                static_for<3>([&](auto R_) {
+                    constexpr int r = decltype(R_)::value;
+                    const double v = AccTile<tt>::template read<r>();           // registers 2r, 2r + 1 of the tile: rotation r
+                    int reg = (b4 + r) & 3, ln = lane;
+                    if (r == 1 && b4 == 3) { reg = 3; ln = ((lane & 3) << 4) | q; }   // (0,3) -> (3,0) transposed
+                    tl[reg * 64 + ln] = v;
+                });
+            } else {
+                static_for<4>([&](auto R_) {
+                    constexpr int r = decltype(R_)::value;
+                    lds[(size_t)w * (TPP * 256) + ((tt - t0) * 4 + r) * 64 + lane] = AccTile<tt>::template read<r>();
+                });
+            }
         });
         // strip accumulator (a, T): lane 16 i + c holds element (row 4 a + i, column c) of tile (NT-1, T); the 16x16x4
         // layout keeps (row, c) in register row / 4 of lane 16 (row % 4) + c: register a of the same lane
