@@ -338,7 +338,7 @@ def main():
                        "n": n, "p": p, "nlambda": int(len(lambdas)), "rows_per_gpu": n_loc,
                        "sharding": "rows/N + one all-reduce of the (p+2)^2 moment buffer" if world > 1 else "none",
                        "oem_iterations_per_solve": niter_total},
-            "roofline": {"bound": "mfma", "kernel": "gram_ring_kernel<7> (v_mfma_f64_16x16x4_f64)",
+            "roofline": {"bound": "mfma", "kernel": "gram_ring_kernel<7> (v_mfma_f64_16x16x4_f64; diagonal tiles and the ragged strip as v_mfma_f64_4x4x4_4b_f64 sub-blocks)",
                          "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src,
