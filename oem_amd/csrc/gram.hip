@@ -192,13 +192,16 @@ __device__ __forceinline__ void set_m0(unsigned lds_byte_addr)
 {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_byte_addr) : "memory");
 }
+#ifndef OEM_GLDS_POLICY
+#define OEM_GLDS_POLICY ""                  // cache policy of the slab DMAs (" nt": experiment knob)
+#endif
 template <int OFFB> __device__ __forceinline__ void glds_v(gptr_t src)               // 64-bit per-lane address
 {
-    asm volatile("global_load_lds_dwordx4 %0, off offset:%1" ::"v"(src), "i"(OFFB) : "memory");
+    asm volatile("global_load_lds_dwordx4 %0, off offset:%1" OEM_GLDS_POLICY ::"v"(src), "i"(OFFB) : "memory");
 }
 template <int OFFB> __device__ __forceinline__ void glds_s(unsigned voff, gptr_t sbase)   // scalar base + 32-bit lane offset
 {
-    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(sbase), "i"(OFFB) : "memory");
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" OEM_GLDS_POLICY ::"v"(voff), "s"(sbase), "i"(OFFB) : "memory");
 }
 template <int PENDING> __device__ __forceinline__ void wait_vm()
 {
@@ -557,12 +560,15 @@ __device__ __forceinline__ void consume_ring_strip(Slab<NT> &s, const v2d (&ua)[
 // the ring slot with a permuted lane address; the three accumulators live in the tile's own AGPRs (a[8T .. 8T + 5]).  In the result
 // layout of the 16x16x4 tile (row = (lane >> 4) + 4 reg, column = lane & 15) the value of rotation r in lane L belongs to register
 // ((L & 15) / 4 + r) mod 4 of the SAME lane (the epilogue stores it there; the (0,3) block goes transposed into register 3).
-// p = 100: 3,141 -> 2,949 MFMA issue cycles per slab.
+// Rotation 2 fills only two of its four block slots with wanted sub-blocks, so two diagonal tiles share one MFMA: block slots 0, 1 take
+// tile 2P's (2,0) and (3,1), slots 2, 3 tile 2P+1's (0,2) and (1,3), their transposes -- A lanes i < 8 <- fragment 2P lanes i + 8, lanes
+// i >= 8 <- fragment 2P+1 lanes i - 8; B lanes i < 8 <- fragment 2P lanes i, lanes i >= 8 <- fragment 2P+1 lanes i (two ring reads with
+// lane-dependent addresses, as many as the two rotated reads they replace; this assignment keeps them free of bank conflicts).  p = 100: 3,141 -> 2,976 (rotations per tile) -> 2,877 (paired) MFMA issue cycles per slab.
 template <int NT, int SB, bool LAST_PLAIN, typename Hook = NoHook>
 __device__ __forceinline__ void consume_ring_dg(Slab<NT> &s, const v2d (&ua)[SB > 0 ? SB : 1], const v2d (&r1)[NT - 1],
                                                 const v2d (&r2)[NT - 1], Hook &&hook = NoHook())
 {
-    constexpr int NM16 = (NT - 1) * NT / 2;
+    constexpr int NM16 = (NT - 1) * NT / 2, NP = (NT - 1) / 2;      // NP pairs of diagonal tiles share their rotation-2 MFMA
     __builtin_amdgcn_sched_barrier(0);
     static_for<2>([&](auto E) {
         constexpr int e = decltype(E)::value;
@@ -575,7 +581,11 @@ __device__ __forceinline__ void consume_ring_dg(Slab<NT> &s, const v2d (&ua)[SB 
             });
             AccTile<I *(I + 1) / 2 + I>::template mfma444<0>(s.v[I][e], s.v[I][e]);
             AccTile<I *(I + 1) / 2 + I>::template mfma444<1>(r1[I][e], s.v[I][e]);
-            AccTile<I *(I + 1) / 2 + I>::template mfma444<2>(r2[I][e], s.v[I][e]);
+            // rotation 2 wants only two of its four block slots per tile: tiles 2P and 2P + 1 share ONE MFMA (operands mixed
+            // from both fragments by the ring reads: r2[P] = A, r2[NP + P] = B), accumulated in tile 2P's third register pair
+            if constexpr (I < 2 * NP) {
+                if constexpr (I % 2 == 0) AccTile<I *(I + 1) / 2 + I>::template mfma444<2>(r2[I / 2][e], r2[NP + I / 2][e]);
+            } else AccTile<I *(I + 1) / 2 + I>::template mfma444<2>(r2[2 * NP][e], s.v[I][e]);
             hook(std::integral_constant<int, e * NM16 + I * (I + 1) / 2 + I>{});
         });
         if constexpr (LAST_PLAIN) {                             // the last tile row as plain tiles (ragged slab; SB == 0)
@@ -684,7 +694,19 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
     // rotated A operands of the diagonal tiles: lane (q, i) reads the 16 B of lane (q, (i + 4 r) mod 16), r = 1, 2
     const v2d *ring_rd1 = reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(lds) + w * (NSLOT * SLOT_B)) + (16 * q + ((i + 4) & 15));
     const v2d *ring_rd2 = reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(lds) + w * (NSLOT * SLOT_B)) + (16 * q + ((i + 8) & 15));
-    constexpr int NR = DG ? NT - 1 : 1;
+    // paired rotation 2 (tiles 2P, 2P + 1; add P * 2048 bytes): A lanes i < 8 <- fragment 2P lane i + 8, i >= 8 <- fragment 2P + 1 lane i - 8;
+    //                                                          B lanes i < 8 <- fragment 2P lane i,     i >= 8 <- fragment 2P + 1 lane i
+    // (the two halves of a 16-lane row then read different halves of the 64 LDS banks; tile 2P + 1's blocks come out transposed)
+    const v2d *ring_rdPA = reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(lds) + w * (NSLOT * SLOT_B)) + (i < 8 ? 0 : 64) + (16 * q + (i ^ 8));
+    const v2d *ring_rdPB = reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(lds) + w * (NSLOT * SLOT_B)) + (i < 8 ? 0 : 64) + (16 * q + i);
+    constexpr int NR = DG ? NT - 1 : 1, NP = (NT - 1) / 2;
+    // r2[] entry e of a slab: e < NP pair A operands, NP <= e < 2 NP pair B operands, e = 2 NP (odd tile count) the last tile's own rotation
+    auto r2_src = [&](auto E_) -> const v2d * {
+        constexpr int e = decltype(E_)::value;
+        if constexpr (e < NP) return ring_rdPA + (e * 2048) / 16;
+        else if constexpr (e < 2 * NP) return ring_rdPB + ((e - NP) * 2048) / 16;
+        else return ring_rd2 + ((NT - 2) * 1024) / 16;
+    };
     auto fetch = [&](Slab<NF> &s, v2d (&ua)[SB > 0 ? SB : 1], v2d (&r1)[NR], v2d (&r2)[NR], int slot) {   // ring slot -> registers (a lane reads back its own 16 B)
 #pragma unroll
         for (int f = 0; f < NF; ++f) s.v[f] = ring_rd[(slot * SLOT_B + f * 1024) / 16];
@@ -692,7 +714,8 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
         for (int a = 0; a < SB; ++a) ua[a] = ring_rdA[(slot * SLOT_B) / 16 + 4 * a];
         if constexpr (DG) {
 #pragma unroll
-            for (int f = 0; f < NT - 1; ++f) { r1[f] = ring_rd1[(slot * SLOT_B + f * 1024) / 16]; r2[f] = ring_rd2[(slot * SLOT_B + f * 1024) / 16]; }
+            for (int f = 0; f < NT - 1; ++f) r1[f] = ring_rd1[(slot * SLOT_B + f * 1024) / 16];
+            static_for<NT - 1>([&](auto E_) { r2[decltype(E_)::value] = r2_src(E_)[(slot * SLOT_B) / 16]; });
         }
     };
     auto next = [](int v) { return v + 1 == NSLOT ? 0 : v + 1; };
@@ -723,7 +746,8 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
         const unsigned dst = ring + (unsigned)islot * SLOT_B;
         const v2d *src = ring_rd + (slot * SLOT_B) / 16;
         const v2d *srcA = ring_rdA + (slot * SLOT_B) / 16;
-        const v2d *src1 = ring_rd1 + (slot * SLOT_B) / 16, *src2 = ring_rd2 + (slot * SLOT_B) / 16;
+        const v2d *src1 = ring_rd1 + (slot * SLOT_B) / 16;
+        const int sl16 = (slot * SLOT_B) / 16;
         // OEM_GRAM_EXP (timing experiments in diagnostic builds only; results are wrong): 1 = no DMA issue,
         // 2 = no ring reads, 3 = no vmcnt wait, 4 = no pointer bumps, 5 = block kernel without shift / VALU sums
         auto hook = [&](auto M_) {
@@ -739,7 +763,7 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
             // rotated operands of the next slab's diagonal tiles: two reads per hook
             if constexpr (DG && m >= 2 * NF + 2 + SB && m < 2 * NF + 2 + SB + (NT - 1)) {
                 constexpr int f = m - (2 * NF + 2 + SB);
-                r1nxt[DG ? f : 0] = src1[(f * 1024) / 16]; r2nxt[DG ? f : 0] = src2[(f * 1024) / 16];
+                r1nxt[DG ? f : 0] = src1[(f * 1024) / 16]; r2nxt[DG ? f : 0] = r2_src(std::integral_constant<int, DG ? f : 0>{})[sl16];
             }
         };
         if constexpr (DG) consume_ring_dg<NT, SB, (SB == 0)>(use, uuse, r1use, r2use, hook);
@@ -802,7 +826,8 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
             for (int f = 0; f < NT - 1; ++f) ring_wr[(f * 1024) / 16] = sa.v[f];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-            for (int f = 0; f < NT - 1; ++f) { ra1[f] = ring_rd1[(f * 1024) / 16]; ra2[f] = ring_rd2[(f * 1024) / 16]; }
+            for (int f = 0; f < NT - 1; ++f) ra1[f] = ring_rd1[(f * 1024) / 16];
+            static_for<NT - 1>([&](auto E_) { ra2[decltype(E_)::value] = r2_src(E_)[0]; });
             asm volatile("s_nop 3" ::: "memory");
             consume_ring_dg<NT, SB, true>(sa, ua, ra1, ra2);
         } else consume_slab<NT, NT, true, true, false, true, SHIFT>(V, sa, X, cy, r, n);
@@ -821,13 +846,24 @@ __device__ __forceinline__ void gram_tri_ring_body(const double *__restrict__ x,
                 double *tl = lds + (size_t)w * (TPP * 256) + (size_t)(tt - t0) * 256;
                 static_for<4>([&](auto R_) { tl[decltype(R_)::value * 64 + lane] = 0.0; });
                 const int b4 = i >> 2;
-                static_for<3>([&](auto R_) {
+                constexpr int I = [] { for (int I2 = 0; I2 < NT - 1; ++I2) if (I2 * (I2 + 3) / 2 == tt) return I2; return 0; }();
+                static_for<2>([&](auto R_) {
                     constexpr int r = decltype(R_)::value;
                     const double v = AccTile<tt>::template read<r>();           // registers 2r, 2r + 1 of the tile: rotation r
                     int reg = (b4 + r) & 3, ln = lane;
                     if (r == 1 && b4 == 3) { reg = 3; ln = ((lane & 3) << 4) | q; }   // (0,3) -> (3,0) transposed
                     tl[reg * 64 + ln] = v;
                 });
+                // rotation 2: a pair's accumulator sits in tile 2P (third register pair); block slots 0, 1 are tile 2P's (2,0), (3,1)
+                // (register b4 + 2, same lane), slots 2, 3 tile 2P + 1's transposed ones (register b4, lane 16 j + 4 (b4 - 2) + row); an unpaired last tile
+                // keeps all four slots ((0,2) and (1,3) are duplicates in the upper triangle, which nobody reads)
+                if constexpr (I >= 2 * ((NT - 1) / 2)) tl[((b4 + 2) & 3) * 64 + lane] = AccTile<tt>::template read<2>();
+                else if constexpr (I % 2 == 0) { const double v = AccTile<tt>::template read<2>(); if (b4 < 2) tl[(b4 + 2) * 64 + lane] = v; }
+                else {
+                    constexpr int ttl = (I - 1) * (I + 2) / 2;                  // the pair's first tile
+                    const double v = AccTile<ttl>::template read<2>();
+                    if (b4 >= 2) tl[b4 * 64 + (((lane & 3) << 4) | ((b4 - 2) << 2) | q)] = v;     // (0,2) -> (2,0), (1,3) -> (3,1): transposed
+                }
             } else {
                 static_for<4>([&](auto R_) {
                     constexpr int r = decltype(R_)::value;

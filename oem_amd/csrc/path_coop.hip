@@ -354,7 +354,7 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
         return th;
     };
     int nst = 0;
-    double bprev = 0.0, theta = 0.0, theta_prev = -__builtin_inf();
+    double bprev = 0.0, theta = 0.0, theta_prev = -__builtin_inf(), mv_prev = __builtin_inf();
     bool have_theta = false;
     for (int j = 0; j < msteps; ++j) {
 #pragma unroll
@@ -376,10 +376,9 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
         if (tid == 0) { Tal[j] = al; Tbe[j] = bb; }
         nst = j + 1;
         if (!(bb > 1e-13 * fabs(al))) break;                        // invariant subspace reached: T is exact
-        if (nst >= 16 && ((nst & 15) == 0 || (nst > 48 && (nst & 7) == 0)) && nst < msteps) {
+        if (lanczos_check_due(nst) && nst < msteps) {
             const double th = top_ritz(nst, theta_prev);            // its first barrier publishes Tal / Tbe
-            if (th - theta_prev <= 1e-14 * fabs(th)) { theta = th; have_theta = true; break; }
-            theta_prev = th;
+            if (lanczos_converged(th, theta_prev, mv_prev)) { theta = th; have_theta = true; break; }
         }
 #pragma unroll
         for (int k = 0; k < EPT; ++k) { vp[k] = v[k]; v[k] = wv[k] * ib; }

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
         __syncthreads();                                            // the slot and the strips are reused
         return th;
     };
-    double theta = 0.0, theta_prev = -__builtin_inf();
+    double theta = 0.0, theta_prev = -__builtin_inf(), mv_prev = __builtin_inf();
     bool have_theta = false;
     for (int j = 0; j < msteps; ++j) {
         gemv_round<R, NW, CW, G>(a, v, wv, P, Uw, w, lane, buf, X OEM_DIAG_PASS);
@@ -614,12 +614,11 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
         if (lane == 0) { Tal[j] = al; Tbe[j] = bb; }
         nst = j + 1;
         if (!(bb > 1e-13 * fabs(al))) break;            // invariant subspace reached: T is exact
-        if (nst >= 16 && ((nst & 15) == 0 || (nst > 48 && (nst & 7) == 0)) && nst < msteps) {
+        if (lanczos_check_due(nst) && nst < msteps) {
             OEM_STAMP(10);
             const double th = top_ritz(nst, theta_prev);
             OEM_STAMP(9);
-            if (th - theta_prev <= 1e-14 * fabs(th)) { theta = th; have_theta = true; break; }
-            theta_prev = th;
+            if (lanczos_converged(th, theta_prev, mv_prev)) { theta = th; have_theta = true; break; }
         }
         const double ib = 1.0 / bb;
 #pragma unroll
@@ -1116,7 +1115,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
         wn = rowok ? ((double)(h >> 8) * (1.0 / 16777216.0) - 0.5) : 0.0;
     }
     int nst = 0;
-    double theta = 0.0, theta_prev = -__builtin_inf(), bb = 0.0;
+    double theta = 0.0, theta_prev = -__builtin_inf(), mv_prev = __builtin_inf(), bb = 0.0;
     bool have_theta = false;
     double al_prev = 0.0;
     OEM_STAMP(5);                                                    // prologue: matrix and vectors into registers
@@ -1128,12 +1127,11 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
             bb = nb;
             *(tid == 0 ? &Tbe[j - 1] : tsink) = bb;
             if (__builtin_expect(__any(!(bb > 1e-13 * fabs(al_prev))), 0)) break;   // invariant subspace reached: T is exact
-            if (__builtin_expect(nst >= 16 && ((nst & 15) == 0 || (nst > 48 && (nst & 7) == 0)), 0)) {
+            if (__builtin_expect(lanczos_check_due(nst), 0)) {
                 OEM_STAMP(6);
                 const double th = top_ritz(nst, theta_prev);
                 OEM_STAMP(7);
-                if (__any(th - theta_prev <= 1e-14 * fabs(th))) { theta = th; have_theta = true; break; }
-                theta_prev = th;
+                if (__any(lanczos_converged(th, theta_prev, mv_prev))) { theta = th; have_theta = true; break; }
             }
         }
         OEM_STAMP(17);                                               // beta store, breakdown / check tests
