@@ -899,6 +899,33 @@ template <int CG, int CGL, int NWT, int J> struct LdsFma {
     }
 };
 
+// sum over all 64 lanes (rows_sum joins row groups 0 + 1 and 2 + 3; one v_permlane32_swap pair joins the halves); every lane gets it
+__device__ __forceinline__ double wave_allsum(double v)
+{
+    const double s = rows_sum(v);
+    const unsigned lo = (unsigned)__double2loint(s), hi = (unsigned)__double2hiint(s);
+    auto l2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto h2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
+}
+// the product alone: B holds the gathered vector (this row group's column slice), returns (M vec)[own row]
+template <int NW, int CG, int CGL, int NBC>
+__device__ __forceinline__ double rows_product(const double (&a)[2][CG], const double *aL, double (&B)[NBC])
+{
+    double tl[2][2];
+    if (CGL > 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) tl[c][r] = aL[(2 * c + r) * NW * 64];
+    }
+    double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    dpp_hazard_fence(B);
+    GroupFma<CG, 0>::run(acc, B, a);
+    LdsFma<CG, CGL, NW * 64, 0>::run(acc, B, aL, tl);
+    return rowgroup_reduce_scatter(acc[0][0] + acc[0][1], acc[1][0] + acc[1][1]);
+}
+
 template <int NW_, int CG, int CGL> struct RowsCfg {
     static constexpr int NW = NW_;
     static constexpr int NBC = (CG + CGL + 15) / 16;
@@ -1109,40 +1136,74 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
         __syncthreads();
         return th;
     };
-    double v = 0.0, vp = 0.0, wn;                                    // wn: the unnormalised next vector
+    // ONE exchange per step.  Every wave keeps the whole Lanczos vector (and its predecessor) a second time in the gathered
+    // layout of the product (Bv / Bvp: this row group's column slice, a copy of every entry per wave).  What crosses waves is
+    // the raw product w = A v with the waves' shares of alpha = v'w; each wave then orthogonalises ITS gathered copy with the
+    // same two FMAs per entry as the owners use on their rows, and takes || w' || from that copy with an in-wave reduction --
+    // identical operands in an identical order in every wave, so the replicas stay bit-identical and the norm needs no second
+    // exchange.  (The two-exchange form spent ~2,100 cycles a step, an OEM round of the same product ~750.)
+    double v, vp = 0.0, bprev = 0.0;
+    double Bv[NBC], Bvp[NBC], Bw[NBC];
+    int nst = 0;
+    double theta = 0.0, theta_prev = -__builtin_inf(), mv_prev = __builtin_inf();
+    bool have_theta = false;
+    auto colmask = [&](int j) { return ecol[j] < 32 * NW ? 1.0 : 0.0; };   // dummy words carry replicas' values: not part of the vector
     {
         const unsigned h = (unsigned)row * 2654435761u + 12345u;     // deterministic non-structured start
-        wn = rowok ? ((double)(h >> 8) * (1.0 / 16777216.0) - 0.5) : 0.0;
+        const double st = rowok ? ((double)(h >> 8) * (1.0 / 16777216.0) - 0.5) : 0.0;
+        const int b = __builtin_amdgcn_readfirstlane(buf);
+        S.V[b * C::VS + wslot] = st;
+        __syncthreads();
+        double n2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NBC; ++j) { Bw[j] = S.V[b * C::VS + ecol[j]] * colmask(j); n2 = fma(Bw[j], Bw[j], n2); }
+        buf = b ^ 1;
+        double nb, ib;
+        sqrt_rsqrt(wave_allsum(n2), nb, ib);
+        v = st * ib;
+#pragma unroll
+        for (int j = 0; j < NBC; ++j) { Bv[j] = Bw[j] * ib; Bvp[j] = 0.0; }
     }
-    int nst = 0;
-    double theta = 0.0, theta_prev = -__builtin_inf(), mv_prev = __builtin_inf(), bb = 0.0;
-    bool have_theta = false;
-    double al_prev = 0.0;
     OEM_STAMP(5);                                                    // prologue: matrix and vectors into registers
     for (int j = 0; j < msteps; ++j) {
-        // one exchange carries the unnormalised vector AND the per-wave shares of its squared norm
-        double nb = rows_sum(wn * wn), ib = 0.0;
-        const double wv = gemv_rows<NW, CG, CGL, false, true, true>(a, aL, wn, wslot, ecol, false, any_unused, nb, S, w, lane, buf, &ib OEM_DIAG_PASS);
-        if (j > 0) {
-            bb = nb;
-            *(tid == 0 ? &Tbe[j - 1] : tsink) = bb;
-            if (__builtin_expect(__any(!(bb > 1e-13 * fabs(al_prev))), 0)) break;   // invariant subspace reached: T is exact
-            if (__builtin_expect(lanczos_check_due(nst), 0)) {
-                OEM_STAMP(6);
-                const double th = top_ritz(nst, theta_prev);
-                OEM_STAMP(7);
-                if (__any(lanczos_converged(th, theta_prev, mv_prev))) { theta = th; have_theta = true; break; }
-            }
-        }
-        OEM_STAMP(17);                                               // beta store, breakdown / check tests
-        vp = v; v = wn * ib;
-        const double al = waves_sum<NW>(rows_sum(v * wv), S.XN, par, w, lane);   // XN: gemv_rows' exchange owns XA
-        OEM_STAMP(18);                                               // alpha: rows_sum + second exchange
+        const double wv = rows_product<NW, CG, CGL>(a, aL, Bv);
+        double share = rows_sum(v * wv);                             // this wave's rows of alpha = v'Av (padding lanes hold 0)
+        OEM_STAMP(3);
+        const int b = __builtin_amdgcn_readfirstlane(buf);
+        S.V[b * C::VS + wslot] = wv;
+        S.XA[(b * NW + w) * 64 + lane] = share;
+        __syncthreads();
+        OEM_STAMP(1);
+        const double xa = S.XA[(b * NW + (lane & (NW - 1))) * 64 + lane];
+#pragma unroll
+        for (int jj = 0; jj < NBC; ++jj) Bw[jj] = S.V[b * C::VS + ecol[jj]];
+        buf = b ^ 1;
+        const double al = lanes_sum<NW>(xa);
+        OEM_STAMP(2);
         *(tid == 0 ? &Tal[j] : tsink) = al;                          // read by wave 0 only (top_ritz)
-        al_prev = al;
+        const double wn = fma(-bprev, vp, fma(-al, v, wv));          // the owners' rows ...
+        double n2 = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < NBC; ++jj) {                           // ... and the same for the gathered copy
+            Bw[jj] = fma(-bprev, Bvp[jj], fma(-al, Bv[jj], Bw[jj])) * colmask(jj);
+            n2 = fma(Bw[jj], Bw[jj], n2);
+        }
+        double bb, ib;
+        sqrt_rsqrt(wave_allsum(n2), bb, ib);
+        OEM_STAMP(17);
+        *(tid == 0 ? &Tbe[j] : tsink) = bb;
         nst = j + 1;
-        wn = (wv - al * v) - bb * vp;
-        OEM_STAMP(19);                                               // alpha store, next vector
+        if (__builtin_expect(__any(!(bb > 1e-13 * fabs(al))), 0)) break;   // invariant subspace reached: T is exact
+        if (__builtin_expect(lanczos_check_due(nst) && nst < msteps, 0)) {
+            OEM_STAMP(6);
+            const double th = top_ritz(nst, theta_prev);
+            OEM_STAMP(7);
+            if (__any(lanczos_converged(th, theta_prev, mv_prev))) { theta = th; have_theta = true; break; }
+        }
+        vp = v; v = wn * ib; bprev = bb;
+#pragma unroll
+        for (int jj = 0; jj < NBC; ++jj) { Bvp[jj] = Bv[jj]; Bv[jj] = Bw[jj] * ib; }
+        OEM_STAMP(19);
     }
     if (!have_theta) theta = top_ritz(nst, theta_prev);
     const double d = theta * 1.005;                                  // ref src/oem_dense.h:498
