@@ -206,6 +206,28 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64
                           double *beta, double *lambda_out, int32_t *niter, double *loss, double *d,
                           double *cvm, double *cvsd);
 
+/* xval.oem over row shards (one process per GPU; oem_amd/distributed.py: xval_oem_sharded): the three phases of
+ * oemgpu_xval_dense_dev as separate calls, with the caller's collectives between them.  The cross-validation of the
+ * reference is additive in exactly the way its fit is: per-fold Gram matrices are sums over rows
+ * (ref src/oem_xval_dense.h:358-484), the K + 1 fits need nothing but those sums (ref src/oem_xval_dense.cpp:213-340),
+ * and the CV error is a mean and a variance over observations (ref :343-461).  All three calls of one fit take the same
+ * (n_local, p, nfolds, weighted, o); the fold-ordered copy of the local rows stays in the context between them.
+ *   1. fold_moments_dev[oemgpu_xval_moments_len(p, nfolds, weighted)] <- per-fold moments of the LOCAL rows (device
+ *      buffer: all-reduce it, sum), fold_n[nfolds] <- local fold sizes (host: all-reduce, sum);
+ *   2. the summed moments and fold sizes in, the replicated fits out (beta ... d as in oemgpu_xval_dense);
+ *   3. triples[npen * nl * 3] <- (count, mean, M2 = sum (v - mean)^2) of the LOCAL rows' errors (host: all-gather);
+ *   oemgpu_xval_merge: the triples of all ranks, in rank order -> cvm, cvsd (Chan, Golub & LeVeque; pure host code). */
+int64_t oemgpu_xval_moments_len(int32_t p, int32_t nfolds, int32_t weighted);
+int oemgpu_xval_fold_moments_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n_local, int64_t ld, int32_t p, const double *y_dev,
+                                 const double *weights_dev /* or NULL */, const int32_t *foldid_dev, int32_t nfolds, const oemgpu_opts *o,
+                                 double *fold_moments_dev, int64_t *fold_n);
+int oemgpu_xval_solve_folds_dev(oemgpu_ctx *ctx, const double *fold_moments_dev, const int64_t *fold_n_total, int64_t n_local, int32_t p,
+                                int32_t nfolds, int32_t weighted, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                                double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
+int oemgpu_xval_cv_triples_dev(oemgpu_ctx *ctx, int64_t n_local, int32_t p, int32_t nfolds, int32_t weighted, int32_t type_measure,
+                               const oemgpu_opts *o, double *triples);
+int oemgpu_xval_merge(const double *triples, int32_t nsets, const oemgpu_opts *o, double *cvm, double *cvsd);
+
 /* 1 if the most recent oemgpu_solve_moments_dev on this context found the shift predicate above true for its
  * sums_dev (and so read moments_dev as accumulated about c), 0 if not, -1 for a NULL context. */
 int oemgpu_last_shift_in_effect(oemgpu_ctx *ctx);

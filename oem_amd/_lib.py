@@ -69,6 +69,13 @@ _SIGS = {
                                     C.c_int32, C.POINTER(OemgpuOpts)] + _OUT + [_dp, _dp]),
     "oemgpu_xval_dense_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_int32, C.POINTER(OemgpuOpts)] + _OUT + [_dp, _dp]),
+    "oemgpu_xval_moments_len": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "oemgpu_xval_fold_moments_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int32, C.POINTER(OemgpuOpts), C.c_void_p, C.POINTER(C.c_int64)]),
+    "oemgpu_xval_solve_folds_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                              C.c_int32, C.c_int32, C.POINTER(OemgpuOpts)] + _OUT),
+    "oemgpu_xval_cv_triples_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(OemgpuOpts), _dp]),
+    "oemgpu_xval_merge": (C.c_int, [_dp, C.c_int32, C.POINTER(OemgpuOpts), _dp, _dp]),
     "oemgpu_eig_max_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, _dp]),
     "oemgpu_last_timings": (C.c_int, [C.c_void_p, _dp]),
     "oemgpu_set_timing": (C.c_int, [C.c_void_p, C.c_int32]),

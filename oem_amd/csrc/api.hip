@@ -835,87 +835,126 @@ static int ctx_aux(oemgpu_ctx *c, size_t bytes)
     return 0;
 }
 
-int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
-                          const double *w_dev, const int32_t *foldid_dev, int32_t nfolds, int32_t standardize, int32_t intercept,
-                          int32_t type_measure, const oemgpu_opts *o,
-                          double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, double *cvm, double *cvsd)
+// The call in three phases over one buffer layout in oemgpu_ctx::aux (a pure function of n, p, K, npen, nl and "weighted", so
+// the phases may also be separate C-ABI calls with a collective between them: row shards on several GPUs, oemgpu_xval_*_dev):
+//   prepare  rows into fold order, per-fold moments of the LOCAL rows           (additive over row shards)
+//   solve    fold sums, the full-data fit and the K left-out-fold fits           (replicated; needs the moments of ALL rows)
+//   cverr    per-observation error of the LOCAL rows, merged to (count, mean, M2) per (penalty, lambda)
+struct XvalLay {
+    int64_t n, ldp;
+    int p, pm, K, npen, nl, nwg;
+    bool weighted;
+    size_t mlen, cslen;
+    GramPlan plmax;
+    size_t a_cs, a_cnt, a_fn, a_bad, a_pos, a_xp, a_yp, a_mf, a_mc, a_ms, a_t, a_v, a_b, a_part, a_out, total;
+};
+static XvalLay xval_layout(oemgpu_ctx *c, int64_t n, int p, int K, int npen, int nl, bool weighted)
 {
-    if (!c || !x_dev || !y_dev || !foldid_dev || !beta || !lambda_out || !niter || !loss || !d || !cvm || !cvsd) {
-        set_error("xval_dense: NULL argument"); return OEMGPU_ERR_ARG;
-    }
-    const int K = nfolds, q = p + (intercept ? 1 : 0);
-    int rc = check_opts(o, p, q);
-    if (rc) return rc;
+    XvalLay L;
+    L.n = n; L.p = p; L.K = K; L.npen = npen; L.nl = nl; L.weighted = weighted;
+    L.ldp = (n + 16 * (int64_t)K + 15) / 16 * 16;
+    // observation weights: the fold-ordered copy gets a leading column sqrt(w) and everything is scaled by sqrt(w), so the moment
+    // kernels see pm = p + 1 data columns and their Gram IS X'WX with its intercept border (ref src/oem_xval_dense.h:486-623)
+    L.pm = p + (weighted ? 1 : 0);
+    L.mlen = (size_t)oemgpu_moments_len(L.pm); L.cslen = (size_t)p + 1;
+    L.nwg = cv_wg_per_fold(n, K, npen, c->num_cu);
+    L.plmax = gram_plan(n, L.pm, c->num_cu);                   // the largest moment plan over the folds is bounded by the plan of all n rows
+    Bump A;
+    L.a_cs = A.take(sizeof(double) * L.cslen * (2 * (size_t)K + 1));      // per fold, then all folds / all but fold ff
+    L.a_cnt = A.take(fold_layout_ints(n, K) * sizeof(int)); L.a_fn = A.take(sizeof(int64_t) * 2 * K); L.a_bad = A.take(256);
+    L.a_pos = A.take(sizeof(int) * (size_t)n); L.a_xp = A.take(sizeof(double) * (size_t)L.ldp * L.pm);
+    L.a_yp = A.take(sizeof(double) * (size_t)L.ldp); L.a_mf = A.take(sizeof(double) * L.mlen * K);
+    L.a_mc = A.take(sizeof(double) * L.mlen); L.a_ms = A.take(sizeof(double) * L.mlen * (K + 1));
+    L.a_t = A.take(L.plmax.tpart_doubles * 8 * 2); L.a_v = A.take(L.plmax.vpart_doubles * 8 * 2);
+    L.a_b = A.take(sizeof(double) * (size_t)K * npen * nl * (p + 1));
+    L.a_part = A.take(sizeof(double) * cv_part_doubles(L.nwg, K, npen, nl)); L.a_out = A.take(sizeof(double) * 3 * (size_t)npen * nl);
+    L.total = A.off;
+    return L;
+}
+
+static int xval_check(oemgpu_ctx *c, const void *x_dev, const void *y_dev, const void *foldid_dev, int64_t n, int64_t ld, int p, int K,
+                      int intercept, int type_measure, bool weighted, const oemgpu_opts *o)
+{
+    if (!c || !o) { set_error("xval_dense: NULL argument"); return OEMGPU_ERR_ARG; }
+    (void)x_dev; (void)y_dev; (void)foldid_dev;
+    if (intercept >= 0) {                                          // (< 0: a phase that does not solve; the options were checked by the one that does)
+        int rc = check_opts(o, p, p + (intercept ? 1 : 0));
+        if (rc) return rc;
+    } else if (!o->penalty || o->npen < 1) { set_error("xval_dense: no penalty"); return OEMGPU_ERR_ARG; }
     if (K < 2 || K > 512) { set_error("xval_dense: nfolds must be in 2..512"); return OEMGPU_ERR_ARG; }
     if (type_measure != 0 && type_measure != 1) { set_error("xval_dense: type_measure must be 0 (mse) or 1 (mae)"); return OEMGPU_ERR_ARG; }
     if (n < 1 || ld < n) { set_error("xval_dense: bad n / ld"); return OEMGPU_ERR_ARG; }
-    if (n <= p) { set_error("dimension of x larger than number of observations"); return OEMGPU_ERR_UNSUPPORTED; }   // ref src/oem_xval_dense.h:690-731
     if (n + 16 * (int64_t)K >= (int64_t)1 << 31) { set_error("xval_dense: n too large for 32-bit row positions"); return OEMGPU_ERR_UNSUPPORTED; }
-    if (w_dev && o->compute_loss) {
+    if (weighted && o->compute_loss) {
         set_error("compute.loss with observation weights: the reference's loss is the unweighted residual sum (src/oem_xval_dense.h:1122-1145), "
                   "which the weighted Gram does not hold");
         return OEMGPU_ERR_UNSUPPORTED;
     }
-    if (set_device(c)) return OEMGPU_ERR_HIP;
-    const int nl = nl_of(o), npen = o->npen;
-    const int64_t ldp = (n + 16 * (int64_t)K + 15) / 16 * 16;
-    // observation weights: the fold-ordered copy gets a leading column sqrt(w) and everything is scaled by sqrt(w), so the moment
-    // kernels see pm = p + 1 data columns and their Gram IS X'WX with its intercept border (ref src/oem_xval_dense.h:486-623)
-    const int pm = p + (w_dev ? 1 : 0);
-    const size_t mlen = (size_t)oemgpu_moments_len(pm), cslen = (size_t)p + 1;
-    const int nwg = cv_wg_per_fold(n, K, npen, c->num_cu);
-    // the largest moment plan over the folds is bounded by the plan of all n rows
-    const GramPlan plmax = gram_plan(n, pm, c->num_cu);
-    Bump A;
-    const size_t a_cs = A.take(sizeof(double) * cslen * (2 * (size_t)K + 1));      // per fold, then all folds / all but fold ff
-    const size_t a_cnt = A.take(fold_layout_ints(n, K) * sizeof(int)), a_fn = A.take(sizeof(int64_t) * 2 * K), a_bad = A.take(256),
-                 a_pos = A.take(sizeof(int) * (size_t)n), a_xp = A.take(sizeof(double) * (size_t)ldp * pm),
-                 a_yp = A.take(sizeof(double) * (size_t)ldp), a_mf = A.take(sizeof(double) * mlen * K),
-                 a_mc = A.take(sizeof(double) * mlen), a_ms = A.take(sizeof(double) * mlen * (K + 1)), a_t = A.take(plmax.tpart_doubles * 8 * 2), a_v = A.take(plmax.vpart_doubles * 8 * 2),
-                 a_b = A.take(sizeof(double) * (size_t)K * npen * nl * (p + 1)),
-                 a_part = A.take(sizeof(double) * cv_part_doubles(nwg, K, npen, nl)), a_out = A.take(sizeof(double) * 2 * (size_t)npen * nl);
-    if (ctx_aux(c, A.off)) return OEMGPU_ERR_HIP;
-    char *ax = c->aux;
-    int *blockcnt = (int *)(ax + a_cnt), *bad = (int *)(ax + a_bad), *pos = (int *)(ax + a_pos);
-    int64_t *fold_n = (int64_t *)(ax + a_fn), *fold_start = fold_n + K;
-    double *xp = (double *)(ax + a_xp), *yp = (double *)(ax + a_yp), *mfold = (double *)(ax + a_mf), *mcur = (double *)(ax + a_mc);
-    double *bdev = (double *)(ax + a_b), *part = (double *)(ax + a_part), *cvout = (double *)(ax + a_out);
+    return 0;
+}
 
+// phase 1: hf <- the local fold sizes [K] and fold starts [K]; mfold (and csq) in aux <- the local rows' per-fold moments
+static int xval_prepare(oemgpu_ctx *c, const XvalLay &L, const double *x_dev, int64_t ld, const double *y_dev, const double *w_dev,
+                        const int32_t *foldid_dev, std::vector<int64_t> &hf)
+{
+    const int64_t n = L.n;
+    const int K = L.K, p = L.p;
+    char *ax = c->aux;
+    int *blockcnt = (int *)(ax + L.a_cnt), *bad = (int *)(ax + L.a_bad), *pos = (int *)(ax + L.a_pos);
+    int64_t *fold_n = (int64_t *)(ax + L.a_fn), *fold_start = fold_n + K;
+    double *xp = (double *)(ax + L.a_xp), *yp = (double *)(ax + L.a_yp), *mfold = (double *)(ax + L.a_mf);
     // ---- rows into fold order
-    rc = launch_fold_layout(c->stream, foldid_dev, n, K, blockcnt, fold_n, fold_start, pos, bad);
+    int rc = launch_fold_layout(c->stream, foldid_dev, n, K, blockcnt, fold_n, fold_start, pos, bad);
     if (rc) return rc;
-    std::vector<int64_t> hf(2 * K);
+    hf.assign(2 * K, 0);
     int hbad = 0;
     OEM_HIP(hipMemcpyAsync(hf.data(), fold_n, sizeof(int64_t) * 2 * K, hipMemcpyDeviceToHost, c->stream));
     OEM_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    double *csq = (double *)(ax + a_cs), *cssum = csq + cslen * K;
+    double *csq = (double *)(ax + L.a_cs);
     if (w_dev) {
-        rc = launch_gather_rows(c->stream, w_dev, n, n, 1, y_dev, pos, xp, ldp, yp);               // column 0 <- w
-        if (!rc) rc = launch_gather_rows(c->stream, x_dev, n, ld, p, y_dev, pos, xp + ldp, ldp, yp);
-        if (!rc) rc = launch_weight_scale(c->stream, xp, ldp, yp, p, K, fold_start, fold_n, csq);
-    } else rc = launch_gather_rows(c->stream, x_dev, n, ld, p, y_dev, pos, xp, ldp, yp);
+        rc = launch_gather_rows(c->stream, w_dev, n, n, 1, y_dev, pos, xp, L.ldp, yp);               // column 0 <- w
+        if (!rc) rc = launch_gather_rows(c->stream, x_dev, n, ld, p, y_dev, pos, xp + L.ldp, L.ldp, yp);
+        if (!rc) rc = launch_weight_scale(c->stream, xp, L.ldp, yp, p, K, fold_start, fold_n, csq);
+    } else rc = launch_gather_rows(c->stream, x_dev, n, ld, p, y_dev, pos, xp, L.ldp, yp);
     if (rc) return rc;
     OEM_HIP(hipStreamSynchronize(c->stream));
     if (hbad) { set_error("xval_dense: foldid must hold values in 1..nfolds"); return OEMGPU_ERR_ARG; }
     // ---- per-fold moments about 0 (ref src/oem_xval_dense.h:358-484), one MFMA pass per fold segment
     for (int k = 0; k < K; ++k) {
         const int64_t nk = hf[k], st = hf[K + k];
-        if (n - nk <= p) { set_error("dimension of x larger than number of observations"); return OEMGPU_ERR_UNSUPPORTED; }  // ref :849-852
-        if (nk == 0) { OEM_HIP(hipMemsetAsync(mfold + mlen * k, 0, sizeof(double) * mlen, c->stream)); continue; }
-        const GramPlan pl = gram_plan(nk, pm, c->num_cu);
-        if (pl.tpart_doubles > 2 * plmax.tpart_doubles || pl.vpart_doubles > 2 * plmax.vpart_doubles) {
+        if (nk == 0) { OEM_HIP(hipMemsetAsync(mfold + L.mlen * k, 0, sizeof(double) * L.mlen, c->stream)); continue; }
+        const GramPlan pl = gram_plan(nk, L.pm, c->num_cu);
+        if (pl.tpart_doubles > 2 * L.plmax.tpart_doubles || pl.vpart_doubles > 2 * L.plmax.vpart_doubles) {
             set_error("internal: fold plan larger than its scratch"); return OEMGPU_ERR_INTERNAL;
         }
-        rc = shard_moments(c, pl, xp + st, nk, ldp, yp + st, nullptr, (double *)(ax + a_t), (double *)(ax + a_v), mfold + mlen * k);
+        rc = shard_moments(c, pl, xp + st, nk, L.ldp, yp + st, nullptr, (double *)(ax + L.a_t), (double *)(ax + L.a_v), mfold + L.mlen * k);
         if (rc) return rc;
     }
-    // ---- the full-data fit (ff = 0) and one fit per left-out fold on the lambdas of the first (ref src/oem_xval_dense.cpp:213-340)
+    return 0;
+}
+
+// phase 2: mfold (and csq) in aux hold the per-fold moments of ALL rows; fold_tot[K] their fold sizes, n_tot the row count.
+// The full-data fit (ff = 0) and one fit per left-out fold on the lambdas of the first (ref src/oem_xval_dense.cpp:213-340);
+// the fold coefficients end in aux (bdev) for phase 3.
+static int xval_solve(oemgpu_ctx *c, const XvalLay &L, const int64_t *fold_tot, int64_t n_tot, int32_t standardize, int32_t intercept,
+                      const oemgpu_opts *o, double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    const int K = L.K, p = L.p, npen = L.npen, nl = L.nl, q = p + (intercept ? 1 : 0);
+    const size_t mlen = L.mlen, cslen = L.cslen;
+    const bool weighted = L.weighted;
+    char *ax = c->aux;
+    double *mfold = (double *)(ax + L.a_mf), *bdev = (double *)(ax + L.a_b);
+    double *csq = (double *)(ax + L.a_cs), *cssum = csq + cslen * K;
+    if (n_tot <= p) { set_error("dimension of x larger than number of observations"); return OEMGPU_ERR_UNSUPPORTED; }   // ref src/oem_xval_dense.h:690-731
+    for (int k = 0; k < K; ++k)
+        if (n_tot - fold_tot[k] <= p) { set_error("dimension of x larger than number of observations"); return OEMGPU_ERR_UNSUPPORTED; }  // ref :849-852
+    int rc = 0;
     const size_t blen = (size_t)npen * nl * (p + 1), nk2 = (size_t)npen * nl;
     std::vector<double> hb(blen * K);
-    double *msum = (double *)(ax + a_ms);                        // [K + 1]: all folds, then all but fold ff
+    double *msum = (double *)(ax + L.a_ms);                      // [K + 1]: all folds, then all but fold ff
     for (int ff = 0; ff <= K; ++ff) {
         rc = launch_fold_sum(c->stream, mfold, K, mlen, ff, msum + mlen * ff);
-        if (!rc && w_dev) rc = launch_fold_sum(c->stream, csq, K, cslen, ff, cssum + cslen * ff);
+        if (!rc && weighted) rc = launch_fold_sum(c->stream, csq, K, cslen, ff, cssum + cslen * ff);
         if (rc) return rc;
     }
     const bool coop_batch = q > SMALL_P_MAX && path_coop_eligible(q, false, o->compute_loss != 0, any_grp_count(o), K + 1) &&
@@ -927,7 +966,7 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t
         std::vector<double> ab(blen * (K + 1)), al(nk2 * (K + 1)), aloss(nk2 * (K + 1)), ad(K + 1);
         std::vector<int32_t> an(nk2 * (K + 1));
         rc = solve_moments_batch(c, msum, mlen, K + 1, p, OEMGPU_SEM_XVAL, standardize, intercept, o, ab.data(), al.data(), an.data(),
-                                 aloss.data(), ad.data(), true, w_dev ? cssum : nullptr, cslen);
+                                 aloss.data(), ad.data(), true, weighted ? cssum : nullptr, cslen);
         if (rc) return rc;
         memcpy(beta, ab.data(), sizeof(double) * blen);
         memcpy(lambda_out, al.data(), sizeof(double) * nk2);
@@ -935,7 +974,7 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t
         memcpy(loss, aloss.data(), sizeof(double) * nk2);       // the reference reports the loss of the full fit only (ref :296-301)
         *d = ad[0];
         memcpy(hb.data(), ab.data() + blen, sizeof(double) * blen * K);
-    } else if (w_dev) {
+    } else if (weighted) {
         // weighted and beyond one launch's size: the K + 1 fits one after the other on this context (each a cooperating-workgroup
         // or launch-per-iteration solve of its own), the folds on the full fit's lambdas
         rc = solve_moments_batch(c, msum, mlen, 1, p, OEMGPU_SEM_XVAL, standardize, intercept, o, beta, lambda_out, niter, loss, d, false,
@@ -985,19 +1024,145 @@ int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t
                 if (rcs[i]) { set_error("fold %d: %s", i + 1, errs[i].c_str()); return rcs[i]; }
         }
     }
-    // ---- per-observation error of every row under the fit that left its fold out (ref src/oem_xval_dense.cpp:343-461)
     OEM_HIP(hipMemcpyAsync(bdev, hb.data(), sizeof(double) * blen * K, hipMemcpyHostToDevice, c->stream));
-    rc = launch_cv_error(c->stream, xp, ldp, yp, fold_start, fold_n, K, p, bdev, npen, nl, type_measure, w_dev ? 1 : 0, nwg, (double)n, part, cvout);
+    OEM_HIP(hipStreamSynchronize(c->stream));                   // hb is a local
+    return 0;
+}
+
+// phase 3: per-observation error of every LOCAL row under the fit that left its fold out (ref src/oem_xval_dense.cpp:343-461).
+// triples == nullptr: cvm / cvsd of these rows (they are all rows); else triples[npen][nl][3] <- (count, mean, M2 = sum (v - mean)^2),
+// which the caller merges over the row shards (oemgpu_xval_merge).
+static int xval_cverr(oemgpu_ctx *c, const XvalLay &L, int32_t type_measure, const oemgpu_opts *o, double *cvm, double *cvsd, double *triples)
+{
+    const int K = L.K, p = L.p, npen = L.npen, nl = L.nl;
+    char *ax = c->aux;
+    int64_t *fold_n = (int64_t *)(ax + L.a_fn), *fold_start = fold_n + K;
+    double *xp = (double *)(ax + L.a_xp), *yp = (double *)(ax + L.a_yp), *bdev = (double *)(ax + L.a_b);
+    double *part = (double *)(ax + L.a_part), *cvout = (double *)(ax + L.a_out);
+    int rc = launch_cv_error(c->stream, xp, L.ldp, yp, fold_start, fold_n, K, p, bdev, npen, nl, type_measure, L.weighted ? 1 : 0, L.nwg, (double)L.n,
+                             part, cvout, triples != nullptr);
     if (rc) { if (rc == OEMGPU_ERR_UNSUPPORTED) set_error("xval_dense: p too large for the CV-error kernel's LDS tile"); return rc; }
-    std::vector<double> hc(2 * (size_t)npen * nl);
+    const int per = triples ? 3 : 2;
+    std::vector<double> hc((size_t)per * npen * nl);
     OEM_HIP(hipMemcpyAsync(hc.data(), cvout, sizeof(double) * hc.size(), hipMemcpyDeviceToHost, c->stream));
     OEM_HIP(hipStreamSynchronize(c->stream));
+    if (triples) { memcpy(triples, hc.data(), sizeof(double) * hc.size()); return 0; }
     for (int k = 0; k < npen; ++k) {
         const int nlam = (o->penalty[k] == OEMGPU_OLS) ? 1 : nl;
         for (int i = 0; i < nl; ++i) {
             const size_t ki = (size_t)k * nl + i;
             cvm[ki] = i < nlam ? hc[2 * ki] : 0.0;
             cvsd[ki] = i < nlam ? hc[2 * ki + 1] : 0.0;
+        }
+    }
+    return 0;
+}
+
+int oemgpu_xval_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
+                          const double *w_dev, const int32_t *foldid_dev, int32_t nfolds, int32_t standardize, int32_t intercept,
+                          int32_t type_measure, const oemgpu_opts *o,
+                          double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, double *cvm, double *cvsd)
+{
+    if (!c || !x_dev || !y_dev || !foldid_dev || !beta || !lambda_out || !niter || !loss || !d || !cvm || !cvsd) {
+        set_error("xval_dense: NULL argument"); return OEMGPU_ERR_ARG;
+    }
+    const int K = nfolds;
+    int rc = xval_check(c, x_dev, y_dev, foldid_dev, n, ld, p, K, intercept, type_measure, w_dev != nullptr, o);
+    if (rc) return rc;
+    if (n <= p) { set_error("dimension of x larger than number of observations"); return OEMGPU_ERR_UNSUPPORTED; }   // ref src/oem_xval_dense.h:690-731
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    const XvalLay L = xval_layout(c, n, p, K, o->npen, nl_of(o), w_dev != nullptr);
+    if (ctx_aux(c, L.total)) return OEMGPU_ERR_HIP;
+    std::vector<int64_t> hf;
+    rc = xval_prepare(c, L, x_dev, ld, y_dev, w_dev, foldid_dev, hf);
+    if (!rc) rc = xval_solve(c, L, hf.data(), n, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+    if (!rc) rc = xval_cverr(c, L, type_measure, o, cvm, cvsd, nullptr);
+    return rc;
+}
+
+// ---- the same three phases as separate calls, for row shards on several GPUs (one process per GPU; the caller sums the fold
+// moments and the fold sizes over the ranks between phases 1 and 2 and merges the error triples after phase 3).  All three calls
+// of one fit take the same (n_local, p, nfolds, weighted, o): the buffer layout in the context is a function of those.
+int64_t oemgpu_xval_moments_len(int32_t p, int32_t nfolds, int32_t weighted)
+{
+    return (int64_t)nfolds * (oemgpu_moments_len(p + (weighted ? 1 : 0)) + (weighted ? p + 1 : 0));
+}
+
+int oemgpu_xval_fold_moments_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
+                                 const double *w_dev, const int32_t *foldid_dev, int32_t nfolds, const oemgpu_opts *o,
+                                 double *fold_moments_dev, int64_t *fold_n)
+{
+    if (!c || !x_dev || !y_dev || !foldid_dev || !fold_moments_dev || !fold_n) { set_error("xval_fold_moments: NULL argument"); return OEMGPU_ERR_ARG; }
+    const int K = nfolds;
+    int rc = xval_check(c, x_dev, y_dev, foldid_dev, n, ld, p, K, -1, 0, w_dev != nullptr, o);
+    if (rc) return rc;
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    const XvalLay L = xval_layout(c, n, p, K, o->npen, nl_of(o), w_dev != nullptr);
+    if (ctx_aux(c, L.total)) return OEMGPU_ERR_HIP;
+    std::vector<int64_t> hf;
+    rc = xval_prepare(c, L, x_dev, ld, y_dev, w_dev, foldid_dev, hf);
+    if (rc) return rc;
+    for (int k = 0; k < K; ++k) fold_n[k] = hf[k];
+    OEM_HIP(hipMemcpyAsync(fold_moments_dev, c->aux + L.a_mf, sizeof(double) * L.mlen * K, hipMemcpyDeviceToDevice, c->stream));
+    if (w_dev) OEM_HIP(hipMemcpyAsync(fold_moments_dev + L.mlen * K, c->aux + L.a_cs, sizeof(double) * L.cslen * K, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int oemgpu_xval_solve_folds_dev(oemgpu_ctx *c, const double *fold_moments_dev, const int64_t *fold_n_total, int64_t n_local, int32_t p,
+                                int32_t nfolds, int32_t weighted, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                                double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    if (!c || !fold_moments_dev || !fold_n_total || !beta || !lambda_out || !niter || !loss || !d) { set_error("xval_solve_folds: NULL argument"); return OEMGPU_ERR_ARG; }
+    const int K = nfolds;
+    int rc = xval_check(c, fold_moments_dev, fold_moments_dev, fold_moments_dev, n_local, n_local, p, K, intercept, 0, weighted != 0, o);
+    if (rc) return rc;
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    const XvalLay L = xval_layout(c, n_local, p, K, o->npen, nl_of(o), weighted != 0);
+    if (c->aux_bytes < L.total) { set_error("xval_solve_folds: call oemgpu_xval_fold_moments_dev with the same arguments first"); return OEMGPU_ERR_ARG; }
+    OEM_HIP(hipMemcpyAsync(c->aux + L.a_mf, fold_moments_dev, sizeof(double) * L.mlen * K, hipMemcpyDeviceToDevice, c->stream));
+    if (weighted) OEM_HIP(hipMemcpyAsync(c->aux + L.a_cs, fold_moments_dev + L.mlen * K, sizeof(double) * L.cslen * K, hipMemcpyDeviceToDevice, c->stream));
+    int64_t n_tot = 0;
+    for (int k = 0; k < K; ++k) n_tot += fold_n_total[k];
+    return xval_solve(c, L, fold_n_total, n_tot, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+}
+
+int oemgpu_xval_cv_triples_dev(oemgpu_ctx *c, int64_t n_local, int32_t p, int32_t nfolds, int32_t weighted, int32_t type_measure,
+                               const oemgpu_opts *o, double *triples)
+{
+    if (!c || !o || !triples) { set_error("xval_cv_triples: NULL argument"); return OEMGPU_ERR_ARG; }
+    int rc = xval_check(c, triples, triples, triples, n_local, n_local, p, nfolds, -1, type_measure, weighted != 0, o);
+    if (rc) return rc;
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    const XvalLay L = xval_layout(c, n_local, p, nfolds, o->npen, nl_of(o), weighted != 0);
+    if (c->aux_bytes < L.total) { set_error("xval_cv_triples: call the first two phases with the same arguments first"); return OEMGPU_ERR_ARG; }
+    return xval_cverr(c, L, type_measure, o, nullptr, nullptr, triples);
+}
+
+// (count, mean, M2) of the union of `nsets` row sets per (penalty, lambda) by Chan, Golub & LeVeque's update, in set order; then
+// cvm = mean, cvsd = sqrt(M2 / (n - 1)) / sqrt(n)  (ref src/oem_xval_dense.cpp:452-461).  Pure host arithmetic.
+int oemgpu_xval_merge(const double *triples, int32_t nsets, const oemgpu_opts *o, double *cvm, double *cvsd)
+{
+    if (!triples || !o || !cvm || !cvsd || nsets < 1) { set_error("xval_merge: bad argument"); return OEMGPU_ERR_ARG; }
+    const int npen = o->npen, nl = nl_of(o);
+    const size_t nk = (size_t)npen * nl;
+    for (int k = 0; k < npen; ++k) {
+        const int nlam = (o->penalty[k] == OEMGPU_OLS) ? 1 : nl;
+        for (int i = 0; i < nl; ++i) {
+            const size_t ki = (size_t)k * nl + i;
+            double na = 0.0, ma = 0.0, qa = 0.0;
+            for (int s = 0; s < nsets; ++s) {
+                const double *t = triples + ((size_t)s * nk + ki) * 3;
+                const double nb = t[0], mb = t[1], qb = t[2];
+                if (!(nb > 0.0)) continue;
+                if (na > 0.0) {
+                    const double nn = na + nb, dl = mb - ma;
+                    ma += dl * (nb / nn);
+                    qa += qb + dl * dl * (na * nb / nn);
+                    na = nn;
+                } else { na = nb; ma = mb; qa = qb; }
+            }
+            cvm[ki] = i < nlam ? ma : 0.0;
+            cvsd[ki] = (i < nlam && na > 1.0) ? std::sqrt((qa < 0.0 ? 0.0 : qa) / (na - 1.0)) / std::sqrt(na) : 0.0;
         }
     }
     return 0;

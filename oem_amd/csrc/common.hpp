@@ -67,7 +67,7 @@ int launch_fold_sum(hipStream_t s, const double *M, int K, size_t len, int skip 
 int cv_wg_per_fold(int64_t n, int K, int npen, int num_cu);
 size_t cv_part_doubles(int nwg, int K, int npen, int nl);
 int launch_cv_error(hipStream_t s, const double *xp, int64_t ldp, const double *yp, const int64_t *fold_start, const int64_t *fold_n,
-                    int K, int p, const double *B, int npen, int nl, int mae, int wmode, int nwg, double n, double *part, double *out);
+                    int K, int p, const double *B, int npen, int nl, int mae, int wmode, int nwg, double n, double *part, double *out, bool triples = false);
 // observation weights of xval.oem (ref src/oem_xval_dense.h:486-623): unweighted column sums of squares per fold, then the
 // fold-ordered copy times sqrt(w); and the weighted counterpart of launch_finalize
 int launch_weight_scale(hipStream_t s, double *xp, int64_t ldp, double *yp, int p, int K, const int64_t *fold_start, const int64_t *fold_n,

@@ -891,6 +891,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         int *flags = reinterpret_cast<int *>(Bv + 2 * (size_t)(q + 8));
         int blocks = (q + 3) / 4;
         if (blocks > num_cu * 2) blocks = num_cu * 2;
+        if (const char *e = getenv("OEM_FUSED_BLOCKS")) { const int b = atoi(e); if (b > 0) blocks = b < (q + 3) / 4 ? b : (q + 3) / 4; }   // experiment knob
         if (blocks > FMAXB) blocks = FMAXB;
         hipLaunchKernelGGL(fused_init_kernel, dim3(1), dim3(1), 0, s, S, a.npen);
         auto enq = [&](int count) {

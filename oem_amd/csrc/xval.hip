@@ -302,8 +302,9 @@ __global__ __launch_bounds__(64 * CVW) void cv_error_kernel(const double *__rest
 
 // cvm = mean error, cvsd = sqrt(sample variance / n)  (ref src/oem_xval_dense.cpp:452-461).  One wave per (penalty, lambda):
 // lanes stride over the workgroup partials, then a fixed butterfly -- reproducible.
+// triples: out[npen][nl][3] <- (count, mean, M2) of the rows seen instead (row shards: the caller merges them, oemgpu_xval_merge).
 __global__ __launch_bounds__(64) void cv_finish_kernel(const double *__restrict__ part, int nparts, int npen, int nl, double n,
-                                                       double *__restrict__ out /* [npen][nl][2] */)
+                                                       double *__restrict__ out /* [npen][nl][2] */, int triples)
 {
     const int t = blockIdx.x, lane = threadIdx.x;
     const int pen = t / nl, lam = t - pen * nl, nl16 = (nl + 15) & ~15;
@@ -331,8 +332,11 @@ __global__ __launch_bounds__(64) void cv_finish_kernel(const double *__restrict_
         else merge(nb, mb, qb);
     }
     if (lane == 0) {
-        out[(size_t)t * 2] = ma;                                // all n observations are in: the mean
-        out[(size_t)t * 2 + 1] = sqrt((qa < 0.0 ? 0.0 : qa) / (n - 1.0)) / sqrt(n);
+        if (triples) { out[(size_t)t * 3] = na; out[(size_t)t * 3 + 1] = ma; out[(size_t)t * 3 + 2] = qa; }
+        else {
+            out[(size_t)t * 2] = ma;                            // all n observations are in: the mean
+            out[(size_t)t * 2 + 1] = sqrt((qa < 0.0 ? 0.0 : qa) / (n - 1.0)) / sqrt(n);
+        }
     }
 }
 
@@ -418,7 +422,7 @@ static int launch_cv_lt(hipStream_t s, dim3 grid, size_t lds, int ksteps, const 
 }
 
 int launch_cv_error(hipStream_t s, const double *xp, int64_t ldp, const double *yp, const int64_t *fold_start, const int64_t *fold_n,
-                    int K, int p, const double *B, int npen, int nl, int mae, int wmode, int nwg, double n, double *part, double *out)
+                    int K, int p, const double *B, int npen, int nl, int mae, int wmode, int nwg, double n, double *part, double *out, bool triples)
 {
     const int K4 = (p + 1 + 3) & ~3, ntile = (nl + 15) >> 4;
     // lambdas per pass: as many 16-wide tiles as fit 140 KB of LDS next to the reduction scratch, at most 7 (accumulator registers);
@@ -442,7 +446,7 @@ int launch_cv_error(hipStream_t s, const double *xp, int64_t ldp, const double *
     default: return OEMGPU_ERR_INTERNAL;
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(cv_finish_kernel, dim3(npen * nl), dim3(64), 0, s, part, nwg * K * CVW, npen, nl, n, out);
+    hipLaunchKernelGGL(cv_finish_kernel, dim3(npen * nl), dim3(64), 0, s, part, nwg * K * CVW, npen, nl, n, out, triples ? 1 : 0);
     OEM_HIP(hipGetLastError());
     return 0;
 }

@@ -10,7 +10,7 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oem_amd  # noqa: E402
-from oem_amd.distributed import HipBackend, oem_sharded, row_partition  # noqa: E402
+from oem_amd.distributed import HipBackend, oem_sharded, row_partition, xval_oem_sharded  # noqa: E402
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
@@ -83,6 +83,35 @@ ref3 = oem_amd.oem(np.asfortranarray(xh), yh, **kw3)
 for k in range(4):
     ok &= bool(np.array_equal(dealt["beta"][k], whole3["beta"][k]) and np.array_equal(dealt["niter"][k], whole3["niter"][k]))
     ok &= float(np.abs(dealt["beta"][k] - ref3["beta"][k]).max()) < 1e-8
+# xval.oem over the row shards (three phases with the collectives between them) == the one-process xval.oem: element-wise and
+# group penalties, observation weights, both error measures, a size beyond one workgroup (p + 1 > 288: the cooperating engine)
+for case, (n4, p4, kw4) in enumerate([
+        (30_000, 40, dict(penalty=["lasso", "mcp"], nlambda=12, tol=1e-9, maxit=2000)),
+        (8_000, 25, dict(penalty=["grp.lasso", "elastic.net"], groups=np.arange(25) // 5 + 1, alpha=0.5, nlambda=8, tol=1e-9, maxit=2000,
+                         type_measure="mae", standardize=False)),
+        (6_000, 30, dict(penalty=["lasso"], nlambda=7, tol=1e-9, maxit=2000, intercept=False)),
+        (9_000, 20, dict(penalty=["lasso", "scad"], nlambda=6, tol=1e-9, maxit=2000, weighted=True)),
+        (5_000, 300, dict(penalty=["lasso"], nlambda=5, tol=1e-8, maxit=2000))]):
+    xh = rng.normal(size=(n4, p4)) * 1.5 + 0.2
+    yh = xh[:, :3] @ np.array([1.0, -2.0, 0.5]) + rng.normal(size=n4) + 0.7
+    K4 = 5 + case
+    fid = rng.permutation(np.resize(np.arange(1, K4 + 1), n4)).astype(np.int32)
+    wts = rng.uniform(0.5, 2.0, size=n4) if kw4.pop("weighted", False) else None
+    xfull = torch.as_tensor(np.ascontiguousarray(xh.T), device="cuda"); yfull = torch.as_tensor(yh, device="cuda")
+    lo4, hi4 = row_partition(n4, world)[rank]
+    fit4 = xval_oem_sharded(xfull[:, lo4:hi4].contiguous().t(), yfull[lo4:hi4].contiguous(),
+                            torch.as_tensor(fid[lo4:hi4].copy(), device="cuda"), K4, backend=be, dist=dist,
+                            weights_local=None if wts is None else torch.as_tensor(wts[lo4:hi4].copy(), device="cuda"), **kw4)
+    ref4 = oem_amd.xval_oem(np.asfortranarray(xh), yh, foldid=fid, weights=() if wts is None else wts, **kw4)
+    ok4 = fit4["nobs"] == n4 and abs(fit4["d"] - ref4["d"]) < 1e-10 * ref4["d"] and abs(fit4["lambda.min"] - ref4["lambda.min"]) < 1e-12 * ref4["lambda.min"]
+    for k in range(len(kw4["penalty"])):
+        ok4 &= float(np.abs(fit4["beta"][k] - ref4["beta"][k]).max()) < 1e-8 * max(1.0, float(np.abs(ref4["beta"][k]).max()))
+        ok4 &= bool(np.allclose(fit4["cvm"][k], ref4["cvm"][k], rtol=1e-9) and np.allclose(fit4["cvsd"][k], ref4["cvsd"][k], rtol=1e-7))
+    if not ok4 and rank == 0:
+        print("xval case", case, "mismatch: nobs", fit4["nobs"], "d", fit4["d"], ref4["d"], "lambda.min", fit4["lambda.min"], ref4["lambda.min"],
+              [(float(np.abs(fit4["beta"][k] - ref4["beta"][k]).max()), float(np.abs(fit4["cvm"][k] / ref4["cvm"][k] - 1).max()),
+                float(np.abs(fit4["cvsd"][k] / ref4["cvsd"][k] - 1).max())) for k in range(len(kw4["penalty"]))], flush=True)
+    ok &= bool(ok4)
 if rank == 0:
     print("DIST_GPU_OK" if ok else "DIST_GPU_MISMATCH", flush=True)
 dist.destroy_process_group()

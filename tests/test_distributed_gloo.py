@@ -59,6 +59,17 @@ def _worker(rank, world, port, q):
                               split_penalties=split)
             res.append((fit["beta"], fit["lambda"], fit["niter"], fit["d"]))
         out[key] = res
+    # xval.oem over the same row shards: fold moments -> one all-reduce -> replicated K + 1 fits -> local errors -> merged triples
+    from oem_amd.distributed import xval_oem_sharded
+    x, y = _data(n=1203, p=9, offset=0.5)
+    fid = np.random.default_rng(11).permutation(np.resize(np.arange(1, 6), x.shape[0]))
+    lo, hi = row_partition(x.shape[0], world)[rank]
+    xl = torch.from_numpy(np.ascontiguousarray(x[lo:hi].T)).t()
+    yl = torch.from_numpy(y[lo:hi].copy())
+    for std, icpt, tm in ((True, True, "mse"), (False, True, "mae"), (True, False, "mse")):
+        fit = xval_oem_sharded(xl, yl, fid[lo:hi], 5, backend=CheckerBackend(), dist=dist, type_measure=tm, penalty=["lasso", "mcp"],
+                               nlambda=8, tol=1e-10, maxit=5000, standardize=std, intercept=icpt)
+        out[("xval", std, icpt, tm)] = (fit["beta"], fit["lambda"], fit["d"], fit["nobs"], fit["cvm"], fit["cvsd"], fit["lambda.min"])
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -91,6 +102,22 @@ def test_sharded_equals_unsharded_world2():
             assert ds == dw
             for k in range(3):                                              # dealt to the ranks == every rank solves everything
                 assert np.array_equal(bs[k], bw[k]) and np.array_equal(ls[k], lw[k]) and np.array_equal(ns[k], nw[k]), (key, r, k)
+    for key in [k for k in got[0] if k[0] == "xval"]:
+        _, std, icpt, tm = key
+        x, y = _data(n=1203, p=9, offset=0.5)
+        fid = np.random.default_rng(11).permutation(np.resize(np.arange(1, 6), x.shape[0]))
+        ref = orc.xval_dense(x, y, fid, penalty=["lasso", "mcp"], nlambda=8, tol=1e-10, maxit=5000, standardize=std, intercept=icpt,
+                             type_measure=tm, lambda_min_ratio=1e-4)
+        for r in (0, 1):
+            beta, lam, d, nobs, cvm, cvsd, lmin = got[r][key]
+            assert nobs == x.shape[0] and abs(d - ref["d"]) < 1e-9 * ref["d"]
+            for k in range(2):
+                assert np.allclose(lam[k], ref["lambda"][k], rtol=1e-10)
+                assert np.abs(beta[k] - ref["beta"][k]).max() < 1e-8 * max(1.0, np.abs(ref["beta"][k]).max()), (key, r, k)
+                assert np.allclose(cvm[k], ref["cvm"][k], rtol=1e-8) and np.allclose(cvsd[k], ref["cvsd"][k], rtol=1e-7), (key, r, k)
+        assert got[0][key][6] == got[1][key][6]
+        for r in (0, 1):
+            got[r].pop(key)
     for key in got[0]:
         offset, std, icpt = key
         x, y = _data(offset=offset)

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""config 4 (oem.xtx, p = 4096, 100-lambda lasso, tol 1e-10): eigen + path milliseconds and microseconds per iteration."""
+import ctypes as C, os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, oem_amd
+from oem_amd import _lib as L
+rng = np.random.default_rng(123)
+p, n = 4096, 65536
+x = rng.normal(size=(n, p)); b = np.zeros(p); b[:25] = rng.uniform(-1, 1, 25); y = x @ b + rng.normal(size=n)
+xtx, xty = x.T @ x / n, x.T @ y / n
+xtxd = torch.as_tensor(xtx, device="cuda")
+lib = L.lib(); ctx = oem_amd.context()
+L.check(lib.oemgpu_set_timing(ctx, 1))
+for knob in sys.argv[1:] or [""]:
+    if knob: os.environ["OEM_FUSED_BLOCKS"] = knob
+    t = []
+    for _ in range(3):
+        fit = oem_amd.oem_xtx(xtxd, xty, penalty="lasso", nlambda=100, tol=1e-10)
+        ms = (C.c_double * 8)(); L.check(lib.oemgpu_last_timings(ctx, ms)); t.append(ms[3])
+    it = int(fit["niter"][0].sum())
+    print(f"blocks={knob or 'default'}: eigen+path {min(t):.2f} ms, {it} iterations, {1e3 * min(t) / it:.2f} us per iteration (incl. Lanczos), {8 * p * p * it / (min(t) * 1e-3) / 1e12:.2f} TB/s over the path")
