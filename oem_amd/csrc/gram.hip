@@ -21,6 +21,8 @@
 // correction is O(sample error^2), so there is no cancellation even when |mean| >> sd.
 #include <cstdlib>
 #include "common.hpp"
+#include <queue>
+#include <vector>
 
 #include <type_traits>
 
@@ -1200,19 +1202,35 @@ __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64
 
 __global__ __launch_bounds__(256) void gram_sb_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                        const double *__restrict__ sums, double *__restrict__ tpart,
-                                                       double *__restrict__ vpart, GramDims a, int nsblk)
+                                                       double *__restrict__ vpart, GramDims a, int nsblk /* super-block ROWS */)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    // Launch order = longest first: ALL off-diagonal super-blocks (32 MFMAs per wave and slab) of all row chunks, then the diagonal
+    // ones (18).  Workgroups are handed to CUs as CUs fall free, so the launch ends one (partial) workgroup after the work runs
+    // out: with the short ones last that tail is short (measured at p = 256: 11 % of the launch in mixed order; gram_plan
+    // also picks the chunk count whose simulated tail is smallest).  Blocks of one row chunk still share blockIdx % 8 (one XCD).
     const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
-    const int sbk = s % nsblk, chunk = (s / nsblk) * 8 + xcd;
-    int SI = (int)((sqrtf(8.0f * (float)sbk + 1.0f) - 1.0f) * 0.5f);
-    while (SI * (SI + 1) / 2 > sbk) --SI;
-    while ((SI + 1) * (SI + 2) / 2 <= sbk) ++SI;
-    const int SJ = sbk - SI * (SI + 1) / 2;
+    const int nsb = nsblk, noff = nsb * (nsb - 1) / 2, soff = noff * (a.nchunk / 8);
+    int SI, SJ, chunk;
+    if (s < soff) {
+        const int ob = s % noff;
+        chunk = (s / noff) * 8 + xcd;
+        SI = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)ob)) * 0.5f);
+        while (SI * (SI - 1) / 2 > ob) --SI;
+        while ((SI + 1) * SI / 2 <= ob) ++SI;
+        SJ = ob - SI * (SI - 1) / 2;
+    } else {
+        const int s2 = s - soff;
+        SI = SJ = s2 % nsb;
+        chunk = (s2 / nsb) * 8 + xcd;
+    }
     const int64_t row_begin = (int64_t)chunk * a.steps * 64;
     double *tdst = tpart + (size_t)chunk * a.ntile * 256;
     double *vdst = vpart + (size_t)chunk * (32 * a.ntc + 4);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef OEM_GRAM_DIAG
+    const unsigned long long dg_c0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // every (kind of super-block, wave, shift) combination is its own straight-line body: a taken scalar branch per slab
     // costs ~80 cycles (measured on the path kernels), a 4-way dispatch up here costs nothing
 #define OEM_SB(D, W, XF) gram_sb_body<D, W, XF>(x, a.n, a.ld, a.p, y, sums, a.ntc, SI, SJ, row_begin, a.steps, tdst, vdst, lds)
@@ -1226,6 +1244,17 @@ __global__ __launch_bounds__(256) void gram_sb_kernel(const double *__restrict__
         else if (w == 2) OEM_SB(true, 2, false); else OEM_SB(true, 3, false);
     }
 #undef OEM_SB
+#ifdef OEM_GRAM_DIAG
+    // one diagonal and one off-diagonal workgroup of the first row chunk: shader cycles, 100 MHz ticks (-> the clock held), 8-row slabs
+    const int sbk = (SI == 0 && SJ == 0) ? 0 : ((SI == 1 && SJ == 0) ? 1 : -1);
+    if (chunk == 0 && sbk >= 0 && threadIdx.x == 0) {
+        int64_t rows = a.n - row_begin; if (rows > (int64_t)a.steps * 64) rows = (int64_t)a.steps * 64;
+        g_gram_diag[4 * sbk + 0] = __builtin_amdgcn_s_memtime() - dg_c0;
+        g_gram_diag[4 * sbk + 1] = __builtin_amdgcn_s_memrealtime() - dg_r0;
+        g_gram_diag[4 * sbk + 2] = (unsigned long long)(rows / 8);
+        g_gram_diag[4 * sbk + 3] = (unsigned long long)(SI == SJ);
+    }
+#endif
 }
 
 GramPlan gram_plan(int64_t n, int p, int num_cu)
@@ -1248,10 +1277,26 @@ GramPlan gram_plan(int64_t n, int p, int num_cu)
         const int nb = (pl.ntc + 3) / 4;
         pl.nblk = nb * (nb + 1) / 2;
         const int nsb = (pl.ntc + 7) / 8, nsblk = nsb * (nsb + 1) / 2;   // the shared-slab kernel's super-blocks
-        int64_t c = ((int64_t)num_cu * 8) / nsblk;            // ~8 rounds of one workgroup per CU
-        if (c > nsteps) c = nsteps;
-        if (c < 1) c = 1;
-        c = (c + 7) / 8 * 8;
+        // 8-12 rounds of one workgroup per CU: the count whose launch ends soonest when the workgroups are handed out longest
+        // first (gram_sb_kernel) -- a greedy replay with the measured costs (tools/gram_diag.py: 2,136 cycles per 8-row slab off
+        // the diagonal, 1,284 on it, ~25 k per workgroup) plus the partials the reduction has to read (2 KB per tile and chunk).
+        int64_t c = 0;
+        double best = 0.0;
+        for (int rounds = 8; rounds <= 12; ++rounds) {
+            int64_t cc = ((int64_t)num_cu * rounds) / nsblk;
+            if (cc > nsteps) cc = nsteps;
+            if (cc < 1) cc = 1;
+            cc = (cc + 7) / 8 * 8;
+            const double slabs = (double)((nsteps + cc - 1) / cc) * 8.0, d_off = slabs * 2136.0 + 25000.0, d_dg = slabs * 1284.0 + 25000.0;
+            std::priority_queue<double, std::vector<double>, std::greater<double>> cu;
+            for (int k = 0; k < num_cu; ++k) cu.push(0.0);
+            double end = 0.0;
+            for (int64_t k = 0; k < cc * (nsblk - nsb); ++k) { const double t = cu.top() + d_off; cu.pop(); cu.push(t); if (t > end) end = t; }
+            for (int64_t k = 0; k < cc * nsb; ++k) { const double t = cu.top() + d_dg; cu.pop(); cu.push(t); if (t > end) end = t; }
+            const double cost = end + (double)cc * pl.ntile * 2048.0 / 3.5e12 * 2.1e9;
+            if (c == 0 || cost < best) { c = cc; best = cost; }
+            if (cc >= nsteps) break;
+        }
         pl.steps = (int)((nsteps + c - 1) / c);
         if (const char *e = getenv("OEM_BLK_STEPS")) {          // experiment knob: rows per chunk = 64 * steps
             const int st = atoi(e);
@@ -1314,7 +1359,7 @@ static int launch_gram_t(hipStream_t s, const GramPlan &pl, const double *x, con
             const int nsb = (pl.ntc + 7) / 8, nsblk = nsb * (nsb + 1) / 2;
             const size_t shb = (size_t)SB_NSLOT * 16 * 1024;                // NSLOT x 16 KiB slots
             OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
-            hipLaunchKernelGGL(gram_sb_kernel, dim3(pl.nchunk * nsblk), dim3(256), shb, s, x, y, sums, tpart, vpart, a, nsblk);
+            hipLaunchKernelGGL(gram_sb_kernel, dim3(pl.nchunk * nsblk), dim3(256), shb, s, x, y, sums, tpart, vpart, a, nsb);
             OEM_HIP(hipGetLastError());
             return 0;
         }

@@ -42,7 +42,15 @@ out = (C.c_ulonglong * 8)()
 if have_diag:
     assert lib.oemgpu_gram_diag_read(out) == 0
 d = list(out)
-ns = d[7]
-print(f"n={n} p={p} mean={mean}: gram kernel {ms[L.T_GRAMK]*1e3:.1f} us; ticks(10 ns): prologue {d[0]} steady {d[4]} drain {d[5]} epilogue {d[6]}; slabs/wave {ns}")
-if ns:
-    print(f"steady ticks per slab {d[4] / max(1, ns - 5):.2f}  (floor: 56 MFMA x 64 cyc = 3584 cyc = {3584/21.0:.1f} ticks at 2.1 GHz)")
+if p + 2 > 112:
+    # shared-slab kernel: one diagonal (sbk 0) and one off-diagonal (sbk 1) workgroup of the first row chunk
+    print(f"n={n} p={p}: gram kernel {ms[L.T_GRAMK]*1e3:.1f} us")
+    for k, name in ((0, "diagonal super-block    (18 MFMA per wave and slab: floor 1152 cycles)"), (1, "off-diagonal super-block (32 MFMA per wave and slab: floor 2048 cycles)")):
+        cyc, ticks, slabs, isd = d[4 * k:4 * k + 4]
+        if ticks and slabs:
+            print(f"  {name}: {cyc} cycles in {ticks / 100.0:.1f} us = {cyc / ticks * 0.1:.3f} GHz held, {slabs} slabs, {cyc / slabs:.0f} cycles per slab (incl. prologue / epilogue)")
+else:
+    ns = d[7]
+    print(f"n={n} p={p} mean={mean}: gram kernel {ms[L.T_GRAMK]*1e3:.1f} us; cycles: prologue {d[0]} steady {d[4]} drain {d[5]} epilogue {d[6]}; slabs/wave {ns}")
+    if ns:
+        print(f"steady cycles per slab {d[4] / max(1, ns - 5):.2f}  (issue floor at p = 100: 2,877)")
