@@ -315,6 +315,27 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
     int gidE[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) gidE[k] = valid[k] ? gid[tid + NTH * k] : -1;
+    // Groups that are aligned blocks of eight consecutive coordinates (config 3: rep(1:64, each = 8)) sit in eight neighbouring
+    // lanes of one register (coordinate j = tid + 256 k), so their norms are three DPP butterfly stages and every lane forms its
+    // group's factor itself: no LDS list walk, no factor exchange, no barrier (1,340 of the 7,000 cycles of a config 3 round).
+    bool aligned8 = false;
+    double gwE[EPT];
+    bool gzE[EPT];
+    {
+        bool mine = ng > 0 && (q & 7) == 0 && ng * 8 == q;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) if (valid[k]) mine = mine && gidE[k] == ((tid + NTH * k) >> 3);
+        if (mine) for (int g = tid; g < ng; g += NTH) mine = mine && (gstart[g + 1] - gstart[g] == 8);
+#ifdef OEM_COOP_NO_ALIGNED                                   // timing experiments: the general group stage for every layout
+        mine = false;
+#endif
+        aligned8 = __syncthreads_and(mine ? 1 : 0) != 0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            gwE[k] = (aligned8 && gidE[k] >= 0) ? GW[gidE[k]] : 0.0;
+            gzE[k] = (aligned8 && gidE[k] >= 0) ? gzero[gidE[k]] != 0 : true;
+        }
+    }
     CoopX X;
     X.buf = (cgu64 *)reinterpret_cast<unsigned long long *>(A.work); X.epoch = 0; X.wg = wg; X.qmax = C::QMAX; X.failed = false;
 #ifdef OEM_PATH_DIAG
@@ -464,7 +485,66 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
                 double u[EPT];
 #pragma unroll
                 for (int k = 0; k < EPT; ++k) { bold[k] = beta[k]; u[k] = valid[k] ? Ush[tid + NTH * k] : 0.0; }
+                double fE[EPT];
                 if constexpr (KIND == K_GRP) {                      // group operators, ref src/oem_dense.h:193-315
+                    // factor of a group from its squared norm: 1 - pen / ||u_g|| with the root and its reciprocal from v_rsq_f64 +
+                    // Goldschmidt (~10 dependent FP64 ops; sqrt followed by a division is ~60), the quotient refined like cdiv;
+                    // ||u_g|| = 0 => f = 0 (quirk Q6); unpenalised groups keep f = 1
+                    auto factor = [&](double s2, double pen_g) {
+                        if (K.kind == K_GRP || K.kind == K_SGL) {
+                            double nrm, rn;
+                            sqrt_rsqrt_lane(s2, nrm, rn);
+                            const double t = 1.0 - cdiv(pen_g, nrm, rn);
+                            return (s2 > 0.0 && 0.0 < t) ? t : 0.0;
+                        }
+                        const double nr = sqrt(s2);
+                        return (K.kind == K_GRP_MCP) ? mcp_norm(nr, pen_g, K.D, K.gamma) : scad_norm(nr, pen_g, K.D, K.gamma);
+                    };
+                    if (aligned8) {
+                        double s2[EPT];
+#pragma unroll
+                        for (int k = 0; k < EPT; ++k) {
+                            if (K.kind == K_SGL) u[k] = soft1(u[k], pfE[k] * K.L1, 1.0);    // the soft-thresholded u feeds the norms
+                            s2[k] = u[k] * u[k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < EPT; ++k) s2[k] += dpp_mov<0xB1, 0xf>(s2[k], 0.0);      // quad_perm [1,0,3,2]
+#pragma unroll
+                        for (int k = 0; k < EPT; ++k) s2[k] += dpp_mov<0x4E, 0xf>(s2[k], 0.0);      // quad_perm [2,3,0,1]
+#pragma unroll
+                        for (int k = 0; k < EPT; ++k) s2[k] += dpp_mov<0x141, 0xf>(s2[k], 0.0);     // row_half_mirror: the eight lanes of the group
+                        bool plain = K.kind == K_GRP || K.kind == K_SGL;
+#pragma unroll
+                        for (int k = 0; k < EPT; ++k) plain = plain && ((s2[k] > 1e-200 && s2[k] < 1e200) || s2[k] == 0.0);
+                        if (__builtin_expect(__all(plain), 1)) {
+                            // the EPT chains side by side, no branch inside: y = rsq(s2), two coupled Goldschmidt steps, one correction of
+                            // the root (path_dev.hpp: sqrt_rsqrt), then t = 1 - pen / nrm through the corrected reciprocal (cdiv)
+                            double g[EPT], h[EPT], e[EPT];
+#pragma unroll
+                            for (int k = 0; k < EPT; ++k) { const double x = s2[k] == 0.0 ? 1.0 : s2[k]; const double y = __builtin_amdgcn_rsq(x); g[k] = x * y; h[k] = 0.5 * y; }
+#pragma unroll
+                            for (int it2 = 0; it2 < 2; ++it2) {
+#pragma unroll
+                                for (int k = 0; k < EPT; ++k) e[k] = fma(-h[k], g[k], 0.5);
+#pragma unroll
+                                for (int k = 0; k < EPT; ++k) { g[k] = fma(g[k], e[k], g[k]); h[k] = fma(h[k], e[k], h[k]); }
+                            }
+#pragma unroll
+                            for (int k = 0; k < EPT; ++k) {
+                                const double x = s2[k] == 0.0 ? 1.0 : s2[k];
+                                e[k] = fma(-g[k], g[k], x);
+                                g[k] = fma(e[k], h[k], g[k]);                               // nrm
+                            }
+#pragma unroll
+                            for (int k = 0; k < EPT; ++k) {
+                                const double t = 1.0 - cdiv(K.L * gwE[k], g[k], 2.0 * h[k]);
+                                fE[k] = gzE[k] ? 1.0 : ((s2[k] > 0.0 && 0.0 < t) ? t : 0.0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < EPT; ++k) fE[k] = gzE[k] ? 1.0 : factor(s2[k], K.L * gwE[k]);
+                        }
+                    } else {
                     if (K.kind == K_SGL) {                          // sparse group lasso: the soft-thresholded u feeds the norms
                         __syncthreads();                            // everybody has read u before it is overwritten
 #pragma unroll
@@ -491,22 +571,14 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
                                 m = gme - gcnt + 8; me = gme;
                             } else { m = gstart[gi]; me = gstart[gi + 1]; }
                             for (; m < me; ++m) { const double x = Ush[gidx[m]]; s2 += x * x; }
-                            const double pen_g = K.L * (first ? gwt : GW[gi]);
-                            if (K.kind == K_GRP || K.kind == K_SGL) {
-                                // 1 - pen / ||u_g|| with the root and its reciprocal from v_rsq_f64 + Goldschmidt (~10 dependent
-                                // FP64 ops; sqrt followed by a division is ~60), the quotient refined like cdiv; ||u_g|| = 0 => f = 0 (quirk Q6)
-                                double nrm, rn;
-                                sqrt_rsqrt_lane(s2, nrm, rn);
-                                const double t = 1.0 - cdiv(pen_g, nrm, rn);
-                                f = (s2 > 0.0 && 0.0 < t) ? t : 0.0;
-                            } else {
-                                s2 = sqrt(s2);
-                                f = (K.kind == K_GRP_MCP) ? mcp_norm(s2, pen_g, K.D, K.gamma) : scad_norm(s2, pen_g, K.D, K.gamma);
-                            }
+                            f = factor(s2, K.L * (first ? gwt : GW[gi]));
                         }
                         F[gi] = f;
                     }
                     __syncthreads();
+#pragma unroll
+                    for (int k = 0; k < EPT; ++k) fE[k] = gidE[k] >= 0 ? F[gidE[k]] : 0.0;
+                    }
                 }
                 COOP_STAMP(9);                                      // u read (+ group norms and factors)
                 bool bad = false;
@@ -517,7 +589,7 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
                     const int j = tid + NTH * k;
                     double bn;
                     if constexpr (KIND == K_GRP) {
-                        const double f = gidE[k] >= 0 ? F[gidE[k]] : 0.0;
+                        const double f = fE[k];
                         bn = (f != 0.0) ? cdiv(u[k] * f, K.D, c.rD) : 0.0;
                     } else bn = thr1<KIND>(u[k], tp[k], c);
                     bn = valid[k] ? bn : 0.0;
