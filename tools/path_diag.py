@@ -45,8 +45,9 @@ if p > 64 and p <= 128:
     print("    per-lambda (slot 8):", round(d[8] / len(fit["lambda"][0]), 1), " prologue:", int(d[5]), " top_ritz calls total:", int(d[9]),
           " Lanczos steps:", int(d[6]), "x", round(d[10] / max(d[6], 1), 1), "cycles (stamped)")
     ns = max(d[6], 1)
-    print("    Lanczos step by segment [norm rows_sum etc | stores+barrier | reads | rsqrt+scale+FMAs | adds+reduce | beta store+tests | alpha rows_sum+exchange | alpha store+next vector]:")
-    print("   ", np.round(np.r_[d[12:17], d[17:20]] / ns, 1), "sum", round((d[12:17].sum() + d[17:20].sum()) / ns, 1))
+    print("    Lanczos step by segment [product + reduce-scatter + alpha share | stores + barrier | reads + alpha sum | orthogonalise copy + in-wave norm + rsqrt | T stores, tests, next vector]:")
+    seg = np.array([d[15], d[13], d[14], d[17], d[19]])
+    print("   ", np.round(seg / ns, 1), "sum", round(seg.sum() / ns, 1))
     sys.exit(0)
 print("Lanczos cycles by segment:", lz.astype(int), "sum", int(lz.sum()))
 print("OEM cycles by segment    :", oem.astype(int), "sum", int(oem.sum()))
