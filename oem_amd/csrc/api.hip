@@ -252,11 +252,11 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const size_t out_doubles = nb + 2 * nk + 4 + (size_t)stats_len(p);
     const size_t out_bytes = out_doubles * sizeof(double) + nk * sizeof(int32_t);
     const size_t out_stride = (out_bytes + 255) / 256 * 256;
-    const bool small = q <= SMALL_P_MAX;
     const bool loss_on = (sem == OEMGPU_SEM_DENSE || sem == OEMGPU_SEM_XVAL || sem == SEM_SPARSE) && o->compute_loss != 0;
     // several instances (xval.oem's K + 1 fits) on the cooperating engine: only if all their workgroup sets are resident at once
-    const bool coop = !small && path_coop_eligible(q, scale_factor != nullptr, loss_on, og.ngroups, nbatch) &&
+    const bool coop = path_coop_eligible(q, scale_factor != nullptr, loss_on, og.ngroups, nbatch) &&
                       (nbatch == 1 || path_coop_workgroups(q) * nbatch <= c->num_cu * 3 / 4);
+    const bool small = q <= SMALL_P_MAX && !coop;
     if (nbatch > 1 && !small && !coop) { set_error("internal: batched paths need p <= %d", SMALL_P_MAX); return OEMGPU_ERR_INTERNAL; }
     // Lanczos step cap: q up to 288 (the whole Krylov space: the recurrence stops by itself when the top Ritz value has settled, and
     // a spectrum that needs more than 128 steps gets them -- ADVICE r1); the large-p engines keep their own caps (256 / 512)
@@ -387,14 +387,14 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
 size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o, int nbatch = 1)
 {
     const int nl = nl_of(o);
-    if (nbatch > 1) return (size_t)nbatch * (paths_ws_bytes(p, q, o) + 1024) + (q > SMALL_P_MAX ? (size_t)nbatch * o->npen * path_coop_xchg_bytes() : 0);
+    if (nbatch > 1) return (size_t)nbatch * (paths_ws_bytes(p, q, o) + 1024) + (q >= path_coop_min_q(true) ? (size_t)nbatch * o->npen * path_coop_xchg_bytes() : 0);
     const size_t splits = (q <= 1024 && o->npen > 1) ? (size_t)o->npen : 1;
     size_t b = 0;
     b += (size_t)o->npen * 4 + (size_t)o->npen * nl * 8 + (size_t)q * (8 + 8 + 4) + (size_t)(o->ngroups + 2) * 16 +
          (size_t)(o->ngroupvars + q + 2) * 4 + 4096;
     b += ((size_t)o->npen * nl * (q + 3) + 4 + stats_len(p)) * 8 + 4096;
     size_t wk = q > SMALL_P_MAX ? path_large_work_doubles(q, 128) * 8 : path_small_xchg_bytes();
-    if (q > SMALL_P_MAX && q <= 1024 && wk < path_coop_xchg_bytes()) wk = path_coop_xchg_bytes();
+    if (q >= path_coop_min_q(true) && q <= 1024 && wk < path_coop_xchg_bytes()) wk = path_coop_xchg_bytes();
     b += wk * splits + 4096;
     return b;
 }

@@ -700,9 +700,20 @@ extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read_coop(unsi
 
 size_t path_coop_xchg_bytes() { return (size_t)2 * 1024 * 2 * sizeof(unsigned long long); }
 
+// Smallest q the cooperating engine takes.  It used to start where one workgroup's registers end (289); measured against the
+// engines below (tools/coop_small_time.py, eigen + path of a 100-lambda path): element-wise penalties at q = 209 1.86 vs 2.70 ms
+// (the four-workgroup replicated kernel), q = 288 2.14 vs 4.34 ms, config 5's q = 257 1.59 vs 2.96 ms -- but q = 200 1.80 vs
+// 0.94 ms (the row-split kernel, up to 208, stays); with a group penalty in the call q = 192 2.25 vs 2.71 ms, q = 160 and 130 equal.
+// OEM_COOP_MIN_Q: experiment knob (never below 129).
+int path_coop_min_q(bool has_groups)
+{
+    static const int v = [] { const char *e = getenv("OEM_COOP_MIN_Q"); const int k = e ? atoi(e) : 0; return k >= 129 ? k : 0; }();
+    return v ? v : (has_groups ? COOP_MIN_Q_GROUPS : COOP_MIN_Q);
+}
+
 bool path_coop_eligible(int q, bool has_sinv, bool compute_loss, int ngroups, int nbatch)
 {
-    if (getenv("OEM_NO_COOP") || q <= SMALL_P_MAX || q > 1024) return false;      // OEM_NO_COOP: the launch-per-iteration engines
+    if (getenv("OEM_NO_COOP") || q < path_coop_min_q(ngroups > 0) || q > 1024) return false;      // OEM_NO_COOP: the launch-per-iteration engines
     if (has_sinv && compute_loss) return false;          // the loss of the un-rescaled member would need a product of its own
     if (ngroups > (q <= 512 ? 512 : 1024)) return false;
     (void)nbatch;                                        // nbatch > 1: the caller checks that all workgroup sets fit (api.hip: run_paths)
