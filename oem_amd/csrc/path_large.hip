@@ -826,7 +826,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     OEM_HIP(hipMemsetAsync(a.work, 0, sizeof(double) * path_large_work_doubles(q, 0), s));
 
     // ---- eigenvalue step: Lanczos (GEMV + single-workgroup vector update), checked every
-    //      32 steps on the host, which is also the convergence test
+    //      16 steps on the host, which is also the convergence test
     const int mmax = q < MAXL ? q : MAXL;
     double theta = 0.0, theta_prev = -1.0;
     double *hT = host_scratch;
@@ -854,7 +854,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         if (rc) return rc;
     } else hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, s, q, v, vp);
     while (m < mmax) {
-        const int chunk = (mmax - m) < 32 ? (mmax - m) : 32;
+        const int chunk = (mmax - m) < 16 ? (mmax - m) : 16;     // a host look costs about one step
         for (int k = 0; k < chunk; ++k, ++m) {
             if (lz_fused) hipLaunchKernelGGL(lzk, dim3(lblocks), dim3(256), lsh, s, a.xx, q, m, Vc, Vp, Wb, T, m & 1);
             else {
@@ -871,6 +871,14 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
             if (!(hT[MAXL + k] > 1e-13 * std::fabs(hT[k]))) { mm = k + 1; break; }     // breakdown: T is exact
         theta = tridiag_max_host(hT, hT + MAXL, mm);
         if (mm < m) break;
+        // the stop rule of the register-resident engines (path_dev.hpp: lanczos_converged) on the top Ritz values of the leading
+        // blocks T_{m-16}, T_{m-8}, T_m, which the host has for free: moved by <= 1e-14 relative over the last 8 steps, or two
+        // successive moves that decay so fast that their geometric tail is <= 1e-12 relative
+        if (m >= 24) {
+            const double t1 = tridiag_max_host(hT, hT + MAXL, m - 8), t0 = tridiag_max_host(hT, hT + MAXL, m - 16);
+            const double mv = theta - t1, mvp = t1 - t0, ath = std::fabs(theta);
+            if (mv <= 1e-14 * ath || (mv < 0.01 * mvp && mv * mv <= 1e-12 * ath * (mvp - mv))) break;
+        }
         if (theta_prev > 0 && std::fabs(theta - theta_prev) <= 1e-12 * std::fabs(theta)) break;
         theta_prev = theta;
     }
