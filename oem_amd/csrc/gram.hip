@@ -1268,6 +1268,7 @@ GramPlan gram_plan(int64_t n, int p, int num_cu)
     if (pl.tri) {
         pl.nblk = 1;
         int64_t c = nsteps < num_cu ? nsteps : num_cu;
+        if (const char *e = getenv("OEM_TRI_ROUNDS")) { const int r = atoi(e); if (r > 1 && nsteps >= (int64_t)num_cu * r) c = (int64_t)num_cu * r; }   // experiment knob
         if (c < 1) c = 1;
         pl.steps = (int)((nsteps + c - 1) / c);
         if (pl.steps < 1) pl.steps = 1;
