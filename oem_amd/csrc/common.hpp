@@ -133,7 +133,7 @@ __device__ __forceinline__ PathArgs path_instance(PathArgs A)
     return A;
 }
 
-static const int COOP_MIN_Q = 209, COOP_MIN_Q_GROUPS = 161;      // from here the cooperating-workgroup engine (path_coop.hip) takes the path when it is eligible (element-wise penalties only / a group penalty in the call)
+static const int COOP_MIN_Q = 209, COOP_MIN_Q_GROUPS = 209;      // from here the cooperating-workgroup engine (path_coop.hip) takes the path when it is eligible (element-wise penalties only / a group penalty in the call)
 int path_coop_min_q(bool has_groups);
 static const int SMALL_P_MAX = 288;     // one workgroup where the matrix fits its registers (+ LDS); else four cooperating workgroups (big.oem's p + 1 = 257 included)
 size_t path_small_xchg_bytes();

@@ -703,7 +703,8 @@ size_t path_coop_xchg_bytes() { return (size_t)2 * 1024 * 2 * sizeof(unsigned lo
 // Smallest q the cooperating engine takes.  It used to start where one workgroup's registers end (289); measured against the
 // engines below (tools/coop_small_time.py, eigen + path of a 100-lambda path): element-wise penalties at q = 209 1.86 vs 2.70 ms
 // (the four-workgroup replicated kernel), q = 288 2.14 vs 4.34 ms, config 5's q = 257 1.59 vs 2.96 ms -- but q = 200 1.80 vs
-// 0.94 ms (the row-split kernel, up to 208, stays); with a group penalty in the call q = 192 2.25 vs 2.71 ms, q = 160 and 130 equal.
+// 0.94 ms (the row-split kernel, up to 208, stays); with a group penalty in the call q = 192 2.25 vs 2.71 ms on the replicated kernel,
+// but 1.83 ms on the row-split kernel now that it has the group operators: the same bound for both.
 // OEM_COOP_MIN_Q: experiment knob (never below 129).
 int path_coop_min_q(bool has_groups)
 {

@@ -942,7 +942,18 @@ template <int NW_, int CG, int CGL> struct RowsCfg {
     static constexpr int LCH = 1024;                      // lambdas staged in LDS at a time
     static constexpr int OFF_L = OFF_TH + 2 + 64 * NW;    // (+ one scratch word per lane before it)
     static constexpr int OFF_A = OFF_L + LCH;             // LDS-resident matrix columns [CGL][2][NW * 64]
-    static constexpr int N_DBL = OFF_A + 2 * CGL * NW * 64;
+    static constexpr int OFF_GX = OFF_A + 2 * CGL * NW * 64;   // group member lists (ints), group penalties only
+    static constexpr int N_DBL = OFF_GX + (32 * NW + 8) / 2 + 4;
+};
+
+// this lane's group (group penalties in the row-split kernel): the members of the group of the lane's row are read from the
+// exchanged u in LDS -- the first eight slots from registers (eight independent reads: one latency), longer groups walk the list
+struct RowGrp {
+    int gi, cnt, start, gmax;       // group index (-1: none), its size, its first entry in the member list, the wave's largest group
+    bool gz;                        // unpenalised group (factor 1)
+    double gw;                      // group weight
+    int gm[8];                      // LDS slots of the first eight members (zero word beyond the group's end)
+    const int *GX;                  // member lists in LDS
 };
 
 struct RowsLds {
@@ -1028,13 +1039,51 @@ __device__ __forceinline__ void iterate_rows_t(const PathArgs &A, const PenK &K,
                                                const double *aL, double xy, double pf, int wslot,
                                                const int (&ecol)[(CG + CGL + 15) / 16],
                                                double &beta, double &ab, double &ak, int &it, int &conv, const RowsLds &S,
-                                               int w, int lane, int &buf OEM_DIAG_ARGS)
+                                               int w, int lane, int &buf, const RowGrp &G OEM_DIAG_ARGS)
 {
     const double tp = pf * K.L, tol = A.tol;
     const int maxit = A.maxit;
+    constexpr int VS = RowsCfg<NW, CG, CGL>::VS;
     OEM_STAMP(8);                       // per-lambda work since the last round
     auto round = [&]() -> bool {
         const double bold = beta;
+        if constexpr (KIND == K_GRP) {
+            // Group operators (ref src/oem_dense.h:193-315).  A group's members are rows of other lanes and waves, so u crosses
+            // the waves once before the threshold (one more exchange than the element-wise operators: the same vector buffers,
+            // which alternate u, beta, u, ...): every lane then sums its own group's squares in member order like the reference
+            // and forms the factor itself; lanes of one group do so redundantly, which costs nothing.
+            double u = ab + xy;
+            if (K.kind == K_SGL) u = soft1(u, pf * K.L1, 1.0);     // sparse group lasso: the soft-thresholded u feeds the norms
+            const int b = __builtin_amdgcn_readfirstlane(buf);
+            S.V[b * VS + wslot] = u;
+            __syncthreads();
+            buf = b ^ 1;
+            double x[8], s2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = S.V[b * VS + G.gm[k]];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s2 += x[k] * x[k];
+            for (int m = 8; m < G.gmax; ++m) {
+                const double xm = S.V[b * VS + (m < G.cnt ? G.GX[G.start + m] : VS - 1)];
+                s2 += xm * xm;
+            }
+            double f = 1.0;
+            const double pen_g = K.L * G.gw;
+            if (K.kind == K_GRP || K.kind == K_SGL) {
+                // 1 - pen / ||u_g|| with the root and its reciprocal from v_rsq_f64 + Goldschmidt, the quotient refined like cdiv;
+                // ||u_g|| = 0 => f = 0 (quirk Q6)
+                double nrm, rn;
+                sqrt_rsqrt_lane(s2, nrm, rn);
+                const double t = 1.0 - cdiv(pen_g, nrm, rn);
+                f = (s2 > 0.0 && 0.0 < t) ? t : 0.0;
+            } else {
+                const double nr = sqrt(s2);
+                f = (K.kind == K_GRP_MCP) ? mcp_norm(nr, pen_g, K.D, K.gamma) : scad_norm(nr, pen_g, K.D, K.gamma);
+            }
+            f = G.gz ? 1.0 : f;
+            f = G.gi >= 0 ? f : 0.0;
+            beta = (f != 0.0) ? cdiv(u * f, c.D, c.rD) : 0.0;
+        } else
         beta = threshold1<KIND>(ab + xy, tp, c);                    // padding lanes: zero matrix rows, xy = 0 => stays 0
         double aux = 0.0;
         if (ACC) {                                                 // ref src/oem_dense.h:633-651
@@ -1121,6 +1170,27 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
     bool any_unused;
     double aux_unused = 0.0;
     OEM_DIAG_DECL
+    RowGrp G;
+    G.gi = -1; G.cnt = 0; G.start = 0; G.gmax = 0; G.gz = false; G.gw = 0.0;
+    G.GX = reinterpret_cast<const int *>(lds + C::OFF_GX);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) G.gm[k] = C::VS - 1;                 // a word that stays zero
+    if (A.ngroups > 0) {
+        int *gx = reinterpret_cast<int *>(lds + C::OFF_GX);
+        const int nm = A.gstart[A.ngroups];
+        for (int m = tid; m < nm && m < 32 * NW + 8; m += NW * 64) gx[m] = A.gidx[m];
+        __syncthreads();
+        if (rowok) {
+            G.gi = A.gid[row];
+            if (G.gi >= 0) {
+                G.start = A.gstart[G.gi]; G.cnt = A.gstart[G.gi + 1] - G.start;
+                G.gz = A.gzero[G.gi] != 0; G.gw = A.gw[G.gi];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) G.gm[k] = k < G.cnt ? gx[G.start + k] : C::VS - 1;
+            }
+        }
+        G.gmax = (int)wave_max((double)G.cnt);
+    }
 
     // ---- eigenvalue step: Lanczos with the vector spread over the waves (one entry per owner lane)
     int msteps = A.lanczos_steps < C::ML ? A.lanczos_steps : C::ML;
@@ -1301,7 +1371,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
                 const PenK K = pen_from_linear(PL, il, d, A.gamma);
                 if (__builtin_expect(ridge, 0)) c = thr_consts<KIND>(K, d);
                 int it = 0, conv = 0;
-                iterate_rows_t<NW, CG, CGL, KIND, ACC>(A, K, c, a, aL, xy, pf, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf OEM_DIAG_PASS);
+                iterate_rows_t<NW, CG, CGL, KIND, ACC>(A, K, c, a, aL, xy, pf, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf, G OEM_DIAG_PASS);
                 // (the loss is taken in the coordinates of the iteration, before any in-place rescale)
                 double lossv = 1e99;
                 if (__builtin_expect(A.compute_loss != 0, 0)) {
@@ -1329,14 +1399,16 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
             case K_SOFT: lambda_loop(std::integral_constant<int, K_SOFT>{}, T{}, pp, pen); break;
             case K_MCP: lambda_loop(std::integral_constant<int, K_MCP>{}, T{}, pp, pen); break;
             case K_SCAD: lambda_loop(std::integral_constant<int, K_SCAD>{}, T{}, pp, pen); break;
-            default: lambda_loop(std::integral_constant<int, K_OLS>{}, T{}, pp, pen); break;
+            case K_OLS: lambda_loop(std::integral_constant<int, K_OLS>{}, T{}, pp, pen); break;
+            default: lambda_loop(std::integral_constant<int, K_GRP>{}, T{}, pp, pen); break;       // every group operator (K.kind selects inside)
             }
         } else {
             switch (kind) {
             case K_SOFT: lambda_loop(std::integral_constant<int, K_SOFT>{}, F{}, pp, pen); break;
             case K_MCP: lambda_loop(std::integral_constant<int, K_MCP>{}, F{}, pp, pen); break;
             case K_SCAD: lambda_loop(std::integral_constant<int, K_SCAD>{}, F{}, pp, pen); break;
-            default: lambda_loop(std::integral_constant<int, K_OLS>{}, F{}, pp, pen); break;
+            case K_OLS: lambda_loop(std::integral_constant<int, K_OLS>{}, F{}, pp, pen); break;
+            default: lambda_loop(std::integral_constant<int, K_GRP>{}, F{}, pp, pen); break;
             }
         }
     }
@@ -1392,9 +1464,10 @@ extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read(unsigned 
 
 int launch_path_small(hipStream_t s, const PathArgs &a)
 {
-    // element-wise penalties, p <= 208: the row-split form (beta all-gather, permlane reduce-scatter); four waves
-    // up to p = 128, eight (two per SIMD, 256 VGPRs each: a[2][CG] must leave room) beyond
-    if (a.ngroups == 0 && a.p <= 208 && !(a.p > 128 && getenv("OEM_NO_ROWS8"))) {
+    // p <= 208: the row-split form (beta all-gather, permlane reduce-scatter; group operators exchange u as well); four waves
+    // up to p = 128, eight (two per SIMD, 256 VGPRs each: a[2][CG] must leave room) beyond.  OEM_NO_ROWS_GROUPS: calls with a
+    // group penalty on the replicated / sliced kernels below, as before round 2 (the tests hold the two against each other)
+    if ((a.ngroups == 0 || !getenv("OEM_NO_ROWS_GROUPS")) && a.p <= 208 && !(a.p > 128 && getenv("OEM_NO_ROWS8"))) {
         if (a.p <= 32) return launch_rows<4, 8>(s, a);
         if (a.p <= 64) return launch_rows<4, 16>(s, a);
         if (a.p <= 80) return launch_rows<4, 20>(s, a);

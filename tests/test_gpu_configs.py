@@ -276,3 +276,41 @@ def test_config5_one_gpu_share_full_size_kkt(oa):
     assert (beta[1:, 19] != 0).sum() >= 30                            # lambda_zero counts the intercept slot (quirk Q10): the early lambdas select nothing
     del x, y
     torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,gsize", [(24, 3), (100, 5), (101, 8), (130, 10), (160, 16), (192, 6), (208, 13)])
+def test_group_operators_in_the_row_split_kernel(oa, p, gsize):
+    """Round 2: calls with a group penalty run on the row-split kernel up to p = 208 (u crosses the waves once more per round and
+    every lane sums its own group in member order).  Against the oracle and against the replicated / sliced kernels that served
+    them before (OEM_NO_ROWS_GROUPS): every group operator, groups longer than the eight cached members, non-contiguous groups,
+    an unpenalised group 0, custom weights, element-wise penalties in the same call, accelerate and compute.loss."""
+    import os
+    rng = np.random.default_rng(1000 + p)
+    n = 4 * p + 50
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 1.5 + 0.2)
+    b = np.concatenate([rng.uniform(-1.0, 1.0, 9), np.zeros(p - 9)])
+    y = x @ b + rng.normal(size=n)
+    groups = rng.permutation(np.arange(p) // gsize)                                     # non-contiguous; group 0 is unpenalised
+    ng = len(np.unique(groups))
+    cases = [dict(penalty=["grp.lasso", "grp.mcp", "grp.scad", "sparse.grp.lasso", "grp.lasso.net", "lasso", "mcp"], groups=groups,
+                  alpha=0.6, tau=0.3, gamma=3.2, nlambda=7, tol=1e-9, maxit=2000),
+             dict(penalty=["grp.lasso", "grp.scad.net"], groups=groups + 1, group_weights=rng.uniform(0.5, 2.0, ng), alpha=0.8,
+                  nlambda=6, tol=1e-9, maxit=2000, accelerate=True, compute_loss=True, standardize=False),
+             dict(penalty=["grp.mcp.net", "ols"], groups=groups, alpha=0.5, nlambda=5, tol=1e-9, maxit=2000, intercept=False)]
+    for kw in cases:
+        fit = oa.oem(x, y, **kw)
+        os.environ["OEM_NO_ROWS_GROUPS"] = "1"
+        try:
+            old = oa.oem(x, y, **kw)
+        finally:
+            del os.environ["OEM_NO_ROWS_GROUPS"]
+        ref = orc.fit_dense(x, y, native=True, unique_groups=np.unique(kw["groups"]), **kw)
+        for k, pen in enumerate(kw["penalty"]):
+            scale = max(1.0, float(np.abs(ref["beta"][k]).max()))
+            assert np.abs(np.asarray(fit["beta"][k]) - np.asarray(ref["beta"][k])).max() < 1e-8 * scale, (pen, kw.get("accelerate"))
+            assert np.abs(np.asarray(fit["beta"][k]) - np.asarray(old["beta"][k])).max() < 1e-9 * scale, pen
+            assert np.abs(np.ravel(fit["niter"][k]).astype(int) - np.ravel(ref["niter"][k]).astype(int)).max() <= 1, pen
+            if kw.get("compute_loss"):
+                assert np.allclose(np.ravel(fit["loss"][k]), np.ravel(ref["loss"][k]), rtol=1e-9), pen
+        assert abs(fit["d"] - ref["d"]) < 1e-9 * ref["d"]
