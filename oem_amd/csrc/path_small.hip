@@ -1357,35 +1357,39 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
                     lam = exp(lv);
                     if (isnet) lam = lam / A.alpha;
                 }
-                LAM[k] = lam;
+                LAM[k] = cdiv(lam, scaley, rscaley);                      // lambda / scale(y), ref src/oem_dense.cpp:241
                 A.lambda_out[(size_t)pp * nl + i] = lam;
+                A.loss[(size_t)pp * nl + i] = 1e99;                       // "not computed" (overwritten below if compute.loss)
             }
             __syncthreads();
             const int kend = nlam - base < cnt ? nlam - base : cnt;
             double lam_next = LAM[0];
+            // output cursors: one pointer bump per lambda instead of a 64-bit multiply-add per store (lanes that own nothing
+            // keep aiming at their sink word: stride 0)
+            double *bptr = owner ? &A.beta[((size_t)pp * nl + base) * p + row] : sinkd;
+            const size_t bstride = owner ? (size_t)p : 0;
+            int *nptr = t0 ? &A.niter[(size_t)pp * nl + base] : sinki;
+            const size_t nstride = t0 ? 1 : 0;
             for (int k = 0; k < kend; ++k) {
-                const double lam = lam_next;
+                const double il = lam_next;
                 lam_next = LAM[k + 1 < cnt ? k + 1 : k];
-                const size_t orow = (size_t)pp * nl + base + k;
-                const double il = cdiv(lam, scaley, rscaley);             // ref src/oem_dense.cpp:241
                 const PenK K = pen_from_linear(PL, il, d, A.gamma);
                 if (__builtin_expect(ridge, 0)) c = thr_consts<KIND>(K, d);
                 int it = 0, conv = 0;
                 iterate_rows_t<NW, CG, CGL, KIND, ACC>(A, K, c, a, aL, xy, pf, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf, G OEM_DIAG_PASS);
                 // (the loss is taken in the coordinates of the iteration, before any in-place rescale)
-                double lossv = 1e99;
                 if (__builtin_expect(A.compute_loss != 0, 0)) {
                     // sum (Y - X beta)^2 through the Gram identity (ref src/oem_dense.h:759-770):
                     // yy - 2 n beta'XY + n beta' XX beta, with XX beta = d beta - A beta
-                    lossv = yy + nobs * waves_sum<NW>(rows_sum(beta * ((d * beta - ab) - 2.0 * xy)), S.XN, par, w, lane);
+                    const double lossv = yy + nobs * waves_sum<NW>(rows_sum(beta * ((d * beta - ab) - 2.0 * xy)), S.XN, par, w, lane);
+                    *(t0 ? &A.loss[(size_t)pp * nl + base + k] : sinkd + 256) = lossv;
                 }
                 // oemXTX::get_beta rescales the member in place (ref src/oem_xtx.h:576-581, quirk Q5)
                 if (__builtin_expect(A.sinv != nullptr, 0)) beta *= sinv;
-                *(owner ? &A.beta[orow * p + row] : sinkd) = beta;
-                *(t0 ? &A.niter[orow] : sinki) = conv ? it : A.maxit + 1; // ref src/oem_base.h:94-109
+                *bptr = beta; bptr += bstride;
+                *nptr = conv ? it : A.maxit + 1; nptr += nstride;         // ref src/oem_base.h:94-109
                 if (__builtin_expect(A.sinv != nullptr, 0))
                     ab = gemv_rows<NW, CG, CGL, false, false>(a, aL, beta, wslot, ecol, false, any_unused, aux_unused, S, w, lane, buf, nullptr OEM_DIAG_PASS);
-                *(t0 ? &A.loss[orow] : sinkd + 256) = lossv;
             }
             __syncthreads();                                             // LAM is rewritten by the next chunk
         }
