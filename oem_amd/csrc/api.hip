@@ -846,7 +846,7 @@ struct XvalLay {
     bool weighted;
     size_t mlen, cslen;
     GramPlan plmax;
-    size_t a_cs, a_cnt, a_fn, a_bad, a_pos, a_xp, a_yp, a_mf, a_mc, a_ms, a_t, a_v, a_b, a_part, a_out, total;
+    size_t a_cs, a_cnt, a_fn, a_bad, a_pos, a_xp, a_yp, a_mf, a_mc, a_ms, a_t, a_v, a_b, a_part, a_out, a_peer, total;
 };
 static XvalLay xval_layout(oemgpu_ctx *c, int64_t n, int p, int K, int npen, int nl, bool weighted)
 {
@@ -868,6 +868,7 @@ static XvalLay xval_layout(oemgpu_ctx *c, int64_t n, int p, int K, int npen, int
     L.a_t = A.take(L.plmax.tpart_doubles * 8 * 2); L.a_v = A.take(L.plmax.vpart_doubles * 8 * 2);
     L.a_b = A.take(sizeof(double) * (size_t)K * npen * nl * (p + 1));
     L.a_part = A.take(sizeof(double) * cv_part_doubles(L.nwg, K, npen, nl)); L.a_out = A.take(sizeof(double) * 3 * (size_t)npen * nl);
+    L.a_peer = A.take(sizeof(double) * (L.mlen + L.cslen) * K);            // another device's fold moments on their way into the sum
     L.total = A.off;
     return L;
 }
@@ -875,8 +876,8 @@ static XvalLay xval_layout(oemgpu_ctx *c, int64_t n, int p, int K, int npen, int
 static int xval_check(oemgpu_ctx *c, const void *x_dev, const void *y_dev, const void *foldid_dev, int64_t n, int64_t ld, int p, int K,
                       int intercept, int type_measure, bool weighted, const oemgpu_opts *o)
 {
-    if (!c || !o) { set_error("xval_dense: NULL argument"); return OEMGPU_ERR_ARG; }
-    (void)x_dev; (void)y_dev; (void)foldid_dev;
+    if (!o) { set_error("xval_dense: NULL argument"); return OEMGPU_ERR_ARG; }
+    (void)c; (void)x_dev; (void)y_dev; (void)foldid_dev;
     if (intercept >= 0) {                                          // (< 0: a phase that does not solve; the options were checked by the one that does)
         int rc = check_opts(o, p, p + (intercept ? 1 : 0));
         if (rc) return rc;
@@ -1168,6 +1169,114 @@ int oemgpu_xval_merge(const double *triples, int32_t nsets, const oemgpu_opts *o
     return 0;
 }
 
+// rows [r0, r1) of the host data resident on the context's device: x (leading dimension *ld), y, foldid and the weights
+static int xval_upload_rows(oemgpu_ctx *c, const double *x, int64_t n, int32_t p, const double *y, const double *weights, const int32_t *foldid,
+                            int64_t r0, int64_t r1, const oemgpu_opts *o, double **xd, int64_t *ld, double **yd, double **wd, int32_t **fd)
+{
+    const int64_t nr = r1 - r0;
+    int rc = host_upload_resident(c, x + r0, nr, p, y + r0, o, xd, ld, yd, n);   // staged through the pinned lanes, leaves room for foldid behind y
+    if (rc) return rc;
+    *fd = (int32_t *)(*yd + ((nr + 2 + 31) / 32 * 32));
+    *wd = nullptr;
+    hipError_t e = hipMemcpyAsync(*fd, foldid + r0, sizeof(int32_t) * (size_t)nr, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { set_error("upload of foldid failed: %s", hipGetErrorString(e)); return OEMGPU_ERR_HIP; }
+    if (weights) {                                               // the rows' weights in the accumulator buffer of the host path (grow-only)
+        rc = ctx_grow(c, &c->acc, &c->acc_bytes, sizeof(double) * (size_t)(nr + 2));
+        if (rc) return rc;
+        *wd = (double *)c->acc;
+        if (hipMemcpyAsync(*wd, weights + r0, sizeof(double) * (size_t)nr, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+            set_error("upload of the weights failed"); return OEMGPU_ERR_HIP;
+        }
+    }
+    return 0;
+}
+
+// opts.ngpus > 1: the three phases of the call (xval_prepare / xval_solve / xval_cverr) with the rows split over the devices like
+// oemgpu_fit_dense does (floor(n / G) each, the remainder on the last), one host thread per device for the two row-bound phases:
+// the fold moments are handed to the first device by peer copies and added in device order, the K + 1 fits run there, the fold
+// coefficients go back to every device, and the error triples of the devices' rows merge on the host (oemgpu_xval_merge).
+static int xval_dense_devices(const std::vector<int> &dev, const double *x, int64_t n, int32_t p, const double *y, const double *weights,
+                              const int32_t *foldid, int32_t K, int32_t standardize, int32_t intercept, int32_t type_measure,
+                              const oemgpu_opts *o, double *beta, double *lambda_out, int32_t *niter, double *loss, double *d,
+                              double *cvm, double *cvsd)
+{
+    const int G = (int)dev.size(), npen = o->npen, nl = nl_of(o);
+    struct Part {
+        oemgpu_ctx *c = nullptr;
+        int64_t r0 = 0, r1 = 0, ld = 0;
+        double *xd = nullptr, *yd = nullptr, *wd = nullptr;
+        int32_t *fd = nullptr;
+        XvalLay L;
+        std::vector<int64_t> hf;
+        std::vector<double> tri;
+        int rc = 0;
+        std::string err;
+    };
+    std::vector<Part> P(G);
+    auto release_all = [&]() { for (Part &q : P) if (q.c) { (void)hipSetDevice(q.c->device); (void)hipStreamSynchronize(q.c->stream); ctx_release(q.c); q.c = nullptr; } };
+    for (int g = 0; g < G; ++g) {
+        oemgpu_row_split(n, G, g, &P[g].r0, &P[g].r1);
+        if (P[g].r1 - P[g].r0 < 1) { release_all(); set_error("xval_dense: fewer rows than devices"); return OEMGPU_ERR_ARG; }
+        P[g].c = ctx_acquire(dev[g]);
+        if (!P[g].c) { release_all(); return OEMGPU_ERR_NO_DEVICE; }
+    }
+    auto each = [&](auto &&work) -> int {                           // work(g) on one host thread per device; the first failure, in device order
+        std::vector<std::thread> th;
+        auto run = [&](int g) {
+            P[g].rc = set_device(P[g].c) ? OEMGPU_ERR_HIP : work(g);
+            if (P[g].rc) P[g].err = oemgpu_last_error();                // the message lives in the worker's thread
+        };
+        for (int g = 1; g < G; ++g) th.emplace_back(run, g);
+        run(0);
+        for (auto &t : th) t.join();
+        for (int g = 0; g < G; ++g) if (P[g].rc) { set_error("device %d: %s", dev[g], P[g].err.c_str()); return P[g].rc; }
+        return 0;
+    };
+    // ---- phase 1: rows up, into fold order, per-fold moments
+    int rc = each([&](int g) -> int {
+        Part &q = P[g];
+        int r = xval_upload_rows(q.c, x, n, p, y, weights, foldid, q.r0, q.r1, o, &q.xd, &q.ld, &q.yd, &q.wd, &q.fd);
+        if (r) return r;
+        q.L = xval_layout(q.c, q.r1 - q.r0, p, K, npen, nl, weights != nullptr);
+        if (ctx_aux(q.c, q.L.total)) return OEMGPU_ERR_HIP;
+        return xval_prepare(q.c, q.L, q.xd, q.ld, q.yd, q.wd, q.fd, q.hf);
+    });
+    if (rc) { release_all(); return rc; }
+    // ---- the fold moments of devices 1 .. G-1 into device 0's, in device order (bitwise reproducible); fold sizes on the host
+    std::vector<int64_t> fold_tot(K, 0);
+    for (int g = 0; g < G; ++g) for (int k = 0; k < K; ++k) fold_tot[k] += P[g].hf[k];
+    Part &Z = P[0];
+    const size_t mlenK = Z.L.mlen * K, cslenK = Z.L.cslen * K;
+    double *peer = (double *)(Z.c->aux + Z.L.a_peer);
+    for (int g = 1; g < G && !rc; ++g) {
+        Part &q = P[g];
+        // the staging area is reused for every peer: the add of peer g-1 must have read it before peer g overwrites it
+        if (set_device(Z.c) || hipEventRecord(Z.c->xfer_ev, Z.c->stream) != hipSuccess || set_device(q.c) ||
+            hipStreamWaitEvent(q.c->stream, Z.c->xfer_ev, 0) != hipSuccess) { set_error("xval_dense: event ordering failed"); rc = OEMGPU_ERR_HIP; break; }
+        rc = host_hand_over(Z.c, peer, q.c, (const double *)(q.c->aux + q.L.a_mf), mlenK);
+        if (!rc && weights) rc = host_hand_over(Z.c, peer + mlenK, q.c, (const double *)(q.c->aux + q.L.a_cs), cslenK);
+        if (!rc) rc = set_device(Z.c) ? OEMGPU_ERR_HIP : host_add_into(Z.c, (double *)(Z.c->aux + Z.L.a_mf), peer, mlenK);
+        if (!rc && weights) rc = host_add_into(Z.c, (double *)(Z.c->aux + Z.L.a_cs), peer + mlenK, cslenK);
+    }
+    // ---- phase 2 on the first device: the K + 1 fits; the fold coefficients back to every device
+    if (!rc) rc = set_device(Z.c) ? OEMGPU_ERR_HIP : xval_solve(Z.c, Z.L, fold_tot.data(), n, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+    const size_t blenK = (size_t)K * npen * nl * (p + 1);
+    for (int g = 1; g < G && !rc; ++g)
+        rc = host_hand_over(P[g].c, (double *)(P[g].c->aux + P[g].L.a_b), Z.c, (const double *)(Z.c->aux + Z.L.a_b), blenK);
+    // ---- phase 3: the error triples of every device's rows, merged in device order
+    if (!rc) rc = each([&](int g) -> int {
+        P[g].tri.assign((size_t)3 * npen * nl, 0.0);
+        return xval_cverr(P[g].c, P[g].L, type_measure, o, nullptr, nullptr, P[g].tri.data());
+    });
+    if (!rc) {
+        std::vector<double> all;
+        for (int g = 0; g < G; ++g) all.insert(all.end(), P[g].tri.begin(), P[g].tri.end());
+        rc = oemgpu_xval_merge(all.data(), G, o, cvm, cvsd);
+    }
+    release_all();
+    return rc;
+}
+
 int oemgpu_xval_dense(const double *x, int64_t n, int32_t p, const double *y, const double *weights, const int32_t *foldid, int32_t nfolds,
                       int32_t standardize, int32_t intercept, int32_t type_measure, const oemgpu_opts *o,
                       double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, double *cvm, double *cvsd)
@@ -1176,24 +1285,22 @@ int oemgpu_xval_dense(const double *x, int64_t n, int32_t p, const double *y, co
     int rc = check_opts(o, p, p + (intercept ? 1 : 0));
     if (rc) return rc;
     if (n < 1) { set_error("xval_dense: bad n"); return OEMGPU_ERR_ARG; }
+    if (o->ngpus > 1) {
+        if (!beta || !lambda_out || !niter || !loss || !d || !cvm || !cvsd) { set_error("xval_dense: NULL argument"); return OEMGPU_ERR_ARG; }
+        std::vector<int> dev;
+        if ((rc = host_device_list(o, dev)) != 0) return rc;
+        rc = xval_check(nullptr, x, y, foldid, n, n, p, nfolds, intercept, type_measure, weights != nullptr, o);
+        if (rc) return rc;
+        if (n <= p) { set_error("dimension of x larger than number of observations"); return OEMGPU_ERR_UNSUPPORTED; }
+        return xval_dense_devices(dev, x, n, p, y, weights, foldid, nfolds, standardize, intercept, type_measure, o, beta, lambda_out,
+                                  niter, loss, d, cvm, cvsd);
+    }
     oemgpu_ctx *c = ctx_acquire(o->device);
     if (!c) return OEMGPU_ERR_NO_DEVICE;
-    double *xd = nullptr, *yd = nullptr;
+    double *xd = nullptr, *yd = nullptr, *wd = nullptr;
+    int32_t *fd = nullptr;
     int64_t ld = 0;
-    rc = host_upload_resident(c, x, n, p, y, o, &xd, &ld, &yd);      // staged through the pinned lanes, leaves room for foldid behind y
-    int32_t *fd = (int32_t *)(yd + ((n + 2 + 31) / 32 * 32));
-    double *wd = nullptr;
-    if (!rc) {
-        hipError_t e = hipMemcpyAsync(fd, foldid, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) { set_error("upload of foldid failed: %s", hipGetErrorString(e)); rc = OEMGPU_ERR_HIP; }
-    }
-    if (!rc && weights) {                                            // n doubles in the accumulator buffer of the host path (grow-only)
-        rc = ctx_grow(c, &c->acc, &c->acc_bytes, sizeof(double) * (size_t)(n + 2));
-        wd = (double *)c->acc;
-        if (!rc && hipMemcpyAsync(wd, weights, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
-            set_error("upload of the weights failed"); rc = OEMGPU_ERR_HIP;
-        }
-    }
+    rc = xval_upload_rows(c, x, n, p, y, weights, foldid, 0, n, o, &xd, &ld, &yd, &wd, &fd);
     if (!rc) rc = oemgpu_xval_dense_dev(c, xd, n, ld, p, yd, wd, fd, nfolds, standardize, intercept, type_measure, o, beta, lambda_out,
                                         niter, loss, d, cvm, cvsd);
     (void)hipStreamSynchronize(c->stream);

@@ -559,15 +559,24 @@ int host_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_t 
     return host_fit(all, n, p, OEMGPU_SEM_BIG, standardize, intercept, o, beta, lambda_out, niter, loss, d);
 }
 
+int host_device_list(const oemgpu_opts *o, std::vector<int> &dev) { return device_list(o, dev); }
+int host_hand_over(oemgpu_ctx *to, double *dst, oemgpu_ctx *from, const double *src, size_t doubles) { return hand_over(to, dst, from, src, doubles); }
+int host_add_into(oemgpu_ctx *c, double *dst, const double *src, size_t doubles)
+{
+    hipLaunchKernelGGL(add_into_kernel, dim3(64), dim3(256), 0, c->stream, dst, src, doubles);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
 int host_upload_resident(oemgpu_ctx *c, const double *x, int64_t n, int32_t p, const double *y, const oemgpu_opts *o,
-                         double **x_dev, int64_t *ld, double **y_dev)
+                         double **x_dev, int64_t *ld, double **y_dev, int64_t ldx)
 {
     DevJob J;
     J.c = c; J.p = p; J.o = o; J.contiguous = true;
     J.T = (o && o->upload_threads > 0) ? o->upload_threads : (int)env_size("OEMGPU_UPLOAD_THREADS", 8);
     if (J.T > 64) J.T = 64;
     J.slot_bytes = env_size("OEMGPU_SLOT_BYTES", (size_t)4 << 20) / 4096 * 4096 + 4096;
-    HostPiece P; P.x = x; P.ldx = n; P.y = y; P.rows = n;
+    HostPiece P; P.x = x; P.ldx = ldx > 0 ? ldx : n; P.y = y; P.rows = n;
     J.pieces.push_back(P);
     int rc = lanes_prepare(c, J.T, J.slot_bytes);
     if (!rc) rc = job_layout(J, (size_t)-1);

@@ -189,3 +189,34 @@ def test_caller_interrupt(oa, monkeypatch):
     calls.clear()
     f = oa.oem(x, y, penalty=["lasso"], nlambda=5, interrupt=lambda: False)
     _cmp(f, orc.fit_dense(x, y, penalty=["lasso"], nlambda=5))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,pens,weighted,tm", [(30, ["lasso", "mcp"], False, "mse"), (41, ["grp.lasso", "elastic.net"], True, "mae"),
+                                                (300, ["lasso"], False, "mse")])
+def test_xval_rows_over_several_devices(oa, p, pens, weighted, tm):
+    """oemgpu_xval_dense with opts.ngpus > 1: the rows split over the devices (here the same device several times, with its own
+    context each), fold moments handed to the first and added in device order, the K + 1 fits there, the fold coefficients back,
+    the error triples merged on the host -- the same numbers as the one-device call."""
+    rng = np.random.default_rng(50 + p)
+    n = 6 * p + 1007
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 1.3 + 0.4)
+    y = x[:, :3] @ np.array([1.0, -1.5, 0.5]) + rng.normal(size=n) + 0.2
+    K = 7
+    foldid = rng.permutation(np.resize(np.arange(1, K + 1), n))
+    kw = dict(penalty=pens, nlambda=6, tol=1e-9, maxit=3000, type_measure=tm, foldid=foldid)
+    if "grp.lasso" in pens:
+        kw["groups"] = np.arange(p) // 4 + 1
+    if weighted:
+        kw["weights"] = rng.uniform(0.5, 2.0, size=n)
+    one = oa.xval_oem(x, y, **kw)
+    for devices in ([0, 0], [0, 0, 0]):
+        many = oa.xval_oem(x, y, devices=devices, **kw)
+        assert abs(many["d"] - one["d"]) < 1e-11 * one["d"]
+        for k in range(len(pens)):
+            scale = max(1.0, float(np.abs(one["beta"][k]).max()))
+            assert np.abs(many["beta"][k] - one["beta"][k]).max() < 1e-9 * scale, (devices, pens[k])
+            assert np.allclose(many["lambda"][k], one["lambda"][k], rtol=1e-12)
+            assert np.allclose(many["cvm"][k], one["cvm"][k], rtol=1e-10) and np.allclose(many["cvsd"][k], one["cvsd"][k], rtol=1e-8), (devices, pens[k])
+    with pytest.raises(Exception):
+        oa.xval_oem(x, y, devices=[0, 99], **kw)
