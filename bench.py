@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--no-c5", action="store_true", help="c1 run: skip the appended c5 weak-scaling measurement")
     ap.add_argument("--c5-rows", type=int, default=12_500_000, help="rows per rank of the c5 workload")
     ap.add_argument("--no-host", action="store_true", help="skip the host-resident (drop-in .Call level) measurement")
+    ap.add_argument("--no-two-callers", action="store_true", help="skip the two-concurrent-callers extra (profiling runs: kernels of two "
+                                                                   "callers overlap and their durations no longer describe one solve)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU baseline sample (0 = the full workload)")
     a = ap.parse_args()
@@ -259,7 +261,7 @@ def main():
     # CU for 0.33 ms, so the moment pass of the other caller's solve runs beside it.  Reported as an extra, never as `value`: a
     # solve is still 0.57 ms long, this is what the chip delivers when the solves are independent.
     two_callers = None
-    if world == 1:
+    if world == 1 and not a.no_two_callers:
         import threading
         backs = [HipBackend(local), HipBackend(local)]
         sets = []
