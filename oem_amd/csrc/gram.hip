@@ -1392,6 +1392,51 @@ int launch_gram(hipStream_t s, const GramPlan &pl, const double *x, int64_t n, i
 // A tile's chunk partials are summed by four thread groups (chunks c = g mod 4, each in ascending order, eight loads in
 // flight) and combined as (g0 + g1) + (g2 + g3): a fixed order, so the result is reproducible; with one group the
 // kernel was a 15 us latency chain of 253 dependent steps on 28 workgroups.
+// The same sum for few tiles (p + 2 <= 112: at most 28): SPL workgroups per tile, each EB = 256 / SPL elements of the tile over
+// NG = 4 SPL groups of chunks -- 28 workgroups of the form below keep 28 of 256 CUs busy (config 1: 11 us for 14.5 MB).
+template <int SPL>
+__global__ __launch_bounds__(1024) void moments_reduce_split_kernel(const double *__restrict__ tpart, int p, int ntile, int nchunk,
+                                                                     double *__restrict__ M)
+{
+    constexpr int EB = 256 / SPL, NG = 4 * SPL;
+    __shared__ double part[NG][EB];
+    const int q = p + 2;
+    const int tile = blockIdx.x / SPL, e = threadIdx.x % EB, grp = threadIdx.x / EB, el = (blockIdx.x % SPL) * EB + e;
+    int I = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+    while (I * (I + 1) / 2 > tile) --I;
+    while ((I + 1) * (I + 2) / 2 <= tile) ++I;
+    const int J = tile - I * (I + 1) / 2;
+    double s = 0.0;
+    const double *src = tpart + (size_t)tile * 256 + el;
+    const size_t stride = (size_t)ntile * 256;
+    int c = grp;
+    for (; c + 7 * NG < nchunk; c += 8 * NG) {                // 8 independent loads in flight, summed in chunk order
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = src[(size_t)(c + NG * k) * stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += t[k];
+    }
+    for (; c < nchunk; c += NG) s += src[(size_t)c * stride];
+    part[grp][e] = s;
+    __syncthreads();
+    if (grp == 0) {
+        double t[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) t[g] = part[g][e];
+#pragma unroll
+        for (int h = 1; h < NG; h <<= 1)                       // fixed pairwise tree
+#pragma unroll
+            for (int g = 0; g + h < NG; g += 2 * h) t[g] += t[g + h];
+        const int reg = el >> 6, lane = el & 63;
+        const int row = 16 * I + (lane >> 4) + 4 * reg, col = 16 * J + (lane & 15);
+        if (row < q && col < q && row >= col) {
+            M[(size_t)col * q + row] = t[0];
+            M[(size_t)row * q + col] = t[0];
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void moments_reduce_kernel(const double *__restrict__ tpart,
                                                                const double *__restrict__ vpart, int p, int ntc,
                                                                int ntile, int nchunk, int nchunk_v, int aug, double *__restrict__ M)
@@ -1465,6 +1510,11 @@ __global__ __launch_bounds__(1024) void moments_reduce_kernel(const double *__re
 int launch_moments_reduce(hipStream_t s, const GramPlan &pl, const double *tpart, const double *vpart, double *moments)
 {
     const int nvblk = pl.tri ? 0 : (32 * pl.ntc + 4 + 255) / 256;
+    if (pl.tri && pl.nchunk >= 64 && !getenv("OEM_NO_REDUCE_SPLIT")) {        // all tiles cover Z: no vector partials
+        hipLaunchKernelGGL(moments_reduce_split_kernel<4>, dim3(pl.ntile * 4), dim3(1024), 0, s, tpart, pl.p, pl.ntile, pl.nchunk, moments);
+        OEM_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(moments_reduce_kernel, dim3(pl.ntile + nvblk), dim3(1024), 0, s, tpart, vpart, pl.p,
                        pl.ntc, pl.ntile, pl.nchunk, pl.nchunk, pl.tri, moments);
     OEM_HIP(hipGetLastError());
