@@ -312,6 +312,9 @@ def main():
             acc += np.array(list(ms))
     L.check(lib.oemgpu_set_timing(backend.ctx, 0))
     acc /= reps
+    _st, _cp = C.c_int32(-1), C.c_int32(-1)
+    L.lib().oemgpu_last_eigen_info(backend.ctx, C.byref(_st), C.byref(_cp))
+    eig_info = {"lanczos_steps": int(_st.value), "step_cap_reached": bool(_cp.value)}
     gram_ms = acc[L.T_GRAMK]
     flops = float(n_loc) * p * (p + 1) + 2.0 * n_loc * p            # lower-triangular syrk + X'y
     bytes_alg = 8.0 * n_loc * p + 8.0 * n_loc
@@ -353,6 +356,7 @@ def main():
             "path_kernel_cycles": acc[6],
             "path_kernel_cycles_per_oem_iteration": acc[6] / niter_total if niter_total > 0 else None,
             "path_kernel_note": "eigenvalue (Lanczos) + 100-lambda path in ONE launch; cycles include the eigen step's fixed cost",
+            "eigen_step": eig_info,
             "vs_baseline_note": "reference README: 1.600 s per solve on unstated CPU hardware",
             "throughput_two_callers": two_callers,
         }

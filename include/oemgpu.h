@@ -228,6 +228,12 @@ int oemgpu_xval_cv_triples_dev(oemgpu_ctx *ctx, int64_t n_local, int32_t p, int3
                                const oemgpu_opts *o, double *triples);
 int oemgpu_xval_merge(const double *triples, int32_t nsets, const oemgpu_opts *o, double *cvm, double *cvsd);
 
+/* The eigenvalue step of the most recent solve (or oemgpu_eig_max_dev) on this context: *steps = Lanczos steps taken, *capped = 1
+ * if the recurrence ran into its step cap (min(2 q, 288) for q <= 288, 256 / 512 on the larger engines) instead of stopping by its
+ * rule or by breakdown -- d = 1.005 x the last Ritz value is then a lower estimate (the reference's Spectra call, tol 1e-10 and up
+ * to 10000 restarts, ref src/oem_dense.h:485-498, has no such cap; OEM converges for any d > lambda_max / 2).  -1 for a NULL context. */
+int oemgpu_last_eigen_info(oemgpu_ctx *ctx, int32_t *steps, int32_t *capped);
+
 /* 1 if the most recent oemgpu_solve_moments_dev on this context found the shift predicate above true for its
  * sums_dev (and so read moments_dev as accumulated about c), 0 if not, -1 for a NULL context. */
 int oemgpu_last_shift_in_effect(oemgpu_ctx *ctx);

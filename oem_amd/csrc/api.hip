@@ -249,7 +249,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
 
     // ---- outputs region (device) : beta | lambda | loss | d[2] | niter | stats copy
     const size_t nb = (size_t)npen * nl * q, nk = (size_t)npen * nl;
-    const size_t out_doubles = nb + 2 * nk + 4 + (size_t)stats_len(p);
+    const size_t out_doubles = nb + 2 * nk + D_OUT_LEN + (size_t)stats_len(p);
     const size_t out_bytes = out_doubles * sizeof(double) + nk * sizeof(int32_t);
     const size_t out_stride = (out_bytes + 255) / 256 * 256;
     const bool loss_on = (sem == OEMGPU_SEM_DENSE || sem == OEMGPU_SEM_XVAL || sem == SEM_SPARSE) && o->compute_loss != 0;
@@ -263,6 +263,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     // (more steps than rows: without re-orthogonalisation a clustered spectrum does not exhaust the Krylov space in q steps -- a 9 x 9
     // standardised sparse Gram was 1.1e-7 short after 9 -- but the top Ritz value keeps converging; the stagnation test ends it)
     int lan = 2 * q < 32 ? 32 : (2 * q < 288 ? 2 * q : 288);
+    if (const char *e = getenv("OEMGPU_LANCZOS_CAP")) { const int k = atoi(e); if (k >= 2 && k < lan) lan = k; }     // test knob: reach the cap
     size_t work_d = small ? path_small_xchg_bytes() / 8 : path_large_work_doubles(q, lan);
     if (coop && work_d < path_coop_xchg_bytes() / 8) work_d = path_coop_xchg_bytes() / 8;
     // the outputs come first: when the caller's frame ends with `stats` (both callers), stats | outputs is one
@@ -312,7 +313,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     a.gid = (const int *)(dblob + o_gid); a.gstart = (const int *)(dblob + o_gst); a.gidx = (const int *)(dblob + o_gix);
     a.gzero = (const int *)(dblob + o_gz); a.gw = (const double *)(dblob + o_gw);
     a.beta = dout; a.lambda_out = dout + nb; a.loss = a.lambda_out + nk; a.d_out = a.loss + nk;
-    double *dstats = a.d_out + 4;
+    double *dstats = a.d_out + D_OUT_LEN;
     a.niter = (int *)(dstats + stats_len(p));
     a.work = (double *)(c->ws + a_work);
     a.lmax_xy = (nbatch > 1 && shared_lmax) ? xy : nullptr;        // instance 0's X'Y
@@ -341,13 +342,14 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const int rows = (sem == SEM_XTX) ? p : p + 1;
     for (int bi = 0; bi < nbatch; ++bi) {
         const double *hb = (const double *)((const char *)c->pinned + (joined ? st_gap : 0) + (size_t)bi * out_stride), *hl = hb + nb,
-                     *hloss = hl + nk, *hd = hloss + nk, *hs = joined ? (const double *)c->pinned : hd + 4;
-        const int32_t *hn = (const int32_t *)(hd + 4 + stats_len(p));
+                     *hloss = hl + nk, *hd = hloss + nk, *hs = joined ? (const double *)c->pinned : hd + D_OUT_LEN;
+        const int32_t *hn = (const int32_t *)(hd + D_OUT_LEN + stats_len(p));
         double *beta_b = beta + (size_t)bi * nk * rows, *lambda_b = lambda_out + (size_t)bi * nk, *loss_b = loss + (size_t)bi * nk;
         int32_t *niter_b = niter + (size_t)bi * nk;
         d_out[bi] = hd[0];
         if (hd[1] < 0.0) { set_error("cooperating workgroups lost each other (exchange timeout)"); return OEMGPU_ERR_INTERNAL; }
         c->diag[0] = hd[2]; c->diag[1] = hd[3];
+        if (bi == 0) { c->eig_steps = (int)hd[4]; c->eig_capped = hd[5] != 0.0; }
         c->shifted = hs[stats_shift_flag(p)] != 0.0;
         c->shift_advised = hs[stats_shift_flag(p) + 1] != 0.0;
         const double meany = hs[0], scaley = hs[1];
@@ -695,10 +697,19 @@ int oemgpu_eig_max_dev(oemgpu_ctx *c, const double *a_dev, int32_t p, double *la
     if (coop) slots.take(path_coop_workgroups(p), c->num_cu * 3 / 4);
     int rc = p <= SMALL_P_MAX ? launch_path_small(c->stream, a) : (coop ? launch_path_coop(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned));
     if (rc) return rc;
-    double h[2];
+    double h[D_OUT_LEN];
     OEM_HIP(hipMemcpyAsync(h, a.d_out, sizeof h, hipMemcpyDeviceToHost, c->stream));
     OEM_HIP(hipStreamSynchronize(c->stream));
     *lambda_max = h[1];
+    c->eig_steps = (int)h[4]; c->eig_capped = h[5] != 0.0;
+    return 0;
+}
+
+int oemgpu_last_eigen_info(oemgpu_ctx *c, int32_t *steps, int32_t *capped)
+{
+    if (!c) return -1;
+    if (steps) *steps = c->eig_steps;
+    if (capped) *capped = c->eig_capped ? 1 : 0;
     return 0;
 }
 

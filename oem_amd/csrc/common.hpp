@@ -101,7 +101,8 @@ struct PathArgs {
     double *lambda_out;      // npen * nl (unscaled lambda actually used)
     int *niter;              // npen * nl
     double *loss;            // npen * nl
-    double *d_out;           // [0] = d, [1] = lambda_max
+    double *d_out;           // D_OUT_LEN doubles: [0] = d, [1] = lambda_max, [2] shader cycles, [3] 100 MHz ticks of the fused kernel,
+                             // [4] Lanczos steps taken, [5] 1 if the step cap ended the recurrence (neither stop rule nor breakdown)
     // workspace for the large-p engine
     double *work;
     // nbatch > 1 (p <= SMALL_P_MAX only): blockIdx.y selects one of nbatch independent problems that share everything above
@@ -133,6 +134,7 @@ __device__ __forceinline__ PathArgs path_instance(PathArgs A)
     return A;
 }
 
+static const int D_OUT_LEN = 6;
 static const int COOP_MIN_Q = 209, COOP_MIN_Q_GROUPS = 209;      // from here the cooperating-workgroup engine (path_coop.hip) takes the path when it is eligible (element-wise penalties only / a group penalty in the call)
 int path_coop_min_q(bool has_groups);
 static const int SMALL_P_MAX = 288;     // one workgroup where the matrix fits its registers (+ LDS); else four cooperating workgroups (big.oem's p + 1 = 257 included)

@@ -33,6 +33,8 @@ struct oemgpu_ctx {
     bool ev_used[OEMGPU_NTIMERS];
     double ms[OEMGPU_NTIMERS];
     double diag[2] = {0.0, 0.0};   // path kernel: shader cycles, 100 MHz ticks
+    int eig_steps = 0;             // the last eigenvalue step: Lanczos steps taken ...
+    bool eig_capped = false;       // ... and whether the step cap ended it (oemgpu_last_eigen_info)
     int shifted = 0;               // the last solve read its moments as accumulated about the provisional shift
     int shift_advised = 0;         // the last solve was given moments about 0 whose columns have |mean| >> sd
     char *aux = nullptr;           // xval.oem: fold-ordered copy of X, fold moments, fold coefficients (grow-only)

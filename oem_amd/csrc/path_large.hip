@@ -299,7 +299,8 @@ double tridiag_max_host(const double *al, const double *be, int m)
 }
 
 // ------------------------------------------------------------------------------------------------ path
-__global__ __launch_bounds__(1024) void path_init_kernel(PathArgs A, LState *st, double *__restrict__ beta, double d, double theta)
+__global__ __launch_bounds__(1024) void path_init_kernel(PathArgs A, LState *st, double *__restrict__ beta, double d, double theta,
+                                                          int lz_steps, int lz_capped)
 {
     __shared__ double sh[16];
     double m = 0.0;
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(1024) void path_init_kernel(PathArgs A, LState *st,
         st->pending_loss = -1; st->reset_next = 1; st->finish_after_loss = 0; st->pad = 0;
         st->ak = 1.0; st->d = d; st->theta = theta;
         st->lmax = mm * (A.yscale ? A.stats[1] : 1.0);
-        A.d_out[0] = d; A.d_out[1] = theta; A.d_out[2] = 0.0; A.d_out[3] = 0.0;
+        A.d_out[0] = d; A.d_out[1] = theta; A.d_out[2] = 0.0; A.d_out[3] = 0.0; A.d_out[4] = (double)lz_steps; A.d_out[5] = (double)lz_capped;
         sh[0] = st->lmax;
     }
     __syncthreads();
@@ -829,6 +830,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     //      16 steps on the host, which is also the convergence test
     const int mmax = q < MAXL ? q : MAXL;
     double theta = 0.0, theta_prev = -1.0;
+    bool lz_capped = true;                              // cleared by whichever rule ends the recurrence
     double *hT = host_scratch;
     int m = 0;
     // fused steps (one launch each) ping-pong between two copies of (v, v_prev, w) kept in their own area
@@ -870,21 +872,22 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         for (int k = 0; k < m; ++k)
             if (!(hT[MAXL + k] > 1e-13 * std::fabs(hT[k]))) { mm = k + 1; break; }     // breakdown: T is exact
         theta = tridiag_max_host(hT, hT + MAXL, mm);
-        if (mm < m) break;
+        if (mm < m) { lz_capped = false; break; }
         // the stop rule of the register-resident engines (path_dev.hpp: lanczos_converged) on the top Ritz values of the leading
         // blocks T_{m-16}, T_{m-8}, T_m, which the host has for free: moved by <= 1e-14 relative over the last 8 steps, or two
         // successive moves that decay so fast that their geometric tail is <= 1e-12 relative
         if (m >= 24) {
             const double t1 = tridiag_max_host(hT, hT + MAXL, m - 8), t0 = tridiag_max_host(hT, hT + MAXL, m - 16);
             const double mv = theta - t1, mvp = t1 - t0, ath = std::fabs(theta);
-            if (mv <= 1e-14 * ath || (mv < 0.01 * mvp && mv * mv <= 1e-12 * ath * (mvp - mv))) break;
+            if (mv <= 1e-14 * ath || (mv < 0.01 * mvp && mv * mv <= 1e-12 * ath * (mvp - mv))) { lz_capped = false; break; }
         }
-        if (theta_prev > 0 && std::fabs(theta - theta_prev) <= 1e-12 * std::fabs(theta)) break;
+        if (theta_prev > 0 && std::fabs(theta - theta_prev) <= 1e-12 * std::fabs(theta)) { lz_capped = false; break; }
         theta_prev = theta;
     }
+    if (mmax >= q) lz_capped = false;                   // the whole Krylov space
     const double d = theta * 1.005;                     // ref src/oem_dense.h:498
 
-    hipLaunchKernelGGL(path_init_kernel, dim3(1), dim3(1024), 0, s, a, st, beta, d, theta);
+    hipLaunchKernelGGL(path_init_kernel, dim3(1), dim3(1024), 0, s, a, st, beta, d, theta, m, lz_capped ? 1 : 0);
     OEM_HIP(hipGetLastError());
     if (a.npen == 0) return 0;
 

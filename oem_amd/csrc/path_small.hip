@@ -597,7 +597,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
         return th;
     };
     double theta = 0.0, theta_prev = -__builtin_inf(), mv_prev = __builtin_inf();
-    bool have_theta = false;
+    bool have_theta = false, lz_ended = false;
     for (int j = 0; j < msteps; ++j) {
         gemv_round<R, NW, CW, G>(a, v, wv, P, Uw, w, lane, buf, X OEM_DIAG_PASS);
         double al = 0.0;
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
         bb = sqrt(wave_sum(bb));
         if (lane == 0) { Tal[j] = al; Tbe[j] = bb; }
         nst = j + 1;
-        if (!(bb > 1e-13 * fabs(al))) break;            // invariant subspace reached: T is exact
+        if (!(bb > 1e-13 * fabs(al))) { lz_ended = true; break; }            // invariant subspace reached: T is exact
         if (lanczos_check_due(nst) && nst < msteps) {
             OEM_STAMP(10);
             const double th = top_ritz(nst, theta_prev);
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
     diag_acc[11] = (unsigned long long)nst;
 #endif
     const double d = theta * 1.005;                       // ref src/oem_dense.h:498
-    if (tid == 0 && writer) { A.d_out[0] = d; A.d_out[1] = theta; }
+    if (tid == 0 && writer) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && !lz_ended && nst < p) ? 1.0 : 0.0; }
 
     // ---- A = d I - XX   (ref src/oem_dense.h:501-505)
 #pragma unroll
@@ -1216,7 +1216,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
     double Bv[NBC], Bvp[NBC], Bw[NBC];
     int nst = 0;
     double theta = 0.0, theta_prev = -__builtin_inf(), mv_prev = __builtin_inf();
-    bool have_theta = false;
+    bool have_theta = false, lz_ended = false;
     auto colmask = [&](int j) { return ecol[j] < 32 * NW ? 1.0 : 0.0; };   // dummy words carry replicas' values: not part of the vector
     {
         const unsigned h = (unsigned)row * 2654435761u + 12345u;     // deterministic non-structured start
@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
         OEM_STAMP(17);
         *(tid == 0 ? &Tbe[j] : tsink) = bb;
         nst = j + 1;
-        if (__builtin_expect(__any(!(bb > 1e-13 * fabs(al))), 0)) break;   // invariant subspace reached: T is exact
+        if (__builtin_expect(__any(!(bb > 1e-13 * fabs(al))), 0)) { lz_ended = true; break; }   // invariant subspace reached: T is exact
         if (__builtin_expect(lanczos_check_due(nst) && nst < msteps, 0)) {
             OEM_STAMP(6);
             const double th = top_ritz(nst, theta_prev);
@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
     }
     if (!have_theta) theta = top_ritz(nst, theta_prev);
     const double d = theta * 1.005;                                  // ref src/oem_dense.h:498
-    if (tid == 0) { A.d_out[0] = d; A.d_out[1] = theta; }
+    if (tid == 0) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && !lz_ended && nst < p) ? 1.0 : 0.0; }
 #ifdef OEM_PATH_DIAG
     OEM_STAMP(7);                                                    // the final top_ritz (slot 7: all top_ritz calls)
     unsigned long long lz[5];

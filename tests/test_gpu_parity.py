@@ -588,3 +588,31 @@ def test_eigen_step_with_the_top_eigenvector_hidden_from_the_start_vector(oa, p)
             nz = bb != 0
             dp = lam[i] if pen == "lasso" else np.maximum(lam[i] - np.abs(bb[nz]) / 3.0, 0.0)
             assert np.abs(g[nz] + dp * np.sign(bb[nz])).max() < 1e-8 and (np.abs(g[~nz]) <= lam[i] * (1 + 1e-9)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [40, 100, 230, 400])
+def test_eigen_step_reports_its_steps_and_a_reached_cap(oa, p, monkeypatch):
+    """the Lanczos recurrence has a step cap the reference's restarted Spectra call has not.  oemgpu_last_eigen_info says
+    how many steps were taken and whether the cap (not the stop rule, not breakdown) ended them; a fit whose cap was reached still
+    ends at the optimum (OEM is a proximal-gradient iteration that converges for every d > lambda_max / 2)."""
+    import ctypes as C
+    import torch
+    from oem_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(p)
+    n = 5 * p
+    x = np.asfortranarray(rng.normal(size=(n, p)))
+    y = x[:, :4] @ np.array([1.0, -1.0, 0.5, 2.0]) + rng.normal(size=n)
+    xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+    steps, capped = C.c_int32(-1), C.c_int32(-1)
+    kw = dict(penalty="lasso", nlambda=6, tol=1e-11, maxit=5000)
+    fit = oa.oem(xd, y, **kw)
+    assert lib.oemgpu_last_eigen_info(oa.context(), C.byref(steps), C.byref(capped)) == 0
+    assert 8 <= steps.value <= max(2 * p, 32) and capped.value == 0, (steps.value, capped.value)
+    monkeypatch.setenv("OEMGPU_LANCZOS_CAP", "8")
+    short = oa.oem(xd, y, **kw)
+    assert lib.oemgpu_last_eigen_info(oa.context(), C.byref(steps), C.byref(capped)) == 0
+    if p <= 1024 and steps.value <= 8:                      # (the host-checked engines look every 16 steps: their cap is theirs)
+        assert capped.value == 1 and short["d"] <= fit["d"] * (1 + 1e-12)
+    assert np.abs(short["beta"][0] - fit["beta"][0]).max() < 1e-7
