@@ -258,8 +258,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     # Two callers at once (two host threads, two contexts / streams, the same resident X): the path kernel of one solve occupies ONE
-    # CU for 0.33 ms, so the moment pass of the other caller's solve runs beside it.  Reported as an extra, never as `value`: a
-    # solve is still 0.57 ms long, this is what the chip delivers when the solves are independent.
+    # CU for 0.30 ms, so the moment pass of the other caller's solve runs beside it.  Reported as an extra, never as `value`: a
+    # solve is still 0.52 ms long, this is what the chip delivers when the solves are independent.
     two_callers = None
     if world == 1 and not a.no_two_callers:
         import threading
