@@ -376,7 +376,7 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
     };
     int nst = 0;
     double bprev = 0.0, theta = 0.0, theta_prev = -__builtin_inf(), mv_prev = __builtin_inf();
-    bool have_theta = false, lz_ended = false;
+    bool have_theta = false;
     for (int j = 0; j < msteps; ++j) {
 #pragma unroll
         for (int k = 0; k < EPT; ++k) if (valid[k]) Bsh[tid + NTH * k] = v[k];
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
         sqrt_rsqrt(coop_block_sum(bb, red, rpar, w, lane), bb, ib);
         if (tid == 0) { Tal[j] = al; Tbe[j] = bb; }
         nst = j + 1;
-        if (!(bb > 1e-13 * fabs(al))) { lz_ended = true; break; }                        // invariant subspace reached: T is exact
+        if (!(bb > 1e-13 * fabs(al))) break;                        // invariant subspace reached: T is exact
         if (lanczos_check_due(nst) && nst < msteps) {
             const double th = top_ritz(nst, theta_prev);            // its first barrier publishes Tal / Tbe
             if (lanczos_converged(th, theta_prev, mv_prev)) { theta = th; have_theta = true; break; }
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
     }
     if (!have_theta) { __syncthreads(); theta = top_ritz(nst, theta_prev); }
     const double d = theta * 1.005;                                  // ref src/oem_dense.h:498
-    if (tid == 0 && writer) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && !lz_ended && nst < q) ? 1.0 : 0.0; }
+    if (tid == 0 && writer) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && nst >= msteps && nst < q) ? 1.0 : 0.0; }
 #ifdef OEM_PATH_DIAG
     COOP_STAMP(0);
     if (tid == 0 && writer) { for (int k = 0; k < 6; ++k) { g_diag_coop[k] = X.acc[k]; } g_diag_coop[6] = X.acc[8]; g_diag_coop[7] = (unsigned long long)nst; }

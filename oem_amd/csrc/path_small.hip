@@ -597,7 +597,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
         return th;
     };
     double theta = 0.0, theta_prev = -__builtin_inf(), mv_prev = __builtin_inf();
-    bool have_theta = false, lz_ended = false;
+    bool have_theta = false;
     for (int j = 0; j < msteps; ++j) {
         gemv_round<R, NW, CW, G>(a, v, wv, P, Uw, w, lane, buf, X OEM_DIAG_PASS);
         double al = 0.0;
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
         bb = sqrt(wave_sum(bb));
         if (lane == 0) { Tal[j] = al; Tbe[j] = bb; }
         nst = j + 1;
-        if (!(bb > 1e-13 * fabs(al))) { lz_ended = true; break; }            // invariant subspace reached: T is exact
+        if (!(bb > 1e-13 * fabs(al))) break;            // invariant subspace reached: T is exact
         if (lanczos_check_due(nst) && nst < msteps) {
             OEM_STAMP(10);
             const double th = top_ritz(nst, theta_prev);
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
     diag_acc[11] = (unsigned long long)nst;
 #endif
     const double d = theta * 1.005;                       // ref src/oem_dense.h:498
-    if (tid == 0 && writer) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && !lz_ended && nst < p) ? 1.0 : 0.0; }
+    if (tid == 0 && writer) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && nst >= msteps && nst < p) ? 1.0 : 0.0; }
 
     // ---- A = d I - XX   (ref src/oem_dense.h:501-505)
 #pragma unroll
@@ -1170,26 +1170,11 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
     bool any_unused;
     double aux_unused = 0.0;
     OEM_DIAG_DECL
-    RowGrp G;
-    G.gi = -1; G.cnt = 0; G.start = 0; G.gmax = 0; G.gz = false; G.gw = 0.0;
-    G.GX = reinterpret_cast<const int *>(lds + C::OFF_GX);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) G.gm[k] = C::VS - 1;                 // a word that stays zero
-    if (A.ngroups > 0) {
+    if (A.ngroups > 0) {                                             // group member lists into LDS (group operators only)
         int *gx = reinterpret_cast<int *>(lds + C::OFF_GX);
         const int nm = A.gstart[A.ngroups];
         for (int m = tid; m < nm && m < 32 * NW + 8; m += NW * 64) gx[m] = A.gidx[m];
         __syncthreads();
-        if (rowok) {
-            G.gi = A.gid[row];
-            if (G.gi >= 0) {
-                G.start = A.gstart[G.gi]; G.cnt = A.gstart[G.gi + 1] - G.start;
-                G.gz = A.gzero[G.gi] != 0; G.gw = A.gw[G.gi];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) G.gm[k] = k < G.cnt ? gx[G.start + k] : C::VS - 1;
-            }
-        }
-        G.gmax = (int)wave_max((double)G.cnt);
     }
 
     // ---- eigenvalue step: Lanczos with the vector spread over the waves (one entry per owner lane)
@@ -1216,7 +1201,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
     double Bv[NBC], Bvp[NBC], Bw[NBC];
     int nst = 0;
     double theta = 0.0, theta_prev = -__builtin_inf(), mv_prev = __builtin_inf();
-    bool have_theta = false, lz_ended = false;
+    bool have_theta = false;
     auto colmask = [&](int j) { return ecol[j] < 32 * NW ? 1.0 : 0.0; };   // dummy words carry replicas' values: not part of the vector
     {
         const unsigned h = (unsigned)row * 2654435761u + 12345u;     // deterministic non-structured start
@@ -1263,7 +1248,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
         OEM_STAMP(17);
         *(tid == 0 ? &Tbe[j] : tsink) = bb;
         nst = j + 1;
-        if (__builtin_expect(__any(!(bb > 1e-13 * fabs(al))), 0)) { lz_ended = true; break; }   // invariant subspace reached: T is exact
+        if (__builtin_expect(__any(!(bb > 1e-13 * fabs(al))), 0)) break;   // invariant subspace reached: T is exact
         if (__builtin_expect(lanczos_check_due(nst) && nst < msteps, 0)) {
             OEM_STAMP(6);
             const double th = top_ritz(nst, theta_prev);
@@ -1277,7 +1262,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
     }
     if (!have_theta) theta = top_ritz(nst, theta_prev);
     const double d = theta * 1.005;                                  // ref src/oem_dense.h:498
-    if (tid == 0) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && !lz_ended && nst < p) ? 1.0 : 0.0; }
+    if (tid == 0) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && nst >= msteps && nst < p) ? 1.0 : 0.0; }
 #ifdef OEM_PATH_DIAG
     OEM_STAMP(7);                                                    // the final top_ritz (slot 7: all top_ritz calls)
     unsigned long long lz[5];
@@ -1334,6 +1319,27 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
         const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
         const bool isnet = pen_is_net(pen);
         double beta = 0.0, ab = 0.0, ak = 1.0;                       // cold start: A 0 = 0
+        // this lane's group, looked up here and not in the kernel's prologue: the eight-wave forms have no registers to keep it
+        // alive through the loops of the element-wise operators
+        RowGrp G;
+        G.gi = -1; G.cnt = 0; G.start = 0; G.gmax = 0; G.gz = false; G.gw = 0.0;
+        G.GX = reinterpret_cast<const int *>(lds + C::OFF_GX);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) G.gm[k] = C::VS - 1;             // a word that stays zero
+        if constexpr (KIND == K_GRP) {
+            if (A.ngroups > 0) {
+                if (rowok) {
+                    G.gi = A.gid[row];
+                    if (G.gi >= 0) {
+                        G.start = A.gstart[G.gi]; G.cnt = A.gstart[G.gi + 1] - G.start;
+                        G.gz = A.gzero[G.gi] != 0; G.gw = A.gw[G.gi];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) G.gm[k] = k < G.cnt ? G.GX[G.start + k] : C::VS - 1;
+                    }
+                }
+                G.gmax = (int)wave_max((double)G.cnt);
+            }
+        }
         // Per-lambda constants.  An FP64 division is a ~300-cycle dependent chain and a taken scalar branch ~80 cycles,
         // so: lambda / scale(y) goes through the corrected reciprocal; the reciprocals of the operator's denominators
         // are recomputed per lambda only if the penalty has a ridge part (otherwise the denominator is d); and the
