@@ -345,6 +345,22 @@ __device__ __forceinline__ double threshold1(double u, double tp, const ThrK &c)
     return cdiv(u, c.d, c.rd);                                                // K_OLS
 }
 
+// The operator's constants are the same in every lane: through v_readfirstlane they live in SGPRs, not in eleven VGPR pairs of
+// a kernel whose eight-wave forms have none to spare (config 2's SCAD loop spilled into every round -- 21.7 instead of 6.1 ms --
+// the moment an unrelated store elsewhere in the kernel moved the register allocation).
+__device__ __forceinline__ double uniform_d(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ ThrK uniform_thr(const ThrK &c)
+{
+    ThrK u;
+    u.D = uniform_d(c.D); u.rD = uniform_d(c.rD); u.gammad = uniform_d(c.gammad); u.dmg = uniform_d(c.dmg); u.rdmg = uniform_d(c.rdmg);
+    u.gm1 = uniform_d(c.gm1); u.gamma = uniform_d(c.gamma); u.dsc = uniform_d(c.dsc); u.rdsc = uniform_d(c.rdsc); u.d = uniform_d(c.d);
+    u.rd = uniform_d(c.rd);
+    return u;
+}
+
 // The OEM iteration for one lambda in the sliced layout (same recurrence and stop rule as `iterate` below).
 template <int R, int NW, int CW, int NB, int KIND>
 __device__ __forceinline__ void iterate_sliced(const PathArgs &A, const PenK &K, double d, const double (&a)[R][CW],
@@ -1348,7 +1364,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
         const double rscaley = 1.0 / scaley;
         const PenLin PL = pen_linear(pen, A.alpha, A.tau);
         const bool ridge = PL.cD != 0.0;
-        ThrK c = thr_consts<KIND>(pen_from_linear(PL, 0.0, d, A.gamma), d);
+        ThrK c = uniform_thr(thr_consts<KIND>(pen_from_linear(PL, 0.0, d, A.gamma), d));
         for (int base = 0; base < nl; base += C::LCH) {
             const int cnt = nl - base < C::LCH ? nl - base : C::LCH;
             for (int k = tid; k < cnt; k += NW * 64) {
@@ -1380,7 +1396,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
                 const double il = lam_next;
                 lam_next = LAM[k + 1 < cnt ? k + 1 : k];
                 const PenK K = pen_from_linear(PL, il, d, A.gamma);
-                if (__builtin_expect(ridge, 0)) c = thr_consts<KIND>(K, d);
+                if (__builtin_expect(ridge, 0)) c = uniform_thr(thr_consts<KIND>(K, d));
                 int it = 0, conv = 0;
                 iterate_rows_t<NW, CG, CGL, KIND, ACC>(A, K, c, a, aL, xy, pf, wslot, ecol, beta, ab, ak, it, conv, S, w, lane, buf, G OEM_DIAG_PASS);
                 // (the loss is taken in the coordinates of the iteration, before any in-place rescale)
