@@ -92,6 +92,32 @@ def audit_dpp_hazards(asm_text):
     return problems
 
 
+def audit_round_spills(asm_text, limit=16):
+    """The eight-wave forms of the row-split path kernel keep 176 of their 256 VGPRs for the matrix, and hipcc's allocation of
+    such a kernel is one edit away from spilling into its hot loop (config 2's SCAD round once went from
+    6 to 22 ms that way, with every result right).  iterate_rows_t marks its rounds in the listing; between the marks of an
+    element-wise operator without the accelerate option there may be at most `limit` scratch instructions (a handful is what
+    the allocator leaves there today; a cliff is a hundred)."""
+    problems, found = [], 0
+    for m in re.finditer(r"^(_ZN6oemgpu\S*path_rows_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end", asm_text, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        kind, count = None, 0
+        for line in body.splitlines():
+            b = re.search(r"; oem-round-begin (\d+)", line)
+            if b:
+                kind, count = int(b.group(1)), 0
+                found += 1
+            elif "; oem-round-end" in line:
+                if kind is not None and kind < 8 and kind % 2 == 0 and count > limit:      # K_SOFT .. K_OLS, accelerate off
+                    problems.append(f"{name}: {count} scratch instructions in a round of operator kind {kind // 2}")
+                kind = None
+            elif kind is not None and "scratch_" in line:
+                count += 1
+    if found == 0:
+        problems.append("no round markers found in path_small.hip (the audit pattern is stale)")
+    return problems
+
+
 def build_diag():
     """liboemgpu_diag.so: the same library with -DOEM_PATH_DIAG (stamped round segments); never the product."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -135,6 +161,9 @@ def build(force=False, verbose=False):
             problems = audit_dpp_hazards(listing[src].result().stdout)
             if problems:
                 raise RuntimeError(src + " ISA audit failed:\n  " + "\n  ".join(problems[:20]))
+        problems = audit_round_spills(listing["path_small.hip"].result().stdout)
+        if problems:
+            raise RuntimeError("path_small.hip round-spill audit failed:\n  " + "\n  ".join(problems[:20]))
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(OUT), *objs], check=True)
     return OUT
 

@@ -1062,6 +1062,7 @@ __device__ __forceinline__ void iterate_rows_t(const PathArgs &A, const PenK &K,
     constexpr int VS = RowsCfg<NW, CG, CGL>::VS;
     OEM_STAMP(8);                       // per-lambda work since the last round
     auto round = [&]() -> bool {
+        asm volatile("; oem-round-begin %0" ::"n"(KIND * 2 + (ACC ? 1 : 0)));      // markers for oem_amd/build.py: audit_round_spills
         const double bold = beta;
         if constexpr (KIND == K_GRP) {
             // Group operators (ref src/oem_dense.h:193-315).  A group's members are rows of other lanes and waves, so u crosses
@@ -1119,6 +1120,7 @@ __device__ __forceinline__ void iterate_rows_t(const PathArgs &A, const PenK &K,
         ab = gemv_rows<NW, CG, CGL, true, ACC>(a, aL, beta, wslot, ecol, moving, any, aux, S, w, lane, buf, nullptr OEM_DIAG_PASS);
         if (ACC && aux > 0.0) ak = 1.0;
         conv = !any;
+        asm volatile("; oem-round-end");
         return conv || it >= maxit;
     };
     // two rounds per trip: a taken branch (fetch redirect) costs ~80 cycles on this chain, a fall-through one nothing
