@@ -184,6 +184,16 @@ struct Blob {
     }
 };
 
+}  // namespace oemgpu
+#ifdef OEM_HOST_TIMING
+#include <chrono>
+namespace { struct HostT { double acc[8] = {0}; long n = 0; ~HostT() { if (n) fprintf(stderr, "host timing over %ld calls (us): entry->moments enqueued %.2f | ->path enqueued %.2f | ->copy enqueued %.2f | ->synced %.2f | ->unpacked/returned %.2f\n", n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n); } } g_ht;
+  double g_tp[6]; inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); } }
+#define HT(i) g_tp[i] = now_us()
+#else
+#define HT(i) do { } while (0)
+#endif
+namespace oemgpu {
 // group bookkeeping of get_group_indexes (ref src/oem_dense.h:421-456).  q = dimension of beta;
 // nscan = number of leading beta positions whose group entry is looked at (oemBig: nvars of nvars+1, quirk Q17).
 struct Groups {
@@ -332,10 +342,13 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
         int rc = small ? launch_path_small(c->stream, a) : (coop ? launch_path_coop(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned));
         if (rc) return rc;
     }
+    HT(2);
     if (!joined) OEM_HIP(hipMemcpy2DAsync(dstats, out_stride, stats, bstride * sizeof(double), sizeof(double) * stats_len(p), nbatch,
                                           hipMemcpyDeviceToDevice, c->stream));
     OEM_HIP(hipMemcpyAsync(c->pinned, joined ? (const void *)stats : (const void *)dout, back_bytes, hipMemcpyDeviceToHost, c->stream));
+    HT(3);
     OEM_HIP(hipStreamSynchronize(c->stream));
+    HT(4);
 
     // ---- unpack (ref src/oem_dense.cpp:249-294, src/DataStd.h:269-293, src/oem_big.h:880-897, src/oem_big.cpp:213-220)
     const int flag = (standardize ? 1 : 0) + 2 * (intercept ? 1 : 0);
@@ -370,14 +383,16 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
                     ob[0] = intercept ? b[0] : 0.0;
                     for (int j = 0; j < p; ++j) ob[j + 1] = b[j + off] * (standardize ? scalex[j] : 1.0);
                 } else {
+                    // DataStd::recover (ref src/DataStd.h:269-293), one loop per flag: the tests inside the loop kept it scalar
+                    // (12 us of host time per config-1 solve with the GPU idle; the same operations in the same order now)
                     double s = 0.0;
-                    for (int j = 0; j < p; ++j) {
-                        double cf = b[j];
-                        if (flag & 1) cf /= scalex[j];
-                        if (flag != 0) cf *= scaley;
-                        if (flag & 2) s += cf * meanx[j];
-                        ob[j + 1] = cf;
+                    switch (flag) {
+                    case 0: for (int j = 0; j < p; ++j) ob[j + 1] = b[j]; break;
+                    case 1: for (int j = 0; j < p; ++j) ob[j + 1] = b[j] / scalex[j] * scaley; break;
+                    case 2: for (int j = 0; j < p; ++j) { const double cf = b[j] * scaley; ob[j + 1] = cf; } break;
+                    default: for (int j = 0; j < p; ++j) { const double cf = b[j] / scalex[j] * scaley; ob[j + 1] = cf; } break;
                     }
+                    if (flag & 2) for (int j = 0; j < p; ++j) s += ob[j + 1] * meanx[j];
                     ob[0] = (flag & 2) ? meany - s : 0.0;
                 }
             }
@@ -602,6 +617,7 @@ int oemgpu_fit_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t 
                          int32_t standardize, int32_t intercept, const oemgpu_opts *o,
                          double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
 {
+    HT(0);
     if (!c || !x_dev || !y_dev) { set_error("fit_dense: NULL argument"); return OEMGPU_ERR_ARG; }
     int rc = check_opts(o, p, p);
     if (rc) return rc;
@@ -626,7 +642,11 @@ int oemgpu_fit_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t 
         rc = shard_moments(c, pl, x_dev, n, ld, y_dev, nullptr, (double *)(c->ws + a_t), (double *)(c->ws + a_v), mom);
         if (rc) return rc;
     }
+    HT(1);
     rc = oemgpu_solve_moments_dev(c, mom, nullptr, p, OEMGPU_SEM_DENSE, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+#ifdef OEM_HOST_TIMING
+    HT(5); g_ht.acc[0] += g_tp[1] - g_tp[0]; g_ht.acc[1] += g_tp[2] - g_tp[1]; g_ht.acc[2] += g_tp[3] - g_tp[2]; g_ht.acc[3] += g_tp[4] - g_tp[3]; g_ht.acc[4] += g_tp[5] - g_tp[4]; ++g_ht.n;
+#endif
     if (rc || !c->shift_advised) return rc;
     {
         Timer t(c, OEMGPU_T_SHIFT);
