@@ -262,8 +262,10 @@ void oemgpu_row_split(int64_t n, int32_t G, int32_t g, int64_t *r0, int64_t *r1)
 /* What the most recent host-resident call (oemgpu_fit_dense / oemgpu_fit_big) of THIS thread did, for bench.py and the tests:
  * [0] wall milliseconds of the whole call  [1] of the upload + moment passes  [2] of the solve(s)  [3] bytes staged to the
  * devices  [4] devices used  [5] row blocks streamed (all devices)  [6] 1 if the rows stayed resident in HBM, 0 if two block
- * buffers were recycled  [7] hipMalloc / hipHostMalloc calls made inside the call (0 in the steady state of repeated calls). */
-#define OEMGPU_NHOSTSTATS 8
+ * buffers were recycled  [7] hipMalloc / hipHostMalloc calls made inside the call (0 in the steady state of repeated calls)
+ * [8] cross-device hand-overs of the moment buffers that were staged through the host because the two devices cannot access each
+ *     other (hipDeviceCanAccessPeer; OEMGPU_NO_PEER=1 forces that route) -- 0 when every pair used one peer copy over xGMI. */
+#define OEMGPU_NHOSTSTATS 9
 int oemgpu_last_host_stats(double *out /* OEMGPU_NHOSTSTATS */);
 
 /* Frees every cached context (streams, workspaces, pinned staging).  The host-resident entry points keep theirs between

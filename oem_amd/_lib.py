@@ -15,7 +15,7 @@ PENALTIES = ["elastic.net", "lasso", "ols", "mcp", "scad", "mcp.net", "scad.net"
 
 OEMGPU_SEM_DENSE, OEMGPU_SEM_BIG = 0, 1
 ERR_INTERRUPTED = -6
-NHOSTSTATS = 8
+NHOSTSTATS = 9
 NTIMERS = 8
 T_SHIFT, T_MOMENTS, T_FINAL, T_EIGPATH, T_GRAMK = 0, 1, 2, 3, 4
 
@@ -123,7 +123,7 @@ def host_stats():
     """oemgpu_last_host_stats of this thread, as a dict"""
     out = (C.c_double * NHOSTSTATS)()
     check(lib().oemgpu_last_host_stats(out))
-    keys = ["call_ms", "upload_moments_ms", "solve_ms", "bytes_staged", "devices", "row_blocks", "resident", "allocations"]
+    keys = ["call_ms", "upload_moments_ms", "solve_ms", "bytes_staged", "devices", "row_blocks", "resident", "allocations", "host_staged_handovers"]
     return dict(zip(keys, list(out)))
 
 

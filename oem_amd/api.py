@@ -434,7 +434,7 @@ _TYPE_MEASURES = ("mse", "deviance", "class", "auc", "mae")
 def xval_oem(x, y, nfolds=10, foldid=None, type_measure=None, ncores=-1, family="gaussian", penalty=None, weights=(),
              lambda_=(), nlambda=100, lambda_min_ratio=None, alpha=1.0, gamma=3.0, tau=0.5, groups=(), penalty_factor=None,
              group_weights=None, standardize=True, intercept=True, maxit=500, tol=1e-7, irls_maxit=100, irls_tol=1e-3,
-             compute_loss=False, varnames=None, rng=None, ngpus=0, devices=None, upload_threads=0):
+             compute_loss=False, varnames=None, rng=None, ngpus=0, devices=None, upload_threads=0, interrupt=None):
     """xval.oem(): R/oem_xval.R:107-460 (gaussian, dense).  foldid: values 1..nfolds; drawn with `rng` (a numpy Generator)
     as sample(rep(seq(nfolds), length = n)) when None.  ngpus / devices (host x only): the rows over several devices inside the
     library, as in oem()."""
@@ -495,7 +495,7 @@ def xval_oem(x, y, nfolds=10, foldid=None, type_measure=None, ncores=-1, family=
         type_measure = "mse"
     a = _Args(penalty, lam_list, int(np.ravel(nlambda)[0]), lambda_min_ratio, alpha, gamma, tau, tol, maxit, False,
               compute_loss, penalty_factor, groups, unique_groups, group_weights, ngpus=ngpus, devices=devices,
-              upload_threads=upload_threads)
+              upload_threads=upload_threads, interrupt=interrupt)
     out = a.outputs(p + 1)
     cvm = np.zeros((a.npen, a.nl)); cvsd = np.zeros((a.npen, a.nl))
     fid = np.ascontiguousarray(foldid, dtype=np.int32)

@@ -27,20 +27,24 @@ void set_error(const char *fmt, ...)
 
 // The cooperating-workgroup engine (path_coop.hip) spins on its partners, so every workgroup of every such kernel in flight must
 // be resident at once: concurrent callers (xval.oem's fold threads, user threads) queue here for CU slots.
+// The count is per DEVICE: launches on different GPUs share no CUs and must not queue behind each other (the penalty split of
+// solve_summed and xval.oem over devices run one such kernel per device side by side -- ADVICE r2).
+static const int COOP_MAX_DEV = 64;
 static std::mutex g_coop_mu;
 static std::condition_variable g_coop_cv;
-static int g_coop_in_flight = 0;
+static int g_coop_in_flight[COOP_MAX_DEV] = {0};
 struct CoopSlots {
-    int n = 0;
-    void take(int want, int capacity)
+    int n = 0, dev = 0;
+    void take(int device, int want, int capacity)
     {
+        dev = (device >= 0 && device < COOP_MAX_DEV) ? device : COOP_MAX_DEV - 1;
         std::unique_lock<std::mutex> lk(g_coop_mu);
-        g_coop_cv.wait(lk, [&] { return g_coop_in_flight == 0 || g_coop_in_flight + want <= capacity; });
-        g_coop_in_flight += want; n = want;
+        g_coop_cv.wait(lk, [&] { return g_coop_in_flight[dev] == 0 || g_coop_in_flight[dev] + want <= capacity; });
+        g_coop_in_flight[dev] += want; n = want;
     }
     ~CoopSlots()
     {
-        if (n) { { std::lock_guard<std::mutex> lk(g_coop_mu); g_coop_in_flight -= n; } g_coop_cv.notify_all(); }
+        if (n) { { std::lock_guard<std::mutex> lk(g_coop_mu); g_coop_in_flight[dev] -= n; } g_coop_cv.notify_all(); }
     }
 };
 
@@ -99,9 +103,21 @@ oemgpu_ctx *ctx_acquire(int device)
     return c;
 }
 
+// A cached context keeps its grow-only buffers between calls (no allocation in the steady state) -- up to a bound: the copy of the
+// host rows (c->xres: up to half of HBM for one large fit) and xval.oem's fold-ordered copy (c->aux) are freed on release when they
+// exceed OEMGPU_CACHE_KEEP_BYTES (default: an eighth of the device's memory, 36 GB on MI355X), so that one large oem() / big.oem()
+// call does not starve torch or other users of the GPU for the rest of the session.  Streams, pinned staging lanes
+// and the workspace stay.  The caller has synchronised the context's stream.
 void ctx_release(oemgpu_ctx *c)
 {
     if (!c) return;
+    size_t keep = c->hbm_total / 8;
+    if (const char *e = getenv("OEMGPU_CACHE_KEEP_BYTES")) { const long long v = atoll(e); if (v >= 0) keep = (size_t)v; }
+    if (c->xres_bytes > keep || c->aux_bytes > keep) {
+        (void)hipSetDevice(c->device);
+        if (c->xres_bytes > keep) { (void)hipFree(c->xres); c->xres = nullptr; c->xres_bytes = 0; }
+        if (c->aux_bytes > keep) { (void)hipFree(c->aux); c->aux = nullptr; c->aux_bytes = 0; }
+    }
     std::lock_guard<std::mutex> lk(g_cache_mu);
     c->busy = false;
 }
@@ -335,7 +351,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const size_t back_bytes = nbatch > 1 ? out_stride * nbatch : out_bytes + (joined ? st_gap : 0);
     if (ctx_pinned(c, back_bytes > 16384 ? back_bytes : 16384)) return OEMGPU_ERR_HIP;
     CoopSlots slots;                                  // held until the stream has been synchronised below
-    if (coop) slots.take(path_coop_workgroups(q) * (pen_split ? npen : 1) * nbatch, c->num_cu * 3 / 4);
+    if (coop) slots.take(c->device, path_coop_workgroups(q) * (pen_split ? npen : 1) * nbatch, c->num_cu * 3 / 4);
     {
         Timer t(c, OEMGPU_T_EIGPATH);
         PollScope poll(o);
@@ -360,7 +376,8 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
         double *beta_b = beta + (size_t)bi * nk * rows, *lambda_b = lambda_out + (size_t)bi * nk, *loss_b = loss + (size_t)bi * nk;
         int32_t *niter_b = niter + (size_t)bi * nk;
         d_out[bi] = hd[0];
-        if (hd[1] < 0.0) { set_error("cooperating workgroups lost each other (exchange timeout)"); return OEMGPU_ERR_INTERNAL; }
+        // poison slot (common.hpp): cleared by the launchers of the multi-workgroup engines, written 0 by the others
+        if (hd[6] != 0.0) { set_error("cooperating workgroups lost each other (exchange timeout)"); return OEMGPU_ERR_INTERNAL; }
         c->diag[0] = hd[2]; c->diag[1] = hd[3];
         if (bi == 0) { c->eig_steps = (int)hd[4]; c->eig_capped = hd[5] != 0.0; }
         c->shifted = hs[stats_shift_flag(p)] != 0.0;
@@ -465,6 +482,7 @@ oemgpu_ctx *oemgpu_create(int32_t device, void *stream)
     oemgpu_ctx *c = new oemgpu_ctx();
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
+    c->hbm_total = prop.totalGlobalMem;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
@@ -496,6 +514,7 @@ void oemgpu_destroy(oemgpu_ctx *c)
     }
     for (int k = 0; k < 2; ++k) if (c->done_ev[k]) (void)hipEventDestroy(c->done_ev[k]);
     if (c->xfer_ev) (void)hipEventDestroy(c->xfer_ev);
+    if (c->xfer_host) (void)hipHostFree(c->xfer_host);
     for (oemgpu_ctx *k : c->kids) oemgpu_destroy(k);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->ev_made) for (int i = 0; i < 2 * OEMGPU_NTIMERS; ++i) (void)hipEventDestroy(c->ev[i]);
@@ -714,12 +733,13 @@ int oemgpu_eig_max_dev(oemgpu_ctx *c, const double *a_dev, int32_t p, double *la
     a.work = (double *)(c->ws + a_w);
     a.pen_lo = 0; a.pen_hi = 0;
     CoopSlots slots;
-    if (coop) slots.take(path_coop_workgroups(p), c->num_cu * 3 / 4);
+    if (coop) slots.take(c->device, path_coop_workgroups(p), c->num_cu * 3 / 4);
     int rc = p <= SMALL_P_MAX ? launch_path_small(c->stream, a) : (coop ? launch_path_coop(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned));
     if (rc) return rc;
     double h[D_OUT_LEN];
     OEM_HIP(hipMemcpyAsync(h, a.d_out, sizeof h, hipMemcpyDeviceToHost, c->stream));
     OEM_HIP(hipStreamSynchronize(c->stream));
+    if (h[6] != 0.0) { set_error("cooperating workgroups lost each other (exchange timeout)"); return OEMGPU_ERR_INTERNAL; }
     *lambda_max = h[1];
     c->eig_steps = (int)h[4]; c->eig_capped = h[5] != 0.0;
     return 0;
@@ -1027,6 +1047,11 @@ static int xval_solve(oemgpu_ctx *c, const XvalLay &L, const int64_t *fold_tot, 
         if (rc) return rc;
         oemgpu_opts of = *o;
         of.lambda_user = lambda_out; of.nlambda_user = nl; of.compute_loss = 0;
+        // The fold fits run on K worker threads: they must never call back into the caller (R's API is single-threaded, and
+        // R_CheckStack on a foreign stack raises a spurious interrupt -- ADVICE r2).  The caller is polled on THIS thread only:
+        // by the full-data fit above, before the fold threads start and after they have joined.
+        of.interrupt = nullptr; of.interrupt_arg = nullptr;
+        if (o->interrupt && o->interrupt(o->interrupt_arg)) { set_error("interrupted by the caller"); return OEMGPU_ERR_INTERRUPTED; }
         std::vector<double> hl(nk2 * K), hloss(nk2 * K), hd(K);
         std::vector<int32_t> hn(nk2 * K);
         msum += mlen;                                            // the folds' sums
@@ -1054,6 +1079,7 @@ static int xval_solve(oemgpu_ctx *c, const XvalLay &L, const int64_t *fold_tot, 
             for (auto &t : th) t.join();
             for (int i = 0; i < K; ++i)
                 if (rcs[i]) { set_error("fold %d: %s", i + 1, errs[i].c_str()); return rcs[i]; }
+            if (o->interrupt && o->interrupt(o->interrupt_arg)) { set_error("interrupted by the caller"); return OEMGPU_ERR_INTERRUPTED; }
         }
     }
     OEM_HIP(hipMemcpyAsync(bdev, hb.data(), sizeof(double) * blen * K, hipMemcpyHostToDevice, c->stream));

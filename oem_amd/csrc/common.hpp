@@ -102,7 +102,9 @@ struct PathArgs {
     int *niter;              // npen * nl
     double *loss;            // npen * nl
     double *d_out;           // D_OUT_LEN doubles: [0] = d, [1] = lambda_max, [2] shader cycles, [3] 100 MHz ticks of the fused kernel,
-                             // [4] Lanczos steps taken, [5] 1 if the step cap ended the recurrence (neither stop rule nor breakdown)
+                             // [4] Lanczos steps taken, [5] 1 if the step cap ended the recurrence (neither stop rule nor breakdown),
+                             // [6] exchange poison: cleared by the host before the launch, set to 1 by ANY workgroup whose exchange
+                             //     timed out (a slot nobody else writes: the writer's stores cannot cover it up -- ADVICE r2)
     // workspace for the large-p engine
     double *work;
     // nbatch > 1 (p <= SMALL_P_MAX only): blockIdx.y selects one of nbatch independent problems that share everything above
@@ -134,7 +136,7 @@ __device__ __forceinline__ PathArgs path_instance(PathArgs A)
     return A;
 }
 
-static const int D_OUT_LEN = 6;
+static const int D_OUT_LEN = 7;
 static const int COOP_MIN_Q = 209, COOP_MIN_Q_GROUPS = 209;      // from here the cooperating-workgroup engine (path_coop.hip) takes the path when it is eligible (element-wise penalties only / a group penalty in the call)
 int path_coop_min_q(bool has_groups);
 static const int SMALL_P_MAX = 288;     // one workgroup where the matrix fits its registers (+ LDS); else four cooperating workgroups (big.oem's p + 1 = 257 included)

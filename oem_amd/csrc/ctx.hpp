@@ -21,6 +21,7 @@ struct oemgpu_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 256;
+    size_t hbm_total = 0;        // bytes of device memory (oemgpu_create)
     char *ws = nullptr;          // device workspace (grow-only)
     size_t ws_bytes = 0;
     char *pinned = nullptr;      // pinned host staging for the results
@@ -50,6 +51,8 @@ struct oemgpu_ctx {
     size_t slot_bytes = 0;
     hipEvent_t done_ev[2] = {nullptr, nullptr};   // "the moment pass over block buffer k has finished reading it"
     hipEvent_t xfer_ev = nullptr;                 // cross-device hand-over of the moment buffers
+    char *xfer_host = nullptr;                    // pinned bounce buffer of a hand-over INTO this context's device when the two devices
+    size_t xfer_host_bytes = 0;                   // are not peers (hoststream.hip: hand_over); grow-only
     char *blob_buf = nullptr;      // the parameter blob of run_paths (grow-only, outside the workspace: it survives between calls)
     size_t blob_bytes = 0;
     const char *blob_dev = nullptr;   // where the last parameter blob was uploaded (run_paths skips an identical upload)

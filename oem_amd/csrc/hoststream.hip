@@ -31,7 +31,7 @@
 namespace oemgpu {
 
 std::atomic<long> g_alloc_count{0};                  // device / pinned allocations and stream / event creations, process-wide
-static thread_local double g_host_stats[OEMGPU_NHOSTSTATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+static thread_local double g_host_stats[OEMGPU_NHOSTSTATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 namespace {
 
@@ -316,10 +316,60 @@ void run_pass(DevJob &J, bool upload, bool want_sums, bool want_moments, const d
     J.T = keepT;
 }
 
-// dst (on device cd) <- src (on device cs), ordered after everything on `from` so far and before anything later on `to`
+// Can `to` read `from`'s memory directly (xGMI / PCIe peer access)?  Asked once per ordered pair and cached; peer access is enabled
+// on first use.  OEMGPU_NO_PEER=1 answers "no" for every pair -- the same device included -- so the host-staged route below can be
+// exercised on a one-GPU box.
+bool peers(int to, int from)
+{
+    static std::mutex mu;
+    static signed char known[64][64];                    // 0 unknown, 1 yes, -1 no
+    static const bool never = getenv("OEMGPU_NO_PEER") != nullptr;
+    if (never) return false;
+    if (to == from) return true;
+    if (to < 0 || from < 0 || to >= 64 || from >= 64) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (known[to][from] == 0) {
+        int can = 0;
+        bool ok = hipDeviceCanAccessPeer(&can, to, from) == hipSuccess && can != 0;
+        if (ok) {
+            int cur = 0;
+            (void)hipGetDevice(&cur);
+            if (hipSetDevice(to) == hipSuccess) {
+                const hipError_t e = hipDeviceEnablePeerAccess(from, 0);
+                ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+                (void)hipGetLastError();                 // "already enabled" is not an error of ours
+            } else ok = false;
+            (void)hipSetDevice(cur);
+        }
+        known[to][from] = ok ? 1 : -1;
+    }
+    return known[to][from] > 0;
+}
+
+std::atomic<long> g_host_staged{0};                      // hand-overs that went through the host (oemgpu_last_host_stats()[8])
+
+// dst (on device cd) <- src (on device cs), ordered after everything on `from` so far and before anything later on `to`.
+// Peers: one hipMemcpyPeerAsync over xGMI on from's stream.  Not peers (hipDeviceCanAccessPeer says no, or OEMGPU_NO_PEER):
+// device -> pinned host buffer of `to` -> device, each leg followed by a stream synchronisation (the buffers are a few hundred
+// KB once per call; the bounce buffer is then free again whatever the caller does next).
 int hand_over(oemgpu_ctx *to, double *dst, oemgpu_ctx *from, const double *src, size_t doubles)
 {
     OEM_HIP(hipSetDevice(from->device));
+    if (!peers(to->device, from->device)) {
+        if (doubles * 8 > to->xfer_host_bytes) {
+            if (to->xfer_host) { OEM_HIP(hipHostFree(to->xfer_host)); to->xfer_host = nullptr; to->xfer_host_bytes = 0; }
+            const size_t want = (doubles * 8 + 4095) / 4096 * 4096;
+            OEM_HIP(hipHostMalloc((void **)&to->xfer_host, want, hipHostMallocPortable)); ++g_alloc_count;
+            to->xfer_host_bytes = want;
+        }
+        OEM_HIP(hipMemcpyAsync(to->xfer_host, src, doubles * 8, hipMemcpyDeviceToHost, from->stream));
+        OEM_HIP(hipStreamSynchronize(from->stream));
+        OEM_HIP(hipSetDevice(to->device));
+        OEM_HIP(hipMemcpyAsync(dst, to->xfer_host, doubles * 8, hipMemcpyHostToDevice, to->stream));
+        OEM_HIP(hipStreamSynchronize(to->stream));
+        ++g_host_staged;
+        return 0;
+    }
     if (to->device == from->device) OEM_HIP(hipMemcpyAsync(dst, src, doubles * 8, hipMemcpyDeviceToDevice, from->stream));
     else OEM_HIP(hipMemcpyPeerAsync(dst, to->device, src, from->device, doubles * 8, from->stream));
     OEM_HIP(hipEventRecord(from->xfer_ev, from->stream));
@@ -451,7 +501,7 @@ int host_fit(const std::vector<HostPiece> &all, int64_t n, int32_t p, int sem, i
              const oemgpu_opts *o, double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
 {
     const Clock::time_point t_call = Clock::now();
-    const long allocs0 = g_alloc_count.load();
+    const long allocs0 = g_alloc_count.load(), staged0 = g_host_staged.load();
     for (double &v : g_host_stats) v = 0.0;
     std::vector<int> dev;
     int rc = device_list(o, dev);
@@ -529,6 +579,7 @@ int host_fit(const std::vector<HostPiece> &all, int64_t n, int32_t p, int sem, i
     g_host_stats[0] = ms_since(t_call); g_host_stats[1] = up_ms; g_host_stats[2] = solve_ms; g_host_stats[3] = (double)staged;
     g_host_stats[4] = G; g_host_stats[5] = (double)nblocks; g_host_stats[6] = resident ? 1.0 : 0.0;
     g_host_stats[7] = (double)(g_alloc_count.load() - allocs0);
+    g_host_stats[8] = (double)(g_host_staged.load() - staged0);
     return rc;
 }
 

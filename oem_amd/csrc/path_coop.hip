@@ -686,7 +686,9 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
         A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
         A.d_out[3] = (double)(__builtin_amdgcn_s_memrealtime() - t_rt0);
     }
-    if (X.failed && tid == 0) A.d_out[1] = -1.0;                     // exchange timeout: poison (the host turns it into an error)
+    // exchange timeout: poison (the host turns it into an error).  X.failed is per-wave state: combined over the workgroup, and
+    // stored to a slot of its own that the host cleared before the launch (d_out[6]; every failing workgroup stores the same 1)
+    if (__syncthreads_or(X.failed ? 1 : 0) && tid == 0) A.d_out[6] = 1.0;
 }
 
 }  // namespace
@@ -732,6 +734,10 @@ int launch_path_coop(hipStream_t s, const PathArgs &a_)
     const int ninst = (a.nbatch > 1 ? a.nbatch : 1) * (a.pen_split ? a.npen : 1);
     if (ninst > 1 && (size_t)a.bs_work * 8 < path_coop_xchg_bytes()) { set_error("internal: coop work stride"); return OEMGPU_ERR_INTERNAL; }
     OEM_HIP(hipMemsetAsync(a.work, 0, (ninst > 1 ? (size_t)a.bs_work * 8 : path_coop_xchg_bytes()) * ninst, s));     // granule tags must start at 0
+    {   // the poison slot of every instance (common.hpp: d_out[6]) starts at 0; only a timed-out workgroup writes it
+        const int nb = a.nbatch > 1 ? a.nbatch : 1;
+        OEM_HIP(hipMemset2DAsync(a.d_out + 6, nb > 1 ? (size_t)a.bs_out : sizeof(double), 0, sizeof(double), (size_t)nb, s));
+    }
     if (q <= 512) {
         typedef CoopCfg<2> C;
         const int W = (q + C::RW - 1) / C::RW;

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(1024) void path_init_kernel(PathArgs A, LState *st,
         st->pending_loss = -1; st->reset_next = 1; st->finish_after_loss = 0; st->pad = 0;
         st->ak = 1.0; st->d = d; st->theta = theta;
         st->lmax = mm * (A.yscale ? A.stats[1] : 1.0);
-        A.d_out[0] = d; A.d_out[1] = theta; A.d_out[2] = 0.0; A.d_out[3] = 0.0; A.d_out[4] = (double)lz_steps; A.d_out[5] = (double)lz_capped;
+        A.d_out[0] = d; A.d_out[1] = theta; A.d_out[2] = 0.0; A.d_out[3] = 0.0; A.d_out[4] = (double)lz_steps; A.d_out[5] = (double)lz_capped; A.d_out[6] = 0.0;
         sh[0] = st->lmax;
     }
     __syncthreads();

@@ -651,7 +651,10 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
     diag_acc[11] = (unsigned long long)nst;
 #endif
     const double d = theta * 1.005;                       // ref src/oem_dense.h:498
-    if (tid == 0 && writer) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && nst >= msteps && nst < p) ? 1.0 : 0.0; }
+    if (tid == 0 && writer) {
+        A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && nst >= msteps && nst < p) ? 1.0 : 0.0;
+        if (G == 1) A.d_out[6] = 0.0;                     // (G > 1: the launcher cleared the poison slot; a timed-out workgroup sets it)
+    }
 
     // ---- A = d I - XX   (ref src/oem_dense.h:501-505)
 #pragma unroll
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
         A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
         A.d_out[3] = (double)(__builtin_amdgcn_s_memrealtime() - t_rt0);
     }
-    if (X.failed && lane == 0) A.d_out[1] = -1.0;     // exchange timeout: poison (host turns it into an error)
+    if (X.failed && lane == 0) A.d_out[6] = 1.0;      // exchange timeout: poison slot, cleared by the host before the launch (the host turns it into an error)
 }
 
 // ================================================================================================
@@ -1280,7 +1283,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
     }
     if (!have_theta) theta = top_ritz(nst, theta_prev);
     const double d = theta * 1.005;                                  // ref src/oem_dense.h:498
-    if (tid == 0) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && nst >= msteps && nst < p) ? 1.0 : 0.0; }
+    if (tid == 0) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && nst >= msteps && nst < p) ? 1.0 : 0.0; A.d_out[6] = 0.0; }
 #ifdef OEM_PATH_DIAG
     OEM_STAMP(7);                                                    // the final top_ritz (slot 7: all top_ritz calls)
     unsigned long long lz[5];
@@ -1470,6 +1473,8 @@ template <int R, int NW, int CW, int G = 1> int launch_cfg(hipStream_t s, const 
     if (G > 1) {                                                                    // granule tags must start at 0
         if (nbatch > 1 && (size_t)a.bs_work * 8 != path_small_xchg_bytes()) { set_error("internal: batch work stride"); return OEMGPU_ERR_INTERNAL; }
         OEM_HIP(hipMemsetAsync(a.work, 0, path_small_xchg_bytes() * nbatch, s));
+        // the poison slot of every instance (common.hpp: d_out[6]) starts at 0; only a timed-out workgroup writes it
+        OEM_HIP(hipMemset2DAsync(a.d_out + 6, nbatch > 1 ? (size_t)a.bs_out : sizeof(double), 0, sizeof(double), (size_t)nbatch, s));
     }
     if (sh > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&path_small_kernel<R, NW, CW, G>),

@@ -30,6 +30,15 @@ from . import api as _api
 _STAGED_ALWAYS = bool(__import__("os").environ.get("OEM_STAGED_ALWAYS"))      # diagnostic: the N > 1 call sequence on one rank too
 
 
+def _many(dist, group):
+    """Do the collectives of the N > 1 call sequence run?  World size > 1 -- or OEM_FORCE_COLLECTIVES=1 with an initialised process
+    group of ANY size: a one-GPU box then executes every RCCL call of this module (all-reduce, all-gather) at world size 1, with
+    the same bits as the plain call (tests/test_gpu_distributed.py, bench.py's rccl_selfcheck).  Read at call time."""
+    if dist is None:
+        return False
+    return dist.get_world_size(group) > 1 or __import__("os").environ.get("OEM_FORCE_COLLECTIVES") == "1"
+
+
 class HipBackend:
     """Local stages on this rank's GPU through the C ABI (oemgpu_*_dev)."""
 
@@ -166,6 +175,10 @@ def _split_solve(backend, dist, group, mom, sums, p, semantics, standardize, int
     dist.all_gather(parts, buf, group=group)
     if outs is None:
         args.outputs(rows)
+    elif C.cast(outs[0], C.c_void_p).value != args.beta.ctypes.data:
+        # the assembled fit is written in place into args.beta / lam_out / niter / loss / d -- which is what `outs` points at
+        # when it came from args.outputs(); foreign result buffers are not supported on this branch
+        raise ValueError("split_penalties: `outs` must be the buffers of an earlier args.outputs(p + 1) of the same args")
     for r in range(min(world, npen)):
         got = parts[r].cpu().numpy()
         for s_, k in enumerate(range(r, npen, world)):
@@ -184,7 +197,7 @@ def solve_row_shards(backend, dist, group, x, n_local, ld, p, y, bufs, semantics
     split_penalties: None = when it pays (several penalties on the engines that walk them one after the other: p + intercept
     column > SMALL_P_MAX); True / False force it."""
     sums, mom = bufs
-    many = dist is not None and dist.get_world_size(group) > 1
+    many = _many(dist, group)
     q = p + (1 if (semantics != L.OEMGPU_SEM_DENSE and intercept) else 0)
     if split_penalties is None:
         split_penalties = q > SMALL_P_MAX
@@ -232,15 +245,14 @@ def oem_sharded(x_local, y_local, backend=None, dist=None, group=None, big=False
     if penalty_factor is None:
         penalty_factor = np.ones(p)
     g, ug, gw = _api._group_setup(penalty, groups, group_weights, p, bool(big and intercept))
-    many = dist is not None and dist.get_world_size(group) > 1
+    many = _many(dist, group)
     if n_total is None:
         n_total = int(n_local)
         if many and (lambda_min_ratio is None or big):           # the default grid and big.oem's n > p + intercept test need the GLOBAL n
-            t = backend.new_buffer(1)
-            t += float(n_local)
-            with backend.section():
+            with backend.section():                              # the fill, the add and the collective on ONE stream
+                t = backend.to_device(np.array([float(n_local)]))
                 dist.all_reduce(t, group=group)
-            n_total = int(round(float(t.cpu()[0])))
+                n_total = int(round(float(backend.to_host(t)[0])))
     if lambda_min_ratio is None:
         lambda_min_ratio = 0.01 if n_total < p else 0.0001        # R/oem.R:348-354, R/big_oem.R:206-212
     if big and n_total <= p + (1 if intercept else 0):
@@ -286,7 +298,7 @@ def xval_oem_sharded(x_local, y_local, foldid_local, nfolds, backend=None, dist=
     if penalty_factor is None:
         penalty_factor = np.ones(p)
     g, ug, gw = _api._group_setup(penalty, groups, group_weights, p, bool(intercept))
-    many = dist is not None and dist.get_world_size(group) > 1
+    many = _many(dist, group)
     weighted = weights_local is not None
     K = int(nfolds)
     with backend.section():

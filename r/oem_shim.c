@@ -14,6 +14,7 @@
 #include <R.h>
 #include <Rinternals.h>
 #include <Rinterface.h>      /* Rf_onintr */
+#include <R_ext/Rdynload.h>  /* DllInfo (R_unload_oem) */
 #include <string.h>
 
 #include "oemgpu.h"
@@ -276,4 +277,20 @@ SEXP oem_fit_sparse(SEXP x_, SEXP y_, SEXP family_, SEXP penalty_, SEXP weights_
                                      Rf_asLogical(intercept_), &o, beta, lam, niter, loss, &d);
     if (rc != 0) raise(rc);
     return pack(&o, p + 1, nl, beta, lam, niter, loss, d);
+}
+
+/* The host-resident entry points keep contexts (streams, pinned staging lanes, workspaces; the device copy of the rows only up to
+ * OEMGPU_CACHE_KEEP_BYTES, default an eighth of the device's memory) in a process-wide cache so that repeated calls allocate
+ * nothing.  `.Call("oem_gpu_release_cache", PACKAGE = "oem")` frees all of it on demand, and unloading the package's shared
+ * object (library.dynam.unload / detach(unload = TRUE)) does the same through R's unload hook. */
+SEXP oem_gpu_release_cache(void)
+{
+    oemgpu_release_cache();
+    return R_NilValue;
+}
+
+void R_unload_oem(DllInfo *info)
+{
+    (void)info;
+    oemgpu_release_cache();
 }

@@ -17,3 +17,28 @@ def test_ranks_share_one_gpu(nproc):
            "--master-port", str(29575 + nproc), str(ROOT / "tests" / "dist_gpu_worker.py")]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert "DIST_GPU_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_at_world_size_one():
+    """RCCL itself, on a one-GPU box: process group "nccl" of world size 1 and OEM_FORCE_COLLECTIVES=1 make every collective of
+    oem_amd/distributed.py execute (tests/rccl_world1_worker.py counts them) -- with the bits of the plain call."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "rccl_world1_worker.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert "RCCL_W1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_workers():
+    """`python bench.py --gpus 2` without a torchrun environment: the parent starts the two workers itself (here both on the one
+    GPU of the box, over gloo: OEM_BENCH_ONE_DEVICE) and the one JSON line comes back through it."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(OEM_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "200000", "--no-c5",
+                        "--no-host", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["collective_backend"] == "gloo" and out["allreduce_ms"] > 0

@@ -191,6 +191,37 @@ def test_caller_interrupt(oa, monkeypatch):
     _cmp(f, orc.fit_dense(x, y, penalty=["lasso"], nlambda=5))
 
 
+def test_fold_threads_never_call_the_caller(oa, monkeypatch):
+    """xval.oem beyond one launch (here: the cooperating engine switched off at p + 1 = 301) fits its folds on K worker threads.
+    opts->interrupt stands for R_CheckUserInterrupt, which must only ever run on the thread that made the call:
+    the fold threads run with the callback removed, the calling thread polls before they start and after they have joined."""
+    import threading
+    from oem_amd import _lib as L
+    monkeypatch.setenv("OEM_NO_COOP", "1")
+    rng = np.random.default_rng(77)
+    n, p, K = 2500, 300, 4
+    x = np.asfortranarray(rng.normal(size=(n, p)))
+    y = x[:, :3] @ np.array([1.0, -1.0, 0.5]) + rng.normal(size=n)
+    foldid = rng.permutation(np.resize(np.arange(1, K + 1), n))
+    kw = dict(penalty=["lasso"], nlambda=4, tol=1e-8, maxit=2000, foldid=foldid)
+    tids, calls = set(), []
+
+    def poll():
+        tids.add(threading.get_ident()); calls.append(1)
+        return False
+    a = oa.xval_oem(x, y, interrupt=poll, **kw)
+    assert calls and tids == {threading.get_ident()}
+    b = oa.xval_oem(x, y, **kw)
+    assert np.array_equal(a["beta"][0], b["beta"][0]) and np.array_equal(a["cvm"][0], b["cvm"][0])
+    for devices in ([0, 0],):                                   # the same through the rows-over-devices form (its phase 2)
+        tids.clear(); calls.clear()
+        oa.xval_oem(x, y, interrupt=poll, devices=devices, **kw)
+        assert calls and tids == {threading.get_ident()}
+    with pytest.raises(oa.OemgpuError) as e:                      # and a "yes" still ends the call
+        oa.xval_oem(x, y, interrupt=lambda: True, **kw)
+    assert e.value.code == L.ERR_INTERRUPTED
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("p,pens,weighted,tm", [(30, ["lasso", "mcp"], False, "mse"), (41, ["grp.lasso", "elastic.net"], True, "mae"),
                                                 (300, ["lasso"], False, "mse")])
@@ -220,3 +251,16 @@ def test_xval_rows_over_several_devices(oa, p, pens, weighted, tm):
             assert np.allclose(many["cvm"][k], one["cvm"][k], rtol=1e-10) and np.allclose(many["cvsd"][k], one["cvsd"][k], rtol=1e-8), (devices, pens[k])
     with pytest.raises(Exception):
         oa.xval_oem(x, y, devices=[0, 99], **kw)
+
+
+def test_handover_staged_through_the_host():
+    """devices that cannot access each other (hipDeviceCanAccessPeer == 0): the moment buffers cross through a pinned host buffer.
+    OEMGPU_NO_PEER=1 forces that route, in a child process (the switch is read once) -- tests/no_peer_worker.py."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tests" / "no_peer_worker.py")], cwd=root, env=dict(os.environ, OEMGPU_NO_PEER="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert "NO_PEER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

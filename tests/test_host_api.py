@@ -147,3 +147,18 @@ def test_plot_and_summary_methods():
            "name": cv["name"], "lambda.min.models": cv["lambda.min.models"], "lambda.1se.models": cv["lambda.1se.models"]}
     assert np.allclose(oa.plot_cv(cvo, "mcp", sign_lambda=-1, show=False)["x"], -np.log(fit["lambda"][1]))
     assert oa.format_summary(oa.summary_cv(cvo)) == txt
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` on a node with fewer devices: one clear line on stderr and a non-zero exit code, from the parent
+    process, before anything touches a GPU (it used to die on an AssertionError)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OEM_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "64"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and r.stdout == ""
+    err = [l for l in r.stderr.splitlines() if l.strip()]
+    assert len(err) == 1 and "--gpus 64" in err[0] and "Traceback" not in r.stderr
