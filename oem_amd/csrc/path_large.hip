@@ -586,6 +586,231 @@ __global__ __launch_bounds__(256) void oem_fused_kernel(PathArgs A, FState *__re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Symmetric-tile engine (q = 128 NBLK, element-wise penalties): XX is symmetric and this engine reads only its lower triangle
+// -- 4 q^2 bytes per iteration instead of 8 q^2 (the row-streaming kernels above read all of it).
+//
+//   tiles      XX in 128 x 128 blocks; workgroup (I, J), I > J, owns block (I, J) (128 KB) and feeds BOTH products it holds:
+//              g_I += T beta_J ("direct", rows of block I) and g_J += T' beta_I ("transposed", columns of block J).  The NBLK
+//              diagonal blocks are read whole by workgroups of their own (direct product only: +3 % bytes at q = 4096) and are
+//              launched last, so that the half-length workgroups fill the dispatch tail.
+//   lanes      lane (a = lane / 8, b = lane % 8) of wave w loads rows 32 w + 8 g + a (g = 0..3), columns 16 h + 2 b, + 1
+//              (h = 0..7): a wave load is 8 rows x 128 contiguous bytes (whole cache lines), the whole block is in flight in
+//              registers (32 KB per wave) before the first FMA.  Direct product: a lane accumulates its row over the 8 column
+//              groups (4 accumulators), the 8 lanes of a row meet in LDS.  Transposed product: a lane accumulates its two
+//              columns over the 4 row groups (16 accumulators), the 8 row lanes x 4 waves meet in LDS.  Both sums run in a fixed
+//              order -- no atomics, bitwise reproducible.
+//   partials   block B of g receives exactly NBLK partial vectors: slot k < B from workgroup (B, k) (direct), slot B from the
+//              diagonal workgroup, slot k > B from workgroup (k, B) (transposed): P[slot][q], 1 MB at q = 4096, double-buffered
+//              by launch parity.
+//   head       The reduction over the slots is the HEAD OF THE NEXT LAUNCH (no second kernel, no fence): workgroup (I, J) sums
+//              the NBLK slots of its own 256 coordinates (blocks I and J) in slot order, thresholds them (the operator is
+//              coordinate-local), and has beta_I, beta_J for its products; the stop rule and the lambda / penalty bookkeeping are
+//              replicated one launch later exactly as in oem_fused_kernel (per-workgroup "still moving" words, state by launch
+//              parity).  The head's loads are issued before the block's (vmcnt retires in order), so the threshold runs while
+//              the block streams in.  The diagonal workgroups leave beta behind for the next launch (beta_prev of the stop rule).
+//   bytes      per iteration: 4 q^2 + 4 q * 128 (blocks) + 8 q NBLK written, + 2 * 128 * NBLK * 8 B per workgroup re-read of the
+//              partials by the heads (L2 / Infinity Cache hits: the buffer is 1 MB).
+// ------------------------------------------------------------------------------------------------
+static const int SYM_TB = 128;
+__host__ __device__ static inline int sym_nwg(int nblk) { return nblk * (nblk - 1) / 2 + nblk; }
+
+// block (I, J) of workgroup b: the nblk (nblk - 1) / 2 off-diagonal ones first (b = I (I - 1) / 2 + J), then the diagonal ones
+__device__ __forceinline__ void sym_block(int b, int nblk, int &I, int &J, bool &diag)
+{
+    const int noff = nblk * (nblk - 1) / 2;
+    diag = b >= noff;
+    if (diag) { I = J = b - noff; return; }
+    int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)b)) * 0.5f);
+    while (i * (i - 1) / 2 > b) --i;
+    while ((i + 1) * i / 2 <= b) ++i;
+    I = i; J = b - i * (i - 1) / 2;
+}
+
+struct SymTile { v2d t[4][8]; };
+
+__device__ __forceinline__ void sym_load(SymTile &T, const double *__restrict__ xx, int q, int I, int J, int w, int a, int bb)
+{
+    const double *tp = xx + (size_t)(SYM_TB * I + 32 * w + a) * q + SYM_TB * J + 2 * bb;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h = 0; h < 8; ++h) T.t[g][h] = *reinterpret_cast<const v2d *>(tp + (size_t)(8 * g) * q + 16 * h);
+}
+
+// the two products of a block with bsh[0..127] = vec_I, bsh[128..255] = vec_J, combined over lanes and waves in LDS, stored as
+// partial vectors: direct -> Pout[J][128 I + r], transposed (off-diagonal blocks) -> Pout[I][128 J + c]
+struct SymLds {
+    double bsh[2 * SYM_TB];
+    double dsh[SYM_TB][9];
+    double tsh[4][8][SYM_TB + 16];
+};
+__device__ __forceinline__ void sym_products(const SymTile &T, SymLds &L, double *__restrict__ Pout, int q, int I, int J, bool diag,
+                                             int tid, int w, int a, int bb)
+{
+    double bi[4];
+    v2d bj[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bi[g] = L.bsh[32 * w + 8 * g + a];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) bj[h] = *reinterpret_cast<const v2d *>(&L.bsh[SYM_TB + 16 * h + 2 * bb]);
+    double ds[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h = 0; h < 8; ++h) { ds[g] = fma(T.t[g][h].x, bj[h].x, ds[g]); ds[g] = fma(T.t[g][h].y, bj[h].y, ds[g]); }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) L.dsh[32 * w + 8 * g + a][bb] = ds[g];
+    if (!diag) {
+        v2d ts[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) { ts[h].x = 0.0; ts[h].y = 0.0; }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int h = 0; h < 8; ++h) { ts[h].x = fma(T.t[g][h].x, bi[g], ts[h].x); ts[h].y = fma(T.t[g][h].y, bi[g], ts[h].y); }
+#pragma unroll
+        for (int h = 0; h < 8; ++h) *reinterpret_cast<v2d *>(&L.tsh[w][a][16 * h + 2 * bb]) = ts[h];
+    }
+    __syncthreads();
+    if (tid < SYM_TB) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += L.dsh[tid][k];
+        Pout[(size_t)J * q + SYM_TB * I + tid] = s;
+    } else if (!diag) {
+        const int c = tid - SYM_TB;
+        double s = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+            for (int aa = 0; aa < 8; ++aa) s += L.tsh[ww][aa][c];
+        Pout[(size_t)I * q + SYM_TB * J + c] = s;
+    }
+}
+
+// g = XX vec as NBLK partial vectors (Lanczos): P[slot][q]; symgemv_sum_kernel adds the slots in slot order
+template <int NBLK>
+__global__ __launch_bounds__(256, 2) void symgemv_kernel(const double *__restrict__ xx, const double *__restrict__ vec, double *__restrict__ P)
+{
+    constexpr int q = SYM_TB * NBLK;
+    __shared__ __attribute__((aligned(16))) SymLds L;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, a = lane >> 3, bb = lane & 7;
+    int I, J; bool diag;
+    sym_block(blockIdx.x, NBLK, I, J, diag);
+    const double mine = vec[tid < SYM_TB ? SYM_TB * I + tid : SYM_TB * J + (tid - SYM_TB)];
+    SymTile T;
+    sym_load(T, xx, q, I, J, w, a, bb);
+    L.bsh[tid] = mine;
+    __syncthreads();
+    sym_products(T, L, P, q, I, J, diag, tid, w, a, bb);
+}
+
+template <int NBLK>
+__global__ __launch_bounds__(128) void symgemv_sum_kernel(const double *__restrict__ P, double *__restrict__ out)
+{
+    constexpr int q = SYM_TB * NBLK;
+    const int c = blockIdx.x * 128 + threadIdx.x;
+    double ps[NBLK];
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) ps[k] = P[(size_t)k * q + c];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) s += ps[k];
+    out[c] = s;
+}
+
+template <int NBLK>
+__global__ __launch_bounds__(256, 2) void oem_symfused_kernel(PathArgs A, FState *__restrict__ S, double *__restrict__ B,
+                                                               double *__restrict__ P, int *__restrict__ flags, int *__restrict__ fdone,
+                                                               int par, double d)
+{
+    constexpr int q = SYM_TB * NBLK;
+    __shared__ __attribute__((aligned(16))) SymLds L;
+    const int nl = A.nl, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, a = lane >> 3, bb = lane & 7;
+    int I, J; bool diag;
+    sym_block(blockIdx.x, NBLK, I, J, diag);
+    // ---- the head's loads first (they retire first): state, flags, this thread's coordinate of beta_t, XY, the penalty factor
+    // and the NBLK partial sums of g = XX beta_t
+    const FState st = S[par];
+    const int cm = tid < SYM_TB ? SYM_TB * I + tid : SYM_TB * J + (tid - SYM_TB);
+    const double *__restrict__ bin = B + (size_t)par * (q + 8);
+    double *__restrict__ bout = B + (size_t)(par ^ 1) * (q + 8);
+    const double *__restrict__ Pin = P + (size_t)par * NBLK * q;
+    int fl[FMAXB / 256];                                             // branch-free: a loop here would put a memory round trip in front of everything
+#pragma unroll
+    for (int k = 0; k < FMAXB / 256; ++k) { const int t = tid + 256 * k; fl[k] = flags[par * FMAXB + (t < (int)gridDim.x ? t : 0)]; }
+    const double bo = bin[cm], xyc = A.xy[cm], pfc = A.pf[cm];
+    double ps[NBLK];
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) ps[k] = Pin[(size_t)k * q + cm];
+    // ---- then the block itself: it streams in while the head computes
+    SymTile T;
+    sym_load(T, A.xx, q, I, J, w, a, bb);
+    if (st.done) {                                                  // the launch after the last one: make both copies agree
+        if (blockIdx.x == 0 && tid == 0) { S[par ^ 1].done = 1; *fdone = 1; }
+        return;
+    }
+    int f = 0;
+#pragma unroll
+    for (int k = 0; k < FMAXB / 256; ++k) f |= (tid + 256 * k < (int)gridDim.x) ? fl[k] : 0;
+    const int any = __syncthreads_or(f);
+    // ---- the replicated state transition (as oem_fused_kernel)
+    int pp = st.pp, i = st.i, it = st.it;
+    bool fresh = st.fresh != 0, finalize = false, done_now = false;
+    size_t kfin = 0;
+    int niter_fin = 0;
+    if (!fresh) {
+        const bool conv = !any;
+        if (conv || it >= A.maxit) {
+            finalize = true; kfin = (size_t)pp * nl + i; niter_fin = conv ? it : A.maxit + 1;     // ref src/oem_base.h:94-109
+            const int nlam = (A.penalty[pp] == OEMGPU_OLS) ? 1 : nl;
+            if (i + 1 < nlam) i = i + 1;
+            else if (pp + 1 < A.npen) { pp = pp + 1; i = 0; fresh = true; }
+            else done_now = true;
+            it = 0;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        FState nx; nx.pp = pp; nx.i = i; nx.it = it + 1; nx.done = done_now ? 1 : 0; nx.fresh = 0; nx.pad0 = nx.pad1 = nx.pad2 = 0;
+        S[par ^ 1] = nx;
+        if (finalize) { A.niter[kfin] = niter_fin; A.loss[kfin] = 1e99; }
+    }
+    if (finalize && diag && tid < SYM_TB) A.beta[kfin * q + cm] = bo;       // the diagonal workgroups own their block of beta
+    if (done_now) return;
+    // ---- beta_{t+1} of this thread's coordinate: g summed in slot order, u = d beta - g + XY, the operator, the stop rule
+    const int pen = A.penalty[pp];
+    const double scaley = A.yscale ? A.stats[1] : 1.0;
+    const PenK K = pen_consts(pen, A.lambda_out[(size_t)pp * nl + i] / scaley, d, A.alpha, A.gamma, A.tau);
+    const double rD = 1.0 / K.D, gammad = K.gamma * K.D, dmg = K.D - 1.0 / K.gamma, rdmg = 1.0 / dmg;
+    const double gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0, rdsc = 1.0 / dsc, rd = 1.0 / d;
+    double g = 0.0;
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) g += ps[k];
+    const double b0 = fresh ? 0.0 : bo;
+    const double u = (d * b0 - (fresh ? 0.0 : g)) + xyc;
+    const double tp = pfc * K.L;
+    double bn;
+    if (K.kind == K_SOFT) bn = cdiv(shrink(u, tp), K.D, rD);
+    else if (K.kind == K_MCP) {
+        const bool big = fabs(u) > gammad * tp;
+        bn = cdiv(big ? u : shrink(u, tp), big ? K.D : dmg, big ? rD : rdmg);
+    } else if (K.kind == K_SCAD) {
+        const double au = fabs(u);
+        const bool big = au > gammad * tp, mid = !big && au > (K.D + 1.0) * tp;
+        const double num = big ? u : (mid ? shrink(gm1 * u, K.gamma * tp) : shrink(u, tp));
+        bn = cdiv(num, mid ? dsc : K.D, mid ? rdsc : rD);
+    } else bn = cdiv(u, d, rd);
+    const double c = fabs(bn), qo = fabs(b0);
+    const bool cn = c > 1e-13, qn = qo > 1e-13;
+    const bool moving = (cn != qn) || (cn && qn && fabs(bn - b0) > A.tol * qo);
+    if (diag && tid < SYM_TB) bout[cm] = bn;
+    L.bsh[tid] = bn;
+    const int mv = __syncthreads_or(moving ? 1 : 0);                 // (also the barrier behind bsh)
+    if (tid == 0) flags[(par ^ 1) * FMAXB + blockIdx.x] = mv;
+    sym_products(T, L, P + (size_t)(par ^ 1) * NBLK * q, q, I, J, diag, tid, w, a, bb);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused iteration, replicated-update form (group penalties, accelerate, compute.loss, scale.factor; same q): what crosses
 // launches is u = d beta - XX beta + XY.  EVERY workgroup thresholds the whole u itself (q <= 4096 coordinates: a few
 // hundred nanoseconds, identical in every workgroup), applies the stop rule, takes the state transition at once, puts
@@ -804,13 +1029,17 @@ __global__ void fused_init_kernel(FState *S, int npen)
     S[0] = z; S[1] = z; S[1].done = 0;
 }
 
+static size_t sym_part_doubles(int p) { return (p % SYM_TB == 0 && p >= 2048 && p <= 4096) ? 2 * (size_t)(p / SYM_TB) * p + 16 : 0; }
+
 size_t path_large_work_doubles(int p, int nsteps)
 {
     (void)nsteps;
     // + fused engine: FState[2] (8 doubles), done word, beta[2][p+8], flags[2][FMAXB] ints
     // + replicated-update engine: GState[2] (16 doubles), u[2][p+8] (beta[2] shared with the fused engine)
     // + fused Lanczos: two copies each of v, v_prev, w
-    return (size_t)STATE_DBL + 5 * (size_t)(p + 8) + 2 * MAXL + 64 + 16 + 2 * (size_t)(p + 8) + FMAXB + 16 + 2 * (size_t)(p + 8) + 6 * (size_t)(p + 8);
+    // + symmetric-tile engine: the partial vectors P[2][p / 128][p] (p a multiple of 128, p >= 2048)
+    return (size_t)STATE_DBL + 5 * (size_t)(p + 8) + 2 * MAXL + 64 + 16 + 2 * (size_t)(p + 8) + FMAXB + 16 + 2 * (size_t)(p + 8) + 6 * (size_t)(p + 8) +
+           sym_part_doubles(p);
 }
 
 // host_scratch: pinned host memory (>= 8 KB)
@@ -840,6 +1069,18 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     const bool lz_full = (q == 512 || q == 1024 || q == 2048 || q == 4096) && (((uintptr_t)a.xx) & 15) == 0;
     double *LZ = T + 2 * MAXL + 64 + 16 + 2 * (size_t)(q + 8) + FMAXB + 16 + 2 * (size_t)(q + 8);
     double *Vc = LZ, *Vp = LZ + 2 * (size_t)(q + 8), *Wb = LZ + 4 * (size_t)(q + 8);
+    double *SP = LZ + 6 * (size_t)(q + 8);             // symmetric-tile engine: partial vectors P[2][q / 128][q]
+    // XX is symmetric: for q = 2048 / 4096 the products read its lower triangle only (symgemv_kernel, oem_symfused_kernel)
+    const bool sym_ok = (q == 2048 || q == 4096) && (((uintptr_t)a.xx) & 15) == 0 && !getenv("OEM_NO_SYM") && !getenv("OEM_NO_FUSED");
+    auto sym_gemv = [&](const double *vec, double *out) {
+        if (q == 2048) {
+            hipLaunchKernelGGL((symgemv_kernel<16>), dim3(sym_nwg(16)), dim3(256), 0, s, a.xx, vec, SP);
+            hipLaunchKernelGGL((symgemv_sum_kernel<16>), dim3(q / 128), dim3(128), 0, s, SP, out);
+        } else {
+            hipLaunchKernelGGL((symgemv_kernel<32>), dim3(sym_nwg(32)), dim3(256), 0, s, a.xx, vec, SP);
+            hipLaunchKernelGGL((symgemv_sum_kernel<32>), dim3(q / 128), dim3(128), 0, s, SP, out);
+        }
+    };
     void (*lzk)(const double *, int, int, double *, double *, double *, double *, int) = nullptr;
     if (lz_fused) {
         if (q <= 512) lzk = lz_full ? lanczos_fused_kernel<8, true> : lanczos_fused_kernel<8, false>;
@@ -860,8 +1101,11 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         for (int k = 0; k < chunk; ++k, ++m) {
             if (lz_fused) hipLaunchKernelGGL(lzk, dim3(lblocks), dim3(256), lsh, s, a.xx, q, m, Vc, Vp, Wb, T, m & 1);
             else {
-                int rc = launch_gemv(s, a.xx, q, v, w, nullptr, num_cu);
-                if (rc) return rc;
+                if (sym_ok) sym_gemv(v, w);
+                else {
+                    int rc = launch_gemv(s, a.xx, q, v, w, nullptr, num_cu);
+                    if (rc) return rc;
+                }
                 hipLaunchKernelGGL(lanczos_update_kernel, dim3(1), dim3(1024), 0, s, q, m, v, vp, w, T);
             }
         }
@@ -904,11 +1148,14 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         if (blocks > num_cu * 2) blocks = num_cu * 2;
         if (const char *e = getenv("OEM_FUSED_BLOCKS")) { const int b = atoi(e); if (b > 0) blocks = b < (q + 3) / 4 ? b : (q + 3) / 4; }   // experiment knob
         if (blocks > FMAXB) blocks = FMAXB;
+        const bool sym = sym_ok && sym_nwg(q / SYM_TB) <= FMAXB && !(q == 2048 && !getenv("OEM_SYM_2048"));
         hipLaunchKernelGGL(fused_init_kernel, dim3(1), dim3(1), 0, s, S, a.npen);
         auto enq = [&](int count) {
             for (int k = 0; k < count; ++k) {
                 const int par = k & 1;
-                if (q == 512) hipLaunchKernelGGL((oem_fused_kernel<8>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);
+                if (sym && q == 4096) hipLaunchKernelGGL((oem_symfused_kernel<32>), dim3(sym_nwg(32)), dim3(256), 0, s, a, S, Bv, SP, flags, fdone, par, d);
+                else if (sym) hipLaunchKernelGGL((oem_symfused_kernel<16>), dim3(sym_nwg(16)), dim3(256), 0, s, a, S, Bv, SP, flags, fdone, par, d);
+                else if (q == 512) hipLaunchKernelGGL((oem_fused_kernel<8>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);
                 else if (q == 1024) hipLaunchKernelGGL((oem_fused_kernel<16>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);
                 else if (q == 2048) hipLaunchKernelGGL((oem_fused_kernel<32>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);
                 else hipLaunchKernelGGL((oem_fused_kernel<64>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);

@@ -166,6 +166,51 @@ def test_fused_iteration_engine(oa, p):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("p", [2048, 4096])
+def test_symmetric_tile_engine(oa, p, monkeypatch):
+    """p = 2048 / 4096 with element-wise penalties (config 4's engine): every iteration reads only the LOWER TRIANGLE of XX --
+    128 x 128 blocks, both products of an off-diagonal block from one read, per-workgroup partial vectors reduced in slot order
+    at the head of the next launch (oem_symfused_kernel), the Lanczos products the same way (symgemv_kernel).  Against the
+    row-streaming engine that reads all of XX (OEM_NO_SYM=1: same iteration, other summation order), through several penalties
+    (fresh starts), maxit exhaustion, penalty factors, and -- p = 2048 -- against the oracle."""
+    import torch
+    rng = np.random.default_rng(p + 1)
+    n = 2 * p
+    x = rng.normal(size=(n, p)) * (1.0 + 0.5 * rng.uniform(size=p))
+    b = np.zeros(p); b[rng.choice(p, 20, replace=False)] = rng.uniform(-1, 1, 20)
+    y = x @ b + rng.normal(size=n)
+    xtx, xty = x.T @ x / n, x.T @ y / n
+    xd = torch.as_tensor(xtx, device="cuda")
+    pf = np.ones(p); pf[:5] = 0.0; pf[5:9] = 2.5
+    monkeypatch.setenv("OEM_SYM_2048", "1")
+    for kw in (dict(penalty=["lasso", "mcp", "scad.net", "ols"], alpha=0.6, gamma=3.5, nlambda=7, tol=1e-9, maxit=600, penalty_factor=pf),
+               dict(penalty=["lasso"], nlambda=5, tol=1e-13, maxit=4)):
+        monkeypatch.delenv("OEM_NO_SYM", raising=False)
+        sym = oa.oem_xtx(xd, xty, **kw)
+        monkeypatch.setenv("OEM_NO_SYM", "1")
+        row = oa.oem_xtx(xd, xty, **kw)
+        assert abs(sym["d"] - row["d"]) <= 1e-11 * row["d"]
+        for k in range(len(kw["penalty"])):
+            scale = max(1.0, float(np.abs(row["beta"][k]).max()))
+            assert np.abs(np.asarray(sym["beta"][k]) - np.asarray(row["beta"][k])).max() <= 1e-10 * scale, kw["penalty"][k]
+            assert np.abs(np.ravel(sym["niter"][k]).astype(int) - np.ravel(row["niter"][k]).astype(int)).max() <= 1, kw["penalty"][k]
+            assert np.allclose(sym["lambda"][k], row["lambda"][k], rtol=1e-13)
+        if kw["maxit"] == 4:
+            assert sym["niter"][0].max() == 5 and np.array_equal(sym["niter"][0], row["niter"][0])
+    monkeypatch.delenv("OEM_NO_SYM", raising=False)
+    a1 = oa.oem_xtx(xd, xty, penalty=["lasso", "mcp"], nlambda=5, tol=1e-9)
+    a2 = oa.oem_xtx(xd, xty, penalty=["lasso", "mcp"], nlambda=5, tol=1e-9)
+    assert all(np.array_equal(u, v) for u, v in zip(a1["beta"], a2["beta"])) and a1["d"] == a2["d"]      # fixed summation order: same bits
+    if p == 2048:
+        kw = dict(penalty=["lasso", "mcp"], nlambda=6, tol=1e-9, maxit=600)
+        fit = oa.oem_xtx(xd, xty, **kw)
+        ref = orc.fit_xtx(xtx, xty, d_override=fit["d"], **kw)
+        _cmp(fit, ref)
+        lam_max = np.linalg.eigvalsh(xtx)[-1]
+        assert abs(fit["d"] - 1.005 * lam_max) <= 1e-10 * lam_max
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("p", [512, 300, 257])
 def test_replicated_update_fused_engine(oa, p):
     """p > 256 with group penalties / accelerate / compute.loss / scale.factor (and any p that is not 512 / 1024 / 2048 / 4096):
