@@ -129,8 +129,10 @@ def self_launch(a, argv):
         print(f"bench.py: --gpus {a.gpus} asked for, but this node shows {ndev} GPU(s): nothing run", file=sys.stderr)
         sys.exit(2)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), str(Path(__file__).resolve())] + list(argv)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+           "--master-port", str(_free_port()), str(Path(__file__).resolve())]
+    # the options travel in the environment: torch.distributed.run's own parser trips over script options it can prefix-match
+    # (`--n` is "ambiguous" between --nnodes, --nproc-per-node, ...) even behind the script's path
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", OEM_BENCH_ARGV=json.dumps(list(argv)))
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
@@ -247,12 +249,15 @@ def main():
     ap.add_argument("--no-rccl-check", action="store_true", help="N = 1: skip the one-rank RCCL self-check (process group of world size 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU baseline sample (0 = the full workload)")
-    a = ap.parse_args()
+    argv = sys.argv[1:]
+    if not argv and "OEM_BENCH_ARGV" in os.environ and "WORLD_SIZE" in os.environ:      # a worker of self_launch()
+        argv = json.loads(os.environ["OEM_BENCH_ARGV"])
+    a = ap.parse_args(argv)
     if a.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
         sys.exit(2)
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        self_launch(a, sys.argv[1:])             # never returns; this process has made no GPU call
+        self_launch(a, argv)                     # never returns; this process has made no GPU call
 
     import torch
     import torch.distributed as dist

@@ -612,6 +612,9 @@ __global__ __launch_bounds__(256) void oem_fused_kernel(PathArgs A, FState *__re
 //              partials by the heads (L2 / Infinity Cache hits: the buffer is 1 MB).
 // ------------------------------------------------------------------------------------------------
 static const int SYM_TB = 128;
+#ifndef OEM_SYM_MINWG
+#define OEM_SYM_MINWG 2          // workgroups per CU the symmetric-tile kernels are compiled for (3 spills: 168 VGPRs do not hold both halves of a block)
+#endif
 __host__ __device__ static inline int sym_nwg(int nblk) { return nblk * (nblk - 1) / 2 + nblk; }
 
 // block (I, J) of workgroup b: the nblk (nblk - 1) / 2 off-diagonal ones first (b = I (I - 1) / 2 + J), then the diagonal ones
@@ -626,15 +629,18 @@ __device__ __forceinline__ void sym_block(int b, int nblk, int &I, int &J, bool 
     I = i; J = b - i * (i - 1) / 2;
 }
 
-struct SymTile { v2d t[4][8]; };
+// half a block per lane: the 4 row groups x 4 of the 8 column groups (16 loads of 16 B); a block is loaded as two halves so that
+// three workgroups fit a CU (<= 168 VGPRs): all nblk (nblk + 1) / 2 workgroups of a launch are then resident at once (528 at
+// q = 4096 against 768 slots -- with two per CU the last 16 waited for a second round)
+struct SymHalf { v2d t[4][4]; };
 
-__device__ __forceinline__ void sym_load(SymTile &T, const double *__restrict__ xx, int q, int I, int J, int w, int a, int bb)
+__device__ __forceinline__ void sym_load(SymHalf &T, const double *__restrict__ xx, int q, int I, int J, int w, int a, int bb, int half)
 {
-    const double *tp = xx + (size_t)(SYM_TB * I + 32 * w + a) * q + SYM_TB * J + 2 * bb;
+    const double *tp = xx + (size_t)(SYM_TB * I + 32 * w + a) * q + SYM_TB * J + 64 * half + 2 * bb;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int h = 0; h < 8; ++h) T.t[g][h] = *reinterpret_cast<const v2d *>(tp + (size_t)(8 * g) * q + 16 * h);
+        for (int h = 0; h < 4; ++h) T.t[g][h] = *reinterpret_cast<const v2d *>(tp + (size_t)(8 * g) * q + 16 * h);
 }
 
 // the two products of a block with bsh[0..127] = vec_I, bsh[128..255] = vec_J, combined over lanes and waves in LDS, stored as
@@ -644,33 +650,27 @@ struct SymLds {
     double dsh[SYM_TB][9];
     double tsh[4][8][SYM_TB + 16];
 };
-__device__ __forceinline__ void sym_products(const SymTile &T, SymLds &L, double *__restrict__ Pout, int q, int I, int J, bool diag,
-                                             int tid, int w, int a, int bb)
+__device__ __forceinline__ void sym_half_products(const SymHalf &T, SymLds &L, double (&ds)[4], const double (&bi)[4], bool diag,
+                                                  int w, int a, int bb, int half)
 {
-    double bi[4];
-    v2d bj[8];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bi[g] = L.bsh[32 * w + 8 * g + a];
+    for (int h = 0; h < 4; ++h) {
+        const v2d bj = *reinterpret_cast<const v2d *>(&L.bsh[SYM_TB + 64 * half + 16 * h + 2 * bb]);
 #pragma unroll
-    for (int h = 0; h < 8; ++h) bj[h] = *reinterpret_cast<const v2d *>(&L.bsh[SYM_TB + 16 * h + 2 * bb]);
-    double ds[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int g = 0; g < 4; ++g) { ds[g] = fma(T.t[g][h].x, bj.x, ds[g]); ds[g] = fma(T.t[g][h].y, bj.y, ds[g]); }
+        if (!diag) {
+            v2d ts; ts.x = 0.0; ts.y = 0.0;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int h = 0; h < 8; ++h) { ds[g] = fma(T.t[g][h].x, bj[h].x, ds[g]); ds[g] = fma(T.t[g][h].y, bj[h].y, ds[g]); }
+            for (int g = 0; g < 4; ++g) { ts.x = fma(T.t[g][h].x, bi[g], ts.x); ts.y = fma(T.t[g][h].y, bi[g], ts.y); }
+            *reinterpret_cast<v2d *>(&L.tsh[w][a][64 * half + 16 * h + 2 * bb]) = ts;
+        }
+    }
+}
+__device__ __forceinline__ void sym_combine(SymLds &L, const double (&ds)[4], double *__restrict__ Pout, int q, int I, int J, bool diag,
+                                            int tid, int w, int a, int bb)
+{
 #pragma unroll
     for (int g = 0; g < 4; ++g) L.dsh[32 * w + 8 * g + a][bb] = ds[g];
-    if (!diag) {
-        v2d ts[8];
-#pragma unroll
-        for (int h = 0; h < 8; ++h) { ts[h].x = 0.0; ts[h].y = 0.0; }
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int h = 0; h < 8; ++h) { ts[h].x = fma(T.t[g][h].x, bi[g], ts[h].x); ts[h].y = fma(T.t[g][h].y, bi[g], ts[h].y); }
-#pragma unroll
-        for (int h = 0; h < 8; ++h) *reinterpret_cast<v2d *>(&L.tsh[w][a][16 * h + 2 * bb]) = ts[h];
-    }
     __syncthreads();
     if (tid < SYM_TB) {
         double s = 0.0;
@@ -690,7 +690,7 @@ __device__ __forceinline__ void sym_products(const SymTile &T, SymLds &L, double
 
 // g = XX vec as NBLK partial vectors (Lanczos): P[slot][q]; symgemv_sum_kernel adds the slots in slot order
 template <int NBLK>
-__global__ __launch_bounds__(256, 2) void symgemv_kernel(const double *__restrict__ xx, const double *__restrict__ vec, double *__restrict__ P)
+__global__ __launch_bounds__(256, OEM_SYM_MINWG) void symgemv_kernel(const double *__restrict__ xx, const double *__restrict__ vec, double *__restrict__ P)
 {
     constexpr int q = SYM_TB * NBLK;
     __shared__ __attribute__((aligned(16))) SymLds L;
@@ -698,11 +698,17 @@ __global__ __launch_bounds__(256, 2) void symgemv_kernel(const double *__restric
     int I, J; bool diag;
     sym_block(blockIdx.x, NBLK, I, J, diag);
     const double mine = vec[tid < SYM_TB ? SYM_TB * I + tid : SYM_TB * J + (tid - SYM_TB)];
-    SymTile T;
-    sym_load(T, xx, q, I, J, w, a, bb);
+    SymHalf T0, T1;
+    sym_load(T0, xx, q, I, J, w, a, bb, 0);
+    sym_load(T1, xx, q, I, J, w, a, bb, 1);
     L.bsh[tid] = mine;
     __syncthreads();
-    sym_products(T, L, P, q, I, J, diag, tid, w, a, bb);
+    double bi[4], ds[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bi[g] = L.bsh[32 * w + 8 * g + a];
+    sym_half_products(T0, L, ds, bi, diag, w, a, bb, 0);
+    sym_half_products(T1, L, ds, bi, diag, w, a, bb, 1);
+    sym_combine(L, ds, P, q, I, J, diag, tid, w, a, bb);
 }
 
 template <int NBLK>
@@ -719,8 +725,36 @@ __global__ __launch_bounds__(128) void symgemv_sum_kernel(const double *__restri
     out[c] = s;
 }
 
+// State of the symmetric-tile engine.  The head of a launch sits in front of its products, so what it needs must be ONE load away:
+// the penalty code and lambda of the position (pp, i) AND of its successor travel inside the state (written by whoever advances
+// the position, off everybody else's path), and so does scale(y) -- no load that depends on another load (the row-streaming
+// kernel thresholds at the end of a row and can afford penalty[pp] -> lambda[pp][i] chains).
+struct SState {
+    int pp, i, it, done, fresh, pen, pen_next, pad;
+    double lam, lam_next, scaley, pad2;
+};
+__device__ __forceinline__ void sym_successor(const PathArgs &A, int pp, int i, int pen, int &pen_next, double &lam_next)
+{
+    const int nlam = (pen == OEMGPU_OLS) ? 1 : A.nl;
+    int sp = -1, si = 0;
+    if (i + 1 < nlam) { sp = pp; si = i + 1; }
+    else if (pp + 1 < A.npen) { sp = pp + 1; si = 0; }
+    pen_next = sp >= 0 ? A.penalty[sp] : 0;
+    lam_next = sp >= 0 ? A.lambda_out[(size_t)sp * A.nl + si] : 0.0;
+}
+__global__ void sym_init_kernel(SState *S, PathArgs A)
+{
+    SState z;
+    z.pp = 0; z.i = 0; z.it = 0; z.done = (A.npen == 0) ? 1 : 0; z.fresh = 1; z.pad = 0; z.pad2 = 0.0;
+    z.pen = A.npen > 0 ? A.penalty[0] : 0; z.lam = A.npen > 0 ? A.lambda_out[0] : 0.0;
+    z.scaley = A.yscale ? A.stats[1] : 1.0;
+    z.pen_next = 0; z.lam_next = 0.0;
+    if (A.npen > 0) sym_successor(A, 0, 0, z.pen, z.pen_next, z.lam_next);
+    S[0] = z; S[1] = z; S[1].done = 0;
+}
+
 template <int NBLK>
-__global__ __launch_bounds__(256, 2) void oem_symfused_kernel(PathArgs A, FState *__restrict__ S, double *__restrict__ B,
+__global__ __launch_bounds__(256, OEM_SYM_MINWG) void oem_symfused_kernel(PathArgs A, SState *__restrict__ S, double *__restrict__ B,
                                                                double *__restrict__ P, int *__restrict__ flags, int *__restrict__ fdone,
                                                                int par, double d)
 {
@@ -731,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void oem_symfused_kernel(PathArgs A, FState
     sym_block(blockIdx.x, NBLK, I, J, diag);
     // ---- the head's loads first (they retire first): state, flags, this thread's coordinate of beta_t, XY, the penalty factor
     // and the NBLK partial sums of g = XX beta_t
-    const FState st = S[par];
+    const SState st = S[par];
     const int cm = tid < SYM_TB ? SYM_TB * I + tid : SYM_TB * J + (tid - SYM_TB);
     const double *__restrict__ bin = B + (size_t)par * (q + 8);
     double *__restrict__ bout = B + (size_t)(par ^ 1) * (q + 8);
@@ -743,9 +777,9 @@ __global__ __launch_bounds__(256, 2) void oem_symfused_kernel(PathArgs A, FState
     double ps[NBLK];
 #pragma unroll
     for (int k = 0; k < NBLK; ++k) ps[k] = Pin[(size_t)k * q + cm];
-    // ---- then the block itself: it streams in while the head computes
-    SymTile T;
-    sym_load(T, A.xx, q, I, J, w, a, bb);
+    // ---- then the first half of the block: it streams in while the head computes
+    SymHalf T0, T1;
+    sym_load(T0, A.xx, q, I, J, w, a, bb, 0);
     if (st.done) {                                                  // the launch after the last one: make both copies agree
         if (blockIdx.x == 0 && tid == 0) { S[par ^ 1].done = 1; *fdone = 1; }
         return;
@@ -755,32 +789,34 @@ __global__ __launch_bounds__(256, 2) void oem_symfused_kernel(PathArgs A, FState
     for (int k = 0; k < FMAXB / 256; ++k) f |= (tid + 256 * k < (int)gridDim.x) ? fl[k] : 0;
     const int any = __syncthreads_or(f);
     // ---- the replicated state transition (as oem_fused_kernel)
-    int pp = st.pp, i = st.i, it = st.it;
-    bool fresh = st.fresh != 0, finalize = false, done_now = false;
+    int pp = st.pp, i = st.i, it = st.it, pen = st.pen;
+    double lam = st.lam;
+    bool fresh = st.fresh != 0, finalize = false, done_now = false, advanced = false;
     size_t kfin = 0;
     int niter_fin = 0;
     if (!fresh) {
         const bool conv = !any;
         if (conv || it >= A.maxit) {
             finalize = true; kfin = (size_t)pp * nl + i; niter_fin = conv ? it : A.maxit + 1;     // ref src/oem_base.h:94-109
-            const int nlam = (A.penalty[pp] == OEMGPU_OLS) ? 1 : nl;
-            if (i + 1 < nlam) i = i + 1;
-            else if (pp + 1 < A.npen) { pp = pp + 1; i = 0; fresh = true; }
+            const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
+            if (i + 1 < nlam) { i = i + 1; advanced = true; }
+            else if (pp + 1 < A.npen) { pp = pp + 1; i = 0; fresh = true; advanced = true; }
             else done_now = true;
+            if (advanced) { pen = st.pen_next; lam = st.lam_next; }
             it = 0;
         }
     }
     if (blockIdx.x == 0 && tid == 0) {
-        FState nx; nx.pp = pp; nx.i = i; nx.it = it + 1; nx.done = done_now ? 1 : 0; nx.fresh = 0; nx.pad0 = nx.pad1 = nx.pad2 = 0;
+        SState nx = st;
+        nx.pp = pp; nx.i = i; nx.it = it + 1; nx.done = done_now ? 1 : 0; nx.fresh = 0; nx.pen = pen; nx.lam = lam;
+        if (advanced) sym_successor(A, pp, i, pen, nx.pen_next, nx.lam_next);      // two dependent loads, on nobody else's path
         S[par ^ 1] = nx;
         if (finalize) { A.niter[kfin] = niter_fin; A.loss[kfin] = 1e99; }
     }
     if (finalize && diag && tid < SYM_TB) A.beta[kfin * q + cm] = bo;       // the diagonal workgroups own their block of beta
     if (done_now) return;
     // ---- beta_{t+1} of this thread's coordinate: g summed in slot order, u = d beta - g + XY, the operator, the stop rule
-    const int pen = A.penalty[pp];
-    const double scaley = A.yscale ? A.stats[1] : 1.0;
-    const PenK K = pen_consts(pen, A.lambda_out[(size_t)pp * nl + i] / scaley, d, A.alpha, A.gamma, A.tau);
+    const PenK K = pen_consts(pen, lam / st.scaley, d, A.alpha, A.gamma, A.tau);
     const double rD = 1.0 / K.D, gammad = K.gamma * K.D, dmg = K.D - 1.0 / K.gamma, rdmg = 1.0 / dmg;
     const double gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0, rdsc = 1.0 / dsc, rd = 1.0 / d;
     double g = 0.0;
@@ -803,11 +839,17 @@ __global__ __launch_bounds__(256, 2) void oem_symfused_kernel(PathArgs A, FState
     const double c = fabs(bn), qo = fabs(b0);
     const bool cn = c > 1e-13, qn = qo > 1e-13;
     const bool moving = (cn != qn) || (cn && qn && fabs(bn - b0) > A.tol * qo);
+    sym_load(T1, A.xx, q, I, J, w, a, bb, 1);                        // the partial sums' registers are free again: the second half
     if (diag && tid < SYM_TB) bout[cm] = bn;
     L.bsh[tid] = bn;
     const int mv = __syncthreads_or(moving ? 1 : 0);                 // (also the barrier behind bsh)
     if (tid == 0) flags[(par ^ 1) * FMAXB + blockIdx.x] = mv;
-    sym_products(T, L, P + (size_t)(par ^ 1) * NBLK * q, q, I, J, diag, tid, w, a, bb);
+    double bi[4], ds[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bi[g] = L.bsh[32 * w + 8 * g + a];
+    sym_half_products(T0, L, ds, bi, diag, w, a, bb, 0);
+    sym_half_products(T1, L, ds, bi, diag, w, a, bb, 1);
+    sym_combine(L, ds, P + (size_t)(par ^ 1) * NBLK * q, q, I, J, diag, tid, w, a, bb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1149,12 +1191,15 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         if (const char *e = getenv("OEM_FUSED_BLOCKS")) { const int b = atoi(e); if (b > 0) blocks = b < (q + 3) / 4 ? b : (q + 3) / 4; }   // experiment knob
         if (blocks > FMAXB) blocks = FMAXB;
         const bool sym = sym_ok && sym_nwg(q / SYM_TB) <= FMAXB && !(q == 2048 && !getenv("OEM_SYM_2048"));
-        hipLaunchKernelGGL(fused_init_kernel, dim3(1), dim3(1), 0, s, S, a.npen);
+        SState *SS = reinterpret_cast<SState *>(SP + 2 * (size_t)(q / SYM_TB) * q);      // behind the partial vectors (sym_part_doubles)
+        static_assert(2 * sizeof(SState) <= 16 * sizeof(double), "SState[2] must fit the 16 spare doubles of the partial area");
+        if (sym) hipLaunchKernelGGL(sym_init_kernel, dim3(1), dim3(1), 0, s, SS, a);
+        else hipLaunchKernelGGL(fused_init_kernel, dim3(1), dim3(1), 0, s, S, a.npen);
         auto enq = [&](int count) {
             for (int k = 0; k < count; ++k) {
                 const int par = k & 1;
-                if (sym && q == 4096) hipLaunchKernelGGL((oem_symfused_kernel<32>), dim3(sym_nwg(32)), dim3(256), 0, s, a, S, Bv, SP, flags, fdone, par, d);
-                else if (sym) hipLaunchKernelGGL((oem_symfused_kernel<16>), dim3(sym_nwg(16)), dim3(256), 0, s, a, S, Bv, SP, flags, fdone, par, d);
+                if (sym && q == 4096) hipLaunchKernelGGL((oem_symfused_kernel<32>), dim3(sym_nwg(32)), dim3(256), 0, s, a, SS, Bv, SP, flags, fdone, par, d);
+                else if (sym) hipLaunchKernelGGL((oem_symfused_kernel<16>), dim3(sym_nwg(16)), dim3(256), 0, s, a, SS, Bv, SP, flags, fdone, par, d);
                 else if (q == 512) hipLaunchKernelGGL((oem_fused_kernel<8>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);
                 else if (q == 1024) hipLaunchKernelGGL((oem_fused_kernel<16>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);
                 else if (q == 2048) hipLaunchKernelGGL((oem_fused_kernel<32>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);
