@@ -245,7 +245,7 @@ enum { SEM_XTX = 2, SEM_SPARSE = 4 };        // OEMGPU_SEM_XVAL = 3 (oemgpu.h): 
 int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const double *stats, int p, int q, int sem,
               int standardize, int intercept, const oemgpu_opts *o, const double *scale_factor,
               double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out,
-              int nbatch = 1, size_t bstride = 0, bool shared_lmax = false)
+              int nbatch = 1, size_t bstride = 0, bool shared_lmax = false, const WideArgs *wide = nullptr)
 {
     const int nl = nl_of(o), npen = o->npen;
     const bool user = o->lambda_user && o->nlambda_user > 0;
@@ -280,9 +280,10 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const size_t out_stride = (out_bytes + 255) / 256 * 256;
     const bool loss_on = (sem == OEMGPU_SEM_DENSE || sem == OEMGPU_SEM_XVAL || sem == SEM_SPARSE) && o->compute_loss != 0;
     // several instances (xval.oem's K + 1 fits) on the cooperating engine: only if all their workgroup sets are resident at once
-    const bool coop = path_coop_eligible(q, scale_factor != nullptr, loss_on, og.ngroups, nbatch) &&
+    // wide != nullptr: the p >= n iteration through the standardised X itself (xx == nullptr: there is no Gram matrix)
+    const bool coop = !wide && path_coop_eligible(q, scale_factor != nullptr, loss_on, og.ngroups, nbatch) &&
                       (nbatch == 1 || path_coop_workgroups(q) * nbatch <= c->num_cu * 3 / 4);
-    const bool small = q <= SMALL_P_MAX && !coop;
+    const bool small = !wide && q <= SMALL_P_MAX && !coop;
     if (nbatch > 1 && !small && !coop) { set_error("internal: batched paths need p <= %d", SMALL_P_MAX); return OEMGPU_ERR_INTERNAL; }
     // Lanczos step cap: q up to 288 (the whole Krylov space: the recurrence stops by itself when the top Ritz value has settled, and
     // a spectrum that needs more than 128 steps gets them -- ADVICE r1); the large-p engines keep their own caps (256 / 512)
@@ -299,9 +300,10 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const size_t a_out = B.take(out_stride * nbatch), a_blob = B.take(bl.h.size()),
                  a_work = B.take(work_d * sizeof(double) * nbatch * (pen_split ? npen : 1));
     // the workspace may be re-allocated by ctx_reserve: xx/xy/stats are offsets into it, so recompute after
-    const size_t off_xx = (const char *)xx - c->ws, off_xy = (const char *)xy - c->ws, off_st = (const char *)stats - c->ws;
+    const size_t off_xx = xx ? (const char *)xx - c->ws : 0, off_xy = (const char *)xy - c->ws, off_st = (const char *)stats - c->ws;
     if (B.off > c->ws_bytes) { set_error("internal: workspace under-reserved (%zu > %zu)", B.off, c->ws_bytes); return OEMGPU_ERR_INTERNAL; }
-    xx = (const double *)(c->ws + off_xx); xy = (const double *)(c->ws + off_xy); stats = (const double *)(c->ws + off_st);
+    if (xx) xx = (const double *)(c->ws + off_xx);
+    xy = (const double *)(c->ws + off_xy); stats = (const double *)(c->ws + off_st);
     (void)a_blob;                                     // (the frame keeps its slot; the blob itself lives in a buffer of its own)
     // its own grow-only buffer, not the workspace: the Gram partials of the NEXT call overlay this frame, and a blob that survives
     // between calls is what lets run_paths skip an identical upload
@@ -355,7 +357,8 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     {
         Timer t(c, OEMGPU_T_EIGPATH);
         PollScope poll(o);
-        int rc = small ? launch_path_small(c->stream, a) : (coop ? launch_path_coop(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned));
+        int rc = wide ? run_path_wide(c->stream, a, *wide, (double *)c->pinned)
+                      : small ? launch_path_small(c->stream, a) : (coop ? launch_path_coop(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned));
         if (rc) return rc;
     }
     HT(2);
@@ -632,6 +635,46 @@ int oemgpu_solve_moments_dev(oemgpu_ctx *c, const double *moments_dev, const dou
     return run_paths(c, B2, xx, xy, st, p, q, semantics, standardize, intercept, o, nullptr, beta, lambda_out, niter, loss, d);
 }
 
+// p >= n.  The reference switches to its two-GEMV iteration when nobs <= nvars (ref src/oem_dense.h:476-482); here that form is
+// taken where it pays: the Gram form (same iteration, p^2 doubles read per iteration and held in memory) wins while p fits the
+// register / cooperating engines (p <= 1024: ~1 us per iteration, no launch per iteration) and while 2 n p >= p^2; beyond, the
+// wide engine reads 8 n p bytes per iteration and needs no p x p matrix (p = 20,000: 80 MB of Xs instead of 3.2 GB).
+// OEM_WIDE=1 forces it wherever it can run (tests), OEM_NO_WIDE=1 switches it off.
+static bool wide_pays(int64_t n, int32_t p)
+{
+    if (n > p || n > WIDE_MAX_N || wide_workgroups(p) > 1024) return false;
+    if (getenv("OEM_NO_WIDE")) return false;
+    if (getenv("OEM_WIDE")) return true;
+    return p > 1024 && 2 * n < p;
+}
+
+static int fit_dense_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
+                              int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                              double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    const int64_t npad = wide_npad((int)n);
+    Bump X;
+    const size_t a_xs = X.take(sizeof(double) * (size_t)npad * p), a_ys = X.take(sizeof(double) * (size_t)npad),
+                 a_sc = X.take(sizeof(double) * wide_scratch_doubles((int)n, p));
+    if (ctx_grow(c, &c->aux, &c->aux_bytes, X.off)) return OEMGPU_ERR_HIP;
+    Bump B;
+    const size_t a_xy = B.take((size_t)p * 8), a_st = B.take((size_t)stats_len(p) * 8);       // stats last: run_paths returns it with the outputs
+    if (ctx_reserve(c, B.off + paths_ws_bytes(p, p, o) + 4096)) return OEMGPU_ERR_HIP;
+    double *xs = (double *)(c->aux + a_xs), *ys = (double *)(c->aux + a_ys);
+    double *xy = (double *)(c->ws + a_xy), *st = (double *)(c->ws + a_st);
+    int rc;
+    {
+        Timer t(c, OEMGPU_T_MOMENTS);             // the stage that reads X: DataStd on the data (the standardised copy, X'Y / n)
+        rc = launch_wide_standardize(c->stream, x_dev, n, ld, p, y_dev, standardize, intercept, npad, xs, ys, xy, st);
+        if (rc) return rc;
+    }
+    WideArgs wd;
+    wd.xs = xs; wd.ys = ys; wd.npad = npad; wd.n = (int)n; wd.scratch = (double *)(c->aux + a_sc);
+    return run_paths(c, B, nullptr, xy, st, p, p, OEMGPU_SEM_DENSE, standardize, intercept, o, nullptr, beta, lambda_out, niter, loss, d,
+                     1, 0, false, &wd);
+}
+
 int oemgpu_fit_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
                          int32_t standardize, int32_t intercept, const oemgpu_opts *o,
                          double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
@@ -641,8 +684,10 @@ int oemgpu_fit_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t 
     int rc = check_opts(o, p, p);
     if (rc) return rc;
     if (n < 1 || ld < n) { set_error("fit_dense: bad n / ld"); return OEMGPU_ERR_ARG; }
-    // p >= n (ref src/oem_dense.h:476-482,513-521: d from XXt / n, u = X'(Y - X b)/n + d b) is served by the same Gram
-    // form: the non-zero spectra of XXt and XtX coincide and X'(Y - X b)/n + d b = (dI - X'X/n) b + X'Y/n.
+    // p >= n (ref src/oem_dense.h:476-482,513-521: d from XXt / n, u = X'(Y - X b)/n + d b): the reference's own form where it
+    // pays (wide_pays), else the same iteration on the Gram: the non-zero spectra of XXt and XtX coincide and
+    // X'(Y - X b)/n + d b = (dI - X'X/n) b + X'Y/n.
+    if (wide_pays(n, p)) return fit_dense_wide_dev(c, x_dev, n, ld, p, y_dev, standardize, intercept, o, beta, lambda_out, niter, loss, d);
     if (set_device(c)) return OEMGPU_ERR_HIP;
     const GramPlan pl = gram_plan(n, p, c->num_cu);
     Bump B;
@@ -763,8 +808,19 @@ int oemgpu_fit_dense(const double *x, int64_t n, int32_t p, const double *y, int
     int rc = check_opts(o, p, p);
     if (rc) return rc;
     if (n < 1) { set_error("fit_dense: bad n"); return OEMGPU_ERR_ARG; }
-    // p >= n (ref src/oem_dense.h:476-482,513-521: d from XXt / n, u = X'(Y - X b)/n + d b) is served by the same Gram
-    // form: the non-zero spectra of XXt and XtX coincide and X'(Y - X b)/n + d b = (dI - X'X/n) b + X'Y/n.
+    // p >= n (ref src/oem_dense.h:476-482,513-521): where the reference's two-GEMV form pays (wide_pays) the rows go up once and the
+    // wide engine iterates through the standardised copy -- no (p+2)^2 moment buffer; otherwise the same iteration on the Gram.
+    if (wide_pays(n, p) && o->ngpus <= 1) {
+        oemgpu_ctx *c = ctx_acquire(o->device);
+        if (!c) return OEMGPU_ERR_NO_DEVICE;
+        double *xd = nullptr, *yd = nullptr;
+        int64_t ld = 0;
+        rc = host_upload_resident(c, x, n, p, y, o, &xd, &ld, &yd);
+        if (!rc) rc = fit_dense_wide_dev(c, xd, n, ld, p, yd, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+        (void)hipStreamSynchronize(c->stream);
+        ctx_release(c);
+        return rc;
+    }
     return host_fit_dense(x, n, p, y, standardize, intercept, o, beta, lambda_out, niter, loss, d);
 }
 

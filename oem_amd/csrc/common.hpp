@@ -150,6 +150,24 @@ int path_coop_workgroups(int q);
 size_t path_coop_xchg_bytes();
 int launch_path_coop(hipStream_t s, const PathArgs &a);
 
+// ------------------------------------------------------------------ p >= n (wide.hip, path_large.hip: run_path_wide)
+// The reference's own iteration for p >= n: no Gram, two products with the standardised X per iteration
+// (ref src/oem_dense.h:363-366, 476-482, 513-521).  xs: npad x p column-major (npad = n rounded up to 64, padding rows zero).
+struct WideArgs {
+    const double *xs;        // standardised X
+    const double *ys;        // standardised y, npad entries (padding zero)
+    long long npad;
+    int n;
+    double *scratch;         // wide_scratch_doubles(n, p) doubles
+};
+static const int WIDE_MAX_N = 2048;          // the columns of xs live in registers: 64 lanes x 32 rows each
+int wide_workgroups(int p);
+int wide_npad(int n);                       // rows of the standardised copy: n rounded up to the kernels' 64 NR
+size_t wide_scratch_doubles(int n, int p);
+int launch_wide_standardize(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, int standardize, int intercept,
+                            int64_t npad, double *xs, double *ys, double *xy, double *stats);
+int run_path_wide(hipStream_t s, const PathArgs &a, const WideArgs &w, double *host_scratch);
+
 // opts->interrupt of the call in progress on this thread (api.hip: run_paths sets it around the engines); false if none
 bool caller_interrupted();
 

@@ -1338,4 +1338,344 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     return rc;
 }
 
+// ================================================================================================
+// p >= n: the reference's own iteration, without a Gram matrix (ref src/oem_dense.h:363-366, 476-482, 513-521):
+//     u = Xs'(Ys - Xs beta)/n + d beta,      d = 1.005 lambda_max(Xs Xs'/n)
+// Xs is the standardised copy (wide.hip): npad x p column-major, npad = 64 NR, padding rows zero.  A column is 8 n bytes and
+// coordinate-local: ONE read of Xs per iteration does both products --
+//   wide_cols_kernel<NR, W_OEM>   a wave owns columns j, j + 4, ...: x_j in registers (NR per lane), u_j = x_j . r / n + d beta_j
+//                                 (wave sum), beta_j' = T(u_j) on the spot (the operator is coordinate-local), and the SAME
+//                                 registers feed r' += x_j beta_j' (lane-local; skipped when beta_j' = 0: sparse paths stream
+//                                 for the dot product only).  The workgroup's share of Xs beta' leaves as a partial vector.
+//   wide_reduce_kernel<W_OEM>     r' = Ys - sum of the partial vectors, in workgroup order (fixed order, no atomics).
+// 8 n p bytes per iteration where the reference's two GEMVs read 16 n p (and the Gram form 8 p^2).  Stop rule and lambda / penalty
+// bookkeeping replicated one launch later, state by launch parity, exactly as the symmetric-tile engine above.
+// Everything that needs the whole of u at once (group operators, Nesterov's step, compute.loss) runs the same two products as
+// separate launches around path_update_kernel: W_XB (Xs beta as partial vectors), the reduction, W_XTV (g = Xs' t / n).
+// The eigenvalue step is Lanczos on Xs Xs'/n with the same kernels (W_EIG: partial vectors of Xs (Xs' v)), n-vectors only.
+// ================================================================================================
+enum { W_EIG = 0, W_OEM = 1, W_XB = 2, W_XTV = 3 };
+
+int wide_workgroups(int p)
+{
+    int w = (p + 15) / 16;                               // >= 4 columns per wave where p allows
+    if (w > 512) w = 512;
+    return w < 1 ? 1 : w;
+}
+static int wide_nr(int n)
+{
+    static const int sizes[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+    const int need = (n + 63) / 64;
+    for (int v : sizes) if (v >= need) return v;
+    return 0;
+}
+// P[W][npad] | r | t | v | vp | w (npad each) | T[2 MAXL + 64] | SState[2] (16) | done (2) | flags[2][FMAXB] ints
+size_t wide_scratch_doubles(int n, int p)
+{
+    const size_t npad = 64 * (size_t)wide_nr(n);
+    return (size_t)wide_workgroups(p) * npad + 5 * npad + 2 * MAXL + 64 + 16 + 2 + FMAXB + 64;
+}
+
+template <int NR> __device__ __forceinline__ void wide_load(double (&x)[NR], const double *__restrict__ col, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < NR; ++k) x[k] = col[lane + 64 * k];
+}
+
+template <int NR, int MODE>
+__global__ __launch_bounds__(256) void wide_cols_kernel(PathArgs A, const double *__restrict__ xs, const double *__restrict__ rin,
+                                                         const double *__restrict__ ysv, double *__restrict__ P, double *__restrict__ beta,
+                                                         double *__restrict__ outv, SState *__restrict__ S, int *__restrict__ flags,
+                                                         int *__restrict__ fdone, const int *__restrict__ done, int par, double d,
+                                                         int n, int cpw)
+{
+    extern __shared__ __attribute__((aligned(16))) double wsh[];     // [4][64 NR]
+    constexpr int NP = 64 * NR;
+    const int q = A.p, nl = A.nl, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int jbeg = blockIdx.x * cpw, jend = (jbeg + cpw < q) ? jbeg + cpw : q;
+    const double rn = 1.0 / (double)n;
+    // ---- head (W_OEM): state, flags -- one load away from the launch (SState carries the penalty code and lambda)
+    SState st;
+    int fl[FMAXB / 256];
+    if (MODE == W_OEM) {
+        st = S[par];
+#pragma unroll
+        for (int k = 0; k < FMAXB / 256; ++k) { const int t = tid + 256 * k; fl[k] = flags[par * FMAXB + (t < (int)gridDim.x ? t : 0)]; }
+    } else if (done && *done) return;
+    int j = jbeg + w;
+    double xc[NR];
+    if (MODE != W_XB && j < jend) wide_load<NR>(xc, xs + (size_t)j * NP, lane);
+    int pp = 0, i = 0, it = 0, pen = 0, niter_fin = 0;
+    double lam = 0.0;
+    bool fresh = false, finalize = false, done_now = false, advanced = false;
+    size_t kfin = 0;
+    if (MODE == W_OEM) {
+        if (st.done) {
+            if (blockIdx.x == 0 && tid == 0) { S[par ^ 1].done = 1; *fdone = 1; }
+            return;
+        }
+        int f = 0;
+#pragma unroll
+        for (int k = 0; k < FMAXB / 256; ++k) f |= (tid + 256 * k < (int)gridDim.x) ? fl[k] : 0;
+        const int any = __syncthreads_or(f);
+        pp = st.pp; i = st.i; it = st.it; pen = st.pen; lam = st.lam; fresh = st.fresh != 0;
+        if (!fresh) {
+            const bool conv = !any;
+            if (conv || it >= A.maxit) {
+                finalize = true; kfin = (size_t)pp * nl + i; niter_fin = conv ? it : A.maxit + 1;     // ref src/oem_base.h:94-109
+                const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
+                if (i + 1 < nlam) { i = i + 1; advanced = true; }
+                else if (pp + 1 < A.npen) { pp = pp + 1; i = 0; fresh = true; advanced = true; }
+                else done_now = true;
+                if (advanced) { pen = st.pen_next; lam = st.lam_next; }
+                it = 0;
+            }
+        }
+        if (blockIdx.x == 0 && tid == 0) {
+            SState nx = st;
+            nx.pp = pp; nx.i = i; nx.it = it + 1; nx.done = done_now ? 1 : 0; nx.fresh = 0; nx.pen = pen; nx.lam = lam;
+            if (advanced) sym_successor(A, pp, i, pen, nx.pen_next, nx.lam_next);
+            S[par ^ 1] = nx;
+            if (finalize) { A.niter[kfin] = niter_fin; A.loss[kfin] = 1e99; }
+        }
+        if (done_now) {                                             // only the last lambda's coefficients are left to store
+            for (int jj = jbeg + tid; jj < jend; jj += 256) A.beta[kfin * q + jj] = beta[jj];
+            return;
+        }
+    }
+    // ---- the n-vector this launch multiplies with (W_OEM: the residual; a fresh penalty starts from beta = 0, so r = Ys)
+    double rr[NR], rp[NR];
+    if (MODE != W_XB) wide_load<NR>(rr, (MODE == W_OEM && fresh) ? ysv : rin, lane);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) rp[k] = 0.0;
+    PenK K;
+    double rD = 0.0, gammad = 0.0, dmg = 0.0, rdmg = 0.0, gm1 = 0.0, dsc = 0.0, rdsc = 0.0, rd = 0.0;
+    if (MODE == W_OEM) {
+        K = pen_consts(pen, lam / st.scaley, d, A.alpha, A.gamma, A.tau);
+        rD = 1.0 / K.D; gammad = K.gamma * K.D; dmg = K.D - 1.0 / K.gamma; rdmg = 1.0 / dmg;
+        gm1 = K.gamma - 1.0; dsc = gm1 * K.D - 1.0; rdsc = 1.0 / dsc; rd = 1.0 / d;
+    }
+    bool moving = false;
+    for (; j < jend; j += 4) {
+        const int jn = j + 4;
+        double xn[NR];
+        constexpr bool PF = NR <= 16 && MODE != W_XB;                // the next column is requested before this one is consumed
+        if (PF && jn < jend) wide_load<NR>(xn, xs + (size_t)jn * NP, lane);
+        if (MODE == W_XB) {
+            const double bj = beta[j];
+            if (bj != 0.0) {                                        // wave-uniform: a zero coefficient's column is never read
+                wide_load<NR>(xc, xs + (size_t)j * NP, lane);
+#pragma unroll
+                for (int k = 0; k < NR; ++k) rp[k] = fma(xc[k], bj, rp[k]);
+            }
+        } else {
+            const double bo = (MODE == W_OEM) ? beta[j] : 0.0;
+            const double xyj = 0.0, pfj = (MODE == W_OEM) ? A.pf[j] : 0.0;
+            (void)xyj;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < NR; k += 2) { a0 = fma(xc[k], rr[k], a0); if (k + 1 < NR) a1 = fma(xc[k + 1], rr[k + 1], a1); }
+            const double dot = wsum(a0 + a1);
+            if (MODE == W_XTV) { if (lane == 0) outv[j] = dot * rn; }
+            else {
+                double bn;
+                if (MODE == W_EIG) bn = dot;
+                else {
+                    const double b0 = fresh ? 0.0 : bo;
+                    const double u = dot * rn + d * b0;              // ref src/oem_dense.h:520: X'(Y - X beta)/n + d beta
+                    const double tp = pfj * K.L;
+                    if (K.kind == K_SOFT) bn = cdiv(shrink(u, tp), K.D, rD);
+                    else if (K.kind == K_MCP) {
+                        const bool big = fabs(u) > gammad * tp;
+                        bn = cdiv(big ? u : shrink(u, tp), big ? K.D : dmg, big ? rD : rdmg);
+                    } else if (K.kind == K_SCAD) {
+                        const double au = fabs(u);
+                        const bool big = au > gammad * tp, mid = !big && au > (K.D + 1.0) * tp;
+                        const double num = big ? u : (mid ? shrink(gm1 * u, K.gamma * tp) : shrink(u, tp));
+                        bn = cdiv(num, mid ? dsc : K.D, mid ? rdsc : rD);
+                    } else bn = cdiv(u, d, rd);
+                    const double c = fabs(bn), qo = fabs(b0);
+                    const bool cn = c > 1e-13, qn = qo > 1e-13;
+                    moving |= (cn != qn) || (cn && qn && fabs(bn - b0) > A.tol * qo);
+                    if (lane == 0) {
+                        if (finalize) A.beta[kfin * q + j] = bo;
+                        beta[j] = bn;
+                    }
+                }
+                if (bn != 0.0) {
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) rp[k] = fma(xc[k], bn, rp[k]);
+                }
+            }
+            if (PF) {
+#pragma unroll
+                for (int k = 0; k < NR; ++k) xc[k] = xn[k];
+            } else if (jn < jend) wide_load<NR>(xc, xs + (size_t)jn * NP, lane);
+        }
+    }
+    if (MODE == W_OEM) {
+        const int mv = __syncthreads_or(moving ? 1 : 0);
+        if (tid == 0) flags[(par ^ 1) * FMAXB + blockIdx.x] = mv;
+    }
+    if (MODE == W_XTV) return;
+    // ---- the workgroup's partial vector: the four waves' sums added in wave order
+#pragma unroll
+    for (int k = 0; k < NR; ++k) wsh[w * NP + lane + 64 * k] = rp[k];
+    __syncthreads();
+    for (int r = tid; r < NP; r += 256) P[(size_t)blockIdx.x * NP + r] = ((wsh[r] + wsh[NP + r]) + wsh[2 * NP + r]) + wsh[3 * NP + r];
+}
+
+// out = Ys - sum_w P[w] (W_OEM: the residual) | sum / n (W_EIG: Xs Xs' v / n) | sum (W_XB: Xs beta); workgroup order, four
+// interleaved chains combined in a fixed order
+template <int MODE>
+__global__ __launch_bounds__(256) void wide_reduce_kernel(const double *__restrict__ P, int W, long long npad, int n, const double *__restrict__ ysv,
+                                                           double *__restrict__ out, const int *__restrict__ done)
+{
+    __shared__ double sh[4][64];
+    if (done && *done) return;
+    const int tid = threadIdx.x, l = tid & 63, part = tid >> 6;
+    const long long i = (long long)blockIdx.x * 64 + l;
+    double s = 0.0;
+    for (int w = part; w < W; w += 4) s += P[(size_t)w * npad + i];
+    sh[part][l] = s;
+    __syncthreads();
+    if (part == 0) {
+        const double t = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
+        out[i] = (MODE == W_OEM) ? ysv[i] - t : (MODE == W_EIG ? t * (1.0 / (double)n) : t);
+    }
+}
+
+template <int NR>
+static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd, double *host_scratch)
+{
+    const int q = a.p, n = wd.n, W = wide_workgroups(q), cpw = (q + W - 1) / W;
+    const long long npad = 64 * NR;
+    if (wd.npad != npad) { set_error("internal: wide engine padding"); return OEMGPU_ERR_INTERNAL; }
+    double *P = wd.scratch, *r = P + (size_t)W * npad, *t = r + npad, *v = t + npad, *vp = v + npad, *w = vp + npad;
+    double *T = w + npad;
+    SState *SS = reinterpret_cast<SState *>(T + 2 * MAXL + 64);
+    int *fdone = reinterpret_cast<int *>(T + 2 * MAXL + 64 + 16);
+    int *flags = reinterpret_cast<int *>(T + 2 * MAXL + 64 + 16 + 2);
+    LState *st = reinterpret_cast<LState *>(a.work);
+    double *beta = a.work + STATE_DBL, *g = beta + (q + 8);
+    OEM_HIP(hipMemsetAsync(a.work, 0, sizeof(double) * path_large_work_doubles(q, 0), s));
+    OEM_HIP(hipMemsetAsync(wd.scratch, 0, sizeof(double) * wide_scratch_doubles(n, q), s));
+    const size_t lds = sizeof(double) * 4 * (size_t)npad;
+#define OEM_WIDE_ATTR(MODE)                                                                                                       \
+    if (lds > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_cols_kernel<NR, MODE>),               \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+    OEM_WIDE_ATTR(W_EIG); OEM_WIDE_ATTR(W_OEM); OEM_WIDE_ATTR(W_XB);
+#undef OEM_WIDE_ATTR
+    const int rblocks = (int)(npad / 64);
+    // ---- d = 1.005 lambda_max(Xs Xs'/n): Lanczos on n-vectors, the product as the two passes of ONE kernel (ref :476-498)
+    const int mmax = n < MAXL ? n : MAXL;
+    double theta = 0.0, theta_prev = -1.0;
+    bool lz_capped = true;
+    double *hT = host_scratch;
+    int m = 0;
+    hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, s, n, v, vp);
+    while (m < mmax) {
+        const int chunk = (mmax - m) < 16 ? (mmax - m) : 16;
+        for (int k = 0; k < chunk; ++k, ++m) {
+            hipLaunchKernelGGL((wide_cols_kernel<NR, W_EIG>), dim3(W), dim3(256), lds, s, a, wd.xs, v, wd.ys, P, (double *)nullptr, (double *)nullptr,
+                               (SState *)nullptr, (int *)nullptr, (int *)nullptr, (const int *)nullptr, 0, 0.0, n, cpw);
+            hipLaunchKernelGGL((wide_reduce_kernel<W_EIG>), dim3(rblocks), dim3(256), 0, s, P, W, npad, n, wd.ys, w, (const int *)nullptr);
+            hipLaunchKernelGGL(lanczos_update_kernel, dim3(1), dim3(1024), 0, s, n, m, v, vp, w, T);
+        }
+        OEM_HIP(hipGetLastError());
+        OEM_HIP(hipMemcpyAsync(hT, T, sizeof(double) * 2 * MAXL, hipMemcpyDeviceToHost, s));
+        OEM_HIP(hipStreamSynchronize(s));
+        int mm = m;
+        for (int k = 0; k < m; ++k)
+            if (!(hT[MAXL + k] > 1e-13 * std::fabs(hT[k]))) { mm = k + 1; break; }     // breakdown: T is exact
+        theta = tridiag_max_host(hT, hT + MAXL, mm);
+        if (mm < m) { lz_capped = false; break; }
+        if (m >= 24) {                                                  // the stop rule of run_path_large
+            const double t1 = tridiag_max_host(hT, hT + MAXL, m - 8), t0 = tridiag_max_host(hT, hT + MAXL, m - 16);
+            const double mv = theta - t1, mvp = t1 - t0, ath = std::fabs(theta);
+            if (mv <= 1e-14 * ath || (mv < 0.01 * mvp && mv * mv <= 1e-12 * ath * (mvp - mv))) { lz_capped = false; break; }
+        }
+        if (theta_prev > 0 && std::fabs(theta - theta_prev) <= 1e-12 * std::fabs(theta)) { lz_capped = false; break; }
+        theta_prev = theta;
+    }
+    if (mmax >= n) lz_capped = false;
+    const double d = theta * 1.005;                     // ref src/oem_dense.h:498
+    hipLaunchKernelGGL(path_init_kernel, dim3(1), dim3(1024), 0, s, a, st, beta, d, theta, m, lz_capped ? 1 : 0);
+    OEM_HIP(hipGetLastError());
+    if (a.npen == 0) return 0;
+    const bool fused = a.ngroups == 0 && !a.accelerate && !a.compute_loss && !a.sinv && W <= FMAXB && !getenv("OEM_WIDE_GENERAL");
+    size_t shu = sizeof(double) * (size_t)(q + (a.ngroups > 0 ? a.ngroups : 0) + 8);
+    if (!fused && shu > 64 * 1024) {
+        if (shu > 160 * 1024 - 4096) { set_error("p >= n with a group penalty / accelerate / compute.loss: p = %d does not fit the update kernel's LDS", q); return OEMGPU_ERR_UNSUPPORTED; }
+        OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shu));
+    }
+    if (fused) hipLaunchKernelGGL(sym_init_kernel, dim3(1), dim3(1), 0, s, SS, a);
+    auto enq = [&](int count) {
+        for (int k = 0; k < count; ++k) {
+            if (fused) {
+                hipLaunchKernelGGL((wide_cols_kernel<NR, W_OEM>), dim3(W), dim3(256), lds, s, a, wd.xs, r, wd.ys, P, beta, (double *)nullptr, SS, flags,
+                                   fdone, (const int *)nullptr, k & 1, d, n, cpw);
+                hipLaunchKernelGGL((wide_reduce_kernel<W_OEM>), dim3(rblocks), dim3(256), 0, s, P, W, npad, n, wd.ys, r, (const int *)fdone);
+            } else {
+                hipLaunchKernelGGL((wide_cols_kernel<NR, W_XB>), dim3(W), dim3(256), lds, s, a, wd.xs, (const double *)nullptr, wd.ys, P, beta,
+                                   (double *)nullptr, (SState *)nullptr, (int *)nullptr, (int *)nullptr, (const int *)&st->done, 0, d, n, cpw);
+                hipLaunchKernelGGL((wide_reduce_kernel<W_XB>), dim3(rblocks), dim3(256), 0, s, P, W, npad, n, wd.ys, t, (const int *)&st->done);
+                hipLaunchKernelGGL((wide_cols_kernel<NR, W_XTV>), dim3(W), dim3(256), lds, s, a, wd.xs, t, wd.ys, P, (double *)nullptr, g,
+                                   (SState *)nullptr, (int *)nullptr, (int *)nullptr, (const int *)&st->done, 0, d, n, cpw);
+                hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), shu, s, a, st, beta, g);
+            }
+        }
+    };
+    const int FB = fused ? 64 : 32;                                  // even: every batch starts at parity 0
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        enq(FB);
+        if (hipStreamEndCapture(s, &graph) != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            graph = nullptr; exec = nullptr;
+            (void)hipGetLastError();
+        }
+    } else (void)hipGetLastError();
+    const long long max_it = (long long)a.npen * a.nl * ((long long)a.maxit + 3) + 8;
+    long long launched = 0;
+    int *hdone = reinterpret_cast<int *>(host_scratch);
+    int rc = 0;
+    for (;;) {
+        if (exec) { if (hipGraphLaunch(exec, s) != hipSuccess) { set_error("hipGraphLaunch failed"); rc = OEMGPU_ERR_HIP; break; } }
+        else enq(FB);
+        if (hipGetLastError() != hipSuccess) { set_error("wide engine: launch failed"); rc = OEMGPU_ERR_HIP; break; }
+        launched += FB;
+        if (hipMemcpyAsync(hdone, fused ? fdone : &st->done, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { set_error("wide engine: device error"); rc = OEMGPU_ERR_HIP; break; }
+        if (*hdone) break;
+        if (caller_interrupted()) { set_error("interrupted by the caller"); rc = OEMGPU_ERR_INTERRUPTED; break; }
+        if (launched > max_it) { set_error("wide engine did not finish within %lld iterations", max_it); rc = OEMGPU_ERR_INTERNAL; break; }
+    }
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+}
+
+int run_path_wide(hipStream_t s, const PathArgs &a, const WideArgs &wd, double *host_scratch)
+{
+    switch (wide_nr(wd.n)) {
+    case 1: return run_path_wide_nr<1>(s, a, wd, host_scratch);
+    case 2: return run_path_wide_nr<2>(s, a, wd, host_scratch);
+    case 3: return run_path_wide_nr<3>(s, a, wd, host_scratch);
+    case 4: return run_path_wide_nr<4>(s, a, wd, host_scratch);
+    case 6: return run_path_wide_nr<6>(s, a, wd, host_scratch);
+    case 8: return run_path_wide_nr<8>(s, a, wd, host_scratch);
+    case 12: return run_path_wide_nr<12>(s, a, wd, host_scratch);
+    case 16: return run_path_wide_nr<16>(s, a, wd, host_scratch);
+    case 24: return run_path_wide_nr<24>(s, a, wd, host_scratch);
+    case 32: return run_path_wide_nr<32>(s, a, wd, host_scratch);
+    default: break;
+    }
+    set_error("p >= n: the wide engine holds columns of n <= %d rows", WIDE_MAX_N);
+    return OEMGPU_ERR_UNSUPPORTED;
+}
+
+int wide_npad(int n) { return 64 * wide_nr(n); }
+
 }  // namespace oemgpu

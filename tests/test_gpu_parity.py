@@ -385,6 +385,97 @@ def test_wide_branch(oa, n, p, std, icpt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,p", [(40, 100), (64, 64), (3, 5), (130, 200), (200, 1030), (700, 701)])
+@pytest.mark.parametrize("flag", [0, 1, 2, 3])
+def test_wide_engine(oa, n, p, flag, monkeypatch):
+    """p >= n through the reference's OWN iteration (ref src/oem_dense.h:363-366, 476-482, 513-521): the standardised copy of X
+    on the device, d from Lanczos on XXt/n applied as two products, u = X'(Y - X beta)/n + d beta -- no Gram matrix
+    (wide.hip, path_large.hip: run_path_wide; OEM_WIDE=1 takes it at every size it can run).  All four DataStd flags; the fused
+    form (element-wise operators: one read of X per iteration) and the general form (group operators, Nesterov's step,
+    compute.loss around path_update_kernel), each against the oracle's restatement of the same branch."""
+    monkeypatch.setenv("OEM_WIDE", "1")
+    std, icpt = bool(flag & 1), bool(flag & 2)
+    x, y = _data(n, p, 300 + n + flag, mean=0.4, nnz=min(6, p))
+    groups = np.arange(p) // 5 + 1
+    lmr = 0.01 if n < p else 0.0001                                   # R/oem.R:348-354
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for kw in (dict(penalty=["lasso", "mcp", "scad", "elastic.net", "ols"], alpha=0.6, nlambda=9, tol=1e-8, maxit=700),
+                   dict(penalty=["lasso", "grp.lasso", "sparse.grp.lasso"], groups=groups, nlambda=7, tol=1e-8, maxit=700, compute_loss=True),
+                   dict(penalty=["lasso"], nlambda=5, tol=1e-12, maxit=3),
+                   dict(penalty=["mcp"], nlambda=6, tol=1e-8, maxit=700, accelerate=True)):
+            f = oa.oem(x, y, standardize=std, intercept=icpt, **kw)
+            okw = dict(kw)
+            if "groups" in okw:
+                okw["unique_groups"] = np.unique(groups)
+            r = orc.fit_dense(x, y, lambda_min_ratio=lmr, standardize=std, intercept=icpt, **okw)
+            assert abs(f["d"] - r["d"]) < 1e-10 * r["d"], (kw["penalty"], f["d"], r["d"])
+            for k in range(len(kw["penalty"])):
+                assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-11)
+                scale = max(1.0, float(np.abs(r["beta"][k]).max()))
+                err = np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max()
+                assert err < 1e-7 * scale, (kw["penalty"][k], err)
+                dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int))
+                assert np.mean(dn > 1) <= 0.25, (kw["penalty"][k], dn)
+                if kw.get("compute_loss"):
+                    assert np.allclose(f["loss"][k], r["loss"][k], rtol=1e-8)
+            if kw["maxit"] == 3:
+                assert f["niter"][0].max() == 4
+    # the same call on the Gram form: the two forms of the iteration agree
+    monkeypatch.delenv("OEM_WIDE")
+    monkeypatch.setenv("OEM_NO_WIDE", "1")
+    kw = dict(penalty=["lasso", "mcp"], nlambda=8, tol=1e-9, maxit=700, standardize=std, intercept=icpt)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g = oa.oem(x, y, **kw)
+        monkeypatch.delenv("OEM_NO_WIDE")
+        monkeypatch.setenv("OEM_WIDE", "1")
+        w = oa.oem(x, y, **kw)
+    for k in range(2):
+        assert np.abs(np.asarray(g["beta"][k]) - np.asarray(w["beta"][k])).max() < 1e-7 * max(1.0, float(np.abs(g["beta"][k]).max()))
+
+
+@pytest.mark.gpu
+def test_wide_engine_where_it_is_chosen(oa):
+    """the sizes the library itself sends to the wide engine (p > 1024, 2 n < p): device-resident and host x, against the oracle;
+    and p = 20,000 (a Gram matrix would be 3.2 GB per iteration) through the lasso KKT conditions on the standardised data."""
+    import torch
+    rng = np.random.default_rng(8)
+    n, p = 300, 2500
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 2.0 + 0.3)
+    y = x[:, :8] @ rng.uniform(0.5, 1.5, 8) + rng.normal(size=n)
+    kw = dict(penalty=["lasso", "mcp"], nlambda=10, tol=1e-8, maxit=1000)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fh = oa.oem(x, y, **kw)
+        fd = oa.oem(torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t(), y, **kw)
+    r = orc.fit_dense(x, y, lambda_min_ratio=0.01, **kw)
+    for f in (fh, fd):
+        assert abs(f["d"] - r["d"]) < 1e-10 * r["d"]
+        for k in range(2):
+            assert np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max() < 1e-7 * max(1.0, float(np.abs(r["beta"][k]).max()))
+            assert np.mean(np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int)) > 1) <= 0.25
+    n, p = 500, 20_000
+    x = np.asfortranarray(rng.normal(size=(n, p)))
+    b = np.zeros(p); b[:10] = rng.uniform(1.0, 2.0, 10)
+    y = x @ b + rng.normal(size=n)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f = oa.oem(x, y, penalty="lasso", nlambda=12, tol=1e-9, maxit=5000, standardize=False, intercept=False)
+    beta, lam = f["beta"][0][1:], f["lambda"][0]
+    assert np.all(beta[:, 0] == 0) and f["niter"][0][0] == 1
+    grad = x.T @ (y[:, None] - x @ beta) / n
+    for i in (1, 4, 8):
+        if f["niter"][0][i] > 5000:
+            continue
+        nz = beta[:, i] != 0
+        assert np.abs(grad[~nz, i]).max() <= lam[i] * (1 + 1e-6)
+        assert np.abs(grad[nz, i] - lam[i] * np.sign(beta[nz, i])).max() <= 1e-6 * lam[0]
+    s = np.linalg.svd(x, compute_uv=False)[0]
+    assert abs(f["d"] - 1.005 * s * s / n) <= 1e-9 * f["d"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("std,icpt", [(True, True), (False, True), (True, False), (False, False)])
 def test_sparse_x(oa, std, icpt):
     """oem() on a sparse x (ref src/oem_sparse.{h,cpp}, n > p): oemSparse's own standardisation and intercept handling (the
