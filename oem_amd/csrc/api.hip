@@ -642,7 +642,7 @@ int oemgpu_solve_moments_dev(oemgpu_ctx *c, const double *moments_dev, const dou
 // OEM_WIDE=1 forces it wherever it can run (tests), OEM_NO_WIDE=1 switches it off.
 static bool wide_pays(int64_t n, int32_t p)
 {
-    if (n > p || n > WIDE_MAX_N || wide_workgroups(p) > 1024) return false;
+    if (n > p || n > WIDE_MAX_N) return false;
     if (getenv("OEM_NO_WIDE")) return false;
     if (getenv("OEM_WIDE")) return true;
     return p > 1024 && 2 * n < p;

@@ -161,7 +161,7 @@ struct WideArgs {
     double *scratch;         // wide_scratch_doubles(n, p) doubles
 };
 static const int WIDE_MAX_N = 2048;          // the columns of xs live in registers: 64 lanes x 32 rows each
-int wide_workgroups(int p);
+int wide_workgroups(int n, int p);
 int wide_npad(int n);                       // rows of the standardised copy: n rounded up to the kernels' 64 NR
 size_t wide_scratch_doubles(int n, int p);
 int launch_wide_standardize(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, int standardize, int intercept,

@@ -1356,12 +1356,6 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
 // ================================================================================================
 enum { W_EIG = 0, W_OEM = 1, W_XB = 2, W_XTV = 3 };
 
-int wide_workgroups(int p)
-{
-    int w = (p + 15) / 16;                               // >= 4 columns per wave where p allows
-    if (w > 512) w = 512;
-    return w < 1 ? 1 : w;
-}
 static int wide_nr(int n)
 {
     static const int sizes[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
@@ -1369,11 +1363,22 @@ static int wide_nr(int n)
     for (int v : sizes) if (v >= need) return v;
     return 0;
 }
+// waves per workgroup: as many as the combine buffer in LDS (NW x 64 NR doubles <= 64 KB) and the registers (3-4 NR doubles per
+// lane) allow -- a wave walks its columns one after the other (dot product -> wave sum -> operator -> update is a serial chain of
+// ~400 cycles per column), so the CU needs several waves per SIMD to keep loads in flight
+__host__ __device__ constexpr int wide_nw(int nr) { return nr <= 8 ? 16 : (nr <= 16 ? 8 : 4); }
+int wide_workgroups(int n, int p)
+{
+    const int nw = wide_nw(wide_nr(n));
+    int w = (p + nw - 1) / nw;                           // small p is latency-bound: a column per wave, as many CUs as that gives
+    if (w > 256) w = 256;                                // one workgroup per CU: every partial vector is read back by the reduction
+    return w < 1 ? 1 : w;
+}
 // P[W][npad] | r | t | v | vp | w (npad each) | T[2 MAXL + 64] | SState[2] (16) | done (2) | flags[2][FMAXB] ints
 size_t wide_scratch_doubles(int n, int p)
 {
     const size_t npad = 64 * (size_t)wide_nr(n);
-    return (size_t)wide_workgroups(p) * npad + 5 * npad + 2 * MAXL + 64 + 16 + 2 + FMAXB + 64;
+    return (size_t)wide_workgroups(n, p) * npad + 5 * npad + 2 * MAXL + 64 + 16 + 2 + FMAXB + 64;
 }
 
 template <int NR> __device__ __forceinline__ void wide_load(double (&x)[NR], const double *__restrict__ col, int lane)
@@ -1383,28 +1388,34 @@ template <int NR> __device__ __forceinline__ void wide_load(double (&x)[NR], con
 }
 
 template <int NR, int MODE>
-__global__ __launch_bounds__(256) void wide_cols_kernel(PathArgs A, const double *__restrict__ xs, const double *__restrict__ rin,
+__global__ __launch_bounds__(64 * wide_nw(NR)) void wide_cols_kernel(PathArgs A, const double *__restrict__ xs, const double *__restrict__ rin,
                                                          const double *__restrict__ ysv, double *__restrict__ P, double *__restrict__ beta,
                                                          double *__restrict__ outv, SState *__restrict__ S, int *__restrict__ flags,
                                                          int *__restrict__ fdone, const int *__restrict__ done, int par, double d,
                                                          int n, int cpw)
 {
-    extern __shared__ __attribute__((aligned(16))) double wsh[];     // [4][64 NR]
-    constexpr int NP = 64 * NR;
+    extern __shared__ __attribute__((aligned(16))) double wsh[];     // [NW][64 NR] | beta of this workgroup's columns [cpw] | penalty factors [cpw]
+    constexpr int NP = 64 * NR, NW = wide_nw(NR), NT = 64 * NW;
+    double *bsh = wsh + NW * NP, *pfsh = bsh + cpw;
     const int q = A.p, nl = A.nl, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int jbeg = blockIdx.x * cpw, jend = (jbeg + cpw < q) ? jbeg + cpw : q;
     const double rn = 1.0 / (double)n;
     // ---- head (W_OEM): state, flags -- one load away from the launch (SState carries the penalty code and lambda)
     SState st;
-    int fl[FMAXB / 256];
+    int fl[(FMAXB + NT - 1) / NT];
     if (MODE == W_OEM) {
         st = S[par];
 #pragma unroll
-        for (int k = 0; k < FMAXB / 256; ++k) { const int t = tid + 256 * k; fl[k] = flags[par * FMAXB + (t < (int)gridDim.x ? t : 0)]; }
+        for (int k = 0; k < (FMAXB + NT - 1) / NT; ++k) { const int t = tid + NT * k; fl[k] = flags[par * FMAXB + (t < (int)gridDim.x ? t : 0)]; }
     } else if (done && *done) return;
+    // the workgroup's coefficients and penalty factors into LDS with one coalesced load each: a load per column inside the loop
+    // would put a memory round trip on every column's chain
+    if (MODE == W_OEM || MODE == W_XB)
+        for (int t = tid; t < jend - jbeg; t += NT) { bsh[t] = beta[jbeg + t]; if (MODE == W_OEM) pfsh[t] = A.pf[jbeg + t]; }
     int j = jbeg + w;
     double xc[NR];
     if (MODE != W_XB && j < jend) wide_load<NR>(xc, xs + (size_t)j * NP, lane);
+    if (MODE == W_XB) __syncthreads();
     int pp = 0, i = 0, it = 0, pen = 0, niter_fin = 0;
     double lam = 0.0;
     bool fresh = false, finalize = false, done_now = false, advanced = false;
@@ -1416,7 +1427,7 @@ __global__ __launch_bounds__(256) void wide_cols_kernel(PathArgs A, const double
         }
         int f = 0;
 #pragma unroll
-        for (int k = 0; k < FMAXB / 256; ++k) f |= (tid + 256 * k < (int)gridDim.x) ? fl[k] : 0;
+        for (int k = 0; k < (FMAXB + NT - 1) / NT; ++k) f |= (tid + NT * k < (int)gridDim.x) ? fl[k] : 0;
         const int any = __syncthreads_or(f);
         pp = st.pp; i = st.i; it = st.it; pen = st.pen; lam = st.lam; fresh = st.fresh != 0;
         if (!fresh) {
@@ -1439,7 +1450,7 @@ __global__ __launch_bounds__(256) void wide_cols_kernel(PathArgs A, const double
             if (finalize) { A.niter[kfin] = niter_fin; A.loss[kfin] = 1e99; }
         }
         if (done_now) {                                             // only the last lambda's coefficients are left to store
-            for (int jj = jbeg + tid; jj < jend; jj += 256) A.beta[kfin * q + jj] = beta[jj];
+            for (int jj = jbeg + tid; jj < jend; jj += NT) A.beta[kfin * q + jj] = bsh[jj - jbeg];
             return;
         }
     }
@@ -1456,22 +1467,20 @@ __global__ __launch_bounds__(256) void wide_cols_kernel(PathArgs A, const double
         gm1 = K.gamma - 1.0; dsc = gm1 * K.D - 1.0; rdsc = 1.0 / dsc; rd = 1.0 / d;
     }
     bool moving = false;
-    for (; j < jend; j += 4) {
-        const int jn = j + 4;
+    for (; j < jend; j += NW) {
+        const int jn = j + NW;
         double xn[NR];
         constexpr bool PF = NR <= 16 && MODE != W_XB;                // the next column is requested before this one is consumed
         if (PF && jn < jend) wide_load<NR>(xn, xs + (size_t)jn * NP, lane);
         if (MODE == W_XB) {
-            const double bj = beta[j];
+            const double bj = bsh[j - jbeg];
             if (bj != 0.0) {                                        // wave-uniform: a zero coefficient's column is never read
                 wide_load<NR>(xc, xs + (size_t)j * NP, lane);
 #pragma unroll
                 for (int k = 0; k < NR; ++k) rp[k] = fma(xc[k], bj, rp[k]);
             }
         } else {
-            const double bo = (MODE == W_OEM) ? beta[j] : 0.0;
-            const double xyj = 0.0, pfj = (MODE == W_OEM) ? A.pf[j] : 0.0;
-            (void)xyj;
+            const double bo = (MODE == W_OEM) ? bsh[j - jbeg] : 0.0, pfj = (MODE == W_OEM) ? pfsh[j - jbeg] : 0.0;
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
             for (int k = 0; k < NR; k += 2) { a0 = fma(xc[k], rr[k], a0); if (k + 1 < NR) a1 = fma(xc[k + 1], rr[k + 1], a1); }
@@ -1518,29 +1527,45 @@ __global__ __launch_bounds__(256) void wide_cols_kernel(PathArgs A, const double
         if (tid == 0) flags[(par ^ 1) * FMAXB + blockIdx.x] = mv;
     }
     if (MODE == W_XTV) return;
-    // ---- the workgroup's partial vector: the four waves' sums added in wave order
+    // ---- the workgroup's partial vector: the waves' sums added in wave order
 #pragma unroll
     for (int k = 0; k < NR; ++k) wsh[w * NP + lane + 64 * k] = rp[k];
     __syncthreads();
-    for (int r = tid; r < NP; r += 256) P[(size_t)blockIdx.x * NP + r] = ((wsh[r] + wsh[NP + r]) + wsh[2 * NP + r]) + wsh[3 * NP + r];
+    for (int r = tid; r < NP; r += NT) {
+        double t = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) t += wsh[ww * NP + r];
+        P[(size_t)blockIdx.x * NP + r] = t;
+    }
 }
 
-// out = Ys - sum_w P[w] (W_OEM: the residual) | sum / n (W_EIG: Xs Xs' v / n) | sum (W_XB: Xs beta); workgroup order, four
-// interleaved chains combined in a fixed order
+// out = Ys - sum_w P[w] (W_OEM: the residual) | sum / n (W_EIG: Xs Xs' v / n) | sum (W_XB: Xs beta).  64 rows per workgroup, sixteen
+// interleaved chains over the workgroups' partial vectors (eight loads in flight per thread: a chain of W dependent-free loads
+// issued one by one was the whole iteration's time), combined in a fixed order: bitwise reproducible.
 template <int MODE>
-__global__ __launch_bounds__(256) void wide_reduce_kernel(const double *__restrict__ P, int W, long long npad, int n, const double *__restrict__ ysv,
-                                                           double *__restrict__ out, const int *__restrict__ done)
+__global__ __launch_bounds__(1024) void wide_reduce_kernel(const double *__restrict__ P, int W, long long npad, int n, const double *__restrict__ ysv,
+                                                            double *__restrict__ out, const int *__restrict__ done)
 {
-    __shared__ double sh[4][64];
+    __shared__ double sh[16][64];
     if (done && *done) return;
     const int tid = threadIdx.x, l = tid & 63, part = tid >> 6;
     const long long i = (long long)blockIdx.x * 64 + l;
     double s = 0.0;
-    for (int w = part; w < W; w += 4) s += P[(size_t)w * npad + i];
+    int w = part;
+    for (; w + 16 * 7 < W; w += 16 * 8) {
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = P[(size_t)(w + 16 * k) * npad + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += t[k];
+    }
+    for (; w < W; w += 16) s += P[(size_t)w * npad + i];
     sh[part][l] = s;
     __syncthreads();
     if (part == 0) {
-        const double t = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][l];
         out[i] = (MODE == W_OEM) ? ysv[i] - t : (MODE == W_EIG ? t * (1.0 / (double)n) : t);
     }
 }
@@ -1548,7 +1573,8 @@ __global__ __launch_bounds__(256) void wide_reduce_kernel(const double *__restri
 template <int NR>
 static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd, double *host_scratch)
 {
-    const int q = a.p, n = wd.n, W = wide_workgroups(q), cpw = (q + W - 1) / W;
+    const int q = a.p, n = wd.n, W = wide_workgroups(n, q), cpw = (q + W - 1) / W;
+    constexpr int NT = 64 * wide_nw(NR);
     const long long npad = 64 * NR;
     if (wd.npad != npad) { set_error("internal: wide engine padding"); return OEMGPU_ERR_INTERNAL; }
     double *P = wd.scratch, *r = P + (size_t)W * npad, *t = r + npad, *v = t + npad, *vp = v + npad, *w = vp + npad;
@@ -1560,11 +1586,11 @@ static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd
     double *beta = a.work + STATE_DBL, *g = beta + (q + 8);
     OEM_HIP(hipMemsetAsync(a.work, 0, sizeof(double) * path_large_work_doubles(q, 0), s));
     OEM_HIP(hipMemsetAsync(wd.scratch, 0, sizeof(double) * wide_scratch_doubles(n, q), s));
-    const size_t lds = sizeof(double) * 4 * (size_t)npad;
+    const size_t lds = sizeof(double) * ((size_t)wide_nw(NR) * (size_t)npad + 2 * (size_t)cpw);
 #define OEM_WIDE_ATTR(MODE)                                                                                                       \
     if (lds > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_cols_kernel<NR, MODE>),               \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
-    OEM_WIDE_ATTR(W_EIG); OEM_WIDE_ATTR(W_OEM); OEM_WIDE_ATTR(W_XB);
+    OEM_WIDE_ATTR(W_EIG); OEM_WIDE_ATTR(W_OEM); OEM_WIDE_ATTR(W_XB); OEM_WIDE_ATTR(W_XTV);
 #undef OEM_WIDE_ATTR
     const int rblocks = (int)(npad / 64);
     // ---- d = 1.005 lambda_max(Xs Xs'/n): Lanczos on n-vectors, the product as the two passes of ONE kernel (ref :476-498)
@@ -1577,9 +1603,9 @@ static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd
     while (m < mmax) {
         const int chunk = (mmax - m) < 16 ? (mmax - m) : 16;
         for (int k = 0; k < chunk; ++k, ++m) {
-            hipLaunchKernelGGL((wide_cols_kernel<NR, W_EIG>), dim3(W), dim3(256), lds, s, a, wd.xs, v, wd.ys, P, (double *)nullptr, (double *)nullptr,
+            hipLaunchKernelGGL((wide_cols_kernel<NR, W_EIG>), dim3(W), dim3(NT), lds, s, a, wd.xs, v, wd.ys, P, (double *)nullptr, (double *)nullptr,
                                (SState *)nullptr, (int *)nullptr, (int *)nullptr, (const int *)nullptr, 0, 0.0, n, cpw);
-            hipLaunchKernelGGL((wide_reduce_kernel<W_EIG>), dim3(rblocks), dim3(256), 0, s, P, W, npad, n, wd.ys, w, (const int *)nullptr);
+            hipLaunchKernelGGL((wide_reduce_kernel<W_EIG>), dim3(rblocks), dim3(1024), 0, s, P, W, npad, n, wd.ys, w, (const int *)nullptr);
             hipLaunchKernelGGL(lanczos_update_kernel, dim3(1), dim3(1024), 0, s, n, m, v, vp, w, T);
         }
         OEM_HIP(hipGetLastError());
@@ -1613,14 +1639,14 @@ static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd
     auto enq = [&](int count) {
         for (int k = 0; k < count; ++k) {
             if (fused) {
-                hipLaunchKernelGGL((wide_cols_kernel<NR, W_OEM>), dim3(W), dim3(256), lds, s, a, wd.xs, r, wd.ys, P, beta, (double *)nullptr, SS, flags,
+                hipLaunchKernelGGL((wide_cols_kernel<NR, W_OEM>), dim3(W), dim3(NT), lds, s, a, wd.xs, r, wd.ys, P, beta, (double *)nullptr, SS, flags,
                                    fdone, (const int *)nullptr, k & 1, d, n, cpw);
-                hipLaunchKernelGGL((wide_reduce_kernel<W_OEM>), dim3(rblocks), dim3(256), 0, s, P, W, npad, n, wd.ys, r, (const int *)fdone);
+                hipLaunchKernelGGL((wide_reduce_kernel<W_OEM>), dim3(rblocks), dim3(1024), 0, s, P, W, npad, n, wd.ys, r, (const int *)fdone);
             } else {
-                hipLaunchKernelGGL((wide_cols_kernel<NR, W_XB>), dim3(W), dim3(256), lds, s, a, wd.xs, (const double *)nullptr, wd.ys, P, beta,
+                hipLaunchKernelGGL((wide_cols_kernel<NR, W_XB>), dim3(W), dim3(NT), lds, s, a, wd.xs, (const double *)nullptr, wd.ys, P, beta,
                                    (double *)nullptr, (SState *)nullptr, (int *)nullptr, (int *)nullptr, (const int *)&st->done, 0, d, n, cpw);
-                hipLaunchKernelGGL((wide_reduce_kernel<W_XB>), dim3(rblocks), dim3(256), 0, s, P, W, npad, n, wd.ys, t, (const int *)&st->done);
-                hipLaunchKernelGGL((wide_cols_kernel<NR, W_XTV>), dim3(W), dim3(256), lds, s, a, wd.xs, t, wd.ys, P, (double *)nullptr, g,
+                hipLaunchKernelGGL((wide_reduce_kernel<W_XB>), dim3(rblocks), dim3(1024), 0, s, P, W, npad, n, wd.ys, t, (const int *)&st->done);
+                hipLaunchKernelGGL((wide_cols_kernel<NR, W_XTV>), dim3(W), dim3(NT), lds, s, a, wd.xs, t, wd.ys, P, (double *)nullptr, g,
                                    (SState *)nullptr, (int *)nullptr, (int *)nullptr, (const int *)&st->done, 0, d, n, cpw);
                 hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), shu, s, a, st, beta, g);
             }
