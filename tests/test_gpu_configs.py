@@ -7,6 +7,11 @@ pytestmark = pytest.mark.gpu
 
 from oracle import oracle as orc
 
+# d = 1.005 lambda_max: the reference's own Spectra tolerance is 1e-10 (ref src/oem_dense.h:494-498); the device recurrence stops
+# at a 1e-12 tail estimate, so every comparison of d with the oracle's exact eigenvalue holds to 1e-10 relative (it was 1e-8: a
+# regression of the eigen step by three orders of magnitude would have passed -- VERDICT r2)
+DTOL = 1e-10
+
 TIGHT = 1e-9
 
 
@@ -26,7 +31,7 @@ def _cmp(fit, ref, tol=TIGHT):
         err = np.abs(a - b).max()
         assert err <= tol, (fit["penalty"][k], err)
         assert np.allclose(fit["lambda"][k], ref["lambda"][k], rtol=1e-12, atol=0)
-    assert abs(fit["d"] - ref["d"]) <= 1e-8 * abs(ref["d"])
+    assert abs(fit["d"] - ref["d"]) <= DTOL * abs(ref["d"])
 
 
 def test_config2_mcp_scad_p200(oa):
@@ -77,7 +82,7 @@ def test_config4_xtx_p1024_against_oracle(oa):
     kw = dict(penalty="lasso", nlambda=30, tol=1e-10)
     fit = oa.oem_xtx(xtx, xty, **kw)
     lam_max = np.linalg.eigvalsh(xtx)[-1]
-    assert abs(fit["d"] - 1.005 * lam_max) <= 1e-9 * lam_max
+    assert abs(fit["d"] - 1.005 * lam_max) <= DTOL * lam_max
     ref = orc.fit_xtx(xtx, xty, d_override=fit["d"], **kw)
     _cmp(fit, ref)
 
@@ -98,7 +103,7 @@ def test_config4_xtx_p4096_kkt(oa):
         assert np.abs(grad[~nz, i]).max() <= lam[i] * (1 + 1e-7)
         assert np.abs(grad[nz, i] - lam[i] * np.sign(beta[nz, i])).max() <= 1e-7 * max(1.0, lam[0])
     lam_max = np.linalg.eigvalsh(xtx)[-1]
-    assert abs(fit["d"] - 1.005 * lam_max) <= 1e-8 * lam_max
+    assert abs(fit["d"] - 1.005 * lam_max) <= DTOL * lam_max
 
 
 def test_config5_big_p256_reduced_n_and_shards(oa):
@@ -115,6 +120,53 @@ def test_config5_big_p256_reduced_n_and_shards(oa):
     xs = [x[cuts[i]:cuts[i + 1]] for i in range(8)]
     ys = [y[cuts[i]:cuts[i + 1]] for i in range(8)]
     _cmp(oa.big_oem(xs, ys, **kw), ref)
+
+
+@pytest.mark.gpu
+def test_config1_full_size_against_the_oracle(oa):
+    """BASELINE config 1 at FULL size (README.md:44-66): n = 1e6, p = 100, the 100 lambdas of a first default fit supplied back,
+    tol 1e-10 -- host x through oemgpu_fit_dense and device-resident x through oemgpu_fit_dense_dev, against the native oracle
+    (one second of CPU): coefficients to 1e-9, d to 1e-10, identical iteration counts.  (bench.py checks the same on every run;
+    this puts the headline configuration into the GPU suite itself.)"""
+    import torch
+    rng = np.random.default_rng(123)
+    n, p, m = 1_000_000, 100, 25
+    b = np.concatenate([rng.uniform(size=m), np.zeros(p - m)])
+    x = np.empty((n, p), order="F")
+    for j0 in range(0, p, 10):
+        x[:, j0:j0 + 10] = rng.standard_normal((n, 10)) * 3.0
+    y = x @ b + rng.standard_normal(n)
+    kw = dict(penalty="elastic.net", alpha=1.0, intercept=True, standardize=False)
+    lam = oa.oem(x, y, **kw)["lambda"][0]
+    ref = orc.fit_dense(x, y, native=True, lambda_=lam, tol=1e-10, **kw)
+    xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+    for fit in (oa.oem(x, y, lambda_=lam, tol=1e-10, **kw), oa.oem(xd, y, lambda_=lam, tol=1e-10, **kw)):
+        assert np.abs(fit["beta"][0] - ref["beta"][0]).max() <= 1e-9
+        assert np.array_equal(fit["niter"][0], ref["niter"][0]) and fit["niter"][0].sum() > 500
+        assert abs(fit["d"] - ref["d"]) <= DTOL * ref["d"]
+        assert np.allclose(fit["lambda"][0], lam, rtol=1e-14)
+
+
+@pytest.mark.gpu
+def test_config5_semantics_4e6_rows_in_eight_shards(oa):
+    """config 5 (big.oem: intercept column, (n - 1) scaling, 100-lambda lasso, p = 256) on n = 4e6 rows handed over as eight row
+    shards -- SURVEY section 7's plan for the largest size an oracle comparison is practical at (the native oracle's serial Gram
+    takes about half a minute) -- against the oracle on the unsharded matrix."""
+    rng = np.random.default_rng(55)
+    n, p, S = 4_000_000, 256, 8
+    x = np.empty((n, p), order="F")
+    for j0 in range(0, p, 16):
+        x[:, j0:j0 + 16] = rng.standard_normal((n, 16), dtype=np.float32)
+    x += 0.25
+    b = np.zeros(p); b[:25] = rng.uniform(-1, 1, 25)
+    y = x @ b + rng.standard_normal(n) + 1.5
+    kw = dict(penalty="lasso", nlambda=100, tol=1e-7)
+    cuts = np.linspace(0, n, S + 1).astype(int)
+    fit = oa.big_oem([x[cuts[i]:cuts[i + 1]] for i in range(S)], [y[cuts[i]:cuts[i + 1]] for i in range(S)], **kw)
+    ref = orc.fit_big(x, y, native=True, **kw)
+    _cmp(fit, ref)
+    assert np.abs(np.ravel(fit["niter"][0]).astype(int) - np.ravel(ref["niter"][0]).astype(int)).max() <= 1
+    assert fit["nobs"] == n
 
 
 def _engines(f):
@@ -157,7 +209,7 @@ def test_fused_iteration_engine(oa, p):
         # same iteration arithmetic; d may differ in its last bits (the fused Lanczos step sums in another order)
         assert np.abs(np.asarray(fit["beta"][k]) - np.asarray(two["beta"][k])).max() < 1e-12, pens[k]
         assert np.abs(np.ravel(fit["niter"][k]).astype(int) - np.ravel(two["niter"][k]).astype(int)).max() <= 1, pens[k]
-    assert abs(coop["d"] - ref["d"]) < 1e-9 * ref["d"]
+    assert abs(coop["d"] - ref["d"]) < DTOL * ref["d"]
     kw = dict(penalty=["lasso"], nlambda=6, tol=1e-12, maxit=3)                                       # exhaustion: maxit + 1
     ref = orc.fit_dense(x, y, native=True, **kw)
     for fit in _engines(lambda: oa.oem(x, y, **kw)):
@@ -358,7 +410,7 @@ def test_group_operators_in_the_row_split_kernel(oa, p, gsize):
             assert np.abs(np.ravel(fit["niter"][k]).astype(int) - np.ravel(ref["niter"][k]).astype(int)).max() <= 1, pen
             if kw.get("compute_loss"):
                 assert np.allclose(np.ravel(fit["loss"][k]), np.ravel(ref["loss"][k]), rtol=1e-9), pen
-        assert abs(fit["d"] - ref["d"]) < 1e-9 * ref["d"]
+        assert abs(fit["d"] - ref["d"]) < DTOL * ref["d"]
 
 
 @pytest.mark.gpu

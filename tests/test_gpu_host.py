@@ -9,6 +9,11 @@ pytestmark = pytest.mark.gpu
 
 from oracle import oracle as orc
 
+# d = 1.005 lambda_max: the reference's own Spectra tolerance is 1e-10 (ref src/oem_dense.h:494-498); the device recurrence stops
+# at a 1e-12 tail estimate, so every comparison of d with the oracle's exact eigenvalue holds to 1e-10 relative (it was 1e-8: a
+# regression of the eigen step by three orders of magnitude would have passed -- VERDICT r2)
+DTOL = 1e-10
+
 
 @pytest.fixture(scope="module")
 def oa():
@@ -29,7 +34,7 @@ def _data(n, p, seed, mean=0.0, sd=2.0, nnz=8):
 
 
 def _cmp(f, r, tol=1e-9):
-    assert abs(f["d"] - r["d"]) <= 1e-8 * abs(r["d"])
+    assert abs(f["d"] - r["d"]) <= DTOL * abs(r["d"])
     for k in range(len(r["beta"])):
         assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-12)
         assert np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max() <= tol, f["penalty"][k]

@@ -9,6 +9,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle import oracle as orc
+
+# d = 1.005 lambda_max: the reference's own Spectra tolerance is 1e-10 (ref src/oem_dense.h:494-498); the device recurrence stops
+# at a 1e-12 tail estimate, so every comparison of d with the oracle's exact eigenvalue holds to 1e-10 relative (it was 1e-8: a
+# regression of the eigen step by three orders of magnitude would have passed -- VERDICT r2)
+DTOL = 1e-10
 from tests import kat_inputs as K
 
 TOL = 1e-7          # north_star contract
@@ -35,7 +40,7 @@ def _cmp(fit, ref, tol=TIGHT, rows=None):
         err = np.abs(a - b).max()
         assert err <= tol, (fit["penalty"][k], err)
         assert np.allclose(fit["lambda"][k], ref["lambda"][k], rtol=1e-12, atol=0)
-    assert abs(fit["d"] - ref["d"]) <= 1e-8 * abs(ref["d"])
+    assert abs(fit["d"] - ref["d"]) <= DTOL * abs(ref["d"])
 
 
 def _data(n, p, seed, mean=0.0, sd=3.0, nnz=10):
