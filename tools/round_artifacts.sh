@@ -2,13 +2,13 @@
 # Round artefacts on the GPU box: kernel-trace stats, PMC traffic passes (separate runs), config times, bench line.
 # usage: bash tools/round_artifacts.sh r2 [quick]     (writes under gpurun_out/<tag>_*; copy what is to be judged into profiles/)
 set -u
-tag=${1:-r2}
+tag=${1:-r3}
 quick=${2:-}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 o=gpurun_out
 mkdir -p $o
-B="--no-cpu-baseline --no-c5 --no-host --no-two-callers"   # the profiled command: the timed solves alone
+B="--no-cpu-baseline --no-c5 --no-host --no-two-callers --no-rccl-check"   # the profiled command: the timed solves alone
 # ---- config 1 (the bench command): per-kernel stats, then FETCH_SIZE / WRITE_SIZE in their own passes
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_trace -o ${tag} -- python3 bench.py --steps 100 --warmup 10 $B > $o/${tag}_trace_bench.json 2> $o/${tag}_trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_fetch -o ${tag} -- python3 bench.py --steps 5 --warmup 2 $B > /dev/null 2> $o/${tag}_pmc_fetch.err
@@ -33,7 +33,16 @@ if [ -z "$quick" ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/${tag}_c4_pmc_$c -o ${tag} -- python3 tools/run_c4.py > /dev/null 2> $o/${tag}_c4_pmc_$c.err
   done
-  python3 tools/pmc_summary.py oem_fused_kernel $o/${tag}_c4_pmc_fused.json "$(find $o/${tag}_c4_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_c4_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
+  python3 tools/pmc_summary.py oem_symfused_kernel $o/${tag}_c4_pmc_symfused.json "$(find $o/${tag}_c4_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_c4_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
+  python3 tools/c4_time.py "" nosym > $o/${tag}_c4_time.txt 2>&1
+  # ---- p >= n (n = 500, p = 20,000): the wide engine's column kernel
+  rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_wide_trace -o ${tag} -- python3 tools/run_wide.py > $o/${tag}_wide_trace.log 2>&1
+  cp "$(find $o/${tag}_wide_trace -name '*kernel_stats.csv' | head -1)" $o/${tag}_wide_n500_p20000_kernel_stats.csv
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/${tag}_wide_pmc_$c -o ${tag} -- python3 tools/run_wide.py > /dev/null 2> $o/${tag}_wide_pmc_$c.err
+  done
+  python3 tools/pmc_summary.py "wide_cols_kernel<8, 1>" $o/${tag}_wide_pmc_cols.json "$(find $o/${tag}_wide_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_wide_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
+  python3 tools/wide_time.py > $o/${tag}_wide_times.txt 2>&1
   python3 tools/config_times.py > $o/${tag}_config_times.json 2> $o/${tag}_config_times.err
 fi
 python3 bench.py > $o/${tag}_bench.json 2> $o/${tag}_bench.err
