@@ -441,6 +441,32 @@ def test_wide_engine(oa, n, p, flag, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,p", [(1100, 1200), (1500, 1501), (2048, 2100)])
+def test_wide_engine_tall_columns(oa, n, p, monkeypatch):
+    """the column heights that take 24 and 32 registers per lane (no software prefetch, four waves per workgroup), up to the
+    engine's limit n = 2048 -- and one row more, where the call must fall back to the Gram form and still agree"""
+    monkeypatch.setenv("OEM_WIDE", "1")
+    x, y = _data(n, p, 40 + n, mean=0.2, nnz=8)
+    kw = dict(penalty=["lasso", "mcp"], nlambda=5, tol=1e-8, maxit=300)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f = oa.oem(x, y, **kw)
+        r = orc.fit_dense(x, y, lambda_min_ratio=0.01, **kw)
+    assert abs(f["d"] - r["d"]) < DTOL * r["d"]
+    for k in range(2):
+        assert np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max() < 1e-7 * max(1.0, float(np.abs(r["beta"][k]).max()))
+        assert np.mean(np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int)) > 1) <= 0.25
+    if n == 2048:
+        x2, y2 = _data(n + 1, p, 41 + n, mean=0.2, nnz=8)          # 2049 rows: beyond the engine, served by the Gram form
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            f2 = oa.oem(x2, y2, **kw)
+            r2 = orc.fit_dense(x2, y2, lambda_min_ratio=0.01, **kw)
+        for k in range(2):
+            assert np.abs(np.asarray(f2["beta"][k]) - np.asarray(r2["beta"][k])).max() < 1e-7 * max(1.0, float(np.abs(r2["beta"][k]).max()))
+
+
+@pytest.mark.gpu
 def test_wide_engine_where_it_is_chosen(oa):
     """the sizes the library itself sends to the wide engine (p > 1024, 2 n < p): device-resident and host x, against the oracle;
     and p = 20,000 (a Gram matrix would be 3.2 GB per iteration) through the lasso KKT conditions on the standardised data."""
