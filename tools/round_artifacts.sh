@@ -45,6 +45,8 @@ if [ -z "$quick" ]; then
   python3 tools/wide_time.py > $o/${tag}_wide_times.txt 2>&1
   python3 tools/config_times.py > $o/${tag}_config_times.json 2> $o/${tag}_config_times.err
 fi
+# the raw traces stay on the box: gpurun copies back at most 64 MiB
+for d in $o/${tag}_trace $o/${tag}_pmc_fetch $o/${tag}_pmc_write $o/${tag}_*_trace $o/${tag}_*_pmc_FETCH_SIZE $o/${tag}_*_pmc_WRITE_SIZE; do [ -d "$d" ] && rm -rf "$d"; done
 python3 bench.py > $o/${tag}_bench.json 2> $o/${tag}_bench.err
 tail -c 300 $o/${tag}_bench.err
 head -c 1500 $o/${tag}_kernel_stats.csv
