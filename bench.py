@@ -259,6 +259,16 @@ def main():
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         self_launch(a, argv)                     # never returns; this process has made no GPU call
 
+    # ONE line on stdout, whatever the libraries print: RCCL writes a version banner to the C-level stdout when a communicator is
+    # created (seen after the JSON line at process exit).  File descriptor 1 is pointed at stderr for the whole run and the JSON
+    # line goes out through the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -299,7 +309,7 @@ def main():
         warm = a.warmup if a.warmup != 10 else 2
         r = c5_weak(torch, dist, world, rank, dev, backend, a.c5_rows, steps, warm)
         if rank == 0:
-            print(json.dumps({"metric": "full-lambda-path solves/sec (config 5 share: big.oem lasso, 1.25e7 x 256 rows per GPU)",
+            emit(({"metric": "full-lambda-path solves/sec (config 5 share: big.oem lasso, 1.25e7 x 256 rows per GPU)",
                               "value": r["value"], "unit": "solves/s", "n_gpus": world, "steps": steps, "warmup": warm,
                               "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                               "dtype": "f64", "data": "synthetic", "config": {"workload": r["workload"], "rows_per_gpu": r["rows_per_gpu"]},
@@ -534,7 +544,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_host:
         # what the drop-in .Call delivers: the same solve from pageable host memory (never `value`)
         hr, hargs = host_resident(xh_full, yh_full, lambdas, p)
-        hr["same_bits_as_the_resident_solve"] = bool(np.array_equal(hargs.beta, beta_timed))
+        hr["max_abs_beta_diff_vs_the_resident_solve"] = float(np.abs(hargs.beta - beta_timed).max())      # (row blocks are summed in another order)
         out["host_resident_ms"] = {"c1": hr}
         if c1_exact:
             out["vs_baseline_host_resident"] = README_SECONDS / (hr["median_ms"] * 1e-3)
@@ -607,7 +617,7 @@ def main():
         out["cpu_baseline_all_cores"] = {"value": 1.0 / tca * (rows / n), "unit": "solves/s", "cores": nc, "kind": "port",
                                          "seconds": tca, "sample": out["cpu_baseline"]["sample"]}
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 if __name__ == "__main__":

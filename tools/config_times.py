@@ -76,9 +76,10 @@ t_gpu = timeit(lambda: oem_amd.oem_xtx(xtxd, xty, **kw), 1)
 fit = oem_amd.oem_xtx(xtxd, xty, **kw)
 its = int(fit["niter"][0].sum())
 its_c4, fit_c4_lambda = its, fit["lambda"][0]
-out["config4_xtx_p4096"] = {"gpu_ms": 1e3 * t_gpu, "iterations": its, "gemv_bytes_per_iteration": 8.0 * p * p + 24 * p,
-                            "note": "includes ~100+ Lanczos GEMVs; per-iteration = one 134 MB GEMV + one update kernel",
-                            "approx_GBps_over_all_gemvs": (its + 130) * (8.0 * p * p) / t_gpu / 1e9}
+out["config4_xtx_p4096"] = {"gpu_ms": 1e3 * t_gpu, "iterations": its, "bytes_per_iteration_symmetric_tile_engine": 4.0 * p * p + 4.0 * 128 * p + 8.0 * p * (p // 128),
+                            "bytes_per_iteration_row_streaming": 8.0 * p * p + 24 * p,
+                            "note": "includes ~140 Lanczos products; symmetric-tile engine: the lower triangle of XX once per iteration (DESIGN 3.3b)",
+                            "approx_GBps_over_all_products": (its + 140) * (4.0 * p * p + 4.0 * 128 * p) / t_gpu / 1e9}
 del xtxd, x
 
 # config 5 semantics on one GPU: big.oem n=4e6 (of 1e8), p=256, lasso, device resident via the sharded driver
@@ -143,7 +144,7 @@ kw = dict(penalty="lasso", nlambda=50, tol=1e-7)
 t = timeit(lambda: oem_amd.oem(xw, yw, **kw), 2)
 t0 = time.perf_counter(); orc.fit_dense(xw, yw, lambda_min_ratio=0.01, native=True, **kw); t_cpu = time.perf_counter() - t0
 out["wide_n500_p2000_lasso"] = {"gpu_ms": 1e3 * t, "cpu_port_1thread_ms": 1e3 * t_cpu,
-                                "note": "p >= n: the reference iterates through X twice; the library runs the Gram form"}
+                                "note": "p >= n: the reference's own iteration through the standardised X (wide engine, one read of X per iteration); OEM_NO_WIDE=1 runs the Gram form"}
 
 # ---- CPU baselines for configs 3, 4, 5 (the oracle = the C restatement of the reference path, 1 thread = the reference's effective
 # default; -O3 -march=native built on this host).  The Gram pass is linear in n and the path does not depend on n, so configs 3 and 5
