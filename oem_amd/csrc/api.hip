@@ -48,6 +48,25 @@ struct CoopSlots {
     }
 };
 
+// (kernel, device) -> largest dynamic-LDS limit set so far
+int lds_limit_once(const void *fn, size_t bytes)
+{
+    struct Key { const void *fn; int dev; size_t bytes; };
+    static std::mutex mu;
+    static std::vector<Key> seen;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Key &k : seen) if (k.fn == fn && k.dev == dev && k.bytes >= bytes) return 0;
+    }
+    OEM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    std::lock_guard<std::mutex> lk(mu);
+    for (Key &k : seen) if (k.fn == fn && k.dev == dev) { if (k.bytes < bytes) k.bytes = bytes; return 0; }
+    seen.push_back(Key{fn, dev, bytes});
+    return 0;
+}
+
 static thread_local int (*g_poll)(void *) = nullptr;
 static thread_local void *g_poll_arg = nullptr;
 bool caller_interrupted() { return g_poll && g_poll(g_poll_arg) != 0; }
@@ -349,9 +368,20 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     a.nbatch = nbatch; a.bs_xx = a.bs_xy = a.bs_stats = (long long)bstride; a.bs_out = (long long)out_stride; a.bs_work = (long long)work_d;
 
     const size_t st_gap = (size_t)((const char *)dout - (const char *)stats);
-    const bool joined = nbatch == 1 && (const char *)stats < (const char *)dout && st_gap == ((size_t)stats_len(p) * 8 + 255) / 256 * 256;
+    // Results straight into pinned host memory (row-split kernel, one instance): that kernel only ever STORES to its outputs, so they
+    // may live in host memory the device writes over PCIe while it runs (a few hundred bytes per lambda); the device-to-host copy
+    // node behind the kernel -- a launch boundary and a DMA set-up with the GPU idle -- disappears.  OEM_NO_ZERO_COPY=1: the copy.
+    a.stats_out = nullptr; a.stats_n = 0;
+    const bool zero_copy = small && nbatch == 1 && !poison && path_small_takes_rows(a) && !getenv("OEM_NO_ZERO_COPY");
+    const bool joined = !zero_copy && nbatch == 1 && (const char *)stats < (const char *)dout && st_gap == ((size_t)stats_len(p) * 8 + 255) / 256 * 256;
     const size_t back_bytes = nbatch > 1 ? out_stride * nbatch : out_bytes + (joined ? st_gap : 0);
     if (ctx_pinned(c, back_bytes > 16384 ? back_bytes : 16384)) return OEMGPU_ERR_HIP;
+    if (zero_copy) {
+        double *hout = (double *)c->pinned;
+        a.beta = hout; a.lambda_out = hout + nb; a.loss = a.lambda_out + nk; a.d_out = a.loss + nk;
+        a.stats_out = a.d_out + D_OUT_LEN; a.stats_n = stats_len(p);
+        a.niter = (int *)(a.stats_out + stats_len(p));
+    }
     CoopSlots slots;                                  // held until the stream has been synchronised below
     if (coop) slots.take(c->device, path_coop_workgroups(q) * (pen_split ? npen : 1) * nbatch, c->num_cu * 3 / 4);
     {
@@ -362,9 +392,11 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
         if (rc) return rc;
     }
     HT(2);
-    if (!joined) OEM_HIP(hipMemcpy2DAsync(dstats, out_stride, stats, bstride * sizeof(double), sizeof(double) * stats_len(p), nbatch,
-                                          hipMemcpyDeviceToDevice, c->stream));
-    OEM_HIP(hipMemcpyAsync(c->pinned, joined ? (const void *)stats : (const void *)dout, back_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (!zero_copy) {
+        if (!joined) OEM_HIP(hipMemcpy2DAsync(dstats, out_stride, stats, bstride * sizeof(double), sizeof(double) * stats_len(p), nbatch,
+                                              hipMemcpyDeviceToDevice, c->stream));
+        OEM_HIP(hipMemcpyAsync(c->pinned, joined ? (const void *)stats : (const void *)dout, back_bytes, hipMemcpyDeviceToHost, c->stream));
+    }
     HT(3);
     OEM_HIP(hipStreamSynchronize(c->stream));
     HT(4);

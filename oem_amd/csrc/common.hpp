@@ -116,6 +116,10 @@ struct PathArgs {
     // the penalties this workgroup walks ([0, npen) without the split)
     int pen_split, pen_lo, pen_hi;
     const double *lmax_xy;   // not null: every instance takes lambda_zero from THIS xy (xval.oem: the grid of the full-data fit, ref src/oem_xval_dense.cpp:177-194)
+    // not null (row-split kernel only): the outputs above point into PINNED HOST memory the device writes directly (the kernel only
+    // ever stores to them), and the kernel leaves a copy of `stats` here as well -- no device-to-host copy node behind the kernel
+    double *stats_out;
+    int stats_n;             // doubles of stats to copy
 };
 
 // the problem instance of this workgroup (see PathArgs::nbatch); all scalar arithmetic
@@ -142,6 +146,10 @@ int path_coop_min_q(bool has_groups);
 static const int SMALL_P_MAX = 288;     // one workgroup where the matrix fits its registers (+ LDS); else four cooperating workgroups (big.oem's p + 1 = 257 included)
 size_t path_small_xchg_bytes();
 int launch_path_small(hipStream_t s, const PathArgs &a);          // p <= SMALL_P_MAX: one fused launch
+bool path_small_takes_rows(const PathArgs &a);                    // will launch_path_small use the row-split kernel (p <= 208)?
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size): the call costs microseconds, and config 1 made it
+// in front of every Gram launch with the GPU idle
+int lds_limit_once(const void *fn, size_t bytes);
 int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch);   // any p: multi-launch engine
 size_t path_large_work_doubles(int p, int nsteps);
 // 288 < p <= 1024: one persistent launch of cooperating workgroups (path_coop.hip)

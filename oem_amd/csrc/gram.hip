@@ -1338,8 +1338,7 @@ static int launch_gram_t(hipStream_t s, const GramPlan &pl, const double *x, con
         const int sb = !saddr ? 0 : (rem <= 4 ? 1 : (rem <= 8 ? 2 : 0));
 #define OEM_RING(NT, SB, SA)                                                                                                   \
     if (pl.ntc == NT && sb == SB && saddr == SA) {                                                                             \
-        if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_ring_kernel<NT, SB, SA>),         \
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                \
+        if (sh > 64 * 1024 && lds_limit_once(reinterpret_cast<const void *>(&gram_ring_kernel<NT, SB, SA>), sh)) return OEMGPU_ERR_HIP; \
         hipLaunchKernelGGL((gram_ring_kernel<NT, SB, SA>), dim3(pl.nchunk), dim3(256), sh, s, x, y, sums, tpart, vpart, a);   \
         OEM_HIP(hipGetLastError());                                                                                            \
         return 0;                                                                                                              \

@@ -1450,6 +1450,7 @@ __global__ __launch_bounds__(NW * 64) void path_rows_kernel(PathArgs A_)
         A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
         A.d_out[3] = (double)(__builtin_amdgcn_s_memrealtime() - t_rt0);
     }
+    if (A.stats_out) for (int k = tid; k < A.stats_n; k += NW * 64) A.stats_out[k] = A.stats[k];      // results in host memory: stats beside them
 }
 
 // workgroup sets of one launch: instances x (penalties, when split)
@@ -1458,8 +1459,7 @@ static inline int path_grid_y(const PathArgs &a) { return (a.nbatch > 1 ? a.nbat
 template <int NW, int CG, int CGL = 0> int launch_rows(hipStream_t s, const PathArgs &a)
 {
     const size_t sh = (size_t)RowsCfg<NW, CG, CGL>::N_DBL * sizeof(double);
-    if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_rows_kernel<NW, CG, CGL>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    if (sh > 64 * 1024 && lds_limit_once(reinterpret_cast<const void *>(&path_rows_kernel<NW, CG, CGL>), sh)) return OEMGPU_ERR_HIP;
     hipLaunchKernelGGL((path_rows_kernel<NW, CG, CGL>), dim3(1, path_grid_y(a)), dim3(NW * 64), sh, s, a);
     OEM_HIP(hipGetLastError());
     return 0;
@@ -1495,12 +1495,17 @@ extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read(unsigned 
 }
 #endif
 
+bool path_small_takes_rows(const PathArgs &a)
+{
+    return (a.ngroups == 0 || !getenv("OEM_NO_ROWS_GROUPS")) && a.p <= 208 && !(a.p > 128 && getenv("OEM_NO_ROWS8"));
+}
+
 int launch_path_small(hipStream_t s, const PathArgs &a)
 {
     // p <= 208: the row-split form (beta all-gather, permlane reduce-scatter; group operators exchange u as well); four waves
     // up to p = 128, eight (two per SIMD, 256 VGPRs each: a[2][CG] must leave room) beyond.  OEM_NO_ROWS_GROUPS: calls with a
     // group penalty on the replicated / sliced kernels below, as before round 2 (the tests hold the two against each other)
-    if ((a.ngroups == 0 || !getenv("OEM_NO_ROWS_GROUPS")) && a.p <= 208 && !(a.p > 128 && getenv("OEM_NO_ROWS8"))) {
+    if (path_small_takes_rows(a)) {
         if (a.p <= 32) return launch_rows<4, 8>(s, a);
         if (a.p <= 64) return launch_rows<4, 16>(s, a);
         if (a.p <= 80) return launch_rows<4, 20>(s, a);
