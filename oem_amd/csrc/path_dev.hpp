@@ -191,7 +191,7 @@ __device__ __forceinline__ double tridiag_max(const double *al, const double *be
 // When the register-resident engines look at the top Ritz value, and when they stop the recurrence.
 //   * every 8 steps from step 16 on (an evaluation costs about six Lanczos steps);
 //   * stop when the value has moved by <= 1e-14 relative since the last look, or when two successive moves decay so fast that
-//     the geometric tail they imply, mv^2 / (mv_prev - mv), is <= 1e-12 relative (the Ritz value of a Krylov method converges
+//     the geometric tail they imply, mv^2 / (mv_prev - mv), is <= OEM_LANCZOS_TAIL_TOL (1e-12) relative (the Ritz value of a Krylov method converges
 //     superlinearly, so the tail estimate is on the safe side: on config 1's matrix it says 3e-13 at step 32 where the true
 //     error is 1e-14; config 1 stops at 32 steps instead of 56).  The reference's own tolerance is 1e-10
 //     (src/oem_dense.h:485-498), and d only sets the step length: a relative 1e-12 in d moves nothing.
@@ -200,7 +200,7 @@ __device__ __forceinline__ bool lanczos_converged(double th, double &theta_prev,
 {
     const double mv = th - theta_prev, ath = fabs(th);
     bool stop = mv <= 1e-14 * ath;
-    if (mv_prev < 1e300 && mv < 0.01 * mv_prev && mv * mv <= 1e-12 * ath * (mv_prev - mv)) stop = true;
+    if (mv_prev < 1e300 && mv < 0.01 * mv_prev && mv * mv <= OEM_LANCZOS_TAIL_TOL * ath * (mv_prev - mv)) stop = true;
     mv_prev = mv; theta_prev = th;
     return stop;
 }

@@ -1165,7 +1165,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         if (m >= 24) {
             const double t1 = tridiag_max_host(hT, hT + MAXL, m - 8), t0 = tridiag_max_host(hT, hT + MAXL, m - 16);
             const double mv = theta - t1, mvp = t1 - t0, ath = std::fabs(theta);
-            if (mv <= 1e-14 * ath || (mv < 0.01 * mvp && mv * mv <= 1e-12 * ath * (mvp - mv))) { lz_capped = false; break; }
+            if (mv <= 1e-14 * ath || (mv < 0.01 * mvp && mv * mv <= OEM_LANCZOS_TAIL_TOL * ath * (mvp - mv))) { lz_capped = false; break; }
         }
         if (theta_prev > 0 && std::fabs(theta - theta_prev) <= 1e-12 * std::fabs(theta)) { lz_capped = false; break; }
         theta_prev = theta;
@@ -1619,7 +1619,7 @@ static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd
         if (m >= 24) {                                                  // the stop rule of run_path_large
             const double t1 = tridiag_max_host(hT, hT + MAXL, m - 8), t0 = tridiag_max_host(hT, hT + MAXL, m - 16);
             const double mv = theta - t1, mvp = t1 - t0, ath = std::fabs(theta);
-            if (mv <= 1e-14 * ath || (mv < 0.01 * mvp && mv * mv <= 1e-12 * ath * (mvp - mv))) { lz_capped = false; break; }
+            if (mv <= 1e-14 * ath || (mv < 0.01 * mvp && mv * mv <= OEM_LANCZOS_TAIL_TOL * ath * (mvp - mv))) { lz_capped = false; break; }
         }
         if (theta_prev > 0 && std::fabs(theta - theta_prev) <= 1e-12 * std::fabs(theta)) { lz_capped = false; break; }
         theta_prev = theta;
