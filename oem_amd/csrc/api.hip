@@ -847,7 +847,7 @@ int oemgpu_fit_dense(const double *x, int64_t n, int32_t p, const double *y, int
         if (!c) return OEMGPU_ERR_NO_DEVICE;
         double *xd = nullptr, *yd = nullptr;
         int64_t ld = 0;
-        rc = host_upload_resident(c, x, n, p, y, o, &xd, &ld, &yd);
+        rc = host_upload_resident(c, x, n, p, y, o, &xd, &ld, &yd, 0, true);      // ld = n: whole columns go up as linear copies
         if (!rc) rc = fit_dense_wide_dev(c, xd, n, ld, p, yd, standardize, intercept, o, beta, lambda_out, niter, loss, d);
         (void)hipStreamSynchronize(c->stream);
         ctx_release(c);

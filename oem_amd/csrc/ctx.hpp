@@ -88,7 +88,7 @@ int host_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_t 
 // the rows of one host matrix resident on the context's device (c->xres: column-major, leading dimension *ld, y behind it at *y_dev)
 // (ldx: column stride of the host matrix, 0 = n -- a row slice of a bigger matrix has ldx > n)
 int host_upload_resident(oemgpu_ctx *c, const double *x, int64_t n, int32_t p, const double *y, const oemgpu_opts *o,
-                         double **x_dev, int64_t *ld, double **y_dev, int64_t ldx = 0);
+                         double **x_dev, int64_t *ld, double **y_dev, int64_t ldx = 0, bool tight = false);   // tight: ld = n, no padding
 // pieces of the in-library multi-device machinery that xval.oem's host entry point shares with host_fit
 int host_device_list(const oemgpu_opts *o, std::vector<int> &dev);                       // opts.ngpus / devices -> ordinals
 int host_hand_over(oemgpu_ctx *to, double *dst, oemgpu_ctx *from, const double *src, size_t doubles);   // (peer) copy on from's stream, to's stream waits for it

@@ -113,6 +113,9 @@ struct DevJob {
     int64_t nrows = 0;
     bool resident = true;
     bool contiguous = false;         // one piece laid out as ONE matrix (host_upload_resident): blocks share ld
+    bool tight = false;              // ... with ld = the row count exactly (no padding to 16 rows): a unit of whole columns of a
+                                     // contiguous host matrix is then ONE linear copy (the p >= n upload: 100,000 columns of 200 rows
+                                     // as a pitched 2-D copy took seconds)
     std::vector<Block> blocks;
     // accumulators (c->acc): moments | block moments | sums | block sums | peer staging
     double *msum = nullptr, *mtmp = nullptr, *ssum = nullptr, *stmp = nullptr, *peer = nullptr;
@@ -176,7 +179,7 @@ int job_layout(DevJob &J, size_t resident_cap)
             J.blocks.push_back(b);
             if (b.nr > maxnr) maxnr = b.nr;
         }
-        ldsum += (rows + 15) / 16 * 16;
+        ldsum += J.tight ? rows : (rows + 15) / 16 * 16;
     }
     const size_t res_bytes = sizeof(double) * ((size_t)ldsum * p + (size_t)ldsum + 64);
     J.resident = J.contiguous || res_bytes <= resident_cap;
@@ -192,7 +195,7 @@ int job_layout(DevJob &J, size_t resident_cap)
     for (size_t i = 0; i < J.blocks.size(); ++i) {
         Block &b = J.blocks[i];
         if (J.resident) {
-            if (b.piece != lastpiece) { piece_base = roff; roff += (J.pieces[b.piece].rows + 15) / 16 * 16; lastpiece = b.piece; }
+            if (b.piece != lastpiece) { piece_base = roff; roff += J.tight ? J.pieces[b.piece].rows : (J.pieces[b.piece].rows + 15) / 16 * 16; lastpiece = b.piece; }
             b.ld = ldsum;
             b.xd = (double *)(c->xres + a_x[0]) + piece_base + b.r0;
             b.yd = (double *)(c->xres + a_y[0]) + piece_base + b.r0;
@@ -257,7 +260,7 @@ void lane_main(DevJob &J, Barrier &bar, int t)
                 for (int j = 0; j < nc; ++j)
                     memcpy(sl + sizeof(double) * (size_t)w * j, P.x + (size_t)(u.j0 + j) * P.ldx + b.r0 + u.s0, sizeof(double) * (size_t)w);
                 double *dst = b.xd + (size_t)u.j0 * b.ld + u.s0;
-                if (nc == 1) JOB_HIP(J, hipMemcpyAsync(dst, sl, sizeof(double) * (size_t)w, hipMemcpyHostToDevice, L.s));
+                if (nc == 1 || w == b.ld) JOB_HIP(J, hipMemcpyAsync(dst, sl, sizeof(double) * (size_t)w * nc, hipMemcpyHostToDevice, L.s));   // whole columns, no pitch
                 else JOB_HIP(J, hipMemcpy2DAsync(dst, sizeof(double) * (size_t)b.ld, sl, sizeof(double) * (size_t)w, sizeof(double) * (size_t)w,
                                                  (size_t)nc, hipMemcpyHostToDevice, L.s));
                 staged += sizeof(double) * (size_t)w * nc;
@@ -620,10 +623,10 @@ int host_add_into(oemgpu_ctx *c, double *dst, const double *src, size_t doubles)
 }
 
 int host_upload_resident(oemgpu_ctx *c, const double *x, int64_t n, int32_t p, const double *y, const oemgpu_opts *o,
-                         double **x_dev, int64_t *ld, double **y_dev, int64_t ldx)
+                         double **x_dev, int64_t *ld, double **y_dev, int64_t ldx, bool tight)
 {
     DevJob J;
-    J.c = c; J.p = p; J.o = o; J.contiguous = true;
+    J.c = c; J.p = p; J.o = o; J.contiguous = true; J.tight = tight;
     J.T = (o && o->upload_threads > 0) ? o->upload_threads : (int)env_size("OEMGPU_UPLOAD_THREADS", 8);
     if (J.T > 64) J.T = 64;
     J.slot_bytes = env_size("OEMGPU_SLOT_BYTES", (size_t)4 << 20) / 4096 * 4096 + 4096;

@@ -22,7 +22,8 @@ for n, p, nlam, gram in ((500, 2000, 50, True), (500, 20000, 50, False), (2000, 
         for _ in range(3):
             t0 = time.perf_counter(); fit = oem_amd.oem(xd, y, **kw); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
             ms = (C.c_double * 8)(); L.check(lib.oemgpu_last_timings(ctx, ms))
-        t0 = time.perf_counter(); oem_amd.oem(x, y, **kw); th = time.perf_counter() - t0
+        for _ in range(2):                                        # (the first host call of a shape allocates its staging and device buffers)
+            t0 = time.perf_counter(); oem_amd.oem(x, y, **kw); th = min(th, time.perf_counter() - t0)
         it = int(fit["niter"][0].sum())
         byt = 8.0 * (64 * ((n + 63) // 64)) * p
         print(f"n={n} p={p} {nlam} lambdas [{mode}]: resident {1e3 * best:.1f} ms (stage reading X {ms[1]:.2f} ms, eigen + path {ms[3]:.1f} ms), "
