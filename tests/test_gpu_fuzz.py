@@ -373,3 +373,63 @@ def test_random_large_q_engines(oa, seed):
             for k in range(len(pens)):
                 assert np.allclose(np.ravel(f["loss"][k]), np.ravel(r["loss"][k]), rtol=1e-7)
     _check(f, r, pens, tol=5e-7)
+
+
+@pytest.mark.parametrize("seed", list(range(130, 148)) + list(range(80000, 80000 + 18 * (SCALE - 1))))
+def test_random_wide(oa, seed, monkeypatch):
+    """p >= n through the wide engine (the reference's own two-product iteration, OEM_WIDE=1 at every size it can run): random
+    shapes with n <= p (column heights across the kernel's register sizes), DataStd flags, penalty mixes with and without group
+    operators, accelerate, compute.loss, penalty factors -- against the oracle's restatement of that branch."""
+    monkeypatch.setenv("OEM_WIDE", "1")
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([2, 5, 40, 64, 65, 130, 200, 257, 400, 700]))
+    p = int(n + rng.integers(0, 3 * n + 60))
+    if p < 2:
+        p = 2
+    x = np.asfortranarray(rng.normal(size=(n, p)) * rng.uniform(0.5, 3.0) + rng.uniform(-1, 1))
+    nnz = int(min(p, rng.integers(1, 6)))
+    b = np.zeros(p); b[rng.choice(p, nnz, replace=False)] = rng.uniform(-1.5, 1.5, nnz)
+    y = x @ b + rng.normal(size=n) * rng.uniform(0.3, 2.0) + rng.uniform(-1, 1)
+    npen = int(rng.integers(1, 4))
+    pool = ELEMENTWISE + (GROUPED if rng.random() < 0.4 else [])
+    pens = list(rng.choice(pool, npen, replace=False))
+    groups = np.arange(p) // int(rng.integers(1, 6)) + (0 if rng.random() < 0.3 else 1)
+    pf = np.where(rng.random(p) < 0.1, 0.0, rng.uniform(0.5, 2.0, p))
+    kw = dict(penalty=pens, nlambda=int(rng.integers(1, 7)), alpha=float(rng.uniform(0.2, 1.0)), gamma=float(rng.uniform(2.1, 5.0)),
+              tau=float(rng.uniform(0.1, 0.9)), tol=float(10.0 ** rng.uniform(-9, -6)), maxit=int(rng.choice([30, 200, 400])),
+              penalty_factor=pf, standardize=bool(rng.integers(2)), intercept=bool(rng.integers(2)),
+              accelerate=bool(rng.random() < 0.25), compute_loss=bool(rng.random() < 0.4))
+    okw = dict(kw)
+    if any("grp" in q for q in pens):
+        kw["groups"] = groups
+        okw.update(groups=groups, unique_groups=np.unique(groups))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f = oa.oem(x, y, **kw)
+    r = orc.fit_dense(x, y, lambda_min_ratio=0.01 if n < p else 1e-4, **okw)
+    _check(f, r, pens, tol=5e-7)
+    if kw["compute_loss"]:
+        for k in range(len(pens)):
+            assert np.allclose(np.ravel(f["loss"][k]), np.ravel(r["loss"][k]), rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("seed", list(range(150, 154)) + list(range(90000, 90000 + 4 * (SCALE - 1))))
+def test_random_symmetric_tile_engine(oa, seed, monkeypatch):
+    """oem.xtx at p = 2048 on the symmetric-tile engine (OEM_SYM_2048=1): random element-wise penalty mixes, penalty factors and
+    maxit, against the oracle (d handed over, as in the config-4 tests: the comparison is the path's)"""
+    monkeypatch.setenv("OEM_SYM_2048", "1")
+    rng = np.random.default_rng(9900 + seed)
+    p, n = 2048, 2048 + int(rng.integers(100, 3000))
+    x = rng.normal(size=(n, p)) * (1.0 + rng.uniform(size=p))
+    b = np.zeros(p); b[rng.choice(p, 12, replace=False)] = rng.uniform(-1, 1, 12)
+    y = x @ b + rng.normal(size=n)
+    xtx, xty = x.T @ x / n, x.T @ y / n
+    pens = list(rng.choice(ELEMENTWISE, int(rng.integers(1, 4)), replace=False))
+    pf = np.where(rng.random(p) < 0.05, 0.0, rng.uniform(0.5, 2.0, p))
+    kw = dict(penalty=pens, nlambda=int(rng.integers(2, 6)), alpha=float(rng.uniform(0.3, 1.0)), gamma=float(rng.uniform(2.5, 5.0)),
+              tol=float(10.0 ** rng.uniform(-9, -7)), maxit=int(rng.choice([60, 400])), penalty_factor=pf)
+    f = oa.oem_xtx(xtx, xty, **kw)
+    r = orc.fit_xtx(xtx, xty, d_override=f["d"], lambda_min_ratio=1e-4, **kw)
+    lam_max = np.linalg.eigvalsh(xtx)[-1]
+    assert abs(f["d"] - 1.005 * lam_max) <= 1e-10 * lam_max
+    _check(f, r, pens, tol=5e-7)
