@@ -390,6 +390,25 @@ def test_wide_branch(oa, n, p, std, icpt):
 
 
 @pytest.mark.gpu
+def test_results_written_straight_into_host_memory(oa, monkeypatch):
+    """the row-split path kernel (p <= 208) stores its results into pinned host memory while it runs (no device-to-host copy
+    behind it); OEM_NO_ZERO_COPY=1 takes the copy: the same bits, every output, several penalties, compute.loss, big.oem"""
+    x, y = _data(5000, 60, 77, mean=0.5)
+    groups = np.arange(60) // 4 + 1
+    kw = dict(penalty=["lasso", "mcp", "grp.lasso", "ols"], groups=groups, nlambda=12, tol=1e-9, compute_loss=True)
+    a = oa.oem(x, y, **kw)
+    b_ = oa.big_oem(x, y, penalty=["lasso", "scad"], nlambda=9, tol=1e-9)
+    monkeypatch.setenv("OEM_NO_ZERO_COPY", "1")
+    c = oa.oem(x, y, **kw)
+    d_ = oa.big_oem(x, y, penalty=["lasso", "scad"], nlambda=9, tol=1e-9)
+    for u, v in ((a, c), (b_, d_)):
+        assert u["d"] == v["d"]
+        for key in ("beta", "lambda", "niter", "loss"):
+            for k in range(len(u[key])):
+                assert np.array_equal(np.asarray(u[key][k]), np.asarray(v[key][k])), key
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,p", [(40, 100), (64, 64), (3, 5), (130, 200), (200, 1030), (700, 701)])
 @pytest.mark.parametrize("flag", [0, 1, 2, 3])
 def test_wide_engine(oa, n, p, flag, monkeypatch):
