@@ -143,7 +143,7 @@ __device__ __forceinline__ PathArgs path_instance(PathArgs A)
 static const int D_OUT_LEN = 7;
 // Stop rule of every Lanczos recurrence here: the geometric tail implied by two successive moves of the top Ritz value, relative.
 // The reference's own tolerance on this eigenvalue is 1e-10 (Spectra, ref src/oem_dense.h:494-498); the estimate is conservative
-// (config 1: it says 3e-13 where the true error is 1e-14), and the tests hold d to 1e-10 against LAPACK / the oracle.  (1e-11 was tried in round 3: config 1 still takes 40 steps, config 4 still 144, and one xval fit moved: no gain.)
+// (config 1: it says 3e-13 where the true error is 1e-14), and the tests hold d to 1e-10 against LAPACK and the CPU restatement.  (1e-11 was tried in round 3: config 1 still takes 40 steps, config 4 still 144, and one xval fit moved: no gain.)
 #ifndef OEM_LANCZOS_TAIL_TOL
 #define OEM_LANCZOS_TAIL_TOL 1e-12
 #endif
