@@ -1381,6 +1381,28 @@ size_t wide_scratch_doubles(int n, int p)
     return (size_t)wide_workgroups(n, p) * npad + 5 * npad + 2 * MAXL + 64 + 16 + 2 + FMAXB + 64;
 }
 
+// sum of p[w * stride] over w = first, first + step, ... < count, in that order, eight loads in flight (a loop of dependent-free
+// loads whose trip count the compiler does not know is issued one load per memory round trip)
+__device__ __forceinline__ double chain_sum(const double *__restrict__ p, int first, int count, int step, size_t stride)
+{
+    double s = 0.0;
+    int w = first;
+    for (; w + 7 * step < count; w += 8 * step) {
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = p[(size_t)(w + k * step) * stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += t[k];
+    }
+    for (; w < count; w += step) s += p[(size_t)w * stride];
+    return s;
+}
+
+template <int I, int N, typename F> __device__ __forceinline__ void const_for(F &&f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); const_for<I + 1, N>(f); }
+}
+
 template <int NR> __device__ __forceinline__ void wide_load(double (&x)[NR], const double *__restrict__ col, int lane)
 {
 #pragma unroll
@@ -1467,61 +1489,82 @@ __global__ __launch_bounds__(64 * wide_nw(NR)) void wide_cols_kernel(PathArgs A,
         gm1 = K.gamma - 1.0; dsc = gm1 * K.D - 1.0; rdsc = 1.0 / dsc; rd = 1.0 / d;
     }
     bool moving = false;
-    for (; j < jend; j += NW) {
-        const int jn = j + NW;
-        double xn[NR];
-        constexpr bool PF = NR <= 16 && MODE != W_XB;                // the next column is requested before this one is consumed
-        if (PF && jn < jend) wide_load<NR>(xn, xs + (size_t)jn * NP, lane);
-        if (MODE == W_XB) {
-            const double bj = bsh[j - jbeg];
-            if (bj != 0.0) {                                        // wave-uniform: a zero coefficient's column is never read
-                wide_load<NR>(xc, xs + (size_t)j * NP, lane);
+    // the wave's columns j, j + NW, ...: a ring of D columns in registers, each requested D columns ahead of its use (a column is a
+    // memory round trip; with one column in flight per wave the small problems were nothing but that latency)
+#ifndef OEM_WIDE_DEPTH_A
+#define OEM_WIDE_DEPTH_A 2          // NR <= 4
+#define OEM_WIDE_DEPTH_B 2          // NR <= 8 (128 VGPRs per wave at sixteen waves per workgroup: 4 x 8 doubles spill)
+#define OEM_WIDE_DEPTH_C 2          // NR <= 16
+#endif
+    constexpr int D = (MODE == W_XB) ? 1 : (NR <= 4 ? OEM_WIDE_DEPTH_A : (NR <= 8 ? OEM_WIDE_DEPTH_B : (NR <= 16 ? OEM_WIDE_DEPTH_C : 1)));
+    double xq[D][NR];
+    if (MODE != W_XB) {
 #pragma unroll
-                for (int k = 0; k < NR; ++k) rp[k] = fma(xc[k], bj, rp[k]);
-            }
-        } else {
-            const double bo = (MODE == W_OEM) ? bsh[j - jbeg] : 0.0, pfj = (MODE == W_OEM) ? pfsh[j - jbeg] : 0.0;
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int k = 0; k < NR; k += 2) { a0 = fma(xc[k], rr[k], a0); if (k + 1 < NR) a1 = fma(xc[k + 1], rr[k + 1], a1); }
-            const double dot = wsum(a0 + a1);
-            if (MODE == W_XTV) { if (lane == 0) outv[j] = dot * rn; }
-            else {
-                double bn;
-                if (MODE == W_EIG) bn = dot;
-                else {
-                    const double b0 = fresh ? 0.0 : bo;
-                    const double u = dot * rn + d * b0;              // ref src/oem_dense.h:520: X'(Y - X beta)/n + d beta
-                    const double tp = pfj * K.L;
-                    if (K.kind == K_SOFT) bn = cdiv(shrink(u, tp), K.D, rD);
-                    else if (K.kind == K_MCP) {
-                        const bool big = fabs(u) > gammad * tp;
-                        bn = cdiv(big ? u : shrink(u, tp), big ? K.D : dmg, big ? rD : rdmg);
-                    } else if (K.kind == K_SCAD) {
-                        const double au = fabs(u);
-                        const bool big = au > gammad * tp, mid = !big && au > (K.D + 1.0) * tp;
-                        const double num = big ? u : (mid ? shrink(gm1 * u, K.gamma * tp) : shrink(u, tp));
-                        bn = cdiv(num, mid ? dsc : K.D, mid ? rdsc : rD);
-                    } else bn = cdiv(u, d, rd);
-                    const double c = fabs(bn), qo = fabs(b0);
-                    const bool cn = c > 1e-13, qn = qo > 1e-13;
-                    moving |= (cn != qn) || (cn && qn && fabs(bn - b0) > A.tol * qo);
-                    if (lane == 0) {
-                        if (finalize) A.beta[kfin * q + j] = bo;
-                        beta[j] = bn;
-                    }
-                }
-                if (bn != 0.0) {
-#pragma unroll
-                    for (int k = 0; k < NR; ++k) rp[k] = fma(xc[k], bn, rp[k]);
-                }
-            }
-            if (PF) {
-#pragma unroll
-                for (int k = 0; k < NR; ++k) xc[k] = xn[k];
-            } else if (jn < jend) wide_load<NR>(xc, xs + (size_t)jn * NP, lane);
-        }
+        for (int k = 0; k < NR; ++k) xq[0][k] = xc[k];               // (column j was requested in front of the head)
+        const_for<1, D>([&](auto DD) __attribute__((always_inline)) {
+            constexpr int dd = decltype(DD)::value;
+            if (j + dd * NW < jend) wide_load<NR>(xq[dd], xs + (size_t)(j + dd * NW) * NP, lane);
+        });
     }
+    // one column (a macro, not a lambda: a closure that captures the accumulator arrays by reference had them spilt to scratch)
+#define OEM_WIDE_COLUMN(X, JJ)                                                                                               \
+    do {                                                                                                                     \
+        const int jj__ = (JJ);                                                                                               \
+        if (MODE == W_XB) {                                                                                                  \
+            const double bj = bsh[jj__ - jbeg];                                                                              \
+            if (bj != 0.0) {                       /* wave-uniform: a zero coefficient's column is never read */              \
+                wide_load<NR>(X, xs + (size_t)jj__ * NP, lane);                                                              \
+                _Pragma("unroll") for (int k = 0; k < NR; ++k) rp[k] = fma(X[k], bj, rp[k]);                                 \
+            }                                                                                                                \
+        } else {                                                                                                             \
+            const double bo = (MODE == W_OEM) ? bsh[jj__ - jbeg] : 0.0, pfj = (MODE == W_OEM) ? pfsh[jj__ - jbeg] : 0.0;     \
+            double a0 = 0.0, a1 = 0.0;                                                                                       \
+            _Pragma("unroll") for (int k = 0; k < NR; k += 2) { a0 = fma(X[k], rr[k], a0); if (k + 1 < NR) a1 = fma(X[k + 1], rr[k + 1], a1); } \
+            const double dot = wsum(a0 + a1);                                                                                \
+            if (MODE == W_XTV) { if (lane == 0) outv[jj__] = dot * rn; }                                                     \
+            else {                                                                                                           \
+                double bn;                                                                                                   \
+                if (MODE == W_EIG) bn = dot;                                                                                 \
+                else {                                                                                                       \
+                    const double b0 = fresh ? 0.0 : bo;                                                                      \
+                    const double u = dot * rn + d * b0;        /* ref src/oem_dense.h:520: X'(Y - X beta)/n + d beta */       \
+                    const double tp = pfj * K.L;                                                                             \
+                    if (K.kind == K_SOFT) bn = cdiv(shrink(u, tp), K.D, rD);                                                 \
+                    else if (K.kind == K_MCP) {                                                                              \
+                        const bool big = fabs(u) > gammad * tp;                                                              \
+                        bn = cdiv(big ? u : shrink(u, tp), big ? K.D : dmg, big ? rD : rdmg);                                \
+                    } else if (K.kind == K_SCAD) {                                                                           \
+                        const double au = fabs(u);                                                                           \
+                        const bool big = au > gammad * tp, mid = !big && au > (K.D + 1.0) * tp;                              \
+                        const double num = big ? u : (mid ? shrink(gm1 * u, K.gamma * tp) : shrink(u, tp));                  \
+                        bn = cdiv(num, mid ? dsc : K.D, mid ? rdsc : rD);                                                    \
+                    } else bn = cdiv(u, d, rd);                                                                              \
+                    const double c = fabs(bn), qo = fabs(b0);                                                                \
+                    const bool cn = c > 1e-13, qn = qo > 1e-13;                                                              \
+                    moving |= (cn != qn) || (cn && qn && fabs(bn - b0) > A.tol * qo);                                        \
+                    if (lane == 0) {                                                                                         \
+                        if (finalize) A.beta[kfin * q + jj__] = bo;                                                          \
+                        beta[jj__] = bn;                                                                                     \
+                    }                                                                                                        \
+                }                                                                                                            \
+                if (bn != 0.0) { _Pragma("unroll") for (int k = 0; k < NR; ++k) rp[k] = fma(X[k], bn, rp[k]); }              \
+            }                                                                                                                \
+        }                                                                                                                    \
+    } while (0)
+#define OEM_WIDE_SLOT(DD)                                                                                                    \
+    if constexpr (D > (DD)) {                                                                                                \
+        const int jj = j + (DD) * NW;                                                                                        \
+        if (jj < jend) {                                                                                                     \
+            OEM_WIDE_COLUMN(xq[(DD) < D ? (DD) : 0], jj);                                                                    \
+            const int jn = jj + D * NW;                                                                                      \
+            if (MODE != W_XB && jn < jend) wide_load<NR>(xq[(DD) < D ? (DD) : 0], xs + (size_t)jn * NP, lane);               \
+        }                                                                                                                    \
+    }
+    for (; j < jend; j += D * NW) {
+        OEM_WIDE_SLOT(0) OEM_WIDE_SLOT(1) OEM_WIDE_SLOT(2) OEM_WIDE_SLOT(3)
+    }
+#undef OEM_WIDE_SLOT
+#undef OEM_WIDE_COLUMN
     if (MODE == W_OEM) {
         const int mv = __syncthreads_or(moving ? 1 : 0);
         if (tid == 0) flags[(par ^ 1) * FMAXB + blockIdx.x] = mv;
@@ -1550,17 +1593,7 @@ __global__ __launch_bounds__(1024) void wide_reduce_kernel(const double *__restr
     if (done && *done) return;
     const int tid = threadIdx.x, l = tid & 63, part = tid >> 6;
     const long long i = (long long)blockIdx.x * 64 + l;
-    double s = 0.0;
-    int w = part;
-    for (; w + 16 * 7 < W; w += 16 * 8) {
-        double t[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = P[(size_t)(w + 16 * k) * npad + i];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += t[k];
-    }
-    for (; w < W; w += 16) s += P[(size_t)w * npad + i];
-    sh[part][l] = s;
+    sh[part][l] = chain_sum(P + i, part, W, 16, (size_t)npad);
     __syncthreads();
     if (part == 0) {
         double t = 0.0;
