@@ -174,6 +174,24 @@ def test_steady_state_allocates_nothing(oa):
     assert np.array_equal(a["beta"][0], c["beta"][0])
 
 
+def test_cache_is_trimmed_on_release(oa, monkeypatch):
+    """cached contexts keep their streams, staging lanes and workspace, but the device copy of the rows only up to
+    OEMGPU_CACHE_KEEP_BYTES (default: an eighth of the device's memory): beyond that it is freed when the call returns, so that one
+    large fit does not hold HBM for the rest of the session.  Forced here with a 1 MB bound: the second call has to
+    allocate the copy again (and nothing else), the fit is the same."""
+    from oem_amd import _lib as L
+    x, y = _data(40000, 30, 9)                      # 9.6 MB of rows
+    kw = dict(penalty=["lasso"], nlambda=8, tol=1e-10)
+    a = oa.oem(x, y, **kw)
+    oa.oem(x, y, **kw)
+    assert L.host_stats()["allocations"] == 0       # default bound: everything stays
+    monkeypatch.setenv("OEMGPU_CACHE_KEEP_BYTES", str(1 << 20))
+    b = oa.oem(x, y, **kw)                          # freed on release ...
+    c = oa.oem(x, y, **kw)
+    assert 1 <= L.host_stats()["allocations"] <= 2  # ... so this call allocated the copy again, and only that
+    assert np.array_equal(a["beta"][0], b["beta"][0]) and np.array_equal(a["beta"][0], c["beta"][0])
+
+
 def test_caller_interrupt(oa, monkeypatch):
     """opts->interrupt (R: R_CheckUserInterrupt under R_ToplevelExec, ref src/oem_dense.cpp:235-238): polled between row blocks
     on the calling thread; a non-zero answer ends the call with OEMGPU_ERR_INTERRUPTED after cleanup, and the next call works"""
