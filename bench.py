@@ -163,7 +163,7 @@ def gen_c1(torch, dev, n, p, m, lo, hi, rank, world):
     return x, y
 
 
-def host_resident(xh, yh, lambdas, p, ngpus=1, calls=5):
+def host_resident(xh, yh, lambdas, p, ngpus=1, calls=5, devices=None):
     """The drop-in level: oemgpu_fit_dense on PAGEABLE host x / y, exactly what `.Call("oem_fit_dense")` hands over
     (staged upload through pinned lanes + moments + solve; contexts and buffers cached by the library).  ngpus > 1: the rows
     split over that many devices INSIDE the library (opts.ngpus: one host thread, staging pipeline and PCIe link per device, the
@@ -174,7 +174,7 @@ def host_resident(xh, yh, lambdas, p, ngpus=1, calls=5):
     lib = L.lib()
     n = xh.shape[0]
     args = api._Args(["elastic.net"], [np.asarray(lambdas)], 100, 1e-4, 1.0, 3.0, 0.5, 1e-10, 500, False, False, np.ones(p),
-                     np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0), ngpus=ngpus if ngpus > 1 else 0)
+                     np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0), ngpus=ngpus if ngpus > 1 else 0, devices=devices)
     outs = args.outputs(p + 1)
     ts, st = [], None
     for k in range(calls + 1):
@@ -192,7 +192,7 @@ def host_resident(xh, yh, lambdas, p, ngpus=1, calls=5):
             "handovers_staged_through_host": st["host_staged_handovers"]}, args
 
 
-def host_resident_c5(torch, dev, ngpus, rows_per_device=2_000_000, calls=3):
+def host_resident_c5(torch, dev, ngpus, rows_per_device=2_000_000, calls=3, devices=None):
     """A sample of config 5's per-GPU share from PAGEABLE host memory through oemgpu_fit_big: `rows_per_device` x 256 rows per
     device (4.1 GB each; the full share is 1.25e7), opts.ngpus devices inside the library.  Every device streams the same host
     block (it is handed over as `ngpus` row shards): the measurement is the staging pipelines, one PCIe link each."""
@@ -210,7 +210,7 @@ def host_resident_c5(torch, dev, ngpus, rows_per_device=2_000_000, calls=3):
     assert xh.flags.f_contiguous
     G = max(1, ngpus)
     args = api._Args(["lasso"], [], 100, 1e-4, 1.0, 3.0, 0.5, 1e-7, 500, False, False, np.ones(p),
-                     np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0), ngpus=G if G > 1 else 0)
+                     np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0), ngpus=G if G > 1 else 0, devices=devices)
     outs = args.outputs(p + 1)
     ns = (C.c_int64 * G)(*[rows_per_device] * G)
     xp = (L._dp * G)(*[api._dptr(xh)] * G)
@@ -566,7 +566,9 @@ def main():
     if in_group:
         dist.destroy_process_group()
     # ---- N > 1: the in-library multi-GPU path (opts.ngpus = N: what an R caller gets), on rank 0 once the other ranks are gone
-    if rank == 0 and world > 1 and not a.no_host and not one_dev:
+    if rank == 0 and world > 1 and not a.no_host:
+        # (OEM_BENCH_ONE_DEVICE: the functional check on a one-GPU box runs the leg too -- N contexts of device 0, a small c5 sample)
+        devs = [0] * world if one_dev else None
         try:
             del backend, bufs
             torch.cuda.empty_cache()
@@ -575,13 +577,13 @@ def main():
             xh = xf.cpu().numpy(); yh = yf.cpu().numpy()
             del xf, yf
             torch.cuda.empty_cache()
-            hr, hargs = host_resident(xh, yh, lambdas, p, ngpus=world)
+            hr, hargs = host_resident(xh, yh, lambdas, p, ngpus=world, devices=devs)
             hr["max_abs_beta_diff_vs_the_rank_sharded_solve"] = float(np.abs(hargs.beta - beta_timed).max())
             out["host_resident_ms"] = {"c1": hr}
             if n == 1_000_000 and p == 100:
                 out["vs_baseline_host_resident"] = README_SECONDS / (hr["median_ms"] * 1e-3)
             del xh, yh
-            out["host_resident_ms"]["c5_sample"] = host_resident_c5(torch, dev, world)
+            out["host_resident_ms"]["c5_sample"] = host_resident_c5(torch, dev, world, rows_per_device=100_000 if one_dev else 2_000_000, devices=devs)
         except Exception as e:
             out.setdefault("host_resident_ms", {})["error"] = repr(e)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -36,9 +36,14 @@ def test_bench_launches_its_own_workers():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env.update(OEM_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "200000", "--no-c5",
-                        "--no-host", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["collective_backend"] == "gloo" and out["allreduce_ms"] > 0
+    # the in-library leg (opts.ngpus = N; here two contexts of the one device), appended by rank 0 after the group is gone
+    hr = out["host_resident_ms"]
+    assert "error" not in hr, hr
+    assert hr["c1"]["ngpus"] == 2 and hr["c1"]["median_ms"] > 0 and hr["c1"]["max_abs_beta_diff_vs_the_rank_sharded_solve"] < 1e-9
+    assert hr["c5_sample"]["ngpus"] == 2 and hr["c5_sample"]["median_ms"] > 0
