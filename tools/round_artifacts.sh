@@ -13,6 +13,8 @@ B="--no-cpu-baseline --no-c5 --no-host --no-two-callers --no-rccl-check"   # the
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_trace -o ${tag} -- python3 bench.py --steps 100 --warmup 10 $B > $o/${tag}_trace_bench.json 2> $o/${tag}_trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_fetch -o ${tag} -- python3 bench.py --steps 5 --warmup 2 $B > /dev/null 2> $o/${tag}_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_write -o ${tag} -- python3 bench.py --steps 5 --warmup 2 $B > /dev/null 2> $o/${tag}_pmc_write.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $o/${tag}_pmc_mfma -o ${tag} -- python3 bench.py --steps 5 --warmup 2 $B > /dev/null 2> $o/${tag}_pmc_mfma.err
+python3 tools/pmc_summary.py gram_ring_kernel $o/${tag}_pmc_gram_mfma.json "$(find $o/${tag}_pmc_mfma -name '*counter_collection.csv' | head -1)"
 f=$(find $o/${tag}_pmc_fetch -name "*counter_collection.csv" | head -1)
 w=$(find $o/${tag}_pmc_write -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_summary.py gram_ring_kernel $o/${tag}_pmc_gram.json "$f" "$w"
@@ -26,6 +28,8 @@ if [ -z "$quick" ]; then
     for c in FETCH_SIZE WRITE_SIZE; do
       rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/${tag}_${cfg}_pmc_$c -o ${tag} -- python3 tools/run_c3.py $cfg 2 > /dev/null 2> $o/${tag}_${cfg}_pmc_$c.err
     done
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $o/${tag}_${cfg}_pmc_mfma -o ${tag} -- python3 tools/run_c3.py $cfg 2 > /dev/null 2> $o/${tag}_${cfg}_pmc_mfma.err
+    python3 tools/pmc_summary.py gram_sb_kernel $o/${tag}_${cfg}_pmc_gram_sb_mfma.json "$(find $o/${tag}_${cfg}_pmc_mfma -name '*counter_collection.csv' | head -1)"
     python3 tools/pmc_summary.py gram_sb_kernel $o/${tag}_${cfg}_pmc_gram_sb.json "$(find $o/${tag}_${cfg}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_${cfg}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
   done
   rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_c4_trace -o ${tag} -- python3 tools/run_c4.py > $o/${tag}_c4_trace.log 2>&1
@@ -46,7 +50,7 @@ if [ -z "$quick" ]; then
   python3 tools/config_times.py > $o/${tag}_config_times.json 2> $o/${tag}_config_times.err
 fi
 # the raw traces stay on the box: gpurun copies back at most 64 MiB
-for d in $o/${tag}_trace $o/${tag}_pmc_fetch $o/${tag}_pmc_write $o/${tag}_*_trace $o/${tag}_*_pmc_FETCH_SIZE $o/${tag}_*_pmc_WRITE_SIZE; do [ -d "$d" ] && rm -rf "$d"; done
+for d in $o/${tag}_trace $o/${tag}_pmc_fetch $o/${tag}_pmc_write $o/${tag}_pmc_mfma $o/${tag}_*_pmc_mfma $o/${tag}_*_trace $o/${tag}_*_pmc_FETCH_SIZE $o/${tag}_*_pmc_WRITE_SIZE; do [ -d "$d" ] && rm -rf "$d"; done
 python3 bench.py > $o/${tag}_bench.json 2> $o/${tag}_bench.err
 tail -c 300 $o/${tag}_bench.err
 head -c 1500 $o/${tag}_kernel_stats.csv
