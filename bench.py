@@ -496,6 +496,12 @@ def main():
         finally:
             os.environ.pop("OEM_FORCE_COLLECTIVES", None)
 
+    mfma_util, mfma_src = None, None
+    mf = sorted((ROOT / "profiles").glob("r*_pmc_gram_mfma.json"))
+    if mf and n == 1_000_000 and p == 100 and world == 1:
+        mfma_util = float(json.loads(mf[-1].read_text())["mfma_util"])
+        mfma_src = ("CONSTANT, not measured in this run: profiles/%s (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on this command): "
+                    "matrix-pipe busy cycles / (GPU cycles x 1024 SIMDs), i.e. at the clock the chip held" % mf[-1].name)
     out = None
     if rank == 0:
         niter_total = int(np.sum(fit["niter"][0]))
@@ -514,7 +520,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gram_ring_kernel<7> (v_mfma_f64_16x16x4_f64; diagonal tiles and the ragged strip as v_mfma_f64_4x4x4_4b_f64 sub-blocks)",
                          "achieved": achieved_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                         "traffic_source": traffic_src,
+                         "traffic_source": traffic_src, "mfma_util_counters": mfma_util, "mfma_util_source": mfma_src,
                          "kernel_ms": gram_ms, "algorithmic_flops": flops, "algorithmic_bytes": bytes_alg,
                          "hbm_GBps_algorithmic": bytes_alg / (gram_ms * 1e-3) / 1e9 if gram_ms > 0 else 0.0},
             "stage_ms": {"shift_sample": acc[L.T_SHIFT], "moments_total": acc[L.T_MOMENTS], "finalize": acc[L.T_FINAL],
