@@ -248,3 +248,47 @@ def test_weighted_xval_against_sklearn_and_numpy():
     b = orc.xval_dense(x, y, foldid, penalty=["lasso", "mcp"], nlambda=8)
     for k in range(2):
         assert np.array_equal(a["beta"][k], b["beta"][k]) and np.allclose(a["cvm"][k], b["cvm"][k], rtol=1e-14)
+
+
+# ------------------------------------------------------------------ the p >= n branch (ref src/oem_dense.h:363-366, 476-482, 513-521)
+@pytest.mark.parametrize("std,icpt", [(False, False), (True, True), (False, True)])
+def test_wide_branch_against_sklearn_and_kkt(std, icpt):
+    """The reference holds no known answer for nobs <= nvars, so the oracle's restatement of that branch (d from XXt / n, two
+    products per iteration) is pinned here on things that are not a restatement: scikit-learn's coordinate-descent lasso on the
+    data as DataStd standardises it, the lasso's KKT conditions written out, and MCP stationarity -- at lambdas where the
+    iteration converges (XtX is singular: small lambdas run into maxit, which is the reference's behaviour and not tested here)."""
+    from sklearn.linear_model import Lasso
+    rng = np.random.default_rng(17)
+    n, p = 60, 150
+    x = np.asfortranarray(rng.normal(size=(n, p)) * rng.uniform(0.5, 2.0, p) + rng.uniform(-1, 1, p))
+    b = np.zeros(p); b[[3, 40, 77, 120]] = [2.0, -1.5, 1.0, 0.8]
+    y = x @ b + 0.3 * rng.normal(size=n) + 0.6
+    # DataStd by hand (ref src/DataStd.h:94-267): flag 1 would scale without centring; the cases here are flags 0, 3 and 2
+    xm = x.mean(0) if icpt else np.zeros(p)
+    xc = x - xm
+    sx = np.sqrt((xc ** 2).sum(0) / n) if std else np.ones(p)
+    xs = xc / sx
+    ym = y.mean() if icpt else 0.0
+    yc = y - ym
+    sy = np.sqrt((yc ** 2).sum() / n) if icpt else 1.0         # flags 2 and 3 both scale y (quirk Q1)
+    ys = yc / sy
+    lam_max = np.abs(xs.T @ ys / n).max() * sy
+    lams = lam_max * np.array([0.9, 0.6, 0.4, 0.25])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fit = orc.fit_dense(x, y, penalty=["lasso", "mcp"], lambda_=lams, gamma=3.0, standardize=std, intercept=icpt, **TIGHT)
+    assert np.all(fit["niter"][0] < TIGHT["maxit"]) and np.all(fit["niter"][1] < TIGHT["maxit"])
+    s2 = np.linalg.svd(xs, compute_uv=False)[0] ** 2 / n
+    assert abs(fit["d"] - 1.005 * s2) < 1e-10 * s2               # d = 1.005 lambda_max(XXt / n) = 1.005 sigma_1^2 / n
+    for i, lam in enumerate(lams):
+        # the oracle's coefficients back on the standardised scale
+        bo = fit["beta"][0][1:, i] * sx / sy
+        sk = Lasso(alpha=lam / sy, fit_intercept=False, tol=1e-14, max_iter=2_000_000).fit(xs, ys)
+        assert np.abs(bo - sk.coef_).max() < 2e-7, (std, icpt, i)
+        g = -xs.T @ (ys - xs @ bo) / n
+        assert _kkt_elementwise(g, bo, np.full(p, lam / sy), lambda t, l: l, 0.0) < 1e-9
+        bm = fit["beta"][1][1:, i] * sx / sy
+        gm = -xs.T @ (ys - xs @ bm) / n
+        assert _kkt_elementwise(gm, bm, np.full(p, lam / sy), lambda t, l: _dmcp(t, l, 3.0), 0.0) < 1e-9
+        if icpt:
+            assert abs(fit["beta"][0][0, i] - (ym - (fit["beta"][0][1:, i] * xm).sum())) < 1e-10
