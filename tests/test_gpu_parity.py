@@ -499,7 +499,11 @@ def test_wide_engine_where_it_is_chosen(oa):
         warnings.simplefilter("ignore")
         fh = oa.oem(x, y, **kw)
         fd = oa.oem(torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t(), y, **kw)
+        buf = torch.zeros((p, n + 7), dtype=torch.float64, device="cuda")      # a column-major view with a leading dimension > n
+        buf[:, :n] = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda")
+        fl = oa.oem(buf[:, :n].t(), y, **kw)
     r = orc.fit_dense(x, y, lambda_min_ratio=0.01, **kw)
+    assert all(np.array_equal(np.asarray(fl["beta"][k]), np.asarray(fd["beta"][k])) for k in range(2))
     for f in (fh, fd):
         assert abs(f["d"] - r["d"]) < 1e-10 * r["d"]
         for k in range(2):
