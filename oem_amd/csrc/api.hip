@@ -685,9 +685,9 @@ static int fit_dense_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int
                               double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
 {
     if (set_device(c)) return OEMGPU_ERR_HIP;
-    const int64_t npad = wide_npad((int)n);
+    const WideLayout lay = wide_layout(n);
     Bump X;
-    const size_t a_xs = X.take(sizeof(double) * (size_t)npad * p), a_ys = X.take(sizeof(double) * (size_t)npad),
+    const size_t a_xs = X.take(sizeof(double) * (size_t)lay.rows() * p), a_ys = X.take(sizeof(double) * (size_t)lay.rows()),
                  a_sc = X.take(sizeof(double) * wide_scratch_doubles((int)n, p));
     if (ctx_grow(c, &c->aux, &c->aux_bytes, X.off)) return OEMGPU_ERR_HIP;
     Bump B;
@@ -698,11 +698,11 @@ static int fit_dense_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int
     int rc;
     {
         Timer t(c, OEMGPU_T_MOMENTS);             // the stage that reads X: DataStd on the data (the standardised copy, X'Y / n)
-        rc = launch_wide_standardize(c->stream, x_dev, n, ld, p, y_dev, standardize, intercept, npad, xs, ys, xy, st);
+        rc = launch_wide_standardize(c->stream, x_dev, n, ld, p, y_dev, standardize, intercept, lay, xs, ys, xy, st);
         if (rc) return rc;
     }
     WideArgs wd;
-    wd.xs = xs; wd.ys = ys; wd.npad = npad; wd.n = (int)n; wd.scratch = (double *)(c->aux + a_sc);
+    wd.xs = xs; wd.ys = ys; wd.lay = lay; wd.n = (int)n; wd.scratch = (double *)(c->aux + a_sc);
     return run_paths(c, B, nullptr, xy, st, p, p, OEMGPU_SEM_DENSE, standardize, intercept, o, nullptr, beta, lambda_out, niter, loss, d,
                      1, 0, false, &wd);
 }

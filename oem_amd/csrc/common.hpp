@@ -166,20 +166,29 @@ int launch_path_coop(hipStream_t s, const PathArgs &a);
 
 // ------------------------------------------------------------------ p >= n (wide.hip, path_large.hip: run_path_wide)
 // The reference's own iteration for p >= n: no Gram, two products with the standardised X per iteration
-// (ref src/oem_dense.h:363-366, 476-482, 513-521).  xs: npad x p column-major (npad = n rounded up to 64, padding rows zero).
+// (ref src/oem_dense.h:363-366, 476-482, 513-521).  Layout of the standardised copy: `nb` row blocks of `rb` rows each (the last
+// may hold fewer), every block a column-major (64 nr) x p matrix of its own with zero padding rows -- a column of a block lives in
+// the registers of one wave (nr <= 32 doubles per lane).  n <= 2048: one block.
+struct WideLayout {
+    int nb;                  // row blocks
+    int rb;                  // data rows per block (block b holds rows [b rb, min(n, (b + 1) rb)))
+    int nr;                  // 64-row register slices per block: a block has 64 nr rows
+    __host__ __device__ long long npad() const { return 64LL * nr; }              // rows of one block
+    __host__ __device__ long long rows() const { return (long long)nb * 64 * nr; }  // rows of all blocks (vectors of this length)
+};
+WideLayout wide_layout(int64_t n);
 struct WideArgs {
-    const double *xs;        // standardised X
-    const double *ys;        // standardised y, npad entries (padding zero)
-    long long npad;
+    const double *xs;        // standardised X: block b at xs + b * npad() * p
+    const double *ys;        // standardised y, rows() entries in the same blocked order (padding zero)
+    WideLayout lay;
     int n;
     double *scratch;         // wide_scratch_doubles(n, p) doubles
 };
-static const int WIDE_MAX_N = 2048;          // the columns of xs live in registers: 64 lanes x 32 rows each
+static const int WIDE_MAX_N = 32768;         // 16 row blocks of 2048 rows
 int wide_workgroups(int n, int p);
-int wide_npad(int n);                       // rows of the standardised copy: n rounded up to the kernels' 64 NR
 size_t wide_scratch_doubles(int n, int p);
 int launch_wide_standardize(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, int standardize, int intercept,
-                            int64_t npad, double *xs, double *ys, double *xy, double *stats);
+                            const WideLayout &lay, double *xs, double *ys, double *xy, double *stats);
 int run_path_wide(hipStream_t s, const PathArgs &a, const WideArgs &w, double *host_scratch);
 
 // opts->interrupt of the call in progress on this thread (api.hip: run_paths sets it around the engines); false if none

@@ -1367,18 +1367,26 @@ static int wide_nr(int n)
 // lane) allow -- a wave walks its columns one after the other (dot product -> wave sum -> operator -> update is a serial chain of
 // ~400 cycles per column), so the CU needs several waves per SIMD to keep loads in flight
 __host__ __device__ constexpr int wide_nw(int nr) { return nr <= 8 ? 16 : (nr <= 16 ? 8 : 4); }
+WideLayout wide_layout(int64_t n)
+{
+    WideLayout L;
+    L.nb = n <= 2048 ? 1 : (int)((n + 2047) / 2048);
+    L.rb = (int)((n + L.nb - 1) / L.nb);
+    L.nr = wide_nr(L.rb);
+    return L;
+}
 int wide_workgroups(int n, int p)
 {
-    const int nw = wide_nw(wide_nr(n));
+    const int nw = wide_nw(wide_layout(n).nr);
     int w = (p + nw - 1) / nw;                           // small p is latency-bound: a column per wave, as many CUs as that gives
     if (w > 256) w = 256;                                // one workgroup per CU: every partial vector is read back by the reduction
     return w < 1 ? 1 : w;
 }
-// P[W][npad] | r | t | v | vp | w (npad each) | T[2 MAXL + 64] | SState[2] (16) | done (2) | flags[2][FMAXB] ints
+// P[W][npad] | r | t | v | vp | w (rows() each) | T[2 MAXL + 64] | SState[2] (16) | done (2) | flags[2][FMAXB] ints | gb[nb][p + 8]
 size_t wide_scratch_doubles(int n, int p)
 {
-    const size_t npad = 64 * (size_t)wide_nr(n);
-    return (size_t)wide_workgroups(n, p) * npad + 5 * npad + 2 * MAXL + 64 + 16 + 2 + FMAXB + 64;
+    const WideLayout L = wide_layout(n);
+    return (size_t)wide_workgroups(n, p) * L.npad() + 5 * (size_t)L.rows() + 2 * MAXL + 64 + 16 + 2 + FMAXB + 64 + (size_t)L.nb * (p + 8);
 }
 
 // sum of p[w * stride] over w = first, first + step, ... < count, in that order, eight loads in flight (a loop of dependent-free
@@ -1603,13 +1611,141 @@ __global__ __launch_bounds__(1024) void wide_reduce_kernel(const double *__restr
     }
 }
 
+// g = sum over the row blocks of their g_b (block order)
+__global__ __launch_bounds__(256) void wide_block_sum_kernel(const double *__restrict__ gb, int nb, int q, double *__restrict__ g, const int *__restrict__ done)
+{
+    if (done && *done) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= q) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += gb[(size_t)b * (q + 8) + j];
+    g[j] = s;
+}
+
+// n > 2048: the rows in nb blocks of <= 2048 (a column of a block fits a wave's registers).  A dot product x_j . r now spans the
+// blocks, so an iteration is the two products as passes of their own -- t = Xs beta block by block (W_XB + reduction), g = Xs' t / n
+// as per-block partial g_b (W_XTV) added in block order -- around path_update_kernel: every penalty, accelerate, compute.loss; 16 n p
+// bytes per iteration like the reference's two GEMVs.  The eigen step the same way on vectors of lay.rows() entries (the padding
+// rows of Xs are zero, so the padded operator has the spectrum of Xs Xs'/n plus zeros).
+template <int NR>
+static int run_path_wide_blocks(hipStream_t s, const PathArgs &a, const WideArgs &wd, double *host_scratch)
+{
+    const int q = a.p, n = wd.n, W = wide_workgroups(n, q), cpw = (q + W - 1) / W, nb = wd.lay.nb;
+    constexpr int NT = 64 * wide_nw(NR);
+    const long long npad = 64 * NR, rows = wd.lay.rows();
+    double *P = wd.scratch, *t = P + (size_t)W * npad + rows, *v = t + rows, *vp = v + rows, *w = vp + rows;
+    double *T = w + rows;
+    double *gb = T + 2 * MAXL + 64 + 16 + 2 + FMAXB + 64;
+    LState *st = reinterpret_cast<LState *>(a.work);
+    double *beta = a.work + STATE_DBL, *g = beta + (q + 8);
+    OEM_HIP(hipMemsetAsync(a.work, 0, sizeof(double) * path_large_work_doubles(q, 0), s));
+    OEM_HIP(hipMemsetAsync(wd.scratch, 0, sizeof(double) * wide_scratch_doubles(n, q), s));
+    const size_t lds = sizeof(double) * ((size_t)wide_nw(NR) * (size_t)npad + 2 * (size_t)cpw);
+    if (lds > 64 * 1024) {
+        OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_cols_kernel<NR, W_XB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_cols_kernel<NR, W_XTV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    const int rblocks = (int)(npad / 64);
+    auto xb = [&](double *coef, double *out, const int *done) {          // out (rows()) = Xs coef, block by block
+        for (int b = 0; b < nb; ++b) {
+            hipLaunchKernelGGL((wide_cols_kernel<NR, W_XB>), dim3(W), dim3(NT), lds, s, a, wd.xs + (size_t)b * npad * q, (const double *)nullptr, wd.ys, P, coef,
+                               (double *)nullptr, (SState *)nullptr, (int *)nullptr, (int *)nullptr, done, 0, 0.0, n, cpw);
+            hipLaunchKernelGGL((wide_reduce_kernel<W_XB>), dim3(rblocks), dim3(1024), 0, s, P, W, npad, n, wd.ys, out + (size_t)b * npad, done);
+        }
+    };
+    auto xtv = [&](const double *vec, double *gout, const int *done) {   // gout (q) = Xs' vec / n
+        for (int b = 0; b < nb; ++b)
+            hipLaunchKernelGGL((wide_cols_kernel<NR, W_XTV>), dim3(W), dim3(NT), lds, s, a, wd.xs + (size_t)b * npad * q, vec + (size_t)b * npad, wd.ys, P,
+                               (double *)nullptr, gb + (size_t)b * (q + 8), (SState *)nullptr, (int *)nullptr, (int *)nullptr, done, 0, 0.0, n, cpw);
+        hipLaunchKernelGGL(wide_block_sum_kernel, dim3((q + 255) / 256), dim3(256), 0, s, gb, nb, q, gout, done);
+    };
+    // ---- d = 1.005 lambda_max(Xs Xs'/n)
+    const int mmax = n < MAXL ? n : MAXL;
+    double theta = 0.0, theta_prev = -1.0;
+    bool lz_capped = true;
+    double *hT = host_scratch;
+    int m = 0;
+    hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, s, (int)rows, v, vp);
+    while (m < mmax) {
+        const int chunk = (mmax - m) < 16 ? (mmax - m) : 16;
+        for (int k = 0; k < chunk; ++k, ++m) {
+            xtv(v, g, nullptr);
+            xb(g, w, nullptr);
+            hipLaunchKernelGGL(lanczos_update_kernel, dim3(1), dim3(1024), 0, s, (int)rows, m, v, vp, w, T);
+        }
+        OEM_HIP(hipGetLastError());
+        OEM_HIP(hipMemcpyAsync(hT, T, sizeof(double) * 2 * MAXL, hipMemcpyDeviceToHost, s));
+        OEM_HIP(hipStreamSynchronize(s));
+        int mm = m;
+        for (int k = 0; k < m; ++k)
+            if (!(hT[MAXL + k] > 1e-13 * std::fabs(hT[k]))) { mm = k + 1; break; }
+        theta = tridiag_max_host(hT, hT + MAXL, mm);
+        if (mm < m) { lz_capped = false; break; }
+        if (m >= 24) {
+            const double t1 = tridiag_max_host(hT, hT + MAXL, m - 8), t0 = tridiag_max_host(hT, hT + MAXL, m - 16);
+            const double mv = theta - t1, mvp = t1 - t0, ath = std::fabs(theta);
+            if (mv <= 1e-14 * ath || (mv < 0.01 * mvp && mv * mv <= OEM_LANCZOS_TAIL_TOL * ath * (mvp - mv))) { lz_capped = false; break; }
+        }
+        if (theta_prev > 0 && std::fabs(theta - theta_prev) <= 1e-12 * std::fabs(theta)) { lz_capped = false; break; }
+        theta_prev = theta;
+    }
+    if (mmax >= n) lz_capped = false;
+    const double d = theta * 1.005;                     // ref src/oem_dense.h:498
+    OEM_HIP(hipMemsetAsync(g, 0, sizeof(double) * (size_t)(q + 8), s));
+    hipLaunchKernelGGL(path_init_kernel, dim3(1), dim3(1024), 0, s, a, st, beta, d, theta, m, lz_capped ? 1 : 0);
+    OEM_HIP(hipGetLastError());
+    if (a.npen == 0) return 0;
+    const size_t shu = a.ngroups > 0 ? sizeof(double) * (size_t)(q + a.ngroups + 8) : 64;
+    if (shu > 64 * 1024) {
+        if (shu > 160 * 1024 - 4096) { set_error("p >= n with a group penalty: p = %d does not fit the update kernel's LDS", q); return OEMGPU_ERR_UNSUPPORTED; }
+        OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shu));
+    }
+    auto enq = [&](int count) {
+        for (int k = 0; k < count; ++k) {
+            xb(beta, t, (const int *)&st->done);
+            xtv(t, g, (const int *)&st->done);
+            hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), shu, s, a, st, beta, g);
+        }
+    };
+    const int FB = 16;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        enq(FB);
+        if (hipStreamEndCapture(s, &graph) != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            graph = nullptr; exec = nullptr;
+            (void)hipGetLastError();
+        }
+    } else (void)hipGetLastError();
+    const long long max_it = (long long)a.npen * a.nl * ((long long)a.maxit + 3) + 8;
+    long long launched = 0;
+    int *hdone = reinterpret_cast<int *>(host_scratch);
+    int rc = 0;
+    for (;;) {
+        if (exec) { if (hipGraphLaunch(exec, s) != hipSuccess) { set_error("hipGraphLaunch failed"); rc = OEMGPU_ERR_HIP; break; } }
+        else enq(FB);
+        if (hipGetLastError() != hipSuccess) { set_error("wide engine: launch failed"); rc = OEMGPU_ERR_HIP; break; }
+        launched += FB;
+        if (hipMemcpyAsync(hdone, &st->done, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { set_error("wide engine: device error"); rc = OEMGPU_ERR_HIP; break; }
+        if (*hdone) break;
+        if (caller_interrupted()) { set_error("interrupted by the caller"); rc = OEMGPU_ERR_INTERRUPTED; break; }
+        if (launched > max_it) { set_error("wide engine did not finish within %lld iterations", max_it); rc = OEMGPU_ERR_INTERNAL; break; }
+    }
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+}
+
 template <int NR>
 static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd, double *host_scratch)
-{
+{    if (wd.lay.nb > 1) return run_path_wide_blocks<NR>(s, a, wd, host_scratch);
+
     const int q = a.p, n = wd.n, W = wide_workgroups(n, q), cpw = (q + W - 1) / W;
     constexpr int NT = 64 * wide_nw(NR);
     const long long npad = 64 * NR;
-    if (wd.npad != npad) { set_error("internal: wide engine padding"); return OEMGPU_ERR_INTERNAL; }
+    if (wd.lay.npad() != npad) { set_error("internal: wide engine padding"); return OEMGPU_ERR_INTERNAL; }
     double *P = wd.scratch, *r = P + (size_t)W * npad, *t = r + npad, *v = t + npad, *vp = v + npad, *w = vp + npad;
     double *T = w + npad;
     SState *SS = reinterpret_cast<SState *>(T + 2 * MAXL + 64);
@@ -1663,9 +1799,9 @@ static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd
     OEM_HIP(hipGetLastError());
     if (a.npen == 0) return 0;
     const bool fused = a.ngroups == 0 && !a.accelerate && !a.compute_loss && !a.sinv && W <= FMAXB && !getenv("OEM_WIDE_GENERAL");
-    size_t shu = sizeof(double) * (size_t)(q + (a.ngroups > 0 ? a.ngroups : 0) + 8);
+    size_t shu = a.ngroups > 0 ? sizeof(double) * (size_t)(q + a.ngroups + 8) : 64;        // U[q] | F[ngroups]: group operators only
     if (!fused && shu > 64 * 1024) {
-        if (shu > 160 * 1024 - 4096) { set_error("p >= n with a group penalty / accelerate / compute.loss: p = %d does not fit the update kernel's LDS", q); return OEMGPU_ERR_UNSUPPORTED; }
+        if (shu > 160 * 1024 - 4096) { set_error("p >= n with a group penalty: p = %d does not fit the update kernel's LDS", q); return OEMGPU_ERR_UNSUPPORTED; }
         OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shu));
     }
     if (fused) hipLaunchKernelGGL(sym_init_kernel, dim3(1), dim3(1), 0, s, SS, a);
@@ -1718,7 +1854,7 @@ static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd
 
 int run_path_wide(hipStream_t s, const PathArgs &a, const WideArgs &wd, double *host_scratch)
 {
-    switch (wide_nr(wd.n)) {
+    switch (wd.lay.nr) {
     case 1: return run_path_wide_nr<1>(s, a, wd, host_scratch);
     case 2: return run_path_wide_nr<2>(s, a, wd, host_scratch);
     case 3: return run_path_wide_nr<3>(s, a, wd, host_scratch);
@@ -1731,10 +1867,9 @@ int run_path_wide(hipStream_t s, const PathArgs &a, const WideArgs &wd, double *
     case 32: return run_path_wide_nr<32>(s, a, wd, host_scratch);
     default: break;
     }
-    set_error("p >= n: the wide engine holds columns of n <= %d rows", WIDE_MAX_N);
+    set_error("p >= n: the wide engine holds n <= %d rows", WIDE_MAX_N);
     return OEMGPU_ERR_UNSUPPORTED;
 }
 
-int wide_npad(int n) { return 64 * wide_nr(n); }
 
 }  // namespace oemgpu

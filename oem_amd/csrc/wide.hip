@@ -40,8 +40,9 @@ __device__ __forceinline__ double block_sum1024(double v, double *sh)
 }
 
 // Y: flag 1 scale by the centred sd_n; flags 2 and 3 (2 falls through into 3, quirk Q1): centre, scaleY = |Yc| / sqrt(n), divide
-// (ref src/DataStd.h:112-138).  ys has npad entries, the tail zero.  stats: [0] meanY [1] scaleY [2] sum ys^2 [3] n.
-__global__ __launch_bounds__(1024) void wide_y_kernel(const double *__restrict__ y, long long n, long long npad, int flag,
+// (ref src/DataStd.h:112-138).  ys is written in the blocked row order of WideLayout (its padding was zeroed by the caller).
+// stats: [0] meanY [1] scaleY [2] sum ys^2 [3] n.
+__global__ __launch_bounds__(1024) void wide_y_kernel(const double *__restrict__ y, long long n, WideLayout lay, int flag,
                                                        double *__restrict__ ys, double *__restrict__ stats)
 {
     __shared__ double sh[16];
@@ -58,10 +59,10 @@ __global__ __launch_bounds__(1024) void wide_y_kernel(const double *__restrict__
         if (flag >= 2) meany = mean;
     }
     double yy = 0.0;
-    for (long long i = tid; i < npad; i += nt) {
-        double v = 0.0;
-        if (i < n) v = (flag == 0) ? y[i] : (flag == 1 ? y[i] / scaley : (y[i] - meany) / scaley);
-        ys[i] = v;
+    for (long long i = tid; i < n; i += nt) {
+        const double v = (flag == 0) ? y[i] : (flag == 1 ? y[i] / scaley : (y[i] - meany) / scaley);
+        const long long b = i / lay.rb;
+        ys[b * lay.npad() + (i - b * lay.rb)] = v;
         yy = fma(v, v, yy);
     }
     yy = block_sum1024(yy, sh);
@@ -69,17 +70,16 @@ __global__ __launch_bounds__(1024) void wide_y_kernel(const double *__restrict__
 }
 
 // X: one wave per column.  flag 1: scale by sd_n (about the mean, the column is NOT centred); flag 2: centre; flag 3: centre,
-// scale = |Xc_j| / sqrt(n) (zero -> 1), divide (ref src/DataStd.h:203-265).  xs: npad x p, the padding rows zero.
+// scale = |Xc_j| / sqrt(n) (zero -> 1), divide (ref src/DataStd.h:203-265).  xs in the blocked layout (padding zeroed by the caller).
 // Then XY_j = xs_j . ys / n.  A column constant to within 32 eps of its mean is the exact constant it is (as gram.hip: Mom::flat).
 __global__ __launch_bounds__(256) void wide_x_kernel(const double *__restrict__ x, long long n, long long ld, int p, int flag,
-                                                      const double *__restrict__ ys, long long npad, double *__restrict__ xs,
+                                                      const double *__restrict__ ys, WideLayout lay, double *__restrict__ xs,
                                                       double *__restrict__ xy, double *__restrict__ stats)
 {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= p) return;
     const double *c = x + (size_t)j * ld;
-    double *o = xs + (size_t)j * npad;
     double mean = 0.0, scale = 1.0;
     bool flat = false;
     if (flag != 0) {
@@ -97,18 +97,18 @@ __global__ __launch_bounds__(256) void wide_x_kernel(const double *__restrict__ 
         }
     }
     const double rs = 1.0 / scale;
+    const long long npb = lay.npad();
     double dot = 0.0;
-    for (long long i = lane; i < npad; i += 64) {
-        double v = 0.0;
-        if (i < n) {
-            const double t = c[i];
-            if (flag == 0) v = t;
-            else if (flag == 1) v = t * rs;                       // ref :211-214 multiplies by the reciprocal
-            else if (flag == 2) v = t - mean;
-            else v = flat ? 0.0 : (t - mean) / scale;
-            dot = fma(v, ys[i], dot);
-        }
-        o[i] = v;
+    for (long long i = lane; i < n; i += 64) {
+        const double t = c[i];
+        double v;
+        if (flag == 0) v = t;
+        else if (flag == 1) v = t * rs;                           // ref :211-214 multiplies by the reciprocal
+        else if (flag == 2) v = t - mean;
+        else v = flat ? 0.0 : (t - mean) / scale;
+        const long long b = i / lay.rb, off = b * npb + (i - b * lay.rb);
+        dot = fma(v, ys[off], dot);
+        xs[((size_t)b * p + j) * npb + (i - b * lay.rb)] = v;
     }
     dot = wave_sum(dot);
     if (lane == 0) {
@@ -121,12 +121,15 @@ __global__ __launch_bounds__(256) void wide_x_kernel(const double *__restrict__ 
 }  // namespace
 
 int launch_wide_standardize(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, int standardize, int intercept,
-                            int64_t npad, double *xs, double *ys, double *xy, double *stats)
+                            const WideLayout &lay, double *xs, double *ys, double *xy, double *stats)
 {
     const int flag = (standardize ? 1 : 0) + 2 * (intercept ? 1 : 0);
     OEM_HIP(hipMemsetAsync(stats + stats_shift_flag(p), 0, 2 * sizeof(double), s));      // no shift machinery on this branch
-    hipLaunchKernelGGL(wide_y_kernel, dim3(1), dim3(1024), 0, s, y, (long long)n, (long long)npad, flag, ys, stats);
-    hipLaunchKernelGGL(wide_x_kernel, dim3((p + 3) / 4), dim3(256), 0, s, x, (long long)n, (long long)ld, p, flag, ys, (long long)npad, xs, xy, stats);
+    // the padding rows of every block are zero: no kernel of the wide engine has bounds logic
+    OEM_HIP(hipMemsetAsync(xs, 0, sizeof(double) * (size_t)lay.rows() * p, s));
+    OEM_HIP(hipMemsetAsync(ys, 0, sizeof(double) * (size_t)lay.rows(), s));
+    hipLaunchKernelGGL(wide_y_kernel, dim3(1), dim3(1024), 0, s, y, (long long)n, lay, flag, ys, stats);
+    hipLaunchKernelGGL(wide_x_kernel, dim3((p + 3) / 4), dim3(256), 0, s, x, (long long)n, (long long)ld, p, flag, ys, lay, xs, xy, stats);
     OEM_HIP(hipGetLastError());
     return 0;
 }

@@ -460,29 +460,32 @@ def test_wide_engine(oa, n, p, flag, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,p", [(1100, 1200), (1500, 1501), (2048, 2100)])
+@pytest.mark.parametrize("n,p", [(1100, 1200), (1500, 1501), (2048, 2100), (2049, 2100), (2500, 2600)])
 def test_wide_engine_tall_columns(oa, n, p, monkeypatch):
-    """the column heights that take 24 and 32 registers per lane (no software prefetch, four waves per workgroup), up to the
-    engine's limit n = 2048 -- and one row more, where the call must fall back to the Gram form and still agree"""
+    """the column heights that take 24 and 32 registers per lane (four waves per workgroup), and beyond 2048 rows the ROW-BLOCKED
+    form: the rows in blocks of <= 2048, the two products as passes of their own (t = Xs beta block by block, g = Xs' t / n as
+    per-block partial sums added in block order) around the single-workgroup update kernel -- element-wise and group penalties,
+    compute.loss, against the oracle's restatement of the branch"""
     monkeypatch.setenv("OEM_WIDE", "1")
     x, y = _data(n, p, 40 + n, mean=0.2, nnz=8)
-    kw = dict(penalty=["lasso", "mcp"], nlambda=5, tol=1e-8, maxit=300)
+    groups = np.arange(p) // 6 + 1
+    kw = dict(penalty=["lasso", "mcp", "grp.lasso"], groups=groups, nlambda=4, tol=1e-8, maxit=200, compute_loss=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f = oa.oem(x, y, **kw)
+        r = orc.fit_dense(x, y, lambda_min_ratio=0.01, unique_groups=np.unique(groups), **kw)
+    assert abs(f["d"] - r["d"]) < DTOL * r["d"]
+    for k in range(3):
+        assert np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max() < 1e-7 * max(1.0, float(np.abs(r["beta"][k]).max()))
+        assert np.mean(np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int)) > 1) <= 0.25
+        assert np.allclose(f["loss"][k], r["loss"][k], rtol=1e-8)
+    kw = dict(penalty=["lasso"], nlambda=4, tol=1e-8, maxit=200)      # element-wise alone: the fused form up to 2048 rows
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         f = oa.oem(x, y, **kw)
         r = orc.fit_dense(x, y, lambda_min_ratio=0.01, **kw)
-    assert abs(f["d"] - r["d"]) < DTOL * r["d"]
-    for k in range(2):
-        assert np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max() < 1e-7 * max(1.0, float(np.abs(r["beta"][k]).max()))
-        assert np.mean(np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int)) > 1) <= 0.25
-    if n == 2048:
-        x2, y2 = _data(n + 1, p, 41 + n, mean=0.2, nnz=8)          # 2049 rows: beyond the engine, served by the Gram form
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            f2 = oa.oem(x2, y2, **kw)
-            r2 = orc.fit_dense(x2, y2, lambda_min_ratio=0.01, **kw)
-        for k in range(2):
-            assert np.abs(np.asarray(f2["beta"][k]) - np.asarray(r2["beta"][k])).max() < 1e-7 * max(1.0, float(np.abs(r2["beta"][k]).max()))
+    assert np.abs(np.asarray(f["beta"][0]) - np.asarray(r["beta"][0])).max() < 1e-7 * max(1.0, float(np.abs(r["beta"][0]).max()))
+    assert np.mean(np.abs(np.ravel(f["niter"][0]).astype(int) - np.ravel(r["niter"][0]).astype(int)) > 1) <= 0.25
 
 
 @pytest.mark.gpu
