@@ -512,6 +512,17 @@ def test_wide_engine_where_it_is_chosen(oa):
         for k in range(2):
             assert np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max() < 1e-7 * max(1.0, float(np.abs(r["beta"][k]).max()))
             assert np.mean(np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int)) > 1) <= 0.25
+    # beyond 2048 rows the library takes the row-blocked form by itself (here two blocks of 1050 rows)
+    n, p = 2100, 4300
+    x = np.asfortranarray(rng.normal(size=(n, p)) + 0.1)
+    y = x[:, :8] @ rng.uniform(0.5, 1.5, 8) + rng.normal(size=n)
+    kw = dict(penalty=["lasso"], nlambda=3, tol=1e-8, maxit=100)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f = oa.oem(x, y, **kw)
+    r = orc.fit_dense(x, y, lambda_min_ratio=0.01, **kw)
+    assert abs(f["d"] - r["d"]) < 1e-10 * r["d"]
+    assert np.abs(np.asarray(f["beta"][0]) - np.asarray(r["beta"][0])).max() < 1e-7 * max(1.0, float(np.abs(r["beta"][0]).max()))
     n, p = 500, 20_000
     x = np.asfortranarray(rng.normal(size=(n, p)))
     b = np.zeros(p); b[:10] = rng.uniform(1.0, 2.0, 10)

@@ -9,7 +9,7 @@ from oem_amd import _lib as L
 warnings.simplefilter("ignore")
 rng = np.random.default_rng(5)
 lib = L.lib()
-for n, p, nlam, gram in ((500, 2000, 50, True), (500, 20000, 50, False), (2000, 20000, 20, False), (200, 100000, 20, False)):
+for n, p, nlam, gram in ((500, 2000, 50, True), (500, 20000, 50, False), (2000, 20000, 20, False), (200, 100000, 20, False), (4000, 50000, 10, False)):
     x = np.asfortranarray(rng.normal(size=(n, p))); y = x[:, :10] @ rng.uniform(0.5, 1.5, 10) + rng.normal(size=n)
     xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
     kw = dict(penalty="lasso", nlambda=nlam, tol=1e-7)
@@ -25,7 +25,7 @@ for n, p, nlam, gram in ((500, 2000, 50, True), (500, 20000, 50, False), (2000, 
         for _ in range(2):                                        # (the first host call of a shape allocates its staging and device buffers)
             t0 = time.perf_counter(); oem_amd.oem(x, y, **kw); th = min(th, time.perf_counter() - t0)
         it = int(fit["niter"][0].sum())
-        byt = 8.0 * (64 * ((n + 63) // 64)) * p
+        byt = 8.0 * (64 * ((n + 63) // 64)) * p * (2 if n > 2048 else 1)      # beyond 2048 rows: two passes over Xs per iteration
         print(f"n={n} p={p} {nlam} lambdas [{mode}]: resident {1e3 * best:.1f} ms (stage reading X {ms[1]:.2f} ms, eigen + path {ms[3]:.1f} ms), "
               f"host x {1e3 * th:.1f} ms; {it} iterations, {1e3 * ms[3] / it:.2f} us per iteration"
-              + (f", {byt * it / (ms[3] * 1e-3) / 1e12:.2f} TB/s over one read of Xs per iteration" if mode == "wide" else ""), flush=True)
+              + (f", {byt * it / (ms[3] * 1e-3) / 1e12:.2f} TB/s over {'two reads' if n > 2048 else 'one read'} of Xs per iteration" if mode == "wide" else ""), flush=True)
