@@ -92,7 +92,7 @@ typedef struct oemgpu_opts {
 /* replaces oem_fit_dense, ref src/oem_dense.cpp:30-309 (family "gaussian", weights empty).
  * Both branches of ref src/oem_dense.h:476-482: n > p, and p >= n, where the reference iterates through X twice
  * (u = X'(Y - X b)/n + d b, d from XXt/n, ref :363-366, 513-521).  The library runs that very form -- a standardised copy of x
- * on the device, one read of it per iteration, no p x p matrix -- where it pays (n <= 2048, p > 1024 and 2 n < p: p = 20,000
+ * on the device, one read of it per iteration, no p x p matrix -- where it pays (n <= 32768, p > 1024 and 2 n < p: p = 20,000
  * needs 80 MB instead of 3.2 GB), and the same iteration written on the Gram elsewhere. */
 int oemgpu_fit_dense(const double *x, int64_t n, int32_t p, const double *y,
                      int32_t standardize, int32_t intercept, const oemgpu_opts *o,
