@@ -136,6 +136,46 @@ def self_launch(a, argv):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
+def live_pmc(kernel_substring, counter_sets, timeout=180):
+    """Hardware counters of one kernel, measured in THIS run: each counter set is one child process
+    `rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 bench.py --steps 3 ...` (counters in passes of their own, the
+    program itself behind `--`, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; a child process, never an exec).  Returns
+    {counter: mean value per dispatch of the kernels whose name contains `kernel_substring`}; raises on any failure (the caller
+    falls back to the figures under profiles/)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        raise RuntimeError("rocprofv3 not on PATH")
+    out = {}
+    for ctrs in counter_sets:
+        tmp = tempfile.mkdtemp(prefix="oem_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--pmc"] + list(ctrs) + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--",
+                   sys.executable, str(Path(__file__).resolve()), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-c5", "--no-host",
+                   "--no-two-callers", "--no-rccl-check", "--no-live-pmc"]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OEM_BENCH_ARGV")}
+            env["TMPDIR"] = "/tmp"
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+            if r.returncode != 0:
+                raise RuntimeError("rocprofv3 pass %s exited with %d" % (ctrs, r.returncode))
+            acc = {}
+            for path in glob.glob(tmp + "/**/*counter_collection.csv", recursive=True):
+                with open(path, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel_substring in row["Kernel_Name"]:
+                            acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for c in ctrs:
+                if c not in acc:
+                    raise RuntimeError("counter %s not reported for %s" % (c, kernel_substring))
+                out[c] = sum(acc[c]) / len(acc[c])
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def gen_c1(torch, dev, n, p, m, lo, hi, rank, world):
     """Rows [lo, hi) of the README-shaped problem on `dev`: (x as an (hi - lo, p) column-major view, y).  The SAME n x p problem for
     every N in {1, 2, 4, 8}: the rows come in 8 blocks, block k from its own seed, and a rank generates exactly the blocks of its
@@ -247,6 +287,8 @@ def main():
     ap.add_argument("--no-two-callers", action="store_true", help="skip the two-concurrent-callers extra (profiling runs: kernels of two "
                                                                    "callers overlap and their durations no longer describe one solve)")
     ap.add_argument("--no-rccl-check", action="store_true", help="N = 1: skip the one-rank RCCL self-check (process group of world size 1)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not measure the Gram kernel's HBM traffic / MFMA utilisation in child rocprofv3 "
+                                                                 "passes (the figures then come from profiles/, flagged as constants)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU baseline sample (0 = the full workload)")
     argv = sys.argv[1:]
@@ -624,6 +666,23 @@ def main():
         tca = time.perf_counter() - t0
         out["cpu_baseline_all_cores"] = {"value": 1.0 / tca * (rows / n), "unit": "solves/s", "cores": nc, "kind": "port",
                                          "seconds": tca, "sample": out["cpu_baseline"]["sample"]}
+    if rank == 0 and world == 1 and not a.no_live_pmc and n == 1_000_000 and p == 100:
+        # HBM traffic and matrix-pipe utilisation of the dominant kernel, measured NOW (three short child passes under rocprofv3) instead
+        # of quoted from profiles/: FETCH_SIZE x 2 + WRITE_SIZE (KB -> bytes; the guide's gfx950 correction for 16-byte-per-lane
+        # streaming reads), and rocprofv3's own MfmaUtil formula (GRBM_GUI_ACTIVE arrives summed over the 8 XCDs)
+        try:
+            t0 = time.perf_counter()
+            c = live_pmc("gram_ring_kernel", [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]])
+            rf = out["roofline"]
+            rf["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            rf["traffic_source"] = ("measured in this run: child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of this command "
+                                    "(--steps 3), mean per launch of gram_ring_kernel; FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes")
+            rf["mfma_util_counters"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+            rf["mfma_util_source"] = ("measured in this run: child pass `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`: busy cycles / "
+                                      "(GPU cycles x 1024 SIMDs), i.e. at the clock the chip held")
+            rf["live_pmc_seconds"] = time.perf_counter() - t0
+        except Exception as e:
+            out["roofline"]["live_pmc_error"] = repr(e)
     if rank == 0:
         emit(out)
 

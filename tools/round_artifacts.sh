@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 o=gpurun_out
 mkdir -p $o
-B="--no-cpu-baseline --no-c5 --no-host --no-two-callers --no-rccl-check"   # the profiled command: the timed solves alone
+B="--no-cpu-baseline --no-c5 --no-host --no-two-callers --no-rccl-check --no-live-pmc"   # the profiled command: the timed solves alone
 # ---- config 1 (the bench command): per-kernel stats, then FETCH_SIZE / WRITE_SIZE in their own passes
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_trace -o ${tag} -- python3 bench.py --steps 100 --warmup 10 $B > $o/${tag}_trace_bench.json 2> $o/${tag}_trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_fetch -o ${tag} -- python3 bench.py --steps 5 --warmup 2 $B > /dev/null 2> $o/${tag}_pmc_fetch.err
