@@ -190,6 +190,13 @@ size_t wide_scratch_doubles(int n, int p);
 int launch_wide_standardize(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, int standardize, int intercept,
                             const WideLayout &lay, double *xs, double *ys, double *xy, double *stats);
 int run_path_wide(hipStream_t s, const PathArgs &a, const WideArgs &w, double *host_scratch);
+// the same iteration as ONE persistent launch of cooperating workgroups with Xs in registers (path_wcoop.hip): element-wise
+// penalties, one row block, p <= 4 CW WCOOP_GMAX columns (CW = 16 / 8 / 4 / 2 by column height)
+static const int WCOOP_GMAX = 128;
+int path_wcoop_workgroups(int n, int p);
+size_t path_wcoop_xchg_doubles(int n, int p);
+bool path_wcoop_eligible(const PathArgs &a, const WideArgs &w);
+int launch_path_wcoop(hipStream_t s, const PathArgs &a, const WideArgs &w);
 
 // opts->interrupt of the call in progress on this thread (api.hip: run_paths sets it around the engines); false if none
 bool caller_interrupted();

@@ -1386,7 +1386,9 @@ int wide_workgroups(int n, int p)
 size_t wide_scratch_doubles(int n, int p)
 {
     const WideLayout L = wide_layout(n);
-    return (size_t)wide_workgroups(n, p) * L.npad() + 5 * (size_t)L.rows() + 2 * MAXL + 64 + 16 + 2 + FMAXB + 64 + (size_t)L.nb * (p + 8);
+    const size_t own = (size_t)wide_workgroups(n, p) * L.npad() + 5 * (size_t)L.rows() + 2 * MAXL + 64 + 16 + 2 + FMAXB + 64 + (size_t)L.nb * (p + 8);
+    const size_t coop = path_wcoop_xchg_doubles(n, p);         // the persistent engine's exchange granules live in the same scratch
+    return own > coop ? own : coop;
 }
 
 // sum of p[w * stride] over w = first, first + step, ... < count, in that order, eight loads in flight (a loop of dependent-free

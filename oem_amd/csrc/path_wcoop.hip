@@ -1,0 +1,644 @@
+// path_wcoop.hip -- p >= n where the standardised X fits the register files of <= 128 CUs: eigenvalue + penalty x lambda path in
+// ONE persistent launch of cooperating workgroups (n = 500, p = 2,000: 14,009 iterations at two launches = 11.3 us each were the
+// whole 158 ms of the launch-per-iteration wide engine, path_large.hip: run_path_wide, on 8 MB of data).
+//
+// Same arithmetic as that engine (ref src/oem_dense.h:363-366, 476-482, 513-521; operators :76-149; stop rule src/utils.cpp:537-549;
+// lambda grid src/oem_dense.cpp:175-227):       u = Xs'(Ys - Xs beta)/n + d beta,   d = 1.005 lambda_max(Xs Xs'/n)
+//
+//   * Xs stays in REGISTERS for the whole call, COLUMNS split over G = ceil(p / (4 CW)) workgroups (one per CU, four waves): a wave
+//     owns CW columns, lane l their rows l, l + 64, ... (NR per column; CW NR <= 64 doubles per lane).  A column is coordinate-local,
+//     so one pass over the registers does both products (as wide_cols_kernel does from memory):
+//       dot_c = x_c . r     lane-local FMAs, then ONE transposed butterfly for all CW columns of the wave (row_mirror,
+//                           row_half_mirror, quad_perm: each stage halves the number of live values, CW - 1 adds instead of
+//                           6 CW), the four rows through v_permlane16/32_swap; lane l ends with the column (l & 15) >> SH
+//       beta_c' = T(dot_c / n + d beta_c)     one operator per lane (its own column), the coefficient lives in that lane
+//       t += x_c beta_c'    v_fmac_f64_dpp row_newbcast straight from the lane that holds beta_c' (zero coefficients skipped)
+//   * what crosses workgroups is the n-vector Xs beta' (or Xs Xs'v during Lanczos) as G partial vectors: an ALL-REDUCE in two
+//     exchanges of n values each, through the memory side as data-tagged 16-byte pairs {lo, tag, hi, tag} (path_coop.hip's recipe:
+//     the data is the flag, each 8-byte half carries its own tag, no fence; device-scope (sc1) stores and polls, ONE poll sweep in
+//     flight, buffers by parity):
+//       1. workgroup g stores its partial rows into the slice owner's area; owner h (rows [h SL, (h + 1) SL)) adds the G
+//          partials of its rows in workgroup order (eight interleaved chains per row, combined by DPP: fixed order, bitwise
+//          reproducible) and forms r = Ys - sum (or sum / n);
+//       2. the owners publish their slices of r and everybody gathers all n rows.
+//     The "some coefficient still moving" bit of every workgroup rides in the tag of its granules (tag = epoch << 1 | bit): the
+//     owners OR what they gathered into the tags of exchange 2, so after the all-reduce every workgroup holds the same stop
+//     decision and the lambda / penalty state machine runs replicated, with no flag or scalar of its own crossing workgroups.
+//   * the eigenvalue step is Lanczos on n-vectors with the same registers and the same all-reduce (vector updates and both inner
+//     products replicated per workgroup), the top Ritz value by the Sturm multisection of path_dev.hpp.
+// Element-wise penalties without Nesterov's step and compute.loss (what the fused form of the launch-per-iteration engine takes);
+// everything else stays on that engine.  Every spin is bounded; a timeout poisons the result (d_out[6]) and the host reports it.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.hpp"
+#include "penalty_ops.hpp"
+#include "path_dev.hpp"
+
+namespace oemgpu {
+
+namespace {
+
+constexpr int WNTH = 256;         // threads per workgroup: one wave per SIMD
+constexpr int WCML = 256;         // Lanczos steps kept
+
+__host__ __device__ constexpr int wc_cw(int nr) { return nr <= 4 ? 16 : (nr <= 8 ? 8 : (nr <= 16 ? 4 : 2)); }
+__host__ __device__ constexpr int wc_log2(int v) { return v <= 1 ? 0 : 1 + wc_log2(v >> 1); }
+
+template <int NR> struct WCfg {
+    static constexpr int NP = 64 * NR;                       // padded rows
+    static constexpr int CW = wc_cw(NR);                     // columns per wave
+    static constexpr int LG = wc_log2(CW);
+    static constexpr int SH = 4 - LG;                        // lane l of a row holds column (l & 15) >> SH
+    static constexpr int CPG = 4 * CW;                       // columns per workgroup
+    static constexpr int E2 = (NP + WNTH - 1) / WNTH;        // rows per thread in the replicated vector work
+    static constexpr int GS = NP + WCOOP_GMAX;               // >= G SL: what a slice owner gathers
+    static constexpr int E1 = (GS + WNTH - 1) / WNTH;
+    // LDS carve (doubles)
+    static constexpr int OFF_R = 0;                          // the n-vector of the product (residual / Lanczos v) [NP + 8]
+    static constexpr int OFF_Y = OFF_R + NP + 8;             // Ys [NP]
+    static constexpr int OFF_P = OFF_Y + NP;                 // the four waves' partial vectors [4][NP]
+    static constexpr int OFF_G = OFF_P + 4 * NP;             // gathered partials of this workgroup's slice [GS]
+    static constexpr int OFF_T = OFF_G + GS;                 // Lanczos alpha [WCML], beta [WCML]
+    static constexpr int OFF_S = OFF_T + 2 * WCML;           // Sturm scratch 2 (WCML + 16)
+    static constexpr int OFF_X = OFF_S + 2 * (WCML + 16);    // block reductions [2][4], theta slot, lmax words [16 + 8], votes [12 ints]
+    static constexpr int N_DBL = OFF_X + 32;
+};
+
+// -DOEM_PATH_DIAG: cycles of wave 0 of workgroup 0 by segment (fenced stamps: read the SHARES)
+#ifdef OEM_PATH_DIAG
+__device__ unsigned long long g_diag_wcoop[16];
+#define WC_STAMP(slot)                                                                     \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        unsigned long long t__;                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        X.acc[slot] += t__ - X.last;                                                       \
+        X.last = t__;                                                                      \
+    } while (0)
+#else
+#define WC_STAMP(slot) do { } while (0)
+#endif
+
+struct WX {
+#ifdef OEM_PATH_DIAG
+    unsigned long long acc[16], last;
+#endif
+    __amdgpu_buffer_rsrc_t rs1, rs2;   // exchange 1: [2 parities][G owners][G senders][SL] pairs of 16 bytes; exchange 2: [2 parities][NP] pairs
+    unsigned epoch;               // all-reduce counter, never 0; identical in every workgroup
+    int wg, G, SL, n, row0, nsl;  // this workgroup's slice: rows [row0, row0 + nsl)
+    int stride1;                  // pairs per parity of exchange 1
+    bool failed;
+};
+
+__device__ __forceinline__ double wc_block_sum(double v, double *red, int &rpar, int w, int lane)
+{
+    const double s = wave_sum(v);
+    double *r = red + 4 * rpar;
+    if (lane == 0) r[w] = s;
+    __syncthreads();
+    const double t = (r[0] + r[1]) + (r[2] + r[3]);
+    rpar ^= 1;                    // the next call writes the other half: no second barrier needed
+    return t;
+}
+
+// ---- the CW column sums of a wave at once.  In: s[c] = this lane's part of column c.  Out: the whole sum of column
+// (lane & 15) >> SH, in every lane.  Stage on row-lane bit b (partner: xor 15 / 7 / 2 / 1, all involutions of the DPP network):
+// a lane keeps the half of the live values its bit b selects and receives the partner's part of the same half.
+template <int B> __device__ __forceinline__ double wc_xchg(double v)
+{
+    if constexpr (B == 3) return dpp_mov<0x140, 0xf>(v, 0.0);        // row_mirror: lane ^ 15
+    else if constexpr (B == 2) return dpp_mov<0x141, 0xf>(v, 0.0);   // row_half_mirror: lane ^ 7
+    else if constexpr (B == 1) return dpp_mov<0x4E, 0xf>(v, 0.0);    // quad_perm [2,3,0,1]: lane ^ 2
+    else return dpp_mov<0xB1, 0xf>(v, 0.0);                          // quad_perm [1,0,3,2]: lane ^ 1
+}
+template <int M, int B, int CW> __device__ __forceinline__ void wc_stage(double (&s)[CW], int lane)
+{
+    if constexpr (B >= 0) {
+        if constexpr (M > 1) {
+            constexpr int H = M / 2;
+            const bool hb = ((lane >> B) & 1) != 0;
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                const double keep = hb ? s[H + i] : s[i], send = hb ? s[i] : s[H + i];
+                s[i] = keep + wc_xchg<B>(send);
+            }
+            wc_stage<H, B - 1, CW>(s, lane);
+        } else {
+            s[0] += wc_xchg<B>(s[0]);
+            wc_stage<1, B - 1, CW>(s, lane);
+        }
+    }
+}
+template <int CW> __device__ __forceinline__ double wc_colsum(double (&s)[CW], int lane)
+{
+    wc_stage<CW, 3, CW>(s, lane);
+    // the four rows: v_permlane16_swap (rows 1, 3 <-> 0, 2), then v_permlane32_swap (rows 2, 3 <-> 0, 1)
+    const double a = s[0];
+    const unsigned lo = (unsigned)__double2loint(a), hi = (unsigned)__double2hiint(a);
+    auto l1 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto h1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double t = __hiloint2double((int)h1[0], (int)l1[0]) + __hiloint2double((int)h1[1], (int)l1[1]);
+    const unsigned lo2 = (unsigned)__double2loint(t), hi2 = (unsigned)__double2hiint(t);
+    auto l2 = __builtin_amdgcn_permlane32_swap(lo2, lo2, false, false);
+    auto h2 = __builtin_amdgcn_permlane32_swap(hi2, hi2, false, false);
+    return __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
+}
+
+// t[k] += x[c][k] * (bn of the lane that holds column c), c = 0 .. CW - 1; columns with a zero coefficient skipped (wave-uniform)
+template <int C, int NR, int CW, int SH> struct WcUpd {
+    static __device__ __forceinline__ void run(double (&acc)[NR], const double &bn, const double (&x)[CW][NR], unsigned long long nz)
+    {
+        if constexpr (C < CW) {
+            if (NR <= 2 || ((nz >> (C << SH)) & 1ull)) {
+#pragma unroll
+                for (int k = 0; k < NR; ++k) BcFma<(C << SH)>::fmac(acc[k], bn, x[C][k]);
+            }
+            WcUpd<C + 1, NR, CW, SH>::run(acc, bn, x, nz);
+        }
+    }
+};
+
+// Gather E granule pairs per thread (pair tid + 256 k from byte offset off0 of the buffer, where `need` has bit k) whose two tags
+// carry this epoch; the low tag bits are OR-ed into `flags`.  A pair is ONE 16-byte load (each 8-byte half validates itself, so a
+// torn pair is only ever seen as "not there yet"), ONE sweep in flight, and a pair that has arrived is not asked for again:
+// tools/xchg_probe.hip -- three sweeps in flight (path_coop.hip's first recipe) flood the fabric with polls and make every
+// exchange SLOWER (64 workgroups, 512 rows: 1.85 us per all-gather against 1.17 us).
+typedef unsigned wc_v4u __attribute__((ext_vector_type(4)));
+template <int E>
+__device__ __forceinline__ void wc_gather(__amdgpu_buffer_rsrc_t rs, int off0, unsigned need, double (&out)[E], int &flags, WX &X, int tid)
+{
+    wc_v4u pv[E];
+    unsigned miss = need;                                       // pairs still to come
+#pragma unroll
+    for (int k = 0; k < E; ++k) pv[k] = wc_v4u{0u, 0u, 0u, 0u};
+    unsigned spins = 0;
+    const unsigned limit = X.failed ? 0u : 1000000u;            // ~1 s: a partner is gone; after one timeout nobody waits again
+    bool ok = true;
+    while (__any(miss != 0u)) {
+#pragma unroll
+        for (int k = 0; k < E; ++k)
+            if ((miss >> k) & 1u) pv[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off0 + (tid + WNTH * k) * 16, 0, 16);      // aux 16: sc1
+#pragma unroll
+        for (int k = 0; k < E; ++k)
+            if (((miss >> k) & 1u) && (pv[k].y >> 1) == X.epoch && (pv[k].w >> 1) == X.epoch) miss &= ~(1u << k);
+        if (++spins >= limit && __any(miss != 0u)) { ok = false; break; }
+    }
+    if (!ok) X.failed = true;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const bool nd = ((need >> k) & 1u) != 0 && ((miss >> k) & 1u) == 0;
+        out[k] = nd ? __hiloint2double((int)pv[k].z, (int)pv[k].x) : 0.0;
+        if (nd) flags |= (int)(pv[k].y & 1u);
+    }
+}
+
+__device__ __forceinline__ void wc_publish(__amdgpu_buffer_rsrc_t rs, int off, double val, unsigned tag)
+{
+    wc_v4u v;
+    v.x = (unsigned)__double2loint(val); v.y = tag; v.z = (unsigned)__double2hiint(val); v.w = tag;
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
+}
+
+// OR of one bit per thread over the workgroup through four LDS words and ONE barrier (the caller's: `words` is read behind it)
+__device__ __forceinline__ void wc_vote(int *words, int w, int lane, int bit)
+{
+    const int wb = __ballot(bit != 0) != 0ull ? 1 : 0;
+    if (lane == 0) words[w] = wb;
+}
+
+// All-reduce of the workgroups' partial vectors.  In: the four waves' parts in Pc (no barrier yet), this thread's "moving" bit.
+// Out (behind a barrier): Rsh[i] = OEM ? Ys[i] - sum_g part_g[i] : sum_g part_g[i] / n for every row i < n, and the OR of every
+// thread's bit in every workgroup (the same value everywhere).  Three barriers.
+template <int NR, bool OEM>
+__device__ __forceinline__ int wc_allreduce(double *Rsh, const double *Ysh, const double *Pc, double *Gsh, int *votes, const int (&pub)[WCfg<NR>::E2],
+                                            unsigned need1, unsigned need2, double rn, int mybit, WX &X, int tid, int w, int lane)
+{
+    typedef WCfg<NR> C;
+    WC_STAMP(0);                                                 // the product (and everything between all-reduces)
+    wc_vote(votes, w, lane, mybit);
+    __syncthreads();                                             // Pc is complete
+    const int wgbit = votes[0] | votes[1] | votes[2] | votes[3];
+    WC_STAMP(1);
+    ++X.epoch;
+    const int par = (int)(X.epoch & 1u);
+    const int off1 = par * X.stride1 * 16, off2 = par * C::NP * 16;       // (bytes; stride1 counts pairs)
+    // ---- exchange 1: this workgroup's partial rows to the slice owners
+    const unsigned tag1 = (X.epoch << 1) | (unsigned)wgbit;
+#pragma unroll
+    for (int k = 0; k < C::E2; ++k) {
+        const int row = tid + WNTH * k;
+        if (pub[k] != -1) {
+            const double t = (Pc[row] + Pc[C::NP + row]) + (Pc[2 * C::NP + row] + Pc[3 * C::NP + row]);
+            if (pub[k] < -1) Gsh[-2 - pub[k]] = t;               // a row of the own slice
+            else wc_publish(X.rs1, off1 + pub[k] * 16, t, tag1);
+        }
+    }
+    WC_STAMP(2);                                                 // publish 1
+    int bits = 0;
+    {
+        double g[C::E1];
+        wc_gather<C::E1>(X.rs1, off1 + X.wg * X.G * X.SL * 16, need1, g, bits, X, tid);
+#pragma unroll
+        for (int k = 0; k < C::E1; ++k) if ((need1 >> k) & 1u) Gsh[tid + WNTH * k] = g[k];
+    }
+    WC_STAMP(3);                                                 // gather 1
+    wc_vote(votes + 4, w, lane, bits);
+    __syncthreads();
+    const int any1 = wgbit | votes[4] | votes[5] | votes[6] | votes[7];  // owners: the OR over all workgroups (every one of them sent a row)
+    WC_STAMP(4);
+    // ---- the slice: G partials per row in workgroup order, eight interleaved chains per row
+    const unsigned tag2 = (X.epoch << 1) | (unsigned)any1;
+    for (int idx = tid; idx < X.nsl * 8; idx += WNTH) {
+        const int s = idx >> 3, part = idx & 7;
+        double t = 0.0;
+        for (int g0 = part; g0 < X.G; g0 += 64) {
+            double a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int g = g0 + 8 * j; a[j] = Gsh[(g < X.G ? g : 0) * X.SL + s]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += (g0 + 8 * j < X.G) ? a[j] : 0.0;
+        }
+        t += dpp_mov<0xB1, 0xf>(t, 0.0);
+        t += dpp_mov<0x4E, 0xf>(t, 0.0);
+        t += dpp_mov<0x141, 0xf>(t, 0.0);
+        if (part == 0) {
+            const int row = X.row0 + s;
+            const double out = OEM ? Ysh[row] - t : t * rn;
+            Rsh[row] = out;
+            wc_publish(X.rs2, off2 + row * 16, out, tag2);
+        }
+    }
+    WC_STAMP(5);                                                 // slice sums, publish 2
+    // ---- exchange 2: everybody gathers the n rows
+    int bits2 = 0;
+    {
+        double r[C::E2];
+        wc_gather<C::E2>(X.rs2, off2, need2, r, bits2, X, tid);
+#pragma unroll
+        for (int k = 0; k < C::E2; ++k) if ((need2 >> k) & 1u) Rsh[tid + WNTH * k] = r[k];
+    }
+    WC_STAMP(6);                                                 // gather 2
+    wc_vote(votes + 8, w, lane, bits2);
+    __syncthreads();
+    const int any = any1 | votes[8] | votes[9] | votes[10] | votes[11];
+    WC_STAMP(7);
+#ifdef OEM_PATH_DIAG
+    X.acc[8] += 1;
+#endif
+    return any;
+}
+
+struct WThr { int kind; double L, D, rD, gammad, dmg, rdmg, gm1, gamma, dsc, rdsc, d, rd; };
+__device__ __forceinline__ WThr wc_thr(const PenK &K, double d)
+{
+    WThr c;
+    c.kind = K.kind; c.L = K.L; c.D = K.D; c.rD = 1.0 / K.D; c.gammad = K.gamma * K.D; c.gamma = K.gamma; c.gm1 = K.gamma - 1.0;
+    c.dmg = K.D - 1.0 / K.gamma; c.rdmg = 1.0 / c.dmg; c.dsc = c.gm1 * K.D - 1.0; c.rdsc = 1.0 / c.dsc; c.d = d; c.rd = 1.0 / d;
+    return c;
+}
+// element-wise operators (ref src/oem_dense.h:76-149), branch-free inside a kind (path_large.hip: wide_cols_kernel has the same)
+__device__ __forceinline__ double wc_op(double u, double tp, const WThr &c)
+{
+    if (c.kind == K_SOFT) return cdiv(shrink(u, tp), c.D, c.rD);
+    if (c.kind == K_MCP) {
+        const bool big = fabs(u) > c.gammad * tp;
+        return cdiv(big ? u : shrink(u, tp), big ? c.D : c.dmg, big ? c.rD : c.rdmg);
+    }
+    if (c.kind == K_SCAD) {
+        const double au = fabs(u);
+        const bool big = au > c.gammad * tp, mid = !big && au > (c.D + 1.0) * tp;
+        const double num = big ? u : (mid ? shrink(c.gm1 * u, c.gamma * tp) : shrink(u, tp));
+        return cdiv(num, mid ? c.dsc : c.D, mid ? c.rdsc : c.rD);
+    }
+    return cdiv(u, c.d, c.rd);
+}
+
+template <int NR>
+__global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const double *__restrict__ xs, const double *__restrict__ ysv, int n,
+                                                           unsigned long long *xchg)
+{
+    typedef WCfg<NR> C;
+    constexpr int NP = C::NP, CW = C::CW, SH = C::SH, E2 = C::E2;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l16 = lane & 15;
+    const int q = A.p, wg = blockIdx.x, G = gridDim.x;
+    const unsigned long long t_cyc0 = __builtin_amdgcn_s_memtime(), t_rt0 = __builtin_amdgcn_s_memrealtime();
+    double *Rsh = lds + C::OFF_R, *Ysh = lds + C::OFF_Y, *Pc = lds + C::OFF_P, *Gsh = lds + C::OFF_G;
+    double *Tal = lds + C::OFF_T, *Tbe = Tal + WCML, *red = lds + C::OFF_X;
+    int *votes = reinterpret_cast<int *>(red + 24);
+    const bool writer = wg == 0;
+    const double rn = 1.0 / (double)n;
+
+    // ---- this wave's CW columns in registers; this lane's own column (the one whose sum and coefficient it ends up with)
+    const int cbase = wg * C::CPG + w * CW;
+    double x[CW][NR];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+        const bool ok = cbase + c < q;
+        const double *col = xs + (size_t)(ok ? cbase + c : 0) * NP;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) { const double t = col[lane + 64 * k]; x[c][k] = ok ? t : 0.0; }
+    }
+    const int mycol = cbase + (l16 >> SH);
+    const bool colok = mycol < q;
+    const bool storer = colok && lane < 16 && (l16 & ((1 << SH) - 1)) == 0;       // one lane per column writes its coefficient out
+    const double pfj = colok ? A.pf[mycol] : 0.0;
+    for (int j = tid; j < NP + 8; j += WNTH) Rsh[j] = 0.0;
+    for (int j = tid; j < NP; j += WNTH) Ysh[j] = j < n ? ysv[j] : 0.0;
+    for (int j = tid; j < C::GS; j += WNTH) Gsh[j] = 0.0;
+
+    // ---- the exchange: slices, what this thread publishes and gathers (fixed for the whole call)
+    WX X;
+    X.G = G; X.wg = wg; X.n = n; X.SL = (n + G - 1) / G; X.row0 = wg * X.SL;
+    X.nsl = n - X.row0 < 0 ? 0 : (n - X.row0 < X.SL ? n - X.row0 : X.SL);
+    X.stride1 = G * G * X.SL;
+    X.rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, 2 * X.stride1 * 16, 0x00020000);
+    X.rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)(xchg + (size_t)4 * X.stride1), 0, 2 * NP * 16, 0x00020000);
+    X.epoch = 0; X.failed = false;
+#ifdef OEM_PATH_DIAG
+    for (int k = 0; k < 16; ++k) X.acc[k] = 0;
+#endif
+    int pub[E2];                                                // -1: nothing; <= -2: own slice, Gsh index -2 - pub; else pair index in exchange 1
+    unsigned need1 = 0, need2 = 0;
+#pragma unroll
+    for (int k = 0; k < E2; ++k) {
+        const int row = tid + WNTH * k;
+        pub[k] = -1;
+        if (row < n) {
+            const int h = row / X.SL, s = row - h * X.SL;
+            pub[k] = (h == wg) ? -2 - (wg * X.SL + s) : (h * G + wg) * X.SL + s;
+            if (h != wg) need2 |= 1u << k;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < C::E1; ++k) {
+        const int e = tid + WNTH * k;
+        if (e < G * X.SL) {
+            const int g = e / X.SL, s = e - g * X.SL;
+            if (g != wg && s < X.nsl) need1 |= 1u << k;
+        }
+    }
+    __syncthreads();
+    int rpar = 0;
+
+    // both products over the registers.  EIG: z = Xs'v, partial Xs z.  OEM: beta' = T(Xs'r / n + d beta), partial Xs beta'.
+    double bcur = 0.0;                                          // the coefficient of this lane's column
+    auto product = [&](auto OEM_, const WThr &c, double tp, double d, bool &moving) __attribute__((always_inline)) {
+        constexpr bool OEM = decltype(OEM_)::value;
+        double rr[NR], s[CW];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) rr[k] = Rsh[lane + 64 * k];
+#pragma unroll
+        for (int cc = 0; cc < CW; ++cc) {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < NR; k += 2) { a0 = fma(x[cc][k], rr[k], a0); if (k + 1 < NR) a1 = fma(x[cc][k + 1], rr[k + 1], a1); }
+            s[cc] = a0 + a1;
+        }
+        const double dot = wc_colsum<CW>(s, lane);
+        double bn[1];
+        if (OEM) {
+            const double u = dot * rn + d * bcur;                // ref src/oem_dense.h:520: X'(Y - X beta)/n + d beta
+            const double b = colok ? wc_op(u, tp, c) : 0.0;
+            const double cu = fabs(b), qo = fabs(bcur);
+            const bool cn = cu > 1e-13, qn = qo > 1e-13;          // ref src/utils.cpp:537-549
+            moving = (cn != qn) || (cn && qn && fabs(b - bcur) > A.tol * qo);
+            bcur = b;
+            bn[0] = b;
+        } else bn[0] = dot;
+        const unsigned long long nz = __ballot(bn[0] != 0.0);
+        dpp_hazard_fence(bn);
+        double acc[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) acc[k] = 0.0;
+        WcUpd<0, NR, CW, SH>::run(acc, bn[0], x, nz);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) Pc[w * NP + lane + 64 * k] = acc[k];
+    };
+
+    // ---- eigenvalue step: Lanczos on Xs Xs'/n (ref src/oem_dense.h:476-498), the vector updates replicated per workgroup
+    double v[E2], vp[E2], wv[E2];
+    bool rowok[E2];
+    {
+        double nn = 0.0;
+#pragma unroll
+        for (int k = 0; k < E2; ++k) {
+            const unsigned j = tid + WNTH * k;
+            rowok[k] = (int)j < n;
+            const unsigned h = j * 2654435761u + 12345u;                 // deterministic non-structured start
+            v[k] = rowok[k] ? ((double)(h >> 8) * (1.0 / 16777216.0) - 0.5) : 0.0;
+            vp[k] = 0.0;
+            nn = fma(v[k], v[k], nn);
+        }
+        nn = 1.0 / sqrt(wc_block_sum(nn, red, rpar, w, lane));
+#pragma unroll
+        for (int k = 0; k < E2; ++k) v[k] *= nn;
+    }
+    int msteps = n < WCML ? n : WCML;
+    if (msteps < 1) msteps = 1;
+    double *theta_slot = red + 8;
+    auto top_ritz = [&](int m, double hint) {
+        if (w == 0) {
+            const double th = tridiag_max(Tal, Tbe, m, lane, lds + C::OFF_S, hint);
+            if (lane == 0) theta_slot[0] = th;
+        }
+        __syncthreads();
+        const double th = theta_slot[0];
+        __syncthreads();
+        return th;
+    };
+    const WThr nothr = {};
+    int nst = 0;
+    double bprev = 0.0, theta = 0.0, theta_prev = -__builtin_inf(), mv_prev = __builtin_inf();
+    bool have_theta = false;
+    for (int j = 0; j < msteps; ++j) {
+#pragma unroll
+        for (int k = 0; k < E2; ++k) if (rowok[k]) Rsh[tid + WNTH * k] = v[k];
+        __syncthreads();
+        bool mv = false;
+        product(std::false_type{}, nothr, 0.0, 0.0, mv);
+        (void)wc_allreduce<NR, false>(Rsh, Ysh, Pc, Gsh, votes, pub, need1, need2, rn, 0, X, tid, w, lane);
+        double al = 0.0;
+#pragma unroll
+        for (int k = 0; k < E2; ++k) { wv[k] = rowok[k] ? Rsh[tid + WNTH * k] : 0.0; al = fma(v[k], wv[k], al); }
+        al = wc_block_sum(al, red, rpar, w, lane);
+        double bb = 0.0;
+#pragma unroll
+        for (int k = 0; k < E2; ++k) {
+            wv[k] = (wv[k] - al * v[k]) - bprev * vp[k];
+            bb = fma(wv[k], wv[k], bb);
+        }
+        double ib;
+        sqrt_rsqrt(wc_block_sum(bb, red, rpar, w, lane), bb, ib);
+        if (tid == 0) { Tal[j] = al; Tbe[j] = bb; }
+        nst = j + 1;
+        if (!(bb > 1e-13 * fabs(al))) break;                        // invariant subspace reached: T is exact
+        if (lanczos_check_due(nst) && nst < msteps) {
+            const double th = top_ritz(nst, theta_prev);            // its first barrier publishes Tal / Tbe
+            if (lanczos_converged(th, theta_prev, mv_prev)) { theta = th; have_theta = true; break; }
+        }
+#pragma unroll
+        for (int k = 0; k < E2; ++k) { vp[k] = v[k]; v[k] = wv[k] * ib; }
+        bprev = bb;
+    }
+    if (!have_theta) { __syncthreads(); theta = top_ritz(nst, theta_prev); }
+    const double d = theta * 1.005;                                  // ref src/oem_dense.h:498
+#ifdef OEM_PATH_DIAG
+    for (int k = 0; k < 16; ++k) X.acc[k] = 0;                       // (the stamps below cover the lambda path only)
+    X.last = __builtin_amdgcn_s_memtime();
+#endif
+    if (tid == 0 && writer) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && nst >= msteps && nst < n) ? 1.0 : 0.0; }
+
+    // ---- lambda grid constants (ref src/oem_dense.cpp:175-192)
+    const double scaley = A.yscale ? A.stats[1] : 1.0;
+    const int nl = A.nl;
+    double lmax = 0.0;
+    {
+        double m = 0.0;
+        for (int j0 = 0; j0 < q; j0 += 8 * WNTH) {
+            double t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int j = j0 + tid + WNTH * k; t[k] = (j < q && j >= A.lmax_from) ? fabs(A.xy[j]) : 0.0; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m = fmax(m, t[k]);
+        }
+        m = wave_max(m);
+        if (lane == 0) red[12 + w] = m;
+        __syncthreads();
+        lmax = fmax(fmax(red[12], red[13]), fmax(red[14], red[15])) * scaley;
+    }
+    const double llo = log(lmax), lhi = log(A.lambda_min_ratio * lmax);
+    const double lstep = nl > 1 ? (lhi - llo) / (double)(nl - 1) : 0.0;
+    const bool lflip = fabs(lhi) < fabs(llo);
+
+    for (int pp = A.pen_lo; pp < A.pen_hi; ++pp) {
+        const int pen = A.penalty[pp];
+        const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
+        const bool isnet = pen_is_net(pen);
+        const int maxit = A.maxit;
+        // cold start (ref src/oem_dense.cpp:243-244): beta = 0, so the residual is Ys
+        bcur = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < E2; ++k) if (rowok[k]) Rsh[tid + WNTH * k] = Ysh[tid + WNTH * k];
+        __syncthreads();
+        double lam_next = A.user_lambda ? A.lambda_user[(size_t)pp * nl] : 0.0;
+        for (int i = 0; i < nl; ++i) {
+            double lam;
+            if (A.user_lambda) {
+                lam = lam_next;
+                if (i + 1 < nl) lam_next = A.lambda_user[(size_t)pp * nl + i + 1];
+            } else {
+                double lv;
+                if (nl == 1) lv = lhi;
+                else if (lflip) lv = (i == 0) ? llo : lhi - (double)(nl - 1 - i) * lstep;
+                else lv = (i == nl - 1) ? lhi : llo + (double)i * lstep;
+                lam = exp(lv);
+                if (isnet) lam = lam / A.alpha;
+            }
+            const size_t orow = (size_t)pp * nl + i;
+            if (tid == 0 && writer) A.lambda_out[orow] = lam;
+            if (i >= nlam) continue;
+            const PenK K = pen_consts(pen, lam / scaley, d, A.alpha, A.gamma, A.tau);       // ref src/oem_dense.cpp:241
+            const WThr c = wc_thr(K, d);
+            const double tp = pfj * K.L;
+            int it = 0;
+            for (;;) {
+                bool moving = false;
+                product(std::true_type{}, c, tp, d, moving);
+                // r' = Ys - Xs beta': the next iteration's input, or the warm start of the next lambda
+                const int any = wc_allreduce<NR, true>(Rsh, Ysh, Pc, Gsh, votes, pub, need1, need2, rn, moving ? 1 : 0, X, tid, w, lane);
+                ++it;
+                const bool conv = !any;
+                if (conv || it >= maxit) {
+                    if (storer) A.beta[orow * q + mycol] = bcur;
+                    if (tid == 0 && writer) { A.niter[orow] = conv ? it : maxit + 1; A.loss[orow] = 1e99; }      // ref src/oem_base.h:94-109
+                    break;
+                }
+            }
+        }
+    }
+#ifdef OEM_PATH_DIAG
+    if (tid == 0 && writer) for (int k = 0; k < 16; ++k) g_diag_wcoop[k] = X.acc[k];
+#endif
+    if (tid == 0 && writer) {
+        A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
+        A.d_out[3] = (double)(__builtin_amdgcn_s_memrealtime() - t_rt0);
+    }
+    // exchange timeout: poison (the host turns it into an error); a slot of its own that the host cleared before the launch
+    if (__syncthreads_or(X.failed ? 1 : 0) && tid == 0) A.d_out[6] = 1.0;
+}
+
+template <int NR> int wcoop_launch(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G)
+{
+    typedef WCfg<NR> C;
+    const size_t sh = (size_t)C::N_DBL * sizeof(double);
+    if (sh > 64 * 1024 && lds_limit_once(reinterpret_cast<const void *>(&path_wcoop_kernel<NR>), sh)) return OEMGPU_ERR_HIP;
+    hipLaunchKernelGGL((path_wcoop_kernel<NR>), dim3(G), dim3(WNTH), sh, s, a, wd.xs, wd.ys, wd.n, reinterpret_cast<unsigned long long *>(wd.scratch));
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+#ifdef OEM_PATH_DIAG
+extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read_wcoop(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_wcoop), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
+
+int path_wcoop_workgroups(int n, int p)
+{
+    const WideLayout L = wide_layout(n);
+    if (L.nb != 1 || L.nr < 1) return 0;
+    return (p + 4 * wc_cw(L.nr) - 1) / (4 * wc_cw(L.nr));
+}
+
+// granules of the two exchanges, both parities (8 bytes each), as doubles of scratch
+size_t path_wcoop_xchg_doubles(int n, int p)
+{
+    const int G = path_wcoop_workgroups(n, p);
+    if (G < 1 || G > WCOOP_GMAX) return 0;
+    const WideLayout L = wide_layout(n);
+    const size_t SL = ((size_t)n + G - 1) / G;
+    return 2 * ((size_t)G * G * SL * 2) + 2 * ((size_t)L.npad() * 2) + 64;
+}
+
+// OEM_NO_WCOOP=1: the launch-per-iteration engine; OEM_WCOOP_MAXG: fewer workgroups allowed (experiments)
+bool path_wcoop_eligible(const PathArgs &a, const WideArgs &wd)
+{
+    const bool off = getenv("OEM_NO_WCOOP") != nullptr;           // (read per call: the tests hold the two engines against each other)
+    static const int maxg = [] { const char *e = getenv("OEM_WCOOP_MAXG"); const int k = e ? atoi(e) : 0; return (k >= 1 && k < WCOOP_GMAX) ? k : WCOOP_GMAX; }();
+    if (off || wd.lay.nb != 1) return false;
+    if (a.ngroups != 0 || a.accelerate || a.compute_loss || a.sinv || a.nbatch > 1 || a.pen_split) return false;
+    const int G = path_wcoop_workgroups(wd.n, a.p);
+    return G >= 1 && G <= maxg;
+}
+
+int launch_path_wcoop(hipStream_t s, const PathArgs &a, const WideArgs &wd)
+{
+    const int G = path_wcoop_workgroups(wd.n, a.p);
+    if (G < 1 || G > WCOOP_GMAX) { set_error("internal: wide cooperating engine asked for %d workgroups", G); return OEMGPU_ERR_INTERNAL; }
+    OEM_HIP(hipMemsetAsync(wd.scratch, 0, sizeof(double) * path_wcoop_xchg_doubles(wd.n, a.p), s));      // granule tags must start at 0
+    OEM_HIP(hipMemsetAsync(a.d_out, 0, sizeof(double) * D_OUT_LEN, s));                                  // [6]: only a timed-out workgroup writes it
+    switch (wd.lay.nr) {
+    case 1: return wcoop_launch<1>(s, a, wd, G);
+    case 2: return wcoop_launch<2>(s, a, wd, G);
+    case 3: return wcoop_launch<3>(s, a, wd, G);
+    case 4: return wcoop_launch<4>(s, a, wd, G);
+    case 6: return wcoop_launch<6>(s, a, wd, G);
+    case 8: return wcoop_launch<8>(s, a, wd, G);
+    case 12: return wcoop_launch<12>(s, a, wd, G);
+    case 16: return wcoop_launch<16>(s, a, wd, G);
+    case 24: return wcoop_launch<24>(s, a, wd, G);
+    case 32: return wcoop_launch<32>(s, a, wd, G);
+    default: break;
+    }
+    set_error("internal: wide cooperating engine, nr = %d", wd.lay.nr);
+    return OEMGPU_ERR_INTERNAL;
+}
+
+}  // namespace oemgpu

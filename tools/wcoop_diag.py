@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Stamped segments of the wide cooperating-workgroup path kernel (liboemgpu_diag.so): python tools/wcoop_diag.py [n] [p] [nlambda]"""
+import ctypes as C, os, sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("OEMGPU_LIB", str(ROOT / "oem_amd" / "liboemgpu_diag.so"))
+os.environ["OEM_WIDE"] = "1"
+import oem_amd as oa
+from oem_amd import _lib as L
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+p = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+nl = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+rng = np.random.default_rng(5)
+x = np.asfortranarray(rng.normal(size=(n, p))); y = x[:, :10] @ rng.uniform(0.5, 1.5, 10) + rng.normal(size=n)
+fit = oa.oem(x, y, penalty="lasso", nlambda=nl, tol=1e-7)
+lib = L.lib(); lib.oemgpu_diag_read_wcoop.argtypes = [C.POINTER(C.c_ulonglong)]
+out = (C.c_ulonglong * 16)(); assert lib.oemgpu_diag_read_wcoop(out) == 0
+d = np.array(list(out), dtype=np.float64)
+names = "product + between | barrier | publish 1 | gather 1 | barrier | slice sums + publish 2 | gather 2 | barrier"
+print(f"n={n} p={p}: OEM iterations {int(np.sum(fit['niter'][0]))}, all-reduces {int(d[8])}: cycles per iteration [{names}]")
+print("   ", np.round(d[0:8] / max(d[8], 1), 0), "sum", round(d[0:8].sum() / max(d[8], 1)))
