@@ -386,11 +386,12 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     if (coop) slots.take(c->device, path_coop_workgroups(q) * (pen_split ? npen : 1) * nbatch, c->num_cu * 3 / 4);
     // p >= n with Xs small enough for the register files of <= 128 CUs: one persistent launch (path_wcoop.hip)
     const bool wcoop = wide && path_wcoop_eligible(a, *wide);
-    if (wcoop) slots.take(c->device, path_wcoop_workgroups(wide->n, q), c->num_cu * 3 / 4);
+    const int wsets = wcoop ? path_wcoop_sets(wide->n, q, npen, c->num_cu) : 1;
+    if (wcoop) slots.take(c->device, path_wcoop_workgroups(wide->n, q) * wsets, c->num_cu * 3 / 4);
     {
         Timer t(c, OEMGPU_T_EIGPATH);
         PollScope poll(o);
-        int rc = wcoop ? launch_path_wcoop(c->stream, a, *wide) : wide ? run_path_wide(c->stream, a, *wide, (double *)c->pinned)
+        int rc = wcoop ? launch_path_wcoop(c->stream, a, *wide, wsets) : wide ? run_path_wide(c->stream, a, *wide, (double *)c->pinned)
                       : small ? launch_path_small(c->stream, a) : (coop ? launch_path_coop(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned));
         if (rc) return rc;
     }

@@ -317,7 +317,7 @@ __device__ __forceinline__ double wc_op(double u, double tp, const WThr &c)
 
 template <int NR>
 __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const double *__restrict__ xs, const double *__restrict__ ysv, int n,
-                                                           unsigned long long *xchg)
+                                                           unsigned long long *xchg, long long set_stride)
 {
     typedef WCfg<NR> C;
     constexpr int NP = C::NP, CW = C::CW, SH = C::SH, E2 = C::E2;
@@ -328,6 +328,10 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
     double *Rsh = lds + C::OFF_R, *Ysh = lds + C::OFF_Y, *Pc = lds + C::OFF_P, *Gsh = lds + C::OFF_G;
     double *Tal = lds + C::OFF_T, *Tbe = Tal + WCML, *red = lds + C::OFF_X;
     int *votes = reinterpret_cast<int *>(red + 24);
+    // blockIdx.y: one set of G workgroups per penalty (independent cold starts, ref src/oem_dense.cpp:243-244), each with the whole
+    // of Xs in its registers and exchange buffers of its own; set y walks penalties y, y + sets, ...
+    const int set = blockIdx.y, nsets = gridDim.y;
+    xchg += (size_t)set * (size_t)set_stride;
     const bool writer = wg == 0;
     const double rn = 1.0 / (double)n;
 
@@ -390,6 +394,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
         double rr[NR], s[CW];
 #pragma unroll
         for (int k = 0; k < NR; ++k) rr[k] = Rsh[lane + 64 * k];
+        WC_STAMP(9);                                             // (state machine, operator constants; the vector's LDS reads issued)
 #pragma unroll
         for (int cc = 0; cc < CW; ++cc) {
             double a0 = 0.0, a1 = 0.0;
@@ -397,7 +402,9 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
             for (int k = 0; k < NR; k += 2) { a0 = fma(x[cc][k], rr[k], a0); if (k + 1 < NR) a1 = fma(x[cc][k + 1], rr[k + 1], a1); }
             s[cc] = a0 + a1;
         }
+        WC_STAMP(10);                                            // dot products
         const double dot = wc_colsum<CW>(s, lane);
+        WC_STAMP(11);                                            // column sums
         double bn[1];
         if (OEM) {
             const double u = dot * rn + d * bcur;                // ref src/oem_dense.h:520: X'(Y - X beta)/n + d beta
@@ -408,6 +415,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
             bcur = b;
             bn[0] = b;
         } else bn[0] = dot;
+        WC_STAMP(12);                                            // operator, stop rule
         const unsigned long long nz = __ballot(bn[0] != 0.0);
         dpp_hazard_fence(bn);
         double acc[NR];
@@ -415,6 +423,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
         for (int k = 0; k < NR; ++k) acc[k] = 0.0;
         WcUpd<0, NR, CW, SH>::run(acc, bn[0], x, nz);
 #pragma unroll
+        WC_STAMP(13);                                            // update
         for (int k = 0; k < NR; ++k) Pc[w * NP + lane + 64 * k] = acc[k];
     };
 
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
     for (int k = 0; k < 16; ++k) X.acc[k] = 0;                       // (the stamps below cover the lambda path only)
     X.last = __builtin_amdgcn_s_memtime();
 #endif
-    if (tid == 0 && writer) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && nst >= msteps && nst < n) ? 1.0 : 0.0; }
+    if (tid == 0 && writer && set == 0) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && nst >= msteps && nst < n) ? 1.0 : 0.0; }
 
     // ---- lambda grid constants (ref src/oem_dense.cpp:175-192)
     const double scaley = A.yscale ? A.stats[1] : 1.0;
@@ -513,7 +522,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
     const double lstep = nl > 1 ? (lhi - llo) / (double)(nl - 1) : 0.0;
     const bool lflip = fabs(lhi) < fabs(llo);
 
-    for (int pp = A.pen_lo; pp < A.pen_hi; ++pp) {
+    for (int pp = A.pen_lo + set; pp < A.pen_hi; pp += nsets) {
         const int pen = A.penalty[pp];
         const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
         const bool isnet = pen_is_net(pen);
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
 #ifdef OEM_PATH_DIAG
     if (tid == 0 && writer) for (int k = 0; k < 16; ++k) g_diag_wcoop[k] = X.acc[k];
 #endif
-    if (tid == 0 && writer) {
+    if (tid == 0 && writer && set == 0) {
         A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
         A.d_out[3] = (double)(__builtin_amdgcn_s_memrealtime() - t_rt0);
     }
@@ -571,12 +580,13 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
     if (__syncthreads_or(X.failed ? 1 : 0) && tid == 0) A.d_out[6] = 1.0;
 }
 
-template <int NR> int wcoop_launch(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G)
+template <int NR> int wcoop_launch(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G, int sets, size_t set_stride)
 {
     typedef WCfg<NR> C;
     const size_t sh = (size_t)C::N_DBL * sizeof(double);
     if (sh > 64 * 1024 && lds_limit_once(reinterpret_cast<const void *>(&path_wcoop_kernel<NR>), sh)) return OEMGPU_ERR_HIP;
-    hipLaunchKernelGGL((path_wcoop_kernel<NR>), dim3(G), dim3(WNTH), sh, s, a, wd.xs, wd.ys, wd.n, reinterpret_cast<unsigned long long *>(wd.scratch));
+    hipLaunchKernelGGL((path_wcoop_kernel<NR>), dim3(G, sets), dim3(WNTH), sh, s, a, wd.xs, wd.ys, wd.n,
+                       reinterpret_cast<unsigned long long *>(wd.scratch), (long long)set_stride);
     OEM_HIP(hipGetLastError());
     return 0;
 }
@@ -593,18 +603,37 @@ extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read_wcoop(uns
 int path_wcoop_workgroups(int n, int p)
 {
     const WideLayout L = wide_layout(n);
-    if (L.nb != 1 || L.nr < 1) return 0;
+    if (L.nb != 1 || L.nr < 1 || L.nr > 16) return 0;          // (taller columns: two per wave, p <= 1024 < n -- never p >= n)
     return (p + 4 * wc_cw(L.nr) - 1) / (4 * wc_cw(L.nr));
 }
 
-// granules of the two exchanges, both parities (8 bytes each), as doubles of scratch
-size_t path_wcoop_xchg_doubles(int n, int p)
+// the two exchanges of ONE workgroup set, both parities (16-byte pairs), as doubles of scratch
+static size_t wcoop_set_doubles(int n, int p)
 {
     const int G = path_wcoop_workgroups(n, p);
     if (G < 1 || G > WCOOP_GMAX) return 0;
     const WideLayout L = wide_layout(n);
     const size_t SL = ((size_t)n + G - 1) / G;
     return 2 * ((size_t)G * G * SL * 2) + 2 * ((size_t)L.npad() * 2) + 64;
+}
+// workgroup sets (one per penalty) that may run side by side: all of them resident at once, on three quarters of the CUs at most
+int path_wcoop_sets(int n, int p, int npen, int num_cu)
+{
+    const int G = path_wcoop_workgroups(n, p);
+    if (G < 1) return 1;
+    int s = (num_cu * 3 / 4) / G;
+    if (s > WCOOP_MAX_SETS) s = WCOOP_MAX_SETS;
+    if (s > npen) s = npen;
+    if (getenv("OEM_WCOOP_ONE_SET")) s = 1;
+    return s < 1 ? 1 : s;
+}
+size_t path_wcoop_xchg_doubles(int n, int p)
+{
+    const int G = path_wcoop_workgroups(n, p);
+    if (G < 1 || G > WCOOP_GMAX) return 0;
+    int s = 192 / G;                                               // (256 CUs; fewer CUs: fewer sets)
+    if (s > WCOOP_MAX_SETS) s = WCOOP_MAX_SETS;
+    return wcoop_set_doubles(n, p) * (size_t)(s < 1 ? 1 : s);
 }
 
 // OEM_NO_WCOOP=1: the launch-per-iteration engine; OEM_WCOOP_MAXG: fewer workgroups allowed (experiments)
@@ -618,23 +647,23 @@ bool path_wcoop_eligible(const PathArgs &a, const WideArgs &wd)
     return G >= 1 && G <= maxg;
 }
 
-int launch_path_wcoop(hipStream_t s, const PathArgs &a, const WideArgs &wd)
+int launch_path_wcoop(hipStream_t s, const PathArgs &a, const WideArgs &wd, int sets)
 {
     const int G = path_wcoop_workgroups(wd.n, a.p);
     if (G < 1 || G > WCOOP_GMAX) { set_error("internal: wide cooperating engine asked for %d workgroups", G); return OEMGPU_ERR_INTERNAL; }
-    OEM_HIP(hipMemsetAsync(wd.scratch, 0, sizeof(double) * path_wcoop_xchg_doubles(wd.n, a.p), s));      // granule tags must start at 0
+    const size_t set_stride = wcoop_set_doubles(wd.n, a.p);
+    if (sets < 1 || set_stride * (size_t)sets > path_wcoop_xchg_doubles(wd.n, a.p)) { set_error("internal: wide cooperating engine, %d sets", sets); return OEMGPU_ERR_INTERNAL; }
+    OEM_HIP(hipMemsetAsync(wd.scratch, 0, sizeof(double) * set_stride * (size_t)sets, s));                 // the tags must start at 0
     OEM_HIP(hipMemsetAsync(a.d_out, 0, sizeof(double) * D_OUT_LEN, s));                                  // [6]: only a timed-out workgroup writes it
     switch (wd.lay.nr) {
-    case 1: return wcoop_launch<1>(s, a, wd, G);
-    case 2: return wcoop_launch<2>(s, a, wd, G);
-    case 3: return wcoop_launch<3>(s, a, wd, G);
-    case 4: return wcoop_launch<4>(s, a, wd, G);
-    case 6: return wcoop_launch<6>(s, a, wd, G);
-    case 8: return wcoop_launch<8>(s, a, wd, G);
-    case 12: return wcoop_launch<12>(s, a, wd, G);
-    case 16: return wcoop_launch<16>(s, a, wd, G);
-    case 24: return wcoop_launch<24>(s, a, wd, G);
-    case 32: return wcoop_launch<32>(s, a, wd, G);
+    case 1: return wcoop_launch<1>(s, a, wd, G, sets, set_stride);
+    case 2: return wcoop_launch<2>(s, a, wd, G, sets, set_stride);
+    case 3: return wcoop_launch<3>(s, a, wd, G, sets, set_stride);
+    case 4: return wcoop_launch<4>(s, a, wd, G, sets, set_stride);
+    case 6: return wcoop_launch<6>(s, a, wd, G, sets, set_stride);
+    case 8: return wcoop_launch<8>(s, a, wd, G, sets, set_stride);
+    case 12: return wcoop_launch<12>(s, a, wd, G, sets, set_stride);
+    case 16: return wcoop_launch<16>(s, a, wd, G, sets, set_stride);
     default: break;
     }
     set_error("internal: wide cooperating engine, nr = %d", wd.lay.nr);

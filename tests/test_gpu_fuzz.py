@@ -420,6 +420,45 @@ def test_random_wide(oa, seed, monkeypatch):
             assert np.allclose(np.ravel(f["loss"][k]), np.ravel(r["loss"][k]), rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("seed", list(range(160, 176)) + list(range(95000, 95000 + 16 * (SCALE - 1))))
+def test_random_wide_cooperating(oa, seed, monkeypatch):
+    """p >= n on the persistent cooperating-workgroup form of the wide engine (path_wcoop.hip; what OEM_WIDE=1 takes whenever the
+    penalties are element-wise without Nesterov's step and compute.loss): random shapes over every column height and workgroup
+    count, ragged all-reduce slices, DataStd flags, penalty factors, one to four penalties (side by side in workgroup sets) --
+    against the oracle's restatement of the branch and against the launch-per-iteration engine."""
+    monkeypatch.setenv("OEM_WIDE", "1")
+    rng = np.random.default_rng(7700 + seed)
+    n = int(rng.choice([1, 2, 7, 33, 64, 65, 100, 129, 192, 193, 250, 300, 385, 450, 520, 769, 900, 1024]))
+    cap = {1: 16, 2: 16, 3: 16, 4: 16, 6: 8, 8: 8, 12: 4, 16: 4}[[v for v in (1, 2, 3, 4, 6, 8, 12, 16) if 64 * v >= n][0]] * 4 * 128
+    p = int(min(cap, n + rng.integers(0, max(2, min(4 * n + 200, 400_000 // max(n, 1))))))
+    p = max(p, 2)
+    x = np.asfortranarray(rng.normal(size=(n, p)) * rng.uniform(0.5, 3.0) + rng.uniform(-1, 1))
+    nnz = int(min(p, rng.integers(1, 6)))
+    b = np.zeros(p); b[rng.choice(p, nnz, replace=False)] = rng.uniform(-1.5, 1.5, nnz)
+    y = x @ b + rng.normal(size=n) * rng.uniform(0.3, 2.0) + rng.uniform(-1, 1)
+    pens = list(rng.choice(ELEMENTWISE, int(rng.integers(1, 5)), replace=False))
+    pf = np.where(rng.random(p) < 0.1, 0.0, rng.uniform(0.5, 2.0, p))
+    kw = dict(penalty=pens, nlambda=int(rng.integers(1, 7)), alpha=float(rng.uniform(0.2, 1.0)), gamma=float(rng.uniform(2.1, 5.0)),
+              tol=float(10.0 ** rng.uniform(-9, -6)), maxit=int(rng.choice([30, 200, 400])), penalty_factor=pf,
+              standardize=bool(rng.integers(2)), intercept=bool(rng.integers(2)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f = oa.oem(x, y, **kw)
+        monkeypatch.setenv("OEM_NO_WCOOP", "1")
+        g = oa.oem(x, y, **kw)
+    r = orc.fit_dense(x, y, lambda_min_ratio=0.01 if n < p else 1e-4, **kw)
+    ok = np.isfinite(r["d"]) and all(np.all(np.isfinite(bk)) for bk in r["beta"]) and all(np.all(np.isfinite(lk)) for lk in r["lambda"])
+    if not ok:                                                    # (n = 1 under standardisation: the reference divides by a zero scale)
+        assert not np.any(np.isinf(np.concatenate([np.ravel(bk) for bk in f["beta"]])))
+        return
+    _check(f, r, pens, tol=5e-7)
+    assert abs(f["d"] - g["d"]) <= 1e-12 * abs(g["d"])
+    for k in range(len(pens)):
+        scale = max(1.0, float(np.abs(np.asarray(g["beta"][k])).max()))
+        assert np.abs(np.asarray(f["beta"][k]) - np.asarray(g["beta"][k])).max() <= 1e-8 * scale, pens[k]
+        assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(g["niter"][k]).astype(int)).max() <= 1, pens[k]
+
+
 @pytest.mark.parametrize("seed", list(range(150, 154)) + list(range(90000, 90000 + 4 * (SCALE - 1))))
 def test_random_symmetric_tile_engine(oa, seed, monkeypatch):
     """oem.xtx at p = 2048 on the symmetric-tile engine (OEM_SYM_2048=1): random element-wise penalty mixes, penalty factors and

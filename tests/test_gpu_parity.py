@@ -460,6 +460,55 @@ def test_wide_engine(oa, n, p, flag, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,p", [(3, 5), (30, 40), (64, 1100), (100, 1500), (130, 2100), (190, 700), (256, 3000), (300, 1300), (384, 900),
+                                 (500, 2000), (513, 1100), (700, 1410), (1000, 1000), (1024, 2048)])
+def test_wide_cooperating_engine(oa, n, p, monkeypatch):
+    """p >= n as ONE persistent launch of cooperating workgroups with the standardised X in registers (path_wcoop.hip): every column
+    height (1 .. 16 registers per column and lane, 16 .. 4 columns per wave), one workgroup up to 128, all-reduce slices that are
+    ragged or empty, the element-wise operators with penalty factors, maxit reached, user lambdas, OLS, several penalties side by
+    side in workgroup sets of their own -- against the oracle's restatement of the branch, and against the launch-per-iteration
+    engine (OEM_NO_WCOOP=1), which must agree to rounding with the same iteration counts."""
+    monkeypatch.setenv("OEM_WIDE", "1")
+    x, y = _data(n, max(p, n), 900 + n + p, mean=0.3, nnz=min(7, p))
+    p = x.shape[1]
+    rng = np.random.default_rng(n + p)
+    pf = rng.uniform(0.5, 2.0, p); pf[rng.integers(p)] = 0.0
+    nlam = 6 if n * p < 1_000_000 else 4
+    calls = (dict(penalty=["lasso", "mcp", "scad", "elastic.net", "mcp.net", "scad.net", "ols"], alpha=0.7, gamma=3.5, nlambda=nlam, tol=1e-8, maxit=400,
+                  penalty_factor=pf, standardize=True, intercept=True),
+             dict(penalty=["lasso"], nlambda=4, tol=1e-12, maxit=3, standardize=False, intercept=True),
+             dict(penalty=["mcp", "lasso"], lambda_=[np.array([0.5, 0.2, 0.05]), np.array([0.4, 0.1, 0.02])], tol=1e-8, maxit=300,
+                  standardize=True, intercept=False))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for kw in calls:
+            f = oa.oem(x, y, **kw)
+            monkeypatch.setenv("OEM_NO_WCOOP", "1")
+            g = oa.oem(x, y, **kw)
+            monkeypatch.delenv("OEM_NO_WCOOP")
+            monkeypatch.setenv("OEM_WCOOP_ONE_SET", "1")
+            h = oa.oem(x, y, **kw)
+            monkeypatch.delenv("OEM_WCOOP_ONE_SET")
+            okw = dict(kw)
+            r = orc.fit_dense(x, y, lambda_min_ratio=0.01 if n < p else 0.0001, **okw)
+            assert abs(f["d"] - r["d"]) < DTOL * r["d"], (f["d"], r["d"])
+            assert abs(f["d"] - g["d"]) < 1e-12 * g["d"]
+            for k in range(len(kw["penalty"])):
+                # one workgroup set per penalty or one set walking them: the same bits
+                assert np.array_equal(np.asarray(f["beta"][k]), np.asarray(h["beta"][k])) and np.array_equal(f["niter"][k], h["niter"][k])
+                assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-11)
+                scale = max(1.0, float(np.abs(r["beta"][k]).max()))
+                assert np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max() < 1e-7 * scale, kw["penalty"][k]
+                assert np.abs(np.asarray(f["beta"][k]) - np.asarray(g["beta"][k])).max() < 1e-9 * scale, kw["penalty"][k]
+                dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int))
+                assert np.mean(dn > 1) <= 0.25, (kw["penalty"][k], dn)
+                dg = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(g["niter"][k]).astype(int))
+                assert dg.max() <= 1, (kw["penalty"][k], dg)
+            if kw["maxit"] == 3:
+                assert f["niter"][0].max() == 4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,p", [(1100, 1200), (1500, 1501), (2048, 2100), (2049, 2100), (2500, 2600)])
 def test_wide_engine_tall_columns(oa, n, p, monkeypatch):
     """the column heights that take 24 and 32 registers per lane (four waves per workgroup), and beyond 2048 rows the ROW-BLOCKED

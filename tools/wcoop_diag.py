@@ -21,3 +21,5 @@ d = np.array(list(out), dtype=np.float64)
 names = "product + between | barrier | publish 1 | gather 1 | barrier | slice sums + publish 2 | gather 2 | barrier"
 print(f"n={n} p={p}: OEM iterations {int(np.sum(fit['niter'][0]))}, all-reduces {int(d[8])}: cycles per iteration [{names}]")
 print("   ", np.round(d[0:8] / max(d[8], 1), 0), "sum", round(d[0:8].sum() / max(d[8], 1)))
+print("    product, further: [between + vector reads | dot products | column sums | operator + stop rule | update] (the partial-vector stores are in the first segment above)")
+print("   ", np.round(d[9:14] / max(d[8], 1), 0))
