@@ -10,8 +10,8 @@
 //     entries to its row), and the four slices of a row meet through v_permlane16/32_swap -- no LDS in the product.
 //     A wave covers 256 columns; CH = 2 (q <= 512) or 4 (q <= 1024) waves share a row set and combine through LDS.
 //   * what crosses workgroups is the PRODUCT: u = d beta - XX beta + XY (or XX v during Lanczos), one all-gather per
-//     iteration through L2 as data-tagged 8-byte granules {epoch, 32 value bits} (guide recipe R2: one aligned atomic store
-//     per granule, the data is the flag, no fence; relaxed agent-scope polls; two buffers by parity).  Every workgroup
+//     iteration through the memory side as data-tagged 16-byte pairs {lo, epoch, hi, epoch} (guide recipe R2: the data is the
+//     flag, each 8-byte half carries its own tag, no fence; device-scope stores and polls; two buffers by parity).  Every workgroup
 //     then thresholds the WHOLE u itself (q / 256 coordinates per thread: group norms, Nesterov step, stop rule, the
 //     lambda / penalty state machine), identically everywhere, so no flag or scalar ever crosses workgroups.
 //   * u does not depend on lambda: the product that follows convergence at lambda_i is the warm start of lambda_{i+1} and
@@ -33,7 +33,6 @@ namespace {
 constexpr int CG = 64;            // columns per 16-lane row group, in registers
 constexpr int NTH = 256;          // threads per workgroup (one wave per SIMD: 512 registers per lane, 256 of them VGPRs)
 constexpr int CML = 256;          // Lanczos steps kept
-typedef __attribute__((address_space(1))) unsigned long long cgu64;
 
 template <int CH> struct CoopCfg {
     static constexpr int RW = 64 / CH;          // rows per workgroup (16 per row set, 4 / CH row sets)
@@ -68,8 +67,9 @@ __device__ unsigned long long g_diag_coop[16];
 #define COOP_STAMP(slot) do { } while (0)
 #endif
 
+typedef unsigned coop_v4u __attribute__((ext_vector_type(4)));
 struct CoopX {
-    cgu64 *buf;                   // [2 parities][QMAX rows][2 granules]
+    __amdgpu_buffer_rsrc_t rs;    // [2 parities][QMAX rows] pairs of 16 bytes: {lo, epoch, hi, epoch}
     unsigned epoch;               // exchange counter, never 0; identical in every workgroup
     int wg, qmax;
     bool failed;
@@ -142,66 +142,41 @@ __device__ __forceinline__ void coop_round(const double (&a)[CG], const int (&bi
     }
     COOP_STAMP(2);                                              // column parts through LDS
     ++X.epoch;
-    cgu64 *base = X.buf + (size_t)(X.epoch & 1) * X.qmax * 2;
+    const int base = (int)(X.epoch & 1u) * X.qmax * 16;        // byte offset of this parity's pairs
     if (publisher) {                                            // lanes 0..15 of the first wave of each row set
         const double out = OEM ? (d * Bsh[row] - g) + xyR : g;
         if (rowok) {
-            const unsigned lo = (unsigned)__double2loint(out), hi = (unsigned)__double2hiint(out);
-            __hip_atomic_store(base + (size_t)row * 2, ((unsigned long long)X.epoch << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(base + (size_t)row * 2 + 1, ((unsigned long long)X.epoch << 32) | hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            coop_v4u pr;
+            pr.x = (unsigned)__double2loint(out); pr.y = X.epoch; pr.z = (unsigned)__double2hiint(out); pr.w = X.epoch;
+            __builtin_amdgcn_raw_buffer_store_b128(pr, X.rs, base + row * 16, 0, 16);       // aux 16: sc1 (device scope)
             Ush[row] = out;
         }
     }
     COOP_STAMP(3);                                              // publish
-    // Gather the rows of the other workgroups: thread t polls rows t, t + 256, ...  THREE sweeps are kept in flight (a new one
-    // is issued whenever the oldest comes back without the data): a poll that leaves just before the stores land no longer costs
-    // a whole extra memory round trip, only a third of one.
-    constexpr int NPOLL = 3;
-    unsigned long long v[2 * C::EPT], pv[NPOLL][2 * C::EPT];
-    bool need[C::EPT];
+    // Gather the rows of the other workgroups: thread t polls rows t, t + 256, ... -- a row is ONE 16-byte load (each 8-byte half
+    // carries its own tag, so a torn pair is only ever seen as "not there yet"), ONE sweep in flight, and a row that has arrived
+    // is not asked for again.  (Round 2 kept three sweeps of 8-byte atomic loads in flight: tools/xchg_probe.hip shows that the
+    // polls then flood the fabric and every exchange gets SLOWER -- 16 workgroups, 512 rows: 1.46 us per all-gather against 1.15.)
+    coop_v4u pv[C::EPT];
+    unsigned miss = 0;
 #pragma unroll
     for (int k = 0; k < C::EPT; ++k) {
         const int j = tid + NTH * k;
-        need[k] = j < q && j / C::RW != X.wg;
-        v[2 * k] = v[2 * k + 1] = 0ull;
+        if (j < q && j / C::RW != X.wg) miss |= 1u << k;
+        pv[k] = coop_v4u{0u, 0u, 0u, 0u};
     }
-    auto issue = [&](auto R_) {
-        constexpr int R = decltype(R_)::value;
-#pragma unroll
-        for (int k = 0; k < C::EPT; ++k) {
-            pv[R][2 * k] = pv[R][2 * k + 1] = 0ull;
-            if (need[k]) {
-                const size_t o = (size_t)(tid + NTH * k) * 2;
-                pv[R][2 * k] = __hip_atomic_load(base + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pv[R][2 * k + 1] = __hip_atomic_load(base + o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    };
-    bool ok = false;
+    const unsigned need = miss;
     unsigned spins = 0;
-    const unsigned limit = X.failed ? 0u : 2000000u;            // ~1 s: a partner is gone; after one timeout nobody waits again
-    auto step = [&](auto R_) -> bool {                          // true: stop (data complete, or timed out)
-        constexpr int R = decltype(R_)::value;
-        bool all = true;
+    const unsigned limit = X.failed ? 0u : 1000000u;            // ~1 s: a partner is gone; after one timeout nobody waits again
+    bool ok = true;
+    while (__any(miss != 0u)) {
 #pragma unroll
         for (int k = 0; k < C::EPT; ++k)
-            if (need[k]) all &= ((unsigned)(pv[R][2 * k] >> 32) == X.epoch) & ((unsigned)(pv[R][2 * k + 1] >> 32) == X.epoch);
-        if (__all(all)) {
+            if ((miss >> k) & 1u) pv[k] = __builtin_amdgcn_raw_buffer_load_b128(X.rs, base + (tid + NTH * k) * 16, 0, 16);
 #pragma unroll
-            for (int k = 0; k < 2 * C::EPT; ++k) v[k] = pv[R][k];
-            ok = true;
-            return true;
-        }
-        if (++spins >= limit) return true;
-        issue(R_);
-        return false;
-    };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    issue(I0{}); issue(I1{}); issue(I2{});
-    for (;;) {
-        if (step(I0{})) break;
-        if (step(I1{})) break;
-        if (step(I2{})) break;
+        for (int k = 0; k < C::EPT; ++k)
+            if (((miss >> k) & 1u) && pv[k].y == X.epoch && pv[k].w == X.epoch) miss &= ~(1u << k);
+        if (++spins >= limit && __any(miss != 0u)) { ok = false; break; }
     }
     if (!ok) X.failed = true;
     COOP_STAMP(4);                                              // polling
@@ -210,7 +185,7 @@ __device__ __forceinline__ void coop_round(const double (&a)[CG], const int (&bi
 #endif
 #pragma unroll
     for (int k = 0; k < C::EPT; ++k)
-        if (need[k]) Ush[tid + NTH * k] = ok ? __hiloint2double((int)(unsigned)v[2 * k + 1], (int)(unsigned)v[2 * k]) : 0.0;
+        if ((need >> k) & 1u) Ush[tid + NTH * k] = ((miss >> k) & 1u) ? 0.0 : __hiloint2double((int)pv[k].z, (int)pv[k].x);
     __syncthreads();
     COOP_STAMP(5);                                              // LDS stores + barrier (waits for the slowest wave's poll)
 }
@@ -337,7 +312,7 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
         }
     }
     CoopX X;
-    X.buf = (cgu64 *)reinterpret_cast<unsigned long long *>(A.work); X.epoch = 0; X.wg = wg; X.qmax = C::QMAX; X.failed = false;
+    X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)A.work, 0, 2 * C::QMAX * 16, 0x00020000); X.epoch = 0; X.wg = wg; X.qmax = C::QMAX; X.failed = false;
 #ifdef OEM_PATH_DIAG
     for (int k = 0; k < 16; ++k) X.acc[k] = 0;
     X.last = __builtin_amdgcn_s_memtime();
