@@ -26,8 +26,8 @@
 //     decision and the lambda / penalty state machine runs replicated, with no flag or scalar of its own crossing workgroups.
 //   * the eigenvalue step is Lanczos on n-vectors with the same registers and the same all-reduce (vector updates and both inner
 //     products replicated per workgroup), the top Ritz value by the Sturm multisection of path_dev.hpp.
-// Element-wise penalties without Nesterov's step and compute.loss (what the fused form of the launch-per-iteration engine takes);
-// everything else stays on that engine.  Every spin is bounded; a timeout poisons the result (d_out[6]) and the host reports it.
+// Element-wise penalties without Nesterov's step (compute.loss included: the residual is at hand); everything else stays on the
+// launch-per-iteration engine.  Every spin is bounded; a timeout poisons the result (d_out[6]) and the host reports it.
 #include <cstdlib>
 #include <type_traits>
 
@@ -563,7 +563,15 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
                 const bool conv = !any;
                 if (conv || it >= maxit) {
                     if (storer) A.beta[orow * q + mycol] = bcur;
-                    if (tid == 0 && writer) { A.niter[orow] = conv ? it : maxit + 1; A.loss[orow] = 1e99; }      // ref src/oem_base.h:94-109
+                    // compute.loss (ref src/oem_dense.h:759-770): sum (Ys - Xs beta)^2 -- the residual every workgroup already holds
+                    double loss = 1e99;
+                    if (A.compute_loss) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int k = 0; k < E2; ++k) { const double r = rowok[k] ? Rsh[tid + WNTH * k] : 0.0; t = fma(r, r, t); }
+                        loss = wc_block_sum(t, red, rpar, w, lane);
+                    }
+                    if (tid == 0 && writer) { A.niter[orow] = conv ? it : maxit + 1; A.loss[orow] = loss; }      // ref src/oem_base.h:94-109
                     break;
                 }
             }
@@ -642,7 +650,7 @@ bool path_wcoop_eligible(const PathArgs &a, const WideArgs &wd)
     const bool off = getenv("OEM_NO_WCOOP") != nullptr;           // (read per call: the tests hold the two engines against each other)
     static const int maxg = [] { const char *e = getenv("OEM_WCOOP_MAXG"); const int k = e ? atoi(e) : 0; return (k >= 1 && k < WCOOP_GMAX) ? k : WCOOP_GMAX; }();
     if (off || wd.lay.nb != 1) return false;
-    if (a.ngroups != 0 || a.accelerate || a.compute_loss || a.sinv || a.nbatch > 1 || a.pen_split) return false;
+    if (a.ngroups != 0 || a.accelerate || a.sinv || a.nbatch > 1 || a.pen_split) return false;
     const int G = path_wcoop_workgroups(wd.n, a.p);
     return G >= 1 && G <= maxg;
 }

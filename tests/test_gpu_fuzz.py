@@ -440,7 +440,7 @@ def test_random_wide_cooperating(oa, seed, monkeypatch):
     pf = np.where(rng.random(p) < 0.1, 0.0, rng.uniform(0.5, 2.0, p))
     kw = dict(penalty=pens, nlambda=int(rng.integers(1, 7)), alpha=float(rng.uniform(0.2, 1.0)), gamma=float(rng.uniform(2.1, 5.0)),
               tol=float(10.0 ** rng.uniform(-9, -6)), maxit=int(rng.choice([30, 200, 400])), penalty_factor=pf,
-              standardize=bool(rng.integers(2)), intercept=bool(rng.integers(2)))
+              standardize=bool(rng.integers(2)), intercept=bool(rng.integers(2)), compute_loss=bool(rng.random() < 0.4))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         f = oa.oem(x, y, **kw)
@@ -457,6 +457,8 @@ def test_random_wide_cooperating(oa, seed, monkeypatch):
         scale = max(1.0, float(np.abs(np.asarray(g["beta"][k])).max()))
         assert np.abs(np.asarray(f["beta"][k]) - np.asarray(g["beta"][k])).max() <= 1e-8 * scale, pens[k]
         assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(g["niter"][k]).astype(int)).max() <= 1, pens[k]
+        if kw["compute_loss"]:
+            assert np.allclose(np.ravel(f["loss"][k]), np.ravel(r["loss"][k]), rtol=1e-7, atol=1e-9), pens[k]
 
 
 @pytest.mark.parametrize("seed", list(range(150, 154)) + list(range(90000, 90000 + 4 * (SCALE - 1))))

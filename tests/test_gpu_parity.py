@@ -476,7 +476,8 @@ def test_wide_cooperating_engine(oa, n, p, monkeypatch):
     nlam = 6 if n * p < 1_000_000 else 4
     calls = (dict(penalty=["lasso", "mcp", "scad", "elastic.net", "mcp.net", "scad.net", "ols"], alpha=0.7, gamma=3.5, nlambda=nlam, tol=1e-8, maxit=400,
                   penalty_factor=pf, standardize=True, intercept=True),
-             dict(penalty=["lasso"], nlambda=4, tol=1e-12, maxit=3, standardize=False, intercept=True),
+             dict(penalty=["lasso"], nlambda=4, tol=1e-12, maxit=3, standardize=False, intercept=True, compute_loss=True),
+             dict(penalty=["scad", "lasso"], nlambda=5, tol=1e-9, maxit=300, standardize=False, intercept=False, compute_loss=True),
              dict(penalty=["mcp", "lasso"], lambda_=[np.array([0.5, 0.2, 0.05]), np.array([0.4, 0.1, 0.02])], tol=1e-8, maxit=300,
                   standardize=True, intercept=False))
     with warnings.catch_warnings():
@@ -504,6 +505,9 @@ def test_wide_cooperating_engine(oa, n, p, monkeypatch):
                 assert np.mean(dn > 1) <= 0.25, (kw["penalty"][k], dn)
                 dg = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(g["niter"][k]).astype(int))
                 assert dg.max() <= 1, (kw["penalty"][k], dg)
+                if kw.get("compute_loss"):
+                    assert np.allclose(f["loss"][k], r["loss"][k], rtol=1e-8), kw["penalty"][k]
+                    assert np.allclose(f["loss"][k], g["loss"][k], rtol=1e-9), kw["penalty"][k]
             if kw["maxit"] == 3:
                 assert f["niter"][0].max() == 4
 
