@@ -611,6 +611,29 @@ def main():
             out["host_resident_ms"]["c5_sample"] = host_resident_c5(torch, dev, 1)
         except Exception as e:
             out["host_resident_ms"]["c5_sample"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not a.no_host:
+        # SURVEY section 8 row f-3 on the record: oem() with p >= n, X resident -- the reference's own iteration without a Gram matrix,
+        # as one persistent launch of cooperating workgroups (500 x 2,000) and streamed from HBM (500 x 20,000).  Never `value`.
+        try:
+            import warnings
+            wide = {}
+            for (wn, wp, wl) in ((500, 2000, 50), (500, 20000, 20)):
+                gw = torch.Generator(device=dev); gw.manual_seed(7)
+                xw = torch.randn((wp, wn), generator=gw, device=dev, dtype=torch.float64)
+                bw = torch.zeros(wp, dtype=torch.float64, device=dev); bw[:10] = 1.0
+                yw = (xw.t() @ bw + torch.randn(wn, generator=gw, device=dev, dtype=torch.float64)).cpu().numpy()
+                best, wfit = 1e9, None
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    for _ in range(2):
+                        t0 = time.perf_counter(); wfit = oem_amd.oem(xw.t(), yw, penalty="lasso", nlambda=wl, tol=1e-7); torch.cuda.synchronize()
+                        best = min(best, time.perf_counter() - t0)
+                it = int(np.sum(wfit["niter"][0]))
+                wide[f"{wn}x{wp}_lasso_{wl}_lambdas"] = {"ms": 1e3 * best, "iterations": it, "us_per_iteration": 1e6 * best / max(it, 1)}
+                del xw
+            out["p_ge_n_ms"] = wide
+        except Exception as e:
+            out["p_ge_n_ms"] = {"error": repr(e)}
     if in_group:
         dist.destroy_process_group()
     # ---- N > 1: the in-library multi-GPU path (opts.ngpus = N: what an R caller gets), on rank 0 once the other ranks are gone
