@@ -61,7 +61,7 @@ template <int NR> struct WCfg {
     static constexpr int OFF_G = OFF_P + 4 * NP;             // gathered partials of this workgroup's slice [GS]
     static constexpr int OFF_T = OFF_G + GS;                 // Lanczos alpha [WCML], beta [WCML]
     static constexpr int OFF_S = OFF_T + 2 * WCML;           // Sturm scratch 2 (WCML + 16)
-    static constexpr int OFF_X = OFF_S + 2 * (WCML + 16);    // block reductions [2][4], theta slot, lmax words [16 + 8], votes [12 ints]
+    static constexpr int OFF_X = OFF_S + 2 * (WCML + 16);    // block reductions [2][4], theta slot, lmax words [16 + 8], votes [16 ints]
     static constexpr int N_DBL = OFF_X + 32;
 };
 
@@ -86,6 +86,8 @@ struct WX {
     unsigned long long acc[16], last;
 #endif
     __amdgpu_buffer_rsrc_t rs1, rs2;   // exchange 1: [2 parities][G owners][G senders][SL] pairs of 16 bytes; exchange 2: [2 parities][NP] pairs
+    __amdgpu_buffer_rsrc_t rs3;        // general form: the all-gather of u, [2 parities][qpad] pairs
+    int qpad;
     unsigned epoch;               // all-reduce counter, never 0; identical in every workgroup
     int wg, G, SL, n, row0, nsl;  // this workgroup's slice: rows [row0, row0 + nsl)
     int stride1;                  // pairs per parity of exchange 1
@@ -199,6 +201,85 @@ __device__ __forceinline__ void wc_publish(__amdgpu_buffer_rsrc_t rs, int off, d
     wc_v4u v;
     v.x = (unsigned)__double2loint(val); v.y = tag; v.z = (unsigned)__double2hiint(val); v.w = tag;
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
+}
+
+// General form (group operators, Nesterov's step): all-gather of u, one value per column.  In: the column owners' values (one lane
+// per column: `storer`).  Out: Ush[j] for every j < q, behind a barrier.  Tagged with the epoch of the all-reduce that follows.
+__device__ __forceinline__ void wc_allgather_u(double *Ush, double u_own, int mycol, bool storer, int q, int cpg, WX &X, int tid)
+{
+    const unsigned ep = X.epoch + 1;
+    const int off3 = (int)(ep & 1u) * X.qpad * 16;
+    if (storer) { wc_publish(X.rs3, off3 + mycol * 16, u_own, ep << 1); Ush[mycol] = u_own; }
+    const int nk = (q + WNTH - 1) / WNTH;                       // <= 16 (q <= 4096)
+    unsigned miss = 0;
+    for (int k = 0; k < nk; ++k) { const int j = tid + WNTH * k; if (j < q && j / cpg != X.wg) miss |= 1u << k; }
+    unsigned spins = 0;
+    const unsigned limit = X.failed ? 0u : 1000000u;
+    // first only ONE value per thread (a sweep of everything is q / 8 cache lines per workgroup: while nothing has landed yet the
+    // sweeps of 63 workgroups are most of the fabric's traffic); when that one is there the rest has mostly landed too
+    while (__any((miss & 1u) != 0u)) {
+        wc_v4u pv = wc_v4u{0u, 0u, 0u, 0u};
+        if (miss & 1u) pv = __builtin_amdgcn_raw_buffer_load_b128(X.rs3, off3 + tid * 16, 0, 16);
+        if ((miss & 1u) && (pv.y >> 1) == ep && (pv.w >> 1) == ep) { Ush[tid] = __hiloint2double((int)pv.z, (int)pv.x); miss &= ~1u; }
+        if (++spins >= limit && __any((miss & 1u) != 0u)) { X.failed = true; break; }
+    }
+    while (!X.failed && __any(miss != 0u)) {
+        for (int k0 = 0; k0 < nk; k0 += 8) {
+            wc_v4u pv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                pv[i] = wc_v4u{0u, 0u, 0u, 0u};
+                if ((miss >> (k0 + i)) & 1u) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(X.rs3, off3 + (tid + WNTH * (k0 + i)) * 16, 0, 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (((miss >> (k0 + i)) & 1u) && (pv[i].y >> 1) == ep && (pv[i].w >> 1) == ep) {
+                    Ush[tid + WNTH * (k0 + i)] = __hiloint2double((int)pv[i].z, (int)pv[i].x);
+                    miss &= ~(1u << (k0 + i));
+                }
+        }
+        if (++spins >= limit && __any(miss != 0u)) { X.failed = true; break; }
+    }
+    for (int k = 0; k < nk; ++k) if ((miss >> k) & 1u) Ush[tid + WNTH * k] = 0.0;        // (timed out: poisoned anyway)
+    __syncthreads();
+}
+
+// The same for the columns on a list (group operators without Nesterov's step: a workgroup only needs u of the members of its own
+// columns' groups -- with groups of neighbouring columns a handful of values from the next workgroup, or none).  Everybody still
+// publishes all its columns.
+__device__ __forceinline__ void wc_gather_u_list(double *Ush, double u_own, int mycol, bool storer, const int *list, int nlist, WX &X, int tid)
+{
+    const unsigned ep = X.epoch + 1;
+    const int off3 = (int)(ep & 1u) * X.qpad * 16;
+    if (storer) { wc_publish(X.rs3, off3 + mycol * 16, u_own, ep << 1); Ush[mycol] = u_own; }
+    const int nk = (nlist + WNTH - 1) / WNTH;
+    unsigned miss = 0;
+    for (int k = 0; k < nk; ++k) if (tid + WNTH * k < nlist) miss |= 1u << k;
+    unsigned spins = 0;
+    const unsigned limit = X.failed ? 0u : 1000000u;
+    while (__any(miss != 0u)) {
+        for (int k0 = 0; k0 < nk; k0 += 4) {
+            wc_v4u pv[4];
+            int col[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pv[i] = wc_v4u{0u, 0u, 0u, 0u};
+                col[i] = 0;
+                if ((miss >> (k0 + i)) & 1u) {
+                    col[i] = list[tid + WNTH * (k0 + i)];
+                    pv[i] = __builtin_amdgcn_raw_buffer_load_b128(X.rs3, off3 + col[i] * 16, 0, 16);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (((miss >> (k0 + i)) & 1u) && (pv[i].y >> 1) == ep && (pv[i].w >> 1) == ep) {
+                    Ush[col[i]] = __hiloint2double((int)pv[i].z, (int)pv[i].x);
+                    miss &= ~(1u << (k0 + i));
+                }
+        }
+        if (++spins >= limit && __any(miss != 0u)) { X.failed = true; break; }
+    }
+    __syncthreads();
 }
 
 // OR of one bit per thread over the workgroup through four LDS words and ONE barrier (the caller's: `words` is read behind it)
@@ -315,7 +396,11 @@ __device__ __forceinline__ double wc_op(double u, double tp, const WThr &c)
     return cdiv(u, c.d, c.rd);
 }
 
-template <int NR>
+// GEN: the general form -- everything that needs the whole of u at once (group operators, Nesterov's step).  One more exchange per
+// iteration: u is all-gathered (one value per column), every workgroup then runs the WHOLE operator stage itself on all q
+// coordinates with identical arithmetic (group norms, factors, Nesterov's extrapolation, stop rule: path_coop.hip's way), and picks
+// the coefficients of its own columns for the update product.  beta of all coordinates lives in LDS.
+template <int NR, bool GEN>
 __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const double *__restrict__ xs, const double *__restrict__ ysv, int n,
                                                            unsigned long long *xchg, long long set_stride)
 {
@@ -360,6 +445,23 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
     X.stride1 = G * G * X.SL;
     X.rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, 2 * X.stride1 * 16, 0x00020000);
     X.rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)(xchg + (size_t)4 * X.stride1), 0, 2 * NP * 16, 0x00020000);
+    X.qpad = G * C::CPG;
+    X.rs3 = __builtin_amdgcn_make_buffer_rsrc((void *)(xchg + (size_t)4 * X.stride1 + (size_t)4 * NP), 0, 2 * X.qpad * 16, 0x00020000);
+    // general form: u and beta of ALL coordinates, the group tables
+    const int ng = GEN ? A.ngroups : 0, qp = (q + 8 + 1) & ~1, ngp = (ng + 2) & ~1;
+    double *Ush = lds + C::N_DBL, *Bsh = Ush + qp, *Pfsh = Bsh + qp, *Fsh = Pfsh + qp, *GWsh = Fsh + ngp;
+    int *gidL = reinterpret_cast<int *>(GWsh + ngp), *gstartL = gidL + qp, *gidxL = gstartL + ngp + 2, *gzeroL = gidxL + qp;
+    int *needL = gzeroL + ngp, *nneedL = needL + qp;             // the columns of other workgroups this one's groups reach into
+    if (GEN) {
+        for (int j = tid; j < qp; j += WNTH) { Ush[j] = 0.0; Bsh[j] = 0.0; Pfsh[j] = j < q ? A.pf[j] : 0.0; }
+        for (int j = tid; j < qp; j += WNTH) gidL[j] = (ng > 0 && j < q) ? A.gid[j] : -1;
+        if (ng > 0) {
+            for (int g = tid; g <= ng; g += WNTH) gstartL[g] = A.gstart[g];
+            for (int g = tid; g < ng; g += WNTH) { gzeroL[g] = A.gzero[g]; GWsh[g] = A.gw[g]; }
+            const int nm = A.gstart[ng];
+            for (int m = tid; m < nm; m += WNTH) gidxL[m] = A.gidx[m];
+        }
+    }
     X.epoch = 0; X.failed = false;
 #ifdef OEM_PATH_DIAG
     for (int k = 0; k < 16; ++k) X.acc[k] = 0;
@@ -385,12 +487,45 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
         }
     }
     __syncthreads();
+    int nneed = 0;
+    if (GEN && ng > 0) {
+        if (tid == 0) nneedL[0] = 0;
+        __syncthreads();
+        const int c0 = wg * C::CPG, cme = c0 + tid;
+        if (tid < C::CPG && cme < q) {
+            const int gi = gidL[cme];
+            bool first = gi >= 0;
+            for (int cc = c0; cc < cme && first; ++cc) first = gidL[cc] != gi;      // one own column per group walks its members
+            if (first)
+                for (int m = gstartL[gi]; m < gstartL[gi + 1]; ++m) {
+                    const int j = gidxL[m];
+                    if (j / C::CPG != wg) needL[atomicAdd(&nneedL[0], 1)] = j;
+                }
+        }
+        __syncthreads();
+        nneed = nneedL[0];
+    }
+    // this lane's column: its group, fixed for the whole call -- weight, member range and the first eight member indices in registers
+    // (per iteration the walk is then ONE round of LDS reads for groups of up to eight)
+    int mygi = -1, gm0 = 0, gm1 = 0, gix[8];
+    bool mygz = true;
+    double mygw = 0.0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) gix[t] = q;                      // slot q: zero words
+    if (GEN && ng > 0 && colok) {
+        mygi = gidL[mycol];
+        if (mygi >= 0) {
+            mygz = gzeroL[mygi] != 0; mygw = GWsh[mygi]; gm0 = gstartL[mygi]; gm1 = gstartL[mygi + 1];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) if (gm0 + t < gm1) gix[t] = gidxL[gm0 + t];
+        }
+    }
     int rpar = 0;
 
-    // both products over the registers.  EIG: z = Xs'v, partial Xs z.  OEM: beta' = T(Xs'r / n + d beta), partial Xs beta'.
-    double bcur = 0.0;                                          // the coefficient of this lane's column
-    auto product = [&](auto OEM_, const WThr &c, double tp, double d, bool &moving) __attribute__((always_inline)) {
-        constexpr bool OEM = decltype(OEM_)::value;
+    // both products over the registers: col_dots() = x_c . Rsh for this lane's column (every lane of the column gets it);
+    // col_update(b) = this wave's part of sum_c x_c b_c into Pc (b: the value of this lane's column)
+    double bcur = 0.0;                                          // (element-wise form) the coefficient of this lane's column
+    auto col_dots = [&]() __attribute__((always_inline)) {
         double rr[NR], s[CW];
 #pragma unroll
         for (int k = 0; k < NR; ++k) rr[k] = Rsh[lane + 64 * k];
@@ -405,25 +540,18 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
         WC_STAMP(10);                                            // dot products
         const double dot = wc_colsum<CW>(s, lane);
         WC_STAMP(11);                                            // column sums
-        double bn[1];
-        if (OEM) {
-            const double u = dot * rn + d * bcur;                // ref src/oem_dense.h:520: X'(Y - X beta)/n + d beta
-            const double b = colok ? wc_op(u, tp, c) : 0.0;
-            const double cu = fabs(b), qo = fabs(bcur);
-            const bool cn = cu > 1e-13, qn = qo > 1e-13;          // ref src/utils.cpp:537-549
-            moving = (cn != qn) || (cn && qn && fabs(b - bcur) > A.tol * qo);
-            bcur = b;
-            bn[0] = b;
-        } else bn[0] = dot;
-        WC_STAMP(12);                                            // operator, stop rule
+        return dot;
+    };
+    auto col_update = [&](double b) __attribute__((always_inline)) {
+        double bn[1] = {b};
         const unsigned long long nz = __ballot(bn[0] != 0.0);
         dpp_hazard_fence(bn);
         double acc[NR];
 #pragma unroll
         for (int k = 0; k < NR; ++k) acc[k] = 0.0;
         WcUpd<0, NR, CW, SH>::run(acc, bn[0], x, nz);
-#pragma unroll
         WC_STAMP(13);                                            // update
+#pragma unroll
         for (int k = 0; k < NR; ++k) Pc[w * NP + lane + 64 * k] = acc[k];
     };
 
@@ -458,7 +586,6 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
         __syncthreads();
         return th;
     };
-    const WThr nothr = {};
     int nst = 0;
     double bprev = 0.0, theta = 0.0, theta_prev = -__builtin_inf(), mv_prev = __builtin_inf();
     bool have_theta = false;
@@ -466,8 +593,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
 #pragma unroll
         for (int k = 0; k < E2; ++k) if (rowok[k]) Rsh[tid + WNTH * k] = v[k];
         __syncthreads();
-        bool mv = false;
-        product(std::false_type{}, nothr, 0.0, 0.0, mv);
+        col_update(col_dots());                                   // z = Xs'v, this workgroup's part of Xs z
         (void)wc_allreduce<NR, false>(Rsh, Ysh, Pc, Gsh, votes, pub, need1, need2, rn, 0, X, tid, w, lane);
         double al = 0.0;
 #pragma unroll
@@ -529,9 +655,11 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
         const int maxit = A.maxit;
         // cold start (ref src/oem_dense.cpp:243-244): beta = 0, so the residual is Ys
         bcur = 0.0;
+        double ak = 1.0;                                          // Nesterov's sequence (ref src/oem_dense.h:633-651), restarted per penalty
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < E2; ++k) if (rowok[k]) Rsh[tid + WNTH * k] = Ysh[tid + WNTH * k];
+        if (GEN) for (int j = tid; j < q; j += WNTH) Bsh[j] = 0.0;
         __syncthreads();
         double lam_next = A.user_lambda ? A.lambda_user[(size_t)pp * nl] : 0.0;
         for (int i = 0; i < nl; ++i) {
@@ -555,10 +683,155 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
             const double tp = pfj * K.L;
             int it = 0;
             for (;;) {
-                bool moving = false;
-                product(std::true_type{}, c, tp, d, moving);
-                // r' = Ys - Xs beta': the next iteration's input, or the warm start of the next lambda
-                const int any = wc_allreduce<NR, true>(Rsh, Ysh, Pc, Gsh, votes, pub, need1, need2, rn, moving ? 1 : 0, X, tid, w, lane);
+                int any;
+                const bool grp = GEN && K.kind >= K_GRP;
+                // 1 - pen / ||u_g|| etc. from the squared norm of a group (ref src/oem_dense.h:193-315; quirk Q6: ||u_g|| = 0 => 0)
+                auto group_factor = [&](double s2, double pen_g) {
+                    if (K.kind == K_GRP || K.kind == K_SGL) {
+                        double nrm, rnm;                                 // root and reciprocal from v_rsq_f64 + Goldschmidt, the quotient
+                        sqrt_rsqrt_lane(s2, nrm, rnm);                   // refined like cdiv (path_coop.hip has the same)
+                        const double t = 1.0 - cdiv(pen_g, nrm, rnm);
+                        return (s2 > 0.0 && 0.0 < t) ? t : 0.0;
+                    }
+                    const double nrm = sqrt(s2);
+                    return (K.kind == K_GRP_MCP) ? mcp_norm(nrm, pen_g, K.D, K.gamma) : scad_norm(nrm, pen_g, K.D, K.gamma);
+                };
+                auto elementwise_iteration = [&]() __attribute__((always_inline)) {
+                    const double dot = col_dots();
+                    const double u = dot * rn + d * bcur;            // ref src/oem_dense.h:520: X'(Y - X beta)/n + d beta
+                    const double b = colok ? wc_op(u, tp, c) : 0.0;
+                    const double cu = fabs(b), qo = fabs(bcur);
+                    const bool cn = cu > 1e-13, qn = qo > 1e-13;      // ref src/utils.cpp:537-549
+                    const bool moving = (cn != qn) || (cn && qn && fabs(b - bcur) > A.tol * qo);
+                    bcur = b;
+                    WC_STAMP(12);                                    // operator, stop rule
+                    col_update(b);
+                    // r' = Ys - Xs beta': the next iteration's input, or the warm start of the next lambda
+                    return wc_allreduce<NR, true>(Rsh, Ysh, Pc, Gsh, votes, pub, need1, need2, rn, moving ? 1 : 0, X, tid, w, lane);
+                };
+                if constexpr (!GEN) any = elementwise_iteration();
+                else if (!grp && !A.accelerate) any = elementwise_iteration();
+                else if (!A.accelerate) {
+                    // ---- a group operator: u of the members of this workgroup's groups (its own columns, and what the list names),
+                    // then every lane forms the factor of ITS column's group and the coefficient of its column
+                    const double dot = col_dots();
+                    const double uo = colok ? dot * rn + d * bcur : 0.0;
+                    wc_gather_u_list(Ush, uo, mycol, storer, needL, nneed, X, tid);
+                    WC_STAMP(14);                                    // exchange of u
+                    const bool sgl = K.kind == K_SGL;                // sparse group lasso: the soft-thresholded u feeds the norms
+                    double f = 0.0;
+                    if (mygi >= 0) {
+                        f = 1.0;
+                        if (!mygz) {
+                            double s2 = 0.0;                         // summed in member order like the reference
+                            {
+                                double xv[8], pv8[8];
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) { xv[t] = Ush[gix[t]]; pv8[t] = sgl ? Pfsh[gix[t]] : 0.0; }
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) { const double xs1 = sgl ? soft1(xv[t], pv8[t] * K.L1, 1.0) : xv[t]; s2 += xs1 * xs1; }
+                            }
+                            for (int m = gm0 + 8; m < gm1; m += 8) {     // longer groups: eight members per trip, the index reads together
+                                int ix[8];
+                                double xv[8], pv8[8];
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) ix[t] = (m + t < gm1) ? gidxL[m + t] : q;
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) { xv[t] = Ush[ix[t]]; pv8[t] = sgl ? Pfsh[ix[t]] : 0.0; }
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) { const double xs1 = sgl ? soft1(xv[t], pv8[t] * K.L1, 1.0) : xv[t]; s2 += xs1 * xs1; }
+                            }
+                            f = group_factor(s2, K.L * mygw);
+                        }
+                    }
+                    WC_STAMP(15);                                    // group norm and factor
+                    const double us = sgl ? soft1(uo, pfj * K.L1, 1.0) : uo;
+                    const double b = (colok && f != 0.0) ? cdiv(us * f, K.D, c.rD) : 0.0;
+                    const double cu = fabs(b), qo = fabs(bcur);
+                    const bool cn = cu > 1e-13, qn = qo > 1e-13;      // ref src/utils.cpp:537-549
+                    const bool moving = (cn != qn) || (cn && qn && fabs(b - bcur) > A.tol * qo);
+                    bcur = b;
+                    WC_STAMP(12);
+                    col_update(b);
+                    any = wc_allreduce<NR, true>(Rsh, Ysh, Pc, Gsh, votes, pub, need1, need2, rn, moving ? 1 : 0, X, tid, w, lane);
+                } else {
+                    // ---- Nesterov's step needs every coordinate's move (a global inner product): u of everybody, then the operator stage
+                    // on ALL coordinates, identically in every workgroup (path_large.hip: path_update has the same)
+                    const double dot = col_dots();
+                    const double uo = colok ? dot * rn + d * Bsh[colok ? mycol : 0] : 0.0;
+                    wc_allgather_u(Ush, uo, mycol, storer, q, C::CPG, X, tid);
+                    WC_STAMP(14);                                    // all-gather of u
+                    if (grp) {
+                        if (K.kind == K_SGL) {                       // sparse group lasso: the soft-thresholded u feeds the norms
+                            for (int j = tid; j < q; j += WNTH) Ush[j] = soft1(Ush[j], Pfsh[j] * K.L1, 1.0);
+                            __syncthreads();
+                        }
+                        for (int gi = tid; gi < ng; gi += WNTH) {
+                            double f = 1.0;
+                            if (!gzeroL[gi]) {
+                                double s2 = 0.0;                     // summed in member order like the reference; eight members per trip:
+                                const int m1 = gstartL[gi + 1];      // the index reads together, then the values (two LDS latencies, not sixteen)
+                                for (int m = gstartL[gi]; m < m1; m += 8) {
+                                    int ix[8];
+                                    double xv[8];
+#pragma unroll
+                                    for (int t = 0; t < 8; ++t) ix[t] = (m + t < m1) ? gidxL[m + t] : q;      // Ush[q]: a zero word
+#pragma unroll
+                                    for (int t = 0; t < 8; ++t) xv[t] = Ush[ix[t]];
+#pragma unroll
+                                    for (int t = 0; t < 8; ++t) s2 += xv[t] * xv[t];
+                                }
+                                f = group_factor(s2, K.L * GWsh[gi]);
+                            }
+                            Fsh[gi] = f;
+                        }
+                        __syncthreads();
+                    }
+                    WC_STAMP(15);                                    // group norms and factors
+                    bool bad = false;
+                    double adp = 0.0;
+                    const double akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak)), ratio = (ak - 1.0) / akn;
+                    for (int j0 = tid; j0 < q; j0 += 4 * WNTH) {        // four coordinates per trip: their LDS reads together
+                        double uo4[4], bo4[4], pf4[4], f4[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int j = j0 + WNTH * t, jj = j < q ? j : q;        // (slot q: zero words)
+                            uo4[t] = Ush[jj]; bo4[t] = Bsh[jj]; pf4[t] = Pfsh[jj];
+                            const int gi = grp ? gidL[jj] : -1;
+                            f4[t] = gi >= 0 ? Fsh[gi] : 0.0;
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int j = j0 + WNTH * t;
+                            const double bo = bo4[t];
+                            double bnj;
+                            if (grp) bnj = (f4[t] != 0.0) ? cdiv(uo4[t] * f4[t], K.D, c.rD) : 0.0;
+                            else bnj = wc_op(uo4[t], pf4[t] * K.L, c);
+                            if (A.accelerate) {
+                                const double upd = bnj, diff = upd - bo;
+                                bnj = upd + ratio * diff;
+                                adp += (bnj - upd) * diff;
+                            }
+                            const double cu = fabs(bnj), qo = fabs(bo);
+                            const bool cn = cu > 1e-13, qn = qo > 1e-13;  // ref src/utils.cpp:537-549
+                            if (j < q) {
+                                bad |= (cn != qn) || (cn && qn && fabs(bnj - bo) > A.tol * qo);
+                                Bsh[j] = bnj;
+                            }
+                        }
+                    }
+                    if (A.accelerate) {
+                        adp = wc_block_sum(adp, red, rpar, w, lane);
+                        ak = (adp > 0.0) ? 1.0 : akn;
+                    }
+                    wc_vote(votes + 12, w, lane, bad ? 1 : 0);
+                    __syncthreads();                                 // beta of every coordinate is in place, and the votes
+                    any = votes[12] | votes[13] | votes[14] | votes[15];
+                    bcur = colok ? Bsh[mycol] : 0.0;
+                    WC_STAMP(12);
+                    col_update(bcur);
+                    (void)wc_allreduce<NR, true>(Rsh, Ysh, Pc, Gsh, votes, pub, need1, need2, rn, 0, X, tid, w, lane);
+                }
                 ++it;
                 const bool conv = !any;
                 if (conv || it >= maxit) {
@@ -588,15 +861,30 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
     if (__syncthreads_or(X.failed ? 1 : 0) && tid == 0) A.d_out[6] = 1.0;
 }
 
-template <int NR> int wcoop_launch(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G, int sets, size_t set_stride)
+static size_t wcoop_gen_lds_doubles(int q, int ng)
+{
+    const size_t qp = (size_t)((q + 8 + 1) & ~1), ngp = (size_t)((ng + 2) & ~1);
+    return 3 * qp + 2 * ngp + (qp + ngp + 2 + qp + ngp + qp + 2 + 1) / 2 + 2;       // Ush, Bsh, Pf | F, GW | ints: gid, gstart, gidx, gzero, need list + count
+}
+template <int NR, bool GEN> int wcoop_launch_as(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G, int sets, size_t set_stride)
 {
     typedef WCfg<NR> C;
-    const size_t sh = (size_t)C::N_DBL * sizeof(double);
-    if (sh > 64 * 1024 && lds_limit_once(reinterpret_cast<const void *>(&path_wcoop_kernel<NR>), sh)) return OEMGPU_ERR_HIP;
-    hipLaunchKernelGGL((path_wcoop_kernel<NR>), dim3(G, sets), dim3(WNTH), sh, s, a, wd.xs, wd.ys, wd.n,
+    const size_t sh = ((size_t)C::N_DBL + (GEN ? wcoop_gen_lds_doubles(a.p, a.ngroups) : 0)) * sizeof(double);
+    if (sh > 64 * 1024 && lds_limit_once(reinterpret_cast<const void *>(&path_wcoop_kernel<NR, GEN>), sh)) return OEMGPU_ERR_HIP;
+    hipLaunchKernelGGL((path_wcoop_kernel<NR, GEN>), dim3(G, sets), dim3(WNTH), sh, s, a, wd.xs, wd.ys, wd.n,
                        reinterpret_cast<unsigned long long *>(wd.scratch), (long long)set_stride);
     OEM_HIP(hipGetLastError());
     return 0;
+}
+static bool wcoop_general(const PathArgs &a) { return a.ngroups != 0 || a.accelerate != 0; }
+template <int NR> int wcoop_launch(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G, int sets, size_t set_stride)
+{
+    return wcoop_general(a) ? wcoop_launch_as<NR, true>(s, a, wd, G, sets, set_stride) : wcoop_launch_as<NR, false>(s, a, wd, G, sets, set_stride);
+}
+// dynamic LDS of the kernel for this call (bytes)
+template <int NR> size_t wcoop_lds_bytes(const PathArgs &a)
+{
+    return ((size_t)WCfg<NR>::N_DBL + (wcoop_general(a) ? wcoop_gen_lds_doubles(a.p, a.ngroups) : 0)) * sizeof(double);
 }
 
 }  // namespace
@@ -622,7 +910,7 @@ static size_t wcoop_set_doubles(int n, int p)
     if (G < 1 || G > WCOOP_GMAX) return 0;
     const WideLayout L = wide_layout(n);
     const size_t SL = ((size_t)n + G - 1) / G;
-    return 2 * ((size_t)G * G * SL * 2) + 2 * ((size_t)L.npad() * 2) + 64;
+    return 2 * ((size_t)G * G * SL * 2) + 2 * ((size_t)L.npad() * 2) + 2 * ((size_t)G * 4 * wc_cw(L.nr) * 2) + 64;
 }
 // workgroup sets (one per penalty) that may run side by side: all of them resident at once, on three quarters of the CUs at most
 int path_wcoop_sets(int n, int p, int npen, int num_cu)
@@ -650,9 +938,20 @@ bool path_wcoop_eligible(const PathArgs &a, const WideArgs &wd)
     const bool off = getenv("OEM_NO_WCOOP") != nullptr;           // (read per call: the tests hold the two engines against each other)
     static const int maxg = [] { const char *e = getenv("OEM_WCOOP_MAXG"); const int k = e ? atoi(e) : 0; return (k >= 1 && k < WCOOP_GMAX) ? k : WCOOP_GMAX; }();
     if (off || wd.lay.nb != 1) return false;
-    if (a.ngroups != 0 || a.accelerate || a.sinv || a.nbatch > 1 || a.pen_split) return false;
+    if (a.sinv || a.nbatch > 1 || a.pen_split) return false;
     const int G = path_wcoop_workgroups(wd.n, a.p);
-    return G >= 1 && G <= maxg;
+    if (G < 1 || G > maxg) return false;
+    if (wcoop_general(a)) {                                      // the general form keeps u and beta of all coordinates and the group tables in LDS
+        if (getenv("OEM_WCOOP_NO_GENERAL") || a.p > 4096) return false;
+        size_t lds = 0;
+        switch (wd.lay.nr) {
+        case 1: lds = wcoop_lds_bytes<1>(a); break; case 2: lds = wcoop_lds_bytes<2>(a); break; case 3: lds = wcoop_lds_bytes<3>(a); break;
+        case 4: lds = wcoop_lds_bytes<4>(a); break; case 6: lds = wcoop_lds_bytes<6>(a); break; case 8: lds = wcoop_lds_bytes<8>(a); break;
+        case 12: lds = wcoop_lds_bytes<12>(a); break; case 16: lds = wcoop_lds_bytes<16>(a); break; default: return false;
+        }
+        if (lds > 150 * 1024) return false;
+    }
+    return true;
 }
 
 int launch_path_wcoop(hipStream_t s, const PathArgs &a, const WideArgs &wd, int sets)

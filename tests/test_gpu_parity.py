@@ -474,12 +474,19 @@ def test_wide_cooperating_engine(oa, n, p, monkeypatch):
     rng = np.random.default_rng(n + p)
     pf = rng.uniform(0.5, 2.0, p); pf[rng.integers(p)] = 0.0
     nlam = 6 if n * p < 1_000_000 else 4
+    grp = np.minimum(np.arange(p) // 7, max(1, p // 9))            # ragged: the last group is long; ids start at 0 (group 0: unpenalised)
+    grp = grp[rng.permutation(p)] if p < 600 else grp             # small p: members scattered over the workgroups
     calls = (dict(penalty=["lasso", "mcp", "scad", "elastic.net", "mcp.net", "scad.net", "ols"], alpha=0.7, gamma=3.5, nlambda=nlam, tol=1e-8, maxit=400,
                   penalty_factor=pf, standardize=True, intercept=True),
              dict(penalty=["lasso"], nlambda=4, tol=1e-12, maxit=3, standardize=False, intercept=True, compute_loss=True),
              dict(penalty=["scad", "lasso"], nlambda=5, tol=1e-9, maxit=300, standardize=False, intercept=False, compute_loss=True),
              dict(penalty=["mcp", "lasso"], lambda_=[np.array([0.5, 0.2, 0.05]), np.array([0.4, 0.1, 0.02])], tol=1e-8, maxit=300,
-                  standardize=True, intercept=False))
+                  standardize=True, intercept=False),
+             # the general form: u all-gathered, the operator stage replicated -- group operators (ragged groups, group 0, weights),
+             # the sparse group lasso, Nesterov's step
+             dict(penalty=["grp.lasso", "sparse.grp.lasso", "grp.mcp", "grp.scad.net", "lasso"], groups=grp, alpha=0.6, tau=0.4,
+                  nlambda=nlam, tol=1e-8, maxit=400, penalty_factor=pf, standardize=True, intercept=True, compute_loss=True),
+             dict(penalty=["lasso", "mcp", "grp.lasso"], groups=grp, nlambda=nlam, tol=1e-8, maxit=400, accelerate=True, standardize=False, intercept=True))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for kw in calls:
@@ -491,6 +498,8 @@ def test_wide_cooperating_engine(oa, n, p, monkeypatch):
             h = oa.oem(x, y, **kw)
             monkeypatch.delenv("OEM_WCOOP_ONE_SET")
             okw = dict(kw)
+            if "groups" in okw:
+                okw["unique_groups"] = np.unique(grp)
             r = orc.fit_dense(x, y, lambda_min_ratio=0.01 if n < p else 0.0001, **okw)
             assert abs(f["d"] - r["d"]) < DTOL * r["d"], (f["d"], r["d"])
             assert abs(f["d"] - g["d"]) < 1e-12 * g["d"]

@@ -14,7 +14,8 @@ p = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 nl = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 rng = np.random.default_rng(5)
 x = np.asfortranarray(rng.normal(size=(n, p))); y = x[:, :10] @ rng.uniform(0.5, 1.5, 10) + rng.normal(size=n)
-fit = oa.oem(x, y, penalty="lasso", nlambda=nl, tol=1e-7)
+gen = len(sys.argv) > 4
+fit = oa.oem(x, y, penalty="grp.lasso", groups=np.arange(p) // 5 + 1, nlambda=nl, tol=1e-7) if gen else oa.oem(x, y, penalty="lasso", nlambda=nl, tol=1e-7)
 lib = L.lib(); lib.oemgpu_diag_read_wcoop.argtypes = [C.POINTER(C.c_ulonglong)]
 out = (C.c_ulonglong * 16)(); assert lib.oemgpu_diag_read_wcoop(out) == 0
 d = np.array(list(out), dtype=np.float64)
@@ -23,3 +24,5 @@ print(f"n={n} p={p}: OEM iterations {int(np.sum(fit['niter'][0]))}, all-reduces 
 print("   ", np.round(d[0:8] / max(d[8], 1), 0), "sum", round(d[0:8].sum() / max(d[8], 1)))
 print("    product, further: [between + vector reads | dot products | column sums | operator + stop rule | update] (the partial-vector stores are in the first segment above)")
 print("   ", np.round(d[9:14] / max(d[8], 1), 0))
+if gen:
+    print("    general form: all-gather of u", round(d[14] / max(d[8], 1)), "cycles, group norms + factors", round(d[15] / max(d[8], 1)), "; 'operator + stop rule' above is the rest of the replicated operator stage")
