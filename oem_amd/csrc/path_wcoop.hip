@@ -26,8 +26,9 @@
 //     decision and the lambda / penalty state machine runs replicated, with no flag or scalar of its own crossing workgroups.
 //   * the eigenvalue step is Lanczos on n-vectors with the same registers and the same all-reduce (vector updates and both inner
 //     products replicated per workgroup), the top Ritz value by the Sturm multisection of path_dev.hpp.
-// Element-wise penalties without Nesterov's step (compute.loss included: the residual is at hand); everything else stays on the
-// launch-per-iteration engine.  Every spin is bounded; a timeout poisons the result (d_out[6]) and the host reports it.
+// Element-wise operators as above; group operators with ONE more exchange (u of the members of a workgroup's own groups); Nesterov's
+// step with u all-gathered and the operator stage replicated (template parameter GEN); compute.loss is the squared norm of the
+// residual every workgroup holds.  Every spin is bounded; a timeout poisons the result (d_out[6]) and the host reports it.
 #include <cstdlib>
 #include <type_traits>
 
