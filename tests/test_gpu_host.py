@@ -287,3 +287,38 @@ def test_handover_staged_through_the_host():
     r = subprocess.run([sys.executable, str(root / "tests" / "no_peer_worker.py")], cwd=root, env=dict(os.environ, OEMGPU_NO_PEER="1"),
                        capture_output=True, text=True, timeout=600)
     assert "NO_PEER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_concurrent_callers_of_the_cooperating_wide_engine(oa):
+    """five host threads fit p >= n problems at once, each through ONE persistent launch of 63 cooperating workgroups per penalty set
+    (path_wcoop.hip): the callers queue for CU slots (api.hip: CoopSlots -- all workgroups of all such kernels in flight must be
+    resident), nobody times out, and every thread gets the bits of the same call made alone"""
+    import threading, warnings
+    rng = np.random.default_rng(17)
+    n, p = 500, 2000
+    x = np.asfortranarray(rng.normal(size=(n, p)))
+    y = x[:, :6] @ rng.uniform(0.5, 1.5, 6) + rng.normal(size=n)
+    kw = dict(penalty=["lasso", "mcp"], nlambda=8, tol=1e-7, maxit=300)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        alone = oa.oem(x, y, **kw)
+    out, errs = [None] * 5, []
+
+    def work(i):
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for _ in range(3):
+                    out[i] = oa.oem(x, y, **kw)
+        except Exception as e:                                    # noqa: BLE001 -- reported below
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(5)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for f in out:
+        assert f["d"] == alone["d"]
+        for k in range(2):
+            assert np.array_equal(f["beta"][k], alone["beta"][k]) and np.array_equal(f["niter"][k], alone["niter"][k])
