@@ -211,7 +211,7 @@ __device__ __forceinline__ void wc_allgather_u(double *Ush, double u_own, int my
     const unsigned ep = X.epoch + 1;
     const int off3 = (int)(ep & 1u) * X.qpad * 16;
     if (storer) { wc_publish(X.rs3, off3 + mycol * 16, u_own, ep << 1); Ush[mycol] = u_own; }
-    const int nk = (q + WNTH - 1) / WNTH;                       // <= 16 (q <= 4096)
+    const int nk = (q + WNTH - 1) / WNTH;                       // <= 32 (q <= 8192)
     unsigned miss = 0;
     for (int k = 0; k < nk; ++k) { const int j = tid + WNTH * k; if (j < q && j / cpg != X.wg) miss |= 1u << k; }
     unsigned spins = 0;
@@ -450,11 +450,13 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
     X.rs3 = __builtin_amdgcn_make_buffer_rsrc((void *)(xchg + (size_t)4 * X.stride1 + (size_t)4 * NP), 0, 2 * X.qpad * 16, 0x00020000);
     // general form: u and beta of ALL coordinates, the group tables
     const int ng = GEN ? A.ngroups : 0, qp = (q + 8 + 1) & ~1, ngp = (ng + 2) & ~1;
-    double *Ush = lds + C::N_DBL, *Bsh = Ush + qp, *Pfsh = Bsh + qp, *Fsh = Pfsh + qp, *GWsh = Fsh + ngp;
+    // (beta and the penalty factors of ALL coordinates only where Nesterov's step replicates the operator stage)
+    const int qacc = (GEN && A.accelerate) ? qp : 0;
+    double *Ush = lds + C::N_DBL, *Bsh = Ush + qp, *Pfsh = Bsh + qacc, *Fsh = Pfsh + qacc, *GWsh = Fsh + ngp;
     int *gidL = reinterpret_cast<int *>(GWsh + ngp), *gstartL = gidL + qp, *gidxL = gstartL + ngp + 2, *gzeroL = gidxL + qp;
     int *needL = gzeroL + ngp, *nneedL = needL + qp;             // the columns of other workgroups this one's groups reach into
     if (GEN) {
-        for (int j = tid; j < qp; j += WNTH) { Ush[j] = 0.0; Bsh[j] = 0.0; Pfsh[j] = j < q ? A.pf[j] : 0.0; }
+        for (int j = tid; j < qp; j += WNTH) { Ush[j] = 0.0; if (qacc) { Bsh[j] = 0.0; Pfsh[j] = j < q ? A.pf[j] : 0.0; } }
         for (int j = tid; j < qp; j += WNTH) gidL[j] = (ng > 0 && j < q) ? A.gid[j] : -1;
         if (ng > 0) {
             for (int g = tid; g <= ng; g += WNTH) gstartL[g] = A.gstart[g];
@@ -660,7 +662,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < E2; ++k) if (rowok[k]) Rsh[tid + WNTH * k] = Ysh[tid + WNTH * k];
-        if (GEN) for (int j = tid; j < q; j += WNTH) Bsh[j] = 0.0;
+        if (GEN && qacc) for (int j = tid; j < q; j += WNTH) Bsh[j] = 0.0;
         __syncthreads();
         double lam_next = A.user_lambda ? A.lambda_user[(size_t)pp * nl] : 0.0;
         for (int i = 0; i < nl; ++i) {
@@ -728,7 +730,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
                             {
                                 double xv[8], pv8[8];
 #pragma unroll
-                                for (int t = 0; t < 8; ++t) { xv[t] = Ush[gix[t]]; pv8[t] = sgl ? Pfsh[gix[t]] : 0.0; }
+                                for (int t = 0; t < 8; ++t) { xv[t] = Ush[gix[t]]; pv8[t] = (sgl && gix[t] < q) ? A.pf[gix[t]] : 0.0; }      // (sparse group lasso only: from L2)
 #pragma unroll
                                 for (int t = 0; t < 8; ++t) { const double xs1 = sgl ? soft1(xv[t], pv8[t] * K.L1, 1.0) : xv[t]; s2 += xs1 * xs1; }
                             }
@@ -738,7 +740,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
 #pragma unroll
                                 for (int t = 0; t < 8; ++t) ix[t] = (m + t < gm1) ? gidxL[m + t] : q;
 #pragma unroll
-                                for (int t = 0; t < 8; ++t) { xv[t] = Ush[ix[t]]; pv8[t] = sgl ? Pfsh[ix[t]] : 0.0; }
+                                for (int t = 0; t < 8; ++t) { xv[t] = Ush[ix[t]]; pv8[t] = (sgl && ix[t] < q) ? A.pf[ix[t]] : 0.0; }
 #pragma unroll
                                 for (int t = 0; t < 8; ++t) { const double xs1 = sgl ? soft1(xv[t], pv8[t] * K.L1, 1.0) : xv[t]; s2 += xs1 * xs1; }
                             }
@@ -862,15 +864,15 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
     if (__syncthreads_or(X.failed ? 1 : 0) && tid == 0) A.d_out[6] = 1.0;
 }
 
-static size_t wcoop_gen_lds_doubles(int q, int ng)
+static size_t wcoop_gen_lds_doubles(int q, int ng, bool accelerate)
 {
     const size_t qp = (size_t)((q + 8 + 1) & ~1), ngp = (size_t)((ng + 2) & ~1);
-    return 3 * qp + 2 * ngp + (qp + ngp + 2 + qp + ngp + qp + 2 + 1) / 2 + 2;       // Ush, Bsh, Pf | F, GW | ints: gid, gstart, gidx, gzero, need list + count
+    return (accelerate ? 3 : 1) * qp + 2 * ngp + (qp + ngp + 2 + qp + ngp + qp + 2 + 1) / 2 + 2;       // Ush (, Bsh, Pf) | F, GW | ints: gid, gstart, gidx, gzero, need list + count
 }
 template <int NR, bool GEN> int wcoop_launch_as(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G, int sets, size_t set_stride)
 {
     typedef WCfg<NR> C;
-    const size_t sh = ((size_t)C::N_DBL + (GEN ? wcoop_gen_lds_doubles(a.p, a.ngroups) : 0)) * sizeof(double);
+    const size_t sh = ((size_t)C::N_DBL + (GEN ? wcoop_gen_lds_doubles(a.p, a.ngroups, a.accelerate != 0) : 0)) * sizeof(double);
     if (sh > 64 * 1024 && lds_limit_once(reinterpret_cast<const void *>(&path_wcoop_kernel<NR, GEN>), sh)) return OEMGPU_ERR_HIP;
     hipLaunchKernelGGL((path_wcoop_kernel<NR, GEN>), dim3(G, sets), dim3(WNTH), sh, s, a, wd.xs, wd.ys, wd.n,
                        reinterpret_cast<unsigned long long *>(wd.scratch), (long long)set_stride);
@@ -885,7 +887,7 @@ template <int NR> int wcoop_launch(hipStream_t s, const PathArgs &a, const WideA
 // dynamic LDS of the kernel for this call (bytes)
 template <int NR> size_t wcoop_lds_bytes(const PathArgs &a)
 {
-    return ((size_t)WCfg<NR>::N_DBL + (wcoop_general(a) ? wcoop_gen_lds_doubles(a.p, a.ngroups) : 0)) * sizeof(double);
+    return ((size_t)WCfg<NR>::N_DBL + (wcoop_general(a) ? wcoop_gen_lds_doubles(a.p, a.ngroups, a.accelerate != 0) : 0)) * sizeof(double);
 }
 
 }  // namespace
@@ -943,7 +945,7 @@ bool path_wcoop_eligible(const PathArgs &a, const WideArgs &wd)
     const int G = path_wcoop_workgroups(wd.n, a.p);
     if (G < 1 || G > maxg) return false;
     if (wcoop_general(a)) {                                      // the general form keeps u and beta of all coordinates and the group tables in LDS
-        if (getenv("OEM_WCOOP_NO_GENERAL") || a.p > 4096) return false;
+        if (getenv("OEM_WCOOP_NO_GENERAL") || a.p > 8192) return false;        // (the gather masks hold 32 x 256 columns)
         size_t lds = 0;
         switch (wd.lay.nr) {
         case 1: lds = wcoop_lds_bytes<1>(a); break; case 2: lds = wcoop_lds_bytes<2>(a); break; case 3: lds = wcoop_lds_bytes<3>(a); break;
