@@ -452,7 +452,7 @@ def test_random_wide_cooperating(oa, seed, monkeypatch):
         assert not np.any(np.isinf(np.concatenate([np.ravel(bk) for bk in f["beta"]])))
         return
     _check(f, r, pens, tol=5e-7)
-    assert abs(f["d"] - g["d"]) <= 1e-12 * abs(g["d"])
+    assert abs(f["d"] - g["d"]) <= 1e-10 * abs(g["d"])           # (two Lanczos recurrences with their own start vectors and looks)
     for k in range(len(pens)):
         scale = max(1.0, float(np.abs(np.asarray(g["beta"][k])).max()))
         assert np.abs(np.asarray(f["beta"][k]) - np.asarray(g["beta"][k])).max() <= 1e-8 * scale, pens[k]

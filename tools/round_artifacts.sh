@@ -48,6 +48,16 @@ if [ -z "$quick" ]; then
   python3 tools/pmc_summary.py "wide_cols_kernel<8, 1>" $o/${tag}_wide_pmc_cols.json "$(find $o/${tag}_wide_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_wide_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
   python3 tools/wide_time.py > $o/${tag}_wide_times.txt 2>&1
   python3 tools/config_times.py > $o/${tag}_config_times.json 2> $o/${tag}_config_times.err
+  # ---- the cooperating engines: p >= n in registers (element-wise and general form), 208 < p <= 1024, and what an exchange costs
+  python3 tools/wcoop_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_wcoop_times.txt
+  python3 tools/wcoop_general_time.py 2>&1 | grep -v amdgpu.ids >> $o/${tag}_wcoop_times.txt
+  if [ -f oem_amd/liboemgpu_diag.so ]; then
+    OEMGPU_LIB=oem_amd/liboemgpu_diag.so python3 tools/wcoop_diag.py 500 2000 2>&1 | grep -v "amdgpu.ids\|warn" >> $o/${tag}_wcoop_times.txt
+    OEMGPU_LIB=oem_amd/liboemgpu_diag.so python3 tools/wcoop_diag.py 500 2000 30 gen 2>&1 | grep -v "amdgpu.ids\|warn" >> $o/${tag}_wcoop_times.txt
+  fi
+  python3 tools/coop_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_coop_times.txt
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/hop_probe tools/hop_probe.hip 2> /dev/null && /tmp/hop_probe > $o/${tag}_exchange_probes.txt 2>&1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/xchg_probe tools/xchg_probe.hip 2> /dev/null && /tmp/xchg_probe >> $o/${tag}_exchange_probes.txt 2>&1
 fi
 # the raw traces stay on the box: gpurun copies back at most 64 MiB
 for d in $o/${tag}_trace $o/${tag}_pmc_fetch $o/${tag}_pmc_write $o/${tag}_pmc_mfma $o/${tag}_*_pmc_mfma $o/${tag}_*_trace $o/${tag}_*_pmc_FETCH_SIZE $o/${tag}_*_pmc_WRITE_SIZE; do [ -d "$d" ] && rm -rf "$d"; done

@@ -6,6 +6,9 @@
 //        1  the same, one sweep in flight
 //        2  one 16-byte store / load per row (buffer_*_dwordx4 sc1), three sweeps in flight
 //        3  the same, one sweep in flight
+//        5 / 6  as 3, the first sweep delayed by s_sleep 6 / 12 (384 / 768 cycles): polls issued before anything can have landed are
+//           wasted traffic, and the one in flight when the data lands costs a whole round trip (measured: 0-8 % in this symmetric
+//           loop; NOT adopted in the engines -- there a workgroup that arrives late would sleep on everybody's critical path)
 //        4  16-byte rows + a compact flag word per workgroup (stored after its rows): poll the G flags, then read the rows once
 //           (every row still validated by its own tags, re-read if a flag overtook it)
 #include <hip/hip_runtime.h>
@@ -56,6 +59,8 @@ __global__ __launch_bounds__(NTH) void allgather(unsigned long long *buf, unsign
         }
         // gather
         constexpr int NS = (MODE == 0 || MODE == 2) ? 3 : 1;
+        if (MODE == 5) __builtin_amdgcn_s_sleep(6);
+        if (MODE == 6) __builtin_amdgcn_s_sleep(12);
         v4u pv[NS][EPT];
         auto issue = [&](int s) {
 #pragma unroll
@@ -125,7 +130,7 @@ int main()
     for (int N : {512, 128})
         for (int G : gs) {
             run<0>(buf, flags, out, G, N, 1); run<1>(buf, flags, out, G, N, 1); run<2>(buf, flags, out, G, N, 1);
-            run<3>(buf, flags, out, G, N, 1); run<4>(buf, flags, out, G, N, 1);
+            run<3>(buf, flags, out, G, N, 1); run<5>(buf, flags, out, G, N, 1); run<6>(buf, flags, out, G, N, 1); run<4>(buf, flags, out, G, N, 1);
             if (G <= 32) { run<0>(buf, flags, out, G, N, 8); run<2>(buf, flags, out, G, N, 8); }
         }
     return 0;
