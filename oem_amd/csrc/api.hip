@@ -682,7 +682,12 @@ static bool wide_pays(int64_t n, int32_t p)
     if (n > p || n > WIDE_MAX_N) return false;
     if (getenv("OEM_NO_WIDE")) return false;
     if (getenv("OEM_WIDE")) return true;
-    return p > 1024 && 2 * n < p;
+    if (p <= 1024) return false;                  // (the register engines run the Gram form at 1-3 us per iteration)
+    if (2 * n < p) return true;
+    // n <= p < 2n: the Gram is the smaller matrix, but where Xs fits the registers of the cooperating engine (path_wcoop.hip) that one
+    // launch beats the launch-per-iteration Gram engines (n = 900, p = 1500: 5.6 against 11.6 us per iteration)
+    const int g = path_wcoop_workgroups((int)n, p);
+    return n <= 1024 && g >= 1 && g <= WCOOP_GMAX && !getenv("OEM_NO_WCOOP");
 }
 
 static int fit_dense_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
