@@ -149,15 +149,15 @@ def build(force=False, verbose=False):
                     print(" ".join(cmd))
                 jobs.append(ex.submit(subprocess.run, cmd, check=True))
             objs.append(str(o))
-        # ISA audits: asm-owned accumulators (gram.hip), DPP hazards of the inline-asm FMAs (path_small.hip)
+        # ISA audits: asm-owned accumulators (gram.hip), DPP hazards of the inline-asm FMAs (the register-resident path engines)
         listing = {src: ex.submit(subprocess.run, [hipcc, *FLAGS, "-S", "--cuda-device-only", "-o", "-", str(CSRC / src)],
-                                  check=True, capture_output=True, text=True) for src in ("gram.hip", "path_small.hip", "path_coop.hip")}
+                                  check=True, capture_output=True, text=True) for src in ("gram.hip", "path_small.hip", "path_coop.hip", "path_wcoop.hip")}
         for j in jobs:
             j.result()
         problems = audit_gram_isa(listing["gram.hip"].result().stdout)
         if problems:
             raise RuntimeError("gram.hip ISA audit failed:\n  " + "\n  ".join(problems[:20]))
-        for src in ("path_small.hip", "path_coop.hip"):
+        for src in ("path_small.hip", "path_coop.hip", "path_wcoop.hip"):
             problems = audit_dpp_hazards(listing[src].result().stdout)
             if problems:
                 raise RuntimeError(src + " ISA audit failed:\n  " + "\n  ".join(problems[:20]))
