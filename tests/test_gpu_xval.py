@@ -128,6 +128,28 @@ def test_kat5_cv_oem_doc_example(oa):
     assert mse == ["9.091859", "9.091859", "9.099376"]
 
 
+@pytest.mark.parametrize("n,p", [(5000, 40), (300, 1500)])
+def test_cv_oem_folds_from_several_threads(oa, n, p):
+    """cv.oem(parallel = TRUE) (R/cv_oem.R:129-150): the fold fits from three host threads at once -- n >> p fits overlap their
+    one-CU path kernels with other folds' moment kernels, p >= n fits run side by side on the cooperating-workgroup engine --
+    with the results of the sequential loop, bit for bit."""
+    import time, warnings
+    rng = np.random.default_rng(77 + p)
+    x = np.asfortranarray(rng.normal(size=(n, p)))
+    y = x[:, :5] @ rng.uniform(0.5, 1.5, 5) + rng.normal(size=n)
+    foldid = rng.permutation(np.resize(np.arange(1, 7), n))
+    kw = dict(penalty=["lasso", "mcp"], nlambda=12, tol=1e-7, foldid=foldid)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        oa.cv_oem(x, y, **kw)                                     # (contexts and staging buffers exist from here on)
+        t0 = time.perf_counter(); a = oa.cv_oem(x, y, **kw); ta = time.perf_counter() - t0
+        t0 = time.perf_counter(); b = oa.cv_oem(x, y, parallel=True, **kw); tb = time.perf_counter() - t0
+    print(f"cv.oem n={n} p={p}, 6 folds: sequential {1e3 * ta:.1f} ms, three threads {1e3 * tb:.1f} ms")
+    for m in range(2):
+        assert np.array_equal(a["cvm"][m], b["cvm"][m]) and np.array_equal(a["cvsd"][m], b["cvsd"][m])
+    assert a["lambda.min"] == b["lambda.min"] and a["best.model"] == b["best.model"]
+
+
 def test_many_small_folds_and_an_empty_one(oa):
     """37 folds of ~54 rows (one of them empty: its id never occurs), n not a multiple of anything."""
     rng = np.random.default_rng(15)
