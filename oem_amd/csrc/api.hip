@@ -384,7 +384,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     }
     CoopSlots slots;                                  // held until the stream has been synchronised below
     if (coop) slots.take(c->device, path_coop_workgroups(q) * (pen_split ? npen : 1) * nbatch, c->num_cu * 3 / 4);
-    // p >= n with Xs small enough for the register files of <= 128 CUs: one persistent launch (path_wcoop.hip)
+    // p >= n with Xs small enough for the register files of <= 192 CUs: one persistent launch (path_wcoop.hip)
     // (all of a set's workgroups must be resident at once: never more of them than three quarters of this device's CUs)
     const bool wcoop = wide && path_wcoop_eligible(a, *wide) && path_wcoop_workgroups(wide->n, q) <= c->num_cu * 3 / 4;
     const int wsets = wcoop ? path_wcoop_sets(wide->n, q, npen, c->num_cu) : 1;

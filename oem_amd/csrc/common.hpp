@@ -191,8 +191,8 @@ int launch_wide_standardize(hipStream_t s, const double *x, int64_t n, int64_t l
                             const WideLayout &lay, double *xs, double *ys, double *xy, double *stats);
 int run_path_wide(hipStream_t s, const PathArgs &a, const WideArgs &w, double *host_scratch);
 // the same iteration as ONE persistent launch of cooperating workgroups with Xs in registers (path_wcoop.hip): element-wise
-// penalties, one row block, p <= 4 CW WCOOP_GMAX columns (CW = 16 / 8 / 4 / 2 by column height)
-static const int WCOOP_GMAX = 128, WCOOP_MAX_SETS = 8;
+// penalties, one row block, p <= 4 CW WCOOP_GMAX columns (CW = 16 / 8 / 4 by column height); WCOOP_GMAX = three quarters of the CUs
+static const int WCOOP_GMAX = 192, WCOOP_MAX_SETS = 8;
 int path_wcoop_workgroups(int n, int p);
 int path_wcoop_sets(int n, int p, int npen, int num_cu);         // workgroup sets side by side, one penalty each
 size_t path_wcoop_xchg_doubles(int n, int p);

@@ -1,4 +1,4 @@
-// path_wcoop.hip -- p >= n where the standardised X fits the register files of <= 128 CUs: eigenvalue + penalty x lambda path in
+// path_wcoop.hip -- p >= n where the standardised X fits the register files of <= 192 CUs: eigenvalue + penalty x lambda path in
 // ONE persistent launch of cooperating workgroups (n = 500, p = 2,000: 14,009 iterations at two launches = 11.3 us each were the
 // whole 158 ms of the launch-per-iteration wide engine, path_large.hip: run_path_wide, on 8 MB of data).
 //

@@ -429,7 +429,7 @@ def test_random_wide_cooperating(oa, seed, monkeypatch):
     monkeypatch.setenv("OEM_WIDE", "1")
     rng = np.random.default_rng(7700 + seed)
     n = int(rng.choice([1, 2, 7, 33, 64, 65, 100, 129, 192, 193, 250, 300, 385, 450, 520, 769, 900, 1024]))
-    cap = {1: 16, 2: 16, 3: 16, 4: 16, 6: 8, 8: 8, 12: 4, 16: 4}[[v for v in (1, 2, 3, 4, 6, 8, 12, 16) if 64 * v >= n][0]] * 4 * 128
+    cap = {1: 16, 2: 16, 3: 16, 4: 16, 6: 8, 8: 8, 12: 4, 16: 4}[[v for v in (1, 2, 3, 4, 6, 8, 12, 16) if 64 * v >= n][0]] * 4 * 192
     p = int(min(cap, n + rng.integers(0, max(2, min(4 * n + 200, 400_000 // max(n, 1))))))
     p = max(p, 2)
     x = np.asfortranarray(rng.normal(size=(n, p)) * rng.uniform(0.5, 3.0) + rng.uniform(-1, 1))

@@ -461,10 +461,10 @@ def test_wide_engine(oa, n, p, flag, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,p", [(3, 5), (30, 40), (64, 1100), (100, 1500), (130, 2100), (190, 700), (256, 3000), (300, 1300), (384, 900),
-                                 (500, 2000), (513, 1100), (700, 1410), (1000, 1000), (1024, 2048), (200, 5000)])
+                                 (500, 2000), (513, 1100), (700, 1410), (1000, 1000), (1024, 2048), (200, 5000), (100, 9000)])
 def test_wide_cooperating_engine(oa, n, p, monkeypatch):
     """p >= n as ONE persistent launch of cooperating workgroups with the standardised X in registers (path_wcoop.hip): every column
-    height (1 .. 16 registers per column and lane, 16 .. 4 columns per wave), one workgroup up to 128, all-reduce slices that are
+    height (1 .. 16 registers per column and lane, 16 .. 4 columns per wave), one workgroup up to 141 (the engine takes up to 192), all-reduce slices that are
     ragged or empty, the element-wise operators with penalty factors, maxit reached, user lambdas, OLS, several penalties side by
     side in workgroup sets of their own -- against the oracle's restatement of the branch, and against the launch-per-iteration
     engine (OEM_NO_WCOOP=1), which must agree to rounding with the same iteration counts."""
