@@ -26,9 +26,9 @@
 //     decision and the lambda / penalty state machine runs replicated, with no flag or scalar of its own crossing workgroups.
 //   * the eigenvalue step is Lanczos on n-vectors with the same registers and the same all-reduce (vector updates and both inner
 //     products replicated per workgroup), the top Ritz value by the Sturm multisection of path_dev.hpp.
-// Element-wise operators as above; group operators with ONE more exchange (u of the members of a workgroup's own groups); Nesterov's
-// step with u all-gathered and the operator stage replicated (template parameter GEN); compute.loss is the squared norm of the
-// residual every workgroup holds.  Every spin is bounded; a timeout poisons the result (d_out[6]) and the host reports it.
+// Element-wise operators as above; group operators with ONE more exchange (u of the members of a workgroup's own groups; template
+// parameter GEN); Nesterov's step with its inner product summed over the workgroups next to the all-reduce; compute.loss is the
+// squared norm of the residual every workgroup holds.  Every spin is bounded; a timeout poisons the result (d_out[6]) and the host reports it.
 #include <cstdlib>
 #include <type_traits>
 
@@ -87,7 +87,8 @@ struct WX {
     unsigned long long acc[16], last;
 #endif
     __amdgpu_buffer_rsrc_t rs1, rs2;   // exchange 1: [2 parities][G owners][G senders][SL] pairs of 16 bytes; exchange 2: [2 parities][NP] pairs
-    __amdgpu_buffer_rsrc_t rs3;        // general form: the all-gather of u, [2 parities][qpad] pairs
+    __amdgpu_buffer_rsrc_t rs3;        // group operators: the exchange of u, [2 parities][qpad] pairs
+    __amdgpu_buffer_rsrc_t rs4;        // Nesterov's step: the workgroups' parts of its inner product, [2 parities][G] pairs
     int qpad;
     unsigned epoch;               // all-reduce counter, never 0; identical in every workgroup
     int wg, G, SL, n, row0, nsl;  // this workgroup's slice: rows [row0, row0 + nsl)
@@ -204,50 +205,10 @@ __device__ __forceinline__ void wc_publish(__amdgpu_buffer_rsrc_t rs, int off, d
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
 }
 
-// General form (group operators, Nesterov's step): all-gather of u, one value per column.  In: the column owners' values (one lane
-// per column: `storer`).  Out: Ush[j] for every j < q, behind a barrier.  Tagged with the epoch of the all-reduce that follows.
-__device__ __forceinline__ void wc_allgather_u(double *Ush, double u_own, int mycol, bool storer, int q, int cpg, WX &X, int tid)
-{
-    const unsigned ep = X.epoch + 1;
-    const int off3 = (int)(ep & 1u) * X.qpad * 16;
-    if (storer) { wc_publish(X.rs3, off3 + mycol * 16, u_own, ep << 1); Ush[mycol] = u_own; }
-    const int nk = (q + WNTH - 1) / WNTH;                       // <= 32 (q <= 8192)
-    unsigned miss = 0;
-    for (int k = 0; k < nk; ++k) { const int j = tid + WNTH * k; if (j < q && j / cpg != X.wg) miss |= 1u << k; }
-    unsigned spins = 0;
-    const unsigned limit = X.failed ? 0u : 1000000u;
-    // first only ONE value per thread (a sweep of everything is q / 8 cache lines per workgroup: while nothing has landed yet the
-    // sweeps of 63 workgroups are most of the fabric's traffic); when that one is there the rest has mostly landed too
-    while (__any((miss & 1u) != 0u)) {
-        wc_v4u pv = wc_v4u{0u, 0u, 0u, 0u};
-        if (miss & 1u) pv = __builtin_amdgcn_raw_buffer_load_b128(X.rs3, off3 + tid * 16, 0, 16);
-        if ((miss & 1u) && (pv.y >> 1) == ep && (pv.w >> 1) == ep) { Ush[tid] = __hiloint2double((int)pv.z, (int)pv.x); miss &= ~1u; }
-        if (++spins >= limit && __any((miss & 1u) != 0u)) { X.failed = true; break; }
-    }
-    while (!X.failed && __any(miss != 0u)) {
-        for (int k0 = 0; k0 < nk; k0 += 8) {
-            wc_v4u pv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                pv[i] = wc_v4u{0u, 0u, 0u, 0u};
-                if ((miss >> (k0 + i)) & 1u) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(X.rs3, off3 + (tid + WNTH * (k0 + i)) * 16, 0, 16);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (((miss >> (k0 + i)) & 1u) && (pv[i].y >> 1) == ep && (pv[i].w >> 1) == ep) {
-                    Ush[tid + WNTH * (k0 + i)] = __hiloint2double((int)pv[i].z, (int)pv[i].x);
-                    miss &= ~(1u << (k0 + i));
-                }
-        }
-        if (++spins >= limit && __any(miss != 0u)) { X.failed = true; break; }
-    }
-    for (int k = 0; k < nk; ++k) if ((miss >> k) & 1u) Ush[tid + WNTH * k] = 0.0;        // (timed out: poisoned anyway)
-    __syncthreads();
-}
-
-// The same for the columns on a list (group operators without Nesterov's step: a workgroup only needs u of the members of its own
-// columns' groups -- with groups of neighbouring columns a handful of values from the next workgroup, or none).  Everybody still
-// publishes all its columns.
+// Group operators: exchange of u, one value per column.  A workgroup only needs u of the members of its own columns' groups: the
+// columns on `list` (with groups of neighbouring columns a handful of values from the next workgroup, or none).  In: the column
+// owners' values (one lane per column: `storer`); everybody publishes all its columns.  Out: Ush[j] for the own columns and the
+// listed ones, behind a barrier.  Tagged with the epoch of the all-reduce that follows.
 __device__ __forceinline__ void wc_gather_u_list(double *Ush, double u_own, int mycol, bool storer, const int *list, int nlist, WX &X, int tid)
 {
     const unsigned ep = X.epoch + 1;
@@ -281,6 +242,32 @@ __device__ __forceinline__ void wc_gather_u_list(double *Ush, double u_own, int 
         if (++spins >= limit && __any(miss != 0u)) { X.failed = true; break; }
     }
     __syncthreads();
+}
+
+// Nesterov's step (ref src/oem_dense.h:633-651) restarts its sequence when sum_j (beta_j+ - beta_j')(beta_j' - beta_j) > 0 -- a sum over
+// ALL coordinates.  Every workgroup publishes its part next to exchange 1 of the all-reduce (wc_adp_publish) and reads the G parts
+// back after it (wc_adp_total: they landed a hop ago), adding them in workgroup order: the same bits everywhere.
+__device__ __forceinline__ void wc_adp_publish(double part, WX &X, int tid)
+{
+    const unsigned ep = X.epoch + 1;
+    if (tid == 0) wc_publish(X.rs4, ((int)(ep & 1u) * X.G + X.wg) * 16, part, ep << 1);
+}
+__device__ __forceinline__ double wc_adp_total(double own, double *red, int &rpar, WX &X, int tid, int w, int lane)
+{
+    const unsigned ep = X.epoch;                                 // (the all-reduce in between has counted)
+    const int off4 = (int)(ep & 1u) * X.G * 16;
+    const bool mine = tid < X.G && tid != X.wg;
+    double v = (tid == X.wg) ? own : 0.0;
+    unsigned spins = 0;
+    const unsigned limit = X.failed ? 0u : 1000000u;
+    bool miss = mine;
+    while (__any(miss)) {
+        wc_v4u pv = wc_v4u{0u, 0u, 0u, 0u};
+        if (miss) pv = __builtin_amdgcn_raw_buffer_load_b128(X.rs4, off4 + tid * 16, 0, 16);
+        if (miss && (pv.y >> 1) == ep && (pv.w >> 1) == ep) { v = __hiloint2double((int)pv.z, (int)pv.x); miss = false; }
+        if (++spins >= limit && __any(miss)) { X.failed = true; break; }
+    }
+    return wc_block_sum(v, red, rpar, w, lane);                  // thread t holds workgroup t's part: a fixed order
 }
 
 // OR of one bit per thread over the workgroup through four LDS words and ONE barrier (the caller's: `words` is read behind it)
@@ -397,10 +384,8 @@ __device__ __forceinline__ double wc_op(double u, double tp, const WThr &c)
     return cdiv(u, c.d, c.rd);
 }
 
-// GEN: the general form -- everything that needs the whole of u at once (group operators, Nesterov's step).  One more exchange per
-// iteration: u is all-gathered (one value per column), every workgroup then runs the WHOLE operator stage itself on all q
-// coordinates with identical arithmetic (group norms, factors, Nesterov's extrapolation, stop rule: path_coop.hip's way), and picks
-// the coefficients of its own columns for the update product.  beta of all coordinates lives in LDS.
+// GEN: a group penalty in the call.  A group's norm needs u of all its members: one more exchange per iteration, of the members of this
+// workgroup's own groups (wc_gather_u_list); every lane then forms the factor of its column's group.  The group tables live in LDS.
 template <int NR, bool GEN>
 __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const double *__restrict__ xs, const double *__restrict__ ysv, int n,
                                                            unsigned long long *xchg, long long set_stride)
@@ -448,15 +433,14 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
     X.rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)(xchg + (size_t)4 * X.stride1), 0, 2 * NP * 16, 0x00020000);
     X.qpad = G * C::CPG;
     X.rs3 = __builtin_amdgcn_make_buffer_rsrc((void *)(xchg + (size_t)4 * X.stride1 + (size_t)4 * NP), 0, 2 * X.qpad * 16, 0x00020000);
-    // general form: u and beta of ALL coordinates, the group tables
+    X.rs4 = __builtin_amdgcn_make_buffer_rsrc((void *)(xchg + (size_t)4 * X.stride1 + (size_t)4 * NP + (size_t)4 * X.qpad), 0, 2 * G * 16, 0x00020000);
+    // group operators: u of the columns this workgroup's groups touch (indexed by column), the group tables
     const int ng = GEN ? A.ngroups : 0, qp = (q + 8 + 1) & ~1, ngp = (ng + 2) & ~1;
-    // (beta and the penalty factors of ALL coordinates only where Nesterov's step replicates the operator stage)
-    const int qacc = (GEN && A.accelerate) ? qp : 0;
-    double *Ush = lds + C::N_DBL, *Bsh = Ush + qp, *Pfsh = Bsh + qacc, *Fsh = Pfsh + qacc, *GWsh = Fsh + ngp;
+    double *Ush = lds + C::N_DBL, *GWsh = Ush + qp;
     int *gidL = reinterpret_cast<int *>(GWsh + ngp), *gstartL = gidL + qp, *gidxL = gstartL + ngp + 2, *gzeroL = gidxL + qp;
     int *needL = gzeroL + ngp, *nneedL = needL + qp;             // the columns of other workgroups this one's groups reach into
     if (GEN) {
-        for (int j = tid; j < qp; j += WNTH) { Ush[j] = 0.0; if (qacc) { Bsh[j] = 0.0; Pfsh[j] = j < q ? A.pf[j] : 0.0; } }
+        for (int j = tid; j < qp; j += WNTH) Ush[j] = 0.0;
         for (int j = tid; j < qp; j += WNTH) gidL[j] = (ng > 0 && j < q) ? A.gid[j] : -1;
         if (ng > 0) {
             for (int g = tid; g <= ng; g += WNTH) gstartL[g] = A.gstart[g];
@@ -662,7 +646,6 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < E2; ++k) if (rowok[k]) Rsh[tid + WNTH * k] = Ysh[tid + WNTH * k];
-        if (GEN && qacc) for (int j = tid; j < q; j += WNTH) Bsh[j] = 0.0;
         __syncthreads();
         double lam_next = A.user_lambda ? A.lambda_user[(size_t)pp * nl] : 0.0;
         for (int i = 0; i < nl; ++i) {
@@ -686,7 +669,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
             const double tp = pfj * K.L;
             int it = 0;
             for (;;) {
-                int any;
+                int any = 0;
                 const bool grp = GEN && K.kind >= K_GRP;
                 // 1 - pen / ||u_g|| etc. from the squared norm of a group (ref src/oem_dense.h:193-315; quirk Q6: ||u_g|| = 0 => 0)
                 auto group_factor = [&](double s2, double pen_g) {
@@ -699,10 +682,18 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
                     const double nrm = sqrt(s2);
                     return (K.kind == K_GRP_MCP) ? mcp_norm(nrm, pen_g, K.D, K.gamma) : scad_norm(nrm, pen_g, K.D, K.gamma);
                 };
-                auto elementwise_iteration = [&]() __attribute__((always_inline)) {
-                    const double dot = col_dots();
-                    const double u = dot * rn + d * bcur;            // ref src/oem_dense.h:520: X'(Y - X beta)/n + d beta
-                    const double b = colok ? wc_op(u, tp, c) : 0.0;
+                // Nesterov's step (ref src/oem_dense.h:633-651): beta+ = beta' + ratio (beta' - beta), its inner product summed over all
+                // workgroups next to the all-reduce; the stop rule looks at beta+ against beta
+                const bool acc = A.accelerate != 0;
+                const double akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak)), ratio = (ak - 1.0) / akn;
+                auto finish_iteration = [&](double upd) __attribute__((always_inline)) {
+                    double b = upd, part = 0.0;
+                    if (acc) {
+                        const double diff = upd - bcur;
+                        b = upd + ratio * diff;
+                        part = wc_block_sum(storer ? (b - upd) * diff : 0.0, red, rpar, w, lane);
+                        wc_adp_publish(part, X, tid);
+                    }
                     const double cu = fabs(b), qo = fabs(bcur);
                     const bool cn = cu > 1e-13, qn = qo > 1e-13;      // ref src/utils.cpp:537-549
                     const bool moving = (cn != qn) || (cn && qn && fabs(b - bcur) > A.tol * qo);
@@ -710,11 +701,15 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
                     WC_STAMP(12);                                    // operator, stop rule
                     col_update(b);
                     // r' = Ys - Xs beta': the next iteration's input, or the warm start of the next lambda
-                    return wc_allreduce<NR, true>(Rsh, Ysh, Pc, Gsh, votes, pub, need1, need2, rn, moving ? 1 : 0, X, tid, w, lane);
+                    const int mv = wc_allreduce<NR, true>(Rsh, Ysh, Pc, Gsh, votes, pub, need1, need2, rn, moving ? 1 : 0, X, tid, w, lane);
+                    if (acc) ak = (wc_adp_total(part, red, rpar, X, tid, w, lane) > 0.0) ? 1.0 : akn;
+                    return mv;
                 };
-                if constexpr (!GEN) any = elementwise_iteration();
-                else if (!grp && !A.accelerate) any = elementwise_iteration();
-                else if (!A.accelerate) {
+                if (!grp) {
+                    const double dot = col_dots();
+                    const double u = dot * rn + d * bcur;            // ref src/oem_dense.h:520: X'(Y - X beta)/n + d beta
+                    any = finish_iteration(colok ? wc_op(u, tp, c) : 0.0);
+                } else if constexpr (GEN) {
                     // ---- a group operator: u of the members of this workgroup's groups (its own columns, and what the list names),
                     // then every lane forms the factor of ITS column's group and the coefficient of its column
                     const double dot = col_dots();
@@ -749,91 +744,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
                     }
                     WC_STAMP(15);                                    // group norm and factor
                     const double us = sgl ? soft1(uo, pfj * K.L1, 1.0) : uo;
-                    const double b = (colok && f != 0.0) ? cdiv(us * f, K.D, c.rD) : 0.0;
-                    const double cu = fabs(b), qo = fabs(bcur);
-                    const bool cn = cu > 1e-13, qn = qo > 1e-13;      // ref src/utils.cpp:537-549
-                    const bool moving = (cn != qn) || (cn && qn && fabs(b - bcur) > A.tol * qo);
-                    bcur = b;
-                    WC_STAMP(12);
-                    col_update(b);
-                    any = wc_allreduce<NR, true>(Rsh, Ysh, Pc, Gsh, votes, pub, need1, need2, rn, moving ? 1 : 0, X, tid, w, lane);
-                } else {
-                    // ---- Nesterov's step needs every coordinate's move (a global inner product): u of everybody, then the operator stage
-                    // on ALL coordinates, identically in every workgroup (path_large.hip: path_update has the same)
-                    const double dot = col_dots();
-                    const double uo = colok ? dot * rn + d * Bsh[colok ? mycol : 0] : 0.0;
-                    wc_allgather_u(Ush, uo, mycol, storer, q, C::CPG, X, tid);
-                    WC_STAMP(14);                                    // all-gather of u
-                    if (grp) {
-                        if (K.kind == K_SGL) {                       // sparse group lasso: the soft-thresholded u feeds the norms
-                            for (int j = tid; j < q; j += WNTH) Ush[j] = soft1(Ush[j], Pfsh[j] * K.L1, 1.0);
-                            __syncthreads();
-                        }
-                        for (int gi = tid; gi < ng; gi += WNTH) {
-                            double f = 1.0;
-                            if (!gzeroL[gi]) {
-                                double s2 = 0.0;                     // summed in member order like the reference; eight members per trip:
-                                const int m1 = gstartL[gi + 1];      // the index reads together, then the values (two LDS latencies, not sixteen)
-                                for (int m = gstartL[gi]; m < m1; m += 8) {
-                                    int ix[8];
-                                    double xv[8];
-#pragma unroll
-                                    for (int t = 0; t < 8; ++t) ix[t] = (m + t < m1) ? gidxL[m + t] : q;      // Ush[q]: a zero word
-#pragma unroll
-                                    for (int t = 0; t < 8; ++t) xv[t] = Ush[ix[t]];
-#pragma unroll
-                                    for (int t = 0; t < 8; ++t) s2 += xv[t] * xv[t];
-                                }
-                                f = group_factor(s2, K.L * GWsh[gi]);
-                            }
-                            Fsh[gi] = f;
-                        }
-                        __syncthreads();
-                    }
-                    WC_STAMP(15);                                    // group norms and factors
-                    bool bad = false;
-                    double adp = 0.0;
-                    const double akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak)), ratio = (ak - 1.0) / akn;
-                    for (int j0 = tid; j0 < q; j0 += 4 * WNTH) {        // four coordinates per trip: their LDS reads together
-                        double uo4[4], bo4[4], pf4[4], f4[4];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int j = j0 + WNTH * t, jj = j < q ? j : q;        // (slot q: zero words)
-                            uo4[t] = Ush[jj]; bo4[t] = Bsh[jj]; pf4[t] = Pfsh[jj];
-                            const int gi = grp ? gidL[jj] : -1;
-                            f4[t] = gi >= 0 ? Fsh[gi] : 0.0;
-                        }
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int j = j0 + WNTH * t;
-                            const double bo = bo4[t];
-                            double bnj;
-                            if (grp) bnj = (f4[t] != 0.0) ? cdiv(uo4[t] * f4[t], K.D, c.rD) : 0.0;
-                            else bnj = wc_op(uo4[t], pf4[t] * K.L, c);
-                            if (A.accelerate) {
-                                const double upd = bnj, diff = upd - bo;
-                                bnj = upd + ratio * diff;
-                                adp += (bnj - upd) * diff;
-                            }
-                            const double cu = fabs(bnj), qo = fabs(bo);
-                            const bool cn = cu > 1e-13, qn = qo > 1e-13;  // ref src/utils.cpp:537-549
-                            if (j < q) {
-                                bad |= (cn != qn) || (cn && qn && fabs(bnj - bo) > A.tol * qo);
-                                Bsh[j] = bnj;
-                            }
-                        }
-                    }
-                    if (A.accelerate) {
-                        adp = wc_block_sum(adp, red, rpar, w, lane);
-                        ak = (adp > 0.0) ? 1.0 : akn;
-                    }
-                    wc_vote(votes + 12, w, lane, bad ? 1 : 0);
-                    __syncthreads();                                 // beta of every coordinate is in place, and the votes
-                    any = votes[12] | votes[13] | votes[14] | votes[15];
-                    bcur = colok ? Bsh[mycol] : 0.0;
-                    WC_STAMP(12);
-                    col_update(bcur);
-                    (void)wc_allreduce<NR, true>(Rsh, Ysh, Pc, Gsh, votes, pub, need1, need2, rn, 0, X, tid, w, lane);
+                    any = finish_iteration((colok && f != 0.0) ? cdiv(us * f, K.D, c.rD) : 0.0);
                 }
                 ++it;
                 const bool conv = !any;
@@ -864,22 +775,22 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
     if (__syncthreads_or(X.failed ? 1 : 0) && tid == 0) A.d_out[6] = 1.0;
 }
 
-static size_t wcoop_gen_lds_doubles(int q, int ng, bool accelerate)
+static size_t wcoop_gen_lds_doubles(int q, int ng)
 {
     const size_t qp = (size_t)((q + 8 + 1) & ~1), ngp = (size_t)((ng + 2) & ~1);
-    return (accelerate ? 3 : 1) * qp + 2 * ngp + (qp + ngp + 2 + qp + ngp + qp + 2 + 1) / 2 + 2;       // Ush (, Bsh, Pf) | F, GW | ints: gid, gstart, gidx, gzero, need list + count
+    return qp + ngp + (qp + ngp + 2 + qp + ngp + qp + 2 + 1) / 2 + 2;       // Ush | GW | ints: gid, gstart, gidx, gzero, need list + count
 }
 template <int NR, bool GEN> int wcoop_launch_as(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G, int sets, size_t set_stride)
 {
     typedef WCfg<NR> C;
-    const size_t sh = ((size_t)C::N_DBL + (GEN ? wcoop_gen_lds_doubles(a.p, a.ngroups, a.accelerate != 0) : 0)) * sizeof(double);
+    const size_t sh = ((size_t)C::N_DBL + (GEN ? wcoop_gen_lds_doubles(a.p, a.ngroups) : 0)) * sizeof(double);
     if (sh > 64 * 1024 && lds_limit_once(reinterpret_cast<const void *>(&path_wcoop_kernel<NR, GEN>), sh)) return OEMGPU_ERR_HIP;
     hipLaunchKernelGGL((path_wcoop_kernel<NR, GEN>), dim3(G, sets), dim3(WNTH), sh, s, a, wd.xs, wd.ys, wd.n,
                        reinterpret_cast<unsigned long long *>(wd.scratch), (long long)set_stride);
     OEM_HIP(hipGetLastError());
     return 0;
 }
-static bool wcoop_general(const PathArgs &a) { return a.ngroups != 0 || a.accelerate != 0; }
+static bool wcoop_general(const PathArgs &a) { return a.ngroups != 0; }
 template <int NR> int wcoop_launch(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G, int sets, size_t set_stride)
 {
     return wcoop_general(a) ? wcoop_launch_as<NR, true>(s, a, wd, G, sets, set_stride) : wcoop_launch_as<NR, false>(s, a, wd, G, sets, set_stride);
@@ -887,7 +798,7 @@ template <int NR> int wcoop_launch(hipStream_t s, const PathArgs &a, const WideA
 // dynamic LDS of the kernel for this call (bytes)
 template <int NR> size_t wcoop_lds_bytes(const PathArgs &a)
 {
-    return ((size_t)WCfg<NR>::N_DBL + (wcoop_general(a) ? wcoop_gen_lds_doubles(a.p, a.ngroups, a.accelerate != 0) : 0)) * sizeof(double);
+    return ((size_t)WCfg<NR>::N_DBL + (wcoop_general(a) ? wcoop_gen_lds_doubles(a.p, a.ngroups) : 0)) * sizeof(double);
 }
 
 }  // namespace
@@ -913,7 +824,7 @@ static size_t wcoop_set_doubles(int n, int p)
     if (G < 1 || G > WCOOP_GMAX) return 0;
     const WideLayout L = wide_layout(n);
     const size_t SL = ((size_t)n + G - 1) / G;
-    return 2 * ((size_t)G * G * SL * 2) + 2 * ((size_t)L.npad() * 2) + 2 * ((size_t)G * 4 * wc_cw(L.nr) * 2) + 64;
+    return 2 * ((size_t)G * G * SL * 2) + 2 * ((size_t)L.npad() * 2) + 2 * ((size_t)G * 4 * wc_cw(L.nr) * 2) + 2 * ((size_t)G * 2) + 64;
 }
 // workgroup sets (one per penalty) that may run side by side: all of them resident at once, on three quarters of the CUs at most
 int path_wcoop_sets(int n, int p, int npen, int num_cu)
@@ -944,8 +855,9 @@ bool path_wcoop_eligible(const PathArgs &a, const WideArgs &wd)
     if (a.sinv || a.nbatch > 1 || a.pen_split) return false;
     const int G = path_wcoop_workgroups(wd.n, a.p);
     if (G < 1 || G > maxg) return false;
-    if (wcoop_general(a)) {                                      // the general form keeps u and beta of all coordinates and the group tables in LDS
-        if (getenv("OEM_WCOOP_NO_GENERAL") || a.p > 8192) return false;        // (the gather masks hold 32 x 256 columns)
+    if (getenv("OEM_WCOOP_NO_GENERAL") && (wcoop_general(a) || a.accelerate)) return false;
+    if (wcoop_general(a)) {                                      // group operators keep u (by column) and the group tables in LDS
+        if (a.p > 8192) return false;                            // (the gather masks hold 32 x 256 columns)
         size_t lds = 0;
         switch (wd.lay.nr) {
         case 1: lds = wcoop_lds_bytes<1>(a); break; case 2: lds = wcoop_lds_bytes<2>(a); break; case 3: lds = wcoop_lds_bytes<3>(a); break;
