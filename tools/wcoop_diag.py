@@ -25,4 +25,4 @@ print("   ", np.round(d[0:8] / max(d[8], 1), 0), "sum", round(d[0:8].sum() / max
 print("    product, further: [between + vector reads | dot products | column sums | operator + stop rule | update] (the partial-vector stores are in the first segment above)")
 print("   ", np.round(d[9:14] / max(d[8], 1), 0))
 if gen:
-    print("    general form: all-gather of u", round(d[14] / max(d[8], 1)), "cycles, group norms + factors", round(d[15] / max(d[8], 1)), "; 'operator + stop rule' above is the rest of the replicated operator stage")
+    print("    group operators: exchange of u", round(d[14] / max(d[8], 1)), "cycles, group norms + factors", round(d[15] / max(d[8], 1)), "cycles")
