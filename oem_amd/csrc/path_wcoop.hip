@@ -384,9 +384,9 @@ __device__ __forceinline__ double wc_op(double u, double tp, const WThr &c)
     return cdiv(u, c.d, c.rd);
 }
 
-// GEN: a group penalty in the call.  A group's norm needs u of all its members: one more exchange per iteration, of the members of this
+// ACC: Nesterov's step.  GEN: a group penalty in the call.  A group's norm needs u of all its members: one more exchange per iteration, of the members of this
 // workgroup's own groups (wc_gather_u_list); every lane then forms the factor of its column's group.  The group tables live in LDS.
-template <int NR, bool GEN>
+template <int NR, bool GEN, bool ACC>
 __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const double *__restrict__ xs, const double *__restrict__ ysv, int n,
                                                            unsigned long long *xchg, long long set_stride)
 {
@@ -684,8 +684,8 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
                 };
                 // Nesterov's step (ref src/oem_dense.h:633-651): beta+ = beta' + ratio (beta' - beta), its inner product summed over all
                 // workgroups next to the all-reduce; the stop rule looks at beta+ against beta
-                const bool acc = A.accelerate != 0;
-                const double akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak)), ratio = (ak - 1.0) / akn;
+                constexpr bool acc = ACC;                            // (a template parameter: the plain iteration carries none of it)
+                const double akn = acc ? 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak)) : 1.0, ratio = acc ? (ak - 1.0) / akn : 0.0;
                 auto finish_iteration = [&](double upd) __attribute__((always_inline)) {
                     double b = upd, part = 0.0;
                     if (acc) {
@@ -780,12 +780,12 @@ static size_t wcoop_gen_lds_doubles(int q, int ng)
     const size_t qp = (size_t)((q + 8 + 1) & ~1), ngp = (size_t)((ng + 2) & ~1);
     return qp + ngp + (qp + ngp + 2 + qp + ngp + qp + 2 + 1) / 2 + 2;       // Ush | GW | ints: gid, gstart, gidx, gzero, need list + count
 }
-template <int NR, bool GEN> int wcoop_launch_as(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G, int sets, size_t set_stride)
+template <int NR, bool GEN, bool ACC> int wcoop_launch_as(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G, int sets, size_t set_stride)
 {
     typedef WCfg<NR> C;
     const size_t sh = ((size_t)C::N_DBL + (GEN ? wcoop_gen_lds_doubles(a.p, a.ngroups) : 0)) * sizeof(double);
-    if (sh > 64 * 1024 && lds_limit_once(reinterpret_cast<const void *>(&path_wcoop_kernel<NR, GEN>), sh)) return OEMGPU_ERR_HIP;
-    hipLaunchKernelGGL((path_wcoop_kernel<NR, GEN>), dim3(G, sets), dim3(WNTH), sh, s, a, wd.xs, wd.ys, wd.n,
+    if (sh > 64 * 1024 && lds_limit_once(reinterpret_cast<const void *>(&path_wcoop_kernel<NR, GEN, ACC>), sh)) return OEMGPU_ERR_HIP;
+    hipLaunchKernelGGL((path_wcoop_kernel<NR, GEN, ACC>), dim3(G, sets), dim3(WNTH), sh, s, a, wd.xs, wd.ys, wd.n,
                        reinterpret_cast<unsigned long long *>(wd.scratch), (long long)set_stride);
     OEM_HIP(hipGetLastError());
     return 0;
@@ -793,7 +793,9 @@ template <int NR, bool GEN> int wcoop_launch_as(hipStream_t s, const PathArgs &a
 static bool wcoop_general(const PathArgs &a) { return a.ngroups != 0; }
 template <int NR> int wcoop_launch(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G, int sets, size_t set_stride)
 {
-    return wcoop_general(a) ? wcoop_launch_as<NR, true>(s, a, wd, G, sets, set_stride) : wcoop_launch_as<NR, false>(s, a, wd, G, sets, set_stride);
+    if (wcoop_general(a))
+        return a.accelerate ? wcoop_launch_as<NR, true, true>(s, a, wd, G, sets, set_stride) : wcoop_launch_as<NR, true, false>(s, a, wd, G, sets, set_stride);
+    return a.accelerate ? wcoop_launch_as<NR, false, true>(s, a, wd, G, sets, set_stride) : wcoop_launch_as<NR, false, false>(s, a, wd, G, sets, set_stride);
 }
 // dynamic LDS of the kernel for this call (bytes)
 template <int NR> size_t wcoop_lds_bytes(const PathArgs &a)
