@@ -422,10 +422,10 @@ def test_random_wide(oa, seed, monkeypatch):
 
 @pytest.mark.parametrize("seed", list(range(160, 176)) + list(range(95000, 95000 + 16 * (SCALE - 1))))
 def test_random_wide_cooperating(oa, seed, monkeypatch):
-    """p >= n on the persistent cooperating-workgroup form of the wide engine (path_wcoop.hip; what OEM_WIDE=1 takes whenever the
-    penalties are element-wise without Nesterov's step and compute.loss): random shapes over every column height and workgroup
-    count, ragged all-reduce slices, DataStd flags, penalty factors, one to four penalties (side by side in workgroup sets) --
-    against the oracle's restatement of the branch and against the launch-per-iteration engine."""
+    """p >= n on the persistent cooperating-workgroup form of the wide engine (path_wcoop.hip): random shapes over every column height
+    and workgroup count, ragged all-reduce slices, DataStd flags, penalty factors, one to four penalties (side by side in workgroup
+    sets), group operators with contiguous and scattered groups, Nesterov's step, compute.loss -- against the oracle's restatement of
+    the branch and against the launch-per-iteration engine."""
     monkeypatch.setenv("OEM_WIDE", "1")
     rng = np.random.default_rng(7700 + seed)
     n = int(rng.choice([1, 2, 7, 33, 64, 65, 100, 129, 192, 193, 250, 300, 385, 450, 520, 769, 900, 1024]))
@@ -436,17 +436,27 @@ def test_random_wide_cooperating(oa, seed, monkeypatch):
     nnz = int(min(p, rng.integers(1, 6)))
     b = np.zeros(p); b[rng.choice(p, nnz, replace=False)] = rng.uniform(-1.5, 1.5, nnz)
     y = x @ b + rng.normal(size=n) * rng.uniform(0.3, 2.0) + rng.uniform(-1, 1)
-    pens = list(rng.choice(ELEMENTWISE, int(rng.integers(1, 5)), replace=False))
+    grouped = rng.random() < 0.45 and p <= 8000                  # group operators: one more exchange, of the members of a workgroup's own groups
+    pens = list(rng.choice(ELEMENTWISE + (GROUPED if grouped else []), int(rng.integers(1, 5)), replace=False))
     pf = np.where(rng.random(p) < 0.1, 0.0, rng.uniform(0.5, 2.0, p))
     kw = dict(penalty=pens, nlambda=int(rng.integers(1, 7)), alpha=float(rng.uniform(0.2, 1.0)), gamma=float(rng.uniform(2.1, 5.0)),
-              tol=float(10.0 ** rng.uniform(-9, -6)), maxit=int(rng.choice([30, 200, 400])), penalty_factor=pf,
-              standardize=bool(rng.integers(2)), intercept=bool(rng.integers(2)), compute_loss=bool(rng.random() < 0.4))
+              tau=float(rng.uniform(0.1, 0.9)), tol=float(10.0 ** rng.uniform(-9, -6)), maxit=int(rng.choice([30, 200, 400])), penalty_factor=pf,
+              standardize=bool(rng.integers(2)), intercept=bool(rng.integers(2)), compute_loss=bool(rng.random() < 0.4),
+              accelerate=bool(rng.random() < 0.3))
+    okw = dict(kw)
+    if any("grp" in q for q in pens):
+        gs = int(rng.choice([1, 2, 3, 5, 8, 13, 40]))
+        groups = np.arange(p) // gs + (0 if rng.random() < 0.3 else 1)            # (ids from 0: group 0 is unpenalised)
+        if rng.random() < 0.4:
+            groups = groups[rng.permutation(p)]                     # members scattered over the workgroups
+        kw["groups"] = groups
+        okw.update(groups=groups, unique_groups=np.unique(groups))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         f = oa.oem(x, y, **kw)
         monkeypatch.setenv("OEM_NO_WCOOP", "1")
         g = oa.oem(x, y, **kw)
-    r = orc.fit_dense(x, y, lambda_min_ratio=0.01 if n < p else 1e-4, **kw)
+    r = orc.fit_dense(x, y, lambda_min_ratio=0.01 if n < p else 1e-4, **okw)
     ok = np.isfinite(r["d"]) and all(np.all(np.isfinite(bk)) for bk in r["beta"]) and all(np.all(np.isfinite(lk)) for lk in r["lambda"])
     if not ok:                                                    # (n = 1 under standardisation: the reference divides by a zero scale)
         assert not np.any(np.isinf(np.concatenate([np.ravel(bk) for bk in f["beta"]])))
