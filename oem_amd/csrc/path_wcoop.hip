@@ -86,9 +86,10 @@ struct WX {
 #ifdef OEM_PATH_DIAG
     unsigned long long acc[16], last;
 #endif
-    __amdgpu_buffer_rsrc_t rs1, rs2;   // exchange 1: [2 parities][G owners][G senders][SL] pairs of 16 bytes; exchange 2: [2 parities][NP] pairs
-    __amdgpu_buffer_rsrc_t rs3;        // group operators: the exchange of u, [2 parities][qpad] pairs
-    __amdgpu_buffer_rsrc_t rs4;        // Nesterov's step: the workgroups' parts of its inner product, [2 parities][G] pairs
+    __amdgpu_buffer_rsrc_t rs;         // ONE descriptor over this set's exchange buffers (four of them were sixteen SGPRs of a file that spills):
+    int o2, o3, o4;                    // exchange 1 at 0: [2 parities][G owners][G senders][SL] pairs of 16 bytes; exchange 2 at o2: [2][NP]
+                                       // pairs; o3: group operators, the exchange of u, [2][qpad] pairs; o4: Nesterov's step, the
+                                       // workgroups' parts of its inner product, [2][G] pairs (byte offsets)
     int qpad;
     unsigned epoch;               // all-reduce counter, never 0; identical in every workgroup
     int wg, G, SL, n, row0, nsl;  // this workgroup's slice: rows [row0, row0 + nsl)
@@ -213,7 +214,7 @@ __device__ __forceinline__ void wc_gather_u_list(double *Ush, double u_own, int 
 {
     const unsigned ep = X.epoch + 1;
     const int off3 = (int)(ep & 1u) * X.qpad * 16;
-    if (storer) { wc_publish(X.rs3, off3 + mycol * 16, u_own, ep << 1); Ush[mycol] = u_own; }
+    if (storer) { wc_publish(X.rs, X.o3 + off3 + mycol * 16, u_own, ep << 1); Ush[mycol] = u_own; }
     const int nk = (nlist + WNTH - 1) / WNTH;
     unsigned miss = 0;
     for (int k = 0; k < nk; ++k) if (tid + WNTH * k < nlist) miss |= 1u << k;
@@ -229,7 +230,7 @@ __device__ __forceinline__ void wc_gather_u_list(double *Ush, double u_own, int 
                 col[i] = 0;
                 if ((miss >> (k0 + i)) & 1u) {
                     col[i] = list[tid + WNTH * (k0 + i)];
-                    pv[i] = __builtin_amdgcn_raw_buffer_load_b128(X.rs3, off3 + col[i] * 16, 0, 16);
+                    pv[i] = __builtin_amdgcn_raw_buffer_load_b128(X.rs, X.o3 + off3 + col[i] * 16, 0, 16);
                 }
             }
 #pragma unroll
@@ -250,7 +251,7 @@ __device__ __forceinline__ void wc_gather_u_list(double *Ush, double u_own, int 
 __device__ __forceinline__ void wc_adp_publish(double part, WX &X, int tid)
 {
     const unsigned ep = X.epoch + 1;
-    if (tid == 0) wc_publish(X.rs4, ((int)(ep & 1u) * X.G + X.wg) * 16, part, ep << 1);
+    if (tid == 0) wc_publish(X.rs, X.o4 + ((int)(ep & 1u) * X.G + X.wg) * 16, part, ep << 1);
 }
 __device__ __forceinline__ double wc_adp_total(double own, double *red, int &rpar, WX &X, int tid, int w, int lane)
 {
@@ -263,7 +264,7 @@ __device__ __forceinline__ double wc_adp_total(double own, double *red, int &rpa
     bool miss = mine;
     while (__any(miss)) {
         wc_v4u pv = wc_v4u{0u, 0u, 0u, 0u};
-        if (miss) pv = __builtin_amdgcn_raw_buffer_load_b128(X.rs4, off4 + tid * 16, 0, 16);
+        if (miss) pv = __builtin_amdgcn_raw_buffer_load_b128(X.rs, X.o4 + off4 + tid * 16, 0, 16);
         if (miss && (pv.y >> 1) == ep && (pv.w >> 1) == ep) { v = __hiloint2double((int)pv.z, (int)pv.x); miss = false; }
         if (++spins >= limit && __any(miss)) { X.failed = true; break; }
     }
@@ -301,14 +302,14 @@ __device__ __forceinline__ int wc_allreduce(double *Rsh, const double *Ysh, cons
         if (pub[k] != -1) {
             const double t = (Pc[row] + Pc[C::NP + row]) + (Pc[2 * C::NP + row] + Pc[3 * C::NP + row]);
             if (pub[k] < -1) Gsh[-2 - pub[k]] = t;               // a row of the own slice
-            else wc_publish(X.rs1, off1 + pub[k] * 16, t, tag1);
+            else wc_publish(X.rs, off1 + pub[k] * 16, t, tag1);
         }
     }
     WC_STAMP(2);                                                 // publish 1
     int bits = 0;
     {
         double g[C::E1];
-        wc_gather<C::E1>(X.rs1, off1 + X.wg * X.G * X.SL * 16, need1, g, bits, X, tid);
+        wc_gather<C::E1>(X.rs, off1 + X.wg * X.G * X.SL * 16, need1, g, bits, X, tid);
 #pragma unroll
         for (int k = 0; k < C::E1; ++k) if ((need1 >> k) & 1u) Gsh[tid + WNTH * k] = g[k];
     }
@@ -336,7 +337,7 @@ __device__ __forceinline__ int wc_allreduce(double *Rsh, const double *Ysh, cons
             const int row = X.row0 + s;
             const double out = OEM ? Ysh[row] - t : t * rn;
             Rsh[row] = out;
-            wc_publish(X.rs2, off2 + row * 16, out, tag2);
+            wc_publish(X.rs, X.o2 + off2 + row * 16, out, tag2);
         }
     }
     WC_STAMP(5);                                                 // slice sums, publish 2
@@ -344,7 +345,7 @@ __device__ __forceinline__ int wc_allreduce(double *Rsh, const double *Ysh, cons
     int bits2 = 0;
     {
         double r[C::E2];
-        wc_gather<C::E2>(X.rs2, off2, need2, r, bits2, X, tid);
+        wc_gather<C::E2>(X.rs, X.o2 + off2, need2, r, bits2, X, tid);
 #pragma unroll
         for (int k = 0; k < C::E2; ++k) if ((need2 >> k) & 1u) Rsh[tid + WNTH * k] = r[k];
     }
@@ -429,11 +430,9 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
     X.G = G; X.wg = wg; X.n = n; X.SL = (n + G - 1) / G; X.row0 = wg * X.SL;
     X.nsl = n - X.row0 < 0 ? 0 : (n - X.row0 < X.SL ? n - X.row0 : X.SL);
     X.stride1 = G * G * X.SL;
-    X.rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, 2 * X.stride1 * 16, 0x00020000);
-    X.rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)(xchg + (size_t)4 * X.stride1), 0, 2 * NP * 16, 0x00020000);
     X.qpad = G * C::CPG;
-    X.rs3 = __builtin_amdgcn_make_buffer_rsrc((void *)(xchg + (size_t)4 * X.stride1 + (size_t)4 * NP), 0, 2 * X.qpad * 16, 0x00020000);
-    X.rs4 = __builtin_amdgcn_make_buffer_rsrc((void *)(xchg + (size_t)4 * X.stride1 + (size_t)4 * NP + (size_t)4 * X.qpad), 0, 2 * G * 16, 0x00020000);
+    X.o2 = 2 * X.stride1 * 16; X.o3 = X.o2 + 2 * NP * 16; X.o4 = X.o3 + 2 * X.qpad * 16;
+    X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, X.o4 + 2 * G * 16, 0x00020000);
     // group operators: u of the columns this workgroup's groups touch (indexed by column), the group tables
     const int ng = GEN ? A.ngroups : 0, qp = (q + 8 + 1) & ~1, ngp = (ng + 2) & ~1;
     double *Ush = lds + C::N_DBL, *GWsh = Ush + qp;
