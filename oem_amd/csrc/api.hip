@@ -389,10 +389,14 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const bool wcoop = wide && path_wcoop_eligible(a, *wide) && path_wcoop_workgroups(wide->n, q) <= c->num_cu * 3 / 4;
     const int wsets = wcoop ? path_wcoop_sets(wide->n, q, npen, c->num_cu) : 1;
     if (wcoop) slots.take(c->device, path_wcoop_workgroups(wide->n, q) * wsets, c->num_cu * 3 / 4);
+    // ... and where it does not fit: the same persistent launch re-reading its column tiles every iteration (path_wstream_kernel)
+    const int wsg = c->num_cu * 3 / 4 < WCOOP_GMAX ? c->num_cu * 3 / 4 : WCOOP_GMAX;
+    const bool wstream = wide && !wcoop && (path_wcoop_workgroups(wide->n, q) > WCOOP_GMAX || getenv("OEM_WSTREAM")) && path_wstream_eligible(a, *wide, wsg);      // (where it pays: measured there)
+    if (wstream) slots.take(c->device, wsg, c->num_cu * 3 / 4);
     {
         Timer t(c, OEMGPU_T_EIGPATH);
         PollScope poll(o);
-        int rc = wcoop ? launch_path_wcoop(c->stream, a, *wide, wsets) : wide ? run_path_wide(c->stream, a, *wide, (double *)c->pinned)
+        int rc = wcoop ? launch_path_wcoop(c->stream, a, *wide, wsets) : wstream ? launch_path_wstream(c->stream, a, *wide, wsg) : wide ? run_path_wide(c->stream, a, *wide, (double *)c->pinned)
                       : small ? launch_path_small(c->stream, a) : (coop ? launch_path_coop(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned));
         if (rc) return rc;
     }

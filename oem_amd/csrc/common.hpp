@@ -198,6 +198,10 @@ int path_wcoop_sets(int n, int p, int npen, int num_cu);         // workgroup se
 size_t path_wcoop_xchg_doubles(int n, int p);
 bool path_wcoop_eligible(const PathArgs &a, const WideArgs &w);
 int launch_path_wcoop(hipStream_t s, const PathArgs &a, const WideArgs &w, int sets);
+// the same where Xs does not fit the registers: G persistent workgroups re-read their column tiles every iteration (path_wcoop.hip: path_wstream_kernel)
+size_t path_wstream_xchg_doubles(int n);
+bool path_wstream_eligible(const PathArgs &a, const WideArgs &w, int G);
+int launch_path_wstream(hipStream_t s, const PathArgs &a, const WideArgs &w, int G);
 
 // opts->interrupt of the call in progress on this thread (api.hip: run_paths sets it around the engines); false if none
 bool caller_interrupted();

@@ -459,6 +459,22 @@ def test_wide_engine(oa, n, p, flag, monkeypatch):
         assert np.abs(np.asarray(g["beta"][k]) - np.asarray(w["beta"][k])).max() < 1e-7 * max(1.0, float(np.abs(g["beta"][k]).max()))
 
 
+def _path_kernel_cycles(oa, x, y, **kw):
+    """shader cycles of the last persistent eigen + path kernel (0 for the launch-per-iteration engines), one device-resident call"""
+    import ctypes as C
+    import torch
+    from oem_amd import _lib as L
+    xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+    ctx = oa.context()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        oa.oem(xd, y, **kw)
+    ms = (C.c_double * L.NTIMERS)()
+    L.check(L.lib().oemgpu_last_timings(ctx, ms))
+    return ms[6]                                                  # OEMGPU_T_PATHCYC
+
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,p", [(3, 5), (30, 40), (64, 1100), (100, 1500), (130, 2100), (190, 700), (256, 3000), (300, 1300), (384, 900),
                                  (500, 2000), (513, 1100), (700, 1410), (1000, 1000), (1024, 2048), (200, 5000), (100, 9000)])
@@ -519,6 +535,61 @@ def test_wide_cooperating_engine(oa, n, p, monkeypatch):
                     assert np.allclose(f["loss"][k], g["loss"][k], rtol=1e-9), kw["penalty"][k]
             if kw["maxit"] == 3:
                 assert f["niter"][0].max() == 4
+    # ONE persistent launch did the work (its cycle counter comes back), and the switch really selects the other engine
+    kw1 = dict(penalty=["lasso"], nlambda=3, tol=1e-6, maxit=50)
+    assert _path_kernel_cycles(oa, x, y, **kw1) > 0
+    monkeypatch.setenv("OEM_NO_WCOOP", "1")
+    assert _path_kernel_cycles(oa, x, y, **kw1) == 0
+    monkeypatch.delenv("OEM_NO_WCOOP")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,p,forced", [(60, 13000, False), (128, 12600, False), (250, 13000, False), (3, 40, True), (100, 700, True),
+                                        (130, 1900, True), (300, 1300, True), (500, 2100, True)])
+def test_wide_streamed_engine(oa, n, p, forced, monkeypatch):
+    """p >= n where the standardised X does not fit the registers: the STREAMED persistent form (path_wcoop.hip: path_wstream_kernel;
+    the workgroups stay for the whole call and re-read their column tiles every iteration, the all-reduce in-kernel) -- where the
+    library takes it by itself (short columns, p beyond the resident form) and forced onto small problems (OEM_WSTREAM=1 with
+    OEM_NO_WCOOP=1: every column height it is built for, one chunk and several, ragged last chunks) -- against the oracle's
+    restatement of the branch and against the launch-per-iteration engine."""
+    monkeypatch.setenv("OEM_WIDE", "1")
+    if forced:
+        monkeypatch.setenv("OEM_WSTREAM", "1"); monkeypatch.setenv("OEM_NO_WCOOP", "1")
+    x, y = _data(n, p, 1700 + n + p, mean=0.3, nnz=min(7, p))
+    rng = np.random.default_rng(n + p)
+    pf = rng.uniform(0.5, 2.0, p); pf[rng.integers(p)] = 0.0
+    calls = (dict(penalty=["lasso", "mcp", "scad.net", "ols"], alpha=0.7, gamma=3.5, nlambda=4, tol=1e-8, maxit=300, penalty_factor=pf,
+                  standardize=True, intercept=True, compute_loss=True),
+             dict(penalty=["lasso"], nlambda=3, tol=1e-12, maxit=3, standardize=False, intercept=True),
+             dict(penalty=["scad"], lambda_=[np.array([0.5, 0.2, 0.05])], tol=1e-8, maxit=300, standardize=True, intercept=False))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for kw in calls:
+            f = oa.oem(x, y, **kw)
+            monkeypatch.setenv("OEM_NO_WSTREAM", "1")
+            g = oa.oem(x, y, **kw)
+            monkeypatch.delenv("OEM_NO_WSTREAM")
+            r = orc.fit_dense(x, y, lambda_min_ratio=0.01 if n < p else 0.0001, **kw)
+            assert abs(f["d"] - r["d"]) < DTOL * r["d"], (f["d"], r["d"])
+            assert abs(f["d"] - g["d"]) < DTOL * g["d"]
+            for k in range(len(kw["penalty"])):
+                assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-11)
+                scale = max(1.0, float(np.abs(r["beta"][k]).max()))
+                assert np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max() < 1e-7 * scale, kw["penalty"][k]
+                assert np.abs(np.asarray(f["beta"][k]) - np.asarray(g["beta"][k])).max() < 1e-9 * scale, kw["penalty"][k]
+                dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int))
+                assert np.mean(dn > 1) <= 0.25, (kw["penalty"][k], dn)
+                dg = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(g["niter"][k]).astype(int))
+                assert dg.max() <= 1, (kw["penalty"][k], dg)
+                if kw.get("compute_loss"):
+                    assert np.allclose(f["loss"][k], r["loss"][k], rtol=1e-8), kw["penalty"][k]
+            if kw["maxit"] == 3:
+                assert f["niter"][0].max() == 4
+    kw1 = dict(penalty=["lasso"], nlambda=3, tol=1e-6, maxit=50)
+    assert _path_kernel_cycles(oa, x, y, **kw1) > 0               # the persistent kernel's cycle counter
+    monkeypatch.setenv("OEM_NO_WSTREAM", "1")
+    assert _path_kernel_cycles(oa, x, y, **kw1) == 0
+    monkeypatch.delenv("OEM_NO_WSTREAM")
 
 
 @pytest.mark.gpu
