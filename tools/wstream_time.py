@@ -8,7 +8,9 @@ import torch, oem_amd
 from oem_amd import _lib as L
 warnings.simplefilter("ignore")
 rng = np.random.default_rng(5); lib = L.lib()
-shapes = ((500, 8000, 30, "lasso"), (1000, 8000, 20, "mcp"), (500, 20000, 30, "lasso"), (200, 30000, 20, "lasso"), (64, 50000, 20, "scad"), (200, 100000, 20, "lasso"))
+shapes = ((30, 100000, 10, "lasso"), (64, 100000, 10, "lasso"), (100, 30000, 10, "lasso"), (128, 40000, 10, "lasso"), (128, 200000, 10, "lasso"), (64, 50000, 20, "scad"),
+          (500, 8000, 30, "lasso"), (250, 16000, 10, "lasso"), (190, 20000, 10, "lasso"), (500, 20000, 30, "lasso"), (200, 30000, 20, "lasso"), (200, 100000, 20, "lasso"))
+os.environ["OEM_WSTREAM"] = "1"                                   # (the comparison also where the library would not take it)
 if len(sys.argv) > 1: shapes = shapes[:int(sys.argv[1])]
 for n, p, nlam, pen in shapes:
     x = np.asfortranarray(rng.normal(size=(n, p))); y = x[:, :10] @ rng.uniform(0.5, 1.5, 10) + rng.normal(size=n)
