@@ -291,6 +291,29 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const size_t o_gix = bl.add(G.gidx.data(), sizeof(int) * G.gidx.size());
     const size_t o_gz = bl.add(G.gzero.data(), sizeof(int) * G.gzero.size());
     const size_t o_gw = bl.add(G.gw.data(), sizeof(double) * G.gw.size());
+    // p >= n on the cooperating engine with group penalties: where every group is a run of neighbouring columns the columns are dealt
+    // to the workgroups in whole groups (<= 4 CW columns each), so that no group's norm needs a value from another workgroup
+    std::vector<int> cst;
+    if (wide && og.ngroups > 0 && !getenv("OEM_WCOOP_NO_ALIGN")) {
+        const int cpg = path_wcoop_cpg(wide->n), gmax = path_wcoop_max_workgroups(wide->n, q);
+        bool ok = cpg > 0 && gmax > 0;
+        cst.push_back(0);
+        int fill = 0;
+        for (int j = 0; j < q && ok;) {
+            int len = 1;
+            const int g = G.gid[j];
+            if (g >= 0) {
+                len = G.gstart[g + 1] - G.gstart[g];
+                for (int k = 0; k < len && ok; ++k) ok = G.gidx[G.gstart[g] + k] == j + k;      // a run of neighbouring columns starting here
+            }
+            if (len > cpg) ok = false;
+            if (fill + len > cpg) { cst.push_back(j); fill = 0; }
+            fill += len; j += len;
+        }
+        cst.push_back(q);
+        if (!ok || (int)cst.size() - 1 > gmax || (int)cst.size() - 1 > c->num_cu * 3 / 4) cst.clear();
+    }
+    const size_t o_cst = cst.empty() ? 0 : bl.add(cst.data(), sizeof(int) * cst.size());
 
     // ---- outputs region (device) : beta | lambda | loss | d[2] | niter | stats copy
     const size_t nb = (size_t)npen * nl * q, nk = (size_t)npen * nl;
@@ -387,8 +410,13 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     // p >= n with Xs small enough for the register files of <= 192 CUs: one persistent launch (path_wcoop.hip)
     // (all of a set's workgroups must be resident at once: never more of them than three quarters of this device's CUs)
     const bool wcoop = wide && path_wcoop_eligible(a, *wide) && path_wcoop_workgroups(wide->n, q) <= c->num_cu * 3 / 4;
-    const int wsets = wcoop ? path_wcoop_sets(wide->n, q, npen, c->num_cu) : 1;
-    if (wcoop) slots.take(c->device, path_wcoop_workgroups(wide->n, q) * wsets, c->num_cu * 3 / 4);
+    // (... unless the few extra workgroups of the cut partition cost a whole penalty set its place beside the others)
+    const bool cut = wcoop && !cst.empty() &&
+                     path_wcoop_sets(wide->n, q, npen, c->num_cu, (int)cst.size() - 1) >= path_wcoop_sets(wide->n, q, npen, c->num_cu, 0);
+    const int *wcst = cut ? (const int *)(dblob + o_cst) : nullptr;
+    const int wg_n = wcst ? (int)cst.size() - 1 : (wcoop ? path_wcoop_workgroups(wide->n, q) : 0);
+    const int wsets = wcoop ? path_wcoop_sets(wide->n, q, npen, c->num_cu, wg_n) : 1;
+    if (wcoop) slots.take(c->device, wg_n * wsets, c->num_cu * 3 / 4);
     // ... and where it does not fit: the same persistent launch re-reading its column tiles every iteration (path_wstream_kernel)
     const int wsg = c->num_cu * 3 / 4 < WCOOP_GMAX ? c->num_cu * 3 / 4 : WCOOP_GMAX;
     const bool wstream = wide && !wcoop && (path_wcoop_workgroups(wide->n, q) > WCOOP_GMAX || getenv("OEM_WSTREAM")) && path_wstream_eligible(a, *wide, wsg);      // (where it pays: measured there)
@@ -396,7 +424,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     {
         Timer t(c, OEMGPU_T_EIGPATH);
         PollScope poll(o);
-        int rc = wcoop ? launch_path_wcoop(c->stream, a, *wide, wsets) : wstream ? launch_path_wstream(c->stream, a, *wide, wsg) : wide ? run_path_wide(c->stream, a, *wide, (double *)c->pinned)
+        int rc = wcoop ? launch_path_wcoop(c->stream, a, *wide, wsets, wcst, wg_n) : wstream ? launch_path_wstream(c->stream, a, *wide, wsg) : wide ? run_path_wide(c->stream, a, *wide, (double *)c->pinned)
                       : small ? launch_path_small(c->stream, a) : (coop ? launch_path_coop(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned));
         if (rc) return rc;
     }

@@ -194,10 +194,12 @@ int run_path_wide(hipStream_t s, const PathArgs &a, const WideArgs &w, double *h
 // penalties, one row block, p <= 4 CW WCOOP_GMAX columns (CW = 16 / 8 / 4 by column height); WCOOP_GMAX = three quarters of the CUs
 static const int WCOOP_GMAX = 192, WCOOP_MAX_SETS = 8;
 int path_wcoop_workgroups(int n, int p);
-int path_wcoop_sets(int n, int p, int npen, int num_cu);         // workgroup sets side by side, one penalty each
+int path_wcoop_cpg(int n);                                        // columns per workgroup (0: not this engine)
+int path_wcoop_max_workgroups(int n, int p);                     // ... of a partition cut at group boundaries, at most
+int path_wcoop_sets(int n, int p, int npen, int num_cu, int G = 0);   // workgroup sets side by side, one penalty each (G: of a cut partition)
 size_t path_wcoop_xchg_doubles(int n, int p);
 bool path_wcoop_eligible(const PathArgs &a, const WideArgs &w);
-int launch_path_wcoop(hipStream_t s, const PathArgs &a, const WideArgs &w, int sets);
+int launch_path_wcoop(hipStream_t s, const PathArgs &a, const WideArgs &w, int sets, const int *cstart = nullptr, int G = 0);   // cstart (device, G + 1 ints): columns cut at group boundaries
 // the same where Xs does not fit the registers: G persistent workgroups re-read their column tiles every iteration (path_wcoop.hip: path_wstream_kernel)
 size_t path_wstream_xchg_doubles(int n);
 bool path_wstream_eligible(const PathArgs &a, const WideArgs &w, int G);

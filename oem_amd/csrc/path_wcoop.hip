@@ -210,11 +210,11 @@ __device__ __forceinline__ void wc_publish(__amdgpu_buffer_rsrc_t rs, int off, d
 // columns on `list` (with groups of neighbouring columns a handful of values from the next workgroup, or none).  In: the column
 // owners' values (one lane per column: `storer`); everybody publishes all its columns.  Out: Ush[j] for the own columns and the
 // listed ones, behind a barrier.  Tagged with the epoch of the all-reduce that follows.
-__device__ __forceinline__ void wc_gather_u_list(double *Ush, double u_own, int mycol, bool storer, const int *list, int nlist, WX &X, int tid)
+__device__ __forceinline__ void wc_gather_u_list(double *Ush, double u_own, int mycol, bool storer, const int *list, int nlist, bool publish, WX &X, int tid)
 {
     const unsigned ep = X.epoch + 1;
     const int off3 = (int)(ep & 1u) * X.qpad * 16;
-    if (storer) { wc_publish(X.rs, X.o3 + off3 + mycol * 16, u_own, ep << 1); Ush[mycol] = u_own; }
+    if (storer) { if (publish) wc_publish(X.rs, X.o3 + off3 + mycol * 16, u_own, ep << 1); Ush[mycol] = u_own; }      // (publish: somebody may ask)
     const int nk = (nlist + WNTH - 1) / WNTH;
     unsigned miss = 0;
     for (int k = 0; k < nk; ++k) if (tid + WNTH * k < nlist) miss |= 1u << k;
@@ -387,9 +387,12 @@ __device__ __forceinline__ double wc_op(double u, double tp, const WThr &c)
 
 // ACC: Nesterov's step.  GEN: a group penalty in the call.  A group's norm needs u of all its members: one more exchange per iteration, of the members of this
 // workgroup's own groups (wc_gather_u_list); every lane then forms the factor of its column's group.  The group tables live in LDS.
+// cstart (GEN only, or null): the columns of workgroup g are [cstart[g], cstart[g + 1]) -- at most 4 CW of them, cut at group
+// boundaries by the host (api.hip) when every group is a run of neighbouring columns: then no group reaches into another workgroup
+// and the exchange of u has nobody to serve.  Null: 4 CW columns each.
 template <int NR, bool GEN, bool ACC>
 __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const double *__restrict__ xs, const double *__restrict__ ysv, int n,
-                                                           unsigned long long *xchg, long long set_stride)
+                                                           unsigned long long *xchg, long long set_stride, const int *__restrict__ cstart)
 {
     typedef WCfg<NR> C;
     constexpr int NP = C::NP, CW = C::CW, SH = C::SH, E2 = C::E2;
@@ -408,17 +411,19 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
     const double rn = 1.0 / (double)n;
 
     // ---- this wave's CW columns in registers; this lane's own column (the one whose sum and coefficient it ends up with)
-    const int cbase = wg * C::CPG + w * CW;
+    const int c0 = (GEN && cstart) ? cstart[wg] : wg * C::CPG;
+    const int c1 = (GEN && cstart) ? cstart[wg + 1] : (c0 + C::CPG < q ? c0 + C::CPG : q);
+    const int cbase = c0 + w * CW;
     double x[CW][NR];
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
-        const bool ok = cbase + c < q;
+        const bool ok = cbase + c < c1;
         const double *col = xs + (size_t)(ok ? cbase + c : 0) * NP;
 #pragma unroll
         for (int k = 0; k < NR; ++k) { const double t = col[lane + 64 * k]; x[c][k] = ok ? t : 0.0; }
     }
     const int mycol = cbase + (l16 >> SH);
-    const bool colok = mycol < q;
+    const bool colok = mycol < c1;
     const bool storer = colok && lane < 16 && (l16 & ((1 << SH) - 1)) == 0;       // one lane per column writes its coefficient out
     const double pfj = colok ? A.pf[mycol] : 0.0;
     for (int j = tid; j < NP + 8; j += WNTH) Rsh[j] = 0.0;
@@ -477,15 +482,15 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
     if (GEN && ng > 0) {
         if (tid == 0) nneedL[0] = 0;
         __syncthreads();
-        const int c0 = wg * C::CPG, cme = c0 + tid;
-        if (tid < C::CPG && cme < q) {
+        const int cme = c0 + tid;
+        if (cme < c1) {
             const int gi = gidL[cme];
             bool first = gi >= 0;
             for (int cc = c0; cc < cme && first; ++cc) first = gidL[cc] != gi;      // one own column per group walks its members
             if (first)
                 for (int m = gstartL[gi]; m < gstartL[gi + 1]; ++m) {
                     const int j = gidxL[m];
-                    if (j / C::CPG != wg) needL[atomicAdd(&nneedL[0], 1)] = j;
+                    if (j < c0 || j >= c1) needL[atomicAdd(&nneedL[0], 1)] = j;
                 }
         }
         __syncthreads();
@@ -713,7 +718,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
                     // then every lane forms the factor of ITS column's group and the coefficient of its column
                     const double dot = col_dots();
                     const double uo = colok ? dot * rn + d * bcur : 0.0;
-                    wc_gather_u_list(Ush, uo, mycol, storer, needL, nneed, X, tid);
+                    wc_gather_u_list(Ush, uo, mycol, storer, needL, nneed, cstart == nullptr, X, tid);
                     WC_STAMP(14);                                    // exchange of u
                     const bool sgl = K.kind == K_SGL;                // sparse group lasso: the soft-thresholded u feeds the norms
                     double f = 0.0;
@@ -1066,22 +1071,22 @@ static size_t wcoop_gen_lds_doubles(int q, int ng)
     const size_t qp = (size_t)((q + 8 + 1) & ~1), ngp = (size_t)((ng + 2) & ~1);
     return qp + ngp + (qp + ngp + 2 + qp + ngp + qp + 2 + 1) / 2 + 2;       // Ush | GW | ints: gid, gstart, gidx, gzero, need list + count
 }
-template <int NR, bool GEN, bool ACC> int wcoop_launch_as(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G, int sets, size_t set_stride)
+template <int NR, bool GEN, bool ACC> int wcoop_launch_as(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G, int sets, size_t set_stride, const int *cstart)
 {
     typedef WCfg<NR> C;
     const size_t sh = ((size_t)C::N_DBL + (GEN ? wcoop_gen_lds_doubles(a.p, a.ngroups) : 0)) * sizeof(double);
     if (sh > 64 * 1024 && lds_limit_once(reinterpret_cast<const void *>(&path_wcoop_kernel<NR, GEN, ACC>), sh)) return OEMGPU_ERR_HIP;
     hipLaunchKernelGGL((path_wcoop_kernel<NR, GEN, ACC>), dim3(G, sets), dim3(WNTH), sh, s, a, wd.xs, wd.ys, wd.n,
-                       reinterpret_cast<unsigned long long *>(wd.scratch), (long long)set_stride);
+                       reinterpret_cast<unsigned long long *>(wd.scratch), (long long)set_stride, GEN ? cstart : (const int *)nullptr);
     OEM_HIP(hipGetLastError());
     return 0;
 }
 static bool wcoop_general(const PathArgs &a) { return a.ngroups != 0; }
-template <int NR> int wcoop_launch(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G, int sets, size_t set_stride)
+template <int NR> int wcoop_launch(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G, int sets, size_t set_stride, const int *cstart)
 {
     if (wcoop_general(a))
-        return a.accelerate ? wcoop_launch_as<NR, true, true>(s, a, wd, G, sets, set_stride) : wcoop_launch_as<NR, true, false>(s, a, wd, G, sets, set_stride);
-    return a.accelerate ? wcoop_launch_as<NR, false, true>(s, a, wd, G, sets, set_stride) : wcoop_launch_as<NR, false, false>(s, a, wd, G, sets, set_stride);
+        return a.accelerate ? wcoop_launch_as<NR, true, true>(s, a, wd, G, sets, set_stride, cstart) : wcoop_launch_as<NR, true, false>(s, a, wd, G, sets, set_stride, cstart);
+    return a.accelerate ? wcoop_launch_as<NR, false, true>(s, a, wd, G, sets, set_stride, cstart) : wcoop_launch_as<NR, false, false>(s, a, wd, G, sets, set_stride, cstart);
 }
 // dynamic LDS of the kernel for this call (bytes)
 template <int NR> size_t wcoop_lds_bytes(const PathArgs &a)
@@ -1105,19 +1110,31 @@ int path_wcoop_workgroups(int n, int p)
     return (p + 4 * wc_cw(L.nr) - 1) / (4 * wc_cw(L.nr));
 }
 
-// the two exchanges of ONE workgroup set, both parities (16-byte pairs), as doubles of scratch
-static size_t wcoop_set_doubles(int n, int p)
+int path_wcoop_cpg(int n)                                        // columns per workgroup
+{
+    const WideLayout L = wide_layout(n);
+    return (L.nb != 1 || L.nr < 1 || L.nr > 16) ? 0 : 4 * wc_cw(L.nr);
+}
+// a partition of the columns cut at group boundaries may need a few more workgroups than p / (4 CW): at most this many
+int path_wcoop_max_workgroups(int n, int p)
 {
     const int G = path_wcoop_workgroups(n, p);
+    if (G < 1) return 0;
+    const int g = G + (G / 4 > 2 ? G / 4 : 2);
+    return g < WCOOP_GMAX ? g : WCOOP_GMAX;
+}
+// the exchanges of ONE set of G workgroups, both parities (16-byte pairs), as doubles of scratch
+static size_t wcoop_set_doubles(int n, int p, int G)
+{
     if (G < 1 || G > WCOOP_GMAX) return 0;
     const WideLayout L = wide_layout(n);
     const size_t SL = ((size_t)n + G - 1) / G;
     return 2 * ((size_t)G * G * SL * 2) + 2 * ((size_t)L.npad() * 2) + 2 * ((size_t)G * 4 * wc_cw(L.nr) * 2) + 2 * ((size_t)G * 2) + 64;
 }
 // workgroup sets (one per penalty) that may run side by side: all of them resident at once, on three quarters of the CUs at most
-int path_wcoop_sets(int n, int p, int npen, int num_cu)
+int path_wcoop_sets(int n, int p, int npen, int num_cu, int G)
 {
-    const int G = path_wcoop_workgroups(n, p);
+    if (G < 1) G = path_wcoop_workgroups(n, p);
     if (G < 1) return 1;
     int s = (num_cu * 3 / 4) / G;
     if (s > WCOOP_MAX_SETS) s = WCOOP_MAX_SETS;
@@ -1127,11 +1144,11 @@ int path_wcoop_sets(int n, int p, int npen, int num_cu)
 }
 size_t path_wcoop_xchg_doubles(int n, int p)
 {
-    const int G = path_wcoop_workgroups(n, p);
+    const int G = path_wcoop_workgroups(n, p), Gx = path_wcoop_max_workgroups(n, p);
     if (G < 1 || G > WCOOP_GMAX) return 0;
     int s = 192 / G;                                               // (256 CUs; fewer CUs: fewer sets)
     if (s > WCOOP_MAX_SETS) s = WCOOP_MAX_SETS;
-    return wcoop_set_doubles(n, p) * (size_t)(s < 1 ? 1 : s);
+    return wcoop_set_doubles(n, p, Gx) * (size_t)(s < 1 ? 1 : s);
 }
 
 // OEM_NO_WCOOP=1: the launch-per-iteration engine; OEM_WCOOP_MAXG: fewer workgroups allowed (experiments)
@@ -1157,23 +1174,23 @@ bool path_wcoop_eligible(const PathArgs &a, const WideArgs &wd)
     return true;
 }
 
-int launch_path_wcoop(hipStream_t s, const PathArgs &a, const WideArgs &wd, int sets)
+int launch_path_wcoop(hipStream_t s, const PathArgs &a, const WideArgs &wd, int sets, const int *cstart, int G)
 {
-    const int G = path_wcoop_workgroups(wd.n, a.p);
-    if (G < 1 || G > WCOOP_GMAX) { set_error("internal: wide cooperating engine asked for %d workgroups", G); return OEMGPU_ERR_INTERNAL; }
-    const size_t set_stride = wcoop_set_doubles(wd.n, a.p);
+    if (!cstart) G = path_wcoop_workgroups(wd.n, a.p);
+    if (G < 1 || G > WCOOP_GMAX || G > path_wcoop_max_workgroups(wd.n, a.p)) { set_error("internal: wide cooperating engine asked for %d workgroups", G); return OEMGPU_ERR_INTERNAL; }
+    const size_t set_stride = wcoop_set_doubles(wd.n, a.p, G);
     if (sets < 1 || set_stride * (size_t)sets > path_wcoop_xchg_doubles(wd.n, a.p)) { set_error("internal: wide cooperating engine, %d sets", sets); return OEMGPU_ERR_INTERNAL; }
     OEM_HIP(hipMemsetAsync(wd.scratch, 0, sizeof(double) * set_stride * (size_t)sets, s));                 // the tags must start at 0
     OEM_HIP(hipMemsetAsync(a.d_out, 0, sizeof(double) * D_OUT_LEN, s));                                  // [6]: only a timed-out workgroup writes it
     switch (wd.lay.nr) {
-    case 1: return wcoop_launch<1>(s, a, wd, G, sets, set_stride);
-    case 2: return wcoop_launch<2>(s, a, wd, G, sets, set_stride);
-    case 3: return wcoop_launch<3>(s, a, wd, G, sets, set_stride);
-    case 4: return wcoop_launch<4>(s, a, wd, G, sets, set_stride);
-    case 6: return wcoop_launch<6>(s, a, wd, G, sets, set_stride);
-    case 8: return wcoop_launch<8>(s, a, wd, G, sets, set_stride);
-    case 12: return wcoop_launch<12>(s, a, wd, G, sets, set_stride);
-    case 16: return wcoop_launch<16>(s, a, wd, G, sets, set_stride);
+    case 1: return wcoop_launch<1>(s, a, wd, G, sets, set_stride, cstart);
+    case 2: return wcoop_launch<2>(s, a, wd, G, sets, set_stride, cstart);
+    case 3: return wcoop_launch<3>(s, a, wd, G, sets, set_stride, cstart);
+    case 4: return wcoop_launch<4>(s, a, wd, G, sets, set_stride, cstart);
+    case 6: return wcoop_launch<6>(s, a, wd, G, sets, set_stride, cstart);
+    case 8: return wcoop_launch<8>(s, a, wd, G, sets, set_stride, cstart);
+    case 12: return wcoop_launch<12>(s, a, wd, G, sets, set_stride, cstart);
+    case 16: return wcoop_launch<16>(s, a, wd, G, sets, set_stride, cstart);
     default: break;
     }
     set_error("internal: wide cooperating engine, nr = %d", wd.lay.nr);

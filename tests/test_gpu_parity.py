@@ -513,6 +513,14 @@ def test_wide_cooperating_engine(oa, n, p, monkeypatch):
             monkeypatch.setenv("OEM_WCOOP_ONE_SET", "1")
             h = oa.oem(x, y, **kw)
             monkeypatch.delenv("OEM_WCOOP_ONE_SET")
+            if "groups" in kw:                                    # columns dealt in whole groups or 4 CW each: the same coefficients
+                monkeypatch.setenv("OEM_WCOOP_NO_ALIGN", "1")
+                h2 = oa.oem(x, y, **kw)
+                monkeypatch.delenv("OEM_WCOOP_NO_ALIGN")
+                for k in range(len(kw["penalty"])):
+                    sc = max(1.0, float(np.abs(np.asarray(h2["beta"][k])).max()))
+                    assert np.abs(np.asarray(f["beta"][k]) - np.asarray(h2["beta"][k])).max() < 1e-9 * sc
+                    assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(h2["niter"][k]).astype(int)).max() <= 1
             okw = dict(kw)
             if "groups" in okw:
                 okw["unique_groups"] = np.unique(grp)
