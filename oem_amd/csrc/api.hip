@@ -421,22 +421,34 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const int wsg = c->num_cu * 3 / 4 < WCOOP_GMAX ? c->num_cu * 3 / 4 : WCOOP_GMAX;
     const bool wstream = wide && !wcoop && (path_wcoop_workgroups(wide->n, q) > WCOOP_GMAX || getenv("OEM_WSTREAM")) && path_wstream_eligible(a, *wide, wsg);      // (where it pays: measured there)
     if (wstream) slots.take(c->device, wsg, c->num_cu * 3 / 4);
-    {
-        Timer t(c, OEMGPU_T_EIGPATH);
-        PollScope poll(o);
-        int rc = wcoop ? launch_path_wcoop(c->stream, a, *wide, wsets, wcst, wg_n) : wstream ? launch_path_wstream(c->stream, a, *wide, wsg) : wide ? run_path_wide(c->stream, a, *wide, (double *)c->pinned)
-                      : small ? launch_path_small(c->stream, a) : (coop ? launch_path_coop(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned));
-        if (rc) return rc;
+    // The persistent p >= n engines need all their workgroups resident at once.  If somebody else holds the CUs (another process on a
+    // shared GPU) their exchanges time out after about a second and poison the result: the call is then made again on the
+    // launch-per-iteration engine, which waits for nobody.
+    for (int attempt = 0;; ++attempt) {
+        const bool persistent = (wcoop || wstream) && attempt == 0;
+        {
+            Timer t(c, OEMGPU_T_EIGPATH);
+            PollScope poll(o);
+            int rc = persistent ? (wcoop ? launch_path_wcoop(c->stream, a, *wide, wsets, wcst, wg_n) : launch_path_wstream(c->stream, a, *wide, wsg))
+                     : wide ? run_path_wide(c->stream, a, *wide, (double *)c->pinned)
+                     : small ? launch_path_small(c->stream, a) : (coop ? launch_path_coop(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned));
+            if (rc) return rc;
+        }
+        HT(2);
+        if (!zero_copy) {
+            if (!joined) OEM_HIP(hipMemcpy2DAsync(dstats, out_stride, stats, bstride * sizeof(double), sizeof(double) * stats_len(p), nbatch,
+                                                  hipMemcpyDeviceToDevice, c->stream));
+            OEM_HIP(hipMemcpyAsync(c->pinned, joined ? (const void *)stats : (const void *)dout, back_bytes, hipMemcpyDeviceToHost, c->stream));
+        }
+        HT(3);
+        OEM_HIP(hipStreamSynchronize(c->stream));
+        HT(4);
+        if (persistent) {
+            const double *hd0 = (const double *)((const char *)c->pinned + (joined ? st_gap : 0)) + nb + 2 * nk;
+            if (hd0[6] != 0.0) { ++c->persistent_fallbacks; continue; }
+        }
+        break;
     }
-    HT(2);
-    if (!zero_copy) {
-        if (!joined) OEM_HIP(hipMemcpy2DAsync(dstats, out_stride, stats, bstride * sizeof(double), sizeof(double) * stats_len(p), nbatch,
-                                              hipMemcpyDeviceToDevice, c->stream));
-        OEM_HIP(hipMemcpyAsync(c->pinned, joined ? (const void *)stats : (const void *)dout, back_bytes, hipMemcpyDeviceToHost, c->stream));
-    }
-    HT(3);
-    OEM_HIP(hipStreamSynchronize(c->stream));
-    HT(4);
 
     // ---- unpack (ref src/oem_dense.cpp:249-294, src/DataStd.h:269-293, src/oem_big.h:880-897, src/oem_big.cpp:213-220)
     const int flag = (standardize ? 1 : 0) + 2 * (intercept ? 1 : 0);

@@ -1063,6 +1063,7 @@ template <int NR> int wstream_launch(hipStream_t s, const PathArgs &a, const Wid
     if (sh > 64 * 1024 && lds_limit_once(reinterpret_cast<const void *>(&path_wstream_kernel<NR>), sh)) return OEMGPU_ERR_HIP;
     hipLaunchKernelGGL((path_wstream_kernel<NR>), dim3(G), dim3(WNTH), sh, s, a, wd.xs, wd.ys, wd.n, reinterpret_cast<unsigned long long *>(wd.scratch), nch);
     OEM_HIP(hipGetLastError());
+    if (getenv("OEM_WCOOP_FAKE_TIMEOUT")) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
     return 0;
 }
 
@@ -1079,6 +1080,7 @@ template <int NR, bool GEN, bool ACC> int wcoop_launch_as(hipStream_t s, const P
     hipLaunchKernelGGL((path_wcoop_kernel<NR, GEN, ACC>), dim3(G, sets), dim3(WNTH), sh, s, a, wd.xs, wd.ys, wd.n,
                        reinterpret_cast<unsigned long long *>(wd.scratch), (long long)set_stride, GEN ? cstart : (const int *)nullptr);
     OEM_HIP(hipGetLastError());
+    if (getenv("OEM_WCOOP_FAKE_TIMEOUT")) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
     return 0;
 }
 static bool wcoop_general(const PathArgs &a) { return a.ngroups != 0; }

@@ -601,6 +601,32 @@ def test_wide_streamed_engine(oa, n, p, forced, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("streamed", [False, True])
+def test_persistent_wide_engines_fall_back_when_their_exchange_times_out(oa, streamed, monkeypatch):
+    """the persistent p >= n engines need all their workgroups resident at once; when somebody else holds the CUs their exchanges time
+    out and poison the result (d_out[6]) -- the host then makes the call again on the launch-per-iteration engine instead of failing.
+    OEM_WCOOP_FAKE_TIMEOUT=1 sets the poison behind a kernel that ran: the caller must get exactly the launch engine's answer."""
+    monkeypatch.setenv("OEM_WIDE", "1")
+    if streamed:
+        monkeypatch.setenv("OEM_WSTREAM", "1"); monkeypatch.setenv("OEM_NO_WCOOP", "1")
+    x, y = _data(200, 1500, 4242, mean=0.2, nnz=6)
+    kw = dict(penalty=["lasso", "mcp"], nlambda=5, tol=1e-8, maxit=300)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        good = oa.oem(x, y, **kw)
+        monkeypatch.setenv("OEM_WCOOP_FAKE_TIMEOUT", "1")
+        back = oa.oem(x, y, **kw)
+        assert _path_kernel_cycles(oa, x, y, **kw) == 0           # what answered in the end was the launch-per-iteration engine
+        monkeypatch.delenv("OEM_WCOOP_FAKE_TIMEOUT")
+        assert _path_kernel_cycles(oa, x, y, **kw) > 0
+        monkeypatch.setenv("OEM_NO_WSTREAM" if streamed else "OEM_NO_WCOOP", "1")
+        launches = oa.oem(x, y, **kw)
+    for k in range(2):
+        assert np.array_equal(np.asarray(back["beta"][k]), np.asarray(launches["beta"][k])) and np.array_equal(back["niter"][k], launches["niter"][k])
+        assert np.abs(np.asarray(back["beta"][k]) - np.asarray(good["beta"][k])).max() < 1e-9
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,p", [(1100, 1200), (1500, 1501), (2048, 2100), (2049, 2100), (2500, 2600)])
 def test_wide_engine_tall_columns(oa, n, p, monkeypatch):
     """the column heights that take 24 and 32 registers per lane (four waves per workgroup), and beyond 2048 rows the ROW-BLOCKED
