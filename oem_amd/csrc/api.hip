@@ -421,17 +421,24 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const int wsg = c->num_cu * 3 / 4 < WCOOP_GMAX ? c->num_cu * 3 / 4 : WCOOP_GMAX;
     const bool wstream = wide && !wcoop && (path_wcoop_workgroups(wide->n, q) > WCOOP_GMAX || getenv("OEM_WSTREAM")) && path_wstream_eligible(a, *wide, wsg);      // (where it pays: measured there)
     if (wstream) slots.take(c->device, wsg, c->num_cu * 3 / 4);
-    // The persistent p >= n engines need all their workgroups resident at once.  If somebody else holds the CUs (another process on a
+    // The persistent engines (p >= n; 208 < p <= 1024) need all their workgroups resident at once.  If somebody else holds the CUs (another process on a
     // shared GPU) their exchanges time out after about a second and poison the result: the call is then made again on the
-    // launch-per-iteration engine, which waits for nobody.
+    // launch-per-iteration engines, which wait for nobody.
     for (int attempt = 0;; ++attempt) {
-        const bool persistent = (wcoop || wstream) && attempt == 0;
+        const bool persistent = (wcoop || wstream || (coop && nbatch == 1)) && attempt == 0;
         {
             Timer t(c, OEMGPU_T_EIGPATH);
             PollScope poll(o);
-            int rc = persistent ? (wcoop ? launch_path_wcoop(c->stream, a, *wide, wsets, wcst, wg_n) : launch_path_wstream(c->stream, a, *wide, wsg))
-                     : wide ? run_path_wide(c->stream, a, *wide, (double *)c->pinned)
-                     : small ? launch_path_small(c->stream, a) : (coop ? launch_path_coop(c->stream, a) : run_path_large(c->stream, a, (double *)c->pinned));
+            int rc;
+            if (persistent) rc = wcoop ? launch_path_wcoop(c->stream, a, *wide, wsets, wcst, wg_n) : wstream ? launch_path_wstream(c->stream, a, *wide, wsg) : launch_path_coop(c->stream, a);
+            else if (wide) rc = run_path_wide(c->stream, a, *wide, (double *)c->pinned);
+            else if (small) rc = launch_path_small(c->stream, a);
+            else if (coop && attempt == 0) rc = launch_path_coop(c->stream, a);                 // (several instances: no second engine takes them)
+            else {
+                PathArgs al = a;                                  // (after a timed-out cooperating launch: one instance, its penalties in turn)
+                al.pen_split = 0; al.pen_lo = 0; al.pen_hi = npen;
+                rc = run_path_large(c->stream, al, (double *)c->pinned);
+            }
             if (rc) return rc;
         }
         HT(2);

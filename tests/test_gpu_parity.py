@@ -627,6 +627,22 @@ def test_persistent_wide_engines_fall_back_when_their_exchange_times_out(oa, str
 
 
 @pytest.mark.gpu
+def test_cooperating_gram_engine_falls_back_when_its_exchange_times_out(oa, monkeypatch):
+    """the same for 208 < p <= 1024 (path_coop.hip): a poisoned exchange sends the call to the launch-per-iteration engine"""
+    x, y = _data(3000, 400, 777, mean=0.1, nnz=8)
+    kw = dict(penalty=["grp.lasso"], groups=np.arange(400) // 8 + 1, nlambda=8, tol=1e-9, compute_loss=True)
+    good = oa.oem(x, y, **kw)
+    monkeypatch.setenv("OEM_WCOOP_FAKE_TIMEOUT", "1")
+    back = oa.oem(x, y, **kw)
+    monkeypatch.delenv("OEM_WCOOP_FAKE_TIMEOUT")
+    monkeypatch.setenv("OEM_NO_COOP", "1")
+    launches = oa.oem(x, y, **kw)
+    assert np.array_equal(np.asarray(back["beta"][0]), np.asarray(launches["beta"][0])) and np.array_equal(back["niter"][0], launches["niter"][0])
+    assert np.abs(np.asarray(back["beta"][0]) - np.asarray(good["beta"][0])).max() < 1e-9
+    assert np.allclose(back["loss"][0], good["loss"][0], rtol=1e-9)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,p", [(1100, 1200), (1500, 1501), (2048, 2100), (2049, 2100), (2500, 2600)])
 def test_wide_engine_tall_columns(oa, n, p, monkeypatch):
     """the column heights that take 24 and 32 registers per lane (four waves per workgroup), and beyond 2048 rows the ROW-BLOCKED
