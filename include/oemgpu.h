@@ -274,6 +274,11 @@ int oemgpu_last_host_stats(double *out /* OEMGPU_NHOSTSTATS */);
  * calls; nothing else needs this.  Contexts in use by another thread are left alone. */
 void oemgpu_release_cache(void);
 
+/* Host-only self-check of the persistent p >= n engine's scratch sizing (pure arithmetic, runs without a GPU): for an n x p problem
+ * with npen penalties on a device of num_cu CUs, 0 if every column partition the launch may choose gets at least one workgroup set
+ * and never more sets than the exchange scratch was sized for; otherwise +/- the offending workgroup count. */
+int oemgpu_selftest_wcoop_sizing(int32_t n, int32_t p, int32_t npen, int32_t num_cu);
+
 const char *oemgpu_last_error(void);
 const char *oemgpu_version(void);
 int         oemgpu_device_count(void);

@@ -568,15 +568,17 @@ def cv_oem(x, y, penalty=None, weights=(), lambda_=None, type_measure=None, nfol
         raise ValueError("nfolds must be bigger than 3; nfolds=10 recommended")
     def fold_fit(i):
         keep_rows = foldid != i
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")                     # (the p > n warning was given once, by the full fit)
-            return oem(np.asfortranarray(xh[keep_rows]), yh[keep_rows], penalty=penalty, lambda_=lam_arg, **kw)
-    if parallel:
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=min(int(nfolds), 3 if parallel is True else int(parallel))) as ex:
-            outlist = list(ex.map(fold_fit, range(1, nfolds + 1)))
-    else:
-        outlist = [fold_fit(i) for i in range(1, nfolds + 1)]
+        return oem(np.asfortranarray(xh[keep_rows]), yh[keep_rows], penalty=penalty, lambda_=lam_arg, **kw)
+    # the p > n warning was given once, by the full fit: only THAT message is silenced for the fold fits, and the filter list is
+    # touched by the calling thread alone, around the whole block (catch_warnings is process-global state: not for worker threads)
+    with warnings.catch_warnings():
+        warnings.filterwarnings("ignore", message=".*optimized for n >> p.*")
+        if parallel:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(int(nfolds), 3 if parallel is True else int(parallel))) as ex:
+                outlist = list(ex.map(fold_fit, range(1, nfolds + 1)))
+        else:
+            outlist = [fold_fit(i) for i in range(1, nfolds + 1)]
     # cv.oemfit_gaussian
     if type_measure in ("default", "deviance"):
         type_measure = "mse"

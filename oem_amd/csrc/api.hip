@@ -409,13 +409,14 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     if (coop) slots.take(c->device, path_coop_workgroups(q) * (pen_split ? npen : 1) * nbatch, c->num_cu * 3 / 4);
     // p >= n with Xs small enough for the register files of <= 192 CUs: one persistent launch (path_wcoop.hip)
     // (all of a set's workgroups must be resident at once: never more of them than three quarters of this device's CUs)
-    const bool wcoop = wide && path_wcoop_eligible(a, *wide) && path_wcoop_workgroups(wide->n, q) <= c->num_cu * 3 / 4;
+    const bool wcoop0 = wide && path_wcoop_eligible(a, *wide) && path_wcoop_workgroups(wide->n, q) <= c->num_cu * 3 / 4;
     // (... unless the few extra workgroups of the cut partition cost a whole penalty set its place beside the others)
-    const bool cut = wcoop && !cst.empty() &&
+    const bool cut = wcoop0 && !cst.empty() && path_wcoop_sets(wide->n, q, npen, c->num_cu, (int)cst.size() - 1) >= 1 &&
                      path_wcoop_sets(wide->n, q, npen, c->num_cu, (int)cst.size() - 1) >= path_wcoop_sets(wide->n, q, npen, c->num_cu, 0);
     const int *wcst = cut ? (const int *)(dblob + o_cst) : nullptr;
-    const int wg_n = wcst ? (int)cst.size() - 1 : (wcoop ? path_wcoop_workgroups(wide->n, q) : 0);
-    const int wsets = wcoop ? path_wcoop_sets(wide->n, q, npen, c->num_cu, wg_n) : 1;
+    const int wg_n = wcst ? (int)cst.size() - 1 : (wcoop0 ? path_wcoop_workgroups(wide->n, q) : 0);
+    const int wsets = wcoop0 ? path_wcoop_sets(wide->n, q, npen, c->num_cu, wg_n) : 1;
+    const bool wcoop = wcoop0 && wsets >= 1;          // (0 sets: the exchange scratch cannot hold this partition -- the launches of run_path_wide take the call)
     if (wcoop) slots.take(c->device, wg_n * wsets, c->num_cu * 3 / 4);
     // ... and where it does not fit: the same persistent launch re-reading its column tiles every iteration (path_wstream_kernel)
     const int wsg = c->num_cu * 3 / 4 < WCOOP_GMAX ? c->num_cu * 3 / 4 : WCOOP_GMAX;

@@ -1133,7 +1133,26 @@ static size_t wcoop_set_doubles(int n, int p, int G)
     const size_t SL = ((size_t)n + G - 1) / G;
     return 2 * ((size_t)G * G * SL * 2) + 2 * ((size_t)L.npad() * 2) + 2 * ((size_t)G * 4 * wc_cw(L.nr) * 2) + 2 * ((size_t)G * 2) + 64;
 }
-// workgroup sets (one per penalty) that may run side by side: all of them resident at once, on three quarters of the CUs at most
+// What the scratch is sized for (wide_scratch_doubles): every partition the launch may pick -- G' workgroups for G <= G' <= Gx (a
+// partition cut at group boundaries needs a few more than p / (4 CW)) -- with as many sets as 192 CUs hold.  A set's size is NOT
+// monotone in G' (2 G'^2 ceil(n / G') pairs: the slice length drops when G' passes a divisor of n), so the bound is the maximum
+// over the range, not the value at Gx (n = 100, p = 6,300 asked for 104,724 doubles of the 93,072 sized at Gx and the
+// launch refused itself).
+static int wcoop_sized_sets(int G) { int s = 192 / G; if (s > WCOOP_MAX_SETS) s = WCOOP_MAX_SETS; return s < 1 ? 1 : s; }
+size_t path_wcoop_xchg_doubles(int n, int p)
+{
+    const int G = path_wcoop_workgroups(n, p), Gx = path_wcoop_max_workgroups(n, p);
+    if (G < 1 || G > WCOOP_GMAX) return 0;
+    size_t m = 0;
+    for (int g = G; g <= Gx; ++g) {
+        const size_t b = wcoop_set_doubles(n, p, g) * (size_t)wcoop_sized_sets(g);
+        if (b > m) m = b;
+    }
+    return m;
+}
+// workgroup sets (one per penalty) that may run side by side: all of them resident at once, on three quarters of the CUs at most,
+// and never more than the scratch was sized for (a device with more than 256 CUs would otherwise ask for more: ADVICE r3).
+// 0: not even one set of G workgroups fits the scratch (the caller then takes the launch-per-iteration engine).
 int path_wcoop_sets(int n, int p, int npen, int num_cu, int G)
 {
     if (G < 1) G = path_wcoop_workgroups(n, p);
@@ -1142,15 +1161,25 @@ int path_wcoop_sets(int n, int p, int npen, int num_cu, int G)
     if (s > WCOOP_MAX_SETS) s = WCOOP_MAX_SETS;
     if (s > npen) s = npen;
     if (getenv("OEM_WCOOP_ONE_SET")) s = 1;
-    return s < 1 ? 1 : s;
+    if (s < 1) s = 1;
+    const size_t have = path_wcoop_xchg_doubles(n, p), one = wcoop_set_doubles(n, p, G);
+    if (one == 0 || one > have) return 0;
+    while (s > 1 && one * (size_t)s > have) --s;
+    return s;
 }
-size_t path_wcoop_xchg_doubles(int n, int p)
+// host-only check of the two functions above against the launch's own test (tests/test_host_api.py sweeps it without a GPU):
+// 0 if every partition size the launch may pick gets at least one set and never more than were sized
+extern "C" __attribute__((visibility("default"))) int oemgpu_selftest_wcoop_sizing(int32_t n, int32_t p, int32_t npen, int32_t num_cu)
 {
     const int G = path_wcoop_workgroups(n, p), Gx = path_wcoop_max_workgroups(n, p);
     if (G < 1 || G > WCOOP_GMAX) return 0;
-    int s = 192 / G;                                               // (256 CUs; fewer CUs: fewer sets)
-    if (s > WCOOP_MAX_SETS) s = WCOOP_MAX_SETS;
-    return wcoop_set_doubles(n, p, Gx) * (size_t)(s < 1 ? 1 : s);
+    const size_t have = path_wcoop_xchg_doubles(n, p);
+    for (int g = G; g <= Gx; ++g) {
+        const int s = path_wcoop_sets(n, p, npen, num_cu, g);
+        if (s < 1) return g;                                         // a partition the launch would have to refuse
+        if (wcoop_set_doubles(n, p, g) * (size_t)s > have) return -g;
+    }
+    return 0;
 }
 
 // OEM_NO_WCOOP=1: the launch-per-iteration engine; OEM_WCOOP_MAXG: fewer workgroups allowed (experiments)
@@ -1209,7 +1238,9 @@ size_t path_wstream_xchg_doubles(int n)
 {
     const WideLayout L = wide_layout(n);
     if (L.nb != 1 || L.nr < 1 || L.nr > 8) return 0;
-    return wstream_xchg_doubles_for(n, WCOOP_GMAX, L.nr);       // (fewer workgroups: less)
+    size_t m = 0;                                                // (G^2 ceil(n / G) is not monotone in G: a device with fewer CUs runs fewer workgroups)
+    for (int g = 1; g <= WCOOP_GMAX; ++g) { const size_t b = wstream_xchg_doubles_for(n, g, L.nr); if (b > m) m = b; }
+    return m;
 }
 static int wstream_chunks(int p, int G, int nr) { const int per = 4 * G * wc_cw(nr); return (p + per - 1) / per; }
 // Where it is taken is a measurement (tools/wstream_time.py, streamed against the launch-per-iteration engine, us per iteration): columns

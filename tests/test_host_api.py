@@ -162,3 +162,23 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     assert r.returncode == 2 and r.stdout == ""
     err = [l for l in r.stderr.splitlines() if l.strip()]
     assert len(err) == 1 and "--gpus 64" in err[0] and "Traceback" not in r.stderr
+
+
+def test_persistent_wide_engine_scratch_holds_every_partition():
+    """the exchange scratch of path_wcoop was sized at the LARGEST workgroup count although a set's size is not monotone
+    in it (n = 100, p = 6,300: 104,724 doubles needed, 93,072 sized -- the launch refused itself).  Host arithmetic only: every
+    (n, workgroup count) the engine can be asked for gets >= 1 set and never more sets than fit, on 256- and 304-CU devices."""
+    import oem_amd
+    L = oem_amd.lib()
+    for n, p in ((100, 6300), (960, 2912), (192, 12200), (36, 2000), (500, 2000), (1000, 3000)):
+        for npen in (1, 3, 8):
+            assert L.oemgpu_selftest_wcoop_sizing(n, p, npen, 256) == 0, (n, p, npen)
+    bad = []
+    for n in range(1, 1025):
+        cpg = 64 if n <= 256 else (32 if n <= 512 else 16)       # columns per workgroup by column height (path_wcoop.hip: wc_cw)
+        for G in list(range(1, 193, 7)) + [99, 141, 150, 182, 191, 192]:
+            p = max(n, G * cpg - 3)
+            for npen, cu in ((1, 256), (8, 256), (8, 304), (2, 128)):
+                if L.oemgpu_selftest_wcoop_sizing(n, p, npen, cu) != 0:
+                    bad.append((n, p, npen, cu))
+    assert not bad, bad[:10]
