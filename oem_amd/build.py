@@ -14,7 +14,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "liboemgpu.so"
-SOURCES = ["api.hip", "hoststream.hip", "gram.hip", "path_small.hip", "path_coop.hip", "path_wcoop.hip", "path_large.hip", "xval.hip", "sparse.hip", "wide.hip"]
+SOURCES = ["api.hip", "hoststream.hip", "gram.hip", "path_small.hip", "path_coop.hip", "path_symcoop.hip", "path_wcoop.hip", "path_large.hip", "xval.hip", "sparse.hip", "wide.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
@@ -118,6 +118,29 @@ def audit_round_spills(asm_text, limit=16):
     return problems
 
 
+def audit_symcoop_isa(asm_text):
+    """path_symcoop.hip keeps two tiles of every wave in AGPRs a0..a255 that only its inline asm names.  That is only sound if
+    hipcc itself never uses the accumulator file in those kernels (its own values must fit the architectural VGPRs) and never
+    spills to scratch: check both on the emitted ISA."""
+    problems, found = [], 0
+    for m in re.finditer(r"^(_ZN6oemgpu\S*path_symcoop_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end", asm_text, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        found += 1
+        in_asm = False
+        for line in body.splitlines():
+            if "#ASMSTART" in line:
+                in_asm = True
+            elif "#ASMEND" in line:
+                in_asm = False
+            elif not in_asm and ("v_accvgpr" in line or re.search(r"\ba\[?\d+", line.split(";")[0])):
+                problems.append(f"{name}: compiler-emitted {line.strip()}")
+            if "scratch_" in line:
+                problems.append(f"{name}: scratch access {line.strip()}")
+    if found == 0:
+        problems.append("no path_symcoop kernel found in the ISA listing (the audit pattern is stale)")
+    return problems
+
+
 def build_diag():
     """liboemgpu_diag.so: the same library with -DOEM_PATH_DIAG (stamped round segments); never the product."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -151,7 +174,7 @@ def build(force=False, verbose=False):
             objs.append(str(o))
         # ISA audits: asm-owned accumulators (gram.hip), DPP hazards of the inline-asm FMAs (the register-resident path engines)
         listing = {src: ex.submit(subprocess.run, [hipcc, *FLAGS, "-S", "--cuda-device-only", "-o", "-", str(CSRC / src)],
-                                  check=True, capture_output=True, text=True) for src in ("gram.hip", "path_small.hip", "path_coop.hip", "path_wcoop.hip")}
+                                  check=True, capture_output=True, text=True) for src in ("gram.hip", "path_small.hip", "path_coop.hip", "path_wcoop.hip", "path_symcoop.hip")}
         for j in jobs:
             j.result()
         problems = audit_gram_isa(listing["gram.hip"].result().stdout)
@@ -161,6 +184,9 @@ def build(force=False, verbose=False):
             problems = audit_dpp_hazards(listing[src].result().stdout)
             if problems:
                 raise RuntimeError(src + " ISA audit failed:\n  " + "\n  ".join(problems[:20]))
+        problems = audit_symcoop_isa(listing["path_symcoop.hip"].result().stdout)
+        if problems:
+            raise RuntimeError("path_symcoop.hip ISA audit failed:\n  " + "\n  ".join(problems[:20]))
         problems = audit_round_spills(listing["path_small.hip"].result().stdout)
         if problems:
             raise RuntimeError("path_small.hip round-spill audit failed:\n  " + "\n  ".join(problems[:20]))

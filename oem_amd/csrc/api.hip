@@ -314,6 +314,20 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
         if (!ok || (int)cst.size() - 1 > gmax || (int)cst.size() - 1 > c->num_cu * 3 / 4) cst.clear();
     }
     const size_t o_cst = cst.empty() ? 0 : bl.add(cst.data(), sizeof(int) * cst.size());
+    // 1024 < q <= 4096, element-wise penalties: the lower triangle of XX in the registers of <= 3/4 of the CUs (path_symcoop.hip);
+    // the plan is a pure function of (q, CUs): kept from call to call
+    static thread_local SymcoopPlan symplan;
+    static thread_local int symplan_q = 0, symplan_gmax = 0;
+    bool symc = false;
+    if (!wide && nbatch == 1 && q > 1024 && q <= 4096 && !any_grp && !scale_factor && !getenv("OEM_NO_SYMCOOP") && !getenv("OEM_NO_COOP")) {
+        const int gmax = c->num_cu * 3 / 4 < WCOOP_GMAX ? c->num_cu * 3 / 4 : WCOOP_GMAX;
+        if (symplan_q != q || symplan_gmax != gmax || getenv("OEM_SYMCOOP_NT")) {
+            if (!symcoop_plan(q, gmax, symplan)) symplan = SymcoopPlan();
+            symplan_q = q; symplan_gmax = gmax;
+        }
+        symc = !symplan.tab.empty();
+    }
+    const size_t o_symp = symc ? bl.add(symplan.tab.data(), sizeof(int) * symplan.tab.size()) : 0;
 
     // ---- outputs region (device) : beta | lambda | loss | d[2] | niter | stats copy
     const size_t nb = (size_t)npen * nl * q, nk = (size_t)npen * nl;
@@ -335,6 +349,8 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     if (const char *e = getenv("OEMGPU_LANCZOS_CAP")) { const int k = atoi(e); if (k >= 2 && k < lan) lan = k; }     // test knob: reach the cap
     size_t work_d = small ? path_small_xchg_bytes() / 8 : path_large_work_doubles(q, lan);
     if (coop && work_d < path_coop_xchg_bytes() / 8) work_d = path_coop_xchg_bytes() / 8;
+    const size_t sym_off_d = (work_d + 31) / 32 * 32;                 // the exchange area of path_symcoop.hip behind the launch-per-iteration engines' workspace (the fallback needs both)
+    if (symc) work_d = sym_off_d + (symcoop_xchg_bytes(symplan) + 7) / 8;
     // the outputs come first: when the caller's frame ends with `stats` (both callers), stats | outputs is one
     // contiguous range and one device-to-host copy returns both
     // one workgroup (set) per penalty: they are independent cold starts (the cooperating sets must all be resident: <= half the CUs)
@@ -407,6 +423,8 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     }
     CoopSlots slots;                                  // held until the stream has been synchronised below
     if (coop) slots.take(c->device, path_coop_workgroups(q) * (pen_split ? npen : 1) * nbatch, c->num_cu * 3 / 4);
+    const bool symcoop = symc && path_symcoop_eligible(a, any_grp);
+    if (symcoop) slots.take(c->device, symplan.G, c->num_cu * 3 / 4);
     // p >= n with Xs small enough for the register files of <= 192 CUs: one persistent launch (path_wcoop.hip)
     // (all of a set's workgroups must be resident at once: never more of them than three quarters of this device's CUs)
     const bool wcoop0 = wide && path_wcoop_eligible(a, *wide) && path_wcoop_workgroups(wide->n, q) <= c->num_cu * 3 / 4;
@@ -426,12 +444,13 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     // shared GPU) their exchanges time out after about a second and poison the result: the call is then made again on the
     // launch-per-iteration engines, which wait for nobody.
     for (int attempt = 0;; ++attempt) {
-        const bool persistent = (wcoop || wstream || (coop && nbatch == 1)) && attempt == 0;
+        const bool persistent = (wcoop || wstream || symcoop || (coop && nbatch == 1)) && attempt == 0;
         {
             Timer t(c, OEMGPU_T_EIGPATH);
             PollScope poll(o);
             int rc;
-            if (persistent) rc = wcoop ? launch_path_wcoop(c->stream, a, *wide, wsets, wcst, wg_n) : wstream ? launch_path_wstream(c->stream, a, *wide, wsg) : launch_path_coop(c->stream, a);
+            if (persistent && symcoop) rc = launch_path_symcoop(c->stream, a, symplan, (const int *)(dblob + o_symp), a.work + sym_off_d);
+            else if (persistent) rc = wcoop ? launch_path_wcoop(c->stream, a, *wide, wsets, wcst, wg_n) : wstream ? launch_path_wstream(c->stream, a, *wide, wsg) : launch_path_coop(c->stream, a);
             else if (wide) rc = run_path_wide(c->stream, a, *wide, (double *)c->pinned);
             else if (small) rc = launch_path_small(c->stream, a);
             else if (coop && attempt == 0) rc = launch_path_coop(c->stream, a);                 // (several instances: no second engine takes them)
@@ -522,6 +541,7 @@ size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o, int nbatch = 1)
     size_t wk = q > SMALL_P_MAX ? path_large_work_doubles(q, 128) * 8 : path_small_xchg_bytes();
     if (q >= path_coop_min_q(true) && q <= 1024 && wk < path_coop_xchg_bytes()) wk = path_coop_xchg_bytes();
     b += wk * splits + 4096;
+    if (q > 1024 && q <= 4096) b += symcoop_xchg_bytes_max(q) + (size_t)(80 + WCOOP_GMAX * 96) * 4 + 1024;      // path_symcoop.hip's exchange area and plan
     return b;
 }
 

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/oemgpu.h"
 
 namespace oemgpu {
@@ -163,6 +165,18 @@ bool path_coop_eligible(int q, bool has_sinv, bool compute_loss, int ngroups, in
 int path_coop_workgroups(int q);
 size_t path_coop_xchg_bytes();
 int launch_path_coop(hipStream_t s, const PathArgs &a);
+
+// 1024 < p <= 4096, element-wise penalties: one persistent launch with the lower triangle of XX in the register files of <= 192 CUs
+// (path_symcoop.hip).  The plan (tiles per wave, blocks per workgroup, senders per block) is pure host arithmetic.
+struct SymcoopPlan {
+    int q = 0, T = 0, NT = 0, G = 0, nsum = 0, e1n = 0;    // 64-blocks, tiles per wave, workgroups, sender rows of exchange 1, sender sweeps per owner
+    std::vector<int> tab;                                   // blkbase[80] then G records (uploaded as is)
+};
+bool symcoop_plan(int q, int gmax, SymcoopPlan &P);
+size_t symcoop_xchg_bytes(const SymcoopPlan &P);
+size_t symcoop_xchg_bytes_max(int q);
+bool path_symcoop_eligible(const PathArgs &a, bool group_penalty);
+int launch_path_symcoop(hipStream_t s, const PathArgs &a, const SymcoopPlan &P, const int *plan_dev, void *xchg);
 
 // ------------------------------------------------------------------ p >= n (wide.hip, path_large.hip: run_path_wide)
 // The reference's own iteration for p >= n: no Gram, two products with the standardised X per iteration

@@ -1,0 +1,813 @@
+// path_symcoop.hip -- eigenvalue + penalty x lambda path for 1024 < q <= 4096 (config 4: oem.xtx at p = 4096): ONE persistent launch
+// of cooperating workgroups with the LOWER TRIANGLE of XX resident in the register files of the chip.
+//
+// Replaces, for element-wise penalties at these sizes, the launch-per-iteration engines of path_large.hip, which stream the matrix
+// (oem_symfused_kernel: its lower triangle, 69 MB at q = 4096) from the Infinity Cache once per OEM iteration: 15.8 us per iteration,
+// 3,504 of them in config 4.  The lower triangle of a 4096 x 4096 FP64 matrix is 67 MB; the register files of 176 CUs hold 88 MB.
+// So nothing is streamed at all.  Same arithmetic as the other engines (ref src/oem_xtx.h:378-381, src/oem_dense.h:501-524, 76-149,
+// src/oem_base.h:90-110, src/utils.cpp:537-549, src/oem_dense.cpp:175-297):
+//
+//   tiles      XX in 64 x 64 tiles, only I >= J.  A wave keeps NT of them (1, 2 or 3: 128 NT registers per lane, the compiler's
+//              VGPR + AGPR file of a one-wave-per-SIMD kernel), a workgroup 4 NT -- a patch of a few tile rows x tile columns.
+//              Lane (rl, cl) of a tile holds the 8 x 8 sub-block of rows 16 (i >> 1) + 2 rl + (i & 1), columns likewise with cl.
+//   products   a tile feeds BOTH products it holds: g_I += T beta_J ("direct") and g_J += T' beta_I ("transposed"; not for the
+//              diagonal tiles, which are stored whole): 128 plain FMAs per lane and tile against 8 + 8 vector entries read from
+//              LDS.  The eight column lanes of a row (and the eight row lanes of a column) meet in a transposed butterfly:
+//              v_permlane32_swap / v_permlane16_swap for the first halving (both directions in one instruction, no select),
+//              two DPP stages after it; the lane bits are dealt so that every partner holds the same rows (or columns).
+//   exchange   what crosses workgroups is an ALL-REDUCE of the q-vector in two SPARSE exchanges through the memory side, as
+//              data-tagged 16-byte pairs {lo, tag, hi, tag} (path_coop.hip's recipe: the data is the flag, sc1 stores and polls,
+//              one poll sweep in flight, two buffers by parity):
+//                1. a workgroup adds its waves' partial vectors per 64-block in LDS (fixed order) and sends each block to the
+//                   owners of its coordinates: block B receives one partial from every workgroup whose patch touches tile row
+//                   or tile column B (16-27 of them, not G); the owner of a slice of q / G coordinates adds them in sender
+//                   order (interleaved chains combined by DPP: bitwise reproducible), applies the operator -- it is
+//                   coordinate-local -- and the stop rule to ITS coordinates;
+//                2. the owners publish their coordinates of the new beta and every workgroup gathers the blocks its patch
+//                   touches (448 values for a 3 x 4 patch, not q).
+//   stop rule  the "still moving" bit of a coordinate rides in the tag of its pair in exchange 2; a workgroup ORs what it gathers
+//              and sends that bit in the tags of the NEXT exchange 1.  For any two blocks some patch touches both (the tile
+//              (max, min) exists), so after that exchange every owner holds the OR over all coordinates: the decision about
+//              iteration t is taken by everybody, identically, at iteration t + 1 -- exactly the "replicated one launch later"
+//              bookkeeping of oem_fused_kernel / oem_symfused_kernel (u does not depend on lambda, so the iteration that detects
+//              convergence at lambda_i already is the first one of lambda_{i+1}).  No flag or scalar of its own crosses.
+//   Lanczos    on the same registers with the same two exchanges; alpha = v'XXv as the sum of the workgroups' v . partial (one
+//              more pair per workgroup next to exchange 1) and ||w'||^2 as the owners' parts next to exchange 2, both added in
+//              workgroup order by everybody: two hops per step.  Top Ritz value by the Sturm multisection of path_dev.hpp.
+// Every spin is bounded; a timeout poisons d_out[6] and the host makes the call again on the launch-per-iteration engine.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+#include "penalty_ops.hpp"
+#include "path_dev.hpp"
+
+namespace oemgpu {
+
+namespace {
+
+constexpr int SNTH = 256;         // threads per workgroup: one wave per SIMD (512 registers per lane)
+constexpr int SNB = 16;           // 64-blocks of the vector a workgroup's patch may touch
+constexpr int SE1 = 4;            // senders per owned coordinate / 8, at most
+constexpr int SE2 = (SNB * 64) / SNTH;
+constexpr int SCML = 512;         // Lanczos steps kept
+constexpr int SSL = SNTH / 8;     // coordinates a workgroup may own
+// per-workgroup plan record (ints)
+enum { SW_NB = 0, SW_C0 = 1, SW_NSL = 2, SW_BLK = 4, SW_RANK = SW_BLK + SNB, SW_TILE = SW_RANK + SNB, SW_CST = SW_TILE + 12,
+       SW_CEN = SW_CST + SNB + 1, SW_INTS = SW_CEN + 24 + 7 };
+static_assert(SW_INTS == 96, "plan record");
+constexpr int SPLAN_HEAD = 80;    // blkbase[T + 1], T <= 64
+
+#ifdef OEM_PATH_DIAG
+__device__ unsigned long long g_diag_symcoop[16];
+#define SX_STAMP(slot)                                                                     \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        unsigned long long t__;                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        X.acc[slot] += t__ - X.last;                                                       \
+        X.last = t__;                                                                      \
+    } while (0)
+#else
+#define SX_STAMP(slot) do { } while (0)
+#endif
+
+typedef unsigned sx_v4u __attribute__((ext_vector_type(4)));
+struct SymX {
+#ifdef OEM_PATH_DIAG
+    unsigned long long acc[16], last;
+#endif
+    __amdgpu_buffer_rsrc_t rs;    // exchange 1 at 0: [2 parities][nsum * 64] pairs; o2: exchange 2, [2][64 T] pairs; o3 / o4: the workgroups'
+    int o2, o3, o4;               // parts of alpha / of ||w'||^2 (Lanczos), [2][G] pairs each (byte offsets)
+    int s1, s2;                   // bytes per parity of exchange 1 / 2
+    unsigned epoch;               // all-reduce counter, never 0; identical in every workgroup
+    int wg, G;
+    bool failed;
+};
+
+__device__ __forceinline__ void sx_publish(__amdgpu_buffer_rsrc_t rs, int off, double val, unsigned tag)
+{
+    sx_v4u v;
+    v.x = (unsigned)__double2loint(val); v.y = tag; v.z = (unsigned)__double2hiint(val); v.w = tag;
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);       // aux 16: sc1 (device scope)
+}
+
+// E pairs per thread at byte offsets off[k] (need bit k), polled until both tags carry this epoch; the low tag bits are OR-ed into
+// `flags`.  One 16-byte load per pair, one sweep in flight, a pair that has arrived is not asked for again (tools/xchg_probe.hip).
+template <int E>
+__device__ __forceinline__ void sx_gather(const int (&off)[E], unsigned need, double (&out)[E], int &flags, SymX &X)
+{
+    sx_v4u pv[E];
+    unsigned miss = need;
+#pragma unroll
+    for (int k = 0; k < E; ++k) pv[k] = sx_v4u{0u, 0u, 0u, 0u};
+    unsigned spins = 0;
+    const unsigned limit = X.failed ? 0u : 1000000u;            // ~1 s: a partner is gone; after one timeout nobody waits again
+    bool ok = true;
+    while (__any(miss != 0u)) {
+#pragma unroll
+        for (int k = 0; k < E; ++k)
+            if ((miss >> k) & 1u) pv[k] = __builtin_amdgcn_raw_buffer_load_b128(X.rs, off[k], 0, 16);
+#pragma unroll
+        for (int k = 0; k < E; ++k)
+            if (((miss >> k) & 1u) && (pv[k].y >> 1) == X.epoch && (pv[k].w >> 1) == X.epoch) miss &= ~(1u << k);
+        if (++spins >= limit && __any(miss != 0u)) { ok = false; break; }
+    }
+    if (!ok) X.failed = true;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const bool nd = ((need >> k) & 1u) != 0 && ((miss >> k) & 1u) == 0;
+        out[k] = nd ? __hiloint2double((int)pv[k].z, (int)pv[k].x) : 0.0;
+        if (nd) flags |= (int)(pv[k].y & 1u);
+    }
+}
+
+__device__ __forceinline__ double sx_block_sum(double v, double *red, int &rpar, int w, int lane)
+{
+    const double s = wave_sum(v);
+    double *r = red + 4 * rpar;
+    if (lane == 0) r[w] = s;
+    __syncthreads();
+    const double t = (r[0] + r[1]) + (r[2] + r[3]);
+    rpar ^= 1;                    // the next call writes the other half: no second barrier needed
+    return t;
+}
+__device__ __forceinline__ void sx_vote(int *words, int w, int lane, int bit)
+{
+    const int wb = __ballot(bit != 0) != 0ull ? 1 : 0;
+    if (lane == 0) words[w] = wb;
+}
+
+// both halves of a v_permlane{16,32}_swap of two doubles, added: lanes whose bit is 0 get a(own) + a(partner), the others b(partner) + b(own)
+template <bool SW32> __device__ __forceinline__ double sx_swap_add(double a, double b)
+{
+    const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    if constexpr (SW32) {
+        auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    } else {
+        auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    }
+}
+template <int CTRL> __device__ __forceinline__ double sx_dpp_stage(double lo, double hi, bool sel)
+{
+    const double keep = sel ? hi : lo, send = sel ? lo : hi;
+    return keep + dpp_mov<CTRL, 0xf>(send, 0.0);
+}
+
+// Where a wave keeps its tiles.  The register file belongs to the matrix, and hipcc's own allocation is not to be trusted with it
+// (three tiles as plain arrays: 512 registers, 57 spilled into the loop): tiles 0 and 1 live in AGPRs a0..a255 that ONLY the inline
+// asm below names -- the compiler's own values fit the 256 architectural VGPRs, so it never touches the accumulator file
+// (oem_amd/build.py: audit_symcoop_isa proves that on the emitted ISA, as for the Gram kernels) -- and the third tile of a wave
+// (q > 3456) half in VGPRs (rows 0..3 of the lane's 8 x 8 sub-block), half in LDS (rows 4..7: sixteen 16-byte reads per lane,
+// [read][lane], a wave's read 1 KiB contiguous).
+template <int IDX> __device__ __forceinline__ double sx_areg_rd()
+{
+    unsigned l, h;
+    asm volatile("v_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]" : "=v"(l), "=v"(h) : "n"(2 * IDX), "n"(2 * IDX + 1));
+    return __hiloint2double((int)h, (int)l);
+}
+template <int IDX> __device__ __forceinline__ void sx_areg_wr(double x)
+{
+    asm volatile("v_accvgpr_write_b32 a[%2], %0\n\tv_accvgpr_write_b32 a[%3], %1" ::"v"(__double2loint(x)), "v"(__double2hiint(x)), "n"(2 * IDX), "n"(2 * IDX + 1));
+}
+
+// The products of ONE tile with the vector blocks at Bsh + oI (rows) and Bsh + oJ (columns), reduced over the lanes.
+// DD: the direct product (T vec_J) -> Wd[64]; TT: the transposed one (T' vec_I) -> Wt[64].  One pass over the tile feeds both.
+// ST: 0 / 1 = the tile in AGPRs a[128 ST ..]; 2 = rows 0..3 in vlo, rows 4..7 in LDS at lt.
+// Lane bits: rl = (b4, b3, b2), cl = (b5, b1 ^ b2, b0 ^ b2) -- the partners of the direct reduction (lane ^ 32, ^ 2, ^ 1) keep rl, those
+// of the transposed one (lane ^ 16, ^ 8, ^ 7) keep cl.
+template <bool DD, bool TT, int ST>
+__device__ __forceinline__ void sx_tile(const double (&vlo)[32], const double *lt, const double *Bsh, int oI, int oJ, unsigned mI, unsigned mJ,
+                                        double *Wd, double *Wt, int lane, int rlv, int clv)
+{
+    double bj[8], bi[8], ad[8], at[8];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        if (DD) { const v2d cj = *reinterpret_cast<const v2d *>(Bsh + oJ + 16 * h + 2 * clv); bj[2 * h] = cj.x; bj[2 * h + 1] = cj.y; }
+        if (TT) { const v2d ci = *reinterpret_cast<const v2d *>(Bsh + oI + 16 * h + 2 * rlv); bi[2 * h] = ci.x; bi[2 * h + 1] = ci.y; }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ad[k] = 0.0; at[k] = 0.0; }
+    // rows i, columns 2 jj and 2 jj + 1 of the lane's sub-block
+    auto cell = [&](auto I_, auto J_) {
+        constexpr int i = decltype(I_)::value, jj = decltype(J_)::value;
+        double x0, x1;
+        if constexpr (ST < 2) { x0 = sx_areg_rd<ST * 64 + i * 8 + 2 * jj>(); x1 = sx_areg_rd<ST * 64 + i * 8 + 2 * jj + 1>(); }
+        else if constexpr (i < 4) { x0 = vlo[i * 8 + 2 * jj]; x1 = vlo[i * 8 + 2 * jj + 1]; }
+        else { const v2d t = *reinterpret_cast<const v2d *>(lt + (((i - 4) * 4 + jj) * 64 + lane) * 2); x0 = t.x; x1 = t.y; }
+        if (DD) { ad[i] = fma(x0, bj[2 * jj], ad[i]); }
+        if (TT) { at[2 * jj] = fma(x0, bi[i], at[2 * jj]); }
+        if (DD) { ad[i] = fma(x1, bj[2 * jj + 1], ad[i]); }
+        if (TT) { at[2 * jj + 1] = fma(x1, bi[i], at[2 * jj + 1]); }
+    };
+    if constexpr (DD && TT) {
+        static_for_dev<8>([&](auto I_) { static_for_dev<4>([&](auto J_) { cell(I_, J_); }); });
+    } else if constexpr (DD) {
+        // only the 16-column groups of the vector block that hold a non-zero (a lasso iterate is sparse inside its blocks too)
+        static_for_dev<4>([&](auto J_) {
+            if ((mJ >> decltype(J_)::value) & 1u) static_for_dev<8>([&](auto I_) { cell(I_, J_); });
+        });
+    } else {
+        static_for_dev<4>([&](auto H_) {                             // ... the 16-row groups
+            constexpr int ii = decltype(H_)::value;
+            if ((mI >> ii) & 1u) static_for_dev<4>([&](auto J_) {
+                cell(std::integral_constant<int, 2 * ii>{}, J_); cell(std::integral_constant<int, 2 * ii + 1>{}, J_);
+            });
+        });
+    }
+    if (DD) {   // over cl -- lane ^ 32, lane ^ 2, lane ^ 1; this lane ends with row index i = clv
+        const bool sc1 = ((clv >> 1) & 1) != 0, sc0 = (clv & 1) != 0;
+        double n1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) n1[i] = sx_swap_add<true>(ad[i], ad[4 + i]);
+        const double n20 = sx_dpp_stage<0x4E>(n1[0], n1[2], sc1), n21 = sx_dpp_stage<0x4E>(n1[1], n1[3], sc1);
+        Wd[16 * (clv >> 1) + 2 * rlv + (clv & 1)] = sx_dpp_stage<0xB1>(n20, n21, sc0);
+    }
+    if (TT) {   // over rl -- lane ^ 16, lane ^ 8 (row_ror:8), lane ^ 7 (row_half_mirror); this lane ends with column index j = rlv
+        const bool sb3 = (lane & 8) != 0, sb2 = (lane & 4) != 0;
+        double m1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m1[j] = sx_swap_add<false>(at[j], at[4 + j]);
+        const double m20 = sx_dpp_stage<0x128>(m1[0], m1[2], sb3), m21 = sx_dpp_stage<0x128>(m1[1], m1[3], sb3);
+        Wt[16 * (rlv >> 1) + 2 * clv + (rlv & 1)] = sx_dpp_stage<0x141>(m20, m21, sb2);
+    }
+}
+
+// element-wise operators (ref src/oem_dense.h:76-149), branch-free inside a kind.  The constants of the lambda in use live in LDS
+// (the register file belongs to the matrix): kind, L, D, 1/D, gamma D, D - 1/gamma and its reciprocal, gamma - 1, gamma,
+// (gamma - 1) D - 1 and its reciprocal, d, 1/d
+enum { TH_L = 0, TH_D, TH_RD, TH_GAMMAD, TH_DMG, TH_RDMG, TH_GM1, TH_GAMMA, TH_DSC, TH_RDSC, TH_D0, TH_RD0, TH_N };
+__device__ __forceinline__ void sx_thr_store(double *th, int *kind, const PenK &K, double d)
+{
+    *kind = K.kind;
+    th[TH_L] = K.L; th[TH_D] = K.D; th[TH_RD] = 1.0 / K.D; th[TH_GAMMAD] = K.gamma * K.D;
+    const double dmg = K.D - 1.0 / K.gamma, gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0;
+    th[TH_DMG] = dmg; th[TH_RDMG] = 1.0 / dmg; th[TH_GM1] = gm1; th[TH_GAMMA] = K.gamma; th[TH_DSC] = dsc; th[TH_RDSC] = 1.0 / dsc;
+    th[TH_D0] = d; th[TH_RD0] = 1.0 / d;
+}
+__device__ __forceinline__ double sx_op(double u, double pf, int kind, const double (&th)[TH_N])
+{
+    const double tp = pf * th[TH_L];
+    if (kind == K_SOFT) return cdiv(shrink(u, tp), th[TH_D], th[TH_RD]);
+    if (kind == K_MCP) {
+        const bool big = fabs(u) > th[TH_GAMMAD] * tp;
+        return cdiv(big ? u : shrink(u, tp), big ? th[TH_D] : th[TH_DMG], big ? th[TH_RD] : th[TH_RDMG]);
+    }
+    if (kind == K_SCAD) {
+        const double au = fabs(u), D = th[TH_D];
+        const bool big = au > th[TH_GAMMAD] * tp, mid = !big && au > (D + 1.0) * tp;
+        const double num = big ? u : (mid ? shrink(th[TH_GM1] * u, th[TH_GAMMA] * tp) : shrink(u, tp));
+        return cdiv(num, mid ? th[TH_DSC] : D, mid ? th[TH_RDSC] : th[TH_RD]);
+    }
+    return cdiv(u, th[TH_D0], th[TH_RD0]);
+}
+
+// wave-uniform doubles into SGPRs (the spilled ones cost a lane of a VGPR, not a VGPR pair: the register file belongs to the matrix)
+__device__ __forceinline__ double sx_uni(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+template <int NT>
+__global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const int *__restrict__ plan, unsigned long long *xchg, int T, int nsum, int e1n)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int q = A.p, wg = blockIdx.x, G = gridDim.x;
+    const unsigned long long t_cyc0 = __builtin_amdgcn_s_memtime(), t_rt0 = __builtin_amdgcn_s_memrealtime();
+    double *Bsh = lds;                                   // the vector going into the product, by block slot [SNB][64]
+    double *Wp = Bsh + SNB * 64;                         // the waves' reduced tile products [8 NT][64]
+    double *Tal = Wp + (8 * NT + 1) * 64, *Tbe = Tal + SCML;   // (a row of zeros behind Wp;) Lanczos alpha, beta
+    double *sturm = Tbe + SCML;                          // Sturm scratch 2 (SCML + 16)
+    double *red = sturm + 2 * (SCML + 16);               // block reductions [2][4], theta slot [8], lmax words [12..16)
+    double *thr = red + 16;                              // operator constants of the lambda in use [TH_N <= 16]
+    int *votes = reinterpret_cast<int *>(thr + 16);      // [8] votes, [8] kind
+    int *nzs = votes + 16;                               // [SNB] which 16-coordinate groups of this slot of Bsh hold a non-zero (4 bits)
+    int *wv = nzs + SNB;                                 // [4] per producing wave: bit e = "entry e of Wp was computed" (then 28 spare)
+    int *rec = wv + 32;                                  // this workgroup's plan record [SW_INTS], then P1[SNB] (pairs index of exchange 1 per slot)
+    int *P1 = rec + SW_INTS;
+    double *Lt = reinterpret_cast<double *>(P1 + SNB + 8) + w * 2048;     // NT == 3: rows 4..7 of every lane's part of this wave's third tile
+    const bool writer = wg == 0;
+
+    const int *__restrict__ blkbase = plan;
+    for (int k = tid; k < SW_INTS; k += SNTH) rec[k] = plan[SPLAN_HEAD + wg * SW_INTS + k];
+    for (int k = tid; k < SNB * 64; k += SNTH) Bsh[k] = 0.0;
+    if (tid < 64) Wp[8 * NT * 64 + tid] = 0.0;
+    __syncthreads();
+    const int nb = rec[SW_NB], c0 = rec[SW_C0], nsl = rec[SW_NSL];
+    if (tid < SNB) P1[tid] = tid < nb ? (blkbase[rec[SW_BLK + tid]] + rec[SW_RANK + tid]) * 64 : 0;
+
+    // ---- the entries (reduced tile products in Wp) of this wave's block slots w, w + 4, w + 8, w + 12: at most eight each, packed as
+    // bytes (0xff: none) so that the block sums below are branch-free reads
+    unsigned elo[4], ehi[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int sl = w + 4 * m;
+        unsigned long long pk = ~0ull;
+        if (sl < nb) {
+            const int x0 = rec[SW_CST + sl], x1 = rec[SW_CST + sl + 1];
+            for (int x = x1 - 1; x >= x0; --x) pk = (pk << 8) | (unsigned long long)(rec[SW_CEN + x] & 0xff);
+        }
+        elo[m] = __builtin_amdgcn_readfirstlane((unsigned)pk); ehi[m] = __builtin_amdgcn_readfirstlane((unsigned)(pk >> 32));
+    }
+    const int nslw = __builtin_amdgcn_readfirstlane(nb > w ? (nb - w + 3) / 4 : 0);       // block slots of this wave
+    // ---- this wave's tiles: lane (rl, cl) holds the 8 x 8 sub-block of rows 16 (i >> 1) + 2 rl + (i & 1), columns alike with cl
+    const int rlv = (lane >> 2) & 7, clv = ((lane >> 5) << 2) | ((((lane >> 1) ^ (lane >> 2)) & 1) << 1) | ((lane ^ (lane >> 2)) & 1);
+    double vlo[32];                                      // NT == 3: rows 0..3 of this lane's part of the wave's third tile
+    int tI[NT], tJ[NT], tflag[NT];                       // block slots of the tile's rows / columns; 0: no tile, 1: off-diagonal, 2: diagonal
+    if constexpr (NT == 1) asm volatile("" ::: "a127"); else asm volatile("" ::: "a255");      // the accumulator file is in use (by the asm alone)
+#pragma unroll
+    for (int k = 0; k < 32; ++k) vlo[k] = 0.0;
+    static_for_dev<NT>([&](auto K_) {
+        constexpr int k = decltype(K_)::value;
+        const int t = __builtin_amdgcn_readfirstlane(rec[SW_TILE + w * NT + k]);
+        const int I = t & 0xff, J = (t >> 8) & 0xff;
+        tflag[k] = t < 0 ? 0 : (I == J ? 2 : 1);
+        tI[k] = t < 0 ? 0 : ((t >> 16) & 0xff); tJ[k] = t < 0 ? 0 : ((t >> 24) & 0x7f);
+        static_for_dev<8>([&](auto I_) {
+            constexpr int i = decltype(I_)::value;
+            const int row = 64 * I + 16 * (i >> 1) + 2 * rlv + (i & 1);
+            static_for_dev<8>([&](auto J_) {
+                constexpr int j = decltype(J_)::value;
+                const int col = 64 * J + 16 * (j >> 1) + 2 * clv + (j & 1);
+                const double x = (t >= 0 && row < q && col < q) ? A.xx[(size_t)col * q + row] : 0.0;
+                if constexpr (k < 2) sx_areg_wr<k * 64 + i * 8 + j>(x);
+                else if constexpr (i < 4) vlo[i * 8 + j] = x;
+                else Lt[(((i - 4) * 4 + (j >> 1)) * 64 + lane) * 2 + (j & 1)] = x;
+            });
+        });
+    });
+    // ---- the coordinate this thread owns (eight lanes per coordinate: the interleaved chains of the sender sum)
+    const int ocl = tid >> 3, part = tid & 7;
+    const bool own = ocl < nsl;
+    const int cg = c0 + (own ? ocl : 0);
+    const double xyc = own ? A.xy[cg] : 0.0, pfc = own ? A.pf[cg] : 0.0;
+    int goff[SE1];                                       // byte offsets (inside a parity) of this thread's senders of coordinate cg
+    unsigned need1 = 0;
+    {
+        const int B = cg >> 6, nsB = blkbase[B + 1] - blkbase[B];
+#pragma unroll
+        for (int e = 0; e < SE1; ++e) {
+            const int r = part + 8 * e;
+            const bool ok = own && e < e1n && r < nsB;
+            goff[e] = ok ? ((blkbase[B] + r) * 64 + (cg & 63)) * 16 : 0;
+            if (ok) need1 |= 1u << e;
+        }
+    }
+    __syncthreads();                                     // P1
+    int p1m[4];                                          // exchange 1: where this wave's block slots go (pairs index inside a parity)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) p1m[m] = __builtin_amdgcn_readfirstlane(w + 4 * m < nb ? P1[w + 4 * m] : 0);
+    const double tol = sx_uni(A.tol);
+    const int maxit = A.maxit, npen = A.npen;
+    int g2off[SE2];                                      // exchange 2: the coordinates of the blocks this workgroup touches (slot w + 4 k: one slot per wave and k)
+    unsigned need2 = 0;
+#pragma unroll
+    for (int k = 0; k < SE2; ++k) {
+        const int s = w + 4 * k;
+        const int j = (s < nb ? rec[SW_BLK + s] : 0) * 64 + lane;
+        const bool ok = s < nb && j < q;
+        g2off[k] = ok ? j * 16 : 0;
+        if (ok) need2 |= 1u << k;
+    }
+    SymX X;
+    X.s1 = nsum * 64 * 16; X.s2 = T * 64 * 16;
+    X.o2 = 2 * X.s1; X.o3 = X.o2 + 2 * X.s2; X.o4 = X.o3 + 2 * G * 16;
+    X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, X.o4 + 2 * G * 16, 0x00020000);
+    X.epoch = 0; X.wg = wg; X.G = G; X.failed = false;
+#ifdef OEM_PATH_DIAG
+    for (int k = 0; k < 16; ++k) X.acc[k] = 0;
+    X.last = __builtin_amdgcn_s_memtime();
+#endif
+    int rpar = 0;
+
+    // ---- Lanczos start vector (every owner keeps its coordinates of v, v_prev), the blocks of v into Bsh
+    auto start_v = [](unsigned j) { const unsigned h = j * 2654435761u + 12345u; return (double)(h >> 8) * (1.0 / 16777216.0) - 0.5; };
+    double ca, cb = 0.0;                                 // Lanczos: this coordinate of v, v_prev; path: beta_t, -
+    {
+        double nn = 0.0;
+        for (int j = tid; j < q; j += SNTH) { const double x = start_v((unsigned)j); nn = fma(x, x, nn); }
+        nn = 1.0 / sqrt(sx_block_sum(nn, red, rpar, w, lane));
+        ca = own ? start_v((unsigned)cg) * nn : 0.0;
+#pragma unroll
+        for (int k = 0; k < SE2; ++k) {
+            const bool nd = ((need2 >> k) & 1u) != 0;
+            if (nd) Bsh[(w + 4 * k) * 64 + lane] = start_v((unsigned)(g2off[k] >> 4)) * nn;
+            if (lane == 0 && w + 4 * k < SNB) nzs[w + 4 * k] = nd ? 15 : 0;
+        }
+        __syncthreads();
+    }
+    int msteps = A.lanczos_steps > SCML ? SCML : A.lanczos_steps;
+    if (q < SCML) msteps = msteps < q ? msteps : q;
+    if (msteps < 1) msteps = 1;
+    double *theta_slot = red + 8;
+    auto top_ritz = [&](int m, double hint) {
+        if (w == 0) {
+            const double th = tridiag_max(Tal, Tbe, m, lane, sturm, hint);
+            if (lane == 0) theta_slot[0] = th;
+        }
+        __syncthreads();
+        const double th = theta_slot[0];
+        __syncthreads();
+        return th;
+    };
+    int nst = 0;
+    double bprev = 0.0, theta_prev = -__builtin_inf(), mv_prev = __builtin_inf(), d = 0.0;
+    // path state (identical in every workgroup)
+    int phase = 0, pp = 0, i = 0, it = 0, pen = 0, mw = 0;
+    bool fresh = true;
+    const int nl = A.nl;
+    double scaley = 1.0, llo = 0.0, lhi = 0.0, lstep = 0.0;
+    bool lflip = false;
+    auto lambda_of = [&](int pq, int iq) {
+        if (A.user_lambda) return A.lambda_user[(size_t)pq * nl + iq];
+        double lv;
+        if (nl == 1) lv = lhi;
+        else if (lflip) lv = (iq == 0) ? llo : lhi - (double)(nl - 1 - iq) * lstep;
+        else lv = (iq == nl - 1) ? lhi : llo + (double)iq * lstep;
+        double lam = exp(lv);
+        if (pen_is_net(A.penalty[pq])) lam = lam / A.alpha;
+        return lam;
+    };
+    auto set_lambda = [&]() {                                        // (uniform: every thread of every workgroup takes it together)
+        const double lam = lambda_of(pp, i);
+        __syncthreads();
+        if (tid == 0) sx_thr_store(thr, votes + 8, pen_consts(pen, lam / scaley, d, A.alpha, A.gamma, A.tau), d);
+        __syncthreads();
+    };
+
+    // ONE loop for the Lanczos steps (phase 0) and the OEM iterations (phase 1): both are product -> exchange 1 -> the owners'
+    // arithmetic -> exchange 2.
+    for (;;) {
+        const bool lz = phase == 0;
+        // ---- products of this wave's tiles (those whose vector block holds a non-zero), reduced over the lanes, into Wp
+        SX_STAMP(0);
+        unsigned mywv = 0;
+        static_for_dev<NT>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            if (tflag[k] == 0) return;
+            const unsigned mJ = (unsigned)__builtin_amdgcn_readfirstlane(nzs[tJ[k]]), mI = tflag[k] == 1 ? (unsigned)__builtin_amdgcn_readfirstlane(nzs[tI[k]]) : 0u;
+            const bool dj = mJ != 0u, di = mI != 0u;
+            double *Wd = Wp + ((w * NT + k) * 2) * 64, *Wt = Wd + 64;
+            if (dj && di) sx_tile<true, true, k>(vlo, Lt, Bsh, tI[k] * 64, tJ[k] * 64, mI, mJ, Wd, Wt, lane, rlv, clv);
+            else if (dj) sx_tile<true, false, k>(vlo, Lt, Bsh, tI[k] * 64, tJ[k] * 64, mI, mJ, Wd, Wt, lane, rlv, clv);
+            else if (di) sx_tile<false, true, k>(vlo, Lt, Bsh, tI[k] * 64, tJ[k] * 64, mI, mJ, Wd, Wt, lane, rlv, clv);
+            mywv |= (dj ? 1u : 0u) << ((w * NT + k) * 2) | (di ? 1u : 0u) << ((w * NT + k) * 2 + 1);
+        });
+        if (lane == 0) wv[w] = (int)mywv;
+        SX_STAMP(1);
+        __syncthreads();                                             // Wp is complete
+        // ---- exchange 1: this workgroup's partial vector per block slot (wave w adds the entries of slots w, w + 4, ... in list
+        // order) to the owners; Lanczos: its part of v'XXv as well
+        ++X.epoch;
+        const int par = (int)(X.epoch & 1u);
+        {
+            const unsigned tag1 = (X.epoch << 1) | (unsigned)(lz ? 0 : mw);
+            double apart = 0.0;
+            const unsigned valid = (unsigned)__builtin_amdgcn_readfirstlane(wv[0] | wv[1] | wv[2] | wv[3]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int sl = w + 4 * m;
+                if (m >= nslw) continue;
+                // eight reads, none depending on another; an entry that is absent or was skipped reads the zero row behind Wp
+                double rr[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned e = ((j < 4 ? elo[m] : ehi[m]) >> (8 * (j & 3))) & 0xffu;
+                    const bool ok = e != 0xffu && ((valid >> (e & 31u)) & 1u) != 0u;
+                    rr[j] = Wp[(ok ? (int)e : 8 * NT) * 64 + lane];
+                }
+                const double t = ((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]));
+                sx_publish(X.rs, par * X.s1 + (p1m[m] + lane) * 16, t, tag1);
+                if (lz) apart = fma(Bsh[sl * 64 + lane], t, apart);
+            }
+            if (lz) {
+                apart = sx_block_sum(apart, red, rpar, w, lane);
+                if (tid == 0) sx_publish(X.rs, X.o3 + (par * G + wg) * 16, apart, X.epoch << 1);
+            }
+        }
+        SX_STAMP(2);
+        // (the operator's constants, asked for now: they arrive while the owners poll)
+        double thc[TH_N];
+#pragma unroll
+        for (int k = 0; k < TH_N; ++k) thc[k] = thr[k];
+        int thkind = votes[8];
+        // ---- the owners: the partials of coordinate cg in sender order (senders part, part + 8, ...: one chain per lane, then the eight lanes)
+        int bits = 0;
+        double gsum;
+        {
+            double g[SE1];
+            int off[SE1];
+#pragma unroll
+            for (int e = 0; e < SE1; ++e) off[e] = par * X.s1 + goff[e];
+            sx_gather<SE1>(off, need1, g, bits, X);
+            double t = (g[0] + g[1]) + (g[2] + g[3]);
+            t += dpp_mov<0xB1, 0xf>(t, 0.0);
+            t += dpp_mov<0x4E, 0xf>(t, 0.0);
+            t += dpp_mov<0x141, 0xf>(t, 0.0);
+            gsum = t;
+        }
+        SX_STAMP(3);
+        double alpha = 0.0;
+        if (lz) {                                                    // thread t holds workgroup t's part: a fixed order
+            int off[1] = {X.o3 + (par * G + (tid < G ? tid : 0)) * 16};
+            double v[1];
+            int fl = 0;
+            sx_gather<1>(off, tid < G ? 1u : 0u, v, fl, X);
+            alpha = sx_block_sum(v[0], red, rpar, w, lane);
+        }
+        sx_vote(votes, w, lane, bits);
+        __syncthreads();
+        const int any = votes[0] | votes[1] | votes[2] | votes[3];   // the OR of "beta_t moved against beta_{t-1}" over ALL coordinates
+        SX_STAMP(4);
+
+        // ---- the owners' arithmetic
+        double val, npart = 0.0;
+        int mybit = 0;
+        if (lz) {
+            val = (gsum - alpha * ca) - bprev * cb;                  // this coordinate of w' (eight lanes hold the same)
+            npart = (own && part == 0) ? val * val : 0.0;
+        } else {
+            // iteration t + 1 of every workgroup: the state transition is taken identically everywhere (oem_symfused_kernel's)
+            bool done_now = false;
+            if (!fresh) {
+                const bool conv = !any;
+                if (conv || it >= maxit) {
+                    const size_t kfin = (size_t)pp * nl + i;
+                    if (own && part == 0) A.beta[kfin * q + cg] = ca;
+                    if (tid == 0 && writer) { A.niter[kfin] = conv ? it : maxit + 1; A.loss[kfin] = 1e99; }      // ref src/oem_base.h:94-109
+                    const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
+                    if (i + 1 < nlam) i = i + 1;
+                    else if (pp + 1 < npen) { pp = pp + 1; i = 0; fresh = true; pen = A.penalty[pp]; }
+                    else done_now = true;
+                    if (!done_now) {
+                        set_lambda();
+#pragma unroll
+                        for (int k = 0; k < TH_N; ++k) thc[k] = thr[k];
+                        thkind = votes[8];
+                    }
+                    it = 0;
+                }
+            }
+            if (done_now) break;
+            // beta_{t+1} of this coordinate: u = d beta - g + XY, the operator, the stop rule (ref src/utils.cpp:537-549)
+            const double b0 = fresh ? 0.0 : ca;
+            const double u = (d * b0 - (fresh ? 0.0 : gsum)) + xyc;
+            const double bn = own ? sx_op(u, pfc, thkind, thc) : 0.0;
+            const double cu = fabs(bn), qo = fabs(b0);
+            const bool cn = cu > 1e-13, qn = qo > 1e-13;
+            mybit = (own && ((cn != qn) || (cn && qn && fabs(bn - b0) > tol * qo))) ? 1 : 0;
+            ca = bn; fresh = false; ++it;
+            val = bn;
+        }
+
+        // ---- exchange 2: the owners' values out, the blocks this workgroup touches in (Lanczos: scaled by 1 / ||w'||, whose
+        // squared parts ride along)
+        if (own && part == 0) sx_publish(X.rs, X.o2 + par * X.s2 + cg * 16, val, (X.epoch << 1) | (unsigned)mybit);
+        if (lz) {
+            const double np = sx_block_sum(npart, red, rpar, w, lane);
+            if (tid == 0) sx_publish(X.rs, X.o4 + (par * G + wg) * 16, np, X.epoch << 1);
+        }
+        SX_STAMP(5);
+        int bits2 = 0;
+        double r[SE2];
+        {
+            int off[SE2];
+#pragma unroll
+            for (int k = 0; k < SE2; ++k) off[k] = X.o2 + par * X.s2 + g2off[k];
+            sx_gather<SE2>(off, need2, r, bits2, X);
+        }
+        SX_STAMP(6);
+        double bb = 0.0, ib = 1.0;
+        if (lz) {
+            int off[1] = {X.o4 + (par * G + (tid < G ? tid : 0)) * 16};
+            double v[1];
+            int fl = 0;
+            sx_gather<1>(off, tid < G ? 1u : 0u, v, fl, X);
+            sqrt_rsqrt(sx_block_sum(v[0], red, rpar, w, lane), bb, ib);
+        }
+#pragma unroll
+        for (int k = 0; k < SE2; ++k) {
+            const bool nd = ((need2 >> k) & 1u) != 0;
+            const double x = lz ? r[k] * ib : r[k];
+            if (nd) Bsh[(w + 4 * k) * 64 + lane] = x;
+            const unsigned long long nzb = __ballot(nd && x != 0.0);       // bit h of the word: 16-coordinate group h of the block holds a non-zero
+            const int nz4 = ((nzb & 0xffffull) ? 1 : 0) | ((nzb & 0xffff0000ull) ? 2 : 0) | ((nzb & 0xffff00000000ull) ? 4 : 0) | ((nzb >> 48) ? 8 : 0);
+            if (lane == 0 && w + 4 * k < SNB) nzs[w + 4 * k] = nz4;
+        }
+        sx_vote(votes + 4, w, lane, bits2);
+        __syncthreads();
+        SX_STAMP(7);
+#ifdef OEM_PATH_DIAG
+        X.acc[8] += 1;
+#endif
+        if (!lz) { mw = votes[4] | votes[5] | votes[6] | votes[7]; continue; }
+
+        // ---- Lanczos bookkeeping (replicated): T, the stop rule, and at the end d and the hand-over to the path
+        if (tid == 0) { Tal[nst] = alpha; Tbe[nst] = bb; }
+        ++nst;
+        bool fin = !(bb > 1e-13 * fabs(alpha)) || nst >= msteps;     // invariant subspace reached (T is exact), or the step cap
+        bool have_theta = false;
+        double theta = 0.0;
+        if (!fin && lanczos_check_due(nst)) {
+            theta = top_ritz(nst, theta_prev);                       // its first barrier publishes Tal / Tbe
+            if (lanczos_converged(theta, theta_prev, mv_prev)) { fin = true; have_theta = true; }
+            theta_prev = sx_uni(theta_prev); mv_prev = sx_uni(mv_prev);
+        }
+        if (!fin) { cb = ca; ca = val * ib; bprev = sx_uni(bb); continue; }
+        if (!have_theta) { __syncthreads(); theta = top_ritz(nst, theta_prev); }
+        d = sx_uni(theta * 1.005);                                   // ref src/oem_dense.h:498, src/oem_xtx.h:369
+        if (tid == 0 && writer) {
+            A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst;
+            A.d_out[5] = (!have_theta && nst >= msteps && nst < q && bb > 1e-13 * fabs(alpha)) ? 1.0 : 0.0;
+        }
+#ifdef OEM_PATH_DIAG
+        SX_STAMP(0);
+        if (tid == 0 && writer) { for (int k = 0; k < 8; ++k) g_diag_symcoop[k] = X.acc[k]; }
+        for (int k = 0; k < 16; ++k) X.acc[k] = 0;
+#endif
+        if (A.npen == 0) break;
+        // lambda grid constants (ref src/oem_dense.cpp:175-192), replicated
+        scaley = sx_uni(A.yscale ? A.stats[1] : 1.0);
+        {
+            double m = 0.0;
+            for (int j = tid; j < q; j += SNTH) {
+                const double xl = A.lmax_xy ? A.lmax_xy[j] : A.xy[j];
+                m = fmax(m, j >= A.lmax_from ? fabs(xl) : 0.0);
+            }
+            m = wave_max(m);
+            if (lane == 0) red[12 + w] = m;
+            __syncthreads();
+            const double lmax = fmax(fmax(red[12], red[13]), fmax(red[14], red[15])) * scaley;
+            llo = sx_uni(log(lmax)); lhi = sx_uni(log(A.lambda_min_ratio * lmax));
+            lstep = sx_uni(nl > 1 ? (lhi - llo) / (double)(nl - 1) : 0.0);
+            lflip = fabs(lhi) < fabs(llo);
+        }
+        if (writer) for (int idx = tid; idx < A.npen * nl; idx += SNTH) A.lambda_out[idx] = lambda_of(idx / nl, idx % nl);
+        // cold start (ref src/oem_dense.cpp:243-244): beta = 0 in Bsh, nothing to multiply
+        phase = 1; pp = 0; i = 0; it = 0; pen = A.penalty[0]; fresh = true; mw = 0; ca = 0.0; cb = 0.0;
+        set_lambda();
+        for (int k = tid; k < SNB * 64; k += SNTH) Bsh[k] = 0.0;
+        if (tid < SNB) nzs[tid] = 0;
+        __syncthreads();
+    }
+#ifdef OEM_PATH_DIAG
+    if (tid == 0 && writer) { for (int k = 0; k < 8; ++k) g_diag_symcoop[8 + k] = X.acc[k]; g_diag_symcoop[7] = X.acc[8]; }
+#endif
+    if (tid == 0 && writer) {
+        A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
+        A.d_out[3] = (double)(__builtin_amdgcn_s_memrealtime() - t_rt0);
+    }
+    if (__syncthreads_or(X.failed ? 1 : 0) && tid == 0) A.d_out[6] = 1.0;       // exchange timeout: poison (api.hip: run_paths falls back)
+}
+
+template <int NT> constexpr size_t symcoop_lds_bytes()
+{
+    return sizeof(double) * (size_t)(SNB * 64 + (8 * NT + 1) * 64 + 2 * SCML + 2 * (SCML + 16) + 16 + 16) + sizeof(int) * (size_t)(16 + SNB + 32 + SW_INTS + SNB + 8) +
+           (NT == 3 ? sizeof(double) * 4 * 2048 : 0);
+}
+
+}  // namespace
+
+#ifdef OEM_PATH_DIAG
+extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read_symcoop(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_symcoop), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// ---- the plan: which tiles a wave holds, which blocks a workgroup touches, who sends to whom.  Pure host arithmetic.
+// Tiles are enumerated in strips of `a` tile rows, column by column inside a strip, and dealt 4 NT at a time: a workgroup is a patch
+// of a tile rows x 4 NT / a tile columns (3 x 4 at NT = 3), a wave one column of the strip (its tiles share their column block).
+bool symcoop_plan(int q, int gmax, SymcoopPlan &P)
+{
+    P = SymcoopPlan();
+    if (q <= 1024 || q > 4096) return false;
+    const int T = (q + 63) / 64, ntile = T * (T + 1) / 2;
+    int NT = 0;
+    for (int nt = 1; nt <= 3; ++nt) if ((ntile + 4 * nt - 1) / (4 * nt) <= gmax) { NT = nt; break; }
+    if (const char *e = getenv("OEM_SYMCOOP_NT")) { const int k = atoi(e); if (k >= 1 && k <= 3 && (ntile + 4 * k - 1) / (4 * k) <= gmax) NT = k; }   // experiments
+    if (!NT) return false;
+    const int a = NT == 3 ? 3 : 2, per = 4 * NT, G = (ntile + per - 1) / per;
+    if (q / G < 1 || (q + G - 1) / G > SSL) return false;
+    std::vector<int> tiles;                                          // I | J << 8
+    for (int r0 = 0; r0 < T;) {                                      // (a short strip comes FIRST, where it holds a handful of tiles: a last strip of one
+        int r1 = r0 + ((r0 == 0 && T % a) ? T % a : a);              //  tile row would be 64 tiles of one row -- twelve entries in one block sum)
+        if (r1 > T) r1 = T;
+        for (int j = 0; j < r1; ++j) for (int i = (j > r0 ? j : r0); i < r1; ++i) tiles.push_back(i | (j << 8));
+        r0 = r1;
+    }
+    std::vector<std::vector<int>> blocks(G), senders(T);
+    for (int g = 0; g < G; ++g) {
+        std::vector<int> &b = blocks[g];
+        for (int k = g * per; k < (g + 1) * per && k < ntile; ++k) { b.push_back(tiles[k] & 0xff); b.push_back(tiles[k] >> 8); }
+        std::sort(b.begin(), b.end());
+        b.erase(std::unique(b.begin(), b.end()), b.end());
+        if ((int)b.size() > SNB) return false;
+        for (int B : b) senders[B].push_back(g);
+    }
+    int maxns = 0, nsum = 0;
+    std::vector<int> tab(SPLAN_HEAD + (size_t)G * SW_INTS, 0);
+    for (int B = 0; B < T; ++B) { tab[B] = nsum; nsum += (int)senders[B].size(); maxns = std::max(maxns, (int)senders[B].size()); }
+    tab[T] = nsum;
+    if (maxns > 8 * SE1) return false;
+    const int base = q / G, rem = q % G;
+    for (int g = 0; g < G; ++g) {
+        int *r = tab.data() + SPLAN_HEAD + (size_t)g * SW_INTS;
+        const std::vector<int> &b = blocks[g];
+        r[SW_NB] = (int)b.size(); r[SW_C0] = g * base + (g < rem ? g : rem); r[SW_NSL] = base + (g < rem ? 1 : 0);
+        auto slot = [&](int B) { return (int)(std::lower_bound(b.begin(), b.end(), B) - b.begin()); };
+        for (int s = 0; s < (int)b.size(); ++s) {
+            r[SW_BLK + s] = b[s];
+            r[SW_RANK + s] = (int)(std::lower_bound(senders[b[s]].begin(), senders[b[s]].end(), g) - senders[b[s]].begin());
+        }
+        for (int wk = 0; wk < 12; ++wk) r[SW_TILE + wk] = -1;
+        // wave w holds tiles w, w + 4, w + 8 of the workgroup's list -- three different tile columns: a lasso iterate's non-zeros
+        // cluster (config 4: all in block 0), the products of a zero block are skipped, and the busiest WAVE sets the pace
+        auto tile_of = [&](int w, int k) { return g * per + k * 4 + w; };
+        for (int w = 0; w < 4; ++w)
+            for (int k = 0; k < NT; ++k) {
+                const int idx = tile_of(w, k);
+                if (idx >= ntile) continue;
+                const int I = tiles[idx] & 0xff, J = tiles[idx] >> 8;
+                r[SW_TILE + w * NT + k] = I | (J << 8) | (slot(I) << 16) | (slot(J) << 24);
+            }
+        int ne = 0;
+        for (int s = 0; s < (int)b.size(); ++s) {                    // the entries of slot s: direct products of tiles in tile row b[s], transposed ones of tile column b[s]
+            r[SW_CST + s] = ne;
+            for (int wk = 0; wk < 4 * NT; ++wk) {                    // entry (w NT + k) 2 + dir, ascending
+                const int idx = tile_of(wk / NT, wk % NT);
+                if (idx >= ntile) continue;
+                const int I = tiles[idx] & 0xff, J = tiles[idx] >> 8;
+                if (I == b[s]) r[SW_CEN + ne++] = wk * 2;
+                if (J == b[s] && I != J) r[SW_CEN + ne++] = wk * 2 + 1;
+            }
+        }
+        for (int s = (int)b.size(); s <= SNB; ++s) r[SW_CST + s] = ne;
+        if (ne > 24) return false;
+        for (int s = 0; s < (int)b.size(); ++s) if (r[SW_CST + s + 1] - r[SW_CST + s] > 8) return false;      // (the block sums read eight entries)
+    }
+    P.q = q; P.T = T; P.NT = NT; P.G = G; P.nsum = nsum; P.e1n = (maxns + 7) / 8;
+    P.tab.swap(tab);
+    return true;
+}
+
+size_t symcoop_xchg_bytes(const SymcoopPlan &P) { return 2 * ((size_t)P.nsum * 64 * 16) + 2 * ((size_t)P.T * 64 * 16) + 4 * ((size_t)P.G * 16) + 256; }
+// an upper bound for any q the engine takes (workspace reservation): every block receives at most 8 SE1 partials
+size_t symcoop_xchg_bytes_max(int q)
+{
+    if (q <= 1024 || q > 4096) return 0;
+    const size_t T = ((size_t)q + 63) / 64;
+    return 2 * (T * 8 * SE1 * 64 * 16) + 2 * (T * 64 * 16) + 4 * ((size_t)WCOOP_GMAX * 16) + 256;
+}
+
+// OEM_NO_SYMCOOP=1: the launch-per-iteration engines
+bool path_symcoop_eligible(const PathArgs &a, bool group_penalty)
+{
+    if (getenv("OEM_NO_SYMCOOP") || getenv("OEM_NO_COOP")) return false;
+    if (a.p <= 1024 || a.p > 4096 || a.nbatch > 1 || a.pen_split) return false;
+    if (a.accelerate || a.compute_loss || a.sinv || group_penalty) return false;      // (they need all of u in one place: path_large.hip's replicated update)
+    return true;
+}
+
+int launch_path_symcoop(hipStream_t s, const PathArgs &a_, const SymcoopPlan &P, const int *plan_dev, void *xchg)
+{
+    PathArgs a = a_;
+    a.lanczos_steps = a.p < SCML ? a.p : SCML;
+    OEM_HIP(hipMemsetAsync(xchg, 0, symcoop_xchg_bytes(P), s));                 // the tags must start at 0
+    OEM_HIP(hipMemsetAsync(a.d_out, 0, sizeof(double) * D_OUT_LEN, s));        // [6]: only a timed-out workgroup writes it
+    unsigned long long *x = reinterpret_cast<unsigned long long *>(xchg);
+    switch (P.NT) {
+    case 1: {
+        const size_t sh = symcoop_lds_bytes<1>();
+        if (int rc = lds_limit_once(reinterpret_cast<const void *>(&path_symcoop_kernel<1>), sh)) return rc;
+        hipLaunchKernelGGL((path_symcoop_kernel<1>), dim3(P.G), dim3(SNTH), sh, s, a, plan_dev, x, P.T, P.nsum, P.e1n);
+        break;
+    }
+    case 2: {
+        const size_t sh = symcoop_lds_bytes<2>();
+        if (int rc = lds_limit_once(reinterpret_cast<const void *>(&path_symcoop_kernel<2>), sh)) return rc;
+        hipLaunchKernelGGL((path_symcoop_kernel<2>), dim3(P.G), dim3(SNTH), sh, s, a, plan_dev, x, P.T, P.nsum, P.e1n);
+        break;
+    }
+    default: {
+        const size_t sh = symcoop_lds_bytes<3>();
+        if (int rc = lds_limit_once(reinterpret_cast<const void *>(&path_symcoop_kernel<3>), sh)) return rc;
+        hipLaunchKernelGGL((path_symcoop_kernel<3>), dim3(P.G), dim3(SNTH), sh, s, a, plan_dev, x, P.T, P.nsum, P.e1n);
+        break;
+    }
+    }
+    OEM_HIP(hipGetLastError());
+    if (getenv("OEM_WCOOP_FAKE_TIMEOUT")) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
+    return 0;
+}
+
+}  // namespace oemgpu

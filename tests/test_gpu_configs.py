@@ -235,6 +235,7 @@ def test_symmetric_tile_engine(oa, p, monkeypatch):
     xd = torch.as_tensor(xtx, device="cuda")
     pf = np.ones(p); pf[:5] = 0.0; pf[5:9] = 2.5
     monkeypatch.setenv("OEM_SYM_2048", "1")
+    monkeypatch.setenv("OEM_NO_SYMCOOP", "1")          # (round 4: the register-resident engine takes these sizes first; this is its fallback)
     for kw in (dict(penalty=["lasso", "mcp", "scad.net", "ols"], alpha=0.6, gamma=3.5, nlambda=7, tol=1e-9, maxit=600, penalty_factor=pf),
                dict(penalty=["lasso"], nlambda=5, tol=1e-13, maxit=4)):
         monkeypatch.delenv("OEM_NO_SYM", raising=False)
@@ -260,6 +261,112 @@ def test_symmetric_tile_engine(oa, p, monkeypatch):
         _cmp(fit, ref)
         lam_max = np.linalg.eigvalsh(xtx)[-1]
         assert abs(fit["d"] - 1.005 * lam_max) <= 1e-10 * lam_max
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [1025, 1500, 2048, 2433, 3000, 3457, 4096])
+def test_register_resident_symmetric_engine(oa, p, monkeypatch):
+    """1024 < p <= 4096 with element-wise penalties (config 4's engine since round 4, path_symcoop.hip): ONE persistent launch with
+    the lower triangle of XX in the register files of <= 192 CUs -- 64 x 64 tiles, one, two or three per wave (sizes on both sides
+    of the two switches, p = 2432 and 3456, ragged last tiles, the full 4096) -- both products of a tile from one pass, the all-reduce
+    as two sparse tagged exchanges, the stop decision replicated one iteration later.  Against the launch-per-iteration engines
+    (OEM_NO_SYMCOOP=1: same iteration, other summation order) through several penalties (cold starts), penalty factors and maxit
+    exhaustion; bit-reproducible run to run; d against LAPACK; and against the oracle."""
+    import torch
+    rng = np.random.default_rng(7 * p + 1)
+    n = p + 2000
+    x = rng.normal(size=(n, p)) * (1.0 + 0.5 * rng.uniform(size=p))
+    b = np.zeros(p); b[rng.choice(p, 20, replace=False)] = rng.uniform(-1, 1, 20)
+    y = x @ b + rng.normal(size=n)
+    xtx, xty = x.T @ x / n, x.T @ y / n
+    xd = torch.as_tensor(xtx, device="cuda")
+    pf = np.ones(p); pf[:5] = 0.0; pf[5:9] = 2.5
+    for kw in (dict(penalty=["lasso", "mcp", "scad.net", "ols"], alpha=0.6, gamma=3.5, nlambda=6, tol=1e-9, maxit=600, penalty_factor=pf),
+               dict(penalty=["elastic.net"], alpha=0.5, nlambda=5, tol=1e-13, maxit=4)):
+        monkeypatch.delenv("OEM_NO_SYMCOOP", raising=False)
+        reg = oa.oem_xtx(xd, xty, **kw)
+        cyc = oa.lib().oemgpu_last_timings                       # (the persistent kernel leaves its cycle counter; the launches leave 0)
+        import ctypes as C
+        ms = (C.c_double * 8)(); assert cyc(oa.context(), ms) == 0 and ms[6] > 0
+        again = oa.oem_xtx(xd, xty, **kw)
+        assert all(np.array_equal(u, v) for u, v in zip(reg["beta"], again["beta"])) and reg["d"] == again["d"]      # fixed summation order: same bits
+        monkeypatch.setenv("OEM_NO_SYMCOOP", "1")
+        row = oa.oem_xtx(xd, xty, **kw)
+        assert cyc(oa.context(), ms) == 0 and ms[6] == 0
+        assert abs(reg["d"] - row["d"]) <= 1e-11 * row["d"]
+        for k in range(len(kw["penalty"])):
+            scale = max(1.0, float(np.abs(row["beta"][k]).max()))
+            assert np.abs(np.asarray(reg["beta"][k]) - np.asarray(row["beta"][k])).max() <= 1e-10 * scale, kw["penalty"][k]
+            assert np.abs(np.ravel(reg["niter"][k]).astype(int) - np.ravel(row["niter"][k]).astype(int)).max() <= 1, kw["penalty"][k]
+            assert np.allclose(reg["lambda"][k], row["lambda"][k], rtol=1e-13)
+        if kw["maxit"] == 4:
+            assert reg["niter"][0].max() == 5 and np.array_equal(reg["niter"][0], row["niter"][0])
+    monkeypatch.delenv("OEM_NO_SYMCOOP", raising=False)
+    lam_max = np.linalg.eigvalsh(xtx)[-1]
+    assert abs(reg["d"] - 1.005 * lam_max) <= DTOL * lam_max
+    if p <= 2500:
+        kw = dict(penalty=["lasso", "mcp"], nlambda=6, tol=1e-9, maxit=600)
+        fit = oa.oem_xtx(xd, xty, **kw)
+        ref = orc.fit_xtx(xtx, xty, d_override=fit["d"], **kw)
+        _cmp(fit, ref)
+        for k in range(2):
+            assert np.abs(np.ravel(fit["niter"][k]).astype(int) - np.ravel(ref["niter"][k]).astype(int)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_register_resident_engine_through_oem(oa, monkeypatch):
+    """the same engine behind oem() (n > p, DataStd flags, y scaled: lambda / scale(y) inside the kernel) against the oracle"""
+    rng = np.random.default_rng(31)
+    n, p = 6000, 1200
+    x = np.asfortranarray(rng.normal(size=(n, p)) * (1.0 + rng.uniform(size=p)) + 0.3)
+    b = np.zeros(p); b[rng.choice(p, 15, replace=False)] = rng.uniform(-1, 1, 15)
+    y = x @ b + rng.normal(size=n) + 1.0
+    for std, icpt in ((True, True), (False, False)):
+        kw = dict(penalty=["lasso", "scad"], nlambda=8, tol=1e-9, standardize=std, intercept=icpt)
+        fit = oa.oem(x, y, **kw)
+        ref = orc.fit_dense(x, y, native=True, **kw)
+        _cmp(fit, ref)
+        for k in range(2):
+            assert np.abs(np.ravel(fit["niter"][k]).astype(int) - np.ravel(ref["niter"][k]).astype(int)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_register_resident_engine_falls_back_when_its_exchange_times_out(oa, monkeypatch):
+    """all its workgroups must be resident at once; a poisoned exchange (OEM_WCOOP_FAKE_TIMEOUT=1 sets the poison behind a kernel that
+    ran) sends the call to the launch-per-iteration engine: the caller gets exactly that engine's answer"""
+    import torch
+    xtx, xty = _xtx_problem(2048, 6000, 77)
+    xd = torch.as_tensor(xtx, device="cuda")
+    kw = dict(penalty=["lasso", "mcp"], nlambda=6, tol=1e-9)
+    good = oa.oem_xtx(xd, xty, **kw)
+    monkeypatch.setenv("OEM_WCOOP_FAKE_TIMEOUT", "1")
+    back = oa.oem_xtx(xd, xty, **kw)
+    monkeypatch.delenv("OEM_WCOOP_FAKE_TIMEOUT")
+    monkeypatch.setenv("OEM_NO_SYMCOOP", "1")
+    launches = oa.oem_xtx(xd, xty, **kw)
+    for k in range(2):
+        assert np.array_equal(np.asarray(back["beta"][k]), np.asarray(launches["beta"][k])) and np.array_equal(back["niter"][k], launches["niter"][k])
+        assert np.abs(np.asarray(back["beta"][k]) - np.asarray(good["beta"][k])).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_config4_xtx_p4096_against_the_oracle(oa):
+    """config 4 at its full size against the oracle (the engine that serves p = 4096 was held to the oracle at half its
+    size only): oem.xtx, p = 4096, lasso, tol 1e-10, six lambdas over the whole range of the 100-lambda grid, through the DEFAULT
+    engine selection.  d is handed to the oracle (it is held against LAPACK at 1e-10 right here); coefficients to 1e-9, niter +- 1."""
+    import torch
+    p = 4096
+    xtx, xty = _xtx_problem(p, 65536, 9)
+    lam_grid = oa.oem_xtx(torch.as_tensor(xtx, device="cuda"), xty, penalty="lasso", nlambda=100, tol=1e-10)["lambda"][0]
+    lam = lam_grid[[0, 10, 30, 55, 80, 99]]
+    kw = dict(penalty="lasso", lambda_=lam, tol=1e-10)
+    fit = oa.oem_xtx(torch.as_tensor(xtx, device="cuda"), xty, **kw)
+    lam_max = np.linalg.eigvalsh(xtx)[-1]
+    assert abs(fit["d"] - 1.005 * lam_max) <= DTOL * lam_max
+    ref = orc.fit_xtx(xtx, xty, d_override=fit["d"], **kw)
+    _cmp(fit, ref)
+    assert np.abs(np.ravel(fit["niter"][0]).astype(int) - np.ravel(ref["niter"][0]).astype(int)).max() <= 1
+    assert (np.asarray(fit["beta"][0])[:, -1] != 0).sum() > 100            # (the small end of the grid: a dense iterate)
 
 
 @pytest.mark.gpu

@@ -520,6 +520,7 @@ def test_random_symmetric_tile_engine(oa, seed, monkeypatch):
     """oem.xtx at p = 2048 on the symmetric-tile engine (OEM_SYM_2048=1): random element-wise penalty mixes, penalty factors and
     maxit, against the oracle (d handed over, as in the config-4 tests: the comparison is the path's)"""
     monkeypatch.setenv("OEM_SYM_2048", "1")
+    monkeypatch.setenv("OEM_NO_SYMCOOP", "1")          # (the launch-per-iteration engine: the register-resident one has its own sweep below)
     rng = np.random.default_rng(9900 + seed)
     p, n = 2048, 2048 + int(rng.integers(100, 3000))
     x = rng.normal(size=(n, p)) * (1.0 + rng.uniform(size=p))
@@ -535,3 +536,26 @@ def test_random_symmetric_tile_engine(oa, seed, monkeypatch):
     lam_max = np.linalg.eigvalsh(xtx)[-1]
     assert abs(f["d"] - 1.005 * lam_max) <= 1e-10 * lam_max
     _check(f, r, pens, tol=5e-7)
+
+
+@pytest.mark.parametrize("seed", list(range(160, 166)) + list(range(95000, 95000 + 6 * (SCALE - 1))))
+def test_random_register_resident_symmetric_engine(oa, seed):
+    """oem.xtx at a random 1024 < p <= 4096 on the register-resident symmetric engine (path_symcoop.hip; every tile count per wave,
+    ragged last tiles): random element-wise penalty mixes, penalty factors and maxit, against the oracle (d handed over)"""
+    rng = np.random.default_rng(9950 + seed)
+    p = int(rng.choice([int(rng.integers(1025, 1400)), int(rng.integers(1400, 2433)), int(rng.integers(2433, 3457)), int(rng.integers(3457, 4097))]))
+    n = p + int(rng.integers(100, 2000))
+    x = rng.normal(size=(n, p)) * (1.0 + rng.uniform(size=p))
+    b = np.zeros(p); b[rng.choice(p, 12, replace=False)] = rng.uniform(-1, 1, 12)
+    y = x @ b + rng.normal(size=n)
+    xtx, xty = x.T @ x / n, x.T @ y / n
+    pens = list(rng.choice(ELEMENTWISE, int(rng.integers(1, 4)), replace=False))
+    pf = np.where(rng.random(p) < 0.05, 0.0, rng.uniform(0.5, 2.0, p))
+    kw = dict(penalty=pens, nlambda=int(rng.integers(2, 5)), alpha=float(rng.uniform(0.3, 1.0)), gamma=float(rng.uniform(2.5, 5.0)),
+              tol=float(10.0 ** rng.uniform(-9, -7)), maxit=int(rng.choice([60, 300])), penalty_factor=pf)
+    f = oa.oem_xtx(xtx, xty, **kw)
+    r = orc.fit_xtx(xtx, xty, d_override=f["d"], lambda_min_ratio=1e-4, **kw)
+    lam_max = np.linalg.eigvalsh(xtx)[-1]
+    assert abs(f["d"] - 1.005 * lam_max) <= 1e-10 * lam_max
+    _check(f, r, pens, tol=5e-7)
+

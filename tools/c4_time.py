@@ -12,8 +12,9 @@ xtxd = torch.as_tensor(xtx, device="cuda")
 lib = L.lib(); ctx = oem_amd.context()
 L.check(lib.oemgpu_set_timing(ctx, 1))
 for knob in sys.argv[1:] or [""]:
-    os.environ.pop("OEM_NO_SYM", None)
-    if knob == "nosym": os.environ["OEM_NO_SYM"] = "1"          # the row-streaming engine that reads all of XX (round 2)
+    os.environ.pop("OEM_NO_SYM", None); os.environ.pop("OEM_NO_SYMCOOP", None)
+    if knob == "nosym": os.environ["OEM_NO_SYM"] = "1"; os.environ["OEM_NO_SYMCOOP"] = "1"          # the row-streaming engine that reads all of XX (round 2)
+    elif knob == "nosymcoop": os.environ["OEM_NO_SYMCOOP"] = "1"          # the symmetric-tile launches of round 3 (the lower triangle streamed per iteration)
     elif knob: os.environ["OEM_FUSED_BLOCKS"] = knob
     t = []
     for _ in range(3):

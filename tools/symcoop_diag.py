@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Stamped segments of the register-resident symmetric engine (path_symcoop.hip; liboemgpu_diag.so): python tools/symcoop_diag.py [p] [nlambda] [n]"""
+import ctypes as C, os, sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("OEMGPU_LIB", str(ROOT / "oem_amd" / "liboemgpu_diag.so"))
+import torch
+import oem_amd as oa
+from oem_amd import _lib as L
+p = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+nl = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+rng = np.random.default_rng(123)
+n = int(sys.argv[3]) if len(sys.argv) > 3 else max(2 * p, 16384)
+x = rng.normal(size=(n, p)); b = np.zeros(p); b[:25] = rng.uniform(-1, 1, 25); y = x @ b + rng.normal(size=n)
+xtx, xty = x.T @ x / n, x.T @ y / n
+fit = oa.oem_xtx(torch.as_tensor(xtx, device="cuda"), xty, penalty="lasso", nlambda=nl, tol=1e-10)
+lib = L.lib(); lib.oemgpu_diag_read_symcoop.argtypes = [C.POINTER(C.c_ulonglong)]
+out = (C.c_ulonglong * 16)(); assert lib.oemgpu_diag_read_symcoop(out) == 0
+d = np.array(list(out), dtype=np.float64)
+names = "between + owners' arithmetic of the previous | products | block sums + publish 1 | gather 1 | (alpha) + vote barrier | operator + publish 2 | gather 2 | LDS stores + barrier"
+it = max(d[7], 1)
+print(f"p={p}: OEM iterations {int(np.sum(fit['niter'][0]))}, all-reduces of the path phase {int(d[7])}; cycles of wave 0 of workgroup 0 per iteration\n  [{names}]")
+print("  path:   ", np.round(d[8:16] / it, 0), "sum", round(d[8:16].sum() / it))
+print("  Lanczos (totals over its steps, slot 7 overwritten):", np.round(d[0:7], 0))
