@@ -350,7 +350,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     size_t work_d = small ? path_small_xchg_bytes() / 8 : path_large_work_doubles(q, lan);
     if (coop && work_d < path_coop_xchg_bytes() / 8) work_d = path_coop_xchg_bytes() / 8;
     const size_t sym_off_d = (work_d + 31) / 32 * 32;                 // the exchange area of path_symcoop.hip behind the launch-per-iteration engines' workspace (the fallback needs both)
-    if (symc) work_d = sym_off_d + (symcoop_xchg_bytes(symplan) + 7) / 8;
+    if (symc) work_d = sym_off_d + (symcoop_work_bytes(symplan) + 7) / 8;
     // the outputs come first: when the caller's frame ends with `stats` (both callers), stats | outputs is one
     // contiguous range and one device-to-host copy returns both
     // one workgroup (set) per penalty: they are independent cold starts (the cooperating sets must all be resident: <= half the CUs)

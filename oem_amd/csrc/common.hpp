@@ -174,6 +174,7 @@ struct SymcoopPlan {
 };
 bool symcoop_plan(int q, int gmax, SymcoopPlan &P);
 size_t symcoop_xchg_bytes(const SymcoopPlan &P);
+size_t symcoop_work_bytes(const SymcoopPlan &P);    // ... plus the kernel's copy of its arguments
 size_t symcoop_xchg_bytes_max(int q);
 bool path_symcoop_eligible(const PathArgs &a, bool group_penalty);
 int launch_path_symcoop(hipStream_t s, const PathArgs &a, const SymcoopPlan &P, const int *plan_dev, void *xchg);

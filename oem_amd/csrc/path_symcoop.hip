@@ -56,9 +56,11 @@ constexpr int SCML = 512;         // Lanczos steps kept
 constexpr int SSL = SNTH / 8;     // coordinates a workgroup may own
 // per-workgroup plan record (ints)
 enum { SW_NB = 0, SW_C0 = 1, SW_NSL = 2, SW_BLK = 4, SW_RANK = SW_BLK + SNB, SW_TILE = SW_RANK + SNB, SW_CST = SW_TILE + 12,
-       SW_CEN = SW_CST + SNB + 1, SW_INTS = SW_CEN + 24 + 7 };
+       SW_TPOS = SW_CST + SNB + 1, SW_INTS = SW_TPOS + 12 + 19 };          // TPOS: row of Wp of a tile's direct product | of its transposed one << 8
 static_assert(SW_INTS == 96, "plan record");
 constexpr int SPLAN_HEAD = 80;    // blkbase[T + 1], T <= 64
+constexpr int SVR = 2;            // rows (of the eight of a lane's sub-block) of a wave's THIRD tile that stay in VGPRs; the others live in LDS
+constexpr int SLT = (8 - SVR) * 4 * 64 * 2;      // doubles of LDS per wave for them
 
 #ifdef OEM_PATH_DIAG
 __device__ unsigned long long g_diag_symcoop[16];
@@ -166,8 +168,8 @@ template <int CTRL> __device__ __forceinline__ double sx_dpp_stage(double lo, do
 // (three tiles as plain arrays: 512 registers, 57 spilled into the loop): tiles 0 and 1 live in AGPRs a0..a255 that ONLY the inline
 // asm below names -- the compiler's own values fit the 256 architectural VGPRs, so it never touches the accumulator file
 // (oem_amd/build.py: audit_symcoop_isa proves that on the emitted ISA, as for the Gram kernels) -- and the third tile of a wave
-// (q > 3456) half in VGPRs (rows 0..3 of the lane's 8 x 8 sub-block), half in LDS (rows 4..7: sixteen 16-byte reads per lane,
-// [read][lane], a wave's read 1 KiB contiguous).
+// (q > 3456) a quarter in VGPRs (rows 0, 1 of the lane's 8 x 8 sub-block), the rest in LDS (24 16-byte reads per lane,
+// [read][lane], a wave's read 1 KiB contiguous: 96 KB per workgroup).
 template <int IDX> __device__ __forceinline__ double sx_areg_rd()
 {
     unsigned l, h;
@@ -181,11 +183,11 @@ template <int IDX> __device__ __forceinline__ void sx_areg_wr(double x)
 
 // The products of ONE tile with the vector blocks at Bsh + oI (rows) and Bsh + oJ (columns), reduced over the lanes.
 // DD: the direct product (T vec_J) -> Wd[64]; TT: the transposed one (T' vec_I) -> Wt[64].  One pass over the tile feeds both.
-// ST: 0 / 1 = the tile in AGPRs a[128 ST ..]; 2 = rows 0..3 in vlo, rows 4..7 in LDS at lt.
+// ST: 0 / 1 = the tile in AGPRs a[128 ST ..]; 2 = rows 0..SVR-1 in vlo, the others in LDS at lt.
 // Lane bits: rl = (b4, b3, b2), cl = (b5, b1 ^ b2, b0 ^ b2) -- the partners of the direct reduction (lane ^ 32, ^ 2, ^ 1) keep rl, those
 // of the transposed one (lane ^ 16, ^ 8, ^ 7) keep cl.
 template <bool DD, bool TT, int ST>
-__device__ __forceinline__ void sx_tile(const double (&vlo)[32], const double *lt, const double *Bsh, int oI, int oJ, unsigned mI, unsigned mJ,
+__device__ __forceinline__ void sx_tile(const double (&vlo)[8 * SVR], const double *lt, const double *Bsh, int oI, int oJ, unsigned mI, unsigned mJ,
                                         double *Wd, double *Wt, int lane, int rlv, int clv)
 {
     double bj[8], bi[8], ad[8], at[8];
@@ -201,8 +203,8 @@ __device__ __forceinline__ void sx_tile(const double (&vlo)[32], const double *l
         constexpr int i = decltype(I_)::value, jj = decltype(J_)::value;
         double x0, x1;
         if constexpr (ST < 2) { x0 = sx_areg_rd<ST * 64 + i * 8 + 2 * jj>(); x1 = sx_areg_rd<ST * 64 + i * 8 + 2 * jj + 1>(); }
-        else if constexpr (i < 4) { x0 = vlo[i * 8 + 2 * jj]; x1 = vlo[i * 8 + 2 * jj + 1]; }
-        else { const v2d t = *reinterpret_cast<const v2d *>(lt + (((i - 4) * 4 + jj) * 64 + lane) * 2); x0 = t.x; x1 = t.y; }
+        else if constexpr (i < SVR) { x0 = vlo[i * 8 + 2 * jj]; x1 = vlo[i * 8 + 2 * jj + 1]; }
+        else { const v2d t = *reinterpret_cast<const v2d *>(lt + (((i - SVR) * 4 + jj) * 64 + lane) * 2); x0 = t.x; x1 = t.y; }
         if (DD) { ad[i] = fma(x0, bj[2 * jj], ad[i]); }
         if (TT) { at[2 * jj] = fma(x0, bi[i], at[2 * jj]); }
         if (DD) { ad[i] = fma(x1, bj[2 * jj + 1], ad[i]); }
@@ -291,10 +293,10 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
     double *thr = red + 16;                              // operator constants of the lambda in use [TH_N <= 16]
     int *votes = reinterpret_cast<int *>(thr + 16);      // [8] votes, [8] kind
     int *nzs = votes + 16;                               // [SNB] which 16-coordinate groups of this slot of Bsh hold a non-zero (4 bits)
-    int *wv = nzs + SNB;                                 // [4] per producing wave: bit e = "entry e of Wp was computed" (then 28 spare)
+    int *wv = nzs + SNB;                                 // (32 spare words)
     int *rec = wv + 32;                                  // this workgroup's plan record [SW_INTS], then P1[SNB] (pairs index of exchange 1 per slot)
     int *P1 = rec + SW_INTS;
-    double *Lt = reinterpret_cast<double *>(P1 + SNB + 8) + w * 2048;     // NT == 3: rows 4..7 of every lane's part of this wave's third tile
+    double *Lt = reinterpret_cast<double *>(P1 + SNB + 8) + w * SLT;      // NT == 3: rows SVR..7 of every lane's part of this wave's third tile
     const bool writer = wg == 0;
 
     const int *__restrict__ blkbase = plan;
@@ -305,33 +307,30 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
     const int nb = rec[SW_NB], c0 = rec[SW_C0], nsl = rec[SW_NSL];
     if (tid < SNB) P1[tid] = tid < nb ? (blkbase[rec[SW_BLK + tid]] + rec[SW_RANK + tid]) * 64 : 0;
 
-    // ---- the entries (reduced tile products in Wp) of this wave's block slots w, w + 4, w + 8, w + 12: at most eight each, packed as
-    // bytes (0xff: none) so that the block sums below are branch-free reads
-    unsigned elo[4], ehi[4];
+    // ---- the reduced tile products that make up block slot s sit in rows cst[s] .. cst[s + 1] - 1 of Wp (the host deals the rows
+    // slot by slot); this wave adds up slots w, w + 4, w + 8, w + 12
+    int erow[4], ecnt[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int sl = w + 4 * m;
-        unsigned long long pk = ~0ull;
-        if (sl < nb) {
-            const int x0 = rec[SW_CST + sl], x1 = rec[SW_CST + sl + 1];
-            for (int x = x1 - 1; x >= x0; --x) pk = (pk << 8) | (unsigned long long)(rec[SW_CEN + x] & 0xff);
-        }
-        elo[m] = __builtin_amdgcn_readfirstlane((unsigned)pk); ehi[m] = __builtin_amdgcn_readfirstlane((unsigned)(pk >> 32));
+        erow[m] = __builtin_amdgcn_readfirstlane(sl < nb ? rec[SW_CST + sl] : 0);
+        ecnt[m] = __builtin_amdgcn_readfirstlane(sl < nb ? rec[SW_CST + sl + 1] - rec[SW_CST + sl] : 0);
     }
     const int nslw = __builtin_amdgcn_readfirstlane(nb > w ? (nb - w + 3) / 4 : 0);       // block slots of this wave
     // ---- this wave's tiles: lane (rl, cl) holds the 8 x 8 sub-block of rows 16 (i >> 1) + 2 rl + (i & 1), columns alike with cl
     const int rlv = (lane >> 2) & 7, clv = ((lane >> 5) << 2) | ((((lane >> 1) ^ (lane >> 2)) & 1) << 1) | ((lane ^ (lane >> 2)) & 1);
-    double vlo[32];                                      // NT == 3: rows 0..3 of this lane's part of the wave's third tile
-    int tI[NT], tJ[NT], tflag[NT];                       // block slots of the tile's rows / columns; 0: no tile, 1: off-diagonal, 2: diagonal
+    double vlo[8 * SVR];                                 // NT == 3: rows 0..SVR-1 of this lane's part of the wave's third tile
+    int tI[NT], tJ[NT], tflag[NT], tpos[NT];             // block slots of the tile's rows / columns; 0: no tile, 1: off-diagonal, 2: diagonal; rows of Wp
     if constexpr (NT == 1) asm volatile("" ::: "a127"); else asm volatile("" ::: "a255");      // the accumulator file is in use (by the asm alone)
 #pragma unroll
-    for (int k = 0; k < 32; ++k) vlo[k] = 0.0;
+    for (int k = 0; k < 8 * SVR; ++k) vlo[k] = 0.0;
     static_for_dev<NT>([&](auto K_) {
         constexpr int k = decltype(K_)::value;
         const int t = __builtin_amdgcn_readfirstlane(rec[SW_TILE + w * NT + k]);
         const int I = t & 0xff, J = (t >> 8) & 0xff;
         tflag[k] = t < 0 ? 0 : (I == J ? 2 : 1);
         tI[k] = t < 0 ? 0 : ((t >> 16) & 0xff); tJ[k] = t < 0 ? 0 : ((t >> 24) & 0x7f);
+        tpos[k] = __builtin_amdgcn_readfirstlane(rec[SW_TPOS + w * NT + k]);
         static_for_dev<8>([&](auto I_) {
             constexpr int i = decltype(I_)::value;
             const int row = 64 * I + 16 * (i >> 1) + 2 * rlv + (i & 1);
@@ -340,8 +339,8 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
                 const int col = 64 * J + 16 * (j >> 1) + 2 * clv + (j & 1);
                 const double x = (t >= 0 && row < q && col < q) ? A.xx[(size_t)col * q + row] : 0.0;
                 if constexpr (k < 2) sx_areg_wr<k * 64 + i * 8 + j>(x);
-                else if constexpr (i < 4) vlo[i * 8 + j] = x;
-                else Lt[(((i - 4) * 4 + (j >> 1)) * 64 + lane) * 2 + (j & 1)] = x;
+                else if constexpr (i < SVR) vlo[i * 8 + j] = x;
+                else Lt[(((i - SVR) * 4 + (j >> 1)) * 64 + lane) * 2 + (j & 1)] = x;
             });
         });
     });
@@ -450,19 +449,22 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
         const bool lz = phase == 0;
         // ---- products of this wave's tiles (those whose vector block holds a non-zero), reduced over the lanes, into Wp
         SX_STAMP(0);
-        unsigned mywv = 0;
+        int fJ[NT], fI[NT];                                          // (all flag words asked for at once: one LDS latency, not six)
+#pragma unroll
+        for (int k = 0; k < NT; ++k) { fJ[k] = nzs[tJ[k]]; fI[k] = nzs[tI[k]]; }
         static_for_dev<NT>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
             if (tflag[k] == 0) return;
-            const unsigned mJ = (unsigned)__builtin_amdgcn_readfirstlane(nzs[tJ[k]]), mI = tflag[k] == 1 ? (unsigned)__builtin_amdgcn_readfirstlane(nzs[tI[k]]) : 0u;
+            const unsigned mJ = (unsigned)__builtin_amdgcn_readfirstlane(fJ[k]), mI = tflag[k] == 1 ? (unsigned)__builtin_amdgcn_readfirstlane(fI[k]) : 0u;
             const bool dj = mJ != 0u, di = mI != 0u;
-            double *Wd = Wp + ((w * NT + k) * 2) * 64, *Wt = Wd + 64;
+            double *Wd = Wp + (tpos[k] & 0xff) * 64, *Wt = Wp + ((tpos[k] >> 8) & 0xff) * 64;
             if (dj && di) sx_tile<true, true, k>(vlo, Lt, Bsh, tI[k] * 64, tJ[k] * 64, mI, mJ, Wd, Wt, lane, rlv, clv);
             else if (dj) sx_tile<true, false, k>(vlo, Lt, Bsh, tI[k] * 64, tJ[k] * 64, mI, mJ, Wd, Wt, lane, rlv, clv);
             else if (di) sx_tile<false, true, k>(vlo, Lt, Bsh, tI[k] * 64, tJ[k] * 64, mI, mJ, Wd, Wt, lane, rlv, clv);
-            mywv |= (dj ? 1u : 0u) << ((w * NT + k) * 2) | (di ? 1u : 0u) << ((w * NT + k) * 2 + 1);
+            // a product that was skipped leaves zeros (the block sums read every row of their slot)
+            if (!dj) Wd[lane] = 0.0;
+            if (!di && tflag[k] == 1) Wt[lane] = 0.0;
         });
-        if (lane == 0) wv[w] = (int)mywv;
         SX_STAMP(1);
         __syncthreads();                                             // Wp is complete
         // ---- exchange 1: this workgroup's partial vector per block slot (wave w adds the entries of slots w, w + 4, ... in list
@@ -472,22 +474,18 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
         {
             const unsigned tag1 = (X.epoch << 1) | (unsigned)(lz ? 0 : mw);
             double apart = 0.0;
-            const unsigned valid = (unsigned)__builtin_amdgcn_readfirstlane(wv[0] | wv[1] | wv[2] | wv[3]);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int sl = w + 4 * m;
                 if (m >= nslw) continue;
-                // eight reads, none depending on another; an entry that is absent or was skipped reads the zero row behind Wp
+                // eight reads, none depending on another; rows beyond the slot's own read the zero row behind Wp
                 double rr[8];
+                int er = erow[m], ec = ecnt[m];
+                asm volatile("" : "+s"(er), "+s"(ec));               // (recomputed addresses, not 32 loop-invariant address registers)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const unsigned e = ((j < 4 ? elo[m] : ehi[m]) >> (8 * (j & 3))) & 0xffu;
-                    const bool ok = e != 0xffu && ((valid >> (e & 31u)) & 1u) != 0u;
-                    rr[j] = Wp[(ok ? (int)e : 8 * NT) * 64 + lane];
-                }
+                for (int j = 0; j < 8; ++j) rr[j] = Wp[(j < ec ? er + j : 8 * NT) * 64 + lane];
                 const double t = ((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]));
                 sx_publish(X.rs, par * X.s1 + (p1m[m] + lane) * 16, t, tag1);
-                if (lz) apart = fma(Bsh[sl * 64 + lane], t, apart);
+                if (lz) apart = fma(Bsh[(w + 4 * m) * 64 + lane], t, apart);
             }
             if (lz) {
                 apart = sx_block_sum(apart, red, rpar, w, lane);
@@ -672,7 +670,7 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
 template <int NT> constexpr size_t symcoop_lds_bytes()
 {
     return sizeof(double) * (size_t)(SNB * 64 + (8 * NT + 1) * 64 + 2 * SCML + 2 * (SCML + 16) + 16 + 16) + sizeof(int) * (size_t)(16 + SNB + 32 + SW_INTS + SNB + 8) +
-           (NT == 3 ? sizeof(double) * 4 * 2048 : 0);
+           (NT == 3 ? sizeof(double) * 4 * SLT : 0);
 }
 
 }  // namespace
@@ -741,19 +739,20 @@ bool symcoop_plan(int q, int gmax, SymcoopPlan &P)
                 r[SW_TILE + w * NT + k] = I | (J << 8) | (slot(I) << 16) | (slot(J) << 24);
             }
         int ne = 0;
-        for (int s = 0; s < (int)b.size(); ++s) {                    // the entries of slot s: direct products of tiles in tile row b[s], transposed ones of tile column b[s]
+        for (int wk = 0; wk < 12; ++wk) r[SW_TPOS + wk] = 0xffff;
+        for (int s = 0; s < (int)b.size(); ++s) {                    // the rows of Wp of slot s: direct products of tiles in tile row b[s], transposed ones of tile column b[s]
             r[SW_CST + s] = ne;
-            for (int wk = 0; wk < 4 * NT; ++wk) {                    // entry (w NT + k) 2 + dir, ascending
+            for (int wk = 0; wk < 4 * NT; ++wk) {
                 const int idx = tile_of(wk / NT, wk % NT);
                 if (idx >= ntile) continue;
                 const int I = tiles[idx] & 0xff, J = tiles[idx] >> 8;
-                if (I == b[s]) r[SW_CEN + ne++] = wk * 2;
-                if (J == b[s] && I != J) r[SW_CEN + ne++] = wk * 2 + 1;
+                if (I == b[s]) r[SW_TPOS + wk] = (r[SW_TPOS + wk] & 0xff00) | ne++;
+                if (J == b[s] && I != J) r[SW_TPOS + wk] = (r[SW_TPOS + wk] & 0x00ff) | (ne++ << 8);
             }
+            if (ne - r[SW_CST + s] > 8) return false;                // (the block sums read eight rows)
         }
         for (int s = (int)b.size(); s <= SNB; ++s) r[SW_CST + s] = ne;
-        if (ne > 24) return false;
-        for (int s = 0; s < (int)b.size(); ++s) if (r[SW_CST + s + 1] - r[SW_CST + s] > 8) return false;      // (the block sums read eight entries)
+        if (ne > 8 * NT) return false;
     }
     P.q = q; P.T = T; P.NT = NT; P.G = G; P.nsum = nsum; P.e1n = (maxns + 7) / 8;
     P.tab.swap(tab);
@@ -761,12 +760,13 @@ bool symcoop_plan(int q, int gmax, SymcoopPlan &P)
 }
 
 size_t symcoop_xchg_bytes(const SymcoopPlan &P) { return 2 * ((size_t)P.nsum * 64 * 16) + 2 * ((size_t)P.T * 64 * 16) + 4 * ((size_t)P.G * 16) + 256; }
+size_t symcoop_work_bytes(const SymcoopPlan &P) { return (symcoop_xchg_bytes(P) + 255) / 256 * 256 + (sizeof(PathArgs) + 255) / 256 * 256; }      // + the kernel's arguments
 // an upper bound for any q the engine takes (workspace reservation): every block receives at most 8 SE1 partials
 size_t symcoop_xchg_bytes_max(int q)
 {
     if (q <= 1024 || q > 4096) return 0;
     const size_t T = ((size_t)q + 63) / 64;
-    return 2 * (T * 8 * SE1 * 64 * 16) + 2 * (T * 64 * 16) + 4 * ((size_t)WCOOP_GMAX * 16) + 256;
+    return 2 * (T * 8 * SE1 * 64 * 16) + 2 * (T * 64 * 16) + 4 * ((size_t)WCOOP_GMAX * 16) + 1024 + sizeof(PathArgs);
 }
 
 // OEM_NO_SYMCOOP=1: the launch-per-iteration engines

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Stamped segments of the register-resident symmetric engine (path_symcoop.hip; liboemgpu_diag.so): python tools/symcoop_diag.py [p] [nlambda] [n]"""
+"""Stamped segments of the register-resident symmetric engine (path_symcoop.hip; liboemgpu_diag.so): python tools/symcoop_diag.py [p] [nlambda] [n] [lambda.min.ratio]"""
 import ctypes as C, os, sys
 from pathlib import Path
 import numpy as np
@@ -15,7 +15,9 @@ rng = np.random.default_rng(123)
 n = int(sys.argv[3]) if len(sys.argv) > 3 else max(2 * p, 16384)
 x = rng.normal(size=(n, p)); b = np.zeros(p); b[:25] = rng.uniform(-1, 1, 25); y = x @ b + rng.normal(size=n)
 xtx, xty = x.T @ x / n, x.T @ y / n
-fit = oa.oem_xtx(torch.as_tensor(xtx, device="cuda"), xty, penalty="lasso", nlambda=nl, tol=1e-10)
+lmr = float(sys.argv[4]) if len(sys.argv) > 4 else None
+fit = oa.oem_xtx(torch.as_tensor(xtx, device="cuda"), xty, penalty="lasso", nlambda=nl, tol=1e-10, lambda_min_ratio=lmr)
+print("non-zeros at the last lambda:", int((np.asarray(fit["beta"][0])[:, -1] != 0).sum()), " kernel ms:", None)
 lib = L.lib(); lib.oemgpu_diag_read_symcoop.argtypes = [C.POINTER(C.c_ulonglong)]
 out = (C.c_ulonglong * 16)(); assert lib.oemgpu_diag_read_symcoop(out) == 0
 d = np.array(list(out), dtype=np.float64)
