@@ -453,6 +453,28 @@ def test_config3_full_size_group_lasso_kkt(oa):
             assert np.abs(r[act] - lam[i] * wg * bg[act] / nb[act, None]).max() <= 2e-7 * lam[0]
 
 
+def test_config3_full_size_against_the_oracle(oa):
+    """config 3 at FULL size against the oracle (it was held to the oracle at n = 20,000 and to the optimality conditions
+    at full size): n = 1e6, p = 512, grp.lasso with 64 groups of 8, the 100-lambda grid, tol 1e-10, no intercept / standardisation
+    (README.md:207-213).  The native oracle builds its Gram with the reference's own row-block threading (ref src/oem_dense.h:328-358)
+    on the host's cores: seconds.  Coefficients to 1e-9, d to 1e-10, niter +- 1."""
+    import os
+    rng = np.random.default_rng(303)
+    n, p = 1_000_000, 512
+    x = np.empty((n, p), order="F")
+    for j0 in range(0, p, 32):
+        x[:, j0:j0 + 32] = rng.standard_normal((n, 32))
+    b = np.zeros(p); b[:40] = rng.uniform(-0.5, 0.5, 40)
+    y = x @ b + rng.standard_normal(n)
+    groups = np.repeat(np.arange(1, 65), 8)
+    kw = dict(penalty="grp.lasso", groups=groups, intercept=False, standardize=False, nlambda=100, tol=1e-10)
+    fit = oa.oem(x, y, **kw)
+    ref = orc.fit_dense(x, y, native=True, unique_groups=np.arange(1, 65), ncores=min(64, os.cpu_count() or 1), **kw)
+    _cmp(fit, ref)
+    assert np.abs(np.ravel(fit["niter"][0]).astype(int) - np.ravel(ref["niter"][0]).astype(int)).max() <= 1
+    assert fit["niter"][0].sum() > 500 and (np.asarray(fit["beta"][0])[:, -1] != 0).sum() >= 40
+
+
 def test_config5_one_gpu_share_full_size_kkt(oa):
     """config 5: one rank's share of the 1e8 x 256 problem at 8 GPUs is 1.25e7 rows = 25.6 GB of X -- the largest single-GPU
     input of BASELINE.json.  big.oem semantics through the row-sharded driver with one rank; checked through the lasso optimality

@@ -43,6 +43,44 @@ def _cmp(fit, ref, tol=TIGHT, rows=None):
     assert abs(fit["d"] - ref["d"]) <= DTOL * abs(ref["d"])
 
 
+def _report(tag, f, r, k, tol, maxit):
+    """OEM_TEST_REPORT=file: per (test, penalty) the statistics the p >= n tolerances are set from"""
+    import os
+    path = os.environ.get("OEM_TEST_REPORT")
+    if not path:
+        return
+    fb, rb = np.asarray(f["beta"][k]), np.asarray(r["beta"][k])
+    fn, rn = np.ravel(f["niter"][k]).astype(int), np.ravel(r["niter"][k]).astype(int)
+    scale = max(1.0, float(np.abs(rb).max()))
+    colerr = np.abs(fb - rb).max(axis=0) / scale
+    same = fn == rn
+    capped = (rn > maxit) | (fn > maxit)
+    with open(path, "a") as fh:
+        fh.write(f"{tag} tol={tol:g} maxit={maxit} nlam={len(fn)} same={int(same.sum())} capped_both={int(((rn > maxit) & (fn > maxit)).sum())} capped_one={int(((rn > maxit) ^ (fn > maxit)).sum())} "
+                 f"err_same={colerr[same].max() if same.any() else 0:.2e} err_diff={colerr[~same].max() if (~same).any() else 0:.2e} "
+                 f"dn={list(np.abs(fn - rn)[~same])} rn_diff={list(rn[~same])} err_over_tol={(colerr[~same].max() / tol if (~same).any() else 0):.2f} capped={int(capped.sum())}\n")
+
+
+def _agree_with_oracle(f, r, k, tol, label):
+    """the p >= n engines against the oracle, at the resolution they deliver (these tests accepted 1e-7 and let a quarter
+    of the lambdas differ by more than one iteration).  Measured over all 608 (shape, flag, penalty) cases of this file, round 4:
+    the iteration counts are IDENTICAL to the oracle's at every lambda -- also where the loop runs into maxit, both sides report
+    maxit + 1 -- and the coefficients agree to 3e-11 of their scale.  Asserted: niter within one (a coordinate may graze the stop
+    rule), coefficients to 1e-9 where the counts are equal, and to four steps of the size the stop rule lets through where one side
+    took one iteration more."""
+    fb, rb = np.asarray(f["beta"][k]), np.asarray(r["beta"][k])
+    fn, rn = np.ravel(f["niter"][k]).astype(int), np.ravel(r["niter"][k]).astype(int)
+    dn = np.abs(fn - rn)
+    assert dn.max() <= 1, (label, dn)
+    scale = max(1.0, float(np.abs(rb).max()))
+    colerr = np.abs(fb - rb).reshape(fb.shape[0], -1).max(axis=0) / scale
+    same = dn == 0
+    assert same.mean() >= 0.75, (label, dn)
+    assert colerr[same].max() <= 1e-9, (label, colerr.max())
+    if (~same).any():
+        assert colerr[~same].max() <= max(1e-9, 4.0 * tol), (label, colerr[~same].max())
+
+
 def _data(n, p, seed, mean=0.0, sd=3.0, nnz=10):
     rng = np.random.default_rng(seed)
     x = np.asfortranarray(rng.normal(size=(n, p)) * sd + mean)
@@ -384,9 +422,8 @@ def test_wide_branch(oa, n, p, std, icpt):
     for k in range(3):
         assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-11)
         scale = max(1.0, float(np.abs(r["beta"][k]).max()))
-        assert np.abs(f["beta"][k] - r["beta"][k]).max() < 1e-7 * scale, (k, np.abs(f["beta"][k] - r["beta"][k]).max())
-        dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]))
-        assert np.mean(dn > 1) <= 0.2, dn
+        _report(f"branch n={n} p={p} std={std} {kw['penalty'][k]}", f, r, k, kw["tol"], kw["maxit"])
+        _agree_with_oracle(f, r, k, kw["tol"], kw["penalty"][k])      # (the Gram form of the iteration against the reference's two products: same counts, 1e-13)
 
 
 @pytest.mark.gpu
@@ -436,11 +473,8 @@ def test_wide_engine(oa, n, p, flag, monkeypatch):
             assert abs(f["d"] - r["d"]) < 1e-10 * r["d"], (kw["penalty"], f["d"], r["d"])
             for k in range(len(kw["penalty"])):
                 assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-11)
-                scale = max(1.0, float(np.abs(r["beta"][k]).max()))
-                err = np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max()
-                assert err < 1e-7 * scale, (kw["penalty"][k], err)
-                dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int))
-                assert np.mean(dn > 1) <= 0.25, (kw["penalty"][k], dn)
+                _report(f"site1 n={n} p={p} {kw['penalty'][k]}", f, r, k, kw["tol"], kw["maxit"])
+                _agree_with_oracle(f, r, k, kw["tol"], kw["penalty"][k])
                 if kw.get("compute_loss"):
                     assert np.allclose(f["loss"][k], r["loss"][k], rtol=1e-8)
             if kw["maxit"] == 3:
@@ -524,7 +558,7 @@ def test_wide_cooperating_engine(oa, n, p, monkeypatch):
             okw = dict(kw)
             if "groups" in okw:
                 okw["unique_groups"] = np.unique(grp)
-            r = orc.fit_dense(x, y, lambda_min_ratio=0.01 if n < p else 0.0001, **okw)
+            r = orc.fit_dense(x, y, native=True, lambda_min_ratio=0.01 if n < p else 0.0001, **okw)
             assert abs(f["d"] - r["d"]) < DTOL * r["d"], (f["d"], r["d"])
             assert abs(f["d"] - g["d"]) < DTOL * g["d"]
             for k in range(len(kw["penalty"])):
@@ -532,10 +566,9 @@ def test_wide_cooperating_engine(oa, n, p, monkeypatch):
                 assert np.array_equal(np.asarray(f["beta"][k]), np.asarray(h["beta"][k])) and np.array_equal(f["niter"][k], h["niter"][k])
                 assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-11)
                 scale = max(1.0, float(np.abs(r["beta"][k]).max()))
-                assert np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max() < 1e-7 * scale, kw["penalty"][k]
                 assert np.abs(np.asarray(f["beta"][k]) - np.asarray(g["beta"][k])).max() < 1e-9 * scale, kw["penalty"][k]
-                dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int))
-                assert np.mean(dn > 1) <= 0.25, (kw["penalty"][k], dn)
+                _report(f"site2 n={n} p={p} {kw['penalty'][k]}", f, r, k, kw["tol"], kw["maxit"])
+                _agree_with_oracle(f, r, k, kw["tol"], kw["penalty"][k])
                 dg = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(g["niter"][k]).astype(int))
                 assert dg.max() <= 1, (kw["penalty"][k], dg)
                 if kw.get("compute_loss"):
@@ -577,16 +610,15 @@ def test_wide_streamed_engine(oa, n, p, forced, monkeypatch):
             monkeypatch.setenv("OEM_NO_WSTREAM", "1")
             g = oa.oem(x, y, **kw)
             monkeypatch.delenv("OEM_NO_WSTREAM")
-            r = orc.fit_dense(x, y, lambda_min_ratio=0.01 if n < p else 0.0001, **kw)
+            r = orc.fit_dense(x, y, native=True, lambda_min_ratio=0.01 if n < p else 0.0001, **kw)
             assert abs(f["d"] - r["d"]) < DTOL * r["d"], (f["d"], r["d"])
             assert abs(f["d"] - g["d"]) < DTOL * g["d"]
             for k in range(len(kw["penalty"])):
                 assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-11)
                 scale = max(1.0, float(np.abs(r["beta"][k]).max()))
-                assert np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max() < 1e-7 * scale, kw["penalty"][k]
                 assert np.abs(np.asarray(f["beta"][k]) - np.asarray(g["beta"][k])).max() < 1e-9 * scale, kw["penalty"][k]
-                dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int))
-                assert np.mean(dn > 1) <= 0.25, (kw["penalty"][k], dn)
+                _report(f"site3 n={n} p={p} {kw['penalty'][k]}", f, r, k, kw["tol"], kw["maxit"])
+                _agree_with_oracle(f, r, k, kw["tol"], kw["penalty"][k])
                 dg = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(g["niter"][k]).astype(int))
                 assert dg.max() <= 1, (kw["penalty"][k], dg)
                 if kw.get("compute_loss"):
@@ -656,19 +688,19 @@ def test_wide_engine_tall_columns(oa, n, p, monkeypatch):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         f = oa.oem(x, y, **kw)
-        r = orc.fit_dense(x, y, lambda_min_ratio=0.01, unique_groups=np.unique(groups), **kw)
+        r = orc.fit_dense(x, y, native=True, lambda_min_ratio=0.01, unique_groups=np.unique(groups), **kw)
     assert abs(f["d"] - r["d"]) < DTOL * r["d"]
     for k in range(3):
-        assert np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max() < 1e-7 * max(1.0, float(np.abs(r["beta"][k]).max()))
-        assert np.mean(np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int)) > 1) <= 0.25
+        _report(f"tall n={n} p={p} {kw['penalty'][k]}", f, r, k, kw["tol"], kw["maxit"])
+        _agree_with_oracle(f, r, k, kw["tol"], kw["penalty"][k])
         assert np.allclose(f["loss"][k], r["loss"][k], rtol=1e-8)
     kw = dict(penalty=["lasso"], nlambda=4, tol=1e-8, maxit=200)      # element-wise alone: the fused form up to 2048 rows
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         f = oa.oem(x, y, **kw)
-        r = orc.fit_dense(x, y, lambda_min_ratio=0.01, **kw)
-    assert np.abs(np.asarray(f["beta"][0]) - np.asarray(r["beta"][0])).max() < 1e-7 * max(1.0, float(np.abs(r["beta"][0]).max()))
-    assert np.mean(np.abs(np.ravel(f["niter"][0]).astype(int) - np.ravel(r["niter"][0]).astype(int)) > 1) <= 0.25
+        r = orc.fit_dense(x, y, native=True, lambda_min_ratio=0.01, **kw)
+    _report(f"tall-fused n={n} p={p} lasso", f, r, 0, kw["tol"], kw["maxit"])
+    _agree_with_oracle(f, r, 0, kw["tol"], "lasso, fused form")
 
 
 @pytest.mark.gpu
@@ -688,13 +720,13 @@ def test_wide_engine_where_it_is_chosen(oa):
         buf = torch.zeros((p, n + 7), dtype=torch.float64, device="cuda")      # a column-major view with a leading dimension > n
         buf[:, :n] = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda")
         fl = oa.oem(buf[:, :n].t(), y, **kw)
-    r = orc.fit_dense(x, y, lambda_min_ratio=0.01, **kw)
+    r = orc.fit_dense(x, y, native=True, lambda_min_ratio=0.01, **kw)
     assert all(np.array_equal(np.asarray(fl["beta"][k]), np.asarray(fd["beta"][k])) for k in range(2))
     for f in (fh, fd):
         assert abs(f["d"] - r["d"]) < 1e-10 * r["d"]
         for k in range(2):
-            assert np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max() < 1e-7 * max(1.0, float(np.abs(r["beta"][k]).max()))
-            assert np.mean(np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int)) > 1) <= 0.25
+            _report(f"chosen n={n} p={p} {kw['penalty'][k]}", f, r, k, kw["tol"], kw["maxit"])
+            _agree_with_oracle(f, r, k, kw["tol"], kw["penalty"][k])
     # beyond 2048 rows the library takes the row-blocked form by itself (here two blocks of 1050 rows)
     n, p = 2100, 4300
     x = np.asfortranarray(rng.normal(size=(n, p)) + 0.1)
@@ -703,9 +735,10 @@ def test_wide_engine_where_it_is_chosen(oa):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         f = oa.oem(x, y, **kw)
-    r = orc.fit_dense(x, y, lambda_min_ratio=0.01, **kw)
+    r = orc.fit_dense(x, y, native=True, lambda_min_ratio=0.01, **kw)
     assert abs(f["d"] - r["d"]) < 1e-10 * r["d"]
-    assert np.abs(np.asarray(f["beta"][0]) - np.asarray(r["beta"][0])).max() < 1e-7 * max(1.0, float(np.abs(r["beta"][0]).max()))
+    _report(f"chosen-blocks n={n} p={p} lasso", f, r, 0, kw["tol"], kw["maxit"])
+    _agree_with_oracle(f, r, 0, kw["tol"], "lasso, row blocks")
     n, p = 500, 20_000
     x = np.asfortranarray(rng.normal(size=(n, p)))
     b = np.zeros(p); b[:10] = rng.uniform(1.0, 2.0, 10)
