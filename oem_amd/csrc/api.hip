@@ -314,6 +314,40 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
         if (!ok || (int)cst.size() - 1 > gmax || (int)cst.size() - 1 > c->num_cu * 3 / 4) cst.clear();
     }
     const size_t o_cst = cst.empty() ? 0 : bl.add(cst.data(), sizeof(int) * cst.size());
+    // p >= n beyond the persistent engines, group penalties: where every group is a run of neighbouring columns (<= WIDE_GRUN_MAX of
+    // them) the runs are dealt to the workgroups of the fused group kernel (path_large.hip: wide_groups_kernel) in whole runs
+    std::vector<int> grs, grg, grw;
+    int grcpw = 0;
+    if (wide && og.ngroups > 0) {
+        bool ok = true;
+        int maxrun = 1;
+        for (int j = 0; j < q && ok;) {
+            const int g = G.gid[j];
+            if (g < 0) { ok = false; break; }
+            const int len = G.gstart[g + 1] - G.gstart[g];
+            for (int k = 0; k < len && ok; ++k) ok = G.gidx[G.gstart[g] + k] == j + k;
+            if (len > WIDE_GRUN_MAX) ok = false;
+            grs.push_back(j); grg.push_back(g);
+            if (len > maxrun) maxrun = len;
+            j += len;
+        }
+        if (ok) {
+            grs.push_back(q);
+            const int Wt = wide_workgroups(wide->n, q), target = (q + Wt - 1) / Wt + maxrun - 1;      // (whole runs: never more than Wt workgroups)
+            int fill = 0;
+            grw.push_back(0);
+            for (int r = 0; r + 1 < (int)grs.size(); ++r) {
+                const int len = grs[r + 1] - grs[r];
+                if (fill > 0 && fill + len > target) { grw.push_back(r); if (fill > grcpw) grcpw = fill; fill = 0; }
+                fill += len;
+            }
+            grw.push_back((int)grs.size() - 1);
+            if (fill > grcpw) grcpw = fill;
+        } else { grs.clear(); grg.clear(); }
+    }
+    const size_t o_grs = grw.empty() ? 0 : bl.add(grs.data(), sizeof(int) * grs.size());
+    const size_t o_grg = grw.empty() ? 0 : bl.add(grg.data(), sizeof(int) * grg.size());
+    const size_t o_grw = grw.empty() ? 0 : bl.add(grw.data(), sizeof(int) * grw.size());
     // 1024 < q <= 4096, element-wise penalties: the lower triangle of XX in the registers of <= 3/4 of the CUs (path_symcoop.hip);
     // the plan is a pure function of (q, CUs): kept from call to call
     static thread_local SymcoopPlan symplan;
@@ -383,6 +417,13 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     static const bool poison = getenv("OEM_POISON_OUT") != nullptr;
     if (poison) { OEM_HIP(hipMemsetAsync(dout, 0xFF, out_stride * nbatch, c->stream)); c->blob_dev = nullptr; }
 
+    WideArgs wide_loc;
+    if (wide && !grw.empty()) {
+        wide_loc = *wide;
+        wide_loc.grun_start = (const int *)(dblob + o_grs); wide_loc.grun_gid = (const int *)(dblob + o_grg); wide_loc.grun_wg = (const int *)(dblob + o_grw);
+        wide_loc.grun_W = (int)grw.size() - 1; wide_loc.grun_cpw = grcpw;
+        wide = &wide_loc;
+    }
     PathArgs a;
     memset(&a, 0, sizeof a);
     a.p = q; a.npen = npen; a.nl = nl; a.user_lambda = user; a.maxit = o->maxit;
@@ -541,6 +582,7 @@ size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o, int nbatch = 1)
     size_t wk = q > SMALL_P_MAX ? path_large_work_doubles(q, 128) * 8 : path_small_xchg_bytes();
     if (q >= path_coop_min_q(true) && q <= 1024 && wk < path_coop_xchg_bytes()) wk = path_coop_xchg_bytes();
     b += wk * splits + 4096;
+    b += (size_t)q * 12 + 64;                                          // the runs of the fused group kernel (p >= n)
     if (q > 1024 && q <= 4096) b += symcoop_xchg_bytes_max(q) + (size_t)(80 + WCOOP_GMAX * 96) * 4 + 1024;      // path_symcoop.hip's exchange area and plan
     return b;
 }

@@ -198,7 +198,14 @@ struct WideArgs {
     WideLayout lay;
     int n;
     double *scratch;         // wide_scratch_doubles(n, p) doubles
+    // group penalties where every group is a run of neighbouring columns (the usual case): the runs in column order, dealt to the
+    // workgroups of the fused group kernel (path_large.hip: wide_groups_kernel) in whole runs.  grun_W = 0: not available.
+    const int *grun_start = nullptr;   // device: nruns + 1 column indices
+    const int *grun_gid = nullptr;     // device: group index of each run
+    const int *grun_wg = nullptr;      // device: grun_W + 1 run indices
+    int grun_W = 0, grun_cpw = 0;      // workgroups; most columns in one workgroup
 };
+static const int WIDE_GRUN_MAX = 64;  // longest run (group) the fused group kernel takes
 static const int WIDE_MAX_N = 32768;         // 16 row blocks of 2048 rows
 int wide_workgroups(int n, int p);
 size_t wide_scratch_doubles(int n, int p);

@@ -467,12 +467,15 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
     } else if (tid == 0) { st->it = it; st->ak = ak; st->reset_next = 0; st->pending_loss = -1; }
 }
 
+// uf: where the group operand U[q] and the factors F[ngroups] live when q + ngroups doubles do not fit the LDS of one workgroup
+// (q + ngroups beyond about 19,900: p >= n with a group penalty at p = 20,000 used to be refused) -- global memory, written and
+// read by this one workgroup between its own barriers; null: LDS.
 __global__ __launch_bounds__(1024) void path_update_kernel(PathArgs A, LState *st, double *__restrict__ beta,
-                                                            const double *__restrict__ g)
+                                                            const double *__restrict__ g, double *uf)
 {
     extern __shared__ __attribute__((aligned(16))) double dyn[];     // U[q] (group operand), F[ngroups]
     __shared__ double sh[16];
-    path_update(A, st, beta, g, dyn, sh);
+    path_update(A, st, beta, g, uf ? uf : dyn, sh);
 }
 
 __global__ __launch_bounds__(1024) void lanczos_update_kernel(int q, int j, double *__restrict__ v, double *__restrict__ vp,
@@ -1071,6 +1074,7 @@ __global__ void fused_init_kernel(FState *S, int npen)
     S[0] = z; S[1] = z; S[1].done = 0;
 }
 
+static size_t update_uf_doubles(int p) { return 2 * (size_t)(p + 8); }       // U[q] | F[ngroups <= q]
 static size_t sym_part_doubles(int p) { return (p % SYM_TB == 0 && p >= 2048 && p <= 4096) ? 2 * (size_t)(p / SYM_TB) * p + 16 : 0; }
 
 size_t path_large_work_doubles(int p, int nsteps)
@@ -1081,7 +1085,18 @@ size_t path_large_work_doubles(int p, int nsteps)
     // + fused Lanczos: two copies each of v, v_prev, w
     // + symmetric-tile engine: the partial vectors P[2][p / 128][p] (p a multiple of 128, p >= 2048)
     return (size_t)STATE_DBL + 5 * (size_t)(p + 8) + 2 * MAXL + 64 + 16 + 2 * (size_t)(p + 8) + FMAXB + 16 + 2 * (size_t)(p + 8) + 6 * (size_t)(p + 8) +
-           sym_part_doubles(p);
+           sym_part_doubles(p) + update_uf_doubles(p);
+}
+// where path_update_kernel keeps U | F when they do not fit its LDS: the tail of the workspace
+static double *update_uf(const PathArgs &a) { return a.work + (path_large_work_doubles(a.p, 0) - update_uf_doubles(a.p)); }
+// LDS bytes of the update kernel (U[q] | F[ngroups] for group operators), or 0 with *uf set when they go to global memory
+static size_t update_lds(const PathArgs &a, double **uf)
+{
+    *uf = nullptr;
+    if (a.ngroups <= 0) return 64;
+    const size_t sh = sizeof(double) * (size_t)(a.p + a.ngroups + 8);
+    if (sh > 160 * 1024 - 4096 && a.ngroups <= a.p) { *uf = update_uf(a); return 64; }
+    return sh;
 }
 
 // host_scratch: pinned host memory (>= 8 KB)
@@ -1295,7 +1310,8 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     // ---- path: (gemv, update) pairs replayed in batches from a hipGraph (eager launches are host-bound at ~3.5 us
     //      each); the host polls the done word once per batch.  Fusing the pair into one launch with a last-arriver
     //      hand-off was measured and is NOT faster: the agent-scope release + acquire cost what the boundary costs.
-    size_t sh = sizeof(double) * (size_t)(q + (a.ngroups > 0 ? a.ngroups : 0) + 8);
+    double *uf = nullptr;
+    const size_t sh = update_lds(a, &uf);                            // (U and F exist for group operators only)
     if (sh > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&path_update_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
@@ -1304,7 +1320,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     auto enqueue = [&](int count) {
         for (int k = 0; k < count; ++k) {
             (void)launch_gemv(s, a.xx, q, beta, g, &st->done, num_cu);
-            hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), sh, s, a, st, beta, g);
+            hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), sh, s, a, st, beta, g, uf);
         }
     };
     const int BATCH = 128;
@@ -1593,6 +1609,163 @@ __global__ __launch_bounds__(64 * wide_nw(NR)) void wide_cols_kernel(PathArgs A,
     }
 }
 
+// The fused iteration with GROUP operators (ref src/oem_dense.h:193-315, 513-521), for groups that are runs of neighbouring columns of
+// at most WIDE_GRUN_MAX members: a run is coordinate-local to ONE wave, as a column is in wide_cols_kernel<W_OEM>.  The wave walks
+// its runs (run w, w + NW, ... of the workgroup's):
+//   pass 1   u_c = x_c . r / n + d beta_c for the members in member order (sparse group lasso: soft-thresholded), kept in LDS words
+//            of the wave's own; the squared norm summed in member order like the reference; the group's factor
+//   pass 2   beta_c' = u_c f / D, the stop rule; r' += x_c beta_c' -- the column is read AGAIN only where beta_c' != 0 (it came by a
+//            moment ago: L2), so a sparse iterate streams Xs once per iteration like the element-wise form
+// One launch + the reduction per iteration instead of four launches around the one-workgroup update kernel (500 x 30,000, 3,000
+// groups of 10: 87 -> us per iteration; and no LDS limit on p + ngroups).  Element-wise penalties of the same call run through the
+// same kernel (runs are just a way of dealing columns).  Stop rule / lambda bookkeeping replicated one launch later as in W_OEM.
+template <int NR>
+__global__ __launch_bounds__(64 * wide_nw(NR)) void wide_groups_kernel(PathArgs A, const double *__restrict__ xs, const double *__restrict__ rin,
+                                                           const double *__restrict__ ysv, double *__restrict__ P, double *__restrict__ beta,
+                                                           SState *__restrict__ S, int *__restrict__ flags, int *__restrict__ fdone, int par, double d,
+                                                           int n, int cpw, const int *__restrict__ rstart, const int *__restrict__ rgid,
+                                                           const int *__restrict__ wgrun)
+{
+    extern __shared__ __attribute__((aligned(16))) double wsh[];     // [NW][64 NR] | beta [cpw] | penalty factors [cpw] | u of a wave's run [NW][WIDE_GRUN_MAX]
+    constexpr int NP = 64 * NR, NW = wide_nw(NR), NT = 64 * NW;
+    double *bsh = wsh + NW * NP, *pfsh = bsh + cpw, *ush = pfsh + cpw;
+    const int q = A.p, nl = A.nl, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r0 = wgrun[blockIdx.x], r1 = wgrun[blockIdx.x + 1];
+    const int jbeg = rstart[r0], jend = rstart[r1];
+    const double rn = 1.0 / (double)n;
+    const SState st = S[par];
+    int fl[(FMAXB + NT - 1) / NT];
+#pragma unroll
+    for (int k = 0; k < (FMAXB + NT - 1) / NT; ++k) { const int t = tid + NT * k; fl[k] = flags[par * FMAXB + (t < (int)gridDim.x ? t : 0)]; }
+    for (int t = tid; t < jend - jbeg; t += NT) { bsh[t] = beta[jbeg + t]; pfsh[t] = A.pf[jbeg + t]; }
+    if (st.done) {
+        if (blockIdx.x == 0 && tid == 0) { S[par ^ 1].done = 1; *fdone = 1; }
+        return;
+    }
+    int f = 0;
+#pragma unroll
+    for (int k = 0; k < (FMAXB + NT - 1) / NT; ++k) f |= (tid + NT * k < (int)gridDim.x) ? fl[k] : 0;
+    const int any = __syncthreads_or(f);                             // (also the barrier behind bsh / pfsh)
+    int pp = st.pp, i = st.i, it = st.it, pen = st.pen, niter_fin = 0;
+    double lam = st.lam;
+    bool fresh = st.fresh != 0, finalize = false, done_now = false, advanced = false;
+    size_t kfin = 0;
+    if (!fresh) {
+        const bool conv = !any;
+        if (conv || it >= A.maxit) {
+            finalize = true; kfin = (size_t)pp * nl + i; niter_fin = conv ? it : A.maxit + 1;     // ref src/oem_base.h:94-109
+            const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
+            if (i + 1 < nlam) { i = i + 1; advanced = true; }
+            else if (pp + 1 < A.npen) { pp = pp + 1; i = 0; fresh = true; advanced = true; }
+            else done_now = true;
+            if (advanced) { pen = st.pen_next; lam = st.lam_next; }
+            it = 0;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        SState nx = st;
+        nx.pp = pp; nx.i = i; nx.it = it + 1; nx.done = done_now ? 1 : 0; nx.fresh = 0; nx.pen = pen; nx.lam = lam;
+        if (advanced) sym_successor(A, pp, i, pen, nx.pen_next, nx.lam_next);
+        S[par ^ 1] = nx;
+        if (finalize) { A.niter[kfin] = niter_fin; A.loss[kfin] = 1e99; }
+    }
+    if (finalize) for (int jj = jbeg + tid; jj < jend; jj += NT) A.beta[kfin * q + jj] = bsh[jj - jbeg];
+    if (done_now) return;
+    double rr[NR], rp[NR];
+    wide_load<NR>(rr, fresh ? ysv : rin, lane);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) rp[k] = 0.0;
+    const PenK K = pen_consts(pen, lam / st.scaley, d, A.alpha, A.gamma, A.tau);
+    const double rD = 1.0 / K.D, gammad = K.gamma * K.D, dmg = K.D - 1.0 / K.gamma, rdmg = 1.0 / dmg;
+    const double gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0, rdsc = 1.0 / dsc, rd = 1.0 / d;
+    const bool grp = K.kind >= K_GRP;
+    bool moving = false;
+    double *uw = ush + w * WIDE_GRUN_MAX;
+    double xa[NR], xb[NR];
+    int run = r0 + w;
+    if (run < r1) wide_load<NR>(xa, xs + (size_t)rstart[run] * NP, lane);
+    for (; run < r1; run += NW) {
+        const int c0 = rstart[run], c1 = rstart[run + 1], g = rgid[run];
+        const int cnext = run + NW < r1 ? rstart[run + NW] : -1;
+        // ---- pass 1: u of the members (the next column is asked for before this one is consumed)
+        double s2 = 0.0;
+        for (int c = c0; c < c1; ++c) {
+            const int cn = c + 1 < c1 ? c + 1 : cnext;
+            if (cn >= 0) wide_load<NR>(xb, xs + (size_t)cn * NP, lane);
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < NR; k += 2) { a0 = fma(xa[k], rr[k], a0); if (k + 1 < NR) a1 = fma(xa[k + 1], rr[k + 1], a1); }
+            const double dot = wsum(a0 + a1);
+            const double b0 = fresh ? 0.0 : bsh[c - jbeg];
+            double u = dot * rn + d * b0;                            // ref src/oem_dense.h:520
+            if (grp) {
+                if (K.kind == K_SGL) u = soft1(u, pfsh[c - jbeg] * K.L1, 1.0);
+                s2 += u * u;
+                if (lane == 0) uw[c - c0] = u;
+            } else {                                                 // element-wise operators: the column is done here, as in wide_cols_kernel
+                const double tp = pfsh[c - jbeg] * K.L;
+                double bn;
+                if (K.kind == K_SOFT) bn = cdiv(shrink(u, tp), K.D, rD);
+                else if (K.kind == K_MCP) {
+                    const bool big = fabs(u) > gammad * tp;
+                    bn = cdiv(big ? u : shrink(u, tp), big ? K.D : dmg, big ? rD : rdmg);
+                } else if (K.kind == K_SCAD) {
+                    const double au = fabs(u);
+                    const bool big = au > gammad * tp, mid = !big && au > (K.D + 1.0) * tp;
+                    const double num = big ? u : (mid ? shrink(gm1 * u, K.gamma * tp) : shrink(u, tp));
+                    bn = cdiv(num, mid ? dsc : K.D, mid ? rdsc : rD);
+                } else bn = cdiv(u, d, rd);
+                const double cu = fabs(bn), qo = fabs(b0);
+                const bool cnz = cu > 1e-13, qn = qo > 1e-13;
+                moving |= (cnz != qn) || (cnz && qn && fabs(bn - b0) > A.tol * qo);
+                if (lane == 0) beta[c] = bn;
+                if (bn != 0.0) {
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) rp[k] = fma(xa[k], bn, rp[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NR; ++k) xa[k] = xb[k];
+        }
+        if (!grp) continue;
+        // ---- the group's factor (the update kernel's arithmetic: path_update)
+        double fct = 1.0;
+        if (g < 0) fct = 0.0;
+        else if (!A.gzero[g]) {
+            const double s = sqrt(s2), pen_g = K.L * A.gw[g];
+            if (K.kind == K_GRP || K.kind == K_SGL) { const double t = 1.0 - pen_g / s; fct = (0.0 < t) ? t : 0.0; }
+            else if (K.kind == K_GRP_MCP) fct = mcp_norm(s, pen_g, K.D, K.gamma);
+            else fct = scad_norm(s, pen_g, K.D, K.gamma);
+        }
+        // ---- pass 2: the members' coefficients; a column is read again only where its coefficient is not zero
+        for (int c = c0; c < c1; ++c) {
+            const double u = uw[c - c0], b0 = fresh ? 0.0 : bsh[c - jbeg];
+            const double bn = (fct != 0.0) ? u * fct / K.D : 0.0;
+            const double cu = fabs(bn), qo = fabs(b0);
+            const bool cnz = cu > 1e-13, qn = qo > 1e-13;
+            moving |= (cnz != qn) || (cnz && qn && fabs(bn - b0) > A.tol * qo);
+            if (lane == 0) beta[c] = bn;
+            if (bn != 0.0) {
+                double xc[NR];
+                wide_load<NR>(xc, xs + (size_t)c * NP, lane);
+#pragma unroll
+                for (int k = 0; k < NR; ++k) rp[k] = fma(xc[k], bn, rp[k]);
+            }
+        }
+    }
+    const int mv = __syncthreads_or(moving ? 1 : 0);
+    if (tid == 0) flags[(par ^ 1) * FMAXB + blockIdx.x] = mv;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) wsh[w * NP + lane + 64 * k] = rp[k];
+    __syncthreads();
+    for (int r = tid; r < NP; r += NT) {
+        double t = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) t += wsh[ww * NP + r];
+        P[(size_t)blockIdx.x * NP + r] = t;
+    }
+}
+
 // out = Ys - sum_w P[w] (W_OEM: the residual) | sum / n (W_EIG: Xs Xs' v / n) | sum (W_XB: Xs beta).  64 rows per workgroup, sixteen
 // interleaved chains over the workgroups' partial vectors (eight loads in flight per thread: a chain of W dependent-free loads
 // issued one by one was the whole iteration's time), combined in a fixed order: bitwise reproducible.
@@ -1698,16 +1871,14 @@ static int run_path_wide_blocks(hipStream_t s, const PathArgs &a, const WideArgs
     hipLaunchKernelGGL(path_init_kernel, dim3(1), dim3(1024), 0, s, a, st, beta, d, theta, m, lz_capped ? 1 : 0);
     OEM_HIP(hipGetLastError());
     if (a.npen == 0) return 0;
-    const size_t shu = a.ngroups > 0 ? sizeof(double) * (size_t)(q + a.ngroups + 8) : 64;
-    if (shu > 64 * 1024) {
-        if (shu > 160 * 1024 - 4096) { set_error("p >= n with a group penalty: p = %d does not fit the update kernel's LDS", q); return OEMGPU_ERR_UNSUPPORTED; }
-        OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shu));
-    }
+    double *uf = nullptr;
+    const size_t shu = update_lds(a, &uf);
+    if (shu > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shu));
     auto enq = [&](int count) {
         for (int k = 0; k < count; ++k) {
             xb(beta, t, (const int *)&st->done);
             xtv(t, g, (const int *)&st->done);
-            hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), shu, s, a, st, beta, g);
+            hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), shu, s, a, st, beta, g, uf);
         }
     };
     const int FB = 16;
@@ -1802,15 +1973,22 @@ static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd
     OEM_HIP(hipGetLastError());
     if (a.npen == 0) return 0;
     const bool fused = a.ngroups == 0 && !a.accelerate && !a.compute_loss && !a.sinv && W <= FMAXB && !getenv("OEM_WIDE_GENERAL");
-    size_t shu = a.ngroups > 0 ? sizeof(double) * (size_t)(q + a.ngroups + 8) : 64;        // U[q] | F[ngroups]: group operators only
-    if (!fused && shu > 64 * 1024) {
-        if (shu > 160 * 1024 - 4096) { set_error("p >= n with a group penalty: p = %d does not fit the update kernel's LDS", q); return OEMGPU_ERR_UNSUPPORTED; }
-        OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shu));
-    }
-    if (fused) hipLaunchKernelGGL(sym_init_kernel, dim3(1), dim3(1), 0, s, SS, a);
+    // group penalties whose groups are runs of neighbouring columns: the fused GROUP form (wide_groups_kernel), one launch + the reduction
+    const bool gfused = !fused && a.ngroups > 0 && wd.grun_W > 0 && wd.grun_W <= W && wd.grun_W <= FMAXB && !a.accelerate && !a.compute_loss && !a.sinv &&
+                        !getenv("OEM_WIDE_GENERAL") && !getenv("OEM_WIDE_NO_GROUP_FUSED");
+    const size_t ldsg = sizeof(double) * ((size_t)wide_nw(NR) * (size_t)npad + 2 * (size_t)wd.grun_cpw + (size_t)wide_nw(NR) * WIDE_GRUN_MAX);
+    if (gfused && ldsg > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_groups_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
+    double *uf = nullptr;
+    const size_t shu = update_lds(a, &uf);                           // U[q] | F[ngroups]: group operators only
+    if (!fused && shu > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shu));
+    if (fused || gfused) hipLaunchKernelGGL(sym_init_kernel, dim3(1), dim3(1), 0, s, SS, a);
     auto enq = [&](int count) {
         for (int k = 0; k < count; ++k) {
-            if (fused) {
+            if (gfused) {
+                hipLaunchKernelGGL((wide_groups_kernel<NR>), dim3(wd.grun_W), dim3(NT), ldsg, s, a, wd.xs, r, wd.ys, P, beta, SS, flags, fdone, k & 1, d, n,
+                                   wd.grun_cpw, wd.grun_start, wd.grun_gid, wd.grun_wg);
+                hipLaunchKernelGGL((wide_reduce_kernel<W_OEM>), dim3(rblocks), dim3(1024), 0, s, P, wd.grun_W, npad, n, wd.ys, r, (const int *)fdone);
+            } else if (fused) {
                 hipLaunchKernelGGL((wide_cols_kernel<NR, W_OEM>), dim3(W), dim3(NT), lds, s, a, wd.xs, r, wd.ys, P, beta, (double *)nullptr, SS, flags,
                                    fdone, (const int *)nullptr, k & 1, d, n, cpw);
                 hipLaunchKernelGGL((wide_reduce_kernel<W_OEM>), dim3(rblocks), dim3(1024), 0, s, P, W, npad, n, wd.ys, r, (const int *)fdone);
@@ -1820,11 +1998,11 @@ static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd
                 hipLaunchKernelGGL((wide_reduce_kernel<W_XB>), dim3(rblocks), dim3(1024), 0, s, P, W, npad, n, wd.ys, t, (const int *)&st->done);
                 hipLaunchKernelGGL((wide_cols_kernel<NR, W_XTV>), dim3(W), dim3(NT), lds, s, a, wd.xs, t, wd.ys, P, (double *)nullptr, g,
                                    (SState *)nullptr, (int *)nullptr, (int *)nullptr, (const int *)&st->done, 0, d, n, cpw);
-                hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), shu, s, a, st, beta, g);
+                hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), shu, s, a, st, beta, g, uf);
             }
         }
     };
-    const int FB = fused ? 64 : 32;                                  // even: every batch starts at parity 0
+    const int FB = (fused || gfused) ? 64 : 32;                      // even: every batch starts at parity 0
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -1844,7 +2022,7 @@ static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd
         else enq(FB);
         if (hipGetLastError() != hipSuccess) { set_error("wide engine: launch failed"); rc = OEMGPU_ERR_HIP; break; }
         launched += FB;
-        if (hipMemcpyAsync(hdone, fused ? fdone : &st->done, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        if (hipMemcpyAsync(hdone, (fused || gfused) ? fdone : &st->done, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess) { set_error("wide engine: device error"); rc = OEMGPU_ERR_HIP; break; }
         if (*hdone) break;
         if (caller_interrupted()) { set_error("interrupted by the caller"); rc = OEMGPU_ERR_INTERRUPTED; break; }

@@ -81,6 +81,25 @@ def _agree_with_oracle(f, r, k, tol, label):
         assert colerr[~same].max() <= max(1e-9, 4.0 * tol), (label, colerr[~same].max())
 
 
+def _oracle_wide(x, y, f, **kw):
+    """the oracle's p >= n branch for the larger shapes of this file: its exact dense eigen-solve of the n x n matrix Xs Xs'/n is
+    O(n^3) Jacobi sweeps (a minute at n = 2048, most of this file's run time).  From 600 rows on, d is held against LAPACK instead
+    (2-norm of the standardised data, ref src/DataStd.h:94-267 restated in three numpy lines, 1e-10) and handed to the oracle, as
+    the config-4 tests do: the comparison that remains is the path's."""
+    n = x.shape[0]
+    if n < 600:
+        return orc.fit_dense(x, y, native=True, **kw)
+    std, icpt = kw.get("standardize", True), kw.get("intercept", True)
+    mu = x.mean(axis=0)
+    xs = x - mu if icpt else x.copy()
+    if std:
+        sd = np.sqrt(((x - mu) ** 2).sum(axis=0) / n); sd[sd == 0] = 1.0
+        xs = xs / sd
+    dref = 1.005 * np.linalg.norm(xs, 2) ** 2 / n
+    assert abs(f["d"] - dref) <= DTOL * dref, (f["d"], dref)
+    return orc.fit_dense(x, y, native=True, d_override=f["d"], **kw)
+
+
 def _data(n, p, seed, mean=0.0, sd=3.0, nnz=10):
     rng = np.random.default_rng(seed)
     x = np.asfortranarray(rng.normal(size=(n, p)) * sd + mean)
@@ -558,7 +577,7 @@ def test_wide_cooperating_engine(oa, n, p, monkeypatch):
             okw = dict(kw)
             if "groups" in okw:
                 okw["unique_groups"] = np.unique(grp)
-            r = orc.fit_dense(x, y, native=True, lambda_min_ratio=0.01 if n < p else 0.0001, **okw)
+            r = _oracle_wide(x, y, f, lambda_min_ratio=0.01 if n < p else 0.0001, **okw)
             assert abs(f["d"] - r["d"]) < DTOL * r["d"], (f["d"], r["d"])
             assert abs(f["d"] - g["d"]) < DTOL * g["d"]
             for k in range(len(kw["penalty"])):
@@ -610,7 +629,7 @@ def test_wide_streamed_engine(oa, n, p, forced, monkeypatch):
             monkeypatch.setenv("OEM_NO_WSTREAM", "1")
             g = oa.oem(x, y, **kw)
             monkeypatch.delenv("OEM_NO_WSTREAM")
-            r = orc.fit_dense(x, y, native=True, lambda_min_ratio=0.01 if n < p else 0.0001, **kw)
+            r = _oracle_wide(x, y, f, lambda_min_ratio=0.01 if n < p else 0.0001, **kw)
             assert abs(f["d"] - r["d"]) < DTOL * r["d"], (f["d"], r["d"])
             assert abs(f["d"] - g["d"]) < DTOL * g["d"]
             for k in range(len(kw["penalty"])):
@@ -684,23 +703,96 @@ def test_wide_engine_tall_columns(oa, n, p, monkeypatch):
     monkeypatch.setenv("OEM_WIDE", "1")
     x, y = _data(n, p, 40 + n, mean=0.2, nnz=8)
     groups = np.arange(p) // 6 + 1
-    kw = dict(penalty=["lasso", "mcp", "grp.lasso"], groups=groups, nlambda=4, tol=1e-8, maxit=200, compute_loss=True)
+    kw = dict(penalty=["lasso", "mcp", "grp.lasso"], groups=groups, nlambda=4, tol=1e-8, maxit=80, compute_loss=True)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         f = oa.oem(x, y, **kw)
-        r = orc.fit_dense(x, y, native=True, lambda_min_ratio=0.01, unique_groups=np.unique(groups), **kw)
+        r = _oracle_wide(x, y, f, lambda_min_ratio=0.01, unique_groups=np.unique(groups), **kw)
     assert abs(f["d"] - r["d"]) < DTOL * r["d"]
     for k in range(3):
         _report(f"tall n={n} p={p} {kw['penalty'][k]}", f, r, k, kw["tol"], kw["maxit"])
         _agree_with_oracle(f, r, k, kw["tol"], kw["penalty"][k])
         assert np.allclose(f["loss"][k], r["loss"][k], rtol=1e-8)
-    kw = dict(penalty=["lasso"], nlambda=4, tol=1e-8, maxit=200)      # element-wise alone: the fused form up to 2048 rows
+    kw = dict(penalty=["lasso"], nlambda=4, tol=1e-8, maxit=80)       # element-wise alone: the fused form up to 2048 rows
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         f = oa.oem(x, y, **kw)
-        r = orc.fit_dense(x, y, native=True, lambda_min_ratio=0.01, **kw)
+        r = _oracle_wide(x, y, f, lambda_min_ratio=0.01, **kw)
     _report(f"tall-fused n={n} p={p} lasso", f, r, 0, kw["tol"], kw["maxit"])
     _agree_with_oracle(f, r, 0, kw["tol"], "lasso, fused form")
+
+
+@pytest.mark.gpu
+def test_wide_engine_group_penalties_beyond_one_workgroups_lds(oa):
+    """p >= n with group penalties where the operand of the group stage (u and the group factors: p + ngroups doubles) does not
+    fit the LDS of the update kernel's one workgroup -- p + ngroups beyond about 19,900 used to return OEMGPU_ERR_UNSUPPORTED
+    (the reference has no such limit, ref src/oem_dense.h:277-315, 513-521).  They now live in global memory there.
+    500 x 30,000, 3,000 groups of 10 (group 0 unpenalised, weights), grp.lasso + sparse.grp.lasso + grp.mcp, against the oracle."""
+    rng = np.random.default_rng(4)
+    n, p = 500, 30_000
+    x = np.asfortranarray(rng.normal(size=(n, p)) + 0.1)
+    b = np.zeros(p); b[:20] = rng.uniform(0.5, 1.5, 20)
+    y = x @ b + rng.normal(size=n)
+    groups = np.arange(p) // 10                                     # ids 0 .. 2999: group 0 is not penalised
+    gw = rng.uniform(0.5, 2.0, 3000)
+    kw = dict(penalty=["grp.lasso", "sparse.grp.lasso", "grp.mcp"], groups=groups, group_weights=gw, tau=0.3, nlambda=3, tol=1e-8, maxit=25,
+              compute_loss=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f = oa.oem(x, y, **kw)
+        r = _oracle_wide(x, y, f, lambda_min_ratio=0.01, unique_groups=np.unique(groups), **kw)
+    assert abs(f["d"] - r["d"]) < DTOL * r["d"]
+    for k in range(3):
+        _agree_with_oracle(f, r, k, kw["tol"], kw["penalty"][k])
+        assert np.allclose(f["loss"][k], r["loss"][k], rtol=1e-8)
+        assert np.any(np.asarray(f["beta"][k])[1:, -1] != 0)
+    # without compute.loss the groups -- runs of neighbouring columns -- take the fused group kernel: the same coefficients
+    kw.pop("compute_loss")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        h = oa.oem(x, y, **kw)
+    for k in range(3):
+        _agree_with_oracle(h, r, k, kw["tol"], kw["penalty"][k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,p", [(120, 9000), (300, 14000), (600, 5000), (1100, 4100), (2000, 2600)])
+def test_wide_fused_group_kernel(oa, n, p, monkeypatch):
+    """p >= n beyond the persistent engines with group penalties whose groups are runs of neighbouring columns: ONE launch + the
+    reduction per iteration (path_large.hip: wide_groups_kernel -- a run is coordinate-local to a wave: u of its members, the norm
+    in member order, the factor, the coefficients; a column is read again only where its coefficient is not zero) instead of four
+    launches around the one-workgroup update kernel.  Ragged runs (1 .. 23 members), group 0 unpenalised, weights, all four group
+    operators and element-wise penalties in the same call, penalty factors, maxit reached, several column heights -- against the
+    oracle and against the general form (OEM_WIDE_NO_GROUP_FUSED=1), which must agree to rounding with the same iteration counts."""
+    monkeypatch.setenv("OEM_WIDE", "1"); monkeypatch.setenv("OEM_NO_WCOOP", "1"); monkeypatch.setenv("OEM_NO_WSTREAM", "1")
+    x, y = _data(n, p, 5100 + n, mean=0.2, nnz=8)
+    rng = np.random.default_rng(n + p)
+    sizes = []
+    while sum(sizes) < p:
+        sizes.append(int(rng.integers(1, 24)))
+    sizes[-1] -= sum(sizes) - p
+    ids = rng.permutation(len(sizes))                                # group ids in no particular order along the columns; id 0 is unpenalised
+    groups = np.repeat(ids, sizes)
+    gw = rng.uniform(0.5, 2.0, len(sizes))
+    pf = rng.uniform(0.5, 2.0, p); pf[rng.integers(p)] = 0.0
+    for kw in (dict(penalty=["grp.lasso", "sparse.grp.lasso", "lasso", "grp.mcp", "grp.scad.net"], groups=groups, group_weights=gw, penalty_factor=pf, alpha=0.6,
+                    tau=0.4, nlambda=3, tol=1e-8, maxit=60),
+               dict(penalty=["grp.lasso"], groups=groups, nlambda=3, tol=1e-12, maxit=3, standardize=False, intercept=True)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            f = oa.oem(x, y, **kw)
+            monkeypatch.setenv("OEM_WIDE_NO_GROUP_FUSED", "1")
+            g = oa.oem(x, y, **kw)
+            monkeypatch.delenv("OEM_WIDE_NO_GROUP_FUSED")
+            r = _oracle_wide(x, y, f, lambda_min_ratio=0.01, unique_groups=np.unique(groups), **kw)
+        assert abs(f["d"] - r["d"]) < DTOL * r["d"]
+        for k in range(len(kw["penalty"])):
+            _agree_with_oracle(f, r, k, kw["tol"], kw["penalty"][k])
+            scale = max(1.0, float(np.abs(np.asarray(g["beta"][k])).max()))
+            assert np.abs(np.asarray(f["beta"][k]) - np.asarray(g["beta"][k])).max() < 1e-10 * scale, kw["penalty"][k]
+            assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(g["niter"][k]).astype(int)).max() <= 1
+        if kw["maxit"] == 3:
+            assert f["niter"][0].max() == 4
 
 
 @pytest.mark.gpu
@@ -720,7 +812,7 @@ def test_wide_engine_where_it_is_chosen(oa):
         buf = torch.zeros((p, n + 7), dtype=torch.float64, device="cuda")      # a column-major view with a leading dimension > n
         buf[:, :n] = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda")
         fl = oa.oem(buf[:, :n].t(), y, **kw)
-    r = orc.fit_dense(x, y, native=True, lambda_min_ratio=0.01, **kw)
+    r = _oracle_wide(x, y, fh, lambda_min_ratio=0.01, **kw)
     assert all(np.array_equal(np.asarray(fl["beta"][k]), np.asarray(fd["beta"][k])) for k in range(2))
     for f in (fh, fd):
         assert abs(f["d"] - r["d"]) < 1e-10 * r["d"]
@@ -735,7 +827,7 @@ def test_wide_engine_where_it_is_chosen(oa):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         f = oa.oem(x, y, **kw)
-    r = orc.fit_dense(x, y, native=True, lambda_min_ratio=0.01, **kw)
+    r = _oracle_wide(x, y, f, lambda_min_ratio=0.01, **kw)
     assert abs(f["d"] - r["d"]) < 1e-10 * r["d"]
     _report(f"chosen-blocks n={n} p={p} lasso", f, r, 0, kw["tol"], kw["maxit"])
     _agree_with_oracle(f, r, 0, kw["tol"], "lasso, row blocks")
