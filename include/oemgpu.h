@@ -279,6 +279,10 @@ void oemgpu_release_cache(void);
  * and never more sets than the exchange scratch was sized for; otherwise +/- the offending workgroup count. */
 int oemgpu_selftest_wcoop_sizing(int32_t n, int32_t p, int32_t npen, int32_t num_cu);
 
+/* Self-test aid (tests/test_gpu_host.py): enqueue, on the context's stream, `blocks` workgroups that each occupy a whole CU and
+ * spin for `ms` milliseconds -- "somebody else holds the CUs", for the fallback of the persistent engines.  Asynchronous. */
+int oemgpu_selftest_hold_cus(oemgpu_ctx *ctx, int32_t blocks, double ms);
+
 const char *oemgpu_last_error(void);
 const char *oemgpu_version(void);
 int         oemgpu_device_count(void);

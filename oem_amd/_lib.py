@@ -83,6 +83,7 @@ _SIGS = {
     "oemgpu_row_split": (None, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "oemgpu_last_host_stats": (C.c_int, [_dp]),
     "oemgpu_release_cache": (None, []),
+    "oemgpu_selftest_hold_cus": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "oemgpu_selftest_wcoop_sizing": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "oemgpu_last_error": (C.c_char_p, []),
     "oemgpu_version": (C.c_char_p, []),

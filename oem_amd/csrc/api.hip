@@ -604,6 +604,15 @@ int shard_moments(oemgpu_ctx *c, const GramPlan &pl, const double *x, int64_t n,
     return launch_moments_reduce(c->stream, pl, tpart, vpart, moments);
 }
 
+// self-test aid: `blocks` workgroups that each take a whole CU (150 KB of LDS) and spin for `ms` milliseconds of device time
+__global__ __launch_bounds__(256) void hold_cus_kernel(unsigned long long ticks, int *sink)
+{
+    extern __shared__ int hold_lds[];
+    hold_lds[threadIdx.x] = (int)threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (hold_lds[threadIdx.x] == -1 && sink) *sink = 1;
+}
 }  // namespace
 
 // =====================================================================================================
@@ -692,6 +701,17 @@ int oemgpu_synchronize(oemgpu_ctx *c)
 {
     if (!c) { set_error("ctx is NULL"); return OEMGPU_ERR_ARG; }
     OEM_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int oemgpu_selftest_hold_cus(oemgpu_ctx *c, int32_t blocks, double ms)
+{
+    if (!c || blocks < 1 || blocks > 4096 || !(ms > 0.0) || ms > 30000.0) { set_error("hold_cus: bad argument"); return OEMGPU_ERR_ARG; }
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    const int lds = 150 * 1024;
+    OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hold_cus_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(hold_cus_kernel, dim3(blocks), dim3(256), lds, c->stream, (unsigned long long)(ms * 1e5), (int *)nullptr);      // s_memrealtime: 100 MHz
+    OEM_HIP(hipGetLastError());
     return 0;
 }
 

@@ -322,3 +322,54 @@ def test_concurrent_callers_of_the_cooperating_wide_engine(oa):
         assert f["d"] == alone["d"]
         for k in range(2):
             assert np.array_equal(f["beta"][k], alone["beta"][k]) and np.array_equal(f["niter"][k], alone["niter"][k])
+
+
+@pytest.mark.gpu
+def test_persistent_engine_under_real_contention(oa, tmp_path):
+    """the fallback of the persistent engines had only ever been tested with a FAKED poison.  Here a second PROCESS
+    holds 200 of the device's CUs (tests/hold_cus_worker.py: workgroups that take a whole CU each and spin for six seconds) while
+    this process calls oem.xtx at p = 4096, whose persistent engine (path_symcoop.hip) needs 174 workgroups resident at once.
+    Whatever the hardware scheduler does -- run what fits beside the holder, so that the exchanges time out after about a second
+    and the call is made again on the launch-per-iteration engine, or queue the launch behind the holder -- the call must come
+    back, within a bounded time, with a right answer: the bits of one of the two engines."""
+    import os, subprocess, sys, time
+    import torch
+    xtx, xty = _xtx_problem_host(4096, 8192, 5)
+    xd = torch.as_tensor(xtx, device="cuda")
+    kw = dict(penalty="lasso", nlambda=5, tol=1e-8)
+    alone = oa.oem_xtx(xd, xty, **kw)
+    os.environ["OEM_NO_SYMCOOP"] = "1"
+    try:
+        launches = oa.oem_xtx(xd, xty, **kw)
+    finally:
+        del os.environ["OEM_NO_SYMCOOP"]
+    flag = tmp_path / "hold.flag"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    holder = subprocess.Popen([sys.executable, os.path.join(root, "tests", "hold_cus_worker.py"), "200", "6000", str(flag)], cwd=root,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        t0 = time.time()
+        while not flag.exists() and time.time() - t0 < 120:
+            time.sleep(0.05)
+        assert flag.exists(), "the holder never started"
+        time.sleep(0.3)
+        t1 = time.time()
+        during = oa.oem_xtx(xd, xty, **kw)
+        wall = time.time() - t1
+        held = flag.read_text() == "holding"                       # (still holding when the call came back?)
+    finally:
+        out, err = holder.communicate(timeout=120)
+    assert "HOLD_DONE" in out, (out[-500:], err[-1500:])
+    assert wall < 30.0, wall
+    same_as = [name for name, ref in (("persistent", alone), ("launches", launches))
+               if np.array_equal(np.asarray(during["beta"][0]), np.asarray(ref["beta"][0])) and np.array_equal(during["niter"][0], ref["niter"][0])]
+    assert same_as, "the answer under contention matches neither engine"
+    print(f"under contention: {wall:.2f} s, answer of the {same_as[0]} engine, holder still holding at return: {held}")
+
+
+def _xtx_problem_host(p, n, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=(n, p))
+    b = np.zeros(p); b[:25] = rng.uniform(-1, 1, 25)
+    y = x @ b + rng.normal(size=n)
+    return x.T @ x / n, x.T @ y / n
