@@ -264,7 +264,7 @@ enum { SEM_XTX = 2, SEM_SPARSE = 4 };        // OEMGPU_SEM_XVAL = 3 (oemgpu.h): 
 int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const double *stats, int p, int q, int sem,
               int standardize, int intercept, const oemgpu_opts *o, const double *scale_factor,
               double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out,
-              int nbatch = 1, size_t bstride = 0, bool shared_lmax = false, const WideArgs *wide = nullptr)
+              int nbatch = 1, size_t bstride = 0, bool shared_lmax = false, const WideArgs *wide = nullptr, const double *lmax_xy_dev = nullptr)
 {
     const int nl = nl_of(o), npen = o->npen;
     const bool user = o->lambda_user && o->nlambda_user > 0;
@@ -443,7 +443,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     double *dstats = a.d_out + D_OUT_LEN;
     a.niter = (int *)(dstats + stats_len(p));
     a.work = (double *)(c->ws + a_work);
-    a.lmax_xy = (nbatch > 1 && shared_lmax) ? xy : nullptr;        // instance 0's X'Y
+    a.lmax_xy = (nbatch > 1 && shared_lmax) ? xy : lmax_xy_dev;    // instance 0's X'Y; or the caller's (big.oem with p >= n: the scaled X'y)
     a.pen_split = pen_split; a.pen_lo = 0; a.pen_hi = npen;
     a.nbatch = nbatch; a.bs_xx = a.bs_xy = a.bs_stats = (long long)bstride; a.bs_out = (long long)out_stride; a.bs_work = (long long)work_d;
 
@@ -851,6 +851,54 @@ static int fit_dense_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int
                      1, 0, false, &wd);
 }
 
+// big.oem / oem() on a sparse x with nobs <= nvars and NO intercept (ref src/oem_big.h:537-541, 568-584, 743-764, 880-897;
+// src/oem_sparse.h:607-612, 638-647): the iteration u = X'(Y - X beta)/n + d beta on the data AS THEY ARE, d from X X'/n, no y scaling;
+// with standardize only lambda_zero (max |x_j'y| colsq_inv_j / n) and the returned coefficients (beta colsq_inv) carry the column
+// scales -- what the reference does.  The wide engine on the DataStd-flag-0 copy is exactly that iteration.  (With an intercept the
+// reference multiplies the n x nvars map by a vector of nvars + 1 entries: refused by the callers.)
+static int fit_big_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev, int32_t standardize,
+                            const oemgpu_opts *o, double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    if (n < 2 || n > WIDE_MAX_N) { set_error("big.oem / sparse x with p >= n: 2 <= n <= %d rows", WIDE_MAX_N); return OEMGPU_ERR_UNSUPPORTED; }
+    const WideLayout lay = wide_layout(n);
+    Bump X;
+    const size_t a_xs = X.take(sizeof(double) * (size_t)lay.rows() * p), a_ys = X.take(sizeof(double) * (size_t)lay.rows()),
+                 a_sc = X.take(sizeof(double) * wide_scratch_doubles((int)n, p));
+    if (ctx_grow(c, &c->aux, &c->aux_bytes, X.off)) return OEMGPU_ERR_HIP;
+    Bump B;
+    const size_t a_xs2 = B.take((size_t)p * 8), a_xy = B.take((size_t)p * 8), a_st = B.take((size_t)stats_len(p) * 8);       // stats last (run_paths)
+    if (ctx_reserve(c, B.off + paths_ws_bytes(p, p, o) + 4096)) return OEMGPU_ERR_HIP;
+    double *xs = (double *)(c->aux + a_xs), *ys = (double *)(c->aux + a_ys);
+    double *xy = (double *)(c->ws + a_xy), *st = (double *)(c->ws + a_st), *xy_std = (double *)(c->ws + a_xs2);
+    int rc;
+    {
+        Timer t(c, OEMGPU_T_MOMENTS);
+        rc = launch_wide_standardize(c->stream, x_dev, n, ld, p, y_dev, 0, 0, lay, xs, ys, xy, st);
+        if (!rc && standardize) rc = launch_big_wide_scales(c->stream, x_dev, n, ld, p, xy, st, xy_std);
+        if (rc) return rc;
+    }
+    WideArgs wd;
+    wd.xs = xs; wd.ys = ys; wd.lay = lay; wd.n = (int)n; wd.scratch = (double *)(c->aux + a_sc);
+    return run_paths(c, B, nullptr, xy, st, p, p, OEMGPU_SEM_BIG, standardize, 0, o, nullptr, beta, lambda_out, niter, loss, d,
+                     1, 0, false, &wd, standardize ? xy_std : nullptr);
+}
+
+// the same from one contiguous host matrix (n rows, column-major, ld = n)
+static int fit_big_wide_host(const double *x, int64_t n, int32_t p, const double *y, int32_t standardize, const oemgpu_opts *o,
+                             double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    oemgpu_ctx *c = ctx_acquire(o->device);
+    if (!c) return OEMGPU_ERR_NO_DEVICE;
+    double *xd = nullptr, *yd = nullptr;
+    int64_t ld = 0;
+    int rc = host_upload_resident(c, x, n, p, y, o, &xd, &ld, &yd, 0, true);
+    if (!rc) rc = fit_big_wide_dev(c, xd, n, ld, p, yd, standardize, o, beta, lambda_out, niter, loss, d);
+    (void)hipStreamSynchronize(c->stream);
+    ctx_release(c);
+    return rc;
+}
+
 int oemgpu_fit_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
                          int32_t standardize, int32_t intercept, const oemgpu_opts *o,
                          double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
@@ -1041,7 +1089,23 @@ int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_
         if (n_shard[s] < 0 || (n_shard[s] > 0 && (!x_shards[s] || !y_shards[s]))) { set_error("fit_big: bad shard %d", s); return OEMGPU_ERR_ARG; }
         n += n_shard[s];
     }
-    if (n <= q) { set_error("p >= n: the XXt branch (ref src/oem_big.h:547-551) is not part of this path"); return OEMGPU_ERR_UNSUPPORTED; }
+    if (n <= q) {
+        // nobs <= nvars + intercept: the XXt branch (ref src/oem_big.h:537-541, 568-584)
+        if (intercept) {
+            set_error("big.oem with p >= n and an intercept: the reference multiplies the n x p map by a vector of p + 1 entries (src/oem_big.h:568-584) -- "
+                      "nothing well-formed to reproduce; intercept = FALSE is served");
+            return OEMGPU_ERR_UNSUPPORTED;
+        }
+        std::vector<double> xc((size_t)n * p), yc((size_t)n);            // the shards as one matrix (n <= p rows: small)
+        int64_t r0 = 0;
+        for (int s = 0; s < nshards; ++s) {
+            const int64_t ns = n_shard[s];
+            for (int j = 0; j < p && ns > 0; ++j) memcpy(xc.data() + (size_t)j * n + r0, x_shards[s] + (size_t)j * ns, sizeof(double) * (size_t)ns);
+            if (ns > 0) memcpy(yc.data() + r0, y_shards[s], sizeof(double) * (size_t)ns);
+            r0 += ns;
+        }
+        return fit_big_wide_host(xc.data(), n, p, yc.data(), standardize, o, beta, lambda_out, niter, loss, d);
+    }
     return host_fit_big(x_shards, n_shard, nshards, p, y_shards, standardize, intercept, o, beta, lambda_out, niter, loss, d);
 }
 
@@ -1605,7 +1669,24 @@ int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t
     const int q = p + (intercept ? 1 : 0);
     int rc = check_opts(o, p, q);             // R prepends the unpenalised group 0 for the intercept slot (ref R/oem.R:296-338); oemSparse scans all groups.size() = q slots (ref src/oem_sparse.h:465)
     if (rc) return rc;
-    if (n <= p) { set_error("p >= n with a sparse x (the XXt branch, ref src/oem_sparse.h:607-612) is not part of this path"); return OEMGPU_ERR_UNSUPPORTED; }
+    if (n <= p) {
+        // nobs <= nvars: the XXt branch (ref src/oem_sparse.h:607-612, 638-647) is oemBig's, line for line
+        if (intercept) {
+            set_error("a sparse x with p >= n and an intercept: the reference multiplies the n x p map by a vector of p + 1 entries (src/oem_sparse.h:638-647) -- "
+                      "nothing well-formed to reproduce; intercept = FALSE is served");
+            return OEMGPU_ERR_UNSUPPORTED;
+        }
+        if (o->compute_loss) { set_error("compute.loss with a sparse x and p >= n is not built"); return OEMGPU_ERR_UNSUPPORTED; }
+        const int64_t nnz0 = colptr[p];
+        if (nnz0 < 0 || (nnz0 > 0 && (!rowidx || !values))) { set_error("fit_sparse: bad compressed-column arrays"); return OEMGPU_ERR_ARG; }
+        std::vector<double> xc((size_t)n * p, 0.0);                     // n <= p rows: the dense copy is small
+        for (int j = 0; j < p; ++j)
+            for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
+                if (rowidx[k] < 0 || rowidx[k] >= n) { set_error("fit_sparse: row index out of range"); return OEMGPU_ERR_ARG; }
+                xc[(size_t)j * n + rowidx[k]] = values[k];
+            }
+        return fit_big_wide_host(xc.data(), n, p, y, standardize, o, beta, lambda_out, niter, loss, d);
+    }
     if (o->compute_loss && q > SMALL_P_MAX) { set_error("compute.loss with a sparse x is built for p + intercept <= %d only", SMALL_P_MAX); return OEMGPU_ERR_UNSUPPORTED; }
     const int64_t nnz = colptr[p];
     if (nnz < 0 || (nnz > 0 && (!rowidx || !values))) { set_error("fit_sparse: bad compressed-column arrays"); return OEMGPU_ERR_ARG; }

@@ -211,6 +211,7 @@ int wide_workgroups(int n, int p);
 size_t wide_scratch_doubles(int n, int p);
 int launch_wide_standardize(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, int standardize, int intercept,
                             const WideLayout &lay, double *xs, double *ys, double *xy, double *stats);
+int launch_big_wide_scales(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *xy, double *stats, double *xy_std);
 int run_path_wide(hipStream_t s, const PathArgs &a, const WideArgs &w, double *host_scratch);
 // the same iteration as ONE persistent launch of cooperating workgroups with Xs in registers (path_wcoop.hip): element-wise
 // penalties, one row block, p <= 4 CW WCOOP_GMAX columns (CW = 16 / 8 / 4 by column height); WCOOP_GMAX = three quarters of the CUs

@@ -304,7 +304,8 @@ __global__ __launch_bounds__(1024) void path_init_kernel(PathArgs A, LState *st,
 {
     __shared__ double sh[16];
     double m = 0.0;
-    for (int j = threadIdx.x; j < A.p; j += blockDim.x) { beta[j] = 0.0; if (j >= A.lmax_from) m = fmax(m, fabs(A.xy[j])); }
+    const double *__restrict__ lx = A.lmax_xy ? A.lmax_xy : A.xy;       // (big.oem with p >= n: lambda_zero from the SCALED X'y, the iteration from the raw one)
+    for (int j = threadIdx.x; j < A.p; j += blockDim.x) { beta[j] = 0.0; if (j >= A.lmax_from) m = fmax(m, fabs(lx[j])); }
     // block max through the sum helper's layout: per-wave max, then 16-way
     for (int s = 1; s < 64; s <<= 1) m = fmax(m, __shfl_xor(m, s, 64));
     __syncthreads();

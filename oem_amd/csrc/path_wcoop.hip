@@ -626,7 +626,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
         for (int j0 = 0; j0 < q; j0 += 8 * WNTH) {
             double t[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const int j = j0 + tid + WNTH * k; t[k] = (j < q && j >= A.lmax_from) ? fabs(A.xy[j]) : 0.0; }
+            for (int k = 0; k < 8; ++k) { const int j = j0 + tid + WNTH * k; t[k] = (j < q && j >= A.lmax_from) ? fabs((A.lmax_xy ? A.lmax_xy : A.xy)[j]) : 0.0; }
 #pragma unroll
             for (int k = 0; k < 8; ++k) m = fmax(m, t[k]);
         }
@@ -981,7 +981,7 @@ __global__ __launch_bounds__(WNTH) void path_wstream_kernel(PathArgs A, const do
         for (int j0 = 0; j0 < q; j0 += 8 * WNTH) {
             double t[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const int j = j0 + tid + WNTH * k; t[k] = (j < q && j >= A.lmax_from) ? fabs(A.xy[j]) : 0.0; }
+            for (int k = 0; k < 8; ++k) { const int j = j0 + tid + WNTH * k; t[k] = (j < q && j >= A.lmax_from) ? fabs((A.lmax_xy ? A.lmax_xy : A.xy)[j]) : 0.0; }
 #pragma unroll
             for (int k = 0; k < 8; ++k) m = fmax(m, t[k]);
         }

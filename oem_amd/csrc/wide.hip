@@ -120,6 +120,30 @@ __global__ __launch_bounds__(256) void wide_x_kernel(const double *__restrict__ 
 
 }  // namespace
 
+// big.oem / sparse x with p >= n (no intercept; ref src/oem_big.h:743-764, 810-826): colsq_inv_j = 1 / sqrt(sum x_j^2 / (n - 1)) (a zero
+// column: 1) into the scale slots of `stats` -- get_beta multiplies the coefficients by it -- and xy_std = xy colsq_inv, which the
+// reference uses for lambda_zero alone (its iteration runs on the data as they are).  One wave per column.
+__global__ __launch_bounds__(256) void big_wide_scales_kernel(const double *__restrict__ x, long long n, long long ld, int p, const double *__restrict__ xy,
+                                                               double *__restrict__ stats, double *__restrict__ xy_std)
+{
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= p) return;
+    const double *c = x + (size_t)j * ld;
+    double s = 0.0;
+    for (long long i = lane; i < n; i += 64) s = fma(c[i], c[i], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    double cs = s / ((double)n - 1.0);
+    if (cs == 0.0) cs = 1.0;
+    const double inv = 1.0 / sqrt(cs);
+    if (lane == 0) { stats[4 + p + j] = inv; xy_std[j] = xy[j] * inv; }
+}
+int launch_big_wide_scales(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *xy, double *stats, double *xy_std)
+{
+    hipLaunchKernelGGL(big_wide_scales_kernel, dim3((p + 3) / 4), dim3(256), 0, s, x, (long long)n, (long long)ld, p, xy, stats, xy_std);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_wide_standardize(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, int standardize, int intercept,
                             const WideLayout &lay, double *xs, double *ys, double *xy, double *stats)
 {

