@@ -60,7 +60,21 @@ template <int N> __device__ __forceinline__ void dpp_hazard_fence(double (&B)[N]
     if constexpr (N == 1) asm volatile("s_nop 1" : "+v"(B[0]));
     else if constexpr (N == 2) asm volatile("s_nop 1" : "+v"(B[0]), "+v"(B[1]));
     else if constexpr (N == 3) asm volatile("s_nop 1" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]));
-    else { static_assert(N == 4, "extend dpp_hazard_fence"); asm volatile("s_nop 1" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3])); }
+    else if constexpr (N == 4) asm volatile("s_nop 1" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]));
+    else { static_assert(N == 8, "extend dpp_hazard_fence"); asm volatile("s_nop 1" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]), "+v"(B[4]), "+v"(B[5]), "+v"(B[6]), "+v"(B[7])); }
+}
+// A double kept in the accumulator file: AGPRs a[2 IDX], a[2 IDX + 1], named by inline asm alone (the compiler's own values must fit
+// the architectural VGPRs of such a kernel: oem_amd/build.py audits that it never emits a v_accvgpr of its own there).  `a[%n]`, not
+// `a%n`: the printer writes immediates above 64 in hex, and `a0x41` does not assemble.
+template <int IDX> __device__ __forceinline__ double areg_rd()
+{
+    unsigned l, h;
+    asm volatile("v_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]" : "=v"(l), "=v"(h) : "n"(2 * IDX), "n"(2 * IDX + 1));
+    return __hiloint2double((int)h, (int)l);
+}
+template <int IDX> __device__ __forceinline__ void areg_wr(double x)
+{
+    asm volatile("v_accvgpr_write_b32 a[%2], %0\n\tv_accvgpr_write_b32 a[%3], %1" ::"v"(__double2loint(x)), "v"(__double2hiint(x)), "n"(2 * IDX), "n"(2 * IDX + 1));
 }
 template <int K> struct BcFma {
     static __device__ __forceinline__ void fmac(double &acc, const double &b, const double &a)

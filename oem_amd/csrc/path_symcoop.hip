@@ -170,17 +170,6 @@ template <int CTRL> __device__ __forceinline__ double sx_dpp_stage(double lo, do
 // (oem_amd/build.py: audit_symcoop_isa proves that on the emitted ISA, as for the Gram kernels) -- and the third tile of a wave
 // (q > 3456) a quarter in VGPRs (rows 0, 1 of the lane's 8 x 8 sub-block), the rest in LDS (24 16-byte reads per lane,
 // [read][lane], a wave's read 1 KiB contiguous: 96 KB per workgroup).
-template <int IDX> __device__ __forceinline__ double sx_areg_rd()
-{
-    unsigned l, h;
-    asm volatile("v_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]" : "=v"(l), "=v"(h) : "n"(2 * IDX), "n"(2 * IDX + 1));
-    return __hiloint2double((int)h, (int)l);
-}
-template <int IDX> __device__ __forceinline__ void sx_areg_wr(double x)
-{
-    asm volatile("v_accvgpr_write_b32 a[%2], %0\n\tv_accvgpr_write_b32 a[%3], %1" ::"v"(__double2loint(x)), "v"(__double2hiint(x)), "n"(2 * IDX), "n"(2 * IDX + 1));
-}
-
 // The products of ONE tile with the vector blocks at Bsh + oI (rows) and Bsh + oJ (columns), reduced over the lanes.
 // DD: the direct product (T vec_J) -> Wd[64]; TT: the transposed one (T' vec_I) -> Wt[64].  One pass over the tile feeds both.
 // ST: 0 / 1 = the tile in AGPRs a[128 ST ..]; 2 = rows 0..SVR-1 in vlo, the others in LDS at lt.
@@ -202,7 +191,7 @@ __device__ __forceinline__ void sx_tile(const double (&vlo)[8 * SVR], const doub
     auto cell = [&](auto I_, auto J_) {
         constexpr int i = decltype(I_)::value, jj = decltype(J_)::value;
         double x0, x1;
-        if constexpr (ST < 2) { x0 = sx_areg_rd<ST * 64 + i * 8 + 2 * jj>(); x1 = sx_areg_rd<ST * 64 + i * 8 + 2 * jj + 1>(); }
+        if constexpr (ST < 2) { x0 = areg_rd<ST * 64 + i * 8 + 2 * jj>(); x1 = areg_rd<ST * 64 + i * 8 + 2 * jj + 1>(); }
         else if constexpr (i < SVR) { x0 = vlo[i * 8 + 2 * jj]; x1 = vlo[i * 8 + 2 * jj + 1]; }
         else { const v2d t = *reinterpret_cast<const v2d *>(lt + (((i - SVR) * 4 + jj) * 64 + lane) * 2); x0 = t.x; x1 = t.y; }
         if (DD) { ad[i] = fma(x0, bj[2 * jj], ad[i]); }
@@ -319,6 +308,7 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
     const int nslw = __builtin_amdgcn_readfirstlane(nb > w ? (nb - w + 3) / 4 : 0);       // block slots of this wave
     // ---- this wave's tiles: lane (rl, cl) holds the 8 x 8 sub-block of rows 16 (i >> 1) + 2 rl + (i & 1), columns alike with cl
     const int rlv = (lane >> 2) & 7, clv = ((lane >> 5) << 2) | ((((lane >> 1) ^ (lane >> 2)) & 1) << 1) | ((lane ^ (lane >> 2)) & 1);
+    const double *xxp = A.xx;
     double vlo[8 * SVR];                                 // NT == 3: rows 0..SVR-1 of this lane's part of the wave's third tile
     int tI[NT], tJ[NT], tflag[NT], tpos[NT];             // block slots of the tile's rows / columns; 0: no tile, 1: off-diagonal, 2: diagonal; rows of Wp
     if constexpr (NT == 1) asm volatile("" ::: "a127"); else asm volatile("" ::: "a255");      // the accumulator file is in use (by the asm alone)
@@ -337,8 +327,8 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
             static_for_dev<8>([&](auto J_) {
                 constexpr int j = decltype(J_)::value;
                 const int col = 64 * J + 16 * (j >> 1) + 2 * clv + (j & 1);
-                const double x = (t >= 0 && row < q && col < q) ? A.xx[(size_t)col * q + row] : 0.0;
-                if constexpr (k < 2) sx_areg_wr<k * 64 + i * 8 + j>(x);
+                const double x = (t >= 0 && row < q && col < q) ? xxp[(size_t)col * q + row] : 0.0;
+                if constexpr (k < 2) areg_wr<k * 64 + i * 8 + j>(x);
                 else if constexpr (i < SVR) vlo[i * 8 + j] = x;
                 else Lt[(((i - SVR) * 4 + (j >> 1)) * 64 + lane) * 2 + (j & 1)] = x;
             });

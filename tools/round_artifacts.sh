@@ -2,7 +2,7 @@
 # Round artefacts on the GPU box: kernel-trace stats, PMC traffic passes (separate runs), config times, bench line.
 # usage: bash tools/round_artifacts.sh r2 [quick]     (writes under gpurun_out/<tag>_*; copy what is to be judged into profiles/)
 set -u
-tag=${1:-r3}
+tag=${1:-r4}
 quick=${2:-}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -37,8 +37,16 @@ if [ -z "$quick" ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/${tag}_c4_pmc_$c -o ${tag} -- python3 tools/run_c4.py > /dev/null 2> $o/${tag}_c4_pmc_$c.err
   done
-  python3 tools/pmc_summary.py oem_symfused_kernel $o/${tag}_c4_pmc_symfused.json "$(find $o/${tag}_c4_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_c4_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
-  python3 tools/c4_time.py "" nosym > $o/${tag}_c4_time.txt 2>&1
+  # (round 4: config 4 is ONE persistent launch, path_symcoop_kernel<3>; its FETCH_SIZE is the lower triangle once plus the polls)
+  python3 tools/pmc_summary.py path_symcoop_kernel $o/${tag}_c4_pmc_symcoop.json "$(find $o/${tag}_c4_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_c4_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
+  python3 tools/c4_time.py "" nosymcoop nosym 2>&1 | grep -v amdgpu.ids > $o/${tag}_c4_time.txt
+  python3 tools/symcoop_check.py 1088 2048 3000 4096 2>&1 | grep -v amdgpu.ids > $o/${tag}_symcoop_sizes.txt
+  if [ -f oem_amd/liboemgpu_diag.so ]; then
+    OEMGPU_LIB=oem_amd/liboemgpu_diag.so python3 tools/symcoop_diag.py 4096 100 65536 2>&1 | grep -v "amdgpu.ids\|warn" > $o/${tag}_symcoop_stamped.txt
+    OEMGPU_LIB=oem_amd/liboemgpu_diag.so python3 tools/symcoop_diag.py 4096 100 65536 0.3 2>&1 | grep -v "amdgpu.ids\|warn" >> $o/${tag}_symcoop_stamped.txt
+    OEMGPU_LIB=oem_amd/liboemgpu_diag.so python3 tools/symcoop_diag.py 2048 2>&1 | grep -v "amdgpu.ids\|warn" >> $o/${tag}_symcoop_stamped.txt
+  fi
+  python3 tools/wide_group_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_wide_group_times.txt
   # ---- p >= n (n = 500, p = 20,000): the wide engine's column kernel
   rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_wide_trace -o ${tag} -- python3 tools/run_wide.py > $o/${tag}_wide_trace.log 2>&1
   cp "$(find $o/${tag}_wide_trace -name '*kernel_stats.csv' | head -1)" $o/${tag}_wide_n500_p20000_kernel_stats.csv
