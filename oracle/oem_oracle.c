@@ -688,11 +688,14 @@ int orc_fit_dense(const double *x_in, int64_t n, int32_t p, const double *y_in,
             for (int64_t i = 0; i < n; i++) t += c[i] * Y[i];
             XY[j] = t / (double)n;
         }
-        double *G = (double *)malloc(sizeof(double) * (size_t)n * n);
-        if (!G) return fail("oracle: out of memory");
-        xxt_over_n(X, n, p, G);
-        d = (o->d_override > 0) ? o->d_override : orc_eig_max(G, (int32_t)n) * 1.005;
-        free(G);
+        if (o->d_override > 0) d = o->d_override;      /* (a test that hands d over does not pay the n^2 p row Gram and its eigen-solve) */
+        else {
+            double *G = (double *)malloc(sizeof(double) * (size_t)n * n);
+            if (!G) return fail("oracle: out of memory");
+            xxt_over_n(X, n, p, G);
+            d = orc_eig_max(G, (int32_t)n) * 1.005;
+            free(G);
+        }
     }
     *d_out = d;
     double lmax = 0.0;
