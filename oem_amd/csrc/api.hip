@@ -350,17 +350,44 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const size_t o_grw = grw.empty() ? 0 : bl.add(grw.data(), sizeof(int) * grw.size());
     // 1024 < q <= 4096, element-wise penalties: the lower triangle of XX in the registers of <= 3/4 of the CUs (path_symcoop.hip);
     // the plan is a pure function of (q, CUs): kept from call to call
-    static thread_local SymcoopPlan symplan;
+    static thread_local SymcoopPlan symplan_plain, symplan_runs;
     static thread_local int symplan_q = 0, symplan_gmax = 0;
+    SymcoopPlan *symplan_p = &symplan_plain;
     bool symc = false;
-    if (!wide && nbatch == 1 && q > 1024 && q <= 4096 && !any_grp && !scale_factor && !getenv("OEM_NO_SYMCOOP") && !getenv("OEM_NO_COOP")) {
+    if (!wide && nbatch == 1 && q > 1024 && q <= 4096 && !scale_factor && !getenv("OEM_NO_SYMCOOP") && !getenv("OEM_NO_COOP")) {
         const int gmax = c->num_cu * 3 / 4 < WCOOP_GMAX ? c->num_cu * 3 / 4 : WCOOP_GMAX;
-        if (symplan_q != q || symplan_gmax != gmax || getenv("OEM_SYMCOOP_NT")) {
-            if (!symcoop_plan(q, gmax, symplan)) symplan = SymcoopPlan();
+        if (any_grp) {
+            // group operators: every group must be a run of neighbouring coordinates (<= 32 of them) -- the owners' slices are cut there
+            std::vector<int> rs;
+            bool ok = true;
+            for (int j = 0; j < q && ok;) {
+                const int g = G.gid[j];
+                int len = 1;
+                if (g >= 0) {
+                    len = G.gstart[g + 1] - G.gstart[g];
+                    for (int k = 0; k < len && ok; ++k) ok = G.gidx[G.gstart[g] + k] == j + k;
+                }
+                rs.push_back(j);
+                j += len;
+            }
+            rs.push_back(q);
+            symplan_p = &symplan_runs;
+            // (the partition of the runs over the owners is a dynamic programme of some milliseconds: kept while q, the CUs and the runs are the same)
+            static thread_local std::vector<int> runs_key;
+            static thread_local int runs_q = 0, runs_gmax = 0;
+            if (!ok) symplan_runs = SymcoopPlan();
+            else if (runs_q != q || runs_gmax != gmax || runs_key != rs) {
+                if (!symcoop_plan(q, gmax, symplan_runs, rs.data(), (int)rs.size() - 1)) symplan_runs = SymcoopPlan();
+                runs_key = rs; runs_q = q; runs_gmax = gmax;
+            }
+            if (!ok) { runs_key.clear(); runs_q = 0; }
+        } else if (symplan_q != q || symplan_gmax != gmax || getenv("OEM_SYMCOOP_NT")) {
+            if (!symcoop_plan(q, gmax, symplan_plain)) symplan_plain = SymcoopPlan();
             symplan_q = q; symplan_gmax = gmax;
         }
-        symc = !symplan.tab.empty();
+        symc = !symplan_p->tab.empty();
     }
+    SymcoopPlan &symplan = *symplan_p;
     const size_t o_symp = symc ? bl.add(symplan.tab.data(), sizeof(int) * symplan.tab.size()) : 0;
 
     // ---- outputs region (device) : beta | lambda | loss | d[2] | niter | stats copy
@@ -464,7 +491,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     }
     CoopSlots slots;                                  // held until the stream has been synchronised below
     if (coop) slots.take(c->device, path_coop_workgroups(q) * (pen_split ? npen : 1) * nbatch, c->num_cu * 3 / 4);
-    const bool symcoop = symc && path_symcoop_eligible(a, any_grp);
+    const bool symcoop = symc && path_symcoop_eligible(a, any_grp, symplan.runs);
     if (symcoop) slots.take(c->device, symplan.G, c->num_cu * 3 / 4);
     // p >= n with Xs small enough for the register files of <= 192 CUs: one persistent launch (path_wcoop.hip)
     // (all of a set's workgroups must be resident at once: never more of them than three quarters of this device's CUs)

@@ -170,13 +170,14 @@ int launch_path_coop(hipStream_t s, const PathArgs &a);
 // (path_symcoop.hip).  The plan (tiles per wave, blocks per workgroup, senders per block) is pure host arithmetic.
 struct SymcoopPlan {
     int q = 0, T = 0, NT = 0, G = 0, nsum = 0, e1n = 0;    // 64-blocks, tiles per wave, workgroups, sender rows of exchange 1, sender sweeps per owner
+    bool runs = false;                                      // the owners' slices are cut at group-run boundaries
     std::vector<int> tab;                                   // blkbase[80] then G records (uploaded as is)
 };
-bool symcoop_plan(int q, int gmax, SymcoopPlan &P);
+bool symcoop_plan(int q, int gmax, SymcoopPlan &P, const int *runs = nullptr, int nruns = 0);   // runs: group runs (starts, nruns + 1) the owners' slices are cut at
 size_t symcoop_xchg_bytes(const SymcoopPlan &P);
 size_t symcoop_work_bytes(const SymcoopPlan &P);    // ... plus the kernel's copy of its arguments
 size_t symcoop_xchg_bytes_max(int q);
-bool path_symcoop_eligible(const PathArgs &a, bool group_penalty);
+bool path_symcoop_eligible(const PathArgs &a, bool group_penalty, bool plan_has_runs);
 int launch_path_symcoop(hipStream_t s, const PathArgs &a, const SymcoopPlan &P, const int *plan_dev, void *xchg);
 
 // ------------------------------------------------------------------ p >= n (wide.hip, path_large.hip: run_path_wide)

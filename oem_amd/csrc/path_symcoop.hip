@@ -59,8 +59,10 @@ enum { SW_NB = 0, SW_C0 = 1, SW_NSL = 2, SW_BLK = 4, SW_RANK = SW_BLK + SNB, SW_
        SW_TPOS = SW_CST + SNB + 1, SW_INTS = SW_TPOS + 12 + 19 };          // TPOS: row of Wp of a tile's direct product | of its transposed one << 8
 static_assert(SW_INTS == 96, "plan record");
 constexpr int SPLAN_HEAD = 80;    // blkbase[T + 1], T <= 64
-constexpr int SVR = 2;            // rows (of the eight of a lane's sub-block) of a wave's THIRD tile that stay in VGPRs; the others live in LDS
-constexpr int SLT = (8 - SVR) * 4 * 64 * 2;      // doubles of LDS per wave for them
+// rows (of the eight of a lane's sub-block) of a wave's THIRD tile that stay in VGPRs; the others live in LDS -- two, or one in the
+// general form (GEN), whose group operators, Nesterov step and loss cost the compiler 50 more registers than the element-wise form
+__host__ __device__ constexpr int sx_svr(bool gen) { return gen ? 1 : 2; }
+__host__ __device__ constexpr int sx_slt(bool gen) { return (8 - sx_svr(gen)) * 4 * 64 * 2; }      // doubles of LDS per wave for them
 
 #ifdef OEM_PATH_DIAG
 __device__ unsigned long long g_diag_symcoop[16];
@@ -175,7 +177,7 @@ template <int CTRL> __device__ __forceinline__ double sx_dpp_stage(double lo, do
 // ST: 0 / 1 = the tile in AGPRs a[128 ST ..]; 2 = rows 0..SVR-1 in vlo, the others in LDS at lt.
 // Lane bits: rl = (b4, b3, b2), cl = (b5, b1 ^ b2, b0 ^ b2) -- the partners of the direct reduction (lane ^ 32, ^ 2, ^ 1) keep rl, those
 // of the transposed one (lane ^ 16, ^ 8, ^ 7) keep cl.
-template <bool DD, bool TT, int ST>
+template <bool DD, bool TT, int ST, int SVR>
 __device__ __forceinline__ void sx_tile(const double (&vlo)[8 * SVR], const double *lt, const double *Bsh, int oI, int oJ, unsigned mI, unsigned mJ,
                                         double *Wd, double *Wt, int lane, int rlv, int clv)
 {
@@ -235,14 +237,14 @@ __device__ __forceinline__ void sx_tile(const double (&vlo)[8 * SVR], const doub
 // element-wise operators (ref src/oem_dense.h:76-149), branch-free inside a kind.  The constants of the lambda in use live in LDS
 // (the register file belongs to the matrix): kind, L, D, 1/D, gamma D, D - 1/gamma and its reciprocal, gamma - 1, gamma,
 // (gamma - 1) D - 1 and its reciprocal, d, 1/d
-enum { TH_L = 0, TH_D, TH_RD, TH_GAMMAD, TH_DMG, TH_RDMG, TH_GM1, TH_GAMMA, TH_DSC, TH_RDSC, TH_D0, TH_RD0, TH_N };
+enum { TH_L = 0, TH_D, TH_RD, TH_GAMMAD, TH_DMG, TH_RDMG, TH_GM1, TH_GAMMA, TH_DSC, TH_RDSC, TH_D0, TH_RD0, TH_L1, TH_N };
 __device__ __forceinline__ void sx_thr_store(double *th, int *kind, const PenK &K, double d)
 {
     *kind = K.kind;
     th[TH_L] = K.L; th[TH_D] = K.D; th[TH_RD] = 1.0 / K.D; th[TH_GAMMAD] = K.gamma * K.D;
     const double dmg = K.D - 1.0 / K.gamma, gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0;
     th[TH_DMG] = dmg; th[TH_RDMG] = 1.0 / dmg; th[TH_GM1] = gm1; th[TH_GAMMA] = K.gamma; th[TH_DSC] = dsc; th[TH_RDSC] = 1.0 / dsc;
-    th[TH_D0] = d; th[TH_RD0] = 1.0 / d;
+    th[TH_D0] = d; th[TH_RD0] = 1.0 / d; th[TH_L1] = K.L1;
 }
 __device__ __forceinline__ double sx_op(double u, double pf, int kind, const double (&th)[TH_N])
 {
@@ -267,7 +269,15 @@ __device__ __forceinline__ double sx_uni(double v)
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
-template <int NT>
+// GEN: what needs more than a coordinate of its own (template parameter: the element-wise form pays nothing for it) --
+//   group operators (ref src/oem_dense.h:193-315): the owners' slices are cut at group boundaries by the host (every group a run of
+//       <= 32 neighbouring coordinates), an owner's u goes through 32 LDS words and every coordinate sums the squares of ITS group in
+//       member order like the reference, forms the group's factor and its coefficient;
+//   Nesterov's step (ref :633-651): its restart test is a sum over ALL coordinates -- the owners' parts ride next to exchange 2 as
+//       Lanczos' norm parts do, added in workgroup order by everybody;
+//   compute.loss (ref :759-770, Gram identity): when a lambda ends, g = XX beta of the finished iterate is in hand; the owners' parts of
+//       beta'(g - 2 XY) go to workgroup 0 through the scalar area of exchange 1.
+template <int NT, bool GEN>
 __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const int *__restrict__ plan, unsigned long long *xchg, int T, int nsum, int e1n)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -283,8 +293,10 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
     int *votes = reinterpret_cast<int *>(thr + 16);      // [8] votes, [8] kind
     int *nzs = votes + 16;                               // [SNB] which 16-coordinate groups of this slot of Bsh hold a non-zero (4 bits)
     int *wv = nzs + SNB;                                 // (32 spare words)
-    int *rec = wv + 32;                                  // this workgroup's plan record [SW_INTS], then P1[SNB] (pairs index of exchange 1 per slot)
+    double *uo = reinterpret_cast<double *>(wv + 32);     // GEN: u of this owner's coordinates [SSL]
+    int *rec = wv + 32 + 2 * SSL;                        // this workgroup's plan record [SW_INTS], then P1[SNB] (pairs index of exchange 1 per slot)
     int *P1 = rec + SW_INTS;
+    constexpr int SVR = sx_svr(GEN), SLT = sx_slt(GEN);
     double *Lt = reinterpret_cast<double *>(P1 + SNB + 8) + w * SLT;      // NT == 3: rows SVR..7 of every lane's part of this wave's third tile
     const bool writer = wg == 0;
 
@@ -339,6 +351,21 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
     const bool own = ocl < nsl;
     const int cg = c0 + (own ? ocl : 0);
     const double xyc = own ? A.xy[cg] : 0.0, pfc = own ? A.pf[cg] : 0.0;
+    // GEN: this coordinate's group -- its members are the slice-local coordinates [gm0, gm1) (a run, inside this owner's slice)
+    int gm0 = 0, gm1 = 0;
+    bool gzr = true;
+    double gwc = 0.0;
+    if (GEN && A.ngroups > 0 && own) {
+        const int g = A.gid[cg];
+        if (g >= 0) {
+            const int m0 = A.gstart[g];
+            gm0 = A.gidx[m0] - c0; gm1 = gm0 + (A.gstart[g + 1] - m0);
+            gzr = A.gzero[g] != 0; gwc = A.gw[g];
+        } else { gm0 = 0; gm1 = -1; }                                // (in no group: its coefficient stays 0, as path_update has it)
+    }
+    double ak = 1.0;                                                 // Nesterov's sequence (ref src/oem_dense.h:529, 633-651)
+    const bool want_loss = GEN && A.compute_loss != 0, accel = GEN && A.accelerate != 0;
+    const double yy = want_loss ? A.stats[2] : 0.0, nobs = want_loss ? A.stats[3] : 0.0;
     int goff[SE1];                                       // byte offsets (inside a parity) of this thread's senders of coordinate cg
     unsigned need1 = 0;
     {
@@ -448,9 +475,9 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
             const unsigned mJ = (unsigned)__builtin_amdgcn_readfirstlane(fJ[k]), mI = tflag[k] == 1 ? (unsigned)__builtin_amdgcn_readfirstlane(fI[k]) : 0u;
             const bool dj = mJ != 0u, di = mI != 0u;
             double *Wd = Wp + (tpos[k] & 0xff) * 64, *Wt = Wp + ((tpos[k] >> 8) & 0xff) * 64;
-            if (dj && di) sx_tile<true, true, k>(vlo, Lt, Bsh, tI[k] * 64, tJ[k] * 64, mI, mJ, Wd, Wt, lane, rlv, clv);
-            else if (dj) sx_tile<true, false, k>(vlo, Lt, Bsh, tI[k] * 64, tJ[k] * 64, mI, mJ, Wd, Wt, lane, rlv, clv);
-            else if (di) sx_tile<false, true, k>(vlo, Lt, Bsh, tI[k] * 64, tJ[k] * 64, mI, mJ, Wd, Wt, lane, rlv, clv);
+            if (dj && di) sx_tile<true, true, k, SVR>(vlo, Lt, Bsh, tI[k] * 64, tJ[k] * 64, mI, mJ, Wd, Wt, lane, rlv, clv);
+            else if (dj) sx_tile<true, false, k, SVR>(vlo, Lt, Bsh, tI[k] * 64, tJ[k] * 64, mI, mJ, Wd, Wt, lane, rlv, clv);
+            else if (di) sx_tile<false, true, k, SVR>(vlo, Lt, Bsh, tI[k] * 64, tJ[k] * 64, mI, mJ, Wd, Wt, lane, rlv, clv);
             // a product that was skipped leaves zeros (the block sums read every row of their slot)
             if (!dj) Wd[lane] = 0.0;
             if (!di && tflag[k] == 1) Wt[lane] = 0.0;
@@ -518,7 +545,7 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
         SX_STAMP(4);
 
         // ---- the owners' arithmetic
-        double val, npart = 0.0;
+        double val, npart = 0.0, acc_akn = 1.0;
         int mybit = 0;
         if (lz) {
             val = (gsum - alpha * ca) - bprev * cb;                  // this coordinate of w' (eight lanes hold the same)
@@ -531,10 +558,23 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
                 if (conv || it >= maxit) {
                     const size_t kfin = (size_t)pp * nl + i;
                     if (own && part == 0) A.beta[kfin * q + cg] = ca;
-                    if (tid == 0 && writer) { A.niter[kfin] = conv ? it : maxit + 1; A.loss[kfin] = 1e99; }      // ref src/oem_base.h:94-109
+                    if (tid == 0 && writer) { A.niter[kfin] = conv ? it : maxit + 1; if (!want_loss) A.loss[kfin] = 1e99; }      // ref src/oem_base.h:94-109
+                    if (want_loss) {
+                        // sum (Y - X beta)^2 = yy + n beta'(XX beta - 2 XY) (ref src/oem_dense.h:759-770): gsum IS XX beta of the finished iterate
+                        const double lp = sx_block_sum((own && part == 0) ? ca * (gsum - 2.0 * xyc) : 0.0, red, rpar, w, lane);
+                        if (tid == 0) sx_publish(X.rs, X.o3 + (par * G + wg) * 16, lp, X.epoch << 1);
+                        if (writer) {                                // (workgroup 0 adds the parts in workgroup order; nobody else waits)
+                            int offl[1] = {X.o3 + (par * G + (tid < G ? tid : 0)) * 16};
+                            double vl[1];
+                            int fll = 0;
+                            sx_gather<1>(offl, tid < G ? 1u : 0u, vl, fll, X);
+                            const double tl = sx_block_sum(vl[0], red, rpar, w, lane);
+                            if (tid == 0) A.loss[kfin] = yy + nobs * tl;
+                        }
+                    }
                     const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
                     if (i + 1 < nlam) i = i + 1;
-                    else if (pp + 1 < npen) { pp = pp + 1; i = 0; fresh = true; pen = A.penalty[pp]; }
+                    else if (pp + 1 < npen) { pp = pp + 1; i = 0; fresh = true; pen = A.penalty[pp]; ak = 1.0; }
                     else done_now = true;
                     if (!done_now) {
                         set_lambda();
@@ -548,19 +588,46 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
             if (done_now) break;
             // beta_{t+1} of this coordinate: u = d beta - g + XY, the operator, the stop rule (ref src/utils.cpp:537-549)
             const double b0 = fresh ? 0.0 : ca;
-            const double u = (d * b0 - (fresh ? 0.0 : gsum)) + xyc;
-            const double bn = own ? sx_op(u, pfc, thkind, thc) : 0.0;
+            double u = (d * b0 - (fresh ? 0.0 : gsum)) + xyc;
+            double bn;
+            if (GEN && thkind >= K_GRP) {
+                // group operators: u of this owner's coordinates through LDS, the squared norm of this coordinate's group in member order
+                if (thkind == K_SGL) u = soft1(u, pfc * thc[TH_L1], 1.0);
+                if (own && part == 0) uo[ocl] = u;
+                __syncthreads();
+                double s2 = 0.0;
+                for (int m = gm0; m < gm1; ++m) { const double x = uo[m]; s2 += x * x; }
+                double f = 1.0;
+                if (gm1 < gm0) f = 0.0;
+                else if (!gzr) {
+                    const double sn = sqrt(s2), pen_g = thc[TH_L] * gwc;
+                    if (thkind == K_GRP || thkind == K_SGL) { const double t = 1.0 - pen_g / sn; f = (0.0 < t) ? t : 0.0; }     // (quirk Q6: 0 / 0 -> NaN -> 0)
+                    else if (thkind == K_GRP_MCP) f = mcp_norm(sn, pen_g, thc[TH_D], thc[TH_GAMMA]);
+                    else f = scad_norm(sn, pen_g, thc[TH_D], thc[TH_GAMMA]);
+                }
+                bn = (own && f != 0.0) ? u * f / thc[TH_D] : 0.0;
+                __syncthreads();                                     // (uo is written again next iteration)
+            } else bn = own ? sx_op(u, pfc, thkind, thc) : 0.0;
+            double adp_part = 0.0, akn = 1.0;
+            if (accel) {                                             // ref src/oem_dense.h:633-651
+                akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak));
+                const double ratio = (ak - 1.0) / akn, upd = bn, diff = upd - b0;
+                bn = upd + ratio * diff;
+                adp_part = (own && part == 0) ? (bn - upd) * diff : 0.0;
+            }
             const double cu = fabs(bn), qo = fabs(b0);
             const bool cn = cu > 1e-13, qn = qo > 1e-13;
             mybit = (own && ((cn != qn) || (cn && qn && fabs(bn - b0) > tol * qo))) ? 1 : 0;
             ca = bn; fresh = false; ++it;
             val = bn;
+            if (accel) { npart = adp_part; acc_akn = akn; }
         }
 
         // ---- exchange 2: the owners' values out, the blocks this workgroup touches in (Lanczos: scaled by 1 / ||w'||, whose
         // squared parts ride along)
         if (own && part == 0) sx_publish(X.rs, X.o2 + par * X.s2 + cg * 16, val, (X.epoch << 1) | (unsigned)mybit);
-        if (lz) {
+        const bool scal = lz || (accel && !lz);                     // a sum over all coordinates rides along: ||w'||^2 (Lanczos) or Nesterov's restart test
+        if (scal) {
             const double np = sx_block_sum(npart, red, rpar, w, lane);
             if (tid == 0) sx_publish(X.rs, X.o4 + (par * G + wg) * 16, np, X.epoch << 1);
         }
@@ -575,12 +642,14 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
         }
         SX_STAMP(6);
         double bb = 0.0, ib = 1.0;
-        if (lz) {
+        if (scal) {
             int off[1] = {X.o4 + (par * G + (tid < G ? tid : 0)) * 16};
             double v[1];
             int fl = 0;
             sx_gather<1>(off, tid < G ? 1u : 0u, v, fl, X);
-            sqrt_rsqrt(sx_block_sum(v[0], red, rpar, w, lane), bb, ib);
+            const double tot = sx_block_sum(v[0], red, rpar, w, lane);
+            if (lz) sqrt_rsqrt(tot, bb, ib);
+            else ak = (tot > 0.0) ? 1.0 : acc_akn;                   // (the extrapolated beta is kept; only the momentum counter restarts)
         }
 #pragma unroll
         for (int k = 0; k < SE2; ++k) {
@@ -657,10 +726,10 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
     if (__syncthreads_or(X.failed ? 1 : 0) && tid == 0) A.d_out[6] = 1.0;       // exchange timeout: poison (api.hip: run_paths falls back)
 }
 
-template <int NT> constexpr size_t symcoop_lds_bytes()
+template <int NT, bool GEN> constexpr size_t symcoop_lds_bytes()
 {
-    return sizeof(double) * (size_t)(SNB * 64 + (8 * NT + 1) * 64 + 2 * SCML + 2 * (SCML + 16) + 16 + 16) + sizeof(int) * (size_t)(16 + SNB + 32 + SW_INTS + SNB + 8) +
-           (NT == 3 ? sizeof(double) * 4 * SLT : 0);
+    return sizeof(double) * (size_t)(SNB * 64 + (8 * NT + 1) * 64 + 2 * SCML + 2 * (SCML + 16) + 16 + 16) + sizeof(int) * (size_t)(16 + SNB + 32 + 2 * SSL + SW_INTS + SNB + 8) +
+           (NT == 3 ? sizeof(double) * 4 * sx_slt(GEN) : 0);
 }
 
 }  // namespace
@@ -675,7 +744,16 @@ extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read_symcoop(u
 // ---- the plan: which tiles a wave holds, which blocks a workgroup touches, who sends to whom.  Pure host arithmetic.
 // Tiles are enumerated in strips of `a` tile rows, column by column inside a strip, and dealt 4 NT at a time: a workgroup is a patch
 // of a tile rows x 4 NT / a tile columns (3 x 4 at NT = 3), a wave one column of the strip (its tiles share their column block).
-bool symcoop_plan(int q, int gmax, SymcoopPlan &P)
+static bool symcoop_plan_per(int q, int gmax, SymcoopPlan &P, const int *runs, int nruns, int per_want);
+bool symcoop_plan(int q, int gmax, SymcoopPlan &P, const int *runs, int nruns)
+{
+    // per_want = 0: 4 NT tiles per workgroup.  With group runs the owners' slices want slack (whole runs, <= SSL coordinates): start from
+    // about 18 coordinates per owner and give the workgroups more tiles until every limit of the plan holds
+    if (!runs) return symcoop_plan_per(q, gmax, P, nullptr, 0, 0);
+    for (int per = 1; per <= 12; ++per) if (symcoop_plan_per(q, gmax, P, runs, nruns, per)) return true;
+    return false;
+}
+static bool symcoop_plan_per(int q, int gmax, SymcoopPlan &P, const int *runs, int nruns, int per_want)
 {
     P = SymcoopPlan();
     if (q <= 1024 || q > 4096) return false;
@@ -684,8 +762,17 @@ bool symcoop_plan(int q, int gmax, SymcoopPlan &P)
     for (int nt = 1; nt <= 3; ++nt) if ((ntile + 4 * nt - 1) / (4 * nt) <= gmax) { NT = nt; break; }
     if (const char *e = getenv("OEM_SYMCOOP_NT")) { const int k = atoi(e); if (k >= 1 && k <= 3 && (ntile + 4 * k - 1) / (4 * k) <= gmax) NT = k; }   // experiments
     if (!NT) return false;
-    const int a = NT == 3 ? 3 : 2, per = 4 * NT, G = (ntile + per - 1) / per;
-    if (q / G < 1 || (q + G - 1) / G > SSL) return false;
+    const int a = NT == 3 ? 3 : 2;
+    int per = 4 * NT;                                                // tiles per workgroup
+    if (per_want > 0) {
+        // group operators: more workgroups with fewer tiles each (some waves then hold fewer than NT) -- never fewer tiles than give about
+        // 18 coordinates per owner
+        const int gt = std::min(gmax, (q + 17) / 18), pmin = std::min(4 * NT, std::max(1, (ntile + gt - 1) / gt));
+        if (per_want < pmin || per_want > 4 * NT) return false;
+        per = per_want;
+    }
+    const int G = (ntile + per - 1) / per;
+    if (G > gmax || q / G < 1 || (q + G - 1) / G > SSL) return false;
     std::vector<int> tiles;                                          // I | J << 8
     for (int r0 = 0; r0 < T;) {                                      // (a short strip comes FIRST, where it holds a handful of tiles: a last strip of one
         int r1 = r0 + ((r0 == 0 && T % a) ? T % a : a);              //  tile row would be 64 tiles of one row -- twelve entries in one block sum)
@@ -707,11 +794,41 @@ bool symcoop_plan(int q, int gmax, SymcoopPlan &P)
     for (int B = 0; B < T; ++B) { tab[B] = nsum; nsum += (int)senders[B].size(); maxns = std::max(maxns, (int)senders[B].size()); }
     tab[T] = nsum;
     if (maxns > 8 * SE1) return false;
-    const int base = q / G, rem = q % G;
+    // the owners' slices: q / G coordinates each -- or, with group operators (runs != null: every group a run of neighbouring
+    // coordinates, runs[0 .. nruns] their starts), whole runs, so that a group's norm never needs a value from another owner
+    std::vector<int> cut((size_t)G + 1, 0);
+    if (runs) {
+        // every owner whole runs, 1 .. SSL coordinates: the partition of the nruns runs into G consecutive pieces with the smallest sum of
+        // squared piece sizes (dynamic programming over (owners, runs); a piece ends at most SSL coordinates after it starts)
+        if (nruns < G) return false;
+        const double INF = 1e300;
+        std::vector<double> cost((size_t)(G + 1) * (nruns + 1), INF);
+        std::vector<int> from((size_t)(G + 1) * (nruns + 1), -1);
+        cost[0] = 0.0;
+        for (int g = 1; g <= G; ++g)
+            for (int r = g; r <= nruns - (G - g); ++r) {
+                double best = INF; int bi = -1;
+                for (int r0 = r - 1; r0 >= g - 1 && runs[r] - runs[r0] <= SSL; --r0) {
+                    const double c = cost[(size_t)(g - 1) * (nruns + 1) + r0];
+                    if (c >= INF) continue;
+                    const double len = (double)(runs[r] - runs[r0]), t = c + len * len;
+                    if (t < best) { best = t; bi = r0; }
+                }
+                cost[(size_t)g * (nruns + 1) + r] = best; from[(size_t)g * (nruns + 1) + r] = bi;
+            }
+        if (cost[(size_t)G * (nruns + 1) + nruns] >= INF) return false;      // (a run longer than an owner holds, or no such partition)
+        int r = nruns;
+        for (int g = G; g >= 1; --g) { cut[g] = runs[r]; r = from[(size_t)g * (nruns + 1) + r]; }
+        cut[0] = 0;
+    } else {
+        const int base = q / G, rem = q % G;
+        for (int g = 0; g <= G; ++g) cut[g] = g * base + (g < rem ? g : rem);
+    }
     for (int g = 0; g < G; ++g) {
         int *r = tab.data() + SPLAN_HEAD + (size_t)g * SW_INTS;
         const std::vector<int> &b = blocks[g];
-        r[SW_NB] = (int)b.size(); r[SW_C0] = g * base + (g < rem ? g : rem); r[SW_NSL] = base + (g < rem ? 1 : 0);
+        r[SW_NB] = (int)b.size(); r[SW_C0] = cut[g]; r[SW_NSL] = cut[g + 1] - cut[g];
+        if (r[SW_NSL] < 1 || r[SW_NSL] > SSL) return false;
         auto slot = [&](int B) { return (int)(std::lower_bound(b.begin(), b.end(), B) - b.begin()); };
         for (int s = 0; s < (int)b.size(); ++s) {
             r[SW_BLK + s] = b[s];
@@ -720,7 +837,7 @@ bool symcoop_plan(int q, int gmax, SymcoopPlan &P)
         for (int wk = 0; wk < 12; ++wk) r[SW_TILE + wk] = -1;
         // wave w holds tiles w, w + 4, w + 8 of the workgroup's list -- three different tile columns: a lasso iterate's non-zeros
         // cluster (config 4: all in block 0), the products of a zero block are skipped, and the busiest WAVE sets the pace
-        auto tile_of = [&](int w, int k) { return g * per + k * 4 + w; };
+        auto tile_of = [&](int w, int k) { return (k * 4 + w < per) ? g * per + k * 4 + w : ntile; };      // (ntile: no tile in this slot)
         for (int w = 0; w < 4; ++w)
             for (int k = 0; k < NT; ++k) {
                 const int idx = tile_of(w, k);
@@ -744,7 +861,7 @@ bool symcoop_plan(int q, int gmax, SymcoopPlan &P)
         for (int s = (int)b.size(); s <= SNB; ++s) r[SW_CST + s] = ne;
         if (ne > 8 * NT) return false;
     }
-    P.q = q; P.T = T; P.NT = NT; P.G = G; P.nsum = nsum; P.e1n = (maxns + 7) / 8;
+    P.q = q; P.T = T; P.NT = NT; P.G = G; P.nsum = nsum; P.e1n = (maxns + 7) / 8; P.runs = runs != nullptr;
     P.tab.swap(tab);
     return true;
 }
@@ -760,11 +877,13 @@ size_t symcoop_xchg_bytes_max(int q)
 }
 
 // OEM_NO_SYMCOOP=1: the launch-per-iteration engines
-bool path_symcoop_eligible(const PathArgs &a, bool group_penalty)
+bool path_symcoop_eligible(const PathArgs &a, bool group_penalty, bool plan_has_runs)
 {
     if (getenv("OEM_NO_SYMCOOP") || getenv("OEM_NO_COOP")) return false;
     if (a.p <= 1024 || a.p > 4096 || a.nbatch > 1 || a.pen_split) return false;
-    if (a.accelerate || a.compute_loss || a.sinv || group_penalty) return false;      // (they need all of u in one place: path_large.hip's replicated update)
+    if (a.sinv) return false;                            // (scale.factor rescales the iterate in place at every lambda: path_large.hip's replicated update)
+    if (group_penalty && !plan_has_runs) return false;   // (groups that are not runs of <= 32 neighbouring coordinates: the same)
+    if ((group_penalty || a.accelerate || a.compute_loss) && getenv("OEM_SYMCOOP_NO_GENERAL")) return false;
     return true;
 }
 
@@ -775,26 +894,19 @@ int launch_path_symcoop(hipStream_t s, const PathArgs &a_, const SymcoopPlan &P,
     OEM_HIP(hipMemsetAsync(xchg, 0, symcoop_xchg_bytes(P), s));                 // the tags must start at 0
     OEM_HIP(hipMemsetAsync(a.d_out, 0, sizeof(double) * D_OUT_LEN, s));        // [6]: only a timed-out workgroup writes it
     unsigned long long *x = reinterpret_cast<unsigned long long *>(xchg);
+    const bool gen = a.ngroups > 0 || a.accelerate || a.compute_loss;      // (group tables present: a group penalty is in the call)
+#define SX_LAUNCH(NT_, GEN_)                                                                                                     \
+    do {                                                                                                                         \
+        const size_t sh = symcoop_lds_bytes<NT_, GEN_>();                                                                              \
+        if (int rc = lds_limit_once(reinterpret_cast<const void *>(&path_symcoop_kernel<NT_, GEN_>), sh)) return rc;             \
+        hipLaunchKernelGGL((path_symcoop_kernel<NT_, GEN_>), dim3(P.G), dim3(SNTH), sh, s, a, plan_dev, x, P.T, P.nsum, P.e1n);  \
+    } while (0)
     switch (P.NT) {
-    case 1: {
-        const size_t sh = symcoop_lds_bytes<1>();
-        if (int rc = lds_limit_once(reinterpret_cast<const void *>(&path_symcoop_kernel<1>), sh)) return rc;
-        hipLaunchKernelGGL((path_symcoop_kernel<1>), dim3(P.G), dim3(SNTH), sh, s, a, plan_dev, x, P.T, P.nsum, P.e1n);
-        break;
+    case 1: if (gen) SX_LAUNCH(1, true); else SX_LAUNCH(1, false); break;
+    case 2: if (gen) SX_LAUNCH(2, true); else SX_LAUNCH(2, false); break;
+    default: if (gen) SX_LAUNCH(3, true); else SX_LAUNCH(3, false); break;
     }
-    case 2: {
-        const size_t sh = symcoop_lds_bytes<2>();
-        if (int rc = lds_limit_once(reinterpret_cast<const void *>(&path_symcoop_kernel<2>), sh)) return rc;
-        hipLaunchKernelGGL((path_symcoop_kernel<2>), dim3(P.G), dim3(SNTH), sh, s, a, plan_dev, x, P.T, P.nsum, P.e1n);
-        break;
-    }
-    default: {
-        const size_t sh = symcoop_lds_bytes<3>();
-        if (int rc = lds_limit_once(reinterpret_cast<const void *>(&path_symcoop_kernel<3>), sh)) return rc;
-        hipLaunchKernelGGL((path_symcoop_kernel<3>), dim3(P.G), dim3(SNTH), sh, s, a, plan_dev, x, P.T, P.nsum, P.e1n);
-        break;
-    }
-    }
+#undef SX_LAUNCH
     OEM_HIP(hipGetLastError());
     if (getenv("OEM_WCOOP_FAKE_TIMEOUT")) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
     return 0;

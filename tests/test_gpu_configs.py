@@ -314,6 +314,92 @@ def test_register_resident_symmetric_engine(oa, p, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("p", [1100, 2048, 2600, 3500, 4096])
+def test_register_resident_engine_general_form(oa, p, monkeypatch):
+    """the same engine with what needs more than a coordinate of its own (path_symcoop_kernel<NT, GEN = true>): group operators --
+    the owners' slices cut at group boundaries, every group a run of <= 32 neighbouring coordinates (ragged runs of 1-12, ids in no
+    particular order, group 0 unpenalised, weights) --, the sparse group lasso, Nesterov's step (its restart test summed over the
+    workgroups next to exchange 2) and compute.loss (the owners' parts of beta'(XX beta - 2 XY) when a lambda ends).  oem.xtx with
+    group penalties and, through oem(), accelerate + compute.loss: against the launch-per-iteration engines
+    (OEM_SYMCOOP_NO_GENERAL=1) and, at the two smaller sizes, against the oracle."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(11 * p + 3)
+    n = p + 1500
+    x = np.asfortranarray(rng.normal(size=(n, p)) * (1.0 + 0.5 * rng.uniform(size=p)) + 0.2)
+    b = np.zeros(p); b[rng.choice(p, 20, replace=False)] = rng.uniform(-1, 1, 20)
+    y = x @ b + rng.normal(size=n) + 0.5
+    sizes = []
+    while sum(sizes) < p:
+        sizes.append(int(rng.integers(1, 13)))
+    sizes[-1] -= sum(sizes) - p
+    groups = np.repeat(rng.permutation(len(sizes)), sizes)
+    gw = rng.uniform(0.5, 2.0, len(sizes))
+    pf = np.ones(p); pf[:3] = 0.0; pf[3:7] = 2.0
+    ms = (C.c_double * 8)()
+
+    def persistent():
+        assert oa.lib().oemgpu_last_timings(oa.context(), ms) == 0
+        return ms[6] > 0
+
+    def same(f, g, k, tol, label, accelerated=False):
+        """two engines, one iteration: equal counts -> equal to rounding; where one took an iteration more (a coordinate grazing the
+        stop rule: Nesterov's step makes that likelier), a few steps of the size the rule lets through"""
+        fb, gb = np.asarray(f["beta"][k]), np.asarray(g["beta"][k])
+        dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(g["niter"][k]).astype(int))
+        assert dn.max() <= 1, (label, dn)
+        err = np.abs(fb - gb).reshape(fb.shape[0], -1).max(axis=0) / max(1.0, float(np.abs(gb).max()))
+        # (Nesterov's restart test is the sign of a sum that passes through zero: the two engines add it in different orders, a restart
+        #  may fall one iteration apart, and the iterates then agree to the stop rule's tolerance, not to rounding)
+        assert err[dn == 0].max() <= (4.0 * tol if accelerated else 1e-10), (label, err)
+        if (dn > 0).any():
+            assert err[dn > 0].max() <= 4.0 * tol, (label, err)
+
+    xtx, xty = x.T @ x / n, x.T @ y / n
+    xd = torch.as_tensor(xtx, device="cuda")
+    kx = dict(penalty=["grp.lasso", "sparse.grp.lasso", "lasso", "grp.mcp", "grp.scad.net"], groups=groups, group_weights=gw, penalty_factor=pf,
+              alpha=0.6, tau=0.4, gamma=3.5, nlambda=5, tol=1e-9, maxit=500)
+    f = oa.oem_xtx(xd, xty, **kx)
+    assert persistent()
+    monkeypatch.setenv("OEM_SYMCOOP_NO_GENERAL", "1")
+    g = oa.oem_xtx(xd, xty, **kx)
+    assert not persistent()
+    monkeypatch.delenv("OEM_SYMCOOP_NO_GENERAL")
+    assert abs(f["d"] - g["d"]) <= 1e-11 * g["d"]
+    for k in range(len(kx["penalty"])):
+        same(f, g, k, kx["tol"], kx["penalty"][k])
+    # oem(): accelerate and compute.loss (device-resident x: the timers of this context)
+    xdev = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+    for kw in (dict(penalty=["lasso", "grp.lasso", "mcp"], groups=groups, nlambda=5, tol=1e-9, accelerate=True, compute_loss=True),
+               dict(penalty=["scad", "sparse.grp.lasso"], groups=groups, group_weights=gw, tau=0.3, nlambda=4, tol=1e-9, compute_loss=True, standardize=False),
+               dict(penalty=["lasso"], nlambda=4, tol=1e-13, maxit=4, accelerate=True)):
+        f = oa.oem(xdev, y, **kw)
+        assert persistent()
+        monkeypatch.setenv("OEM_SYMCOOP_NO_GENERAL", "1")
+        g = oa.oem(xdev, y, **kw)
+        monkeypatch.delenv("OEM_SYMCOOP_NO_GENERAL")
+        for k in range(len(kw["penalty"])):
+            same(f, g, k, kw["tol"], kw["penalty"][k], accelerated=bool(kw.get("accelerate")))
+            if kw.get("compute_loss"):
+                eq = np.ravel(f["niter"][k]) == np.ravel(g["niter"][k])
+                if not kw.get("accelerate"):
+                    assert np.allclose(np.ravel(f["loss"][k])[eq], np.ravel(g["loss"][k])[eq], rtol=1e-10), kw["penalty"][k]
+                assert np.allclose(f["loss"][k], g["loss"][k], rtol=1e-6), kw["penalty"][k]
+        if kw.get("maxit") == 4:
+            assert f["niter"][0].max() == 5
+        if p <= 2048 and kw.get("compute_loss"):
+            okw = dict(kw); okw["unique_groups"] = np.unique(groups)
+            r = orc.fit_dense(x, y, native=True, **okw)
+            _cmp(f, r)
+            for k in range(len(kw["penalty"])):
+                assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int)).max() <= 1
+                assert np.allclose(f["loss"][k], r["loss"][k], rtol=1e-9)
+    # groups that are NOT runs of neighbouring coordinates: the launch-per-iteration engines take the call (same answer as ever)
+    sc = oa.oem_xtx(xd, xty, penalty="grp.lasso", groups=rng.permutation(groups), nlambda=3, tol=1e-8)
+    assert not persistent() and np.isfinite(np.asarray(sc["beta"][0])).all()
+
+
+@pytest.mark.gpu
 def test_register_resident_engine_through_oem(oa, monkeypatch):
     """the same engine behind oem() (n > p, DataStd flags, y scaled: lambda / scale(y) inside the kernel) against the oracle"""
     rng = np.random.default_rng(31)

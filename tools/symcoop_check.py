@@ -15,13 +15,15 @@ for p in ps:
     xtx, xty = x.T @ x / n, x.T @ y / n
     xd = torch.as_tensor(xtx, device="cuda")
     res = {}
+    grp = os.environ.get("SYMCOOP_CHECK_GROUPS")                  # SYMCOOP_CHECK_GROUPS=8: group penalties (groups of that many neighbours) instead
+    pkw = dict(penalty=["grp.lasso", "grp.mcp"], groups=np.arange(p) // int(grp) + 1) if grp else dict(penalty=["lasso", "mcp"])
     for name in ("symcoop", "launches"):
         os.environ.pop("OEM_NO_SYMCOOP", None)
         if name == "launches": os.environ["OEM_NO_SYMCOOP"] = "1"
         t = []
         for _ in range(2):
             t0 = time.perf_counter()
-            fit = oem_amd.oem_xtx(xd, xty, penalty=["lasso", "mcp"], nlambda=20, tol=1e-10)
+            fit = oem_amd.oem_xtx(xd, xty, nlambda=20, tol=1e-10, **pkw)
             wall = (time.perf_counter() - t0) * 1e3
             ms = (C.c_double * 8)(); L.check(lib.oemgpu_last_timings(ctx, ms)); t.append((ms[3], wall))
         res[name] = (fit, min(t))
