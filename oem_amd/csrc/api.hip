@@ -844,11 +844,17 @@ static bool wide_pays(int64_t n, int32_t p)
     if (getenv("OEM_NO_WIDE")) return false;
     if (getenv("OEM_WIDE")) return true;
     if (p <= 1024) return false;                  // (the register engines run the Gram form at 1-3 us per iteration)
-    if (2 * n < p) return true;
-    // n <= p < 2n: the Gram is the smaller matrix, but where Xs fits the registers of the cooperating engine (path_wcoop.hip) that one
-    // launch beats the launch-per-iteration Gram engines (n = 900, p = 1500: 5.6 against 11.6 us per iteration)
+    // where Xs fits the registers of the cooperating engine (path_wcoop.hip) that one launch beats everything else at these sizes
+    // (n = 900, p = 1500: 5.6 against 11.6 us per iteration on the launch-per-iteration Gram engines)
     const int g = path_wcoop_workgroups((int)n, p);
-    return n <= 1024 && g >= 1 && g <= WCOOP_GMAX && !getenv("OEM_NO_WCOOP");
+    const bool wc = n <= 1024 && g >= 1 && g <= WCOOP_GMAX && !getenv("OEM_NO_WCOOP");
+    // round 4: up to p = 4096 the Gram lives in the register files of the chip (path_symcoop.hip: 5-7 us per iteration, no launch per
+    // iteration) -- that beats the wide engine's launches (1,000 x 4,000: ~20 us per iteration) wherever the persistent wide engine
+    // does not take the call
+    if (p <= 4096 && !getenv("OEM_NO_SYMCOOP") && !getenv("OEM_NO_COOP")) return wc;
+    if (2 * n < p) return true;
+    // n <= p < 2n: the Gram is the smaller matrix
+    return wc;
 }
 
 static int fit_dense_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,

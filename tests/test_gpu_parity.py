@@ -841,6 +841,34 @@ def test_big_and_sparse_wide_branch_without_an_intercept(oa, n, p, standardize):
 
 
 @pytest.mark.gpu
+def test_p_ge_n_on_the_register_resident_gram_engine(oa, monkeypatch):
+    """p >= n with 1024 < p <= 4096 where the persistent wide engine cannot hold X (here n > 1024): since round 4 the Gram form of the
+    iteration on the register-resident engine (path_symcoop.hip: ~6 us per iteration) instead of the wide engine's launches (~20):
+    api.hip: wide_pays.  Same iteration (the non-zero spectra of XX' and X'X coincide): against the oracle's two-product restatement
+    and against the wide engine (OEM_WIDE=1)."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(77)
+    n, p = 1300, 3000
+    x = np.asfortranarray(rng.normal(size=(n, p)) + 0.2)
+    y = x[:, :8] @ rng.uniform(0.5, 1.5, 8) + rng.normal(size=n)
+    xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+    kw = dict(penalty=["lasso", "mcp"], nlambda=5, tol=1e-9, maxit=300)
+    ms = (C.c_double * 8)()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f = oa.oem(xd, y, **kw)
+        assert oa.lib().oemgpu_last_timings(oa.context(), ms) == 0 and ms[6] > 0          # one persistent launch
+        monkeypatch.setenv("OEM_WIDE", "1")
+        w = oa.oem(xd, y, **kw)
+        monkeypatch.delenv("OEM_WIDE")
+    r = _oracle_wide(x, y, f, lambda_min_ratio=0.01, **kw)
+    for k in range(2):
+        _agree_with_oracle(f, r, k, kw["tol"], kw["penalty"][k])
+        _agree_with_oracle(w, r, k, kw["tol"], kw["penalty"][k])
+
+
+@pytest.mark.gpu
 def test_wide_engine_where_it_is_chosen(oa):
     """the sizes the library itself sends to the wide engine (p > 1024, 2 n < p): device-resident and host x, against the oracle;
     and p = 20,000 (a Gram matrix would be 3.2 GB per iteration) through the lasso KKT conditions on the standardised data."""
