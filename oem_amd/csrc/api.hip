@@ -1129,7 +1129,9 @@ int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_
                       "nothing well-formed to reproduce; intercept = FALSE is served");
             return OEMGPU_ERR_UNSUPPORTED;
         }
-        std::vector<double> xc((size_t)n * p), yc((size_t)n);            // the shards as one matrix (n <= p rows: small)
+        std::vector<double> xc, yc;                                     // the shards as one matrix (n <= p rows)
+        try { xc.resize((size_t)n * p); yc.resize((size_t)n); }
+        catch (const std::bad_alloc &) { set_error("big.oem with p >= n: no host memory for the %lld x %d matrix", (long long)n, p); return OEMGPU_ERR_ARG; }
         int64_t r0 = 0;
         for (int s = 0; s < nshards; ++s) {
             const int64_t ns = n_shard[s];
@@ -1712,7 +1714,9 @@ int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t
         if (o->compute_loss) { set_error("compute.loss with a sparse x and p >= n is not built"); return OEMGPU_ERR_UNSUPPORTED; }
         const int64_t nnz0 = colptr[p];
         if (nnz0 < 0 || (nnz0 > 0 && (!rowidx || !values))) { set_error("fit_sparse: bad compressed-column arrays"); return OEMGPU_ERR_ARG; }
-        std::vector<double> xc((size_t)n * p, 0.0);                     // n <= p rows: the dense copy is small
+        std::vector<double> xc;                                         // n <= p rows: the dense copy the wide engine reads
+        try { xc.assign((size_t)n * p, 0.0); }
+        catch (const std::bad_alloc &) { set_error("sparse x with p >= n: no host memory for the dense %lld x %d copy", (long long)n, p); return OEMGPU_ERR_ARG; }
         for (int j = 0; j < p; ++j)
             for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
                 if (rowidx[k] < 0 || rowidx[k] >= n) { set_error("fit_sparse: row index out of range"); return OEMGPU_ERR_ARG; }
