@@ -612,8 +612,10 @@ def main():
         except Exception as e:
             out["host_resident_ms"]["c5_sample"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.no_host:
-        # SURVEY section 8 row f-3 on the record: oem() with p >= n, X resident -- the reference's own iteration without a Gram matrix,
-        # as one persistent launch of cooperating workgroups (500 x 2,000) and streamed from HBM (500 x 20,000).  Never `value`.
+        # SURVEY section 8 row f-3 on the record: oem() with p >= n, X resident -- 500 x 2,000: since round 4 the Gram form of the iteration
+        # on the row-split engine (the whole 2000 x 2000 Gram in the accumulator files of 125 CUs, ONE exchange per iteration; round 3:
+        # the reference's own two-product form as one persistent launch, two exchanges); 500 x 20,000: that form streamed from HBM, no
+        # Gram matrix.  Never `value`.
         try:
             import warnings
             wide = {}

@@ -123,7 +123,7 @@ def audit_symcoop_isa(asm_text):
     hipcc itself never uses the accumulator file in those kernels (its own values must fit the architectural VGPRs) and never
     spills to scratch: check both on the emitted ISA."""
     problems, found = [], 0
-    for m in re.finditer(r"^(_ZN6oemgpu\S*path_symcoop_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end", asm_text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN6oemgpu\S*path_(?:symcoop|rowcoop)_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end", asm_text, re.S | re.M):
         name, body = m.group(1), m.group(2)
         found += 1
         in_asm = False
@@ -138,6 +138,8 @@ def audit_symcoop_isa(asm_text):
                 problems.append(f"{name}: scratch access {line.strip()}")
     if found == 0:
         problems.append("no path_symcoop kernel found in the ISA listing (the audit pattern is stale)")
+    elif found < 7:
+        problems.append(f"only {found} of the 7 register-resident kernels found in the ISA listing (the audit pattern is stale)")
     return problems
 
 

@@ -491,8 +491,11 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     }
     CoopSlots slots;                                  // held until the stream has been synchronised below
     if (coop) slots.take(c->device, path_coop_workgroups(q) * (pen_split ? npen : 1) * nbatch, c->num_cu * 3 / 4);
-    const bool symcoop = symc && path_symcoop_eligible(a, any_grp, symplan.runs);
-    if (symcoop) slots.take(c->device, symplan.G, c->num_cu * 3 / 4);
+    // 1024 < q <= 2048, element-wise penalties: the row-split form with ONE exchange per iteration, else the symmetric one
+    const bool rowcoop = symc && path_rowcoop_eligible(a, any_grp) && path_rowcoop_workgroups(q) <= c->num_cu * 3 / 4 &&
+                         symcoop_work_bytes(symplan) >= path_rowcoop_xchg_bytes();
+    const bool symcoop = symc && (rowcoop || path_symcoop_eligible(a, any_grp, symplan.runs));
+    if (symcoop) slots.take(c->device, rowcoop ? path_rowcoop_workgroups(q) : symplan.G, c->num_cu * 3 / 4);
     // p >= n with Xs small enough for the register files of <= 192 CUs: one persistent launch (path_wcoop.hip)
     // (all of a set's workgroups must be resident at once: never more of them than three quarters of this device's CUs)
     const bool wcoop0 = wide && path_wcoop_eligible(a, *wide) && path_wcoop_workgroups(wide->n, q) <= c->num_cu * 3 / 4;
@@ -517,7 +520,8 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
             Timer t(c, OEMGPU_T_EIGPATH);
             PollScope poll(o);
             int rc;
-            if (persistent && symcoop) rc = launch_path_symcoop(c->stream, a, symplan, (const int *)(dblob + o_symp), a.work + sym_off_d);
+            if (persistent && rowcoop) rc = launch_path_rowcoop(c->stream, a, a.work + sym_off_d);
+            else if (persistent && symcoop) rc = launch_path_symcoop(c->stream, a, symplan, (const int *)(dblob + o_symp), a.work + sym_off_d);
             else if (persistent) rc = wcoop ? launch_path_wcoop(c->stream, a, *wide, wsets, wcst, wg_n) : wstream ? launch_path_wstream(c->stream, a, *wide, wsg) : launch_path_coop(c->stream, a);
             else if (wide) rc = run_path_wide(c->stream, a, *wide, (double *)c->pinned);
             else if (small) rc = launch_path_small(c->stream, a);
@@ -838,11 +842,16 @@ int oemgpu_solve_moments_dev(oemgpu_ctx *c, const double *moments_dev, const dou
 // register / cooperating engines (p <= 1024: ~1 us per iteration, no launch per iteration) and while 2 n p >= p^2; beyond, the
 // wide engine reads 8 n p bytes per iteration and needs no p x p matrix (p = 20,000: 80 MB of Xs instead of 3.2 GB).
 // OEM_WIDE=1 forces it wherever it can run (tests), OEM_NO_WIDE=1 switches it off.
-static bool wide_pays(int64_t n, int32_t p)
+static bool wide_pays(int64_t n, int32_t p, const oemgpu_opts *o)
 {
     if (n > p || n > WIDE_MAX_N) return false;
     if (getenv("OEM_NO_WIDE")) return false;
     if (getenv("OEM_WIDE")) return true;
+    // round 4: one element-wise penalty at 1024 < p <= 2048 -- the Gram form on the row-split engine (path_rowcoop_kernel: ONE exchange
+    // per iteration, ~3.4 us) beats the persistent wide engine's two (500 x 2,000: 4.0 us).  Several penalties stay here: the wide
+    // engine runs them side by side in workgroup sets of their own.
+    if (p > 1024 && p <= 2048 && o && o->npen == 1 && !pen_is_grp(o->penalty[0]) && !o->accelerate && !o->compute_loss &&
+        !getenv("OEM_NO_ROWCOOP") && !getenv("OEM_NO_SYMCOOP") && !getenv("OEM_NO_COOP")) return false;
     if (p <= 1024) return false;                  // (the register engines run the Gram form at 1-3 us per iteration)
     // where Xs fits the registers of the cooperating engine (path_wcoop.hip) that one launch beats everything else at these sizes
     // (n = 900, p = 1500: 5.6 against 11.6 us per iteration on the launch-per-iteration Gram engines)
@@ -944,7 +953,7 @@ int oemgpu_fit_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t 
     // p >= n (ref src/oem_dense.h:476-482,513-521: d from XXt / n, u = X'(Y - X b)/n + d b): the reference's own form where it
     // pays (wide_pays), else the same iteration on the Gram: the non-zero spectra of XXt and XtX coincide and
     // X'(Y - X b)/n + d b = (dI - X'X/n) b + X'Y/n.
-    if (wide_pays(n, p)) return fit_dense_wide_dev(c, x_dev, n, ld, p, y_dev, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+    if (wide_pays(n, p, o)) return fit_dense_wide_dev(c, x_dev, n, ld, p, y_dev, standardize, intercept, o, beta, lambda_out, niter, loss, d);
     if (set_device(c)) return OEMGPU_ERR_HIP;
     const GramPlan pl = gram_plan(n, p, c->num_cu);
     Bump B;
@@ -1067,7 +1076,7 @@ int oemgpu_fit_dense(const double *x, int64_t n, int32_t p, const double *y, int
     if (n < 1) { set_error("fit_dense: bad n"); return OEMGPU_ERR_ARG; }
     // p >= n (ref src/oem_dense.h:476-482,513-521): where the reference's two-GEMV form pays (wide_pays) the rows go up once and the
     // wide engine iterates through the standardised copy -- no (p+2)^2 moment buffer; otherwise the same iteration on the Gram.
-    if (wide_pays(n, p) && o->ngpus <= 1) {
+    if (wide_pays(n, p, o) && o->ngpus <= 1) {
         oemgpu_ctx *c = ctx_acquire(o->device);
         if (!c) return OEMGPU_ERR_NO_DEVICE;
         double *xd = nullptr, *yd = nullptr;

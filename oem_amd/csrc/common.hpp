@@ -180,6 +180,12 @@ size_t symcoop_xchg_bytes_max(int q);
 bool path_symcoop_eligible(const PathArgs &a, bool group_penalty, bool plan_has_runs);
 int launch_path_symcoop(hipStream_t s, const PathArgs &a, const SymcoopPlan &P, const int *plan_dev, void *xchg);
 
+// 1024 < p <= 2048, element-wise penalties: the row-split form, ONE exchange per iteration (path_symcoop.hip: path_rowcoop_kernel)
+bool path_rowcoop_eligible(const PathArgs &a, bool group_penalty);
+int path_rowcoop_workgroups(int q);
+size_t path_rowcoop_xchg_bytes();
+int launch_path_rowcoop(hipStream_t s, const PathArgs &a, void *xchg);
+
 // ------------------------------------------------------------------ p >= n (wide.hip, path_large.hip: run_path_wide)
 // The reference's own iteration for p >= n: no Gram, two products with the standardised X per iteration
 // (ref src/oem_dense.h:363-366, 476-482, 513-521).  Layout of the standardised copy: `nb` row blocks of `rb` rows each (the last

@@ -732,7 +732,305 @@ template <int NT, bool GEN> constexpr size_t symcoop_lds_bytes()
            (NT == 3 ? sizeof(double) * 4 * sx_slt(GEN) : 0);
 }
 
+// ================================================================================================================================
+// 1024 < q <= 2048, element-wise penalties: the ROW-SPLIT form -- ONE exchange per iteration.
+//
+// At these sizes the WHOLE matrix (32 MB at q = 2048) fits the accumulator files of q / 16 <= 128 CUs: workgroup g keeps rows
+// 16 g .. 16 g + 15 -- a 16-lane row group of a wave 128 columns of them, 128 doubles per lane = a0..a255, named by inline asm alone
+// (path_dev.hpp: areg_rd) -- multiplies them with v_fmac_f64_dpp row_newbcast as path_coop.hip does (each lane supplies eight vector
+// entries to its row, the four slices of a row meet through v_permlane16/32_swap, the four waves through LDS) and so holds u of ITS
+// rows complete: no partial vectors, no reduce-scatter.  The operator runs on the sixteen owner lanes, and the one exchange is the
+// all-gather of the new coefficients (tagged pairs, the "still moving" bit of a coordinate in its tag: every workgroup gathers all of
+// them, so the stop decision is everybody's in the SAME iteration).  path_coop.hip extended to these sizes does not close its
+// register budget (its replicated update at eight coordinates per thread: DESIGN section 0, item 4); here a thread owns at most one
+// coordinate.  16-column groups of the vector that are all zero are skipped (a lasso iterate is sparse).  Lanczos the same way, the
+// vector updates replicated from the gathered product (LDS-resident v, v_prev).  Group operators, Nesterov's step, compute.loss and
+// scale.factor go to the symmetric engine above / the launches.
+// ================================================================================================================================
+constexpr int RQ = 2048;          // columns a workgroup covers: 4 waves x 4 row groups x 128
+constexpr int RE = RQ / SNTH;     // pairs per thread in the all-gather
+
+#ifdef OEM_PATH_DIAG
+__device__ unsigned long long g_diag_rowcoop[16];
+#endif
+
+template <int C> struct RowFma {
+    static __device__ __forceinline__ void run(double (&acc)[4], const double (&B)[8], unsigned nzmask)
+    {
+        if constexpr (C < 128) {
+            if constexpr ((C & 15) == 0) {
+                // sixteen columns at a time; a group whose vector entries are zero in every lane of the wave is skipped (wave-uniform)
+                if ((nzmask >> (C >> 4)) & 1u) RowFma16<C>(acc, B);
+                RowFma<C + 16>::run(acc, B, nzmask);
+            }
+        }
+    }
+    template <int C0> static __device__ __forceinline__ void RowFma16(double (&acc)[4], const double (&B)[8])
+    {
+        static_for_dev<16>([&](auto K_) {
+            constexpr int c = C0 + decltype(K_)::value;
+            const double x = areg_rd<c>();
+            BcFma<(c & 15)>::fmac(acc[c & 3], B[c >> 4], x);
+        });
+    }
+};
+
+__global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned long long *xchg)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l16 = lane & 15, grp = lane >> 4;
+    const int q = A.p, wg = blockIdx.x, G = gridDim.x;
+    const unsigned long long t_cyc0 = __builtin_amdgcn_s_memtime(), t_rt0 = __builtin_amdgcn_s_memrealtime();
+    double *Bsh = lds;                                   // the vector going into the product [RQ + 16] (zero words behind it)
+    double *Vp = Bsh + RQ + 16;                          // Lanczos: v_prev [RQ]
+    double *Wv = Vp + RQ;                                // Lanczos: the gathered product [RQ]
+    double *Tal = Wv + RQ, *Tbe = Tal + SCML;
+    double *sturm = Tbe + SCML;
+    double *red = sturm + 2 * (SCML + 16);               // block reductions [2][4], theta slot [8], lmax words [12..16)
+    double *thr = red + 16;
+    double *Pc = thr + 16;                               // the waves' parts of the sixteen row sums [4][16]
+    int *votes = reinterpret_cast<int *>(Pc + 64);       // [8] votes, [8] kind
+    const bool writer = wg == 0;
+    asm volatile("" ::: "a255");                         // the accumulator file is in use (by the asm alone)
+
+    // ---- this lane's 128 matrix entries: row 16 wg + l16, columns 512 w + 128 grp + k
+    const int row = 16 * wg + l16, cbase = 512 * w + 128 * grp;
+    const bool rowok = row < q;
+    static_for_dev<128>([&](auto K_) {
+        constexpr int k = decltype(K_)::value;
+        const int col = cbase + k;
+        areg_wr<k>((rowok && col < q) ? A.xx[(size_t)col * q + row] : 0.0);
+    });
+    int bidx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int col = cbase + 16 * j + l16; bidx[j] = col < q ? col : RQ + (lane & 7); }
+    for (int j = tid; j < RQ + 16; j += SNTH) Bsh[j] = 0.0;
+    for (int j = tid; j < 2 * RQ; j += SNTH) Vp[j] = 0.0;
+    // the coordinate this thread owns: lanes 0..15 of wave 0
+    const bool own = w == 0 && lane < 16 && rowok;
+    const double xyc = own ? A.xy[row] : 0.0, pfc = own ? A.pf[row] : 0.0;
+    SymX X;
+    X.s1 = 0; X.s2 = RQ * 16; X.o2 = 0; X.o3 = 0; X.o4 = 0;
+    X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, 2 * RQ * 16, 0x00020000);
+    X.epoch = 0; X.wg = wg; X.G = G; X.failed = false;
+#ifdef OEM_PATH_DIAG
+    for (int k = 0; k < 16; ++k) X.acc[k] = 0;
+    X.last = __builtin_amdgcn_s_memtime();
+#endif
+    int g2off[RE];
+    unsigned need2 = 0;
+#pragma unroll
+    for (int k = 0; k < RE; ++k) { const int j = tid + SNTH * k; g2off[k] = j < q ? j * 16 : 0; if (j < q) need2 |= 1u << k; }
+    int rpar = 0;
+    const double tol = sx_uni(A.tol);
+    const int maxit = A.maxit, npen = A.npen, nl = A.nl;
+    __syncthreads();
+
+    // (M vec)[row] for the sixteen rows of this workgroup, complete, in lanes 0..15 of wave 0 (the other lanes: garbage)
+    auto product = [&]() -> double {
+        SX_STAMP(0);
+        double B[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) B[j] = Bsh[bidx[j]];
+        unsigned nz = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nz |= (__ballot(B[j] != 0.0) != 0ull ? 1u : 0u) << j;
+        dpp_hazard_fence(B);
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        RowFma<0>::run(acc, B, nz);
+        const double s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        // the four row groups (column slices) of the wave: v_permlane16_swap, then v_permlane32_swap
+        const double t = sx_swap_add<false>(s, s);
+        const double g4 = sx_swap_add<true>(t, t);
+        if (lane < 16) Pc[w * 16 + lane] = g4;
+        SX_STAMP(1);
+        __syncthreads();
+        return (Pc[l16] + Pc[16 + l16]) + (Pc[32 + l16] + Pc[48 + l16]);
+    };
+    // the owners' values out, all q coordinates in: Dst[j] (behind a barrier); returns the OR of the bits in the tags
+    auto all_gather = [&](double val, int mybit, double *Dst) -> int {
+        ++X.epoch;
+        const int par = (int)(X.epoch & 1u);
+        if (own) sx_publish(X.rs, par * X.s2 + row * 16, val, (X.epoch << 1) | (unsigned)mybit);
+        SX_STAMP(2);
+        int bits = 0;
+        double r[RE];
+        int off[RE];
+#pragma unroll
+        for (int k = 0; k < RE; ++k) off[k] = par * X.s2 + g2off[k];
+        sx_gather<RE>(off, need2, r, bits, X);
+        SX_STAMP(3);
+#pragma unroll
+        for (int k = 0; k < RE; ++k) if ((need2 >> k) & 1u) Dst[tid + SNTH * k] = r[k];
+        sx_vote(votes, w, lane, bits);
+        __syncthreads();
+        SX_STAMP(4);
+#ifdef OEM_PATH_DIAG
+        X.acc[8] += 1;
+#endif
+        return votes[0] | votes[1] | votes[2] | votes[3];
+    };
+
+    // ---- eigenvalue step: Lanczos, the vector updates replicated from the gathered product (v in Bsh, v_prev in Vp)
+    auto start_v = [](unsigned j) { const unsigned h = j * 2654435761u + 12345u; return (double)(h >> 8) * (1.0 / 16777216.0) - 0.5; };
+    {
+        double nn = 0.0;
+        for (int j = tid; j < q; j += SNTH) { const double x = start_v((unsigned)j); nn = fma(x, x, nn); }
+        nn = 1.0 / sqrt(sx_block_sum(nn, red, rpar, w, lane));
+        for (int j = tid; j < q; j += SNTH) Bsh[j] = start_v((unsigned)j) * nn;
+        __syncthreads();
+    }
+    int msteps = q < SCML ? q : SCML;
+    double *theta_slot = red + 8;
+    auto top_ritz = [&](int m, double hint) {
+        if (w == 0) {
+            const double th = tridiag_max(Tal, Tbe, m, lane, sturm, hint);
+            if (lane == 0) theta_slot[0] = th;
+        }
+        __syncthreads();
+        const double th = theta_slot[0];
+        __syncthreads();
+        return th;
+    };
+    int nst = 0;
+    double bprev = 0.0, theta = 0.0, theta_prev = -__builtin_inf(), mv_prev = __builtin_inf();
+    bool have_theta = false;
+    for (int js = 0; js < msteps; ++js) {
+        const double g = product();
+        (void)all_gather(g, 0, Wv);
+        double al = 0.0;
+        for (int j = tid; j < q; j += SNTH) al = fma(Bsh[j], Wv[j], al);
+        al = sx_block_sum(al, red, rpar, w, lane);
+        double bb2 = 0.0;
+        for (int j = tid; j < q; j += SNTH) { const double x = (Wv[j] - al * Bsh[j]) - bprev * Vp[j]; Wv[j] = x; bb2 = fma(x, x, bb2); }
+        double bb, ib;
+        sqrt_rsqrt(sx_block_sum(bb2, red, rpar, w, lane), bb, ib);
+        if (tid == 0) { Tal[js] = al; Tbe[js] = bb; }
+        nst = js + 1;
+        if (!(bb > 1e-13 * fabs(al))) break;                         // invariant subspace reached: T is exact
+        if (lanczos_check_due(nst) && nst < msteps) {
+            const double th = top_ritz(nst, theta_prev);
+            if (lanczos_converged(th, theta_prev, mv_prev)) { theta = th; have_theta = true; break; }
+            theta_prev = sx_uni(theta_prev); mv_prev = sx_uni(mv_prev);
+        }
+        for (int j = tid; j < q; j += SNTH) { Vp[j] = Bsh[j]; Bsh[j] = Wv[j] * ib; }        // (each thread its own entries: no barrier between)
+        bprev = sx_uni(bb);
+        __syncthreads();
+    }
+    if (!have_theta) { __syncthreads(); theta = top_ritz(nst, theta_prev); }
+    const double d = sx_uni(theta * 1.005);                          // ref src/oem_dense.h:498, src/oem_xtx.h:369
+    if (tid == 0 && writer) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && nst >= msteps && nst < q) ? 1.0 : 0.0; }
+#ifdef OEM_PATH_DIAG
+    for (int k = 0; k < 16; ++k) X.acc[k] = 0;
+#endif
+
+    // ---- lambda grid constants (ref src/oem_dense.cpp:175-192), replicated
+    const double scaley = sx_uni(A.yscale ? A.stats[1] : 1.0);
+    double lmax = 0.0;
+    {
+        double m = 0.0;
+        for (int j = tid; j < q; j += SNTH) {
+            const double xl = A.lmax_xy ? A.lmax_xy[j] : A.xy[j];
+            m = fmax(m, j >= A.lmax_from ? fabs(xl) : 0.0);
+        }
+        m = wave_max(m);
+        if (lane == 0) red[12 + w] = m;
+        __syncthreads();
+        lmax = fmax(fmax(red[12], red[13]), fmax(red[14], red[15])) * scaley;
+    }
+    const double llo = sx_uni(log(lmax)), lhi = sx_uni(log(A.lambda_min_ratio * lmax));
+    const double lstep = sx_uni(nl > 1 ? (lhi - llo) / (double)(nl - 1) : 0.0);
+    const bool lflip = fabs(lhi) < fabs(llo);
+    auto lambda_of = [&](int pq, int iq) {
+        if (A.user_lambda) return A.lambda_user[(size_t)pq * nl + iq];
+        double lv;
+        if (nl == 1) lv = lhi;
+        else if (lflip) lv = (iq == 0) ? llo : lhi - (double)(nl - 1 - iq) * lstep;
+        else lv = (iq == nl - 1) ? lhi : llo + (double)iq * lstep;
+        double lam = exp(lv);
+        if (pen_is_net(A.penalty[pq])) lam = lam / A.alpha;
+        return lam;
+    };
+    if (writer) for (int idx = tid; idx < npen * nl; idx += SNTH) A.lambda_out[idx] = lambda_of(idx / nl, idx % nl);
+
+    // ---- the penalty x lambda path (ref src/oem_base.h:90-110): product, the operator on the owner lanes, ONE all-gather
+    for (int pp = 0; pp < npen; ++pp) {
+        const int pen = A.penalty[pp];
+        const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
+        __syncthreads();
+        for (int j = tid; j < RQ; j += SNTH) Bsh[j] = 0.0;           // cold start (ref src/oem_dense.cpp:243-244)
+        double bc = 0.0;                                             // this owner lane's coefficient
+        __syncthreads();
+        for (int i = 0; i < nlam; ++i) {
+            const double lam = lambda_of(pp, i);
+            __syncthreads();
+            if (tid == 0) sx_thr_store(thr, votes + 8, pen_consts(pen, lam / scaley, d, A.alpha, A.gamma, A.tau), d);
+            __syncthreads();
+            double thc[TH_N];
+#pragma unroll
+            for (int k = 0; k < TH_N; ++k) thc[k] = thr[k];
+            const int thkind = votes[8];
+            int it = 0;
+            bool conv = false;
+            while (it < maxit) {
+                const double g = product();
+                const double u = (d * bc - g) + xyc;                 // ref src/oem_dense.h:512
+                const double bn = own ? sx_op(u, pfc, thkind, thc) : 0.0;
+                const double cu = fabs(bn), qo = fabs(bc);
+                const bool cn = cu > 1e-13, qn = qo > 1e-13;         // ref src/utils.cpp:537-549
+                const int moving = (own && ((cn != qn) || (cn && qn && fabs(bn - bc) > tol * qo))) ? 1 : 0;
+                bc = bn;
+                ++it;
+                const int any = all_gather(bn, moving, Bsh);
+                if (!any) { conv = true; break; }
+            }
+            const size_t kfin = (size_t)pp * nl + i;
+            if (own) A.beta[kfin * q + row] = bc;
+            if (tid == 0 && writer) { A.niter[kfin] = conv ? it : maxit + 1; A.loss[kfin] = 1e99; }      // ref src/oem_base.h:94-109
+        }
+        if (tid == 0 && writer) for (int r = nlam; r < nl; ++r) { A.niter[(size_t)pp * nl + r] = 0; A.loss[(size_t)pp * nl + r] = 1e99; }
+    }
+#ifdef OEM_PATH_DIAG
+    if (tid == 0 && writer) { for (int k = 0; k < 9; ++k) g_diag_rowcoop[k] = X.acc[k]; }
+#endif
+    if (tid == 0 && writer) {
+        A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
+        A.d_out[3] = (double)(__builtin_amdgcn_s_memrealtime() - t_rt0);
+    }
+    if (__syncthreads_or(X.failed ? 1 : 0) && tid == 0) A.d_out[6] = 1.0;       // exchange timeout: poison (api.hip: run_paths falls back)
+}
+
+constexpr size_t rowcoop_lds_bytes() { return sizeof(double) * (size_t)(RQ + 16 + 2 * RQ + 2 * SCML + 2 * (SCML + 16) + 16 + 16 + 64) + sizeof(int) * 16; }
+
 }  // namespace
+
+#ifdef OEM_PATH_DIAG
+extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read_rowcoop(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_rowcoop), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// 1024 < q <= 2048, element-wise penalties: the one-exchange row-split form (OEM_NO_ROWCOOP=1: the symmetric engine)
+bool path_rowcoop_eligible(const PathArgs &a, bool group_penalty)
+{
+    if (getenv("OEM_NO_ROWCOOP") || getenv("OEM_NO_SYMCOOP") || getenv("OEM_NO_COOP")) return false;
+    if (a.p <= 1024 || a.p > RQ || a.nbatch > 1 || a.pen_split) return false;
+    return !(a.sinv || group_penalty || a.accelerate || a.compute_loss);
+}
+int path_rowcoop_workgroups(int q) { return (q + 15) / 16; }
+size_t path_rowcoop_xchg_bytes() { return (size_t)2 * RQ * 16 + 256; }
+int launch_path_rowcoop(hipStream_t s, const PathArgs &a, void *xchg)
+{
+    OEM_HIP(hipMemsetAsync(xchg, 0, path_rowcoop_xchg_bytes(), s));            // the tags must start at 0
+    OEM_HIP(hipMemsetAsync(a.d_out, 0, sizeof(double) * D_OUT_LEN, s));        // [6]: only a timed-out workgroup writes it
+    const size_t sh = rowcoop_lds_bytes();
+    if (int rc = lds_limit_once(reinterpret_cast<const void *>(&path_rowcoop_kernel), sh)) return rc;
+    hipLaunchKernelGGL(path_rowcoop_kernel, dim3(path_rowcoop_workgroups(a.p)), dim3(SNTH), sh, s, a, reinterpret_cast<unsigned long long *>(xchg));
+    OEM_HIP(hipGetLastError());
+    if (getenv("OEM_WCOOP_FAKE_TIMEOUT")) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
+    return 0;
+}
 
 #ifdef OEM_PATH_DIAG
 extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read_symcoop(unsigned long long *out)

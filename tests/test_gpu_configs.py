@@ -314,6 +314,60 @@ def test_register_resident_symmetric_engine(oa, p, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("p", [1025, 1030, 1536, 2047, 2048])
+def test_row_split_one_exchange_engine(oa, p, monkeypatch):
+    """1024 < p <= 2048 with element-wise penalties (path_symcoop.hip: path_rowcoop_kernel): the WHOLE matrix in the
+    accumulator files of p / 16 CUs, a workgroup's sixteen rows of u complete without a reduce-scatter, the operator on sixteen owner
+    lanes, ONE all-gather per iteration with the stop decision in the same iteration.  Boundary sizes on both sides, ragged last row
+    set and column slice; against the oracle, against the symmetric engine (OEM_NO_ROWCOOP=1) and the launches (OEM_NO_SYMCOOP=1);
+    several penalties, penalty factors, maxit exhaustion, bit-reproducible, and the fallback."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(5 * p + 2)
+    n = p + 1800
+    x = rng.normal(size=(n, p)) * (1.0 + 0.5 * rng.uniform(size=p))
+    b = np.zeros(p); b[rng.choice(p, 20, replace=False)] = rng.uniform(-1, 1, 20)
+    y = x @ b + rng.normal(size=n)
+    xtx, xty = x.T @ x / n, x.T @ y / n
+    xd = torch.as_tensor(xtx, device="cuda")
+    pf = np.ones(p); pf[:5] = 0.0; pf[5:9] = 2.5
+    ms = (C.c_double * 8)()
+    kw = dict(penalty=["lasso", "mcp", "scad.net", "ols", "elastic.net"], alpha=0.6, gamma=3.5, nlambda=6, tol=1e-9, maxit=600, penalty_factor=pf)
+    f = oa.oem_xtx(xd, xty, **kw)
+    assert oa.lib().oemgpu_last_timings(oa.context(), ms) == 0 and ms[6] > 0
+    again = oa.oem_xtx(xd, xty, **kw)
+    assert all(np.array_equal(u, v) for u, v in zip(f["beta"], again["beta"])) and f["d"] == again["d"]
+    lam_max = np.linalg.eigvalsh(xtx)[-1]
+    assert abs(f["d"] - 1.005 * lam_max) <= DTOL * lam_max
+    ref = orc.fit_xtx(xtx, xty, d_override=f["d"], **kw)
+    _cmp(f, ref)
+    for k in range(len(kw["penalty"])):
+        fn, rn = np.ravel(f["niter"][k]).astype(int), np.ravel(ref["niter"][k]).astype(int)
+        # (within one; where a lambda takes hundreds of iterations -- OLS on an ill-conditioned Gram: a contraction factor of 0.99 -- the
+        #  last coordinate crosses the stop rule's threshold so flatly that rounding moves the count by a few: half a per cent)
+        assert np.all(np.abs(fn - rn) <= np.maximum(1, np.ceil(0.005 * rn))), (kw["penalty"][k], fn, rn)
+    for env in ("OEM_NO_ROWCOOP", "OEM_NO_SYMCOOP"):
+        monkeypatch.setenv(env, "1")
+        g = oa.oem_xtx(xd, xty, **kw)
+        monkeypatch.delenv(env)
+        for k in range(len(kw["penalty"])):
+            scale = max(1.0, float(np.abs(g["beta"][k]).max()))
+            assert np.abs(np.asarray(f["beta"][k]) - np.asarray(g["beta"][k])).max() <= 1e-9 * scale, (env, kw["penalty"][k])
+    kw = dict(penalty=["lasso"], nlambda=5, tol=1e-13, maxit=4)
+    f = oa.oem_xtx(xd, xty, **kw)
+    ref = orc.fit_xtx(xtx, xty, d_override=f["d"], **kw)
+    assert f["niter"][0].max() == 5 and np.array_equal(f["niter"][0], ref["niter"][0])
+    _cmp(f, ref)
+    if p == 1536:
+        good = oa.oem_xtx(xd, xty, penalty="lasso", nlambda=5, tol=1e-9)
+        monkeypatch.setenv("OEM_WCOOP_FAKE_TIMEOUT", "1")
+        back = oa.oem_xtx(xd, xty, penalty="lasso", nlambda=5, tol=1e-9)
+        monkeypatch.delenv("OEM_WCOOP_FAKE_TIMEOUT")
+        assert oa.lib().oemgpu_last_timings(oa.context(), ms) == 0 and ms[6] == 0          # the launches answered
+        assert np.abs(np.asarray(back["beta"][0]) - np.asarray(good["beta"][0])).max() < 1e-9
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("p", [1100, 2048, 2600, 3500, 4096])
 def test_register_resident_engine_general_form(oa, p, monkeypatch):
     """the same engine with what needs more than a coordinate of its own (path_symcoop_kernel<NT, GEN = true>): group operators --
