@@ -398,7 +398,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const bool loss_on = (sem == OEMGPU_SEM_DENSE || sem == OEMGPU_SEM_XVAL || sem == SEM_SPARSE) && o->compute_loss != 0;
     // several instances (xval.oem's K + 1 fits) on the cooperating engine: only if all their workgroup sets are resident at once
     // wide != nullptr: the p >= n iteration through the standardised X itself (xx == nullptr: there is no Gram matrix)
-    const bool coop = !wide && path_coop_eligible(q, scale_factor != nullptr, loss_on, og.ngroups, nbatch) &&
+    const bool coop = !wide && path_coop_eligible(q, scale_factor != nullptr, loss_on && !(scale_factor && nbatch == 1), og.ngroups, nbatch) &&
                       (nbatch == 1 || path_coop_workgroups(q) * nbatch <= c->num_cu * 3 / 4);
     const bool small = !wide && q <= SMALL_P_MAX && !coop;
     if (nbatch > 1 && !small && !coop) { set_error("internal: batched paths need p <= %d", SMALL_P_MAX); return OEMGPU_ERR_INTERNAL; }
@@ -456,6 +456,10 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     a.p = q; a.npen = npen; a.nl = nl; a.user_lambda = user; a.maxit = o->maxit;
     a.accelerate = (sem == OEMGPU_SEM_DENSE) ? (o->accelerate != 0) : 0;           // only oemDense accelerates (quirk Q12)
     a.compute_loss = (sem == OEMGPU_SEM_DENSE || sem == OEMGPU_SEM_XVAL || sem == SEM_SPARSE) ? (o->compute_loss != 0) : 0;
+    // oemSparse with an intercept beyond the single-workgroup kernels: the engines rescale the member in place before the product their
+    // loss would come from, so the loss is a pass of its own behind them (sparse.hip: gram_loss_kernel)
+    const bool loss_post = loss_on && scale_factor && !small && !wide && nbatch == 1;
+    if (loss_post) a.compute_loss = 0;
     a.ngroups = og.ngroups; a.lanczos_steps = lan; a.yscale = (sem == OEMGPU_SEM_DENSE);
     a.lmax_from = (sem == OEMGPU_SEM_XVAL || sem == SEM_SPARSE) ? off : 0;              // ref src/oem_xval_dense.h:1025-1032
     a.alpha = o->alpha; a.gamma = o->gamma; a.tau = o->tau; a.tol = o->tol; a.lambda_min_ratio = o->lambda_min_ratio;
@@ -532,6 +536,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
                 rc = run_path_large(c->stream, al, (double *)c->pinned);
             }
             if (rc) return rc;
+            if (loss_post && (rc = launch_gram_loss(c->stream, xx, xy, stats, q, a.beta, a.sinv, a.niter, a.loss, (int)nk))) return rc;
         }
         HT(2);
         if (!zero_copy) {
@@ -573,7 +578,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
                 const size_t ki = (size_t)k * nl + i;
                 lambda_b[ki] = hl[ki];
                 niter_b[ki] = (i < nlam) ? hn[ki] : 0;
-                loss_b[ki] = (i < nlam && a.compute_loss) ? hloss[ki] : 1e99;
+                loss_b[ki] = (i < nlam && (a.compute_loss || loss_post)) ? hloss[ki] : 1e99;
                 double *ob = beta_b + ki * rows;
                 const double *b = hb + ki * q;
                 if (i >= nlam) { for (int j = 0; j < rows; ++j) ob[j] = 0.0; continue; }
@@ -899,7 +904,7 @@ static int fit_dense_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int
 // scales -- what the reference does.  The wide engine on the DataStd-flag-0 copy is exactly that iteration.  (With an intercept the
 // reference multiplies the n x nvars map by a vector of nvars + 1 entries: refused by the callers.)
 static int fit_big_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev, int32_t standardize,
-                            const oemgpu_opts *o, double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+                            const oemgpu_opts *o, double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, bool sparse_loss = false)
 {
     if (set_device(c)) return OEMGPU_ERR_HIP;
     if (n < 2 || n > WIDE_MAX_N) { set_error("big.oem / sparse x with p >= n: 2 <= n <= %d rows", WIDE_MAX_N); return OEMGPU_ERR_UNSUPPORTED; }
@@ -922,20 +927,33 @@ static int fit_big_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64
     }
     WideArgs wd;
     wd.xs = xs; wd.ys = ys; wd.lay = lay; wd.n = (int)n; wd.scratch = (double *)(c->aux + a_sc);
-    return run_paths(c, B, nullptr, xy, st, p, p, OEMGPU_SEM_BIG, standardize, 0, o, nullptr, beta, lambda_out, niter, loss, d,
-                     1, 0, false, &wd, standardize ? xy_std : nullptr);
+    rc = run_paths(c, B, nullptr, xy, st, p, p, OEMGPU_SEM_BIG, standardize, 0, o, nullptr, beta, lambda_out, niter, loss, d,
+                   1, 0, false, &wd, standardize ? xy_std : nullptr);
+    if (rc || !sparse_loss) return rc;
+    // oemSparse::get_loss (ref src/oem_sparse.h:932-941): the residual of the RETURNED coefficients on the data as they are
+    const size_t nk = (size_t)o->npen * nl_of(o), nchunk = (size_t)((n + 2047) / 2048);
+    Bump L;
+    const size_t a_b = L.take(nk * (size_t)(p + 1) * 8), a_p = L.take(nk * nchunk * 8), a_l = L.take(nk * 8);
+    if (ctx_reserve(c, L.off + 4096)) return OEMGPU_ERR_HIP;          // (the paths are done: their frame may be overlaid)
+    double *bd = (double *)(c->ws + a_b), *ld_ = (double *)(c->ws + a_l);
+    OEM_HIP(hipMemcpyAsync(bd, beta, nk * (size_t)(p + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if ((rc = launch_resid_loss(c->stream, x_dev, n, ld, p, y_dev, bd, p + 1, (int)nk, (double *)(c->ws + a_p), ld_))) return rc;
+    OEM_HIP(hipMemcpyAsync(loss, ld_, nk * 8, hipMemcpyDeviceToHost, c->stream));
+    OEM_HIP(hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < nk; ++k) if (niter[k] == 0) loss[k] = 1e99;
+    return 0;
 }
 
 // the same from one contiguous host matrix (n rows, column-major, ld = n)
 static int fit_big_wide_host(const double *x, int64_t n, int32_t p, const double *y, int32_t standardize, const oemgpu_opts *o,
-                             double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+                             double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, bool sparse_loss = false)
 {
     oemgpu_ctx *c = ctx_acquire(o->device);
     if (!c) return OEMGPU_ERR_NO_DEVICE;
     double *xd = nullptr, *yd = nullptr;
     int64_t ld = 0;
     int rc = host_upload_resident(c, x, n, p, y, o, &xd, &ld, &yd, 0, true);
-    if (!rc) rc = fit_big_wide_dev(c, xd, n, ld, p, yd, standardize, o, beta, lambda_out, niter, loss, d);
+    if (!rc) rc = fit_big_wide_dev(c, xd, n, ld, p, yd, standardize, o, beta, lambda_out, niter, loss, d, sparse_loss);
     (void)hipStreamSynchronize(c->stream);
     ctx_release(c);
     return rc;
@@ -1720,7 +1738,6 @@ int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t
                       "nothing well-formed to reproduce; intercept = FALSE is served");
             return OEMGPU_ERR_UNSUPPORTED;
         }
-        if (o->compute_loss) { set_error("compute.loss with a sparse x and p >= n is not built"); return OEMGPU_ERR_UNSUPPORTED; }
         const int64_t nnz0 = colptr[p];
         if (nnz0 < 0 || (nnz0 > 0 && (!rowidx || !values))) { set_error("fit_sparse: bad compressed-column arrays"); return OEMGPU_ERR_ARG; }
         std::vector<double> xc;                                         // n <= p rows: the dense copy the wide engine reads
@@ -1731,9 +1748,8 @@ int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t
                 if (rowidx[k] < 0 || rowidx[k] >= n) { set_error("fit_sparse: row index out of range"); return OEMGPU_ERR_ARG; }
                 xc[(size_t)j * n + rowidx[k]] = values[k];
             }
-        return fit_big_wide_host(xc.data(), n, p, y, standardize, o, beta, lambda_out, niter, loss, d);
+        return fit_big_wide_host(xc.data(), n, p, y, standardize, o, beta, lambda_out, niter, loss, d, o->compute_loss != 0);
     }
-    if (o->compute_loss && q > SMALL_P_MAX) { set_error("compute.loss with a sparse x is built for p + intercept <= %d only", SMALL_P_MAX); return OEMGPU_ERR_UNSUPPORTED; }
     const int64_t nnz = colptr[p];
     if (nnz < 0 || (nnz > 0 && (!rowidx || !values))) { set_error("fit_sparse: bad compressed-column arrays"); return OEMGPU_ERR_ARG; }
     // rows per staging tile: the dense tile is capped at 2 GiB, whatever n is

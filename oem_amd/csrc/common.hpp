@@ -58,6 +58,10 @@ size_t csc_moments_work_bytes(int64_t n, int p);
 bool csc_moments_fits(int p);
 int launch_csc_moments(hipStream_t s, const int64_t *colptr, const int32_t *rowidx, const double *val, const double *y, int64_t n, int p,
                        void *work, double *moments);
+int launch_gram_loss(hipStream_t s, const double *xx, const double *xy, const double *stats, int q, const double *beta, const double *sinv,
+                     const int *niter, double *loss, int nk);                       // oemSparse's compute.loss behind the larger engines
+int launch_resid_loss(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, const double *beta, int rows, int nk,
+                      double *part, double *loss);                                  // ... and with p >= n
 
 // ------------------------------------------------------------------ xval.oem (xval.hip)
 size_t fold_layout_ints(int64_t n, int K);

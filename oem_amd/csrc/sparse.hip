@@ -138,7 +138,94 @@ __global__ __launch_bounds__(256) void csc_stats_kernel(const int64_t *__restric
     }
 }
 
+// compute.loss of oemSparse where the path engine cannot take it itself (the in-place rescale of the intercept slot, ref
+// src/oem_sparse.h:897-900, changes the member before get_loss): sum (Y - X beta)^2 of the coefficients in the coordinates of the
+// iteration through the Gram identity yy + n (beta' XX beta - 2 beta' XY) (ref src/oem_sparse.h:919-944 takes the residual of the same
+// fitted values).  One workgroup per (penalty, lambda); only the rows of non-zero coefficients are read.
+__global__ __launch_bounds__(256) void gram_loss_kernel(const double *__restrict__ xx, const double *__restrict__ xy, const double *__restrict__ stats, int q,
+                                                        const double *__restrict__ beta, const double *__restrict__ sinv, const int *__restrict__ niter,
+                                                        double *__restrict__ loss)
+{
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    __shared__ double part[4];
+    const double *b = beta + (size_t)k * q;
+    if (niter[k] == 0) { if (tid == 0) loss[k] = 1e99; return; }
+    double t = 0.0;
+    for (int i = w; i < q; i += 4) {
+        const double bi = sinv ? b[i] / sinv[i] : b[i];
+        if (bi == 0.0) continue;                                     // (wave-uniform)
+        const double *row = xx + (size_t)i * q;                      // XX is symmetric: row i = column i, contiguous
+        double g = 0.0;
+        for (int j = lane; j < q; j += 64) {
+            const double bj = sinv ? b[j] / sinv[j] : b[j];
+            g = fma(row[j], bj, g);
+        }
+        g = wave_sum(g);
+        t += bi * (g - 2.0 * xy[i]);
+    }
+    if (lane == 0) part[w] = t;
+    __syncthreads();
+    if (tid == 0) loss[k] = stats[2] + stats[3] * ((part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// the same for p >= n (no Gram matrix): the residual itself, Y - X beta of the RETURNED coefficients on the data as they are
+// (ref src/oem_sparse.h:932-941: with standardize the member times colsq_inv -- what get_beta returns).  2048 rows per workgroup,
+// the chunks of a (penalty, lambda) added in chunk order by resid_loss_sum_kernel.
+__global__ __launch_bounds__(256) void resid_loss_kernel(const double *__restrict__ x, int64_t n, int64_t ld, int p, const double *__restrict__ y,
+                                                         const double *__restrict__ beta, int rows, double *__restrict__ part)
+{
+    const int c = blockIdx.x, k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    __shared__ double ws[4];
+    const double *b = beta + (size_t)k * rows + 1;                   // slot 0: the intercept (none here)
+    double r[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { const int64_t i = (int64_t)c * 2048 + m * 256 + tid; r[m] = i < n ? y[i] : 0.0; }
+    for (int j = 0; j < p; ++j) {
+        const double bj = b[j];
+        if (bj == 0.0) continue;                                     // (uniform)
+        const double *col = x + (size_t)j * ld;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { const int64_t i = (int64_t)c * 2048 + m * 256 + tid; if (i < n) r[m] = fma(-col[i], bj, r[m]); }
+    }
+    double t = 0.0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) t = fma(r[m], r[m], t);
+    t = wave_sum(t);
+    if (lane == 0) ws[w] = t;
+    __syncthreads();
+    if (tid == 0) part[(size_t)k * gridDim.x + c] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+__global__ void resid_loss_sum_kernel(const double *__restrict__ part, int nchunk, int nk, double *__restrict__ loss)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nk) return;
+    double t = 0.0;
+    for (int c = 0; c < nchunk; ++c) t += part[(size_t)k * nchunk + c];
+    loss[k] = t;
+}
+
 }  // namespace
+
+int launch_gram_loss(hipStream_t s, const double *xx, const double *xy, const double *stats, int q, const double *beta, const double *sinv,
+                     const int *niter, double *loss, int nk)
+{
+    hipLaunchKernelGGL(gram_loss_kernel, dim3(nk), dim3(256), 0, s, xx, xy, stats, q, beta, sinv, niter, loss);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+// part: nk * ceil(n / 2048) doubles of scratch; loss: nk doubles (device)
+int launch_resid_loss(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, const double *beta, int rows, int nk,
+                      double *part, double *loss)
+{
+    const int nchunk = (int)((n + 2047) / 2048);
+    hipLaunchKernelGGL(resid_loss_kernel, dim3(nchunk, nk), dim3(256), 0, s, x, n, ld, p, y, beta, rows, part);
+    OEM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(resid_loss_sum_kernel, dim3((nk + 255) / 256), dim3(256), 0, s, part, nchunk, nk, loss);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
 
 static int csc_ranges(int64_t n, int p)
 {

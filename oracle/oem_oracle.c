@@ -1139,13 +1139,31 @@ int orc_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t *r
 {
     if (n <= p) {
         /* the XXt branch (ref: src/oem_sparse.h:607-612, 638-647) is oemBig's, line for line: see big_wide */
-        if (o->compute_loss) return fail("oracle: compute.loss with a sparse x and p >= n is not restated");
         double *xd = (double *)calloc((size_t)n * p, sizeof(double));
         if (!xd) return fail("oracle: out of memory");
         for (int j = 0; j < p; j++)
             for (int64_t k = colptr[j]; k < colptr[j + 1]; k++) xd[(size_t)j * n + rowidx[k]] = val[k];
         int rcw = big_wide(xd, n, p, y, standardize, intercept, o, beta, lambda_out, niter, loss, d_out);
         free(xd);
+        if (rcw == 0 && o->compute_loss) {
+            /* get_loss (ref: src/oem_sparse.h:932-941): the member times colsq_inv with standardize -- the coefficients get_beta returned */
+            const int nl = nl_of(o);
+            double *res = (double *)malloc(sizeof(double) * (size_t)n);
+            if (!res) return fail("oracle: out of memory");
+            for (int pp = 0; pp < o->npen; pp++) {
+                int nlam = (o->penalty[pp] == ORC_OLS) ? 1 : nl;
+                for (int i = 0; i < nlam; i++) {
+                    const double *out = beta + ((size_t)pp * nl + i) * (p + 1);
+                    memcpy(res, y, sizeof(double) * (size_t)n);
+                    for (int j = 0; j < p; j++)
+                        for (int64_t k = colptr[j]; k < colptr[j + 1]; k++) res[rowidx[k]] -= val[k] * out[j + 1];
+                    double l = 0.0;
+                    for (int64_t r = 0; r < n; r++) l += res[r] * res[r];
+                    loss[(size_t)pp * nl + i] = l;
+                }
+            }
+            free(res);
+        }
         return rcw;
     }
     const int off = intercept ? 1 : 0, q = p + off, nl = nl_of(o);

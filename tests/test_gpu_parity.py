@@ -825,7 +825,8 @@ def test_big_and_sparse_wide_branch_without_an_intercept(oa, n, p, standardize):
         _agree_with_oracle(f, r, k, kw["tol"], kw["penalty"][k])
         assert np.array_equal(np.asarray(f["beta"][k]), np.asarray(fs["beta"][k]))
         assert np.all(np.asarray(f["beta"][k])[0] == 0.0)
-    skw = dict(penalty=["lasso", "scad"], nlambda=5, lambda_min_ratio=0.05, tol=1e-9, maxit=400, standardize=standardize, intercept=False)
+    # (with compute.loss: oemSparse::get_loss takes the residual of the returned coefficients, ref src/oem_sparse.h:932-941)
+    skw = dict(penalty=["lasso", "scad"], nlambda=5, lambda_min_ratio=0.05, tol=1e-9, maxit=400, standardize=standardize, intercept=False, compute_loss=True)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         g = oa.oem(sp.csc_matrix(x), y, **skw)
@@ -833,6 +834,7 @@ def test_big_and_sparse_wide_branch_without_an_intercept(oa, n, p, standardize):
     assert abs(g["d"] - rs["d"]) <= DTOL * rs["d"]
     for k in range(2):
         _agree_with_oracle(g, rs, k, skw["tol"], skw["penalty"][k])
+        assert np.allclose(np.ravel(g["loss"][k]), np.ravel(rs["loss"][k]), rtol=1e-7), (g["loss"][k], rs["loss"][k])
     with pytest.raises(oa.OemgpuError, match="p \\+ 1 entries"):
         oa.big_oem(x, y, penalty="lasso", standardize=standardize, intercept=True)
     with pytest.raises(oa.OemgpuError, match="p \\+ 1 entries"), warnings.catch_warnings():
@@ -1022,6 +1024,34 @@ def test_sparse_x_large_p_engine(oa):
     for k in range(2):
         assert np.abs(f["beta"][k] - r["beta"][k]).max() < 1e-8 * max(1.0, float(np.abs(r["beta"][k]).max()))
         assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k])).max() <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,icpt,knob", [(300, True, None), (300, True, "OEM_NO_COOP"), (640, True, None), (1100, True, None), (1100, False, None),
+                                         (1100, False, "OEM_NO_SYMCOOP"), (2300, True, None), (2300, False, None)])
+def test_sparse_compute_loss_beyond_one_workgroup(oa, monkeypatch, p, icpt, knob):
+    """compute.loss of oemSparse (ref src/oem_sparse.h:919-944) beyond p + intercept = 288 (refused until round 4).  Without
+    an intercept the engines' own loss (the Gram identity of the dense path); with one the member is rescaled in place before the
+    product that loss would come from, so it is a pass of its own behind the engine (sparse.hip: gram_loss_kernel) -- on the
+    cooperating engine, the launches, and the register-resident ones.  Against the oracle's residual of the same fitted values."""
+    import scipy.sparse as sp
+    if knob:
+        monkeypatch.setenv(knob, "1")
+    rng = np.random.default_rng(p + icpt)
+    n = 3 * p
+    x = sp.random(n, p, density=0.03, random_state=p, format="csc", data_rvs=lambda k: rng.normal(size=k) * 1.5)
+    b = np.zeros(p); b[:8] = rng.uniform(0.5, 1.5, 8)
+    y = x @ b + rng.normal(size=n) * 0.3 + (1.2 if icpt else 0.0)
+    groups = np.arange(p) // 5 + 1
+    pens = ["lasso", "grp.lasso", "ols"]
+    kw = dict(penalty=pens, groups=groups, nlambda=6, tol=1e-9, maxit=800, intercept=icpt)
+    f = oa.oem(x, y, compute_loss=True, **kw)
+    rg, rug = orc.r_sparse_groups(groups, icpt)
+    r = orc.fit_sparse(x, y, lambda_min_ratio=1e-4, compute_loss=True, native=True, d_override=f["d"], **dict(kw, groups=rg, unique_groups=rug))
+    for k in range(len(pens)):
+        assert np.abs(f["beta"][k] - r["beta"][k]).max() < 1e-8 * max(1.0, float(np.abs(r["beta"][k]).max())), pens[k]
+        fl, rl = np.ravel(f["loss"][k]), np.ravel(r["loss"][k])
+        assert fl.shape == rl.shape and np.all(fl < 1e98) and np.allclose(fl, rl, rtol=1e-8), (pens[k], fl, rl)
 
 
 @pytest.mark.gpu

@@ -41,11 +41,14 @@ if [ -z "$quick" ]; then
   python3 tools/pmc_summary.py path_symcoop_kernel $o/${tag}_c4_pmc_symcoop.json "$(find $o/${tag}_c4_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_c4_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
   python3 tools/c4_time.py "" nosymcoop nosym 2>&1 | grep -v amdgpu.ids > $o/${tag}_c4_time.txt
   python3 tools/symcoop_check.py 1088 2048 3000 4096 2>&1 | grep -v amdgpu.ids > $o/${tag}_symcoop_sizes.txt
+  SYMCOOP_CHECK_GROUPS=8 python3 tools/symcoop_check.py 1088 2048 3000 4096 2>&1 | grep -v amdgpu.ids > $o/${tag}_symcoop_sizes_group_penalties.txt
   if [ -f oem_amd/liboemgpu_diag.so ]; then
     OEMGPU_LIB=oem_amd/liboemgpu_diag.so python3 tools/symcoop_diag.py 4096 100 65536 2>&1 | grep -v "amdgpu.ids\|warn" > $o/${tag}_symcoop_stamped.txt
     OEMGPU_LIB=oem_amd/liboemgpu_diag.so python3 tools/symcoop_diag.py 4096 100 65536 0.3 2>&1 | grep -v "amdgpu.ids\|warn" >> $o/${tag}_symcoop_stamped.txt
     OEMGPU_LIB=oem_amd/liboemgpu_diag.so python3 tools/symcoop_diag.py 2048 2>&1 | grep -v "amdgpu.ids\|warn" >> $o/${tag}_symcoop_stamped.txt
+    OEM_NO_ROWCOOP=1 OEMGPU_LIB=oem_amd/liboemgpu_diag.so python3 tools/symcoop_diag.py 2048 2>&1 | grep -v "amdgpu.ids\|warn" >> $o/${tag}_symcoop_stamped.txt
   fi
+  python3 tools/pgen_rowcoop_ab.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_pgen_rowcoop_ab.txt
   python3 tools/wide_group_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_wide_group_times.txt
   # ---- p >= n (n = 500, p = 20,000): the wide engine's column kernel
   rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_wide_trace -o ${tag} -- python3 tools/run_wide.py > $o/${tag}_wide_trace.log 2>&1

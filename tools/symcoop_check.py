@@ -33,3 +33,9 @@ for p in ps:
     dn = max(int(np.abs(np.ravel(a["niter"][k]).astype(int) - np.ravel(b_["niter"][k]).astype(int)).max()) for k in range(2))
     print(f"p={p}: max|dbeta|={err:.2e} max|dniter|={dn} d rel diff={abs(a['d'] - b_['d']) / b_['d']:.2e} iterations={its} "
           f"symcoop {res['symcoop'][1][0]:.2f} ms (wall {res['symcoop'][1][1]:.2f}) = {1e3 * res['symcoop'][1][0] / its:.2f} us/it | launches {res['launches'][1][0]:.2f} ms = {1e3 * res['launches'][1][0] / its:.2f} us/it", flush=True)
+    if p <= 2048 and not grp:
+        c = res["default"][0]
+        e2 = max(float(np.abs(np.asarray(c["beta"][k]) - np.asarray(b_["beta"][k])).max()) for k in range(2))
+        i2 = sum(int(np.sum(v)) for v in c["niter"])
+        print(f"        row-split one-exchange engine (the default here): {res['default'][1][0]:.2f} ms = {1e3 * res['default'][1][0] / i2:.2f} us/it, "
+              f"max|dbeta| vs launches {e2:.2e}, iterations {i2}", flush=True)

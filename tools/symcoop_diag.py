@@ -18,7 +18,17 @@ xtx, xty = x.T @ x / n, x.T @ y / n
 lmr = float(sys.argv[4]) if len(sys.argv) > 4 else None
 fit = oa.oem_xtx(torch.as_tensor(xtx, device="cuda"), xty, penalty="lasso", nlambda=nl, tol=1e-10, lambda_min_ratio=lmr)
 print("non-zeros at the last lambda:", int((np.asarray(fit["beta"][0])[:, -1] != 0).sum()), " kernel ms:", None)
-lib = L.lib(); lib.oemgpu_diag_read_symcoop.argtypes = [C.POINTER(C.c_ulonglong)]
+lib = L.lib()
+if p <= 2048 and not os.environ.get("OEM_NO_ROWCOOP"):
+    # the row-split one-exchange engine (path_rowcoop_kernel) served this size
+    lib.oemgpu_diag_read_rowcoop.argtypes = [C.POINTER(C.c_ulonglong)]
+    out = (C.c_ulonglong * 16)(); assert lib.oemgpu_diag_read_rowcoop(out) == 0
+    d = np.array(list(out), dtype=np.float64); it = max(d[8], 1)
+    print(f"p={p} (row-split engine): OEM iterations {int(np.sum(fit['niter'][0]))}, all-gathers of the path phase {int(d[8])}; cycles of wave 0 of workgroup 0 per iteration\n"
+          "  [operator + between | products + wave sums | LDS partials barrier + publish | gather | LDS stores + vote + barrier]")
+    print("  path:   ", np.round(d[0:5] / it, 0), "sum", round(d[0:5].sum() / it))
+    sys.exit(0)
+lib.oemgpu_diag_read_symcoop.argtypes = [C.POINTER(C.c_ulonglong)]
 out = (C.c_ulonglong * 16)(); assert lib.oemgpu_diag_read_symcoop(out) == 0
 d = np.array(list(out), dtype=np.float64)
 names = "between + owners' arithmetic of the previous | products | block sums + publish 1 | gather 1 | (alpha) + vote barrier | operator + publish 2 | gather 2 | LDS stores + barrier"
