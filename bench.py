@@ -614,8 +614,9 @@ def main():
     if rank == 0 and world == 1 and not a.no_host:
         # SURVEY section 8 row f-3 on the record: oem() with p >= n, X resident -- 500 x 2,000: since round 4 the Gram form of the iteration
         # on the row-split engine (the whole 2000 x 2000 Gram in the accumulator files of 125 CUs, ONE exchange per iteration; round 3:
-        # the reference's own two-product form as one persistent launch, two exchanges); 500 x 20,000: that form streamed from HBM, no
-        # Gram matrix.  Never `value`.
+        # the reference's own two-product form as one persistent launch, two exchanges); 500 x 20,000: that two-product form with the
+        # 82 MB of standardised X in the vector AND accumulator registers of 209 CUs (path_wres_kernel, round 4; until then streamed from
+        # HBM every iteration at 20 us).  Never `value`.
         try:
             import warnings
             wide = {}
@@ -631,7 +632,8 @@ def main():
                         t0 = time.perf_counter(); wfit = oem_amd.oem(xw.t(), yw, penalty="lasso", nlambda=wl, tol=1e-7); torch.cuda.synchronize()
                         best = min(best, time.perf_counter() - t0)
                 it = int(np.sum(wfit["niter"][0]))
-                wide[f"{wn}x{wp}_lasso_{wl}_lambdas"] = {"ms": 1e3 * best, "iterations": it, "us_per_iteration": 1e6 * best / max(it, 1)}
+                wide[f"{wn}x{wp}_lasso_{wl}_lambdas"] = {"ms": 1e3 * best, "iterations": it, "us_per_iteration": 1e6 * best / max(it, 1),
+                                                         "engine": oem_amd.last_path_engine()[0]}
                 del xw
             out["p_ge_n_ms"] = wide
         except Exception as e:

@@ -236,6 +236,23 @@ int oemgpu_xval_merge(const double *triples, int32_t nsets, const oemgpu_opts *o
  * to 10000 restarts, ref src/oem_dense.h:485-498, has no such cap; OEM converges for any d > lambda_max / 2).  -1 for a NULL context. */
 int oemgpu_last_eigen_info(oemgpu_ctx *ctx, int32_t *steps, int32_t *capped);
 
+/* Which kernel family ran the most recent penalty x lambda path on this context (diagnostics and tests: the engines are chosen by
+ * size and options, api.hip: run_paths), and how many calls of a persistent engine so far timed out in their exchanges (somebody
+ * else held the CUs) and were made again on the launch-per-iteration engines.  -1 for a NULL context. */
+enum {
+    OEMGPU_ENGINE_NONE = 0,
+    OEMGPU_ENGINE_ROWS = 1,      /* p <= 288: one workgroup per penalty (path_small.hip) */
+    OEMGPU_ENGINE_COOP = 2,      /* <= 1024: cooperating workgroups, one exchange per iteration (path_coop.hip) */
+    OEMGPU_ENGINE_ROWCOOP = 3,   /* <= 2048, element-wise: the matrix in the accumulator files, one exchange (path_symcoop.hip) */
+    OEMGPU_ENGINE_SYMCOOP = 4,   /* <= 4096: the lower triangle in registers, two exchanges (path_symcoop.hip) */
+    OEMGPU_ENGINE_LAUNCHES = 5,  /* any p: launch-per-iteration engines on the Gram (path_large.hip) */
+    OEMGPU_ENGINE_WCOOP = 6,     /* p >= n: the standardised X in vector registers (path_wcoop.hip) */
+    OEMGPU_ENGINE_WRES = 7,      /* p >= n: ... and in the accumulator file (path_wcoop.hip: path_wres_kernel) */
+    OEMGPU_ENGINE_WSTREAM = 8,   /* p >= n: persistent, X re-read every iteration (path_wcoop.hip: path_wstream_kernel) */
+    OEMGPU_ENGINE_WLAUNCHES = 9  /* p >= n: launch-per-iteration (path_large.hip: run_path_wide) */
+};
+int oemgpu_last_path_engine(oemgpu_ctx *ctx, int32_t *engine, int32_t *persistent_fallbacks);
+
 /* 1 if the most recent oemgpu_solve_moments_dev on this context found the shift predicate above true for its
  * sums_dev (and so read moments_dev as accumulated about c), 0 if not, -1 for a NULL context. */
 int oemgpu_last_shift_in_effect(oemgpu_ctx *ctx);

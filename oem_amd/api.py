@@ -219,6 +219,17 @@ def _device_matrix(x):
 _ctx_cache = {}
 
 
+ENGINES = ("none", "rows", "coop", "rowcoop", "symcoop", "launches", "wcoop", "wres", "wstream", "wlaunches")   # OEMGPU_ENGINE_* (include/oemgpu.h)
+
+
+def last_path_engine(ctx=None):
+    """(name of the kernel family that ran the most recent penalty x lambda path on this context, number of persistent-engine calls
+    so far that timed out and were made again with launches) -- for device-resident inputs, whose calls run on `context()`."""
+    e, f = C.c_int32(0), C.c_int32(0)
+    L.check(L.lib().oemgpu_last_path_engine(ctx if ctx is not None else context(), C.byref(e), C.byref(f)))
+    return ENGINES[e.value], f.value
+
+
 def context(device=None, stream=None):
     """A cached oemgpu_ctx per (device, stream).  stream: a torch.cuda.Stream or None (own stream)."""
     import torch

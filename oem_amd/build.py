@@ -118,6 +118,28 @@ def audit_round_spills(asm_text, limit=16):
     return problems
 
 
+def audit_wres_isa(asm_text):
+    """path_wcoop.hip: path_wres_kernel keeps two to eight column sets of every wave in AGPRs a0..a255 that only its inline asm names
+    (as path_symcoop.hip's kernels): hipcc itself must not touch the accumulator file there, nor spill to scratch."""
+    problems, found = [], 0
+    for m in re.finditer(r"^(_ZN6oemgpu\S*path_wres_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end", asm_text, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        found += 1
+        in_asm = False
+        for line in body.splitlines():
+            if "#ASMSTART" in line:
+                in_asm = True
+            elif "#ASMEND" in line:
+                in_asm = False
+            elif not in_asm and ("v_accvgpr" in line or re.search(r"\ba\[?\d+", line.split(";")[0])):
+                problems.append(f"{name}: compiler-emitted {line.strip()}")
+            if "scratch_" in line:
+                problems.append(f"{name}: scratch access {line.strip()}")
+    if found < 6:
+        problems.append(f"only {found} of the 6 path_wres kernels found in the ISA listing (the audit pattern is stale)")
+    return problems
+
+
 def audit_symcoop_isa(asm_text):
     """path_symcoop.hip keeps two tiles of every wave in AGPRs a0..a255 that only its inline asm names.  That is only sound if
     hipcc itself never uses the accumulator file in those kernels (its own values must fit the architectural VGPRs) and never
@@ -186,6 +208,9 @@ def build(force=False, verbose=False):
             problems = audit_dpp_hazards(listing[src].result().stdout)
             if problems:
                 raise RuntimeError(src + " ISA audit failed:\n  " + "\n  ".join(problems[:20]))
+        problems = audit_wres_isa(listing["path_wcoop.hip"].result().stdout)
+        if problems:
+            raise RuntimeError("path_wcoop.hip (path_wres_kernel) ISA audit failed:\n  " + "\n  ".join(problems[:20]))
         problems = audit_symcoop_isa(listing["path_symcoop.hip"].result().stdout)
         if problems:
             raise RuntimeError("path_symcoop.hip ISA audit failed:\n  " + "\n  ".join(problems[:20]))

@@ -509,23 +509,32 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const int *wcst = cut ? (const int *)(dblob + o_cst) : nullptr;
     const int wg_n = wcst ? (int)cst.size() - 1 : (wcoop0 ? path_wcoop_workgroups(wide->n, q) : 0);
     const int wsets = wcoop0 ? path_wcoop_sets(wide->n, q, npen, c->num_cu, wg_n) : 1;
-    const bool wcoop = wcoop0 && wsets >= 1;          // (0 sets: the exchange scratch cannot hold this partition -- the launches of run_path_wide take the call)
+    const bool wres_forced = wide && getenv("OEM_WRES") && path_wres_eligible(a, *wide, c->num_cu - 8);      // (tests: also where the vector registers would do)
+    const bool wcoop = wcoop0 && wsets >= 1 && !wres_forced;          // (0 sets: the exchange scratch cannot hold this partition -- the launches of run_path_wide take the call)
     if (wcoop) slots.take(c->device, wg_n * wsets, c->num_cu * 3 / 4);
+    // ... where the vector registers alone cannot hold Xs: more column sets of every wave in the ACCUMULATOR file (path_wres_kernel: Xs up to
+    // ~11 M entries; 500 x 20,000 on 209 CUs).  That is more than three quarters of the CUs: every CU but a few, and alone on the device.
+    const bool wres = wide && !wcoop && path_wres_eligible(a, *wide, c->num_cu - 8);
+    if (wres) slots.take(c->device, path_wres_workgroups(wide->n, q) > c->num_cu * 3 / 4 ? c->num_cu : path_wres_workgroups(wide->n, q), c->num_cu * 3 / 4);
     // ... and where it does not fit: the same persistent launch re-reading its column tiles every iteration (path_wstream_kernel)
     const int wsg = c->num_cu * 3 / 4 < WCOOP_GMAX ? c->num_cu * 3 / 4 : WCOOP_GMAX;
-    const bool wstream = wide && !wcoop && (path_wcoop_workgroups(wide->n, q) > WCOOP_GMAX || getenv("OEM_WSTREAM")) && path_wstream_eligible(a, *wide, wsg);      // (where it pays: measured there)
+    const bool wstream = wide && !wcoop && !wres && (path_wcoop_workgroups(wide->n, q) > WCOOP_GMAX || getenv("OEM_WSTREAM")) && path_wstream_eligible(a, *wide, wsg);      // (where it pays: measured there)
     if (wstream) slots.take(c->device, wsg, c->num_cu * 3 / 4);
     // The persistent engines (p >= n; 208 < p <= 1024) need all their workgroups resident at once.  If somebody else holds the CUs (another process on a
     // shared GPU) their exchanges time out after about a second and poison the result: the call is then made again on the
     // launch-per-iteration engines, which wait for nobody.
     for (int attempt = 0;; ++attempt) {
-        const bool persistent = (wcoop || wstream || symcoop || (coop && nbatch == 1)) && attempt == 0;
+        const bool persistent = (wcoop || wres || wstream || symcoop || (coop && nbatch == 1)) && attempt == 0;
         {
             Timer t(c, OEMGPU_T_EIGPATH);
             PollScope poll(o);
             int rc;
+            c->last_engine = (persistent && rowcoop) ? OEMGPU_ENGINE_ROWCOOP : (persistent && symcoop) ? OEMGPU_ENGINE_SYMCOOP : (persistent && wres) ? OEMGPU_ENGINE_WRES
+                             : (persistent && wcoop) ? OEMGPU_ENGINE_WCOOP : (persistent && wstream) ? OEMGPU_ENGINE_WSTREAM : persistent ? OEMGPU_ENGINE_COOP
+                             : wide ? OEMGPU_ENGINE_WLAUNCHES : small ? OEMGPU_ENGINE_ROWS : (coop && attempt == 0) ? OEMGPU_ENGINE_COOP : OEMGPU_ENGINE_LAUNCHES;
             if (persistent && rowcoop) rc = launch_path_rowcoop(c->stream, a, a.work + sym_off_d);
             else if (persistent && symcoop) rc = launch_path_symcoop(c->stream, a, symplan, (const int *)(dblob + o_symp), a.work + sym_off_d);
+            else if (persistent && wres) rc = launch_path_wres(c->stream, a, *wide);
             else if (persistent) rc = wcoop ? launch_path_wcoop(c->stream, a, *wide, wsets, wcst, wg_n) : wstream ? launch_path_wstream(c->stream, a, *wide, wsg) : launch_path_coop(c->stream, a);
             else if (wide) rc = run_path_wide(c->stream, a, *wide, (double *)c->pinned);
             else if (small) rc = launch_path_small(c->stream, a);
@@ -1071,6 +1080,14 @@ int oemgpu_eig_max_dev(oemgpu_ctx *c, const double *a_dev, int32_t p, double *la
     if (h[6] != 0.0) { set_error("cooperating workgroups lost each other (exchange timeout)"); return OEMGPU_ERR_INTERNAL; }
     *lambda_max = h[1];
     c->eig_steps = (int)h[4]; c->eig_capped = h[5] != 0.0;
+    return 0;
+}
+
+int oemgpu_last_path_engine(oemgpu_ctx *c, int32_t *engine, int32_t *persistent_fallbacks)
+{
+    if (!c) return -1;
+    if (engine) *engine = c->last_engine;
+    if (persistent_fallbacks) *persistent_fallbacks = c->persistent_fallbacks;
     return 0;
 }
 

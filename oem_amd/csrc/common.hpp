@@ -236,6 +236,11 @@ bool path_wcoop_eligible(const PathArgs &a, const WideArgs &w);
 int launch_path_wcoop(hipStream_t s, const PathArgs &a, const WideArgs &w, int sets, const int *cstart = nullptr, int G = 0);   // cstart (device, G + 1 ints): columns cut at group boundaries
 // the same where Xs does not fit the registers: G persistent workgroups re-read their column tiles every iteration (path_wcoop.hip: path_wstream_kernel)
 size_t path_wstream_xchg_doubles(int n);
+// ... and with more column sets of every wave in the accumulator file (path_wres_kernel): Xs up to ~11 M entries in registers
+int path_wres_workgroups(int n, int p);
+size_t path_wres_xchg_doubles(int n, int p);
+bool path_wres_eligible(const PathArgs &a, const WideArgs &wd, int max_wg);
+int launch_path_wres(hipStream_t s, const PathArgs &a, const WideArgs &wd);
 bool path_wstream_eligible(const PathArgs &a, const WideArgs &w, int G);
 int launch_path_wstream(hipStream_t s, const PathArgs &a, const WideArgs &w, int G);
 

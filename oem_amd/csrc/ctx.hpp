@@ -35,6 +35,7 @@ struct oemgpu_ctx {
     double ms[OEMGPU_NTIMERS];
     double diag[2] = {0.0, 0.0};   // path kernel: shader cycles, 100 MHz ticks
     int eig_steps = 0;             // the last eigenvalue step: Lanczos steps taken ...
+    int last_engine = 0;           // OEMGPU_ENGINE_* of the most recent penalty x lambda path (oemgpu_last_path_engine)
     int persistent_fallbacks = 0;  // calls of a persistent p >= n engine that timed out (CUs held by somebody else) and were made again with launches
     bool eig_capped = false;       // ... and whether the step cap ended it (oemgpu_last_eigen_info)
     int shifted = 0;               // the last solve read its moments as accumulated about the provisional shift

@@ -1406,6 +1406,7 @@ size_t wide_scratch_doubles(int n, int p)
     const size_t own = (size_t)wide_workgroups(n, p) * L.npad() + 5 * (size_t)L.rows() + 2 * MAXL + 64 + 16 + 2 + FMAXB + 64 + (size_t)L.nb * (p + 8);
     size_t coop = path_wcoop_xchg_doubles(n, p);               // the persistent engines' exchange buffers live in the same scratch
     if (path_wstream_xchg_doubles((int)n) > coop) coop = path_wstream_xchg_doubles((int)n);
+    if (path_wres_xchg_doubles(n, p) > coop) coop = path_wres_xchg_doubles(n, p);
     return own > coop ? own : coop;
 }
 

@@ -44,6 +44,9 @@
 #include "penalty_ops.hpp"
 #include "path_dev.hpp"
 
+#ifndef OEM_XCHG_SLEEP
+#define OEM_XCHG_SLEEP 12         // s_sleep units (64 cycles) before the first poll sweep of a gather (tools/xchg_sleep_ab.sh)
+#endif
 namespace oemgpu {
 
 namespace {
@@ -108,6 +111,7 @@ __device__ __forceinline__ void sx_gather(const int (&off)[E], unsigned need, do
     unsigned miss = need;
 #pragma unroll
     for (int k = 0; k < E; ++k) pv[k] = sx_v4u{0u, 0u, 0u, 0u};
+    if (E > 1 && OEM_XCHG_SLEEP > 0) __builtin_amdgcn_s_sleep(OEM_XCHG_SLEEP);      // (path_wcoop.hip: wc_gather has the measurement; E = 1: scalars that landed a hop ago)
     unsigned spins = 0;
     const unsigned limit = X.failed ? 0u : 1000000u;            // ~1 s: a partner is gone; after one timeout nobody waits again
     bool ok = true;

@@ -515,6 +515,51 @@ def test_random_wide_streamed(oa, seed, monkeypatch):
             assert np.allclose(np.ravel(f["loss"][k]), np.ravel(r["loss"][k]), rtol=1e-7, atol=1e-9), pens[k]
 
 
+@pytest.mark.parametrize("seed", list(range(200, 212)) + list(range(98000, 98000 + 12 * (SCALE - 1))))
+def test_random_wide_resident_in_the_accumulator_file(oa, seed, monkeypatch):
+    """p >= n with column sets of every wave in the accumulator file too (path_wcoop.hip: path_wres_kernel, round 4), forced onto random
+    shapes (OEM_WRES=1: also where the vector registers alone would do): every column height it is built for (3 .. 9 column sets per
+    wave), ragged last sets / waves / workgroups, DataStd flags, penalty factors, one to four element-wise penalties, compute.loss --
+    against the oracle's restatement of the branch and against the launch-per-iteration engine."""
+    monkeypatch.setenv("OEM_WIDE", "1"); monkeypatch.setenv("OEM_WRES", "1")
+    rng = np.random.default_rng(8100 + seed)
+    n = int(rng.choice([1, 2, 9, 40, 64, 65, 120, 128, 129, 192, 200, 256, 257, 320, 384, 385, 500, 512]))
+    p = int(max(2, n + rng.integers(0, max(2, min(8 * n + 300, 700_000 // max(n, 1))))))
+    if rng.random() < 0.25:
+        n = int(rng.choice([20, 64, 100, 130])); p = int(rng.choice([9000, 12289, 20000]))       # many workgroups, short columns
+    x = np.asfortranarray(rng.normal(size=(n, p)) * rng.uniform(0.5, 3.0) + rng.uniform(-1, 1))
+    nnz = int(min(p, rng.integers(1, 6)))
+    b = np.zeros(p); b[rng.choice(p, nnz, replace=False)] = rng.uniform(-1.5, 1.5, nnz)
+    y = x @ b + rng.normal(size=n) * rng.uniform(0.3, 2.0) + rng.uniform(-1, 1)
+    pens = list(rng.choice(ELEMENTWISE, int(rng.integers(1, 5)), replace=False))
+    pf = np.where(rng.random(p) < 0.1, 0.0, rng.uniform(0.5, 2.0, p))
+    kw = dict(penalty=pens, nlambda=int(rng.integers(1, 6)), alpha=float(rng.uniform(0.2, 1.0)), gamma=float(rng.uniform(2.1, 5.0)),
+              tol=float(10.0 ** rng.uniform(-9, -6)), maxit=int(rng.choice([30, 200, 400])), penalty_factor=pf,
+              standardize=bool(rng.integers(2)), intercept=bool(rng.integers(2)), compute_loss=bool(rng.random() < 0.4))
+    import torch
+    xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f = oa.oem(xd, y, **kw)
+        assert oa.last_path_engine()[0] == "wres"
+        monkeypatch.setenv("OEM_NO_WCOOP", "1"); monkeypatch.setenv("OEM_NO_WSTREAM", "1")       # (the first also switches path_wres_kernel off)
+        g = oa.oem(xd, y, **kw)
+        assert oa.last_path_engine()[0] == "wlaunches"
+    r = orc.fit_dense(x, y, lambda_min_ratio=0.01 if n < p else 1e-4, **kw)
+    ok = np.isfinite(r["d"]) and r["d"] > 0 and all(np.all(np.isfinite(bk)) for bk in r["beta"]) and all(np.all(np.isfinite(lk)) for lk in r["lambda"])
+    if not ok:                                                    # (the blow-up regimes of test_random_wide_cooperating)
+        assert not np.any(np.isinf(np.concatenate([np.ravel(bk) for bk in f["beta"]])))
+        return
+    _check(f, r, pens, tol=5e-7)
+    assert abs(f["d"] - g["d"]) <= 1e-10 * abs(g["d"])
+    for k in range(len(pens)):
+        scale = max(1.0, float(np.abs(np.asarray(g["beta"][k])).max()))
+        assert np.abs(np.asarray(f["beta"][k]) - np.asarray(g["beta"][k])).max() <= 1e-8 * scale, pens[k]
+        assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(g["niter"][k]).astype(int)).max() <= 1, pens[k]
+        if kw["compute_loss"]:
+            assert np.allclose(np.ravel(f["loss"][k]), np.ravel(r["loss"][k]), rtol=1e-7, atol=1e-9), pens[k]
+
+
 @pytest.mark.parametrize("seed", list(range(150, 154)) + list(range(90000, 90000 + 4 * (SCALE - 1))))
 def test_random_symmetric_tile_engine(oa, seed, monkeypatch):
     """oem.xtx at p = 2048 on the symmetric-tile engine (OEM_SYM_2048=1): random element-wise penalty mixes, penalty factors and

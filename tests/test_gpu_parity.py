@@ -613,6 +613,7 @@ def test_wide_streamed_engine(oa, n, p, forced, monkeypatch):
     OEM_NO_WCOOP=1: every column height it is built for, one chunk and several, ragged last chunks) -- against the oracle's
     restatement of the branch and against the launch-per-iteration engine."""
     monkeypatch.setenv("OEM_WIDE", "1")
+    monkeypatch.setenv("OEM_NO_WRES", "1")                        # (round 4: these sizes now stay in registers, path_wres_kernel; the streamed form serves what is beyond it)
     if forced:
         monkeypatch.setenv("OEM_WSTREAM", "1"); monkeypatch.setenv("OEM_NO_WCOOP", "1")
     x, y = _data(n, p, 1700 + n + p, mean=0.3, nnz=min(7, p))
@@ -1024,6 +1025,67 @@ def test_sparse_x_large_p_engine(oa):
     for k in range(2):
         assert np.abs(f["beta"][k] - r["beta"][k]).max() < 1e-8 * max(1.0, float(np.abs(r["beta"][k]).max()))
         assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k])).max() <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,p", [(3, 700), (40, 1200), (64, 5200), (100, 2500), (128, 9000), (130, 2100), (192, 5000), (200, 1000), (256, 3000), (300, 1300),
+                                 (384, 2000), (500, 2000), (512, 2200), (380, 4000)])
+def test_wide_engine_resident_in_the_accumulator_file(oa, n, p, monkeypatch):
+    """p >= n with more column sets of every wave in the ACCUMULATOR file (path_wcoop.hip: path_wres_kernel, round 4 -- Xs up to ~11 M
+    entries stays in registers).  OEM_WRES=1 takes it also where the vector registers alone would do, so every
+    column height it is built for (1, 2, 3, 4, 6, 8 registers per column and lane: 9 .. 3 column sets per wave), ragged last sets and
+    workgroups, all-reduce slices that are ragged or empty run here at sizes the oracle finishes: element-wise operators with penalty
+    factors, maxit reached, user lambdas, OLS, compute.loss, all four standardisation flags -- against the oracle's restatement of
+    the branch and the launch-per-iteration engine; and the host's fallback when its exchange times out."""
+    monkeypatch.setenv("OEM_WIDE", "1")
+    monkeypatch.setenv("OEM_WRES", "1")
+    x, y = _data(n, p, 4100 + n + p, mean=0.3, nnz=min(7, p))
+    rng = np.random.default_rng(n + p)
+    pf = rng.uniform(0.5, 2.0, p); pf[rng.integers(p)] = 0.0
+    nlam = 6 if n * p < 1_000_000 else 4
+    calls = (dict(penalty=["lasso", "mcp", "scad", "elastic.net", "mcp.net", "scad.net", "ols"], alpha=0.7, gamma=3.5, nlambda=nlam, tol=1e-8, maxit=400,
+                  penalty_factor=pf, standardize=True, intercept=True, compute_loss=True),
+             dict(penalty=["lasso"], nlambda=4, tol=1e-12, maxit=3, standardize=False, intercept=True, compute_loss=True),
+             dict(penalty=["scad", "lasso"], nlambda=5, tol=1e-9, maxit=300, standardize=False, intercept=False),
+             dict(penalty=["mcp", "lasso"], lambda_=[np.array([0.5, 0.2, 0.05]), np.array([0.4, 0.1, 0.02])], tol=1e-8, maxit=300,
+                  standardize=True, intercept=False))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for ci, kw in enumerate(calls):
+            f = oa.oem(x, y, **kw)
+            monkeypatch.setenv("OEM_NO_WCOOP", "1")               # (also switches path_wres_kernel off: the launches)
+            g = oa.oem(x, y, **kw)
+            monkeypatch.delenv("OEM_NO_WCOOP")
+            monkeypatch.delenv("OEM_WRES")                        # the default selection: path_wcoop_kernel where it fits
+            h = oa.oem(x, y, **kw)
+            monkeypatch.setenv("OEM_WRES", "1")
+            r = _oracle_wide(x, y, f, lambda_min_ratio=0.01 if n < p else 0.0001, **kw)
+            assert abs(f["d"] - r["d"]) < DTOL * r["d"], (f["d"], r["d"])
+            for k in range(len(kw["penalty"])):
+                assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-11)
+                scale = max(1.0, float(np.abs(r["beta"][k]).max()))
+                for other in (g, h):
+                    assert np.abs(np.asarray(f["beta"][k]) - np.asarray(other["beta"][k])).max() < 1e-9 * scale, kw["penalty"][k]
+                    assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(other["niter"][k]).astype(int)).max() <= 1
+                _agree_with_oracle(f, r, k, kw["tol"], kw["penalty"][k])
+                if kw.get("compute_loss"):
+                    assert np.allclose(f["loss"][k], r["loss"][k], rtol=1e-8), kw["penalty"][k]
+            if ci == 0:                                           # which kernel family ran (device-resident x: the call is on oa.context())
+                import torch
+                xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+                f2 = oa.oem(xd, y, **kw)
+                assert oa.last_path_engine()[0] == "wres"
+                assert all(np.array_equal(np.asarray(f2["beta"][k]), np.asarray(f["beta"][k])) for k in range(len(kw["penalty"])))
+                monkeypatch.delenv("OEM_WRES")
+                oa.oem(xd, y, **kw)
+                assert oa.last_path_engine()[0] == "wcoop"
+                monkeypatch.setenv("OEM_WRES", "1")
+            if ci == 0 and n in (64, 500):
+                monkeypatch.setenv("OEM_WCOOP_FAKE_TIMEOUT", "1")
+                t = oa.oem(x, y, **kw)
+                monkeypatch.delenv("OEM_WCOOP_FAKE_TIMEOUT")
+                for k in range(len(kw["penalty"])):                # the launch-per-iteration engine's bits
+                    assert np.array_equal(np.asarray(t["beta"][k]), np.asarray(g["beta"][k])) and np.array_equal(t["niter"][k], g["niter"][k])
 
 
 @pytest.mark.gpu

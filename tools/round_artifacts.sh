@@ -68,7 +68,11 @@ if [ -z "$quick" ]; then
   fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_wcoop_trace -o ${tag} -- python3 tools/run_wcoop.py > $o/${tag}_wcoop_trace.log 2>&1
   cp "$(find $o/${tag}_wcoop_trace -name '*kernel_stats.csv' | head -1)" $o/${tag}_wcoop_n500_p2000_kernel_stats.csv
-  python3 tools/wstream_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_wstream_times.txt
+  python3 tools/wres_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_wres_times.txt
+  if [ -f oem_amd/liboemgpu_diag.so ]; then
+    OEMGPU_LIB=oem_amd/liboemgpu_diag.so python3 tools/wcoop_diag.py 500 20000 30 2>&1 | grep -v "amdgpu.ids\|warn" >> $o/${tag}_wres_times.txt
+  fi
+  OEM_NO_WRES=1 python3 tools/wstream_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_wstream_times.txt
   python3 tools/coop_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_coop_times.txt
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/hop_probe tools/hop_probe.hip 2> /dev/null && /tmp/hop_probe > $o/${tag}_exchange_probes.txt 2>&1
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/xchg_probe tools/xchg_probe.hip 2> /dev/null && /tmp/xchg_probe >> $o/${tag}_exchange_probes.txt 2>&1

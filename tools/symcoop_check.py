@@ -17,9 +17,10 @@ for p in ps:
     res = {}
     grp = os.environ.get("SYMCOOP_CHECK_GROUPS")                  # SYMCOOP_CHECK_GROUPS=8: group penalties (groups of that many neighbours) instead
     pkw = dict(penalty=["grp.lasso", "grp.mcp"], groups=np.arange(p) // int(grp) + 1) if grp else dict(penalty=["lasso", "mcp"])
-    for name in ("symcoop", "launches"):
-        os.environ.pop("OEM_NO_SYMCOOP", None)
+    for name in ("symcoop", "launches", "default"):               # "default": the row-split one-exchange engine where it applies
+        os.environ.pop("OEM_NO_SYMCOOP", None); os.environ.pop("OEM_NO_ROWCOOP", None)
         if name == "launches": os.environ["OEM_NO_SYMCOOP"] = "1"
+        if name == "symcoop": os.environ["OEM_NO_ROWCOOP"] = "1"
         t = []
         for _ in range(2):
             t0 = time.perf_counter()

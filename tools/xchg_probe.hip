@@ -9,6 +9,8 @@
 //        5 / 6  as 3, the first sweep delayed by s_sleep 6 / 12 (384 / 768 cycles): polls issued before anything can have landed are
 //           wasted traffic, and the one in flight when the data lands costs a whole round trip (measured: 0-8 % in this symmetric
 //           loop; NOT adopted in the engines -- there a workgroup that arrives late would sleep on everybody's critical path)
+//        7 / 8  as 3 / 6 with FOUR replicas of the published rows (a reader takes replica wg % 4): fewer pollers per cache line --
+//           round 4, for path_wres_kernel's 209 workgroups
 //        4  16-byte rows + a compact flag word per workgroup (stored after its rows): poll the G flags, then read the rows once
 //           (every row still validated by its own tags, re-read if a flag overtook it)
 #include <hip/hip_runtime.h>
@@ -25,7 +27,9 @@ __global__ __launch_bounds__(NTH) void allgather(unsigned long long *buf, unsign
     if (blockIdx.x % stride) return;
     const int tid = threadIdx.x, wg = blockIdx.x / stride, G = gridDim.x / stride, RW = (N + G - 1) / G;
     __shared__ double sh[512];
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)buf, 0, 2 * N * 16, 0x00020000);
+    constexpr int REP = (MODE == 7 || MODE == 8) ? 4 : 1;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)buf, 0, 2 * N * 16 * REP, 0x00020000);
+    const int myrep = wg % REP;
     bool need[EPT], own[EPT];
     for (int k = 0; k < EPT; ++k) { const int row = tid + NTH * k; own[k] = row < N && row / RW == wg; need[k] = row < N && !own[k]; }
     unsigned long long bad = 0;
@@ -44,15 +48,16 @@ __global__ __launch_bounds__(NTH) void allgather(unsigned long long *buf, unsign
                 __hip_atomic_store(base + (size_t)row * 2 + 1, ((unsigned long long)ep << 32) | hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 v4u v; v.x = lo; v.y = ep; v.z = hi; v.w = ep;
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs, (par * N + row) * 16, 0, 16);
+#pragma unroll
+                for (int r = 0; r < REP; ++r) __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((par * REP + r) * N + row) * 16, 0, 16);
             }
         }
         if (MODE == 4) {
             // the flag of this workgroup after its rows (no fence: the rows validate themselves)
-            if (tid == 0) __hip_atomic_store((gu64 *)flags + par * 64 + wg, (unsigned long long)ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store((gu64 *)flags + par * 256 + wg, (unsigned long long)ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned spins = 0;
             for (;;) {
-                const unsigned long long f = tid < G ? __hip_atomic_load((gu64 *)flags + par * 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ep;
+                const unsigned long long f = tid < G ? __hip_atomic_load((gu64 *)flags + par * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ep;
                 if (__syncthreads_and(f == ep)) break;
                 if (++spins > 1000000u) { bad = 1; break; }
             }
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(NTH) void allgather(unsigned long long *buf, unsign
         // gather
         constexpr int NS = (MODE == 0 || MODE == 2) ? 3 : 1;
         if (MODE == 5) __builtin_amdgcn_s_sleep(6);
-        if (MODE == 6) __builtin_amdgcn_s_sleep(12);
+        if (MODE == 6 || MODE == 8) __builtin_amdgcn_s_sleep(12);
         v4u pv[NS][EPT];
         auto issue = [&](int s) {
 #pragma unroll
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(NTH) void allgather(unsigned long long *buf, unsign
                         const unsigned long long a = __hip_atomic_load(base + (size_t)row * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const unsigned long long b = __hip_atomic_load(base + (size_t)row * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         pv[s][k] = v4u{(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
-                    } else pv[s][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (par * N + row) * 16, 0, 16);
+                    } else pv[s][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((par * REP + myrep) * N + row) * 16, 0, 16);
                 }
             }
         };
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(NTH) void allgather(unsigned long long *buf, unsign
 
 template <int MODE> void run(unsigned long long *buf, unsigned long long *flags, unsigned long long *out, int G, int N, int stride)
 {
-    CK(hipMemset(buf, 0, 2 * 512 * 16)); CK(hipMemset(flags, 0, 2 * 64 * 8)); CK(hipMemset(out, 0, 16));
+    CK(hipMemset(buf, 0, 2 * 512 * 16 * 4)); CK(hipMemset(flags, 0, 2 * 256 * 8)); CK(hipMemset(out, 0, 16));
     hipLaunchKernelGGL((allgather<MODE>), dim3(G * stride), dim3(NTH), 0, 0, buf, flags, N, out, stride);
     CK(hipDeviceSynchronize());
     unsigned long long h[2];
@@ -125,7 +130,7 @@ template <int MODE> void run(unsigned long long *buf, unsigned long long *flags,
 int main()
 {
     unsigned long long *buf, *flags, *out;
-    CK(hipMalloc(&buf, 2 * 512 * 16)); CK(hipMalloc(&flags, 2 * 64 * 8)); CK(hipMalloc(&out, 16));
+    CK(hipMalloc(&buf, 2 * 512 * 16 * 4)); CK(hipMalloc(&flags, 2 * 256 * 8)); CK(hipMalloc(&out, 16));
     const int gs[] = {2, 8, 16, 32, 64};
     for (int N : {512, 128})
         for (int G : gs) {
@@ -133,5 +138,8 @@ int main()
             run<3>(buf, flags, out, G, N, 1); run<5>(buf, flags, out, G, N, 1); run<6>(buf, flags, out, G, N, 1); run<4>(buf, flags, out, G, N, 1);
             if (G <= 32) { run<0>(buf, flags, out, G, N, 8); run<2>(buf, flags, out, G, N, 8); }
         }
+    // round 4: the workgroup counts of path_wres_kernel (p >= n with columns in the accumulator file)
+    for (int N : {500, 128})
+        for (int G : {64, 128, 167, 209, 240}) { run<3>(buf, flags, out, G, N, 1); run<6>(buf, flags, out, G, N, 1); run<7>(buf, flags, out, G, N, 1); run<8>(buf, flags, out, G, N, 1); }
     return 0;
 }
