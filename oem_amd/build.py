@@ -135,8 +135,8 @@ def audit_wres_isa(asm_text):
                 problems.append(f"{name}: compiler-emitted {line.strip()}")
             if "scratch_" in line:
                 problems.append(f"{name}: scratch access {line.strip()}")
-    if found < 6:
-        problems.append(f"only {found} of the 6 path_wres kernels found in the ISA listing (the audit pattern is stale)")
+    if found < 8:
+        problems.append(f"only {found} of the 8 path_wres kernels found in the ISA listing (the audit pattern is stale)")
     return problems
 
 

@@ -1083,12 +1083,10 @@ __global__ __launch_bounds__(WNTH) void path_wres_kernel(PathArgs A, const doubl
     if (tid == 0 && writer) { A.d_out[0] = d; A.d_out[1] = theta; A.d_out[4] = (double)nst; A.d_out[5] = (!have_theta && nst >= msteps && nst < n) ? 1.0 : 0.0; }
 
     unsigned colok = 0;                                          // bit s: this lane's column of set s exists
-    double pfj[NS], bcur[NS];                                    // (declared behind the eigenvalue step: nothing of the path lives across it)
+    double bcur[NS];                                             // (declared behind the eigenvalue step: nothing of the path lives across it)
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const bool ok = mycol0 + s * CW < c1;
-        colok |= ok ? 1u << s : 0u;
-        pfj[s] = ok ? A.pf[mycol0 + s * CW] : 0.0;
+        colok |= (mycol0 + s * CW < c1) ? 1u << s : 0u;
         bcur[s] = 0.0;
     }
     for (int pp = A.pen_lo; pp < A.pen_hi; ++pp) {
@@ -1106,11 +1104,16 @@ __global__ __launch_bounds__(WNTH) void path_wres_kernel(PathArgs A, const doubl
             const size_t orow = (size_t)pp * nl + i;
             if (i >= nlam) continue;
             const double lam = wc_uni(A.lambda_out[orow]);
-            const PenK K = pen_consts(pen, lam / scaley, d, A.alpha, A.gamma, A.tau);       // ref src/oem_dense.cpp:241
+            double al_ = A.alpha, ga_ = A.gamma, ta_ = A.tau;
+            asm volatile("" : "+s"(al_), "+s"(ga_), "+s"(ta_));      // (opaque per lambda: what hipcc hoists out of these loops it parks in the accumulator file)
+            const PenK K = pen_consts(pen, lam / scaley, d, al_, ga_, ta_);                  // ref src/oem_dense.cpp:241
             WThr c = wc_thr(K, d);
             c.L = wc_uni(c.L); c.D = wc_uni(c.D); c.rD = wc_uni(c.rD); c.gammad = wc_uni(c.gammad); c.dmg = wc_uni(c.dmg); c.rdmg = wc_uni(c.rdmg);
             c.gm1 = wc_uni(c.gm1); c.gamma = wc_uni(c.gamma); c.dsc = wc_uni(c.dsc); c.rdsc = wc_uni(c.rdsc); c.d = wc_uni(c.d); c.rd = wc_uni(c.rd);
             const double tol = wc_uni(A.tol);
+            double tp[NS];                                       // penalty factor x lambda of this lane's columns (read per lambda: short live ranges
+#pragma unroll                                                   // around the set-up code are what keeps hipcc out of the accumulator file)
+            for (int s = 0; s < NS; ++s) tp[s] = ((colok >> s) & 1u) ? A.pf[mycol0 + s * CW] * c.L : 0.0;
             int it = 0;
             for (;;) {
                 double bn[NS];
@@ -1119,7 +1122,7 @@ __global__ __launch_bounds__(WNTH) void path_wres_kernel(PathArgs A, const doubl
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const double u = bn[s] * rn + d * bcur[s];       // ref src/oem_dense.h:520: X'(Y - X beta)/n + d beta
-                    const double b = ((colok >> s) & 1u) ? wc_op(u, pfj[s] * c.L, c) : 0.0;
+                    const double b = ((colok >> s) & 1u) ? wc_op(u, tp[s], c) : 0.0;
                     const double cu = fabs(b), qo = fabs(bcur[s]);
                     const bool cn = cu > 1e-13, qn = qo > 1e-13;      // ref src/utils.cpp:537-549
                     moving |= (cn != qn) || (cn && qn && fabs(b - bcur[s]) > tol * qo);
@@ -1610,7 +1613,7 @@ int launch_path_wcoop(hipStream_t s, const PathArgs &a, const WideArgs &wd, int 
 
 // ---- the resident form with columns in the accumulator file too (path_wres_kernel)
 static int wres_cpg(int nr) { return 4 * wc_cw(nr) * (1 + 128 / (wc_cw(nr) * nr)); }
-static bool wres_nr_built(int nr) { return nr == 1 || nr == 2 || nr == 3 || nr == 4 || nr == 6 || nr == 8; }
+static bool wres_nr_built(int nr) { return nr == 1 || nr == 2 || nr == 3 || nr == 4 || nr == 6 || nr == 8 || nr == 12 || nr == 16; }
 int path_wres_workgroups(int n, int p)
 {
     const WideLayout L = wide_layout(n);
@@ -1659,6 +1662,8 @@ int launch_path_wres(hipStream_t s, const PathArgs &a, const WideArgs &wd)
     case 4: return wres_launch<4>(s, a, wd, G);
     case 6: return wres_launch<6>(s, a, wd, G);
     case 8: return wres_launch<8>(s, a, wd, G);
+    case 12: return wres_launch<12>(s, a, wd, G);
+    case 16: return wres_launch<16>(s, a, wd, G);
     default: break;
     }
     set_error("internal: resident wide engine, nr = %d", wd.lay.nr);

@@ -523,7 +523,7 @@ def test_random_wide_resident_in_the_accumulator_file(oa, seed, monkeypatch):
     against the oracle's restatement of the branch and against the launch-per-iteration engine."""
     monkeypatch.setenv("OEM_WIDE", "1"); monkeypatch.setenv("OEM_WRES", "1")
     rng = np.random.default_rng(8100 + seed)
-    n = int(rng.choice([1, 2, 9, 40, 64, 65, 120, 128, 129, 192, 200, 256, 257, 320, 384, 385, 500, 512]))
+    n = int(rng.choice([1, 2, 9, 40, 64, 65, 120, 128, 129, 192, 200, 256, 257, 320, 384, 385, 500, 512, 513, 700, 768, 769, 900, 1024]))
     p = int(max(2, n + rng.integers(0, max(2, min(8 * n + 300, 700_000 // max(n, 1))))))
     if rng.random() < 0.25:
         n = int(rng.choice([20, 64, 100, 130])); p = int(rng.choice([9000, 12289, 20000]))       # many workgroups, short columns

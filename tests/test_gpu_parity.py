@@ -1029,11 +1029,11 @@ def test_sparse_x_large_p_engine(oa):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,p", [(3, 700), (40, 1200), (64, 5200), (100, 2500), (128, 9000), (130, 2100), (192, 5000), (200, 1000), (256, 3000), (300, 1300),
-                                 (384, 2000), (500, 2000), (512, 2200), (380, 4000)])
+                                 (384, 2000), (500, 2000), (512, 2200), (380, 4000), (700, 1410), (768, 2100), (1000, 1000), (1024, 2048)])
 def test_wide_engine_resident_in_the_accumulator_file(oa, n, p, monkeypatch):
     """p >= n with more column sets of every wave in the ACCUMULATOR file (path_wcoop.hip: path_wres_kernel, round 4 -- Xs up to ~11 M
     entries stays in registers).  OEM_WRES=1 takes it also where the vector registers alone would do, so every
-    column height it is built for (1, 2, 3, 4, 6, 8 registers per column and lane: 9 .. 3 column sets per wave), ragged last sets and
+    column height it is built for (1, 2, 3, 4, 6, 8, 12, 16 registers per column and lane: 9 .. 3 column sets per wave), ragged last sets and
     workgroups, all-reduce slices that are ragged or empty run here at sizes the oracle finishes: element-wise operators with penalty
     factors, maxit reached, user lambdas, OLS, compute.loss, all four standardisation flags -- against the oracle's restatement of
     the branch and the launch-per-iteration engine; and the host's fallback when its exchange times out."""

@@ -9,7 +9,7 @@ from oem_amd import _lib as L
 warnings.simplefilter("ignore")
 rng = np.random.default_rng(5); lib = L.lib()
 shapes = ((500, 20000, 30, "lasso"), (500, 8000, 30, "lasso"), (250, 16000, 10, "lasso"), (190, 20000, 10, "lasso"), (200, 30000, 20, "lasso"),
-          (64, 100000, 10, "lasso"), (128, 40000, 10, "lasso"), (100, 30000, 10, "lasso"), (64, 50000, 20, "scad"), (380, 24000, 10, "mcp"), (30, 100000, 10, "lasso"))
+          (64, 100000, 10, "lasso"), (128, 40000, 10, "lasso"), (100, 30000, 10, "lasso"), (64, 50000, 20, "scad"), (1000, 8000, 10, "lasso"), (700, 12000, 10, "mcp"), (30, 100000, 10, "lasso"))
 if len(sys.argv) > 1: shapes = shapes[:int(sys.argv[1])]
 for n, p, nlam, pen in shapes:
     x = np.asfortranarray(rng.normal(size=(n, p))); y = x[:, :10] @ rng.uniform(0.5, 1.5, 10) + rng.normal(size=n)
