@@ -328,21 +328,24 @@ __device__ __forceinline__ int wc_allreduce(double *Rsh, const double *Ysh, cons
     __syncthreads();
     const int any1 = wgbit | votes[4] | votes[5] | votes[6] | votes[7];  // owners: the OR over all workgroups (every one of them sent a row)
     WC_STAMP(4);
-    // ---- the slice: G partials per row in workgroup order, eight interleaved chains per row
+    // ---- the slice: G partials per row in workgroup order, eight interleaved chains per row (sixteen for path_wres_kernel's
+    // > 192 workgroups: a chain of 27 dependent adds per row became the longest thing between the two gathers)
+    constexpr int PARTS = GM > WCOOP_GMAX ? 16 : 8;
     const unsigned tag2 = (X.epoch << 1) | (unsigned)any1;
-    for (int idx = tid; idx < X.nsl * 8; idx += WNTH) {
-        const int s = idx >> 3, part = idx & 7;
+    for (int idx = tid; idx < X.nsl * PARTS; idx += WNTH) {
+        const int s = idx / PARTS, part = idx % PARTS;
         double t = 0.0;
-        for (int g0 = part; g0 < X.G; g0 += 64) {
+        for (int g0 = part; g0 < X.G; g0 += 8 * PARTS) {
             double a[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const int g = g0 + 8 * j; a[j] = Gsh[(g < X.G ? g : 0) * X.SL + s]; }
+            for (int j = 0; j < 8; ++j) { const int g = g0 + PARTS * j; a[j] = Gsh[(g < X.G ? g : 0) * X.SL + s]; }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t += (g0 + 8 * j < X.G) ? a[j] : 0.0;
+            for (int j = 0; j < 8; ++j) t += (g0 + PARTS * j < X.G) ? a[j] : 0.0;
         }
         t += dpp_mov<0xB1, 0xf>(t, 0.0);
         t += dpp_mov<0x4E, 0xf>(t, 0.0);
         t += dpp_mov<0x141, 0xf>(t, 0.0);
+        if constexpr (PARTS == 16) t += dpp_mov<0x140, 0xf>(t, 0.0);
         if (part == 0) {
             const int row = X.row0 + s;
             const double out = OEM ? Ysh[row] - t : t * rn;

@@ -68,6 +68,12 @@ if [ -z "$quick" ]; then
   fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_wcoop_trace -o ${tag} -- python3 tools/run_wcoop.py > $o/${tag}_wcoop_trace.log 2>&1
   cp "$(find $o/${tag}_wcoop_trace -name '*kernel_stats.csv' | head -1)" $o/${tag}_wcoop_n500_p2000_kernel_stats.csv
+  rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_wres_trace -o ${tag} -- python3 tools/run_wres.py > $o/${tag}_wres_trace.log 2>&1
+  cp "$(find $o/${tag}_wres_trace -name '*kernel_stats.csv' | head -1)" $o/${tag}_wres_n500_p20000_kernel_stats.csv
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/${tag}_wres_pmc_$c -o ${tag} -- python3 tools/run_wres.py > /dev/null 2> $o/${tag}_wres_pmc_$c.err
+  done
+  python3 tools/pmc_summary.py "path_wres_kernel" $o/${tag}_wres_pmc.json "$(find $o/${tag}_wres_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_wres_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
   python3 tools/wres_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_wres_times.txt
   if [ -f oem_amd/liboemgpu_diag.so ]; then
     OEMGPU_LIB=oem_amd/liboemgpu_diag.so python3 tools/wcoop_diag.py 500 20000 30 2>&1 | grep -v "amdgpu.ids\|warn" >> $o/${tag}_wres_times.txt
