@@ -325,24 +325,43 @@ def test_concurrent_callers_of_the_cooperating_wide_engine(oa):
 
 
 @pytest.mark.gpu
-def test_persistent_engine_under_real_contention(oa, tmp_path):
+@pytest.mark.parametrize("engine", ["symcoop", "wres"])
+def test_persistent_engine_under_real_contention(oa, tmp_path, engine):
     """the fallback of the persistent engines had only ever been tested with a FAKED poison.  Here a second PROCESS
     holds 200 of the device's CUs (tests/hold_cus_worker.py: workgroups that take a whole CU each and spin for six seconds) while
-    this process calls oem.xtx at p = 4096, whose persistent engine (path_symcoop.hip) needs 174 workgroups resident at once.
-    Whatever the hardware scheduler does -- run what fits beside the holder, so that the exchanges time out after about a second
-    and the call is made again on the launch-per-iteration engine, or queue the launch behind the holder -- the call must come
-    back, within a bounded time, with a right answer: the bits of one of the two engines."""
-    import os, subprocess, sys, time
+    this process calls oem.xtx at p = 4096, whose persistent engine (path_symcoop.hip) needs 174 workgroups resident at once -- or
+    oem() at 250 x 16,000, whose standardised X lives in the vector and accumulator registers of 84 workgroups (path_wres_kernel,
+    the engine that may take up to 240 CUs).  Whatever the hardware scheduler does -- run what fits beside the holder, so that the
+    exchanges time out after about a second and the call is made again on the launch-per-iteration engine, or queue the launch
+    behind the holder -- the call must come back, within a bounded time, with a right answer: the bits of one of the two engines."""
+    import os, subprocess, sys, time, warnings
     import torch
-    xtx, xty = _xtx_problem_host(4096, 8192, 5)
-    xd = torch.as_tensor(xtx, device="cuda")
-    kw = dict(penalty="lasso", nlambda=5, tol=1e-8)
-    alone = oa.oem_xtx(xd, xty, **kw)
-    os.environ["OEM_NO_SYMCOOP"] = "1"
+    if engine == "symcoop":
+        xtx, xty = _xtx_problem_host(4096, 8192, 5)
+        xd = torch.as_tensor(xtx, device="cuda")
+        kw = dict(penalty="lasso", nlambda=5, tol=1e-8)
+        call = lambda: oa.oem_xtx(xd, xty, **kw)
+        off = ("OEM_NO_SYMCOOP",)
+    else:
+        rng = np.random.default_rng(77)
+        xh = rng.normal(size=(250, 16000)); yh = xh[:, :8] @ rng.uniform(0.5, 1.5, 8) + rng.normal(size=250)
+        xd = torch.as_tensor(np.ascontiguousarray(xh.T), device="cuda").t()
+        kw = dict(penalty="lasso", nlambda=5, tol=1e-8)
+
+        def call():
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                return oa.oem(xd, yh, **kw)
+        off = ("OEM_NO_WCOOP", "OEM_NO_WSTREAM")
+    alone = call()
+    assert oa.last_path_engine()[0] == engine
+    for k in off:
+        os.environ[k] = "1"
     try:
-        launches = oa.oem_xtx(xd, xty, **kw)
+        launches = call()
     finally:
-        del os.environ["OEM_NO_SYMCOOP"]
+        for k in off:
+            del os.environ[k]
     flag = tmp_path / "hold.flag"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     holder = subprocess.Popen([sys.executable, os.path.join(root, "tests", "hold_cus_worker.py"), "200", "6000", str(flag)], cwd=root,
@@ -354,7 +373,7 @@ def test_persistent_engine_under_real_contention(oa, tmp_path):
         assert flag.exists(), "the holder never started"
         time.sleep(0.3)
         t1 = time.time()
-        during = oa.oem_xtx(xd, xty, **kw)
+        during = call()
         wall = time.time() - t1
         held = flag.read_text() == "holding"                       # (still holding when the call came back?)
     finally:
@@ -364,7 +383,8 @@ def test_persistent_engine_under_real_contention(oa, tmp_path):
     same_as = [name for name, ref in (("persistent", alone), ("launches", launches))
                if np.array_equal(np.asarray(during["beta"][0]), np.asarray(ref["beta"][0])) and np.array_equal(during["niter"][0], ref["niter"][0])]
     assert same_as, "the answer under contention matches neither engine"
-    print(f"under contention: {wall:.2f} s, answer of the {same_as[0]} engine, holder still holding at return: {held}")
+    print(f"{engine} under contention: {wall:.2f} s, answer of the {same_as[0]} engine, holder still holding at return: {held}, "
+          f"engine of the last attempt {oa.last_path_engine()}")
 
 
 def _xtx_problem_host(p, n, seed):

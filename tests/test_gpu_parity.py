@@ -1029,7 +1029,7 @@ def test_sparse_x_large_p_engine(oa):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,p", [(3, 700), (40, 1200), (64, 5200), (100, 2500), (128, 9000), (130, 2100), (192, 5000), (200, 1000), (256, 3000), (300, 1300),
-                                 (384, 2000), (500, 2000), (512, 2200), (380, 4000), (700, 1410), (768, 2100), (1000, 1000), (1024, 2048)])
+                                 (384, 2000), (500, 2000), (512, 1300), (380, 2500), (700, 1410), (768, 1100), (1000, 1000), (1024, 1300)])
 def test_wide_engine_resident_in_the_accumulator_file(oa, n, p, monkeypatch):
     """p >= n with more column sets of every wave in the ACCUMULATOR file (path_wcoop.hip: path_wres_kernel, round 4 -- Xs up to ~11 M
     entries stays in registers).  OEM_WRES=1 takes it also where the vector registers alone would do, so every
