@@ -112,6 +112,14 @@ int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_
                    int32_t standardize, int32_t intercept, const oemgpu_opts *o,
                    double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
 
+/* oem_fit_dense with a non-empty `weights_` (ref src/oem_dense.cpp:34,75,152,162; src/oem_dense.h:368-414, 699-707, 759-770;
+ * src/DataStd.h:94-202): the R front end never sends one ("weights not implemented yet", R/oem.R:244), the compiled entry takes it.
+ * Computed as the reference computes it (sqrt(w)-weighted DataStd statistics -- unweighted for x under flag 3 --, X'WX / n, X'(Yw) / n,
+ * loss = sum w r^2).  nobs > nvars; with nobs <= nvars: OEMGPU_ERR_UNSUPPORTED.  weights: n values, finite, >= 0. */
+int oemgpu_fit_dense_weighted(const double *x, int64_t n, int32_t p, const double *y, const double *weights,
+                              int32_t standardize, int32_t intercept, const oemgpu_opts *opts,
+                              double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
+
 /* replaces oem_fit_sparse, ref src/oem_sparse.cpp:30-267 (family "gaussian", weights empty, n > p): oem() on a dgCMatrix.
  * colptr[p + 1], rowidx[nnz], values[nnz]: the compressed sparse column slots @p, @i, @x (row indices increasing inside a
  * column).  Outputs as oemgpu_fit_dense.  The semantics are oemSparse's, not oemDense's: no centring, columns scaled by
@@ -187,6 +195,10 @@ int oemgpu_solve_moments_dev(oemgpu_ctx *ctx, const double *moments_dev, const d
 int oemgpu_fit_dense_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
                          int32_t standardize, int32_t intercept, const oemgpu_opts *o,
                          double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
+/* oemgpu_fit_dense_weighted with X, y and the weights already on the device. */
+int oemgpu_fit_dense_weighted_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
+                                  const double *weights_dev, int32_t standardize, int32_t intercept, const oemgpu_opts *opts,
+                                  double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);
 
 /* oemgpu_fit_xtx with xtx (p x p) / xty on the device. */
 int oemgpu_fit_xtx_dev(oemgpu_ctx *ctx, const double *xtx_dev, const double *xty_dev, int32_t p,

@@ -48,6 +48,9 @@ _lib = None
 _OUT = [_dp, _dp, _ip, _dp, _dp]           # beta, lambda_out, niter, loss, d
 _SIGS = {
     "oemgpu_fit_dense": (C.c_int, [_dp, C.c_int64, C.c_int32, _dp, C.c_int32, C.c_int32, C.POINTER(OemgpuOpts)] + _OUT),
+    "oemgpu_fit_dense_weighted": (C.c_int, [_dp, C.c_int64, C.c_int32, _dp, _dp, C.c_int32, C.c_int32, C.POINTER(OemgpuOpts)] + _OUT),
+    "oemgpu_fit_dense_weighted_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                                C.c_int32, C.POINTER(OemgpuOpts)] + _OUT),
     "oemgpu_fit_xtx": (C.c_int, [_dp, _dp, C.c_int32, _dp, C.POINTER(OemgpuOpts)] + _OUT),
     "oemgpu_fit_big": (C.c_int, [C.POINTER(_dp), C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.POINTER(_dp), C.c_int32,
                                  C.c_int32, C.POINTER(OemgpuOpts)] + _OUT),

@@ -250,7 +250,7 @@ def oem(x, y, family="gaussian", penalty=None, weights=(), lambda_=(), nlambda=1
         alpha=1.0, gamma=3.0, tau=0.5, groups=(), penalty_factor=None, group_weights=None, standardize=True,
         intercept=True, maxit=500, tol=1e-7, irls_maxit=100, irls_tol=1e-3, accelerate=False, ncores=-1,
         compute_loss=False, hessian_type="upper.bound", varnames=None, ngpus=0, devices=None, upload_threads=0,
-        interrupt=None):
+        interrupt=None, _entry_weights=None):
     """oem(): R/oem.R:162-507, dense gaussian branch.  ngpus / devices / upload_threads / interrupt: the host-resident
     options of include/oemgpu.h (`options` gains ngpus / device; absent => one GPU)."""
     if family not in ("gaussian", "binomial"):
@@ -297,6 +297,28 @@ def oem(x, y, family="gaussian", penalty=None, weights=(), lambda_=(), nlambda=1
         L.check(lib.oemgpu_fit_sparse(n, p, colptr.ctypes.data, _iptr(rowidx), _dptr(vals), _dptr(yh), int(bool(standardize)),
                                       int(bool(intercept)), C.byref(a.c), *a.outputs(p + 1)))
         return _decorate(a, penalty, varnames, True, n, p)
+    if _entry_weights is not None:                                     # oem_fit_dense with a weights vector (oem_fit_dense_weighted below)
+        if is_sparse:
+            raise ValueError("observation weights: dense x only (oem_fit_sparse ignores its weights argument)")
+        wh = np.ascontiguousarray(np.asarray(_entry_weights, dtype=np.float64).reshape(-1))
+        if wh.shape[0] != n:
+            raise ValueError("length of weights not same as number of observations in x")       # R/oem.R:261-266
+        if _is_torch_cuda(x):
+            import torch
+            xp, n_, p_, ld, keep = _device_matrix(x)
+            yd = torch.as_tensor(np.asarray(y.cpu() if _is_torch_cuda(y) else y, dtype=np.float64), device=x.device).reshape(-1)
+            wd = torch.as_tensor(wh, device=x.device)
+            ctx = context(x.device.index)
+            torch.cuda.current_stream(x.device).synchronize()
+            L.check(lib.oemgpu_fit_dense_weighted_dev(ctx, xp, n, ld, p, yd.data_ptr(), wd.data_ptr(), int(bool(standardize)),
+                                                      int(bool(intercept)), C.byref(a.c), *a.outputs(p + 1)))
+            del keep
+        else:
+            xh = np.asfortranarray(x, dtype=np.float64)
+            yh = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+            L.check(lib.oemgpu_fit_dense_weighted(_dptr(xh), n, p, _dptr(yh), _dptr(wh), int(bool(standardize)), int(bool(intercept)),
+                                                  C.byref(a.c), *a.outputs(p + 1)))
+        return _decorate(a, penalty, varnames, True, n, p)
     if _is_torch_cuda(x):
         import torch
         xp, n_, p_, ld, keep = _device_matrix(x)
@@ -313,6 +335,13 @@ def oem(x, y, family="gaussian", penalty=None, weights=(), lambda_=(), nlambda=1
         L.check(lib.oemgpu_fit_dense(_dptr(xh), n, p, _dptr(yh), int(bool(standardize)), int(bool(intercept)),
                                      C.byref(a.c), *a.outputs(p + 1)))
     return _decorate(a, penalty, varnames, True, n, p)
+
+
+def oem_fit_dense_weighted(x, y, weights, **kw):
+    """What the compiled entry `oem_fit_dense` computes when it is handed a non-empty `weights_` (ref src/oem_dense.cpp:34,75,152,162;
+    src/oem_dense.h:368-414, 699-707, 759-770; src/DataStd.h:94-202).  R's oem() stops with "weights not implemented yet" before it
+    gets there (R/oem.R:244) and so does `oem()` here; this is the entry below that check, with oem()'s other arguments."""
+    return oem(x, y, _entry_weights=weights, **kw)
 
 
 # ------------------------------------------------------------------------------------------ oem.xtx()

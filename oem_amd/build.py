@@ -14,7 +14,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "liboemgpu.so"
-SOURCES = ["api.hip", "hoststream.hip", "gram.hip", "path_small.hip", "path_coop.hip", "path_symcoop.hip", "path_wcoop.hip", "path_large.hip", "xval.hip", "sparse.hip", "wide.hip"]
+SOURCES = ["api.hip", "hoststream.hip", "gram.hip", "path_small.hip", "path_coop.hip", "path_symcoop.hip", "path_wcoop.hip", "path_large.hip", "xval.hip", "sparse.hip", "wide.hip", "weighted.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 

@@ -811,9 +811,23 @@ int oemgpu_moments_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld
     return shard_moments(c, pl, x_dev, n, ld, y_dev, sums_dev, (double *)(c->ws + a_t), (double *)(c->ws + a_v), moments_dev);
 }
 
+// wpatch (device, or NULL): the constants of DataStd's WEIGHTED standardisation (weighted.hip).  The moments are then those of the
+// standardised, sqrt(w)-scaled copy: finalize takes them as they are (flag 0) and the constants go into `stats` for the lambda
+// grid (scaleY) and for recover(), which run under the caller's flags.
+static int solve_moments_impl(oemgpu_ctx *c, const double *moments_dev, const double *sums_dev, int32_t p,
+                              int32_t semantics, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                              double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, const double *wpatch);
+
 int oemgpu_solve_moments_dev(oemgpu_ctx *c, const double *moments_dev, const double *sums_dev, int32_t p,
                              int32_t semantics, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
                              double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    return solve_moments_impl(c, moments_dev, sums_dev, p, semantics, standardize, intercept, o, beta, lambda_out, niter, loss, d, nullptr);
+}
+
+static int solve_moments_impl(oemgpu_ctx *c, const double *moments_dev, const double *sums_dev, int32_t p,
+                              int32_t semantics, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                              double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, const double *wpatch)
 {
     if (!c || !moments_dev || !beta || !lambda_out || !niter || !loss || !d) { set_error("solve_moments: NULL argument"); return OEMGPU_ERR_ARG; }
     if (semantics != OEMGPU_SEM_DENSE && semantics != OEMGPU_SEM_BIG && semantics != OEMGPU_SEM_XVAL) { set_error("unknown semantics %d", semantics); return OEMGPU_ERR_ARG; }
@@ -845,7 +859,8 @@ int oemgpu_solve_moments_dev(oemgpu_ctx *c, const double *moments_dev, const dou
     double *xx = (double *)(c->ws + base + a_xx), *xy = (double *)(c->ws + base + a_xy), *st = (double *)(c->ws + base + a_st);
     {
         Timer t(c, OEMGPU_T_FINAL);
-        rc = launch_finalize(c->stream, moments_dev, sums_dev, p, semantics, standardize, intercept, xx, xy, st);
+        rc = launch_finalize(c->stream, moments_dev, sums_dev, p, semantics, wpatch ? 0 : standardize, wpatch ? 0 : intercept, xx, xy, st);
+        if (!rc && wpatch) rc = launch_weighted_patch_stats(c->stream, wpatch, p, st);
         if (rc) return rc;
     }
     return run_paths(c, B2, xx, xy, st, p, q, semantics, standardize, intercept, o, nullptr, beta, lambda_out, niter, loss, d);
@@ -1016,6 +1031,79 @@ int oemgpu_fit_dense_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t 
         if (rc) return rc;
     }
     return oemgpu_solve_moments_dev(c, mom, sums, p, OEMGPU_SEM_DENSE, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+}
+
+// oemDense with observation weights (weighted.hip has the algebra and the reference lines).  n > p.
+static int fit_dense_weighted_impl(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev, const double *w_dev,
+                                   const double *w_host, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                                   double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    if (!c || !x_dev || !y_dev || (!w_dev && !w_host)) { set_error("fit_dense_weighted: NULL argument"); return OEMGPU_ERR_ARG; }
+    int rc = check_opts(o, p, p);
+    if (rc) return rc;
+    if (n < 1 || ld < n) { set_error("fit_dense_weighted: bad n / ld"); return OEMGPU_ERR_ARG; }
+    if (n <= p) {
+        set_error("observation weights with nobs <= nvars are not built (the reference iterates with w squared there, src/oem_dense.h:513-517)");
+        return OEMGPU_ERR_UNSUPPORTED;
+    }
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    const int flag = (standardize ? 1 : 0) + 2 * (intercept ? 1 : 0);
+    const int64_t ldz = (n + 63) / 64 * 64;
+    Bump Z;
+    const size_t a_z = Z.take(sizeof(double) * (size_t)ldz * p), a_yz = Z.take(sizeof(double) * (size_t)ldz), a_ws = Z.take(sizeof(double) * (size_t)(2 + 2 * p)),
+                 a_w = Z.take(sizeof(double) * (size_t)n);
+    if (ctx_grow(c, &c->aux, &c->aux_bytes, Z.off)) return OEMGPU_ERR_HIP;
+    double *z = (double *)(c->aux + a_z), *yz = (double *)(c->aux + a_yz), *wsd = (double *)(c->aux + a_ws);
+    if (w_host) {
+        for (int64_t i = 0; i < n; ++i)
+            if (!(w_host[i] >= 0.0) || !std::isfinite(w_host[i])) { set_error("fit_dense_weighted: weights must be finite and >= 0"); return OEMGPU_ERR_ARG; }
+        OEM_HIP(hipMemcpyAsync(c->aux + a_w, w_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        w_dev = (const double *)(c->aux + a_w);
+    }
+    const GramPlan pl = gram_plan(n, p, c->num_cu);
+    Bump B;
+    const size_t a_mom = B.take((size_t)oemgpu_moments_len(p) * 8);
+    const size_t frame = B.off;
+    const size_t a_t = B.take(pl.tpart_doubles * 8), a_v = B.take(pl.vpart_doubles * 8);
+    size_t need = B.off;
+    const size_t need2 = frame + ((size_t)p * p + p + stats_len(p)) * 8 + 1024 + paths_ws_bytes(p, p, o) + 4096;
+    if (need2 > need) need = need2;
+    if (ctx_reserve(c, need)) return OEMGPU_ERR_HIP;
+    double *mom = (double *)(c->ws + a_mom);
+    {
+        Timer t(c, OEMGPU_T_MOMENTS);
+        rc = launch_weighted_stats(c->stream, x_dev, n, ld, p, y_dev, w_dev, flag, wsd);
+        if (!rc) rc = launch_weighted_apply(c->stream, x_dev, n, ld, p, y_dev, w_dev, flag, wsd, 0, z, ldz, yz);
+        if (!rc) rc = shard_moments(c, pl, z, n, ldz, yz, nullptr, (double *)(c->ws + a_t), (double *)(c->ws + a_v), mom);
+        if (rc) return rc;
+    }
+    return solve_moments_impl(c, mom, nullptr, p, OEMGPU_SEM_DENSE, standardize, intercept, o, beta, lambda_out, niter, loss, d, wsd);
+}
+
+int oemgpu_fit_dense_weighted_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev, const double *w_dev,
+                                  int32_t standardize, int32_t intercept, const oemgpu_opts *o,
+                                  double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    return fit_dense_weighted_impl(c, x_dev, n, ld, p, y_dev, w_dev, nullptr, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+}
+
+// host buffers in, as `.Call("oem_fit_dense", x, y, family, penalty, weights, ...)` hands them over (ref src/oem_dense.cpp:30-75)
+int oemgpu_fit_dense_weighted(const double *x, int64_t n, int32_t p, const double *y, const double *weights, int32_t standardize, int32_t intercept,
+                              const oemgpu_opts *o, double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
+{
+    if (!x || !y || !weights || !o || !beta || !lambda_out || !niter || !loss || !d) { set_error("fit_dense_weighted: NULL argument"); return OEMGPU_ERR_ARG; }
+    int rc = check_opts(o, p, p);
+    if (rc) return rc;
+    if (n < 1) { set_error("fit_dense_weighted: bad n"); return OEMGPU_ERR_ARG; }
+    oemgpu_ctx *c = ctx_acquire(o->device);
+    if (!c) return OEMGPU_ERR_NO_DEVICE;
+    double *xd = nullptr, *yd = nullptr;
+    int64_t ld = 0;
+    rc = host_upload_resident(c, x, n, p, y, o, &xd, &ld, &yd, 0, true);
+    if (!rc) rc = fit_dense_weighted_impl(c, xd, n, ld, p, yd, nullptr, weights, standardize, intercept, o, beta, lambda_out, niter, loss, d);
+    (void)hipStreamSynchronize(c->stream);
+    ctx_release(c);
+    return rc;
 }
 
 int oemgpu_fit_xtx_dev(oemgpu_ctx *c, const double *xtx_dev, const double *xty_dev, int32_t p, const double *scale_factor,

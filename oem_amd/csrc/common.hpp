@@ -58,6 +58,11 @@ size_t csc_moments_work_bytes(int64_t n, int p);
 bool csc_moments_fits(int p);
 int launch_csc_moments(hipStream_t s, const int64_t *colptr, const int32_t *rowidx, const double *val, const double *y, int64_t n, int p,
                        void *work, double *moments);
+// observation weights of oemDense (weighted.hip): DataStd's weighted statistics, the scaled copy, its constants into `stats`
+int launch_weighted_stats(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, const double *w, int flag, double *ws);
+int launch_weighted_apply(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, const double *w, int flag, const double *ws,
+                          int squared, double *z, int64_t ldz, double *yz);
+int launch_weighted_patch_stats(hipStream_t s, const double *ws, int p, double *stats);
 int launch_gram_loss(hipStream_t s, const double *xx, const double *xy, const double *stats, int q, const double *beta, const double *sinv,
                      const int *niter, double *loss, int nk);                       // oemSparse's compute.loss behind the larger engines
 int launch_resid_loss(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, const double *beta, int rows, int nk,

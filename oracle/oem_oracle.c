@@ -738,6 +738,136 @@ int orc_fit_dense(const double *x_in, int64_t n, int32_t p, const double *y_in,
 }
 
 /* ------------------------------------------------------------------ */
+/* oemDense with observation weights -- what `.Call("oem_fit_dense", ..., weights_, ...)` computes (the R front end stops with
+ * "weights not implemented yet", R/oem.R:244, so nothing the package ships reaches it: no reference-held number exists for this
+ * branch; PARITY UNPINNED here, the restatement is held against numpy in tests/test_oracle_independent.py).  Restated as it is,
+ * inconsistencies included:
+ *   DataStd::standardize(X, Y, wts), ref src/DataStd.h:94-202: Y by sqrt(w)-weighted statistics in every flag (flag 2 falls through
+ *     into flag 3); X by sd_n(x sqrt w) (flag 1), mean(x sqrt w) (flag 2) and the UNWEIGHTED mean / norm (flag 3);
+ *   XY = X'(Y w)/n (ref src/oem_dense.h:699-707); nobs > nvars: XX = X' diag(w) X / n (:368-414, 466-483);
+ *   nobs <= nvars: d from (sqrt(w) X)(sqrt(w) X)'/n (:410-414) but next_u = X'((Y - X beta) w^2)/n + d beta (:513-517: w SQUARED);
+ *   get_loss = sum w (Y - X beta)^2 on the standardised data (:759-770). */
+int orc_fit_dense_w(const double *x_in, int64_t n, int32_t p, const double *y_in, const double *w,
+                    int32_t standardize, int32_t intercept, const orc_opts *o,
+                    double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out)
+{
+    const int wide = n <= p;
+    if (wide && n > 8192) return fail("oracle: the p >= n branch is restated for n <= 8192 only (dense n x n eigen-solve)");
+    int flag = (standardize ? 1 : 0) + 2 * (intercept ? 1 : 0);
+    int nl = nl_of(o);
+    double *X = (double *)malloc(sizeof(double) * (size_t)n * p), *Z = (double *)malloc(sizeof(double) * (size_t)n * p);
+    double *Y = (double *)malloc(sizeof(double) * (size_t)n * 3), *Yw = Y + n, *tmp = Yw + n;
+    double *meanx = (double *)malloc(sizeof(double) * (size_t)p * 2), *scalex = meanx + p;
+    double *XX = (double *)malloc(sizeof(double) * (size_t)(wide ? 1 : p) * (wide ? 1 : p));
+    double *XY = (double *)malloc(sizeof(double) * (size_t)p);
+    double *lam = (double *)malloc(sizeof(double) * (size_t)o->npen * nl), *lams = (double *)malloc(sizeof(double) * (size_t)o->npen * nl);
+    double *bstd = (double *)malloc(sizeof(double) * (size_t)o->npen * nl * p);
+    if (!X || !Z || !Y || !meanx || !XX || !XY || !lam || !lams || !bstd) return fail("oracle: out of memory");
+    memcpy(X, x_in, sizeof(double) * (size_t)n * p);
+    memcpy(Y, y_in, sizeof(double) * (size_t)n);
+    const double n_invsqrt = 1.0 / sqrt((double)n);
+    double meany = 0.0, scaley = 1.0;
+    for (int j = 0; j < p; j++) { meanx[j] = 0.0; scalex[j] = 1.0; }
+    /* Y (ref src/DataStd.h:100-137) */
+    if (flag == 1) {
+        for (int64_t i = 0; i < n; i++) tmp[i] = Y[i] * sqrt(w[i]);
+        scaley = sd_n(tmp, n);
+        for (int64_t i = 0; i < n; i++) Y[i] /= scaley;
+    } else if (flag >= 2) {
+        for (int64_t i = 0; i < n; i++) tmp[i] = Y[i] * sqrt(w[i]);
+        meany = col_mean(tmp, n);
+        for (int64_t i = 0; i < n; i++) Y[i] -= meany;
+        for (int64_t i = 0; i < n; i++) tmp[i] = Y[i] * sqrt(w[i]);
+        scaley = col_norm(tmp, n) * n_invsqrt;
+        for (int64_t i = 0; i < n; i++) Y[i] /= scaley;
+    }
+    /* X (ref src/DataStd.h:140-202) */
+    for (int j = 0; j < p && flag; j++) {
+        double *c = X + (size_t)j * n;
+        if (flag == 1) {
+            for (int64_t i = 0; i < n; i++) tmp[i] = c[i] * sqrt(w[i]);
+            scalex[j] = sd_n(tmp, n);
+            if (scalex[j] == 0.0) scalex[j] = 1.0;
+            double r = 1.0 / scalex[j];
+            for (int64_t i = 0; i < n; i++) c[i] *= r;
+        } else if (flag == 2) {
+            for (int64_t i = 0; i < n; i++) tmp[i] = c[i] * sqrt(w[i]);
+            meanx[j] = col_mean(tmp, n);
+            for (int64_t i = 0; i < n; i++) c[i] -= meanx[j];
+        } else {
+            meanx[j] = col_mean(c, n);
+            for (int64_t i = 0; i < n; i++) c[i] -= meanx[j];
+            scalex[j] = col_norm(c, n) * n_invsqrt;
+            if (scalex[j] == 0.0) scalex[j] = 1.0;          /* (the __AVX__ build's guard, ref :172-175) */
+            for (int64_t i = 0; i < n; i++) c[i] /= scalex[j];
+        }
+    }
+    /* XY = X'(Y w) / n */
+    for (int64_t i = 0; i < n; i++) Yw[i] = Y[i] * w[i];
+    for (int j = 0; j < p; j++) {
+        const double *c = X + (size_t)j * n;
+        double t = 0.0;
+        for (int64_t i = 0; i < n; i++) t += c[i] * Yw[i];
+        XY[j] = t / (double)n;
+    }
+    /* Z = diag(sqrt w) X: XtWX = Z'Z, XWXt = Z Z' */
+    for (int j = 0; j < p; j++)
+        for (int64_t i = 0; i < n; i++) Z[(size_t)j * n + i] = X[(size_t)j * n + i] * sqrt(w[i]);
+    double d;
+    if (!wide) {
+        xtx_full(Z, n, p, o->ncores < 1 ? 1 : o->ncores, 1, XX);
+        for (size_t k = 0; k < (size_t)p * p; k++) XX[k] /= (double)n;
+        d = (o->d_override > 0) ? o->d_override : orc_eig_max(XX, p) * 1.005;
+    } else if (o->d_override > 0) d = o->d_override;
+    else {
+        double *G = (double *)malloc(sizeof(double) * (size_t)n * n);
+        if (!G) return fail("oracle: out of memory");
+        xxt_over_n(Z, n, p, G);
+        d = orc_eig_max(G, (int32_t)n) * 1.005;
+        free(G);
+    }
+    *d_out = d;
+    double lmax = 0.0;
+    for (int j = 0; j < p; j++) if (fabs(XY[j]) > lmax) lmax = fabs(XY[j]);
+    lmax *= scaley;
+    lambda_grid(o, lmax, lam);
+    for (size_t k = 0; k < (size_t)o->npen * nl; k++) { lambda_out[k] = lam[k]; loss[k] = 1e99; niter[k] = 0; lams[k] = lam[k] / scaley; }
+    int rc;
+    if (!wide) rc = path_run(XX, XY, p, d, o, lams, nl, NULL, bstd, niter, NULL, NULL, 0);
+    else {
+        /* next_u = X'((Y - X beta) w^2)/n + d beta = (wX)'(wY - (wX) beta)/n + d beta: the unweighted form on the w-scaled data */
+        for (int j = 0; j < p; j++)
+            for (int64_t i = 0; i < n; i++) Z[(size_t)j * n + i] = X[(size_t)j * n + i] * w[i];
+        rc = path_run(NULL, XY, p, d, o, lams, nl, NULL, bstd, niter, Z, Yw, n);
+    }
+    if (rc == 0) {
+        for (int pp = 0; pp < o->npen; pp++) {
+            int nlam = (o->penalty[pp] == ORC_OLS) ? 1 : nl;
+            for (int i = 0; i < nl; i++) {
+                double *out = beta + ((size_t)pp * nl + i) * (p + 1);
+                if (i >= nlam) { for (int j = 0; j <= p; j++) out[j] = 0.0; continue; }
+                const double *b = bstd + ((size_t)pp * nl + i) * p;
+                if (o->compute_loss) {
+                    double l = 0.0;
+                    memcpy(tmp, Y, sizeof(double) * (size_t)n);
+                    for (int j = 0; j < p; j++) {
+                        if (b[j] == 0.0) continue;
+                        const double *c = X + (size_t)j * n;
+                        for (int64_t k = 0; k < n; k++) tmp[k] -= c[k] * b[j];
+                    }
+                    for (int64_t k = 0; k < n; k++) l += tmp[k] * tmp[k] * w[k];
+                    loss[(size_t)pp * nl + i] = l;
+                }
+                memcpy(out + 1, b, sizeof(double) * (size_t)p);
+                recover(flag, p, out + 1, out, meanx, scalex, meany, scaley);
+            }
+        }
+    }
+    free(X); free(Z); free(Y); free(meanx); free(XX); free(XY); free(lam); free(lams); free(bstd);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ */
 int orc_fit_xtx(const double *xtx, const double *xty, int32_t p, const double *scale_factor,
                 const orc_opts *o,
                 double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out)

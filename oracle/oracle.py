@@ -165,6 +165,16 @@ def fit_dense(x, y, penalty="elastic.net", standardize=True, intercept=True, nat
                  C.c_int32(int(standardize)), C.c_int32(int(intercept)), native=native)
 
 
+def fit_dense_w(x, y, weights, penalty="elastic.net", standardize=True, intercept=True, native=False, **kw):
+    """oemDense with observation weights as the C++ entry computes it (unreachable from R/oem.R:244; parity unpinned)."""
+    x = np.asfortranarray(x, dtype=np.float64); y = _d(y); w = _d(weights)
+    n, p = x.shape
+    o = _Opts(p, penalty, **kw)
+    L = lib(native)
+    return _call(L.orc_fit_dense_w, o, p + 1, _ptr(x), C.c_int64(n), C.c_int32(p), _ptr(y), _ptr(w),
+                 C.c_int32(int(standardize)), C.c_int32(int(intercept)), native=native)
+
+
 def fit_xtx(xtx, xty, penalty="elastic.net", scale_factor=None, native=False, **kw):
     xtx = np.asfortranarray(xtx, dtype=np.float64); xty = _d(xty)
     p = xtx.shape[0]

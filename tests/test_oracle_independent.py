@@ -336,3 +336,61 @@ def test_big_and_sparse_wide_branch_without_an_intercept(standardize):
         assert np.array_equal(spf["beta"][k], big["beta"][k]) and np.array_equal(spf["niter"][k], big["niter"][k])
     with pytest.raises(Exception):
         orc.fit_big(x, y, standardize=standardize, intercept=True, **kw)       # ill-formed in the reference: nothing to restate
+
+
+# ------------------------------------------------------------------ observation weights of oemDense (unreachable from R; parity unpinned)
+def _weighted_datastd(x, y, w, std, icpt):
+    """DataStd::standardize(X, Y, wts) in numpy, from the reference lines themselves (src/DataStd.h:94-202)"""
+    n = x.shape[0]
+    sw = np.sqrt(w)
+    flag = int(std) + 2 * int(icpt)
+    xs, ys = x.copy(), y.copy()
+    my, sy = 0.0, 1.0
+    mx, sx = np.zeros(x.shape[1]), np.ones(x.shape[1])
+    if flag == 1:
+        v = ys * sw; sy = np.sqrt(np.mean((v - v.mean()) ** 2)); ys = ys / sy
+        v = xs * sw[:, None]; sx = np.sqrt(np.mean((v - v.mean(0)) ** 2, axis=0)); xs = xs / sx
+    elif flag >= 2:
+        my = np.mean(ys * sw); ys = ys - my; sy = np.linalg.norm(ys * sw) / np.sqrt(n); ys = ys / sy
+        if flag == 2:
+            mx = np.mean(xs * sw[:, None], axis=0); xs = xs - mx
+        else:
+            mx = xs.mean(0); xs = xs - mx; sx = np.linalg.norm(xs, axis=0) / np.sqrt(n); xs = xs / sx
+    return xs, ys, mx, sx, my, sy, flag
+
+
+@pytest.mark.parametrize("std,icpt", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("wide", [False, True])
+def test_observation_weights_branch_against_numpy_and_kkt(std, icpt, wide):
+    """oemDense with a weights vector as `.Call("oem_fit_dense")` computes it (ref src/oem_dense.h:368-414, 466-483, 513-517, 699-707,
+    759-770; src/DataStd.h:94-202).  No number of the reference exists for it (R/oem.R:244 stops first): the oracle's restatement is
+    held against the same lines written in numpy -- d, lambda_zero, the stationarity of every solution in the standardised
+    coordinates (for nobs <= nvars with the weights SQUARED, as the reference iterates there), recover() and the weighted loss."""
+    rng = np.random.default_rng(5 + 2 * std + icpt)
+    n, p = (40, 70) if wide else (300, 18)
+    x = np.asfortranarray(rng.normal(size=(n, p)) * rng.uniform(0.5, 2.0, p) + 0.4)
+    b = np.zeros(p); b[:5] = [1.0, -0.8, 0.6, 0.0, 1.2]
+    y = x @ b + rng.normal(size=n) + 0.3
+    w = rng.uniform(0.2, 2.5, n)
+    f = orc.fit_dense_w(x, y, w, penalty=["lasso", "mcp"], nlambda=5, lambda_min_ratio=0.05, gamma=3.0, standardize=std, intercept=icpt,
+                        compute_loss=True, **TIGHT)
+    xs, ys, mx, sx, my, sy, flag = _weighted_datastd(x, y, w, std, icpt)
+    z1 = xs * np.sqrt(w)[:, None]
+    xy = xs.T @ (ys * w) / n
+    dref = 1.005 * np.linalg.norm(z1, 2) ** 2 / n
+    assert abs(f["d"] - dref) < 1e-9 * dref
+    assert abs(f["lambda"][0][0] - np.abs(xy).max() * sy) < 1e-12 * np.abs(xy).max() * sy
+    wk = w ** 2 if wide else w                                    # what the iteration's gradient carries
+    for k, (dpen) in enumerate((lambda t, l: l, lambda t, l: _dmcp(t, l, 3.0))):
+        for i in range(5):
+            out = f["beta"][k][:, i]
+            coef = out[1:]
+            bstd = coef * (sx if flag in (1, 3) else 1.0) / (sy if flag else 1.0)
+            lam = f["lambda"][k][i] / sy
+            g = -(xs.T @ (wk * (ys - xs @ bstd)) / n)
+            assert _kkt_elementwise(g, bstd, np.full(p, lam), dpen, 0.0) < 2e-8, (k, i)
+            assert abs(out[0] - ((my - coef @ mx) if flag >= 2 else 0.0)) < 1e-9
+            assert abs(f["loss"][k][i] - np.sum(w * (ys - xs @ bstd) ** 2)) < 1e-8 * (1 + f["loss"][k][i])
+    one = orc.fit_dense_w(x, y, np.ones(n), penalty=["lasso"], nlambda=5, lambda_min_ratio=0.05, standardize=std, intercept=icpt, **TIGHT)
+    ref = orc.fit_dense(x, y, penalty=["lasso"], nlambda=5, lambda_min_ratio=0.05, standardize=std, intercept=icpt, **TIGHT)
+    assert np.array_equal(one["beta"][0], ref["beta"][0]) and one["d"] == ref["d"]          # unit weights: the unweighted branch, bit for bit
