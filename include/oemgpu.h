@@ -115,7 +115,8 @@ int oemgpu_fit_big(const double *const *x_shards, const int64_t *n_shard, int32_
 /* oem_fit_dense with a non-empty `weights_` (ref src/oem_dense.cpp:34,75,152,162; src/oem_dense.h:368-414, 699-707, 759-770;
  * src/DataStd.h:94-202): the R front end never sends one ("weights not implemented yet", R/oem.R:244), the compiled entry takes it.
  * Computed as the reference computes it (sqrt(w)-weighted DataStd statistics -- unweighted for x under flag 3 --, X'WX / n, X'(Yw) / n,
- * loss = sum w r^2).  nobs > nvars; with nobs <= nvars: OEMGPU_ERR_UNSUPPORTED.  weights: n values, finite, >= 0. */
+ * loss = sum w r^2; with nobs <= nvars d from (sqrt(w) X)(sqrt(w) X)'/n but the iteration X'((Y - X beta) w^2)/n + d beta, w SQUARED, as
+ * src/oem_dense.h:513-517 has it -- there through the p x p Gram forms on the launch-per-iteration engine).  weights: n values, finite, >= 0. */
 int oemgpu_fit_dense_weighted(const double *x, int64_t n, int32_t p, const double *y, const double *weights,
                               int32_t standardize, int32_t intercept, const oemgpu_opts *opts,
                               double *beta, double *lambda_out, int32_t *niter, double *loss, double *d);

@@ -261,11 +261,17 @@ enum { SEM_XTX = 2, SEM_SPARSE = 4 };        // OEMGPU_SEM_XVAL = 3 (oemgpu.h): 
 
 // nbatch > 1: that many independent problems (instance b at xx + b * bstride, ... ; outputs of instance b at beta + b * npen * nl *
 // rows, lambda_out / niter / loss + b * npen * nl, d_out[b]) solved by ONE launch, one workgroup (set) each; q <= SMALL_P_MAX only.
+// Weighted oemDense with nobs <= nvars (weighted.hip): d comes from one matrix, the iteration runs on another and the loss belongs to
+// the first again -- d handed over (launch-per-iteration Gram engine only), the loss as a pass of its own over (loss_xx, loss_xy, loss_stats).
+struct PathExtras { double d_fixed = 0.0; const double *loss_xx = nullptr, *loss_xy = nullptr, *loss_stats = nullptr; };
+
 int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const double *stats, int p, int q, int sem,
               int standardize, int intercept, const oemgpu_opts *o, const double *scale_factor,
               double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out,
-              int nbatch = 1, size_t bstride = 0, bool shared_lmax = false, const WideArgs *wide = nullptr, const double *lmax_xy_dev = nullptr)
+              int nbatch = 1, size_t bstride = 0, bool shared_lmax = false, const WideArgs *wide = nullptr, const double *lmax_xy_dev = nullptr,
+              const PathExtras *ex = nullptr)
 {
+    const bool launches_only = ex && ex->d_fixed > 0.0;
     const int nl = nl_of(o), npen = o->npen;
     const bool user = o->lambda_user && o->nlambda_user > 0;
     bool any_grp = false;
@@ -354,7 +360,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     static thread_local int symplan_q = 0, symplan_gmax = 0;
     SymcoopPlan *symplan_p = &symplan_plain;
     bool symc = false;
-    if (!wide && nbatch == 1 && q > 1024 && q <= 4096 && !scale_factor && !getenv("OEM_NO_SYMCOOP") && !getenv("OEM_NO_COOP")) {
+    if (!wide && !launches_only && nbatch == 1 && q > 1024 && q <= 4096 && !scale_factor && !getenv("OEM_NO_SYMCOOP") && !getenv("OEM_NO_COOP")) {
         const int gmax = c->num_cu * 3 / 4 < WCOOP_GMAX ? c->num_cu * 3 / 4 : WCOOP_GMAX;
         if (any_grp) {
             // group operators: every group must be a run of neighbouring coordinates (<= 32 of them) -- the owners' slices are cut there
@@ -398,9 +404,9 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const bool loss_on = (sem == OEMGPU_SEM_DENSE || sem == OEMGPU_SEM_XVAL || sem == SEM_SPARSE) && o->compute_loss != 0;
     // several instances (xval.oem's K + 1 fits) on the cooperating engine: only if all their workgroup sets are resident at once
     // wide != nullptr: the p >= n iteration through the standardised X itself (xx == nullptr: there is no Gram matrix)
-    const bool coop = !wide && path_coop_eligible(q, scale_factor != nullptr, loss_on && !(scale_factor && nbatch == 1), og.ngroups, nbatch) &&
+    const bool coop = !wide && !launches_only && path_coop_eligible(q, scale_factor != nullptr, loss_on && !(scale_factor && nbatch == 1), og.ngroups, nbatch) &&
                       (nbatch == 1 || path_coop_workgroups(q) * nbatch <= c->num_cu * 3 / 4);
-    const bool small = !wide && q <= SMALL_P_MAX && !coop;
+    const bool small = !wide && !launches_only && q <= SMALL_P_MAX && !coop;
     if (nbatch > 1 && !small && !coop) { set_error("internal: batched paths need p <= %d", SMALL_P_MAX); return OEMGPU_ERR_INTERNAL; }
     // Lanczos step cap: q up to 288 (the whole Krylov space: the recurrence stops by itself when the top Ritz value has settled, and
     // a spectrum that needs more than 128 steps gets them -- ADVICE r1); the large-p engines keep their own caps (256 / 512)
@@ -458,8 +464,10 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     a.compute_loss = (sem == OEMGPU_SEM_DENSE || sem == OEMGPU_SEM_XVAL || sem == SEM_SPARSE) ? (o->compute_loss != 0) : 0;
     // oemSparse with an intercept beyond the single-workgroup kernels: the engines rescale the member in place before the product their
     // loss would come from, so the loss is a pass of its own behind them (sparse.hip: gram_loss_kernel)
-    const bool loss_post = loss_on && scale_factor && !small && !wide && nbatch == 1;
+    const bool loss_ext = loss_on && ex && ex->loss_xx;                // (weighted oemDense, nobs <= nvars: the loss of ANOTHER Gram, see PathExtras)
+    const bool loss_post = loss_ext || (loss_on && scale_factor && !small && !wide && nbatch == 1);
     if (loss_post) a.compute_loss = 0;
+    a.d_fixed = launches_only ? ex->d_fixed : 0.0;
     a.ngroups = og.ngroups; a.lanczos_steps = lan; a.yscale = (sem == OEMGPU_SEM_DENSE);
     a.lmax_from = (sem == OEMGPU_SEM_XVAL || sem == SEM_SPARSE) ? off : 0;              // ref src/oem_xval_dense.h:1025-1032
     a.alpha = o->alpha; a.gamma = o->gamma; a.tau = o->tau; a.tol = o->tol; a.lambda_min_ratio = o->lambda_min_ratio;
@@ -545,7 +553,8 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
                 rc = run_path_large(c->stream, al, (double *)c->pinned);
             }
             if (rc) return rc;
-            if (loss_post && (rc = launch_gram_loss(c->stream, xx, xy, stats, q, a.beta, a.sinv, a.niter, a.loss, (int)nk))) return rc;
+            if (loss_post && (rc = launch_gram_loss(c->stream, loss_ext ? ex->loss_xx : xx, loss_ext ? ex->loss_xy : xy, loss_ext ? ex->loss_stats : stats, q,
+                                                    a.beta, a.sinv, a.niter, a.loss, (int)nk))) return rc;
         }
         HT(2);
         if (!zero_copy) {
@@ -816,7 +825,8 @@ int oemgpu_moments_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld
 // grid (scaleY) and for recover(), which run under the caller's flags.
 static int solve_moments_impl(oemgpu_ctx *c, const double *moments_dev, const double *sums_dev, int32_t p,
                               int32_t semantics, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
-                              double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, const double *wpatch);
+                              double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, const double *wpatch,
+                              const PathExtras *ex = nullptr, const double *lmax_xy = nullptr, size_t extra_ws = 0);
 
 int oemgpu_solve_moments_dev(oemgpu_ctx *c, const double *moments_dev, const double *sums_dev, int32_t p,
                              int32_t semantics, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
@@ -827,7 +837,8 @@ int oemgpu_solve_moments_dev(oemgpu_ctx *c, const double *moments_dev, const dou
 
 static int solve_moments_impl(oemgpu_ctx *c, const double *moments_dev, const double *sums_dev, int32_t p,
                               int32_t semantics, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
-                              double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, const double *wpatch)
+                              double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, const double *wpatch,
+                              const PathExtras *ex, const double *lmax_xy, size_t extra_ws)
 {
     if (!c || !moments_dev || !beta || !lambda_out || !niter || !loss || !d) { set_error("solve_moments: NULL argument"); return OEMGPU_ERR_ARG; }
     if (semantics != OEMGPU_SEM_DENSE && semantics != OEMGPU_SEM_BIG && semantics != OEMGPU_SEM_XVAL) { set_error("unknown semantics %d", semantics); return OEMGPU_ERR_ARG; }
@@ -850,7 +861,7 @@ static int solve_moments_impl(oemgpu_ctx *c, const double *moments_dev, const do
         if (e > base) base = e;
     }
     base = (base + 255) / 256 * 256;
-    const size_t need = base + B.off + paths_ws_bytes(p, q, o) + 4096;
+    const size_t need = base + B.off + paths_ws_bytes(p, q, o) + extra_ws + 4096;
     if (need > c->ws_bytes) {
         if (base != 0) { set_error("internal: workspace frame too small"); return OEMGPU_ERR_INTERNAL; }
         if (ctx_reserve(c, need)) return OEMGPU_ERR_HIP;
@@ -863,7 +874,8 @@ static int solve_moments_impl(oemgpu_ctx *c, const double *moments_dev, const do
         if (!rc && wpatch) rc = launch_weighted_patch_stats(c->stream, wpatch, p, st);
         if (rc) return rc;
     }
-    return run_paths(c, B2, xx, xy, st, p, q, semantics, standardize, intercept, o, nullptr, beta, lambda_out, niter, loss, d);
+    return run_paths(c, B2, xx, xy, st, p, q, semantics, standardize, intercept, o, nullptr, beta, lambda_out, niter, loss, d,
+                     1, 0, false, nullptr, lmax_xy, ex);
 }
 
 // p >= n.  The reference switches to its two-GEMV iteration when nobs <= nvars (ref src/oem_dense.h:476-482); here that form is
@@ -1042,16 +1054,16 @@ static int fit_dense_weighted_impl(oemgpu_ctx *c, const double *x_dev, int64_t n
     int rc = check_opts(o, p, p);
     if (rc) return rc;
     if (n < 1 || ld < n) { set_error("fit_dense_weighted: bad n / ld"); return OEMGPU_ERR_ARG; }
-    if (n <= p) {
-        set_error("observation weights with nobs <= nvars are not built (the reference iterates with w squared there, src/oem_dense.h:513-517)");
-        return OEMGPU_ERR_UNSUPPORTED;
-    }
+    const bool wide = n <= p;                             // the XWXt branch (ref src/oem_dense.h:466-471, 513-517)
     if (set_device(c)) return OEMGPU_ERR_HIP;
     const int flag = (standardize ? 1 : 0) + 2 * (intercept ? 1 : 0);
     const int64_t ldz = (n + 63) / 64 * 64;
     Bump Z;
     const size_t a_z = Z.take(sizeof(double) * (size_t)ldz * p), a_yz = Z.take(sizeof(double) * (size_t)ldz), a_ws = Z.take(sizeof(double) * (size_t)(2 + 2 * p)),
                  a_w = Z.take(sizeof(double) * (size_t)n);
+    // nobs <= nvars: the first pass's X'WX / n, X'(Yw) / n and constants are kept -- d, lambda_zero and the loss belong to them
+    const size_t a_xx1 = wide ? Z.take(sizeof(double) * (size_t)p * p) : 0, a_xy1 = wide ? Z.take(sizeof(double) * (size_t)p) : 0,
+                 a_st1 = wide ? Z.take(sizeof(double) * (size_t)stats_len(p)) : 0;
     if (ctx_grow(c, &c->aux, &c->aux_bytes, Z.off)) return OEMGPU_ERR_HIP;
     double *z = (double *)(c->aux + a_z), *yz = (double *)(c->aux + a_yz), *wsd = (double *)(c->aux + a_ws);
     if (w_host) {
@@ -1066,7 +1078,8 @@ static int fit_dense_weighted_impl(oemgpu_ctx *c, const double *x_dev, int64_t n
     const size_t frame = B.off;
     const size_t a_t = B.take(pl.tpart_doubles * 8), a_v = B.take(pl.vpart_doubles * 8);
     size_t need = B.off;
-    const size_t need2 = frame + ((size_t)p * p + p + stats_len(p)) * 8 + 1024 + paths_ws_bytes(p, p, o) + 4096;
+    const size_t large_ws = wide ? path_large_work_doubles(p, 128) * 8 + 4096 : 0;      // (the launch-per-iteration engine at any p)
+    const size_t need2 = frame + ((size_t)p * p + p + stats_len(p)) * 8 + 1024 + paths_ws_bytes(p, p, o) + large_ws + 4096;
     if (need2 > need) need = need2;
     if (ctx_reserve(c, need)) return OEMGPU_ERR_HIP;
     double *mom = (double *)(c->ws + a_mom);
@@ -1077,7 +1090,27 @@ static int fit_dense_weighted_impl(oemgpu_ctx *c, const double *x_dev, int64_t n
         if (!rc) rc = shard_moments(c, pl, z, n, ldz, yz, nullptr, (double *)(c->ws + a_t), (double *)(c->ws + a_v), mom);
         if (rc) return rc;
     }
-    return solve_moments_impl(c, mom, nullptr, p, OEMGPU_SEM_DENSE, standardize, intercept, o, beta, lambda_out, niter, loss, d, wsd);
+    if (!wide) return solve_moments_impl(c, mom, nullptr, p, OEMGPU_SEM_DENSE, standardize, intercept, o, beta, lambda_out, niter, loss, d, wsd);
+    // ---- nobs <= nvars.  The reference takes d from (sqrt(w) Xs)(sqrt(w) Xs)'/n -- the non-zero spectrum of the Z'Z / n just formed --
+    // and lambda_zero from XY = Xs'(Ys w)/n, but iterates u = Xs'((Ys - Xs beta) w^2)/n + d beta: the Gram form on Z2 = diag(w) Xs.
+    double *xx1 = (double *)(c->aux + a_xx1), *xy1 = (double *)(c->aux + a_xy1), *st1 = (double *)(c->aux + a_st1);
+    rc = launch_finalize(c->stream, mom, nullptr, p, OEMGPU_SEM_DENSE, 0, 0, xx1, xy1, st1);
+    if (!rc) rc = launch_weighted_patch_stats(c->stream, wsd, p, st1);
+    double lam1 = 0.0;
+    if (!rc) rc = oemgpu_eig_max_dev(c, xx1, p, &lam1);              // (uses the workspace from its start: nothing of this call lives there now)
+    if (rc) return rc;
+    if (ctx_reserve(c, need)) return OEMGPU_ERR_HIP;
+    mom = (double *)(c->ws + a_mom);
+    {
+        Timer t(c, OEMGPU_T_MOMENTS);
+        rc = launch_weighted_apply(c->stream, x_dev, n, ld, p, y_dev, w_dev, flag, wsd, 1, z, ldz, yz);
+        if (!rc) rc = shard_moments(c, pl, z, n, ldz, yz, nullptr, (double *)(c->ws + a_t), (double *)(c->ws + a_v), mom);
+        if (rc) return rc;
+    }
+    PathExtras ex;
+    ex.d_fixed = lam1 * 1.005;                                        // ref src/oem_dense.h:498
+    ex.loss_xx = xx1; ex.loss_xy = xy1; ex.loss_stats = st1;          // get_loss = sum w (Ys - Xs beta)^2 (ref :759-770): the FIRST Gram's identity
+    return solve_moments_impl(c, mom, nullptr, p, OEMGPU_SEM_DENSE, standardize, intercept, o, beta, lambda_out, niter, loss, d, wsd, &ex, xy1, large_ws);
 }
 
 int oemgpu_fit_dense_weighted_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev, const double *w_dev,

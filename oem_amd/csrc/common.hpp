@@ -131,6 +131,8 @@ struct PathArgs {
     // ever stores to them), and the kernel leaves a copy of `stats` here as well -- no device-to-host copy node behind the kernel
     double *stats_out;
     int stats_n;             // doubles of stats to copy
+    double d_fixed;          // > 0 (launch-per-iteration Gram engine only): d handed over, no eigenvalue step (weighted oemDense with nobs <= nvars:
+                             // the reference takes d from one matrix and iterates on another, ref src/oem_dense.h:466-483, 513-517)
 };
 
 // the problem instance of this workgroup (see PathArgs::nbatch); all scalar arithmetic

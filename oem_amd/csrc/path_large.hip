@@ -1149,12 +1149,14 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     int lblocks = (q + 3) / 4;
     if (lblocks > num_cu * 2) lblocks = num_cu * 2;
     const size_t lsh = sizeof(double) * (size_t)(q + 8);
-    if (lz_fused) {
+    const bool d_given = a.d_fixed > 0.0;                // (the caller's d: no recurrence)
+    if (d_given) { theta = a.d_fixed / 1.005; lz_capped = false; }
+    else if (lz_fused) {
         hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, s, q, Vc, Vp);
         int rc = launch_gemv(s, a.xx, q, Vc, Wb, nullptr, num_cu);           // w_0 = M v_0; every later product is fused
         if (rc) return rc;
     } else hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, s, q, v, vp);
-    while (m < mmax) {
+    while (m < mmax && !d_given) {
         const int chunk = (mmax - m) < 16 ? (mmax - m) : 16;     // a host look costs about one step
         for (int k = 0; k < chunk; ++k, ++m) {
             if (lz_fused) hipLaunchKernelGGL(lzk, dim3(lblocks), dim3(256), lsh, s, a.xx, q, m, Vc, Vp, Wb, T, m & 1);
@@ -1187,7 +1189,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         theta_prev = theta;
     }
     if (mmax >= q) lz_capped = false;                   // the whole Krylov space
-    const double d = theta * 1.005;                     // ref src/oem_dense.h:498
+    const double d = d_given ? a.d_fixed : theta * 1.005;     // ref src/oem_dense.h:498
 
     hipLaunchKernelGGL(path_init_kernel, dim3(1), dim3(1024), 0, s, a, st, beta, d, theta, m, lz_capped ? 1 : 0);
     OEM_HIP(hipGetLastError());

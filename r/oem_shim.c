@@ -136,7 +136,8 @@ SEXP oem_fit_dense(SEXP x_, SEXP y_, SEXP family_, SEXP penalty_, SEXP weights_,
 {
     if (strcmp(CHAR(STRING_ELT(family_, 0)), "gaussian") != 0)
         Rf_error("binomial not available for oem_fit_dense, use oem_fit_logistic_dense");     /* ref src/oem_dense.cpp:168 */
-    if (XLENGTH(weights_) > 0) Rf_error("weights not implemented yet.");
+    /* a non-empty weights_ (R's oem() never sends one: R/oem.R:244) takes the weighted entry, as the reference's compiled code does
+     * (ref src/oem_dense.cpp:75,152,162) */
     SEXP dim = Rf_getAttrib(x_, R_DimSymbol);
     const int64_t n = INTEGER(dim)[0];
     const int p = INTEGER(dim)[1];
@@ -149,8 +150,12 @@ SEXP oem_fit_dense(SEXP x_, SEXP y_, SEXP family_, SEXP penalty_, SEXP weights_,
     double *loss = (double *)R_alloc(nk, sizeof(double)), d = 0.0;
     int32_t *niter = (int32_t *)R_alloc(nk, sizeof(int32_t));
     /* x and y are read-only for the library: no copy (the reference copies, ref src/oem_dense.cpp:61-67) */
-    const int rc = oemgpu_fit_dense(REAL(x_), n, p, REAL(y_), Rf_asLogical(standardize_), Rf_asLogical(intercept_), &o,
-                                    beta, lam, niter, loss, &d);
+    if (XLENGTH(weights_) > 0 && XLENGTH(weights_) != n) Rf_error("length of weights not same as number of observations in x");
+    const int rc = XLENGTH(weights_) > 0
+        ? oemgpu_fit_dense_weighted(REAL(x_), n, p, REAL(y_), REAL(weights_), Rf_asLogical(standardize_), Rf_asLogical(intercept_), &o,
+                                    beta, lam, niter, loss, &d)
+        : oemgpu_fit_dense(REAL(x_), n, p, REAL(y_), Rf_asLogical(standardize_), Rf_asLogical(intercept_), &o,
+                           beta, lam, niter, loss, &d);
     if (rc != 0) raise(rc);
     return pack(&o, p + 1, nl, beta, lam, niter, loss, d);
 }

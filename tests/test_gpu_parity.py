@@ -1089,29 +1089,35 @@ def test_wide_engine_resident_in_the_accumulator_file(oa, n, p, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,p", [(3000, 40), (2500, 300), (3000, 1100)])
+@pytest.mark.parametrize("n,p", [(3000, 40), (2500, 300), (3000, 1100), (40, 70), (150, 400), (300, 1100)])
 @pytest.mark.parametrize("std,icpt", [(False, False), (True, False), (False, True), (True, True)])
 def test_observation_weights_of_the_compiled_entry(oa, n, p, std, icpt):
     """oem_fit_dense with a non-empty weights vector (ref src/oem_dense.h:368-414, 699-707, 759-770,
     src/DataStd.h:94-202): R's oem() -- and oem() here -- stop with "weights not implemented yet" (R/oem.R:244); the compiled entry
     computes sqrt(w)-weighted DataStd statistics (unweighted for x under both flags), X'WX / n, X'(Yw) / n and loss = sum w r^2.  Here
     (weighted.hip): the statistics, the standardised sqrt(w)-scaled copy, the ordinary MFMA moment pass over it, the path engines
-    of every size class -- against the oracle's restatement (held against numpy and the KKT conditions in
-    tests/test_oracle_independent.py; no reference-held number exists), from host and from device memory."""
+    of every size class -- and for nobs <= nvars d from that Gram, the iteration on the Gram of the w-scaled copy (the reference squares
+    the weights there, src/oem_dense.h:513-517), the loss from the first again -- against the oracle's restatement (held against numpy
+    and the KKT conditions in tests/test_oracle_independent.py; no reference-held number exists), from host and from device memory."""
     import torch
     rng = np.random.default_rng(n + p + 2 * std + icpt)
     x = np.asfortranarray(rng.normal(size=(n, p)) * rng.uniform(0.5, 2.5, p) + rng.uniform(-1, 1, p))
     b = np.zeros(p); b[:6] = rng.uniform(0.5, 1.5, 6)
     y = x @ b + rng.normal(size=n) + 0.6
     w = rng.uniform(0.1, 3.0, n); w[rng.integers(n, size=5)] = 0.0           # (a few rows out)
+    if n <= p:
+        w = w / 3.0       # nobs <= nvars: d bounds X'WX / n but the reference iterates on X'W^2 X / n -- with weights above 1 ITS iteration
+                          # diverges at the small lambdas (1e21 in the oracle, inf here); weights <= 1 keep W^2 below W
     groups = np.arange(p) // 4 + 1
     kw = dict(penalty=["lasso", "mcp", "grp.lasso", "ols"], groups=groups, nlambda=5, lambda_min_ratio=0.02, tol=1e-9, maxit=2000,
               standardize=std, intercept=icpt, compute_loss=True)
     with pytest.raises(ValueError, match="weights not implemented yet"):
         oa.oem(x, y, weights=w, penalty="lasso")
-    f = oa.oem_fit_dense_weighted(x, y, w, **kw)
-    xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
-    fd = oa.oem_fit_dense_weighted(xd, y, w, **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f = oa.oem_fit_dense_weighted(x, y, w, **kw)
+        xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+        fd = oa.oem_fit_dense_weighted(xd, y, w, **kw)
     r = orc.fit_dense_w(x, y, w, native=True, unique_groups=np.unique(groups), **kw)
     assert abs(f["d"] - r["d"]) < DTOL * r["d"]
     for k in range(4):
@@ -1122,8 +1128,10 @@ def test_observation_weights_of_the_compiled_entry(oa, n, p, std, icpt):
         assert np.allclose(np.ravel(f["loss"][k]), np.ravel(r["loss"][k]), rtol=1e-8)
         assert np.abs(np.asarray(f["beta"][k]) - np.asarray(fd["beta"][k])).max() < 1e-10 * sc
     # unit weights: the unweighted fit (another route to the same moments: agreement to rounding)
-    one = oa.oem_fit_dense_weighted(x, y, np.ones(n), penalty="lasso", nlambda=5, tol=1e-9, standardize=std, intercept=icpt)
-    ref = oa.oem(x, y, penalty="lasso", nlambda=5, tol=1e-9, standardize=std, intercept=icpt)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        one = oa.oem_fit_dense_weighted(x, y, np.ones(n), penalty="lasso", nlambda=5, tol=1e-9, standardize=std, intercept=icpt)
+        ref = oa.oem(x, y, penalty="lasso", nlambda=5, tol=1e-9, standardize=std, intercept=icpt)
     assert np.abs(np.asarray(one["beta"][0]) - np.asarray(ref["beta"][0])).max() < 1e-9 * max(1.0, float(np.abs(ref["beta"][0]).max()))
     with pytest.raises(ValueError, match="length of weights"):
         oa.oem_fit_dense_weighted(x, y, w[:-1], penalty="lasso")
