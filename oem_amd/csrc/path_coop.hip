@@ -26,6 +26,9 @@
 #include "penalty_ops.hpp"
 #include "path_dev.hpp"
 
+#ifndef OEM_XCHG_SLEEP
+#define OEM_XCHG_SLEEP 12         // s_sleep units (64 cycles) before the first poll sweep of the gather (tools/coop_sleep_ab.sh: config 3 path 2.23 -> 2.17 ms, p = 1024 3.99 -> 3.75)
+#endif
 namespace oemgpu {
 
 namespace {
@@ -166,6 +169,7 @@ __device__ __forceinline__ void coop_round(const double (&a)[CG], const int (&bi
         pv[k] = coop_v4u{0u, 0u, 0u, 0u};
     }
     const unsigned need = miss;
+    if (OEM_XCHG_SLEEP > 0) __builtin_amdgcn_s_sleep(OEM_XCHG_SLEEP);      // (nothing of this epoch can have landed yet: path_wcoop.hip, wc_gather)
     unsigned spins = 0;
     const unsigned limit = X.failed ? 0u : 1000000u;            // ~1 s: a partner is gone; after one timeout nobody waits again
     bool ok = true;
