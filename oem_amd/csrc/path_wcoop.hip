@@ -43,6 +43,10 @@ namespace {
 #ifndef OEM_XCHG_SLEEP
 #define OEM_XCHG_SLEEP 12         // s_sleep units (64 cycles) before the first poll sweep of a gather (tools/xchg_sleep_ab.sh)
 #endif
+#ifndef OEM_XCHG_SLEEP2
+#define OEM_XCHG_SLEEP2 0         // ... and between sweeps: measured WORSE (tools/xchg_sleep2_ab.sh, us per iteration at s_sleep 0 / 1 / 3 / 6: 500 x 20,000
+                                  // 7.00 / 7.07 / 7.12 / 7.21, 500 x 2,000 3.84 / 3.96 / 4.07 / 4.22) -- once something can have landed, ask
+#endif
 constexpr int WNTH = 256;         // threads per workgroup: one wave per SIMD
 constexpr int WCML = 256;         // Lanczos steps kept
 
@@ -199,6 +203,9 @@ __device__ __forceinline__ void wc_gather(__amdgpu_buffer_rsrc_t rs, int off0, u
         for (int k = 0; k < E; ++k)
             if (((miss >> k) & 1u) && (pv[k].y >> 1) == X.epoch && (pv[k].w >> 1) == X.epoch) miss &= ~(1u << k);
         if (++spins >= limit && __any(miss != 0u)) { ok = false; break; }
+#if OEM_XCHG_SLEEP2 > 0
+        if (__any(miss != 0u)) __builtin_amdgcn_s_sleep(OEM_XCHG_SLEEP2);
+#endif
     }
     if (!ok) X.failed = true;
 #pragma unroll
