@@ -506,10 +506,21 @@ typedef struct {
     double *resid;         /* n */
 } core_t;
 
+/* ORC_THREADS=k: the two products of next_u on k OpenMP threads.  Columns (p >= n) and row slices (n > p) are dealt to the threads whole
+ * and every one of them is summed in the order of the single-thread loop, so the results are bit-identical -- it only shortens the GPU
+ * suite, whose wall clock is mostly this loop. */
+static int orc_threads(void)
+{
+    static int t = 0;
+    if (t == 0) { const char *e = getenv("ORC_THREADS"); t = e ? atoi(e) : 1; if (t < 1) t = 1; if (t > 64) t = 64; }
+    return t;
+}
+
 static int solve_one(core_t *s, int pen, double lambda, const orc_opts *o, const double *pf, const grp_t *g,
                      double *ak)
 {
     int p = s->p, i;
+    const int nth = orc_threads();
     for (i = 0; i < o->maxit; ++i) {
         memcpy(s->beta_prev, s->beta, sizeof(double) * (size_t)p);
         if (s->X) {
@@ -521,6 +532,7 @@ static int solve_one(core_t *s, int pen, double lambda, const orc_opts *o, const
                 const double *col = s->X + (size_t)c * s->n;
                 for (int64_t k = 0; k < s->n; k++) s->resid[k] -= col[k] * b;
             }
+            #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && (double)p * (double)s->n > 2e5)
             for (int c = 0; c < p; c++) {
                 const double *col = s->X + (size_t)c * s->n;
                 double t = 0.0;
@@ -529,14 +541,18 @@ static int solve_one(core_t *s, int pen, double lambda, const orc_opts *o, const
             }
         } else {
         /* next_u: u = A * beta_prev + XY  (ref: src/oem_dense.h:512) */
-        for (int r = 0; r < p; r++) s->u[r] = 0.0;
-        for (int c = 0; c < p; c++) {
-            double b = s->beta_prev[c];
-            if (b == 0.0) continue;               /* adds exact zeros otherwise */
-            const double *col = s->A + (size_t)c * p;
-            for (int r = 0; r < p; r++) s->u[r] += col[r] * b;
+        #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && (double)p * (double)p > 2e5)
+        for (int blk = 0; blk < nth; blk++) {
+            const int r0 = (int)((long long)p * blk / nth), r1 = (int)((long long)p * (blk + 1) / nth);
+            for (int r = r0; r < r1; r++) s->u[r] = 0.0;
+            for (int c = 0; c < p; c++) {
+                double b = s->beta_prev[c];
+                if (b == 0.0) continue;               /* adds exact zeros otherwise */
+                const double *col = s->A + (size_t)c * p;
+                for (int r = r0; r < r1; r++) s->u[r] += col[r] * b;
+            }
+            for (int r = r0; r < r1; r++) s->u[r] += s->XY[r];
         }
-        for (int r = 0; r < p; r++) s->u[r] += s->XY[r];
         }
         if (o->accelerate) memcpy(s->beta_last, s->beta, sizeof(double) * (size_t)p);
         next_beta(pen, s->beta, s->u, p, lambda, s->d, o->alpha, o->gamma, o->tau, pf, g, s->tmp);
