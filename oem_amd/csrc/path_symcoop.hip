@@ -758,23 +758,28 @@ constexpr int RE = RQ / SNTH;     // pairs per thread in the all-gather
 __device__ unsigned long long g_diag_rowcoop[16];
 #endif
 
+constexpr int RVG = 48;           // the first RVG of a lane's 128 matrix entries live in VGPRs (an accumulator value costs two v_accvgpr_read_b32
+                                  // per use: 8 of the 12 cycles of a column; the kernel has the registers for three groups of sixteen)
 template <int C> struct RowFma {
-    static __device__ __forceinline__ void run(double (&acc)[4], const double (&B)[8], unsigned nzmask)
+    static __device__ __forceinline__ void run(double (&acc)[4], const double (&B)[8], const double (&xv)[RVG], unsigned nzmask)
     {
         if constexpr (C < 128) {
             if constexpr ((C & 15) == 0) {
                 // sixteen columns at a time; a group whose vector entries are zero in every lane of the wave is skipped (wave-uniform)
-                if ((nzmask >> (C >> 4)) & 1u) RowFma16<C>(acc, B);
-                RowFma<C + 16>::run(acc, B, nzmask);
+                if ((nzmask >> (C >> 4)) & 1u) RowFma16<C>(acc, B, xv);
+                RowFma<C + 16>::run(acc, B, xv, nzmask);
             }
         }
     }
-    template <int C0> static __device__ __forceinline__ void RowFma16(double (&acc)[4], const double (&B)[8])
+    template <int C0> static __device__ __forceinline__ void RowFma16(double (&acc)[4], const double (&B)[8], const double (&xv)[RVG])
     {
         static_for_dev<16>([&](auto K_) {
             constexpr int c = C0 + decltype(K_)::value;
-            const double x = areg_rd<c>();
-            BcFma<(c & 15)>::fmac(acc[c & 3], B[c >> 4], x);
+            if constexpr (c < RVG) BcFma<(c & 15)>::fmac(acc[c & 3], B[c >> 4], xv[c]);
+            else {
+                const double x = areg_rd<c>();
+                BcFma<(c & 15)>::fmac(acc[c & 3], B[c >> 4], x);
+            }
         });
     }
 };
@@ -800,10 +805,12 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
     // ---- this lane's 128 matrix entries: row 16 wg + l16, columns 512 w + 128 grp + k
     const int row = 16 * wg + l16, cbase = 512 * w + 128 * grp;
     const bool rowok = row < q;
+    double xv[RVG];
     static_for_dev<128>([&](auto K_) {
         constexpr int k = decltype(K_)::value;
         const int col = cbase + k;
-        areg_wr<k>((rowok && col < q) ? A.xx[(size_t)col * q + row] : 0.0);
+        const double t = (rowok && col < q) ? A.xx[(size_t)col * q + row] : 0.0;
+        if constexpr (k < RVG) xv[k] = t; else areg_wr<k>(t);
     });
     int bidx[8];
 #pragma unroll
@@ -841,7 +848,7 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
         for (int j = 0; j < 8; ++j) nz |= (__ballot(B[j] != 0.0) != 0ull ? 1u : 0u) << j;
         dpp_hazard_fence(B);
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        RowFma<0>::run(acc, B, nz);
+        RowFma<0>::run(acc, B, xv, nz);
         const double s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         // the four row groups (column slices) of the wave: v_permlane16_swap, then v_permlane32_swap
         const double t = sx_swap_add<false>(s, s);
