@@ -822,7 +822,7 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
     const double xyc = own ? A.xy[row] : 0.0, pfc = own ? A.pf[row] : 0.0;
     SymX X;
     X.s1 = 0; X.s2 = RQ * 16; X.o2 = 0; X.o3 = 0; X.o4 = 0;
-    X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, 2 * RQ * 16, 0x00020000);
+    X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, 2 * RQ * 16 + 2 * (RQ / 16) * 16, 0x00020000);      // (+ compute.loss: the workgroups' parts, [2][RQ / 16] pairs)
     X.epoch = 0; X.wg = wg; X.G = G; X.failed = false;
 #ifdef OEM_PATH_DIAG
     for (int k = 0; k < 16; ++k) X.acc[k] = 0;
@@ -965,6 +965,7 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
     if (writer) for (int idx = tid; idx < npen * nl; idx += SNTH) A.lambda_out[idx] = lambda_of(idx / nl, idx % nl);
 
     // ---- the penalty x lambda path (ref src/oem_base.h:90-110): product, the operator on the owner lanes, ONE all-gather
+    unsigned lep = 0;                                            // compute.loss: the epoch of its own little exchange
     for (int pp = 0; pp < npen; ++pp) {
         const int pen = A.penalty[pp];
         const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
@@ -997,7 +998,27 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
             }
             const size_t kfin = (size_t)pp * nl + i;
             if (own) A.beta[kfin * q + row] = bc;
-            if (tid == 0 && writer) { A.niter[kfin] = conv ? it : maxit + 1; A.loss[kfin] = 1e99; }      // ref src/oem_base.h:94-109
+            if (tid == 0 && writer) { A.niter[kfin] = conv ? it : maxit + 1; if (!A.compute_loss) A.loss[kfin] = 1e99; }      // ref src/oem_base.h:94-109
+            if (A.compute_loss) {
+                // sum (Y - X beta)^2 = yy + n beta'(XX beta - 2 XY) (ref src/oem_dense.h:759-770): one more product, of the FINISHED iterate (Bsh holds
+                // it: the last all-gather), the workgroups' parts to workgroup 0 through pairs of their own -- once per lambda, nobody else waits
+                const double gfin = product();
+                const double lp = sx_block_sum(own ? bc * (gfin - 2.0 * xyc) : 0.0, red, rpar, w, lane);
+                ++lep;
+                const int lpar = (int)(lep & 1u), lbase = 2 * RQ * 16 + lpar * (RQ / 16) * 16;
+                if (tid == 0) sx_publish(X.rs, lbase + wg * 16, lp, lep << 1);
+                if (writer) {
+                    const unsigned keep = X.epoch;
+                    X.epoch = lep;                               // (sx_gather matches tags against X.epoch)
+                    int offl[1] = {lbase + (tid < G ? tid : 0) * 16};
+                    double vl[1];
+                    int fll = 0;
+                    sx_gather<1>(offl, tid < G ? 1u : 0u, vl, fll, X);
+                    X.epoch = keep;
+                    const double tl = sx_block_sum(vl[0], red, rpar, w, lane);      // thread t holds workgroup t's part: a fixed order
+                    if (tid == 0) A.loss[kfin] = A.stats[2] + A.stats[3] * tl;
+                }
+            }
         }
         if (tid == 0 && writer) for (int r = nlam; r < nl; ++r) { A.niter[(size_t)pp * nl + r] = 0; A.loss[(size_t)pp * nl + r] = 1e99; }
     }
@@ -1027,10 +1048,10 @@ bool path_rowcoop_eligible(const PathArgs &a, bool group_penalty)
 {
     if (getenv("OEM_NO_ROWCOOP") || getenv("OEM_NO_SYMCOOP") || getenv("OEM_NO_COOP")) return false;
     if (a.p <= 1024 || a.p > RQ || a.nbatch > 1 || a.pen_split) return false;
-    return !(a.sinv || group_penalty || a.accelerate || a.compute_loss);
+    return !(a.sinv || group_penalty || a.accelerate);
 }
 int path_rowcoop_workgroups(int q) { return (q + 15) / 16; }
-size_t path_rowcoop_xchg_bytes() { return (size_t)2 * RQ * 16 + 256; }
+size_t path_rowcoop_xchg_bytes() { return (size_t)2 * RQ * 16 + (size_t)2 * (RQ / 16) * 16 + 256; }
 int launch_path_rowcoop(hipStream_t s, const PathArgs &a, void *xchg)
 {
     OEM_HIP(hipMemsetAsync(xchg, 0, path_rowcoop_xchg_bytes(), s));            // the tags must start at 0

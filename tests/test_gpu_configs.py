@@ -461,6 +461,8 @@ def test_register_resident_engine_through_oem(oa, monkeypatch):
     x = np.asfortranarray(rng.normal(size=(n, p)) * (1.0 + rng.uniform(size=p)) + 0.3)
     b = np.zeros(p); b[rng.choice(p, 15, replace=False)] = rng.uniform(-1, 1, 15)
     y = x @ b + rng.normal(size=n) + 1.0
+    import torch
+    xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
     for std, icpt in ((True, True), (False, False)):
         kw = dict(penalty=["lasso", "scad"], nlambda=8, tol=1e-9, standardize=std, intercept=icpt)
         fit = oa.oem(x, y, **kw)
@@ -468,6 +470,19 @@ def test_register_resident_engine_through_oem(oa, monkeypatch):
         _cmp(fit, ref)
         for k in range(2):
             assert np.abs(np.ravel(fit["niter"][k]).astype(int) - np.ravel(ref["niter"][k]).astype(int)).max() <= 1
+        # compute.loss: on the row-split engine one more product of the finished iterate and the workgroups' parts to workgroup 0
+        # (round 4; until then these calls took the symmetric engine's general form -- still held here under OEM_NO_ROWCOOP=1)
+        ref = orc.fit_dense(x, y, native=True, compute_loss=True, **kw)
+        for knob, engine in ((None, "rowcoop"), ("OEM_NO_ROWCOOP", "symcoop")):
+            if knob:
+                monkeypatch.setenv(knob, "1")
+            fit = oa.oem(xd, y, compute_loss=True, **kw)
+            assert oa.last_path_engine()[0] == engine
+            if knob:
+                monkeypatch.delenv(knob)
+            _cmp(fit, ref)
+            for k in range(2):
+                assert np.allclose(np.ravel(fit["loss"][k]), np.ravel(ref["loss"][k]), rtol=1e-9), (engine, fit["loss"][k], ref["loss"][k])
 
 
 @pytest.mark.gpu
