@@ -907,6 +907,57 @@ static bool wide_pays(int64_t n, int32_t p, const oemgpu_opts *o)
     return wc;
 }
 
+// p >= n, several penalties, some of them group penalties: one group penalty sends the WHOLE call to the engines that know group
+// operators, and where the standardised X only fits the chip's registers WITH the accumulator file (path_wres_kernel: element-wise
+// operators only) that is the launch-per-iteration engine re-reading Xs every iteration (500 x 20,000: 26-33 us per iteration
+// against 7).  Penalties are independent cold starts (ref src/oem_dense.cpp:206-246), so the call is made in two parts there --
+// the element-wise penalties, then the group penalties -- and the results go back into the caller's order.  (The eigenvalue step
+// runs twice; both engines hold d to 1e-10 and the first part's is reported.)  OEM_NO_PENALTY_SPLIT=1: one call.
+static int run_paths_wide(oemgpu_ctx *c, Bump B, const double *xy, const double *st, int p, int sem, int standardize, int intercept,
+                          const oemgpu_opts *o, double *beta, double *lambda_out, int32_t *niter, double *loss, double *d,
+                          const WideArgs *wd, const double *lmax_xy)
+{
+    std::vector<int> ie, ig;
+    for (int k = 0; k < o->npen; ++k) (pen_is_grp(o->penalty[k]) ? ig : ie).push_back(k);
+    const int gw = path_wres_workgroups(wd->n, p);
+    const bool wcoop_fits = path_wcoop_workgroups(wd->n, p) >= 1 && path_wcoop_workgroups(wd->n, p) <= (c->num_cu * 3 / 4 < WCOOP_GMAX ? c->num_cu * 3 / 4 : WCOOP_GMAX);
+    const bool split = !ie.empty() && !ig.empty() && !o->accelerate && !wcoop_fits && gw >= 1 && gw <= c->num_cu - 8 && path_wres_xchg_doubles(wd->n, p) > 0 &&
+                       !getenv("OEM_NO_PENALTY_SPLIT") && !getenv("OEM_NO_WRES") && !getenv("OEM_NO_WCOOP");
+    if (!split)
+        return run_paths(c, B, nullptr, xy, st, p, p, sem, standardize, intercept, o, nullptr, beta, lambda_out, niter, loss, d, 1, 0, false, wd, lmax_xy);
+    const int nl = nl_of(o), rows = p + 1;
+    const bool user = o->lambda_user && o->nlambda_user > 0;
+    bool first = true;
+    for (const std::vector<int> *part : {&ie, &ig}) {
+        const int m = (int)part->size();
+        std::vector<int32_t> pen(m);
+        std::vector<double> lam(user ? (size_t)m * nl : 0);
+        for (int k = 0; k < m; ++k) {
+            pen[k] = o->penalty[(*part)[k]];
+            if (user) memcpy(&lam[(size_t)k * nl], o->lambda_user + (size_t)(*part)[k] * nl, sizeof(double) * nl);
+        }
+        oemgpu_opts os = *o;
+        os.npen = m; os.penalty = pen.data(); os.lambda_user = user ? lam.data() : nullptr;
+        std::vector<double> b((size_t)m * nl * rows), lo((size_t)m * nl), ls((size_t)m * nl);
+        std::vector<int32_t> ni((size_t)m * nl);
+        double dd = 0.0;
+        Bump Bp = B;                                             // (each part takes the same frame behind xy / stats)
+        const int rc = run_paths(c, Bp, nullptr, xy, st, p, p, sem, standardize, intercept, &os, nullptr, b.data(), lo.data(), ni.data(), ls.data(), &dd,
+                                 1, 0, false, wd, lmax_xy);
+        if (rc) return rc;
+        for (int k = 0; k < m; ++k) {
+            const size_t dst = (size_t)(*part)[k] * nl, src = (size_t)k * nl;
+            memcpy(beta + dst * rows, &b[src * rows], sizeof(double) * (size_t)nl * rows);
+            memcpy(lambda_out + dst, &lo[src], sizeof(double) * nl);
+            memcpy(loss + dst, &ls[src], sizeof(double) * nl);
+            memcpy(niter + dst, &ni[src], sizeof(int32_t) * nl);
+        }
+        if (first) *d = dd;
+        first = false;
+    }
+    return 0;
+}
+
 static int fit_dense_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev,
                               int32_t standardize, int32_t intercept, const oemgpu_opts *o,
                               double *beta, double *lambda_out, int32_t *niter, double *loss, double *d)
@@ -930,8 +981,7 @@ static int fit_dense_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int
     }
     WideArgs wd;
     wd.xs = xs; wd.ys = ys; wd.lay = lay; wd.n = (int)n; wd.scratch = (double *)(c->aux + a_sc);
-    return run_paths(c, B, nullptr, xy, st, p, p, OEMGPU_SEM_DENSE, standardize, intercept, o, nullptr, beta, lambda_out, niter, loss, d,
-                     1, 0, false, &wd);
+    return run_paths_wide(c, B, xy, st, p, OEMGPU_SEM_DENSE, standardize, intercept, o, beta, lambda_out, niter, loss, d, &wd, nullptr);
 }
 
 // big.oem / oem() on a sparse x with nobs <= nvars and NO intercept (ref src/oem_big.h:537-541, 568-584, 743-764, 880-897;
@@ -963,8 +1013,7 @@ static int fit_big_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64
     }
     WideArgs wd;
     wd.xs = xs; wd.ys = ys; wd.lay = lay; wd.n = (int)n; wd.scratch = (double *)(c->aux + a_sc);
-    rc = run_paths(c, B, nullptr, xy, st, p, p, OEMGPU_SEM_BIG, standardize, 0, o, nullptr, beta, lambda_out, niter, loss, d,
-                   1, 0, false, &wd, standardize ? xy_std : nullptr);
+    rc = run_paths_wide(c, B, xy, st, p, OEMGPU_SEM_BIG, standardize, 0, o, beta, lambda_out, niter, loss, d, &wd, standardize ? xy_std : nullptr);
     if (rc || !sparse_loss) return rc;
     // oemSparse::get_loss (ref src/oem_sparse.h:932-941): the residual of the RETURNED coefficients on the data as they are
     const size_t nk = (size_t)o->npen * nl_of(o), nchunk = (size_t)((n + 2047) / 2048);

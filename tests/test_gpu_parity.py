@@ -1089,6 +1089,44 @@ def test_wide_engine_resident_in_the_accumulator_file(oa, n, p, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_wide_call_with_group_and_elementwise_penalties_is_made_in_two_parts(oa, monkeypatch):
+    """p >= n where the standardised X fits the chip's registers only WITH the accumulator file (path_wres_kernel: element-wise operators):
+    a call that mixes group and element-wise penalties is made in two parts -- penalties are independent cold starts (ref
+    src/oem_dense.cpp:206-246) -- so that one group penalty does not send the lasso to the engine that re-reads X every iteration
+    (api.hip: run_paths_wide).  Same results as the one-call form (OEM_NO_PENALTY_SPLIT=1) in the caller's order, user lambdas and
+    compute.loss included; against the oracle."""
+    import torch
+    n, p = 120, 12800                                              # 200 workgroups of path_wcoop_kernel (it takes 192): path_wres_kernel's size, 40 workgroups
+    rng = np.random.default_rng(99)
+    x = np.asfortranarray(rng.normal(size=(n, p)) * rng.uniform(0.5, 2.0, p))
+    b = np.zeros(p); b[:8] = rng.uniform(0.5, 1.5, 8)
+    y = x @ b + rng.normal(size=n)
+    groups = np.arange(p) // 5 + 1
+    lam = [np.array([0.6, 0.3, 0.1])] * 4
+    calls = (dict(penalty=["grp.lasso", "lasso", "grp.mcp", "scad"], groups=groups, nlambda=4, lambda_min_ratio=0.05, tol=1e-8, maxit=300, compute_loss=True),
+             dict(penalty=["lasso", "grp.lasso", "mcp", "ols"], groups=groups, lambda_=lam, tol=1e-8, maxit=300, standardize=False))
+    xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for kw in calls:
+            f = oa.oem(xd, y, **kw)
+            assert oa.last_path_engine()[0] == "wlaunches"        # the second part: the group penalties
+            monkeypatch.setenv("OEM_NO_PENALTY_SPLIT", "1")
+            g = oa.oem(xd, y, **kw)
+            monkeypatch.delenv("OEM_NO_PENALTY_SPLIT")
+            r = orc.fit_dense(x, y, native=True, unique_groups=np.unique(groups), **kw)
+            assert abs(f["d"] - r["d"]) < DTOL * r["d"]
+            for k in range(4):
+                assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-11)
+                sc = max(1.0, float(np.abs(r["beta"][k]).max()))
+                assert np.abs(np.asarray(f["beta"][k]) - np.asarray(g["beta"][k])).max() < 1e-9 * sc, kw["penalty"][k]
+                assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(g["niter"][k]).astype(int)).max() <= 1
+                _agree_with_oracle(f, r, k, kw["tol"], kw["penalty"][k])
+                if kw.get("compute_loss"):
+                    assert np.allclose(np.ravel(f["loss"][k]), np.ravel(r["loss"][k]), rtol=1e-8)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,p", [(3000, 40), (2500, 300), (3000, 1100), (40, 70), (150, 400), (300, 1100)])
 @pytest.mark.parametrize("std,icpt", [(False, False), (True, False), (False, True), (True, True)])
 def test_observation_weights_of_the_compiled_entry(oa, n, p, std, icpt):
