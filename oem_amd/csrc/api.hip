@@ -820,6 +820,10 @@ int oemgpu_moments_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld
     return shard_moments(c, pl, x_dev, n, ld, y_dev, sums_dev, (double *)(c->ws + a_t), (double *)(c->ws + a_v), moments_dev);
 }
 
+static int run_paths_parts(oemgpu_ctx *c, Bump B, const double *xx, const double *xy, const double *st, int p, int q, int sem, int standardize, int intercept,
+                           const oemgpu_opts *o, double *beta, double *lambda_out, int32_t *niter, double *loss, double *d,
+                           const WideArgs *wd, const double *lmax_xy);
+
 // wpatch (device, or NULL): the constants of DataStd's WEIGHTED standardisation (weighted.hip).  The moments are then those of the
 // standardised, sqrt(w)-scaled copy: finalize takes them as they are (flag 0) and the constants go into `stats` for the lambda
 // grid (scaleY) and for recover(), which run under the caller's flags.
@@ -874,6 +878,7 @@ static int solve_moments_impl(oemgpu_ctx *c, const double *moments_dev, const do
         if (!rc && wpatch) rc = launch_weighted_patch_stats(c->stream, wpatch, p, st);
         if (rc) return rc;
     }
+    if (!ex) return run_paths_parts(c, B2, xx, xy, st, p, q, semantics, standardize, intercept, o, beta, lambda_out, niter, loss, d, nullptr, lmax_xy);
     return run_paths(c, B2, xx, xy, st, p, q, semantics, standardize, intercept, o, nullptr, beta, lambda_out, niter, loss, d,
                      1, 0, false, nullptr, lmax_xy, ex);
 }
@@ -913,18 +918,24 @@ static bool wide_pays(int64_t n, int32_t p, const oemgpu_opts *o)
 // against 7).  Penalties are independent cold starts (ref src/oem_dense.cpp:206-246), so the call is made in two parts there --
 // the element-wise penalties, then the group penalties -- and the results go back into the caller's order.  (The eigenvalue step
 // runs twice; both engines hold d to 1e-10 and the first part's is reported.)  OEM_NO_PENALTY_SPLIT=1: one call.
-static int run_paths_wide(oemgpu_ctx *c, Bump B, const double *xy, const double *st, int p, int sem, int standardize, int intercept,
-                          const oemgpu_opts *o, double *beta, double *lambda_out, int32_t *niter, double *loss, double *d,
-                          const WideArgs *wd, const double *lmax_xy)
+// The same for n > p with 1024 < p <= 2048: the element-wise penalties take the one-exchange row-split engine (path_rowcoop_kernel, ~3 us
+// per iteration), the group penalties the symmetric engine's general form (~5).
+static int run_paths_parts(oemgpu_ctx *c, Bump B, const double *xx, const double *xy, const double *st, int p, int q, int sem, int standardize, int intercept,
+                           const oemgpu_opts *o, double *beta, double *lambda_out, int32_t *niter, double *loss, double *d,
+                           const WideArgs *wd, const double *lmax_xy)
 {
     std::vector<int> ie, ig;
     for (int k = 0; k < o->npen; ++k) (pen_is_grp(o->penalty[k]) ? ig : ie).push_back(k);
-    const int gw = path_wres_workgroups(wd->n, p);
-    const bool wcoop_fits = path_wcoop_workgroups(wd->n, p) >= 1 && path_wcoop_workgroups(wd->n, p) <= (c->num_cu * 3 / 4 < WCOOP_GMAX ? c->num_cu * 3 / 4 : WCOOP_GMAX);
-    const bool split = !ie.empty() && !ig.empty() && !o->accelerate && !wcoop_fits && gw >= 1 && gw <= c->num_cu - 8 && path_wres_xchg_doubles(wd->n, p) > 0 &&
-                       !getenv("OEM_NO_PENALTY_SPLIT") && !getenv("OEM_NO_WRES") && !getenv("OEM_NO_WCOOP");
+    bool split = !ie.empty() && !ig.empty() && !o->accelerate && !getenv("OEM_NO_PENALTY_SPLIT");
+    if (split && wd) {
+        const int gw = path_wres_workgroups(wd->n, p);
+        const bool wcoop_fits = path_wcoop_workgroups(wd->n, p) >= 1 && path_wcoop_workgroups(wd->n, p) <= (c->num_cu * 3 / 4 < WCOOP_GMAX ? c->num_cu * 3 / 4 : WCOOP_GMAX);
+        split = !wcoop_fits && gw >= 1 && gw <= c->num_cu - 8 && path_wres_xchg_doubles(wd->n, p) > 0 && !getenv("OEM_NO_WRES") && !getenv("OEM_NO_WCOOP");
+    } else if (split)
+        split = q > 1024 && q <= 2048 && sem == OEMGPU_SEM_DENSE && path_rowcoop_workgroups(q) <= c->num_cu * 3 / 4 &&
+                !getenv("OEM_NO_ROWCOOP") && !getenv("OEM_NO_SYMCOOP") && !getenv("OEM_NO_COOP");
     if (!split)
-        return run_paths(c, B, nullptr, xy, st, p, p, sem, standardize, intercept, o, nullptr, beta, lambda_out, niter, loss, d, 1, 0, false, wd, lmax_xy);
+        return run_paths(c, B, xx, xy, st, p, q, sem, standardize, intercept, o, nullptr, beta, lambda_out, niter, loss, d, 1, 0, false, wd, lmax_xy);
     const int nl = nl_of(o), rows = p + 1;
     const bool user = o->lambda_user && o->nlambda_user > 0;
     bool first = true;
@@ -942,7 +953,7 @@ static int run_paths_wide(oemgpu_ctx *c, Bump B, const double *xy, const double 
         std::vector<int32_t> ni((size_t)m * nl);
         double dd = 0.0;
         Bump Bp = B;                                             // (each part takes the same frame behind xy / stats)
-        const int rc = run_paths(c, Bp, nullptr, xy, st, p, p, sem, standardize, intercept, &os, nullptr, b.data(), lo.data(), ni.data(), ls.data(), &dd,
+        const int rc = run_paths(c, Bp, xx, xy, st, p, q, sem, standardize, intercept, &os, nullptr, b.data(), lo.data(), ni.data(), ls.data(), &dd,
                                  1, 0, false, wd, lmax_xy);
         if (rc) return rc;
         for (int k = 0; k < m; ++k) {
@@ -981,7 +992,7 @@ static int fit_dense_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int
     }
     WideArgs wd;
     wd.xs = xs; wd.ys = ys; wd.lay = lay; wd.n = (int)n; wd.scratch = (double *)(c->aux + a_sc);
-    return run_paths_wide(c, B, xy, st, p, OEMGPU_SEM_DENSE, standardize, intercept, o, beta, lambda_out, niter, loss, d, &wd, nullptr);
+    return run_paths_parts(c, B, nullptr, xy, st, p, p, OEMGPU_SEM_DENSE, standardize, intercept, o, beta, lambda_out, niter, loss, d, &wd, nullptr);
 }
 
 // big.oem / oem() on a sparse x with nobs <= nvars and NO intercept (ref src/oem_big.h:537-541, 568-584, 743-764, 880-897;
@@ -1013,7 +1024,7 @@ static int fit_big_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64
     }
     WideArgs wd;
     wd.xs = xs; wd.ys = ys; wd.lay = lay; wd.n = (int)n; wd.scratch = (double *)(c->aux + a_sc);
-    rc = run_paths_wide(c, B, xy, st, p, OEMGPU_SEM_BIG, standardize, 0, o, beta, lambda_out, niter, loss, d, &wd, standardize ? xy_std : nullptr);
+    rc = run_paths_parts(c, B, nullptr, xy, st, p, p, OEMGPU_SEM_BIG, standardize, 0, o, beta, lambda_out, niter, loss, d, &wd, standardize ? xy_std : nullptr);
     if (rc || !sparse_loss) return rc;
     // oemSparse::get_loss (ref src/oem_sparse.h:932-941): the residual of the RETURNED coefficients on the data as they are
     const size_t nk = (size_t)o->npen * nl_of(o), nchunk = (size_t)((n + 2047) / 2048);

@@ -486,6 +486,35 @@ def test_register_resident_engine_through_oem(oa, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_mixed_penalties_are_fitted_in_two_parts(oa, monkeypatch):
+    """1024 < p <= 2048, group and element-wise penalties in one call: the element-wise ones on the one-exchange row-split engine, the group
+    penalties on the symmetric engine's general form (api.hip: run_paths_parts; penalties are independent cold starts, ref
+    src/oem_dense.cpp:206-246) -- the caller's order, the one-call form's results (OEM_NO_PENALTY_SPLIT=1), the oracle's."""
+    import time
+    import torch
+    rng = np.random.default_rng(47)
+    n, p = 5000, 1500
+    x = np.asfortranarray(rng.normal(size=(n, p)) * (1.0 + rng.uniform(size=p)) + 0.2)
+    b = np.zeros(p); b[rng.choice(p, 15, replace=False)] = rng.uniform(-1, 1, 15)
+    y = x @ b + rng.normal(size=n) + 0.5
+    groups = np.arange(p) // 5 + 1
+    kw = dict(penalty=["grp.lasso", "lasso", "grp.mcp", "mcp"], groups=groups, nlambda=8, tol=1e-9, compute_loss=True)
+    xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+    f = oa.oem(xd, y, **kw)
+    assert oa.last_path_engine()[0] == "symcoop"                  # (the second part)
+    monkeypatch.setenv("OEM_NO_PENALTY_SPLIT", "1")
+    g = oa.oem(xd, y, **kw)
+    monkeypatch.delenv("OEM_NO_PENALTY_SPLIT")
+    ref = orc.fit_dense(x, y, native=True, unique_groups=np.unique(groups), **kw)
+    _cmp(f, ref)
+    for k in range(4):
+        sc = max(1.0, float(np.abs(ref["beta"][k]).max()))
+        assert np.abs(np.asarray(f["beta"][k]) - np.asarray(g["beta"][k])).max() < 1e-9 * sc
+        assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(ref["niter"][k]).astype(int)).max() <= 1
+        assert np.allclose(np.ravel(f["loss"][k]), np.ravel(ref["loss"][k]), rtol=1e-9)
+
+
+@pytest.mark.gpu
 def test_register_resident_engine_falls_back_when_its_exchange_times_out(oa, monkeypatch):
     """all its workgroups must be resident at once; a poisoned exchange (OEM_WCOOP_FAKE_TIMEOUT=1 sets the poison behind a kernel that
     ran) sends the call to the launch-per-iteration engine: the caller gets exactly that engine's answer"""

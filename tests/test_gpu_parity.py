@@ -1093,7 +1093,7 @@ def test_wide_call_with_group_and_elementwise_penalties_is_made_in_two_parts(oa,
     """p >= n where the standardised X fits the chip's registers only WITH the accumulator file (path_wres_kernel: element-wise operators):
     a call that mixes group and element-wise penalties is made in two parts -- penalties are independent cold starts (ref
     src/oem_dense.cpp:206-246) -- so that one group penalty does not send the lasso to the engine that re-reads X every iteration
-    (api.hip: run_paths_wide).  Same results as the one-call form (OEM_NO_PENALTY_SPLIT=1) in the caller's order, user lambdas and
+    (api.hip: run_paths_parts).  Same results as the one-call form (OEM_NO_PENALTY_SPLIT=1) in the caller's order, user lambdas and
     compute.loss included; against the oracle."""
     import torch
     n, p = 120, 12800                                              # 200 workgroups of path_wcoop_kernel (it takes 192): path_wres_kernel's size, 40 workgroups
