@@ -49,6 +49,7 @@ if [ -z "$quick" ]; then
     OEM_NO_ROWCOOP=1 OEMGPU_LIB=oem_amd/liboemgpu_diag.so python3 tools/symcoop_diag.py 2048 2>&1 | grep -v "amdgpu.ids\|warn" >> $o/${tag}_symcoop_stamped.txt
   fi
   python3 tools/pgen_rowcoop_ab.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_pgen_rowcoop_ab.txt
+  python3 tools/penalty_split_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_penalty_split_times.txt
   python3 tools/wide_group_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_wide_group_times.txt
   # ---- p >= n (n = 500, p = 20,000): the wide engine's column kernel
   rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_wide_trace -o ${tag} -- python3 tools/run_wide.py > $o/${tag}_wide_trace.log 2>&1
