@@ -1,0 +1,185 @@
+"""Size bands no test had run (VERDICT r4 "next round" item 1): every engine at the sizes it exists for, against the oracle.
+
+* the Gram form beyond q = 4096 -- the launch-per-iteration engines of path_large.hip at 4,097 / 5,000 / 8,192 (`oem.xtx`) and
+  `oem()` with n > p at p = 5,000 (ref src/oem_xtx.h:347-381, src/oem_dense.h:508-524);
+* `path_wres_kernel` where it was built for: 500 x 20,000 and 200 x 30,000 with the DEFAULT selection (no OEM_WRES);
+* config 4's only remaining production case of the launch engines at that size: `scale.factor` at p = 4,096;
+* `xval.oem` between p = 300 and the old limit of the CV-error kernel, and beyond it (ref src/oem_xval_dense.cpp:343-461).
+
+d = 1.005 lambda_max is held against ARPACK / LAPACK to 1e-10 and then handed to the oracle (as the config-4 tests do): what is
+compared is the path -- coefficients to 1e-9, iteration counts within one."""
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc
+
+DTOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def oa():
+    import torch
+    assert torch.cuda.is_available()
+    import oem_amd
+    oem_amd.lib()
+    return oem_amd
+
+
+def _lam_max(a):
+    """largest eigenvalue of a symmetric matrix to machine precision (ARPACK, tol = 0) -- LAPACK's full solve takes minutes at 8,192"""
+    from scipy.sparse.linalg import eigsh
+    return float(eigsh(a, k=1, which="LA", tol=0, ncv=24, return_eigenvectors=False)[0])
+
+
+def _gram_problem(p, n, seed, nnz=25):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=(n, p))
+    b = np.zeros(p); b[rng.choice(p, nnz, replace=False)] = rng.uniform(-1, 1, nnz)
+    y = x @ b + rng.normal(size=n)
+    return x.T @ x / n, x.T @ y / n
+
+
+def _same_path(f, r, k, label, tol=1e-9):
+    fb, rb = np.asarray(f["beta"][k]), np.asarray(r["beta"][k])
+    assert fb.shape == rb.shape, label
+    assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-12, atol=0), label
+    scale = max(1.0, float(np.abs(rb).max()))
+    assert np.abs(fb - rb).max() <= tol * scale, (label, np.abs(fb - rb).max())
+    dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int))
+    assert dn.max() <= 1, (label, dn)
+
+
+@pytest.mark.parametrize("p", [4097, 5000, 8192])
+def test_xtx_beyond_4096_runs_the_launch_engines(oa, p):
+    """oem.xtx at q > 4096: no register file holds the matrix any more (p = 8,192: 512 MB, beyond the Infinity Cache), so the
+    launch-per-iteration engines serve it -- lasso + a group penalty in one call; at 5,000 also `scale.factor`."""
+    import torch
+    xtx, xty = _gram_problem(p, p + p // 2, 4000 + p)
+    xd = torch.as_tensor(xtx, device="cuda")
+    groups = np.arange(p) // 5 + 1
+    kw = dict(penalty=["lasso", "grp.lasso"], nlambda=4, lambda_min_ratio=0.05, tol=1e-9, maxit=400)
+    f = oa.oem_xtx(xd, xty, groups=groups, **kw)
+    assert oa.last_path_engine()[0] == "launches"
+    lmax = _lam_max(xtx)
+    assert abs(f["d"] - 1.005 * lmax) <= DTOL * lmax, (f["d"], 1.005 * lmax)
+    r = orc.fit_xtx(xtx, xty, native=True, groups=groups, unique_groups=np.unique(groups), d_override=f["d"], **kw)
+    for k in range(2):
+        _same_path(f, r, k, (p, kw["penalty"][k]))
+        assert (np.asarray(f["beta"][k])[:, -1] != 0).sum() >= 10
+    if p == 5000:
+        sf = np.linspace(0.5, 2.0, p)
+        kw = dict(penalty=["lasso", "mcp"], nlambda=3, lambda_min_ratio=0.1, tol=1e-9, maxit=400)
+        f = oa.oem_xtx(xd, xty, scale_factor=sf, **kw)
+        assert oa.last_path_engine()[0] == "launches"
+        s = xtx / sf[:, None] / sf[None, :]                      # ref src/oem_xtx.h:349-356: S^-1 XX S^-1
+        lmax = _lam_max(s)
+        assert abs(f["d"] - 1.005 * lmax) <= DTOL * lmax
+        r = orc.fit_xtx(xtx, xty, native=True, scale_factor=sf, d_override=f["d"], **kw)
+        for k in range(2):
+            _same_path(f, r, k, (p, "scale.factor", kw["penalty"][k]))
+
+
+def test_dense_n_gt_p_at_p_5000(oa):
+    """oem() with n > p at p = 5,000 (standardised, with an intercept): the MFMA moment pass at 5,002 columns, the eigen step and
+    the launch-per-iteration path engines behind it."""
+    rng = np.random.default_rng(5005)
+    n, p = 6000, 5000
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 2.0 + 0.3)
+    b = np.zeros(p); b[:20] = rng.uniform(-1, 1, 20)
+    y = x @ b + rng.normal(size=n) + 0.5
+    kw = dict(penalty=["lasso", "scad"], nlambda=4, lambda_min_ratio=0.05, tol=1e-9, maxit=400)
+    f = oa.oem(x, y, **kw)
+    mu = x.mean(axis=0)
+    xs = x - mu
+    xs /= np.sqrt((xs ** 2).sum(axis=0) / n)
+    lmax = _lam_max(xs.T @ xs / n)
+    assert abs(f["d"] - 1.005 * lmax) <= DTOL * lmax
+    r = orc.fit_dense(x, y, native=True, d_override=f["d"], **kw)
+    for k in range(2):
+        _same_path(f, r, k, kw["penalty"][k])
+    import torch
+    xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+    g = oa.oem(xd, y, **kw)
+    assert oa.last_path_engine()[0] == "launches"
+    for k in range(2):
+        _same_path(g, r, k, ("device-resident", kw["penalty"][k]))
+
+
+def test_config4_scale_factor_at_p4096(oa):
+    """config 4 with `scale.factor` (ref src/oem_xtx.h:347-381): the one production case at p = 4,096 that the register-resident
+    engine does not take"""
+    import torch
+    p = 4096
+    xtx, xty = _gram_problem(p, 65536 // 4, 9)
+    sf = np.random.default_rng(3).uniform(0.5, 2.0, p)
+    kw = dict(penalty="lasso", nlambda=3, lambda_min_ratio=0.1, tol=1e-10, maxit=500)
+    f = oa.oem_xtx(torch.as_tensor(xtx, device="cuda"), xty, scale_factor=sf, **kw)
+    assert oa.last_path_engine()[0] == "launches"
+    lmax = _lam_max(xtx / sf[:, None] / sf[None, :])
+    assert abs(f["d"] - 1.005 * lmax) <= DTOL * lmax
+    r = orc.fit_xtx(xtx, xty, native=True, scale_factor=sf, d_override=f["d"], **kw)
+    _same_path(f, r, 0, "scale.factor at 4096")
+
+
+@pytest.mark.parametrize("n,p", [(500, 20_000), (200, 30_000)])
+def test_wres_at_its_operating_sizes_against_the_oracle(oa, n, p):
+    """p >= n with Xs in the vector AND accumulator registers of ~200 CUs (path_wcoop.hip: path_wres_kernel) at the sizes it was
+    built for, through the DEFAULT engine selection, against the oracle's restatement of the reference's two-product iteration
+    (ref src/oem_dense.h:513-521) -- these shapes used to be held through KKT only."""
+    import torch
+    rng = np.random.default_rng(n + p)
+    x = np.asfortranarray(rng.normal(size=(n, p)) * 1.5 + 0.2)
+    b = np.zeros(p); b[:10] = rng.uniform(1.0, 2.0, 10)
+    y = x @ b + rng.normal(size=n) + 0.3
+    pf = rng.uniform(0.5, 2.0, p)
+    kw = dict(penalty=["lasso", "mcp"], nlambda=4, lambda_min_ratio=0.05, tol=1e-8, maxit=600, penalty_factor=pf, compute_loss=True)
+    xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f = oa.oem(xd, y, **kw)
+    assert oa.last_path_engine()[0] == "wres"
+    xs = x - x.mean(axis=0)
+    xs /= np.sqrt((xs ** 2).sum(axis=0) / n)
+    lmax = float(np.linalg.eigvalsh(xs @ xs.T / n)[-1])
+    assert abs(f["d"] - 1.005 * lmax) <= DTOL * lmax
+    r = orc.fit_dense(x, y, native=True, d_override=f["d"], **kw)
+    for k in range(2):
+        _same_path(f, r, k, (n, p, kw["penalty"][k]))
+        assert np.allclose(f["loss"][k], r["loss"][k], rtol=1e-8)
+    # the lasso KKT conditions on the standardised data beside it (independent of the oracle)
+    ys = y - y.mean()
+    sy = np.sqrt((ys ** 2).sum() / n)
+    beta = np.asarray(f["beta"][0])[1:]
+    sx = np.sqrt(((x - x.mean(axis=0)) ** 2).sum(axis=0) / n)
+    bs = beta * sx[:, None] / sy                                 # back to the standardised scale (ref src/DataStd.h:269-293)
+    grad = xs.T @ (ys[:, None] / sy - xs @ bs) / n
+    lam = f["lambda"][0] / sy
+    for i in range(1, 4):
+        if f["niter"][0][i] > kw["maxit"]:
+            continue
+        nz = bs[:, i] != 0
+        assert np.all(np.abs(grad[~nz, i]) <= pf[~nz] * lam[i] * (1 + 1e-5))
+        assert np.abs(grad[nz, i] - pf[nz] * lam[i] * np.sign(bs[nz, i])).max() <= 1e-5 * lam[0]
+
+
+@pytest.mark.parametrize("p", [600, 1100, 2000])
+def test_xval_at_larger_p(oa, p):
+    """xval.oem (ref src/oem_xval_dense.cpp:343-461) between p = 300 -- the largest any test had run -- and 1,183, where the
+    CV-error kernel's coefficient tile used to end, and beyond it at p = 2,000: the reference has no limit there."""
+    rng = np.random.default_rng(p)
+    n, nf = (4000, 5) if p < 2000 else (6000, 5)
+    x = np.asfortranarray(rng.normal(size=(n, p)) + 0.2)
+    y = x[:, :8] @ rng.uniform(0.5, 1.5, 8) + rng.normal(size=n) + 1.0
+    foldid = rng.permutation(np.resize(np.arange(1, nf + 1), n))
+    kw = dict(penalty=["lasso", "mcp"], nlambda=8, lambda_min_ratio=0.02, tol=1e-9, maxit=2000)
+    f = oa.xval_oem(x, y, foldid=foldid, **kw)
+    r = orc.xval_dense(x, y, foldid, native=True, **kw)
+    assert abs(f["d"] - r["d"]) <= DTOL * r["d"]
+    for k in range(2):
+        _same_path(f, r, k, (p, kw["penalty"][k]))
+        assert np.allclose(f["cvm"][k], r["cvm"][k], rtol=1e-8), (k, f["cvm"][k], r["cvm"][k])
+        assert np.allclose(f["cvsd"][k], r["cvsd"][k], rtol=1e-8)
