@@ -1655,7 +1655,7 @@ static int xval_cverr(oemgpu_ctx *c, const XvalLay &L, int32_t type_measure, con
     double *part = (double *)(ax + L.a_part), *cvout = (double *)(ax + L.a_out);
     int rc = launch_cv_error(c->stream, xp, L.ldp, yp, fold_start, fold_n, K, p, bdev, npen, nl, type_measure, L.weighted ? 1 : 0, L.nwg, (double)L.n,
                              part, cvout, triples != nullptr);
-    if (rc) { if (rc == OEMGPU_ERR_UNSUPPORTED) set_error("xval_dense: p too large for the CV-error kernel's LDS tile"); return rc; }
+    if (rc) return rc;
     const int per = triples ? 3 : 2;
     std::vector<double> hc((size_t)per * npen * nl);
     OEM_HIP(hipMemcpyAsync(hc.data(), cvout, sizeof(double) * hc.size(), hipMemcpyDeviceToHost, c->stream));

@@ -179,8 +179,13 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // grid (workgroups per fold, K folds, npen); 512 threads = 2 waves per SIMD sharing one copy of the coefficients in LDS.
 // B: [K][npen][nl][p + 1], row 0 of each column the intercept.  part: [K * gridDim.x * CVW][npen][nl16][4] per WAVE: rows, centre c, sum (v - c), sum (v - c)^2 -- merged by Chan's formula in cv_finish_kernel
 // KC: k-steps (4 columns each) whose X fragments a lane holds at once (SINGLE: p + 1 <= 4 KC, one chunk per row tile).
+// CHUNK (the coefficient tile of all p + 1 rows does not fit LDS beside LT lambda tiles -- p beyond ~160 at 100 lambdas): LDS holds KCH
+// coefficient rows at a time; the workgroup's eight waves take one 16-row tile of X each ("round"), keep its LT accumulator tiles
+// over the chunks, and the chunk is staged again (from L2: the K x npen x nl x (p + 1) coefficients are a few MB) for every round.
+// X is still read ONCE per pass over the lambdas, and p has no limit: the traffic added is 16 LT / 128 bytes of L2 per byte of X.
 constexpr int CVW = 8;                   // waves per workgroup
-template <int LT, int KC, bool SINGLE>
+constexpr int CV_KCH = 112;              // coefficient rows per LDS chunk (CHUNK): two fragment loads of KC = 14 k-steps
+template <int LT, int KC, bool SINGLE, bool CHUNK>
 __global__ __launch_bounds__(64 * CVW) void cv_error_kernel(const double *__restrict__ xp, int64_t ldp, const double *__restrict__ yp,
                                                             const int64_t *__restrict__ fold_start, const int64_t *__restrict__ fold_n,
                                                             int p, const double *__restrict__ B, int nl, int mae, int wmode,
@@ -212,10 +217,10 @@ __global__ __launch_bounds__(64 * CVW) void cv_error_kernel(const double *__rest
         }
     };
 
-    for (int l0 = 0; l0 < ntile; l0 += LT) {
-        __syncthreads();
-        for (int idx = tid; idx < K4 * LW; idx += 64 * CVW) {
-            const int c = idx / LW, j = idx - c * LW, lam = l0 * 16 + j;
+    // coefficient rows [cc, cc + ncols) of the lambda tiles from l0 on -> Bl[ncols][LW]
+    auto stage = [&](int l0, int cc, int ncols) {
+        for (int idx = tid; idx < ncols * LW; idx += 64 * CVW) {
+            const int c = cc + idx / LW, j = idx % LW, lam = l0 * 16 + j;
             double v = 0.0;
             if (lam < nl) {
                 if (wmode) { if (c <= p) v = Bsrc[(size_t)lam * Kd + c]; }      // column 0 (sqrt(w)) meets the intercept
@@ -224,7 +229,14 @@ __global__ __launch_bounds__(64 * CVW) void cv_error_kernel(const double *__rest
             }
             Bl[idx] = v;
         }
-        __syncthreads();
+    };
+
+    for (int l0 = 0; l0 < ntile; l0 += LT) {
+        if constexpr (!CHUNK) {
+            __syncthreads();
+            stage(l0, 0, K4);
+            __syncthreads();
+        }
         // The reference runs Welford's update over the observations (ref src/oem_xval_dense.cpp:420-422,452-461).  Here every wave
         // accumulates sum (v - c) and sum (v - c)^2 about a centre c of its own -- the error of the FIRST row it meets, per lambda --
         // so nothing cancels however small the spread of the errors is next to their mean, and the wave partials
@@ -239,12 +251,12 @@ __global__ __launch_bounds__(64 * CVW) void cv_error_kernel(const double *__rest
 #pragma unroll
             for (int t = 0; t < LT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
         };
-        auto mac = [&](const double (&a)[KC], int c0) {
+        auto mac = [&](const double (&a)[KC], int c0, int cc) {       // cc: the coefficient row Bl starts at
 #pragma unroll
             for (int s_ = 0; s_ < KC; ++s_) {
                 const int kk = c0 + 4 * s_ + g;
                 if (SINGLE || c0 + 4 * s_ < K4) {
-                    const double *bp = Bl + (size_t)(kk < K4 ? kk : 0) * LW + l16;
+                    const double *bp = Bl + (size_t)(kk < K4 ? kk - cc : 0) * LW + l16;
                     const double av = (kk < K4) ? a[s_] : 0.0;
 #pragma unroll
                     for (int t = 0; t < LT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[16 * t], acc[t], 0, 0, 0);
@@ -275,14 +287,36 @@ __global__ __launch_bounds__(64 * CVW) void cv_error_kernel(const double *__rest
             }
         };
         // all fragments of a chunk are requested before its first MFMA; the second wave of the SIMD covers the wait
-        for (int64_t rt = (int64_t)wg * CVW + w; rt * 16 < nk; rt += stride) {
-            clear();
-            for (int c0 = 0; c0 < K4; c0 += 4 * KC) {
-                double a[KC];
-                load_a(a, rt, c0);
-                mac(a, c0);
+        if constexpr (!CHUNK) {
+            for (int64_t rt = (int64_t)wg * CVW + w; rt * 16 < nk; rt += stride) {
+                clear();
+                for (int c0 = 0; c0 < K4; c0 += 4 * KC) {
+                    double a[KC];
+                    load_a(a, rt, c0);
+                    mac(a, c0, 0);
+                }
+                finish(rt);
             }
-            finish(rt);
+        } else {
+            // rounds: wave w of the workgroup takes row tile r0 + w; the barriers of the staging are met by all eight waves
+            for (int64_t r0 = (int64_t)wg * CVW; r0 * 16 < nk; r0 += stride) {
+                const int64_t rt = r0 + w;
+                const bool valid = rt * 16 < nk;
+                clear();
+                for (int cc = 0; cc < K4; cc += CV_KCH) {
+                    const int ncols = K4 - cc < CV_KCH ? K4 - cc : CV_KCH;
+                    double a[KC];
+                    if (valid) load_a(a, rt, cc);                       // in flight while the chunk is staged
+                    __syncthreads();
+                    stage(l0, cc, ncols);
+                    __syncthreads();
+                    if (valid) {
+                        mac(a, cc, cc);
+                        for (int c0 = cc + 4 * KC; c0 < cc + ncols; c0 += 4 * KC) { load_a(a, rt, c0); mac(a, c0, cc); }
+                    }
+                }
+                if (valid) finish(rt);
+            }
         }
         // the four row groups of a wave (fixed order); every wave leaves its own partial
         cnt += __shfl_xor(cnt, 16, 64); cnt += __shfl_xor(cnt, 32, 64);
@@ -406,16 +440,17 @@ int cv_wg_per_fold(int64_t n, int K, int npen, int num_cu)
 size_t cv_part_doubles(int nwg, int K, int npen, int nl) { return (size_t)nwg * K * CVW * npen * ((nl + 15) & ~15) * 4; }
 
 template <int LT>
-static int launch_cv_lt(hipStream_t s, dim3 grid, size_t lds, int ksteps, const double *xp, int64_t ldp, const double *yp,
+static int launch_cv_lt(hipStream_t s, dim3 grid, size_t lds, int ksteps, bool chunk, const double *xp, int64_t ldp, const double *yp,
                         const int64_t *fold_start, const int64_t *fold_n, int p, const double *B, int nl, int mae, int wmode, double *part)
 {
-#define OEM_CVK(KC, SINGLE)                                                                                                          \
+#define OEM_CVK(KC, SINGLE, CHUNK)                                                                                                   \
     do {                                                                                                                             \
-        OEM_HIP(hipFuncSetAttribute((const void *)cv_error_kernel<LT, KC, SINGLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((cv_error_kernel<LT, KC, SINGLE>), grid, dim3(64 * CVW), lds, s, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); \
+        OEM_HIP(hipFuncSetAttribute((const void *)cv_error_kernel<LT, KC, SINGLE, CHUNK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((cv_error_kernel<LT, KC, SINGLE, CHUNK>), grid, dim3(64 * CVW), lds, s, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); \
     } while (0)
-    if (ksteps <= 14) OEM_CVK(14, true);
-    else OEM_CVK(14, false);          // 28 fragments at once spill next to 7 accumulator tiles
+    if (chunk) OEM_CVK(14, false, true);
+    else if (ksteps <= 14) OEM_CVK(14, true, false);
+    else OEM_CVK(14, false, false);   // 28 fragments at once spill next to 7 accumulator tiles
 #undef OEM_CVK
     OEM_HIP(hipGetLastError());
     return 0;
@@ -425,24 +460,24 @@ int launch_cv_error(hipStream_t s, const double *xp, int64_t ldp, const double *
                     int K, int p, const double *B, int npen, int nl, int mae, int wmode, int nwg, double n, double *part, double *out, bool triples)
 {
     const int K4 = (p + 1 + 3) & ~3, ntile = (nl + 15) >> 4;
-    // lambdas per pass: as many 16-wide tiles as fit 140 KB of LDS next to the reduction scratch, at most 7 (accumulator registers);
-    // all of them in one pass whenever that fits, so that X is read once
-    auto bytes = [&](int lt) { return ((size_t)K4 * 16 * lt + (size_t)CVW * 16 * lt * 2) * sizeof(double); };
+    // lambdas per pass: at most 7 16-wide tiles (accumulator registers), in even passes; all of them in one pass whenever there are
+    // <= 112 lambdas, so that X is read once.  The coefficient tile of those lambdas stays in LDS for the whole pass when it fits
+    // 140 KB; beyond that (p + 1 > ~160 at 100 lambdas) it goes through LDS in chunks of CV_KCH rows (CHUNK above) -- no limit on p
+    // (this used to shrink the lambda tile instead, re-reading X up to seven times, and to refuse p > 1,183).
     int lt = ntile < 7 ? ntile : 7;
-    while (lt > 1 && bytes(lt) > 140 * 1024) --lt;
-    if (bytes(lt) > 150 * 1024) return OEMGPU_ERR_UNSUPPORTED;
     if (ntile > lt) lt = (ntile + (ntile + lt - 1) / lt - 1) / ((ntile + lt - 1) / lt);      // even passes
-    const size_t lds = bytes(lt);
+    const bool chunk = (size_t)K4 * 16 * lt * sizeof(double) > 140 * 1024;
+    const size_t lds = (size_t)(chunk ? CV_KCH : K4) * 16 * lt * sizeof(double);
     dim3 grid(nwg, K, npen);
     int rc;
     switch (lt) {
-    case 1: rc = launch_cv_lt<1>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
-    case 2: rc = launch_cv_lt<2>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
-    case 3: rc = launch_cv_lt<3>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
-    case 4: rc = launch_cv_lt<4>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
-    case 5: rc = launch_cv_lt<5>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
-    case 6: rc = launch_cv_lt<6>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
-    case 7: rc = launch_cv_lt<7>(s, grid, lds, K4 / 4, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
+    case 1: rc = launch_cv_lt<1>(s, grid, lds, K4 / 4, chunk, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
+    case 2: rc = launch_cv_lt<2>(s, grid, lds, K4 / 4, chunk, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
+    case 3: rc = launch_cv_lt<3>(s, grid, lds, K4 / 4, chunk, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
+    case 4: rc = launch_cv_lt<4>(s, grid, lds, K4 / 4, chunk, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
+    case 5: rc = launch_cv_lt<5>(s, grid, lds, K4 / 4, chunk, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
+    case 6: rc = launch_cv_lt<6>(s, grid, lds, K4 / 4, chunk, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
+    case 7: rc = launch_cv_lt<7>(s, grid, lds, K4 / 4, chunk, xp, ldp, yp, fold_start, fold_n, p, B, nl, mae, wmode, part); break;
     default: return OEMGPU_ERR_INTERNAL;
     }
     if (rc) return rc;
