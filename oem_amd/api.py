@@ -347,8 +347,9 @@ def oem_fit_dense_weighted(x, y, weights, **kw):
 # ------------------------------------------------------------------------------------------ oem.xtx()
 def oem_xtx(xtx, xty, family="gaussian", penalty=None, lambda_=(), nlambda=100, lambda_min_ratio=None, alpha=1.0,
             gamma=3.0, tau=0.5, groups=(), scale_factor=(), penalty_factor=None, group_weights=None, maxit=500,
-            tol=1e-7, irls_maxit=100, irls_tol=1e-3, varnames=None):
-    """oem.xtx(): R/oem_xtx.R:109-360."""
+            tol=1e-7, irls_maxit=100, irls_tol=1e-3, varnames=None, interrupt=None):
+    """oem.xtx(): R/oem_xtx.R:109-360.  interrupt: a callable polled on the calling thread while the library waits for the GPU
+    (the R shim's is R_CheckUserInterrupt, ref src/oem_xtx.cpp:160-163); True ends the call with OEMGPU_ERR_INTERRUPTED."""
     penalty = _match_penalty(penalty)
     if getattr(xtx, "ndim", 0) != 2:
         raise ValueError("xtx must be a matrix")
@@ -380,7 +381,7 @@ def oem_xtx(xtx, xty, family="gaussian", penalty=None, lambda_=(), nlambda=100, 
     if sf.size > 0 and sf.size != p:
         raise ValueError("scale.factor must be same length as xty (nvars)")
     a = _Args(penalty, lam_list, int(np.ravel(nlambda)[0]), lambda_min_ratio, alpha, gamma, tau, tol, maxit, False,
-              False, penalty_factor, groups, unique_groups, group_weights)
+              False, penalty_factor, groups, unique_groups, group_weights, interrupt=interrupt)
     lib = L.lib()
     if _is_torch_cuda(xtx):
         import torch

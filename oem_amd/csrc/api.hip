@@ -4,6 +4,7 @@
 // kernels of gram.hip / path_small.hip / path_large.hip; there is no CPU fallback.
 #include "ctx.hpp"
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -531,8 +532,20 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     // The persistent engines (p >= n; 208 < p <= 1024) need all their workgroups resident at once.  If somebody else holds the CUs (another process on a
     // shared GPU) their exchanges time out after about a second and poison the result: the call is then made again on the
     // launch-per-iteration engines, which wait for nobody.
+    // A persistent launch runs the whole penalty x lambda path (config 4: 23 ms; p >= n at maxit: seconds) and the reference polls for user
+    // interrupts every third lambda (ref src/oem_dense.cpp:235-238): with an interrupt callback the kernel gets an abort word in
+    // host-coherent memory, and the host waits for the launch by polling the stream AND the callback (on the calling thread).
+    const bool abortable = o->interrupt != nullptr && (wcoop || wres || wstream || symcoop || coop);
+    if (abortable) {
+        if (!c->abort_host) {
+            OEM_HIP(hipHostMalloc((void **)&c->abort_host, 64, hipHostMallocMapped)); ++g_alloc_count;
+            OEM_HIP(hipHostGetDevicePointer((void **)&c->abort_dev, c->abort_host, 0));
+        }
+        __atomic_store_n(c->abort_host, 0, __ATOMIC_SEQ_CST);
+    }
     for (int attempt = 0;; ++attempt) {
         const bool persistent = (wcoop || wres || wstream || symcoop || (coop && nbatch == 1)) && attempt == 0;
+        a.abort_word = (abortable && (persistent || (coop && attempt == 0))) ? c->abort_dev : nullptr;
         {
             Timer t(c, OEMGPU_T_EIGPATH);
             PollScope poll(o);
@@ -563,6 +576,25 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
             OEM_HIP(hipMemcpyAsync(c->pinned, joined ? (const void *)stats : (const void *)dout, back_bytes, hipMemcpyDeviceToHost, c->stream));
         }
         HT(3);
+        if (a.abort_word) {
+            bool asked = false;
+            const auto t0 = std::chrono::steady_clock::now();
+            auto last = t0;
+            for (;;) {
+                const hipError_t qe = hipStreamQuery(c->stream);
+                if (qe == hipSuccess) break;
+                if (qe != hipErrorNotReady) OEM_HIP(qe);
+                const auto now = std::chrono::steady_clock::now();
+                if (!asked && now - last >= std::chrono::milliseconds(1)) {          // the callback at most once per millisecond
+                    last = now;
+                    if (o->interrupt(o->interrupt_arg)) { __atomic_store_n(c->abort_host, 1, __ATOMIC_SEQ_CST); asked = true; }
+                }
+                if (now - t0 < std::chrono::milliseconds(2)) std::this_thread::yield();
+                else std::this_thread::sleep_for(std::chrono::microseconds(100));
+            }
+            OEM_HIP(hipStreamSynchronize(c->stream));
+            if (asked) { set_error("interrupted by the caller"); return OEMGPU_ERR_INTERRUPTED; }
+        }
         OEM_HIP(hipStreamSynchronize(c->stream));
         HT(4);
         if (persistent) {
@@ -720,6 +752,7 @@ void oemgpu_destroy(oemgpu_ctx *c)
     if (c->aux) (void)hipFree(c->aux);
     if (c->xres) (void)hipFree(c->xres);
     if (c->blob_buf) (void)hipFree(c->blob_buf);
+    if (c->abort_host) (void)hipHostFree(c->abort_host);
     if (c->acc) (void)hipFree(c->acc);
     for (oemgpu_lane &l : c->lanes) {
         for (int k = 0; k < 2; ++k) {
@@ -830,7 +863,7 @@ static int run_paths_parts(oemgpu_ctx *c, Bump B, const double *xx, const double
 static int solve_moments_impl(oemgpu_ctx *c, const double *moments_dev, const double *sums_dev, int32_t p,
                               int32_t semantics, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
                               double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, const double *wpatch,
-                              const PathExtras *ex = nullptr, const double *lmax_xy = nullptr, size_t extra_ws = 0);
+                              const PathExtras *ex = nullptr, const double *lmax_xy = nullptr, size_t extra_ws = 0, double *big_xy_std = nullptr);
 
 int oemgpu_solve_moments_dev(oemgpu_ctx *c, const double *moments_dev, const double *sums_dev, int32_t p,
                              int32_t semantics, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
@@ -842,7 +875,7 @@ int oemgpu_solve_moments_dev(oemgpu_ctx *c, const double *moments_dev, const dou
 static int solve_moments_impl(oemgpu_ctx *c, const double *moments_dev, const double *sums_dev, int32_t p,
                               int32_t semantics, int32_t standardize, int32_t intercept, const oemgpu_opts *o,
                               double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, const double *wpatch,
-                              const PathExtras *ex, const double *lmax_xy, size_t extra_ws)
+                              const PathExtras *ex, const double *lmax_xy, size_t extra_ws, double *big_xy_std)
 {
     if (!c || !moments_dev || !beta || !lambda_out || !niter || !loss || !d) { set_error("solve_moments: NULL argument"); return OEMGPU_ERR_ARG; }
     if (semantics != OEMGPU_SEM_DENSE && semantics != OEMGPU_SEM_BIG && semantics != OEMGPU_SEM_XVAL) { set_error("unknown semantics %d", semantics); return OEMGPU_ERR_ARG; }
@@ -874,8 +907,12 @@ static int solve_moments_impl(oemgpu_ctx *c, const double *moments_dev, const do
     double *xx = (double *)(c->ws + base + a_xx), *xy = (double *)(c->ws + base + a_xy), *st = (double *)(c->ws + base + a_st);
     {
         Timer t(c, OEMGPU_T_FINAL);
-        rc = launch_finalize(c->stream, moments_dev, sums_dev, p, semantics, wpatch ? 0 : standardize, wpatch ? 0 : intercept, xx, xy, st);
+        // big_xy_std (big.oem / sparse x with nobs <= nvars on the Gram, fit_big_gram_dev): X'X / n and X'y / n of the data as they are,
+        // the column scales only in `stats` (returned coefficients) and in big_xy_std = xy colsq_inv (lambda_zero)
+        const bool plain = wpatch || big_xy_std;
+        rc = launch_finalize(c->stream, moments_dev, sums_dev, p, semantics, plain ? 0 : standardize, plain ? 0 : intercept, xx, xy, st);
         if (!rc && wpatch) rc = launch_weighted_patch_stats(c->stream, wpatch, p, st);
+        if (!rc && big_xy_std) { rc = launch_big_gram_scales(c->stream, xx, xy, p, standardize, st, big_xy_std); lmax_xy = big_xy_std; }
         if (rc) return rc;
     }
     if (!ex) return run_paths_parts(c, B2, xx, xy, st, p, q, semantics, standardize, intercept, o, beta, lambda_out, niter, loss, d, nullptr, lmax_xy);
@@ -995,6 +1032,24 @@ static int fit_dense_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int
     return run_paths_parts(c, B, nullptr, xy, st, p, p, OEMGPU_SEM_DENSE, standardize, intercept, o, beta, lambda_out, niter, loss, d, &wd, nullptr);
 }
 
+// oemSparse::get_loss with nobs <= nvars (ref src/oem_sparse.h:932-941): the residual of the RETURNED coefficients on the data as they are
+static int big_wide_sparse_loss(oemgpu_ctx *c, const double *x_dev, int64_t n, int64_t ld, int32_t p, const double *y_dev, const oemgpu_opts *o,
+                                const double *beta, const int32_t *niter, double *loss)
+{
+    const size_t nk = (size_t)o->npen * nl_of(o), nchunk = (size_t)((n + 2047) / 2048);
+    Bump L;
+    const size_t a_b = L.take(nk * (size_t)(p + 1) * 8), a_p = L.take(nk * nchunk * 8), a_l = L.take(nk * 8);
+    if (ctx_reserve(c, L.off + 4096)) return OEMGPU_ERR_HIP;          // (the paths are done: their frame may be overlaid)
+    double *bd = (double *)(c->ws + a_b), *ld_ = (double *)(c->ws + a_l);
+    OEM_HIP(hipMemcpyAsync(bd, beta, nk * (size_t)(p + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    int rc;
+    if ((rc = launch_resid_loss(c->stream, x_dev, n, ld, p, y_dev, bd, p + 1, (int)nk, (double *)(c->ws + a_p), ld_))) return rc;
+    OEM_HIP(hipMemcpyAsync(loss, ld_, nk * 8, hipMemcpyDeviceToHost, c->stream));
+    OEM_HIP(hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < nk; ++k) if (niter[k] == 0) loss[k] = 1e99;
+    return 0;
+}
+
 // big.oem / oem() on a sparse x with nobs <= nvars and NO intercept (ref src/oem_big.h:537-541, 568-584, 743-764, 880-897;
 // src/oem_sparse.h:607-612, 638-647): the iteration u = X'(Y - X beta)/n + d beta on the data AS THEY ARE, d from X X'/n, no y scaling;
 // with standardize only lambda_zero (max |x_j'y| colsq_inv_j / n) and the returned coefficients (beta colsq_inv) carry the column
@@ -1004,7 +1059,33 @@ static int fit_big_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64
                             const oemgpu_opts *o, double *beta, double *lambda_out, int32_t *niter, double *loss, double *d, bool sparse_loss = false)
 {
     if (set_device(c)) return OEMGPU_ERR_HIP;
-    if (n < 2 || n > WIDE_MAX_N) { set_error("big.oem / sparse x with p >= n: 2 <= n <= %d rows", WIDE_MAX_N); return OEMGPU_ERR_UNSUPPORTED; }
+    if (n < 2) { set_error("big.oem / sparse x with p >= n: at least two rows"); return OEMGPU_ERR_UNSUPPORTED; }
+    int rc;
+    if (!wide_pays(n, p, o)) {
+        // ... on the Gram where the two-product form does not pay (p <= 1024: the register engines; n <= p < 2 n beyond the persistent
+        // engines; more than WIDE_MAX_N rows, where the wide engine ends) -- as oemgpu_fit_dense_dev does for oemDense: the iteration
+        // u = X'(Y - X b)/n + d b is (dI - X'X/n) b + X'Y/n, and X X'/n and X'X/n share their non-zero spectrum
+        const GramPlan pl = gram_plan(n, p, c->num_cu);
+        Bump B;
+        const size_t a_xs2 = B.take((size_t)p * 8), a_mom = B.take((size_t)oemgpu_moments_len(p) * 8);
+        const size_t frame = B.off;
+        const size_t a_t = B.take(pl.tpart_doubles * 8), a_v = B.take(pl.vpart_doubles * 8);
+        size_t need = B.off;
+        const size_t need2 = frame + ((size_t)p * p + p + stats_len(p)) * 8 + 1024 + paths_ws_bytes(p, p, o) + 4096;
+        if (need2 > need) need = need2;
+        if (ctx_reserve(c, need)) return OEMGPU_ERR_HIP;
+        double *mom = (double *)(c->ws + a_mom);
+        {
+            Timer t(c, OEMGPU_T_MOMENTS);
+            rc = shard_moments(c, pl, x_dev, n, ld, y_dev, nullptr, (double *)(c->ws + a_t), (double *)(c->ws + a_v), mom);
+            if (rc) return rc;
+        }
+        oemgpu_opts og = *o;
+        og.compute_loss = 0;                          // (a sparse x: the loss is a pass of its own below; big.oem never has one)
+        rc = solve_moments_impl(c, mom, nullptr, p, OEMGPU_SEM_BIG, standardize, 0, &og, beta, lambda_out, niter, loss, d, nullptr, nullptr, nullptr, 0,
+                                (double *)(c->ws + a_xs2));
+        return (rc || !sparse_loss) ? rc : big_wide_sparse_loss(c, x_dev, n, ld, p, y_dev, o, beta, niter, loss);
+    }
     const WideLayout lay = wide_layout(n);
     Bump X;
     const size_t a_xs = X.take(sizeof(double) * (size_t)lay.rows() * p), a_ys = X.take(sizeof(double) * (size_t)lay.rows()),
@@ -1015,7 +1096,6 @@ static int fit_big_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64
     if (ctx_reserve(c, B.off + paths_ws_bytes(p, p, o) + 4096)) return OEMGPU_ERR_HIP;
     double *xs = (double *)(c->aux + a_xs), *ys = (double *)(c->aux + a_ys);
     double *xy = (double *)(c->ws + a_xy), *st = (double *)(c->ws + a_st), *xy_std = (double *)(c->ws + a_xs2);
-    int rc;
     {
         Timer t(c, OEMGPU_T_MOMENTS);
         rc = launch_wide_standardize(c->stream, x_dev, n, ld, p, y_dev, 0, 0, lay, xs, ys, xy, st);
@@ -1025,19 +1105,7 @@ static int fit_big_wide_dev(oemgpu_ctx *c, const double *x_dev, int64_t n, int64
     WideArgs wd;
     wd.xs = xs; wd.ys = ys; wd.lay = lay; wd.n = (int)n; wd.scratch = (double *)(c->aux + a_sc);
     rc = run_paths_parts(c, B, nullptr, xy, st, p, p, OEMGPU_SEM_BIG, standardize, 0, o, beta, lambda_out, niter, loss, d, &wd, standardize ? xy_std : nullptr);
-    if (rc || !sparse_loss) return rc;
-    // oemSparse::get_loss (ref src/oem_sparse.h:932-941): the residual of the RETURNED coefficients on the data as they are
-    const size_t nk = (size_t)o->npen * nl_of(o), nchunk = (size_t)((n + 2047) / 2048);
-    Bump L;
-    const size_t a_b = L.take(nk * (size_t)(p + 1) * 8), a_p = L.take(nk * nchunk * 8), a_l = L.take(nk * 8);
-    if (ctx_reserve(c, L.off + 4096)) return OEMGPU_ERR_HIP;          // (the paths are done: their frame may be overlaid)
-    double *bd = (double *)(c->ws + a_b), *ld_ = (double *)(c->ws + a_l);
-    OEM_HIP(hipMemcpyAsync(bd, beta, nk * (size_t)(p + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    if ((rc = launch_resid_loss(c->stream, x_dev, n, ld, p, y_dev, bd, p + 1, (int)nk, (double *)(c->ws + a_p), ld_))) return rc;
-    OEM_HIP(hipMemcpyAsync(loss, ld_, nk * 8, hipMemcpyDeviceToHost, c->stream));
-    OEM_HIP(hipStreamSynchronize(c->stream));
-    for (size_t k = 0; k < nk; ++k) if (niter[k] == 0) loss[k] = 1e99;
-    return 0;
+    return (rc || !sparse_loss) ? rc : big_wide_sparse_loss(c, x_dev, n, ld, p, y_dev, o, beta, niter, loss);
 }
 
 // the same from one contiguous host matrix (n rows, column-major, ld = n)

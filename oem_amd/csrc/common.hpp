@@ -133,7 +133,22 @@ struct PathArgs {
     int stats_n;             // doubles of stats to copy
     double d_fixed;          // > 0 (launch-per-iteration Gram engine only): d handed over, no eigenvalue step (weighted oemDense with nobs <= nvars:
                              // the reference takes d from one matrix and iterates on another, ref src/oem_dense.h:466-483, 513-517)
+    // The persistent engines only (one launch for the whole penalty x lambda path): a word in host-coherent pinned memory that the host
+    // sets when the caller's interrupt callback fires while it waits for the launch (ref src/oem_dense.cpp:235-238: the reference polls
+    // every third lambda).  Every workgroup reads it once per 128 iterations and inside any exchange spin that lasts; whoever sees it
+    // stops waiting for anybody, the "leave" bit rides in the workgroup's next vote and the loops are left.  Null: never asked.
+    const int *abort_word;
 };
+
+// the read of PathArgs::abort_word (system scope: the word lives in host memory)
+// (wave-uniform by construction -- every lane reads the same word in the same instruction -- and said so: the engines keep what
+// follows from it in scalar registers)
+__device__ __forceinline__ bool path_abort_asked(const int *w)
+{
+    return w && __builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0;
+}
+constexpr unsigned PATH_ABORT_SPINS = 1023u;   // an exchange spin looks at the word every 1,024 sweeps (~1 ms): never on the way of an exchange that arrives
+constexpr int PATH_FAILED_TIMEOUT = 1, PATH_FAILED_ABORT = 2;
 
 // the problem instance of this workgroup (see PathArgs::nbatch); all scalar arithmetic
 __device__ __forceinline__ PathArgs path_instance(PathArgs A)
@@ -230,6 +245,7 @@ size_t wide_scratch_doubles(int n, int p);
 int launch_wide_standardize(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, int standardize, int intercept,
                             const WideLayout &lay, double *xs, double *ys, double *xy, double *stats);
 int launch_big_wide_scales(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *xy, double *stats, double *xy_std);
+int launch_big_gram_scales(hipStream_t s, const double *xx, const double *xy, int p, int standardize, double *stats, double *xy_std);
 int run_path_wide(hipStream_t s, const PathArgs &a, const WideArgs &w, double *host_scratch);
 // the same iteration as ONE persistent launch of cooperating workgroups with Xs in registers (path_wcoop.hip): element-wise
 // penalties, one row block, p <= 4 CW WCOOP_GMAX columns (CW = 16 / 8 / 4 by column height); WCOOP_GMAX = three quarters of the CUs

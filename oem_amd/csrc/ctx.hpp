@@ -59,6 +59,8 @@ struct oemgpu_ctx {
     size_t blob_bytes = 0;
     const char *blob_dev = nullptr;   // where the last parameter blob was uploaded (run_paths skips an identical upload)
     size_t blob_len = 0;
+    int *abort_host = nullptr;     // the abort word of the persistent path engines (PathArgs::abort_word): one int of host-coherent pinned memory,
+    int *abort_dev = nullptr;      // mapped into the device; allocated by the first call that has an interrupt callback
     bool cached = false;           // owned by the process-wide cache (oemgpu_release_cache frees it)
     bool busy = false;
 };

@@ -75,7 +75,8 @@ struct CoopX {
     __amdgpu_buffer_rsrc_t rs;    // [2 parities][QMAX rows] pairs of 16 bytes: {lo, epoch, hi, epoch}
     unsigned epoch;               // exchange counter, never 0; identical in every workgroup
     int wg, qmax;
-    bool failed;
+    int failed;                   // 0; PATH_FAILED_TIMEOUT: an exchange timed out; PATH_FAILED_ABORT: the host's abort word was seen (common.hpp)
+    const int *abortw;            // PathArgs::abort_word
 #ifdef OEM_PATH_DIAG
     unsigned long long acc[16], last;
 #endif
@@ -181,8 +182,9 @@ __device__ __forceinline__ void coop_round(const double (&a)[CG], const int (&bi
         for (int k = 0; k < C::EPT; ++k)
             if (((miss >> k) & 1u) && pv[k].y == X.epoch && pv[k].w == X.epoch) miss &= ~(1u << k);
         if (++spins >= limit && __any(miss != 0u)) { ok = false; break; }
+        if ((spins & PATH_ABORT_SPINS) == 0u && path_abort_asked(X.abortw)) { X.failed = PATH_FAILED_ABORT; break; }
     }
-    if (!ok) X.failed = true;
+    if (!ok && X.failed == 0) X.failed = PATH_FAILED_TIMEOUT;
     COOP_STAMP(4);                                              // polling
 #ifdef OEM_PATH_DIAG
     X.acc[8] += 1;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
         }
     }
     CoopX X;
-    X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)A.work, 0, 2 * C::QMAX * 16, 0x00020000); X.epoch = 0; X.wg = wg; X.qmax = C::QMAX; X.failed = false;
+    X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)A.work, 0, 2 * C::QMAX * 16, 0x00020000); X.epoch = 0; X.wg = wg; X.qmax = C::QMAX; X.failed = 0; X.abortw = A.abort_word;
 #ifdef OEM_PATH_DIAG
     for (int k = 0; k < 16; ++k) X.acc[k] = 0;
     X.last = __builtin_amdgcn_s_memtime();
@@ -419,6 +421,8 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
     int *flagw = reinterpret_cast<int *>(red + 10);                 // "some coefficient still moving", one word per wave
     // One lambda loop per (operator family, accelerate) pair: the dispatch happens once per penalty, the serial loop carries only
     // the arithmetic of the operator in use.  KIND == K_GRP covers every group operator (K.kind selects inside).
+    bool left = false;                                           // the host's abort word was seen (PathArgs::abort_word): every loop is left
+    unsigned tick = 0u;
     auto lambda_loop = [&](auto KIND_, auto ACC_, int pp, int pen) {
         constexpr int KIND = decltype(KIND_)::value;
         constexpr bool ACC = decltype(ACC_)::value;
@@ -460,6 +464,7 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
             for (int k = 0; k < EPT; ++k) tp[k] = pfE[k] * K.L;
             int it = 0;
             for (;;) {
+                if ((tick++ & 127u) == 0u && path_abort_asked(X.abortw)) X.failed = PATH_FAILED_ABORT;
                 // ---- beta = T(u) for every coordinate (replicated), acceleration, stop rule
                 double u[EPT];
 #pragma unroll
@@ -589,13 +594,14 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
                 }
                 COOP_STAMP(10);                                     // threshold, stop rule
                 // one barrier: Bsh is complete, and every wave's "still moving" word is in place
-                const int mine = (__ballot(bad) != 0ull) ? 1 : 0;
+                const int mine = ((__ballot(bad) != 0ull) ? 1 : 0) | (X.failed == PATH_FAILED_ABORT ? 2 : 0);      // (bit 1: the abort word was seen)
                 if (lane == 0) flagw[w] = mine;
                 __syncthreads();
                 const int anybad = flagw[0] | flagw[1] | flagw[2] | flagw[3];
                 COOP_STAMP(11);                                     // the barrier
                 ++it;
-                const bool conv = !anybad;
+                if (anybad & 2) { left = true; break; }
+                const bool conv = !(anybad & 1);
                 const bool fin = conv || it >= maxit;
                 if (__builtin_expect(fin, 0)) {
                     if (has_sinv) {                                 // oemXTX::get_beta rescales the member in place (quirk Q5)
@@ -630,6 +636,7 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
                     break;
                 }
             }
+            if (left) break;
         }
     };
     for (int pp = A.pen_lo; pp < A.pen_hi; ++pp) {
@@ -653,6 +660,7 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
             default: lambda_loop(std::integral_constant<int, K_GRP>{}, Fa{}, pp, pen); break;
             }
         }
+        if (left) break;
     }
 #ifdef OEM_PATH_DIAG
     if (tid == 0 && writer) {

@@ -92,8 +92,21 @@ struct SymX {
     int s1, s2;                   // bytes per parity of exchange 1 / 2
     unsigned epoch;               // all-reduce counter, never 0; identical in every workgroup
     int wg, G;
-    bool failed;
+    bool failed;                  // an exchange timed out, or the host's abort word was seen: nobody waits any more
+    // PathArgs::abort_word without a register of its own (path_rowcoop_kernel has none to spare: one more live value and hipcc parks
+    // its own in the accumulator file the inline asm owns -- oem_amd/build.py audits that): the pointer sits in an LDS slot and is read
+    // where it is needed, and "seen" is an LDS word (0 / 2) that is read next to the votes behind their barrier
+    const int *const *abortp;
+    int *aflag;
 };
+// the host's abort word, looked at by the whole wave: seen => nobody waits any more, and the workgroup's next vote says "leave"
+__device__ __forceinline__ bool sx_abort_seen(SymX &X)
+{
+    if (!path_abort_asked(*X.abortp)) return false;
+    X.failed = true;
+    *X.aflag = 2;
+    return true;
+}
 
 __device__ __forceinline__ void sx_publish(__amdgpu_buffer_rsrc_t rs, int off, double val, unsigned tag)
 {
@@ -123,6 +136,7 @@ __device__ __forceinline__ void sx_gather(const int (&off)[E], unsigned need, do
         for (int k = 0; k < E; ++k)
             if (((miss >> k) & 1u) && (pv[k].y >> 1) == X.epoch && (pv[k].w >> 1) == X.epoch) miss &= ~(1u << k);
         if (++spins >= limit && __any(miss != 0u)) { ok = false; break; }
+        if ((spins & PATH_ABORT_SPINS) == 0u && sx_abort_seen(X)) break;
     }
     if (!ok) X.failed = true;
 #pragma unroll
@@ -296,7 +310,7 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
     double *thr = red + 16;                              // operator constants of the lambda in use [TH_N <= 16]
     int *votes = reinterpret_cast<int *>(thr + 16);      // [8] votes, [8] kind
     int *nzs = votes + 16;                               // [SNB] which 16-coordinate groups of this slot of Bsh hold a non-zero (4 bits)
-    int *wv = nzs + SNB;                                 // (32 spare words)
+    int *wv = nzs + SNB;                                 // (32 spare words; [0..1]: PathArgs::abort_word, SymX::abortp, [2]: SymX::aflag)
     double *uo = reinterpret_cast<double *>(wv + 32);     // GEN: u of this owner's coordinates [SSL]
     int *rec = wv + 32 + 2 * SSL;                        // this workgroup's plan record [SW_INTS], then P1[SNB] (pairs index of exchange 1 per slot)
     int *P1 = rec + SW_INTS;
@@ -306,6 +320,7 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
 
     const int *__restrict__ blkbase = plan;
     for (int k = tid; k < SW_INTS; k += SNTH) rec[k] = plan[SPLAN_HEAD + wg * SW_INTS + k];
+    if (tid == 0) { *reinterpret_cast<const int **>(wv) = A.abort_word; wv[2] = 0; }
     for (int k = tid; k < SNB * 64; k += SNTH) Bsh[k] = 0.0;
     if (tid < 64) Wp[8 * NT * 64 + tid] = 0.0;
     __syncthreads();
@@ -402,7 +417,7 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
     X.s1 = nsum * 64 * 16; X.s2 = T * 64 * 16;
     X.o2 = 2 * X.s1; X.o3 = X.o2 + 2 * X.s2; X.o4 = X.o3 + 2 * G * 16;
     X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, X.o4 + 2 * G * 16, 0x00020000);
-    X.epoch = 0; X.wg = wg; X.G = G; X.failed = false;
+    X.epoch = 0; X.wg = wg; X.G = G; X.failed = false; X.abortp = reinterpret_cast<const int *const *>(wv); X.aflag = wv + 2;
 #ifdef OEM_PATH_DIAG
     for (int k = 0; k < 16; ++k) X.acc[k] = 0;
     X.last = __builtin_amdgcn_s_memtime();
@@ -466,8 +481,10 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
 
     // ONE loop for the Lanczos steps (phase 0) and the OEM iterations (phase 1): both are product -> exchange 1 -> the owners'
     // arithmetic -> exchange 2.
+    unsigned tick = 0u;
     for (;;) {
         const bool lz = phase == 0;
+        if ((tick++ & 127u) == 0u) (void)sx_abort_seen(X);           // (PathArgs::abort_word: the caller's interrupt)
         // ---- products of this wave's tiles (those whose vector block holds a non-zero), reduced over the lanes, into Wp
         SX_STAMP(0);
         int fJ[NT], fI[NT];                                          // (all flag words asked for at once: one LDS latency, not six)
@@ -670,7 +687,11 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
 #ifdef OEM_PATH_DIAG
         X.acc[8] += 1;
 #endif
-        if (!lz) { mw = votes[4] | votes[5] | votes[6] | votes[7]; continue; }
+        {
+            const int v2 = votes[4] | votes[5] | votes[6] | votes[7] | X.aflag[0];
+            if (v2 & 2) break;                                       // somebody here has seen the host's abort word: nobody waits any more, leave
+            if (!lz) { mw = v2; continue; }
+        }
 
         // ---- Lanczos bookkeeping (replicated): T, the stop rule, and at the end d and the hand-over to the path
         if (tid == 0) { Tal[nst] = alpha; Tbe[nst] = bb; }
@@ -798,9 +819,10 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
     double *red = sturm + 2 * (SCML + 16);               // block reductions [2][4], theta slot [8], lmax words [12..16)
     double *thr = red + 16;
     double *Pc = thr + 16;                               // the waves' parts of the sixteen row sums [4][16]
-    int *votes = reinterpret_cast<int *>(Pc + 64);       // [8] votes, [8] kind
+    int *votes = reinterpret_cast<int *>(Pc + 64);       // [8] votes, [8] kind, [2] PathArgs::abort_word (SymX::abortp), [1] SymX::aflag
     const bool writer = wg == 0;
     asm volatile("" ::: "a255");                         // the accumulator file is in use (by the asm alone)
+    if (tid == 0) { *reinterpret_cast<const int **>(votes + 16) = A.abort_word; votes[18] = 0; }      // (read behind the barriers of the set-up below)
 
     // ---- this lane's 128 matrix entries: row 16 wg + l16, columns 512 w + 128 grp + k
     const int row = 16 * wg + l16, cbase = 512 * w + 128 * grp;
@@ -823,7 +845,7 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
     SymX X;
     X.s1 = 0; X.s2 = RQ * 16; X.o2 = 0; X.o3 = 0; X.o4 = 0;
     X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, 2 * RQ * 16 + 2 * (RQ / 16) * 16, 0x00020000);      // (+ compute.loss: the workgroups' parts, [2][RQ / 16] pairs)
-    X.epoch = 0; X.wg = wg; X.G = G; X.failed = false;
+    X.epoch = 0; X.wg = wg; X.G = G; X.failed = false; X.abortp = reinterpret_cast<const int *const *>(votes + 16); X.aflag = votes + 18;
 #ifdef OEM_PATH_DIAG
     for (int k = 0; k < 16; ++k) X.acc[k] = 0;
     X.last = __builtin_amdgcn_s_memtime();
@@ -879,7 +901,7 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
 #ifdef OEM_PATH_DIAG
         X.acc[8] += 1;
 #endif
-        return votes[0] | votes[1] | votes[2] | votes[3];
+        return votes[0] | votes[1] | votes[2] | votes[3] | X.aflag[0];      // (bit 1: the host's abort word was seen in this workgroup)
     };
 
     // ---- eigenvalue step: Lanczos, the vector updates replicated from the gathered product (v in Bsh, v_prev in Vp)
@@ -993,9 +1015,15 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
                 const int moving = (own && ((cn != qn) || (cn && qn && fabs(bn - bc) > tol * qo))) ? 1 : 0;
                 bc = bn;
                 ++it;
+                // PathArgs::abort_word (the caller's interrupt), looked at once per lambda and per 128 iterations; whoever sees it waits for
+                // nobody any more, and the bit rides in this workgroup's vote: every loop is left (pp = npen says so -- no flag of its own:
+                // this kernel has no scalar register to spare)
+                if ((it & 127) == 1) (void)sx_abort_seen(X);
                 const int any = all_gather(bn, moving, Bsh);
+                if (any & 2) { pp = npen; break; }
                 if (!any) { conv = true; break; }
             }
+            if (pp >= npen) break;
             const size_t kfin = (size_t)pp * nl + i;
             if (own) A.beta[kfin * q + row] = bc;
             if (tid == 0 && writer) { A.niter[kfin] = conv ? it : maxit + 1; if (!A.compute_loss) A.loss[kfin] = 1e99; }      // ref src/oem_base.h:94-109
@@ -1020,6 +1048,7 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
                 }
             }
         }
+        if (pp >= npen) break;                                       // (left on the abort word)
         if (tid == 0 && writer) for (int r = nlam; r < nl; ++r) { A.niter[(size_t)pp * nl + r] = 0; A.loss[(size_t)pp * nl + r] = 1e99; }
     }
 #ifdef OEM_PATH_DIAG
@@ -1032,7 +1061,7 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
     if (__syncthreads_or(X.failed ? 1 : 0) && tid == 0) A.d_out[6] = 1.0;       // exchange timeout: poison (api.hip: run_paths falls back)
 }
 
-constexpr size_t rowcoop_lds_bytes() { return sizeof(double) * (size_t)(RQ + 16 + 2 * RQ + 2 * SCML + 2 * (SCML + 16) + 16 + 16 + 64) + sizeof(int) * 16; }
+constexpr size_t rowcoop_lds_bytes() { return sizeof(double) * (size_t)(RQ + 16 + 2 * RQ + 2 * SCML + 2 * (SCML + 16) + 16 + 16 + 64) + sizeof(int) * 20; }
 
 }  // namespace
 

@@ -103,7 +103,8 @@ struct WX {
     unsigned epoch;               // all-reduce counter, never 0; identical in every workgroup
     int wg, G, SL, n, row0, nsl;  // this workgroup's slice: rows [row0, row0 + nsl)
     int stride1;                  // pairs per parity of exchange 1
-    bool failed;
+    int failed;                   // 0; PATH_FAILED_TIMEOUT: an exchange timed out (a partner is gone); PATH_FAILED_ABORT: the host asked to stop
+    const int *abortw;            // PathArgs::abort_word
 };
 
 __device__ __forceinline__ double wc_block_sum(double v, double *red, int &rpar, int w, int lane)
@@ -203,11 +204,12 @@ __device__ __forceinline__ void wc_gather(__amdgpu_buffer_rsrc_t rs, int off0, u
         for (int k = 0; k < E; ++k)
             if (((miss >> k) & 1u) && (pv[k].y >> 1) == X.epoch && (pv[k].w >> 1) == X.epoch) miss &= ~(1u << k);
         if (++spins >= limit && __any(miss != 0u)) { ok = false; break; }
+        if ((spins & PATH_ABORT_SPINS) == 0u && path_abort_asked(X.abortw)) { X.failed = PATH_FAILED_ABORT; break; }
 #if OEM_XCHG_SLEEP2 > 0
         if (__any(miss != 0u)) __builtin_amdgcn_s_sleep(OEM_XCHG_SLEEP2);
 #endif
     }
-    if (!ok) X.failed = true;
+    if (!ok && X.failed == 0) X.failed = PATH_FAILED_TIMEOUT;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
         const bool nd = ((need >> k) & 1u) != 0 && ((miss >> k) & 1u) == 0;
@@ -257,7 +259,8 @@ __device__ __forceinline__ void wc_gather_u_list(double *Ush, double u_own, int 
                     miss &= ~(1u << (k0 + i));
                 }
         }
-        if (++spins >= limit && __any(miss != 0u)) { X.failed = true; break; }
+        if (++spins >= limit && __any(miss != 0u)) { if (X.failed == 0) X.failed = PATH_FAILED_TIMEOUT; break; }
+        if ((spins & PATH_ABORT_SPINS) == 0u && path_abort_asked(X.abortw)) { X.failed = PATH_FAILED_ABORT; break; }
     }
     __syncthreads();
 }
@@ -283,15 +286,16 @@ __device__ __forceinline__ double wc_adp_total(double own, double *red, int &rpa
         wc_v4u pv = wc_v4u{0u, 0u, 0u, 0u};
         if (miss) pv = __builtin_amdgcn_raw_buffer_load_b128(X.rs, X.o4 + off4 + tid * 16, 0, 16);
         if (miss && (pv.y >> 1) == ep && (pv.w >> 1) == ep) { v = __hiloint2double((int)pv.z, (int)pv.x); miss = false; }
-        if (++spins >= limit && __any(miss)) { X.failed = true; break; }
+        if (++spins >= limit && __any(miss)) { if (X.failed == 0) X.failed = PATH_FAILED_TIMEOUT; break; }
+        if ((spins & PATH_ABORT_SPINS) == 0u && path_abort_asked(X.abortw)) { X.failed = PATH_FAILED_ABORT; break; }
     }
     return wc_block_sum(v, red, rpar, w, lane);                  // thread t holds workgroup t's part: a fixed order
 }
 
 // OR of one bit per thread over the workgroup through four LDS words and ONE barrier (the caller's: `words` is read behind it)
-__device__ __forceinline__ void wc_vote(int *words, int w, int lane, int bit)
+__device__ __forceinline__ void wc_vote(int *words, int w, int lane, int bit, int extra = 0)
 {
-    const int wb = __ballot(bit != 0) != 0ull ? 1 : 0;
+    const int wb = (__ballot(bit != 0) != 0ull ? 1 : 0) | extra;      // (extra: wave-uniform bits -- 2: this wave has seen the host's abort word)
     if (lane == 0) words[w] = wb;
 }
 
@@ -370,7 +374,8 @@ __device__ __forceinline__ int wc_allreduce(double *Rsh, const double *Ysh, cons
         for (int k = 0; k < C::E2; ++k) if ((need2 >> k) & 1u) Rsh[tid + WNTH * k] = r[k];
     }
     WC_STAMP(6);                                                 // gather 2
-    wc_vote(votes + 8, w, lane, bits2);
+    // (bit 1 of the result: somebody in this workgroup has seen the host's abort word -- the caller leaves its loops; nobody waits any more)
+    wc_vote(votes + 8, w, lane, bits2, X.failed == PATH_FAILED_ABORT ? 2 : 0);
     __syncthreads();
     const int any = any1 | votes[8] | votes[9] | votes[10] | votes[11];
     WC_STAMP(7);
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
             for (int m = tid; m < nm; m += WNTH) gidxL[m] = A.gidx[m];
         }
     }
-    X.epoch = 0; X.failed = false;
+    X.epoch = 0; X.failed = 0; X.abortw = A.abort_word;
 #ifdef OEM_PATH_DIAG
     for (int k = 0; k < 16; ++k) X.acc[k] = 0;
 #endif
@@ -659,6 +664,8 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
     const double lstep = nl > 1 ? (lhi - llo) / (double)(nl - 1) : 0.0;
     const bool lflip = fabs(lhi) < fabs(llo);
 
+    bool left = false;                                           // the host's abort word was seen (PathArgs::abort_word): every loop is left
+    unsigned tick = 0u;
     for (int pp = A.pen_lo + set; pp < A.pen_hi; pp += nsets) {
         const int pen = A.penalty[pp];
         const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
@@ -693,6 +700,7 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
             const double tp = pfj * K.L;
             int it = 0;
             for (;;) {
+                if ((tick++ & 127u) == 0u && path_abort_asked(X.abortw)) X.failed = PATH_FAILED_ABORT;
                 int any = 0;
                 const bool grp = GEN && K.kind >= K_GRP;
                 // 1 - pen / ||u_g|| etc. from the squared norm of a group (ref src/oem_dense.h:193-315; quirk Q6: ||u_g|| = 0 => 0)
@@ -771,7 +779,8 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
                     any = finish_iteration((colok && f != 0.0) ? cdiv(us * f, K.D, c.rD) : 0.0);
                 }
                 ++it;
-                const bool conv = !any;
+                if (any & 2) { left = true; break; }
+                const bool conv = !(any & 1);
                 if (conv || it >= maxit) {
                     if (storer) A.beta[orow * q + mycol] = bcur;
                     // compute.loss (ref src/oem_dense.h:759-770): sum (Ys - Xs beta)^2 -- the residual every workgroup already holds
@@ -786,7 +795,9 @@ __global__ __launch_bounds__(WNTH) void path_wcoop_kernel(PathArgs A, const doub
                     break;
                 }
             }
+            if (left) break;
         }
+        if (left) break;
     }
 #ifdef OEM_PATH_DIAG
     if (tid == 0 && writer) for (int k = 0; k < 16; ++k) g_diag_wcoop[k] = X.acc[k];
@@ -941,7 +952,7 @@ __global__ __launch_bounds__(WNTH) void path_wres_kernel(PathArgs A, const doubl
     X.qpad = 0;
     X.o2 = 2 * X.stride1 * 16; X.o3 = X.o2 + 2 * NP * 16; X.o4 = X.o3;
     X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, X.o3, 0x00020000);
-    X.epoch = 0; X.failed = false;
+    X.epoch = 0; X.failed = 0; X.abortw = A.abort_word;
 #ifdef OEM_PATH_DIAG
     for (int k = 0; k < 16; ++k) X.acc[k] = 0;
     X.last = __builtin_amdgcn_s_memtime();
@@ -1099,6 +1110,8 @@ __global__ __launch_bounds__(WNTH) void path_wres_kernel(PathArgs A, const doubl
         colok |= (mycol0 + s * CW < c1) ? 1u << s : 0u;
         bcur[s] = 0.0;
     }
+    bool left = false;                                           // the host's abort word was seen (PathArgs::abort_word): every loop is left
+    unsigned tick = 0u;
     for (int pp = A.pen_lo; pp < A.pen_hi; ++pp) {
         const int pen = A.penalty[pp];
         const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
@@ -1126,6 +1139,7 @@ __global__ __launch_bounds__(WNTH) void path_wres_kernel(PathArgs A, const doubl
             for (int s = 0; s < NS; ++s) tp[s] = ((colok >> s) & 1u) ? A.pf[mycol0 + s * CW] * c.L : 0.0;
             int it = 0;
             for (;;) {
+                if ((tick++ & 127u) == 0u && path_abort_asked(X.abortw)) X.failed = PATH_FAILED_ABORT;
                 double bn[NS];
                 all_dots(bn);
                 bool moving = false;
@@ -1143,7 +1157,8 @@ __global__ __launch_bounds__(WNTH) void path_wres_kernel(PathArgs A, const doubl
                 // r' = Ys - Xs beta': the next iteration's input, or the warm start of the next lambda
                 const int any = wc_allreduce<NR, true, WRES_GMAX>(Rsh, Ysh, Pc, Gsh, votes, pub, need1, need2, rn, moving ? 1 : 0, X, tid, w, lane);
                 ++it;
-                const bool conv = !any;
+                if (any & 2) { left = true; break; }
+                const bool conv = !(any & 1);
                 if (conv || it >= maxit) {
 #pragma unroll
                     for (int s = 0; s < NS; ++s)
@@ -1160,7 +1175,9 @@ __global__ __launch_bounds__(WNTH) void path_wres_kernel(PathArgs A, const doubl
                     break;
                 }
             }
+            if (left) break;
         }
+        if (left) break;
     }
 #ifdef OEM_PATH_DIAG
     if (tid == 0 && writer) for (int k = 0; k < 16; ++k) g_diag_wcoop[k] = X.acc[k];
@@ -1228,7 +1245,7 @@ __global__ __launch_bounds__(WNTH) void path_wstream_kernel(PathArgs A, const do
     X.qpad = 0;
     X.o2 = 2 * X.stride1 * 16; X.o3 = X.o2 + 2 * NP * 16; X.o4 = X.o3;
     X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, X.o3, 0x00020000);
-    X.epoch = 0; X.failed = false;
+    X.epoch = 0; X.failed = 0; X.abortw = A.abort_word;
 #ifdef OEM_PATH_DIAG
     for (int k = 0; k < 16; ++k) X.acc[k] = 0;
     X.last = __builtin_amdgcn_s_memtime();
@@ -1387,6 +1404,8 @@ __global__ __launch_bounds__(WNTH) void path_wstream_kernel(PathArgs A, const do
     const double lstep = nl > 1 ? (lhi - llo) / (double)(nl - 1) : 0.0;
     const bool lflip = fabs(lhi) < fabs(llo);
 
+    bool left = false;                                           // the host's abort word was seen (PathArgs::abort_word): every loop is left
+    unsigned tick = 0u;
     for (int pp = A.pen_lo; pp < A.pen_hi; ++pp) {
         const int pen = A.penalty[pp];
         const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
@@ -1419,10 +1438,12 @@ __global__ __launch_bounds__(WNTH) void path_wstream_kernel(PathArgs A, const do
             const WThr c = wc_thr(K, d);
             int it = 0;
             for (;;) {
+                if ((tick++ & 127u) == 0u && path_abort_asked(X.abortw)) X.failed = PATH_FAILED_ABORT;
                 const bool moving = pass(std::true_type{}, c, d);
                 const int any = wc_allreduce<NR, true>(Rsh, Ysh, Pc, Gsh, votes, pub, need1, need2, rn, moving ? 1 : 0, X, tid, w, lane);
                 ++it;
-                const bool conv = !any;
+                if (any & 2) { left = true; break; }
+                const bool conv = !(any & 1);
                 if (conv || it >= maxit) {
                     if (storer)
                         for (int ch = 0; ch < nch; ++ch) {
@@ -1440,7 +1461,9 @@ __global__ __launch_bounds__(WNTH) void path_wstream_kernel(PathArgs A, const do
                     break;
                 }
             }
+            if (left) break;
         }
+        if (left) break;
     }
     if (tid == 0 && writer) {
         A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);

@@ -137,6 +137,29 @@ __global__ __launch_bounds__(256) void big_wide_scales_kernel(const double *__re
     const double inv = 1.0 / sqrt(cs);
     if (lane == 0) { stats[4 + p + j] = inv; xy_std[j] = xy[j] * inv; }
 }
+// The same constants from the Gram of the data as they are (xx = X'X / n, stats[3] = n; fit_big_gram_dev): sum x_j^2 = n xx_jj.
+// standardize == 0: scales 1, xy_std = xy.
+__global__ __launch_bounds__(256) void big_gram_scales_kernel(const double *__restrict__ xx, const double *__restrict__ xy, int p, int standardize,
+                                                               double *__restrict__ stats, double *__restrict__ xy_std)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= p) return;
+    const double n = stats[3];
+    double inv = 1.0;
+    if (standardize) {
+        double cs = xx[(size_t)j * p + j] * n / (n - 1.0);
+        if (cs == 0.0) cs = 1.0;
+        inv = 1.0 / sqrt(cs);
+    }
+    stats[4 + p + j] = inv;
+    xy_std[j] = xy[j] * inv;
+}
+int launch_big_gram_scales(hipStream_t s, const double *xx, const double *xy, int p, int standardize, double *stats, double *xy_std)
+{
+    hipLaunchKernelGGL(big_gram_scales_kernel, dim3((p + 255) / 256), dim3(256), 0, s, xx, xy, p, standardize, stats, xy_std);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
 int launch_big_wide_scales(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *xy, double *stats, double *xy_std)
 {
     hipLaunchKernelGGL(big_wide_scales_kernel, dim3((p + 3) / 4), dim3(256), 0, s, x, (long long)n, (long long)ld, p, xy, stats, xy_std);

@@ -2,6 +2,8 @@
 bounce slots, row blocks overlapped with the moment pass, rows over several devices inside the library (here: the same device
 several times -- this pool has one GPU per box), penalties dealt to devices, cached contexts, caller interrupts.
 All through the C ABI, against the CPU oracle."""
+import warnings
+
 import numpy as np
 import pytest
 
@@ -393,3 +395,61 @@ def _xtx_problem_host(p, n, seed):
     b = np.zeros(p); b[:25] = rng.uniform(-1, 1, 25)
     y = x @ b + rng.normal(size=n)
     return x.T @ x / n, x.T @ y / n
+
+
+@pytest.mark.parametrize("engine", ["wres", "wcoop", "wstream", "symcoop", "rowcoop", "coop"])
+def test_interrupt_reaches_a_persistent_launch(oa, engine):
+    """The persistent engines run the whole penalty x lambda path in ONE kernel (config 4: 23 ms; p >= n at maxit: seconds), and the
+    reference polls for user interrupts every third lambda (ref src/oem_dense.cpp:235-238).  With an interrupt callback the kernel gets
+    an abort word in host-coherent memory: the host waits for the launch by polling the stream and the callback (calling thread only),
+    sets the word when the callback fires, every workgroup sees it within 128 iterations or inside the exchange it is waiting in, and
+    the call returns OEMGPU_ERR_INTERRUPTED -- here within 50 ms of the callback's first True, out of a call that would run for
+    seconds.  The context is as good as new: the next call returns the bits of the call before."""
+    import threading
+    import time
+    import torch
+    from oem_amd import _lib as L
+    rng = np.random.default_rng(17)
+    if engine in ("wres", "wcoop", "wstream"):
+        n, p = {"wres": (500, 20000), "wcoop": (500, 2500), "wstream": (64, 100_000)}[engine]
+        x = np.asfortranarray(rng.normal(size=(n, p)))
+        y = x[:, :10] @ rng.uniform(1.0, 2.0, 10) + rng.normal(size=n)
+        xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
+        pens = ["lasso"] if engine == "wres" else ["lasso", "mcp"]
+        call = lambda **kw: oa.oem(xd, y, penalty=pens, standardize=False, intercept=False, **kw)
+    else:
+        p = {"symcoop": 4096, "rowcoop": 2048, "coop": 1000}[engine]
+        x = rng.normal(size=(p + p // 2, p))
+        y = x[:, :25] @ rng.uniform(-1, 1, 25) + rng.normal(size=x.shape[0])
+        xtx = torch.as_tensor(x.T @ x / x.shape[0], device="cuda")
+        xty = x.T @ y / x.shape[0]
+        call = lambda **kw: oa.oem_xtx(xtx, xty, penalty="lasso", **kw)
+    small = dict(nlambda=4, tol=1e-8, maxit=300)
+    long_ = dict(nlambda=100, tol=0.0, maxit=5000, lambda_min_ratio=1e-4)      # tol 0: every lambda runs into maxit -- seconds of iterations
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        before = call(**small)
+        assert oa.last_path_engine()[0] == engine
+        state = {"t0": None, "fired": None, "calls": 0, "tids": set()}
+
+        def poll():
+            now = time.perf_counter()
+            state["calls"] += 1
+            state["tids"].add(threading.get_ident())
+            if state["t0"] is None:
+                state["t0"] = now
+            if now - state["t0"] >= 0.1 and state["fired"] is None:
+                state["fired"] = now
+            return state["fired"] is not None
+        with pytest.raises(oa.OemgpuError) as e:
+            call(interrupt=poll, **long_)
+        t_back = time.perf_counter()
+        assert e.value.code == L.ERR_INTERRUPTED
+        assert oa.last_path_engine()[0] == engine                  # (it was the persistent launch that was interrupted, not a fallback)
+        assert state["fired"] is not None and t_back - state["fired"] <= 0.05, t_back - state["fired"]
+        assert state["tids"] == {threading.get_ident()} and state["calls"] >= 50       # polled about once per millisecond, on the calling thread only
+        after = call(**small)
+        again = call(interrupt=lambda: False, **small)             # (a callback that never fires changes nothing)
+    for k in range(len(before["beta"])):
+        assert np.array_equal(np.asarray(before["beta"][k]), np.asarray(after["beta"][k])) and np.array_equal(before["niter"][k], after["niter"][k])
+        assert np.array_equal(np.asarray(before["beta"][k]), np.asarray(again["beta"][k]))

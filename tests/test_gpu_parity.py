@@ -797,9 +797,10 @@ def test_wide_fused_group_kernel(oa, n, p, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,p", [(40, 100), (200, 1030), (300, 2500), (120, 9000)])
+@pytest.mark.parametrize("n,p,route", [(40, 100, "chosen"), (64, 600, "chosen"), (200, 1030, "chosen"), (300, 2500, "chosen"), (120, 9000, "chosen"),
+                                       (40, 100, "two products"), (64, 600, "two products")])
 @pytest.mark.parametrize("standardize", [False, True])
-def test_big_and_sparse_wide_branch_without_an_intercept(oa, n, p, standardize):
+def test_big_and_sparse_wide_branch_without_an_intercept(oa, n, p, route, standardize, monkeypatch):
     """big.oem() and oem() on a sparse x with nobs <= nvars and intercept = FALSE (ref src/oem_big.h:537-541, 568-584, 743-764,
     880-897; src/oem_sparse.h:607-612, 638-647; VERDICT r3: refused until round 4): the reference iterates on the data as they
     are, takes lambda_zero from the scaled X'y and returns beta colsq_inv -- the wide engines on the DataStd-flag-0 copy with the
@@ -807,9 +808,12 @@ def test_big_and_sparse_wide_branch_without_an_intercept(oa, n, p, standardize):
     conditions, tests/test_oracle_independent.py): element-wise and group penalties, row shards, a sparse x.  With an intercept
     the reference's expression is ill-formed: refused, with the reason."""
     import scipy.sparse as sp
+    if route == "two products":                                     # (round 5: the library takes the Gram form of the same iteration where
+        monkeypatch.setenv("OEM_WIDE", "1")                         #  that is faster -- p <= 1024 -- as it does for oemDense; this forces the other)
     rng = np.random.default_rng(n + p)
     x = rng.normal(size=(n, p)) * rng.uniform(0.5, 3.0, p)
     x[rng.random((n, p)) < 0.7] = 0.0
+    x[:, 5] = 0.0                                                   # (a column of zeros: colsq falls back to 1, ref src/oem_big.h:757-760)
     x = np.asfortranarray(x)
     b = np.zeros(p); b[:6] = rng.uniform(1, 2, 6)
     y = x @ b + 0.5 * rng.normal(size=n)
