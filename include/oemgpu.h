@@ -309,9 +309,25 @@ void oemgpu_release_cache(void);
  * and never more sets than the exchange scratch was sized for; otherwise +/- the offending workgroup count. */
 int oemgpu_selftest_wcoop_sizing(int32_t n, int32_t p, int32_t npen, int32_t num_cu);
 
+/* Host-only self-check of the engine PLAN (pure arithmetic, runs without a GPU): what api.hip: plan_paths decides for a call with
+ * these sizes and options on a device of num_cu CUs -- *engine = the OEMGPU_ENGINE_* of the first attempt -- and whether the
+ * buffers the callers size hold what the launch will carve: *frame_bytes (outputs + parameter blob + engine workspace) against
+ * *reserved_bytes, and for p >= n (wide_n > 0 rows, no Gram matrix) the persistent engine's exchange buffers against the scratch
+ * (*scratch_need_doubles <= *scratch_have_doubles).  p: columns of x; q: dimension of beta (p + 1 with big.oem's intercept);
+ * semantics: OEMGPU_SEM_* (2: oem.xtx). */
+int oemgpu_selftest_plan(int32_t p, int32_t q, int32_t semantics, int32_t intercept, const oemgpu_opts *o, int32_t has_scale, int32_t nbatch,
+                         int64_t wide_n, int32_t num_cu, int32_t *engine, int64_t *frame_bytes, int64_t *reserved_bytes,
+                         int64_t *scratch_need_doubles, int64_t *scratch_have_doubles);
+
 /* Self-test aid (tests/test_gpu_host.py): enqueue, on the context's stream, `blocks` workgroups that each occupy a whole CU and
  * spin for `ms` milliseconds -- "somebody else holds the CUs", for the fallback of the persistent engines.  Asynchronous. */
 int oemgpu_selftest_hold_cus(oemgpu_ctx *ctx, int32_t blocks, double ms);
+
+/* The OEM_* / OEMGPU_* environment switches (engine selection for tests, knobs of the host-resident upload; none is needed in
+ * production: DESIGN.md section 7b) are parsed ONCE, at the first call into the library.  oemgpu_reload_switches() parses the
+ * environment again (tests); oemgpu_switch_names() is the space-separated list of every name the library reads. */
+void        oemgpu_reload_switches(void);
+const char *oemgpu_switch_names(void);
 
 const char *oemgpu_last_error(void);
 const char *oemgpu_version(void);

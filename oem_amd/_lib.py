@@ -89,6 +89,10 @@ _SIGS = {
     "oemgpu_release_cache": (None, []),
     "oemgpu_selftest_hold_cus": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "oemgpu_selftest_wcoop_sizing": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "oemgpu_selftest_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
+                             C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "oemgpu_reload_switches": (None, []),
+    "oemgpu_switch_names": (C.c_char_p, []),
     "oemgpu_last_error": (C.c_char_p, []),
     "oemgpu_version": (C.c_char_p, []),
     "oemgpu_device_count": (C.c_int, []),
@@ -118,6 +122,13 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def reload_switches():
+    """The OEM_* / OEMGPU_* environment switches are parsed once, at the first call into the library (include/oemgpu.h); a test that
+    changes one calls this (tests/conftest.py does it behind every monkeypatch.setenv / delenv).  A no-op while the library is not loaded."""
+    if _lib is not None:
+        _lib.oemgpu_reload_switches()
 
 
 def check(rc):

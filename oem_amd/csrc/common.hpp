@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/oemgpu.h"
+#include "switches.hpp"
 
 namespace oemgpu {
 
@@ -255,6 +256,7 @@ int path_wcoop_cpg(int n);                                        // columns per
 int path_wcoop_max_workgroups(int n, int p);                     // ... of a partition cut at group boundaries, at most
 int path_wcoop_sets(int n, int p, int npen, int num_cu, int G = 0);   // workgroup sets side by side, one penalty each (G: of a cut partition)
 size_t path_wcoop_xchg_doubles(int n, int p);
+size_t path_wcoop_launch_doubles(int n, int p, int G, int sets);
 bool path_wcoop_eligible(const PathArgs &a, const WideArgs &w);
 int launch_path_wcoop(hipStream_t s, const PathArgs &a, const WideArgs &w, int sets, const int *cstart = nullptr, int G = 0);   // cstart (device, G + 1 ints): columns cut at group boundaries
 // the same where Xs does not fit the registers: G persistent workgroups re-read their column tiles every iteration (path_wcoop.hip: path_wstream_kernel)

@@ -59,6 +59,12 @@ struct oemgpu_ctx {
     size_t blob_bytes = 0;
     const char *blob_dev = nullptr;   // where the last parameter blob was uploaded (run_paths skips an identical upload)
     size_t blob_len = 0;
+    // A persistent engine that timed out (somebody else holds the CUs) is not tried again at once: the next `persistent_skip` calls
+    // that would take one -- for at most 30 s -- go straight to the launch-per-iteration engines; the count doubles (4 .. 64) with every
+    // further timeout and starts over after a persistent launch that came back (or when the switches are read again).
+    int persistent_backoff = 0, persistent_skip = 0;
+    double persistent_skip_until = 0.0;        // steady-clock seconds
+    unsigned sw_generation = 0;                // Switches::generation this state belongs to
     int *abort_host = nullptr;     // the abort word of the persistent path engines (PathArgs::abort_word): one int of host-coherent pinned memory,
     int *abort_dev = nullptr;      // mapped into the device; allocated by the first call that has an interrupt callback
     bool cached = false;           // owned by the process-wide cache (oemgpu_release_cache frees it)

@@ -1268,7 +1268,6 @@ GramPlan gram_plan(int64_t n, int p, int num_cu)
     if (pl.tri) {
         pl.nblk = 1;
         int64_t c = nsteps < num_cu ? nsteps : num_cu;
-        if (const char *e = getenv("OEM_TRI_ROUNDS")) { const int r = atoi(e); if (r > 1 && nsteps >= (int64_t)num_cu * r) c = (int64_t)num_cu * r; }   // experiment knob
         if (c < 1) c = 1;
         pl.steps = (int)((nsteps + c - 1) / c);
         if (pl.steps < 1) pl.steps = 1;
@@ -1299,10 +1298,6 @@ GramPlan gram_plan(int64_t n, int p, int num_cu)
             if (cc >= nsteps) break;
         }
         pl.steps = (int)((nsteps + c - 1) / c);
-        if (const char *e = getenv("OEM_BLK_STEPS")) {          // experiment knob: rows per chunk = 64 * steps
-            const int st = atoi(e);
-            if (st > 0 && st < pl.steps) { pl.steps = st; c = ((nsteps + st - 1) / st + 7) / 8 * 8; }
-        }
         if (pl.steps < 1) pl.steps = 1;
         pl.nchunk = (int)c;
     }
@@ -1355,7 +1350,7 @@ static int launch_gram_t(hipStream_t s, const GramPlan &pl, const double *x, con
         default: set_error("gram: bad tile count %d", pl.ntc); return OEMGPU_ERR_INTERNAL;
         }
     } else {
-        if (ALIGNED && a.n >= 64 && !getenv("OEM_GRAM_BLK") && (double)a.ld * 16.0 * 8.0 < 4294967296.0) {   // 32-bit lane offsets within a tile
+        if (ALIGNED && a.n >= 64 && (double)a.ld * 16.0 * 8.0 < 4294967296.0) {   // 32-bit lane offsets within a tile
             const int nsb = (pl.ntc + 7) / 8, nsblk = nsb * (nsb + 1) / 2;
             const size_t shb = (size_t)SB_NSLOT * 16 * 1024;                // NSLOT x 16 KiB slots
             OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
@@ -1509,7 +1504,7 @@ __global__ __launch_bounds__(1024) void moments_reduce_kernel(const double *__re
 int launch_moments_reduce(hipStream_t s, const GramPlan &pl, const double *tpart, const double *vpart, double *moments)
 {
     const int nvblk = pl.tri ? 0 : (32 * pl.ntc + 4 + 255) / 256;
-    if (pl.tri && pl.nchunk >= 64 && !getenv("OEM_NO_REDUCE_SPLIT")) {        // all tiles cover Z: no vector partials
+    if (pl.tri && pl.nchunk >= 64) {        // all tiles cover Z: no vector partials
         hipLaunchKernelGGL(moments_reduce_split_kernel<4>, dim3(pl.ntile * 4), dim3(1024), 0, s, tpart, pl.p, pl.ntile, pl.nchunk, moments);
         OEM_HIP(hipGetLastError());
         return 0;

@@ -69,13 +69,7 @@ public:
     }
 };
 
-size_t env_size(const char *name, size_t dflt)
-{
-    const char *e = getenv(name);
-    if (!e || !*e) return dflt;
-    const long long v = atoll(e);
-    return v > 0 ? (size_t)v : dflt;
-}
+size_t env_size(const Switch &s, size_t dflt) { return (s.set && s.num > 0) ? (size_t)s.num : dflt; }
 
 int lanes_prepare(oemgpu_ctx *c, int T, size_t slot_bytes)
 {
@@ -165,7 +159,7 @@ int job_layout(DevJob &J, size_t resident_cap)
 {
     oemgpu_ctx *c = J.c;
     const int p = J.p;
-    const size_t block_bytes = env_size("OEMGPU_BLOCK_BYTES", (size_t)256 << 20);
+    const size_t block_bytes = env_size(sw().OEMGPU_BLOCK_BYTES, (size_t)256 << 20);
     const int64_t BR = block_rows(p, block_bytes, J.slot_bytes);
     J.blocks.clear();
     J.nrows = 0;
@@ -326,7 +320,7 @@ bool peers(int to, int from)
 {
     static std::mutex mu;
     static signed char known[64][64];                    // 0 unknown, 1 yes, -1 no
-    static const bool never = getenv("OEMGPU_NO_PEER") != nullptr;
+    const bool never = sw().OEMGPU_NO_PEER.set;
     if (never) return false;
     if (to == from) return true;
     if (to < 0 || from < 0 || to >= 64 || from >= 64) return false;
@@ -457,7 +451,7 @@ int solve_summed(std::vector<DevJob> &J, bool with_sums, int p, int sem, int sta
 {
     const int G = (int)J.size();
     const int q = p + ((sem != OEMGPU_SEM_DENSE && intercept) ? 1 : 0);
-    const bool split = G > 1 && o->npen > 1 && q > SMALL_P_MAX && !getenv("OEMGPU_NO_PENALTY_SPLIT");
+    const bool split = G > 1 && o->npen > 1 && q > SMALL_P_MAX && !sw().OEMGPU_NO_PENALTY_SPLIT.set;
     if (!split) {
         OEM_HIP(hipSetDevice(J[0].c->device));
         return oemgpu_solve_moments_dev(J[0].c, J[0].msum, with_sums ? J[0].ssum : nullptr, p, sem, standardize, intercept, o, beta, lambda_out,
@@ -510,9 +504,9 @@ int host_fit(const std::vector<HostPiece> &all, int64_t n, int32_t p, int sem, i
     int rc = device_list(o, dev);
     if (rc) return rc;
     const int G = (int)dev.size();
-    int T = o->upload_threads > 0 ? o->upload_threads : (int)env_size("OEMGPU_UPLOAD_THREADS", 8);
+    int T = o->upload_threads > 0 ? o->upload_threads : (int)env_size(sw().OEMGPU_UPLOAD_THREADS, 8);
     if (T > 64) T = 64;
-    const size_t slot_bytes = env_size("OEMGPU_SLOT_BYTES", (size_t)4 << 20) / 4096 * 4096 + 4096;
+    const size_t slot_bytes = env_size(sw().OEMGPU_SLOT_BYTES, (size_t)4 << 20) / 4096 * 4096 + 4096;
     std::vector<DevJob> J(G);
     std::atomic<int> stop{0};
     std::vector<oemgpu_ctx *> held;
@@ -533,7 +527,7 @@ int host_fit(const std::vector<HostPiece> &all, int64_t n, int32_t p, int sem, i
         J[g].c = c; J[g].p = p; J[g].T = T; J[g].slot_bytes = slot_bytes; J[g].o = o; J[g].stop = &stop; J[g].poll = g == 0;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { free_b = total_b = (size_t)64 << 30; }
-        size_t cap = env_size("OEMGPU_RESIDENT_BYTES", total_b / 2);
+        size_t cap = env_size(sw().OEMGPU_RESIDENT_BYTES, total_b / 2);
         if (cap > free_b + c->xres_bytes) cap = free_b + c->xres_bytes;
         if ((rc = lanes_prepare(c, T, slot_bytes)) != 0 || (rc = job_layout(J[g], cap)) != 0) { release_all(); return rc; }
     }
@@ -627,9 +621,9 @@ int host_upload_resident(oemgpu_ctx *c, const double *x, int64_t n, int32_t p, c
 {
     DevJob J;
     J.c = c; J.p = p; J.o = o; J.contiguous = true; J.tight = tight;
-    J.T = (o && o->upload_threads > 0) ? o->upload_threads : (int)env_size("OEMGPU_UPLOAD_THREADS", 8);
+    J.T = (o && o->upload_threads > 0) ? o->upload_threads : (int)env_size(sw().OEMGPU_UPLOAD_THREADS, 8);
     if (J.T > 64) J.T = 64;
-    J.slot_bytes = env_size("OEMGPU_SLOT_BYTES", (size_t)4 << 20) / 4096 * 4096 + 4096;
+    J.slot_bytes = env_size(sw().OEMGPU_SLOT_BYTES, (size_t)4 << 20) / 4096 * 4096 + 4096;
     HostPiece P; P.x = x; P.ldx = ldx > 0 ? ldx : n; P.y = y; P.rows = n;
     J.pieces.push_back(P);
     int rc = lanes_prepare(c, J.T, J.slot_bytes);

@@ -225,15 +225,14 @@ template <int KIND> __device__ __forceinline__ double thr1(double u, double tp, 
 }
 
 template <int CH>
-__global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_, int stride)
+__global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_)
 {
-    if (blockIdx.x % stride != 0) return;                       // stride 8: the working workgroups share one XCD (speed only)
     const PathArgs A = path_instance(A_);
     typedef CoopCfg<CH> C;
     constexpr int EPT = C::EPT;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l16 = lane & 15, grp = lane >> 4;
-    const int q = A.p, wg = blockIdx.x / stride;
+    const int q = A.p, wg = blockIdx.x;
     const unsigned long long t_cyc0 = __builtin_amdgcn_s_memtime(), t_rt0 = __builtin_amdgcn_s_memrealtime();
     double *Ush = lds + C::OFF_U, *Bsh = lds + C::OFF_B, *F = lds + C::OFF_F, *GW = lds + C::OFF_GW;
     double *Tal = lds + C::OFF_T, *Tbe = Tal + CML, *red = lds + C::OFF_R, *Pc = lds + C::OFF_P;
@@ -697,13 +696,13 @@ size_t path_coop_xchg_bytes() { return (size_t)2 * 1024 * 2 * sizeof(unsigned lo
 // OEM_COOP_MIN_Q: experiment knob (never below 129).
 int path_coop_min_q(bool has_groups)
 {
-    static const int v = [] { const char *e = getenv("OEM_COOP_MIN_Q"); const int k = e ? atoi(e) : 0; return k >= 129 ? k : 0; }();
+    const int v = (sw().OEM_COOP_MIN_Q.set && sw().OEM_COOP_MIN_Q.num >= 129) ? (int)sw().OEM_COOP_MIN_Q.num : 0;
     return v ? v : (has_groups ? COOP_MIN_Q_GROUPS : COOP_MIN_Q);
 }
 
 bool path_coop_eligible(int q, bool has_sinv, bool compute_loss, int ngroups, int nbatch)
 {
-    if (getenv("OEM_NO_COOP") || q < path_coop_min_q(ngroups > 0) || q > 1024) return false;      // OEM_NO_COOP: the launch-per-iteration engines
+    if (sw().OEM_NO_COOP.set || q < path_coop_min_q(ngroups > 0) || q > 1024) return false;      // OEM_NO_COOP: the launch-per-iteration engines
     if (has_sinv && compute_loss) return false;          // the loss of the un-rescaled member would need a product of its own
     if (ngroups > (q <= 512 ? 512 : 1024)) return false;
     (void)nbatch;                                        // nbatch > 1: the caller checks that all workgroup sets fit (api.hip: run_paths)
@@ -717,7 +716,6 @@ int launch_path_coop(hipStream_t s, const PathArgs &a_)
     PathArgs a = a_;
     const int q = a.p;
     a.lanczos_steps = q < CML ? q : CML;
-    static const int stride = getenv("OEM_COOP_STRIDE") ? atoi(getenv("OEM_COOP_STRIDE")) : 1;
     const int ninst = (a.nbatch > 1 ? a.nbatch : 1) * (a.pen_split ? a.npen : 1);
     if (ninst > 1 && (size_t)a.bs_work * 8 < path_coop_xchg_bytes()) { set_error("internal: coop work stride"); return OEMGPU_ERR_INTERNAL; }
     OEM_HIP(hipMemsetAsync(a.work, 0, (ninst > 1 ? (size_t)a.bs_work * 8 : path_coop_xchg_bytes()) * ninst, s));     // granule tags must start at 0
@@ -730,16 +728,16 @@ int launch_path_coop(hipStream_t s, const PathArgs &a_)
         const int W = (q + C::RW - 1) / C::RW;
         const size_t sh = (size_t)C::N_DBL * sizeof(double);
         if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_coop_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL((path_coop_kernel<2>), dim3(W * stride, ninst), dim3(NTH), sh, s, a, stride);
+        hipLaunchKernelGGL((path_coop_kernel<2>), dim3(W, ninst), dim3(NTH), sh, s, a);
     } else {
         typedef CoopCfg<4> C;
         const int W = (q + C::RW - 1) / C::RW;
         const size_t sh = (size_t)C::N_DBL * sizeof(double);
         if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_coop_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL((path_coop_kernel<4>), dim3(W * stride, ninst), dim3(NTH), sh, s, a, stride);
+        hipLaunchKernelGGL((path_coop_kernel<4>), dim3(W, ninst), dim3(NTH), sh, s, a);
     }
     OEM_HIP(hipGetLastError());
-    if (getenv("OEM_WCOOP_FAKE_TIMEOUT") && ninst == 1) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
+    if (sw().OEM_WCOOP_FAKE_TIMEOUT.set && ninst == 1) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
     return 0;
 }
 

@@ -1123,13 +1123,13 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     // fused steps (one launch each) ping-pong between two copies of (v, v_prev, w) kept in their own area
     // (measured at q = 4096: 35.7 us fused vs 23.8 + 7.9 + a boundary -- the replicated reductions over q numbers sit in
     // front of the stream -- so the fused step is used where the launch count dominates)
-    const bool lz_fused = q <= 1024 && !getenv("OEM_NO_FUSED");
+    const bool lz_fused = q <= 1024 && !sw().OEM_NO_FUSED.set;
     const bool lz_full = (q == 512 || q == 1024 || q == 2048 || q == 4096) && (((uintptr_t)a.xx) & 15) == 0;
     double *LZ = T + 2 * MAXL + 64 + 16 + 2 * (size_t)(q + 8) + FMAXB + 16 + 2 * (size_t)(q + 8);
     double *Vc = LZ, *Vp = LZ + 2 * (size_t)(q + 8), *Wb = LZ + 4 * (size_t)(q + 8);
     double *SP = LZ + 6 * (size_t)(q + 8);             // symmetric-tile engine: partial vectors P[2][q / 128][q]
     // XX is symmetric: for q = 2048 / 4096 the products read its lower triangle only (symgemv_kernel, oem_symfused_kernel)
-    const bool sym_ok = (q == 2048 || q == 4096) && (((uintptr_t)a.xx) & 15) == 0 && !getenv("OEM_NO_SYM") && !getenv("OEM_NO_FUSED");
+    const bool sym_ok = (q == 2048 || q == 4096) && (((uintptr_t)a.xx) & 15) == 0 && !sw().OEM_NO_SYM.set && !sw().OEM_NO_FUSED.set;
     auto sym_gemv = [&](const double *vec, double *out) {
         if (q == 2048) {
             hipLaunchKernelGGL((symgemv_kernel<16>), dim3(sym_nwg(16)), dim3(256), 0, s, a.xx, vec, SP);
@@ -1197,7 +1197,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
 
     // ---- fused engine when the operators are row-local and nothing needs a global sum per iteration
     const bool fused_ok = a.ngroups == 0 && !a.accelerate && !a.compute_loss && !a.sinv && (q == 512 || q == 1024 || q == 2048 || q == 4096) &&
-                          (((uintptr_t)a.xx) & 15) == 0 && !getenv("OEM_NO_FUSED");
+                          (((uintptr_t)a.xx) & 15) == 0 && !sw().OEM_NO_FUSED.set;
     if (fused_ok) {
         double *fbase = T + 2 * MAXL + 64;
         FState *S = reinterpret_cast<FState *>(fbase);
@@ -1206,9 +1206,9 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         int *flags = reinterpret_cast<int *>(Bv + 2 * (size_t)(q + 8));
         int blocks = (q + 3) / 4;
         if (blocks > num_cu * 2) blocks = num_cu * 2;
-        if (const char *e = getenv("OEM_FUSED_BLOCKS")) { const int b = atoi(e); if (b > 0) blocks = b < (q + 3) / 4 ? b : (q + 3) / 4; }   // experiment knob
+        if (sw().OEM_FUSED_BLOCKS.set) { const int b = (int)sw().OEM_FUSED_BLOCKS.num; if (b > 0) blocks = b < (q + 3) / 4 ? b : (q + 3) / 4; }   // experiment knob
         if (blocks > FMAXB) blocks = FMAXB;
-        const bool sym = sym_ok && sym_nwg(q / SYM_TB) <= FMAXB && !(q == 2048 && !getenv("OEM_SYM_2048"));
+        const bool sym = sym_ok && sym_nwg(q / SYM_TB) <= FMAXB && !(q == 2048 && !sw().OEM_SYM_2048.set);
         SState *SS = reinterpret_cast<SState *>(SP + 2 * (size_t)(q / SYM_TB) * q);      // behind the partial vectors (sym_part_doubles)
         static_assert(2 * sizeof(SState) <= 16 * sizeof(double), "SState[2] must fit the 16 spare doubles of the partial area");
         if (sym) hipLaunchKernelGGL(sym_init_kernel, dim3(1), dim3(1), 0, s, SS, a);
@@ -1256,7 +1256,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     }
 
     // ---- replicated-update fused engine: everything else at the same sizes
-    const bool rep_ok = q <= 4096 && !getenv("OEM_NO_FUSED");
+    const bool rep_ok = q <= 4096 && !sw().OEM_NO_FUSED.set;
     if (rep_ok) {
         double *fbase = T + 2 * MAXL + 64;
         int *fdone = reinterpret_cast<int *>(fbase + 8);
@@ -1976,10 +1976,10 @@ static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd
     hipLaunchKernelGGL(path_init_kernel, dim3(1), dim3(1024), 0, s, a, st, beta, d, theta, m, lz_capped ? 1 : 0);
     OEM_HIP(hipGetLastError());
     if (a.npen == 0) return 0;
-    const bool fused = a.ngroups == 0 && !a.accelerate && !a.compute_loss && !a.sinv && W <= FMAXB && !getenv("OEM_WIDE_GENERAL");
+    const bool fused = a.ngroups == 0 && !a.accelerate && !a.compute_loss && !a.sinv && W <= FMAXB;
     // group penalties whose groups are runs of neighbouring columns: the fused GROUP form (wide_groups_kernel), one launch + the reduction
     const bool gfused = !fused && a.ngroups > 0 && wd.grun_W > 0 && wd.grun_W <= W && wd.grun_W <= FMAXB && !a.accelerate && !a.compute_loss && !a.sinv &&
-                        !getenv("OEM_WIDE_GENERAL") && !getenv("OEM_WIDE_NO_GROUP_FUSED");
+                        !sw().OEM_WIDE_NO_GROUP_FUSED.set;
     const size_t ldsg = sizeof(double) * ((size_t)wide_nw(NR) * (size_t)npad + 2 * (size_t)wd.grun_cpw + (size_t)wide_nw(NR) * WIDE_GRUN_MAX);
     if (gfused && ldsg > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_groups_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
     double *uf = nullptr;

@@ -191,29 +191,7 @@ __device__ __forceinline__ void gemv_round(const double (&a)[R][CW], const doubl
     buf ^= 1;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Sliced form of the round (single workgroup, element-wise penalties).  Measured (tools/valu_probe.hip): with four
-// waves each broadcast-reading its CW vector entries, the LDS return path (128 B/clk per CU, a broadcast still returns
-// 64 x 16 B per ds_read_b128) costs ~400 cycles a round, on top of the strip's write->read round trip.  Here the
-// vector never passes through LDS: wave w keeps ONLY its own CW entries, NB = ceil(CW/16) per lane, replicated in
-// each of its four 16-lane rows (entry 16 j + (lane & 15) of the slice in register j), thresholds just those, and the
-// GEMV takes each entry straight from the neighbour lane with v_fmac_f64_dpp row_newbcast:k.  The partial sums
-// cross waves exactly as before (one LDS write, one barrier), and each lane reads back the NW partials of ITS
-// entries.  What used to be replicated per wave and now is not -- the stop rule -- rides along: every wave drops a
-// "some coefficient still moving" flag beside its partials and all waves OR the NW flags after the same barrier.
-// ------------------------------------------------------------------------------------------------
-template <int R, int CW, int NCH, int C> struct SliceFma {
-    template <int NB>
-    static __device__ __forceinline__ void run(double (&acc)[R][NCH], const double (&B)[NB], const double (&a)[R][CW])
-    {
-        if constexpr (C < CW) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) BcFma<(C & 15)>::fmac(acc[r][C % NCH], B[C >> 4], a[r][C]);
-            SliceFma<R, CW, NCH, C + 1>::run(acc, B, a);
-        }
-    }
-};
-
+// LDS words of a workgroup's cross-wave sums outside the round (cross_wave_sum)
 struct SliceLds {
     double *P;          // partials [2][NW][PR]
     int *flag;          // [2][NW][64]: every lane of wave w stores the wave's flag in its own word
@@ -221,78 +199,6 @@ struct SliceLds {
     double *sum;        // [NW]      (cross-wave scalar sums outside the round)
 };
 
-// one round: ab[j] = (M beta)[e_j] for this lane's entries e_j; returns the OR over waves of `moving`.
-// aux (USE_AUX): a wave-uniform partial that is summed over the waves in fixed order and returned through aux.
-template <int R, int NW, int CW, int NB, bool USE_AUX>
-__device__ __forceinline__ bool gemv_sliced(const double (&a)[R][CW], const double (&B)[NB], double (&ab)[NB],
-                                            const int (&eoff)[NB], bool moving, double &aux, const SliceLds &S, int w,
-                                            int lane, int &buf OEM_DIAG_ARGS)
-{
-    constexpr int PR = 64 * R, NCH = (R >= 2) ? 2 : 4;
-    OEM_STAMP(0);
-    const int any_mine = (__ballot(moving) != 0ull) ? 1 : 0;      // resolved in the shadow of the FMAs
-    double acc[R][NCH];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) acc[r][c] = 0.0;
-    double Bf[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) Bf[j] = B[j];
-    dpp_hazard_fence(Bf);                                       // VALU write of B -> DPP read: 2 wait states
-    SliceFma<R, CW, NCH, 0>::run(acc, Bf, a);
-    OEM_STAMP(1);
-    double *Pb = S.P + buf * NW * PR;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        double t = acc[r][0];
-#pragma unroll
-        for (int c = 1; c < NCH; ++c) t += acc[r][c];
-        Pb[w * PR + lane + 64 * r] = t;
-    }
-    // Stop flags ride beside the partials at (almost) no cost: every lane stores its wave's flag in a word of its
-    // own (no exec-masked branch), and after the barrier lane l reads ONE word of wave l mod NW -- a 256-byte read --
-    // and a wave-wide "any" replaces the OR of NW broadcast words.  (Measured, tools/valu_probe.hip: a lane-0 store
-    // plus a broadcast ds_read_b128 per lane cost 200-300 cycles a round.)
-    S.flag[(buf * NW + w) * 64 + lane] = any_mine;
-    if (USE_AUX && lane == 0) S.aux[buf * NW + w] = aux;
-    __syncthreads();
-    OEM_STAMP(2);
-    const int f = S.flag[(buf * NW + (lane & (NW - 1))) * 64 + lane];
-    double xs[NW];
-    if (USE_AUX) {
-#pragma unroll
-        for (int ww = 0; ww < NW; ++ww) xs[ww] = S.aux[buf * NW + ww];
-    }
-    // every read is issued before the first add: left alone, the scheduler trades registers for four serial LDS
-    // round trips (read, wait, add, read, ...), ~300 cycles a round
-    double t[NB][NW];
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int ww = 0; ww < NW; ++ww) t[j][ww] = Pb[ww * PR + eoff[j]];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-#pragma unroll
-        for (int h = 1; h < NW; h <<= 1)
-#pragma unroll
-            for (int ww = 0; ww + h < NW; ww += 2 * h) t[j][ww] += t[j][ww + h];
-        ab[j] = t[j][0];
-    }
-    if (USE_AUX) {
-#pragma unroll
-        for (int h = 1; h < NW; h <<= 1)
-#pragma unroll
-            for (int ww = 0; ww + h < NW; ww += 2 * h) xs[ww] += xs[ww + h];
-        aux = xs[0];
-    }
-    OEM_STAMP(3);
-    buf ^= 1;
-    return __any(f != 0);
-}
-
-// sum over the waves of a wave-uniform value (outside the round: loss); fixed order, identical in every wave.
 // Safe to reuse S.sum on every call: consecutive calls are separated by at least one round barrier.
 template <int NW>
 __device__ __forceinline__ double cross_wave_sum(double v, const SliceLds &S, int w, int lane)
@@ -359,63 +265,6 @@ __device__ __forceinline__ ThrK uniform_thr(const ThrK &c)
     u.gm1 = uniform_d(c.gm1); u.gamma = uniform_d(c.gamma); u.dsc = uniform_d(c.dsc); u.rdsc = uniform_d(c.rdsc); u.d = uniform_d(c.d);
     u.rd = uniform_d(c.rd);
     return u;
-}
-
-// The OEM iteration for one lambda in the sliced layout (same recurrence and stop rule as `iterate` below).
-template <int R, int NW, int CW, int NB, int KIND>
-__device__ __forceinline__ void iterate_sliced(const PathArgs &A, const PenK &K, double d, const double (&a)[R][CW],
-                                               const double (&xy)[NB], const double (&pf)[NB], const bool (&valid)[NB],
-                                               const int (&eoff)[NB], double (&beta)[NB], double (&bold)[NB],
-                                               double (&ab)[NB], double &ak, int &it, int &conv, const SliceLds &S,
-                                               int w, int lane, int &buf OEM_DIAG_ARGS)
-{
-    const ThrK c = thr_consts<KIND>(K, d);
-    double tp[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) tp[j] = pf[j] * K.L;
-    const double tol = A.tol;
-    const bool first_row = lane < 16;                               // the other three 16-lane rows hold replicas
-    OEM_STAMP(8);                       // per-lambda work since the last round (lambda, constants, stores)
-    for (;;) {
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            bold[j] = beta[j];
-            const double b = threshold1<KIND>(ab[j] + xy[j], tp[j], c);
-            beta[j] = valid[j] ? b : 0.0;
-        }
-        double aux = 0.0;
-        if (A.accelerate) {                                        // ref src/oem_dense.h:633-651
-            const double akp = ak;
-            ak = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak));
-            const double ratio = (akp - 1.0) / ak;
-            double adp = 0.0;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const double upd = beta[j], diff = upd - bold[j];
-                beta[j] = upd + ratio * diff;
-                adp += (beta[j] - upd) * diff;
-            }
-            aux = wave_sum(first_row ? adp : 0.0);
-        }
-        ++it;
-        // stop rule (ref src/utils.cpp:537-549; |(cur - prev) / prev| > tol written as |cur - prev| > tol |prev|)
-        bool moving = false;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const double cu = fabs(beta[j]), q = fabs(bold[j]);
-            const bool cn = cu > 1e-13, qn = q > 1e-13;
-            moving |= (cn != qn);
-            moving |= (cn && qn && fabs(beta[j] - bold[j]) > tol * q);
-        }
-        bool any;
-        if (A.accelerate) {
-            any = gemv_sliced<R, NW, CW, NB, true>(a, beta, ab, eoff, moving, aux, S, w, lane, buf OEM_DIAG_PASS);
-            if (aux > 0.0) ak = 1.0;
-        } else
-            any = gemv_sliced<R, NW, CW, NB, false>(a, beta, ab, eoff, moving, aux, S, w, lane, buf OEM_DIAG_PASS);
-        conv = !any;
-        if (conv || it >= A.maxit) break;
-    }
 }
 
 // The OEM iteration for one lambda (ref src/oem_base.h:90-110), specialised per operator so that the serial loop
@@ -683,21 +532,6 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
     const double lstep = nl > 1 ? (lhi - llo) / (double)(nl - 1) : 0.0;
     const bool lflip = fabs(lhi) < fabs(llo);
 
-    // ---- sliced layout (single workgroup): this lane's NB entries of the wave's column slice
-    constexpr bool CAN_SLICE = (G == 1);
-    constexpr int NB = (CW + 15) / 16;
-    int eoff[NB];
-    bool valid[NB];
-    double xyE[NB], pfE[NB], sinvE[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int loc = 16 * j + (lane & 15), e = w * CW + loc;
-        valid[j] = CAN_SLICE && loc < CW && e < p;
-        eoff[j] = valid[j] ? e : 0;
-        xyE[j] = valid[j] ? A.xy[e] : 0.0;
-        pfE[j] = valid[j] ? A.pf[e] : 0.0;
-        sinvE[j] = (valid[j] && A.sinv) ? A.sinv[e] : 1.0;
-    }
     SliceLds S;
     S.P = P;
     S.aux = lds + C::OFF_X + NW;
@@ -705,16 +539,12 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
     S.flag = reinterpret_cast<int *>(lds + C::OFF_X + 4 * NW);
 
     double beta[R], bold[R], ab[R];
-    double betaE[NB], boldE[NB], abE[NB];
     for (int pp = A.pen_lo; pp < A.pen_hi; ++pp) {
         const int pen = A.penalty[pp];
         const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
         const bool isnet = pen_is_net(pen);
-        const bool sliced = CAN_SLICE && pen_consts(pen, 1.0, d, A.alpha, A.gamma, A.tau).kind <= K_OLS;
 #pragma unroll
         for (int r = 0; r < R; ++r) { beta[r] = 0.0; ab[r] = 0.0; }     // cold start: A 0 = 0
-#pragma unroll
-        for (int j = 0; j < NB; ++j) { betaE[j] = 0.0; abE[j] = 0.0; }
         double ak = 1.0;
         // user-supplied lambdas are fetched one lambda ahead: a dependent global load costs 1-2 us on this serial chain
         double lam_next = A.user_lambda ? A.lambda_user[(size_t)pp * nl] : 0.0;
@@ -738,53 +568,12 @@ __global__ __launch_bounds__(NW * 64) void path_small_kernel(PathArgs A_)
             const PenK K = pen_consts(pen, il, d, A.alpha, A.gamma, A.tau);
             int it = 0, conv = 0;
             const size_t orow = ((size_t)pp * nl + i);
-            if constexpr (CAN_SLICE) {
-                if (sliced) {
-                    switch (K.kind) {
-                    case K_SOFT: iterate_sliced<R, NW, CW, NB, K_SOFT>(A, K, d, a, xyE, pfE, valid, eoff, betaE, boldE, abE, ak, it, conv, S, w, lane, buf OEM_DIAG_PASS); break;
-                    case K_MCP: iterate_sliced<R, NW, CW, NB, K_MCP>(A, K, d, a, xyE, pfE, valid, eoff, betaE, boldE, abE, ak, it, conv, S, w, lane, buf OEM_DIAG_PASS); break;
-                    case K_SCAD: iterate_sliced<R, NW, CW, NB, K_SCAD>(A, K, d, a, xyE, pfE, valid, eoff, betaE, boldE, abE, ak, it, conv, S, w, lane, buf OEM_DIAG_PASS); break;
-                    default: iterate_sliced<R, NW, CW, NB, K_OLS>(A, K, d, a, xyE, pfE, valid, eoff, betaE, boldE, abE, ak, it, conv, S, w, lane, buf OEM_DIAG_PASS); break;
-                    }
-                    // (the loss is taken in the coordinates of the iteration, before any in-place rescale)
-                    if (A.compute_loss) {
-                        // sum (Y - X beta)^2 through the Gram identity (ref src/oem_dense.h:759-770), see below
-                        double t = 0.0;
-#pragma unroll
-                        for (int j = 0; j < NB; ++j) t += betaE[j] * ((d * betaE[j] - abE[j]) - 2.0 * xyE[j]);
-                        t = wave_sum(lane < 16 ? t : 0.0);
-                        t = cross_wave_sum<NW>(t, S, w, lane);
-                        if (tid == 0 && writer) A.loss[orow] = yy + nobs * t;
-                    } else if (tid == 0 && writer) A.loss[orow] = 1e99;
-                    // oemXTX::get_beta rescales the member in place (ref src/oem_xtx.h:576-581, quirk Q5)
-                    if (A.sinv) {
-#pragma unroll
-                        for (int j = 0; j < NB; ++j) betaE[j] *= sinvE[j];
-                    }
-                    if (writer && lane < 16) {                      // every wave stores its own slice
-#pragma unroll
-                        for (int j = 0; j < NB; ++j)
-                            if (valid[j]) A.beta[orow * p + eoff[j]] = betaE[j];
-                    }
-                    if (tid == 0 && writer) A.niter[orow] = conv ? it : A.maxit + 1;   // ref src/oem_base.h:94-109
-                    if (A.sinv) {
-                        double none = 0.0;
-                        gemv_sliced<R, NW, CW, NB, false>(a, betaE, abE, eoff, false, none, S, w, lane, buf OEM_DIAG_PASS);
-                    }
-                    continue;
-                }
-            }
-            if constexpr (CAN_SLICE) {
-                // only the group operators take the replicated-vector form in a single workgroup
-                iterate<R, NW, CW, G, K_GRP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS);
-            } else {
-                switch (K.kind) {
-                case K_SOFT: iterate<R, NW, CW, G, K_SOFT>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
-                case K_MCP: iterate<R, NW, CW, G, K_MCP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
-                case K_SCAD: iterate<R, NW, CW, G, K_SCAD>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
-                case K_OLS: iterate<R, NW, CW, G, K_OLS>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
-                default: iterate<R, NW, CW, G, K_GRP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
-                }
+            switch (K.kind) {
+            case K_SOFT: iterate<R, NW, CW, G, K_SOFT>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
+            case K_MCP: iterate<R, NW, CW, G, K_MCP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
+            case K_SCAD: iterate<R, NW, CW, G, K_SCAD>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
+            case K_OLS: iterate<R, NW, CW, G, K_OLS>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
+            default: iterate<R, NW, CW, G, K_GRP>(A, K, d, a, xy, pf, gid, beta, bold, ab, ak, it, conv, P, Uw, Fw, gstart, gidx, gzero, ng, w, lane, buf, X OEM_DIAG_PASS); break;
             }
             // the loss belongs to the coordinates the iteration ran in: before any in-place rescale (oemSparse takes it after
             // get_beta, where the rescaled intercept slot gives the same fitted values, ref src/oem_sparse.h:897-944)
@@ -1497,14 +1286,13 @@ extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read(unsigned 
 
 bool path_small_takes_rows(const PathArgs &a)
 {
-    return (a.ngroups == 0 || !getenv("OEM_NO_ROWS_GROUPS")) && a.p <= 208 && !(a.p > 128 && getenv("OEM_NO_ROWS8"));
+    return a.p <= 208;
 }
 
 int launch_path_small(hipStream_t s, const PathArgs &a)
 {
     // p <= 208: the row-split form (beta all-gather, permlane reduce-scatter; group operators exchange u as well); four waves
-    // up to p = 128, eight (two per SIMD, 256 VGPRs each: a[2][CG] must leave room) beyond.  OEM_NO_ROWS_GROUPS: calls with a
-    // group penalty on the replicated / sliced kernels below, as before round 2 (the tests hold the two against each other)
+    // up to p = 128, eight (two per SIMD, 256 VGPRs each: a[2][CG] must leave room) beyond.
     if (path_small_takes_rows(a)) {
         if (a.p <= 32) return launch_rows<4, 8>(s, a);
         if (a.p <= 64) return launch_rows<4, 16>(s, a);
@@ -1517,15 +1305,10 @@ int launch_path_small(hipStream_t s, const PathArgs &a)
         if (a.p <= 176) return launch_rows<8, 44>(s, a);
         return launch_rows<8, 44, 8>(s, a);
     }
-    // 4 waves (one per SIMD), CW = columns per wave rounded up to an even count: all CW/2 broadcast reads fit in
-    // registers next to the matrix slice, so a round exposes the LDS latency once.
-    if (a.p <= 32) return launch_cfg<1, 4, 8>(s, a);
-    if (a.p <= 64) return launch_cfg<1, 4, 16>(s, a);
-    if (a.p <= 80) return launch_cfg<2, 4, 20>(s, a);
-    if (a.p <= 104) return launch_cfg<2, 4, 26>(s, a);
-    if (a.p <= 128) return launch_cfg<2, 4, 32>(s, a);
-    if (a.p <= 160) return launch_cfg<3, 8, 20>(s, a);
-    if (a.p <= 192) return launch_cfg<3, 8, 24>(s, a);
+    // 208 < p <= 288 that the cooperating engine (path_coop.hip) does not take -- scale.factor together with compute.loss, or the
+    // engine switched off: four cooperating workgroups of eight waves, every wave with the whole vector.  (Until round 5 this kernel
+    // also had single-workgroup forms for p <= 192 -- replicated for group penalties, "sliced" for element-wise ones -- that nothing
+    // but two A/B switches could reach since the row-split kernel took every penalty in round 2: removed)
     if (a.p <= 256) return launch_cfg<4, 8, 8, 4>(s, a);          // four cooperating workgroups, 64 columns each
     if (a.p <= 288) return launch_cfg<5, 8, 10, 4>(s, a);         // ... 80 column slots each (CW must be even): big.oem's p = 256 + intercept lands here
     set_error("path_small: p = %d exceeds %d", a.p, SMALL_P_MAX);

@@ -1075,7 +1075,7 @@ extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read_rowcoop(u
 // 1024 < q <= 2048, element-wise penalties: the one-exchange row-split form (OEM_NO_ROWCOOP=1: the symmetric engine)
 bool path_rowcoop_eligible(const PathArgs &a, bool group_penalty)
 {
-    if (getenv("OEM_NO_ROWCOOP") || getenv("OEM_NO_SYMCOOP") || getenv("OEM_NO_COOP")) return false;
+    if (sw().OEM_NO_ROWCOOP.set || sw().OEM_NO_SYMCOOP.set || sw().OEM_NO_COOP.set) return false;
     if (a.p <= 1024 || a.p > RQ || a.nbatch > 1 || a.pen_split) return false;
     return !(a.sinv || group_penalty || a.accelerate);
 }
@@ -1089,7 +1089,7 @@ int launch_path_rowcoop(hipStream_t s, const PathArgs &a, void *xchg)
     if (int rc = lds_limit_once(reinterpret_cast<const void *>(&path_rowcoop_kernel), sh)) return rc;
     hipLaunchKernelGGL(path_rowcoop_kernel, dim3(path_rowcoop_workgroups(a.p)), dim3(SNTH), sh, s, a, reinterpret_cast<unsigned long long *>(xchg));
     OEM_HIP(hipGetLastError());
-    if (getenv("OEM_WCOOP_FAKE_TIMEOUT")) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
+    if (sw().OEM_WCOOP_FAKE_TIMEOUT.set) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
     return 0;
 }
 
@@ -1119,7 +1119,7 @@ static bool symcoop_plan_per(int q, int gmax, SymcoopPlan &P, const int *runs, i
     const int T = (q + 63) / 64, ntile = T * (T + 1) / 2;
     int NT = 0;
     for (int nt = 1; nt <= 3; ++nt) if ((ntile + 4 * nt - 1) / (4 * nt) <= gmax) { NT = nt; break; }
-    if (const char *e = getenv("OEM_SYMCOOP_NT")) { const int k = atoi(e); if (k >= 1 && k <= 3 && (ntile + 4 * k - 1) / (4 * k) <= gmax) NT = k; }   // experiments
+    if (sw().OEM_SYMCOOP_NT.set) { const int k = (int)sw().OEM_SYMCOOP_NT.num; if (k >= 1 && k <= 3 && (ntile + 4 * k - 1) / (4 * k) <= gmax) NT = k; }   // experiments
     if (!NT) return false;
     const int a = NT == 3 ? 3 : 2;
     int per = 4 * NT;                                                // tiles per workgroup
@@ -1238,11 +1238,11 @@ size_t symcoop_xchg_bytes_max(int q)
 // OEM_NO_SYMCOOP=1: the launch-per-iteration engines
 bool path_symcoop_eligible(const PathArgs &a, bool group_penalty, bool plan_has_runs)
 {
-    if (getenv("OEM_NO_SYMCOOP") || getenv("OEM_NO_COOP")) return false;
+    if (sw().OEM_NO_SYMCOOP.set || sw().OEM_NO_COOP.set) return false;
     if (a.p <= 1024 || a.p > 4096 || a.nbatch > 1 || a.pen_split) return false;
     if (a.sinv) return false;                            // (scale.factor rescales the iterate in place at every lambda: path_large.hip's replicated update)
     if (group_penalty && !plan_has_runs) return false;   // (groups that are not runs of <= 32 neighbouring coordinates: the same)
-    if ((group_penalty || a.accelerate || a.compute_loss) && getenv("OEM_SYMCOOP_NO_GENERAL")) return false;
+    if ((group_penalty || a.accelerate || a.compute_loss) && sw().OEM_SYMCOOP_NO_GENERAL.set) return false;
     return true;
 }
 
@@ -1267,7 +1267,7 @@ int launch_path_symcoop(hipStream_t s, const PathArgs &a_, const SymcoopPlan &P,
     }
 #undef SX_LAUNCH
     OEM_HIP(hipGetLastError());
-    if (getenv("OEM_WCOOP_FAKE_TIMEOUT")) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
+    if (sw().OEM_WCOOP_FAKE_TIMEOUT.set) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
     return 0;
 }
 

@@ -1479,7 +1479,7 @@ template <int NR> int wstream_launch(hipStream_t s, const PathArgs &a, const Wid
     if (sh > 64 * 1024 && lds_limit_once(reinterpret_cast<const void *>(&path_wstream_kernel<NR>), sh)) return OEMGPU_ERR_HIP;
     hipLaunchKernelGGL((path_wstream_kernel<NR>), dim3(G), dim3(WNTH), sh, s, a, wd.xs, wd.ys, wd.n, reinterpret_cast<unsigned long long *>(wd.scratch), nch);
     OEM_HIP(hipGetLastError());
-    if (getenv("OEM_WCOOP_FAKE_TIMEOUT")) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
+    if (sw().OEM_WCOOP_FAKE_TIMEOUT.set) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
     return 0;
 }
 
@@ -1496,7 +1496,7 @@ template <int NR, bool GEN, bool ACC> int wcoop_launch_as(hipStream_t s, const P
     hipLaunchKernelGGL((path_wcoop_kernel<NR, GEN, ACC>), dim3(G, sets), dim3(WNTH), sh, s, a, wd.xs, wd.ys, wd.n,
                        reinterpret_cast<unsigned long long *>(wd.scratch), (long long)set_stride, GEN ? cstart : (const int *)nullptr);
     OEM_HIP(hipGetLastError());
-    if (getenv("OEM_WCOOP_FAKE_TIMEOUT")) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
+    if (sw().OEM_WCOOP_FAKE_TIMEOUT.set) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
     return 0;
 }
 static bool wcoop_general(const PathArgs &a) { return a.ngroups != 0; }
@@ -1555,6 +1555,8 @@ static size_t wcoop_set_doubles(int n, int p, int G)
 // over the range, not the value at Gx (n = 100, p = 6,300 asked for 104,724 doubles of the 93,072 sized at Gx and the
 // launch refused itself).
 static int wcoop_sized_sets(int G) { int s = 192 / G; if (s > WCOOP_MAX_SETS) s = WCOOP_MAX_SETS; return s < 1 ? 1 : s; }
+// what a launch of `sets` sets of G workgroups needs (oemgpu_selftest_plan holds it against the scratch the callers allocate)
+size_t path_wcoop_launch_doubles(int n, int p, int G, int sets) { return wcoop_set_doubles(n, p, G) * (size_t)(sets > 0 ? sets : 1); }
 size_t path_wcoop_xchg_doubles(int n, int p)
 {
     const int G = path_wcoop_workgroups(n, p), Gx = path_wcoop_max_workgroups(n, p);
@@ -1576,7 +1578,7 @@ int path_wcoop_sets(int n, int p, int npen, int num_cu, int G)
     int s = (num_cu * 3 / 4) / G;
     if (s > WCOOP_MAX_SETS) s = WCOOP_MAX_SETS;
     if (s > npen) s = npen;
-    if (getenv("OEM_WCOOP_ONE_SET")) s = 1;
+    if (sw().OEM_WCOOP_ONE_SET.set) s = 1;
     if (s < 1) s = 1;
     const size_t have = path_wcoop_xchg_doubles(n, p), one = wcoop_set_doubles(n, p, G);
     if (one == 0 || one > have) return 0;
@@ -1598,16 +1600,16 @@ extern "C" __attribute__((visibility("default"))) int oemgpu_selftest_wcoop_sizi
     return 0;
 }
 
-// OEM_NO_WCOOP=1: the launch-per-iteration engine; OEM_WCOOP_MAXG: fewer workgroups allowed (experiments)
+// OEM_NO_WCOOP=1: the launch-per-iteration engine
 bool path_wcoop_eligible(const PathArgs &a, const WideArgs &wd)
 {
-    const bool off = getenv("OEM_NO_WCOOP") != nullptr;           // (read per call: the tests hold the two engines against each other)
-    static const int maxg = [] { const char *e = getenv("OEM_WCOOP_MAXG"); const int k = e ? atoi(e) : 0; return (k >= 1 && k < WCOOP_GMAX) ? k : WCOOP_GMAX; }();
+    const bool off = sw().OEM_NO_WCOOP.set;           // (read per call: the tests hold the two engines against each other)
+    const int maxg = WCOOP_GMAX;
     if (off || wd.lay.nb != 1) return false;
     if (a.sinv || a.nbatch > 1 || a.pen_split) return false;
     const int G = path_wcoop_workgroups(wd.n, a.p);
     if (G < 1 || G > maxg) return false;
-    if (getenv("OEM_WCOOP_NO_GENERAL") && (wcoop_general(a) || a.accelerate)) return false;
+    if (sw().OEM_WCOOP_NO_GENERAL.set && (wcoop_general(a) || a.accelerate)) return false;
     if (wcoop_general(a)) {                                      // group operators keep u (by column) and the group tables in LDS
         if (a.p > 8192) return false;                            // (the gather masks hold 32 x 256 columns)
         size_t lds = 0;
@@ -1666,7 +1668,7 @@ size_t path_wres_xchg_doubles(int n, int p)
 // also where path_wcoop_kernel would have run (tests).
 bool path_wres_eligible(const PathArgs &a, const WideArgs &wd, int max_wg)
 {
-    if (getenv("OEM_NO_WRES") || getenv("OEM_NO_WCOOP") || wd.lay.nb != 1 || !wres_nr_built(wd.lay.nr)) return false;
+    if (sw().OEM_NO_WRES.set || sw().OEM_NO_WCOOP.set || wd.lay.nb != 1 || !wres_nr_built(wd.lay.nr)) return false;
     if (a.ngroups != 0 || a.accelerate || a.sinv || a.nbatch > 1 || a.pen_split) return false;
     const int G = path_wres_workgroups(wd.n, a.p);
     return G >= 1 && G <= WRES_GMAX && G <= max_wg;
@@ -1678,7 +1680,7 @@ template <int NR> static int wres_launch(hipStream_t s, const PathArgs &a, const
     if (sh > 64 * 1024 && lds_limit_once(reinterpret_cast<const void *>(&path_wres_kernel<NR>), sh)) return OEMGPU_ERR_HIP;
     hipLaunchKernelGGL((path_wres_kernel<NR>), dim3(G), dim3(WNTH), sh, s, a, wd.xs, wd.ys, wd.n, reinterpret_cast<unsigned long long *>(wd.scratch));
     OEM_HIP(hipGetLastError());
-    if (getenv("OEM_WCOOP_FAKE_TIMEOUT")) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
+    if (sw().OEM_WCOOP_FAKE_TIMEOUT.set) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
     return 0;
 }
 int launch_path_wres(hipStream_t s, const PathArgs &a, const WideArgs &wd)
@@ -1726,11 +1728,11 @@ static int wstream_chunks(int p, int G, int nr) { const int per = 4 * G * wc_cw(
 // OEM_NO_WSTREAM=1: the launch-per-iteration engine; OEM_WSTREAM=1: wherever it can run (tests).
 bool path_wstream_eligible(const PathArgs &a, const WideArgs &wd, int G)
 {
-    if (getenv("OEM_NO_WSTREAM") || wd.lay.nb != 1 || wd.lay.nr < 1 || wd.lay.nr > 8 || G < 1 || G > WCOOP_GMAX) return false;
+    if (sw().OEM_NO_WSTREAM.set || wd.lay.nb != 1 || wd.lay.nr < 1 || wd.lay.nr > 8 || G < 1 || G > WCOOP_GMAX) return false;
     if (a.ngroups != 0 || a.accelerate || a.sinv || a.nbatch > 1 || a.pen_split) return false;
     const int nch = wstream_chunks(a.p, G, wd.lay.nr);
     if ((size_t)nch * 64 * 2 * sizeof(double) > 64 * 1024) return false;      // coefficients and penalty factors of the chunks in LDS
-    if (getenv("OEM_WSTREAM")) return true;
+    if (sw().OEM_WSTREAM.set) return true;
     return wd.lay.nr <= 2 || (long long)wd.lay.npad() * a.p <= 4500000LL;
 }
 int launch_path_wstream(hipStream_t s, const PathArgs &a, const WideArgs &wd, int G)

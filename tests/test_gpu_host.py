@@ -337,6 +337,7 @@ def test_persistent_engine_under_real_contention(oa, tmp_path, engine):
     exchanges time out after about a second and the call is made again on the launch-per-iteration engine, or queue the launch
     behind the holder -- the call must come back, within a bounded time, with a right answer: the bits of one of the two engines."""
     import os, subprocess, sys, time, warnings
+    from oem_amd import _lib as L
     import torch
     if engine == "symcoop":
         xtx, xty = _xtx_problem_host(4096, 8192, 5)
@@ -359,11 +360,13 @@ def test_persistent_engine_under_real_contention(oa, tmp_path, engine):
     assert oa.last_path_engine()[0] == engine
     for k in off:
         os.environ[k] = "1"
+    L.reload_switches()                                            # (the library parses its switches once: oem_amd/csrc/switches.hpp)
     try:
         launches = call()
     finally:
         for k in off:
             del os.environ[k]
+        L.reload_switches()
     flag = tmp_path / "hold.flag"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     holder = subprocess.Popen([sys.executable, os.path.join(root, "tests", "hold_cus_worker.py"), "200", "6000", str(flag)], cwd=root,
@@ -411,7 +414,7 @@ def test_interrupt_reaches_a_persistent_launch(oa, engine):
     from oem_amd import _lib as L
     rng = np.random.default_rng(17)
     if engine in ("wres", "wcoop", "wstream"):
-        n, p = {"wres": (500, 20000), "wcoop": (500, 2500), "wstream": (64, 100_000)}[engine]
+        n, p = {"wres": (500, 20000), "wcoop": (500, 2500), "wstream": (128, 200_000)}[engine]
         x = np.asfortranarray(rng.normal(size=(n, p)))
         y = x[:, :10] @ rng.uniform(1.0, 2.0, 10) + rng.normal(size=n)
         xd = torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()
@@ -453,3 +456,36 @@ def test_interrupt_reaches_a_persistent_launch(oa, engine):
     for k in range(len(before["beta"])):
         assert np.array_equal(np.asarray(before["beta"][k]), np.asarray(after["beta"][k])) and np.array_equal(before["niter"][k], after["niter"][k])
         assert np.array_equal(np.asarray(before["beta"][k]), np.asarray(again["beta"][k]))
+
+
+def test_a_timed_out_persistent_engine_is_not_tried_again_at_once(oa, monkeypatch):
+    """a caller on a shared GPU paid the second of an exchange timeout on EVERY call, with no memory of the last failure.
+    Now the context remembers: after a timeout the next 4 (.. 64, doubling) calls that would take a persistent engine go straight to
+    the launch-per-iteration engines, for at most 30 s; a persistent launch that comes back, or a re-read of the switches, starts
+    over.  (The timeout is the faked one: OEM_WCOOP_FAKE_TIMEOUT poisons the launch's result, as in the fallback tests.)"""
+    import torch
+    xtx, xty = _xtx_problem_host(2048, 3000, 8)
+    xd = torch.as_tensor(xtx, device="cuda")
+    kw = dict(penalty="lasso", nlambda=4, tol=1e-8)
+    good = oa.oem_xtx(xd, xty, **kw)
+    assert oa.last_path_engine()[0] == "rowcoop"
+    f0 = oa.last_path_engine()[1]
+    monkeypatch.setenv("OEM_WCOOP_FAKE_TIMEOUT", "1")
+    first = oa.oem_xtx(xd, xty, **kw)                               # the persistent launch "times out": made again on the launches
+    assert oa.last_path_engine() == ("launches", f0 + 1)
+    # the switch is gone from the environment but the library has not been told: what follows is the context's memory alone
+    import os
+    del os.environ["OEM_WCOOP_FAKE_TIMEOUT"]
+    skipped = [oa.oem_xtx(xd, xty, **kw) for _ in range(4)]
+    assert oa.last_path_engine() == ("launches", f0 + 1)             # four calls skipped the persistent engine: no new timeout
+    for f in [first] + skipped:
+        assert np.abs(np.asarray(f["beta"][0]) - np.asarray(good["beta"][0])).max() < 1e-9
+        assert np.array_equal(np.asarray(f["beta"][0]), np.asarray(first["beta"][0]))
+    # ... and then it is tried again: the fake is still in the library's table, so this one times out as well and the back-off doubles
+    again = oa.oem_xtx(xd, xty, **kw)
+    assert oa.last_path_engine() == ("launches", f0 + 2)
+    monkeypatch.setenv("OEM_WCOOP_FAKE_TIMEOUT", "1")                # (so that monkeypatch's undo finds what it set)
+    monkeypatch.delenv("OEM_WCOOP_FAKE_TIMEOUT")                     # re-read without the fake: the memory starts over
+    back = oa.oem_xtx(xd, xty, **kw)
+    assert oa.last_path_engine() == ("rowcoop", f0 + 2)
+    assert np.array_equal(np.asarray(back["beta"][0]), np.asarray(good["beta"][0])) and np.array_equal(np.asarray(again["beta"][0]), np.asarray(first["beta"][0]))

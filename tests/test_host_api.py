@@ -182,3 +182,108 @@ def test_persistent_wide_engine_scratch_holds_every_partition():
                 if L.oemgpu_selftest_wcoop_sizing(n, p, npen, cu) != 0:
                     bad.append((n, p, npen, cu))
     assert not bad, bad[:10]
+
+
+# ---------------------------------------------------------------------------------------------- the engine plan (api.hip: plan_paths)
+_ENGINES = api.ENGINES
+_SEM_DENSE, _SEM_BIG, _SEM_XTX, _SEM_XVAL = 0, 1, 2, 3
+
+
+def _plan(p, pens, sem=_SEM_DENSE, intercept=0, groups=None, has_scale=False, nbatch=1, wide_n=0, num_cu=256, accelerate=False,
+          compute_loss=False, nlambda=100, user_lambda=False):
+    """oemgpu_selftest_plan: (engine name, frame bytes, reserved bytes, scratch need, scratch have) -- pure host arithmetic"""
+    import ctypes as C
+    from oem_amd import _lib as L
+    q = p + (1 if (sem in (_SEM_BIG, _SEM_XVAL) and intercept) else 0)
+    ngv = q if sem in (_SEM_BIG, _SEM_XVAL) else p
+    if groups is None:
+        g, ug, gw = [], [], []
+    else:
+        g = np.asarray(groups(ngv), dtype=np.int32)
+        ug = np.unique(g); gw = []
+    lam = [np.linspace(1.0, 0.1, 7)] * len(pens) if user_lambda else []
+    a = api._Args(pens, lam, nlambda, 1e-4, 0.7, 3.0, 0.4, 1e-7, 500, accelerate, compute_loss, np.ones(p), g, ug, gw)
+    eng, frame, res, need, have = C.c_int32(-1), C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    rc = L.lib().oemgpu_selftest_plan(p, q, sem, intercept, C.byref(a.c), int(has_scale), nbatch, wide_n, num_cu, C.byref(eng), C.byref(frame),
+                                      C.byref(res), C.byref(need), C.byref(have))
+    assert rc == 0, (p, pens, sem, L.lib().oemgpu_last_error().decode())
+    return _ENGINES[eng.value], frame.value, res.value, need.value, have.value
+
+
+_RUNS4 = lambda n: np.arange(n) // 4 + 1                    # groups of four neighbouring columns
+_SCATTER = lambda n: np.arange(n) % 7 + 1                   # seven groups dealt round robin: no group is a run
+_PEN_SETS = [(["lasso"], None), (["lasso", "mcp", "scad"], None), (["grp.lasso"], _RUNS4), (["grp.lasso", "lasso"], _RUNS4),
+             (["grp.mcp", "sparse.grp.lasso"], _SCATTER),
+             (["elastic.net", "lasso", "ols", "mcp", "scad", "mcp.net", "scad.net", "grp.lasso"], _RUNS4)]
+
+
+def test_the_plan_names_one_engine_and_a_workspace_that_fits_at_every_size():
+    """VERDICT r4 item 6 / ADVICE r3: the launch of an engine must never reject the workspace its own caller sized.  plan_paths is the
+    host function that decides engine and sizes for every call; this sweeps it without a GPU over q in [2, 20,000] (every q up to
+    300, then the engines' boundaries and a coarse grid), penalty families (element-wise, groups that are runs, scattered groups,
+    eight penalties), options (accelerate, compute.loss, scale.factor, user lambdas), the entry points' semantics, K + 1 batched
+    fits, and devices of 64 .. 304 CUs."""
+    qs = sorted(set(list(range(2, 301)) + [q + d for q in (512, 1024, 2048, 3457, 4096, 8192) for d in (-1, 0, 1)] +
+                    list(range(320, 4200, 97)) + [5000, 12000, 20000]))
+    seen = set()
+    for p in qs:
+        for pens, grp in _PEN_SETS:
+            variants = [dict(), dict(accelerate=True, compute_loss=True), dict(user_lambda=True, nlambda=7)]
+            if p % 5 == 0:
+                variants += [dict(sem=_SEM_XTX, has_scale=True), dict(sem=_SEM_BIG, intercept=1), dict(sem=_SEM_XVAL, intercept=1, compute_loss=True),
+                             dict(num_cu=304), dict(num_cu=64)]
+            if p < 512 and p % 7 == 0:                                 # (xval.oem batches its K + 1 fits only where all their workgroup sets fit the chip)
+                variants += [dict(sem=_SEM_XVAL, intercept=1, nbatch=6)]
+            for kw in variants:
+                eng, frame, res, need, have = _plan(p, pens, groups=grp, **kw)
+                assert eng in _ENGINES[1:6], (p, pens, kw, eng)           # a Gram engine
+                assert frame <= res, (p, pens, kw, eng, frame, res)
+                seen.add(eng)
+    assert seen == {"rows", "coop", "rowcoop", "symcoop", "launches"}
+    # the sizes BASELINE.json names
+    assert _plan(100, ["elastic.net"])[0] == "rows"                       # config 1
+    assert _plan(200, ["mcp"])[0] == "rows" and _plan(512, ["grp.lasso"], groups=lambda n: np.arange(n) // 8 + 1)[0] == "coop"      # configs 2, 3
+    assert _plan(4096, ["lasso"], sem=_SEM_XTX)[0] == "symcoop" and _plan(4096, ["lasso"], sem=_SEM_XTX, has_scale=True)[0] == "launches"      # config 4
+    assert _plan(257 - 1, ["lasso"], sem=_SEM_BIG, intercept=1)[0] == "coop"                                              # config 5: q = 257 (from 209 on)
+    assert _plan(2048, ["lasso"])[0] == "rowcoop" and _plan(2048, ["grp.lasso"], groups=_RUNS4)[0] == "symcoop" and _plan(4097, ["lasso"])[0] == "launches"
+
+
+def test_the_plan_for_p_ge_n_fits_the_scratch_the_callers_allocate():
+    """the same for the two-product form (no Gram matrix): rows 3 .. 5,000 x columns up to 100,000 -- the persistent engines' exchange
+    buffers against wide_scratch_doubles, the frame against the reservation"""
+    seen = set()
+    for n in (3, 40, 64, 100, 128, 192, 200, 256, 500, 700, 960, 1000, 1024, 1500, 2048, 2100, 5000):
+        for p in sorted({n, n + 1, 2 * n + 3, 1100, 1500, 2500, 2912, 6300, 9000, 12200, 20000, 30000, 100000}):
+            if p < n:
+                continue
+            for pens, grp in _PEN_SETS:
+                for kw in (dict(), dict(accelerate=True, compute_loss=True), dict(num_cu=304), dict(num_cu=104), dict(sem=_SEM_BIG)):
+                    eng, frame, res, need, have = _plan(p, pens, groups=grp, wide_n=n, **kw)
+                    assert eng in _ENGINES[6:], (n, p, pens, kw, eng)
+                    assert frame <= res, (n, p, pens, kw, eng, frame, res)
+                    assert need <= have, (n, p, pens, kw, eng, need, have)
+                    seen.add(eng)
+    assert seen == {"wcoop", "wres", "wstream", "wlaunches"}
+    assert _plan(20000, ["lasso"], wide_n=500)[0] == "wres" and _plan(2500, ["lasso", "mcp"], wide_n=500)[0] == "wcoop"
+    assert _plan(200000, ["lasso"], wide_n=128)[0] == "wstream" and _plan(20000, ["lasso"], wide_n=2000)[0] == "wlaunches"
+
+
+def test_every_switch_is_documented():
+    """the library's environment switches live in ONE table (oem_amd/csrc/switches.hpp) that is parsed once; DESIGN.md section 7b must
+    name every one of them, and no source may call getenv on its own"""
+    import re
+    from pathlib import Path
+    from oem_amd import _lib as L
+    root = Path(__file__).resolve().parent.parent
+    names = L.lib().oemgpu_switch_names().decode().split()
+    assert 30 <= len(names) <= 40 and len(set(names)) == len(names)     # (round 4: 45 names read by getenv at call time)
+    design = (root / "DESIGN.md").read_text()
+    sec = design[design.index("## 7b."):]
+    sec = sec[:sec.index("\n## ", 5)]
+    missing = [n for n in names if n not in sec]
+    assert not missing, missing
+    for src in sorted((root / "oem_amd" / "csrc").glob("*.h*")):
+        if src.name == "switches.hpp":
+            continue
+        calls = [ln for ln in src.read_text().splitlines() if re.search(r"\bgetenv\(", ln) and "sw_parse" not in ln and "const char *e = getenv(name)" not in ln]
+        assert not calls, (src.name, calls)

@@ -16,6 +16,7 @@ for knob in sys.argv[1:] or [""]:
     if knob == "nosym": os.environ["OEM_NO_SYM"] = "1"; os.environ["OEM_NO_SYMCOOP"] = "1"          # the row-streaming engine that reads all of XX (round 2)
     elif knob == "nosymcoop": os.environ["OEM_NO_SYMCOOP"] = "1"          # the symmetric-tile launches of round 3 (the lower triangle streamed per iteration)
     elif knob: os.environ["OEM_FUSED_BLOCKS"] = knob
+    __import__('oem_amd')._lib.reload_switches()      # (the library parses its switches once)
     t = []
     for _ in range(3):
         fit = oem_amd.oem_xtx(xtxd, xty, penalty="lasso", nlambda=100, tol=1e-10)

@@ -22,7 +22,7 @@ for (n, p, kw) in [(1_000_000, 512, dict(penalty="grp.lasso", groups=np.repeat(n
     yd = (xt.t() @ bb + torch.randn(n, generator=g, device="cuda", dtype=torch.float64)).contiguous()
     f = lambda: oem_amd.oem(xt.t(), yd, **kw)
     res = {}
-    for name, env in (("coop", {}), ("coop stride 8", {"OEM_COOP_STRIDE": "8"}), ("launch-per-iteration", {"OEM_NO_COOP": "1"})):
+    for name, env in (("coop", {}), ("launch-per-iteration", {"OEM_NO_COOP": "1"})):
         for k, v in env.items(): os.environ[k] = v
         try:
             res[name] = run(f)

@@ -37,8 +37,10 @@ import os
 t_dense, fit = timeit(lambda: oem_amd.oem(xd, ys, **kw))
 t_sparse, fits = timeit(lambda: oem_amd.oem(xs, ys, lambda_=fit["lambda"], **kw))           # density 1 %: the compressed-column Gram
 os.environ["OEM_SPARSE_GRAM"] = "dense"
+__import__('oem_amd')._lib.reload_switches()      # (the library parses its switches once)
 t_sparse_tiles, fitt = timeit(lambda: oem_amd.oem(xs, ys, lambda_=fit["lambda"], **kw))     # zero-filled tiles + MFMA pass
 del os.environ["OEM_SPARSE_GRAM"]
+__import__('oem_amd')._lib.reload_switches()      # (the library parses its switches once)
 other = {}
 for dens in (0.001, 0.05):                                                                  # both ways at other densities
     xo = sp.random(n, p, density=dens, random_state=8, format="csc", data_rvs=lambda k: rng.normal(size=k))
@@ -46,9 +48,11 @@ for dens in (0.001, 0.05):                                                      
     r = {}
     for mode in ("csc", "dense"):
         os.environ["OEM_SPARSE_GRAM"] = mode
+        __import__('oem_amd')._lib.reload_switches()      # (the library parses its switches once)
         r[mode + "_ms"], f_ = timeit(lambda: oem_amd.oem(xo, yo, **kw))
         r[mode] = f_
     del os.environ["OEM_SPARSE_GRAM"]
+    __import__('oem_amd')._lib.reload_switches()      # (the library parses its switches once)
     other[str(dens)] = {"csc_ms": r["csc_ms"], "dense_tiles_ms": r["dense_ms"],
                         "max_abs_diff": float(max(np.abs(r["csc"]["beta"][k] - r["dense"]["beta"][k]).max() for k in range(2)))}
 t0 = time.perf_counter()
