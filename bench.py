@@ -36,6 +36,10 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix peak (AMD spec; 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
+# config 4's iteration on the register-resident symmetric engine, as far as THIS design goes: two memory-side
+# exchanges (1.05 us per all-gather at the hop floor, profiles/r4_exchange_probes.txt) + the products at the issue floor of an
+# accumulator-fed tile (tools/areg_fma_probe.hip, profiles/r5_c4_areg_fma_probe.txt: 3 tiles per wave) + the owners' arithmetic
+C4_FLOOR_US = 4.6
 README_SECONDS = 1.600241        # reference README.md:73, oem[lasso] mean over 5 runs, hardware unstated
 
 
@@ -98,6 +102,20 @@ def c5_weak(torch, dist, world, rank, dev, backend, rows, steps, warmup):
             acc += np.array(list(ms))
     L.check(lib.oemgpu_set_timing(backend.ctx, 0))
     acc /= 5
+    # the collective on its own: the (p+2)^2 moment buffer of this workload (HIP events on the stream the collectives are ordered on)
+    allreduce_ms = None
+    if world > 1:
+        scratch = bufs[1].clone()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with backend.section():
+            for _ in range(5):
+                dist.all_reduce(scratch)
+            e0.record()
+            for _ in range(50):
+                dist.all_reduce(scratch)
+            e1.record()
+        torch.cuda.synchronize()
+        allreduce_ms = e0.elapsed_time(e1) / 50
     flops = float(rows) * p * (p + 1) + 2.0 * rows * p
     nit = int(np.sum(args.niter))
     del x, xt, y
@@ -107,6 +125,7 @@ def c5_weak(torch, dist, world, rank, dev, backend, rows, steps, warmup):
             "rows_per_gpu": rows, "n_total": rows * world, "rows_per_second": rows * world * steps / dt,
             "stage_ms": {"moments_total": acc[L.T_MOMENTS], "gram_kernel": acc[L.T_GRAMK], "finalize": acc[L.T_FINAL],
                          "eigen_plus_path": acc[L.T_EIGPATH]},
+            "allreduce_ms": allreduce_ms, "allreduce_doubles": (p + 2) * (p + 2),
             "gram_TFLOPs": flops / (acc[L.T_GRAMK] * 1e-3) / 1e12 if acc[L.T_GRAMK] > 0 else None,
             "gram_frac_of_fp64_mfma_peak": flops / (acc[L.T_GRAMK] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if acc[L.T_GRAMK] > 0 else None,
             "oem_iterations_per_solve": nit}
@@ -606,6 +625,20 @@ def main():
         except Exception as e:          # e.g. not enough free HBM on a shared device: the headline line must still print
             if rank == 0:
                 out["c5_weak"] = {"error": repr(e)}
+    if rank == 0:
+        # ONE object per run that explains this point of the 1 -> N curve for BOTH workloads: per-GPU rows and
+        # where a step's time goes -- the moment pass on the local rows, the one all-reduce, the replicated solve
+        def _point(value, ms_step, rows, st, ar):
+            return {"value_solves_per_s": value, "ms_per_step": ms_step, "rows_per_gpu": rows, "moments_ms": st.get("moments_total"),
+                    "allreduce_ms": ar, "solve_ms": (st.get("finalize") or 0.0) + (st.get("eigen_plus_path") or 0.0)}
+        curve = {"n_gpus": world, "c1_strong": _point(out["value"], out["ms_per_step"], n_loc, out["stage_ms"], out.get("allreduce_ms") if world > 1 else None)}
+        r5o = out.get("c5_weak")
+        if isinstance(r5o, dict) and "value" in r5o:
+            curve["c5_weak"] = _point(r5o["value"], r5o["ms_per_step"], r5o["rows_per_gpu"], r5o["stage_ms"], r5o.get("allreduce_ms"))
+        curve["note"] = ("c1: n = 1e6 rows split over the GPUs (strong: the moment pass shrinks, all-reduce and solve do not); c5: 1.25e7 rows on "
+                         "EVERY GPU (weak: all three stay, the all-reduce grows with log N at most).  No 1 -> 8 curve has been measured on hardware "
+                         "by the builder: these objects from the driver's N = 1, 2, 4, 8 runs are the curve and its explanation")
+        out["scaling_point"] = curve
     if rank == 0 and world == 1 and not a.no_host:
         try:
             out["host_resident_ms"]["c5_sample"] = host_resident_c5(torch, dev, 1)
@@ -666,6 +699,12 @@ def main():
                             "eigen_plus_path_ms": best, "oem_iterations": it4, "us_per_iteration_incl_lanczos": 1e3 * best / max(it4, 1),
                             "lanczos_steps": int(st4.value), "persistent_kernel_cycles": ms4[6],
                             "algorithmic_GBps_at_8p2_plus_24p_bytes_per_iteration": alg / (best * 1e-3) / 1e9,
+                            # the bound that applies: FP64 VALU (2 p^2 flops per product, OEM iterations + Lanczos steps), and the floor of an
+                            # iteration as stamped and probed (profiles/r5_c4_*)
+                            "fp64_valu_TFLOPs": 2.0 * p4 * p4 * (it4 + int(st4.value)) / (best * 1e-3) / 1e12,
+                            "fp64_valu_frac_of_peak": 2.0 * p4 * p4 * (it4 + int(st4.value)) / (best * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                            "us_per_iteration_floor_of_this_design": C4_FLOOR_US,
+                            "frac_of_that_floor": C4_FLOOR_US / (1e3 * best / max(it4 + int(st4.value), 1)),
                             "note": "the matrix is register-resident for the whole call: the 'bandwidth' above is SURVEY 8(d)'s byte count over the "
                                     "measured time (multiples of the 8 TB/s HBM peak because the bytes are never read); the loop is bound by two "
                                     "exchanges per iteration through the memory side and by FP64 VALU, not by HBM"}

@@ -148,7 +148,8 @@ __device__ __forceinline__ bool path_abort_asked(const int *w)
 {
     return w && __builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0;
 }
-constexpr unsigned PATH_ABORT_SPINS = 1023u;   // an exchange spin looks at the word every 1,024 sweeps (~1 ms): never on the way of an exchange that arrives
+constexpr unsigned PATH_ABORT_SPINS = 1024u;   // an exchange spin looks at the word (and at its timeout) every 1,024 sweeps (~1 ms): never on the way of an exchange that arrives
+constexpr unsigned PATH_TIMEOUT_ROUNDS = 1000u; // ... and gives up after that many rounds (~1 s): a partner is gone
 constexpr int PATH_FAILED_TIMEOUT = 1, PATH_FAILED_ABORT = 2;
 
 // the problem instance of this workgroup (see PathArgs::nbatch); all scalar arithmetic

@@ -171,8 +171,9 @@ __device__ __forceinline__ void coop_round(const double (&a)[CG], const int (&bi
     }
     const unsigned need = miss;
     if (OEM_XCHG_SLEEP > 0) __builtin_amdgcn_s_sleep(OEM_XCHG_SLEEP);      // (nothing of this epoch can have landed yet: path_wcoop.hip, wc_gather)
-    unsigned spins = 0;
-    const unsigned limit = X.failed ? 0u : 1000000u;            // ~1 s: a partner is gone; after one timeout nobody waits again
+    // ONE counter in the sweep loop: it runs out once per 1,024 sweeps (~1 ms), and only then are the abort word and the timeout looked at
+    // (~1 s = 1,000 such rounds: a partner is gone; after one timeout -- or the abort word -- nobody waits again: one sweep each)
+    unsigned left = X.failed ? 1u : PATH_ABORT_SPINS, rounds = 0u;
     bool ok = true;
     while (__any(miss != 0u)) {
 #pragma unroll
@@ -181,8 +182,11 @@ __device__ __forceinline__ void coop_round(const double (&a)[CG], const int (&bi
 #pragma unroll
         for (int k = 0; k < C::EPT; ++k)
             if (((miss >> k) & 1u) && pv[k].y == X.epoch && pv[k].w == X.epoch) miss &= ~(1u << k);
-        if (++spins >= limit && __any(miss != 0u)) { ok = false; break; }
-        if ((spins & PATH_ABORT_SPINS) == 0u && path_abort_asked(X.abortw)) { X.failed = PATH_FAILED_ABORT; break; }
+        if (--left == 0u && __any(miss != 0u)) {
+            if (X.failed || ++rounds >= PATH_TIMEOUT_ROUNDS) { ok = false; break; }
+            if (path_abort_asked(X.abortw)) { X.failed = PATH_FAILED_ABORT; break; }
+            left = PATH_ABORT_SPINS;
+        }
     }
     if (!ok && X.failed == 0) X.failed = PATH_FAILED_TIMEOUT;
     COOP_STAMP(4);                                              // polling

@@ -69,6 +69,7 @@ __host__ __device__ constexpr int sx_slt(bool gen) { return (8 - sx_svr(gen)) * 
 
 #ifdef OEM_PATH_DIAG
 __device__ unsigned long long g_diag_symcoop[16];
+__device__ unsigned long long g_diag_symcoop_waves[4 * 16];      // the path phase of every wave of workgroup 0: acc[0..10] (tools/symcoop_diag.py)
 #define SX_STAMP(slot)                                                                     \
     do {                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                 \
@@ -125,8 +126,9 @@ __device__ __forceinline__ void sx_gather(const int (&off)[E], unsigned need, do
 #pragma unroll
     for (int k = 0; k < E; ++k) pv[k] = sx_v4u{0u, 0u, 0u, 0u};
     if (E > 1 && OEM_XCHG_SLEEP > 0) __builtin_amdgcn_s_sleep(OEM_XCHG_SLEEP);      // (path_wcoop.hip: wc_gather has the measurement; E = 1: scalars that landed a hop ago)
-    unsigned spins = 0;
-    const unsigned limit = X.failed ? 0u : 1000000u;            // ~1 s: a partner is gone; after one timeout nobody waits again
+    // ONE counter in the sweep loop: it runs out once per 1,024 sweeps (~1 ms), and only then are the abort word and the timeout looked at
+    // (~1 s = 1,000 such rounds: a partner is gone; after one timeout -- or the abort word -- nobody waits again: one sweep each)
+    unsigned left = X.failed ? 1u : PATH_ABORT_SPINS, rounds = 0u;
     bool ok = true;
     while (__any(miss != 0u)) {
 #pragma unroll
@@ -135,8 +137,11 @@ __device__ __forceinline__ void sx_gather(const int (&off)[E], unsigned need, do
 #pragma unroll
         for (int k = 0; k < E; ++k)
             if (((miss >> k) & 1u) && (pv[k].y >> 1) == X.epoch && (pv[k].w >> 1) == X.epoch) miss &= ~(1u << k);
-        if (++spins >= limit && __any(miss != 0u)) { ok = false; break; }
-        if ((spins & PATH_ABORT_SPINS) == 0u && sx_abort_seen(X)) break;
+        if (--left == 0u && __any(miss != 0u)) {
+            if (X.failed || ++rounds >= PATH_TIMEOUT_ROUNDS) { ok = false; break; }
+            if (sx_abort_seen(X)) break;
+            left = PATH_ABORT_SPINS;
+        }
     }
     if (!ok) X.failed = true;
 #pragma unroll
@@ -484,7 +489,9 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
     unsigned tick = 0u;
     for (;;) {
         const bool lz = phase == 0;
+#ifndef OEM_EXP_NO_TICK
         if ((tick++ & 127u) == 0u) (void)sx_abort_seen(X);           // (PathArgs::abort_word: the caller's interrupt)
+#endif
         // ---- products of this wave's tiles (those whose vector block holds a non-zero), reduced over the lanes, into Wp
         SX_STAMP(0);
         int fJ[NT], fI[NT];                                          // (all flag words asked for at once: one LDS latency, not six)
@@ -505,6 +512,7 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
         });
         SX_STAMP(1);
         __syncthreads();                                             // Wp is complete
+        SX_STAMP(9);                                                 // (the wait behind the slowest wave's products)
         // ---- exchange 1: this workgroup's partial vector per block slot (wave w adds the entries of slots w, w + 4, ... in list
         // order) to the owners; Lanczos: its part of v'XXv as well
         ++X.epoch;
@@ -681,6 +689,7 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
             const int nz4 = ((nzb & 0xffffull) ? 1 : 0) | ((nzb & 0xffff0000ull) ? 2 : 0) | ((nzb & 0xffff00000000ull) ? 4 : 0) | ((nzb >> 48) ? 8 : 0);
             if (lane == 0 && w + 4 * k < SNB) nzs[w + 4 * k] = nz4;
         }
+        SX_STAMP(10);                                                // (LDS stores and ballots; what follows is the wait behind the slowest wave's gather)
         sx_vote(votes + 4, w, lane, bits2);
         __syncthreads();
         SX_STAMP(7);
@@ -688,7 +697,11 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
         X.acc[8] += 1;
 #endif
         {
+#ifndef OEM_EXP_NO_AFLAG
             const int v2 = votes[4] | votes[5] | votes[6] | votes[7] | X.aflag[0];
+#else
+            const int v2 = votes[4] | votes[5] | votes[6] | votes[7];
+#endif
             if (v2 & 2) break;                                       // somebody here has seen the host's abort word: nobody waits any more, leave
             if (!lz) { mw = v2; continue; }
         }
@@ -743,6 +756,7 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
     }
 #ifdef OEM_PATH_DIAG
     if (tid == 0 && writer) { for (int k = 0; k < 8; ++k) g_diag_symcoop[8 + k] = X.acc[k]; g_diag_symcoop[7] = X.acc[8]; }
+    if (lane == 0 && writer) { for (int k = 0; k < 16; ++k) g_diag_symcoop_waves[w * 16 + k] = X.acc[k]; }
 #endif
     if (tid == 0 && writer) {
         A.d_out[2] = (double)(__builtin_amdgcn_s_memtime() - t_cyc0);
@@ -1097,6 +1111,10 @@ int launch_path_rowcoop(hipStream_t s, const PathArgs &a, void *xchg)
 extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read_symcoop(unsigned long long *out)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_symcoop), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read_symcoop_waves(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_symcoop_waves), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -193,8 +193,9 @@ __device__ __forceinline__ void wc_gather(__amdgpu_buffer_rsrc_t rs, int off0, u
     // all-gather polling at once, 1.20 us with the first sweep 768 cycles late (64 workgroups, 128 rows: 1.36 -> 0.83).  A
     // workgroup that arrives LAST sleeps too, but its partners cannot see its rows before it wakes.
     if (OEM_XCHG_SLEEP > 0) __builtin_amdgcn_s_sleep(OEM_XCHG_SLEEP);
-    unsigned spins = 0;
-    const unsigned limit = X.failed ? 0u : 1000000u;            // ~1 s: a partner is gone; after one timeout nobody waits again
+    // ONE counter in the sweep loop: it runs out once per 1,024 sweeps (~1 ms), and only then are the abort word and the timeout looked at
+    // (~1 s = 1,000 such rounds: a partner is gone; after one timeout -- or the abort word -- nobody waits again: one sweep each)
+    unsigned left = X.failed ? 1u : PATH_ABORT_SPINS, rounds = 0u;
     bool ok = true;
     while (__any(miss != 0u)) {
 #pragma unroll
@@ -203,8 +204,11 @@ __device__ __forceinline__ void wc_gather(__amdgpu_buffer_rsrc_t rs, int off0, u
 #pragma unroll
         for (int k = 0; k < E; ++k)
             if (((miss >> k) & 1u) && (pv[k].y >> 1) == X.epoch && (pv[k].w >> 1) == X.epoch) miss &= ~(1u << k);
-        if (++spins >= limit && __any(miss != 0u)) { ok = false; break; }
-        if ((spins & PATH_ABORT_SPINS) == 0u && path_abort_asked(X.abortw)) { X.failed = PATH_FAILED_ABORT; break; }
+        if (--left == 0u && __any(miss != 0u)) {
+            if (X.failed || ++rounds >= PATH_TIMEOUT_ROUNDS) { ok = false; break; }
+            if (path_abort_asked(X.abortw)) { X.failed = PATH_FAILED_ABORT; break; }
+            left = PATH_ABORT_SPINS;
+        }
 #if OEM_XCHG_SLEEP2 > 0
         if (__any(miss != 0u)) __builtin_amdgcn_s_sleep(OEM_XCHG_SLEEP2);
 #endif
@@ -237,8 +241,7 @@ __device__ __forceinline__ void wc_gather_u_list(double *Ush, double u_own, int 
     const int nk = (nlist + WNTH - 1) / WNTH;
     unsigned miss = 0;
     for (int k = 0; k < nk; ++k) if (tid + WNTH * k < nlist) miss |= 1u << k;
-    unsigned spins = 0;
-    const unsigned limit = X.failed ? 0u : 1000000u;
+    unsigned left = X.failed ? 1u : PATH_ABORT_SPINS, rounds = 0u;
     while (__any(miss != 0u)) {
         for (int k0 = 0; k0 < nk; k0 += 4) {
             wc_v4u pv[4];
@@ -259,8 +262,11 @@ __device__ __forceinline__ void wc_gather_u_list(double *Ush, double u_own, int 
                     miss &= ~(1u << (k0 + i));
                 }
         }
-        if (++spins >= limit && __any(miss != 0u)) { if (X.failed == 0) X.failed = PATH_FAILED_TIMEOUT; break; }
-        if ((spins & PATH_ABORT_SPINS) == 0u && path_abort_asked(X.abortw)) { X.failed = PATH_FAILED_ABORT; break; }
+        if (--left == 0u && __any(miss != 0u)) {
+            if (X.failed || ++rounds >= PATH_TIMEOUT_ROUNDS) { if (X.failed == 0) X.failed = PATH_FAILED_TIMEOUT; break; }
+            if (path_abort_asked(X.abortw)) { X.failed = PATH_FAILED_ABORT; break; }
+            left = PATH_ABORT_SPINS;
+        }
     }
     __syncthreads();
 }
@@ -279,15 +285,17 @@ __device__ __forceinline__ double wc_adp_total(double own, double *red, int &rpa
     const int off4 = (int)(ep & 1u) * X.G * 16;
     const bool mine = tid < X.G && tid != X.wg;
     double v = (tid == X.wg) ? own : 0.0;
-    unsigned spins = 0;
-    const unsigned limit = X.failed ? 0u : 1000000u;
+    unsigned left = X.failed ? 1u : PATH_ABORT_SPINS, rounds = 0u;
     bool miss = mine;
     while (__any(miss)) {
         wc_v4u pv = wc_v4u{0u, 0u, 0u, 0u};
         if (miss) pv = __builtin_amdgcn_raw_buffer_load_b128(X.rs, X.o4 + off4 + tid * 16, 0, 16);
         if (miss && (pv.y >> 1) == ep && (pv.w >> 1) == ep) { v = __hiloint2double((int)pv.z, (int)pv.x); miss = false; }
-        if (++spins >= limit && __any(miss)) { if (X.failed == 0) X.failed = PATH_FAILED_TIMEOUT; break; }
-        if ((spins & PATH_ABORT_SPINS) == 0u && path_abort_asked(X.abortw)) { X.failed = PATH_FAILED_ABORT; break; }
+        if (--left == 0u && __any(miss)) {
+            if (X.failed || ++rounds >= PATH_TIMEOUT_ROUNDS) { if (X.failed == 0) X.failed = PATH_FAILED_TIMEOUT; break; }
+            if (path_abort_asked(X.abortw)) { X.failed = PATH_FAILED_ABORT; break; }
+            left = PATH_ABORT_SPINS;
+        }
     }
     return wc_block_sum(v, red, rpar, w, lane);                  // thread t holds workgroup t's part: a fixed order
 }

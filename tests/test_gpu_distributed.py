@@ -50,19 +50,31 @@ def test_bench_launches_its_own_workers():
 
 
 @pytest.mark.gpu
-def test_bench_launcher_at_eight_ranks():
+@pytest.mark.parametrize("route", ["peer copies", "staged through the host"])
+def test_bench_launcher_at_eight_ranks(route):
     """the first 8-rank run should not be the driver's.  `python bench.py --gpus 8` on the one GPU of the box
     (OEM_BENCH_ONE_DEVICE: eight workers on device 0 over gloo): rendezvous, ordinals, the row split with n not a multiple of 8,
-    the one JSON line."""
+    the one JSON line with its `scaling_point` -- and behind the ranks the in-library leg, opts.ngpus = 8 (eight
+    contexts of the one device), by BOTH hand-over routes of hoststream.hip: peer copies, and OEMGPU_NO_PEER=1 -- every moment buffer
+    through a pinned host buffer, as between devices that cannot access each other."""
     import json
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "OEMGPU_NO_PEER")}
     env.update(OEM_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if route == "staged through the host":
+        env["OEMGPU_NO_PEER"] = "1"
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--n", "100003", "--no-c5",
-                        "--no-cpu-baseline", "--no-host"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["steps"] == 2 and out["value"] > 0 and out["collective_backend"] == "gloo" and out["allreduce_ms"] > 0
     assert out["scaling"] == "strong"
-
+    sp = out["scaling_point"]
+    assert sp["n_gpus"] == 8 and sp["c1_strong"]["rows_per_gpu"] in (100003 // 8, 100003 - 7 * (100003 // 8))
+    assert sp["c1_strong"]["moments_ms"] > 0 and sp["c1_strong"]["allreduce_ms"] > 0 and sp["c1_strong"]["solve_ms"] > 0
+    hr = out["host_resident_ms"]
+    assert "error" not in hr, hr
+    assert hr["c1"]["ngpus"] == 8 and hr["c1"]["max_abs_beta_diff_vs_the_rank_sharded_solve"] < 1e-9
+    staged = hr["c1"]["handovers_staged_through_host"]
+    assert (staged >= 7) if route == "staged through the host" else (staged == 0), staged

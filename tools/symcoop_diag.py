@@ -31,8 +31,17 @@ if p <= 2048 and not os.environ.get("OEM_NO_ROWCOOP"):
 lib.oemgpu_diag_read_symcoop.argtypes = [C.POINTER(C.c_ulonglong)]
 out = (C.c_ulonglong * 16)(); assert lib.oemgpu_diag_read_symcoop(out) == 0
 d = np.array(list(out), dtype=np.float64)
-names = "between + owners' arithmetic of the previous | products | block sums + publish 1 | gather 1 | (alpha) + vote barrier | operator + publish 2 | gather 2 | LDS stores + barrier"
+names = "between + owners' arithmetic of the previous | products | block sums + publish 1 | gather 1 | (alpha) + vote barrier | operator + publish 2 | gather 2 | barrier behind the LDS stores"
+# (round 5: the wait behind the slowest wave's products and the LDS stores + ballots have slots of their own, 9 and 10: the per-wave lines below)
 it = max(d[7], 1)
 print(f"p={p}: OEM iterations {int(np.sum(fit['niter'][0]))}, all-reduces of the path phase {int(d[7])}; cycles of wave 0 of workgroup 0 per iteration\n  [{names}]")
 print("  path:   ", np.round(d[8:16] / it, 0), "sum", round(d[8:16].sum() / it))
 print("  Lanczos (totals over its steps, slot 7 overwritten):", np.round(d[0:7], 0))
+lib.oemgpu_diag_read_symcoop_waves.argtypes = [C.POINTER(C.c_ulonglong)]
+ow = (C.c_ulonglong * 64)(); assert lib.oemgpu_diag_read_symcoop_waves(ow) == 0
+dw = np.array(list(ow), dtype=np.float64).reshape(4, 16) / it
+print("  one level deeper, every wave of workgroup 0 (cycles per iteration): products | wait behind the slowest wave's products | block sums + publish 1 |"
+      " gather 1 | vote barrier | operator + publish 2 | gather 2 | LDS stores + ballots | wait behind the slowest wave's gather")
+for wv in range(4):
+    r = dw[wv]
+    print(f"    wave {wv}:", np.round([r[1], r[9], r[2], r[3], r[4], r[5], r[6], r[10], r[7]], 0), "sum", round(float(r[0] + r[1] + r[9] + r[2] + r[3] + r[4] + r[5] + r[6] + r[10] + r[7])))
