@@ -489,9 +489,7 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
     unsigned tick = 0u;
     for (;;) {
         const bool lz = phase == 0;
-#ifndef OEM_EXP_NO_TICK
         if ((tick++ & 127u) == 0u) (void)sx_abort_seen(X);           // (PathArgs::abort_word: the caller's interrupt)
-#endif
         // ---- products of this wave's tiles (those whose vector block holds a non-zero), reduced over the lanes, into Wp
         SX_STAMP(0);
         int fJ[NT], fI[NT];                                          // (all flag words asked for at once: one LDS latency, not six)
@@ -524,6 +522,8 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
             for (int m = 0; m < 4; ++m) {
                 if (m >= nslw) continue;
                 // eight reads, none depending on another; rows beyond the slot's own read the zero row behind Wp
+                // (round 5: four reads where the slot has no more entries -- most slots -- measured no faster, 22.60 -> 22.66 ms: the second
+                // code path cost more in scalar spills than the reads saved)
                 double rr[8];
                 int er = erow[m], ec = ecnt[m];
                 asm volatile("" : "+s"(er), "+s"(ec));               // (recomputed addresses, not 32 loop-invariant address registers)
@@ -680,14 +680,22 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
             if (lz) sqrt_rsqrt(tot, bb, ib);
             else ak = (tot > 0.0) ? 1.0 : acc_akn;                   // (the extrapolated beta is kept; only the momentum counter restarts)
         }
+        // (a pair this thread did not ask for -- a slot beyond the workgroup's blocks, a coordinate beyond q -- came back as 0.0: stored like
+        // the others, into slots nobody reads / over the zeros the ragged end of the last block holds anyway.  No predicate, no masked store:
+        // at one wave per SIMD an instruction is ~5 cycles, and this tail was 300 of them -- 1,570 cycles, profiles/r5_symcoop_stamped.txt)
+        static_assert(SE2 * 4 <= SNB, "every slot w + 4 k is a row of Bsh");
+        if (lz) {
+#pragma unroll
+            for (int k = 0; k < SE2; ++k) r[k] *= ib;
+        }
 #pragma unroll
         for (int k = 0; k < SE2; ++k) {
-            const bool nd = ((need2 >> k) & 1u) != 0;
-            const double x = lz ? r[k] * ib : r[k];
-            if (nd) Bsh[(w + 4 * k) * 64 + lane] = x;
-            const unsigned long long nzb = __ballot(nd && x != 0.0);       // bit h of the word: 16-coordinate group h of the block holds a non-zero
-            const int nz4 = ((nzb & 0xffffull) ? 1 : 0) | ((nzb & 0xffff0000ull) ? 2 : 0) | ((nzb & 0xffff00000000ull) ? 4 : 0) | ((nzb >> 48) ? 8 : 0);
-            if (lane == 0 && w + 4 * k < SNB) nzs[w + 4 * k] = nz4;
+            const double x = r[k];
+            Bsh[(w + 4 * k) * 64 + lane] = x;
+            const unsigned long long nzb = __ballot(x != 0.0);             // bit h of the word: 16-coordinate group h of the block holds a non-zero
+            const unsigned nlo = (unsigned)nzb, nhi = (unsigned)(nzb >> 32);
+            const int nz4 = ((nlo & 0xffffu) ? 1 : 0) | ((nlo >> 16) ? 2 : 0) | ((nhi & 0xffffu) ? 4 : 0) | ((nhi >> 16) ? 8 : 0);
+            if (lane == 0) nzs[w + 4 * k] = nz4;
         }
         SX_STAMP(10);                                                // (LDS stores and ballots; what follows is the wait behind the slowest wave's gather)
         sx_vote(votes + 4, w, lane, bits2);
@@ -697,11 +705,7 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
         X.acc[8] += 1;
 #endif
         {
-#ifndef OEM_EXP_NO_AFLAG
             const int v2 = votes[4] | votes[5] | votes[6] | votes[7] | X.aflag[0];
-#else
-            const int v2 = votes[4] | votes[5] | votes[6] | votes[7];
-#endif
             if (v2 & 2) break;                                       // somebody here has seen the host's abort word: nobody waits any more, leave
             if (!lz) { mw = v2; continue; }
         }
