@@ -124,6 +124,21 @@ def lib():
     return _lib
 
 
+_env_seen = None
+
+
+def sync_switches():
+    """Called by the Python mirrors of the R front ends (oem, oem_xtx, big_oem, xval_oem) at every call: if an OEM_* / OEMGPU_*
+    environment variable has changed since the last look, the library parses its switch table again.  So a script that flips a
+    switch between two calls gets what it asks for, as when the library read the environment at every call (rounds 1-4) -- while
+    the C library itself never calls getenv on the path of a call (callers of the C ABI use oemgpu_reload_switches())."""
+    global _env_seen
+    cur = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith(("OEM_", "OEMGPU_"))))
+    if cur != _env_seen:
+        _env_seen = cur
+        reload_switches()
+
+
 def reload_switches():
     """The OEM_* / OEMGPU_* environment switches are parsed once, at the first call into the library (include/oemgpu.h); a test that
     changes one calls this (tests/conftest.py does it behind every monkeypatch.setenv / delenv).  A no-op while the library is not loaded."""

@@ -253,6 +253,7 @@ def oem(x, y, family="gaussian", penalty=None, weights=(), lambda_=(), nlambda=1
         interrupt=None, _entry_weights=None):
     """oem(): R/oem.R:162-507, dense gaussian branch.  ngpus / devices / upload_threads / interrupt: the host-resident
     options of include/oemgpu.h (`options` gains ngpus / device; absent => one GPU)."""
+    L.sync_switches()
     if family not in ("gaussian", "binomial"):
         raise ValueError("'arg' should be one of 'gaussian', 'binomial'")
     penalty = _match_penalty(penalty)
@@ -350,6 +351,7 @@ def oem_xtx(xtx, xty, family="gaussian", penalty=None, lambda_=(), nlambda=100, 
             tol=1e-7, irls_maxit=100, irls_tol=1e-3, varnames=None, interrupt=None):
     """oem.xtx(): R/oem_xtx.R:109-360.  interrupt: a callable polled on the calling thread while the library waits for the GPU
     (the R shim's is R_CheckUserInterrupt, ref src/oem_xtx.cpp:160-163); True ends the call with OEMGPU_ERR_INTERRUPTED."""
+    L.sync_switches()
     penalty = _match_penalty(penalty)
     if getattr(xtx, "ndim", 0) != 2:
         raise ValueError("xtx must be a matrix")
@@ -408,6 +410,7 @@ def big_oem(x, y, family="gaussian", penalty=None, weights=(), lambda_=(), nlamb
             hessian_type="full", varnames=None, ngpus=0, devices=None, upload_threads=0, interrupt=None):
     """big.oem(): R/big_oem.R:121-441.  x: a (host) matrix or a list of row shards (the big.matrix stand-in);
     y: a vector or the matching list of shards."""
+    L.sync_switches()
     penalty = PENALTIES if penalty is None else _match_penalty(penalty)      # match.arg(several.ok=TRUE), no default narrowing
     shards = list(x) if isinstance(x, (list, tuple)) else [x]
     yshards = list(y) if isinstance(y, (list, tuple)) else [y]
@@ -479,6 +482,7 @@ def xval_oem(x, y, nfolds=10, foldid=None, type_measure=None, ncores=-1, family=
     """xval.oem(): R/oem_xval.R:107-460 (gaussian, dense).  foldid: values 1..nfolds; drawn with `rng` (a numpy Generator)
     as sample(rep(seq(nfolds), length = n)) when None.  ngpus / devices (host x only): the rows over several devices inside the
     library, as in oem()."""
+    L.sync_switches()
     if family not in ("gaussian", "binomial"):
         raise ValueError("'arg' should be one of 'gaussian', 'binomial'")
     penalty = _match_penalty(penalty)

@@ -911,8 +911,9 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
         for (int k = 0; k < RE; ++k) off[k] = par * X.s2 + g2off[k];
         sx_gather<RE>(off, need2, r, bits, X);
         SX_STAMP(3);
+        // (a coordinate beyond q came back as 0.0 and is stored like the others, over the zeros that sit there: no masked stores)
 #pragma unroll
-        for (int k = 0; k < RE; ++k) if ((need2 >> k) & 1u) Dst[tid + SNTH * k] = r[k];
+        for (int k = 0; k < RE; ++k) Dst[tid + SNTH * k] = r[k];
         sx_vote(votes, w, lane, bits);
         __syncthreads();
         SX_STAMP(4);

@@ -473,19 +473,16 @@ def test_a_timed_out_persistent_engine_is_not_tried_again_at_once(oa, monkeypatc
     monkeypatch.setenv("OEM_WCOOP_FAKE_TIMEOUT", "1")
     first = oa.oem_xtx(xd, xty, **kw)                               # the persistent launch "times out": made again on the launches
     assert oa.last_path_engine() == ("launches", f0 + 1)
-    # the switch is gone from the environment but the library has not been told: what follows is the context's memory alone
-    import os
-    del os.environ["OEM_WCOOP_FAKE_TIMEOUT"]
+    # the fake stays on: what follows is the context's memory -- four calls that never try the persistent engine (no new timeout) ...
     skipped = [oa.oem_xtx(xd, xty, **kw) for _ in range(4)]
-    assert oa.last_path_engine() == ("launches", f0 + 1)             # four calls skipped the persistent engine: no new timeout
+    assert oa.last_path_engine() == ("launches", f0 + 1)
     for f in [first] + skipped:
         assert np.abs(np.asarray(f["beta"][0]) - np.asarray(good["beta"][0])).max() < 1e-9
         assert np.array_equal(np.asarray(f["beta"][0]), np.asarray(first["beta"][0]))
-    # ... and then it is tried again: the fake is still in the library's table, so this one times out as well and the back-off doubles
+    # ... and then it is tried again: it "times out" as well, and the back-off doubles
     again = oa.oem_xtx(xd, xty, **kw)
     assert oa.last_path_engine() == ("launches", f0 + 2)
-    monkeypatch.setenv("OEM_WCOOP_FAKE_TIMEOUT", "1")                # (so that monkeypatch's undo finds what it set)
-    monkeypatch.delenv("OEM_WCOOP_FAKE_TIMEOUT")                     # re-read without the fake: the memory starts over
+    monkeypatch.delenv("OEM_WCOOP_FAKE_TIMEOUT")                     # the switches are read again without the fake: the memory starts over
     back = oa.oem_xtx(xd, xty, **kw)
     assert oa.last_path_engine() == ("rowcoop", f0 + 2)
     assert np.array_equal(np.asarray(back["beta"][0]), np.asarray(good["beta"][0])) and np.array_equal(np.asarray(again["beta"][0]), np.asarray(first["beta"][0]))

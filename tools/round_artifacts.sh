@@ -91,3 +91,8 @@ tail -c 300 $o/${tag}_bench.err
 head -c 1500 $o/${tag}_kernel_stats.csv
 [ -z "$quick" ] && head -c 4000 $o/${tag}_config_times.json
 exit 0
+# ---- round 5: the probes behind DESIGN.md section 3.3c's floor analysis, the A/B-free c4 time, xval at larger p
+if [ -z "$quick" ]; then
+  [ -x tools/areg_fma_probe ] && ./tools/areg_fma_probe > $o/${tag}_c4_areg_fma_probe.txt 2>&1
+  [ -x tools/valu_probe ] && ./tools/valu_probe > $o/${tag}_valu_probe.txt 2>&1
+fi
