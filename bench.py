@@ -721,9 +721,17 @@ def main():
             del backend, bufs
             torch.cuda.empty_cache()
             time.sleep(3.0)                        # the other ranks leave their devices
-            xf, yf = gen_c1(torch, dev, n, p, m, 0, n, 0, 1)
-            xh = xf.cpu().numpy(); yh = yf.cpu().numpy()
-            del xf, yf
+            if n % 8 == 0 and 8 % world == 0:
+                xf, yf = gen_c1(torch, dev, n, p, m, 0, n, 0, 1)
+                xh = xf.cpu().numpy(); yh = yf.cpu().numpy()
+                del xf, yf
+            else:
+                # (n not a multiple of 8: every rank drew its rows from its own seed -- the same rows again, rank by rank)
+                xh = np.empty((n, p), order="F"); yh = np.empty(n)
+                for r_, (lo_, hi_) in enumerate(row_partition(n, world)):
+                    xr, yr = gen_c1(torch, dev, n, p, m, lo_, hi_, r_, world)
+                    xh[lo_:hi_] = xr.cpu().numpy(); yh[lo_:hi_] = yr.cpu().numpy()
+                    del xr, yr
             torch.cuda.empty_cache()
             hr, hargs = host_resident(xh, yh, lambdas, p, ngpus=world, devices=devs)
             hr["max_abs_beta_diff_vs_the_rank_sharded_solve"] = float(np.abs(hargs.beta - beta_timed).max())

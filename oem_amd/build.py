@@ -183,24 +183,47 @@ def build(force=False, verbose=False):
     objs = []
     bdir = HERE / "_build"
     bdir.mkdir(exist_ok=True)
-    # the four objects and the two ISA listings are independent hipcc runs: do them side by side (a cold build is
-    # ~1.5 minutes of wall clock instead of ~5)
+    # the objects are independent hipcc runs: side by side
     from concurrent.futures import ThreadPoolExecutor
     jobs = []
-    with ThreadPoolExecutor(max_workers=int(os.environ.get("OEM_BUILD_JOBS", "6"))) as ex:
+    AUDITED = ("gram.hip", "path_small.hip", "path_coop.hip", "path_wcoop.hip", "path_symcoop.hip")
+    # the audited sources are compiled ONCE: -save-temps=obj leaves the device ISA of the very object that is linked next to it (until
+    # round 5 each of the five largest translation units was compiled twice, once for the object and once more with -S for the audit:
+    # the cold build's critical path)
+    def isa_path(src):
+        return bdir / (src + ".tmp") / (src[:-4] + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("OEM_BUILD_JOBS", str(min(8, os.cpu_count() or 1))))) as ex:
         for s in SOURCES:
             o = bdir / (s + ".o")
-            if force or _newer(CSRC / s, o) or any(_newer(d, o) for d in _deps()[len(SOURCES):]):
+            stale = force or _newer(CSRC / s, o) or any(_newer(d, o) for d in _deps()[len(SOURCES):]) or (s in AUDITED and not isa_path(s).exists())
+            if stale:
                 cmd = [hipcc, *FLAGS, "-c", str(CSRC / s), "-o", str(o)]
+                if s in AUDITED:
+                    tmp = bdir / (s + ".tmp")
+                    tmp.mkdir(exist_ok=True)
+                    cmd = [hipcc, *FLAGS, "-save-temps=obj", "-c", str(CSRC / s), "-o", str(tmp / (s[:-4] + ".o"))]
                 if verbose:
                     print(" ".join(cmd))
-                jobs.append(ex.submit(subprocess.run, cmd, check=True))
+                jobs.append((s, ex.submit(subprocess.run, cmd, capture_output=s in AUDITED, text=True)))
             objs.append(str(o))
-        # ISA audits: asm-owned accumulators (gram.hip), DPP hazards of the inline-asm FMAs (the register-resident path engines)
-        listing = {src: ex.submit(subprocess.run, [hipcc, *FLAGS, "-S", "--cuda-device-only", "-o", "-", str(CSRC / src)],
-                                  check=True, capture_output=True, text=True) for src in ("gram.hip", "path_small.hip", "path_coop.hip", "path_wcoop.hip", "path_symcoop.hip")}
-        for j in jobs:
-            j.result()
+        for s, j in jobs:
+            r = j.result()
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {s}:\n" + ((r.stderr or "")[-4000:]))
+            if s in AUDITED:
+                import shutil
+                shutil.copyfile(bdir / (s + ".tmp") / (s[:-4] + ".o"), bdir / (s + ".o"))
+                for f in (bdir / (s + ".tmp")).iterdir():             # (keep the ISA listing only: the other temporaries are 100 MB)
+                    if f != isa_path(s):
+                        f.unlink()
+
+        class _Listing:                                  # (the shape the audits below were written against)
+            def __init__(self, path):
+                self.stdout = Path(path).read_text()
+
+            def result(self):
+                return self
+        listing = {src: _Listing(isa_path(src)) for src in AUDITED}
         problems = audit_gram_isa(listing["gram.hip"].result().stdout)
         if problems:
             raise RuntimeError("gram.hip ISA audit failed:\n  " + "\n  ".join(problems[:20]))
