@@ -797,7 +797,7 @@ def test_wide_fused_group_kernel(oa, n, p, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,p,route", [(40, 100, "chosen"), (64, 600, "chosen"), (200, 1030, "chosen"), (300, 2500, "chosen"), (120, 9000, "chosen"),
+@pytest.mark.parametrize("n,p,route", [(40, 100, "chosen"), (45, 131, "chosen"), (64, 600, "chosen"), (200, 1030, "chosen"), (300, 2500, "chosen"), (120, 9000, "chosen"),
                                        (40, 100, "two products"), (64, 600, "two products")])
 @pytest.mark.parametrize("standardize", [False, True])
 def test_big_and_sparse_wide_branch_without_an_intercept(oa, n, p, route, standardize, monkeypatch):
