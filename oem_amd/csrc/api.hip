@@ -420,7 +420,7 @@ static int plan_paths(const PlanIn &in, PathPlan &P)
     static thread_local int runs_q = 0, runs_gmax = 0;
     if (plans_gen != sw().generation) { symplan_q = 0; runs_q = 0; runs_key.clear(); plans_gen = sw().generation; }
     SymcoopPlan *symplan_p = &symplan_plain;
-    if (!wide && !launches_only && nbatch == 1 && q > 1024 && q <= 4096 && !in.has_scale && !sw().OEM_NO_SYMCOOP.set && !sw().OEM_NO_COOP.set) {
+    if (!wide && !launches_only && nbatch == 1 && q > 1024 && q <= 4096 && !sw().OEM_NO_SYMCOOP.set && !sw().OEM_NO_COOP.set) {
         const int gmax = num_cu * 3 / 4 < WCOOP_GMAX ? num_cu * 3 / 4 : WCOOP_GMAX;
         if (any_grp) {
             // group operators: every group must be a run of neighbouring coordinates (<= 32 of them) -- the owners' slices are cut there

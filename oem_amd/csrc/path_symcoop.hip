@@ -389,6 +389,11 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
     }
     double ak = 1.0;                                                 // Nesterov's sequence (ref src/oem_dense.h:529, 633-651)
     const bool want_loss = GEN && A.compute_loss != 0, accel = GEN && A.accelerate != 0;
+    // GEN: oem.xtx's scale.factor (and oemSparse's intercept slot): oemXTX::get_beta rescales the iterate IN PLACE when a lambda ends (ref
+    // src/oem_xtx.h:576-581, quirk Q5), so the next lambda starts from beta / s -- whose product is not the one in hand.  The owners
+    // rescale, publish the rescaled coordinates in a round of their own (no operator, not an iteration) and the path goes on from there.
+    // (1 / s of this coordinate is read where it is used, once per lambda: the NT = 3 general form has no register left for it)
+    bool resc = false;
     const double yy = want_loss ? A.stats[2] : 0.0, nobs = want_loss ? A.stats[3] : 0.0;
     int goff[SE1];                                       // byte offsets (inside a parity) of this thread's senders of coordinate cg
     unsigned need1 = 0;
@@ -586,6 +591,11 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
                 const bool conv = !any;
                 if (conv || it >= maxit) {
                     const size_t kfin = (size_t)pp * nl + i;
+                    if (GEN && A.sinv) {
+                        int cgo = cg;
+                        asm volatile("" : "+v"(cgo));                // (opaque: an address or a load hipcc can hoist out of the loop is a register pair the NT = 3 general form does not have)
+                        ca *= A.sinv[cgo];
+                    }
                     if (own && part == 0) A.beta[kfin * q + cg] = ca;
                     if (tid == 0 && writer) { A.niter[kfin] = conv ? it : maxit + 1; if (!want_loss) A.loss[kfin] = 1e99; }      // ref src/oem_base.h:94-109
                     if (want_loss) {
@@ -602,7 +612,7 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
                         }
                     }
                     const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
-                    if (i + 1 < nlam) i = i + 1;
+                    if (i + 1 < nlam) { i = i + 1; resc = GEN && A.sinv != nullptr; }
                     else if (pp + 1 < npen) { pp = pp + 1; i = 0; fresh = true; pen = A.penalty[pp]; ak = 1.0; }
                     else done_now = true;
                     if (!done_now) {
@@ -615,41 +625,47 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
                 }
             }
             if (done_now) break;
-            // beta_{t+1} of this coordinate: u = d beta - g + XY, the operator, the stop rule (ref src/utils.cpp:537-549)
-            const double b0 = fresh ? 0.0 : ca;
-            double u = (d * b0 - (fresh ? 0.0 : gsum)) + xyc;
-            double bn;
-            if (GEN && thkind >= K_GRP) {
-                // group operators: u of this owner's coordinates through LDS, the squared norm of this coordinate's group in member order
-                if (thkind == K_SGL) u = soft1(u, pfc * thc[TH_L1], 1.0);
-                if (own && part == 0) uo[ocl] = u;
-                __syncthreads();
-                double s2 = 0.0;
-                for (int m = gm0; m < gm1; ++m) { const double x = uo[m]; s2 += x * x; }
-                double f = 1.0;
-                if (gm1 < gm0) f = 0.0;
-                else if (!gzr) {
-                    const double sn = sqrt(s2), pen_g = thc[TH_L] * gwc;
-                    if (thkind == K_GRP || thkind == K_SGL) { const double t = 1.0 - pen_g / sn; f = (0.0 < t) ? t : 0.0; }     // (quirk Q6: 0 / 0 -> NaN -> 0)
-                    else if (thkind == K_GRP_MCP) f = mcp_norm(sn, pen_g, thc[TH_D], thc[TH_GAMMA]);
-                    else f = scad_norm(sn, pen_g, thc[TH_D], thc[TH_GAMMA]);
+            if (GEN && resc) {
+                // the round of the rescaled iterate (above): beta / s goes out as it is, marked "moving" so that nobody takes this round
+                // for a converged iteration; it is not counted
+                val = ca; mybit = 1; resc = false;
+            } else {
+                // beta_{t+1} of this coordinate: u = d beta - g + XY, the operator, the stop rule (ref src/utils.cpp:537-549)
+                const double b0 = fresh ? 0.0 : ca;
+                double u = (d * b0 - (fresh ? 0.0 : gsum)) + xyc;
+                double bn;
+                if (GEN && thkind >= K_GRP) {
+                    // group operators: u of this owner's coordinates through LDS, the squared norm of this coordinate's group in member order
+                    if (thkind == K_SGL) u = soft1(u, pfc * thc[TH_L1], 1.0);
+                    if (own && part == 0) uo[ocl] = u;
+                    __syncthreads();
+                    double s2 = 0.0;
+                    for (int m = gm0; m < gm1; ++m) { const double x = uo[m]; s2 += x * x; }
+                    double f = 1.0;
+                    if (gm1 < gm0) f = 0.0;
+                    else if (!gzr) {
+                        const double sn = sqrt(s2), pen_g = thc[TH_L] * gwc;
+                        if (thkind == K_GRP || thkind == K_SGL) { const double t = 1.0 - pen_g / sn; f = (0.0 < t) ? t : 0.0; }     // (quirk Q6: 0 / 0 -> NaN -> 0)
+                        else if (thkind == K_GRP_MCP) f = mcp_norm(sn, pen_g, thc[TH_D], thc[TH_GAMMA]);
+                        else f = scad_norm(sn, pen_g, thc[TH_D], thc[TH_GAMMA]);
+                    }
+                    bn = (own && f != 0.0) ? u * f / thc[TH_D] : 0.0;
+                    __syncthreads();                                     // (uo is written again next iteration)
+                } else bn = own ? sx_op(u, pfc, thkind, thc) : 0.0;
+                double adp_part = 0.0, akn = 1.0;
+                if (accel) {                                             // ref src/oem_dense.h:633-651
+                    akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak));
+                    const double ratio = (ak - 1.0) / akn, upd = bn, diff = upd - b0;
+                    bn = upd + ratio * diff;
+                    adp_part = (own && part == 0) ? (bn - upd) * diff : 0.0;
                 }
-                bn = (own && f != 0.0) ? u * f / thc[TH_D] : 0.0;
-                __syncthreads();                                     // (uo is written again next iteration)
-            } else bn = own ? sx_op(u, pfc, thkind, thc) : 0.0;
-            double adp_part = 0.0, akn = 1.0;
-            if (accel) {                                             // ref src/oem_dense.h:633-651
-                akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak));
-                const double ratio = (ak - 1.0) / akn, upd = bn, diff = upd - b0;
-                bn = upd + ratio * diff;
-                adp_part = (own && part == 0) ? (bn - upd) * diff : 0.0;
+                const double cu = fabs(bn), qo = fabs(b0);
+                const bool cn = cu > 1e-13, qn = qo > 1e-13;
+                mybit = (own && ((cn != qn) || (cn && qn && fabs(bn - b0) > tol * qo))) ? 1 : 0;
+                ca = bn; fresh = false; ++it;
+                val = bn;
+                if (accel) { npart = adp_part; acc_akn = akn; }
             }
-            const double cu = fabs(bn), qo = fabs(b0);
-            const bool cn = cu > 1e-13, qn = qo > 1e-13;
-            mybit = (own && ((cn != qn) || (cn && qn && fabs(bn - b0) > tol * qo))) ? 1 : 0;
-            ca = bn; fresh = false; ++it;
-            val = bn;
-            if (accel) { npart = adp_part; acc_akn = akn; }
         }
 
         // ---- exchange 2: the owners' values out, the blocks this workgroup touches in (Lanczos: scaled by 1 / ||w'||, whose
@@ -1263,9 +1279,8 @@ bool path_symcoop_eligible(const PathArgs &a, bool group_penalty, bool plan_has_
 {
     if (sw().OEM_NO_SYMCOOP.set || sw().OEM_NO_COOP.set) return false;
     if (a.p <= 1024 || a.p > 4096 || a.nbatch > 1 || a.pen_split) return false;
-    if (a.sinv) return false;                            // (scale.factor rescales the iterate in place at every lambda: path_large.hip's replicated update)
     if (group_penalty && !plan_has_runs) return false;   // (groups that are not runs of <= 32 neighbouring coordinates: the same)
-    if ((group_penalty || a.accelerate || a.compute_loss) && sw().OEM_SYMCOOP_NO_GENERAL.set) return false;
+    if ((group_penalty || a.accelerate || a.compute_loss || a.sinv) && sw().OEM_SYMCOOP_NO_GENERAL.set) return false;
     return true;
 }
 
@@ -1276,7 +1291,7 @@ int launch_path_symcoop(hipStream_t s, const PathArgs &a_, const SymcoopPlan &P,
     OEM_HIP(hipMemsetAsync(xchg, 0, symcoop_xchg_bytes(P), s));                 // the tags must start at 0
     OEM_HIP(hipMemsetAsync(a.d_out, 0, sizeof(double) * D_OUT_LEN, s));        // [6]: only a timed-out workgroup writes it
     unsigned long long *x = reinterpret_cast<unsigned long long *>(xchg);
-    const bool gen = a.ngroups > 0 || a.accelerate || a.compute_loss;      // (group tables present: a group penalty is in the call)
+    const bool gen = a.ngroups > 0 || a.accelerate || a.compute_loss || a.sinv;      // (group tables present: a group penalty is in the call; sinv: the in-place rescale)
 #define SX_LAUNCH(NT_, GEN_)                                                                                                     \
     do {                                                                                                                         \
         const size_t sh = symcoop_lds_bytes<NT_, GEN_>();                                                                              \

@@ -109,20 +109,37 @@ def test_dense_n_gt_p_at_p_5000(oa):
         _same_path(g, r, k, ("device-resident", kw["penalty"][k]))
 
 
-def test_config4_scale_factor_at_p4096(oa):
-    """config 4 with `scale.factor` (ref src/oem_xtx.h:347-381): the one production case at p = 4,096 that the register-resident
-    engine does not take"""
+def test_config4_scale_factor_at_p4096(oa, monkeypatch):
+    """config 4 with `scale.factor` (ref src/oem_xtx.h:347-381, 576-581: the iterate is rescaled IN PLACE when a lambda ends, quirk Q5) --
+    until round 5 the one production case at p = 4,096 that the register-resident engine did not take; now the owners rescale their
+    coordinates and publish them in a round of their own (path_symcoop.hip, the general form).  Against the oracle through the default
+    selection, and the launch-per-iteration engine (the fallback) against the same."""
     import torch
     p = 4096
     xtx, xty = _gram_problem(p, 65536 // 4, 9)
     sf = np.random.default_rng(3).uniform(0.5, 2.0, p)
     kw = dict(penalty="lasso", nlambda=3, lambda_min_ratio=0.1, tol=1e-10, maxit=500)
-    f = oa.oem_xtx(torch.as_tensor(xtx, device="cuda"), xty, scale_factor=sf, **kw)
-    assert oa.last_path_engine()[0] == "launches"
+    xd = torch.as_tensor(xtx, device="cuda")
+    f = oa.oem_xtx(xd, xty, scale_factor=sf, **kw)
+    assert oa.last_path_engine()[0] == "symcoop"
     lmax = _lam_max(xtx / sf[:, None] / sf[None, :])
     assert abs(f["d"] - 1.005 * lmax) <= DTOL * lmax
     r = orc.fit_xtx(xtx, xty, native=True, scale_factor=sf, d_override=f["d"], **kw)
     _same_path(f, r, 0, "scale.factor at 4096")
+    monkeypatch.setenv("OEM_NO_SYMCOOP", "1")
+    g = oa.oem_xtx(xd, xty, scale_factor=sf, **kw)
+    assert oa.last_path_engine()[0] == "launches"
+    _same_path(g, r, 0, "scale.factor at 4096, launches")
+    monkeypatch.delenv("OEM_NO_SYMCOOP")
+    # several penalties, more lambdas, a smaller size of the same engine (two tiles per wave), user lambdas
+    xtx2, xty2 = _gram_problem(3000, 4500, 11)
+    sf2 = np.random.default_rng(4).uniform(0.25, 4.0, 3000)
+    kw2 = dict(penalty=["lasso", "mcp", "scad.net", "ols"], alpha=0.6, nlambda=9, lambda_min_ratio=0.02, tol=1e-9, maxit=300)
+    f2 = oa.oem_xtx(torch.as_tensor(xtx2, device="cuda"), xty2, scale_factor=sf2, **kw2)
+    assert oa.last_path_engine()[0] == "symcoop"
+    r2 = orc.fit_xtx(xtx2, xty2, native=True, scale_factor=sf2, d_override=f2["d"], **kw2)
+    for k in range(4):
+        _same_path(f2, r2, k, ("scale.factor at 3000", kw2["penalty"][k]))
 
 
 @pytest.mark.parametrize("n,p", [(500, 20_000), (200, 30_000)])

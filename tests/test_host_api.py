@@ -243,7 +243,7 @@ def test_the_plan_names_one_engine_and_a_workspace_that_fits_at_every_size():
     # the sizes BASELINE.json names
     assert _plan(100, ["elastic.net"])[0] == "rows"                       # config 1
     assert _plan(200, ["mcp"])[0] == "rows" and _plan(512, ["grp.lasso"], groups=lambda n: np.arange(n) // 8 + 1)[0] == "coop"      # configs 2, 3
-    assert _plan(4096, ["lasso"], sem=_SEM_XTX)[0] == "symcoop" and _plan(4096, ["lasso"], sem=_SEM_XTX, has_scale=True)[0] == "launches"      # config 4
+    assert _plan(4096, ["lasso"], sem=_SEM_XTX)[0] == "symcoop" and _plan(4096, ["lasso"], sem=_SEM_XTX, has_scale=True)[0] == "symcoop"      # config 4 (scale.factor: on the register-resident engine since round 5)
     assert _plan(257 - 1, ["lasso"], sem=_SEM_BIG, intercept=1)[0] == "coop"                                              # config 5: q = 257 (from 209 on)
     assert _plan(2048, ["lasso"])[0] == "rowcoop" and _plan(2048, ["grp.lasso"], groups=_RUNS4)[0] == "symcoop" and _plan(4097, ["lasso"])[0] == "launches"
 
