@@ -113,19 +113,104 @@ __global__ __launch_bounds__(256) void gemv_sym_kernel(const double *__restrict_
     }
 }
 
-// generic fallback (q > 4096): vector re-read from L1/L2
-__global__ __launch_bounds__(256) void gemv_sym_generic_kernel(const double *__restrict__ M, int q, const double *__restrict__ vec,
-                                                                double *__restrict__ out, const int *__restrict__ done)
+// q > 4096, aligned rows: the matrix no longer sits in the Infinity Cache (q = 8,192: 537 MB), so this is a plain HBM stream and has to
+// be issued like one.  The generic kernel of rounds 1-4 read 8 bytes per lane with ONE dependent accumulator and fetched the vector again
+// for every row: 2.1 TB/s (profiles/r5_large_q_times.txt).  Here a workgroup takes GT = 16 consecutive rows (four per wave), stages the
+// vector through LDS in panels of GP columns (once per row tile: 1 / 16 of the matrix bytes, from L2), and every lane keeps eight
+// 16-byte loads in flight -- two column steps of four rows -- with an accumulator pair per row across the panels.  Columns beyond q read a
+// clamped address against a zero of the staged vector (no exec-masked loads).
+constexpr int GL_GP = 8192, GL_RW = 4;               // columns per LDS panel (64 KB: two workgroups per CU); rows per wave
+__global__ __launch_bounds__(256) void gemv_large_kernel(const double *__restrict__ M, int q, const double *__restrict__ vec,
+                                                          double *__restrict__ out, const int *__restrict__ done)
 {
+    extern __shared__ __attribute__((aligned(16))) double vsh[];
     if (done && *done) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
-    for (int r = wave; r < q; r += nwave) {
-        const double *row = M + (size_t)r * q;
-        double a = 0.0;
-        for (int c = lane; c < q; c += 64) a = fma(row[c], vec[c], a);
-        const double s = wsum(a);
-        if (lane == 0) out[r] = s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ntile = (q + 4 * GL_RW - 1) / (4 * GL_RW);
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int r0 = tile * 4 * GL_RW + w * GL_RW;
+        const double *row[GL_RW];
+#pragma unroll
+        for (int i = 0; i < GL_RW; ++i) row[i] = M + (size_t)(r0 + i < q ? r0 + i : q - 1) * q;      // (rows beyond q: the last row again, never stored)
+        double a0[GL_RW], a1[GL_RW];
+#pragma unroll
+        for (int i = 0; i < GL_RW; ++i) { a0[i] = 0.0; a1[i] = 0.0; }
+        for (int c0 = 0; c0 < q; c0 += GL_GP) {
+            const int pc = q - c0 < GL_GP ? q - c0 : GL_GP, pcp = (pc + 255) & ~255;
+            __syncthreads();                                     // (the previous panel has been read)
+            for (int j = 2 * tid; j < pcp; j += 512) {
+                v2d t = v2d{0.0, 0.0};
+                if (j + 1 < pc) t = *reinterpret_cast<const v2d *>(vec + c0 + j);
+                else if (j < pc) t.x = vec[c0 + j];
+                *reinterpret_cast<v2d *>(vsh + j) = t;
+            }
+            __syncthreads();
+            const int cmax = q - 2;                              // the last pair of a row (q is even: aligned rows)
+            for (int j = 2 * lane; j < pcp; j += 256) {
+                const int ja = c0 + j < cmax ? c0 + j : cmax, jb = c0 + j + 128 < cmax ? c0 + j + 128 : cmax;
+                v2d ta[GL_RW], tb[GL_RW];
+#pragma unroll
+                for (int i = 0; i < GL_RW; ++i) { ta[i] = *reinterpret_cast<const v2d *>(row[i] + ja); tb[i] = *reinterpret_cast<const v2d *>(row[i] + jb); }
+                const v2d va = *reinterpret_cast<const v2d *>(vsh + j), vb = *reinterpret_cast<const v2d *>(vsh + j + 128);
+#pragma unroll
+                for (int i = 0; i < GL_RW; ++i) {
+                    a0[i] = fma(ta[i].x, va.x, a0[i]); a1[i] = fma(ta[i].y, va.y, a1[i]);
+                    a0[i] = fma(tb[i].x, vb.x, a0[i]); a1[i] = fma(tb[i].y, vb.y, a1[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GL_RW; ++i) {
+            const double sres = wsum(a0[i] + a1[i]);
+            if (lane == 0 && r0 + i < q) out[r0 + i] = sres;
+        }
+    }
+}
+
+// ... and the same stream where the rows are only 8-byte aligned (q odd: big.oem / xval.oem / a sparse x with an intercept have q = p + 1):
+// 8-byte loads, four column steps of four rows in flight per lane instead of two
+__global__ __launch_bounds__(256) void gemv_large_u_kernel(const double *__restrict__ M, int q, const double *__restrict__ vec,
+                                                            double *__restrict__ out, const int *__restrict__ done)
+{
+    extern __shared__ __attribute__((aligned(16))) double vsh[];
+    if (done && *done) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ntile = (q + 4 * GL_RW - 1) / (4 * GL_RW);
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int r0 = tile * 4 * GL_RW + w * GL_RW;
+        const double *row[GL_RW];
+#pragma unroll
+        for (int i = 0; i < GL_RW; ++i) row[i] = M + (size_t)(r0 + i < q ? r0 + i : q - 1) * q;
+        double a0[GL_RW], a1[GL_RW];
+#pragma unroll
+        for (int i = 0; i < GL_RW; ++i) { a0[i] = 0.0; a1[i] = 0.0; }
+        for (int c0 = 0; c0 < q; c0 += GL_GP) {
+            const int pc = q - c0 < GL_GP ? q - c0 : GL_GP, pcp = (pc + 255) & ~255;
+            __syncthreads();
+            for (int j = tid; j < pcp; j += 256) vsh[j] = j < pc ? vec[c0 + j] : 0.0;
+            __syncthreads();
+            const int cmax = q - 1;
+            for (int j = lane; j < pcp; j += 256) {
+                double t[4][GL_RW], vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jc = c0 + j + 64 * u < cmax ? c0 + j + 64 * u : cmax;
+#pragma unroll
+                    for (int i = 0; i < GL_RW; ++i) t[u][i] = row[i][jc];
+                    vv[u] = vsh[j + 64 * u];
+                }
+#pragma unroll
+                for (int i = 0; i < GL_RW; ++i) {
+                    a0[i] = fma(t[0][i], vv[0], a0[i]); a1[i] = fma(t[1][i], vv[1], a1[i]);
+                    a0[i] = fma(t[2][i], vv[2], a0[i]); a1[i] = fma(t[3][i], vv[3], a1[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GL_RW; ++i) {
+            const double sres = wsum(a0[i] + a1[i]);
+            if (lane == 0 && r0 + i < q) out[r0 + i] = sres;
+        }
     }
 }
 
@@ -145,7 +230,17 @@ int launch_gemv(hipStream_t s, const double *M, int q, const double *vec, double
     else if (q <= 1024) OEM_GEMV(16);
     else if (q <= 2048) OEM_GEMV(32);
     else if (q <= 4096) OEM_GEMV(64);
-    else hipLaunchKernelGGL(gemv_sym_generic_kernel, dim3(blocks), dim3(256), 0, s, M, q, vec, out, done);
+    else if (al && vec_al) {
+        const size_t lds = sizeof(double) * GL_GP;
+        if (lds_limit_once(reinterpret_cast<const void *>(&gemv_large_kernel), lds)) return OEMGPU_ERR_HIP;
+        const int ntile = (q + 4 * GL_RW - 1) / (4 * GL_RW);
+        hipLaunchKernelGGL(gemv_large_kernel, dim3(ntile < num_cu * 2 ? ntile : num_cu * 2), dim3(256), lds, s, M, q, vec, out, done);
+    } else {
+        const size_t lds = sizeof(double) * GL_GP;
+        if (lds_limit_once(reinterpret_cast<const void *>(&gemv_large_u_kernel), lds)) return OEMGPU_ERR_HIP;
+        const int ntile = (q + 4 * GL_RW - 1) / (4 * GL_RW);
+        hipLaunchKernelGGL(gemv_large_u_kernel, dim3(ntile < num_cu * 2 ? ntile : num_cu * 2), dim3(256), lds, s, M, q, vec, out, done);
+    }
 #undef OEM_GEMV
     OEM_HIP(hipGetLastError());
     return 0;
