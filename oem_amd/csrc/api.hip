@@ -972,6 +972,17 @@ int oemgpu_synchronize(oemgpu_ctx *c)
     return 0;
 }
 
+int oemgpu_selftest_gram_plan(int64_t n, int32_t p, int32_t num_cu, int64_t *out)
+{
+    if (n < 1 || p < 1 || num_cu < 1 || !out) { set_error("selftest_gram_plan: bad argument"); return OEMGPU_ERR_ARG; }
+    const GramPlan pl = gram_plan(n, p, num_cu);
+    const int64_t n8 = pl.n8, n6 = pl.n6;
+    out[0] = pl.ntc; out[1] = n8; out[2] = n6; out[3] = pl.nchunk; out[4] = pl.steps;
+    out[5] = 64 * (n8 * (n8 - 1) / 2) + 48 * n8 * n6 + 36 * (n6 * (n6 - 1) / 2) + 36 * n8 + 24 * n6;
+    out[6] = (int64_t)pl.ntc * (pl.ntc + 1) / 2;
+    return 0;
+}
+
 int oemgpu_selftest_hold_cus(oemgpu_ctx *c, int32_t blocks, double ms)
 {
     if (!c || blocks < 1 || blocks > 4096 || !(ms > 0.0) || ms > 30000.0) { set_error("hold_cus: bad argument"); return OEMGPU_ERR_ARG; }

@@ -980,34 +980,44 @@ __global__ __launch_bounds__(256) void gram_blk_kernel(const double *__restrict_
 #endif
 constexpr int SB_NSLOT = OEM_SB_NSLOT;           // ring depth: the prefetch distance is (NSLOT - 3) slabs
 
+// Super-block heights.  A super-block row is HI = 8 or 6 tile columns high (gram_plan deals the ntc tile columns into eights and
+// sixes so that little of the last one is padding: with eights alone p = 160 multiplied 136 tiles' worth for 55 real ones,
+// p = 300 300 for 190 -- tools/gram_band.sh, round 5); the eights come first, so an off-diagonal super-block (SI > SJ) is
+// 8 x 8, 6 x 8 or 6 x 6 tiles and its four waves take (HI / 2) x (HJ / 2) tiles each.
 // row of the lower triangle that holds row-major index tt (tt = I (I + 1) / 2 + J, J <= I)
 constexpr int tri_row(int tt) { int I = 0; while ((I + 1) * (I + 2) / 2 <= tt) ++I; return I; }
+// diagonal super-block of height H: wave W multiplies tiles sb_diag_t0(H, W) .. sb_diag_t0(H, W + 1) - 1 of the row-major triangle
+// (H = 8: 36 tiles, 9 each; H = 6: 21 tiles, 6 + 5 + 5 + 5)
+constexpr int sb_diag_t0(int H, int W) { return H == 8 ? 9 * W : (W == 0 ? 0 : 1 + 5 * W); }
 
-// One slab of one wave of a super-block.  Eight fragments in registers.
-//   off-diagonal super-block: s.v[0..3] = the block's tile rows, s.v[4..7] = its tile columns, 16 tiles (I, J);
-//   diagonal super-block (8 x 8 tile triangle = 36 tiles): s.v[f] = fragment f, wave W multiplies tiles 9 W .. 9 W + 8 of
-//   the row-major triangle (9 each: balanced), and carries X'y / column sums of fragments 2 W, 2 W + 1 on the VALU.
-template <bool DIAGSB, int W, bool XF, bool MASKED, typename Hook = NoHook>
+// One slab of one wave of a super-block.  Up to eight fragments in registers.
+//   off-diagonal super-block: s.v[0 .. NR-1] = the wave's tile rows, s.v[NR .. NR+NC-1] = its tile columns, NR x NC tiles (I, J);
+//   diagonal super-block (H = NR = NC; H (H + 1) / 2 tiles): s.v[f] = fragment f, wave W multiplies its share of the row-major
+//   triangle and carries X'y / column sums of fragments 2 W, 2 W + 1 (where those exist) on the VALU.
+template <bool DIAGSB, int W, bool XF, bool MASKED, int NR, int NC, typename Hook = NoHook>
 __device__ __forceinline__ void sb_consume(Slab<8> &s, const double (&c)[8], double cy, double (&sx)[2], double (&sxy)[2],
                                            double &sy, double &syy, int64_t r, int64_t n, Hook &&hook = NoHook())
 {
+    constexpr int NFR = DIAGSB ? NR : NR + NC;
     double m0 = 1.0, m1 = 1.0;
     if (MASKED) { m0 = (r < n) ? 1.0 : 0.0; m1 = (r + 1 < n) ? 1.0 : 0.0; }
 #pragma unroll
-    for (int f = 0; f < 8; ++f) {
+    for (int f = 0; f < NFR; ++f) {
         if (XF) { s.v[f].x -= c[f]; s.v[f].y -= c[f]; }
         if (MASKED) { s.v[f].x *= m0; s.v[f].y *= m1; }
     }
     if (DIAGSB) {
         double y0 = s.y.x - cy, y1 = s.y.y - cy;
         if (MASKED) { y0 *= m0; y1 *= m1; }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const v2d v = s.v[2 * W + k];
-            sx[k] = (sx[k] + v.x) + v.y;
-            sxy[k] = fma(v.x, y0, sxy[k]);
-            sxy[k] = fma(v.y, y1, sxy[k]);
-        }
+        static_for<2>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            if constexpr (2 * W + k < NR) {
+                const v2d v = s.v[2 * W + k];
+                sx[k] = (sx[k] + v.x) + v.y;
+                sxy[k] = fma(v.x, y0, sxy[k]);
+                sxy[k] = fma(v.y, y1, sxy[k]);
+            }
+        });
         if (W == 0) { sy = (sy + y0) + y1; syy = fma(y0, y0, syy); syy = fma(y1, y1, syy); }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1015,64 +1025,70 @@ __device__ __forceinline__ void sb_consume(Slab<8> &s, const double (&c)[8], dou
     static_for<2>([&](auto E) {
         constexpr int e = decltype(E)::value;
         if constexpr (DIAGSB) {
-            static_for<9>([&](auto T_) {
-                constexpr int t = decltype(T_)::value, tt = 9 * W + t, I = tri_row(tt), J = tt - I * (I + 1) / 2;
+            constexpr int T0 = sb_diag_t0(NR, W), NT = sb_diag_t0(NR, W + 1) - T0;
+            static_for<NT>([&](auto T_) {
+                constexpr int t = decltype(T_)::value, tt = T0 + t, I = tri_row(tt), J = tt - I * (I + 1) / 2;
                 AccTile<t>::mfma(s.v[I][e], s.v[J][e]);
-                hook(std::integral_constant<int, e * 9 + t>{});
+                hook(std::integral_constant<int, e * NT + t>{});
             });
         } else {
-            static_for<16>([&](auto T_) {
+            static_for<NR * NC>([&](auto T_) {
                 constexpr int t = decltype(T_)::value;
-                AccTile<t>::mfma(s.v[t / 4][e], s.v[4 + t % 4][e]);
-                hook(std::integral_constant<int, e * 16 + t>{});
+                AccTile<t>::mfma(s.v[t / NC][e], s.v[NR + t % NC][e]);
+                hook(std::integral_constant<int, e * NR * NC + t>{});
             });
         }
     });
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool DIAGSB, int W, bool XF>
+template <bool DIAGSB, int W, bool XF, int HI, int HJ>
 __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64_t n, int64_t ld, int p,
-                                             const double *__restrict__ y, const double *__restrict__ sums, int ntc, int SI,
-                                             int SJ, int64_t row_begin, int steps, double *__restrict__ tdst,
+                                             const double *__restrict__ y, const double *__restrict__ sums, int ntc, int TI,
+                                             int TJ /* first tile column of the row / column group */, int64_t row_begin, int steps, double *__restrict__ tdst,
                                              double *__restrict__ vdst, double *lds)
 {
-    constexpr int F = DIAGSB ? 8 : 16;                 // x fragments per slab
-    constexpr int DPW = DIAGSB ? 3 : 4;                // DMAs per wave per slab (diagonal: 2 fragments + its own copy of y)
-    constexpr int NFETCH = DIAGSB ? 9 : 8;             // ring reads per wave per slab
-    constexpr int NMFMA = DIAGSB ? 18 : 32;
+    static_assert(HI <= HJ && (HI == 6 || HI == 8) && (HJ == 6 || HJ == 8) && (!DIAGSB || HI == HJ), "super-block heights");
+    constexpr int NR = DIAGSB ? HI : HI / 2, NC = DIAGSB ? HI : HJ / 2;   // the wave's tile block (diagonal: the whole triangle's fragments)
+    constexpr int NFR = DIAGSB ? HI : NR + NC;         // fragments in this wave's registers
+    constexpr int F = DIAGSB ? HI : HI + HJ;           // x fragments per slab
+    constexpr int NDMA = (F + 3) / 4;                  // ... dealt to the four waves (a ragged deal repeats the last fragment)
+    constexpr int DPW = NDMA + (DIAGSB ? 1 : 0);       // DMAs per wave per slab (diagonal: + its own copy of y)
+    constexpr int NFETCH = NFR + (DIAGSB ? 1 : 0);     // ring reads per wave per slab
+    constexpr int NTW = DIAGSB ? sb_diag_t0(HI, W + 1) - sb_diag_t0(HI, W) : NR * NC;   // tiles of this wave
+    constexpr int NMFMA = 2 * NTW;
+    constexpr int NACT = 1 + NFETCH + DPW;             // hand-over + ring reads + DMAs, one after each of the first MFMAs
     constexpr int SLOT_B = (F + (DIAGSB ? 4 : 0)) * 1024, NSLOT = SB_NSLOT;
     static_assert((NSLOT - 2) * DPW <= 63, "vmcnt field is 6 bits");
-    static_assert(1 + NFETCH + DPW <= NMFMA, "not enough MFMAs per slab to carry the hooks");
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, q = lane >> 4;
     const gptr_t xg = (gptr_t)x, yg = (gptr_t)y;
     const double inv_cnt = XF ? 1.0 / sums[p + 1] : 0.0;
     const double cy = XF ? sums[p] * inv_cnt : 0.0;
     // tile column of fragment f of this super-block
-    auto frag_tile = [&](int f) { return DIAGSB ? 8 * SI + f : (f < 8 ? 8 * SI + f : 8 * SJ + (f - 8)); };
+    auto frag_tile = [&](int f) { return DIAGSB ? TI + f : (f < HI ? TI + f : TJ + (f - HI)); };
     auto frag_col = [&](int f) { const int col = 16 * frag_tile(f) + i; return col < p ? col : p - 1; };
     // ---- DMA duty of this wave: fragments w, w + 4 (, w + 8, w + 12) (+ its own copy of y in a diagonal super-block).
     // Addressing: one scalar base per fragment (first column of its tile at the chunk's first row, bumped by a scalar
     // add per slab) + a 32-bit lane offset (column within the tile, row pair) -- 64-bit VALU adds run on the DP units.
-    constexpr int NDMA = F / 4;
     gptr_t dbase[NDMA];
     unsigned doff[NDMA];
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) {
-        int t0 = 16 * frag_tile(w + 4 * k);                       // wave-uniform
+        const int fr = w + 4 * k < F ? w + 4 * k : F - 1;
+        int t0 = 16 * frag_tile(fr);                              // wave-uniform
         if (t0 > p - 1) t0 = p - 1;
         dbase[k] = xg + (size_t)t0 * ld + row_begin;
-        doff[k] = (unsigned)(((int64_t)(frag_col(w + 4 * k) - t0) * ld + 2 * q) * 8);
+        doff[k] = (unsigned)(((int64_t)(frag_col(fr) - t0) * ld + 2 * q) * 8);
     }
     gptr_t ybase = yg + row_begin;
     const unsigned yoff = (unsigned)(2 * q * 8);
     // ---- the fragments this wave multiplies: registers 0..7 <- ring fragments rf[0..7]
     int rb = 0, cb = 0;                                            // off-diagonal: first fragment of the row / column group
-    if (!DIAGSB) { rb = __builtin_amdgcn_readfirstlane(4 * (w >> 1)); cb = __builtin_amdgcn_readfirstlane(8 + 4 * (w & 1)); }
-    auto reg_frag = [&](int f) { return DIAGSB ? f : (f < 4 ? rb + f : cb + f - 4); };
+    if (!DIAGSB) { rb = __builtin_amdgcn_readfirstlane(NR * (w >> 1)); cb = __builtin_amdgcn_readfirstlane(HI + NC * (w & 1)); }
+    auto reg_frag = [&](int f) { return DIAGSB ? f : (f < NR ? rb + f : cb + f - NR); };
     double c[8];
 #pragma unroll
-    for (int f = 0; f < 8; ++f) c[f] = XF ? sums[frag_col(reg_frag(f))] * inv_cnt : 0.0;
+    for (int f = 0; f < 8; ++f) c[f] = (XF && f < NFR) ? sums[frag_col(reg_frag(f))] * inv_cnt : 0.0;
     double sx[2] = {0.0, 0.0}, sxy[2] = {0.0, 0.0}, sy = 0.0, syy = 0.0;
     static_for<16>([&](auto T_) { AccTile<decltype(T_)::value>::zero(); });
     asm volatile("s_nop 7" ::: "memory");
@@ -1086,7 +1102,11 @@ __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64
     auto issue1 = [&](int slot, auto K_) {                         // one DMA of this wave's share of the next slab
         constexpr int k = decltype(K_)::value;
         const unsigned dst = ring + (unsigned)slot * SLOT_B;
-        if constexpr (k < NDMA) { set_m0(dst + (unsigned)(w + 4 * k) * 1024); glds_s<0>(doff[k], dbase[k]); dbase[k] += 8; }
+        if constexpr (k < NDMA) {
+            unsigned fr = (unsigned)(w + 4 * k);
+            if constexpr (4 * k + 3 >= F) fr = fr < (unsigned)F ? fr : (unsigned)(F - 1);   // the repeat lands where the original does
+            set_m0(dst + fr * 1024); glds_s<0>(doff[k], dbase[k]); dbase[k] += 8;
+        }
         else { set_m0(dst + (unsigned)(F + w) * 1024); glds_s<0>(yoff, ybase); ybase += 8; }
     };
     auto issue = [&](int slot) { static_for<DPW>([&](auto K_) { issue1(slot, K_); }); };
@@ -1095,7 +1115,7 @@ __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64
     auto fetch1 = [&](Slab<8> &s, int slot, auto J_) {
         constexpr int j = decltype(J_)::value;
         const v2d *b = rd + (slot * SLOT_B) / 16;
-        if constexpr (j < 8) s.v[j] = b[reg_frag(j) * 64];
+        if constexpr (j < NFR) s.v[j] = b[reg_frag(j) * 64];
         else s.y = b[(F + w) * 64];
     };
     auto fetch = [&](Slab<8> &s, int slot) { static_for<NFETCH>([&](auto J_) { fetch1(s, slot, J_); }); };
@@ -1117,11 +1137,17 @@ __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64
     int k = 0;
     auto steady = [&](Slab<8> &use, Slab<8> &nxt) {
         const int rs = rslot, is = islot;
-        sb_consume<DIAGSB, W, XF, false>(use, c, cy, sx, sxy, sy, syy, 0, n, [&](auto M_) {
+        sb_consume<DIAGSB, W, XF, false, NR, NC>(use, c, cy, sx, sxy, sy, syy, 0, n, [&](auto M_) {
             constexpr int m = decltype(M_)::value;
-            if constexpr (m == 0) { wait_vm<(NSLOT - 4) * DPW>(); __syncthreads(); }
-            if constexpr (m >= 1 && m <= NFETCH) fetch1(nxt, rs, std::integral_constant<int, m - 1>{});
-            if constexpr (m > NFETCH && m <= NFETCH + DPW) issue1(is, std::integral_constant<int, m - NFETCH - 1>{});
+            // action a goes after MFMA min(a, NMFMA - 1): a wave with fewer MFMAs than actions does the rest after its last one
+            static_for<NACT>([&](auto A_) {
+                constexpr int act = decltype(A_)::value, at = act < NMFMA ? act : NMFMA - 1;
+                if constexpr (at == m) {
+                    if constexpr (act == 0) { wait_vm<(NSLOT - 4) * DPW>(); __syncthreads(); }
+                    else if constexpr (act <= NFETCH) fetch1(nxt, rs, std::integral_constant<int, act - 1>{});
+                    else issue1(is, std::integral_constant<int, act - NFETCH - 1>{});
+                }
+            });
         });
         rslot = next(rslot); islot = next(islot);
     };
@@ -1138,7 +1164,7 @@ __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64
         __syncthreads();
         if (k + 1 < ns) { fetch(nxt, rslot); rslot = next(rslot); }
         if (issued < ns) { issue(islot); islot = next(islot); ++issued; }
-        sb_consume<DIAGSB, W, XF, false>(use, c, cy, sx, sxy, sy, syy, 0, n);
+        sb_consume<DIAGSB, W, XF, false, NR, NC>(use, c, cy, sx, sxy, sy, syy, 0, n);
         ++k;
     };
     while (k < ns) {
@@ -1152,12 +1178,12 @@ __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64
         const int64_t r0 = r < n ? r : n - 1, r1 = r + 1 < n ? r + 1 : n - 1;
         Slab<8> t;
 #pragma unroll
-        for (int f = 0; f < 8; ++f) {
+        for (int f = 0; f < NFR; ++f) {
             const gptr_t pf = xg + (size_t)frag_col(reg_frag(f)) * ld;
             t.v[f].x = pf[r0]; t.v[f].y = pf[r1];
         }
         t.y.x = yg[r0]; t.y.y = yg[r1];
-        sb_consume<DIAGSB, W, XF, true>(t, c, cy, sx, sxy, sy, syy, r, n);
+        sb_consume<DIAGSB, W, XF, true, NR, NC>(t, c, cy, sx, sxy, sy, syy, r, n);
     }
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     // ---- results: tiles are wave-private -> straight to the partial buffer; vector sums of the diagonal super-blocks
@@ -1172,26 +1198,26 @@ __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64
         if (q == 0) {
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
-                const int T = 8 * SI + 2 * W + k2;
-                if (T < ntc) { vdst[16 * T + i] = sx[k2]; vdst[16 * ntc + 16 * T + i] = sxy[k2]; }
+                const int T = TI + 2 * W + k2;
+                if (2 * W + k2 < HI && T < ntc) { vdst[16 * T + i] = sx[k2]; vdst[16 * ntc + 16 * T + i] = sxy[k2]; }
             }
-            if (W == 0 && i == 0 && SI == 0) {
+            if (W == 0 && i == 0 && TI == 0) {
                 vdst[32 * ntc] = sy; vdst[32 * ntc + 1] = syy; vdst[32 * ntc + 2] = (double)rows; vdst[32 * ntc + 3] = 0.0;
             }
         }
-        static_for<9>([&](auto T_) {
-            constexpr int t = decltype(T_)::value, tt = 9 * W + t, I = tri_row(tt), J = tt - I * (I + 1) / 2;
-            const int gi = 8 * SI + I, gj = 8 * SI + J;
+        static_for<NTW>([&](auto T_) {
+            constexpr int t = decltype(T_)::value, tt = sb_diag_t0(HI, W) + t, I = tri_row(tt), J = tt - I * (I + 1) / 2;
+            const int gi = TI + I, gj = TI + J;
             if (gi < ntc && gj < ntc) {
                 double *dst = tdst + (size_t)(gi * (gi + 1) / 2 + gj) * 256;
                 static_for<4>([&](auto R_) { constexpr int r = decltype(R_)::value; dst[r * 64 + lane] = AccTile<t>::template read<r>(); });
             }
         });
     } else {
-        const int BI = 2 * SI + (w >> 1), BJ = 2 * SJ + (w & 1);
-        static_for<16>([&](auto T_) {
+        const int bi = TI + NR * (w >> 1), bj = TJ + NC * (w & 1);
+        static_for<NR * NC>([&](auto T_) {
             constexpr int t = decltype(T_)::value;
-            const int gi = 4 * BI + t / 4, gj = 4 * BJ + t % 4;
+            const int gi = bi + t / NC, gj = bj + t % NC;
             if (gi < ntc && gj < ntc) {
                 double *dst = tdst + (size_t)(gi * (gi + 1) / 2 + gj) * 256;
                 static_for<4>([&](auto R_) { constexpr int r = decltype(R_)::value; dst[r * 64 + lane] = AccTile<t>::template read<r>(); });
@@ -1202,28 +1228,29 @@ __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64
 
 __global__ __launch_bounds__(256) void gram_sb_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                        const double *__restrict__ sums, double *__restrict__ tpart,
-                                                       double *__restrict__ vpart, GramDims a, int nsblk /* super-block ROWS */)
+                                                       double *__restrict__ vpart, GramDims a, int n8, int n6 /* super-block rows of height 8 / 6 */)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    // Launch order = longest first: ALL off-diagonal super-blocks (32 MFMAs per wave and slab) of all row chunks, then the diagonal
-    // ones (18).  Workgroups are handed to CUs as CUs fall free, so the launch ends one (partial) workgroup after the work runs
-    // out: with the short ones last that tail is short (measured at p = 256: 11 % of the launch in mixed order; gram_plan
-    // also picks the chunk count whose simulated tail is smallest).  Blocks of one row chunk still share blockIdx % 8 (one XCD).
-    const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
-    const int nsb = nsblk, noff = nsb * (nsb - 1) / 2, soff = noff * (a.nchunk / 8);
-    int SI, SJ, chunk;
-    if (s < soff) {
-        const int ob = s % noff;
-        chunk = (s / noff) * 8 + xcd;
-        SI = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)ob)) * 0.5f);
-        while (SI * (SI - 1) / 2 > ob) --SI;
-        while ((SI + 1) * SI / 2 <= ob) ++SI;
-        SJ = ob - SI * (SI - 1) / 2;
-    } else {
-        const int s2 = s - soff;
-        SI = SJ = s2 % nsb;
-        chunk = (s2 / nsb) * 8 + xcd;
-    }
+    // Launch order = longest first: the off-diagonal super-blocks of all row chunks by size (8 x 8 tiles: 32 MFMAs per wave and
+    // slab, 6 x 8: 24, 6 x 6: 18), then the diagonal ones (18, 12).  Workgroups are handed to CUs as CUs fall free, so the launch
+    // ends one (partial) workgroup after the work runs out: with the short ones last that tail is short (measured at p = 256:
+    // 11 % of the launch in mixed order; gram_plan also picks the chunk count whose simulated tail is smallest).  Blocks of one
+    // row chunk still share blockIdx % 8 (one XCD).
+    const int L = blockIdx.x, xcd = L & 7, ng = a.nchunk / 8;
+    int s = L >> 3, SI = 0, SJ = 0, chunk = 0, kind = 0;           // kind 0: 8 x 8, 1: 6 x 8, 2: 6 x 6, 3: diagonal 8, 4: diagonal 6
+    auto tri_decode = [](int ob, int &I, int &J) {                 // ob = I (I - 1) / 2 + J, J < I
+        I = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)ob)) * 0.5f);
+        while (I * (I - 1) / 2 > ob) --I;
+        while ((I + 1) * I / 2 <= ob) ++I;
+        J = ob - I * (I - 1) / 2;
+    };
+    const int c0 = n8 * (n8 - 1) / 2, c1 = n6 * n8, c2 = n6 * (n6 - 1) / 2;
+    if (s < c0 * ng) { chunk = (s / c0) * 8 + xcd; tri_decode(s % c0, SI, SJ); kind = 0; }
+    else if ((s -= c0 * ng) < c1 * ng) { const int ob = s % c1; chunk = (s / c1) * 8 + xcd; SI = n8 + ob / n8; SJ = ob % n8; kind = 1; }
+    else if ((s -= c1 * ng) < c2 * ng) { chunk = (s / c2) * 8 + xcd; tri_decode(s % c2, SI, SJ); SI += n8; SJ += n8; kind = 2; }
+    else if ((s -= c2 * ng) < n8 * ng) { chunk = (s / n8) * 8 + xcd; SI = SJ = s % n8; kind = 3; }
+    else { s -= n8 * ng; chunk = (s / n6) * 8 + xcd; SI = SJ = n8 + s % n6; kind = 4; }
+    const int TI = SI < n8 ? 8 * SI : 8 * n8 + 6 * (SI - n8), TJ = SJ < n8 ? 8 * SJ : 8 * n8 + 6 * (SJ - n8);   // first tile columns
     const int64_t row_begin = (int64_t)chunk * a.steps * 64;
     double *tdst = tpart + (size_t)chunk * a.ntile * 256;
     double *vdst = vpart + (size_t)chunk * (32 * a.ntc + 4);
@@ -1232,17 +1259,24 @@ __global__ __launch_bounds__(256) void gram_sb_kernel(const double *__restrict__
     const unsigned long long dg_c0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // every (kind of super-block, wave, shift) combination is its own straight-line body: a taken scalar branch per slab
-    // costs ~80 cycles (measured on the path kernels), a 4-way dispatch up here costs nothing
-#define OEM_SB(D, W, XF) gram_sb_body<D, W, XF>(x, a.n, a.ld, a.p, y, sums, a.ntc, SI, SJ, row_begin, a.steps, tdst, vdst, lds)
-    if (shift_needed_wave(sums, a.p)) {
-        if (SI != SJ) OEM_SB(false, 0, true);
-        else if (w == 0) OEM_SB(true, 0, true); else if (w == 1) OEM_SB(true, 1, true);
-        else if (w == 2) OEM_SB(true, 2, true); else OEM_SB(true, 3, true);
-    } else {
-        if (SI != SJ) OEM_SB(false, 0, false);
-        else if (w == 0) OEM_SB(true, 0, false); else if (w == 1) OEM_SB(true, 1, false);
-        else if (w == 2) OEM_SB(true, 2, false); else OEM_SB(true, 3, false);
-    }
+    // costs ~80 cycles (measured on the path kernels), a dispatch up here costs nothing
+#define OEM_SB(D, W, XF, HI, HJ) gram_sb_body<D, W, XF, HI, HJ>(x, a.n, a.ld, a.p, y, sums, a.ntc, TI, TJ, row_begin, a.steps, tdst, vdst, lds)
+#define OEM_SB_DIAG(XF, H)                                                                          \
+    do {                                                                                            \
+        if (w == 0) OEM_SB(true, 0, XF, H, H); else if (w == 1) OEM_SB(true, 1, XF, H, H);          \
+        else if (w == 2) OEM_SB(true, 2, XF, H, H); else OEM_SB(true, 3, XF, H, H);                 \
+    } while (0)
+#define OEM_SB_ALL(XF)                                                                              \
+    do {                                                                                            \
+        if (kind == 0) OEM_SB(false, 0, XF, 8, 8);                                                  \
+        else if (kind == 1) OEM_SB(false, 0, XF, 6, 8);                                             \
+        else if (kind == 2) OEM_SB(false, 0, XF, 6, 6);                                             \
+        else if (kind == 3) OEM_SB_DIAG(XF, 8);                                                     \
+        else OEM_SB_DIAG(XF, 6);                                                                    \
+    } while (0)
+    if (shift_needed_wave(sums, a.p)) OEM_SB_ALL(true); else OEM_SB_ALL(false);
+#undef OEM_SB_ALL
+#undef OEM_SB_DIAG
 #undef OEM_SB
 #ifdef OEM_GRAM_DIAG
     // one diagonal and one off-diagonal workgroup of the first row chunk: shader cycles, 100 MHz ticks (-> the clock held), 8-row slabs
@@ -1257,11 +1291,27 @@ __global__ __launch_bounds__(256) void gram_sb_kernel(const double *__restrict__
 #endif
 }
 
+// The deal of ntc tile columns into n8 super-block rows of eight and n6 of six: the one with the least multiply time (in tile
+// units: an off-diagonal super-block of h1 x h2 tiles costs h1 h2, a diagonal one 36 (eight) or 24 (six: 6 + 5 + 5 + 5 tiles over
+// the four waves)); ties go to fewer super-blocks.
+void gram_sb_deal(int ntc, int *n8_out, int *n6_out)
+{
+    int best8 = (ntc + 7) / 8, best6 = 0;
+    long best = -1;
+    for (int n6 = 0; 6 * (n6 - 1) < ntc; ++n6) {
+        const int rest = ntc - 6 * n6, n8 = rest > 0 ? (rest + 7) / 8 : 0;
+        const long cost = 64L * n8 * (n8 - 1) / 2 + 48L * n8 * n6 + 36L * n6 * (n6 - 1) / 2 + 36L * n8 + 24L * n6;
+        if (best < 0 || cost < best || (cost == best && n8 + n6 < best8 + best6)) { best = cost; best8 = n8; best6 = n6; }
+    }
+    *n8_out = best8; *n6_out = best6;
+}
+
 GramPlan gram_plan(int64_t n, int p, int num_cu)
 {
     GramPlan pl;
     pl.p = p;
     pl.tri = (p + 2 + 15) / 16 <= 7;                     // Z = [X | y | 1] fits one wave's triangle
+    pl.n8 = pl.n6 = 0;
     pl.ntc = pl.tri ? (p + 2 + 15) / 16 : (p + 15) / 16;
     pl.ntile = pl.ntc * (pl.ntc + 1) / 2;
     const int64_t nsteps = (n + 63) / 64;
@@ -1276,10 +1326,16 @@ GramPlan gram_plan(int64_t n, int p, int num_cu)
     } else {
         const int nb = (pl.ntc + 3) / 4;
         pl.nblk = nb * (nb + 1) / 2;
-        const int nsb = (pl.ntc + 7) / 8, nsblk = nsb * (nsb + 1) / 2;   // the shared-slab kernel's super-blocks
+        int n8 = 0, n6 = 0;
+        gram_sb_deal(pl.ntc, &n8, &n6);                                  // the shared-slab kernel's super-block rows
+        pl.n8 = n8; pl.n6 = n6;
+        const int nsb = n8 + n6, nsblk = nsb * (nsb + 1) / 2;
         // 8-12 rounds of one workgroup per CU: the count whose launch ends soonest when the workgroups are handed out longest
         // first (gram_sb_kernel) -- a greedy replay with the measured costs (tools/gram_diag.py: 2,136 cycles per 8-row slab off
-        // the diagonal, 1,284 on it, ~25 k per workgroup) plus the partials the reduction has to read (2 KB per tile and chunk).
+        // the diagonal at 32 MFMAs per wave, 1,284 on it at 18: ~66 per MFMA + ~100; ~25 k per workgroup) plus the partials the
+        // reduction has to read (2 KB per tile and chunk).
+        const int64_t cnt[5] = {(int64_t)n8 * (n8 - 1) / 2, (int64_t)n6 * n8, (int64_t)n6 * (n6 - 1) / 2, n8, n6};
+        const double per_slab[5] = {2136.0, 1680.0, 1284.0, 1284.0, 890.0};
         int64_t c = 0;
         double best = 0.0;
         for (int rounds = 8; rounds <= 12; ++rounds) {
@@ -1287,12 +1343,14 @@ GramPlan gram_plan(int64_t n, int p, int num_cu)
             if (cc > nsteps) cc = nsteps;
             if (cc < 1) cc = 1;
             cc = (cc + 7) / 8 * 8;
-            const double slabs = (double)((nsteps + cc - 1) / cc) * 8.0, d_off = slabs * 2136.0 + 25000.0, d_dg = slabs * 1284.0 + 25000.0;
+            const double slabs = (double)((nsteps + cc - 1) / cc) * 8.0;
             std::priority_queue<double, std::vector<double>, std::greater<double>> cu;
             for (int k = 0; k < num_cu; ++k) cu.push(0.0);
             double end = 0.0;
-            for (int64_t k = 0; k < cc * (nsblk - nsb); ++k) { const double t = cu.top() + d_off; cu.pop(); cu.push(t); if (t > end) end = t; }
-            for (int64_t k = 0; k < cc * nsb; ++k) { const double t = cu.top() + d_dg; cu.pop(); cu.push(t); if (t > end) end = t; }
+            for (int kind = 0; kind < 5; ++kind) {
+                const double d = slabs * per_slab[kind] + 25000.0;
+                for (int64_t k = 0; k < cc * cnt[kind]; ++k) { const double t = cu.top() + d; cu.pop(); cu.push(t); if (t > end) end = t; }
+            }
             const double cost = end + (double)cc * pl.ntile * 2048.0 / 3.5e12 * 2.1e9;
             if (c == 0 || cost < best) { c = cc; best = cost; }
             if (cc >= nsteps) break;
@@ -1351,10 +1409,10 @@ static int launch_gram_t(hipStream_t s, const GramPlan &pl, const double *x, con
         }
     } else {
         if (ALIGNED && a.n >= 64 && (double)a.ld * 16.0 * 8.0 < 4294967296.0) {   // 32-bit lane offsets within a tile
-            const int nsb = (pl.ntc + 7) / 8, nsblk = nsb * (nsb + 1) / 2;
+            const int nsb = pl.n8 + pl.n6, nsblk = nsb * (nsb + 1) / 2;
             const size_t shb = (size_t)SB_NSLOT * 16 * 1024;                // NSLOT x 16 KiB slots
             OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
-            hipLaunchKernelGGL(gram_sb_kernel, dim3(pl.nchunk * nsblk), dim3(256), shb, s, x, y, sums, tpart, vpart, a, nsb);
+            hipLaunchKernelGGL(gram_sb_kernel, dim3(pl.nchunk * nsblk), dim3(256), shb, s, x, y, sums, tpart, vpart, a, pl.n8, pl.n6);
             OEM_HIP(hipGetLastError());
             return 0;
         }
