@@ -980,6 +980,18 @@ int oemgpu_selftest_gram_plan(int64_t n, int32_t p, int32_t num_cu, int64_t *out
     out[0] = pl.ntc; out[1] = n8; out[2] = n6; out[3] = pl.nchunk; out[4] = pl.steps;
     out[5] = 64 * (n8 * (n8 - 1) / 2) + 48 * n8 * n6 + 36 * (n6 * (n6 - 1) / 2) + 36 * n8 + 24 * n6;
     out[6] = (int64_t)pl.ntc * (pl.ntc + 1) / 2;
+    // the scratch sized for "any row count up to n" holds the plans of smaller row counts (folds, row tiles)
+    const GramPlan bd = gram_plan_bound(n, p, num_cu);
+    for (int64_t d = 1; d <= 4096 && n / d >= 1; d = d < 16 ? d + 1 : d * 2) {
+        for (int64_t m : {n / d, n / d + 1, n - n / (d + 1)}) {
+            if (m < 1 || m > n) continue;
+            const GramPlan q = gram_plan(m, p, num_cu);
+            if (q.tpart_doubles > bd.tpart_doubles || q.vpart_doubles > bd.vpart_doubles) {
+                set_error("selftest_gram_plan: the plan of %lld rows (%d chunks) does not fit the bound for %lld (%d chunks)", (long long)m, q.nchunk, (long long)n, bd.nchunk);
+                return OEMGPU_ERR_INTERNAL;
+            }
+        }
+    }
     return 0;
 }
 
@@ -1725,14 +1737,14 @@ static XvalLay xval_layout(oemgpu_ctx *c, int64_t n, int p, int K, int npen, int
     L.pm = p + (weighted ? 1 : 0);
     L.mlen = (size_t)oemgpu_moments_len(L.pm); L.cslen = (size_t)p + 1;
     L.nwg = cv_wg_per_fold(n, K, npen, c->num_cu);
-    L.plmax = gram_plan(n, L.pm, c->num_cu);                   // the largest moment plan over the folds is bounded by the plan of all n rows
+    L.plmax = gram_plan_bound(n, L.pm, c->num_cu);             // holds the moment plan of every fold
     Bump A;
     L.a_cs = A.take(sizeof(double) * L.cslen * (2 * (size_t)K + 1));      // per fold, then all folds / all but fold ff
     L.a_cnt = A.take(fold_layout_ints(n, K) * sizeof(int)); L.a_fn = A.take(sizeof(int64_t) * 2 * K); L.a_bad = A.take(256);
     L.a_pos = A.take(sizeof(int) * (size_t)n); L.a_xp = A.take(sizeof(double) * (size_t)L.ldp * L.pm);
     L.a_yp = A.take(sizeof(double) * (size_t)L.ldp); L.a_mf = A.take(sizeof(double) * L.mlen * K);
     L.a_mc = A.take(sizeof(double) * L.mlen); L.a_ms = A.take(sizeof(double) * L.mlen * (K + 1));
-    L.a_t = A.take(L.plmax.tpart_doubles * 8 * 2); L.a_v = A.take(L.plmax.vpart_doubles * 8 * 2);
+    L.a_t = A.take(L.plmax.tpart_doubles * 8); L.a_v = A.take(L.plmax.vpart_doubles * 8);
     L.a_b = A.take(sizeof(double) * (size_t)K * npen * nl * (p + 1));
     L.a_part = A.take(sizeof(double) * cv_part_doubles(L.nwg, K, npen, nl)); L.a_out = A.take(sizeof(double) * 3 * (size_t)npen * nl);
     L.a_peer = A.take(sizeof(double) * (L.mlen + L.cslen) * K);            // another device's fold moments on their way into the sum
@@ -1792,7 +1804,7 @@ static int xval_prepare(oemgpu_ctx *c, const XvalLay &L, const double *x_dev, in
         const int64_t nk = hf[k], st = hf[K + k];
         if (nk == 0) { OEM_HIP(hipMemsetAsync(mfold + L.mlen * k, 0, sizeof(double) * L.mlen, c->stream)); continue; }
         const GramPlan pl = gram_plan(nk, L.pm, c->num_cu);
-        if (pl.tpart_doubles > 2 * L.plmax.tpart_doubles || pl.vpart_doubles > 2 * L.plmax.vpart_doubles) {
+        if (pl.tpart_doubles > L.plmax.tpart_doubles || pl.vpart_doubles > L.plmax.vpart_doubles) {
             set_error("internal: fold plan larger than its scratch"); return OEMGPU_ERR_INTERNAL;
         }
         rc = shard_moments(c, pl, xp + st, nk, L.ldp, yp + st, nullptr, (double *)(ax + L.a_t), (double *)(ax + L.a_v), mfold + L.mlen * k);
@@ -2271,10 +2283,10 @@ int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t
     // matrix pipe does not care about zeros: the cost is that of a dense n x p pass whatever the density, with no dense copy of x
     // beyond one tile.  (A compressed-column Gram kernel would win below ~0.1 % density; it is not built.)
     if (!rc) {
-        const GramPlan plmax = gram_plan(rcrows, p, c->num_cu);
+        const GramPlan plmax = gram_plan_bound(rcrows, p, c->num_cu);
         Bump B;
         const size_t mlen = (size_t)oemgpu_moments_len(p);
-        const size_t a_mom = B.take(mlen * 8), a_tmp = B.take(mlen * 8), a_t = B.take(plmax.tpart_doubles * 8 * 2), a_v = B.take(plmax.vpart_doubles * 8 * 2);
+        const size_t a_mom = B.take(mlen * 8), a_tmp = B.take(mlen * 8), a_t = B.take(plmax.tpart_doubles * 8), a_v = B.take(plmax.vpart_doubles * 8);
         const size_t a_xx = B.take((size_t)q * q * 8), a_xy = B.take((size_t)q * 8), a_st = B.take((size_t)stats_len(p) * 8);
         rc = ctx_reserve(c, B.off + paths_ws_bytes(p, q, o) + 4096) ? OEMGPU_ERR_HIP : 0;
         double *mom = (double *)(c->ws + a_mom), *mtmp = (double *)(c->ws + a_tmp);
@@ -2288,7 +2300,7 @@ int oemgpu_fit_sparse(int64_t n, int32_t p, const int64_t *colptr, const int32_t
                 if (hipGetLastError() != hipSuccess) { set_error("fit_sparse: densify launch failed"); rc = OEMGPU_ERR_HIP; break; }
             }
             const GramPlan pl = gram_plan(nr, p, c->num_cu);
-            if (pl.tpart_doubles > 2 * plmax.tpart_doubles || pl.vpart_doubles > 2 * plmax.vpart_doubles) { set_error("internal: tile plan larger than its scratch"); rc = OEMGPU_ERR_INTERNAL; break; }
+            if (pl.tpart_doubles > plmax.tpart_doubles || pl.vpart_doubles > plmax.vpart_doubles) { set_error("internal: tile plan larger than its scratch"); rc = OEMGPU_ERR_INTERNAL; break; }
             rc = shard_moments(c, pl, xd, nr, ld, yd + r0, nullptr, (double *)(c->ws + a_t), (double *)(c->ws + a_v), mtmp);
             if (!rc) hipLaunchKernelGGL(accumulate_kernel, dim3(64), dim3(256), 0, c->stream, mom, mtmp, mlen);
         }

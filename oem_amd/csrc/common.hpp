@@ -40,6 +40,7 @@ struct GramPlan {
     size_t vpart_doubles;   // nchunk * (2*16*ntc + 4)
 };
 GramPlan gram_plan(int64_t n, int p, int num_cu);
+GramPlan gram_plan_bound(int64_t nmax, int p, int num_cu);   // sizes that hold the plan of any n <= nmax
 void gram_sb_deal(int ntc, int *n8, int *n6);
 
 int launch_shift_sums(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, double *sums);

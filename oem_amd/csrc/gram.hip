@@ -21,7 +21,6 @@
 // correction is O(sample error^2), so there is no cancellation even when |mean| >> sd.
 #include <cstdlib>
 #include "common.hpp"
-#include <queue>
 #include <vector>
 
 #include <type_traits>
@@ -1306,7 +1305,9 @@ void gram_sb_deal(int ntc, int *n8_out, int *n6_out)
     *n8_out = best8; *n6_out = best6;
 }
 
-GramPlan gram_plan(int64_t n, int p, int num_cu)
+constexpr int GRAM_MAX_ROUNDS = 12;
+
+static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
 {
     GramPlan pl;
     pl.p = p;
@@ -1330,34 +1331,83 @@ GramPlan gram_plan(int64_t n, int p, int num_cu)
         gram_sb_deal(pl.ntc, &n8, &n6);                                  // the shared-slab kernel's super-block rows
         pl.n8 = n8; pl.n6 = n6;
         const int nsb = n8 + n6, nsblk = nsb * (nsb + 1) / 2;
-        // 8-12 rounds of one workgroup per CU: the count whose launch ends soonest when the workgroups are handed out longest
+        // 1-12 rounds of one workgroup per CU: the count whose launch ends soonest when the workgroups are handed out longest
         // first (gram_sb_kernel) -- a greedy replay with the measured costs (tools/gram_diag.py: 2,136 cycles per 8-row slab off
-        // the diagonal at 32 MFMAs per wave, 1,284 on it at 18: ~66 per MFMA + ~100; ~25 k per workgroup) plus the partials the
-        // reduction has to read (2 KB per tile and chunk).
+        // the diagonal at 32 MFMAs per wave, 1,284 on it at 18: ~66 per MFMA + ~100; ~25 k per workgroup: ring fill, 72-128 KB of
+        // partials written) plus the partials the reduction has to read (2 KB per tile and chunk).  Until round 5 the search began
+        // at 8 rounds, which is right for the configurations' row counts (millions) and wrong below: at n = 1e5 a workgroup then
+        // has 3 steps of rows and spends more time filling its ring than multiplying (p = 128: 82 us, with ONE round 42;
+        // p = 256: 178 -> 141 with three; profiles/r5_gram_rounds_experiment.txt holds the grid this replay was checked against).
         const int64_t cnt[5] = {(int64_t)n8 * (n8 - 1) / 2, (int64_t)n6 * n8, (int64_t)n6 * (n6 - 1) / 2, n8, n6};
         const double per_slab[5] = {2136.0, 1680.0, 1284.0, 1284.0, 890.0};
         int64_t c = 0;
         double best = 0.0;
-        for (int rounds = 8; rounds <= 12; ++rounds) {
+        for (int rounds = 1; rounds <= GRAM_MAX_ROUNDS; ++rounds) {
             int64_t cc = ((int64_t)num_cu * rounds) / nsblk;
             if (cc > nsteps) cc = nsteps;
             if (cc < 1) cc = 1;
             cc = (cc + 7) / 8 * 8;
             const double slabs = (double)((nsteps + cc - 1) / cc) * 8.0;
-            std::priority_queue<double, std::vector<double>, std::greater<double>> cu;
-            for (int k = 0; k < num_cu; ++k) cu.push(0.0);
+            // CUs that fall free at the same time form a group: (time, CUs), ascending; a kind's workgroups go to the earliest group
+            // first, whole groups at a time -- the same schedule as a heap of 256 finish times in ~rounds x kinds steps
+            std::vector<std::pair<double, int64_t>> grp{{0.0, (int64_t)num_cu}};
             double end = 0.0;
             for (int kind = 0; kind < 5; ++kind) {
                 const double d = slabs * per_slab[kind] + 25000.0;
-                for (int64_t k = 0; k < cc * cnt[kind]; ++k) { const double t = cu.top() + d; cu.pop(); cu.push(t); if (t > end) end = t; }
+                for (int64_t m = cc * cnt[kind]; m > 0;) {
+                    const double t = grp.front().first + d;
+                    const int64_t take = grp.front().second < m ? grp.front().second : m;
+                    if ((grp.front().second -= take) == 0) grp.erase(grp.begin());
+                    size_t at = grp.size();
+                    while (at > 0 && grp[at - 1].first > t) --at;
+                    if (at > 0 && grp[at - 1].first == t) grp[at - 1].second += take; else grp.insert(grp.begin() + at, {t, take});
+                    m -= take;
+                    if (t > end) end = t;
+                }
             }
             const double cost = end + (double)cc * pl.ntile * 2048.0 / 3.5e12 * 2.1e9;
-            if (c == 0 || cost < best) { c = cc; best = cost; }
+            if (c == 0 || cost < best * 0.995) { c = cc; best = cost; }      // a later (larger) count has to win by more than noise
             if (cc >= nsteps) break;
         }
         pl.steps = (int)((nsteps + c - 1) / c);
         if (pl.steps < 1) pl.steps = 1;
         pl.nchunk = (int)c;
+    }
+    pl.tpart_doubles = (size_t)pl.nchunk * pl.ntile * 256;
+    pl.vpart_doubles = (size_t)pl.nchunk * (32 * pl.ntc + 4);
+    return pl;
+}
+
+// The plan of the last (n, p, device) of this thread is kept: the replay above is ~0.1-0.3 ms of host time, and callers come back
+// with the same sizes (a bench loop, the folds of xval.oem, the row blocks of a host-resident call).
+GramPlan gram_plan(int64_t n, int p, int num_cu)
+{
+    struct Memo { int64_t n; int p, cu; GramPlan pl; };
+    static thread_local Memo memo[4] = {{-1, 0, 0, {}}, {-1, 0, 0, {}}, {-1, 0, 0, {}}, {-1, 0, 0, {}}};
+    static thread_local unsigned next = 0;
+    for (const Memo &m : memo) if (m.n == n && m.p == p && m.cu == num_cu) return m.pl;
+    Memo &m = memo[next++ & 3];
+    m.n = n; m.p = p; m.cu = num_cu; m.pl = gram_plan_compute(n, p, num_cu);
+    return m.pl;
+}
+
+// tpart / vpart sizes that hold the plan of ANY row count up to nmax (scratch shared by the folds of xval.oem or the row tiles of
+// a sparse x: the chunk count is not monotone in n)
+GramPlan gram_plan_bound(int64_t nmax, int p, int num_cu)
+{
+    GramPlan pl = gram_plan(nmax, p, num_cu);
+    if (!pl.tri) {
+        const int nsb = pl.n8 + pl.n6, nsblk = nsb * (nsb + 1) / 2;
+        const int64_t nsteps = (nmax + 63) / 64;
+        int64_t cc = ((int64_t)num_cu * GRAM_MAX_ROUNDS) / nsblk;
+        if (cc > nsteps) cc = nsteps;
+        if (cc < 1) cc = 1;
+        cc = (cc + 7) / 8 * 8;
+        if (cc > pl.nchunk) pl.nchunk = (int)cc;
+    } else {
+        const int64_t nsteps = (nmax + 63) / 64;                      // one chunk per CU, fewer when there are fewer steps
+        const int64_t cc = nsteps < num_cu ? (nsteps < 1 ? 1 : nsteps) : num_cu;
+        if (cc > pl.nchunk) pl.nchunk = (int)cc;
     }
     pl.tpart_doubles = (size_t)pl.nchunk * pl.ntile * 256;
     pl.vpart_doubles = (size_t)pl.nchunk * (32 * pl.ntc + 4);

@@ -194,8 +194,8 @@ def test_moment_plan_deals_the_tile_columns_into_eights_and_sixes():
     out = (C.c_int64 * 7)()
     worst = {}
     for p in list(range(1, 1300)) + [2048, 3000, 4096, 5000, 8192, 12000]:
-        for n in (64, 5000, 1_000_000):
-            assert L.oemgpu_selftest_gram_plan(n, p, 256, out) == 0
+        for n in (64, 5000, 100_000, 1_000_000):
+            assert L.oemgpu_selftest_gram_plan(n, p, 256, out) == 0, L.oemgpu_last_error().decode()
             ntc, n8, n6, nchunk, steps, cost, real = list(out)
             assert nchunk >= 1 and steps >= 1 and nchunk * steps * 64 >= n, (n, p)
             if p + 2 <= 112:
@@ -210,6 +210,13 @@ def test_moment_plan_deals_the_tile_columns_into_eights_and_sixes():
     assert min(v for p, v in worst.items() if p >= 177) >= 0.8, min((v, p) for p, v in worst.items() if p >= 177)
     assert min(worst.values()) >= 0.5, min((v, p) for p, v in worst.items())
     assert worst[256] == 1.0 and worst[512] == 1.0 and worst[4096] == 1.0         # the configurations' sizes stay all eights
+    # rounds of workgroups per CU: few where a workgroup would otherwise have a handful of row steps (the ring fill and the partials it
+    # writes cost ~25 k cycles), several at the configurations' row counts
+    for n, p, lo, hi in ((100_000, 128, 1, 1), (100_000, 256, 2, 4), (200_000, 300, 2, 4), (12_500_000, 256, 3, 12), (1_000_000, 512, 3, 12)):
+        assert L.oemgpu_selftest_gram_plan(n, p, 256, out) == 0
+        nsb = out[1] + out[2]
+        rounds = out[3] * (nsb * (nsb + 1) // 2) / 256.0
+        assert lo - 0.1 <= rounds <= hi + 0.1, (n, p, rounds)
 
 
 # ---------------------------------------------------------------------------------------------- the engine plan (api.hip: plan_paths)
