@@ -83,6 +83,15 @@ if [ -z "$quick" ]; then
   python3 tools/coop_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_coop_times.txt
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/hop_probe tools/hop_probe.hip 2> /dev/null && /tmp/hop_probe > $o/${tag}_exchange_probes.txt 2>&1
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/xchg_probe tools/xchg_probe.hip 2> /dev/null && /tmp/xchg_probe >> $o/${tag}_exchange_probes.txt 2>&1
+  # ---- round 5: the probes behind DESIGN.md section 3.3c's floor analysis; the bands between the configurations' sizes
+  for pr in areg_fma_probe valu_probe; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/$pr tools/$pr.hip 2> /dev/null && /tmp/$pr > $o/${tag}_$pr.txt 2>&1
+  done
+  bash tools/gram_band.sh > $o/${tag}_gram_band_now.txt 2>&1
+  bash tools/gram_band_small.sh > $o/${tag}_gram_band_small.txt 2>&1
+  for p in 128 256 300 512 1024; do python3 tools/gram_by_n.py $p 30000 60000 100000 200000 500000 2000000 2>&1 | grep -v amdgpu.ids; done > $o/${tag}_gram_by_n_now.txt
+  python3 tools/large_q_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_large_q_now.txt
+  python3 tools/scale_factor_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_scale_factor_now.txt
 fi
 # the raw traces stay on the box: gpurun copies back at most 64 MiB
 for d in $o/${tag}_trace $o/${tag}_pmc_fetch $o/${tag}_pmc_write $o/${tag}_pmc_mfma $o/${tag}_*_pmc_mfma $o/${tag}_*_trace $o/${tag}_*_pmc_FETCH_SIZE $o/${tag}_*_pmc_WRITE_SIZE; do [ -d "$d" ] && rm -rf "$d"; done
@@ -91,8 +100,3 @@ tail -c 300 $o/${tag}_bench.err
 head -c 1500 $o/${tag}_kernel_stats.csv
 [ -z "$quick" ] && head -c 4000 $o/${tag}_config_times.json
 exit 0
-# ---- round 5: the probes behind DESIGN.md section 3.3c's floor analysis, the A/B-free c4 time, xval at larger p
-if [ -z "$quick" ]; then
-  [ -x tools/areg_fma_probe ] && ./tools/areg_fma_probe > $o/${tag}_c4_areg_fma_probe.txt 2>&1
-  [ -x tools/valu_probe ] && ./tools/valu_probe > $o/${tag}_valu_probe.txt 2>&1
-fi
