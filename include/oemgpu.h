@@ -265,6 +265,10 @@ enum {
     OEMGPU_ENGINE_WLAUNCHES = 9  /* p >= n: launch-per-iteration (path_large.hip: run_path_wide) */
 };
 int oemgpu_last_path_engine(oemgpu_ctx *ctx, int32_t *engine, int32_t *persistent_fallbacks);
+/* OEMGPU_ENGINE_COOP with q <= 512 puts the cooperating workgroups of an instance on ONE XCD where the device's layout allows (the
+ * exchange then stays in that XCD's L2).  Of the most recent path launch on this context: 0 not asked for, 1 ran on one XCD, 2 asked for,
+ * refused by the launch's own proof of placement and made again with the exchange at device scope. */
+int oemgpu_last_placement(oemgpu_ctx *ctx);
 
 /* 1 if the most recent oemgpu_solve_moments_dev on this context found the shift predicate above true for its
  * sums_dev (and so read moments_dev as accumulated about c), 0 if not, -1 for a NULL context. */

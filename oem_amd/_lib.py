@@ -68,6 +68,7 @@ _SIGS = {
     "oemgpu_last_shift_advised": (C.c_int, [C.c_void_p]),
     "oemgpu_last_eigen_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "oemgpu_last_path_engine": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "oemgpu_last_placement": (C.c_int, [C.c_void_p]),
     "oemgpu_fit_sparse": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                     C.POINTER(OemgpuOpts)] + _OUT),
     "oemgpu_xval_dense": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

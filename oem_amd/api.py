@@ -230,6 +230,12 @@ def last_path_engine(ctx=None):
     return ENGINES[e.value], f.value
 
 
+def last_placement(ctx=None):
+    """"none" / "one-xcd" / "refused": whether the cooperating engine of the most recent path launch on this context ran with all
+    workgroups of an instance on one XCD (include/oemgpu.h: oemgpu_last_placement)."""
+    return ("none", "one-xcd", "refused")[L.lib().oemgpu_last_placement(ctx if ctx is not None else context())]
+
+
 def context(device=None, stream=None):
     """A cached oemgpu_ctx per (device, stream).  stream: a torch.cuda.Stream or None (own stream)."""
     import torch

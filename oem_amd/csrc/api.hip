@@ -69,6 +69,7 @@ static const int COOP_MAX_DEV = 64;
 static std::mutex g_coop_mu;
 static std::condition_variable g_coop_cv;
 static int g_coop_in_flight[COOP_MAX_DEV] = {0};
+static std::atomic<unsigned> g_xcd_next{0};
 struct CoopSlots {
     int n = 0, dev = 0;
     void take(int device, int want, int capacity)
@@ -332,10 +333,42 @@ struct PlanIn {
     bool loss_ext = false;           // the loss of ANOTHER Gram (PathExtras::loss_xx)
     int wide_n = 0;                  // > 0: the p >= n iteration through the standardised X itself (WideArgs::n rows), no Gram matrix
 };
+// Which XCD does workgroup i of a launch run on?  The one-XCD form of the cooperating engine (path_coop.hip) assumes "i mod 8" up to a
+// rotation; this asks the hardware once per context (64 workgroups report HW_REG_XCC_ID), and every such launch proves its own
+// placement again before it relies on it.
+__global__ void xcc_probe_kernel(int *out)
+{
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(id & 0xfu);
+}
+
+static bool ctx_xcd_layout_ok(oemgpu_ctx *c)
+{
+    if (c->xcd_layout == 0) {
+        c->xcd_layout = -1;
+        int *dv = nullptr, h[64];
+        if (hipMalloc((void **)&dv, sizeof h) == hipSuccess) {          // (once per context, outside the workspace a call in progress has carved)
+            hipLaunchKernelGGL(xcc_probe_kernel, dim3(64), dim3(64), 0, c->stream, dv);
+            if (hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess &&
+                hipMemcpy(h, dv, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+                bool ok = true;
+                unsigned seen = 0;
+                for (int i = 0; i < 64; ++i) ok = ok && h[i] == h[i & 7];
+                for (int i = 0; i < 8; ++i) seen |= 1u << (h[i] & 15);
+                if (ok && __builtin_popcount(seen) == 8) c->xcd_layout = 1;
+            }
+            (void)hipFree(dv);
+        }
+    }
+    return c->xcd_layout == 1;
+}
+
 struct PathPlan {
     int engine = OEMGPU_ENGINE_NONE;                 // of the first attempt
     bool any_grp = false, loss_on = false, loss_post = false;
     bool small = false, coop = false, symc = false, rowcoop = false, symcoop = false, pen_split = false;
+    bool one_xcd = false;                            // path_coop.hip with all workgroups of an instance on ONE XCD (if the device's layout allows: run_paths)
     bool wcoop = false, wres = false, wstream = false, cut = false;
     int lan = 0, wg_n = 0, wsets = 1, wsg = 0, grcpw = 0;
     size_t work_d = 0, sym_off_d = 0;                // doubles of `work` per instance; where path_symcoop.hip's exchange area starts in it
@@ -480,6 +513,13 @@ static int plan_paths(const PlanIn &in, PathPlan &P)
     P.work_d = work_d;
     // one workgroup (set) per penalty: they are independent cold starts (the cooperating sets must all be resident: <= half the CUs)
     P.pen_split = npen > 1 && (P.small || (P.coop && path_coop_workgroups(q) * npen * nbatch <= num_cu / 2));
+    // q <= 512: the <= 16 cooperating workgroups of an instance fit ONE XCD (an eighth of the CUs), where an exchange through the local L2
+    // costs 0.65 us instead of 1.05 (path_coop.hip: LOCAL); instance y goes to XCD (base + y) mod 8, so the instances that share an XCD
+    // must fit it together
+    {
+        const int ninst = nbatch * (P.pen_split ? npen : 1), per_xcd = (ninst + 7) / 8;
+        P.one_xcd = P.coop && q <= 512 && num_cu >= 64 && num_cu % 8 == 0 && !sw().OEM_NO_ONE_XCD.set && path_coop_workgroups(q) * per_xcd <= num_cu / 8;
+    }
 
     // ---- the scalar part of the kernels' arguments
     PathArgs &a = P.ap;
@@ -650,7 +690,17 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     // The persistent engines spin on their partners: every workgroup of every such kernel in flight must be resident at once, so
     // concurrent callers queue for CU slots (held until the stream has been synchronised below)
     CoopSlots slots;
-    if (coop) slots.take(c->device, path_coop_workgroups(q) * (pen_split ? npen : 1) * nbatch, c->num_cu * 3 / 4);
+    // (one XCD: an instance's <= 16 workgroups compete for the 32 CUs of ITS XCD.  Such a call books every XCD it touches whole; with the
+    // 3/4 capacity at most six instances of concurrent callers are in flight, their first XCDs handed out in turn (g_xcd_next), so no XCD
+    // is ever asked for more than two instances = all of its CUs)
+    // (a reload of the switches -- tests -- also forgets a timed-out engine's back-off and a refused placement)
+    if (c->sw_generation != sw().generation) { c->sw_generation = sw().generation; c->persistent_backoff = 0; c->persistent_skip = 0; if (c->xcd_layout < 0) c->xcd_layout = 0; }
+    bool local = P.one_xcd && ctx_xcd_layout_ok(c);
+    {
+        const int ninst = (pen_split ? npen : 1) * nbatch;
+        if (coop) slots.take(c->device, local ? (c->num_cu / 8) * (ninst < 8 ? ninst : 8) : path_coop_workgroups(q) * ninst, c->num_cu * 3 / 4);
+    }
+    c->last_placement = 0;
     if (symcoop) slots.take(c->device, rowcoop ? path_rowcoop_workgroups(q) : symplan.G, c->num_cu * 3 / 4);
     if (wcoop) slots.take(c->device, wg_n * wsets, c->num_cu * 3 / 4);
     if (wres) slots.take(c->device, path_wres_workgroups(wide->n, q) > c->num_cu * 3 / 4 ? c->num_cu : path_wres_workgroups(wide->n, q), c->num_cu * 3 / 4);
@@ -671,13 +721,14 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     }
     const bool any_persistent = wcoop || wres || wstream || symcoop || (coop && nbatch == 1);
     auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    if (c->sw_generation != sw().generation) { c->sw_generation = sw().generation; c->persistent_backoff = 0; c->persistent_skip = 0; }
     // (ctx.hpp: a caller on a shared GPU does not pay the second of a timeout on every call -- VERDICT r4)
     const bool skip_persistent = any_persistent && c->persistent_skip > 0 && now_s() < c->persistent_skip_until;
     if (skip_persistent) --c->persistent_skip;
     for (int attempt = skip_persistent ? 1 : 0;; ++attempt) {
         const bool persistent = any_persistent && attempt == 0;
         a.abort_word = (abortable && (persistent || (coop && attempt == 0))) ? c->abort_dev : nullptr;
+        a.one_xcd = (coop && attempt == 0 && local) ? (sw().OEM_FAKE_XCD_MISMATCH.set ? 2 : 1) : 0;
+        a.xcd_base = a.one_xcd ? (int)(g_xcd_next.fetch_add(1u, std::memory_order_relaxed) & 7u) : 0;     // concurrent callers start at different XCDs
         {
             Timer t(c, OEMGPU_T_EIGPATH);
             PollScope poll(o);
@@ -729,6 +780,17 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
         }
         OEM_HIP(hipStreamSynchronize(c->stream));
         HT(4);
+        if (a.one_xcd) {
+            // the launch's own proof of placement (path_coop.hip): poison value 2 in any instance = its workgroups were NOT on one XCD and
+            // nothing was computed; this context does not ask again, and the call is made again with the exchange at device scope
+            bool refused = false;
+            for (int bi = 0; bi < nbatch; ++bi) {
+                const double *hdb = (const double *)((const char *)c->pinned + (joined ? st_gap : 0) + (size_t)bi * out_stride) + nb + 2 * nk;
+                refused = refused || hdb[6] == 2.0;
+            }
+            c->last_placement = refused ? 2 : 1;
+            if (refused) { c->xcd_layout = -1; local = false; --attempt; continue; }
+        }
         if (persistent) {
             const double *hd0 = (const double *)((const char *)c->pinned + (joined ? st_gap : 0)) + nb + 2 * nk;
             if (hd0[6] != 0.0) {
@@ -1543,6 +1605,8 @@ int oemgpu_last_path_engine(oemgpu_ctx *c, int32_t *engine, int32_t *persistent_
     if (persistent_fallbacks) *persistent_fallbacks = c->persistent_fallbacks;
     return 0;
 }
+
+int oemgpu_last_placement(oemgpu_ctx *c) { return c ? c->last_placement : -1; }
 
 int oemgpu_last_eigen_info(oemgpu_ctx *c, int32_t *steps, int32_t *capped)
 {

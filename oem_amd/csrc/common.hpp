@@ -142,6 +142,9 @@ struct PathArgs {
     // every third lambda).  Every workgroup reads it once per 128 iterations and inside any exchange spin that lasts; whoever sees it
     // stops waiting for anybody, the "leave" bit rides in the workgroup's next vote and the loops are left.  Null: never asked.
     const int *abort_word;
+    // path_coop.hip, q <= 512: the cooperating workgroups of an instance all on ONE XCD (8 x as many workgroups are launched and only
+    // those with blockIdx.x % 8 == (xcd_base + blockIdx.y) % 8 take part; the kernel proves the placement before it relies on it)
+    int one_xcd, xcd_base;
 };
 
 // the read of PathArgs::abort_word (system scope: the word lives in host memory)

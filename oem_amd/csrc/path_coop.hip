@@ -29,6 +29,9 @@
 #ifndef OEM_XCHG_SLEEP
 #define OEM_XCHG_SLEEP 12         // s_sleep units (64 cycles) before the first poll sweep of the gather (tools/coop_sleep_ab.sh: config 3 path 2.23 -> 2.17 ms, p = 1024 3.99 -> 3.75)
 #endif
+#ifndef OEM_XCHG_SLEEP_LOCAL
+#define OEM_XCHG_SLEEP_LOCAL 2    // the same inside one XCD, where a pair is there after ~0.25 us (tools/coop_sleep_local_ab.sh: 0 / 2 / 5 within noise, 8 +4 %, 12 +10 %)
+#endif
 namespace oemgpu {
 
 namespace {
@@ -127,7 +130,10 @@ __device__ __forceinline__ double coop_product(const double (&a)[CG], const doub
 
 // One product + all-gather.  In: the vector in Bsh (complete, behind a barrier).  Out: Ush[j] for every j < q, behind a
 // barrier: OEM ? (d vec_j - (M vec)_j) + xy_j : (M vec)_j.
-template <int CH, bool OEM>
+// LOCAL: all workgroups of the instance sit on ONE XCD (proved at the start of the kernel), whose L2 is the point of coherence for its
+// CUs: plain stores and sc1 loads then make the exchange -- the pair never leaves the XCD (tools/xchg_probe.hip modes 3 / 9: 16
+// workgroups, 512 rows, 1.04 -> 0.65 us per all-gather; between XCDs a plain store is never seen)
+template <int CH, bool OEM, bool LOCAL>
 __device__ __forceinline__ void coop_round(const double (&a)[CG], const int (&bidx)[CG / 16], double *Ush, const double *Bsh, double *Pc,
                                            int q, int row, bool rowok, bool publisher, double d, double xyR, CoopX &X, int w, int lane, int tid)
 {
@@ -152,7 +158,7 @@ __device__ __forceinline__ void coop_round(const double (&a)[CG], const int (&bi
         if (rowok) {
             coop_v4u pr;
             pr.x = (unsigned)__double2loint(out); pr.y = X.epoch; pr.z = (unsigned)__double2hiint(out); pr.w = X.epoch;
-            __builtin_amdgcn_raw_buffer_store_b128(pr, X.rs, base + row * 16, 0, 16);       // aux 16: sc1 (device scope)
+            __builtin_amdgcn_raw_buffer_store_b128(pr, X.rs, base + row * 16, 0, LOCAL ? 0 : 16);       // aux 16: sc1 (device scope)
             Ush[row] = out;
         }
     }
@@ -170,7 +176,7 @@ __device__ __forceinline__ void coop_round(const double (&a)[CG], const int (&bi
         pv[k] = coop_v4u{0u, 0u, 0u, 0u};
     }
     const unsigned need = miss;
-    if (OEM_XCHG_SLEEP > 0) __builtin_amdgcn_s_sleep(OEM_XCHG_SLEEP);      // (nothing of this epoch can have landed yet: path_wcoop.hip, wc_gather)
+    if (OEM_XCHG_SLEEP > 0) __builtin_amdgcn_s_sleep(LOCAL ? OEM_XCHG_SLEEP_LOCAL : OEM_XCHG_SLEEP);      // (nothing of this epoch can have landed yet: path_wcoop.hip, wc_gather)
     // ONE counter in the sweep loop: it runs out once per 1,024 sweeps (~1 ms), and only then are the abort word and the timeout looked at
     // (~1 s = 1,000 such rounds: a partner is gone; after one timeout -- or the abort word -- nobody waits again: one sweep each)
     unsigned left = X.failed ? 1u : PATH_ABORT_SPINS, rounds = 0u;
@@ -228,15 +234,18 @@ template <int KIND> __device__ __forceinline__ double thr1(double u, double tp, 
     return cdiv(u, c.d, c.rd);
 }
 
-template <int CH>
+template <int CH, bool LOCAL>
 __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_)
 {
+    // LOCAL: eight times the workgroups were launched; workgroup ids go round the XCDs, so those with the same id mod 8 share one --
+    // instance y takes the ones of XCD (xcd_base + y) mod 8, the others leave at once
+    if (LOCAL && (int)(blockIdx.x & 7u) != ((A_.xcd_base + (int)blockIdx.y) & 7)) return;
     const PathArgs A = path_instance(A_);
     typedef CoopCfg<CH> C;
     constexpr int EPT = C::EPT;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l16 = lane & 15, grp = lane >> 4;
-    const int q = A.p, wg = blockIdx.x;
+    const int q = A.p, wg = LOCAL ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const unsigned long long t_cyc0 = __builtin_amdgcn_s_memtime(), t_rt0 = __builtin_amdgcn_s_memrealtime();
     double *Ush = lds + C::OFF_U, *Bsh = lds + C::OFF_B, *F = lds + C::OFF_F, *GW = lds + C::OFF_GW;
     double *Tal = lds + C::OFF_T, *Tbe = Tal + CML, *red = lds + C::OFF_R, *Pc = lds + C::OFF_P;
@@ -321,7 +330,43 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_)
         }
     }
     CoopX X;
-    X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)A.work, 0, 2 * C::QMAX * 16, 0x00020000); X.epoch = 0; X.wg = wg; X.qmax = C::QMAX; X.failed = 0; X.abortw = A.abort_word;
+    X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)A.work, 0, 2 * C::QMAX * 16 + (LOCAL ? 1024 : 0), 0x00020000); X.epoch = 0; X.wg = wg; X.qmax = C::QMAX; X.failed = 0; X.abortw = A.abort_word;
+    if (LOCAL) {
+        // The proof of placement, before anything relies on it: every workgroup publishes the XCD it runs on (device scope: this
+        // exchange has to work ACROSS XCDs) behind the pairs, reads everybody's and compares.  All workgroups reach the same verdict
+        // (somebody differs or nobody does), so on a mismatch they all leave without waiting for each other; the host then makes
+        // the call again with the exchange at device scope.
+        constexpr unsigned MAGIC = 0x58434431u;                  // "XCD1"
+        const int W = (q + C::RW - 1) / C::RW, xoff = 2 * C::QMAX * 16;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc = (xcc & 0xfu) + 1u;
+        if (A.one_xcd == 2 && wg == 1) xcc += 1u;                 // tests (OEM_FAKE_XCD_MISMATCH): a placement that is not what the launch assumed
+        if (tid == 0) {
+            coop_v4u pr; pr.x = xcc; pr.y = MAGIC; pr.z = xcc; pr.w = MAGIC;
+            __builtin_amdgcn_raw_buffer_store_b128(pr, X.rs, xoff + wg * 16, 0, 16);
+        }
+        coop_v4u got = coop_v4u{xcc, MAGIC, xcc, MAGIC};
+        bool there = tid >= W;
+        unsigned spin_left = PATH_ABORT_SPINS, spin_rounds = 0u;
+        bool timed_out = false;
+        while (__any(!there)) {
+            if (!there) {
+                got = __builtin_amdgcn_raw_buffer_load_b128(X.rs, xoff + tid * 16, 0, 16);
+                there = got.y == MAGIC && got.w == MAGIC && got.x == got.z;
+            }
+            if (--spin_left == 0u && __any(!there)) {
+                if (++spin_rounds >= PATH_TIMEOUT_ROUNDS || path_abort_asked(X.abortw)) { timed_out = true; break; }
+                spin_left = PATH_ABORT_SPINS;
+            }
+        }
+        const bool lost = __syncthreads_or(timed_out ? 1 : 0) != 0;                                   // a partner never came: the usual poison
+        const bool apart = __syncthreads_or((there && tid < W && got.x != xcc) ? 1 : 0) != 0;        // not one XCD
+        if (lost || apart) {
+            if (tid == 0) A.d_out[6] = lost ? 1.0 : 2.0;
+            return;
+        }
+    }
 #ifdef OEM_PATH_DIAG
     for (int k = 0; k < 16; ++k) X.acc[k] = 0;
     X.last = __builtin_amdgcn_s_memtime();
@@ -365,7 +410,7 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_)
 #pragma unroll
         for (int k = 0; k < EPT; ++k) if (valid[k]) Bsh[tid + NTH * k] = v[k];
         __syncthreads();
-        coop_round<CH, false>(a, bidx, Ush, Bsh, Pc, q, row, rowok, publisher, 0.0, 0.0, X, w, lane, tid);
+        coop_round<CH, false, LOCAL>(a, bidx, Ush, Bsh, Pc, q, row, rowok, publisher, 0.0, 0.0, X, w, lane, tid);
         double al = 0.0;
 #pragma unroll
         for (int k = 0; k < EPT; ++k) { wv[k] = valid[k] ? Ush[tid + NTH * k] : 0.0; al = fma(v[k], wv[k], al); }
@@ -622,7 +667,7 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_)
                     }
                 }
                 // ---- u = d beta - XX beta + XY: the next iteration's input, or the warm start of the next lambda
-                coop_round<CH, true>(a, bidx, Ush, Bsh, Pc, q, row, rowok, publisher, d, xyR, X, w, lane, tid);
+                coop_round<CH, true, LOCAL>(a, bidx, Ush, Bsh, Pc, q, row, rowok, publisher, d, xyR, X, w, lane, tid);
                 if (__builtin_expect(fin, 0)) {
                     if (want_loss) {
                         // sum (Y - X beta)^2 through the Gram identity (ref src/oem_dense.h:759-770): XX beta = d beta - u + XY
@@ -731,14 +776,20 @@ int launch_path_coop(hipStream_t s, const PathArgs &a_)
         typedef CoopCfg<2> C;
         const int W = (q + C::RW - 1) / C::RW;
         const size_t sh = (size_t)C::N_DBL * sizeof(double);
-        if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_coop_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL((path_coop_kernel<2>), dim3(W, ninst), dim3(NTH), sh, s, a);
+        if (a.one_xcd) {
+            if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_coop_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            hipLaunchKernelGGL((path_coop_kernel<2, true>), dim3(8 * W, ninst), dim3(NTH), sh, s, a);
+        } else {
+            if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_coop_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            hipLaunchKernelGGL((path_coop_kernel<2, false>), dim3(W, ninst), dim3(NTH), sh, s, a);
+        }
     } else {
         typedef CoopCfg<4> C;
         const int W = (q + C::RW - 1) / C::RW;
         const size_t sh = (size_t)C::N_DBL * sizeof(double);
-        if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_coop_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL((path_coop_kernel<4>), dim3(W, ninst), dim3(NTH), sh, s, a);
+        if (a.one_xcd) { set_error("internal: the one-XCD form of the cooperating engine stops at q = 512"); return OEMGPU_ERR_INTERNAL; }
+        if (sh > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_coop_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL((path_coop_kernel<4, false>), dim3(W, ninst), dim3(NTH), sh, s, a);
     }
     OEM_HIP(hipGetLastError());
     if (sw().OEM_WCOOP_FAKE_TIMEOUT.set && ninst == 1) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback

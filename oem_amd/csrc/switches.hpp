@@ -24,7 +24,7 @@ namespace oemgpu {
     /* moment kernels, sparse x */                                                                                                   \
     X(OEM_SPARSE_GRAM) X(OEM_SPARSE_TILE_ROWS)             \
     /* faults and checks */                                                                                                          \
-    X(OEM_WCOOP_FAKE_TIMEOUT) X(OEM_POISON_OUT) X(OEMGPU_LANCZOS_CAP)                                                                \
+    X(OEM_WCOOP_FAKE_TIMEOUT) X(OEM_POISON_OUT) X(OEMGPU_LANCZOS_CAP) X(OEM_NO_ONE_XCD) X(OEM_FAKE_XCD_MISMATCH)                                                                \
     /* the host-resident path */                                                                                                     \
     X(OEMGPU_NO_PEER) X(OEMGPU_NO_PENALTY_SPLIT) X(OEMGPU_CACHE_KEEP_BYTES) X(OEMGPU_UPLOAD_THREADS) X(OEMGPU_SLOT_BYTES)            \
     X(OEMGPU_BLOCK_BYTES) X(OEMGPU_RESIDENT_BYTES)

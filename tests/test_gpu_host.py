@@ -486,3 +486,89 @@ def test_a_timed_out_persistent_engine_is_not_tried_again_at_once(oa, monkeypatc
     back = oa.oem_xtx(xd, xty, **kw)
     assert oa.last_path_engine() == ("rowcoop", f0 + 2)
     assert np.array_equal(np.asarray(back["beta"][0]), np.asarray(good["beta"][0])) and np.array_equal(np.asarray(again["beta"][0]), np.asarray(first["beta"][0]))
+
+
+def _same_fit(a, b):
+    return all(np.array_equal(np.asarray(a["beta"][k]), np.asarray(b["beta"][k])) and np.array_equal(a["niter"][k], b["niter"][k])
+               for k in range(len(a["beta"])))
+
+
+@pytest.mark.parametrize("case", ["lasso-256", "grp.lasso-512", "three-penalties-300", "scad-accelerate-loss-430"])
+def test_cooperating_engine_on_one_xcd(oa, case, monkeypatch):
+    """209 <= q <= 512: the <= 16 cooperating workgroups of an instance are placed on ONE XCD (eight times the workgroups are launched, the
+    ones of the other seven XCDs leave at once), where the exchange is plain stores and sc1 loads through that XCD's L2 -- 0.65 us per
+    all-gather instead of 1.05.  The arithmetic is the same: bit-identical to the device-scope exchange (OEM_NO_ONE_XCD), which is in turn
+    held to the launch-per-iteration engines and the oracle elsewhere; the launch proves its placement before it relies on it, and a
+    refused proof (faked: one workgroup reports another XCD) makes the call again at device scope -- same bits -- and this context does
+    not ask again until the switches are re-read."""
+    import torch
+    rng = np.random.default_rng(77)
+    if case == "lasso-256":
+        q, kw = 256, dict(penalty="lasso", nlambda=30, tol=1e-9)
+    elif case == "grp.lasso-512":
+        q, kw = 512, dict(penalty="grp.lasso", groups=np.repeat(np.arange(1, 65), 8), nlambda=25, tol=1e-9)
+    elif case == "three-penalties-300":
+        q, kw = 300, dict(penalty=["lasso", "mcp", "grp.lasso"], groups=np.arange(300) // 6 + 1, nlambda=20, tol=1e-9)
+    else:
+        q, kw = 430, dict(penalty=["scad", "elastic.net"], alpha=0.6, nlambda=15, tol=1e-9, accelerate=True, compute_loss=True)
+    n = 3000
+    x = rng.normal(size=(n, q)) * rng.uniform(0.5, 2.0, q)
+    b = np.zeros(q); b[:20] = rng.uniform(-1, 1, 20)
+    y = x @ b + rng.normal(size=n)
+    xd = torch.as_tensor(np.asfortranarray(x), device="cuda"); yd = torch.as_tensor(y, device="cuda")
+    fit = oa.oem(xd, yd, **kw)
+    assert oa.last_path_engine()[0] == "coop" and oa.api.last_placement() == "one-xcd"
+    monkeypatch.setenv("OEM_NO_ONE_XCD", "1")
+    ref = oa.oem(xd, yd, **kw)
+    assert oa.last_path_engine()[0] == "coop" and oa.api.last_placement() == "none"
+    assert _same_fit(fit, ref)
+    monkeypatch.delenv("OEM_NO_ONE_XCD")
+    f0 = oa.last_path_engine()[1]
+    monkeypatch.setenv("OEM_FAKE_XCD_MISMATCH", "1")
+    refused = oa.oem(xd, yd, **kw)
+    assert oa.api.last_placement() == "refused" and oa.last_path_engine() == ("coop", f0)      # made again on the SAME engine: not a fallback
+    assert _same_fit(refused, ref)
+    after = oa.oem(xd, yd, **kw)                                     # the context remembers: not asked for again
+    assert oa.api.last_placement() == "none" and _same_fit(after, ref)
+    monkeypatch.delenv("OEM_FAKE_XCD_MISMATCH")                      # switches re-read: asked for again
+    back = oa.oem(xd, yd, **kw)
+    assert oa.api.last_placement() == "one-xcd" and _same_fit(back, ref)
+
+
+def test_cooperating_engine_on_one_xcd_many_instances(oa, monkeypatch):
+    """xval.oem's K + 1 fits as instances of ONE cooperating launch: instance y on XCD (first + y) mod 8, two instances on an XCD where
+    there are more than eight -- identical to the device-scope exchange; and concurrent callers (threads) start at different XCDs."""
+    import threading
+    import torch
+    rng = np.random.default_rng(78)
+    n, q = 4000, 300
+    x = rng.normal(size=(n, q)); b = np.zeros(q); b[:10] = rng.uniform(-1, 1, 10)
+    y = x @ b + rng.normal(size=n)
+    foldid = np.arange(n) % 10 + 1
+    kw = dict(penalty="lasso", nlambda=12, tol=1e-8, foldid=foldid)
+    xd = torch.as_tensor(np.asfortranarray(x), device="cuda"); yd = torch.as_tensor(y, device="cuda")
+    fit = oa.xval_oem(xd, yd, **kw)
+    placed = oa.api.last_placement()
+    assert placed == "one-xcd"                                       # 11 instances x 10 workgroups: two instances on three of the XCDs
+    monkeypatch.setenv("OEM_NO_ONE_XCD", "1")
+    ref = oa.xval_oem(xd, yd, **kw)
+    assert oa.api.last_placement() == "none"
+    monkeypatch.delenv("OEM_NO_ONE_XCD")
+    assert np.array_equal(np.asarray(fit["beta"][0]), np.asarray(ref["beta"][0])) and np.array_equal(np.asarray(fit["cvm"][0]), np.asarray(ref["cvm"][0]))
+    # several host threads, each with its own context: their launches overlap on the device
+    xs = [rng.normal(size=(2000, 260 + 20 * t)) for t in range(4)]
+    ys = [xx[:, :5] @ np.ones(5) + rng.normal(size=2000) for xx in xs]
+    single = [oa.oem(xx, yy, penalty="lasso", nlambda=10, tol=1e-8) for xx, yy in zip(xs, ys)]
+    out, errs = [None] * 4, []
+
+    def work(t):
+        try:
+            for _ in range(5):
+                out[t] = oa.oem(xs[t], ys[t], penalty="lasso", nlambda=10, tol=1e-8)
+        except Exception as e:                                        # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    for t in range(4):
+        assert np.array_equal(np.asarray(out[t]["beta"][0]), np.asarray(single[t]["beta"][0]))

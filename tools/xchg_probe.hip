@@ -11,6 +11,9 @@
 //           loop; NOT adopted in the engines -- there a workgroup that arrives late would sleep on everybody's critical path)
 //        7 / 8  as 3 / 6 with FOUR replicas of the published rows (a reader takes replica wg % 4): fewer pollers per cache line --
 //           round 4, for path_wres_kernel's 209 workgroups
+//        9 / 10  as 3 / 2 with PLAIN stores (wave scope: the line stays in the writer XCD's L2) and sc1 loads -- only meaningful between
+//           workgroups of ONE XCD (stride 8); round 5: what an engine confined to one XCD would pay per exchange
+//        11  as 9 with nt stores and nt loads
 //        4  16-byte rows + a compact flag word per workgroup (stored after its rows): poll the G flags, then read the rows once
 //           (every row still validated by its own tags, re-read if a flag overtook it)
 #include <hip/hip_runtime.h>
@@ -28,6 +31,7 @@ __global__ __launch_bounds__(NTH) void allgather(unsigned long long *buf, unsign
     const int tid = threadIdx.x, wg = blockIdx.x / stride, G = gridDim.x / stride, RW = (N + G - 1) / G;
     __shared__ double sh[512];
     constexpr int REP = (MODE == 7 || MODE == 8) ? 4 : 1;
+    constexpr int STAUX = (MODE == 9 || MODE == 10) ? 0 : (MODE == 11 ? 2 : 16), LDAUX = MODE == 11 ? 2 : 16;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)buf, 0, 2 * N * 16 * REP, 0x00020000);
     const int myrep = wg % REP;
     bool need[EPT], own[EPT];
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(NTH) void allgather(unsigned long long *buf, unsign
             } else {
                 v4u v; v.x = lo; v.y = ep; v.z = hi; v.w = ep;
 #pragma unroll
-                for (int r = 0; r < REP; ++r) __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((par * REP + r) * N + row) * 16, 0, 16);
+                for (int r = 0; r < REP; ++r) __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((par * REP + r) * N + row) * 16, 0, STAUX);
             }
         }
         if (MODE == 4) {
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(NTH) void allgather(unsigned long long *buf, unsign
             }
         }
         // gather
-        constexpr int NS = (MODE == 0 || MODE == 2) ? 3 : 1;
+        constexpr int NS = (MODE == 0 || MODE == 2 || MODE == 10) ? 3 : 1;
         if (MODE == 5) __builtin_amdgcn_s_sleep(6);
         if (MODE == 6 || MODE == 8) __builtin_amdgcn_s_sleep(12);
         v4u pv[NS][EPT];
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(NTH) void allgather(unsigned long long *buf, unsign
                         const unsigned long long a = __hip_atomic_load(base + (size_t)row * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const unsigned long long b = __hip_atomic_load(base + (size_t)row * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         pv[s][k] = v4u{(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
-                    } else pv[s][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((par * REP + myrep) * N + row) * 16, 0, 16);
+                    } else pv[s][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((par * REP + myrep) * N + row) * 16, 0, LDAUX);
                 }
             }
         };
@@ -111,6 +115,7 @@ __global__ __launch_bounds__(NTH) void allgather(unsigned long long *buf, unsign
             sh[row] = v;
         }
         __syncthreads();
+        if (bad) break;                                                // (a mode that cannot work here: do not spin through every round)
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
     if (wg == 0 && tid == 0) out[0] = t1 - t0;
@@ -131,12 +136,12 @@ int main()
 {
     unsigned long long *buf, *flags, *out;
     CK(hipMalloc(&buf, 2 * 512 * 16 * 4)); CK(hipMalloc(&flags, 2 * 256 * 8)); CK(hipMalloc(&out, 16));
-    const int gs[] = {2, 8, 16, 32, 64};
+    const int gs[] = {2, 4, 8, 16, 32, 64};
     for (int N : {512, 128})
         for (int G : gs) {
             run<0>(buf, flags, out, G, N, 1); run<1>(buf, flags, out, G, N, 1); run<2>(buf, flags, out, G, N, 1);
             run<3>(buf, flags, out, G, N, 1); run<5>(buf, flags, out, G, N, 1); run<6>(buf, flags, out, G, N, 1); run<4>(buf, flags, out, G, N, 1);
-            if (G <= 32) { run<0>(buf, flags, out, G, N, 8); run<2>(buf, flags, out, G, N, 8); }
+            if (G <= 32) { run<0>(buf, flags, out, G, N, 8); run<2>(buf, flags, out, G, N, 8); run<3>(buf, flags, out, G, N, 8); run<9>(buf, flags, out, G, N, 8); run<10>(buf, flags, out, G, N, 8); run<11>(buf, flags, out, G, N, 8); }
         }
     // round 4: the workgroup counts of path_wres_kernel (p >= n with columns in the accumulator file)
     for (int N : {500, 128})
