@@ -314,7 +314,8 @@ void oemgpu_release_cache(void);
 int oemgpu_selftest_wcoop_sizing(int32_t n, int32_t p, int32_t npen, int32_t num_cu);
 
 /* Host-only self-check of the engine PLAN (pure arithmetic, runs without a GPU): what api.hip: plan_paths decides for a call with
- * these sizes and options on a device of num_cu CUs -- *engine = the OEMGPU_ENGINE_* of the first attempt -- and whether the
+ * these sizes and options on a device of num_cu CUs -- *engine = the OEMGPU_ENGINE_* of the first attempt (+ 256 where the cooperating
+ * engine is planned with every instance on ONE XCD: run time still asks the device for its layout) -- and whether the
  * buffers the callers size hold what the launch will carve: *frame_bytes (outputs + parameter blob + engine workspace) against
  * *reserved_bytes, and for p >= n (wide_n > 0 rows, no Gram matrix) the persistent engine's exchange buffers against the scratch
  * (*scratch_need_doubles <= *scratch_have_doubles).  p: columns of x; q: dimension of beta (p + 1 with big.oem's intercept);

@@ -242,7 +242,8 @@ def _plan(p, pens, sem=_SEM_DENSE, intercept=0, groups=None, has_scale=False, nb
     rc = L.lib().oemgpu_selftest_plan(p, q, sem, intercept, C.byref(a.c), int(has_scale), nbatch, wide_n, num_cu, C.byref(eng), C.byref(frame),
                                       C.byref(res), C.byref(need), C.byref(have))
     assert rc == 0, (p, pens, sem, L.lib().oemgpu_last_error().decode())
-    return _ENGINES[eng.value], frame.value, res.value, need.value, have.value
+    _plan.one_xcd = bool(eng.value & 256)                         # (the cooperating engine planned with every instance on one XCD)
+    return _ENGINES[eng.value & 255], frame.value, res.value, need.value, have.value
 
 
 _RUNS4 = lambda n: np.arange(n) // 4 + 1                    # groups of four neighbouring columns
@@ -250,6 +251,35 @@ _SCATTER = lambda n: np.arange(n) % 7 + 1                   # seven groups dealt
 _PEN_SETS = [(["lasso"], None), (["lasso", "mcp", "scad"], None), (["grp.lasso"], _RUNS4), (["grp.lasso", "lasso"], _RUNS4),
              (["grp.mcp", "sparse.grp.lasso"], _SCATTER),
              (["elastic.net", "lasso", "ols", "mcp", "scad", "mcp.net", "scad.net", "grp.lasso"], _RUNS4)]
+
+
+def test_the_plan_puts_the_cooperating_engine_on_one_xcd_only_where_its_instances_fit():
+    """path_coop.hip's one-XCD form (q <= 512): instance y goes to XCD (first + y) mod 8, so ceil(instances / 8) workgroup sets share an
+    XCD and must fit its num_cu / 8 CUs together; never beyond q = 512, never on another engine."""
+    for num_cu in (64, 104, 128, 256, 304):
+        for q in (150, 208, 209, 256, 300, 400, 512, 513, 700, 1024, 1025):
+            for pens in (["lasso"], ["lasso", "mcp", "scad"], ["elastic.net", "lasso", "ols", "mcp", "scad", "mcp.net", "scad.net", "grp.lasso"]):
+                for sem, nbatch in ((_SEM_DENSE, 1), (_SEM_XTX, 1), (_SEM_XVAL, 6), (_SEM_XVAL, 11)):
+                    groups = _RUNS4 if "grp.lasso" in pens else None
+                    try:
+                        eng = _plan(q, pens, sem=sem, nbatch=nbatch, groups=groups, num_cu=num_cu)[0]
+                    except AssertionError:
+                        assert nbatch > 1                        # (batched fits the single launch does not take: xval.oem runs its folds on threads)
+                        continue
+                    if not _plan.one_xcd:
+                        continue
+                    assert eng == "coop" and 209 <= q <= 512 and num_cu % 8 == 0, (num_cu, q, pens, sem, nbatch, eng)
+                    W = (q + 31) // 32
+                    # (penalties side by side only when all their sets fit half the device; otherwise one set runs them in turn)
+                    for ninst in {nbatch, nbatch * len(pens)}:
+                        if W * ((ninst + 7) // 8) <= num_cu // 8:
+                            break
+                    else:
+                        raise AssertionError((num_cu, q, pens, sem, nbatch))
+    assert _plan(300, ["lasso"], num_cu=256)[0] == "coop" and _plan.one_xcd
+    assert _plan(512, ["lasso"], sem=_SEM_XVAL, nbatch=11, num_cu=256)[0] == "coop" and _plan.one_xcd      # 11 x 16 workgroups: two sets on three XCDs
+    assert _plan(400, ["lasso"], sem=_SEM_XVAL, nbatch=6, num_cu=128)[0] == "coop" and _plan.one_xcd        # 13 workgroups of the 16 CUs of an XCD
+    assert _plan(300, ["lasso", "mcp", "scad"], num_cu=64)[0] == "coop" and not _plan.one_xcd              # 10 workgroups do not fit 8 CUs
 
 
 def test_the_plan_names_one_engine_and_a_workspace_that_fits_at_every_size():
