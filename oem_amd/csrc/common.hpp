@@ -33,7 +33,7 @@ struct GramPlan {
     int ntile;      // ntc*(ntc+1)/2
     int tri;        // 1: one wave holds the whole lower triangle (ntc <= 7); 0: 4x4 tile blocks
     int nblk;       // tile blocks per row chunk (1 when tri)
-    int n8, n6;     // shared-slab kernel: super-block rows of 8 and of 6 tile columns (gram_sb_deal; 0 when tri)
+    int n8, n6, n4; // shared-slab kernel: super-block rows of 8, 6 and (at most one) 4 tile columns (gram_sb_deal; 0 when tri)
     int nchunk;     // row chunks (workgroups along rows)
     int steps;      // 64-row steps per chunk
     size_t tpart_doubles;   // nchunk * ntile * 256
@@ -41,7 +41,7 @@ struct GramPlan {
 };
 GramPlan gram_plan(int64_t n, int p, int num_cu);
 GramPlan gram_plan_bound(int64_t nmax, int p, int num_cu);   // sizes that hold the plan of any n <= nmax
-void gram_sb_deal(int ntc, int *n8, int *n6);
+void gram_sb_deal(int ntc, int *n8, int *n6, int *n4);
 
 int launch_shift_sums(hipStream_t s, const double *x, int64_t n, int64_t ld, int p, const double *y, double *sums);
 int launch_gram(hipStream_t s, const GramPlan &pl, const double *x, int64_t n, int64_t ld, const double *y,

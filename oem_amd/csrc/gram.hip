@@ -977,17 +977,18 @@ __global__ __launch_bounds__(256) void gram_blk_kernel(const double *__restrict_
 #ifndef OEM_SB_NSLOT
 #define OEM_SB_NSLOT 9
 #endif
-constexpr int SB_NSLOT = OEM_SB_NSLOT;           // ring depth: the prefetch distance is (NSLOT - 3) slabs
+constexpr int SB_NSLOT = OEM_SB_NSLOT;
+constexpr int SB_KINDS = 7;                      // kinds of super-block, in launch order (gram_sb_kernel)           // ring depth: the prefetch distance is (NSLOT - 3) slabs
 
-// Super-block heights.  A super-block row is HI = 8 or 6 tile columns high (gram_plan deals the ntc tile columns into eights and
-// sixes so that little of the last one is padding: with eights alone p = 160 multiplied 136 tiles' worth for 55 real ones,
-// p = 300 300 for 190 -- tools/gram_band.sh, round 5); the eights come first, so an off-diagonal super-block (SI > SJ) is
-// 8 x 8, 6 x 8 or 6 x 6 tiles and its four waves take (HI / 2) x (HJ / 2) tiles each.
+// Super-block heights.  A super-block row is HI = 8, 6 or 4 tile columns high (gram_plan deals the ntc tile columns into eights,
+// at most one six and one four so that little of the last one is padding: with eights alone p = 160 multiplied 136 tiles' worth for
+// 55 real ones, p = 300 300 for 190 -- tools/gram_band.sh, round 5); the eights come first, then the six, then the four, so an
+// off-diagonal super-block (SI > SJ) is 8 x 8, 6 x 8, 4 x 8 or 4 x 6 tiles and its four waves take (HI / 2) x (HJ / 2) tiles each.
 // row of the lower triangle that holds row-major index tt (tt = I (I + 1) / 2 + J, J <= I)
 constexpr int tri_row(int tt) { int I = 0; while ((I + 1) * (I + 2) / 2 <= tt) ++I; return I; }
 // diagonal super-block of height H: wave W multiplies tiles sb_diag_t0(H, W) .. sb_diag_t0(H, W + 1) - 1 of the row-major triangle
-// (H = 8: 36 tiles, 9 each; H = 6: 21 tiles, 6 + 5 + 5 + 5)
-constexpr int sb_diag_t0(int H, int W) { return H == 8 ? 9 * W : (W == 0 ? 0 : 1 + 5 * W); }
+// (H = 8: 36 tiles, 9 each; H = 6: 21 tiles, 6 + 5 + 5 + 5; H = 4: 10 tiles, 3 + 3 + 2 + 2)
+constexpr int sb_diag_t0(int H, int W) { return H == 8 ? 9 * W : H == 6 ? (W == 0 ? 0 : 1 + 5 * W) : (W < 2 ? 3 * W : 2 + 2 * W); }
 
 // One slab of one wave of a super-block.  Up to eight fragments in registers.
 //   off-diagonal super-block: s.v[0 .. NR-1] = the wave's tile rows, s.v[NR .. NR+NC-1] = its tile columns, NR x NC tiles (I, J);
@@ -1047,7 +1048,7 @@ __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64
                                              int TJ /* first tile column of the row / column group */, int64_t row_begin, int steps, double *__restrict__ tdst,
                                              double *__restrict__ vdst, double *lds)
 {
-    static_assert(HI <= HJ && (HI == 6 || HI == 8) && (HJ == 6 || HJ == 8) && (!DIAGSB || HI == HJ), "super-block heights");
+    static_assert(HI <= HJ && (HI == 4 || HI == 6 || HI == 8) && (HJ == 4 || HJ == 6 || HJ == 8) && (!DIAGSB || HI == HJ), "super-block heights");
     constexpr int NR = DIAGSB ? HI : HI / 2, NC = DIAGSB ? HI : HJ / 2;   // the wave's tile block (diagonal: the whole triangle's fragments)
     constexpr int NFR = DIAGSB ? HI : NR + NC;         // fragments in this wave's registers
     constexpr int F = DIAGSB ? HI : HI + HJ;           // x fragments per slab
@@ -1227,29 +1228,39 @@ __device__ __forceinline__ void gram_sb_body(const double *__restrict__ x, int64
 
 __global__ __launch_bounds__(256) void gram_sb_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                        const double *__restrict__ sums, double *__restrict__ tpart,
-                                                       double *__restrict__ vpart, GramDims a, int n8, int n6 /* super-block rows of height 8 / 6 */)
+                                                       double *__restrict__ vpart, GramDims a, int n8, int n6, int n4 /* super-block rows of height 8 / 6 / 4 */)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    // Launch order = longest first: the off-diagonal super-blocks of all row chunks by size (8 x 8 tiles: 32 MFMAs per wave and
-    // slab, 6 x 8: 24, 6 x 6: 18), then the diagonal ones (18, 12).  Workgroups are handed to CUs as CUs fall free, so the launch
-    // ends one (partial) workgroup after the work runs out: with the short ones last that tail is short (measured at p = 256:
-    // 11 % of the launch in mixed order; gram_plan also picks the chunk count whose simulated tail is smallest).  Blocks of one
-    // row chunk still share blockIdx % 8 (one XCD).
+    // Launch order = longest first: the super-blocks of all row chunks by the MFMAs a wave issues per slab -- off the diagonal 8 x 8
+    // tiles 32, 6 x 8 24, diagonal eight 18, 4 x 8 16, 4 x 6 12, diagonal six 12, diagonal four 6.  Workgroups are handed
+    // to CUs as CUs fall free, so the launch ends one (partial) workgroup after the work runs out: with the short ones last that
+    // tail is short (measured at p = 256: 11 % of the launch in mixed order; gram_plan also picks the chunk count whose simulated
+    // tail is smallest).  Blocks of one row chunk still share blockIdx % 8 (one XCD).
     const int L = blockIdx.x, xcd = L & 7, ng = a.nchunk / 8;
-    int s = L >> 3, SI = 0, SJ = 0, chunk = 0, kind = 0;           // kind 0: 8 x 8, 1: 6 x 8, 2: 6 x 6, 3: diagonal 8, 4: diagonal 6
+    int s = L >> 3, SI = 0, SJ = 0, kind = 0;
     auto tri_decode = [](int ob, int &I, int &J) {                 // ob = I (I - 1) / 2 + J, J < I
         I = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)ob)) * 0.5f);
         while (I * (I - 1) / 2 > ob) --I;
         while ((I + 1) * I / 2 <= ob) ++I;
         J = ob - I * (I - 1) / 2;
     };
-    const int c0 = n8 * (n8 - 1) / 2, c1 = n6 * n8, c2 = n6 * (n6 - 1) / 2;
-    if (s < c0 * ng) { chunk = (s / c0) * 8 + xcd; tri_decode(s % c0, SI, SJ); kind = 0; }
-    else if ((s -= c0 * ng) < c1 * ng) { const int ob = s % c1; chunk = (s / c1) * 8 + xcd; SI = n8 + ob / n8; SJ = ob % n8; kind = 1; }
-    else if ((s -= c1 * ng) < c2 * ng) { chunk = (s / c2) * 8 + xcd; tri_decode(s % c2, SI, SJ); SI += n8; SJ += n8; kind = 2; }
-    else if ((s -= c2 * ng) < n8 * ng) { chunk = (s / n8) * 8 + xcd; SI = SJ = s % n8; kind = 3; }
-    else { s -= n8 * ng; chunk = (s / n6) * 8 + xcd; SI = SJ = n8 + s % n6; kind = 4; }
-    const int TI = SI < n8 ? 8 * SI : 8 * n8 + 6 * (SI - n8), TJ = SJ < n8 ? 8 * SJ : 8 * n8 + 6 * (SJ - n8);   // first tile columns
+    const int cnt[SB_KINDS] = {n8 * (n8 - 1) / 2, n6 * n8, n8, n4 * n8, n4 * n6, n6, n4};       // (n6, n4 <= 1: gram_sb_deal)
+#pragma unroll
+    for (int k = 0; k < SB_KINDS - 1; ++k) {
+        if (kind == k) { if (s < cnt[k] * ng) break; s -= cnt[k] * ng; kind = k + 1; }
+    }
+    const int ck = cnt[kind] > 0 ? cnt[kind] : 1, ob = s % ck, chunk = (s / ck) * 8 + xcd;
+    switch (kind) {
+    case 0: tri_decode(ob, SI, SJ); break;                         // 8 x 8
+    case 1: SI = n8 + ob / n8; SJ = ob % n8; break;                // 6 x 8
+    case 2: SI = SJ = ob; break;                                   // diagonal eight
+    case 3: SI = n8 + n6 + ob / n8; SJ = ob % n8; break;           // 4 x 8
+    case 4: SI = n8 + n6 + ob / n6; SJ = n8 + ob % n6; break;      // 4 x 6
+    case 5: SI = SJ = n8 + ob; break;                              // diagonal six
+    default: SI = SJ = n8 + n6 + ob; break;                        // diagonal four
+    }
+    auto first_tile = [&](int S) { return S < n8 ? 8 * S : (S < n8 + n6 ? 8 * n8 + 6 * (S - n8) : 8 * n8 + 6 * n6 + 4 * (S - n8 - n6)); };
+    const int TI = first_tile(SI), TJ = first_tile(SJ);            // first tile columns of the row / column group
     const int64_t row_begin = (int64_t)chunk * a.steps * 64;
     double *tdst = tpart + (size_t)chunk * a.ntile * 256;
     double *vdst = vpart + (size_t)chunk * (32 * a.ntc + 4);
@@ -1269,9 +1280,11 @@ __global__ __launch_bounds__(256) void gram_sb_kernel(const double *__restrict__
     do {                                                                                            \
         if (kind == 0) OEM_SB(false, 0, XF, 8, 8);                                                  \
         else if (kind == 1) OEM_SB(false, 0, XF, 6, 8);                                             \
-        else if (kind == 2) OEM_SB(false, 0, XF, 6, 6);                                             \
-        else if (kind == 3) OEM_SB_DIAG(XF, 8);                                                     \
-        else OEM_SB_DIAG(XF, 6);                                                                    \
+        else if (kind == 2) OEM_SB_DIAG(XF, 8);                                                     \
+        else if (kind == 3) OEM_SB(false, 0, XF, 4, 8);                                             \
+        else if (kind == 4) OEM_SB(false, 0, XF, 4, 6);                                             \
+        else if (kind == 5) OEM_SB_DIAG(XF, 6);                                                     \
+        else OEM_SB_DIAG(XF, 4);                                                                    \
     } while (0)
     if (shift_needed_wave(sums, a.p)) OEM_SB_ALL(true); else OEM_SB_ALL(false);
 #undef OEM_SB_ALL
@@ -1290,19 +1303,23 @@ __global__ __launch_bounds__(256) void gram_sb_kernel(const double *__restrict__
 #endif
 }
 
-// The deal of ntc tile columns into n8 super-block rows of eight and n6 of six: the one with the least multiply time (in tile
-// units: an off-diagonal super-block of h1 x h2 tiles costs h1 h2, a diagonal one 36 (eight) or 24 (six: 6 + 5 + 5 + 5 tiles over
-// the four waves)); ties go to fewer super-blocks.
-void gram_sb_deal(int ntc, int *n8_out, int *n6_out)
+// The deal of ntc tile columns into n8 super-block rows of eight, n6 <= 1 of six and n4 <= 1 of four: the one with the least
+// multiply time (in tile units: an off-diagonal super-block of h1 x h2 tiles costs h1 h2; a diagonal one 36 (eight), 24 (six:
+// 6 + 5 + 5 + 5 tiles over the four waves) or 12 (four: 3 + 3 + 2 + 2)); ties go to fewer super-blocks.  One six and one four next to
+// the eights cover every remainder of ntc mod 8 with at most one tile column of padding (two at 8 k + 1 ... never more), which no
+// deal with more sixes or fours beats -- and it keeps the kinds of super-block at seven.
+void gram_sb_deal(int ntc, int *n8_out, int *n6_out, int *n4_out)
 {
-    int best8 = (ntc + 7) / 8, best6 = 0;
+    int best8 = (ntc + 7) / 8, best6 = 0, best4 = 0;
     long best = -1;
-    for (int n6 = 0; 6 * (n6 - 1) < ntc; ++n6) {
-        const int rest = ntc - 6 * n6, n8 = rest > 0 ? (rest + 7) / 8 : 0;
-        const long cost = 64L * n8 * (n8 - 1) / 2 + 48L * n8 * n6 + 36L * n6 * (n6 - 1) / 2 + 36L * n8 + 24L * n6;
-        if (best < 0 || cost < best || (cost == best && n8 + n6 < best8 + best6)) { best = cost; best8 = n8; best6 = n6; }
-    }
-    *n8_out = best8; *n6_out = best6;
+    for (int n4 = 0; n4 <= 1; ++n4)
+        for (int n6 = 0; n6 <= 1; ++n6) {
+            const int rest = ntc - 6 * n6 - 4 * n4, n8 = rest > 0 ? (rest + 7) / 8 : 0;
+            if (n8 + n6 + n4 == 0 || 8 * n8 + 6 * n6 + 4 * n4 - ntc >= 4) continue;      // (no super-block row that is all padding)
+            const long cost = 64L * n8 * (n8 - 1) / 2 + 48L * n8 * n6 + 32L * n8 * n4 + 24L * n6 * n4 + 36L * n8 + 24L * n6 + 12L * n4;
+            if (best < 0 || cost < best || (cost == best && n8 + n6 + n4 < best8 + best6 + best4)) { best = cost; best8 = n8; best6 = n6; best4 = n4; }
+        }
+    *n8_out = best8; *n6_out = best6; *n4_out = best4;
 }
 
 constexpr int GRAM_MAX_ROUNDS = 12;
@@ -1312,7 +1329,7 @@ static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
     GramPlan pl;
     pl.p = p;
     pl.tri = (p + 2 + 15) / 16 <= 7;                     // Z = [X | y | 1] fits one wave's triangle
-    pl.n8 = pl.n6 = 0;
+    pl.n8 = pl.n6 = pl.n4 = 0;
     pl.ntc = pl.tri ? (p + 2 + 15) / 16 : (p + 15) / 16;
     pl.ntile = pl.ntc * (pl.ntc + 1) / 2;
     const int64_t nsteps = (n + 63) / 64;
@@ -1327,10 +1344,10 @@ static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
     } else {
         const int nb = (pl.ntc + 3) / 4;
         pl.nblk = nb * (nb + 1) / 2;
-        int n8 = 0, n6 = 0;
-        gram_sb_deal(pl.ntc, &n8, &n6);                                  // the shared-slab kernel's super-block rows
-        pl.n8 = n8; pl.n6 = n6;
-        const int nsb = n8 + n6, nsblk = nsb * (nsb + 1) / 2;
+        int n8 = 0, n6 = 0, n4 = 0;
+        gram_sb_deal(pl.ntc, &n8, &n6, &n4);                             // the shared-slab kernel's super-block rows
+        pl.n8 = n8; pl.n6 = n6; pl.n4 = n4;
+        const int nsb = n8 + n6 + n4, nsblk = nsb * (nsb + 1) / 2;
         // 1-12 rounds of one workgroup per CU: the count whose launch ends soonest when the workgroups are handed out longest
         // first (gram_sb_kernel) -- a greedy replay with the measured costs (tools/gram_diag.py: 2,136 cycles per 8-row slab off
         // the diagonal at 32 MFMAs per wave, 1,284 on it at 18: ~66 per MFMA + ~100; ~25 k per workgroup: ring fill, 72-128 KB of
@@ -1338,8 +1355,8 @@ static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
         // at 8 rounds, which is right for the configurations' row counts (millions) and wrong below: at n = 1e5 a workgroup then
         // has 3 steps of rows and spends more time filling its ring than multiplying (p = 128: 82 us, with ONE round 42;
         // p = 256: 178 -> 141 with three; profiles/r5_gram_rounds_experiment.txt holds the grid this replay was checked against).
-        const int64_t cnt[5] = {(int64_t)n8 * (n8 - 1) / 2, (int64_t)n6 * n8, (int64_t)n6 * (n6 - 1) / 2, n8, n6};
-        const double per_slab[5] = {2136.0, 1680.0, 1284.0, 1284.0, 890.0};
+        const int64_t cnt[SB_KINDS] = {(int64_t)n8 * (n8 - 1) / 2, (int64_t)n6 * n8, n8, (int64_t)n4 * n8, (int64_t)n4 * n6, n6, n4};
+        const double per_slab[SB_KINDS] = {2136.0, 1680.0, 1284.0, 1160.0, 890.0, 890.0, 520.0};      // (the kernel's launch order)
         int64_t c = 0;
         double best = 0.0;
         for (int rounds = 1; rounds <= GRAM_MAX_ROUNDS; ++rounds) {
@@ -1352,7 +1369,7 @@ static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
             // first, whole groups at a time -- the same schedule as a heap of 256 finish times in ~rounds x kinds steps
             std::vector<std::pair<double, int64_t>> grp{{0.0, (int64_t)num_cu}};
             double end = 0.0;
-            for (int kind = 0; kind < 5; ++kind) {
+            for (int kind = 0; kind < SB_KINDS; ++kind) {
                 const double d = slabs * per_slab[kind] + 25000.0;
                 for (int64_t m = cc * cnt[kind]; m > 0;) {
                     const double t = grp.front().first + d;
@@ -1397,7 +1414,7 @@ GramPlan gram_plan_bound(int64_t nmax, int p, int num_cu)
 {
     GramPlan pl = gram_plan(nmax, p, num_cu);
     if (!pl.tri) {
-        const int nsb = pl.n8 + pl.n6, nsblk = nsb * (nsb + 1) / 2;
+        const int nsb = pl.n8 + pl.n6 + pl.n4, nsblk = nsb * (nsb + 1) / 2;
         const int64_t nsteps = (nmax + 63) / 64;
         int64_t cc = ((int64_t)num_cu * GRAM_MAX_ROUNDS) / nsblk;
         if (cc > nsteps) cc = nsteps;
@@ -1459,10 +1476,10 @@ static int launch_gram_t(hipStream_t s, const GramPlan &pl, const double *x, con
         }
     } else {
         if (ALIGNED && a.n >= 64 && (double)a.ld * 16.0 * 8.0 < 4294967296.0) {   // 32-bit lane offsets within a tile
-            const int nsb = pl.n8 + pl.n6, nsblk = nsb * (nsb + 1) / 2;
+            const int nsb = pl.n8 + pl.n6 + pl.n4, nsblk = nsb * (nsb + 1) / 2;
             const size_t shb = (size_t)SB_NSLOT * 16 * 1024;                // NSLOT x 16 KiB slots
             OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
-            hipLaunchKernelGGL(gram_sb_kernel, dim3(pl.nchunk * nsblk), dim3(256), shb, s, x, y, sums, tpart, vpart, a, pl.n8, pl.n6);
+            hipLaunchKernelGGL(gram_sb_kernel, dim3(pl.nchunk * nsblk), dim3(256), shb, s, x, y, sums, tpart, vpart, a, pl.n8, pl.n6, pl.n4);
             OEM_HIP(hipGetLastError());
             return 0;
         }

@@ -312,14 +312,14 @@ def test_ring_strip_forms_of_the_moment_kernel(oa, p, n):
     assert got[p + 1, p + 1] == n
 
 
-# p -> super-block rows (eights, sixes) of gram_sb_deal: 120 (1, 0); 130, 150, 176, 192 (0, 2) with 3, 2, 1, 0 tile columns of padding;
-# 200, 224 (1, 1); 240, 256 (2, 0); 272 (0, 3); 300 (1, 2); 330 (2, 1); 400 (1, 3); 520 (3, 2); 700 (4, 2)
+# p -> super-block rows (eights, six, four) of gram_sb_deal: 111, 113, 120 (1, 0, 0); 130, 150 (0, 1, 1); 176, 192 (1, 0, 1);
+# 200, 224 (1, 1, 0); 240, 256 (2, 0, 0); 272 (1, 1, 1); 300 (2, 0, 1); 330 (2, 1, 0); 400 (2, 1, 1); 520 (3, 1, 1); 700 (5, 0, 1); 720 (5, 1, 0)
 @pytest.mark.parametrize("p,n", [(p, n) for p in (120, 200, 256, 300, 520) for n in (4096, 3001, 1000, 10010)]
-                         + [(p, n) for p in (111, 113, 130, 150, 176, 192, 224, 240, 272, 330, 400, 700) for n in (3001, 4104)])
+                         + [(p, n) for p in (111, 113, 130, 150, 176, 192, 224, 240, 272, 330, 400, 700, 720) for n in (3001, 4104)])
 def test_shared_slab_moment_kernel(oa, p, n):
     """the workgroup-shared-slab Gram kernel (p + 2 > 112, aligned X): diagonal and off-diagonal super-blocks of every shape the
-    deal into eights and sixes makes (8 x 8, 6 x 8, 6 x 6 tiles; diagonal 8 and 6), partial super-blocks (tile columns of padding),
-    ragged row tails; shifted and un-shifted accumulation"""
+    deal into eights, a six and a four makes (8 x 8, 6 x 8, 4 x 8, 4 x 6 tiles; diagonal 8, 6 and 4), partial super-blocks (tile columns
+    of padding), ragged row tails; shifted and un-shifted accumulation"""
     import torch
     from oem_amd import _lib as L
     from tests.checker_backend import shift_in_effect

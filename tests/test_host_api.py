@@ -184,37 +184,38 @@ def test_persistent_wide_engine_scratch_holds_every_partition():
     assert not bad, bad[:10]
 
 
-def test_moment_plan_deals_the_tile_columns_into_eights_and_sixes():
+def test_moment_plan_deals_the_tile_columns_into_eights_sixes_and_a_four():
     """gram.hip: gram_plan / gram_sb_deal (host arithmetic): the shared-slab kernel's super-block rows cover every tile column, never
     cost more multiply time than eights alone (the deal before round 5: p = 160 multiplied 136 tiles' worth for 55 real ones), and from
-    p = 177 on at most a fifth of it is padding; the row chunks cover n."""
+    p = 177 on at most a fifth of it is padding (a quarter below: 129 <= p <= 176 is a six and a four, or an eight and a four); the row
+    chunks cover n."""
     import ctypes as C
     import oem_amd
     L = oem_amd.lib()
-    out = (C.c_int64 * 7)()
+    out = (C.c_int64 * 8)()
     worst = {}
     for p in list(range(1, 1300)) + [2048, 3000, 4096, 5000, 8192, 12000]:
         for n in (64, 5000, 100_000, 1_000_000):
             assert L.oemgpu_selftest_gram_plan(n, p, 256, out) == 0, L.oemgpu_last_error().decode()
-            ntc, n8, n6, nchunk, steps, cost, real = list(out)
+            ntc, n8, n6, nchunk, steps, cost, real, n4 = list(out)
             assert nchunk >= 1 and steps >= 1 and nchunk * steps * 64 >= n, (n, p)
             if p + 2 <= 112:
-                assert (n8, n6) == (0, 0) and ntc == (p + 2 + 15) // 16
+                assert (n8, n6, n4) == (0, 0, 0) and ntc == (p + 2 + 15) // 16
                 continue
-            assert ntc == (p + 15) // 16 and 8 * n8 + 6 * n6 >= ntc, (p, n8, n6)
-            assert 8 * n8 + 6 * n6 - ntc < 8, (p, n8, n6)                         # no super-block row is all padding
+            assert ntc == (p + 15) // 16 and 8 * n8 + 6 * n6 + 4 * n4 >= ntc and n4 <= 1 and n6 <= 1, (p, n8, n6, n4)
+            assert 8 * n8 + 6 * n6 + 4 * n4 - ntc < 4, (p, n8, n6, n4)            # no super-block row is all padding
             e = (ntc + 7) // 8
             assert cost <= 64 * (e * (e - 1) // 2) + 36 * e, (p, n8, n6)
             assert nchunk % 8 == 0                                               # the kernel deals row chunks to XCDs in eights
             worst[p] = real / cost
     assert min(v for p, v in worst.items() if p >= 177) >= 0.8, min((v, p) for p, v in worst.items() if p >= 177)
-    assert min(worst.values()) >= 0.5, min((v, p) for p, v in worst.items())
+    assert min(worst.values()) >= 0.75, min((v, p) for p, v in worst.items())
     assert worst[256] == 1.0 and worst[512] == 1.0 and worst[4096] == 1.0         # the configurations' sizes stay all eights
     # rounds of workgroups per CU: few where a workgroup would otherwise have a handful of row steps (the ring fill and the partials it
     # writes cost ~25 k cycles), several at the configurations' row counts
     for n, p, lo, hi in ((100_000, 128, 1, 1), (100_000, 256, 2, 4), (200_000, 300, 2, 4), (12_500_000, 256, 3, 12), (1_000_000, 512, 3, 12)):
         assert L.oemgpu_selftest_gram_plan(n, p, 256, out) == 0
-        nsb = out[1] + out[2]
+        nsb = out[1] + out[2] + out[7]
         rounds = out[3] * (nsb * (nsb + 1) // 2) / 256.0
         assert lo - 0.1 <= rounds <= hi + 0.1, (n, p, rounds)
 
