@@ -5,6 +5,7 @@
 #include "ctx.hpp"
 
 #include <atomic>
+#include <unistd.h>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -69,7 +70,7 @@ static const int COOP_MAX_DEV = 64;
 static std::mutex g_coop_mu;
 static std::condition_variable g_coop_cv;
 static int g_coop_in_flight[COOP_MAX_DEV] = {0};
-static std::atomic<unsigned> g_xcd_next{0};
+static std::atomic<unsigned> g_xcd_next{(unsigned)getpid()};      // (processes that share a GPU start at different XCDs more often than not)
 struct CoopSlots {
     int n = 0, dev = 0;
     void take(int device, int want, int capacity)
