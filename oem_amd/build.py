@@ -14,7 +14,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "liboemgpu.so"
-SOURCES = ["api.hip", "hoststream.hip", "gram.hip", "path_small.hip", "path_coop.hip", "path_symcoop.hip", "path_wcoop.hip", "path_large.hip", "xval.hip", "sparse.hip", "wide.hip", "weighted.hip"]
+SOURCES = ["api.hip", "hoststream.hip", "gram.hip", "gram_sb.hip", "path_small.hip", "path_coop.hip", "path_symcoop.hip", "path_wcoop.hip", "path_large.hip", "xval.hip", "sparse.hip", "wide.hip", "weighted.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
@@ -186,7 +186,7 @@ def build(force=False, verbose=False):
     # the objects are independent hipcc runs: side by side
     from concurrent.futures import ThreadPoolExecutor
     jobs = []
-    AUDITED = ("gram.hip", "path_small.hip", "path_coop.hip", "path_wcoop.hip", "path_symcoop.hip")
+    AUDITED = ("gram.hip", "gram_sb.hip", "path_small.hip", "path_coop.hip", "path_wcoop.hip", "path_symcoop.hip")
     # the audited sources are compiled ONCE: -save-temps=obj leaves the device ISA of the very object that is linked next to it (until
     # round 5 each of the five largest translation units was compiled twice, once for the object and once more with -S for the audit:
     # the cold build's critical path)
@@ -224,9 +224,10 @@ def build(force=False, verbose=False):
             def result(self):
                 return self
         listing = {src: _Listing(isa_path(src)) for src in AUDITED}
-        problems = audit_gram_isa(listing["gram.hip"].result().stdout)
-        if problems:
-            raise RuntimeError("gram.hip ISA audit failed:\n  " + "\n  ".join(problems[:20]))
+        for src in ("gram.hip", "gram_sb.hip"):
+            problems = audit_gram_isa(listing[src].result().stdout)
+            if problems:
+                raise RuntimeError(src + " ISA audit failed:\n  " + "\n  ".join(problems[:20]))
         for src in ("path_small.hip", "path_coop.hip", "path_wcoop.hip"):
             problems = audit_dpp_hazards(listing[src].result().stdout)
             if problems:

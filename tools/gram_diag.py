@@ -28,9 +28,10 @@ sums = torch.zeros(L.sums_len(p), dtype=torch.float64, device="cuda")
 mom = torch.zeros(L.moments_len(p), dtype=torch.float64, device="cuda")
 lib = L.lib()
 ctx = api.context(0, torch.cuda.current_stream())
-have_diag = hasattr(lib, "oemgpu_gram_diag_read")          # only the -DOEM_GRAM_DIAG build exports it
+reader = "oemgpu_gram_sb_diag_read" if p + 2 > 112 else "oemgpu_gram_diag_read"      # (the shared-slab kernel is a translation unit of its own: gram_sb.hip)
+have_diag = hasattr(lib, reader)                              # only the -DOEM_GRAM_DIAG build exports it
 if have_diag:
-    lib.oemgpu_gram_diag_read.argtypes = [C.POINTER(C.c_ulonglong)]
+    getattr(lib, reader).argtypes = [C.POINTER(C.c_ulonglong)]
 L.check(lib.oemgpu_set_timing(ctx, 1))
 ms = (C.c_double * L.NTIMERS)()
 for it in range(5):
@@ -40,7 +41,7 @@ for it in range(5):
     L.check(lib.oemgpu_last_timings(ctx, ms))
 out = (C.c_ulonglong * 8)()
 if have_diag:
-    assert lib.oemgpu_gram_diag_read(out) == 0
+    assert getattr(lib, reader)(out) == 0
 d = list(out)
 if p + 2 > 112:
     # shared-slab kernel: one diagonal (sbk 0) and one off-diagonal (sbk 1) workgroup of the first row chunk
