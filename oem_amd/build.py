@@ -14,7 +14,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "liboemgpu.so"
-SOURCES = ["api.hip", "hoststream.hip", "gram.hip", "gram_sb.hip", "path_small.hip", "path_coop.hip", "path_symcoop.hip", "path_wcoop.hip", "path_large.hip", "xval.hip", "sparse.hip", "wide.hip", "weighted.hip"]
+SOURCES = ["api.hip", "hoststream.hip", "gram.hip", "gram_sb.hip", "gram_wd.hip", "path_small.hip", "path_coop.hip", "path_symcoop.hip", "path_wcoop.hip", "path_large.hip", "xval.hip", "sparse.hip", "wide.hip", "weighted.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
@@ -34,7 +34,7 @@ def audit_gram_isa(asm_text):
     file and never spills in those kernels: check both in the emitted ISA."""
     problems = []
     found = 0
-    for m in re.finditer(r"^(_ZN6oemgpu1[4567]gram_(?:tri|blk|ring|sb)_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end", asm_text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN6oemgpu1[4567]gram_(?:tri|blk|ring|sb|wd)_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end", asm_text, re.S | re.M):
         name, body = m.group(1), m.group(2)
         found += 1
         in_asm = False
@@ -186,7 +186,7 @@ def build(force=False, verbose=False):
     # the objects are independent hipcc runs: side by side
     from concurrent.futures import ThreadPoolExecutor
     jobs = []
-    AUDITED = ("gram.hip", "gram_sb.hip", "path_small.hip", "path_coop.hip", "path_wcoop.hip", "path_symcoop.hip")
+    AUDITED = ("gram.hip", "gram_sb.hip", "gram_wd.hip", "path_small.hip", "path_coop.hip", "path_wcoop.hip", "path_symcoop.hip")
     # the audited sources are compiled ONCE: -save-temps=obj leaves the device ISA of the very object that is linked next to it (until
     # round 5 each of the five largest translation units was compiled twice, once for the object and once more with -S for the audit:
     # the cold build's critical path)
@@ -224,7 +224,7 @@ def build(force=False, verbose=False):
             def result(self):
                 return self
         listing = {src: _Listing(isa_path(src)) for src in AUDITED}
-        for src in ("gram.hip", "gram_sb.hip"):
+        for src in ("gram.hip", "gram_sb.hip", "gram_wd.hip"):
             problems = audit_gram_isa(listing[src].result().stdout)
             if problems:
                 raise RuntimeError(src + " ISA audit failed:\n  " + "\n  ".join(problems[:20]))

@@ -826,7 +826,7 @@ static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
     GramPlan pl;
     pl.p = p;
     pl.tri = (p + 2 + 15) / 16 <= 7;                     // Z = [X | y | 1] fits one wave's triangle
-    pl.n8 = pl.n6 = pl.n4 = 0;
+    pl.n8 = pl.n6 = pl.n4 = 0; pl.wd = 0;
     pl.ntc = pl.tri ? (p + 2 + 15) / 16 : (p + 15) / 16;
     pl.ntile = pl.ntc * (pl.ntc + 1) / 2;
     const int64_t nsteps = (n + 63) / 64;
@@ -844,7 +844,10 @@ static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
         int n8 = 0, n6 = 0, n4 = 0;
         gram_sb_deal(pl.ntc, &n8, &n6, &n4);                             // the shared-slab kernel's super-block rows
         pl.n8 = n8; pl.n6 = n6; pl.n4 = n4;
-        const int nsb = n8 + n6 + n4, nsblk = nsb * (nsb + 1) / 2;
+        // 15 or 16 tile columns (225 <= p <= 256: config 5): ONE workgroup of eight waves per row chunk multiplies the whole triangle
+        // from one read of X (gram_wd.hip) instead of three super-blocks that each stream the rows
+        pl.wd = (pl.ntc == 15 || pl.ntc == 16) && !sw().OEM_NO_GRAM_WD.set;
+        const int nsb = n8 + n6 + n4, nsblk = pl.wd ? 1 : nsb * (nsb + 1) / 2;
         // 1-12 rounds of one workgroup per CU: the count whose launch ends soonest when the workgroups are handed out longest
         // first (gram_sb_kernel) -- a greedy replay with the measured costs (tools/gram_diag.py: 2,136 cycles per 8-row slab off
         // the diagonal at 32 MFMAs per wave, 1,284 on it at 18: ~66 per MFMA + ~100; ~25 k per workgroup: ring fill, 72-128 KB of
@@ -867,8 +870,9 @@ static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
             std::vector<std::pair<double, int64_t>> grp{{0.0, (int64_t)num_cu}};
             double end = 0.0;
             for (int kind = 0; kind < SB_KINDS; ++kind) {
-                const double d = slabs * per_slab[kind] + 25000.0;
-                for (int64_t m = cc * cnt[kind]; m > 0;) {
+                // (gram_wd.hip: one kind of workgroup, 68 MFMAs per SIMD and slab -- 4,352 cycles of issue, ~4,500 measured)
+                const double d = slabs * (pl.wd ? 4500.0 : per_slab[kind]) + 25000.0;
+                for (int64_t m = pl.wd ? (kind == 0 ? cc : 0) : cc * cnt[kind]; m > 0;) {
                     const double t = grp.front().first + d;
                     const int64_t take = grp.front().second < m ? grp.front().second : m;
                     if ((grp.front().second -= take) == 0) grp.erase(grp.begin());
@@ -896,12 +900,13 @@ static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
 // with the same sizes (a bench loop, the folds of xval.oem, the row blocks of a host-resident call).
 GramPlan gram_plan(int64_t n, int p, int num_cu)
 {
-    struct Memo { int64_t n; int p, cu; GramPlan pl; };
-    static thread_local Memo memo[4] = {{-1, 0, 0, {}}, {-1, 0, 0, {}}, {-1, 0, 0, {}}, {-1, 0, 0, {}}};
+    struct Memo { int64_t n; int p, cu; unsigned gen; GramPlan pl; };
+    static thread_local Memo memo[4] = {{-1, 0, 0, 0u, {}}, {-1, 0, 0, 0u, {}}, {-1, 0, 0, 0u, {}}, {-1, 0, 0, 0u, {}}};
     static thread_local unsigned next = 0;
-    for (const Memo &m : memo) if (m.n == n && m.p == p && m.cu == num_cu) return m.pl;
+    const unsigned gen = sw().generation;                          // (a switch -- OEM_NO_GRAM_WD -- is part of the plan)
+    for (const Memo &m : memo) if (m.n == n && m.p == p && m.cu == num_cu && m.gen == gen) return m.pl;
     Memo &m = memo[next++ & 3];
-    m.n = n; m.p = p; m.cu = num_cu; m.pl = gram_plan_compute(n, p, num_cu);
+    m.n = n; m.p = p; m.cu = num_cu; m.gen = gen; m.pl = gram_plan_compute(n, p, num_cu);
     return m.pl;
 }
 
@@ -911,7 +916,7 @@ GramPlan gram_plan_bound(int64_t nmax, int p, int num_cu)
 {
     GramPlan pl = gram_plan(nmax, p, num_cu);
     if (!pl.tri) {
-        const int nsb = pl.n8 + pl.n6 + pl.n4, nsblk = nsb * (nsb + 1) / 2;
+        const int nsb = pl.n8 + pl.n6 + pl.n4, nsblk = pl.wd ? 1 : nsb * (nsb + 1) / 2;
         const int64_t nsteps = (nmax + 63) / 64;
         int64_t cc = ((int64_t)num_cu * GRAM_MAX_ROUNDS) / nsblk;
         if (cc > nsteps) cc = nsteps;
@@ -973,6 +978,7 @@ static int launch_gram_t(hipStream_t s, const GramPlan &pl, const double *x, con
         }
     } else {
         if (ALIGNED && a.n >= 64 && (double)a.ld * 16.0 * 8.0 < 4294967296.0) {   // 32-bit lane offsets within a tile
+            if (pl.wd) return launch_gram_wd(s, pl, x, y, sums, tpart, vpart, a);
             return launch_gram_sb(s, pl, x, y, sums, tpart, vpart, a);
         }
         size_t sh = 16 * tile_bytes;

@@ -173,6 +173,7 @@ struct GramDims {
 
 // the shared-slab launch (gram_sb.hip) behind launch_gram
 int launch_gram_sb(hipStream_t s, const GramPlan &pl, const double *x, const double *y, const double *sums, double *tpart, double *vpart, const GramDims &a);
+int launch_gram_wd(hipStream_t s, const GramPlan &pl, const double *x, const double *y, const double *sums, double *tpart, double *vpart, const GramDims &a);   // gram_wd.hip: 15-16 tile columns, one read of X
 constexpr int SB_KINDS = 7;                      // kinds of super-block, in launch order (gram_sb_kernel)
 
 }  // namespace oemgpu

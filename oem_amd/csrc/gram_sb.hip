@@ -318,7 +318,11 @@ __global__ __launch_bounds__(256) void gram_sb_kernel(const double *__restrict__
     }
     auto first_tile = [&](int S) { return S < n8 ? 8 * S : (S < n8 + n6 ? 8 * n8 + 6 * (S - n8) : 8 * n8 + 6 * n6 + 4 * (S - n8 - n6)); };
     const int TI = first_tile(SI), TJ = first_tile(SJ);            // first tile columns of the row / column group
+#ifdef OEM_SB_EXP_SAMEROWS                                  // experiment (never the product): every workgroup multiplies the rows of its XCD's first chunk -- the same
+    const int64_t row_begin = (int64_t)(chunk & 7) * a.steps * 64;      // MFMA work with (almost) no HBM traffic: what would one read of X be worth?
+#else
     const int64_t row_begin = (int64_t)chunk * a.steps * 64;
+#endif
     double *tdst = tpart + (size_t)chunk * a.ntile * 256;
     double *vdst = vpart + (size_t)chunk * (32 * a.ntc + 4);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -313,9 +313,9 @@ def test_ring_strip_forms_of_the_moment_kernel(oa, p, n):
 
 
 # p -> super-block rows (eights, six, four) of gram_sb_deal: 111, 113, 120 (1, 0, 0); 130, 150 (0, 1, 1); 176, 192 (1, 0, 1);
-# 200, 224 (1, 1, 0); 240, 256 (2, 0, 0); 272 (1, 1, 1); 300 (2, 0, 1); 330 (2, 1, 0); 400 (2, 1, 1); 520 (3, 1, 1); 700 (5, 0, 1); 720 (5, 1, 0)
+# 200, 224 (1, 1, 0); 225 ... 256: 15-16 tile columns, the one-read eight-wave workgroup of gram_wd.hip (OEM_NO_GRAM_WD=1: (2, 0, 0)); 272 (1, 1, 1); 300 (2, 0, 1); 330 (2, 1, 0); 400 (2, 1, 1); 520 (3, 1, 1); 700 (5, 0, 1); 720 (5, 1, 0)
 @pytest.mark.parametrize("p,n", [(p, n) for p in (120, 200, 256, 300, 520) for n in (4096, 3001, 1000, 10010)]
-                         + [(p, n) for p in (111, 113, 130, 150, 176, 192, 224, 240, 272, 330, 400, 700, 720) for n in (3001, 4104)])
+                         + [(p, n) for p in (111, 113, 130, 150, 176, 192, 224, 225, 240, 241, 250, 272, 330, 400, 700, 720) for n in (3001, 4104)])
 def test_shared_slab_moment_kernel(oa, p, n):
     """the workgroup-shared-slab Gram kernel (p + 2 > 112, aligned X): diagonal and off-diagonal super-blocks of every shape the
     deal into eights, a six and a four makes (8 x 8, 6 x 8, 4 x 8, 4 x 6 tiles; diagonal 8, 6 and 4), partial super-blocks (tile columns
@@ -343,6 +343,43 @@ def test_shared_slab_moment_kernel(oa, p, n):
         scale = np.sqrt(np.outer(np.diag(want), np.diag(want))) + 1e-300
         assert np.abs((got - want) / scale).max() < 1e-11, (mean,)
         assert got[p + 1, p + 1] == n
+
+
+@pytest.mark.parametrize("p", [225, 240, 256])
+@pytest.mark.parametrize("n,mean", [(20011, 0.3), (5000, 75.0), (64, 0.0), (200000, 0.0)])
+def test_one_read_moment_kernel_against_the_super_blocks(oa, p, n, mean, monkeypatch):
+    """225 <= p <= 256 (config 5): gram_wd.hip -- one workgroup of eight waves per row chunk, X read once -- against gram_sb_kernel's three
+    super-blocks per chunk (OEM_NO_GRAM_WD=1) and numpy: same partial layout, same reduction; the two differ in summation order only."""
+    import torch
+    from oem_amd import _lib as L
+    from tests.checker_backend import shift_in_effect
+    x, y = _data(n, p, 900 + p, mean=mean)
+    ld = n + (n & 1)
+    xd = torch.zeros((p, ld), dtype=torch.float64, device="cuda")
+    xd[:, :n] = torch.as_tensor(np.ascontiguousarray(x.T))
+    yd = torch.as_tensor(y, device="cuda")
+    ctx = oa.context()
+    got = {}
+    for form in ("wd", "sb"):
+        if form == "sb":
+            monkeypatch.setenv("OEM_NO_GRAM_WD", "1")
+        L.sync_switches()
+        sums = torch.zeros(L.sums_len(p), dtype=torch.float64, device="cuda")
+        M = torch.zeros((p + 2, p + 2), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        L.check(L.lib().oemgpu_shift_sums_dev(ctx, xd.data_ptr(), n, ld, p, yd.data_ptr(), sums.data_ptr()))
+        L.check(L.lib().oemgpu_moments_dev(ctx, xd.data_ptr(), n, ld, p, yd.data_ptr(), sums.data_ptr(), M.data_ptr()))
+        L.check(L.lib().oemgpu_synchronize(ctx))
+        got[form] = M.cpu().numpy()
+        c = shift_in_effect(sums.cpu().numpy(), p)
+    z = np.column_stack([x - c[:p], y - c[p], np.ones(n)])
+    want = z.T @ z
+    scale = np.sqrt(np.outer(np.diag(want), np.diag(want))) + 1e-300
+    assert np.abs((got["wd"] - want) / scale).max() < 1e-11 and np.abs((got["sb"] - want) / scale).max() < 1e-11
+    assert np.abs((got["wd"] - got["sb"]) / scale).max() < 1e-12
+    assert got["wd"][p + 1, p + 1] == n
+    if n >= 20000:
+        assert not np.array_equal(got["wd"], got["sb"])              # (two different kernels did run)
 
 
 def test_xtx_matches_dense_and_oracle(oa, doc_kats):
