@@ -3,7 +3,7 @@
 // gram_sb_kernel covers 16 tile columns with three workgroups per row chunk (two diagonal super-blocks of 8 x 8 tiles and the
 // off-diagonal one between them), each streaming the chunk's rows by itself: 32 fragment reads per 8-row slab for 16 distinct
 // fragments -- the counters show 2.0 x the algorithmic HBM bytes at p = 256 (profiles/r5_c5_pmc_gram_sb.json), and the same MFMA work
-// with the traffic taken away runs 15 % faster (tools/x_samerows.sh, profiles/r5_gram_one_read.txt).  Here ONE workgroup of EIGHT
+// with the traffic taken away runs 15 % faster (tools/gram_samerows_ab.sh, profiles/r5_gram_one_read.txt).  Here ONE workgroup of EIGHT
 // waves (two per SIMD, 256 registers each) owns all 136 tiles of the 16 x 16-tile triangle over the rows of its chunk: the 16
 // fragments of a slab are DMA'd once into the workgroup's LDS ring (two per wave; wave 0 also brings y), every wave copies the eight
 // fragments it multiplies to registers one slab ahead and issues its 17 tiles = 34 MFMAs per slab -- 68 per SIMD, the same issue

@@ -378,8 +378,8 @@ def test_one_read_moment_kernel_against_the_super_blocks(oa, p, n, mean, monkeyp
     assert np.abs((got["wd"] - want) / scale).max() < 1e-11 and np.abs((got["sb"] - want) / scale).max() < 1e-11
     assert np.abs((got["wd"] - got["sb"]) / scale).max() < 1e-12
     assert got["wd"][p + 1, p + 1] == n
-    if n >= 20000:
-        assert not np.array_equal(got["wd"], got["sb"])              # (two different kernels did run)
+    if n == 20011:                                                   # (two different kernels did run: 157 row chunks against 88 here, so the roundings
+        assert not np.array_equal(got["wd"], got["sb"])              # differ -- at n = 200,000 both plans cut 241 chunks and the bits agree)
 
 
 def test_xtx_matches_dense_and_oracle(oa, doc_kats):
