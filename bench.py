@@ -374,7 +374,7 @@ def main():
                               "value": r["value"], "unit": "solves/s", "n_gpus": world, "steps": steps, "warmup": warm,
                               "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                               "dtype": "f64", "data": "synthetic", "config": {"workload": r["workload"], "rows_per_gpu": r["rows_per_gpu"]},
-                              "roofline": {"bound": "mfma", "kernel": "gram_sb_kernel (v_mfma_f64_16x16x4_f64)", "achieved": r["gram_TFLOPs"],
+                              "roofline": {"bound": "mfma", "kernel": "gram_wd_kernel (v_mfma_f64_16x16x4_f64; one eight-wave workgroup per row chunk, one read of X)", "achieved": r["gram_TFLOPs"],
                                            "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r["gram_frac_of_fp64_mfma_peak"],
                                            "traffic": None},
                               "rccl_ranks": world if coll_backend == "nccl" else None, "collective_backend": coll_backend,

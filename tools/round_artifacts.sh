@@ -29,8 +29,9 @@ if [ -z "$quick" ]; then
       rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/${tag}_${cfg}_pmc_$c -o ${tag} -- python3 tools/run_c3.py $cfg 2 > /dev/null 2> $o/${tag}_${cfg}_pmc_$c.err
     done
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $o/${tag}_${cfg}_pmc_mfma -o ${tag} -- python3 tools/run_c3.py $cfg 2 > /dev/null 2> $o/${tag}_${cfg}_pmc_mfma.err
-    python3 tools/pmc_summary.py gram_sb_kernel $o/${tag}_${cfg}_pmc_gram_sb_mfma.json "$(find $o/${tag}_${cfg}_pmc_mfma -name '*counter_collection.csv' | head -1)"
-    python3 tools/pmc_summary.py gram_sb_kernel $o/${tag}_${cfg}_pmc_gram_sb.json "$(find $o/${tag}_${cfg}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_${cfg}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
+    k=gram_sb; [ $cfg = c5 ] && k=gram_wd         # (config 5's p = 256 runs on the one-read kernel of gram_wd.hip since round 5)
+    python3 tools/pmc_summary.py ${k}_kernel $o/${tag}_${cfg}_pmc_${k}_mfma.json "$(find $o/${tag}_${cfg}_pmc_mfma -name '*counter_collection.csv' | head -1)"
+    python3 tools/pmc_summary.py ${k}_kernel $o/${tag}_${cfg}_pmc_${k}.json "$(find $o/${tag}_${cfg}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_${cfg}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
   done
   rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_c4_trace -o ${tag} -- python3 tools/run_c4.py > $o/${tag}_c4_trace.log 2>&1
   cp "$(find $o/${tag}_c4_trace -name '*kernel_stats.csv' | head -1)" $o/${tag}_c4_kernel_stats.csv
