@@ -142,7 +142,7 @@ __device__ __forceinline__ void gram_wd_body(const double *__restrict__ x, int64
     const unsigned yoff = (unsigned)(2 * q * 8);
     // the shift table behind the ring: entry [tile column][column within the tile]; this lane reads [.][i]
     double *cst = lds + (size_t)WD_NSLOT * WD_SLOT_B / 8;
-    if (XF) { if (tid < 256) cst[tid] = sums[(tid < p) ? tid : p - 1] * inv_cnt; }      // (visible after the first barrier below)
+    if (XF) { if (tid < 256) cst[tid] = sums[(tid < p) ? tid : p - 1] * inv_cnt; __syncthreads(); }      // (a chunk of fewer than 8 rows meets no other barrier before it reads the table)
     const double *cs = cst + i;
     double sx[2] = {0.0, 0.0}, sxy[2] = {0.0, 0.0}, sy = 0.0, syy = 0.0;
     v4d acc16 = {0.0, 0.0, 0.0, 0.0};

@@ -346,7 +346,7 @@ def test_shared_slab_moment_kernel(oa, p, n):
 
 
 @pytest.mark.parametrize("p", [225, 240, 256])
-@pytest.mark.parametrize("n,mean", [(20011, 0.3), (5000, 75.0), (64, 0.0), (200000, 0.0)])
+@pytest.mark.parametrize("n,mean", [(20011, 0.3), (5000, 75.0), (64, 0.0), (70, 80.0), (200000, 0.0)])
 def test_one_read_moment_kernel_against_the_super_blocks(oa, p, n, mean, monkeypatch):
     """225 <= p <= 256 (config 5): gram_wd.hip -- one workgroup of eight waves per row chunk, X read once -- against gram_sb_kernel's three
     super-blocks per chunk (OEM_NO_GRAM_WD=1) and numpy: same partial layout, same reduction; the two differ in summation order only."""
