@@ -34,7 +34,7 @@ def audit_gram_isa(asm_text):
     file and never spills in those kernels: check both in the emitted ISA."""
     problems = []
     found = 0
-    for m in re.finditer(r"^(_ZN6oemgpu1[4567]gram_(?:tri|blk|ring|sb|wd)_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end", asm_text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN6oemgpu1[4567]gram_(?:tri|blk|ring|sb|wd3?)_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end", asm_text, re.S | re.M):
         name, body = m.group(1), m.group(2)
         found += 1
         in_asm = False

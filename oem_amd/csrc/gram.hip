@@ -846,7 +846,8 @@ static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
         pl.n8 = n8; pl.n6 = n6; pl.n4 = n4;
         // 15 or 16 tile columns (225 <= p <= 256: config 5): ONE workgroup of eight waves per row chunk multiplies the whole triangle
         // from one read of X (gram_wd.hip) instead of three super-blocks that each stream the rows
-        pl.wd = (pl.ntc == 15 || pl.ntc == 16) && !sw().OEM_NO_GRAM_WD.set;
+        // (11 or 12 tile columns, 161 <= p <= 192: the same with groups of three tile columns -- 78 tiles, nine or ten per wave)
+        pl.wd = sw().OEM_NO_GRAM_WD.set ? 0 : ((pl.ntc == 15 || pl.ntc == 16) ? 4 : ((pl.ntc == 11 || pl.ntc == 12) ? 3 : 0));
         const int nsb = n8 + n6 + n4, nsblk = pl.wd ? 1 : nsb * (nsb + 1) / 2;
         // 1-12 rounds of one workgroup per CU: the count whose launch ends soonest when the workgroups are handed out longest
         // first (gram_sb_kernel) -- a greedy replay with the measured costs (tools/gram_diag.py: 2,136 cycles per 8-row slab off
@@ -871,7 +872,7 @@ static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
             double end = 0.0;
             for (int kind = 0; kind < SB_KINDS; ++kind) {
                 // (gram_wd.hip: one kind of workgroup, 68 MFMAs per SIMD and slab -- 4,352 cycles of issue, ~4,500 measured)
-                const double d = slabs * (pl.wd ? 4500.0 : per_slab[kind]) + 25000.0;
+                const double d = slabs * (pl.wd == 4 ? 4500.0 : (pl.wd == 3 ? 2700.0 : per_slab[kind])) + 25000.0;
                 for (int64_t m = pl.wd ? (kind == 0 ? cc : 0) : cc * cnt[kind]; m > 0;) {
                     const double t = grp.front().first + d;
                     const int64_t take = grp.front().second < m ? grp.front().second : m;

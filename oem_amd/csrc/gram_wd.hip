@@ -26,33 +26,33 @@ namespace oemgpu {
 
 namespace {
 
-constexpr int WD_NSLOT = 9;                       // ring depth (17 KiB slots: 16 fragments + y)
-constexpr int WD_SLOT_B = 17 * 1024;
-constexpr int WD_NT = 17;                         // tiles per wave
+constexpr int WD_NSLOT = 9;                       // ring depth (slots of 4 B + 1 KiB: the fragments of a slab + y)
 
-// ---- the deal (compile-time): fragment f of wave W's registers is tile column wd_frag(W, f); tile t of wave W is (row fragment,
-// column fragment) in REGISTER indices
-constexpr int wd_frag(int W, int f)
+// ---- the deal (compile-time), for 4 x 4 groups of B tile columns (B = 4: 16 tile columns, 136 tiles, 17 per wave; B = 3: 12 tile
+// columns, 78 tiles, 9 / 10 per wave).  Fragment f of wave W's registers is tile column wd_frag(W, f); tile t of wave W is (row
+// fragment, column fragment) in REGISTER indices.
+template <int B> constexpr int wd_frag(int W, int f)
 {
-    constexpr int rows[8] = {0, 8, 4, 8, 12, 8, 12, 12}, cols[8] = {4, 12, 0, 0, 0, 4, 4, 8};
-    return f < 4 ? rows[W] + f : cols[W] + (f - 4);                 // registers 0-3: the block's tile rows, 4-7: its tile columns
+    constexpr int rows[8] = {0, 2, 1, 2, 3, 2, 3, 3}, cols[8] = {1, 3, 0, 0, 0, 1, 1, 2};      // in groups of B tile columns
+    return f < B ? B * rows[W] + f : B * cols[W] + (f - B);         // registers 0 .. B-1: the block's tile rows, B .. 2B-1: its tile columns
 }
+template <int B> constexpr int wd_ntiles(int W) { return W < 2 ? B * (B + 1) - 3 : B * B + 1; }
 struct WdTile { int a, b; };                                        // register indices: tile (wd_frag(W, a), wd_frag(W, b)), a's column >= b's
-constexpr WdTile wd_tile(int W, int t)
+template <int B> constexpr WdTile wd_tile(int W, int t)
 {
     if (W >= 2) {
-        if (t < 16) return WdTile{t / 4, 4 + t % 4};               // the off-diagonal block
-        // the diagonal tile taken over from waves 0 / 1: tile columns 0, 1, 2 (waves 2, 3, 4), 8 (wave 5), 12 (wave 6), 9 (wave 7)
-        constexpr int reg[8] = {0, 0, 4, 5, 6, 0, 0, 5};            // W = 2: column 0 = register 4; 3: column 1 = 5; 4: column 2 = 6; 5: column 8 = 0; 6: column 12 = 0; 7: column 9 = 5
+        if (t < B * B) return WdTile{t / B, B + t % B};            // the off-diagonal block
+        // the diagonal tile taken over from waves 0 / 1: tile columns 0, 1, 2 (waves 2, 3, 4), 2B (wave 5), 3B (wave 6), 2B + 1 (wave 7)
+        constexpr int reg[8] = {0, 0, B, B + 1, B + 2, 0, 0, B + 1};
         return WdTile{reg[W], reg[W]};
     }
-    // waves 0 / 1: the lower triangles of two 4 x 4 tile blocks (registers 0-3 and 4-7) without three diagonal tiles:
-    // wave 0 gives away (0,0) (1,1) (2,2); wave 1 (8,8) (9,9) (12,12) = registers (0,0) (1,1) (4,4)
+    // waves 0 / 1: the lower triangles of two B x B tile blocks (registers 0 .. B-1 and B .. 2B-1) without three diagonal tiles:
+    // wave 0 gives away (0,0) (1,1) (2,2); wave 1 (2B,2B) (2B+1,2B+1) (3B,3B) = registers (0,0) (1,1) (B,B)
     int k = 0;
     for (int blk = 0; blk < 2; ++blk)
-        for (int I = 0; I < 4; ++I)
+        for (int I = 0; I < B; ++I)
             for (int J = 0; J <= I; ++J) {
-                const int ra = 4 * blk + I, rb = 4 * blk + J;
+                const int ra = B * blk + I, rb = B * blk + J;
                 const bool given = I == J && (W == 0 ? (blk == 0 && I < 3) : ((blk == 0 && I < 2) || (blk == 1 && I == 0)));
                 if (given) continue;
                 if (k == t) return WdTile{ra, rb};
@@ -60,13 +60,19 @@ constexpr WdTile wd_tile(int W, int t)
             }
     return WdTile{0, 0};
 }
-// the two REGISTER fragments whose X'y / column sums wave W carries (every tile column once over the eight waves)
-constexpr int wd_sum_reg(int W, int k)
+// the REGISTER fragments whose X'y / column sums wave W carries (every tile column once over the eight waves), -1: none
+template <int B> constexpr int wd_sum_reg(int W, int k)
 {
-    // tile columns: W0: 0,1  W1: 8,9  W2: 2,3  W3: 10,11  W4: 12,13  W5: 4,5  W6: 6,7  W7: 14,15
-    constexpr int reg[8][2] = {{0, 1}, {0, 1}, {6, 7}, {2, 3}, {0, 1}, {4, 5}, {6, 7}, {2, 3}};
+    if (B == 4) {      // tile columns: W0: 0,1  W1: 8,9  W2: 2,3  W3: 10,11  W4: 12,13  W5: 4,5  W6: 6,7  W7: 14,15
+        constexpr int reg[8][2] = {{0, 1}, {0, 1}, {6, 7}, {2, 3}, {0, 1}, {4, 5}, {6, 7}, {2, 3}};
+        return reg[W][k];
+    }
+    // B = 3, tile columns: W0: 0,1  W1: 6,7  W2: 2  W3: 8  W4: 9,10  W5: 3,4  W6: 5  W7: 11
+    constexpr int reg[8][2] = {{0, 1}, {0, 1}, {5, -1}, {2, -1}, {0, 1}, {3, 4}, {5, -1}, {2, -1}};
     return reg[W][k];
 }
+// DMA duty of wave W: fragments (tile columns) W and W + 8 where those exist
+template <int B> constexpr int wd_ndma(int W) { return W + 8 < 4 * B ? 2 : 1; }
 
 typedef double v4d __attribute__((ext_vector_type(4)));            // the 17th tile of a wave: eight VGPRs (with two waves per SIMD the
                                                                     // accumulator file ends at a127 = sixteen tiles)
@@ -77,16 +83,16 @@ __device__ __forceinline__ void wd_mfma_v(v4d &acc, double a, double b)
 
 // shift: the column means live in LDS (cs: [16 tile columns][16] doubles behind the ring) and are subtracted as a slab's fragments arrive
 // in registers -- eight constants per lane would not fit beside two slabs and a tile in 128 VGPRs
-template <int W, bool XF, bool MASKED, typename Hook = NoHook>
+template <int B, int W, bool XF, bool MASKED, typename Hook = NoHook>
 __device__ __forceinline__ void wd_consume(Slab<8> &s, v4d &acc16, const double *cs, double cy, double (&sx)[2], double (&sxy)[2],
                                            double &sy, double &syy, int64_t r, int64_t n, Hook &&hook = NoHook())
 {
     double m0 = 1.0, m1 = 1.0;
     if (MASKED) { m0 = (r < n) ? 1.0 : 0.0; m1 = (r + 1 < n) ? 1.0 : 0.0; }
     if (XF || MASKED) {
-        static_for<8>([&](auto F_) {
+        static_for<2 * B>([&](auto F_) {
             constexpr int f = decltype(F_)::value;
-            if (XF) { const double c = cs[wd_frag(W, f) * 16]; s.v[f].x -= c; s.v[f].y -= c; }
+            if (XF) { const double c = cs[wd_frag<B>(W, f) * 16]; s.v[f].x -= c; s.v[f].y -= c; }
             if (MASKED) { s.v[f].x *= m0; s.v[f].y *= m1; }
         });
     }
@@ -94,33 +100,36 @@ __device__ __forceinline__ void wd_consume(Slab<8> &s, v4d &acc16, const double 
     if (MASKED) { y0 *= m0; y1 *= m1; }
     static_for<2>([&](auto K_) {
         constexpr int k = decltype(K_)::value;
-        const v2d v = s.v[wd_sum_reg(W, k)];
-        sx[k] = (sx[k] + v.x) + v.y;
-        sxy[k] = fma(v.x, y0, sxy[k]);
-        sxy[k] = fma(v.y, y1, sxy[k]);
+        if constexpr (wd_sum_reg<B>(W, k) >= 0) {
+            const v2d v = s.v[wd_sum_reg<B>(W, k)];
+            sx[k] = (sx[k] + v.x) + v.y;
+            sxy[k] = fma(v.x, y0, sxy[k]);
+            sxy[k] = fma(v.y, y1, sxy[k]);
+        }
     });
     if (W == 0) { sy = (sy + y0) + y1; syy = fma(y0, y0, syy); syy = fma(y1, y1, syy); }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 3" ::: "memory");                          // VALU write -> MFMA read (hipcc pads nothing for asm)
     static_for<2>([&](auto E) {
         constexpr int e = decltype(E)::value;
-        static_for<WD_NT>([&](auto T_) {
+        static_for<wd_ntiles<B>(W)>([&](auto T_) {
             constexpr int t = decltype(T_)::value;
-            constexpr WdTile tl = wd_tile(W, t);
+            constexpr WdTile tl = wd_tile<B>(W, t);
             if constexpr (t < 16) AccTile<t>::mfma(s.v[tl.a][e], s.v[tl.b][e]);
             else wd_mfma_v(acc16, s.v[tl.a][e], s.v[tl.b][e]);
-            hook(std::integral_constant<int, e * WD_NT + t>{});
+            hook(std::integral_constant<int, e * wd_ntiles<B>(W) + t>{});
         });
     });
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int W, bool XF>
+template <int B, int W, bool XF>
 __device__ __forceinline__ void gram_wd_body(const double *__restrict__ x, int64_t n, int64_t ld, int p, const double *__restrict__ y,
                                              const double *__restrict__ sums, int ntc, int64_t row_begin, int steps,
                                              double *__restrict__ tdst, double *__restrict__ vdst, double *lds)
 {
-    constexpr int NDMA = 2, DPW = NDMA + (W == 0 ? 1 : 0), NFETCH = 9, NMFMA = 2 * WD_NT, NACT = 1 + NFETCH + DPW, NSLOT = WD_NSLOT;
+    constexpr int NF = 2 * B, NT = wd_ntiles<B>(W), SLOT_B = (4 * B + 1) * 1024;
+    constexpr int NDMA = wd_ndma<B>(W), DPW = NDMA + (W == 0 ? 1 : 0), NFETCH = NF + 1, NMFMA = 2 * NT, NACT = 1 + NFETCH + DPW, NSLOT = WD_NSLOT;
     static_assert((NSLOT - 2) * DPW <= 63, "vmcnt field is 6 bits");
     static_assert(NACT <= NMFMA, "more hook actions than MFMAs");
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, q = lane >> 4;
@@ -141,12 +150,12 @@ __device__ __forceinline__ void gram_wd_body(const double *__restrict__ x, int64
     gptr_t ybase = yg + row_begin;
     const unsigned yoff = (unsigned)(2 * q * 8);
     // the shift table behind the ring: entry [tile column][column within the tile]; this lane reads [.][i]
-    double *cst = lds + (size_t)WD_NSLOT * WD_SLOT_B / 8;
-    if (XF) { if (tid < 256) cst[tid] = sums[(tid < p) ? tid : p - 1] * inv_cnt; __syncthreads(); }      // (a chunk of fewer than 8 rows meets no other barrier before it reads the table)
+    double *cst = lds + (size_t)WD_NSLOT * SLOT_B / 8;
+    if (XF) { if (tid < 64 * B) cst[tid] = sums[(tid < p) ? tid : p - 1] * inv_cnt; __syncthreads(); }      // (a chunk of fewer than 8 rows meets no other barrier before it reads the table)
     const double *cs = cst + i;
     double sx[2] = {0.0, 0.0}, sxy[2] = {0.0, 0.0}, sy = 0.0, syy = 0.0;
     v4d acc16 = {0.0, 0.0, 0.0, 0.0};
-    static_for<16>([&](auto T_) { AccTile<decltype(T_)::value>::zero(); });
+    static_for<(NT < 16 ? NT : 16)>([&](auto T_) { AccTile<decltype(T_)::value>::zero(); });
     asm volatile("s_nop 7" ::: "memory");
 
     const int64_t rows_chunk = (int64_t)steps * 64;
@@ -156,18 +165,18 @@ __device__ __forceinline__ void gram_wd_body(const double *__restrict__ x, int64
     const v2d *rd = reinterpret_cast<const v2d *>(lds) + lane;
     auto issue1 = [&](int slot, auto K_) {
         constexpr int k = decltype(K_)::value;
-        const unsigned dst = ring + (unsigned)slot * WD_SLOT_B;
+        const unsigned dst = ring + (unsigned)slot * SLOT_B;
         if constexpr (k < NDMA) { set_m0(dst + (unsigned)(W + 8 * k) * 1024); glds_s<0>(doff[k], dbase[k]); dbase[k] += 8; }
-        else { set_m0(dst + 16u * 1024u); glds_s<0>(yoff, ybase); ybase += 8; }
+        else { set_m0(dst + (unsigned)(4 * B) * 1024u); glds_s<0>(yoff, ybase); ybase += 8; }
     };
     auto issue = [&](int slot) { static_for<DPW>([&](auto K_) { issue1(slot, K_); }); };
     Slab<8> sa, sb;
     sa.y = v2d{0.0, 0.0}; sb.y = sa.y;
     auto fetch1 = [&](Slab<8> &s, int slot, auto J_) {
         constexpr int j = decltype(J_)::value;
-        const v2d *b = rd + (slot * WD_SLOT_B) / 16;
-        if constexpr (j < 8) s.v[j] = b[wd_frag(W, j) * 64];
-        else s.y = b[16 * 64];
+        const v2d *b = rd + (slot * SLOT_B) / 16;
+        if constexpr (j < NF) s.v[j] = b[wd_frag<B>(W, j) * 64];
+        else s.y = b[4 * B * 64];
     };
     auto fetch = [&](Slab<8> &s, int slot) { static_for<NFETCH>([&](auto J_) { fetch1(s, slot, J_); }); };
     auto next = [](int v) { return v + 1 == NSLOT ? 0 : v + 1; };
@@ -183,7 +192,7 @@ __device__ __forceinline__ void gram_wd_body(const double *__restrict__ x, int64
     int k = 0;
     auto steady = [&](Slab<8> &use, Slab<8> &nxt) {
         const int rs = rslot, is = islot;
-        wd_consume<W, XF, false>(use, acc16, cs, cy, sx, sxy, sy, syy, 0, n, [&](auto M_) {
+        wd_consume<B, W, XF, false>(use, acc16, cs, cy, sx, sxy, sy, syy, 0, n, [&](auto M_) {
             constexpr int m = decltype(M_)::value;
             if constexpr (m == 0) { wait_vm<(NSLOT - 4) * DPW>(); __syncthreads(); }
             else if constexpr (m <= NFETCH) fetch1(nxt, rs, std::integral_constant<int, m - 1>{});
@@ -203,7 +212,7 @@ __device__ __forceinline__ void gram_wd_body(const double *__restrict__ x, int64
         __syncthreads();
         if (k + 1 < ns) { fetch(nxt, rslot); rslot = next(rslot); }
         if (issued < ns) { issue(islot); islot = next(islot); ++issued; }
-        wd_consume<W, XF, false>(use, acc16, cs, cy, sx, sxy, sy, syy, 0, n);
+        wd_consume<B, W, XF, false>(use, acc16, cs, cy, sx, sxy, sy, syy, 0, n);
         ++k;
     };
     while (k < ns) {
@@ -217,12 +226,12 @@ __device__ __forceinline__ void gram_wd_body(const double *__restrict__ x, int64
         const int64_t r0 = r < n ? r : n - 1, r1 = r + 1 < n ? r + 1 : n - 1;
         Slab<8> t;
 #pragma unroll
-        for (int f = 0; f < 8; ++f) {
-            const gptr_t pf = xg + (size_t)tile_col(wd_frag(W, f)) * ld;
+        for (int f = 0; f < NF; ++f) {
+            const gptr_t pf = xg + (size_t)tile_col(wd_frag<B>(W, f)) * ld;
             t.v[f].x = pf[r0]; t.v[f].y = pf[r1];
         }
         t.y.x = yg[r0]; t.y.y = yg[r1];
-        wd_consume<W, XF, true>(t, acc16, cs, cy, sx, sxy, sy, syy, r, n);
+        wd_consume<B, W, XF, true>(t, acc16, cs, cy, sx, sxy, sy, syy, r, n);
     }
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     // ---- results: tiles are wave-private -> straight to the partial buffer; the vector sums of this wave's two tile columns
@@ -235,17 +244,20 @@ __device__ __forceinline__ void gram_wd_body(const double *__restrict__ x, int64
     syy += shfl_xor_d(syy, 16); syy += shfl_xor_d(syy, 32);
     if (q == 0) {
         static_for<2>([&](auto K_) {
-            constexpr int k2 = decltype(K_)::value, T = wd_frag(W, wd_sum_reg(W, k2));
-            if (T < ntc) { vdst[16 * T + i] = sx[k2]; vdst[16 * ntc + 16 * T + i] = sxy[k2]; }
+            constexpr int k2 = decltype(K_)::value;
+            if constexpr (wd_sum_reg<B>(W, k2) >= 0) {
+                constexpr int T = wd_frag<B>(W, wd_sum_reg<B>(W, k2));
+                if (T < ntc) { vdst[16 * T + i] = sx[k2]; vdst[16 * ntc + 16 * T + i] = sxy[k2]; }
+            }
         });
         if (W == 0 && i == 0) {
             vdst[32 * ntc] = sy; vdst[32 * ntc + 1] = syy; vdst[32 * ntc + 2] = (double)rows; vdst[32 * ntc + 3] = 0.0;
         }
     }
-    static_for<WD_NT>([&](auto T_) {
+    static_for<NT>([&](auto T_) {
         constexpr int t = decltype(T_)::value;
-        constexpr WdTile tl = wd_tile(W, t);
-        constexpr int gi = wd_frag(W, tl.a), gj = wd_frag(W, tl.b);
+        constexpr WdTile tl = wd_tile<B>(W, t);
+        constexpr int gi = wd_frag<B>(W, tl.a), gj = wd_frag<B>(W, tl.b);
         static_assert(gi >= gj, "a tile of the lower triangle");
         if (gi < ntc && gj < ntc) {
             double *dst = tdst + (size_t)(gi * (gi + 1) / 2 + gj) * 256;
@@ -257,9 +269,9 @@ __device__ __forceinline__ void gram_wd_body(const double *__restrict__ x, int64
 
 }  // namespace
 
-__global__ __launch_bounds__(512) void gram_wd_kernel(const double *__restrict__ x, const double *__restrict__ y,
-                                                       const double *__restrict__ sums, double *__restrict__ tpart,
-                                                       double *__restrict__ vpart, GramDims a)
+template <int B>
+__device__ __forceinline__ void gram_wd_kernel_body(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ sums,
+                                                    double *__restrict__ tpart, double *__restrict__ vpart, const GramDims &a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int chunk = blockIdx.x;
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(512) void gram_wd_kernel(const double *__restrict__
     double *tdst = tpart + (size_t)chunk * a.ntile * 256;
     double *vdst = vpart + (size_t)chunk * (32 * a.ntc + 4);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#define OEM_WD(W, XF) gram_wd_body<W, XF>(x, a.n, a.ld, a.p, y, sums, a.ntc, row_begin, a.steps, tdst, vdst, lds)
+#define OEM_WD(W, XF) gram_wd_body<B, W, XF>(x, a.n, a.ld, a.p, y, sums, a.ntc, row_begin, a.steps, tdst, vdst, lds)
 #define OEM_WD_ALL(XF)                                                                                                   \
     do {                                                                                                                 \
         if (w == 0) OEM_WD(0, XF); else if (w == 1) OEM_WD(1, XF); else if (w == 2) OEM_WD(2, XF); else if (w == 3) OEM_WD(3, XF);   \
@@ -278,11 +290,28 @@ __global__ __launch_bounds__(512) void gram_wd_kernel(const double *__restrict__
 #undef OEM_WD
 }
 
+__global__ __launch_bounds__(512) void gram_wd_kernel(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ sums,
+                                                       double *__restrict__ tpart, double *__restrict__ vpart, GramDims a)
+{
+    gram_wd_kernel_body<4>(x, y, sums, tpart, vpart, a);             // 15-16 tile columns
+}
+__global__ __launch_bounds__(512) void gram_wd3_kernel(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ sums,
+                                                        double *__restrict__ tpart, double *__restrict__ vpart, GramDims a)
+{
+    gram_wd_kernel_body<3>(x, y, sums, tpart, vpart, a);             // 11-12 tile columns
+}
+
 int launch_gram_wd(hipStream_t s, const GramPlan &pl, const double *x, const double *y, const double *sums, double *tpart, double *vpart, const GramDims &a)
 {
-    const size_t shb = (size_t)WD_NSLOT * WD_SLOT_B + 256 * sizeof(double);      // the ring + the shift table
-    if (lds_limit_once(reinterpret_cast<const void *>(&gram_wd_kernel), shb)) return OEMGPU_ERR_HIP;
-    hipLaunchKernelGGL(gram_wd_kernel, dim3(pl.nchunk), dim3(512), shb, s, x, y, sums, tpart, vpart, a);
+    const int B = pl.wd;
+    const size_t shb = (size_t)WD_NSLOT * (4 * B + 1) * 1024 + (size_t)64 * B * sizeof(double);      // the ring + the shift table
+    if (B == 4) {
+        if (lds_limit_once(reinterpret_cast<const void *>(&gram_wd_kernel), shb)) return OEMGPU_ERR_HIP;
+        hipLaunchKernelGGL(gram_wd_kernel, dim3(pl.nchunk), dim3(512), shb, s, x, y, sums, tpart, vpart, a);
+    } else if (B == 3) {
+        if (lds_limit_once(reinterpret_cast<const void *>(&gram_wd3_kernel), shb)) return OEMGPU_ERR_HIP;
+        hipLaunchKernelGGL(gram_wd3_kernel, dim3(pl.nchunk), dim3(512), shb, s, x, y, sums, tpart, vpart, a);
+    } else { set_error("internal: gram_wd block size %d", B); return OEMGPU_ERR_INTERNAL; }
     OEM_HIP(hipGetLastError());
     return 0;
 }

@@ -203,7 +203,7 @@ def test_moment_plan_deals_the_tile_columns_into_eights_sixes_and_a_four():
                 assert (n8, n6, n4) == (0, 0, 0) and ntc == (p + 2 + 15) // 16
                 continue
             if (n8, n6, n4) == (-1, -1, -1):                                     # gram_wd.hip: the whole triangle of 15-16 tile columns in one workgroup
-                assert ntc in (15, 16) and cost == 136
+                assert (ntc in (15, 16) and cost == 136) or (ntc in (11, 12) and cost == 80)     # (B = 3: eight waves x ten tile slots)
                 worst[p] = real / cost
                 assert nchunk % 8 == 0
                 continue
