@@ -1,4 +1,4 @@
-// gram_wd.hip -- the moment kernel for 240 < p <= 256 (config 5's p = 256): ONE read of X.
+// gram_wd.hip -- the moment kernel for 225 <= p <= 256 (config 5's p = 256) and 161 <= p <= 192: ONE read of X.
 //
 // gram_sb_kernel covers 16 tile columns with three workgroups per row chunk (two diagonal super-blocks of 8 x 8 tiles and the
 // off-diagonal one between them), each streaming the chunk's rows by itself: 32 fragment reads per 8-row slab for 16 distinct
