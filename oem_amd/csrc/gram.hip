@@ -820,6 +820,9 @@ void gram_sb_deal(int ntc, int *n8_out, int *n6_out, int *n4_out)
 }
 
 constexpr int GRAM_MAX_ROUNDS = 12;
+// (gram_wd.hip's workgroups are all alike: more than one round per CU never won -- profiles/r5_gram_one_read.txt -- and the scratch that
+// holds 'any smaller row count' is sized by the largest count the search may return)
+static inline int gram_max_rounds(const GramPlan &pl) { return pl.wd ? 2 : GRAM_MAX_ROUNDS; }
 
 static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
 {
@@ -860,7 +863,7 @@ static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
         const double per_slab[SB_KINDS] = {2136.0, 1680.0, 1284.0, 1160.0, 890.0, 890.0, 520.0};      // (the kernel's launch order)
         int64_t c = 0;
         double best = 0.0;
-        for (int rounds = 1; rounds <= GRAM_MAX_ROUNDS; ++rounds) {
+        for (int rounds = 1; rounds <= gram_max_rounds(pl); ++rounds) {
             int64_t cc = ((int64_t)num_cu * rounds) / nsblk;
             if (cc > nsteps) cc = nsteps;
             if (cc < 1) cc = 1;
@@ -919,7 +922,7 @@ GramPlan gram_plan_bound(int64_t nmax, int p, int num_cu)
     if (!pl.tri) {
         const int nsb = pl.n8 + pl.n6 + pl.n4, nsblk = pl.wd ? 1 : nsb * (nsb + 1) / 2;
         const int64_t nsteps = (nmax + 63) / 64;
-        int64_t cc = ((int64_t)num_cu * GRAM_MAX_ROUNDS) / nsblk;
+        int64_t cc = ((int64_t)num_cu * gram_max_rounds(pl)) / nsblk;
         if (cc > nsteps) cc = nsteps;
         if (cc < 1) cc = 1;
         cc = (cc + 7) / 8 * 8;
