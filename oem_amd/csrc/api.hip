@@ -1043,7 +1043,7 @@ int oemgpu_selftest_gram_plan(int64_t n, int32_t p, int32_t num_cu, int64_t *out
     out[0] = pl.ntc; out[1] = n8; out[2] = n6; out[3] = pl.nchunk; out[4] = pl.steps;
     out[5] = 64 * (n8 * (n8 - 1) / 2) + 48 * n8 * n6 + 32 * n8 * n4 + 24 * n6 * n4 + 36 * n8 + 24 * n6 + 12 * n4;
     out[7] = n4;
-    if (pl.wd) { out[1] = out[2] = out[7] = -1; out[5] = pl.wd == 4 ? 136 : 80; }      // (one eight-wave workgroup per row chunk, the triangle of 16 tile columns: gram_wd.hip)
+    if (pl.wd) { out[1] = out[2] = out[7] = -1; out[5] = pl.wd == 4 ? 136 * pl.wd_units + 128 * pl.wd_units * (pl.wd_units - 1) : 80; }      // (one eight-wave workgroup per row chunk, the triangle of 16 tile columns: gram_wd.hip)
     out[6] = (int64_t)pl.ntc * (pl.ntc + 1) / 2;
     // the scratch sized for "any row count up to n" holds the plans of smaller row counts (folds, row tiles)
     const GramPlan bd = gram_plan_bound(n, p, num_cu);

@@ -33,6 +33,7 @@ struct GramPlan {
     int ntile;      // ntc*(ntc+1)/2
     int tri;        // 1: one wave holds the whole lower triangle (ntc <= 7); 0: 4x4 tile blocks
     int nblk;       // tile blocks per row chunk (1 when tri)
+    int wd_units;   // gram_wd.hip: diagonal units of 16 tile columns per row chunk (1: p <= 256; k: 16 k tile columns, with k (k - 1) off-diagonal 8 x 16-tile blocks)
     int wd;         // 4 / 3: 15-16 / 11-12 tile columns, one eight-wave workgroup per row chunk (gram_wd.hip, groups of 4 / 3 tile columns) instead of the super-blocks below; 0: those
     int n8, n6, n4; // shared-slab kernel: super-block rows of 8, 6 and (at most one) 4 tile columns (gram_sb_deal; 0 when tri)
     int nchunk;     // row chunks (workgroups along rows)

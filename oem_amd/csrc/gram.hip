@@ -822,14 +822,14 @@ void gram_sb_deal(int ntc, int *n8_out, int *n6_out, int *n4_out)
 constexpr int GRAM_MAX_ROUNDS = 12;
 // (gram_wd.hip's workgroups are all alike: more than one round per CU never won -- profiles/r5_gram_one_read.txt -- and the scratch that
 // holds 'any smaller row count' is sized by the largest count the search may return)
-static inline int gram_max_rounds(const GramPlan &pl) { return pl.wd ? 2 : GRAM_MAX_ROUNDS; }
+static inline int gram_max_rounds(const GramPlan &pl) { return (pl.wd && pl.wd_units == 1) ? 2 : GRAM_MAX_ROUNDS; }
 
 static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
 {
     GramPlan pl;
     pl.p = p;
     pl.tri = (p + 2 + 15) / 16 <= 7;                     // Z = [X | y | 1] fits one wave's triangle
-    pl.n8 = pl.n6 = pl.n4 = 0; pl.wd = 0;
+    pl.n8 = pl.n6 = pl.n4 = 0; pl.wd = 0; pl.wd_units = 0;
     pl.ntc = pl.tri ? (p + 2 + 15) / 16 : (p + 15) / 16;
     pl.ntile = pl.ntc * (pl.ntc + 1) / 2;
     const int64_t nsteps = (n + 63) / 64;
@@ -851,7 +851,12 @@ static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
         // from one read of X (gram_wd.hip) instead of three super-blocks that each stream the rows
         // (11 or 12 tile columns, 161 <= p <= 192: the same with groups of three tile columns -- 78 tiles, nine or ten per wave)
         pl.wd = sw().OEM_NO_GRAM_WD.set ? 0 : ((pl.ntc == 15 || pl.ntc == 16) ? 4 : ((pl.ntc == 11 || pl.ntc == 12) ? 3 : 0));
-        const int nsb = n8 + n6 + n4, nsblk = pl.wd ? 1 : nsb * (nsb + 1) / 2;
+        pl.wd_units = pl.wd ? 1 : 0;
+        // 16 k tile columns (k >= 2: p = 512, 1,024, ... and the fifteen columns below each): k such diagonal units and, between every
+        // two of them, two off-diagonal blocks of 8 x 16 tiles on eight waves -- one launch, 80 fragment reads per slab at p = 512
+        // where the super-blocks make 128
+        if (!sw().OEM_NO_GRAM_WD.set && !sw().OEM_NO_GRAM_UNITS.set && pl.ntc >= 31 && (pl.ntc % 16 == 0 || pl.ntc % 16 == 15)) { pl.wd = 4; pl.wd_units = (pl.ntc + 15) / 16; }
+        const int nsb = n8 + n6 + n4, nsblk = pl.wd ? pl.wd_units * pl.wd_units : nsb * (nsb + 1) / 2;
         // 1-12 rounds of one workgroup per CU: the count whose launch ends soonest when the workgroups are handed out longest
         // first (gram_sb_kernel) -- a greedy replay with the measured costs (tools/gram_diag.py: 2,136 cycles per 8-row slab off
         // the diagonal at 32 MFMAs per wave, 1,284 on it at 18: ~66 per MFMA + ~100; ~25 k per workgroup: ring fill, 72-128 KB of
@@ -875,8 +880,9 @@ static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
             double end = 0.0;
             for (int kind = 0; kind < SB_KINDS; ++kind) {
                 // (gram_wd.hip: one kind of workgroup, 68 MFMAs per SIMD and slab -- 4,352 cycles of issue, ~4,500 measured)
-                const double d = slabs * (pl.wd == 4 ? 4500.0 : (pl.wd == 3 ? 2700.0 : per_slab[kind])) + 25000.0;
-                for (int64_t m = pl.wd ? (kind == 0 ? cc : 0) : cc * cnt[kind]; m > 0;) {
+                // (units: kind 0 = the diagonal units, kind 1 = the off-diagonal 8 x 16-tile blocks, 64 MFMAs per SIMD and slab)
+                const double d = slabs * (pl.wd == 4 ? (kind == 0 ? 4500.0 : 4250.0) : (pl.wd == 3 ? 2700.0 : per_slab[kind])) + 25000.0;
+                for (int64_t m = pl.wd ? (kind == 0 ? cc * pl.wd_units : (kind == 1 ? cc * pl.wd_units * (pl.wd_units - 1) : 0)) : cc * cnt[kind]; m > 0;) {
                     const double t = grp.front().first + d;
                     const int64_t take = grp.front().second < m ? grp.front().second : m;
                     if ((grp.front().second -= take) == 0) grp.erase(grp.begin());
@@ -920,7 +926,7 @@ GramPlan gram_plan_bound(int64_t nmax, int p, int num_cu)
 {
     GramPlan pl = gram_plan(nmax, p, num_cu);
     if (!pl.tri) {
-        const int nsb = pl.n8 + pl.n6 + pl.n4, nsblk = pl.wd ? 1 : nsb * (nsb + 1) / 2;
+        const int nsb = pl.n8 + pl.n6 + pl.n4, nsblk = pl.wd ? pl.wd_units * pl.wd_units : nsb * (nsb + 1) / 2;
         const int64_t nsteps = (nmax + 63) / 64;
         int64_t cc = ((int64_t)num_cu * gram_max_rounds(pl)) / nsblk;
         if (cc > nsteps) cc = nsteps;

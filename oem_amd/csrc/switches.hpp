@@ -22,7 +22,7 @@ namespace oemgpu {
     X(OEM_WIDE) X(OEM_NO_WIDE) X(OEM_NO_WCOOP) X(OEM_WRES) X(OEM_NO_WRES) X(OEM_WSTREAM) X(OEM_NO_WSTREAM)        \
     X(OEM_WIDE_NO_GROUP_FUSED) X(OEM_WCOOP_ONE_SET) X(OEM_WCOOP_NO_GENERAL) X(OEM_WCOOP_NO_ALIGN) X(OEM_NO_PENALTY_SPLIT) \
     /* moment kernels, sparse x */                                                                                                   \
-    X(OEM_SPARSE_GRAM) X(OEM_SPARSE_TILE_ROWS) X(OEM_NO_GRAM_WD)             \
+    X(OEM_SPARSE_GRAM) X(OEM_SPARSE_TILE_ROWS) X(OEM_NO_GRAM_WD) X(OEM_NO_GRAM_UNITS)             \
     /* faults and checks */                                                                                                          \
     X(OEM_WCOOP_FAKE_TIMEOUT) X(OEM_POISON_OUT) X(OEMGPU_LANCZOS_CAP) X(OEM_NO_ONE_XCD) X(OEM_FAKE_XCD_MISMATCH)                                                                \
     /* the host-resident path */                                                                                                     \
