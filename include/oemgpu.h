@@ -326,8 +326,8 @@ int oemgpu_selftest_plan(int32_t p, int32_t q, int32_t semantics, int32_t interc
 
 /* Host-only self-check of the MOMENT plan (gram.hip: gram_plan; pure arithmetic, runs without a GPU) for n rows and p columns on
  * a device of num_cu CUs: out[0] = tile columns of 16, out[1] / out[2] / out[7] = super-block rows of eight / six / four tile columns
- * the shared-slab kernel deals them into (all 0: p + 2 <= 112, one wave holds the triangle; all -1: 11-12 or 15-16 tile columns, one eight-wave
- * workgroup per row chunk holds it), out[3] = row chunks, out[4] = 64-row
+ * the shared-slab kernel deals them into (all 0: p + 2 <= 112, one wave holds the triangle; all -1: 11-12, 15-16 or 16 k (- 1) tile columns: eight-wave
+ * workgroups hold whole units of the triangle, gram_wd.hip), out[3] = row chunks, out[4] = 64-row
  * steps per chunk, out[5] = the multiply time of that deal in tile units (an h1 x h2 off-diagonal super-block h1 h2, a diagonal
  * one 36 / 24 / 12), out[6] = real tiles of the lower triangle.  Also checks that the partial-sum scratch sized for "any row count up
  * to n" (the folds of xval.oem, the row tiles of a sparse x) holds the plans of smaller row counts: OEMGPU_ERR_INTERNAL if not. */

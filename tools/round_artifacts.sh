@@ -29,7 +29,7 @@ if [ -z "$quick" ]; then
       rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/${tag}_${cfg}_pmc_$c -o ${tag} -- python3 tools/run_c3.py $cfg 2 > /dev/null 2> $o/${tag}_${cfg}_pmc_$c.err
     done
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $o/${tag}_${cfg}_pmc_mfma -o ${tag} -- python3 tools/run_c3.py $cfg 2 > /dev/null 2> $o/${tag}_${cfg}_pmc_mfma.err
-    k=gram_sb; [ $cfg = c5 ] && k=gram_wd         # (config 5's p = 256 runs on the one-read kernel of gram_wd.hip since round 5)
+    k=gram_wd                                     # (p = 256 and p = 512 run on gram_wd.hip since round 5: one unit / two units + off-diagonal blocks)
     python3 tools/pmc_summary.py ${k}_kernel $o/${tag}_${cfg}_pmc_${k}_mfma.json "$(find $o/${tag}_${cfg}_pmc_mfma -name '*counter_collection.csv' | head -1)"
     python3 tools/pmc_summary.py ${k}_kernel $o/${tag}_${cfg}_pmc_${k}.json "$(find $o/${tag}_${cfg}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_${cfg}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
   done
