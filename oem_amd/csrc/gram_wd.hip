@@ -14,6 +14,10 @@
 //                 12-15 x 4-7, 12-15 x 8-11) plus ONE of those diagonal tiles -- a diagonal tile needs one fragment, which the
 //                 taker already holds.  17 tiles and 8 fragments per wave, 136 accumulator registers.
 //   X'y and the column sums ride on the VALU, two fragments per wave (every fragment once), y from the ring.
+// Groups of THREE tile columns (78 tiles, nine or ten per wave) serve 11-12 tile columns (161 <= p <= 192) the same way.
+// UNITS: for 16 k tile columns, k >= 2 (p = 512, 1,024, ...), one launch runs per row chunk k such diagonal units and, between every two of
+// them, two off-diagonal blocks of 8 x 16 tiles on eight waves (gram_od_body below) -- 80 fragment reads per slab at p = 512 where
+// gram_sb_kernel's ten super-blocks make 128.
 // Same partial layout as gram_sb_kernel (tiles by their global index, vector partials), same reduction behind it.
 // References: ref src/oem_dense.h:316-366 (XtX), src/oem_big.h:455-534 (row blocks); DESIGN.md section 3.1c.
 #include <cstdlib>
