@@ -287,10 +287,10 @@ def test_random_moment_kernels(oa, seed):
     from oem_amd import _lib as L
     from oem_amd.distributed import HipBackend
     rng = np.random.default_rng(7000 + seed)
-    # (129 ... 420: the deals of the shared-slab kernel's tile columns into rows of eight, a six and a four; 225 ... 256: the one-read
-    # eight-wave workgroup of gram_wd.hip)
+    # (129 ... 420: the deals of the shared-slab kernel's tile columns into rows of eight, a six and a four; 161 ... 192, 225 ... 256: the
+    # one-read eight-wave workgroup of gram_wd.hip; 481 ... 512, 750, 1000: its units of sixteen tile columns)
     p = int(rng.choice([2, 13, 14, 15, 29, 30, 31, 46, 62, 63, 78, 94, 100, 105, 106, 109, 110, 111, 112, 126, 129, 145, 161, 177, 200, 209, 225, 226, 240, 241, 254, 255,
-                        256, 257, 273, 300, 321, 340, 401, 420, 511, 512]))
+                        256, 257, 273, 300, 321, 340, 401, 420, 481, 497, 511, 512, 750, 1000]))
     n = int(rng.choice([1, 63, 64, 65, 127, 128, 129, 191, 1000, 4095, 4096, 4097, 16383, 20001, 65537]))
     pad = int(rng.choice([0, 0, 2, 6, 10]))
     odd = bool(rng.random() < 0.25)                               # leading dimension odd and base 8-byte aligned only
