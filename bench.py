@@ -711,6 +711,52 @@ def main():
             del xtx4
         except Exception as e:
             out["c4_ms"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not a.no_host:
+        # BASELINE configs 2 and 3 on the record (device-resident X, whole oem() calls): c2 = MCP and SCAD at n = 5,000, p = 200, 200 lambdas
+        # (one CU: the serial chain of the row-split kernel); c3 = grp.lasso at n = 1e6, p = 512, 64 groups of 8, 100 lambdas (moment kernel
+        # on eight-wave units + the cooperating engine on one XCD).  Parity of both at full size: tests/test_gpu_configs.py.  Never `value`.
+        try:
+            ctx3 = oem_amd.context()
+            rec = {}
+            g2 = torch.Generator(device=dev); g2.manual_seed(21)
+            x2 = torch.randn((200, 5000), generator=g2, device=dev, dtype=torch.float64)
+            b2 = torch.zeros(200, dtype=torch.float64, device=dev); b2[:20] = torch.rand(20, generator=g2, device=dev, dtype=torch.float64) - 0.5
+            y2 = (x2.t() @ b2 + torch.randn(5000, generator=g2, device=dev, dtype=torch.float64)).contiguous()
+            for pen, gam in (("mcp", 2.0), ("scad", 4.0)):
+                best, f2 = 1e9, None
+                for _ in range(3):
+                    t0 = time.perf_counter(); f2 = oem_amd.oem(x2.t(), y2, penalty=pen, gamma=gam, nlambda=200, tol=1e-7); torch.cuda.synchronize()
+                    best = min(best, time.perf_counter() - t0)
+                rec[pen] = {"ms": 1e3 * best, "iterations": int(np.sum(f2["niter"][0])), "engine": oem_amd.last_path_engine()[0]}
+            out["c2_ms"] = {"workload": "config 2: oem() MCP (gamma 2) / SCAD (gamma 4), n = 5000, p = 200, 200 lambdas, tol 1e-7", **rec}
+            del x2, y2
+            g3 = torch.Generator(device=dev); g3.manual_seed(22)
+            n3, p3 = 1_000_000, 512
+            x3 = torch.empty((p3, n3), device=dev, dtype=torch.float64)
+            for j0 in range(0, p3, 64):
+                x3[j0:j0 + 64].normal_(generator=g3)
+            b3 = torch.zeros(p3, dtype=torch.float64, device=dev); b3[:24] = torch.rand(24, generator=g3, device=dev, dtype=torch.float64) - 0.5
+            y3 = (x3.t() @ b3 + torch.randn(n3, generator=g3, device=dev, dtype=torch.float64)).contiguous()
+            L.check(L.lib().oemgpu_set_timing(ctx3, 1))
+            best, f3, tm3 = 1e9, None, None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                f3 = oem_amd.oem(x3.t(), y3, penalty="grp.lasso", groups=np.repeat(np.arange(1, 65), 8), nlambda=100, tol=1e-7)
+                torch.cuda.synchronize()
+                wall = time.perf_counter() - t0
+                if wall < best:
+                    best = wall
+                    tm3 = (C.c_double * L.NTIMERS)(); L.check(L.lib().oemgpu_last_timings(ctx3, tm3))
+            L.check(L.lib().oemgpu_set_timing(ctx3, 0))
+            fl3 = float(n3) * p3 * (p3 + 1.0) + 2.0 * n3 * p3
+            out["c3_ms"] = {"workload": "config 3: oem() grp.lasso, n = 1e6, p = 512, 64 groups of 8, 100 lambdas, tol 1e-7", "ms": 1e3 * best,
+                            "gram_kernel_ms": tm3[L.T_GRAMK], "gram_TFLOPs": fl3 / (tm3[L.T_GRAMK] * 1e-3) / 1e12,
+                            "gram_frac_of_fp64_mfma_peak": fl3 / (tm3[L.T_GRAMK] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                            "eigen_plus_path_ms": tm3[L.T_EIGPATH], "iterations": int(np.sum(f3["niter"][0])),
+                            "engine": oem_amd.last_path_engine()[0], "placement": oem_amd.api.last_placement()}
+            del x3, y3
+        except Exception as e:
+            out["c3_ms"] = {"error": repr(e)}
     if in_group:
         dist.destroy_process_group()
     # ---- N > 1: the in-library multi-GPU path (opts.ngpus = N: what an R caller gets), on rank 0 once the other ranks are gone
