@@ -822,7 +822,7 @@ void gram_sb_deal(int ntc, int *n8_out, int *n6_out, int *n4_out)
 constexpr int GRAM_MAX_ROUNDS = 12;
 // (gram_wd.hip's workgroups are all alike: more than one round per CU never won -- profiles/r5_gram_one_read.txt -- and the scratch that
 // holds 'any smaller row count' is sized by the largest count the search may return)
-static inline int gram_max_rounds(const GramPlan &pl) { return (pl.wd && pl.wd_units == 1) ? 2 : GRAM_MAX_ROUNDS; }
+static inline int gram_max_rounds(const GramPlan &pl) { return pl.wd ? (pl.wd_units == 1 ? 2 : 6) : GRAM_MAX_ROUNDS; }      // (units: two kinds of workgroup of almost one length)
 
 static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
 {
