@@ -161,7 +161,7 @@ oemgpu_ctx *ctx_acquire(int device)
 }
 
 // A cached context keeps its grow-only buffers between calls (no allocation in the steady state) -- up to a bound: the copy of the
-// host rows (c->xres: up to half of HBM for one large fit) and xval.oem's fold-ordered copy (c->aux) are freed on release when they
+// host rows (c->xres: up to half of HBM for one large fit) xval.oem's fold-ordered copy (c->aux) and the packed triangle of a q > 4096 Gram (c->pack_buf) are freed on release when they
 // exceed OEMGPU_CACHE_KEEP_BYTES (default: an eighth of the device's memory, 36 GB on MI355X), so that one large oem() / big.oem()
 // call does not starve torch or other users of the GPU for the rest of the session.  Streams, pinned staging lanes
 // and the workspace stay.  The caller has synchronised the context's stream.
@@ -170,10 +170,11 @@ void ctx_release(oemgpu_ctx *c)
     if (!c) return;
     size_t keep = c->hbm_total / 8;
     if (sw().OEMGPU_CACHE_KEEP_BYTES.set && sw().OEMGPU_CACHE_KEEP_BYTES.num >= 0) keep = (size_t)sw().OEMGPU_CACHE_KEEP_BYTES.num;
-    if (c->xres_bytes > keep || c->aux_bytes > keep) {
+    if (c->xres_bytes > keep || c->aux_bytes > keep || c->pack_bytes > keep) {
         (void)hipSetDevice(c->device);
         if (c->xres_bytes > keep) { (void)hipFree(c->xres); c->xres = nullptr; c->xres_bytes = 0; }
         if (c->aux_bytes > keep) { (void)hipFree(c->aux); c->aux = nullptr; c->aux_bytes = 0; }
+        if (c->pack_bytes > keep) { (void)hipFree(c->pack_buf); c->pack_buf = nullptr; c->pack_bytes = 0; }
     }
     std::lock_guard<std::mutex> lk(g_cache_mu);
     c->busy = false;
@@ -747,6 +748,10 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
             else {
                 PathArgs al = a;                                  // (after a timed-out cooperating launch: one instance, its penalties in turn)
                 al.pen_split = 0; al.pen_lo = 0; al.pen_hi = npen;
+                if (const size_t pkd = sympk_doubles(q)) {         // q > 4096: the products stream a packed copy of the lower triangle
+                    if (ctx_grow(c, &c->pack_buf, &c->pack_bytes, pkd * sizeof(double))) return OEMGPU_ERR_HIP;
+                    al.sympk = (double *)c->pack_buf;
+                }
                 rc = run_path_large(c->stream, al, (double *)c->pinned);
             }
             if (rc) return rc;
@@ -996,6 +1001,7 @@ void oemgpu_destroy(oemgpu_ctx *c)
     if (c->aux) (void)hipFree(c->aux);
     if (c->xres) (void)hipFree(c->xres);
     if (c->blob_buf) (void)hipFree(c->blob_buf);
+    if (c->pack_buf) (void)hipFree(c->pack_buf);
     if (c->abort_host) (void)hipHostFree(c->abort_host);
     if (c->acc) (void)hipFree(c->acc);
     for (oemgpu_lane &l : c->lanes) {

@@ -124,6 +124,9 @@ struct PathArgs {
                              //     timed out (a slot nobody else writes: the writer's stores cannot cover it up -- ADVICE r2)
     // workspace for the large-p engine
     double *work;
+    // q > 4096 on the launch-per-iteration Gram engine: sympk_doubles(q) doubles for the packed lower triangle of XX and the partial
+    // vectors of its products (path_large.hip: sympk_*; a buffer of the context, outside the workspace frame); null: the row-streaming product
+    double *sympk;
     // nbatch > 1 (p <= SMALL_P_MAX only): blockIdx.y selects one of nbatch independent problems that share everything above
     // except xx, xy, stats (element strides bs_xx, bs_xy, bs_stats), the outputs (byte stride bs_out) and work (bs_work)
     int nbatch;
@@ -196,6 +199,7 @@ bool path_small_takes_rows(const PathArgs &a);                    // will launch
 int lds_limit_once(const void *fn, size_t bytes);
 int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch);   // any p: multi-launch engine
 size_t path_large_work_doubles(int p, int nsteps);
+size_t sympk_doubles(int q);                                      // 0 for q <= 4096
 // 288 < p <= 1024: one persistent launch of cooperating workgroups (path_coop.hip)
 bool path_coop_eligible(int q, bool has_sinv, bool compute_loss, int ngroups, int nbatch);
 int path_coop_workgroups(int q);

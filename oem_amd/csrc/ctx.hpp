@@ -57,6 +57,8 @@ struct oemgpu_ctx {
     size_t xfer_host_bytes = 0;                   // are not peers (hoststream.hip: hand_over); grow-only
     char *blob_buf = nullptr;      // the parameter blob of run_paths (grow-only, outside the workspace: it survives between calls)
     size_t blob_bytes = 0;
+    char *pack_buf = nullptr;      // q > 4096: the packed lower triangle of XX and its products' partial vectors (PathArgs::sympk; grow-only,
+    size_t pack_bytes = 0;         // released with the cache's other big buffers when it exceeds OEMGPU_CACHE_KEEP_BYTES)
     const char *blob_dev = nullptr;   // where the last parameter blob was uploaded (run_paths skips an identical upload)
     size_t blob_len = 0;
     // A persistent engine that timed out (somebody else holds the CUs) is not tried again at once: the next `persistent_skip` calls

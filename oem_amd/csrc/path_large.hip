@@ -952,6 +952,207 @@ __global__ __launch_bounds__(256, OEM_SYM_MINWG) void oem_symfused_kernel(PathAr
 }
 
 // ------------------------------------------------------------------------------------------------
+// q > 4096: the lower triangle of XX PACKED once per call, then streamed once per product (sympk_*).
+// Beyond q = 4096 the matrix is neither register- nor Infinity-Cache-resident (q = 8,192: 537 MB): every product is an HBM stream, and
+// the row-streaming kernels above read all 8 q^2 bytes of a symmetric matrix.  Here the 128 x 128 blocks of the lower triangle
+// (diagonal blocks whole) are copied ONCE per call into a buffer of their own, block b = I (I + 1) / 2 + J behind block b - 1 and
+// inside a block in the order the product kernel's lanes read it -- wave w, load k, lane l at ((32 w + k) 64 + l) 16 bytes -- so a
+// product is ONE contiguous sweep of 4 q^2 + 512 q bytes: every wave instruction 1 KiB, every workgroup 128 KiB, no bounds logic
+// (the ragged last block row / column is zero-filled by the pack, which also takes rows that are only 8-byte aligned: q odd).
+// The arithmetic of a block is oem_symfused_kernel's (both products from one read, fixed summation order, partial vectors by slot);
+// the slots are summed by a kernel of its own -- a workgroup's head would re-read as many bytes of partials as its block has at
+// NBLK = 64 -- which for element-wise penalties is also the operator, the stop rule's "still moving" words and the replicated
+// lambda / penalty bookkeeping (sympk_head_kernel: oem_symfused_kernel's head, 64 coordinates per workgroup); everything else gets
+// g = XX beta from sympk_sum_kernel and runs path_update_kernel / lanczos_update_kernel unchanged.
+// bytes per product: 4 q^2 + 512 q read + 8 q NBLK written and read again (q = 8,192: 272.6 + 4.2 + 4.2 MB).
+// ------------------------------------------------------------------------------------------------
+static const int SPK_TILE = SYM_TB * SYM_TB;             // doubles of a packed block (128 KiB)
+__host__ __device__ static inline int spk_nblk(int q) { return (q + SYM_TB - 1) / SYM_TB; }
+__host__ __device__ static inline size_t spk_ntile(int q) { const size_t nb = (size_t)spk_nblk(q); return nb * (nb + 1) / 2; }
+
+// block (I, J), J <= I, of workgroup b: row-major over the lower triangle
+__device__ __forceinline__ void spk_block(int b, int &I, int &J)
+{
+    int i = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
+    while (i * (i + 1) / 2 > b) --i;
+    while ((i + 1) * (i + 2) / 2 <= b) ++i;
+    I = i; J = b - i * (i + 1) / 2;
+}
+
+__global__ __launch_bounds__(256) void sympk_pack_kernel(const double *__restrict__ xx, int q, double *__restrict__ pk)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, a = lane >> 3, bb = lane & 7;
+    int I, J;
+    spk_block(blockIdx.x, I, J);
+    double *tp = pk + (size_t)blockIdx.x * SPK_TILE + ((size_t)w * 32 * 64 + lane) * 2;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {                          // k = 16 half + 4 g + h: SymHalf::t[g][h] of that half
+        const int half = k >> 4, g = (k >> 2) & 3, h = k & 3;
+        const int r = SYM_TB * I + 32 * w + 8 * g + a, c = SYM_TB * J + 64 * half + 16 * h + 2 * bb;
+        v2d t = v2d{0.0, 0.0};
+        if (r < q) {
+            const double *row = xx + (size_t)r * q;          // (symmetric: row r is the contiguous column r)
+            if (c < q) t.x = row[c];
+            if (c + 1 < q) t.y = row[c + 1];
+        }
+        *reinterpret_cast<v2d *>(tp + (size_t)k * 128) = t;
+    }
+}
+
+__device__ __forceinline__ void spk_load(SymHalf &T, const double *__restrict__ tp, int half)
+{
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) T.t[g][h] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(tp + (size_t)(16 * half + 4 * g + h) * 128));
+}
+
+// one product with the packed triangle: P[slot][qpad] partial vectors (qpad = 128 NBLK), vec read as 0 beyond q
+__global__ __launch_bounds__(256, OEM_SYM_MINWG) void sympk_gemv_kernel(const double *__restrict__ pk, int q, int qpad, const double *__restrict__ vec,
+                                                                         double *__restrict__ P, const int *__restrict__ done)
+{
+    __shared__ __attribute__((aligned(16))) SymLds L;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, a = lane >> 3, bb = lane & 7;
+    int I, J;
+    spk_block(blockIdx.x, I, J);
+    const bool diag = I == J;
+    const int cm = tid < SYM_TB ? SYM_TB * I + tid : SYM_TB * J + (tid - SYM_TB);
+    const int dn = done ? *done : 0;
+    const double mine = cm < q ? vec[cm] : 0.0;
+    const double *tp = pk + (size_t)blockIdx.x * SPK_TILE + ((size_t)w * 32 * 64 + lane) * 2;
+    if (dn) return;
+    SymHalf T0, T1;
+    spk_load(T0, tp, 0);
+    spk_load(T1, tp, 1);
+    L.bsh[tid] = mine;
+    __syncthreads();
+    double bi[4], ds[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bi[g] = L.bsh[32 * w + 8 * g + a];
+    sym_half_products(T0, L, ds, bi, diag, w, a, bb, 0);
+    sym_half_products(T1, L, ds, bi, diag, w, a, bb, 1);
+    sym_combine(L, ds, P, qpad, I, J, diag, tid, w, a, bb);
+}
+
+// the NBLK slots of 64 coordinates per workgroup: wave w adds slots [w NBLK / 4, (w + 1) NBLK / 4) in slot order, the four wave sums
+// meet as (s0 + s1) + (s2 + s3) -- one fixed order, the same in the sum kernel and in the head
+__device__ __forceinline__ double spk_slot_sum(const double *__restrict__ P, int nblk, int qpad, int c, int w, double (*sh)[64], int l)
+{
+    const int k0 = (w * nblk) >> 2, k1 = ((w + 1) * nblk) >> 2;
+    const double *pc = P + (size_t)k0 * qpad + c;
+    double s = 0.0;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8, pc += (size_t)8 * qpad) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = pc[(size_t)u * qpad];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; k < k1; ++k, pc += qpad) s += *pc;
+    sh[w][l] = s;
+    __syncthreads();
+    return (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
+}
+
+__global__ __launch_bounds__(256) void sympk_sum_kernel(const double *__restrict__ P, int nblk, int q, int qpad, double *__restrict__ out,
+                                                         const int *__restrict__ done)
+{
+    __shared__ double sh[4][64];
+    if (done && *done) return;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.x * 64 + l;
+    const double s = spk_slot_sum(P, nblk, qpad, c, w, sh, l);
+    if (w == 0 && c < q) out[c] = s;
+}
+
+// Element-wise penalties: the slot sum IS the head of oem_symfused_kernel -- state, "still moving" words of the previous launch, the
+// replicated transition, the operator on the workgroup's 64 coordinates, beta_{t+1} into B[par ^ 1] (which the product kernel of
+// this iteration then reads), the workgroup's "still moving" word.  One (head, product) pair of launches per iteration.
+__global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__restrict__ S, double *__restrict__ B, const double *__restrict__ P,
+                                                          int *__restrict__ flags, int *__restrict__ fdone, int par, double d, int nblk, int qpad)
+{
+    __shared__ double sh[4][64];
+    const int q = A.p, nl = A.nl, tid = threadIdx.x, l = tid & 63, w = tid >> 6, cm = blockIdx.x * 64 + l;
+    const bool own = w == 0 && cm < q;
+    const SState st = S[par];
+    const double *__restrict__ bin = B + (size_t)par * qpad;
+    double *__restrict__ bout = B + (size_t)(par ^ 1) * qpad;
+    int fl[FMAXB / 256];
+#pragma unroll
+    for (int k = 0; k < FMAXB / 256; ++k) { const int t = tid + 256 * k; fl[k] = flags[par * FMAXB + (t < (int)gridDim.x ? t : 0)]; }
+    const double bo = own ? bin[cm] : 0.0, xyc = own ? A.xy[cm] : 0.0, pfc = own ? A.pf[cm] : 0.0;
+    if (st.done) {                                                  // the launch after the last one: make both copies agree
+        if (blockIdx.x == 0 && tid == 0) { S[par ^ 1].done = 1; *fdone = 1; }
+        return;
+    }
+    const double g = spk_slot_sum(P, nblk, qpad, cm, w, sh, l);     // (fresh: P is not there yet and g is not used)
+    int f = 0;
+#pragma unroll
+    for (int k = 0; k < FMAXB / 256; ++k) f |= (tid + 256 * k < (int)gridDim.x) ? fl[k] : 0;
+    const int any = __syncthreads_or(f);
+    int pp = st.pp, i = st.i, it = st.it, pen = st.pen;
+    double lam = st.lam;
+    bool fresh = st.fresh != 0, finalize = false, done_now = false, advanced = false;
+    size_t kfin = 0;
+    int niter_fin = 0;
+    if (!fresh) {
+        const bool conv = !any;
+        if (conv || it >= A.maxit) {
+            finalize = true; kfin = (size_t)pp * nl + i; niter_fin = conv ? it : A.maxit + 1;     // ref src/oem_base.h:94-109
+            const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
+            if (i + 1 < nlam) { i = i + 1; advanced = true; }
+            else if (pp + 1 < A.npen) { pp = pp + 1; i = 0; fresh = true; advanced = true; }
+            else done_now = true;
+            if (advanced) { pen = st.pen_next; lam = st.lam_next; }
+            it = 0;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        SState nx = st;
+        nx.pp = pp; nx.i = i; nx.it = it + 1; nx.done = done_now ? 1 : 0; nx.fresh = 0; nx.pen = pen; nx.lam = lam;
+        if (advanced) sym_successor(A, pp, i, pen, nx.pen_next, nx.lam_next);
+        S[par ^ 1] = nx;
+        if (finalize) { A.niter[kfin] = niter_fin; A.loss[kfin] = 1e99; }
+    }
+    if (finalize && own) A.beta[kfin * q + cm] = bo;
+    if (done_now) {
+        if (blockIdx.x == 0 && tid == 0) *fdone = 1;                // (the products behind this launch return at once)
+        return;
+    }
+    const PenK K = pen_consts(pen, lam / st.scaley, d, A.alpha, A.gamma, A.tau);
+    const double rD = 1.0 / K.D, gammad = K.gamma * K.D, dmg = K.D - 1.0 / K.gamma, rdmg = 1.0 / dmg;
+    const double gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0, rdsc = 1.0 / dsc, rd = 1.0 / d;
+    const double b0 = fresh ? 0.0 : bo;
+    const double u = (d * b0 - (fresh ? 0.0 : g)) + xyc;
+    const double tp = pfc * K.L;
+    double bn;
+    if (K.kind == K_SOFT) bn = cdiv(shrink(u, tp), K.D, rD);
+    else if (K.kind == K_MCP) {
+        const bool big = fabs(u) > gammad * tp;
+        bn = cdiv(big ? u : shrink(u, tp), big ? K.D : dmg, big ? rD : rdmg);
+    } else if (K.kind == K_SCAD) {
+        const double au = fabs(u);
+        const bool big = au > gammad * tp, mid = !big && au > (K.D + 1.0) * tp;
+        const double num = big ? u : (mid ? shrink(gm1 * u, K.gamma * tp) : shrink(u, tp));
+        bn = cdiv(num, mid ? dsc : K.D, mid ? rdsc : rD);
+    } else bn = cdiv(u, d, rd);
+    const double c = fabs(bn), qo = fabs(b0);
+    const bool cn = c > 1e-13, qn = qo > 1e-13;
+    const bool moving = own && ((cn != qn) || (cn && qn && fabs(bn - b0) > A.tol * qo));
+    if (own) bout[cm] = bn;
+    const int mv = __syncthreads_or(moving ? 1 : 0);
+    if (tid == 0) flags[(par ^ 1) * FMAXB + blockIdx.x] = mv;
+}
+
+size_t sympk_doubles(int q)
+{
+    if (q <= 4096) return 0;
+    const size_t nblk = (size_t)spk_nblk(q), qpad = nblk * SYM_TB;
+    // blocks | partial vectors P[NBLK][qpad] | B[2][qpad] | flags[2][FMAXB] ints | SState[2] | done word
+    return spk_ntile(q) * SPK_TILE + nblk * qpad + 2 * qpad + FMAXB + 16 + 8;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused iteration, replicated-update form (group penalties, accelerate, compute.loss, scale.factor; same q): what crosses
 // launches is u = d beta - XX beta + XY.  EVERY workgroup thresholds the whole u itself (q <= 4096 coordinates: a few
 // hundred nanoseconds, identical in every workgroup), applies the stop rule, takes the state transition at once, puts
@@ -1195,6 +1396,40 @@ static size_t update_lds(const PathArgs &a, double **uf)
     return sh;
 }
 
+// `enq(FB)` enqueues FB iterations (FB even: every batch starts at launch parity 0); they are captured ONCE into a hipGraph and replayed
+// until the device says done (eager launches are host-bound at ~3.5 us each); the host looks at one word per batch.
+template <typename F>
+static int replay_batches(hipStream_t s, F &&enq, const int *done_dev, int *hdone, long long max_it, const char *what)
+{
+    const int FB = 128;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        enq(FB);
+        if (hipStreamEndCapture(s, &graph) != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            graph = nullptr; exec = nullptr;
+            (void)hipGetLastError();
+        }
+    } else (void)hipGetLastError();
+    long long launched = 0;
+    int rc = 0;
+    for (;;) {
+        if (exec) { if (hipGraphLaunch(exec, s) != hipSuccess) { set_error("hipGraphLaunch failed"); rc = OEMGPU_ERR_HIP; break; } }
+        else enq(FB);
+        if (hipGetLastError() != hipSuccess) { set_error("%s: launch failed", what); rc = OEMGPU_ERR_HIP; break; }
+        launched += FB;
+        if (hipMemcpyAsync(hdone, done_dev, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { set_error("%s: device error", what); rc = OEMGPU_ERR_HIP; break; }
+        if (*hdone) break;
+        if (caller_interrupted()) { set_error("interrupted by the caller"); rc = OEMGPU_ERR_INTERRUPTED; break; }
+        if (launched > max_it) { set_error("%s did not finish within %lld iterations", what, max_it); rc = OEMGPU_ERR_INTERNAL; break; }
+    }
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+}
+
 // host_scratch: pinned host memory (>= 8 KB)
 int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
 {
@@ -1225,8 +1460,22 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     double *SP = LZ + 6 * (size_t)(q + 8);             // symmetric-tile engine: partial vectors P[2][q / 128][q]
     // XX is symmetric: for q = 2048 / 4096 the products read its lower triangle only (symgemv_kernel, oem_symfused_kernel)
     const bool sym_ok = (q == 2048 || q == 4096) && (((uintptr_t)a.xx) & 15) == 0 && !sw().OEM_NO_SYM.set && !sw().OEM_NO_FUSED.set;
+    // ... and beyond 4096 a packed copy of it, made here (sympk_*: one contiguous sweep of 4 q^2 bytes per product)
+    const bool spk = q > 4096 && a.sympk != nullptr && !sw().OEM_NO_SYM.set;
+    const int spk_nb = spk_nblk(q), spk_qpad = spk_nb * SYM_TB, spk_nt = (int)spk_ntile(q);
+    double *spk_P = spk ? a.sympk + (size_t)spk_nt * SPK_TILE : nullptr, *spk_B = spk ? spk_P + (size_t)spk_nb * spk_qpad : nullptr;
+    if (spk) {
+        OEM_HIP(hipMemsetAsync(spk_B, 0, sizeof(double) * (2 * (size_t)spk_qpad + FMAXB + 16 + 8), s));
+        hipLaunchKernelGGL(sympk_pack_kernel, dim3(spk_nt), dim3(256), 0, s, a.xx, q, a.sympk);
+        OEM_HIP(hipGetLastError());
+    }
+    auto spk_gemv = [&](const double *vec, double *out, const int *done) {
+        hipLaunchKernelGGL(sympk_gemv_kernel, dim3(spk_nt), dim3(256), 0, s, a.sympk, q, spk_qpad, vec, spk_P, done);
+        if (out) hipLaunchKernelGGL(sympk_sum_kernel, dim3(spk_qpad / 64), dim3(256), 0, s, spk_P, spk_nb, q, spk_qpad, out, done);
+    };
     auto sym_gemv = [&](const double *vec, double *out) {
-        if (q == 2048) {
+        if (spk) spk_gemv(vec, out, nullptr);
+        else if (q == 2048) {
             hipLaunchKernelGGL((symgemv_kernel<16>), dim3(sym_nwg(16)), dim3(256), 0, s, a.xx, vec, SP);
             hipLaunchKernelGGL((symgemv_sum_kernel<16>), dim3(q / 128), dim3(128), 0, s, SP, out);
         } else {
@@ -1256,7 +1505,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         for (int k = 0; k < chunk; ++k, ++m) {
             if (lz_fused) hipLaunchKernelGGL(lzk, dim3(lblocks), dim3(256), lsh, s, a.xx, q, m, Vc, Vp, Wb, T, m & 1);
             else {
-                if (sym_ok) sym_gemv(v, w);
+                if (sym_ok || spk) sym_gemv(v, w);
                 else {
                     int rc = launch_gemv(s, a.xx, q, v, w, nullptr, num_cu);
                     if (rc) return rc;
@@ -1290,6 +1539,22 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     OEM_HIP(hipGetLastError());
     if (a.npen == 0) return 0;
 
+    // ---- q > 4096, element-wise penalties: (head, product) pairs over the packed triangle
+    if (spk && a.ngroups == 0 && !a.accelerate && !a.compute_loss && !a.sinv && spk_qpad / 64 <= FMAXB && !sw().OEM_NO_FUSED.set) {
+        int *flags = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad);
+        SState *SS = reinterpret_cast<SState *>(spk_B + 2 * (size_t)spk_qpad + FMAXB);
+        int *fdone = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad + FMAXB + 16);
+        hipLaunchKernelGGL(sym_init_kernel, dim3(1), dim3(1), 0, s, SS, a);
+        auto enq = [&](int count) {
+            for (int k = 0; k < count; ++k) {
+                const int par = k & 1;
+                hipLaunchKernelGGL(sympk_head_kernel, dim3(spk_qpad / 64), dim3(256), 0, s, a, SS, spk_B, spk_P, flags, fdone, par, d, spk_nb, spk_qpad);
+                hipLaunchKernelGGL(sympk_gemv_kernel, dim3(spk_nt), dim3(256), 0, s, a.sympk, q, spk_qpad, spk_B + (size_t)(par ^ 1) * spk_qpad, spk_P, fdone);
+            }
+        };
+        return replay_batches(s, enq, fdone, reinterpret_cast<int *>(host_scratch), (long long)a.npen * a.nl * ((long long)a.maxit + 2) + 8, "packed-triangle engine");
+    }
+
     // ---- fused engine when the operators are row-local and nothing needs a global sum per iteration
     const bool fused_ok = a.ngroups == 0 && !a.accelerate && !a.compute_loss && !a.sinv && (q == 512 || q == 1024 || q == 2048 || q == 4096) &&
                           (((uintptr_t)a.xx) & 15) == 0 && !sw().OEM_NO_FUSED.set;
@@ -1319,35 +1584,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
                 else hipLaunchKernelGGL((oem_fused_kernel<64>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);
             }
         };
-        const int FB = 128;                                          // even: every batch starts at parity 0
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            enq(FB);
-            if (hipStreamEndCapture(s, &graph) != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-                if (graph) (void)hipGraphDestroy(graph);
-                graph = nullptr; exec = nullptr;
-                (void)hipGetLastError();
-            }
-        } else (void)hipGetLastError();
-        const long long max_it = (long long)a.npen * a.nl * ((long long)a.maxit + 2) + 8;
-        long long launched = 0;
-        int *hdone = reinterpret_cast<int *>(host_scratch);
-        int rc = 0;
-        for (;;) {
-            if (exec) { if (hipGraphLaunch(exec, s) != hipSuccess) { set_error("hipGraphLaunch failed"); rc = OEMGPU_ERR_HIP; break; } }
-            else enq(FB);
-            if (hipGetLastError() != hipSuccess) { set_error("fused engine: launch failed"); rc = OEMGPU_ERR_HIP; break; }
-            launched += FB;
-            if (hipMemcpyAsync(hdone, fdone, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                hipStreamSynchronize(s) != hipSuccess) { set_error("fused engine: device error"); rc = OEMGPU_ERR_HIP; break; }
-            if (*hdone) break;
-            if (caller_interrupted()) { set_error("interrupted by the caller"); rc = OEMGPU_ERR_INTERRUPTED; break; }
-            if (launched > max_it) { set_error("fused engine did not finish within %lld iterations", max_it); rc = OEMGPU_ERR_INTERNAL; break; }
-        }
-        if (exec) (void)hipGraphExecDestroy(exec);
-        if (graph) (void)hipGraphDestroy(graph);
-        return rc;
+        return replay_batches(s, enq, fdone, reinterpret_cast<int *>(host_scratch), (long long)a.npen * a.nl * ((long long)a.maxit + 2) + 8, "fused engine");
     }
 
     // ---- replicated-update fused engine: everything else at the same sizes
@@ -1374,35 +1611,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         auto enq = [&](int count) {
             for (int k = 0; k < count; ++k) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shb, s, a, S, Uv, Bv, fdone, k & 1, d);
         };
-        const int FB = 128;
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            enq(FB);
-            if (hipStreamEndCapture(s, &graph) != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-                if (graph) (void)hipGraphDestroy(graph);
-                graph = nullptr; exec = nullptr;
-                (void)hipGetLastError();
-            }
-        } else (void)hipGetLastError();
-        const long long max_it = (long long)a.npen * a.nl * ((long long)a.maxit + 3) + 8;
-        long long launched = 0;
-        int *hdone = reinterpret_cast<int *>(host_scratch);
-        int rc = 0;
-        for (;;) {
-            if (exec) { if (hipGraphLaunch(exec, s) != hipSuccess) { set_error("hipGraphLaunch failed"); rc = OEMGPU_ERR_HIP; break; } }
-            else enq(FB);
-            if (hipGetLastError() != hipSuccess) { set_error("fused engine: launch failed"); rc = OEMGPU_ERR_HIP; break; }
-            launched += FB;
-            if (hipMemcpyAsync(hdone, fdone, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                hipStreamSynchronize(s) != hipSuccess) { set_error("fused engine: device error"); rc = OEMGPU_ERR_HIP; break; }
-            if (*hdone) break;
-            if (caller_interrupted()) { set_error("interrupted by the caller"); rc = OEMGPU_ERR_INTERRUPTED; break; }
-            if (launched > max_it) { set_error("fused engine did not finish within %lld iterations", max_it); rc = OEMGPU_ERR_INTERNAL; break; }
-        }
-        if (exec) (void)hipGraphExecDestroy(exec);
-        if (graph) (void)hipGraphDestroy(graph);
-        return rc;
+        return replay_batches(s, enq, fdone, reinterpret_cast<int *>(host_scratch), (long long)a.npen * a.nl * ((long long)a.maxit + 3) + 8, "fused engine");
     }
 
     // ---- path: (gemv, update) pairs replayed in batches from a hipGraph (eager launches are host-bound at ~3.5 us
@@ -1417,39 +1626,12 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     }
     auto enqueue = [&](int count) {
         for (int k = 0; k < count; ++k) {
-            (void)launch_gemv(s, a.xx, q, beta, g, &st->done, num_cu);
+            if (spk) spk_gemv(beta, g, &st->done);
+            else (void)launch_gemv(s, a.xx, q, beta, g, &st->done, num_cu);
             hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), sh, s, a, st, beta, g, uf);
         }
     };
-    const int BATCH = 128;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        enqueue(BATCH);
-        if (hipStreamEndCapture(s, &graph) != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-            if (graph) (void)hipGraphDestroy(graph);
-            graph = nullptr; exec = nullptr;
-            (void)hipGetLastError();
-        }
-    } else (void)hipGetLastError();
-    const long long max_updates = (long long)a.npen * a.nl * ((long long)a.maxit + 2) + 8;
-    long long launched = 0;
-    int *hdone = reinterpret_cast<int *>(host_scratch);
-    int rc = 0;
-    for (;;) {
-        if (exec) { if (hipGraphLaunch(exec, s) != hipSuccess) { set_error("hipGraphLaunch failed"); rc = OEMGPU_ERR_HIP; break; } }
-        else enqueue(BATCH);
-        if (hipGetLastError() != hipSuccess) { set_error("large-p engine: launch failed"); rc = OEMGPU_ERR_HIP; break; }
-        launched += BATCH;
-        if (hipMemcpyAsync(hdone, &st->done, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess) { set_error("large-p engine: device error"); rc = OEMGPU_ERR_HIP; break; }
-        if (*hdone) break;
-        if (caller_interrupted()) { set_error("interrupted by the caller"); rc = OEMGPU_ERR_INTERRUPTED; break; }
-        if (launched > max_updates) { set_error("large-p engine did not finish within %lld updates", max_updates); rc = OEMGPU_ERR_INTERNAL; break; }
-    }
-    if (exec) (void)hipGraphExecDestroy(exec);
-    if (graph) (void)hipGraphDestroy(graph);
-    return rc;
+    return replay_batches(s, enqueue, &st->done, reinterpret_cast<int *>(host_scratch), (long long)a.npen * a.nl * ((long long)a.maxit + 2) + 8, "large-p engine");
 }
 
 // ================================================================================================
