@@ -155,7 +155,7 @@ def self_launch(a, argv):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-def live_pmc(kernel_substring, counter_sets, timeout=180):
+def live_pmc(kernel_substring, counter_sets, timeout=180, program=None):
     """Hardware counters of one kernel, measured in THIS run: each counter set is one child process
     `rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 bench.py --steps 3 ...` (counters in passes of their own, the
     program itself behind `--`, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; a child process, never an exec).  Returns
@@ -172,9 +172,9 @@ def live_pmc(kernel_substring, counter_sets, timeout=180):
     for ctrs in counter_sets:
         tmp = tempfile.mkdtemp(prefix="oem_pmc_", dir="/tmp")
         try:
-            cmd = ["rocprofv3", "--pmc"] + list(ctrs) + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--",
-                   sys.executable, str(Path(__file__).resolve()), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-c5", "--no-host",
-                   "--no-two-callers", "--no-rccl-check", "--no-live-pmc"]
+            prog = program or [str(Path(__file__).resolve()), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-c5", "--no-host",
+                               "--no-two-callers", "--no-rccl-check", "--no-live-pmc"]
+            cmd = ["rocprofv3", "--pmc"] + list(ctrs) + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable] + prog
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OEM_BENCH_ARGV")}
             env["TMPDIR"] = "/tmp"
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
@@ -622,6 +622,19 @@ def main():
             r5 = c5_weak(torch, dist, world, rank, dev, backend, a.c5_rows, 10, 2)
             if rank == 0:
                 out["c5_weak"] = r5
+                if world == 1 and not a.no_cpu_baseline:
+                    # CPU figure, EXTRAPOLATED: the oracle's big.oem on 40,000 and 80,000 rows of the same shape, t(n) = a + b n to this share's rows
+                    from oracle import oracle as orc
+                    orc.lib(True)
+                    r5g = np.random.default_rng(55)
+                    pts5 = []
+                    for nn in (40_000, 80_000):
+                        xs = np.asfortranarray(r5g.normal(size=(nn, 256))); bb5 = np.zeros(256); bb5[:25] = r5g.uniform(0, 1, 25)
+                        ys = xs @ bb5 + r5g.normal(size=nn)
+                        t0 = time.perf_counter(); orc.fit_big(xs, ys, native=True, penalty=["lasso"], nlambda=100, tol=1e-7); pts5.append(time.perf_counter() - t0)
+                    full5 = pts5[0] + (pts5[1] - pts5[0]) / 40_000.0 * (a.c5_rows - 40_000)
+                    r5["cpu_baseline"] = {"value": 1.0 / full5, "unit": "solves/s", "cores": 1, "kind": "port", "seconds": full5,
+                                          "sample": "EXTRAPOLATED: the oracle on 40,000 and 80,000 rows (%.2f s, %.2f s), t(n) = a + b n to the %d rows of one GPU's share" % (pts5[0], pts5[1], a.c5_rows)}
         except Exception as e:          # e.g. not enough free HBM on a shared device: the headline line must still print
             if rank == 0:
                 out["c5_weak"] = {"error": repr(e)}
@@ -708,28 +721,121 @@ def main():
                             "note": "the matrix is register-resident for the whole call: the 'bandwidth' above is SURVEY 8(d)'s byte count over the "
                                     "measured time (multiples of the 8 TB/s HBM peak because the bytes are never read); the loop is bound by two "
                                     "exchanges per iteration through the memory side and by FP64 VALU, not by HBM"}
+            if not a.no_cpu_baseline:
+                # CPU figure, EXTRAPOLATED: the oracle on the first four lambdas of the same grid (one 134 MB GEMV + threshold per iteration),
+                # its ms per iteration x the full path's iteration count
+                from oracle import oracle as orc
+                orc.lib(True)
+                xtx4h = xtx4.cpu().numpy()
+                t0 = time.perf_counter()
+                r4 = orc.fit_xtx(xtx4h, xty4, native=True, penalty=["lasso"], lambda_=np.asarray(f4["lambda"][0])[:4], tol=1e-10, d_override=float(f4["d"]))
+                t4c = time.perf_counter() - t0
+                it4c = int(np.sum(r4["niter"][0]))
+                out["c4_ms"]["cpu_baseline"] = {"value": t4c / max(it4c, 1) * it4 * 1e3, "unit": "ms per call", "cores": 1, "kind": "port",
+                                                "sample": "EXTRAPOLATED: the oracle on the first 4 of the 100 lambdas (%d iterations in %.2f s, d handed over: no eigen-solve), "
+                                                          "ms per iteration x the %d iterations of the full path" % (it4c, t4c, it4)}
+                del xtx4h
             del xtx4
         except Exception as e:
             out["c4_ms"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.no_host:
-        # BASELINE configs 2 and 3 on the record (device-resident X, whole oem() calls): c2 = MCP and SCAD at n = 5,000, p = 200, 200 lambdas
-        # (one CU: the serial chain of the row-split kernel); c3 = grp.lasso at n = 1e6, p = 512, 64 groups of 8, 100 lambdas (moment kernel
-        # on eight-wave units + the cooperating engine on one XCD).  Parity of both at full size: tests/test_gpu_configs.py.  Never `value`.
+        # The one GEMV loop that IS HBM-bound (north_star: "OEM GEMV loop at >= 70 % HBM peak, evidenced by rocprof"): oem.xtx beyond the
+        # register-resident engines, q = 8,192 -- config 4's recipe at twice the size (X'X/n of n = 16 q Gaussian rows, 25 non-zeros, 100-lambda
+        # lasso, tol 1e-10).  The matrix (537 MB) fits neither registers nor the Infinity Cache: every product streams the packed lower
+        # triangle once (path_large.hip: sympk_*).  `roofline` prices the product kernel's own time (HIP events on its stream,
+        # oemgpu_selftest_sympk_gemv) on the bytes its algorithm moves; `traffic` is measured now by child rocprofv3 passes.  Never `value`.
         try:
-            ctx3 = oem_amd.context()
+            q8, n8 = 8192, 16 * 8192
+            g8 = torch.Generator(device=dev); g8.manual_seed(8192)
+            xtx8 = torch.zeros((q8, q8), device=dev, dtype=torch.float64)
+            b8 = torch.zeros(q8, dtype=torch.float64, device=dev); b8[:25] = 2.0 * torch.rand(25, generator=g8, device=dev, dtype=torch.float64) - 1.0
+            xty8 = torch.zeros(q8, device=dev, dtype=torch.float64)
+            for _ in range(8):                                   # rows in eight blocks: no 8.6 GB temporary
+                xb = torch.randn((n8 // 8, q8), generator=g8, device=dev, dtype=torch.float64)
+                yb = xb @ b8 + torch.randn(n8 // 8, generator=g8, device=dev, dtype=torch.float64)
+                xtx8 += xb.t() @ xb; xty8 += xb.t() @ yb
+                del xb, yb
+            xtx8 /= n8; xty8h = (xty8 / n8).cpu().numpy()
+            ctx8 = oem_amd.context()
+            L.check(L.lib().oemgpu_set_timing(ctx8, 1))
+            ts8, f8 = [], None
+            for _ in range(3):
+                f8 = oem_amd.oem_xtx(xtx8, xty8h, penalty="lasso", nlambda=100, tol=1e-10); torch.cuda.synchronize()
+                ms8 = (C.c_double * L.NTIMERS)(); L.check(L.lib().oemgpu_last_timings(ctx8, ms8))
+                ts8.append(ms8[L.T_EIGPATH])
+            L.check(L.lib().oemgpu_set_timing(ctx8, 0))
+            st8, cp8 = C.c_int32(-1), C.c_int32(-1)
+            L.lib().oemgpu_last_eigen_info(ctx8, C.byref(st8), C.byref(cp8))
+            it8 = int(np.sum(f8["niter"][0])); prod8 = it8 + int(st8.value)
+            v8 = torch.randn(q8, generator=g8, device=dev, dtype=torch.float64); o8 = torch.empty_like(v8)
+            us8 = C.c_double(0.0)
+            L.check(L.lib().oemgpu_selftest_sympk_gemv(ctx8, xtx8.data_ptr(), q8, v8.data_ptr(), o8.data_ptr(), 50, C.byref(us8)))
+            gemv_err = float((o8 - xtx8 @ v8).abs().max() / (xtx8 @ v8).abs().max())
+            nblk8 = (q8 + 127) // 128
+            bytes8 = 4.0 * (128 * nblk8) ** 2 + 512.0 * 128 * nblk8 + 8.0 * 128 * nblk8 * nblk8      # blocks of the lower triangle (diagonal ones whole) + the partial vectors written
+            med8 = float(np.median(ts8))
+            rf8 = {"bound": "hbm", "kernel": "sympk_gemv_kernel (one 128 x 128 block of the packed lower triangle per workgroup, both products from one read)",
+                   "achieved": bytes8 / (us8.value * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": bytes8 / (us8.value * 1e-6) / 1e9 / 8000.0,
+                   "traffic": None, "traffic_unit": "bytes per launch", "kernel_us": us8.value, "algorithmic_bytes": bytes8,
+                   "note": "algorithmic bytes = 4 q^2 + 512 q (blocks) + 8 q ceil(q / 128) (partial vectors written); SURVEY 8(d)'s 8 q^2 + 24 q "
+                           "is what a row-streaming product reads -- half of it is never read here"}
+            if not a.no_live_pmc:
+                try:
+                    t0 = time.perf_counter()
+                    c8 = live_pmc("sympk_gemv_kernel", [["FETCH_SIZE"], ["WRITE_SIZE"]], program=[str(ROOT / "tools" / "run_q8192.py")])
+                    rf8["traffic"] = (2.0 * c8["FETCH_SIZE"] + c8["WRITE_SIZE"]) * 1024.0
+                    rf8["traffic_source"] = ("measured in this run: child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE -- python3 tools/run_q8192.py`, "
+                                             "mean per launch of sympk_gemv_kernel; FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes")
+                    rf8["achieved_on_traffic_GBps"] = rf8["traffic"] / (us8.value * 1e-6) / 1e9
+                    rf8["live_pmc_seconds"] = time.perf_counter() - t0
+                except Exception as e:
+                    rf8["live_pmc_error"] = repr(e)
+            out["q8192_ms"] = {"workload": "oem.xtx, q = 8192 (X'X/n of n = 131072 Gaussian rows, 25 non-zeros), 100-lambda lasso, tol 1e-10: the Gram form beyond the register-resident engines",
+                               "eigen_plus_path_ms": med8, "eigen_plus_path_ms_runs": ts8, "oem_iterations": it8, "lanczos_steps": int(st8.value),
+                               "us_per_product_all_in": 1e3 * med8 / max(prod8, 1),
+                               "GBps_at_8q2_plus_24q_bytes_per_product": (8.0 * q8 * q8 + 24.0 * q8) * prod8 / (med8 * 1e-3) / 1e9,
+                               "engine": oem_amd.last_path_engine()[0], "product_rel_err_vs_torch": gemv_err, "roofline": rf8}
+            del xtx8, v8, o8
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["q8192_ms"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not a.no_host:
+        # BASELINE configs 2 and 3 on the record, as SURVEY section 8(d) and the reference's README state them (device-resident X, whole oem()
+        # calls, median of five, tol 1e-10): c2 = MCP (gamma 2) and SCAD (gamma 4) at n = 5,000, p = 200, b ~ U(-0.5, 0.5) x 25, X ~ N(0, 9), 200
+        # lambdas, intercept + standardize (README.md:100-141; one CU: the serial chain of the row-split kernel); c3 = grp.lasso at n = 1e6,
+        # p = 512, 64 groups of 8, 100 lambdas with intercept = FALSE, standardize = FALSE as README.md:199-213 -- and the defaults beside it.
+        # Each with its CPU figure: the oracle (C port, one thread, -O3 -march=native) on the same data for c2, for c3 extrapolated from
+        # two sub-sampled row counts (the moment pass is linear in n, the path does not depend on n).  Parity of both at full size:
+        # tests/test_gpu_configs.py.  Never `value`.
+        cpu_ok = not a.no_cpu_baseline
+        if cpu_ok:
+            from oracle import oracle as orc
+            orc.lib(True)
+        ctx3 = oem_amd.context()
+        try:
             rec = {}
             g2 = torch.Generator(device=dev); g2.manual_seed(21)
-            x2 = torch.randn((200, 5000), generator=g2, device=dev, dtype=torch.float64)
-            b2 = torch.zeros(200, dtype=torch.float64, device=dev); b2[:20] = torch.rand(20, generator=g2, device=dev, dtype=torch.float64) - 0.5
+            x2 = torch.randn((200, 5000), generator=g2, device=dev, dtype=torch.float64) * 3.0
+            b2 = torch.zeros(200, dtype=torch.float64, device=dev); b2[:25] = torch.rand(25, generator=g2, device=dev, dtype=torch.float64) - 0.5
             y2 = (x2.t() @ b2 + torch.randn(5000, generator=g2, device=dev, dtype=torch.float64)).contiguous()
+            x2h = np.asfortranarray(x2.t().cpu().numpy()); y2h = y2.cpu().numpy()
             for pen, gam in (("mcp", 2.0), ("scad", 4.0)):
-                best, f2 = 1e9, None
-                for _ in range(3):
-                    t0 = time.perf_counter(); f2 = oem_amd.oem(x2.t(), y2, penalty=pen, gamma=gam, nlambda=200, tol=1e-7); torch.cuda.synchronize()
-                    best = min(best, time.perf_counter() - t0)
-                rec[pen] = {"ms": 1e3 * best, "iterations": int(np.sum(f2["niter"][0])), "engine": oem_amd.last_path_engine()[0]}
-            out["c2_ms"] = {"workload": "config 2: oem() MCP (gamma 2) / SCAD (gamma 4), n = 5000, p = 200, 200 lambdas, tol 1e-7", **rec}
+                ts2, f2 = [], None
+                for k2 in range(6):
+                    t0 = time.perf_counter(); f2 = oem_amd.oem(x2.t(), y2, penalty=pen, gamma=gam, nlambda=200, tol=1e-10); torch.cuda.synchronize()
+                    if k2:
+                        ts2.append(1e3 * (time.perf_counter() - t0))
+                rec[pen] = {"ms": float(np.median(ts2)), "ms_runs": ts2, "iterations": int(np.sum(f2["niter"][0])), "engine": oem_amd.last_path_engine()[0],
+                            "reference_readme_ms": 105.9 if pen == "mcp" else 80.2}
+                if cpu_ok:
+                    t0 = time.perf_counter(); r2 = orc.fit_dense(x2h, y2h, native=True, penalty=pen, gamma=gam, nlambda=200, tol=1e-10); tc2_ = time.perf_counter() - t0
+                    rec[pen]["cpu_baseline"] = {"value": 1e3 * tc2_, "unit": "ms per call", "cores": 1, "kind": "port", "sample": "the full workload, 1 call"}
+                    rec[pen]["max_abs_beta_err_vs_cpu"] = float(np.abs(np.asarray(f2["beta"][0]) - np.asarray(r2["beta"][0])).max())
+            out["c2_ms"] = {"workload": "config 2: oem() MCP (gamma 2) / SCAD (gamma 4), n = 5000, p = 200, 200 lambdas, tol 1e-10, intercept + standardize (README.md:100-141)", **rec}
             del x2, y2
+        except Exception as e:
+            out["c2_ms"] = {"error": repr(e)}
+        try:
             g3 = torch.Generator(device=dev); g3.manual_seed(22)
             n3, p3 = 1_000_000, 512
             x3 = torch.empty((p3, n3), device=dev, dtype=torch.float64)
@@ -737,23 +843,41 @@ def main():
                 x3[j0:j0 + 64].normal_(generator=g3)
             b3 = torch.zeros(p3, dtype=torch.float64, device=dev); b3[:24] = torch.rand(24, generator=g3, device=dev, dtype=torch.float64) - 0.5
             y3 = (x3.t() @ b3 + torch.randn(n3, generator=g3, device=dev, dtype=torch.float64)).contiguous()
-            L.check(L.lib().oemgpu_set_timing(ctx3, 1))
-            best, f3, tm3 = 1e9, None, None
-            for _ in range(3):
-                t0 = time.perf_counter()
-                f3 = oem_amd.oem(x3.t(), y3, penalty="grp.lasso", groups=np.repeat(np.arange(1, 65), 8), nlambda=100, tol=1e-7)
-                torch.cuda.synchronize()
-                wall = time.perf_counter() - t0
-                if wall < best:
-                    best = wall
-                    tm3 = (C.c_double * L.NTIMERS)(); L.check(L.lib().oemgpu_last_timings(ctx3, tm3))
-            L.check(L.lib().oemgpu_set_timing(ctx3, 0))
+            grp3 = np.repeat(np.arange(1, 65), 8)
             fl3 = float(n3) * p3 * (p3 + 1.0) + 2.0 * n3 * p3
-            out["c3_ms"] = {"workload": "config 3: oem() grp.lasso, n = 1e6, p = 512, 64 groups of 8, 100 lambdas, tol 1e-7", "ms": 1e3 * best,
-                            "gram_kernel_ms": tm3[L.T_GRAMK], "gram_TFLOPs": fl3 / (tm3[L.T_GRAMK] * 1e-3) / 1e12,
-                            "gram_frac_of_fp64_mfma_peak": fl3 / (tm3[L.T_GRAMK] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                            "eigen_plus_path_ms": tm3[L.T_EIGPATH], "iterations": int(np.sum(f3["niter"][0])),
-                            "engine": oem_amd.last_path_engine()[0], "placement": oem_amd.api.last_placement()}
+            L.check(L.lib().oemgpu_set_timing(ctx3, 1))
+            c3 = {}
+            for label, kw3 in (("readme", dict(intercept=False, standardize=False)), ("defaults", dict())):
+                ts3, tm3s, f3 = [], [], None
+                for k3 in range(6):
+                    t0 = time.perf_counter()
+                    f3 = oem_amd.oem(x3.t(), y3, penalty="grp.lasso", groups=grp3, nlambda=100, tol=1e-10, **kw3)
+                    torch.cuda.synchronize()
+                    if k3:
+                        ts3.append(1e3 * (time.perf_counter() - t0))
+                        tm3 = (C.c_double * L.NTIMERS)(); L.check(L.lib().oemgpu_last_timings(ctx3, tm3))
+                        tm3s.append((tm3[L.T_GRAMK], tm3[L.T_EIGPATH]))
+                gk = float(np.median([t[0] for t in tm3s]))
+                c3[label] = {"ms": float(np.median(ts3)), "ms_runs": ts3, "gram_kernel_ms": gk, "gram_TFLOPs": fl3 / (gk * 1e-3) / 1e12,
+                             "gram_frac_of_fp64_mfma_peak": fl3 / (gk * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                             "eigen_plus_path_ms": float(np.median([t[1] for t in tm3s])), "iterations": int(np.sum(f3["niter"][0])),
+                             "engine": oem_amd.last_path_engine()[0], "placement": oem_amd.api.last_placement()}
+            L.check(L.lib().oemgpu_set_timing(ctx3, 0))
+            out["c3_ms"] = {"workload": "config 3: oem() grp.lasso, n = 1e6, p = 512, 64 groups of 8, 100 lambdas, tol 1e-10; `readme`: intercept = FALSE, "
+                                        "standardize = FALSE (README.md:199-213), `defaults`: both TRUE", **c3["readme"], "defaults": c3["defaults"]}
+            if cpu_ok:
+                pts = []
+                for nn in (20_000, 40_000):
+                    xs = np.asfortranarray(x3[:, :nn].t().cpu().numpy()); ys = y3[:nn].cpu().numpy()
+                    t0 = time.perf_counter()
+                    orc.fit_dense(xs, ys, native=True, penalty=["grp.lasso"], groups=grp3, unique_groups=np.unique(grp3), nlambda=100, tol=1e-10,
+                                  standardize=False, intercept=False)
+                    pts.append(time.perf_counter() - t0)
+                slope = (pts[1] - pts[0]) / 20_000.0
+                full = pts[0] + slope * (n3 - 20_000)
+                out["c3_ms"]["cpu_baseline"] = {"value": 1e3 * full, "unit": "ms per call", "cores": 1, "kind": "port",
+                                                "sample": "EXTRAPOLATED: the oracle on the first 20,000 and 40,000 of the 1e6 rows (%.2f s, %.2f s), t(n) = a + b n "
+                                                          "through the two points (the moment pass is linear in n, the path does not depend on n)" % (pts[0], pts[1])}
             del x3, y3
         except Exception as e:
             out["c3_ms"] = {"error": repr(e)}

@@ -337,6 +337,14 @@ int oemgpu_selftest_gram_plan(int64_t n, int32_t p, int32_t num_cu, int64_t *out
  * spin for `ms` milliseconds -- "somebody else holds the CUs", for the fallback of the persistent engines.  Asynchronous. */
 int oemgpu_selftest_hold_cus(oemgpu_ctx *ctx, int32_t blocks, double ms);
 
+/* Self-test / measurement aid: out = XX vec for a symmetric q x q matrix (q > 4096, column-major, device) through the packed lower
+ * triangle the launch-per-iteration Gram engine streams beyond q = 4096 (path_large.hip: sympk_*; replaces the GEMV of
+ * ref src/oem_xtx.h:378-381 / src/oem_dense.h:508-512): the pack, then `reps` products back to back between two HIP events on the
+ * context's stream.  *us_per_product = the product kernel's own duration (bench.py prices 4 q^2 + 512 q + 8 q ceil(q / 128) bytes
+ * against it).  Synchronises the stream. */
+int oemgpu_selftest_sympk_gemv(oemgpu_ctx *ctx, const double *xx_dev, int32_t q, const double *vec_dev, double *out_dev, int32_t reps,
+                               double *us_per_product);
+
 /* The OEM_* / OEMGPU_* environment switches (engine selection for tests, knobs of the host-resident upload; none is needed in
  * production: DESIGN.md section 7b) are parsed ONCE, at the first call into the library.  oemgpu_reload_switches() parses the
  * environment again (tests); oemgpu_switch_names() is the space-separated list of every name the library reads. */

@@ -1077,6 +1077,14 @@ int oemgpu_selftest_hold_cus(oemgpu_ctx *c, int32_t blocks, double ms)
     return 0;
 }
 
+int oemgpu_selftest_sympk_gemv(oemgpu_ctx *c, const double *xx_dev, int32_t q, const double *vec_dev, double *out_dev, int32_t reps, double *us_per_product)
+{
+    if (!c || !xx_dev || !vec_dev || !out_dev || q <= 4096 || reps < 0 || reps > 100000) { set_error("selftest_sympk_gemv: bad argument (q > 4096)"); return OEMGPU_ERR_ARG; }
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    if (ctx_grow(c, &c->pack_buf, &c->pack_bytes, sympk_doubles(q) * sizeof(double))) return OEMGPU_ERR_HIP;
+    return sympk_gemv_probe(c->stream, xx_dev, q, (double *)c->pack_buf, vec_dev, out_dev, reps, us_per_product);
+}
+
 int oemgpu_set_timing(oemgpu_ctx *c, int32_t on)
 {
     if (!c) { set_error("ctx is NULL"); return OEMGPU_ERR_ARG; }

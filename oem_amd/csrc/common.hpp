@@ -200,6 +200,7 @@ int lds_limit_once(const void *fn, size_t bytes);
 int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch);   // any p: multi-launch engine
 size_t path_large_work_doubles(int p, int nsteps);
 size_t sympk_doubles(int q);                                      // 0 for q <= 4096
+int sympk_gemv_probe(hipStream_t s, const double *xx, int q, double *pk, const double *vec, double *out, int reps, double *us_per_product);
 // 288 < p <= 1024: one persistent launch of cooperating workgroups (path_coop.hip)
 bool path_coop_eligible(int q, bool has_sinv, bool compute_loss, int ngroups, int nbatch);
 int path_coop_workgroups(int q);

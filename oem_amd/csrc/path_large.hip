@@ -439,23 +439,44 @@ __global__ __launch_bounds__(1024) void path_init_kernel(PathArgs A, LState *st,
     }
 }
 
+// R > 0: the thread's R coordinates of beta, g, XY, the penalty factors and the group ids are loaded into registers FIRST, before the
+// state's dependent loads -- every load of the kernel that does not depend on another is then in flight together (q = 8,192 with 1,024
+// groups: 14.4 us of dependent round trips, one per loop trip, for 256 KB of operands).  R = 0: the loops read memory as they go (any q).
+// Same operations in the same order either way.
+template <int R>
 __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, double *__restrict__ beta,
                                             const double *__restrict__ g, double *dyn, double *sh)
 {
-    if (st->done) return;
+    constexpr int RR = R ? R : 1;
     const int q = A.p, nl = A.nl, tid = threadIdx.x, nt = blockDim.x;
+    double rb[RR], rg[RR], rxy[RR], rpf[RR];
+    int rgid[RR];
+    if (R) {
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            const int j = tid + nt * r, jc = j < q ? j : q - 1;
+            rb[r] = beta[jc]; rg[r] = g[jc]; rxy[r] = A.xy[jc]; rpf[r] = A.pf[jc];
+            rgid[r] = A.ngroups > 0 ? A.gid[jc] : -1;
+        }
+    }
+    int pgz = 1, pgs0 = 0, pgs1 = 0;
+    double pgw = 0.0;
+    if (R && tid < A.ngroups) { pgz = A.gzero[tid]; pgs0 = A.gstart[tid]; pgs1 = A.gstart[tid + 1]; pgw = A.gw[tid]; }
+    if (st->done) return;
     const int pp = st->pp, i = st->i;
     int it = st->it;
     const double d = st->d;
     const double scaley = A.yscale ? A.stats[1] : 1.0;
     const double yy = A.stats[2], nobs = A.stats[3];
     double *U = dyn, *F = dyn + q;
+#define OEM_UPD_LOOP _Pragma("unroll RR") for (int r = 0, j = tid; R ? r < RR : j < q; ++r, j += nt) if (!R || j < q)
+#define OEM_UPD(reg, mem) (R ? (reg)[R ? r : 0] : (mem))
 
     // ---- loss of the lambda that converged in the previous update: g is XX beta_final (Gram identity, see path_small)
     const int pl = st->pending_loss;
     if (pl >= 0) {
         double t = 0.0;
-        for (int j = tid; j < q; j += nt) t += beta[j] * (g[j] - 2.0 * A.xy[j]);
+        OEM_UPD_LOOP t += OEM_UPD(rb, beta[j]) * (OEM_UPD(rg, g[j]) - 2.0 * OEM_UPD(rxy, A.xy[j]));
         t = block_sum(t, sh);
         if (tid == 0) A.loss[pl] = yy + nobs * t;
     }
@@ -477,19 +498,29 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
 
     // ---- u and (for group operators) the group factors
     if (grp) {
-        for (int j = tid; j < q; j += nt) {
-            const double bo = reset ? 0.0 : beta[j];
-            const double u = (d * bo - (reset ? 0.0 : g[j])) + A.xy[j];
-            U[j] = (K.kind == K_SGL) ? soft1(u, A.pf[j] * K.L1, 1.0) : u;
+        OEM_UPD_LOOP {
+            const double bo = reset ? 0.0 : OEM_UPD(rb, beta[j]);
+            const double u = (d * bo - (reset ? 0.0 : OEM_UPD(rg, g[j]))) + OEM_UPD(rxy, A.xy[j]);
+            U[j] = (K.kind == K_SGL) ? soft1(u, OEM_UPD(rpf, A.pf[j]) * K.L1, 1.0) : u;
         }
         __syncthreads();
         for (int gi = tid; gi < A.ngroups; gi += nt) {
             double f = 1.0;
-            if (!A.gzero[gi]) {
+            const bool first = R && gi == tid;                   // (the first trip's group was fetched with the operands)
+            if (!(first ? pgz : A.gzero[gi])) {
                 double s = 0.0;
-                for (int m = A.gstart[gi]; m < A.gstart[gi + 1]; ++m) { const double x = U[A.gidx[m]]; s += x * x; }
+                // members in member order, their indices fetched eight at a time (one dependent load per member was a memory round trip each)
+                const int m1 = first ? pgs1 : A.gstart[gi + 1];
+                for (int m = first ? pgs0 : A.gstart[gi]; m < m1; m += 8) {
+                    int ix[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) ix[u] = A.gidx[m + u < m1 ? m + u : m1 - 1];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (m + u < m1) { const double x = U[ix[u]]; s += x * x; }
+                }
                 s = sqrt(s);
-                const double pen_g = K.L * A.gw[gi];
+                const double pen_g = K.L * (first ? pgw : A.gw[gi]);
                 if (K.kind == K_GRP || K.kind == K_SGL) { const double t = 1.0 - pen_g / s; f = (0.0 < t) ? t : 0.0; }
                 else if (K.kind == K_GRP_MCP) f = mcp_norm(s, pen_g, K.D, K.gamma);
                 else f = scad_norm(s, pen_g, K.D, K.gamma);
@@ -502,16 +533,16 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
     bool bad = false;
     double adp = 0.0;
     const double akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak)), ratio = (ak - 1.0) / akn;
-    for (int j = tid; j < q; j += nt) {
-        const double bo = reset ? 0.0 : beta[j];
+    OEM_UPD_LOOP {
+        const double bo = reset ? 0.0 : OEM_UPD(rb, beta[j]);
         double bn;
         if (grp) {
-            const int gi = A.gid[j];
+            const int gi = OEM_UPD(rgid, A.gid[j]);
             const double f = gi >= 0 ? F[gi] : 0.0;
             bn = (f != 0.0) ? U[j] * f / K.D : 0.0;
         } else {
-            const double u = (d * bo - (reset ? 0.0 : g[j])) + A.xy[j];
-            const double tp = A.pf[j] * K.L;
+            const double u = (d * bo - (reset ? 0.0 : OEM_UPD(rg, g[j]))) + OEM_UPD(rxy, A.xy[j]);
+            const double tp = OEM_UPD(rpf, A.pf[j]) * K.L;
             if (K.kind == K_SOFT) bn = cdiv(shrink(u, tp), K.D, rD);
             else if (K.kind == K_MCP) {
                 const bool big = fabs(u) > gammad * tp;
@@ -533,6 +564,7 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
         bad |= (cn != qn);
         bad |= (cn && qn && fabs(bn - bo) > A.tol * qo);
         beta[j] = bn;
+        if (R) rb[R ? r : 0] = bn;
     }
     if (A.accelerate) {
         adp = block_sum(adp, sh);
@@ -543,8 +575,8 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
     const bool conv = !anybad;
     if (conv || it >= A.maxit) {
         const size_t ki = (size_t)pp * nl + i;
-        for (int j = tid; j < q; j += nt) {
-            double b = beta[j];
+        OEM_UPD_LOOP {
+            double b = OEM_UPD(rb, beta[j]);
             if (A.sinv) { b *= A.sinv[j]; beta[j] = b; }            // quirk Q5: the member itself is rescaled
             A.beta[ki * q + j] = b;
         }
@@ -561,17 +593,20 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
             }
         }
     } else if (tid == 0) { st->it = it; st->ak = ak; st->reset_next = 0; st->pending_loss = -1; }
+#undef OEM_UPD_LOOP
+#undef OEM_UPD
 }
 
 // uf: where the group operand U[q] and the factors F[ngroups] live when q + ngroups doubles do not fit the LDS of one workgroup
 // (q + ngroups beyond about 19,900: p >= n with a group penalty at p = 20,000 used to be refused) -- global memory, written and
 // read by this one workgroup between its own barriers; null: LDS.
+template <int R>
 __global__ __launch_bounds__(1024) void path_update_kernel(PathArgs A, LState *st, double *__restrict__ beta,
                                                             const double *__restrict__ g, double *uf)
 {
     extern __shared__ __attribute__((aligned(16))) double dyn[];     // U[q] (group operand), F[ngroups]
     __shared__ double sh[16];
-    path_update(A, st, beta, g, uf ? uf : dyn, sh);
+    path_update<R>(A, st, beta, g, uf ? uf : dyn, sh);
 }
 
 __global__ __launch_bounds__(1024) void lanczos_update_kernel(int q, int j, double *__restrict__ v, double *__restrict__ vp,
@@ -579,6 +614,50 @@ __global__ __launch_bounds__(1024) void lanczos_update_kernel(int q, int j, doub
 {
     __shared__ double sh[16];
     lanczos_update(q, j, v, vp, w, T, sh);
+}
+
+// The same update with a thread's R entries of v, v_prev and w in registers: every load of the kernel is issued before the first
+// reduction (q = 8,192: 12.9 -> one memory round trip and two block sums).  Same operations in the same order as lanczos_update.
+template <int R>
+__global__ __launch_bounds__(1024) void lanczos_update_reg_kernel(int q, int j, double *__restrict__ v, double *__restrict__ vp,
+                                                                   const double *__restrict__ w, double *__restrict__ T)
+{
+    __shared__ double sh[16];
+    double *al = T, *be = T + MAXL;
+    const int tid = threadIdx.x;
+    double xv[R], xp[R], xw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = tid + 1024 * r, kc = k < q ? k : q - 1;
+        const double m = k < q ? 1.0 : 0.0;
+        xv[r] = v[kc] * m; xp[r] = vp[kc] * m; xw[r] = w[kc] * m;
+    }
+    if (j > 0 && !(be[j - 1] > 1e-13 * fabs(al[j - 1]))) {          // invariant subspace already reached
+        if (tid == 0) { al[j] = al[j - 1]; be[j] = 0.0; }
+        return;
+    }
+    const double bprev = j > 0 ? be[j - 1] : 0.0;
+    double a = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) a = fma(xv[r], xw[r], a);
+    a = block_sum(a, sh);
+    double bb = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double t = (xw[r] - a * xv[r]) - bprev * xp[r];
+        xw[r] = t;
+        bb = fma(t, t, bb);
+    }
+    bb = sqrt(block_sum(bb, sh));
+    if (tid == 0) { al[j] = a; be[j] = bb; }
+    if (bb > 1e-13 * fabs(a)) {
+        const double ib = 1.0 / bb;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int k = tid + 1024 * r;
+            if (k < q) { vp[k] = xv[r]; v[k] = xw[r] * ib; }
+        }
+    }
 }
 
 }  // namespace
@@ -962,7 +1041,7 @@ __global__ __launch_bounds__(256, OEM_SYM_MINWG) void oem_symfused_kernel(PathAr
 // The arithmetic of a block is oem_symfused_kernel's (both products from one read, fixed summation order, partial vectors by slot);
 // the slots are summed by a kernel of its own -- a workgroup's head would re-read as many bytes of partials as its block has at
 // NBLK = 64 -- which for element-wise penalties is also the operator, the stop rule's "still moving" words and the replicated
-// lambda / penalty bookkeeping (sympk_head_kernel: oem_symfused_kernel's head, 64 coordinates per workgroup); everything else gets
+// lambda / penalty bookkeeping (sympk_head_kernel: oem_symfused_kernel's head, 32 coordinates per workgroup); everything else gets
 // g = XX beta from sympk_sum_kernel and runs path_update_kernel / lanczos_update_kernel unchanged.
 // bytes per product: 4 q^2 + 512 q read + 8 q NBLK written and read again (q = 8,192: 272.6 + 4.2 + 4.2 MB).
 // ------------------------------------------------------------------------------------------------
@@ -1020,9 +1099,9 @@ __global__ __launch_bounds__(256, OEM_SYM_MINWG) void sympk_gemv_kernel(const do
     const int dn = done ? *done : 0;
     const double mine = cm < q ? vec[cm] : 0.0;
     const double *tp = pk + (size_t)blockIdx.x * SPK_TILE + ((size_t)w * 32 * 64 + lane) * 2;
-    if (dn) return;
     SymHalf T0, T1;
-    spk_load(T0, tp, 0);
+    spk_load(T0, tp, 0);                                  // (in flight before the done word is looked at: no round trip in front of the stream)
+    if (dn) return;
     spk_load(T1, tp, 1);
     L.bsh[tid] = mine;
     __syncthreads();
@@ -1034,11 +1113,13 @@ __global__ __launch_bounds__(256, OEM_SYM_MINWG) void sympk_gemv_kernel(const do
     sym_combine(L, ds, P, qpad, I, J, diag, tid, w, a, bb);
 }
 
-// the NBLK slots of 64 coordinates per workgroup: wave w adds slots [w NBLK / 4, (w + 1) NBLK / 4) in slot order, the four wave sums
-// meet as (s0 + s1) + (s2 + s3) -- one fixed order, the same in the sum kernel and in the head
-__device__ __forceinline__ double spk_slot_sum(const double *__restrict__ P, int nblk, int qpad, int c, int w, double (*sh)[64], int l)
+// the NBLK slots of SPK_HC = 32 coordinates per workgroup: thread (ch = tid / 32, l = tid % 32) adds slots [ch NBLK / 8, (ch + 1) NBLK / 8) of
+// coordinate l in slot order -- at q = 8,192 eight loads, all in flight at once: the kernel is one memory round trip -- and the eight
+// chunk sums meet as ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)): one fixed order, the same in the sum kernel and in the head
+constexpr int SPK_HC = 32;
+__device__ __forceinline__ double spk_slot_sum(const double *__restrict__ P, int nblk, int qpad, int c, int ch, double (*sh)[SPK_HC], int l)
 {
-    const int k0 = (w * nblk) >> 2, k1 = ((w + 1) * nblk) >> 2;
+    const int k0 = (ch * nblk) >> 3, k1 = ((ch + 1) * nblk) >> 3;
     const double *pc = P + (size_t)k0 * qpad + c;
     double s = 0.0;
     int k = k0;
@@ -1049,20 +1130,26 @@ __device__ __forceinline__ double spk_slot_sum(const double *__restrict__ P, int
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += t[u];
     }
-    for (; k < k1; ++k, pc += qpad) s += *pc;
-    sh[w][l] = s;
+    {                                                      // the rest of the chunk (< 8 slots), branch-free loads of a clamped slot
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = pc[(ptrdiff_t)(k + u < k1 ? u : k1 - 1 - k) * qpad];      // (never past the chunk's last slot)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (k + u < k1) ? t[u] : 0.0;
+    }
+    sh[ch][l] = s;
     __syncthreads();
-    return (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
+    return ((sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l])) + ((sh[4][l] + sh[5][l]) + (sh[6][l] + sh[7][l]));
 }
 
 __global__ __launch_bounds__(256) void sympk_sum_kernel(const double *__restrict__ P, int nblk, int q, int qpad, double *__restrict__ out,
                                                          const int *__restrict__ done)
 {
-    __shared__ double sh[4][64];
-    if (done && *done) return;
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.x * 64 + l;
-    const double s = spk_slot_sum(P, nblk, qpad, c, w, sh, l);
-    if (w == 0 && c < q) out[c] = s;
+    __shared__ double sh[8][SPK_HC];
+    const int dn = done ? *done : 0;                      // (consumed behind the slot loads)
+    const int l = threadIdx.x & (SPK_HC - 1), ch = threadIdx.x / SPK_HC, c = blockIdx.x * SPK_HC + l;
+    const double s = spk_slot_sum(P, nblk, qpad, c, ch, sh, l);
+    if (ch == 0 && c < q && !dn) out[c] = s;
 }
 
 // Element-wise penalties: the slot sum IS the head of oem_symfused_kernel -- state, "still moving" words of the previous launch, the
@@ -1071,9 +1158,9 @@ __global__ __launch_bounds__(256) void sympk_sum_kernel(const double *__restrict
 __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__restrict__ S, double *__restrict__ B, const double *__restrict__ P,
                                                           int *__restrict__ flags, int *__restrict__ fdone, int par, double d, int nblk, int qpad)
 {
-    __shared__ double sh[4][64];
-    const int q = A.p, nl = A.nl, tid = threadIdx.x, l = tid & 63, w = tid >> 6, cm = blockIdx.x * 64 + l;
-    const bool own = w == 0 && cm < q;
+    __shared__ double sh[8][SPK_HC];
+    const int q = A.p, nl = A.nl, tid = threadIdx.x, l = tid & (SPK_HC - 1), ch = tid / SPK_HC, cm = blockIdx.x * SPK_HC + l;
+    const bool own = ch == 0 && cm < q;
     const SState st = S[par];
     const double *__restrict__ bin = B + (size_t)par * qpad;
     double *__restrict__ bout = B + (size_t)(par ^ 1) * qpad;
@@ -1081,11 +1168,11 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
 #pragma unroll
     for (int k = 0; k < FMAXB / 256; ++k) { const int t = tid + 256 * k; fl[k] = flags[par * FMAXB + (t < (int)gridDim.x ? t : 0)]; }
     const double bo = own ? bin[cm] : 0.0, xyc = own ? A.xy[cm] : 0.0, pfc = own ? A.pf[cm] : 0.0;
+    const double g = spk_slot_sum(P, nblk, qpad, cm, ch, sh, l);    // (fresh: P is not there yet and g is not used; the loads are issued before the state is looked at)
     if (st.done) {                                                  // the launch after the last one: make both copies agree
         if (blockIdx.x == 0 && tid == 0) { S[par ^ 1].done = 1; *fdone = 1; }
         return;
     }
-    const double g = spk_slot_sum(P, nblk, qpad, cm, w, sh, l);     // (fresh: P is not there yet and g is not used)
     int f = 0;
 #pragma unroll
     for (int k = 0; k < FMAXB / 256; ++k) f |= (tid + 256 * k < (int)gridDim.x) ? fl[k] : 0;
@@ -1142,6 +1229,30 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
     if (own) bout[cm] = bn;
     const int mv = __syncthreads_or(moving ? 1 : 0);
     if (tid == 0) flags[(par ^ 1) * FMAXB + blockIdx.x] = mv;
+}
+
+// out = XX vec through the packed triangle (pack, then `reps` products back to back between two HIP events on the stream):
+// *us_per_product is the product kernel's own duration -- what bench.py prices against the HBM peak (oemgpu_selftest_sympk_gemv)
+int sympk_gemv_probe(hipStream_t s, const double *xx, int q, double *pk, const double *vec, double *out, int reps, double *us_per_product)
+{
+    const int nb = spk_nblk(q), qpad = nb * SYM_TB, nt = (int)spk_ntile(q);
+    double *P = pk + (size_t)nt * SPK_TILE;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    OEM_HIP(hipEventCreate(&e0));
+    OEM_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(sympk_pack_kernel, dim3(nt), dim3(256), 0, s, xx, q, pk);
+    hipLaunchKernelGGL(sympk_gemv_kernel, dim3(nt), dim3(256), 0, s, pk, q, qpad, vec, P, (const int *)nullptr);     // (warm)
+    OEM_HIP(hipEventRecord(e0, s));
+    for (int k = 0; k < reps; ++k) hipLaunchKernelGGL(sympk_gemv_kernel, dim3(nt), dim3(256), 0, s, pk, q, qpad, vec, P, (const int *)nullptr);
+    OEM_HIP(hipEventRecord(e1, s));
+    hipLaunchKernelGGL(sympk_sum_kernel, dim3(qpad / SPK_HC), dim3(256), 0, s, P, nb, q, qpad, out, (const int *)nullptr);
+    OEM_HIP(hipGetLastError());
+    OEM_HIP(hipStreamSynchronize(s));
+    float ms = 0.0f;
+    OEM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (us_per_product) *us_per_product = reps > 0 ? 1e3 * (double)ms / reps : 0.0;
+    return 0;
 }
 
 size_t sympk_doubles(int q)
@@ -1471,7 +1582,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     }
     auto spk_gemv = [&](const double *vec, double *out, const int *done) {
         hipLaunchKernelGGL(sympk_gemv_kernel, dim3(spk_nt), dim3(256), 0, s, a.sympk, q, spk_qpad, vec, spk_P, done);
-        if (out) hipLaunchKernelGGL(sympk_sum_kernel, dim3(spk_qpad / 64), dim3(256), 0, s, spk_P, spk_nb, q, spk_qpad, out, done);
+        if (out) hipLaunchKernelGGL(sympk_sum_kernel, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, spk_P, spk_nb, q, spk_qpad, out, done);
     };
     auto sym_gemv = [&](const double *vec, double *out) {
         if (spk) spk_gemv(vec, out, nullptr);
@@ -1510,7 +1621,9 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
                     int rc = launch_gemv(s, a.xx, q, v, w, nullptr, num_cu);
                     if (rc) return rc;
                 }
-                hipLaunchKernelGGL(lanczos_update_kernel, dim3(1), dim3(1024), 0, s, q, m, v, vp, w, T);
+                if (q > 4096 && q <= 8192) hipLaunchKernelGGL(lanczos_update_reg_kernel<8>, dim3(1), dim3(1024), 0, s, q, m, v, vp, w, T);
+                else if (q > 8192 && q <= 12288) hipLaunchKernelGGL(lanczos_update_reg_kernel<12>, dim3(1), dim3(1024), 0, s, q, m, v, vp, w, T);
+                else hipLaunchKernelGGL(lanczos_update_kernel, dim3(1), dim3(1024), 0, s, q, m, v, vp, w, T);
             }
         }
         OEM_HIP(hipGetLastError());
@@ -1540,7 +1653,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     if (a.npen == 0) return 0;
 
     // ---- q > 4096, element-wise penalties: (head, product) pairs over the packed triangle
-    if (spk && a.ngroups == 0 && !a.accelerate && !a.compute_loss && !a.sinv && spk_qpad / 64 <= FMAXB && !sw().OEM_NO_FUSED.set) {
+    if (spk && a.ngroups == 0 && !a.accelerate && !a.compute_loss && !a.sinv && spk_qpad / SPK_HC <= FMAXB && !sw().OEM_NO_FUSED.set) {
         int *flags = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad);
         SState *SS = reinterpret_cast<SState *>(spk_B + 2 * (size_t)spk_qpad + FMAXB);
         int *fdone = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad + FMAXB + 16);
@@ -1548,7 +1661,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         auto enq = [&](int count) {
             for (int k = 0; k < count; ++k) {
                 const int par = k & 1;
-                hipLaunchKernelGGL(sympk_head_kernel, dim3(spk_qpad / 64), dim3(256), 0, s, a, SS, spk_B, spk_P, flags, fdone, par, d, spk_nb, spk_qpad);
+                hipLaunchKernelGGL(sympk_head_kernel, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, a, SS, spk_B, spk_P, flags, fdone, par, d, spk_nb, spk_qpad);
                 hipLaunchKernelGGL(sympk_gemv_kernel, dim3(spk_nt), dim3(256), 0, s, a.sympk, q, spk_qpad, spk_B + (size_t)(par ^ 1) * spk_qpad, spk_P, fdone);
             }
         };
@@ -1619,8 +1732,10 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     //      hand-off was measured and is NOT faster: the agent-scope release + acquire cost what the boundary costs.
     double *uf = nullptr;
     const size_t sh = update_lds(a, &uf);                            // (U and F exist for group operators only)
+    // (4096 < q <= 8192: the operands in registers, every independent load of the kernel issued at once)
+    void (*updk)(PathArgs, LState *, double *, const double *, double *) = (q > 4096 && q <= 8192) ? path_update_kernel<8> : path_update_kernel<0>;
     if (sh > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&path_update_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(updk),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %zu): %s", sh, hipGetErrorString(e)); return OEMGPU_ERR_HIP; }
     }
@@ -1628,7 +1743,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         for (int k = 0; k < count; ++k) {
             if (spk) spk_gemv(beta, g, &st->done);
             else (void)launch_gemv(s, a.xx, q, beta, g, &st->done, num_cu);
-            hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), sh, s, a, st, beta, g, uf);
+            hipLaunchKernelGGL(updk, dim3(1), dim3(1024), sh, s, a, st, beta, g, uf);
         }
     };
     return replay_batches(s, enqueue, &st->done, reinterpret_cast<int *>(host_scratch), (long long)a.npen * a.nl * ((long long)a.maxit + 2) + 8, "large-p engine");
@@ -2154,12 +2269,12 @@ static int run_path_wide_blocks(hipStream_t s, const PathArgs &a, const WideArgs
     if (a.npen == 0) return 0;
     double *uf = nullptr;
     const size_t shu = update_lds(a, &uf);
-    if (shu > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shu));
+    if (shu > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_update_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shu));
     auto enq = [&](int count) {
         for (int k = 0; k < count; ++k) {
             xb(beta, t, (const int *)&st->done);
             xtv(t, g, (const int *)&st->done);
-            hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), shu, s, a, st, beta, g, uf);
+            hipLaunchKernelGGL(path_update_kernel<0>, dim3(1), dim3(1024), shu, s, a, st, beta, g, uf);
         }
     };
     const int FB = 16;
@@ -2261,7 +2376,7 @@ static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd
     if (gfused && ldsg > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_groups_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
     double *uf = nullptr;
     const size_t shu = update_lds(a, &uf);                           // U[q] | F[ngroups]: group operators only
-    if (!fused && shu > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shu));
+    if (!fused && shu > 64 * 1024) OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&path_update_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shu));
     if (fused || gfused) hipLaunchKernelGGL(sym_init_kernel, dim3(1), dim3(1), 0, s, SS, a);
     auto enq = [&](int count) {
         for (int k = 0; k < count; ++k) {
@@ -2279,7 +2394,7 @@ static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd
                 hipLaunchKernelGGL((wide_reduce_kernel<W_XB>), dim3(rblocks), dim3(1024), 0, s, P, W, npad, n, wd.ys, t, (const int *)&st->done);
                 hipLaunchKernelGGL((wide_cols_kernel<NR, W_XTV>), dim3(W), dim3(NT), lds, s, a, wd.xs, t, wd.ys, P, (double *)nullptr, g,
                                    (SState *)nullptr, (int *)nullptr, (int *)nullptr, (const int *)&st->done, 0, d, n, cpw);
-                hipLaunchKernelGGL(path_update_kernel, dim3(1), dim3(1024), shu, s, a, st, beta, g, uf);
+                hipLaunchKernelGGL(path_update_kernel<0>, dim3(1), dim3(1024), shu, s, a, st, beta, g, uf);
             }
         }
     };

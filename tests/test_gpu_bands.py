@@ -83,6 +83,61 @@ def test_xtx_beyond_4096_runs_the_launch_engines(oa, p):
             _same_path(f, r, k, (p, "scale.factor", kw["penalty"][k]))
 
 
+def test_xtx_beyond_4096_streams_the_packed_lower_triangle(oa, monkeypatch):
+    """q > 4096 (round 6): every product is ONE sweep over a packed copy of the lower triangle of XX (path_large.hip: sympk_*, 4 q^2 bytes
+    where the row-streaming kernel reads 8 q^2; ref src/oem_xtx.h:378-381, src/oem_dense.h:508-512).  q = 6,145: a ragged last block
+    and rows that are only 8-byte aligned (q odd).  Element-wise penalties take the (head, product) pairs; lasso + grp.lasso in the
+    parametrised test above the product + slot sum + update kernel form.  Against the oracle, run to run (fixed summation order:
+    the same bits), and against the row-streaming kernels (OEM_NO_SYM=1) on the same problem."""
+    import torch
+    p = 6145
+    xtx, xty = _gram_problem(p, p + p // 2, 6145)
+    xd = torch.as_tensor(xtx, device="cuda")
+    kw = dict(penalty=["lasso", "mcp", "scad.net", "ols"], alpha=0.7, nlambda=4, lambda_min_ratio=0.05, tol=1e-9, maxit=400)
+    f = oa.oem_xtx(xd, xty, **kw)
+    assert oa.last_path_engine()[0] == "launches"
+    lmax = _lam_max(xtx)
+    assert abs(f["d"] - 1.005 * lmax) <= DTOL * lmax, (f["d"], 1.005 * lmax)
+    r = orc.fit_xtx(xtx, xty, native=True, d_override=f["d"], **kw)
+    for k in range(4):
+        _same_path(f, r, k, (p, kw["penalty"][k]))
+    g = oa.oem_xtx(xd, xty, **kw)
+    assert g["d"] == f["d"] and all(np.array_equal(np.asarray(g["beta"][k]), np.asarray(f["beta"][k])) for k in range(4))
+    monkeypatch.setenv("OEM_NO_SYM", "1")
+    h = oa.oem_xtx(xd, xty, **kw)
+    monkeypatch.delenv("OEM_NO_SYM")
+    assert abs(h["d"] - f["d"]) <= 1e-13 * f["d"]
+    for k in range(4):
+        _same_path(f, h, k, ("row-streaming", kw["penalty"][k]), tol=1e-12)
+    # the three-launch form (the whole of u in one place: here `scale.factor`) at the same ragged size
+    sf = np.linspace(0.5, 2.0, p)
+    kw2 = dict(penalty=["lasso"], nlambda=3, lambda_min_ratio=0.1, tol=1e-9, maxit=400, scale_factor=sf)
+    f2 = oa.oem_xtx(xd, xty, **kw2)
+    r2 = orc.fit_xtx(xtx, xty, native=True, d_override=f2["d"], **kw2)
+    _same_path(f2, r2, 0, (p, "scale.factor"))
+
+
+@pytest.mark.parametrize("q", [4097, 4224, 6145])
+def test_packed_triangle_product_against_numpy(oa, q):
+    """The product kernel on its own (oemgpu_selftest_sympk_gemv): out = XX v through the packed lower triangle -- the first size past the
+    register engines (one ragged block of one row), a multiple of 128, and an odd ragged size -- against numpy; and the same bits twice."""
+    import ctypes as C
+    import torch
+    from oem_amd import _lib as L
+    rng = np.random.default_rng(q)
+    a = rng.normal(size=(q, q)); a = (a + a.T) / 2
+    v = rng.normal(size=q)
+    ad, vd = torch.as_tensor(a, device="cuda"), torch.as_tensor(v, device="cuda")
+    o1, o2 = torch.empty_like(vd), torch.empty_like(vd)
+    us = C.c_double(0.0)
+    ctx = oa.context()
+    L.check(L.lib().oemgpu_selftest_sympk_gemv(ctx, ad.data_ptr(), q, vd.data_ptr(), o1.data_ptr(), 2, C.byref(us)))
+    L.check(L.lib().oemgpu_selftest_sympk_gemv(ctx, ad.data_ptr(), q, vd.data_ptr(), o2.data_ptr(), 0, C.byref(us)))
+    ref = a @ v
+    assert np.abs(o1.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert torch.equal(o1, o2)
+
+
 def test_dense_n_gt_p_at_p_5000(oa):
     """oem() with n > p at p = 5,000 (standardised, with an intercept): the MFMA moment pass at 5,002 columns, the eigen step and
     the launch-per-iteration path engines behind it."""

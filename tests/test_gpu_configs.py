@@ -182,7 +182,7 @@ def _engines(f):
         try:
             two = f()
         finally:
-            del os.environ["OEM_NO_FUSED"]
+            del os.environ["OEM_NO_FUSED"]; reload_switches()
     finally:
         del os.environ["OEM_NO_COOP"]; reload_switches()
     return coop, fused, two
