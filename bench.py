@@ -103,19 +103,10 @@ def c5_weak(torch, dist, world, rank, dev, backend, rows, steps, warmup):
     L.check(lib.oemgpu_set_timing(backend.ctx, 0))
     acc /= 5
     # the collective on its own: the (p+2)^2 moment buffer of this workload (HIP events on the stream the collectives are ordered on)
-    allreduce_ms = None
+    allreduce_ms = allgather_ms = None
     if world > 1:
-        scratch = bufs[1].clone()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with backend.section():
-            for _ in range(5):
-                dist.all_reduce(scratch)
-            e0.record()
-            for _ in range(50):
-                dist.all_reduce(scratch)
-            e1.record()
-        torch.cuda.synchronize()
-        allreduce_ms = e0.elapsed_time(e1) / 50
+        ex = time_exchanges(torch, dist, backend, bufs[1])
+        allreduce_ms, allgather_ms = ex["allreduce_ms"], ex["allgather_ms"]
     flops = float(rows) * p * (p + 1) + 2.0 * rows * p
     nit = int(np.sum(args.niter))
     del x, xt, y
@@ -125,10 +116,30 @@ def c5_weak(torch, dist, world, rank, dev, backend, rows, steps, warmup):
             "rows_per_gpu": rows, "n_total": rows * world, "rows_per_second": rows * world * steps / dt,
             "stage_ms": {"moments_total": acc[L.T_MOMENTS], "gram_kernel": acc[L.T_GRAMK], "finalize": acc[L.T_FINAL],
                          "eigen_plus_path": acc[L.T_EIGPATH]},
-            "allreduce_ms": allreduce_ms, "allreduce_doubles": (p + 2) * (p + 2),
+            "allreduce_ms": allreduce_ms, "allgather_ms": allgather_ms, "allreduce_doubles": (p + 2) * (p + 2),
             "gram_TFLOPs": flops / (acc[L.T_GRAMK] * 1e-3) / 1e12 if acc[L.T_GRAMK] > 0 else None,
             "gram_frac_of_fp64_mfma_peak": flops / (acc[L.T_GRAMK] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if acc[L.T_GRAMK] > 0 else None,
             "oem_iterations_per_solve": nit}
+
+
+def time_exchanges(torch, dist, backend, buf, reps=50):
+    """The two ways of summing a moment buffer over the ranks, each on its own (HIP events on the stream the collectives are ordered on):
+    dist.all_reduce, and the default of oem_amd/distributed.py -- one all-gather + one kernel that adds the buffers in rank order."""
+    from oem_amd.distributed import sum_over_ranks
+    res = {}
+    for name, mode in (("allreduce_ms", "allreduce"), ("allgather_ms", "ordered")):
+        scratch = buf.clone()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with backend.section():
+            for _ in range(5):
+                sum_over_ranks(backend, dist, None, scratch, mode)
+            e0.record()
+            for _ in range(reps):
+                sum_over_ranks(backend, dist, None, scratch, mode)
+            e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / reps
+    return res
 
 
 def _free_port():
@@ -431,19 +442,10 @@ def main():
     dt = time.perf_counter() - t0
     beta_timed = args.beta.copy()
     # ---- the collective on its own: the (p+2)^2 moment buffer, HIP events on the stream the collectives are ordered on
-    allreduce_ms = None
+    allreduce_ms = allgather_ms = None
     if world > 1:
-        scratch = bufs[1].clone()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with backend.section():
-            for _ in range(5):
-                dist.all_reduce(scratch)
-            e0.record()
-            for _ in range(50):
-                dist.all_reduce(scratch)
-            e1.record()
-        torch.cuda.synchronize()
-        allreduce_ms = e0.elapsed_time(e1) / 50
+        ex = time_exchanges(torch, dist, backend, bufs[1])
+        allreduce_ms, allgather_ms = ex["allreduce_ms"], ex["allgather_ms"]
     # Two callers at once (two host threads, two contexts / streams, the same resident X): the path kernel of one solve occupies ONE
     # CU for 0.30 ms, so the moment pass of the other caller's solve runs beside it.  Reported as an extra, never as `value`: a
     # solve is still 0.5 ms long, this is what the chip delivers when the solves are independent.  Each thread runs for a fixed
@@ -535,21 +537,15 @@ def main():
             os.environ["OEM_FORCE_COLLECTIVES"] = "1"
             ar = new_args()
             bf, ou = sharded_buffers(backend, p), ar.outputs(p + 1)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             with backend.section():
                 for _ in range(3):
                     solve_row_shards(backend, dist, None, x, n_loc, n_loc, p, y, bf, L.OEMGPU_SEM_DENSE, False, True, ar, ou)
-                scratch = bf[1].clone()
-                for _ in range(5):
-                    dist.all_reduce(scratch)
-                e0.record()
-                for _ in range(50):
-                    dist.all_reduce(scratch)
-                e1.record()
             torch.cuda.synchronize()
+            ex = time_exchanges(torch, dist, backend, bf[1])
             rccl_check = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
                           "same_bits_as_the_plain_solve": bool(np.array_equal(ar.beta, beta_timed)),
-                          "allreduce_ms": e0.elapsed_time(e1) / 50, "allreduce_doubles": int(scratch.numel())}
+                          "allreduce_ms": ex["allreduce_ms"], "allgather_ms": ex["allgather_ms"], "allreduce_doubles": int(bf[1].numel()),
+                          "exchange": "the solve sums its moment buffers by ONE all-gather + one kernel in rank order (allgather_ms); allreduce_ms is dist.all_reduce of the same buffer"}
             if not in_group:
                 dist.destroy_process_group()
         except Exception as e:                   # the headline line must print whatever RCCL does on this box
@@ -598,6 +594,7 @@ def main():
             "rccl_ranks": world if coll_backend == "nccl" else (rccl_check or {}).get("rccl_ranks"),
             "collective_backend": coll_backend if coll_backend else (rccl_check or {}).get("backend"),
             "allreduce_ms": allreduce_ms if allreduce_ms is not None else (rccl_check or {}).get("allreduce_ms"),
+            "allgather_ms": allgather_ms if allgather_ms is not None else (rccl_check or {}).get("allgather_ms"),
             "allreduce_doubles": (p + 2) * (p + 2),
             "rccl_selfcheck": rccl_check,
             "throughput_two_callers": two_callers,
@@ -641,15 +638,17 @@ def main():
     if rank == 0:
         # ONE object per run that explains this point of the 1 -> N curve for BOTH workloads: per-GPU rows and
         # where a step's time goes -- the moment pass on the local rows, the one all-reduce, the replicated solve
-        def _point(value, ms_step, rows, st, ar):
+        def _point(value, ms_step, rows, st, ar, ag):
             return {"value_solves_per_s": value, "ms_per_step": ms_step, "rows_per_gpu": rows, "moments_ms": st.get("moments_total"),
-                    "allreduce_ms": ar, "solve_ms": (st.get("finalize") or 0.0) + (st.get("eigen_plus_path") or 0.0)}
-        curve = {"n_gpus": world, "c1_strong": _point(out["value"], out["ms_per_step"], n_loc, out["stage_ms"], out.get("allreduce_ms") if world > 1 else None)}
+                    "allreduce_ms": ar, "allgather_ms": ag, "solve_ms": (st.get("finalize") or 0.0) + (st.get("eigen_plus_path") or 0.0)}
+        curve = {"n_gpus": world, "c1_strong": _point(out["value"], out["ms_per_step"], n_loc, out["stage_ms"], out.get("allreduce_ms") if world > 1 else None,
+                                                      out.get("allgather_ms") if world > 1 else None)}
         r5o = out.get("c5_weak")
         if isinstance(r5o, dict) and "value" in r5o:
-            curve["c5_weak"] = _point(r5o["value"], r5o["ms_per_step"], r5o["rows_per_gpu"], r5o["stage_ms"], r5o.get("allreduce_ms"))
-        curve["note"] = ("c1: n = 1e6 rows split over the GPUs (strong: the moment pass shrinks, all-reduce and solve do not); c5: 1.25e7 rows on "
-                         "EVERY GPU (weak: all three stay, the all-reduce grows with log N at most).  No 1 -> 8 curve has been measured on hardware "
+            curve["c5_weak"] = _point(r5o["value"], r5o["ms_per_step"], r5o["rows_per_gpu"], r5o["stage_ms"], r5o.get("allreduce_ms"), r5o.get("allgather_ms"))
+        curve["note"] = ("c1: n = 1e6 rows split over the GPUs (strong: the moment pass shrinks, the exchange and the solve do not); c5: 1.25e7 rows on "
+                         "EVERY GPU (weak: all three stay).  The timed steps sum the moment buffers by one all-gather + one kernel in rank order "
+                         "(allgather_ms; fixed summation order); allreduce_ms is dist.all_reduce of the same buffer, for comparison.  No 1 -> 8 curve has been measured on hardware "
                          "by the builder: these objects from the driver's N = 1, 2, 4, 8 runs are the curve and its explanation")
         out["scaling_point"] = curve
     if rank == 0 and world == 1 and not a.no_host:

@@ -180,6 +180,13 @@ int oemgpu_shift_sums_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64
 int oemgpu_moments_dev(oemgpu_ctx *ctx, const double *x_dev, int64_t n, int64_t ld, int32_t p,
                        const double *y_dev, const double *sums_dev, double *moments_dev);
 
+/* out_dev[i] = ((parts[0][i] + parts[1][i]) + parts[2][i]) + ...: `nparts` buffers of `len` doubles, contiguous one behind the other
+ * (an all-gather of the ranks' moment buffers), added in shard order by ONE kernel -- the order the in-library multi-GPU path
+ * (opts.ngpus) adds its devices' buffers in, so both forms return the same bits whatever algorithm a collective library would
+ * choose for an all-reduce.  The reference's own order is the arrival order of its threads at a critical section
+ * (ref src/oem_dense.h:328-358).  Asynchronous on the context's stream. */
+int oemgpu_sum_in_order_dev(oemgpu_ctx *ctx, const double *parts_dev, int32_t nparts, int64_t len, double *out_dev);
+
 /* semantics selector for oemgpu_solve_moments_dev */
 #define OEMGPU_SEM_DENSE 0   /* DataStd + oemDense (ref src/DataStd.h, src/oem_dense.h) */
 #define OEMGPU_SEM_BIG   1   /* oemBig: (n-1)-scaling, intercept as Gram row/column (ref src/oem_big.h:731-842,469-566) */
@@ -267,7 +274,9 @@ enum {
 int oemgpu_last_path_engine(oemgpu_ctx *ctx, int32_t *engine, int32_t *persistent_fallbacks);
 /* OEMGPU_ENGINE_COOP with q <= 512 puts the cooperating workgroups of an instance on ONE XCD where the device's layout allows (the
  * exchange then stays in that XCD's L2).  Of the most recent path launch on this context: 0 not asked for, 1 ran on one XCD, 2 asked for,
- * refused by the launch's own proof of placement and made again with the exchange at device scope. */
+ * refused by the launch's own proof of placement and made again with the exchange at device scope (this context does not ask again),
+ * 3 asked for, but an instance's workgroups were not all resident on its XCD (somebody else holds CUs there): made again once with the
+ * workgroups anywhere on the device. */
 int oemgpu_last_placement(oemgpu_ctx *ctx);
 
 /* 1 if the most recent oemgpu_solve_moments_dev on this context found the shift predicate above true for its
@@ -336,6 +345,13 @@ int oemgpu_selftest_gram_plan(int64_t n, int32_t p, int32_t num_cu, int64_t *out
 /* Self-test aid (tests/test_gpu_host.py): enqueue, on the context's stream, `blocks` workgroups that each occupy a whole CU and
  * spin for `ms` milliseconds -- "somebody else holds the CUs", for the fallback of the persistent engines.  Asynchronous. */
 int oemgpu_selftest_hold_cus(oemgpu_ctx *ctx, int32_t blocks, double ms);
+
+/* Host-only self-check of the CU-slot book of the persistent engines (pure arithmetic, runs without a GPU): `calls` concurrent callers
+ * each place `ninst` instances of W cooperating workgroups with every instance on ONE XCD of a device with num_cu CUs (path_coop.hip,
+ * q <= 512).  bases[k] = the XCD of call k's first instance (chosen where the XCDs are emptiest), *peak = the most CUs any XCD was
+ * booked for while all calls were in flight (<= num_cu / 8 whenever that is possible).  OEMGPU_ERR_ARG if the calls would have to
+ * wait for each other (more than 3/4 of the CUs). */
+int oemgpu_selftest_coop_slots(int32_t num_cu, int32_t W, int32_t ninst, int32_t calls, int32_t *bases, int32_t *peak);
 
 /* Self-test / measurement aid: out = XX vec for a symmetric q x q matrix (q > 4096, column-major, device) through the packed lower
  * triangle the launch-per-iteration Gram engine streams beyond q = 4096 (path_large.hip: sympk_*; replaces the GEMV of

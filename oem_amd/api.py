@@ -233,7 +233,7 @@ def last_path_engine(ctx=None):
 def last_placement(ctx=None):
     """"none" / "one-xcd" / "refused": whether the cooperating engine of the most recent path launch on this context ran with all
     workgroups of an instance on one XCD (include/oemgpu.h: oemgpu_last_placement)."""
-    return ("none", "one-xcd", "refused")[L.lib().oemgpu_last_placement(ctx if ctx is not None else context())]
+    return ("none", "one-xcd", "refused", "crowded")[L.lib().oemgpu_last_placement(ctx if ctx is not None else context())]
 
 
 def context(device=None, stream=None):

@@ -70,20 +70,61 @@ static const int COOP_MAX_DEV = 64;
 static std::mutex g_coop_mu;
 static std::condition_variable g_coop_cv;
 static int g_coop_in_flight[COOP_MAX_DEV] = {0};
+static int g_xcd_load[COOP_MAX_DEV][8] = {{0}};                    // CUs of every XCD booked by persistent launches in flight (per device, under g_coop_mu)
 static std::atomic<unsigned> g_xcd_next{(unsigned)getpid()};      // (processes that share a GPU start at different XCDs more often than not)
+// CU slots of the persistent engines: all workgroups of all such kernels in flight must be resident at once, so concurrent callers queue.
+// Booked per device AND per XCD: a device-scope launch of `want` workgroups is dealt round the XCDs by the dispatcher
+// (ceil(want / 8) CUs of each); a one-XCD launch (path_coop.hip, q <= 512) puts the W workgroups of instance y on XCD (base + y) mod 8
+// and gets the base for which the fullest XCD it touches stays emptiest -- and waits while no base leaves every XCD within its CUs.
 struct CoopSlots {
     int n = 0, dev = 0;
+    int add[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     void take(int device, int want, int capacity)
     {
         dev = (device >= 0 && device < COOP_MAX_DEV) ? device : COOP_MAX_DEV - 1;
         std::unique_lock<std::mutex> lk(g_coop_mu);
         g_coop_cv.wait(lk, [&] { return g_coop_in_flight[dev] == 0 || g_coop_in_flight[dev] + want <= capacity; });
-        g_coop_in_flight[dev] += want; n = want;
+        g_coop_in_flight[dev] += want; n += want;
+        for (int x = 0; x < 8; ++x) { const int a = (want + 7) / 8; add[x] += a; g_xcd_load[dev][x] += a; }
     }
-    ~CoopSlots()
+    // `ninst` instances of W workgroups, each on ONE XCD of a device with num_cu CUs; returns the XCD of instance 0
+    int take_local(int device, int W, int ninst, int num_cu, int capacity)
     {
-        if (n) { { std::lock_guard<std::mutex> lk(g_coop_mu); g_coop_in_flight[dev] -= n; } g_coop_cv.notify_all(); }
+        dev = (device >= 0 && device < COOP_MAX_DEV) ? device : COOP_MAX_DEV - 1;
+        const int per = num_cu / 8, want = W * ninst, start = (int)(g_xcd_next.fetch_add(1u, std::memory_order_relaxed) & 7u);
+        int best = -1;
+        auto fits = [&](bool must) {
+            best = -1;
+            int best_peak = 0;
+            for (int k = 0; k < 8; ++k) {
+                const int base = (start + k) & 7;
+                int peak = 0;
+                for (int x = 0; x < 8; ++x) {
+                    const int cnt = ninst / 8 + (((x - base) & 7) < ninst % 8 ? 1 : 0);       // instances y with (base + y) mod 8 == x
+                    if (cnt) { const int l = g_xcd_load[dev][x] + cnt * W; if (l > peak) peak = l; }
+                }
+                if (best < 0 || peak < best_peak) { best = base; best_peak = peak; }
+            }
+            return must || best_peak <= per;
+        };
+        std::unique_lock<std::mutex> lk(g_coop_mu);
+        g_coop_cv.wait(lk, [&] { return g_coop_in_flight[dev] == 0 ? fits(true) : (g_coop_in_flight[dev] + want <= capacity && fits(false)); });
+        g_coop_in_flight[dev] += want; n += want;
+        for (int x = 0; x < 8; ++x) {
+            const int a = (ninst / 8 + (((x - best) & 7) < ninst % 8 ? 1 : 0)) * W;
+            add[x] += a; g_xcd_load[dev][x] += a;
+        }
+        return best;
     }
+    void release()
+    {
+        if (n) {
+            { std::lock_guard<std::mutex> lk(g_coop_mu); g_coop_in_flight[dev] -= n; for (int x = 0; x < 8; ++x) { g_xcd_load[dev][x] -= add[x]; add[x] = 0; } }
+            n = 0;
+            g_coop_cv.notify_all();
+        }
+    }
+    ~CoopSlots() { release(); }
 };
 
 // (kernel, device) -> largest dynamic-LDS limit set so far
@@ -692,15 +733,15 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     // The persistent engines spin on their partners: every workgroup of every such kernel in flight must be resident at once, so
     // concurrent callers queue for CU slots (held until the stream has been synchronised below)
     CoopSlots slots;
-    // (one XCD: an instance's <= 16 workgroups compete for the 32 CUs of ITS XCD.  Such a call books every XCD it touches whole; with the
-    // 3/4 capacity at most six instances of concurrent callers are in flight, their first XCDs handed out in turn (g_xcd_next), so no XCD
-    // is ever asked for more than two instances = all of its CUs)
+    // (one XCD: an instance's <= 16 workgroups compete for the 32 CUs of ITS XCD -- booked per XCD, the first XCD chosen where the load is lowest)
     // (a reload of the switches -- tests -- also forgets a timed-out engine's back-off and a refused placement)
     if (c->sw_generation != sw().generation) { c->sw_generation = sw().generation; c->persistent_backoff = 0; c->persistent_skip = 0; if (c->xcd_layout < 0) c->xcd_layout = 0; }
     bool local = P.one_xcd && ctx_xcd_layout_ok(c);
-    {
-        const int ninst = (pen_split ? npen : 1) * nbatch;
-        if (coop) slots.take(c->device, local ? (c->num_cu / 8) * (ninst < 8 ? ninst : 8) : path_coop_workgroups(q) * ninst, c->num_cu * 3 / 4);
+    const int coop_ninst = (pen_split ? npen : 1) * nbatch;
+    int local_base = 0;
+    if (coop) {
+        if (local) local_base = slots.take_local(c->device, path_coop_workgroups(q), coop_ninst, c->num_cu, c->num_cu * 3 / 4);
+        else slots.take(c->device, path_coop_workgroups(q) * coop_ninst, c->num_cu * 3 / 4);
     }
     c->last_placement = 0;
     if (symcoop) slots.take(c->device, rowcoop ? path_rowcoop_workgroups(q) : symplan.G, c->num_cu * 3 / 4);
@@ -730,7 +771,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
         const bool persistent = any_persistent && attempt == 0;
         a.abort_word = (abortable && (persistent || (coop && attempt == 0))) ? c->abort_dev : nullptr;
         a.one_xcd = (coop && attempt == 0 && local) ? (sw().OEM_FAKE_XCD_MISMATCH.set ? 2 : 1) : 0;
-        a.xcd_base = a.one_xcd ? (int)(g_xcd_next.fetch_add(1u, std::memory_order_relaxed) & 7u) : 0;     // concurrent callers start at different XCDs
+        a.xcd_base = a.one_xcd ? local_base : 0;          // (CoopSlots::take_local: where this device's XCDs are emptiest)
         {
             Timer t(c, OEMGPU_T_EIGPATH);
             PollScope poll(o);
@@ -789,13 +830,23 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
         if (a.one_xcd) {
             // the launch's own proof of placement (path_coop.hip): poison value 2 in any instance = its workgroups were NOT on one XCD and
             // nothing was computed; this context does not ask again, and the call is made again with the exchange at device scope
-            bool refused = false;
+            // Poison 3 = a partner never came to the proof: the instance's workgroups were not co-resident on ITS XCD (somebody this process does
+            // not know of holds CUs there) -- and, for several instances (which have no second engine), a later exchange that timed out the same
+            // way: the call is made again ONCE with the workgroups anywhere on the device; no back-off, the context keeps asking.
+            bool refused = false, crowded = false;
             for (int bi = 0; bi < nbatch; ++bi) {
                 const double *hdb = (const double *)((const char *)c->pinned + (joined ? st_gap : 0) + (size_t)bi * out_stride) + nb + 2 * nk;
                 refused = refused || hdb[6] == 2.0;
+                crowded = crowded || hdb[6] == 3.0 || (nbatch > 1 && hdb[6] == 1.0);
             }
-            c->last_placement = refused ? 2 : 1;
-            if (refused) { c->xcd_layout = -1; local = false; --attempt; continue; }
+            c->last_placement = refused ? 2 : crowded ? 3 : 1;
+            if (refused) c->xcd_layout = -1;
+            if (refused || crowded) {
+                local = false; --attempt;
+                slots.release();
+                slots.take(c->device, path_coop_workgroups(q) * coop_ninst, c->num_cu * 3 / 4);
+                continue;
+            }
         }
         if (persistent) {
             const double *hd0 = (const double *)((const char *)c->pinned + (joined ? st_gap : 0)) + nb + 2 * nk;
@@ -881,6 +932,17 @@ size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o, int nbatch)
     b += (size_t)q * 12 + 64;                                          // the runs of the fused group kernel (p >= n)
     if (q > 1024 && q <= 4096) b += symcoop_xchg_bytes_max(q) + (size_t)(80 + WCOOP_GMAX * 96) * 4 + 1024;      // path_symcoop.hip's exchange area and plan
     return b;
+}
+
+// out[i] = ((parts[0][i] + parts[1][i]) + parts[2][i]) + ...: the shards' moment buffers added in shard (= rank = device) order -- the order
+// hoststream.hip adds them in, so the one-process-per-GPU form (all-gather + this kernel) and the in-library form return the same bits
+__global__ __launch_bounds__(256) void sum_in_order_kernel(const double *__restrict__ parts, int nparts, size_t len, double *__restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) {
+        double s = parts[i];
+        for (int r = 1; r < nparts; ++r) s += parts[(size_t)r * len + i];
+        out[i] = s;
+    }
 }
 
 __global__ void accumulate_kernel(double *__restrict__ dst, const double *__restrict__ src, size_t n)
@@ -1074,6 +1136,28 @@ int oemgpu_selftest_hold_cus(oemgpu_ctx *c, int32_t blocks, double ms)
     OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hold_cus_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(hold_cus_kernel, dim3(blocks), dim3(256), lds, c->stream, (unsigned long long)(ms * 1e5), (int *)nullptr);      // s_memrealtime: 100 MHz
     OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+int oemgpu_sum_in_order_dev(oemgpu_ctx *c, const double *parts_dev, int32_t nparts, int64_t len, double *out_dev)
+{
+    if (!c || !parts_dev || !out_dev || nparts < 1 || len < 1) { set_error("sum_in_order: bad argument"); return OEMGPU_ERR_ARG; }
+    if (set_device(c)) return OEMGPU_ERR_HIP;
+    const int blocks = (int)std::min<int64_t>((len + 255) / 256, 2048);
+    hipLaunchKernelGGL(sum_in_order_kernel, dim3(blocks), dim3(256), 0, c->stream, parts_dev, (int)nparts, (size_t)len, out_dev);
+    OEM_HIP(hipGetLastError());
+    return 0;
+}
+
+int oemgpu_selftest_coop_slots(int32_t num_cu, int32_t W, int32_t ninst, int32_t calls, int32_t *bases, int32_t *peak)
+{
+    if (num_cu < 8 || num_cu % 8 || W < 1 || ninst < 1 || calls < 1 || calls > 64 || !bases || !peak) { set_error("selftest_coop_slots: bad argument"); return OEMGPU_ERR_ARG; }
+    if ((long long)W * ninst * calls > num_cu * 3 / 4) { set_error("selftest_coop_slots: %d calls of %d x %d workgroups would wait for each other", calls, ninst, W); return OEMGPU_ERR_ARG; }
+    std::vector<CoopSlots> held(calls);
+    const int dev = COOP_MAX_DEV - 2;                    // (a device index no GPU of this process has: the book of a device of its own)
+    *peak = 0;
+    for (int k = 0; k < calls; ++k) bases[k] = held[k].take_local(dev, W, ninst, num_cu, num_cu * 3 / 4);
+    { std::lock_guard<std::mutex> lk(g_coop_mu); for (int x = 0; x < 8; ++x) if (g_xcd_load[dev][x] > *peak) *peak = g_xcd_load[dev][x]; }
     return 0;
 }
 

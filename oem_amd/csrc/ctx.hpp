@@ -66,7 +66,8 @@ struct oemgpu_ctx {
     // further timeout and starts over after a persistent launch that came back (or when the switches are read again).
     int persistent_backoff = 0, persistent_skip = 0;
     // path_coop.hip's one-XCD form: 0 not probed yet, 1 workgroup ids go round 8 XCDs (blockIdx % 8), -1 they do not (or a launch's own
-    // proof of placement failed once: never again on this context); what the last path launch did (0 n/a, 1 one XCD, 2 asked for and refused by the proof)
+    // proof of placement failed once: never again on this context); what the last path launch did (0 n/a, 1 one XCD, 2 asked for and refused by the proof,
+    // 3 asked for but not co-resident on its XCD: made again at device scope)
     int xcd_layout = 0, last_placement = 0;
     double persistent_skip_until = 0.0;        // steady-clock seconds
     unsigned sw_generation = 0;                // Switches::generation this state belongs to

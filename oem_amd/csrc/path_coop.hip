@@ -363,7 +363,7 @@ __global__ __launch_bounds__(NTH) void path_coop_kernel(PathArgs A_)
         const bool lost = __syncthreads_or(timed_out ? 1 : 0) != 0;                                   // a partner never came: the usual poison
         const bool apart = __syncthreads_or((there && tid < W && got.x != xcc) ? 1 : 0) != 0;        // not one XCD
         if (lost || apart) {
-            if (tid == 0) A.d_out[6] = lost ? 1.0 : 2.0;
+            if (tid == 0) A.d_out[6] = lost ? 3.0 : 2.0;       // (3: a partner never came to the PROOF -- the instance was not co-resident on its XCD; 2: not one XCD)
             return;
         }
     }

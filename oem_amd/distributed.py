@@ -5,7 +5,8 @@ ref src/oem_dense.h:328-358, and across slices, ref src/oem_big.h:329-358).  Eac
 contiguous block of rows, builds the shifted moment buffer M_r of its block with the MFMA kernel,
 and the ranks sum them:
 
-    M      <- all_reduce(M_r)             ((p+2)^2 doubles about c = 0, ONE collective; c1: 83 KB, c5: 532 KB)
+    M      <- M_0 + M_1 + ... + M_{N-1}   ((p+2)^2 doubles about c = 0 per rank, ONE collective -- an all-gather -- and one kernel that adds
+                                           them in rank order (sum_over_ranks; c1: 83 KB, c5: 532 KB per rank); reduce="allreduce": dist.all_reduce)
     result <- solve_moments(M)            (replicated: the lambda path is a serial chain of tiny GEMVs)
 
 The shift c that guards the centred moments against cancellation would be a function of ALL the data, which a rank does not
@@ -125,6 +126,10 @@ class HipBackend:
         L.check(self.lib.oemgpu_xval_merge(t.ctypes.data_as(dp), int(t.shape[0]), C.byref(args.c), cvm.ctypes.data_as(dp), cvsd.ctypes.data_as(dp)))
         return cvm, cvsd
 
+    def sum_in_order(self, parts, nparts, n, out):
+        """out <- parts[0] + parts[1] + ... (nparts buffers of n doubles, contiguous), added in that order by one kernel"""
+        L.check(self.lib.oemgpu_sum_in_order_dev(self.ctx, parts.data_ptr(), nparts, n, out.data_ptr()))
+
     def shift_in_effect(self):
         """did the last solve() find that its sums call for a shift (and read the moments as shifted)?"""
         return self.lib.oemgpu_last_shift_in_effect(self.ctx) == 1
@@ -132,6 +137,32 @@ class HipBackend:
     def shift_advised(self):
         """was the last solve() given moments about 0 of columns with |mean| >> sd (redo about a shift)?"""
         return self.lib.oemgpu_last_shift_advised(self.ctx) == 1
+
+
+REDUCE = "ordered"         # how buffers are summed over the ranks: "ordered" (default) or "allreduce" (sum_over_ranks)
+
+
+def sum_over_ranks(backend, dist, group, buf, reduce=None):
+    """buf <- the sum of every rank's buf.  "ordered" (the default): ONE all-gather of the buffers and ONE kernel that adds them in
+    rank order, ((M_0 + M_1) + M_2) + ... -- the order the in-library multi-GPU path (opts.ngpus, hoststream.hip) adds its devices'
+    buffers in.  The result is then a function of the row partition alone: the same bits from every rank, from run to run, on any
+    topology, and the same as the in-library form on the same shards (SURVEY section 8e asks for fixed-rank-order summation; an
+    all-reduce leaves the order to the collective library's choice of algorithm).  The payload is N (p+2)^2 doubles (c5 at 8 GPUs:
+    4.3 MB) -- latency-bound like the all-reduce it replaces.  "allreduce": dist.all_reduce, kept selectable for the day both can be
+    timed on real links."""
+    mode = reduce or REDUCE
+    if mode == "allreduce":
+        dist.all_reduce(buf, group=group)
+        return
+    if mode != "ordered":
+        raise ValueError("reduce must be 'ordered' or 'allreduce'")
+    world, n = dist.get_world_size(group), buf.numel()
+    cache = backend.__dict__.setdefault("_gathered", {})
+    gathered = cache.get((world, n))
+    if gathered is None:
+        gathered = cache[(world, n)] = backend.new_buffer(world * n)
+    dist.all_gather_into_tensor(gathered, buf, group=group)
+    backend.sum_in_order(gathered, world, n, buf)
 
 
 def row_partition(n, world):
@@ -191,11 +222,11 @@ def _split_solve(backend, dist, group, mom, sums, p, semantics, standardize, int
 
 
 def solve_row_shards(backend, dist, group, x, n_local, ld, p, y, bufs, semantics, standardize, intercept, args, outs=None,
-                     split_penalties=None):
+                     split_penalties=None, reduce=None):
     """The local stages and the collective between them (module docstring); call inside backend.section().
     Every rank ends with the full result in `args`.
     split_penalties: None = when it pays (several penalties on the engines that walk them one after the other: p + intercept
-    column > SMALL_P_MAX); True / False force it."""
+    column > SMALL_P_MAX); True / False force it.  reduce: sum_over_ranks' mode (None: the module default, "ordered")."""
     sums, mom = bufs
     many = _many(dist, group)
     q = p + (1 if (semantics != L.OEMGPU_SEM_DENSE and intercept) else 0)
@@ -213,22 +244,22 @@ def solve_row_shards(backend, dist, group, x, n_local, ld, p, y, bufs, semantics
         return
     backend.moments(x, n_local, ld, p, y, None, mom)              # about c = 0: the usual verdict
     if many:
-        dist.all_reduce(mom, group=group)                         # the single Gram all-reduce of the north star
+        sum_over_ranks(backend, dist, group, mom, reduce)         # the single Gram exchange of the north star, summed in rank order
     solve(None)
     if backend.shift_advised():                                   # same reduced moments on every rank: all redo or none
         backend.shift_sums(x, n_local, ld, p, y, sums)
         if many:
-            dist.all_reduce(sums, group=group)
+            sum_over_ranks(backend, dist, group, sums, reduce)
         backend.moments(x, n_local, ld, p, y, sums, mom)
         if many:
-            dist.all_reduce(mom, group=group)
+            sum_over_ranks(backend, dist, group, mom, reduce)
         solve(sums)
 
 
 def oem_sharded(x_local, y_local, backend=None, dist=None, group=None, big=False, penalty=None, lambda_=(),
                 nlambda=100, lambda_min_ratio=None, alpha=1.0, gamma=3.0, tau=0.5, groups=(), penalty_factor=None,
                 group_weights=None, standardize=True, intercept=True, maxit=500, tol=1e-7, accelerate=False,
-                compute_loss=False, varnames=None, split_penalties=None, n_total=None):
+                compute_loss=False, varnames=None, split_penalties=None, n_total=None, reduce=None):
     """oem() (big=False: DataStd + oemDense semantics) or big.oem() (big=True) on row shards.
     n_total: the global number of rows if the caller knows it (the default lambda.min.ratio depends on n < p, R/oem.R:348-354);
     otherwise one tiny all-reduce of the local row counts finds it.
@@ -265,7 +296,7 @@ def oem_sharded(x_local, y_local, backend=None, dist=None, group=None, big=False
         bufs = sharded_buffers(backend, p)
         solve_row_shards(backend, dist, group, x_local, n_local, ld, p, y_local, bufs,
                          L.OEMGPU_SEM_BIG if big else L.OEMGPU_SEM_DENSE, standardize, intercept, args,
-                         split_penalties=split_penalties)
+                         split_penalties=split_penalties, reduce=reduce)
         if many:
             n_total = int(round(float(bufs[1].reshape(p + 2, p + 2)[p + 1, p + 1])))      # the reduced row count
     if varnames is None:
@@ -321,7 +352,7 @@ def xval_oem_sharded(x_local, y_local, foldid_local, nfolds, backend=None, dist=
         fold_n = backend.xval_fold_moments(x_local, n_local, ld, p, y_local, weights_local, foldid_local, K, args, mom)
         mom[-K:] = backend.to_device(fold_n.astype(np.float64))
         if many:
-            dist.all_reduce(mom, group=group)                     # the one collective of the Gram stage
+            sum_over_ranks(backend, dist, group, mom)             # the one exchange of the Gram stage, the K buffers summed in rank order
         fold_tot = np.rint(backend.to_host(mom[-K:])).astype(np.int64)
         backend.xval_solve_folds(mom, fold_tot, n_local, p, K, weighted, standardize, intercept, args)
         tri = backend.xval_cv_triples(n_local, p, K, weighted, tm, args)

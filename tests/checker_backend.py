@@ -27,6 +27,12 @@ class CheckerBackend:
     def new_buffer(self, n):
         return torch.zeros(n, dtype=torch.float64)
 
+    def sum_in_order(self, parts, nparts, n, out):
+        acc = parts[:n].clone()
+        for r in range(1, nparts):
+            acc += parts[r * n:(r + 1) * n]
+        out.copy_(acc)
+
     def shift_sums(self, x, n, ld, p, y, out):
         xn, yn = x.numpy(), y.numpy()
         k = min(n, 64)                                   # any common sample works: the shift is only provisional

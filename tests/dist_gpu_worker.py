@@ -15,7 +15,7 @@ from oem_amd.distributed import HipBackend, oem_sharded, row_partition, xval_oem
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dist.init_process_group("gloo")
-n, p = 400_000, 100
+n, p = 399_996, 100             # (shards of 2 and 3 ranks with an even number of rows: both multi-GPU forms then run the same moment kernel on a shard)
 g = torch.Generator(device="cuda"); g.manual_seed(7)
 xt = torch.randn((p, n), generator=g, device="cuda", dtype=torch.float64) * 3.0      # every rank generates the whole problem
 b = torch.cat([torch.rand(25, generator=g, device="cuda", dtype=torch.float64), torch.zeros(75, device="cuda", dtype=torch.float64)])
@@ -34,6 +34,16 @@ for rep in range(6):                         # back to back, no host sync in bet
         err = float(np.abs(fit["beta"][k] - ref["beta"][k]).max())
         ok &= err < 1e-9 and np.array_equal(fit["niter"][k], ref["niter"][k])
 ok &= not be.shift_advised() and not be.shift_in_effect()      # centred data: one collective, no redo
+# the ranks' moment buffers are all-gathered and added in RANK order -- the order the in-library multi-GPU form
+# (opts.ngpus; here `world` contexts of the one device) adds its devices' buffers in: the two forms agree BIT FOR BIT on the same shards
+if rank == 0:
+    inlib = oem_amd.oem(np.asfortranarray(xt.t().cpu().numpy()), y.cpu().numpy(), devices=[0] * world, **kw)
+    same_bits = inlib["d"] == fit["d"] and all(np.array_equal(np.asarray(inlib["beta"][k]), np.asarray(fit["beta"][k])) and
+                                               np.array_equal(inlib["niter"][k], fit["niter"][k]) for k in range(2))
+    if not same_bits:
+        print("in-library sum differs from the rank-order sum: d", inlib["d"], fit["d"],
+              [float(np.abs(np.asarray(inlib["beta"][k]) - np.asarray(fit["beta"][k])).max()) for k in range(2)], flush=True)
+    ok &= bool(same_bits)
 # columns with |mean| = 67 sd: the reduced sums call for the shift, every rank redoes its pass about the agreed c
 xs = (xt[:, lo:hi] + 200.0).contiguous().t()
 whole = (xt + 200.0).t()

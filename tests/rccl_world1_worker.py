@@ -1,7 +1,7 @@
 """Worker of tests/test_gpu_distributed.py::test_rccl_collectives_at_world_size_one (run as a child process: a process group is
 process-wide state).  One rank, backend "nccl" (= RCCL on ROCm), OEM_FORCE_COLLECTIVES=1: every collective of
-oem_amd/distributed.py -- the Gram all-reduce, the shift redo's two extra all-reduces, the penalty split's all-gather, xval.oem's
-all-reduce and all-gather, the global-n all-reduce -- EXECUTES on a one-GPU box and must leave the bits of the plain call."""
+oem_amd/distributed.py -- the Gram exchange (all-gather + in-order sum; dist.all_reduce on request), the shift redo's two extra ones, the
+penalty split's all-gather, xval.oem's exchange and all-gather, the global-n all-reduce -- EXECUTES on a one-GPU box and must leave the bits of the plain call."""
 import os
 import sys
 
@@ -22,8 +22,8 @@ assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
 be = HipBackend(0)
 rng = np.random.default_rng(31)
 ok = True
-calls = {"all_reduce": 0, "all_gather": 0}
-_ar, _ag = dist.all_reduce, dist.all_gather
+calls = {"all_reduce": 0, "all_gather": 0, "gather_sum": 0}           # gather_sum: all_gather_into_tensor, behind which the buffers are added in rank order
+_ar, _ag, _agt = dist.all_reduce, dist.all_gather, dist.all_gather_into_tensor
 
 
 def ar(*a, **k):
@@ -36,7 +36,12 @@ def ag(*a, **k):
     return _ag(*a, **k)
 
 
-dist.all_reduce, dist.all_gather = ar, ag          # count what really reaches RCCL
+def agt(*a, **k):
+    calls["gather_sum"] += 1
+    return _agt(*a, **k)
+
+
+dist.all_reduce, dist.all_gather, dist.all_gather_into_tensor = ar, ag, agt          # count what really reaches RCCL
 
 
 def both(fn, *a, **k):
@@ -69,18 +74,21 @@ xt = torch.randn((p, n), device=dev, dtype=torch.float64) * 3.0
 y = xt.t()[:, :5] @ torch.tensor([1.0, -1.0, 0.5, 2.0, -0.7], device=dev, dtype=torch.float64) + torch.randn(n, device=dev, dtype=torch.float64)
 c0 = dict(calls)
 a, b = both(oem_sharded, xt.t(), y, backend=be, penalty=["elastic.net", "mcp"], nlambda=30, tol=1e-10)
-check("dense", same(a, b) and calls["all_reduce"] == c0["all_reduce"] + 2)
+check("dense", same(a, b) and calls["all_reduce"] == c0["all_reduce"] + 1 and calls["gather_sum"] == c0["gather_sum"] + 1)      # the global n; the moments
 c0 = dict(calls)
 a, b = both(oem_sharded, xt.t(), y, backend=be, big=True, penalty=["lasso"], nlambda=20, tol=1e-9)
-check("big", same(a, b) and calls["all_reduce"] == c0["all_reduce"] + 2)
+check("big", same(a, b) and calls["all_reduce"] == c0["all_reduce"] + 1 and calls["gather_sum"] == c0["gather_sum"] + 1)
 c0 = dict(calls)
 a, b = both(oem_sharded, xt.t(), y, backend=be, penalty=["lasso"], nlambda=10, tol=1e-9, lambda_min_ratio=1e-3, n_total=n)
-check("dense, n known", same(a, b) and calls["all_reduce"] == c0["all_reduce"] + 1)       # the ONE all-reduce of the north star
+check("dense, n known", same(a, b) and calls["all_reduce"] == c0["all_reduce"] and calls["gather_sum"] == c0["gather_sum"] + 1)       # the ONE exchange of the north star
+c0 = dict(calls)
+a, b = both(oem_sharded, xt.t(), y, backend=be, penalty=["lasso"], nlambda=10, tol=1e-9, lambda_min_ratio=1e-3, n_total=n, reduce="allreduce")
+check("dense, n known, all-reduce", same(a, b) and calls["all_reduce"] == c0["all_reduce"] + 1 and calls["gather_sum"] == c0["gather_sum"])   # ... as dist.all_reduce, still selectable
 # 2. columns far from zero: the reduced moments advise a shift -> sample sums all-reduce + second moment all-reduce
 xs = (xt + 200.0).t()
 c0 = dict(calls)
 a, b = both(oem_sharded, xs, y, backend=be, penalty=["lasso"], nlambda=15, tol=1e-10)
-check("shift redo", same(a, b) and be.shift_in_effect() and calls["all_reduce"] == c0["all_reduce"] + 4)      # n, moments, sample sums, moments about c
+check("shift redo", same(a, b) and be.shift_in_effect() and calls["all_reduce"] == c0["all_reduce"] + 1 and calls["gather_sum"] == c0["gather_sum"] + 3)      # n; moments, sample sums, moments about c
 # 3. p > 288 with several penalties: penalties dealt to the ranks, one all-gather
 p3, n3 = 320, 4000
 xh = rng.normal(size=(n3, p3)); yh = xh[:, :5] @ np.array([1.0, -1.0, 0.5, 2.0, -0.7]) + rng.normal(size=n3)
@@ -95,6 +103,7 @@ fid = rng.permutation(np.resize(np.arange(1, K4 + 1), n4)).astype(np.int32)
 x4 = torch.as_tensor(np.ascontiguousarray(xh.T), device=dev).t(); y4 = torch.as_tensor(yh, device=dev); f4 = torch.as_tensor(fid, device=dev)
 c0 = dict(calls)
 a, b = both(xval_oem_sharded, x4, y4, f4, K4, backend=be, penalty=["lasso", "mcp"], nlambda=10, tol=1e-9, maxit=2000)
-check("xval", same(a, b, keys=("beta", "lambda", "niter", "cvm", "cvsd")) and calls["all_reduce"] == c0["all_reduce"] + 2 and calls["all_gather"] == c0["all_gather"] + 1)
+check("xval", same(a, b, keys=("beta", "lambda", "niter", "cvm", "cvsd")) and calls["all_reduce"] == c0["all_reduce"] + 1 and calls["gather_sum"] == c0["gather_sum"] + 1 and
+      calls["all_gather"] == c0["all_gather"] + 1)
 print("RCCL_W1_OK" if ok else "RCCL_W1_MISMATCH", calls, flush=True)
 dist.destroy_process_group()

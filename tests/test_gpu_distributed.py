@@ -72,7 +72,7 @@ def test_bench_launcher_at_eight_ranks(route):
     assert out["scaling"] == "strong"
     sp = out["scaling_point"]
     assert sp["n_gpus"] == 8 and sp["c1_strong"]["rows_per_gpu"] in (100003 // 8, 100003 - 7 * (100003 // 8))
-    assert sp["c1_strong"]["moments_ms"] > 0 and sp["c1_strong"]["allreduce_ms"] > 0 and sp["c1_strong"]["solve_ms"] > 0
+    assert sp["c1_strong"]["moments_ms"] > 0 and sp["c1_strong"]["allreduce_ms"] > 0 and sp["c1_strong"]["allgather_ms"] > 0 and sp["c1_strong"]["solve_ms"] > 0
     hr = out["host_resident_ms"]
     assert "error" not in hr, hr
     assert hr["c1"]["ngpus"] == 8 and hr["c1"]["max_abs_beta_diff_vs_the_rank_sharded_solve"] < 1e-9

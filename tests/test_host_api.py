@@ -290,6 +290,29 @@ def test_the_plan_puts_the_cooperating_engine_on_one_xcd_only_where_its_instance
     assert _plan(300, ["lasso", "mcp", "scad"], num_cu=64)[0] == "coop" and not _plan.one_xcd              # 10 workgroups do not fit 8 CUs
 
 
+def test_concurrent_one_xcd_launches_are_booked_per_xcd():
+    """the CU slots of the one-XCD cooperating launches are booked per XCD, and a call's first XCD is the one where the load
+    is lowest -- three calls of one 16-workgroup instance (q = 512) in flight at once must not meet on one XCD (the old turn counter put
+    calls 0, 8 and 16 all on XCD 0: 48 workgroups on 32 CUs, an exchange timeout and a second of waiting)."""
+    import ctypes as C
+    from oem_amd import _lib as L
+    lib = L.lib()
+    def book(num_cu, W, ninst, calls):
+        bases, peak = (C.c_int32 * calls)(), C.c_int32(-1)
+        L.check(lib.oemgpu_selftest_coop_slots(num_cu, W, ninst, calls, bases, C.byref(peak)))
+        return list(bases), peak.value
+    for calls in (2, 3, 8):
+        bases, peak = book(256, 16, 1, calls)
+        assert len(set(bases)) == calls and peak == 16, (calls, bases, peak)          # every call an XCD of its own
+    bases, peak = book(256, 16, 1, 12)
+    assert peak == 32                                                                 # twelve on eight XCDs: two on four of them, never three
+    bases, peak = book(256, 10, 11, 1)                                                # xval.oem's eleven instances: two on three XCDs
+    assert peak == 20
+    bases, peak = book(256, 10, 3, 4)                                                 # four callers x three penalties side by side
+    assert peak <= 20
+    assert lib.oemgpu_selftest_coop_slots(256, 16, 8, 2, (C.c_int32 * 2)(), C.byref(C.c_int32())) != 0      # 256 workgroups: the second call would wait
+
+
 def test_the_plan_names_one_engine_and_a_workspace_that_fits_at_every_size():
     """VERDICT r4 item 6 / ADVICE r3: the launch of an engine must never reject the workspace its own caller sized.  plan_paths is the
     host function that decides engine and sizes for every call; this sweeps it without a GPU over q in [2, 20,000] (every q up to
