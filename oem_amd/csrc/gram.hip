@@ -850,12 +850,12 @@ static GramPlan gram_plan_compute(int64_t n, int p, int num_cu)
         // 15 or 16 tile columns (225 <= p <= 256: config 5): ONE workgroup of eight waves per row chunk multiplies the whole triangle
         // from one read of X (gram_wd.hip) instead of three super-blocks that each stream the rows
         // (11 or 12 tile columns, 161 <= p <= 192: the same with groups of three tile columns -- 78 tiles, nine or ten per wave)
-        pl.wd = sw().OEM_NO_GRAM_WD.set ? 0 : ((pl.ntc == 15 || pl.ntc == 16) ? 4 : ((pl.ntc == 11 || pl.ntc == 12) ? 3 : 0));
+        pl.wd = (pl.ntc == 15 || pl.ntc == 16) ? 4 : ((pl.ntc == 11 || pl.ntc == 12) ? 3 : 0);
         pl.wd_units = pl.wd ? 1 : 0;
         // 16 k tile columns (k >= 2: p = 512, 1,024, ... and the fifteen columns below each): k such diagonal units and, between every
         // two of them, two off-diagonal blocks of 8 x 16 tiles on eight waves -- one launch, 80 fragment reads per slab at p = 512
         // where the super-blocks make 128
-        if (!sw().OEM_NO_GRAM_WD.set && !sw().OEM_NO_GRAM_UNITS.set && pl.ntc >= 31 && (pl.ntc % 16 == 0 || pl.ntc % 16 == 15)) { pl.wd = 4; pl.wd_units = (pl.ntc + 15) / 16; }
+        if (pl.ntc >= 31 && (pl.ntc % 16 == 0 || pl.ntc % 16 == 15)) { pl.wd = 4; pl.wd_units = (pl.ntc + 15) / 16; }
         const int nsb = n8 + n6 + n4, nsblk = pl.wd ? pl.wd_units * pl.wd_units : nsb * (nsb + 1) / 2;
         // 1-12 rounds of one workgroup per CU: the count whose launch ends soonest when the workgroups are handed out longest
         // first (gram_sb_kernel) -- a greedy replay with the measured costs (tools/gram_diag.py: 2,136 cycles per 8-row slab off
@@ -913,7 +913,7 @@ GramPlan gram_plan(int64_t n, int p, int num_cu)
     struct Memo { int64_t n; int p, cu; unsigned gen; GramPlan pl; };
     static thread_local Memo memo[4] = {{-1, 0, 0, 0u, {}}, {-1, 0, 0, 0u, {}}, {-1, 0, 0, 0u, {}}, {-1, 0, 0, 0u, {}}};
     static thread_local unsigned next = 0;
-    const unsigned gen = sw().generation;                          // (a switch -- OEM_NO_GRAM_WD -- is part of the plan)
+    const unsigned gen = sw().generation;
     for (const Memo &m : memo) if (m.n == n && m.p == p && m.cu == num_cu && m.gen == gen) return m.pl;
     Memo &m = memo[next++ & 3];
     m.n = n; m.p = p; m.cu = num_cu; m.gen = gen; m.pl = gram_plan_compute(n, p, num_cu);

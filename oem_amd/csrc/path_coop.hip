@@ -742,11 +742,9 @@ size_t path_coop_xchg_bytes() { return (size_t)2 * 1024 * 2 * sizeof(unsigned lo
 // (the four-workgroup replicated kernel), q = 288 2.14 vs 4.34 ms, config 5's q = 257 1.59 vs 2.96 ms -- but q = 200 1.80 vs
 // 0.94 ms (the row-split kernel, up to 208, stays); with a group penalty in the call q = 192 2.25 vs 2.71 ms on the replicated kernel,
 // but 1.83 ms on the row-split kernel now that it has the group operators: the same bound for both.
-// OEM_COOP_MIN_Q: experiment knob (never below 129).
 int path_coop_min_q(bool has_groups)
 {
-    const int v = (sw().OEM_COOP_MIN_Q.set && sw().OEM_COOP_MIN_Q.num >= 129) ? (int)sw().OEM_COOP_MIN_Q.num : 0;
-    return v ? v : (has_groups ? COOP_MIN_Q_GROUPS : COOP_MIN_Q);
+    return has_groups ? COOP_MIN_Q_GROUPS : COOP_MIN_Q;
 }
 
 bool path_coop_eligible(int q, bool has_sinv, bool compute_loss, int ngroups, int nbatch)

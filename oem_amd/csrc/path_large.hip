@@ -1483,7 +1483,7 @@ __global__ void fused_init_kernel(FState *S, int npen)
 }
 
 static size_t update_uf_doubles(int p) { return 2 * (size_t)(p + 8); }       // U[q] | F[ngroups <= q]
-static size_t sym_part_doubles(int p) { return (p % SYM_TB == 0 && p >= 2048 && p <= 4096) ? 2 * (size_t)(p / SYM_TB) * p + 16 : 0; }
+static size_t sym_part_doubles(int p) { return p == 4096 ? 2 * (size_t)(p / SYM_TB) * p + 16 : 0; }
 
 size_t path_large_work_doubles(int p, int nsteps)
 {
@@ -1491,7 +1491,7 @@ size_t path_large_work_doubles(int p, int nsteps)
     // + fused engine: FState[2] (8 doubles), done word, beta[2][p+8], flags[2][FMAXB] ints
     // + replicated-update engine: GState[2] (16 doubles), u[2][p+8] (beta[2] shared with the fused engine)
     // + fused Lanczos: two copies each of v, v_prev, w
-    // + symmetric-tile engine: the partial vectors P[2][p / 128][p] (p a multiple of 128, p >= 2048)
+    // + symmetric-tile engine (p = 4096): the partial vectors P[2][p / 128][p]
     return (size_t)STATE_DBL + 5 * (size_t)(p + 8) + 2 * MAXL + 64 + 16 + 2 * (size_t)(p + 8) + FMAXB + 16 + 2 * (size_t)(p + 8) + 6 * (size_t)(p + 8) +
            sym_part_doubles(p) + update_uf_doubles(p);
 }
@@ -1569,8 +1569,8 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     double *LZ = T + 2 * MAXL + 64 + 16 + 2 * (size_t)(q + 8) + FMAXB + 16 + 2 * (size_t)(q + 8);
     double *Vc = LZ, *Vp = LZ + 2 * (size_t)(q + 8), *Wb = LZ + 4 * (size_t)(q + 8);
     double *SP = LZ + 6 * (size_t)(q + 8);             // symmetric-tile engine: partial vectors P[2][q / 128][q]
-    // XX is symmetric: for q = 2048 / 4096 the products read its lower triangle only (symgemv_kernel, oem_symfused_kernel)
-    const bool sym_ok = (q == 2048 || q == 4096) && (((uintptr_t)a.xx) & 15) == 0 && !sw().OEM_NO_SYM.set && !sw().OEM_NO_FUSED.set;
+    // XX is symmetric: at q = 4096 the products read its lower triangle only (symgemv_kernel, oem_symfused_kernel)
+    const bool sym_ok = q == 4096 && (((uintptr_t)a.xx) & 15) == 0 && !sw().OEM_NO_SYM.set && !sw().OEM_NO_FUSED.set;
     // ... and beyond 4096 a packed copy of it, made here (sympk_*: one contiguous sweep of 4 q^2 bytes per product)
     const bool spk = q > 4096 && a.sympk != nullptr && !sw().OEM_NO_SYM.set;
     const int spk_nb = spk_nblk(q), spk_qpad = spk_nb * SYM_TB, spk_nt = (int)spk_ntile(q);
@@ -1586,10 +1586,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     };
     auto sym_gemv = [&](const double *vec, double *out) {
         if (spk) spk_gemv(vec, out, nullptr);
-        else if (q == 2048) {
-            hipLaunchKernelGGL((symgemv_kernel<16>), dim3(sym_nwg(16)), dim3(256), 0, s, a.xx, vec, SP);
-            hipLaunchKernelGGL((symgemv_sum_kernel<16>), dim3(q / 128), dim3(128), 0, s, SP, out);
-        } else {
+        else {
             hipLaunchKernelGGL((symgemv_kernel<32>), dim3(sym_nwg(32)), dim3(256), 0, s, a.xx, vec, SP);
             hipLaunchKernelGGL((symgemv_sum_kernel<32>), dim3(q / 128), dim3(128), 0, s, SP, out);
         }
@@ -1597,9 +1594,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     void (*lzk)(const double *, int, int, double *, double *, double *, double *, int) = nullptr;
     if (lz_fused) {
         if (q <= 512) lzk = lz_full ? lanczos_fused_kernel<8, true> : lanczos_fused_kernel<8, false>;
-        else if (q <= 1024) lzk = lz_full ? lanczos_fused_kernel<16, true> : lanczos_fused_kernel<16, false>;
-        else if (q <= 2048) lzk = lz_full ? lanczos_fused_kernel<32, true> : lanczos_fused_kernel<32, false>;
-        else lzk = lz_full ? lanczos_fused_kernel<64, true> : lanczos_fused_kernel<64, false>;
+        else lzk = lz_full ? lanczos_fused_kernel<16, true> : lanczos_fused_kernel<16, false>;
     }
     int lblocks = (q + 3) / 4;
     if (lblocks > num_cu * 2) lblocks = num_cu * 2;
@@ -1679,9 +1674,8 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         int *flags = reinterpret_cast<int *>(Bv + 2 * (size_t)(q + 8));
         int blocks = (q + 3) / 4;
         if (blocks > num_cu * 2) blocks = num_cu * 2;
-        if (sw().OEM_FUSED_BLOCKS.set) { const int b = (int)sw().OEM_FUSED_BLOCKS.num; if (b > 0) blocks = b < (q + 3) / 4 ? b : (q + 3) / 4; }   // experiment knob
         if (blocks > FMAXB) blocks = FMAXB;
-        const bool sym = sym_ok && sym_nwg(q / SYM_TB) <= FMAXB && !(q == 2048 && !sw().OEM_SYM_2048.set);
+        const bool sym = sym_ok;
         SState *SS = reinterpret_cast<SState *>(SP + 2 * (size_t)(q / SYM_TB) * q);      // behind the partial vectors (sym_part_doubles)
         static_assert(2 * sizeof(SState) <= 16 * sizeof(double), "SState[2] must fit the 16 spare doubles of the partial area");
         if (sym) hipLaunchKernelGGL(sym_init_kernel, dim3(1), dim3(1), 0, s, SS, a);
@@ -1689,8 +1683,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         auto enq = [&](int count) {
             for (int k = 0; k < count; ++k) {
                 const int par = k & 1;
-                if (sym && q == 4096) hipLaunchKernelGGL((oem_symfused_kernel<32>), dim3(sym_nwg(32)), dim3(256), 0, s, a, SS, Bv, SP, flags, fdone, par, d);
-                else if (sym) hipLaunchKernelGGL((oem_symfused_kernel<16>), dim3(sym_nwg(16)), dim3(256), 0, s, a, SS, Bv, SP, flags, fdone, par, d);
+                if (sym) hipLaunchKernelGGL((oem_symfused_kernel<32>), dim3(sym_nwg(32)), dim3(256), 0, s, a, SS, Bv, SP, flags, fdone, par, d);
                 else if (q == 512) hipLaunchKernelGGL((oem_fused_kernel<8>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);
                 else if (q == 1024) hipLaunchKernelGGL((oem_fused_kernel<16>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);
                 else if (q == 2048) hipLaunchKernelGGL((oem_fused_kernel<32>), dim3(blocks), dim3(256), 0, s, a, S, Bv, flags, fdone, par, d);

@@ -1158,7 +1158,6 @@ static bool symcoop_plan_per(int q, int gmax, SymcoopPlan &P, const int *runs, i
     const int T = (q + 63) / 64, ntile = T * (T + 1) / 2;
     int NT = 0;
     for (int nt = 1; nt <= 3; ++nt) if ((ntile + 4 * nt - 1) / (4 * nt) <= gmax) { NT = nt; break; }
-    if (sw().OEM_SYMCOOP_NT.set) { const int k = (int)sw().OEM_SYMCOOP_NT.num; if (k >= 1 && k <= 3 && (ntile + 4 * k - 1) / (4 * k) <= gmax) NT = k; }   // experiments
     if (!NT) return false;
     const int a = NT == 3 ? 3 : 2;
     int per = 4 * NT;                                                // tiles per workgroup

@@ -16,13 +16,13 @@ namespace oemgpu {
 // X(name): the switch's environment variable; sw().name.set / .num (atoll of the value; 0 when unset or not a number) / .str
 #define OEM_SWITCH_TABLE(X)                                                                                                          \
     /* engine selection: Gram form */                                                                                                \
-    X(OEM_NO_COOP) X(OEM_NO_SYMCOOP) X(OEM_NO_ROWCOOP) X(OEM_NO_FUSED) X(OEM_NO_SYM) X(OEM_SYM_2048) \
-    X(OEM_SYMCOOP_NO_GENERAL) X(OEM_SYMCOOP_NT) X(OEM_COOP_MIN_Q) X(OEM_FUSED_BLOCKS) X(OEM_NO_ZERO_COPY)          \
+    X(OEM_NO_COOP) X(OEM_NO_SYMCOOP) X(OEM_NO_ROWCOOP) X(OEM_NO_FUSED) X(OEM_NO_SYM) \
+    X(OEM_SYMCOOP_NO_GENERAL) X(OEM_NO_ZERO_COPY)          \
     /* engine selection: p >= n */                                                                                                   \
     X(OEM_WIDE) X(OEM_NO_WIDE) X(OEM_NO_WCOOP) X(OEM_WRES) X(OEM_NO_WRES) X(OEM_WSTREAM) X(OEM_NO_WSTREAM)        \
     X(OEM_WIDE_NO_GROUP_FUSED) X(OEM_WCOOP_ONE_SET) X(OEM_WCOOP_NO_GENERAL) X(OEM_WCOOP_NO_ALIGN) X(OEM_NO_PENALTY_SPLIT) \
     /* moment kernels, sparse x */                                                                                                   \
-    X(OEM_SPARSE_GRAM) X(OEM_SPARSE_TILE_ROWS) X(OEM_NO_GRAM_WD) X(OEM_NO_GRAM_UNITS)             \
+    X(OEM_SPARSE_GRAM) X(OEM_SPARSE_TILE_ROWS)             \
     /* faults and checks */                                                                                                          \
     X(OEM_WCOOP_FAKE_TIMEOUT) X(OEM_POISON_OUT) X(OEMGPU_LANCZOS_CAP) X(OEM_NO_ONE_XCD) X(OEM_FAKE_XCD_MISMATCH)                                                                \
     /* the host-resident path */                                                                                                     \

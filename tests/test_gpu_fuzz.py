@@ -563,25 +563,29 @@ def test_random_wide_resident_in_the_accumulator_file(oa, seed, monkeypatch):
             assert np.allclose(np.ravel(f["loss"][k]), np.ravel(r["loss"][k]), rtol=1e-7, atol=1e-9), pens[k]
 
 
-@pytest.mark.parametrize("seed", list(range(150, 154)) + list(range(90000, 90000 + 4 * (SCALE - 1))))
-def test_random_symmetric_tile_engine(oa, seed, monkeypatch):
-    """oem.xtx at p = 2048 on the symmetric-tile engine (OEM_SYM_2048=1): random element-wise penalty mixes, penalty factors and
-    maxit, against the oracle (d handed over, as in the config-4 tests: the comparison is the path's)"""
-    monkeypatch.setenv("OEM_SYM_2048", "1")
-    monkeypatch.setenv("OEM_NO_SYMCOOP", "1")          # (the launch-per-iteration engine: the register-resident one has its own sweep below)
+@pytest.mark.parametrize("seed", list(range(150, 152)) + list(range(90000, 90000 + 2 * (SCALE - 1))))
+def test_random_packed_triangle_engine(oa, seed):
+    """oem.xtx at a random 4096 < p <= 4500 (the first sizes beyond the register engines: a ragged last block, odd sizes with rows that are
+    only 8-byte aligned) on the packed lower triangle (path_large.hip: sympk_*): random element-wise penalty mixes -- the (head, product)
+    pairs -- or a group penalty in the call -- product, slot sum, update kernel --, penalty factors and maxit, against the oracle
+    (d handed over, as in the config-4 tests: the comparison is the path's)"""
+    from scipy.sparse.linalg import eigsh
     rng = np.random.default_rng(9900 + seed)
-    p, n = 2048, 2048 + int(rng.integers(100, 3000))
+    p = int(rng.integers(4097, 4500)); n = p + int(rng.integers(100, 3000))
     x = rng.normal(size=(n, p)) * (1.0 + rng.uniform(size=p))
     b = np.zeros(p); b[rng.choice(p, 12, replace=False)] = rng.uniform(-1, 1, 12)
     y = x @ b + rng.normal(size=n)
     xtx, xty = x.T @ x / n, x.T @ y / n
     pens = list(rng.choice(ELEMENTWISE, int(rng.integers(1, 4)), replace=False))
     pf = np.where(rng.random(p) < 0.05, 0.0, rng.uniform(0.5, 2.0, p))
-    kw = dict(penalty=pens, nlambda=int(rng.integers(2, 6)), alpha=float(rng.uniform(0.3, 1.0)), gamma=float(rng.uniform(2.5, 5.0)),
-              tol=float(10.0 ** rng.uniform(-9, -7)), maxit=int(rng.choice([60, 400])), penalty_factor=pf)
+    kw = dict(penalty=pens, nlambda=int(rng.integers(2, 5)), alpha=float(rng.uniform(0.3, 1.0)), gamma=float(rng.uniform(2.5, 5.0)),
+              tol=float(10.0 ** rng.uniform(-9, -7)), maxit=int(rng.choice([60, 300])), penalty_factor=pf)
+    if seed % 2:
+        kw["penalty"] = pens = pens[:1] + ["grp.lasso"]; kw["groups"] = rng.permutation(np.arange(p) // 6 + 1)
     f = oa.oem_xtx(xtx, xty, **kw)
-    r = orc.fit_xtx(xtx, xty, d_override=f["d"], lambda_min_ratio=1e-4, **kw)
-    lam_max = np.linalg.eigvalsh(xtx)[-1]
+    assert oa.last_path_engine()[0] == "launches"
+    r = orc.fit_xtx(xtx, xty, d_override=f["d"], lambda_min_ratio=1e-4, unique_groups=np.unique(kw["groups"]) if "groups" in kw else None, **kw)
+    lam_max = float(eigsh(xtx, k=1, which="LA", tol=0, ncv=24, return_eigenvectors=False)[0])
     assert abs(f["d"] - 1.005 * lam_max) <= 1e-10 * lam_max
     _check(f, r, pens, tol=5e-7)
 

@@ -15,11 +15,10 @@ for knob in sys.argv[1:] or [""]:
     os.environ.pop("OEM_NO_SYM", None); os.environ.pop("OEM_NO_SYMCOOP", None)
     if knob == "nosym": os.environ["OEM_NO_SYM"] = "1"; os.environ["OEM_NO_SYMCOOP"] = "1"          # the row-streaming engine that reads all of XX (round 2)
     elif knob == "nosymcoop": os.environ["OEM_NO_SYMCOOP"] = "1"          # the symmetric-tile launches of round 3 (the lower triangle streamed per iteration)
-    elif knob: os.environ["OEM_FUSED_BLOCKS"] = knob
     __import__('oem_amd')._lib.reload_switches()      # (the library parses its switches once)
     t = []
     for _ in range(3):
         fit = oem_amd.oem_xtx(xtxd, xty, penalty="lasso", nlambda=100, tol=1e-10)
         ms = (C.c_double * 8)(); L.check(lib.oemgpu_last_timings(ctx, ms)); t.append(ms[3])
     it = int(fit["niter"][0].sum())
-    print(f"blocks={knob or 'default'}: eigen+path {min(t):.2f} ms, {it} iterations, {1e3 * min(t) / it:.2f} us per iteration (incl. Lanczos), {8 * p * p * it / (min(t) * 1e-3) / 1e12:.2f} TB/s over the path counted at 8 p^2 bytes per iteration (the symmetric-tile engine reads 4 p^2 + 4 * 128 p: {(4 * p * p + 512 * p) * it / (min(t) * 1e-3) / 1e12:.2f} TB/s)")
+    print(f"{knob or 'default'}: eigen+path {min(t):.2f} ms, {it} iterations, {1e3 * min(t) / it:.2f} us per iteration (incl. Lanczos), {8 * p * p * it / (min(t) * 1e-3) / 1e12:.2f} TB/s over the path counted at 8 p^2 bytes per iteration (the symmetric-tile engine reads 4 p^2 + 4 * 128 p: {(4 * p * p + 512 * p) * it / (min(t) * 1e-3) / 1e12:.2f} TB/s)")

@@ -89,7 +89,7 @@ if [ -z "$quick" ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/$pr tools/$pr.hip 2> /dev/null && /tmp/$pr > $o/${tag}_$pr.txt 2>&1
   done
   bash tools/gram_band.sh > $o/${tag}_gram_band_now.txt 2>&1
-  bash tools/gram_band_small.sh > $o/${tag}_gram_band_small.txt 2>&1
+  bash tools/attic/gram_band_small.sh > $o/${tag}_gram_band_small.txt 2>&1
   for p in 128 256 300 512 1024; do python3 tools/gram_by_n.py $p 30000 60000 100000 200000 500000 2000000 2>&1 | grep -v amdgpu.ids; done > $o/${tag}_gram_by_n_now.txt
   python3 tools/large_q_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_large_q_now.txt
   python3 tools/scale_factor_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_scale_factor_now.txt
