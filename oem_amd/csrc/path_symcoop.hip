@@ -44,6 +44,9 @@
 #include "penalty_ops.hpp"
 #include "path_dev.hpp"
 
+#ifndef OEM_SX_VOTE_BARRIER
+#define OEM_SX_VOTE_BARRIER 0     // 1 (A/B builds): the workgroup vote + barrier behind gather 1 also in the path phase of the element-wise form (rounds 4-5)
+#endif
 #ifndef OEM_XCHG_SLEEP
 #define OEM_XCHG_SLEEP 12         // s_sleep units (64 cycles) before the first poll sweep of a gather (tools/xchg_sleep_ab.sh)
 #endif
@@ -118,7 +121,9 @@ __device__ __forceinline__ void sx_publish(__amdgpu_buffer_rsrc_t rs, int off, d
 
 // E pairs per thread at byte offsets off[k] (need bit k), polled until both tags carry this epoch; the low tag bits are OR-ed into
 // `flags`.  One 16-byte load per pair, one sweep in flight, a pair that has arrived is not asked for again (tools/xchg_probe.hip).
-template <int E>
+// (DS >= 0, diagnostic builds only: acc[DS] += cycles from the first sweep until the wave's FIRST pair is there, acc[DS + 1] += from then until
+// its last one -- how far apart a wave's pairs arrive is what "multiply a block as soon as ITS coefficients are there" could overlap)
+template <int E, int DS = -1>
 __device__ __forceinline__ void sx_gather(const int (&off)[E], unsigned need, double (&out)[E], int &flags, SymX &X)
 {
     sx_v4u pv[E];
@@ -126,6 +131,10 @@ __device__ __forceinline__ void sx_gather(const int (&off)[E], unsigned need, do
 #pragma unroll
     for (int k = 0; k < E; ++k) pv[k] = sx_v4u{0u, 0u, 0u, 0u};
     if (E > 1 && OEM_XCHG_SLEEP > 0) __builtin_amdgcn_s_sleep(OEM_XCHG_SLEEP);      // (path_wcoop.hip: wc_gather has the measurement; E = 1: scalars that landed a hop ago)
+#ifdef OEM_PATH_DIAG
+    unsigned long long dg0 = 0, dg1 = 0;
+    if (DS >= 0) dg0 = __builtin_amdgcn_s_memtime();
+#endif
     // ONE counter in the sweep loop: it runs out once per 1,024 sweeps (~1 ms), and only then are the abort word and the timeout looked at
     // (~1 s = 1,000 such rounds: a partner is gone; after one timeout -- or the abort word -- nobody waits again: one sweep each)
     unsigned left = X.failed ? 1u : PATH_ABORT_SPINS, rounds = 0u;
@@ -137,12 +146,18 @@ __device__ __forceinline__ void sx_gather(const int (&off)[E], unsigned need, do
 #pragma unroll
         for (int k = 0; k < E; ++k)
             if (((miss >> k) & 1u) && (pv[k].y >> 1) == X.epoch && (pv[k].w >> 1) == X.epoch) miss &= ~(1u << k);
+#ifdef OEM_PATH_DIAG
+        if (DS >= 0 && dg1 == 0 && __any(miss != need)) dg1 = __builtin_amdgcn_s_memtime();
+#endif
         if (--left == 0u && __any(miss != 0u)) {
             if (X.failed || ++rounds >= PATH_TIMEOUT_ROUNDS) { ok = false; break; }
             if (sx_abort_seen(X)) break;
             left = PATH_ABORT_SPINS;
         }
     }
+#ifdef OEM_PATH_DIAG
+    if (DS >= 0) { const unsigned long long dg2 = __builtin_amdgcn_s_memtime(); if (dg1 == 0) dg1 = dg2; X.acc[DS >= 0 ? DS : 0] += dg1 - dg0; X.acc[DS >= 0 ? DS + 1 : 0] += dg2 - dg1; }
+#endif
     if (!ok) X.failed = true;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
@@ -402,7 +417,9 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
 #pragma unroll
         for (int e = 0; e < SE1; ++e) {
             const int r = part + 8 * e;
-            const bool ok = own && e < e1n && r < nsB;
+            // (element-wise form: the first lane group of a wave that owns no coordinate gathers the pairs of coordinate c0 as well -- for their
+            // tags alone: every wave then holds the "still moving" OR over ALL coordinates by itself, see the vote below)
+            const bool ok = (own || (!GEN && lane < 8)) && e < e1n && r < nsB;
             goff[e] = ok ? ((blkbase[B] + r) * 64 + (cg & 63)) * 16 : 0;
             if (ok) need1 |= 1u << e;
         }
@@ -557,7 +574,7 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
             int off[SE1];
 #pragma unroll
             for (int e = 0; e < SE1; ++e) off[e] = par * X.s1 + goff[e];
-            sx_gather<SE1>(off, need1, g, bits, X);
+            sx_gather<SE1, 11>(off, need1, g, bits, X);
             double t = (g[0] + g[1]) + (g[2] + g[3]);
             t += dpp_mov<0xB1, 0xf>(t, 0.0);
             t += dpp_mov<0x4E, 0xf>(t, 0.0);
@@ -573,9 +590,17 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
             sx_gather<1>(off, tid < G ? 1u : 0u, v, fl, X);
             alpha = sx_block_sum(v[0], red, rpar, w, lane);
         }
-        sx_vote(votes, w, lane, bits);
-        __syncthreads();
-        const int any = votes[0] | votes[1] | votes[2] | votes[3];   // the OR of "beta_t moved against beta_{t-1}" over ALL coordinates
+        // The OR of "beta_t moved against beta_{t-1}" over ALL coordinates.  The senders of ONE coordinate already carry it: for any other block B'
+        // some workgroup's patch holds the tile (max(B, B'), min(B, B')), touches both blocks, sends to this coordinate's block B and has
+        // OR-ed B' into its tag -- so in the path phase of the element-wise form every wave takes the OR of its own lanes' tags (every wave
+        // gathers at least one coordinate, above) and there is NO barrier behind gather 1.  Lanczos and the general
+        // form keep the workgroup vote (alpha's block sum / the owners' LDS words need the barrier anyway).
+        int any;
+        if (GEN || lz || OEM_SX_VOTE_BARRIER) {
+            sx_vote(votes, w, lane, bits);
+            __syncthreads();
+            any = votes[0] | votes[1] | votes[2] | votes[3];
+        } else any = __ballot(bits != 0) != 0ull ? 1 : 0;
         SX_STAMP(4);
 
         // ---- the owners' arithmetic
@@ -683,7 +708,7 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
             int off[SE2];
 #pragma unroll
             for (int k = 0; k < SE2; ++k) off[k] = X.o2 + par * X.s2 + g2off[k];
-            sx_gather<SE2>(off, need2, r, bits2, X);
+            sx_gather<SE2, 13>(off, need2, r, bits2, X);
         }
         SX_STAMP(6);
         double bb = 0.0, ib = 1.0;

@@ -582,7 +582,8 @@ def test_random_packed_triangle_engine(oa, seed):
               tol=float(10.0 ** rng.uniform(-9, -7)), maxit=int(rng.choice([60, 300])), penalty_factor=pf)
     if seed % 2:
         kw["penalty"] = pens = pens[:1] + ["grp.lasso"]; kw["groups"] = rng.permutation(np.arange(p) // 6 + 1)
-    f = oa.oem_xtx(xtx, xty, **kw)
+    import torch
+    f = oa.oem_xtx(torch.as_tensor(xtx, device="cuda"), xty, **kw)
     assert oa.last_path_engine()[0] == "launches"
     r = orc.fit_xtx(xtx, xty, d_override=f["d"], lambda_min_ratio=1e-4, unique_groups=np.unique(kw["groups"]) if "groups" in kw else None, **kw)
     lam_max = float(eigsh(xtx, k=1, which="LA", tol=0, ncv=24, return_eigenvectors=False)[0])

@@ -45,3 +45,7 @@ print("  one level deeper, every wave of workgroup 0 (cycles per iteration): pro
 for wv in range(4):
     r = dw[wv]
     print(f"    wave {wv}:", np.round([r[1], r[9], r[2], r[3], r[4], r[5], r[6], r[10], r[7]], 0), "sum", round(float(r[0] + r[1] + r[9] + r[2] + r[3] + r[4] + r[5] + r[6] + r[10] + r[7])))
+print("  arrival spread inside the two gathers (cycles per iteration): gather 1 [first sweep -> the wave's FIRST pair | first pair -> its LAST pair], gather 2 [the same]")
+for wv in range(4):
+    r = dw[wv]
+    print(f"    wave {wv}:", np.round([r[11], r[12]], 0), np.round([r[13], r[14]], 0))
