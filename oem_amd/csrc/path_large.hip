@@ -1257,7 +1257,7 @@ int sympk_gemv_probe(hipStream_t s, const double *xx, int q, double *pk, const d
 
 size_t sympk_doubles(int q)
 {
-    if (q <= 4096) return 0;
+    if (q <= 1024) return 0;
     const size_t nblk = (size_t)spk_nblk(q), qpad = nblk * SYM_TB;
     // blocks | partial vectors P[NBLK][qpad] | B[2][qpad] | flags[2][FMAXB] ints | SState[2] | done word
     return spk_ntile(q) * SPK_TILE + nblk * qpad + 2 * qpad + FMAXB + 16 + 8;
@@ -1572,20 +1572,25 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     // XX is symmetric: at q = 4096 the products read its lower triangle only (symgemv_kernel, oem_symfused_kernel)
     const bool sym_ok = q == 4096 && (((uintptr_t)a.xx) & 15) == 0 && !sw().OEM_NO_SYM.set && !sw().OEM_NO_FUSED.set;
     // ... and beyond 4096 a packed copy of it, made here (sympk_*: one contiguous sweep of 4 q^2 bytes per product)
-    const bool spk = q > 4096 && a.sympk != nullptr && !sw().OEM_NO_SYM.set;
+    // (1024 < q <= 4096 too: what the register-resident engines do not take -- groups that are not runs of neighbours, a timed-out persistent
+    // launch's second attempt -- used to run the row-streaming kernels with bounds logic at every q that is not 2048 or 4096: 50-60 us per
+    // iteration at q = 3,000; the packed blocks have no ragged edge)
+    const bool spk = q > 1024 && a.sympk != nullptr && !sw().OEM_NO_SYM.set;
     const int spk_nb = spk_nblk(q), spk_qpad = spk_nb * SYM_TB, spk_nt = (int)spk_ntile(q);
     double *spk_P = spk ? a.sympk + (size_t)spk_nt * SPK_TILE : nullptr, *spk_B = spk ? spk_P + (size_t)spk_nb * spk_qpad : nullptr;
-    if (spk) {
-        OEM_HIP(hipMemsetAsync(spk_B, 0, sizeof(double) * (2 * (size_t)spk_qpad + FMAXB + 16 + 8), s));
+    bool spk_packed = false;
+    auto spk_pack = [&]() {                               // before the first product (never inside a graph capture)
+        if (spk_packed) return;
+        (void)hipMemsetAsync(spk_B, 0, sizeof(double) * (2 * (size_t)spk_qpad + FMAXB + 16 + 8), s);
         hipLaunchKernelGGL(sympk_pack_kernel, dim3(spk_nt), dim3(256), 0, s, a.xx, q, a.sympk);
-        OEM_HIP(hipGetLastError());
-    }
+        spk_packed = true;
+    };
     auto spk_gemv = [&](const double *vec, double *out, const int *done) {
         hipLaunchKernelGGL(sympk_gemv_kernel, dim3(spk_nt), dim3(256), 0, s, a.sympk, q, spk_qpad, vec, spk_P, done);
         if (out) hipLaunchKernelGGL(sympk_sum_kernel, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, spk_P, spk_nb, q, spk_qpad, out, done);
     };
     auto sym_gemv = [&](const double *vec, double *out) {
-        if (spk) spk_gemv(vec, out, nullptr);
+        if (!sym_ok) { spk_pack(); spk_gemv(vec, out, nullptr); }
         else {
             hipLaunchKernelGGL((symgemv_kernel<32>), dim3(sym_nwg(32)), dim3(256), 0, s, a.xx, vec, SP);
             hipLaunchKernelGGL((symgemv_sum_kernel<32>), dim3(q / 128), dim3(128), 0, s, SP, out);
@@ -1616,7 +1621,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
                     int rc = launch_gemv(s, a.xx, q, v, w, nullptr, num_cu);
                     if (rc) return rc;
                 }
-                if (q > 4096 && q <= 8192) hipLaunchKernelGGL(lanczos_update_reg_kernel<8>, dim3(1), dim3(1024), 0, s, q, m, v, vp, w, T);
+                if (q > 1024 && q <= 8192) hipLaunchKernelGGL(lanczos_update_reg_kernel<8>, dim3(1), dim3(1024), 0, s, q, m, v, vp, w, T);
                 else if (q > 8192 && q <= 12288) hipLaunchKernelGGL(lanczos_update_reg_kernel<12>, dim3(1), dim3(1024), 0, s, q, m, v, vp, w, T);
                 else hipLaunchKernelGGL(lanczos_update_kernel, dim3(1), dim3(1024), 0, s, q, m, v, vp, w, T);
             }
@@ -1647,24 +1652,9 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     OEM_HIP(hipGetLastError());
     if (a.npen == 0) return 0;
 
-    // ---- q > 4096, element-wise penalties: (head, product) pairs over the packed triangle
-    if (spk && a.ngroups == 0 && !a.accelerate && !a.compute_loss && !a.sinv && spk_qpad / SPK_HC <= FMAXB && !sw().OEM_NO_FUSED.set) {
-        int *flags = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad);
-        SState *SS = reinterpret_cast<SState *>(spk_B + 2 * (size_t)spk_qpad + FMAXB);
-        int *fdone = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad + FMAXB + 16);
-        hipLaunchKernelGGL(sym_init_kernel, dim3(1), dim3(1), 0, s, SS, a);
-        auto enq = [&](int count) {
-            for (int k = 0; k < count; ++k) {
-                const int par = k & 1;
-                hipLaunchKernelGGL(sympk_head_kernel, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, a, SS, spk_B, spk_P, flags, fdone, par, d, spk_nb, spk_qpad);
-                hipLaunchKernelGGL(sympk_gemv_kernel, dim3(spk_nt), dim3(256), 0, s, a.sympk, q, spk_qpad, spk_B + (size_t)(par ^ 1) * spk_qpad, spk_P, fdone);
-            }
-        };
-        return replay_batches(s, enq, fdone, reinterpret_cast<int *>(host_scratch), (long long)a.npen * a.nl * ((long long)a.maxit + 2) + 8, "packed-triangle engine");
-    }
-
     // ---- fused engine when the operators are row-local and nothing needs a global sum per iteration
-    const bool fused_ok = a.ngroups == 0 && !a.accelerate && !a.compute_loss && !a.sinv && (q == 512 || q == 1024 || q == 2048 || q == 4096) &&
+    const bool elementwise = a.ngroups == 0 && !a.accelerate && !a.compute_loss && !a.sinv;
+    const bool fused_ok = elementwise && (q == 512 || q == 1024 || q == 2048 || q == 4096) &&
                           (((uintptr_t)a.xx) & 15) == 0 && !sw().OEM_NO_FUSED.set;
     if (fused_ok) {
         double *fbase = T + 2 * MAXL + 64;
@@ -1693,8 +1683,27 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         return replay_batches(s, enq, fdone, reinterpret_cast<int *>(host_scratch), (long long)a.npen * a.nl * ((long long)a.maxit + 2) + 8, "fused engine");
     }
 
-    // ---- replicated-update fused engine: everything else at the same sizes
-    const bool rep_ok = q <= 4096 && !sw().OEM_NO_FUSED.set;
+    // ---- element-wise penalties at every other q > 1024: (head, product) pairs over the packed triangle
+    if (spk && elementwise && spk_qpad / SPK_HC <= FMAXB && !sw().OEM_NO_FUSED.set) {
+        spk_pack();
+        int *flags = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad);
+        SState *SS = reinterpret_cast<SState *>(spk_B + 2 * (size_t)spk_qpad + FMAXB);
+        int *fdone = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad + FMAXB + 16);
+        hipLaunchKernelGGL(sym_init_kernel, dim3(1), dim3(1), 0, s, SS, a);
+        auto enq = [&](int count) {
+            for (int k = 0; k < count; ++k) {
+                const int par = k & 1;
+                hipLaunchKernelGGL(sympk_head_kernel, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, a, SS, spk_B, spk_P, flags, fdone, par, d, spk_nb, spk_qpad);
+                hipLaunchKernelGGL(sympk_gemv_kernel, dim3(spk_nt), dim3(256), 0, s, a.sympk, q, spk_qpad, spk_B + (size_t)(par ^ 1) * spk_qpad, spk_P, fdone);
+            }
+        };
+        return replay_batches(s, enq, fdone, reinterpret_cast<int *>(host_scratch), (long long)a.npen * a.nl * ((long long)a.maxit + 2) + 8, "packed-triangle engine");
+    }
+
+    // ---- replicated-update fused engine: everything else up to q = 2048 (one launch per iteration, every workgroup thresholds the whole of u).
+    // Beyond, the packed products + slot sum + update kernel are faster (tools/scattered_groups_time.py, grp.lasso with 60 scattered groups,
+    // us per iteration: q = 3,000 65.9 -> 22.4, 4,096 47.0 -> 29.0; but 1,536 13.9 -> 15.7, 2,048 15.6 -> 15.8: three launches against one)
+    const bool rep_ok = q <= 4096 && !sw().OEM_NO_FUSED.set && !(spk && q > 2048);
     if (rep_ok) {
         double *fbase = T + 2 * MAXL + 64;
         int *fdone = reinterpret_cast<int *>(fbase + 8);
@@ -1725,16 +1734,18 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     //      hand-off was measured and is NOT faster: the agent-scope release + acquire cost what the boundary costs.
     double *uf = nullptr;
     const size_t sh = update_lds(a, &uf);                            // (U and F exist for group operators only)
-    // (4096 < q <= 8192: the operands in registers, every independent load of the kernel issued at once)
-    void (*updk)(PathArgs, LState *, double *, const double *, double *) = (q > 4096 && q <= 8192) ? path_update_kernel<8> : path_update_kernel<0>;
+    // (1024 < q <= 8192: the operands in registers, every independent load of the kernel issued at once)
+    void (*updk)(PathArgs, LState *, double *, const double *, double *) =
+        (q > 1024 && q <= 4096) ? path_update_kernel<4> : (q > 4096 && q <= 8192) ? path_update_kernel<8> : path_update_kernel<0>;
     if (sh > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(updk),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %zu): %s", sh, hipGetErrorString(e)); return OEMGPU_ERR_HIP; }
     }
+    if (spk) spk_pack();
     auto enqueue = [&](int count) {
         for (int k = 0; k < count; ++k) {
-            if (spk) spk_gemv(beta, g, &st->done);
+            if (spk) spk_gemv(beta, g, &st->done);                    // (packed before the capture, below)
             else (void)launch_gemv(s, a.xx, q, beta, g, &st->done, num_cu);
             hipLaunchKernelGGL(updk, dim3(1), dim3(1024), sh, s, a, st, beta, g, uf);
         }
