@@ -712,7 +712,7 @@ def main():
                             "lanczos_steps": int(st4.value), "persistent_kernel_cycles": ms4[6],
                             "algorithmic_GBps_at_8p2_plus_24p_bytes_per_iteration": alg / (best * 1e-3) / 1e9,
                             # the bound that applies: FP64 VALU (2 p^2 flops per product, OEM iterations + Lanczos steps), and the floor of an
-                            # iteration as stamped and probed (profiles/r5_c4_*)
+                            # iteration as stamped and probed (profiles/r5_c4_*, profiles/r6_symcoop_stamped.txt)
                             "fp64_valu_TFLOPs": 2.0 * p4 * p4 * (it4 + int(st4.value)) / (best * 1e-3) / 1e12,
                             "fp64_valu_frac_of_peak": 2.0 * p4 * p4 * (it4 + int(st4.value)) / (best * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                             "us_per_iteration_floor_of_this_design": C4_FLOOR_US,

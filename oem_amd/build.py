@@ -94,7 +94,7 @@ def audit_dpp_hazards(asm_text):
 
 def audit_round_spills(asm_text, limit=16):
     """The eight-wave forms of the row-split path kernel keep 176 of their 256 VGPRs for the matrix, and hipcc's allocation of
-    such a kernel is one edit away from spilling into its hot loop (config 2's SCAD round once went from
+    such a kernel is one edit away from spilling into its hot loop (docs/history.md section 3.2: config 2's SCAD round once went from
     6 to 22 ms that way, with every result right).  iterate_rows_t marks its rounds in the listing; between the marks of an
     element-wise operator without the accelerate option there may be at most `limit` scratch instructions (a handful is what
     the allocator leaves there today; a cliff is a hundred)."""

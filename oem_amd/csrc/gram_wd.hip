@@ -19,7 +19,7 @@
 // them, two off-diagonal blocks of 8 x 16 tiles on eight waves (gram_od_body below) -- 80 fragment reads per slab at p = 512 where
 // gram_sb_kernel's ten super-blocks make 128.
 // Same partial layout as gram_sb_kernel (tiles by their global index, vector partials), same reduction behind it.
-// References: ref src/oem_dense.h:316-366 (XtX), src/oem_big.h:455-534 (row blocks); DESIGN.md section 3.1c.
+// References: ref src/oem_dense.h:316-366 (XtX), src/oem_big.h:455-534 (row blocks); DESIGN.md section 3.1 (docs/history.md section 3.1c for how it got there).
 #include <cstdlib>
 #include <type_traits>
 
