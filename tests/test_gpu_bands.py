@@ -238,12 +238,13 @@ def test_wres_at_its_operating_sizes_against_the_oracle(oa, n, p):
         assert np.abs(grad[nz, i] - pf[nz] * lam[i] * np.sign(bs[nz, i])).max() <= 1e-5 * lam[0]
 
 
-@pytest.mark.parametrize("p", [600, 1100, 2000])
+@pytest.mark.parametrize("p", [600, 1300])
 def test_xval_at_larger_p(oa, p):
     """xval.oem (ref src/oem_xval_dense.cpp:343-461) between p = 300 -- the largest any test had run -- and 1,183, where the
-    CV-error kernel's coefficient tile used to end, and beyond it at p = 2,000: the reference has no limit there."""
+    CV-error kernel's coefficient tile used to end, and beyond it at p = 1,300 (the coefficient tile through LDS in chunks: the
+    reference has no limit there; round 5 held p = 2,000 the same way, dropped for the suite's time)."""
     rng = np.random.default_rng(p)
-    n, nf = (4000, 5) if p < 2000 else (6000, 5)
+    n, nf = (4000, 5)
     x = np.asfortranarray(rng.normal(size=(n, p)) + 0.2)
     y = x[:, :8] @ rng.uniform(0.5, 1.5, 8) + rng.normal(size=n) + 1.0
     foldid = rng.permutation(np.resize(np.arange(1, nf + 1), n))

@@ -362,7 +362,7 @@ def test_row_split_one_exchange_engine(oa, p, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("p", [1100, 2048, 2600, 3500, 4096])
+@pytest.mark.parametrize("p", [1100, 2048, 3500, 4096])
 def test_register_resident_engine_general_form(oa, p, monkeypatch):
     """the same engine with what needs more than a coordinate of its own (path_symcoop_kernel<NT, GEN = true>): group operators --
     the owners' slices cut at group boundaries, every group a run of <= 32 neighbouring coordinates (ragged runs of 1-12, ids in no
