@@ -614,6 +614,58 @@ static int plan_paths(const PlanIn &in, PathPlan &P)
 
 size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o, int nbatch = 1);
 
+// ---- scattered groups at 1024 < q <= 4096: the register-resident engine (path_symcoop.hip) cuts the owners' slices at group boundaries, so
+// it takes group penalties only where every group is a RUN of <= 32 neighbouring coordinates; other layouts went to the launch-per-iteration
+// engines (q = 3,000: 22 against 6-7 us per iteration -- the reference has no such cliff between group layouts, ref src/oem_dense.h:421-456).
+// The OEM iteration does not care where a coordinate sits: u = A beta + XY, coordinate- / group-wise operators, a stop rule over all
+// coordinates, d an eigenvalue.  So groups of <= 32 members that are not runs are MADE runs: coordinates reordered group by group (groups in
+// the order of their first member, members in their own order -- the order the reference sums their squares in), XX, XY, the column
+// constants, penalty factors and scale factors permuted alike, the path solved there, the coefficients put back.  One gather of q^2
+// doubles per call.
+__global__ __launch_bounds__(256) void permute_sym_kernel(const double *__restrict__ xx, const double *__restrict__ xy, const double *__restrict__ st, int q, int p_stats,
+                                                           const int *__restrict__ perm, double *__restrict__ xx2, double *__restrict__ xy2, double *__restrict__ st2)
+{
+    const int j = blockIdx.x, pj = perm[j];
+    for (int i = threadIdx.x; i < q; i += blockDim.x) xx2[(size_t)j * q + i] = xx[(size_t)pj * q + perm[i]];
+    if (threadIdx.x == 0) {
+        xy2[j] = xy[pj];
+        if (j < p_stats) { st2[4 + j] = st[4 + pj]; st2[4 + p_stats + j] = st[4 + p_stats + pj]; }      // meanX | scaleX (stats layout, common.hpp)
+    }
+    if (j == 0) {
+        for (int k = threadIdx.x; k < 4; k += blockDim.x) st2[k] = st[k];
+        for (int k = 4 + 2 * p_stats + threadIdx.x; k < stats_len(p_stats); k += blockDim.x) st2[k] = st[k];
+    }
+}
+
+// new position -> old position, or empty when the groups need no reordering / cannot be made runs of <= 32
+static std::vector<int> group_run_permutation(const oemgpu_opts *o, int q)
+{
+    std::vector<int> perm;
+    if (o->ngroups <= 0 || o->ngroupvars != q) return perm;
+    oemgpu_opts og = *o;
+    Groups G;
+    build_groups(&og, q, q, G);
+    bool runs = true;
+    int longest = 0;
+    for (int g = 0; g < o->ngroups; ++g) {
+        const int len = G.gstart[g + 1] - G.gstart[g];
+        if (len > longest) longest = len;
+        for (int k = 1; k < len && runs; ++k) runs = G.gidx[G.gstart[g] + k] == G.gidx[G.gstart[g]] + k;
+    }
+    if (runs || longest > 32) return perm;
+    perm.reserve(q);
+    std::vector<char> done(o->ngroups, 0);
+    for (int j = 0; j < q; ++j) {
+        const int g = G.gid[j];
+        if (g < 0) perm.push_back(j);
+        else if (!done[g]) { done[g] = 1; for (int m = G.gstart[g]; m < G.gstart[g + 1]; ++m) perm.push_back(G.gidx[m]); }
+    }
+    if ((int)perm.size() != q) perm.clear();            // (a variable listed in two groups: not ours to untangle)
+    return perm;
+}
+
+static thread_local bool g_in_permuted_call = false;
+
 int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const double *stats, int p, int q, int sem,
               int standardize, int intercept, const oemgpu_opts *o, const double *scale_factor,
               double *beta, double *lambda_out, int32_t *niter, double *loss, double *d_out,
@@ -623,6 +675,42 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const bool launches_only = ex && ex->d_fixed > 0.0;
     const int nl = nl_of(o), npen = o->npen;
     const bool user = o->lambda_user && o->nlambda_user > 0;
+    if (!g_in_permuted_call && q > 1024 && q <= 4096 && nbatch == 1 && !wide && !ex && !lmax_xy_dev && xx && (sem == OEMGPU_SEM_DENSE || sem == SEM_XTX) &&
+        o->ngroups > 0 && !sw().OEM_NO_SYMCOOP.set && !sw().OEM_NO_COOP.set && !sw().OEM_SYMCOOP_NO_GENERAL.set) {
+        bool any_group_penalty = false;
+        for (int k = 0; k < npen; ++k) any_group_penalty |= pen_is_grp(o->penalty[k]);
+        const std::vector<int> perm = any_group_penalty ? group_run_permutation(o, q) : std::vector<int>();
+        if (!perm.empty()) {
+            // the permuted problem in a buffer of its own (xx2 | xy2 | stats2 | perm), the options with their per-coordinate arrays permuted
+            const size_t nd = (size_t)q * q + q + stats_len(p) + 8;
+            if (ctx_grow(c, &c->perm_buf, &c->perm_bytes, nd * sizeof(double) + (size_t)q * sizeof(int) + 256)) return OEMGPU_ERR_HIP;
+            double *xx2 = (double *)c->perm_buf, *xy2 = xx2 + (size_t)q * q, *st2 = xy2 + q;
+            int *perm_dev = (int *)(st2 + stats_len(p) + 8);
+            OEM_HIP(hipMemcpyAsync(perm_dev, perm.data(), sizeof(int) * q, hipMemcpyHostToDevice, c->stream));
+            OEM_HIP(hipStreamSynchronize(c->stream));                  // (perm is a pageable vector of this frame)
+            hipLaunchKernelGGL(permute_sym_kernel, dim3(q), dim3(256), 0, c->stream, xx, xy, stats, q, p, perm_dev, xx2, xy2, st2);
+            OEM_HIP(hipGetLastError());
+            std::vector<int32_t> g2(q);
+            std::vector<double> pf2(p), sf2(scale_factor ? q : 0);
+            for (int j = 0; j < q; ++j) { g2[j] = o->groups[perm[j]]; pf2[j] = o->penalty_factor[perm[j]]; if (scale_factor) sf2[j] = scale_factor[perm[j]]; }
+            oemgpu_opts o2 = *o;
+            o2.groups = g2.data(); o2.penalty_factor = pf2.data();
+            g_in_permuted_call = true;
+            const int rc = run_paths(c, B, xx2, xy2, st2, p, q, sem, standardize, intercept, &o2, scale_factor ? sf2.data() : nullptr, beta, lambda_out, niter, loss, d_out,
+                                     nbatch, bstride, shared_lmax, wide, lmax_xy_dev, ex);
+            g_in_permuted_call = false;
+            if (rc) return rc;
+            // the coefficients back to where the caller's variables are (row 0 of oem()'s result is the intercept)
+            const int rows = (sem == SEM_XTX) ? p : p + 1, off = rows - q;
+            std::vector<double> row(rows);
+            for (size_t ki = 0; ki < (size_t)npen * nl; ++ki) {
+                double *ob = beta + ki * rows;
+                memcpy(row.data(), ob, sizeof(double) * rows);
+                for (int j = 0; j < q; ++j) ob[off + perm[j]] = row[off + j];
+            }
+            return 0;
+        }
+    }
     PlanIn pin;
     pin.num_cu = c->num_cu; pin.p = p; pin.q = q; pin.sem = sem; pin.intercept = intercept; pin.nbatch = nbatch; pin.o = o;
     pin.has_scale = scale_factor != nullptr; pin.launches_only = launches_only; pin.loss_ext = ex && ex->loss_xx; pin.wide_n = wide ? wide->n : 0;
@@ -801,8 +889,9 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
         }
         HT(2);
         if (!zero_copy) {
-            if (!joined) OEM_HIP(hipMemcpy2DAsync(dstats, out_stride, stats, bstride * sizeof(double), sizeof(double) * stats_len(p), nbatch,
-                                                  hipMemcpyDeviceToDevice, c->stream));
+            if (!joined && nbatch == 1) OEM_HIP(hipMemcpyAsync(dstats, stats, sizeof(double) * stats_len(p), hipMemcpyDeviceToDevice, c->stream));      // (stats outside the frame: the permuted problem)
+            else if (!joined) OEM_HIP(hipMemcpy2DAsync(dstats, out_stride, stats, bstride * sizeof(double), sizeof(double) * stats_len(p), nbatch,
+                                                       hipMemcpyDeviceToDevice, c->stream));
             OEM_HIP(hipMemcpyAsync(c->pinned, joined ? (const void *)stats : (const void *)dout, back_bytes, hipMemcpyDeviceToHost, c->stream));
         }
         HT(3);
@@ -1064,6 +1153,7 @@ void oemgpu_destroy(oemgpu_ctx *c)
     if (c->xres) (void)hipFree(c->xres);
     if (c->blob_buf) (void)hipFree(c->blob_buf);
     if (c->pack_buf) (void)hipFree(c->pack_buf);
+    if (c->perm_buf) (void)hipFree(c->perm_buf);
     if (c->abort_host) (void)hipHostFree(c->abort_host);
     if (c->acc) (void)hipFree(c->acc);
     for (oemgpu_lane &l : c->lanes) {

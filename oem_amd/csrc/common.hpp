@@ -52,7 +52,7 @@ int launch_moments_reduce(hipStream_t s, const GramPlan &pl, const double *tpart
 
 // stats layout written by finalize (doubles): [0] meanY [1] scaleY [2] yy (sum of squared standardised y)
 // [3] nobs [4..4+p) meanX [4+p..4+2p) scaleX (dense) or colsq_inv (big) [4+2p] 1 if the moments were read as shifted [4+2p+1] 0
-static inline int stats_len(int p) { return 4 + 2 * p + 2; }
+__host__ __device__ static inline int stats_len(int p) { return 4 + 2 * p + 2; }
 __host__ __device__ static inline int stats_shift_flag(int p) { return 4 + 2 * p; }
 int launch_finalize(hipStream_t s, const double *moments, const double *sums, int p, int sem, int standardize,
                     int intercept, double *xx /* q x q */, double *xy /* q */, double *stats);

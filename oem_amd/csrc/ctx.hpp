@@ -59,6 +59,8 @@ struct oemgpu_ctx {
     size_t blob_bytes = 0;
     char *pack_buf = nullptr;      // q > 4096: the packed lower triangle of XX and its products' partial vectors (PathArgs::sympk; grow-only,
     size_t pack_bytes = 0;         // released with the cache's other big buffers when it exceeds OEMGPU_CACHE_KEEP_BYTES)
+    char *perm_buf = nullptr;      // 1024 < q <= 4096 with scattered groups: XX, XY and the column constants reordered so that every group is a run
+    size_t perm_bytes = 0;         // of neighbours (api.hip: group_run_permutation; grow-only)
     const char *blob_dev = nullptr;   // where the last parameter blob was uploaded (run_paths skips an identical upload)
     size_t blob_len = 0;
     // A persistent engine that timed out (somebody else holds the CUs) is not tried again at once: the next `persistent_skip` calls

@@ -417,9 +417,10 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
 #pragma unroll
         for (int e = 0; e < SE1; ++e) {
             const int r = part + 8 * e;
-            // (element-wise form: the first lane group of a wave that owns no coordinate gathers the pairs of coordinate c0 as well -- for their
-            // tags alone: every wave then holds the "still moving" OR over ALL coordinates by itself, see the vote below)
-            const bool ok = (own || (!GEN && lane < 8)) && e < e1n && r < nsB;
+            // (the first lane group of a wave that owns no coordinate gathers the pairs of coordinate c0 as well -- for their tags alone: every
+            // wave -- and a workgroup that owns nothing, general form with a few large groups -- then holds the "still moving" OR over ALL
+            // coordinates by itself, see the vote below)
+            const bool ok = (own || lane < 8) && e < e1n && r < nsB;
             goff[e] = ok ? ((blkbase[B] + r) * 64 + (cg & 63)) * 16 : 0;
             if (ok) need1 |= 1u << e;
         }
@@ -1222,13 +1223,15 @@ static bool symcoop_plan_per(int q, int gmax, SymcoopPlan &P, const int *runs, i
     if (runs) {
         // every owner whole runs, 1 .. SSL coordinates: the partition of the nruns runs into G consecutive pieces with the smallest sum of
         // squared piece sizes (dynamic programming over (owners, runs); a piece ends at most SSL coordinates after it starts)
-        if (nruns < G) return false;
+        // (fewer runs than workgroups -- a few large groups: the first K = nruns owners take a run each, the others own nothing: an owner's
+        //  coordinates are worked on by eight lanes each, all at once, so an owner with 30 of them is no slower than one with 20)
+        const int K = std::min(G, nruns);
         const double INF = 1e300;
-        std::vector<double> cost((size_t)(G + 1) * (nruns + 1), INF);
-        std::vector<int> from((size_t)(G + 1) * (nruns + 1), -1);
+        std::vector<double> cost((size_t)(K + 1) * (nruns + 1), INF);
+        std::vector<int> from((size_t)(K + 1) * (nruns + 1), -1);
         cost[0] = 0.0;
-        for (int g = 1; g <= G; ++g)
-            for (int r = g; r <= nruns - (G - g); ++r) {
+        for (int g = 1; g <= K; ++g)
+            for (int r = g; r <= nruns - (K - g); ++r) {
                 double best = INF; int bi = -1;
                 for (int r0 = r - 1; r0 >= g - 1 && runs[r] - runs[r0] <= SSL; --r0) {
                     const double c = cost[(size_t)(g - 1) * (nruns + 1) + r0];
@@ -1238,9 +1241,10 @@ static bool symcoop_plan_per(int q, int gmax, SymcoopPlan &P, const int *runs, i
                 }
                 cost[(size_t)g * (nruns + 1) + r] = best; from[(size_t)g * (nruns + 1) + r] = bi;
             }
-        if (cost[(size_t)G * (nruns + 1) + nruns] >= INF) return false;      // (a run longer than an owner holds, or no such partition)
+        if (cost[(size_t)K * (nruns + 1) + nruns] >= INF) return false;      // (a run longer than an owner holds, or no such partition)
         int r = nruns;
-        for (int g = G; g >= 1; --g) { cut[g] = runs[r]; r = from[(size_t)g * (nruns + 1) + r]; }
+        for (int g = G; g > K; --g) cut[g] = q;
+        for (int g = K; g >= 1; --g) { cut[g] = runs[r]; r = from[(size_t)g * (nruns + 1) + r]; }
         cut[0] = 0;
     } else {
         const int base = q / G, rem = q % G;
@@ -1249,8 +1253,8 @@ static bool symcoop_plan_per(int q, int gmax, SymcoopPlan &P, const int *runs, i
     for (int g = 0; g < G; ++g) {
         int *r = tab.data() + SPLAN_HEAD + (size_t)g * SW_INTS;
         const std::vector<int> &b = blocks[g];
-        r[SW_NB] = (int)b.size(); r[SW_C0] = cut[g]; r[SW_NSL] = cut[g + 1] - cut[g];
-        if (r[SW_NSL] < 1 || r[SW_NSL] > SSL) return false;
+        r[SW_NB] = (int)b.size(); r[SW_C0] = cut[g] < q ? cut[g] : q - 1; r[SW_NSL] = cut[g + 1] - cut[g];      // (an owner of nothing points at a valid coordinate: it reads that one's tags, path_symcoop_kernel)
+        if (r[SW_NSL] < (runs ? 0 : 1) || r[SW_NSL] > SSL) return false;
         auto slot = [&](int B) { return (int)(std::lower_bound(b.begin(), b.end(), B) - b.begin()); };
         for (int s = 0; s < (int)b.size(); ++s) {
             r[SW_BLK + s] = b[s];

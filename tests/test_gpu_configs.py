@@ -362,6 +362,56 @@ def test_row_split_one_exchange_engine(oa, p, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("p", [1500, 3000])
+def test_scattered_groups_stay_on_the_register_resident_engine(oa, p):
+    """1024 < q <= 4096 with groups that are NOT runs of neighbouring coordinates (dealt round robin: the members of a group are 75 / 100
+    coordinates apart; group 0 unpenalised, custom weights, penalty factors): the coordinates are reordered group by group, the path solved
+    on path_symcoop_kernel<.., GEN> and the coefficients put back (api.hip: group_run_permutation) -- until round 6 such calls ran the
+    launch-per-iteration engines at 3-10 x the time per iteration; the reference has no cliff between group layouts (ref
+    src/oem_dense.h:421-456, 193-315).  oem.xtx (+ scale.factor) and oem() with standardisation and an intercept, against the oracle."""
+    import torch
+    rng = np.random.default_rng(77 * p)
+    n = p + 1200
+    x = np.asfortranarray(rng.normal(size=(n, p)) * (1.0 + 0.5 * rng.uniform(size=p)) + 0.3)
+    b = np.zeros(p); b[rng.choice(p, 20, replace=False)] = rng.uniform(-1, 1, 20)
+    y = x @ b + rng.normal(size=n) + 0.5
+    ngr = p // 20 if p == 1500 else p // 30                          # 20 / 30 members each, scattered
+    groups = np.arange(p) % ngr                                       # (group 0: unpenalised, ref src/oem_dense.h:207)
+    gw = rng.uniform(0.5, 2.0, ngr)
+    pf = np.ones(p); pf[:3] = 0.0; pf[3:7] = 2.0
+    xtx, xty = x.T @ x / n, x.T @ y / n
+    xd = torch.as_tensor(xtx, device="cuda")
+    kw = dict(penalty=["grp.lasso", "sparse.grp.lasso", "lasso", "grp.mcp"], groups=groups, group_weights=gw, penalty_factor=pf, tau=0.4, gamma=3.5,
+              nlambda=4, lambda_min_ratio=0.05, tol=1e-9, maxit=400)
+    f = oa.oem_xtx(xd, xty, **kw)
+    assert oa.last_path_engine()[0] == "symcoop"
+    r = orc.fit_xtx(xtx, xty, native=True, unique_groups=np.unique(groups), d_override=f["d"], **kw)
+    lam_max = np.linalg.eigvalsh(xtx)[-1]
+    assert abs(f["d"] - 1.005 * lam_max) <= 1e-10 * lam_max
+    for k in range(4):
+        assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-12)
+        assert np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max() <= 1e-9 * max(1.0, float(np.abs(r["beta"][k]).max())), kw["penalty"][k]
+        assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int)).max() <= 1
+        assert (np.asarray(f["beta"][k])[:, -1] != 0).sum() >= 5
+    if p == 1500:
+        sf = np.linspace(0.6, 1.8, p)
+        kws = dict(penalty=["grp.lasso", "lasso"], groups=groups, nlambda=3, lambda_min_ratio=0.1, tol=1e-9, maxit=400, scale_factor=sf)
+        fs = oa.oem_xtx(xd, xty, **kws)
+        assert oa.last_path_engine()[0] == "symcoop"
+        rs = orc.fit_xtx(xtx, xty, native=True, unique_groups=np.unique(groups), d_override=fs["d"], **kws)
+        for k in range(2):
+            assert np.abs(np.asarray(fs["beta"][k]) - np.asarray(rs["beta"][k])).max() <= 1e-9 * max(1.0, float(np.abs(rs["beta"][k]).max()))
+        # through oem(): DataStd's constants travel with their columns, the intercept comes back in row 0
+        kwd = dict(penalty=["grp.lasso", "grp.scad"], groups=groups, group_weights=gw, nlambda=4, lambda_min_ratio=0.05, tol=1e-9, maxit=400, compute_loss=True)
+        fd = oa.oem(x, y, **kwd)
+        assert oa.last_path_engine()[0] == "symcoop"
+        rd = orc.fit_dense(x, y, native=True, unique_groups=np.unique(groups), d_override=fd["d"], **kwd)
+        for k in range(2):
+            assert np.abs(np.asarray(fd["beta"][k]) - np.asarray(rd["beta"][k])).max() <= 1e-9 * max(1.0, float(np.abs(rd["beta"][k]).max()))
+            assert np.allclose(fd["loss"][k], rd["loss"][k], rtol=1e-8)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("p", [1100, 2048, 3500, 4096])
 def test_register_resident_engine_general_form(oa, p, monkeypatch):
     """the same engine with what needs more than a coordinate of its own (path_symcoop_kernel<NT, GEN = true>): group operators --
@@ -442,9 +492,13 @@ def test_register_resident_engine_general_form(oa, p, monkeypatch):
             for k in range(len(kw["penalty"])):
                 assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int)).max() <= 1
                 assert np.allclose(f["loss"][k], r["loss"][k], rtol=1e-9)
-    # groups that are NOT runs of neighbouring coordinates: the launch-per-iteration engines take the call (same answer as ever)
+    # groups that are NOT runs of neighbouring coordinates (<= 12 members each): reordered into runs, still this engine (round 6;
+    # test_scattered_groups_stay_on_the_register_resident_engine holds that against the oracle) -- groups too large for an owner's
+    # slice (> 32 members) go to the launch-per-iteration engines
     sc = oa.oem_xtx(xd, xty, penalty="grp.lasso", groups=rng.permutation(groups), nlambda=3, tol=1e-8)
-    assert not persistent() and np.isfinite(np.asarray(sc["beta"][0])).all()
+    assert persistent() and np.isfinite(np.asarray(sc["beta"][0])).all()
+    big = oa.oem_xtx(xd, xty, penalty="grp.lasso", groups=np.arange(p) % (p // 40), nlambda=3, tol=1e-8)
+    assert not persistent() and np.isfinite(np.asarray(big["beta"][0])).all()
 
 
 @pytest.mark.gpu

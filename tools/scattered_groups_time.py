@@ -21,7 +21,9 @@ for p in [int(a) for a in sys.argv[1:]] or [1536, 2048, 3000, 4096]:
     lib = L.lib(); ctx = oem_amd.context()
     L.check(lib.oemgpu_set_timing(ctx, 1))
     scattered = np.arange(p) % 60 + 1
-    for label, env, kw in (("grp.lasso, 60 scattered groups", {}, dict(penalty=["grp.lasso"], groups=scattered)),
+    small = np.arange(p) % (p // 25) + 1                 # <= 32 members each: reordered into runs, the register-resident engine takes them
+    for label, env, kw in (("grp.lasso, scattered groups of 25", {}, dict(penalty=["grp.lasso"], groups=small)),
+                           ("grp.lasso, 60 scattered groups", {}, dict(penalty=["grp.lasso"], groups=scattered)),
                            ("lasso, launches (OEM_NO_SYMCOOP=1)", {"OEM_NO_SYMCOOP": "1"}, dict(penalty=["lasso"])),
                            ("lasso, row-streaming launches (OEM_NO_SYMCOOP=1 OEM_NO_SYM=1)", {"OEM_NO_SYMCOOP": "1", "OEM_NO_SYM": "1"}, dict(penalty=["lasso"])),
                            ("grp.lasso scattered, row-streaming launches (OEM_NO_SYM=1)", {"OEM_NO_SYM": "1"}, dict(penalty=["grp.lasso"], groups=scattered))):
