@@ -26,8 +26,9 @@ struct LState {
     int pending_loss;        // index k*nl+i whose loss is due from the next g = XX beta, or -1
     int reset_next;          // the next update starts a penalty from beta = 0
     int finish_after_loss;   // all lambdas done; stop once the pending loss is written
-    int pad;
-    double ak, d, theta, lmax;
+    int pen;                 // penalty[pp] and lambda_out[pp * nl + i] of the position in use, written by whoever advances it: the update kernel
+    double ak, d, theta, lmax;     // runs behind a product that has swept the caches, where every DEPENDENT load is an HBM round trip
+    double lam;
 };
 static const int STATE_DBL = 16;
 static const int MAXL = 512;       // Lanczos steps kept
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(1024) void path_init_kernel(PathArgs A, LState *st,
         double mm = 0.0;
         for (int k = 0; k < (int)(blockDim.x >> 6); ++k) mm = fmax(mm, sh[k]);
         st->pp = 0; st->i = 0; st->it = 0; st->done = (A.npen == 0);
-        st->pending_loss = -1; st->reset_next = 1; st->finish_after_loss = 0; st->pad = 0;
+        st->pending_loss = -1; st->reset_next = 1; st->finish_after_loss = 0; st->pen = 0; st->lam = 0.0;
         st->ak = 1.0; st->d = d; st->theta = theta;
         st->lmax = mm * (A.yscale ? A.stats[1] : 1.0);
         A.d_out[0] = d; A.d_out[1] = theta; A.d_out[2] = 0.0; A.d_out[3] = 0.0; A.d_out[4] = (double)lz_steps; A.d_out[5] = (double)lz_capped; A.d_out[6] = 0.0;
@@ -437,6 +438,8 @@ __global__ __launch_bounds__(1024) void path_init_kernel(PathArgs A, LState *st,
         }
         A.lambda_out[idx] = l;
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && A.npen > 0) { st->pen = A.penalty[0]; st->lam = A.lambda_out[0]; }
 }
 
 // R > 0: the thread's R coordinates of beta, g, XY, the penalty factors and the group ids are loaded into registers FIRST, before the
@@ -459,9 +462,13 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
             rgid[r] = A.ngroups > 0 ? A.gid[jc] : -1;
         }
     }
-    int pgz = 1, pgs0 = 0, pgs1 = 0;
+    int pgz = 1, pgs0 = 0, pgs1 = 0, pix[8];
     double pgw = 0.0;
     if (R && tid < A.ngroups) { pgz = A.gzero[tid]; pgs0 = A.gstart[tid]; pgs1 = A.gstart[tid + 1]; pgw = A.gw[tid]; }
+    if (R) {                                                   // ... and the first eight member indices of that group: a second chain next to the state's
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pix[u] = (tid < A.ngroups && pgs0 < pgs1) ? A.gidx[pgs0 + u < pgs1 ? pgs0 + u : pgs1 - 1] : 0;
+    }
     if (st->done) return;
     const int pp = st->pp, i = st->i;
     int it = st->it;
@@ -486,10 +493,9 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
         return;
     }
     const bool reset = st->reset_next != 0;
-    const int pen = A.penalty[pp];
+    const int pen = st->pen;
     const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
-
-    const double lam = A.lambda_out[(size_t)pp * nl + i];          // table written by path_init_kernel
+    const double lam = st->lam;
     const PenK K = pen_consts(pen, lam / scaley, d, A.alpha, A.gamma, A.tau);
     const double rD = 1.0 / K.D, gammad = K.gamma * K.D, dmg = K.D - 1.0 / K.gamma, rdmg = 1.0 / dmg;
     const double gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0, rdsc = 1.0 / dsc;
@@ -511,10 +517,11 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
                 double s = 0.0;
                 // members in member order, their indices fetched eight at a time (one dependent load per member was a memory round trip each)
                 const int m1 = first ? pgs1 : A.gstart[gi + 1];
-                for (int m = first ? pgs0 : A.gstart[gi]; m < m1; m += 8) {
+                const int mbeg = first ? pgs0 : A.gstart[gi];
+                for (int m = mbeg; m < m1; m += 8) {
                     int ix[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) ix[u] = A.gidx[m + u < m1 ? m + u : m1 - 1];
+                    for (int u = 0; u < 8; ++u) ix[u] = (R && first && m == mbeg) ? pix[u] : A.gidx[m + u < m1 ? m + u : m1 - 1];
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
                         if (m + u < m1) { const double x = U[ix[u]]; s += x * x; }
@@ -539,7 +546,7 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
         if (grp) {
             const int gi = OEM_UPD(rgid, A.gid[j]);
             const double f = gi >= 0 ? F[gi] : 0.0;
-            bn = (f != 0.0) ? U[j] * f / K.D : 0.0;
+            bn = (f != 0.0) ? cdiv(U[j] * f, K.D, rD) : 0.0;       // (a true FP64 division per coordinate is ~40 instructions on the one CU this kernel has)
         } else {
             const double u = (d * bo - (reset ? 0.0 : OEM_UPD(rg, g[j]))) + OEM_UPD(rxy, A.xy[j]);
             const double tp = OEM_UPD(rpf, A.pf[j]) * K.L;
@@ -585,8 +592,8 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
             if (!A.compute_loss) A.loss[ki] = 1e99;
             st->pending_loss = A.compute_loss ? (int)ki : -1;
             st->it = 0; st->ak = ak;
-            if (i + 1 < nlam) { st->i = i + 1; st->reset_next = 0; }
-            else if (pp + 1 < A.npen) { st->pp = pp + 1; st->i = 0; st->reset_next = 1; }
+            if (i + 1 < nlam) { st->i = i + 1; st->reset_next = 0; st->lam = A.lambda_out[(size_t)pp * nl + i + 1]; }
+            else if (pp + 1 < A.npen) { st->pp = pp + 1; st->i = 0; st->reset_next = 1; st->pen = A.penalty[pp + 1]; st->lam = A.lambda_out[(size_t)(pp + 1) * nl]; }
             else {
                 st->reset_next = 0;
                 if (A.compute_loss) st->finish_after_loss = 1; else st->done = 1;

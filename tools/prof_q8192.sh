@@ -8,5 +8,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/pmc_summary.py sympk_gemv_kernel $o/${tag}_q8192_pmc_sympk_gemv.json "$(find $o/${tag}_q8192_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_q8192_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
 python3 tools/pmc_summary.py sympk_head_kernel $o/${tag}_q8192_pmc_sympk_head.json "$(find $o/${tag}_q8192_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $o/${tag}_q8192_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)"
-for f in $o/${tag}_q8192_kernel_stats.csv $o/${tag}_q8192_grp_kernel_stats.csv; do grep "oemgpu::" $f | cut -c1-60,140-400 | sed "s/([^)]*)//" | head -8; done
+
 rm -rf $o/${tag}_q8192_trace $o/${tag}_q8192g_trace $o/${tag}_q8192_pmc_FETCH_SIZE $o/${tag}_q8192_pmc_WRITE_SIZE

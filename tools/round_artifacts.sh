@@ -92,6 +92,11 @@ if [ -z "$quick" ]; then
   bash tools/attic/gram_band_small.sh > $o/${tag}_gram_band_small.txt 2>&1
   for p in 128 256 300 512 1024; do python3 tools/gram_by_n.py $p 30000 60000 100000 200000 500000 2000000 2>&1 | grep -v amdgpu.ids; done > $o/${tag}_gram_by_n_now.txt
   python3 tools/large_q_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_large_q_now.txt
+  # ---- round 6: the HBM-bound GEMV loop (q = 8,192 on the packed lower triangle: kernel stats + FETCH_SIZE / WRITE_SIZE), what the register
+  # engines do not take at 1024 < q <= 4096, config 4's stamps with the arrival spread of its gathers
+  bash tools/prof_q8192.sh > /dev/null 2>&1
+  python3 tools/scattered_groups_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_scattered_groups_now.txt
+  python3 tools/spk_check.py 4097 6145 8192 2>&1 | grep -v amdgpu.ids > $o/${tag}_spk_check.txt
   python3 tools/scale_factor_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_scale_factor_now.txt
 fi
 # the raw traces stay on the box: gpurun copies back at most 64 MiB
