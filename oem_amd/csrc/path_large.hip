@@ -446,12 +446,21 @@ __global__ __launch_bounds__(1024) void path_init_kernel(PathArgs A, LState *st,
 // state's dependent loads -- every load of the kernel that does not depend on another is then in flight together (q = 8,192 with 1,024
 // groups: 14.4 us of dependent round trips, one per loop trip, for 256 KB of operands).  R = 0: the loops read memory as they go (any q).
 // Same operations in the same order either way.
+#ifdef OEM_PATH_DIAG
+__device__ unsigned long long g_diag_update[8];       // cycles of thread 0 per phase of path_update<R > 0> (tools/attic/update_diag.py): [7] = calls
+#define UPD_STAMP(k) do { if (R && tid == 0) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t__ = __builtin_amdgcn_s_memtime(); g_diag_update[k] += t__ - upd_t; upd_t = t__; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define UPD_STAMP(k) do { } while (0)
+#endif
 template <int R>
 __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, double *__restrict__ beta,
                                             const double *__restrict__ g, double *dyn, double *sh)
 {
     constexpr int RR = R ? R : 1;
     const int q = A.p, nl = A.nl, tid = threadIdx.x, nt = blockDim.x;
+#ifdef OEM_PATH_DIAG
+    unsigned long long upd_t = __builtin_amdgcn_s_memtime();
+#endif
     double rb[RR], rg[RR], rxy[RR], rpf[RR];
     int rgid[RR];
     if (R) {
@@ -473,6 +482,7 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
     const int pp = st->pp, i = st->i;
     int it = st->it;
     const double d = st->d;
+    UPD_STAMP(0);                                              // the state is there (the first memory round trip)
     const double scaley = A.yscale ? A.stats[1] : 1.0;
     const double yy = A.stats[2], nobs = A.stats[3];
     double *U = dyn, *F = dyn + q;
@@ -501,6 +511,7 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
     const double gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0, rdsc = 1.0 / dsc;
     const bool grp = K.kind >= K_GRP;
     double ak = reset ? 1.0 : st->ak;
+    UPD_STAMP(1);                                              // the operator's constants
 
     // ---- u and (for group operators) the group factors
     if (grp) {
@@ -510,6 +521,7 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
             U[j] = (K.kind == K_SGL) ? soft1(u, OEM_UPD(rpf, A.pf[j]) * K.L1, 1.0) : u;
         }
         __syncthreads();
+        UPD_STAMP(2);                                          // u of every coordinate in LDS (the operands are there)
         for (int gi = tid; gi < A.ngroups; gi += nt) {
             double f = 1.0;
             const bool first = R && gi == tid;                   // (the first trip's group was fetched with the operands)
@@ -535,6 +547,7 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
             F[gi] = f;
         }
         __syncthreads();
+        UPD_STAMP(3);                                          // the group factors
     }
     // ---- beta = T(u), acceleration, stop rule.  Each thread owns its coordinates: it reads the old value, then writes.
     bool bad = false;
@@ -577,8 +590,10 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
         adp = block_sum(adp, sh);
         ak = (adp > 0.0) ? 1.0 : akn;
     }
+    UPD_STAMP(4);                                              // the new coefficients, stored
     const int anybad = __syncthreads_or(bad ? 1 : 0);
     ++it;
+    UPD_STAMP(5);
     const bool conv = !anybad;
     if (conv || it >= A.maxit) {
         const size_t ki = (size_t)pp * nl + i;
@@ -600,6 +615,10 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
             }
         }
     } else if (tid == 0) { st->it = it; st->ak = ak; st->reset_next = 0; st->pending_loss = -1; }
+    UPD_STAMP(6);
+#ifdef OEM_PATH_DIAG
+    if (R && tid == 0) g_diag_update[7] += 1;
+#endif
 #undef OEM_UPD_LOOP
 #undef OEM_UPD
 }
@@ -1547,6 +1566,15 @@ static int replay_batches(hipStream_t s, F &&enq, const int *done_dev, int *hdon
     if (graph) (void)hipGraphDestroy(graph);
     return rc;
 }
+
+#ifdef OEM_PATH_DIAG
+extern "C" __attribute__((visibility("default"))) int oemgpu_diag_read_update(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_update), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag_update), z, sizeof z); }
+    return 0;
+}
+#endif
 
 // host_scratch: pinned host memory (>= 8 KB)
 int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
