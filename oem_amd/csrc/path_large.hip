@@ -452,9 +452,15 @@ __device__ unsigned long long g_diag_update[8];       // cycles of thread 0 per 
 #else
 #define UPD_STAMP(k) do { } while (0)
 #endif
+// a workgroup barrier behind LDS traffic only (s_waitcnt lgkmcnt(0)), or __syncthreads() where global memory crosses threads too
+__device__ __forceinline__ void upd_barrier(bool lds_only)
+{
+    if (lds_only) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
+    else __syncthreads();
+}
 template <int R>
 __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, double *__restrict__ beta,
-                                            const double *__restrict__ g, double *dyn, double *sh)
+                                            const double *__restrict__ g, double *dyn, double *sh, bool lds_only)
 {
     constexpr int RR = R ? R : 1;
     const int q = A.p, nl = A.nl, tid = threadIdx.x, nt = blockDim.x;
@@ -478,49 +484,56 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
 #pragma unroll
         for (int u = 0; u < 8; ++u) pix[u] = (tid < A.ngroups && pgs0 < pgs1) ? A.gidx[pgs0 + u < pgs1 ? pgs0 + u : pgs1 - 1] : 0;
     }
-    if (st->done) return;
-    const int pp = st->pp, i = st->i;
+    // Everything the kernel needs from memory is asked for HERE, and consumed before the first branch: hipcc sinks a load below a branch it
+    // does not have to precede, and behind a product that has swept the caches every such load is an HBM round trip of its own (stamped,
+    // tools/attic/update_diag.py, q = 8,192 with groups: 37.3 k -> 34.5 k cycles per launch, element-wise 21.5 k -> 18.2 k).  What remains is
+    // ONE CU's memory path: 330 KB of operands in and 64 KB out at the ~55 GB/s a single CU pulls are 6-7 us whatever the order -- the
+    // stamps show the waves arriving at the first barrier 5 us apart.  Faster means more workgroups.
+    const int done0 = st->done, pp = st->pp, i = st->i, pen = st->pen, pl = st->pending_loss, fin0 = st->finish_after_loss;
+    const bool reset = st->reset_next != 0;
     int it = st->it;
-    const double d = st->d;
-    UPD_STAMP(0);                                              // the state is there (the first memory round trip)
+    const double d = st->d, ak0 = st->ak, lam = st->lam;
     const double scaley = A.yscale ? A.stats[1] : 1.0;
-    const double yy = A.stats[2], nobs = A.stats[3];
+    const double ilam = lam / scaley;
+    double ru[RR];                                             // u = d beta - g + XY of the thread's coordinates (R > 0)
+    if (R) {
+#pragma unroll
+        for (int r = 0; r < RR; ++r) ru[r] = (d * (reset ? 0.0 : rb[r]) - (reset ? 0.0 : rg[r])) + rxy[r];
+    }
+    if (done0) return;
+    UPD_STAMP(0);                                              // the state and the operands are there (the one memory round trip)
     double *U = dyn, *F = dyn + q;
 #define OEM_UPD_LOOP _Pragma("unroll RR") for (int r = 0, j = tid; R ? r < RR : j < q; ++r, j += nt) if (!R || j < q)
 #define OEM_UPD(reg, mem) (R ? (reg)[R ? r : 0] : (mem))
 
     // ---- loss of the lambda that converged in the previous update: g is XX beta_final (Gram identity, see path_small)
-    const int pl = st->pending_loss;
     if (pl >= 0) {
+        const double yy = A.stats[2], nobs = A.stats[3];
         double t = 0.0;
         OEM_UPD_LOOP t += OEM_UPD(rb, beta[j]) * (OEM_UPD(rg, g[j]) - 2.0 * OEM_UPD(rxy, A.xy[j]));
         t = block_sum(t, sh);
         if (tid == 0) A.loss[pl] = yy + nobs * t;
     }
-    if (st->finish_after_loss) {
+    if (fin0) {
         __syncthreads();
         if (tid == 0) { st->pending_loss = -1; st->done = 1; }
         return;
     }
-    const bool reset = st->reset_next != 0;
-    const int pen = st->pen;
     const int nlam = (pen == OEMGPU_OLS) ? 1 : nl;
-    const double lam = st->lam;
-    const PenK K = pen_consts(pen, lam / scaley, d, A.alpha, A.gamma, A.tau);
+    const PenK K = pen_consts(pen, ilam, d, A.alpha, A.gamma, A.tau);
     const double rD = 1.0 / K.D, gammad = K.gamma * K.D, dmg = K.D - 1.0 / K.gamma, rdmg = 1.0 / dmg;
     const double gm1 = K.gamma - 1.0, dsc = gm1 * K.D - 1.0, rdsc = 1.0 / dsc;
     const bool grp = K.kind >= K_GRP;
-    double ak = reset ? 1.0 : st->ak;
+    double ak = reset ? 1.0 : ak0;
     UPD_STAMP(1);                                              // the operator's constants
 
     // ---- u and (for group operators) the group factors
     if (grp) {
         OEM_UPD_LOOP {
-            const double bo = reset ? 0.0 : OEM_UPD(rb, beta[j]);
-            const double u = (d * bo - (reset ? 0.0 : OEM_UPD(rg, g[j]))) + OEM_UPD(rxy, A.xy[j]);
+            const double u = R ? ru[R ? r : 0] : (d * (reset ? 0.0 : beta[j]) - (reset ? 0.0 : g[j])) + A.xy[j];
             U[j] = (K.kind == K_SGL) ? soft1(u, OEM_UPD(rpf, A.pf[j]) * K.L1, 1.0) : u;
         }
-        __syncthreads();
+        upd_barrier(lds_only);
         UPD_STAMP(2);                                          // u of every coordinate in LDS (the operands are there)
         for (int gi = tid; gi < A.ngroups; gi += nt) {
             double f = 1.0;
@@ -546,7 +559,7 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
             }
             F[gi] = f;
         }
-        __syncthreads();
+        upd_barrier(lds_only);
         UPD_STAMP(3);                                          // the group factors
     }
     // ---- beta = T(u), acceleration, stop rule.  Each thread owns its coordinates: it reads the old value, then writes.
@@ -561,7 +574,7 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
             const double f = gi >= 0 ? F[gi] : 0.0;
             bn = (f != 0.0) ? cdiv(U[j] * f, K.D, rD) : 0.0;       // (a true FP64 division per coordinate is ~40 instructions on the one CU this kernel has)
         } else {
-            const double u = (d * bo - (reset ? 0.0 : OEM_UPD(rg, g[j]))) + OEM_UPD(rxy, A.xy[j]);
+            const double u = R ? ru[R ? r : 0] : (d * bo - (reset ? 0.0 : g[j])) + A.xy[j];
             const double tp = OEM_UPD(rpf, A.pf[j]) * K.L;
             if (K.kind == K_SOFT) bn = cdiv(shrink(u, tp), K.D, rD);
             else if (K.kind == K_MCP) {
@@ -591,7 +604,17 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
         ak = (adp > 0.0) ? 1.0 : akn;
     }
     UPD_STAMP(4);                                              // the new coefficients, stored
-    const int anybad = __syncthreads_or(bad ? 1 : 0);
+    // (the vote crosses threads through LDS alone: no wait for the coefficient stores' acknowledgements in front of the barrier)
+    int anybad;
+    {
+        int *vote = reinterpret_cast<int *>(sh + 16);
+        const int wb = __ballot(bad) != 0ull ? 1 : 0;
+        if ((tid & 63) == 0) vote[tid >> 6] = wb;
+        upd_barrier(true);
+        int o = 0;
+        for (int k = 0; k < (nt >> 6); ++k) o |= vote[k];
+        anybad = o;
+    }
     ++it;
     UPD_STAMP(5);
     const bool conv = !anybad;
@@ -631,8 +654,8 @@ __global__ __launch_bounds__(1024) void path_update_kernel(PathArgs A, LState *s
                                                             const double *__restrict__ g, double *uf)
 {
     extern __shared__ __attribute__((aligned(16))) double dyn[];     // U[q] (group operand), F[ngroups]
-    __shared__ double sh[16];
-    path_update<R>(A, st, beta, g, uf ? uf : dyn, sh);
+    __shared__ double sh[16 + 8];                                    // block sums | the stop rule's 16 wave votes (ints)
+    path_update<R>(A, st, beta, g, uf ? uf : dyn, sh, uf == nullptr);
 }
 
 __global__ __launch_bounds__(1024) void lanczos_update_kernel(int q, int j, double *__restrict__ v, double *__restrict__ vp,
