@@ -14,7 +14,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "liboemgpu.so"
-SOURCES = ["api.hip", "hoststream.hip", "gram.hip", "gram_sb.hip", "gram_wd.hip", "path_small.hip", "path_coop.hip", "path_symcoop.hip", "path_wcoop.hip", "path_large.hip", "xval.hip", "sparse.hip", "wide.hip", "weighted.hip"]
+SOURCES = ["api.hip", "hoststream.hip", "gram.hip", "gram_sb.hip", "gram_wd.hip", "path_small.hip", "path_coop.hip", "path_symcoop.hip", "path_wcoop.hip", "path_wres.hip", "path_large.hip", "xval.hip", "sparse.hip", "wide.hip", "weighted.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
@@ -119,7 +119,7 @@ def audit_round_spills(asm_text, limit=16):
 
 
 def audit_wres_isa(asm_text):
-    """path_wcoop.hip: path_wres_kernel keeps two to eight column sets of every wave in AGPRs a0..a255 that only its inline asm names
+    """path_wres.hip: path_wres_kernel keeps two to eight column sets of every wave in AGPRs a0..a255 that only its inline asm names
     (as path_symcoop.hip's kernels): hipcc itself must not touch the accumulator file there, nor spill to scratch."""
     problems, found = [], 0
     for m in re.finditer(r"^(_ZN6oemgpu\S*path_wres_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end", asm_text, re.S | re.M):
@@ -186,7 +186,7 @@ def build(force=False, verbose=False):
     # the objects are independent hipcc runs: side by side
     from concurrent.futures import ThreadPoolExecutor
     jobs = []
-    AUDITED = ("gram.hip", "gram_sb.hip", "gram_wd.hip", "path_small.hip", "path_coop.hip", "path_wcoop.hip", "path_symcoop.hip")
+    AUDITED = ("gram.hip", "gram_sb.hip", "gram_wd.hip", "path_small.hip", "path_coop.hip", "path_wcoop.hip", "path_wres.hip", "path_symcoop.hip")
     # the audited sources are compiled ONCE: -save-temps=obj leaves the device ISA of the very object that is linked next to it (until
     # round 5 each of the five largest translation units was compiled twice, once for the object and once more with -S for the audit:
     # the cold build's critical path)
@@ -228,13 +228,13 @@ def build(force=False, verbose=False):
             problems = audit_gram_isa(listing[src].result().stdout)
             if problems:
                 raise RuntimeError(src + " ISA audit failed:\n  " + "\n  ".join(problems[:20]))
-        for src in ("path_small.hip", "path_coop.hip", "path_wcoop.hip"):
+        for src in ("path_small.hip", "path_coop.hip", "path_wcoop.hip", "path_wres.hip"):
             problems = audit_dpp_hazards(listing[src].result().stdout)
             if problems:
                 raise RuntimeError(src + " ISA audit failed:\n  " + "\n  ".join(problems[:20]))
-        problems = audit_wres_isa(listing["path_wcoop.hip"].result().stdout)
+        problems = audit_wres_isa(listing["path_wres.hip"].result().stdout)
         if problems:
-            raise RuntimeError("path_wcoop.hip (path_wres_kernel) ISA audit failed:\n  " + "\n  ".join(problems[:20]))
+            raise RuntimeError("path_wres.hip (path_wres_kernel) ISA audit failed:\n  " + "\n  ".join(problems[:20]))
         problems = audit_symcoop_isa(listing["path_symcoop.hip"].result().stdout)
         if problems:
             raise RuntimeError("path_symcoop.hip ISA audit failed:\n  " + "\n  ".join(problems[:20]))
