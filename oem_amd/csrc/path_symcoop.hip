@@ -829,8 +829,8 @@ template <int NT, bool GEN> constexpr size_t symcoop_lds_bytes()
 // them, so the stop decision is everybody's in the SAME iteration).  path_coop.hip extended to these sizes does not close its
 // register budget (its replicated update at eight coordinates per thread: DESIGN section 0, item 4); here a thread owns at most one
 // coordinate.  16-column groups of the vector that are all zero are skipped (a lasso iterate is sparse).  Lanczos the same way, the
-// vector updates replicated from the gathered product (LDS-resident v, v_prev).  Group operators, Nesterov's step, compute.loss and
-// scale.factor go to the symmetric engine above / the launches.
+// vector updates replicated from the gathered product (LDS-resident v, v_prev).  compute.loss and (round 6, template parameter ACC) Nesterov's
+// step run here; group operators and scale.factor go to the symmetric engine above / the launches.
 // ================================================================================================================================
 constexpr int RQ = 2048;          // columns a workgroup covers: 4 waves x 4 row groups x 128
 constexpr int RE = RQ / SNTH;     // pairs per thread in the all-gather
@@ -865,6 +865,10 @@ template <int C> struct RowFma {
     }
 };
 
+// ACC: Nesterov's step (ref src/oem_dense.h:633-651) -- beta = T(u) + r (T(u) - beta_prev); its restart test, the sign of
+// sum_j (beta_j - T(u)_j)(T(u)_j - beta_prev_j) over ALL coordinates, as the workgroups' parts: one more tagged pair per workgroup published next to
+// the coefficients and gathered behind them (thread t holds workgroup t's part: a fixed order) -- the ONE exchange per iteration stays one.
+template <bool ACC>
 __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned long long *xchg)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -904,7 +908,7 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
     const double xyc = own ? A.xy[row] : 0.0, pfc = own ? A.pf[row] : 0.0;
     SymX X;
     X.s1 = 0; X.s2 = RQ * 16; X.o2 = 0; X.o3 = 0; X.o4 = 0;
-    X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, 2 * RQ * 16 + 2 * (RQ / 16) * 16, 0x00020000);      // (+ compute.loss: the workgroups' parts, [2][RQ / 16] pairs)
+    X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, 2 * RQ * 16 + 4 * (RQ / 16) * 16, 0x00020000);      // (+ compute.loss, + Nesterov's restart test: the workgroups' parts, [2][RQ / 16] pairs each)
     X.epoch = 0; X.wg = wg; X.G = G; X.failed = false; X.abortp = reinterpret_cast<const int *const *>(votes + 16); X.aflag = votes + 18;
 #ifdef OEM_PATH_DIAG
     for (int k = 0; k < 16; ++k) X.acc[k] = 0;
@@ -1055,6 +1059,7 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
         __syncthreads();
         for (int j = tid; j < RQ; j += SNTH) Bsh[j] = 0.0;           // cold start (ref src/oem_dense.cpp:243-244)
         double bc = 0.0;                                             // this owner lane's coefficient
+        double ak = 1.0;                                             // Nesterov's sequence, reset at every penalty's cold start (ref src/oem_dense.h:744), not between lambdas
         __syncthreads();
         for (int i = 0; i < nlam; ++i) {
             const double lam = lambda_of(pp, i);
@@ -1070,7 +1075,16 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
             while (it < maxit) {
                 const double g = product();
                 const double u = (d * bc - g) + xyc;                 // ref src/oem_dense.h:512
-                const double bn = own ? sx_op(u, pfc, thkind, thc) : 0.0;
+                double bn = own ? sx_op(u, pfc, thkind, thc) : 0.0;
+                double akn = 1.0;
+                if (ACC) {
+                    akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak));
+                    const double upd = bn, diff = upd - bc;
+                    bn = upd + ((ak - 1.0) / akn) * diff;
+                    // this workgroup's part of the restart test: its sixteen owner lanes are lanes 0..15 of wave 0 (the others hold 0)
+                    const double part = wave_sum(own ? (bn - upd) * diff : 0.0);
+                    if (tid == 0) sx_publish(X.rs, 2 * RQ * 16 + 2 * (RQ / 16) * 16 + (int)((X.epoch + 1u) & 1u) * (RQ / 16) * 16 + wg * 16, part, (X.epoch + 1u) << 1);
+                }
                 const double cu = fabs(bn), qo = fabs(bc);
                 const bool cn = cu > 1e-13, qn = qo > 1e-13;         // ref src/utils.cpp:537-549
                 const int moving = (own && ((cn != qn) || (cn && qn && fabs(bn - bc) > tol * qo))) ? 1 : 0;
@@ -1081,6 +1095,14 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
                 // this kernel has no scalar register to spare)
                 if ((it & 127) == 1) (void)sx_abort_seen(X);
                 const int any = all_gather(bn, moving, Bsh);
+                if (ACC) {                                           // (the parts were published with the coefficients: they are there by now)
+                    int offa[1] = {2 * RQ * 16 + 2 * (RQ / 16) * 16 + (int)(X.epoch & 1u) * (RQ / 16) * 16 + (tid < G ? tid : 0) * 16};
+                    double va[1];
+                    int fla = 0;
+                    sx_gather<1>(offa, tid < G ? 1u : 0u, va, fla, X);
+                    const double tot = sx_block_sum(va[0], red, rpar, w, lane);
+                    ak = (tot > 0.0) ? 1.0 : akn;                    // (the extrapolated beta is kept; only the momentum counter restarts)
+                }
                 if (any & 2) { pp = npen; break; }
                 if (!any) { conv = true; break; }
             }
@@ -1138,17 +1160,18 @@ bool path_rowcoop_eligible(const PathArgs &a, bool group_penalty)
 {
     if (sw().OEM_NO_ROWCOOP.set || sw().OEM_NO_SYMCOOP.set || sw().OEM_NO_COOP.set) return false;
     if (a.p <= 1024 || a.p > RQ || a.nbatch > 1 || a.pen_split) return false;
-    return !(a.sinv || group_penalty || a.accelerate);
+    return !(a.sinv || group_penalty);
 }
 int path_rowcoop_workgroups(int q) { return (q + 15) / 16; }
-size_t path_rowcoop_xchg_bytes() { return (size_t)2 * RQ * 16 + (size_t)2 * (RQ / 16) * 16 + 256; }
+size_t path_rowcoop_xchg_bytes() { return (size_t)2 * RQ * 16 + (size_t)4 * (RQ / 16) * 16 + 256; }
 int launch_path_rowcoop(hipStream_t s, const PathArgs &a, void *xchg)
 {
     OEM_HIP(hipMemsetAsync(xchg, 0, path_rowcoop_xchg_bytes(), s));            // the tags must start at 0
     OEM_HIP(hipMemsetAsync(a.d_out, 0, sizeof(double) * D_OUT_LEN, s));        // [6]: only a timed-out workgroup writes it
     const size_t sh = rowcoop_lds_bytes();
-    if (int rc = lds_limit_once(reinterpret_cast<const void *>(&path_rowcoop_kernel), sh)) return rc;
-    hipLaunchKernelGGL(path_rowcoop_kernel, dim3(path_rowcoop_workgroups(a.p)), dim3(SNTH), sh, s, a, reinterpret_cast<unsigned long long *>(xchg));
+    void (*kern)(PathArgs, unsigned long long *) = a.accelerate ? path_rowcoop_kernel<true> : path_rowcoop_kernel<false>;
+    if (int rc = lds_limit_once(reinterpret_cast<const void *>(kern), sh)) return rc;
+    hipLaunchKernelGGL(kern, dim3(path_rowcoop_workgroups(a.p)), dim3(SNTH), sh, s, a, reinterpret_cast<unsigned long long *>(xchg));
     OEM_HIP(hipGetLastError());
     if (sw().OEM_WCOOP_FAKE_TIMEOUT.set) OEM_HIP(hipMemsetAsync(a.d_out + 6, 0xFF, sizeof(double), s));      // tests: the host's fallback
     return 0;

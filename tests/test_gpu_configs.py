@@ -362,6 +362,44 @@ def test_row_split_one_exchange_engine(oa, p, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("p", [1100, 1536, 2048])
+def test_nesterov_step_on_the_one_exchange_engine(oa, p, monkeypatch):
+    """`accelerate = TRUE` (ref src/oem_dense.h:529, 633-651) at 1024 < p <= 2048 with element-wise penalties: path_rowcoop_kernel<ACC> -- the
+    workgroups' parts of the restart test ride next to the coefficients in the ONE all-gather of an iteration (round 6; until then such calls
+    took the two-exchange engine).  Through oem() (only oemDense accelerates, quirk Q12) against the oracle -- iteration counts within one,
+    and where a restart falls an iteration apart the iterates agree to the stop rule's tolerance --, against the symmetric engine's general
+    form (OEM_NO_ROWCOOP=1), with compute.loss, and the same bits twice."""
+    rng = np.random.default_rng(9 * p + 1)
+    n = p + 2000
+    x = np.asfortranarray(rng.normal(size=(n, p)) * (1.0 + 0.5 * rng.uniform(size=p)) + 0.2)
+    b = np.zeros(p); b[rng.choice(p, 20, replace=False)] = rng.uniform(-1, 1, 20)
+    y = x @ b + rng.normal(size=n) + 0.5
+    tol = 1e-9
+    kw = dict(penalty=["lasso", "mcp", "elastic.net"], alpha=0.7, gamma=3.0, nlambda=6, tol=tol, maxit=600, accelerate=True, compute_loss=True)
+    import torch
+    xh, x = x, torch.as_tensor(np.ascontiguousarray(x.T), device="cuda").t()      # (device-resident: the engine of the default context is the one asserted)
+    f = oa.oem(x, y, **kw)
+    assert oa.last_path_engine()[0] == "rowcoop"
+    f2 = oa.oem(x, y, **kw)
+    assert f["d"] == f2["d"] and all(np.array_equal(np.asarray(u), np.asarray(v)) for u, v in zip(f["beta"], f2["beta"]))
+    r = orc.fit_dense(xh, y, native=True, d_override=f["d"], **kw)
+    monkeypatch.setenv("OEM_NO_ROWCOOP", "1")
+    g = oa.oem(x, y, **kw)
+    assert oa.last_path_engine()[0] == "symcoop"
+    monkeypatch.delenv("OEM_NO_ROWCOOP")
+    for other, label in ((r, "oracle"), (g, "symcoop")):
+        for k in range(3):
+            fb, ob = np.asarray(f["beta"][k]), np.asarray(other["beta"][k])
+            dn = np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(other["niter"][k]).astype(int))
+            assert dn.max() <= 1, (label, kw["penalty"][k], dn)
+            err = np.abs(fb - ob).max(axis=0) / max(1.0, float(np.abs(ob).max()))
+            assert err.max() <= 4.0 * tol, (label, kw["penalty"][k], err)          # (a restart one iteration apart: equal to the tolerance, not to rounding)
+            assert err[dn == 0].max() <= 4.0 * tol
+            assert np.allclose(f["loss"][k], other["loss"][k], rtol=1e-6), (label, kw["penalty"][k])
+    assert sum(int(np.sum(f["niter"][k])) for k in range(3)) < sum(int(np.sum(oa.oem(x, y, **dict(kw, accelerate=False))["niter"][k])) for k in range(3))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("p", [1500, 3000])
 def test_scattered_groups_stay_on_the_register_resident_engine(oa, p):
     """1024 < q <= 4096 with groups that are NOT runs of neighbouring coordinates (dealt round robin: the members of a group are 75 / 100
