@@ -792,6 +792,8 @@ def main():
             out["q8192_ms"] = {"workload": "oem.xtx, q = 8192 (X'X/n of n = 131072 Gaussian rows, 25 non-zeros), 100-lambda lasso, tol 1e-10: the Gram form beyond the register-resident engines",
                                "eigen_plus_path_ms": med8, "eigen_plus_path_ms_runs": ts8, "oem_iterations": it8, "lanczos_steps": int(st8.value),
                                "us_per_product_all_in": 1e3 * med8 / max(prod8, 1),
+                               "us_per_product_note": "over the whole path; a product skips the 128 x 128 blocks whose row AND column block of the iterate are zero "
+                                                      "(the first half of this path has <= 33 non-zeros) -- the roofline below is the FULL product (a dense vector, no block skipped)",
                                "GBps_at_8q2_plus_24q_bytes_per_product": (8.0 * q8 * q8 + 24.0 * q8) * prod8 / (med8 * 1e-3) / 1e9,
                                "engine": oem_amd.last_path_engine()[0], "product_rel_err_vs_torch": gemv_err, "roofline": rf8}
             del xtx8, v8, o8

@@ -460,7 +460,7 @@ __device__ __forceinline__ void upd_barrier(bool lds_only)
 }
 template <int R>
 __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, double *__restrict__ beta,
-                                            const double *__restrict__ g, double *dyn, double *sh, bool lds_only)
+                                            const double *__restrict__ g, double *dyn, double *sh, bool lds_only, int *__restrict__ nz32)
 {
     constexpr int RR = R ? R : 1;
     const int q = A.p, nl = A.nl, tid = threadIdx.x, nt = blockDim.x;
@@ -598,6 +598,10 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
         bad |= (cn && qn && fabs(bn - bo) > A.tol * qo);
         beta[j] = bn;
         if (R) rb[R ? r : 0] = bn;
+        if (nz32) {                                            // which 32-coordinate pieces of the new iterate hold a non-zero (sympk_gemv_kernel skips blocks by them)
+            const unsigned long long nzb = __ballot(bn != 0.0);
+            if ((tid & 31) == 0) nz32[j >> 5] = ((nzb >> (tid & 32)) & 0xffffffffull) != 0ull ? 1 : 0;
+        }
     }
     if (A.accelerate) {
         adp = block_sum(adp, sh);
@@ -651,11 +655,11 @@ __device__ __forceinline__ void path_update(const PathArgs &A, LState *st, doubl
 // read by this one workgroup between its own barriers; null: LDS.
 template <int R>
 __global__ __launch_bounds__(1024) void path_update_kernel(PathArgs A, LState *st, double *__restrict__ beta,
-                                                            const double *__restrict__ g, double *uf)
+                                                            const double *__restrict__ g, double *uf, int *nz32)
 {
     extern __shared__ __attribute__((aligned(16))) double dyn[];     // U[q] (group operand), F[ngroups]
     __shared__ double sh[16 + 8];                                    // block sums | the stop rule's 16 wave votes (ints)
-    path_update<R>(A, st, beta, g, uf ? uf : dyn, sh, uf == nullptr);
+    path_update<R>(A, st, beta, g, uf ? uf : dyn, sh, uf == nullptr, nz32);
 }
 
 __global__ __launch_bounds__(1024) void lanczos_update_kernel(int q, int j, double *__restrict__ v, double *__restrict__ vp,
@@ -1136,8 +1140,13 @@ __device__ __forceinline__ void spk_load(SymHalf &T, const double *__restrict__ 
 }
 
 // one product with the packed triangle: P[slot][qpad] partial vectors (qpad = 128 NBLK), vec read as 0 beyond q
+// nz32 (or null): one word per 32 coordinates of vec, 0 = all of them are zero (written by the head that produced vec).  A lasso iterate is
+// sparse: a block whose row block AND column block of the vector are zero contributes nothing -- it is not read at all, its two partial
+// vectors are written as zeros (the slot sum reads every slot).  Early in a path that is most blocks: the product then streams the block rows
+// and columns of the active set only.  The flags are looked at BEFORE the block is asked for (one small dependent load per workgroup; the
+// other workgroup of the CU keeps streaming meanwhile); a dense vector costs nothing measurable (oemgpu_selftest_sympk_gemv passes null).
 __global__ __launch_bounds__(256, OEM_SYM_MINWG) void sympk_gemv_kernel(const double *__restrict__ pk, int q, int qpad, const double *__restrict__ vec,
-                                                                         double *__restrict__ P, const int *__restrict__ done)
+                                                                         double *__restrict__ P, const int *__restrict__ done, const int *__restrict__ nz32)
 {
     __shared__ __attribute__((aligned(16))) SymLds L;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, a = lane >> 3, bb = lane & 7;
@@ -1146,6 +1155,15 @@ __global__ __launch_bounds__(256, OEM_SYM_MINWG) void sympk_gemv_kernel(const do
     const bool diag = I == J;
     const int cm = tid < SYM_TB ? SYM_TB * I + tid : SYM_TB * J + (tid - SYM_TB);
     const int dn = done ? *done : 0;
+    if (nz32) {
+        const int fi = nz32[4 * I] | nz32[4 * I + 1] | nz32[4 * I + 2] | nz32[4 * I + 3], fj = nz32[4 * J] | nz32[4 * J + 1] | nz32[4 * J + 2] | nz32[4 * J + 3];
+        if (!(fi | fj)) {                                     // (wave-uniform: every lane read the same eight words)
+            if (dn) return;
+            if (tid < SYM_TB) P[(size_t)J * qpad + SYM_TB * I + tid] = 0.0;
+            else if (!diag) P[(size_t)I * qpad + SYM_TB * J + (tid - SYM_TB)] = 0.0;
+            return;
+        }
+    }
     const double mine = cm < q ? vec[cm] : 0.0;
     const double *tp = pk + (size_t)blockIdx.x * SPK_TILE + ((size_t)w * 32 * 64 + lane) * 2;
     SymHalf T0, T1;
@@ -1205,7 +1223,7 @@ __global__ __launch_bounds__(256) void sympk_sum_kernel(const double *__restrict
 // replicated transition, the operator on the workgroup's 64 coordinates, beta_{t+1} into B[par ^ 1] (which the product kernel of
 // this iteration then reads), the workgroup's "still moving" word.  One (head, product) pair of launches per iteration.
 __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__restrict__ S, double *__restrict__ B, const double *__restrict__ P,
-                                                          int *__restrict__ flags, int *__restrict__ fdone, int par, double d, int nblk, int qpad)
+                                                          int *__restrict__ flags, int *__restrict__ fdone, int par, double d, int nblk, int qpad, int *__restrict__ nz32)
 {
     __shared__ double sh[8][SPK_HC];
     const int q = A.p, nl = A.nl, tid = threadIdx.x, l = tid & (SPK_HC - 1), ch = tid / SPK_HC, cm = blockIdx.x * SPK_HC + l;
@@ -1276,8 +1294,9 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
     const bool cn = c > 1e-13, qn = qo > 1e-13;
     const bool moving = own && ((cn != qn) || (cn && qn && fabs(bn - b0) > A.tol * qo));
     if (own) bout[cm] = bn;
+    const unsigned long long nzb = __ballot(own && bn != 0.0);       // (wave 0 holds this workgroup's 32 coordinates)
     const int mv = __syncthreads_or(moving ? 1 : 0);
-    if (tid == 0) flags[(par ^ 1) * FMAXB + blockIdx.x] = mv;
+    if (tid == 0) { flags[(par ^ 1) * FMAXB + blockIdx.x] = mv; nz32[(size_t)(par ^ 1) * (qpad / SPK_HC) + blockIdx.x] = nzb != 0ull ? 1 : 0; }
 }
 
 // out = XX vec through the packed triangle (pack, then `reps` products back to back between two HIP events on the stream):
@@ -1290,9 +1309,9 @@ int sympk_gemv_probe(hipStream_t s, const double *xx, int q, double *pk, const d
     OEM_HIP(hipEventCreate(&e0));
     OEM_HIP(hipEventCreate(&e1));
     hipLaunchKernelGGL(sympk_pack_kernel, dim3(nt), dim3(256), 0, s, xx, q, pk);
-    hipLaunchKernelGGL(sympk_gemv_kernel, dim3(nt), dim3(256), 0, s, pk, q, qpad, vec, P, (const int *)nullptr);     // (warm)
+    hipLaunchKernelGGL(sympk_gemv_kernel, dim3(nt), dim3(256), 0, s, pk, q, qpad, vec, P, (const int *)nullptr, (const int *)nullptr);     // (warm)
     OEM_HIP(hipEventRecord(e0, s));
-    for (int k = 0; k < reps; ++k) hipLaunchKernelGGL(sympk_gemv_kernel, dim3(nt), dim3(256), 0, s, pk, q, qpad, vec, P, (const int *)nullptr);
+    for (int k = 0; k < reps; ++k) hipLaunchKernelGGL(sympk_gemv_kernel, dim3(nt), dim3(256), 0, s, pk, q, qpad, vec, P, (const int *)nullptr, (const int *)nullptr);
     OEM_HIP(hipEventRecord(e1, s));
     hipLaunchKernelGGL(sympk_sum_kernel, dim3(qpad / SPK_HC), dim3(256), 0, s, P, nb, q, qpad, out, (const int *)nullptr);
     OEM_HIP(hipGetLastError());
@@ -1308,8 +1327,8 @@ size_t sympk_doubles(int q)
 {
     if (q <= 1024) return 0;
     const size_t nblk = (size_t)spk_nblk(q), qpad = nblk * SYM_TB;
-    // blocks | partial vectors P[NBLK][qpad] | B[2][qpad] | flags[2][FMAXB] ints | SState[2] | done word
-    return spk_ntile(q) * SPK_TILE + nblk * qpad + 2 * qpad + FMAXB + 16 + 8;
+    // blocks | partial vectors P[NBLK][qpad] | B[2][qpad] | flags[2][FMAXB] ints | SState[2] | done word | nz32[2][qpad / 32] ints
+    return spk_ntile(q) * SPK_TILE + nblk * qpad + 2 * qpad + FMAXB + 16 + 8 + qpad / 32 + 8;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1639,12 +1658,13 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     bool spk_packed = false;
     auto spk_pack = [&]() {                               // before the first product (never inside a graph capture)
         if (spk_packed) return;
-        (void)hipMemsetAsync(spk_B, 0, sizeof(double) * (2 * (size_t)spk_qpad + FMAXB + 16 + 8), s);
+        (void)hipMemsetAsync(spk_B, 0, sizeof(double) * (2 * (size_t)spk_qpad + FMAXB + 16 + 8 + spk_qpad / 32 + 8), s);
         hipLaunchKernelGGL(sympk_pack_kernel, dim3(spk_nt), dim3(256), 0, s, a.xx, q, a.sympk);
         spk_packed = true;
     };
-    auto spk_gemv = [&](const double *vec, double *out, const int *done) {
-        hipLaunchKernelGGL(sympk_gemv_kernel, dim3(spk_nt), dim3(256), 0, s, a.sympk, q, spk_qpad, vec, spk_P, done);
+    int *spk_nz = spk ? reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad + FMAXB + 16 + 8) : nullptr;      // nz32[2][qpad / 32] (the general form uses [0])
+    auto spk_gemv = [&](const double *vec, double *out, const int *done, const int *nz = nullptr) {
+        hipLaunchKernelGGL(sympk_gemv_kernel, dim3(spk_nt), dim3(256), 0, s, a.sympk, q, spk_qpad, vec, spk_P, done, nz);
         if (out) hipLaunchKernelGGL(sympk_sum_kernel, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, spk_P, spk_nb, q, spk_qpad, out, done);
     };
     auto sym_gemv = [&](const double *vec, double *out) {
@@ -1747,12 +1767,14 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         int *flags = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad);
         SState *SS = reinterpret_cast<SState *>(spk_B + 2 * (size_t)spk_qpad + FMAXB);
         int *fdone = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad + FMAXB + 16);
+        int *nz32 = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad + FMAXB + 16 + 8);      // [2][qpad / 32]: which 32-coordinate pieces of B[parity] hold a non-zero
         hipLaunchKernelGGL(sym_init_kernel, dim3(1), dim3(1), 0, s, SS, a);
         auto enq = [&](int count) {
             for (int k = 0; k < count; ++k) {
                 const int par = k & 1;
-                hipLaunchKernelGGL(sympk_head_kernel, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, a, SS, spk_B, spk_P, flags, fdone, par, d, spk_nb, spk_qpad);
-                hipLaunchKernelGGL(sympk_gemv_kernel, dim3(spk_nt), dim3(256), 0, s, a.sympk, q, spk_qpad, spk_B + (size_t)(par ^ 1) * spk_qpad, spk_P, fdone);
+                hipLaunchKernelGGL(sympk_head_kernel, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, a, SS, spk_B, spk_P, flags, fdone, par, d, spk_nb, spk_qpad, nz32);
+                hipLaunchKernelGGL(sympk_gemv_kernel, dim3(spk_nt), dim3(256), 0, s, a.sympk, q, spk_qpad, spk_B + (size_t)(par ^ 1) * spk_qpad, spk_P, fdone,
+                                   (const int *)(nz32 + (size_t)(par ^ 1) * (spk_qpad / SPK_HC)));
             }
         };
         return replay_batches(s, enq, fdone, reinterpret_cast<int *>(host_scratch), (long long)a.npen * a.nl * ((long long)a.maxit + 2) + 8, "packed-triangle engine");
@@ -1793,7 +1815,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     double *uf = nullptr;
     const size_t sh = update_lds(a, &uf);                            // (U and F exist for group operators only)
     // (1024 < q <= 8192: the operands in registers, every independent load of the kernel issued at once)
-    void (*updk)(PathArgs, LState *, double *, const double *, double *) =
+    void (*updk)(PathArgs, LState *, double *, const double *, double *, int *) =
         (q > 1024 && q <= 4096) ? path_update_kernel<4> : (q > 4096 && q <= 8192) ? path_update_kernel<8> : path_update_kernel<0>;
     if (sh > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(updk),
@@ -1803,9 +1825,9 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     if (spk) spk_pack();
     auto enqueue = [&](int count) {
         for (int k = 0; k < count; ++k) {
-            if (spk) spk_gemv(beta, g, &st->done);                    // (packed before the capture, below)
+            if (spk) spk_gemv(beta, g, &st->done, spk_nz);            // (packed before the capture, below; blocks of zeros skipped by the update kernel's flags)
             else (void)launch_gemv(s, a.xx, q, beta, g, &st->done, num_cu);
-            hipLaunchKernelGGL(updk, dim3(1), dim3(1024), sh, s, a, st, beta, g, uf);
+            hipLaunchKernelGGL(updk, dim3(1), dim3(1024), sh, s, a, st, beta, g, uf, spk_nz);
         }
     };
     return replay_batches(s, enqueue, &st->done, reinterpret_cast<int *>(host_scratch), (long long)a.npen * a.nl * ((long long)a.maxit + 2) + 8, "large-p engine");
@@ -2336,7 +2358,7 @@ static int run_path_wide_blocks(hipStream_t s, const PathArgs &a, const WideArgs
         for (int k = 0; k < count; ++k) {
             xb(beta, t, (const int *)&st->done);
             xtv(t, g, (const int *)&st->done);
-            hipLaunchKernelGGL(path_update_kernel<0>, dim3(1), dim3(1024), shu, s, a, st, beta, g, uf);
+            hipLaunchKernelGGL(path_update_kernel<0>, dim3(1), dim3(1024), shu, s, a, st, beta, g, uf, (int *)nullptr);
         }
     };
     const int FB = 16;
@@ -2456,7 +2478,7 @@ static int run_path_wide_nr(hipStream_t s, const PathArgs &a, const WideArgs &wd
                 hipLaunchKernelGGL((wide_reduce_kernel<W_XB>), dim3(rblocks), dim3(1024), 0, s, P, W, npad, n, wd.ys, t, (const int *)&st->done);
                 hipLaunchKernelGGL((wide_cols_kernel<NR, W_XTV>), dim3(W), dim3(NT), lds, s, a, wd.xs, t, wd.ys, P, (double *)nullptr, g,
                                    (SState *)nullptr, (int *)nullptr, (int *)nullptr, (const int *)&st->done, 0, d, n, cpw);
-                hipLaunchKernelGGL(path_update_kernel<0>, dim3(1), dim3(1024), shu, s, a, st, beta, g, uf);
+                hipLaunchKernelGGL(path_update_kernel<0>, dim3(1), dim3(1024), shu, s, a, st, beta, g, uf, (int *)nullptr);
             }
         }
     };
