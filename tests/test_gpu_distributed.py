@@ -9,13 +9,30 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
+def _run(cmd, env, timeout):
+    """a child process with a time limit, started a second time if the first one ran into it: N workers of torch.distributed.run on ONE
+    device over gloo hung once in ~20 runs of this file in round 6 (16 s otherwise; never reproduced in isolation) -- a launcher that hangs
+    twice in a row is a failure, one that hangs once must not take the whole suite's time limit with it"""
+    import signal
+    for attempt in (0, 1):
+        pr = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, err = pr.communicate(timeout=timeout)
+            return subprocess.CompletedProcess(cmd, pr.returncode, out, err)
+        except subprocess.TimeoutExpired:
+            os.killpg(pr.pid, signal.SIGKILL)             # (the launcher AND its workers: exactly the process group started here)
+            pr.communicate()
+            if attempt:
+                raise
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("nproc", [2, 3])              # 3: the row split leaves a remainder on the last rank
 def test_ranks_share_one_gpu(nproc):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(29575 + nproc), str(ROOT / "tests" / "dist_gpu_worker.py")]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    r = _run(cmd, env, 300)
     assert "DIST_GPU_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
@@ -24,7 +41,7 @@ def test_rccl_collectives_at_world_size_one():
     """RCCL itself, on a one-GPU box: process group "nccl" of world size 1 and OEM_FORCE_COLLECTIVES=1 make every collective of
     oem_amd/distributed.py execute (tests/rccl_world1_worker.py counts them) -- with the bits of the plain call."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, str(ROOT / "tests" / "rccl_world1_worker.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    r = _run([sys.executable, str(ROOT / "tests" / "rccl_world1_worker.py")], env, 300)
     assert "RCCL_W1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
@@ -35,8 +52,7 @@ def test_bench_launches_its_own_workers():
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env.update(OEM_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "200000", "--no-c5",
-                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    r = _run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "200000", "--no-c5", "--no-cpu-baseline"], env, 240)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -62,8 +78,7 @@ def test_bench_launcher_at_eight_ranks(route):
     env.update(OEM_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if route == "staged through the host":
         env["OEMGPU_NO_PEER"] = "1"
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--n", "100003", "--no-c5",
-                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    r = _run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--n", "100003", "--no-c5", "--no-cpu-baseline"], env, 240)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
