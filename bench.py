@@ -788,10 +788,10 @@ def main():
             if not a.no_live_pmc:
                 try:
                     t0 = time.perf_counter()
-                    c8 = live_pmc("sympk_gemv_kernel", [["FETCH_SIZE"], ["WRITE_SIZE"]], program=[str(ROOT / "tools" / "run_q8192.py")])
+                    c8 = live_pmc("sympk_gemv_kernel", [["FETCH_SIZE"], ["WRITE_SIZE"]], program=[str(ROOT / "tools" / "run_q8192.py"), "8192", "full"])
                     rf8["traffic"] = (2.0 * c8["FETCH_SIZE"] + c8["WRITE_SIZE"]) * 1024.0
-                    rf8["traffic_source"] = ("measured in this run: child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE -- python3 tools/run_q8192.py`, "
-                                             "mean per launch of sympk_gemv_kernel; FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes")
+                    rf8["traffic_source"] = ("measured in this run: child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE -- python3 tools/run_q8192.py 8192 full` (dense-vector "
+                                             "products: no block skipped), mean per launch of sympk_gemv_kernel; FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes")
                     rf8["achieved_on_traffic_GBps"] = rf8["traffic"] / (us8.value * 1e-6) / 1e9
                     rf8["live_pmc_seconds"] = time.perf_counter() - t0
                 except Exception as e:
