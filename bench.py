@@ -428,7 +428,7 @@ def main():
     # (a fixed 0.2 s of untimed solves first, whatever W is: the GPU's clocks settle over milliseconds, W = 5 steps are 2.5 ms -- the timed K steps
     #  then measure the steady state the metric means, not the ramp the driver's choice of W happens to leave: 20 steps behind 5 gave 0.538 ms where
     #  200 behind 10 gave 0.517-0.524 on the same box.  The same count on every rank: the solves contain a collective.  Reported as `prewarm_solves`.)
-    PREWARM = 400
+    PREWARM = 0 if one_dev else 400                     # (OEM_BENCH_ONE_DEVICE: a functional check of the N > 1 path on one GPU, never a measurement)
     with backend.section():
         for _ in range(PREWARM):
             solve()
