@@ -346,6 +346,14 @@ int oemgpu_selftest_gram_plan(int64_t n, int32_t p, int32_t num_cu, int64_t *out
  * spin for `ms` milliseconds -- "somebody else holds the CUs", for the fallback of the persistent engines.  Asynchronous. */
 int oemgpu_selftest_hold_cus(oemgpu_ctx *ctx, int32_t blocks, double ms);
 
+/* Host-only self-check of the group reordering (api.hip: group_run_permutation; pure arithmetic, runs without a GPU): for the groups of `o`
+ * over q coordinates, the permutation (new position -> old position) that makes every group a run of neighbouring coordinates -- groups in
+ * the order of their first member, members in their own order (the order the reference sums their squares in, ref src/oem_dense.h:193-315) --
+ * which lets the register-resident engine at 1024 < q <= 4096 take group penalties whatever the layout.  Returns q and fills perm[0..q), or 0
+ * when no reordering applies: the groups are runs already, some group has more than 32 members (an owner's slice), or the group vector does
+ * not cover q coordinates. */
+int oemgpu_selftest_group_permutation(const oemgpu_opts *o, int32_t q, int32_t *perm);
+
 /* Host-only self-check of the CU-slot book of the persistent engines (pure arithmetic, runs without a GPU): `calls` concurrent callers
  * each place `ninst` instances of W cooperating workgroups with every instance on ONE XCD of a device with num_cu CUs (path_coop.hip,
  * q <= 512).  bases[k] = the XCD of call k's first instance (chosen where the XCDs are emptiest), *peak = the most CUs any XCD was

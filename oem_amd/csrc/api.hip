@@ -1239,6 +1239,14 @@ int oemgpu_sum_in_order_dev(oemgpu_ctx *c, const double *parts_dev, int32_t npar
     return 0;
 }
 
+int oemgpu_selftest_group_permutation(const oemgpu_opts *o, int32_t q, int32_t *perm)
+{
+    if (!o || !perm || q < 1) { set_error("selftest_group_permutation: bad argument"); return OEMGPU_ERR_ARG; }
+    const std::vector<int> pm = group_run_permutation(o, q);
+    for (size_t j = 0; j < pm.size(); ++j) perm[j] = pm[j];
+    return (int)pm.size();
+}
+
 int oemgpu_selftest_coop_slots(int32_t num_cu, int32_t W, int32_t ninst, int32_t calls, int32_t *bases, int32_t *peak)
 {
     if (num_cu < 8 || num_cu % 8 || W < 1 || ninst < 1 || calls < 1 || calls > 64 || !bases || !peak) { set_error("selftest_coop_slots: bad argument"); return OEMGPU_ERR_ARG; }

@@ -290,6 +290,34 @@ def test_the_plan_puts_the_cooperating_engine_on_one_xcd_only_where_its_instance
     assert _plan(300, ["lasso", "mcp", "scad"], num_cu=64)[0] == "coop" and not _plan.one_xcd              # 10 workgroups do not fit 8 CUs
 
 
+def test_scattered_groups_are_reordered_into_runs():
+    """api.hip: group_run_permutation (host arithmetic): groups of <= 32 members that are not runs of neighbouring coordinates are made runs --
+    groups in the order of their first member, members in their own order, ungrouped coordinates where they stood between them -- so that
+    the register-resident engine at 1024 < q <= 4096 takes them (ref src/oem_dense.h:421-456: the reference knows no group layout)."""
+    import ctypes as C
+    from oem_amd import _lib as L
+    rng = np.random.default_rng(5)
+
+    def perm_of(groups, q):
+        g = np.asarray(groups, dtype=np.int32)
+        a = api._Args(["grp.lasso"], [], 10, 1e-4, 1.0, 3.0, 0.5, 1e-7, 500, False, False, np.ones(q), g, np.unique(g), [])
+        out = (C.c_int32 * q)()
+        n = L.lib().oemgpu_selftest_group_permutation(C.byref(a.c), q, out)
+        return np.array(out[:n])
+    for q, groups in ((1500, np.arange(1500) % 75 + 1), (3000, rng.permutation(np.arange(3000) // 25 + 1)), (2000, np.arange(2000) % 100)):
+        pm = perm_of(groups, q)
+        assert sorted(pm.tolist()) == list(range(q))                                   # a permutation
+        gp = np.asarray(groups)[pm]
+        starts = np.flatnonzero(np.r_[True, gp[1:] != gp[:-1]])
+        assert len(starts) == len(np.unique(groups))                                   # every group one run
+        first = [np.flatnonzero(np.asarray(groups) == gp[s])[0] for s in starts]
+        assert first == sorted(first)                                                  # groups in the order of their first member
+        for s_, e_ in zip(starts, np.r_[starts[1:], q]):
+            assert np.all(np.diff(pm[s_:e_]) > 0)                                      # members in their own order
+    assert len(perm_of(np.arange(1500) // 5 + 1, 1500)) == 0                           # runs already: nothing to do
+    assert len(perm_of(np.arange(3000) % 60 + 1, 3000)) == 0                           # 50 members: more than an owner's slice holds
+
+
 def test_concurrent_one_xcd_launches_are_booked_per_xcd():
     """the CU slots of the one-XCD cooperating launches are booked per XCD, and a call's first XCD is the one where the load
     is lowest -- three calls of one 16-workgroup instance (q = 512) in flight at once must not meet on one XCD (the old turn counter put
