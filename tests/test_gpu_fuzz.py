@@ -612,3 +612,40 @@ def test_random_register_resident_symmetric_engine(oa, seed):
     assert abs(f["d"] - 1.005 * lam_max) <= 1e-10 * lam_max
     _check(f, r, pens, tol=5e-7)
 
+
+
+@pytest.mark.parametrize("seed", list(range(170, 173)) + list(range(97000, 97000 + 3 * (SCALE - 1))))
+def test_random_scattered_groups_on_the_register_resident_engine(oa, seed):
+    """oem.xtx at a random 1024 < p <= 4096 with group penalties whose groups are NOT runs of neighbouring coordinates (sizes 1-32 in a
+    random layout, group 0 unpenalised, weights, penalty factors, now and then `scale.factor`): reordered into runs (api.hip:
+    group_run_permutation), solved on path_symcoop_kernel<.., GEN>, put back -- against the oracle (d handed over), also where there are
+    fewer runs than workgroups (some owners own nothing)."""
+    import torch
+    rng = np.random.default_rng(9970 + seed)
+    p = int(rng.choice([int(rng.integers(1025, 1600)), int(rng.integers(1600, 2600)), int(rng.integers(2600, 4097))]))
+    n = p + int(rng.integers(100, 1500))
+    x = rng.normal(size=(n, p)) * (1.0 + rng.uniform(size=p))
+    b = np.zeros(p); b[rng.choice(p, 12, replace=False)] = rng.uniform(-1, 1, 12)
+    y = x @ b + rng.normal(size=n)
+    xtx, xty = x.T @ x / n, x.T @ y / n
+    hi = int(rng.choice([4, 12, 32]))                                    # (32: few large groups -- fewer runs than workgroups)
+    sizes = []
+    while sum(sizes) < p:
+        sizes.append(int(rng.integers(max(1, hi // 2), hi + 1)))
+    sizes[-1] -= sum(sizes) - p
+    groups = rng.permutation(np.repeat(np.arange(len(sizes)), sizes))   # group 0 exists: unpenalised (ref src/oem_dense.h:207)
+    gw = rng.uniform(0.5, 2.0, len(sizes))
+    pens = list(rng.choice(GROUPED, int(rng.integers(1, 3)), replace=False)) + list(rng.choice(ELEMENTWISE, int(rng.integers(0, 2)), replace=False))
+    pf = np.where(rng.random(p) < 0.05, 0.0, rng.uniform(0.5, 2.0, p))
+    kw = dict(penalty=pens, groups=groups, group_weights=gw, nlambda=int(rng.integers(2, 5)), alpha=float(rng.uniform(0.3, 1.0)), gamma=float(rng.uniform(2.5, 5.0)),
+              tau=float(rng.uniform(0.2, 0.8)), tol=float(10.0 ** rng.uniform(-9, -7)), maxit=int(rng.choice([60, 300])), penalty_factor=pf)
+    if seed % 3 == 0:
+        kw["scale_factor"] = rng.uniform(0.5, 2.0, p)
+    f = oa.oem_xtx(torch.as_tensor(xtx, device="cuda"), xty, **kw)
+    # (the register engine wherever the runs can be dealt to its owners -- <= 32 coordinates each, whole runs: groups of 17-32 members need an
+    #  owner each, and more of them than the engine has workgroups go to the launch engines: the same answer either way)
+    assert oa.last_path_engine()[0] in ("symcoop", "launches")
+    if hi <= 12:
+        assert oa.last_path_engine()[0] == "symcoop"
+    r = orc.fit_xtx(xtx, xty, d_override=f["d"], lambda_min_ratio=1e-4, unique_groups=np.unique(groups), **kw)
+    _check(f, r, pens, tol=5e-7)
