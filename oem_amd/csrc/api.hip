@@ -499,7 +499,7 @@ static int plan_paths(const PlanIn &in, PathPlan &P)
     if (!wide && !launches_only && nbatch == 1 && q > 1024 && q <= 4096 && !sw().OEM_NO_SYMCOOP.set && !sw().OEM_NO_COOP.set) {
         const int gmax = num_cu * 3 / 4 < WCOOP_GMAX ? num_cu * 3 / 4 : WCOOP_GMAX;
         if (any_grp) {
-            // group operators: every group must be a run of neighbouring coordinates (<= 32 of them) -- the owners' slices are cut there
+            // group operators: every group must be a run of neighbouring coordinates -- the owners' slices are cut there (and inside runs of more than 32)
             std::vector<int> rs;
             bool ok = true;
             for (int j = 0; j < q && ok;) {
@@ -652,7 +652,8 @@ static std::vector<int> group_run_permutation(const oemgpu_opts *o, int q)
         if (len > longest) longest = len;
         for (int k = 1; k < len && runs; ++k) runs = G.gidx[G.gstart[g] + k] == G.gidx[G.gstart[g]] + k;
     }
-    if (runs || longest > 32) return perm;
+    (void)longest;                                       // (groups of more than 32 members: their norms are summed over several owners, path_symcoop.hip)
+    if (runs) return perm;
     perm.reserve(q);
     std::vector<char> done(o->ngroups, 0);
     for (int j = 0; j < q; ++j) {
@@ -1019,7 +1020,7 @@ size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o, int nbatch)
     if (q >= path_coop_min_q(true) && q <= 1024 && wk < path_coop_xchg_bytes()) wk = path_coop_xchg_bytes();
     b += wk * splits + 4096;
     b += (size_t)q * 12 + 64;                                          // the runs of the fused group kernel (p >= n)
-    if (q > 1024 && q <= 4096) b += symcoop_xchg_bytes_max(q) + (size_t)(80 + WCOOP_GMAX * 96) * 4 + 1024;      // path_symcoop.hip's exchange area and plan
+    if (q > 1024 && q <= 4096) b += symcoop_xchg_bytes_max(q) + (size_t)(80 + WCOOP_GMAX * 96) * 4 + (size_t)q * 8 + 1024;      // path_symcoop.hip's exchange area and plan (+ the fragment table of split groups)
     return b;
 }
 

@@ -212,7 +212,8 @@ int launch_path_coop(hipStream_t s, const PathArgs &a);
 struct SymcoopPlan {
     int q = 0, T = 0, NT = 0, G = 0, nsum = 0, e1n = 0;    // 64-blocks, tiles per wave, workgroups, sender rows of exchange 1, sender sweeps per owner
     bool runs = false;                                      // the owners' slices are cut at group-run boundaries
-    std::vector<int> tab;                                   // blkbase[80] then G records (uploaded as is)
+    int split = 0;                                          // ... and some group (of more than 32 members) lies in several owners' slices: the most owners of one
+    std::vector<int> tab;                                   // blkbase[80] then G records (uploaded as is); split groups: + the fragment table [2 q]
 };
 bool symcoop_plan(int q, int gmax, SymcoopPlan &P, const int *runs = nullptr, int nruns = 0);   // runs: group runs (starts, nruns + 1) the owners' slices are cut at
 size_t symcoop_xchg_bytes(const SymcoopPlan &P);

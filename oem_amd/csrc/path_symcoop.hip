@@ -316,7 +316,7 @@ __device__ __forceinline__ double sx_uni(double v)
 //   compute.loss (ref :759-770, Gram identity): when a lambda ends, g = XX beta of the finished iterate is in hand; the owners' parts of
 //       beta'(g - 2 XY) go to workgroup 0 through the scalar area of exchange 1.
 template <int NT, bool GEN>
-__global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const int *__restrict__ plan, unsigned long long *xchg, int T, int nsum, int e1n)
+__global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const int *__restrict__ plan, unsigned long long *xchg, int T, int nsum, int e1n, int gsplit)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -335,7 +335,9 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
     int *rec = wv + 32 + 2 * SSL;                        // this workgroup's plan record [SW_INTS], then P1[SNB] (pairs index of exchange 1 per slot)
     int *P1 = rec + SW_INTS;
     constexpr int SVR = sx_svr(GEN), SLT = sx_slt(GEN);
-    double *Lt = reinterpret_cast<double *>(P1 + SNB + 8) + w * SLT;      // NT == 3: rows SVR..7 of every lane's part of this wave's third tile
+    int *gfr = P1 + SNB + 8;                             // GEN, split groups: per owned coordinate (first owner of its group) * 2 + slot, number of owners [2 SSL]
+    double *gwl = reinterpret_cast<double *>(gfr + 2 * SSL);      // GEN: the weight of an owned coordinate's group [SSL] (read where it is used: two registers the NT = 3 form does not have)
+    double *Lt = gwl + SSL + w * SLT;                    // NT == 3: rows SVR..7 of every lane's part of this wave's third tile
     const bool writer = wg == 0;
 
     const int *__restrict__ blkbase = plan;
@@ -391,16 +393,25 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
     const int cg = c0 + (own ? ocl : 0);
     const double xyc = own ? A.xy[cg] : 0.0, pfc = own ? A.pf[cg] : 0.0;
     // GEN: this coordinate's group -- its members are the slice-local coordinates [gm0, gm1) (a run, inside this owner's slice)
+    // gsplit > 0: a group of more than SSL members lies in the slices of k > 1 (<= gsplit) neighbouring owners, the first of them a (gfr[2 ocl] =
+    // 2 a + 1 if its fragment does not start that owner's slice, gfr[2 ocl + 1] = k -- in LDS: the NT = 3 form has no register for them);
+    // [gm0, gm1) then reaches beyond this slice and is clamped where it is used
     int gm0 = 0, gm1 = 0;
     bool gzr = true;
-    double gwc = 0.0;
+    if (GEN && part == 0) gwl[ocl] = 0.0;
     if (GEN && A.ngroups > 0 && own) {
         const int g = A.gid[cg];
         if (g >= 0) {
             const int m0 = A.gstart[g];
             gm0 = A.gidx[m0] - c0; gm1 = gm0 + (A.gstart[g + 1] - m0);
-            gzr = A.gzero[g] != 0; gwc = A.gw[g];
+            gzr = A.gzero[g] != 0;
+            if (part == 0) gwl[ocl] = A.gw[g];
         } else { gm0 = 0; gm1 = -1; }                                // (in no group: its coefficient stays 0, as path_update has it)
+    }
+    if (GEN && tid < SSL) {
+        const bool sp = gsplit > 0 && A.ngroups > 0 && tid < nsl && A.gid[c0 + tid] >= 0;
+        const int *ft = plan + SPLAN_HEAD + G * SW_INTS + 2 * (c0 + (sp ? tid : 0));
+        gfr[2 * tid] = sp ? ft[0] : 0; gfr[2 * tid + 1] = sp ? ft[1] : 1;
     }
     double ak = 1.0;                                                 // Nesterov's sequence (ref src/oem_dense.h:529, 633-651)
     const bool want_loss = GEN && A.compute_loss != 0, accel = GEN && A.accelerate != 0;
@@ -444,7 +455,8 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
     SymX X;
     X.s1 = nsum * 64 * 16; X.s2 = T * 64 * 16;
     X.o2 = 2 * X.s1; X.o3 = X.o2 + 2 * X.s2; X.o4 = X.o3 + 2 * G * 16;
-    X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, X.o4 + 2 * G * 16, 0x00020000);
+    const int o5 = X.o4 + 2 * G * 16;                    // the owners' parts of split groups' squared norms, [2 parities][G][2] pairs
+    X.rs = __builtin_amdgcn_make_buffer_rsrc((void *)xchg, 0, o5 + 4 * G * 16, 0x00020000);
     X.epoch = 0; X.wg = wg; X.G = G; X.failed = false; X.abortp = reinterpret_cast<const int *const *>(wv); X.aflag = wv + 2;
 #ifdef OEM_PATH_DIAG
     for (int k = 0; k < 16; ++k) X.acc[k] = 0;
@@ -666,11 +678,39 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
                     if (own && part == 0) uo[ocl] = u;
                     __syncthreads();
                     double s2 = 0.0;
-                    for (int m = gm0; m < gm1; ++m) { const double x = uo[m]; s2 += x * x; }
+                    const int ma = gm0 > 0 ? gm0 : 0, mb = gm1 < nsl ? gm1 : nsl;      // (whole groups: gm0, gm1)
+                    for (int m = ma; m < mb; ++m) { const double x = uo[m]; s2 += x * x; }
+                    if (gsplit > 0) {
+                        // groups in several owners' slices: the owners' parts (each in member order) through one more tagged exchange -- the
+                        // part of the fragment that holds a slice's first coordinate in the owner's pair 0, the other one's in pair 1 --, added
+                        // in owner order by the eight lanes of every member (lane k: owners k, k + 8, ...; then the lanes): the same bits everywhere
+                        const int gfa = gfr[2 * ocl], gfk = gfr[2 * ocl + 1];
+                        const bool sp = gfk > 1 && own;
+                        if (sp && part == 0 && ocl == ma) sx_publish(X.rs, o5 + ((par * G + wg) * 2 + (gm0 > 0 ? 1 : 0)) * 16, s2, X.epoch << 1);
+                        double t = 0.0;
+                        for (int f0 = 0; f0 < gsplit; f0 += 16) {
+                            double gp[2];
+                            int offp[2], flp = 0;
+                            unsigned needp = 0;
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const int fr = f0 + part + 8 * e;
+                                const bool okp = sp && fr < gfk;
+                                offp[e] = okp ? o5 + (par * G * 2 + (fr == 0 ? gfa : ((gfa >> 1) + fr) * 2)) * 16 : 0;
+                                if (okp) needp |= 1u << e;
+                            }
+                            sx_gather<2>(offp, needp, gp, flp, X);
+                            t += gp[0]; t += gp[1];
+                        }
+                        t += dpp_mov<0xB1, 0xf>(t, 0.0);
+                        t += dpp_mov<0x4E, 0xf>(t, 0.0);
+                        t += dpp_mov<0x141, 0xf>(t, 0.0);
+                        if (sp) s2 = t;
+                    }
                     double f = 1.0;
                     if (gm1 < gm0) f = 0.0;
                     else if (!gzr) {
-                        const double sn = sqrt(s2), pen_g = thc[TH_L] * gwc;
+                        const double sn = sqrt(s2), pen_g = thc[TH_L] * gwl[ocl];
                         if (thkind == K_GRP || thkind == K_SGL) { const double t = 1.0 - pen_g / sn; f = (0.0 < t) ? t : 0.0; }     // (quirk Q6: 0 / 0 -> NaN -> 0)
                         else if (thkind == K_GRP_MCP) f = mcp_norm(sn, pen_g, thc[TH_D], thc[TH_GAMMA]);
                         else f = scad_norm(sn, pen_g, thc[TH_D], thc[TH_GAMMA]);
@@ -813,7 +853,7 @@ __global__ __launch_bounds__(SNTH) void path_symcoop_kernel(PathArgs A, const in
 
 template <int NT, bool GEN> constexpr size_t symcoop_lds_bytes()
 {
-    return sizeof(double) * (size_t)(SNB * 64 + (8 * NT + 1) * 64 + 2 * SCML + 2 * (SCML + 16) + 16 + 16) + sizeof(int) * (size_t)(16 + SNB + 32 + 2 * SSL + SW_INTS + SNB + 8) +
+    return sizeof(double) * (size_t)(SNB * 64 + (8 * NT + 1) * 64 + 2 * SCML + 2 * (SCML + 16) + 16 + 16) + sizeof(int) * (size_t)(16 + SNB + 32 + 2 * SSL + SW_INTS + SNB + 8 + 4 * SSL) +
            (NT == 3 ? sizeof(double) * 4 * sx_slt(GEN) : 0);
 }
 
@@ -1197,8 +1237,40 @@ bool symcoop_plan(int q, int gmax, SymcoopPlan &P, const int *runs, int nruns)
     // per_want = 0: 4 NT tiles per workgroup.  With group runs the owners' slices want slack (whole runs, <= SSL coordinates): start from
     // about 18 coordinates per owner and give the workgroups more tiles until every limit of the plan holds
     if (!runs) return symcoop_plan_per(q, gmax, P, nullptr, 0, 0);
-    for (int per = 1; per <= 12; ++per) if (symcoop_plan_per(q, gmax, P, runs, nruns, per)) return true;
-    return false;
+    // A run longer than an owner holds (a group of more than SSL members) may be cut after every fourth of its coordinates: the owners'
+    // slices end at run boundaries or at these cuts, and such a group's squared norm is then the sum of its owners' parts (one more hop of
+    // the kernel, its fragment table behind the workgroups' records)
+    std::vector<int> cuts;
+    bool longrun = false;
+    for (int r = 0; r < nruns; ++r) {
+        const int len = runs[r + 1] - runs[r];
+        longrun = longrun || len > SSL;
+        for (int k = 0; k < (len > SSL ? len : 1); k += 4) cuts.push_back(runs[r] + k);
+    }
+    cuts.push_back(q);
+    bool ok = false;
+    for (int per = 1; per <= 12 && !ok; ++per) ok = symcoop_plan_per(q, gmax, P, cuts.data(), (int)cuts.size() - 1, per);
+    if (!ok) return false;
+    if (!longrun) return true;
+    // per coordinate: (first owner of its group) * 2 + (1: that owner's fragment does not start its slice), the number of owners
+    const int G = P.G;
+    std::vector<int> c0(G + 1, q);
+    for (int g = 0; g < G; ++g) {
+        const int *r = P.tab.data() + SPLAN_HEAD + (size_t)g * SW_INTS;
+        if (r[SW_NSL] > 0) c0[g] = r[SW_C0];
+    }
+    for (int g = G - 1; g >= 0; --g) if (c0[g] > c0[g + 1]) c0[g] = c0[g + 1];      // (owners of nothing sit behind the others)
+    const size_t base = P.tab.size();
+    P.tab.resize(base + 2 * (size_t)q, 0);
+    for (int r = 0; r < nruns; ++r) {
+        const int gs = runs[r], ge = runs[r + 1];
+        const int a = (int)(std::upper_bound(c0.begin(), c0.begin() + G, gs) - c0.begin()) - 1;
+        const int b = (int)(std::upper_bound(c0.begin(), c0.begin() + G, ge - 1) - c0.begin()) - 1;
+        if (a < 0 || b < a) return false;
+        if (b > a && b - a + 1 > P.split) P.split = b - a + 1;
+        for (int j = gs; j < ge; ++j) { P.tab[base + 2 * (size_t)j] = 2 * a + (gs == c0[a] ? 0 : 1); P.tab[base + 2 * (size_t)j + 1] = b - a + 1; }
+    }
+    return true;
 }
 static bool symcoop_plan_per(int q, int gmax, SymcoopPlan &P, const int *runs, int nruns, int per_want)
 {
@@ -1315,14 +1387,14 @@ static bool symcoop_plan_per(int q, int gmax, SymcoopPlan &P, const int *runs, i
     return true;
 }
 
-size_t symcoop_xchg_bytes(const SymcoopPlan &P) { return 2 * ((size_t)P.nsum * 64 * 16) + 2 * ((size_t)P.T * 64 * 16) + 4 * ((size_t)P.G * 16) + 256; }
+size_t symcoop_xchg_bytes(const SymcoopPlan &P) { return 2 * ((size_t)P.nsum * 64 * 16) + 2 * ((size_t)P.T * 64 * 16) + 8 * ((size_t)P.G * 16) + 256; }
 size_t symcoop_work_bytes(const SymcoopPlan &P) { return (symcoop_xchg_bytes(P) + 255) / 256 * 256 + (sizeof(PathArgs) + 255) / 256 * 256; }      // + the kernel's arguments
 // an upper bound for any q the engine takes (workspace reservation): every block receives at most 8 SE1 partials
 size_t symcoop_xchg_bytes_max(int q)
 {
     if (q <= 1024 || q > 4096) return 0;
     const size_t T = ((size_t)q + 63) / 64;
-    return 2 * (T * 8 * SE1 * 64 * 16) + 2 * (T * 64 * 16) + 4 * ((size_t)WCOOP_GMAX * 16) + 1024 + sizeof(PathArgs);
+    return 2 * (T * 8 * SE1 * 64 * 16) + 2 * (T * 64 * 16) + 8 * ((size_t)WCOOP_GMAX * 16) + 1024 + sizeof(PathArgs);
 }
 
 // OEM_NO_SYMCOOP=1: the launch-per-iteration engines
@@ -1347,7 +1419,7 @@ int launch_path_symcoop(hipStream_t s, const PathArgs &a_, const SymcoopPlan &P,
     do {                                                                                                                         \
         const size_t sh = symcoop_lds_bytes<NT_, GEN_>();                                                                              \
         if (int rc = lds_limit_once(reinterpret_cast<const void *>(&path_symcoop_kernel<NT_, GEN_>), sh)) return rc;             \
-        hipLaunchKernelGGL((path_symcoop_kernel<NT_, GEN_>), dim3(P.G), dim3(SNTH), sh, s, a, plan_dev, x, P.T, P.nsum, P.e1n);  \
+        hipLaunchKernelGGL((path_symcoop_kernel<NT_, GEN_>), dim3(P.G), dim3(SNTH), sh, s, a, plan_dev, x, P.T, P.nsum, P.e1n, P.split);  \
     } while (0)
     switch (P.NT) {
     case 1: if (gen) SX_LAUNCH(1, true); else SX_LAUNCH(1, false); break;

@@ -450,6 +450,70 @@ def test_scattered_groups_stay_on_the_register_resident_engine(oa, p):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("p,layout", [(1536, "fifty"), (3000, "fifty"), (4096, "mixed"), (2600, "huge")])
+def test_groups_larger_than_an_owners_slice_stay_on_the_register_resident_engine(oa, p, layout):
+    """1024 < q <= 4096, groups of MORE than 32 members (q = 3,000 with 60 scattered groups of 50 ran the launches at
+    3 x the time per iteration): an owner's slice of path_symcoop_kernel holds <= 32 coordinates, so such a group lies in several owners'
+    slices -- each owner sums the squares of ITS members, the parts cross in one more tagged exchange and every member adds them in owner
+    order (path_symcoop.hip: gsplit).  Layouts: 'fifty' = p / 50 groups dealt round robin (scattered); 'mixed' = runs of 1 .. 120 members in
+    a random order, group 0 unpenalised, some coordinates in groups of their own; 'huge' = five scattered groups of p / 5 (a group in ~20
+    owners' slices).  Every group penalty, a lasso beside them, weights, penalty factors; through oem.xtx (+ scale.factor) and oem() with
+    accelerate + compute.loss -- against the oracle (ref src/oem_dense.h:193-315, 421-456)."""
+    import torch
+    rng = np.random.default_rng(131 * p)
+    n = p + 900
+    x = np.asfortranarray(rng.normal(size=(n, p)) * (1.0 + 0.5 * rng.uniform(size=p)) + 0.2)
+    b = np.zeros(p); b[rng.choice(p, 24, replace=False)] = rng.uniform(-1, 1, 24)
+    y = x @ b + rng.normal(size=n) + 0.5
+    if layout == "fifty":
+        groups = np.arange(p) % (p // 50) + 1
+    elif layout == "huge":
+        groups = rng.permutation(np.arange(p) % 5)
+    else:
+        sizes = []
+        while sum(sizes) < p:
+            sizes.append(int(rng.choice([1, 3, 20, 33, 47, 64, 120])))
+        sizes[-1] -= sum(sizes) - p
+        groups = np.repeat(rng.permutation(len(sizes)), sizes)        # runs, in a random order of labels; label 0 unpenalised
+    ug = np.unique(groups)
+    gw = rng.uniform(0.5, 2.0, len(ug))
+    pf = np.ones(p); pf[:3] = 0.0; pf[3:9] = 2.0
+    xtx, xty = x.T @ x / n, x.T @ y / n
+    xd = torch.as_tensor(xtx, device="cuda")
+    kw = dict(penalty=["grp.lasso", "sparse.grp.lasso", "lasso", "grp.mcp", "grp.scad.net"], groups=groups, group_weights=gw, penalty_factor=pf, tau=0.4, gamma=3.5,
+              alpha=0.8, nlambda=4, lambda_min_ratio=0.05, tol=1e-9, maxit=400)
+    f = oa.oem_xtx(xd, xty, **kw)
+    assert oa.last_path_engine() == ("symcoop", 0)
+    r = orc.fit_xtx(xtx, xty, native=True, unique_groups=ug, d_override=f["d"], **kw)
+    lam_max = np.linalg.eigvalsh(xtx)[-1]
+    assert abs(f["d"] - 1.005 * lam_max) <= 1e-10 * lam_max
+    for k in range(len(kw["penalty"])):
+        assert np.allclose(f["lambda"][k], r["lambda"][k], rtol=1e-12)
+        assert np.abs(np.asarray(f["beta"][k]) - np.asarray(r["beta"][k])).max() <= 1e-9 * max(1.0, float(np.abs(r["beta"][k]).max())), kw["penalty"][k]
+        assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int)).max() <= 1
+        assert (np.asarray(f["beta"][k])[:, -1] != 0).sum() >= 5
+    f2 = oa.oem_xtx(xd, xty, **kw)                                    # the owners' parts are added in owner order: the same bits run to run
+    assert all(np.array_equal(np.asarray(f["beta"][k]), np.asarray(f2["beta"][k])) for k in range(len(kw["penalty"])))
+    if layout == "fifty" and p == 1536:
+        sf = np.linspace(0.6, 1.8, p)
+        kws = dict(penalty=["grp.lasso", "lasso"], groups=groups, nlambda=3, lambda_min_ratio=0.1, tol=1e-9, maxit=400, scale_factor=sf)
+        fs = oa.oem_xtx(xd, xty, **kws)
+        assert oa.last_path_engine()[0] == "symcoop"
+        rs = orc.fit_xtx(xtx, xty, native=True, unique_groups=ug, d_override=fs["d"], **kws)
+        for k in range(2):
+            assert np.abs(np.asarray(fs["beta"][k]) - np.asarray(rs["beta"][k])).max() <= 1e-9 * max(1.0, float(np.abs(rs["beta"][k]).max()))
+    if layout in ("fifty", "huge") and p <= 2600:
+        kwd = dict(penalty=["grp.lasso", "grp.scad"], groups=groups, group_weights=gw, nlambda=4, lambda_min_ratio=0.05, tol=1e-9, maxit=400, compute_loss=True,
+                   accelerate=(layout == "huge"))
+        fd = oa.oem(x, y, **kwd)
+        assert oa.last_path_engine()[0] == "symcoop"
+        rd = orc.fit_dense(x, y, native=True, unique_groups=ug, d_override=fd["d"], **kwd)
+        for k in range(2):
+            assert np.abs(np.asarray(fd["beta"][k]) - np.asarray(rd["beta"][k])).max() <= (1e-7 if kwd["accelerate"] else 1e-9) * max(1.0, float(np.abs(rd["beta"][k]).max()))
+            assert np.allclose(fd["loss"][k], rd["loss"][k], rtol=1e-8)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("p", [1100, 2048, 3500, 4096])
 def test_register_resident_engine_general_form(oa, p, monkeypatch):
     """the same engine with what needs more than a coordinate of its own (path_symcoop_kernel<NT, GEN = true>): group operators --
@@ -531,12 +595,12 @@ def test_register_resident_engine_general_form(oa, p, monkeypatch):
                 assert np.abs(np.ravel(f["niter"][k]).astype(int) - np.ravel(r["niter"][k]).astype(int)).max() <= 1
                 assert np.allclose(f["loss"][k], r["loss"][k], rtol=1e-9)
     # groups that are NOT runs of neighbouring coordinates (<= 12 members each): reordered into runs, still this engine (round 6;
-    # test_scattered_groups_stay_on_the_register_resident_engine holds that against the oracle) -- groups too large for an owner's
-    # slice (> 32 members) go to the launch-per-iteration engines
+    # test_scattered_groups_stay_on_the_register_resident_engine holds that against the oracle) -- and so are groups too large for an
+    # owner's slice (> 32 members: test_groups_larger_than_an_owners_slice_stay_on_the_register_resident_engine)
     sc = oa.oem_xtx(xd, xty, penalty="grp.lasso", groups=rng.permutation(groups), nlambda=3, tol=1e-8)
     assert persistent() and np.isfinite(np.asarray(sc["beta"][0])).all()
     big = oa.oem_xtx(xd, xty, penalty="grp.lasso", groups=np.arange(p) % (p // 40), nlambda=3, tol=1e-8)
-    assert not persistent() and np.isfinite(np.asarray(big["beta"][0])).all()
+    assert persistent() and np.isfinite(np.asarray(big["beta"][0])).all()
 
 
 @pytest.mark.gpu

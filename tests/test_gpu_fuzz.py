@@ -616,7 +616,7 @@ def test_random_register_resident_symmetric_engine(oa, seed):
 
 @pytest.mark.parametrize("seed", list(range(170, 173)) + list(range(97000, 97000 + 3 * (SCALE - 1))))
 def test_random_scattered_groups_on_the_register_resident_engine(oa, seed):
-    """oem.xtx at a random 1024 < p <= 4096 with group penalties whose groups are NOT runs of neighbouring coordinates (sizes 1-32 in a
+    """oem.xtx at a random 1024 < p <= 4096 with group penalties whose groups are NOT runs of neighbouring coordinates (sizes 1-400 in a
     random layout, group 0 unpenalised, weights, penalty factors, now and then `scale.factor`): reordered into runs (api.hip:
     group_run_permutation), solved on path_symcoop_kernel<.., GEN>, put back -- against the oracle (d handed over), also where there are
     fewer runs than workgroups (some owners own nothing)."""
@@ -628,7 +628,7 @@ def test_random_scattered_groups_on_the_register_resident_engine(oa, seed):
     b = np.zeros(p); b[rng.choice(p, 12, replace=False)] = rng.uniform(-1, 1, 12)
     y = x @ b + rng.normal(size=n)
     xtx, xty = x.T @ x / n, x.T @ y / n
-    hi = int(rng.choice([4, 12, 32]))                                    # (32: few large groups -- fewer runs than workgroups)
+    hi = int(rng.choice([4, 12, 32, 90, 400]))                           # (32: few large groups -- fewer runs than workgroups; 90, 400: groups in several owners' slices)
     sizes = []
     while sum(sizes) < p:
         sizes.append(int(rng.integers(max(1, hi // 2), hi + 1)))
@@ -645,7 +645,7 @@ def test_random_scattered_groups_on_the_register_resident_engine(oa, seed):
     # (the register engine wherever the runs can be dealt to its owners -- <= 32 coordinates each, whole runs: groups of 17-32 members need an
     #  owner each, and more of them than the engine has workgroups go to the launch engines: the same answer either way)
     assert oa.last_path_engine()[0] in ("symcoop", "launches")
-    if hi <= 12:
+    if hi <= 12 or hi > 32:
         assert oa.last_path_engine()[0] == "symcoop"
     r = orc.fit_xtx(xtx, xty, d_override=f["d"], lambda_min_ratio=1e-4, unique_groups=np.unique(groups), **kw)
     _check(f, r, pens, tol=5e-7)

@@ -256,8 +256,10 @@ def _plan(p, pens, sem=_SEM_DENSE, intercept=0, groups=None, has_scale=False, nb
 
 _RUNS4 = lambda n: np.arange(n) // 4 + 1                    # groups of four neighbouring columns
 _SCATTER = lambda n: np.arange(n) % 7 + 1                   # seven groups dealt round robin: no group is a run
+_RUNS50 = lambda n: np.arange(n) // 50 + 1                  # runs of fifty: more than an owner's slice of the register engine holds (1024 < q <= 4096)
+_RUNS7 = lambda n: np.arange(n) * 7 // n + 1                # seven runs of q / 7
 _PEN_SETS = [(["lasso"], None), (["lasso", "mcp", "scad"], None), (["grp.lasso"], _RUNS4), (["grp.lasso", "lasso"], _RUNS4),
-             (["grp.mcp", "sparse.grp.lasso"], _SCATTER),
+             (["grp.mcp", "sparse.grp.lasso"], _SCATTER), (["grp.lasso", "grp.scad.net"], _RUNS50), (["grp.lasso"], _RUNS7),
              (["elastic.net", "lasso", "ols", "mcp", "scad", "mcp.net", "scad.net", "grp.lasso"], _RUNS4)]
 
 
@@ -304,7 +306,7 @@ def test_scattered_groups_are_reordered_into_runs():
         out = (C.c_int32 * q)()
         n = L.lib().oemgpu_selftest_group_permutation(C.byref(a.c), q, out)
         return np.array(out[:n])
-    for q, groups in ((1500, np.arange(1500) % 75 + 1), (3000, rng.permutation(np.arange(3000) // 25 + 1)), (2000, np.arange(2000) % 100)):
+    for q, groups in ((1500, np.arange(1500) % 75 + 1), (3000, rng.permutation(np.arange(3000) // 25 + 1)), (2000, np.arange(2000) % 100), (3000, rng.permutation(np.arange(3000) // 70))):
         pm = perm_of(groups, q)
         assert sorted(pm.tolist()) == list(range(q))                                   # a permutation
         gp = np.asarray(groups)[pm]
@@ -315,7 +317,8 @@ def test_scattered_groups_are_reordered_into_runs():
         for s_, e_ in zip(starts, np.r_[starts[1:], q]):
             assert np.all(np.diff(pm[s_:e_]) > 0)                                      # members in their own order
     assert len(perm_of(np.arange(1500) // 5 + 1, 1500)) == 0                           # runs already: nothing to do
-    assert len(perm_of(np.arange(3000) % 60 + 1, 3000)) == 0                           # 50 members: more than an owner's slice holds
+    pm = perm_of(np.arange(3000) % 60 + 1, 3000)                                       # 50 members, more than an owner's slice holds: made runs all the same
+    assert np.array_equal(pm, np.arange(3000).reshape(50, 60).T.ravel())
 
 
 def test_concurrent_one_xcd_launches_are_booked_per_xcd():
@@ -370,6 +373,9 @@ def test_the_plan_names_one_engine_and_a_workspace_that_fits_at_every_size():
     assert _plan(4096, ["lasso"], sem=_SEM_XTX)[0] == "symcoop" and _plan(4096, ["lasso"], sem=_SEM_XTX, has_scale=True)[0] == "symcoop"      # config 4 (scale.factor: on the register-resident engine since round 5)
     assert _plan(257 - 1, ["lasso"], sem=_SEM_BIG, intercept=1)[0] == "coop"                                              # config 5: q = 257 (from 209 on)
     assert _plan(2048, ["lasso"])[0] == "rowcoop" and _plan(2048, ["grp.lasso"], groups=_RUNS4)[0] == "symcoop" and _plan(4097, ["lasso"])[0] == "launches"
+    # groups of more than 32 members stay on the register engine (their norms summed over several owners' slices)
+    for q in (1025, 1536, 3000, 4096):
+        assert _plan(q, ["grp.lasso"], groups=_RUNS50)[0] == "symcoop" and _plan(q, ["grp.mcp"], groups=_RUNS7, accelerate=True)[0] == "symcoop", q
 
 
 def test_the_plan_for_p_ge_n_fits_the_scratch_the_callers_allocate():
