@@ -350,8 +350,9 @@ int oemgpu_selftest_hold_cus(oemgpu_ctx *ctx, int32_t blocks, double ms);
  * over q coordinates, the permutation (new position -> old position) that makes every group a run of neighbouring coordinates -- groups in
  * the order of their first member, members in their own order (the order the reference sums their squares in, ref src/oem_dense.h:193-315) --
  * which lets the register-resident engine at 1024 < q <= 4096 take group penalties whatever the layout.  Returns q and fills perm[0..q), or 0
- * when no reordering applies: the groups are runs already, some group has more than 32 members (an owner's slice), or the group vector does
- * not cover q coordinates. */
+ * when no reordering applies: the groups are runs already, a variable is listed in two groups, or the group vector does not cover q
+ * coordinates.  (Groups of more than 32 members -- an owner's slice -- are reordered like the others: the engine sums their norms over
+ * several owners.) */
 int oemgpu_selftest_group_permutation(const oemgpu_opts *o, int32_t q, int32_t *perm);
 
 /* Host-only self-check of the CU-slot book of the persistent engines (pure arithmetic, runs without a GPU): `calls` concurrent callers

@@ -614,11 +614,11 @@ static int plan_paths(const PlanIn &in, PathPlan &P)
 
 size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o, int nbatch = 1);
 
-// ---- scattered groups at 1024 < q <= 4096: the register-resident engine (path_symcoop.hip) cuts the owners' slices at group boundaries, so
-// it takes group penalties only where every group is a RUN of <= 32 neighbouring coordinates; other layouts went to the launch-per-iteration
-// engines (q = 3,000: 22 against 6-7 us per iteration -- the reference has no such cliff between group layouts, ref src/oem_dense.h:421-456).
-// The OEM iteration does not care where a coordinate sits: u = A beta + XY, coordinate- / group-wise operators, a stop rule over all
-// coordinates, d an eigenvalue.  So groups of <= 32 members that are not runs are MADE runs: coordinates reordered group by group (groups in
+// ---- scattered groups at 1024 < q <= 4096: the register-resident engine (path_symcoop.hip) cuts the owners' slices at group boundaries (and
+// inside runs of more than 32), so it takes group penalties only where every group is a RUN of neighbouring coordinates; other layouts went to the
+// launch-per-iteration engines (q = 3,000: 22 against 6-8 us per iteration -- the reference has no such cliff between group layouts, ref
+// src/oem_dense.h:421-456).  The OEM iteration does not care where a coordinate sits: u = A beta + XY, coordinate- / group-wise operators, a stop
+// rule over all coordinates, d an eigenvalue.  So groups that are not runs are MADE runs: coordinates reordered group by group (groups in
 // the order of their first member, members in their own order -- the order the reference sums their squares in), XX, XY, the column
 // constants, penalty factors and scale factors permuted alike, the path solved there, the coefficients put back.  One gather of q^2
 // doubles per call.
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void permute_sym_kernel(const double *__restri
     }
 }
 
-// new position -> old position, or empty when the groups need no reordering / cannot be made runs of <= 32
+// new position -> old position, or empty when the groups need no reordering / cannot be made runs
 static std::vector<int> group_run_permutation(const oemgpu_opts *o, int q)
 {
     std::vector<int> perm;

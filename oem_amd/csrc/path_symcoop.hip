@@ -309,8 +309,9 @@ __device__ __forceinline__ double sx_uni(double v)
 
 // GEN: what needs more than a coordinate of its own (template parameter: the element-wise form pays nothing for it) --
 //   group operators (ref src/oem_dense.h:193-315): the owners' slices are cut at group boundaries by the host (every group a run of
-//       <= 32 neighbouring coordinates), an owner's u goes through 32 LDS words and every coordinate sums the squares of ITS group in
-//       member order like the reference, forms the group's factor and its coefficient;
+//       neighbouring coordinates), an owner's u goes through 32 LDS words and every coordinate sums the squares of ITS group in
+//       member order like the reference, forms the group's factor and its coefficient; a group of more than 32 members lies in several
+//       owners' slices -- their parts of the sum cross in a third tagged exchange and are added in owner order (gsplit);
 //   Nesterov's step (ref :633-651): its restart test is a sum over ALL coordinates -- the owners' parts ride next to exchange 2 as
 //       Lanczos' norm parts do, added in workgroup order by everybody;
 //   compute.loss (ref :759-770, Gram identity): when a lambda ends, g = XX beta of the finished iterate is in hand; the owners' parts of
