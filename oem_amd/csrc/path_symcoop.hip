@@ -986,10 +986,21 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
         return (Pc[l16] + Pc[16 + l16]) + (Pc[32 + l16] + Pc[48 + l16]);
     };
     // the owners' values out, all q coordinates in: Dst[j] (behind a barrier); returns the OR of the bits in the tags
-    auto all_gather = [&](double val, int mybit, double *Dst) -> int {
+    // ACC, xsum != null: *xsum = the sum of the workgroups' parts of Nesterov's restart test (rpart: this lane's part), thread t holding
+    // workgroup t's -- a fixed order.  The parts go out BEHIND the coefficients and their load is issued when the coefficients are all there,
+    // in front of the LDS stores; its wave sums meet behind the gather's own barrier: no round trip and no barrier of their own
+    auto all_gather = [&](double val, int mybit, double *Dst, double rpart = 0.0, double *xsum = nullptr) -> int {
         ++X.epoch;
         const int par = (int)(X.epoch & 1u);
         if (own) sx_publish(X.rs, par * X.s2 + row * 16, val, (X.epoch << 1) | (unsigned)mybit);
+        if constexpr (ACC) {
+            // Nesterov: this workgroup's part of the restart test (its sixteen owner lanes are lanes 0..15 of wave 0, the others hold 0),
+            // published behind the coefficients
+            if (xsum && w == 0) {
+                const double part = wave_sum(rpart);
+                if (tid == 0) sx_publish(X.rs, 2 * RQ * 16 + 2 * (RQ / 16) * 16 + par * (RQ / 16) * 16 + wg * 16, part, X.epoch << 1);
+            }
+        }
         SX_STAMP(2);
         int bits = 0;
         double r[RE];
@@ -998,11 +1009,31 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
         for (int k = 0; k < RE; ++k) off[k] = par * X.s2 + g2off[k];
         sx_gather<RE>(off, need2, r, bits, X);
         SX_STAMP(3);
+        sx_v4u xp = sx_v4u{0u, 0u, 0u, 0u};
+        const int xoff = 2 * RQ * 16 + 2 * (RQ / 16) * 16 + par * (RQ / 16) * 16 + (tid < G ? tid : 0) * 16;
+        if constexpr (ACC) { if (xsum && tid < G) xp = __builtin_amdgcn_raw_buffer_load_b128(X.rs, xoff, 0, 16); }
         // (a coordinate beyond q came back as 0.0 and is stored like the others, over the zeros that sit there: no masked stores)
 #pragma unroll
         for (int k = 0; k < RE; ++k) Dst[tid + SNTH * k] = r[k];
         sx_vote(votes, w, lane, bits);
+        double *xr = red + 4 * rpar;
+        if constexpr (ACC) {
+            if (xsum) {
+                const bool xn = tid < G;
+                double xv = __hiloint2double((int)xp.z, (int)xp.x);
+                if (__any(xn && ((xp.y >> 1) != X.epoch || (xp.w >> 1) != X.epoch))) {      // (a part that is not there yet -- rare: it left before the last coefficient arrived)
+                    int offa[1] = {xoff};
+                    double va[1];
+                    int fla = 0;
+                    sx_gather<1>(offa, xn ? 1u : 0u, va, fla, X);
+                    xv = va[0];
+                }
+                const double xs = wave_sum(xn ? xv : 0.0);
+                if (lane == 0) xr[w] = xs;
+            }
+        }
         __syncthreads();
+        if constexpr (ACC) { if (xsum) { *xsum = (xr[0] + xr[1]) + (xr[2] + xr[3]); rpar ^= 1; } }
         SX_STAMP(4);
 #ifdef OEM_PATH_DIAG
         X.acc[8] += 1;
@@ -1114,17 +1145,17 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
             int it = 0;
             bool conv = false;
             while (it < maxit) {
+                // (Nesterov's sequence depends on the previous restart test alone: its square root and division go in front of the product,
+                // into the shadow of its LDS reads, not between the operator and the publication of the coefficients)
+                double akn = 1.0, aratio = 0.0, rpart = 0.0;
+                if (ACC) { akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak)); aratio = (ak - 1.0) / akn; }
                 const double g = product();
                 const double u = (d * bc - g) + xyc;                 // ref src/oem_dense.h:512
                 double bn = own ? sx_op(u, pfc, thkind, thc) : 0.0;
-                double akn = 1.0;
                 if (ACC) {
-                    akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak));
                     const double upd = bn, diff = upd - bc;
-                    bn = upd + ((ak - 1.0) / akn) * diff;
-                    // this workgroup's part of the restart test: its sixteen owner lanes are lanes 0..15 of wave 0 (the others hold 0)
-                    const double part = wave_sum(own ? (bn - upd) * diff : 0.0);
-                    if (tid == 0) sx_publish(X.rs, 2 * RQ * 16 + 2 * (RQ / 16) * 16 + (int)((X.epoch + 1u) & 1u) * (RQ / 16) * 16 + wg * 16, part, (X.epoch + 1u) << 1);
+                    bn = upd + aratio * diff;
+                    rpart = own ? (bn - upd) * diff : 0.0;           // (its wave sum and its pair go out BEHIND the coefficient, inside all_gather: nobody's product waits for them)
                 }
                 const double cu = fabs(bn), qo = fabs(bc);
                 const bool cn = cu > 1e-13, qn = qo > 1e-13;         // ref src/utils.cpp:537-549
@@ -1135,15 +1166,9 @@ __global__ __launch_bounds__(SNTH) void path_rowcoop_kernel(PathArgs A, unsigned
                 // nobody any more, and the bit rides in this workgroup's vote: every loop is left (pp = npen says so -- no flag of its own:
                 // this kernel has no scalar register to spare)
                 if ((it & 127) == 1) (void)sx_abort_seen(X);
-                const int any = all_gather(bn, moving, Bsh);
-                if (ACC) {                                           // (the parts were published with the coefficients: they are there by now)
-                    int offa[1] = {2 * RQ * 16 + 2 * (RQ / 16) * 16 + (int)(X.epoch & 1u) * (RQ / 16) * 16 + (tid < G ? tid : 0) * 16};
-                    double va[1];
-                    int fla = 0;
-                    sx_gather<1>(offa, tid < G ? 1u : 0u, va, fla, X);
-                    const double tot = sx_block_sum(va[0], red, rpar, w, lane);
-                    ak = (tot > 0.0) ? 1.0 : akn;                    // (the extrapolated beta is kept; only the momentum counter restarts)
-                }
+                double tot = 0.0;
+                const int any = all_gather(bn, moving, Bsh, rpart, ACC ? &tot : nullptr);
+                if (ACC) ak = (tot > 0.0) ? 1.0 : akn;               // (the extrapolated beta is kept; only the momentum counter restarts)
                 if (any & 2) { pp = npen; break; }
                 if (!any) { conv = true; break; }
             }
