@@ -98,6 +98,7 @@ if [ -z "$quick" ]; then
   python3 tools/scattered_groups_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_scattered_groups_now.txt
   python3 tools/spk_check.py 4097 6145 8192 2>&1 | grep -v amdgpu.ids > $o/${tag}_spk_check.txt
   python3 tools/scale_factor_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_scale_factor_now.txt
+  python3 tools/rowcoop_accel_time.py 2>&1 | grep -v amdgpu.ids > $o/${tag}_rowcoop_accelerate_now.txt
 fi
 # the raw traces stay on the box: gpurun copies back at most 64 MiB
 for d in $o/${tag}_trace $o/${tag}_pmc_fetch $o/${tag}_pmc_write $o/${tag}_pmc_mfma $o/${tag}_*_pmc_mfma $o/${tag}_*_trace $o/${tag}_*_pmc_FETCH_SIZE $o/${tag}_*_pmc_WRITE_SIZE; do [ -d "$d" ] && rm -rf "$d"; done

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""1024 < q <= 4096 where the register-resident engines do not apply -- groups that are NOT runs of neighbouring coordinates (60 scattered groups of
-q / 60), and the second attempt after a timed-out persistent launch (OEM_NO_SYMCOOP=1, element-wise) -- on the launch-per-iteration engines:
-us per iteration.  python tools/scattered_groups_time.py [q ...]"""
+"""1024 < q <= 4096 with groups that are NOT runs of neighbouring coordinates -- of about 25 members, and 60 scattered groups of q / 60 (more than the
+32 coordinates of an owner's slice: norms summed over several owners) -- on the register-resident engine, and the same calls / the second attempt after a
+timed-out persistent launch (OEM_NO_SYMCOOP=1) on the launch-per-iteration engines: us per iteration.  python tools/scattered_groups_time.py [q ...]"""
 import os, sys, ctypes as C
 from pathlib import Path
 import numpy as np
@@ -24,9 +24,10 @@ for p in [int(a) for a in sys.argv[1:]] or [1536, 2048, 3000, 4096]:
     small = np.arange(p) % (p // 25) + 1                 # <= 32 members each: reordered into runs, the register-resident engine takes them
     for label, env, kw in (("grp.lasso, scattered groups of 25", {}, dict(penalty=["grp.lasso"], groups=small)),
                            ("grp.lasso, 60 scattered groups", {}, dict(penalty=["grp.lasso"], groups=scattered)),
+                           ("grp.lasso, 60 scattered groups, launches (OEM_NO_SYMCOOP=1)", {"OEM_NO_SYMCOOP": "1"}, dict(penalty=["grp.lasso"], groups=scattered)),
                            ("lasso, launches (OEM_NO_SYMCOOP=1)", {"OEM_NO_SYMCOOP": "1"}, dict(penalty=["lasso"])),
                            ("lasso, row-streaming launches (OEM_NO_SYMCOOP=1 OEM_NO_SYM=1)", {"OEM_NO_SYMCOOP": "1", "OEM_NO_SYM": "1"}, dict(penalty=["lasso"])),
-                           ("grp.lasso scattered, row-streaming launches (OEM_NO_SYM=1)", {"OEM_NO_SYM": "1"}, dict(penalty=["grp.lasso"], groups=scattered))):
+                           ("grp.lasso scattered, row-streaming launches (OEM_NO_SYMCOOP=1 OEM_NO_SYM=1)", {"OEM_NO_SYMCOOP": "1", "OEM_NO_SYM": "1"}, dict(penalty=["grp.lasso"], groups=scattered))):
         for k, v in env.items(): os.environ[k] = v
         best = 1e9
         for _ in range(2):
