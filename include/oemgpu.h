@@ -355,6 +355,16 @@ int oemgpu_selftest_hold_cus(oemgpu_ctx *ctx, int32_t blocks, double ms);
  * several owners.) */
 int oemgpu_selftest_group_permutation(const oemgpu_opts *o, int32_t q, int32_t *perm);
 
+/* Host-only self-check of how the register-resident engine at 1024 < q <= 4096 deals group runs to its workgroups (path_symcoop.hip:
+ * symcoop_plan; pure arithmetic, runs without a GPU).  runs[0 .. nruns]: the starts of the runs of neighbouring coordinates (one per group,
+ * ungrouped coordinates runs of one), runs[nruns] = q.  On return *nowners workgroups (0: no plan, the launch-per-iteration engines take the
+ * call), workgroup g owning the owner_n[g] coordinates from owner_c0[g] on (<= 32; slices end at run boundaries, or after every fourth
+ * coordinate inside a run of more than 32), and per coordinate j frag[2 j] = 2 (first owner of j's run) + (1 if the run does not start that
+ * owner's slice), frag[2 j + 1] = the number of owners the run lies in; *split = the most owners of one run (0: no run is split).  The arrays
+ * hold 192 / 192 / 2 q entries. */
+int oemgpu_selftest_symcoop_owners(int32_t q, int32_t num_cu, const int32_t *runs, int32_t nruns, int32_t *owner_c0, int32_t *owner_n, int32_t *frag,
+                                   int32_t *nowners, int32_t *split);
+
 /* Host-only self-check of the CU-slot book of the persistent engines (pure arithmetic, runs without a GPU): `calls` concurrent callers
  * each place `ninst` instances of W cooperating workgroups with every instance on ONE XCD of a device with num_cu CUs (path_coop.hip,
  * q <= 512).  bases[k] = the XCD of call k's first instance (chosen where the XCDs are emptiest), *peak = the most CUs any XCD was

@@ -91,6 +91,8 @@ _SIGS = {
     "oemgpu_release_cache": (None, []),
     "oemgpu_selftest_hold_cus": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "oemgpu_selftest_group_permutation": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "oemgpu_selftest_symcoop_owners": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "oemgpu_selftest_coop_slots": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "oemgpu_selftest_sympk_gemv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "oemgpu_selftest_wcoop_sizing": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

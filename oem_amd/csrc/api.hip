@@ -1248,6 +1248,19 @@ int oemgpu_selftest_group_permutation(const oemgpu_opts *o, int32_t q, int32_t *
     return (int)pm.size();
 }
 
+int oemgpu_selftest_symcoop_owners(int32_t q, int32_t num_cu, const int32_t *runs, int32_t nruns, int32_t *owner_c0, int32_t *owner_n, int32_t *frag,
+                                   int32_t *nowners, int32_t *split)
+{
+    if (q <= 1024 || q > 4096 || num_cu < 8 || !runs || nruns < 1 || !owner_c0 || !owner_n || !frag || !nowners || !split || runs[0] != 0 || runs[nruns] != q) {
+        set_error("selftest_symcoop_owners: bad argument (1024 < q <= 4096, runs[0] = 0, runs[nruns] = q)"); return OEMGPU_ERR_ARG;
+    }
+    const int gmax = num_cu * 3 / 4 < WCOOP_GMAX ? num_cu * 3 / 4 : WCOOP_GMAX;
+    int G = 0, sp = 0;
+    if (!symcoop_plan_owners(q, gmax, runs, nruns, owner_c0, owner_n, frag, &G, &sp)) { *nowners = 0; *split = 0; return 0; }      // (no plan: the launches take the call)
+    *nowners = G; *split = sp;
+    return 0;
+}
+
 int oemgpu_selftest_coop_slots(int32_t num_cu, int32_t W, int32_t ninst, int32_t calls, int32_t *bases, int32_t *peak)
 {
     if (num_cu < 8 || num_cu % 8 || W < 1 || ninst < 1 || calls < 1 || calls > 64 || !bases || !peak) { set_error("selftest_coop_slots: bad argument"); return OEMGPU_ERR_ARG; }

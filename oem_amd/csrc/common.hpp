@@ -216,6 +216,7 @@ struct SymcoopPlan {
     std::vector<int> tab;                                   // blkbase[80] then G records (uploaded as is); split groups: + the fragment table [2 q]
 };
 bool symcoop_plan(int q, int gmax, SymcoopPlan &P, const int *runs = nullptr, int nruns = 0);   // runs: group runs (starts, nruns + 1) the owners' slices are cut at
+int symcoop_plan_owners(int q, int gmax, const int *runs, int nruns, int *owner_c0, int *owner_n, int *frag, int *G_out, int *split_out);
 size_t symcoop_xchg_bytes(const SymcoopPlan &P);
 size_t symcoop_work_bytes(const SymcoopPlan &P);    // ... plus the kernel's copy of its arguments
 size_t symcoop_xchg_bytes_max(int q);

@@ -1413,6 +1413,21 @@ static bool symcoop_plan_per(int q, int gmax, SymcoopPlan &P, const int *runs, i
     return true;
 }
 
+// Host-only self-check (include/oemgpu.h: oemgpu_selftest_symcoop_owners): the owners' slices and the fragment table the plan deals for these runs
+int symcoop_plan_owners(int q, int gmax, const int *runs, int nruns, int *owner_c0, int *owner_n, int *frag, int *G_out, int *split_out)
+{
+    SymcoopPlan P;
+    if (!symcoop_plan(q, gmax, P, runs, nruns)) return 0;
+    for (int g = 0; g < P.G; ++g) {
+        const int *r = P.tab.data() + SPLAN_HEAD + (size_t)g * SW_INTS;
+        owner_c0[g] = r[SW_C0]; owner_n[g] = r[SW_NSL];
+    }
+    const size_t base = SPLAN_HEAD + (size_t)P.G * SW_INTS;
+    for (int j = 0; j < 2 * q; ++j) frag[j] = P.tab.size() > base ? P.tab[base + j] : (j & 1);
+    *G_out = P.G; *split_out = P.split;
+    return 1;
+}
+
 size_t symcoop_xchg_bytes(const SymcoopPlan &P) { return 2 * ((size_t)P.nsum * 64 * 16) + 2 * ((size_t)P.T * 64 * 16) + 8 * ((size_t)P.G * 16) + 256; }
 size_t symcoop_work_bytes(const SymcoopPlan &P) { return (symcoop_xchg_bytes(P) + 255) / 256 * 256 + (sizeof(PathArgs) + 255) / 256 * 256; }      // + the kernel's arguments
 // an upper bound for any q the engine takes (workspace reservation): every block receives at most 8 SE1 partials

@@ -321,6 +321,66 @@ def test_scattered_groups_are_reordered_into_runs():
     assert np.array_equal(pm, np.arange(3000).reshape(50, 60).T.ravel())
 
 
+def test_groups_larger_than_an_owners_slice_are_dealt_in_fragments():
+    """path_symcoop.hip: symcoop_plan (host arithmetic) for group runs at 1024 < q <= 4096: every owner holds <= 32 coordinates; a run of <= 32 is
+    never cut; a longer run (a group of more than 32 members) is cut only after every fourth of its coordinates; and the fragment table the kernel
+    sums a split group's norm by names, for every coordinate, the first owner of its run, how many owners the run lies in, and whether the run
+    starts that owner's slice -- re-derived here from the slices alone (ref src/oem_dense.h:193-315: the reference sums a group's squares whatever
+    its size)."""
+    import ctypes as C
+    from oem_amd import _lib as L
+    rng = np.random.default_rng(11)
+    lib = L.lib()
+
+    def owners(q, sizes, num_cu=256):
+        runs = np.r_[0, np.cumsum(sizes)].astype(np.int32)
+        assert runs[-1] == q
+        c0, cn, frag = (C.c_int32 * 192)(), (C.c_int32 * 192)(), (C.c_int32 * (2 * q))()
+        G, sp = C.c_int32(-1), C.c_int32(-1)
+        L.check(lib.oemgpu_selftest_symcoop_owners(q, num_cu, runs.ctypes.data_as(C.POINTER(C.c_int32)), len(sizes), c0, cn, frag, C.byref(G), C.byref(sp)))
+        return runs, np.array(c0[:G.value]), np.array(cn[:G.value]), np.array(frag[:]).reshape(q, 2), sp.value
+
+    def sizes_for(q, pick):
+        out = []
+        while sum(out) < q:
+            out.append(int(pick()))
+        out[-1] -= sum(out) - q
+        return [s for s in out if s > 0]
+
+    cases = [(3000, [50] * 60), (4096, [68] * 60 + [16]), (1536, [25, 26] * 30 + [6]), (2600, [520] * 5), (1100, [1100]),
+             (2048, sizes_for(2048, lambda: rng.choice([1, 3, 20, 33, 47, 64, 120]))), (3777, sizes_for(3777, lambda: rng.integers(1, 400))),
+             (4000, sizes_for(4000, lambda: rng.choice([31, 32, 33]))), (1300, [1] * 1300)]
+    for q, sizes in cases:
+        runs, c0, cn, frag, split = owners(q, sizes)
+        assert len(c0) > 0, (q, sizes[:5])
+        live = cn > 0
+        assert cn.max() <= 32 and cn.sum() == q
+        if not live.all():
+            assert not live[np.argmin(live):].any()                                             # owners of nothing sit behind the others
+        starts = c0[live]
+        assert starts[0] == 0 and np.array_equal(starts[1:], (starts + cn[live])[:-1])          # the slices follow one another
+        ends = np.r_[starts[1:], q]
+        most = 0
+        for r in range(len(sizes)):
+            gs, ge = int(runs[r]), int(runs[r + 1])
+            inside = starts[(starts > gs) & (starts < ge)]
+            if ge - gs <= 32:
+                assert len(inside) == 0, (q, r, gs, ge)                                         # a group that fits an owner is never cut
+            else:
+                assert np.all((inside - gs) % 4 == 0)                                           # cuts after every fourth coordinate at most
+            a = int(np.searchsorted(starts, gs, side="right")) - 1
+            b = int(np.searchsorted(starts, ge - 1, side="right")) - 1
+            assert ends[b] >= ge and starts[a] <= gs
+            k = b - a + 1
+            most = max(most, k if k > 1 else 0)
+            if split > 0:
+                assert np.all(frag[gs:ge, 1] == k) and np.all(frag[gs:ge, 0] == 2 * a + (0 if starts[a] == gs else 1)), (q, r)
+        assert split == most, (q, split, most)
+    # the verdict's layout: sixty groups of fifty -- every group in a few owners' slices (the slices hold ~18 coordinates each)
+    assert 2 <= owners(3000, [50] * 60)[4] <= 4
+    assert owners(1536, [25] * 61 + [11])[4] == 0                                               # nothing to split: no table, no hop
+
+
 def test_concurrent_one_xcd_launches_are_booked_per_xcd():
     """the CU slots of the one-XCD cooperating launches are booked per XCD, and a call's first XCD is the one where the load
     is lowest -- three calls of one 16-workgroup instance (q = 512) in flight at once must not meet on one XCD (the old turn counter put
