@@ -418,6 +418,9 @@ struct PathPlan {
     size_t out_stride = 0, out_bytes = 0, nb = 0, nk = 0;
     Groups G;
     std::vector<int> cst, grs, grg, grw;
+    bool grp_head = false;                           // group operators in the head of the packed-triangle pairs (PathArgs::grp_head)
+    std::vector<int> grun;                           // ... [2 q]
+    std::vector<double> gwc;                         // ... [q]
     SymcoopPlan *symplan = nullptr;                  // (thread-local cache: a pure function of q, the CUs and the group runs)
     PathArgs ap;                                     // the scalar fields of the kernels' arguments (the eligibility rules read them)
     size_t frame_bytes() const { const int np = pen_split ? ap.npen : 1; Bump t; t.take(out_stride * ap.nbatch); t.take(work_d * sizeof(double) * ap.nbatch * np); return t.off; }
@@ -583,6 +586,29 @@ static int plan_paths(const PlanIn &in, PathPlan &P)
     a.pen_split = P.pen_split; a.pen_lo = 0; a.pen_hi = npen;
     a.nbatch = nbatch;
 
+    // the launch engines at q > 1024 (the packed triangle): groups that are runs of <= 32 neighbouring coordinates, nothing that needs a sum over
+    // all coordinates -- the group operators run in the head of the (head, product) pairs (path_large.hip), one launch fewer per iteration
+    // and no single-workgroup update kernel (q = 8,192: 65 -> 52 us per iteration)
+    if (!wide && any_grp && q > 1024 && nbatch == 1 && !a.accelerate && !a.compute_loss && !P.loss_post && !in.has_scale && (int)G.gidx.size() <= q) {
+        bool ok = true;
+        for (int g = 0; g < og.ngroups && ok; ++g) {
+            const int m0 = G.gstart[g], len = G.gstart[g + 1] - m0;
+            ok = len <= 32;
+            for (int k = 0; k < len && ok; ++k) ok = G.gidx[m0 + k] == G.gidx[m0] + k && G.gid[G.gidx[m0 + k]] == g;
+        }
+        if (ok) {
+            P.grp_head = true;
+            P.grun.assign(2 * (size_t)q, 0); P.gwc.assign(q, 0.0);
+            for (int j = 0; j < q; ++j) {
+                const int g = G.gid[j];
+                if (g < 0) { P.grun[2 * j] = 1; P.grun[2 * j + 1] = 0; continue; }
+                const int gs = G.gidx[G.gstart[g]], ge = gs + (G.gstart[g + 1] - G.gstart[g]);
+                P.grun[2 * j] = gs; P.grun[2 * j + 1] = ge | (G.gzero[g] ? (1 << 30) : 0);
+                P.gwc[j] = G.gw[g];
+            }
+        }
+    }
+
     // 1024 < q <= 2048, element-wise penalties: the row-split form with ONE exchange per iteration, else the symmetric one
     P.rowcoop = P.symc && path_rowcoop_eligible(a, any_grp) && path_rowcoop_workgroups(q) <= num_cu * 3 / 4 &&
                 symcoop_work_bytes(symplan) >= path_rowcoop_xchg_bytes();
@@ -638,7 +664,7 @@ __global__ __launch_bounds__(256) void permute_sym_kernel(const double *__restri
 }
 
 // new position -> old position, or empty when the groups need no reordering / cannot be made runs
-static std::vector<int> group_run_permutation(const oemgpu_opts *o, int q)
+static std::vector<int> group_run_permutation(const oemgpu_opts *o, int q, int max_len)
 {
     std::vector<int> perm;
     if (o->ngroups <= 0 || o->ngroupvars != q) return perm;
@@ -652,8 +678,9 @@ static std::vector<int> group_run_permutation(const oemgpu_opts *o, int q)
         if (len > longest) longest = len;
         for (int k = 1; k < len && runs; ++k) runs = G.gidx[G.gstart[g] + k] == G.gidx[G.gstart[g]] + k;
     }
-    (void)longest;                                       // (groups of more than 32 members: their norms are summed over several owners, path_symcoop.hip)
-    if (runs) return perm;
+    // (groups of more than 32 members: the register engine sums their norms over several owners, path_symcoop.hip -- max_len = q;
+    //  the launches' head form beyond 4096 takes runs of <= 32: max_len = 32, nothing to gain otherwise)
+    if (runs || longest > max_len) return perm;
     perm.reserve(q);
     std::vector<char> done(o->ngroups, 0);
     for (int j = 0; j < q; ++j) {
@@ -676,11 +703,14 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const bool launches_only = ex && ex->d_fixed > 0.0;
     const int nl = nl_of(o), npen = o->npen;
     const bool user = o->lambda_user && o->nlambda_user > 0;
-    if (!g_in_permuted_call && q > 1024 && q <= 4096 && nbatch == 1 && !wide && !ex && !lmax_xy_dev && xx && (sem == OEMGPU_SEM_DENSE || sem == SEM_XTX) &&
-        o->ngroups > 0 && !sw().OEM_NO_SYMCOOP.set && !sw().OEM_NO_COOP.set && !sw().OEM_SYMCOOP_NO_GENERAL.set) {
+    // (beyond 4096 the same reordering where it buys the launches their head form -- every group <= 32 members, PathArgs::grp_head)
+    const bool perm_reg = q > 1024 && q <= 4096 && !sw().OEM_NO_SYMCOOP.set && !sw().OEM_NO_COOP.set && !sw().OEM_SYMCOOP_NO_GENERAL.set;
+    const bool perm_large = q > 4096 && !o->accelerate && !o->compute_loss && !scale_factor && !sw().OEM_NO_SYM.set && !sw().OEM_NO_FUSED.set;
+    if (!g_in_permuted_call && (perm_reg || perm_large) && nbatch == 1 && !wide && !ex && !lmax_xy_dev && xx && (sem == OEMGPU_SEM_DENSE || sem == SEM_XTX) &&
+        o->ngroups > 0) {
         bool any_group_penalty = false;
         for (int k = 0; k < npen; ++k) any_group_penalty |= pen_is_grp(o->penalty[k]);
-        const std::vector<int> perm = any_group_penalty ? group_run_permutation(o, q) : std::vector<int>();
+        const std::vector<int> perm = any_group_penalty ? group_run_permutation(o, q, perm_reg ? q : 32) : std::vector<int>();
         if (!perm.empty()) {
             // the permuted problem in a buffer of its own (xx2 | xy2 | stats2 | perm), the options with their per-coordinate arrays permuted
             const size_t nd = (size_t)q * q + q + stats_len(p) + 8;
@@ -747,6 +777,8 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const size_t o_grg = grw.empty() ? 0 : bl.add(grg.data(), sizeof(int) * grg.size());
     const size_t o_grw = grw.empty() ? 0 : bl.add(grw.data(), sizeof(int) * grw.size());
     const size_t o_symp = symc ? bl.add(symplan.tab.data(), sizeof(int) * symplan.tab.size()) : 0;
+    const size_t o_grun = P.grp_head ? bl.add(P.grun.data(), sizeof(int) * P.grun.size()) : 0;
+    const size_t o_gwc = P.grp_head ? bl.add(P.gwc.data(), sizeof(double) * P.gwc.size()) : 0;
 
     // the outputs come first: when the caller's frame ends with `stats` (both callers), stats | outputs is one
     // contiguous range and one device-to-host copy returns both
@@ -794,6 +826,8 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     a.sinv = scale_factor ? (const double *)(dblob + o_sinv) : nullptr;
     a.gid = (const int *)(dblob + o_gid); a.gstart = (const int *)(dblob + o_gst); a.gidx = (const int *)(dblob + o_gix);
     a.gzero = (const int *)(dblob + o_gz); a.gw = (const double *)(dblob + o_gw);
+    a.grp_head = P.grp_head ? 1 : 0;
+    a.grun = P.grp_head ? (const int *)(dblob + o_grun) : nullptr; a.gwc = P.grp_head ? (const double *)(dblob + o_gwc) : nullptr;
     a.beta = dout; a.lambda_out = dout + nb; a.loss = a.lambda_out + nk; a.d_out = a.loss + nk;
     double *dstats = a.d_out + D_OUT_LEN;
     a.niter = (int *)(dstats + stats_len(p));
@@ -1010,7 +1044,7 @@ size_t paths_ws_bytes(int p, int q, const oemgpu_opts *o, int nbatch)
     const size_t splits = (q <= 1024 && o->npen > 1) ? (size_t)o->npen : 1;
     size_t b = 0;
     b += (size_t)o->npen * 4 + (size_t)o->npen * nl * 8 + (size_t)q * (8 + 8 + 4) + (size_t)(o->ngroups + 2) * 16 +
-         (size_t)(o->ngroupvars + q + 2) * 4 + 4096;
+         (size_t)(o->ngroupvars + q + 2) * 4 + (q > 1024 ? (size_t)q * 16 : 0) + 4096;      // (+ the per-coordinate group runs and weights of PathArgs::grp_head)
     b += ((size_t)o->npen * nl * (q + 3) + 4 + stats_len(p)) * 8 + 4096;
     // (from the cooperating engine's smallest q on -- 209, below the single-workgroup limit of 288 -- a call that is not small keeps the
     // launch-per-iteration engines' workspace as its fallback: oemgpu_selftest_plan found 209 <= q <= 288 with several penalties sized for
@@ -1086,7 +1120,8 @@ int oemgpu_selftest_plan(int32_t p, int32_t q, int32_t semantics, int32_t interc
     const int nl = nl_of(o);
     size_t blob = (size_t)o->npen * 4 + ((o->lambda_user && o->nlambda_user > 0) ? (size_t)o->npen * nl * 8 : 0) + (size_t)q * (8 + 8 + 4) +
                   P.G.gstart.size() * 4 + P.G.gidx.size() * 4 + P.G.gzero.size() * 4 + P.G.gw.size() * 8 + P.cst.size() * 4 +
-                  (P.grw.empty() ? 0 : (P.grs.size() + P.grg.size() + P.grw.size()) * 4) + (P.symc ? P.symplan->tab.size() * 4 : 0) + 16 * 16;
+                  (P.grw.empty() ? 0 : (P.grs.size() + P.grg.size() + P.grw.size()) * 4) + (P.symc ? P.symplan->tab.size() * 4 : 0) +
+                  (P.grp_head ? P.grun.size() * 4 + P.gwc.size() * 8 : 0) + 18 * 16;
     *frame_bytes = (int64_t)(P.frame_bytes() + (blob + 255) / 256 * 256);
     *reserved_bytes = (int64_t)(paths_ws_bytes(p, q, o, nbatch) + 4096);
     // p >= n: the exchange buffers of the persistent engine chosen against the scratch every caller allocates (wide_scratch_doubles)
@@ -1243,7 +1278,7 @@ int oemgpu_sum_in_order_dev(oemgpu_ctx *c, const double *parts_dev, int32_t npar
 int oemgpu_selftest_group_permutation(const oemgpu_opts *o, int32_t q, int32_t *perm)
 {
     if (!o || !perm || q < 1) { set_error("selftest_group_permutation: bad argument"); return OEMGPU_ERR_ARG; }
-    const std::vector<int> pm = group_run_permutation(o, q);
+    const std::vector<int> pm = group_run_permutation(o, q, q);
     for (size_t j = 0; j < pm.size(); ++j) perm[j] = pm[j];
     return (int)pm.size();
 }

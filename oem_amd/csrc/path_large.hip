@@ -1184,6 +1184,33 @@ __global__ __launch_bounds__(256, OEM_SYM_MINWG) void sympk_gemv_kernel(const do
 // coordinate l in slot order -- at q = 8,192 eight loads, all in flight at once: the kernel is one memory round trip -- and the eight
 // chunk sums meet as ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)): one fixed order, the same in the sum kernel and in the head
 constexpr int SPK_HC = 32;
+// (the chunk's part alone: slots [ch NBLK / 8, (ch + 1) NBLK / 8) of coordinate c, in slot order)
+__device__ __forceinline__ double spk_chunk_sum(const double *__restrict__ P, int nblk, int qpad, int c, int ch)
+{
+    const int k0 = (ch * nblk) >> 3, k1 = ((ch + 1) * nblk) >> 3;
+    const double *pc = P + (size_t)k0 * qpad + c;
+    double s = 0.0;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8, pc += (size_t)8 * qpad) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = pc[(size_t)u * qpad];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = pc[(ptrdiff_t)(k + u < k1 ? u : k1 - 1 - k) * qpad];      // (never past the chunk's last slot)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (k + u < k1) ? t[u] : 0.0;
+    }
+    return s;
+}
+__device__ __forceinline__ double spk_chunk_tree(const double (*sh)[SPK_HC], int l)
+{
+    return ((sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l])) + ((sh[4][l] + sh[5][l]) + (sh[6][l] + sh[7][l]));
+}
 __device__ __forceinline__ double spk_slot_sum(const double *__restrict__ P, int nblk, int qpad, int c, int ch, double (*sh)[SPK_HC], int l)
 {
     const int k0 = (ch * nblk) >> 3, k1 = ((ch + 1) * nblk) >> 3;
@@ -1220,22 +1247,52 @@ __global__ __launch_bounds__(256) void sympk_sum_kernel(const double *__restrict
 }
 
 // Element-wise penalties: the slot sum IS the head of oem_symfused_kernel -- state, "still moving" words of the previous launch, the
-// replicated transition, the operator on the workgroup's 64 coordinates, beta_{t+1} into B[par ^ 1] (which the product kernel of
+// replicated transition, the operator on the workgroup's 32 coordinates, beta_{t+1} into B[par ^ 1] (which the product kernel of
 // this iteration then reads), the workgroup's "still moving" word.  One (head, product) pair of launches per iteration.
+// GRP (PathArgs::grp_head: every group a run of <= 32 neighbouring coordinates, no Nesterov step, no loss, no scale.factor): the group operators
+// as well (ref src/oem_dense.h:193-315).  A group of one of the workgroup's coordinates lies inside the window of the 32 coordinates before
+// them, themselves and the 32 behind them: the workgroup forms u of the whole window (three slot sums instead of one -- the partial vectors
+// are 4 MB against the product's 270 -- threads (ch, l), ch = 0 / 1 / 2, take the coordinate l of the own / the lower / the upper block),
+// puts it through LDS and every own coordinate sums the squares of ITS group in member order.  A group that straddles two workgroups is summed by
+// both, from the same numbers in the same order.  Everything else -- state, flags, the blocks of zeros -- is the element-wise head's.
+template <bool GRP>
 __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__restrict__ S, double *__restrict__ B, const double *__restrict__ P,
                                                           int *__restrict__ flags, int *__restrict__ fdone, int par, double d, int nblk, int qpad, int *__restrict__ nz32)
 {
-    __shared__ double sh[8][SPK_HC];
-    const int q = A.p, nl = A.nl, tid = threadIdx.x, l = tid & (SPK_HC - 1), ch = tid / SPK_HC, cm = blockIdx.x * SPK_HC + l;
+    __shared__ double sh[GRP ? 3 : 1][8][SPK_HC];
+    __shared__ double Ush[GRP ? 3 * SPK_HC : 1];
+    const int q = A.p, nl = A.nl, tid = threadIdx.x, l = tid & (SPK_HC - 1), ch = tid / SPK_HC, c0 = blockIdx.x * SPK_HC, cm = c0 + l;
     const bool own = ch == 0 && cm < q;
+    // the window coordinate of this thread (GRP; ch >= 3: none) -- or its own one
+    const int wslot = ch == 1 ? 0 : ch == 0 ? 1 : 2;                // block of the window: 0 lower, 1 own, 2 upper
+    const int cw = GRP ? c0 + SPK_HC * (wslot - 1) + l : cm;
+    const bool wok = GRP ? (ch < 3 && cw >= 0 && cw < q) : own;
     const SState st = S[par];
     const double *__restrict__ bin = B + (size_t)par * qpad;
     double *__restrict__ bout = B + (size_t)(par ^ 1) * qpad;
     int fl[FMAXB / 256];
 #pragma unroll
     for (int k = 0; k < FMAXB / 256; ++k) { const int t = tid + 256 * k; fl[k] = flags[par * FMAXB + (t < (int)gridDim.x ? t : 0)]; }
-    const double bo = own ? bin[cm] : 0.0, xyc = own ? A.xy[cm] : 0.0, pfc = own ? A.pf[cm] : 0.0;
-    const double g = spk_slot_sum(P, nblk, qpad, cm, ch, sh, l);    // (fresh: P is not there yet and g is not used; the loads are issued before the state is looked at)
+    const double bo = wok ? bin[cw] : 0.0, xyc = wok ? A.xy[cw] : 0.0, pfc = wok ? A.pf[cw] : 0.0;
+    int gs = 1, ge = 0;
+    bool gz = false;
+    double gwc = 0.0;
+    if (GRP && own) {
+        const int e = A.grun[2 * cm + 1];
+        gs = A.grun[2 * cm]; ge = e & 0x3fffffff; gz = ((e >> 30) & 1) != 0; gwc = A.gwc[cm];
+    }
+    double g;                                                       // (fresh: P is not there yet and g is not used; the loads are issued before the state is looked at)
+    if constexpr (!GRP) g = spk_slot_sum(P, nblk, qpad, cm, ch, sh[0], l);
+    else {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            int cb = c0 + SPK_HC * (b - 1) + l;
+            cb = cb < 0 ? 0 : (cb < qpad ? cb : qpad - 1);          // (beyond the vector: read somewhere, never used)
+            sh[b][ch][l] = spk_chunk_sum(P, nblk, qpad, cb, ch);
+        }
+        __syncthreads();
+        g = spk_chunk_tree(sh[wslot], l);
+    }
     if (st.done) {                                                  // the launch after the last one: make both copies agree
         if (blockIdx.x == 0 && tid == 0) { S[par ^ 1].done = 1; *fdone = 1; }
         return;
@@ -1280,7 +1337,22 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
     const double u = (d * b0 - (fresh ? 0.0 : g)) + xyc;
     const double tp = pfc * K.L;
     double bn;
-    if (K.kind == K_SOFT) bn = cdiv(shrink(u, tp), K.D, rD);
+    if (GRP && K.kind >= K_GRP) {                                   // (wave-uniform: the penalty is the state's)
+        const double uu = (K.kind == K_SGL) ? soft1(u, pfc * K.L1, 1.0) : u;
+        if (ch < 3) Ush[SPK_HC * wslot + l] = wok ? uu : 0.0;
+        __syncthreads();
+        double s2 = 0.0;
+        for (int m = gs; m < ge; ++m) { const double x = Ush[m - (c0 - SPK_HC)]; s2 += x * x; }      // member order (a run: ascending coordinates)
+        double fg = 1.0;
+        if (ge < gs) fg = 0.0;                                      // (in no group: its coefficient stays 0, as path_update has it)
+        else if (!gz) {
+            const double sn = sqrt(s2), pen_g = K.L * gwc;
+            if (K.kind == K_GRP || K.kind == K_SGL) { const double t = 1.0 - pen_g / sn; fg = (0.0 < t) ? t : 0.0; }      // (quirk Q6: 0 / 0 -> NaN -> 0)
+            else if (K.kind == K_GRP_MCP) fg = mcp_norm(sn, pen_g, K.D, K.gamma);
+            else fg = scad_norm(sn, pen_g, K.D, K.gamma);
+        }
+        bn = (fg != 0.0) ? cdiv(uu * fg, K.D, rD) : 0.0;
+    } else if (K.kind == K_SOFT) bn = cdiv(shrink(u, tp), K.D, rD);
     else if (K.kind == K_MCP) {
         const bool big = fabs(u) > gammad * tp;
         bn = cdiv(big ? u : shrink(u, tp), big ? K.D : dmg, big ? rD : rdmg);
@@ -1762,7 +1834,9 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     }
 
     // ---- element-wise penalties at every other q > 1024: (head, product) pairs over the packed triangle
-    if (spk && elementwise && spk_qpad / SPK_HC <= FMAXB && !sw().OEM_NO_FUSED.set) {
+    // (... and group operators whose groups are runs of <= 32 neighbouring coordinates, PathArgs::grp_head: the same pairs, sympk_head_kernel<true>)
+    const bool grp_head = a.grp_head && a.ngroups > 0 && !a.accelerate && !a.compute_loss && !a.sinv;
+    if (spk && (elementwise || grp_head) && spk_qpad / SPK_HC <= FMAXB && !sw().OEM_NO_FUSED.set) {
         spk_pack();
         int *flags = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad);
         SState *SS = reinterpret_cast<SState *>(spk_B + 2 * (size_t)spk_qpad + FMAXB);
@@ -1772,7 +1846,8 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         auto enq = [&](int count) {
             for (int k = 0; k < count; ++k) {
                 const int par = k & 1;
-                hipLaunchKernelGGL(sympk_head_kernel, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, a, SS, spk_B, spk_P, flags, fdone, par, d, spk_nb, spk_qpad, nz32);
+                if (grp_head) hipLaunchKernelGGL(sympk_head_kernel<true>, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, a, SS, spk_B, spk_P, flags, fdone, par, d, spk_nb, spk_qpad, nz32);
+                else hipLaunchKernelGGL(sympk_head_kernel<false>, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, a, SS, spk_B, spk_P, flags, fdone, par, d, spk_nb, spk_qpad, nz32);
                 hipLaunchKernelGGL(sympk_gemv_kernel, dim3(spk_nt), dim3(256), 0, s, a.sympk, q, spk_qpad, spk_B + (size_t)(par ^ 1) * spk_qpad, spk_P, fdone,
                                    (const int *)(nz32 + (size_t)(par ^ 1) * (spk_qpad / SPK_HC)));
             }

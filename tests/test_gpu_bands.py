@@ -83,6 +83,51 @@ def test_xtx_beyond_4096_runs_the_launch_engines(oa, p):
             _same_path(f, r, k, (p, "scale.factor", kw["penalty"][k]))
 
 
+@pytest.mark.parametrize("p,layout", [(4500, "runs"), (6145, "scattered"), (2500, "launches below 4096")])
+def test_group_operators_in_the_head_of_the_packed_triangle_pairs(oa, p, layout, monkeypatch):
+    """Launch engines on the packed triangle, group penalties whose groups have <= 32 members (PathArgs::grp_head, path_large.hip:
+    sympk_head_kernel<true>): the group operators run in the head of the (head, product) pairs -- every workgroup forms u of the 32
+    coordinates before its own, its own and the 32 behind them, and sums a group's squares in member order (ref src/oem_dense.h:193-315) --
+    instead of the product + slot sum + single-workgroup update kernel.  'runs': groups of 1 .. 32 neighbouring coordinates in a random
+    order of sizes (they straddle the workgroups' 32-coordinate blocks), group 0 unpenalised, weights, penalty factors, every group kind
+    with a lasso beside them; 'scattered': the same sizes dealt at random over the coordinates of an odd ragged q -- reordered into runs
+    first (api.hip: group_run_permutation, beyond 4096 where every group has <= 32 members); 'launches below 4096': what the register
+    engine's second attempt runs (OEM_NO_SYMCOOP=1).  Against the oracle; the same bits run to run; a group of 40 members takes the
+    update-kernel form and agrees with the oracle as well."""
+    import torch
+    rng = np.random.default_rng(900 + p)
+    xtx, xty = _gram_problem(p, p + p // 2, 5100 + p)
+    xd = torch.as_tensor(xtx, device="cuda")
+    sizes = []
+    while sum(sizes) < p:
+        sizes.append(int(rng.integers(1, 33)))
+    sizes[-1] -= sum(sizes) - p
+    groups = np.repeat(np.arange(len(sizes)), sizes)                  # label 0: unpenalised (ref src/oem_dense.h:207)
+    if layout == "scattered":
+        groups = rng.permutation(groups)
+    ug = np.unique(groups)
+    gw = rng.uniform(0.5, 2.0, len(ug))
+    pf = np.ones(p); pf[:3] = 0.0; pf[3:9] = 2.0
+    kw = dict(penalty=["grp.lasso", "lasso", "sparse.grp.lasso", "grp.mcp", "grp.scad.net"], groups=groups, group_weights=gw, penalty_factor=pf,
+              tau=0.4, gamma=3.5, alpha=0.8, nlambda=4, lambda_min_ratio=0.05, tol=1e-9, maxit=400)
+    if layout.startswith("launches"):
+        monkeypatch.setenv("OEM_NO_SYMCOOP", "1")
+    f = oa.oem_xtx(xd, xty, **kw)
+    assert oa.last_path_engine()[0] == "launches"
+    r = orc.fit_xtx(xtx, xty, native=True, unique_groups=ug, d_override=f["d"], **kw)
+    for k in range(len(kw["penalty"])):
+        _same_path(f, r, k, (p, layout, kw["penalty"][k]))
+        assert (np.asarray(f["beta"][k])[:, -1] != 0).sum() >= 5
+    f2 = oa.oem_xtx(xd, xty, **kw)
+    assert all(np.array_equal(np.asarray(f["beta"][k]), np.asarray(f2["beta"][k])) for k in range(len(kw["penalty"])))
+    if layout == "runs":
+        big = np.minimum(np.arange(p) // 40, p // 40 - 1) + 1        # groups of 40 (the last one larger): the update-kernel form
+        kwb = dict(penalty=["grp.lasso"], groups=big, nlambda=3, lambda_min_ratio=0.1, tol=1e-9, maxit=400)
+        fb = oa.oem_xtx(xd, xty, **kwb)
+        rb = orc.fit_xtx(xtx, xty, native=True, unique_groups=np.unique(big), d_override=fb["d"], **kwb)
+        _same_path(fb, rb, 0, (p, "groups of 40"))
+
+
 def test_xtx_beyond_4096_streams_the_packed_lower_triangle(oa, monkeypatch):
     """q > 4096 (round 6): every product is ONE sweep over a packed copy of the lower triangle of XX (path_large.hip: sympk_*, 4 q^2 bytes
     where the row-streaming kernel reads 8 q^2; ref src/oem_xtx.h:378-381, src/oem_dense.h:508-512).  q = 6,145: a ragged last block
