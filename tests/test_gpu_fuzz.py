@@ -581,7 +581,16 @@ def test_random_packed_triangle_engine(oa, seed):
     kw = dict(penalty=pens, nlambda=int(rng.integers(2, 5)), alpha=float(rng.uniform(0.3, 1.0)), gamma=float(rng.uniform(2.5, 5.0)),
               tol=float(10.0 ** rng.uniform(-9, -7)), maxit=int(rng.choice([60, 300])), penalty_factor=pf)
     if seed % 2:
-        kw["penalty"] = pens = pens[:1] + ["grp.lasso"]; kw["groups"] = rng.permutation(np.arange(p) // 6 + 1)
+        # a group penalty beside them: groups of <= hi members dealt at random over the coordinates.  hi <= 32: reordered into runs, the group
+        # operators in the head of the pairs (sympk_head_kernel<true>); hi = 50: as they are, on the update-kernel form
+        hi = int(rng.choice([6, 32, 50]))
+        sizes = []
+        while sum(sizes) < p:
+            sizes.append(int(rng.integers(1, hi + 1)))
+        sizes[-1] -= sum(sizes) - p
+        kw["penalty"] = pens = pens[:1] + list(rng.choice(GROUPED, int(rng.integers(1, 3)), replace=False))
+        kw["groups"] = rng.permutation(np.repeat(np.arange(len(sizes)), sizes))      # label 0: unpenalised
+        kw["group_weights"] = rng.uniform(0.5, 2.0, len(sizes)); kw["tau"] = float(rng.uniform(0.2, 0.8))
     import torch
     f = oa.oem_xtx(torch.as_tensor(xtx, device="cuda"), xty, **kw)
     assert oa.last_path_engine()[0] == "launches"
