@@ -418,7 +418,7 @@ struct PathPlan {
     size_t out_stride = 0, out_bytes = 0, nb = 0, nk = 0;
     Groups G;
     std::vector<int> cst, grs, grg, grw;
-    bool grp_head = false;                           // group operators in the head of the packed-triangle pairs (PathArgs::grp_head)
+    int grp_head = 0;                                // group operators in the head of the packed-triangle pairs (PathArgs::grp_head: 1 .. 3)
     std::vector<int> grun;                           // ... [2 q]
     std::vector<double> gwc;                         // ... [q]
     SymcoopPlan *symplan = nullptr;                  // (thread-local cache: a pure function of q, the CUs and the group runs)
@@ -586,18 +586,20 @@ static int plan_paths(const PlanIn &in, PathPlan &P)
     a.pen_split = P.pen_split; a.pen_lo = 0; a.pen_hi = npen;
     a.nbatch = nbatch;
 
-    // the launch engines at q > 1024 (the packed triangle): groups that are runs of <= 32 neighbouring coordinates, nothing that needs a sum over
+    // the launch engines at q > 1024 (the packed triangle): groups that are runs of <= 96 neighbouring coordinates, nothing that needs a sum over
     // all coordinates -- the group operators run in the head of the (head, product) pairs (path_large.hip), one launch fewer per iteration
     // and no single-workgroup update kernel (q = 8,192: 65 -> 52 us per iteration)
     if (!wide && any_grp && q > 1024 && nbatch == 1 && !a.accelerate && !a.compute_loss && !P.loss_post && !in.has_scale && (int)G.gidx.size() <= q) {
         bool ok = true;
+        int longest = 0;
         for (int g = 0; g < og.ngroups && ok; ++g) {
             const int m0 = G.gstart[g], len = G.gstart[g + 1] - m0;
-            ok = len <= 32;
+            ok = len <= 96;
+            if (len > longest) longest = len;
             for (int k = 0; k < len && ok; ++k) ok = G.gidx[m0 + k] == G.gidx[m0] + k && G.gid[G.gidx[m0 + k]] == g;
         }
         if (ok) {
-            P.grp_head = true;
+            P.grp_head = longest <= 32 ? 1 : (longest <= 64 ? 2 : 3);      // blocks of 32 coordinates on either side of a head workgroup's own
             P.grun.assign(2 * (size_t)q, 0); P.gwc.assign(q, 0.0);
             for (int j = 0; j < q; ++j) {
                 const int g = G.gid[j];
@@ -679,7 +681,7 @@ static std::vector<int> group_run_permutation(const oemgpu_opts *o, int q, int m
         for (int k = 1; k < len && runs; ++k) runs = G.gidx[G.gstart[g] + k] == G.gidx[G.gstart[g]] + k;
     }
     // (groups of more than 32 members: the register engine sums their norms over several owners, path_symcoop.hip -- max_len = q;
-    //  the launches' head form beyond 4096 takes runs of <= 32: max_len = 32, nothing to gain otherwise)
+    //  the launches' head form beyond 4096 takes runs of <= 96: max_len = 96, nothing to gain otherwise)
     if (runs || longest > max_len) return perm;
     perm.reserve(q);
     std::vector<char> done(o->ngroups, 0);
@@ -703,14 +705,14 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const bool launches_only = ex && ex->d_fixed > 0.0;
     const int nl = nl_of(o), npen = o->npen;
     const bool user = o->lambda_user && o->nlambda_user > 0;
-    // (beyond 4096 the same reordering where it buys the launches their head form -- every group <= 32 members, PathArgs::grp_head)
+    // (beyond 4096 the same reordering where it buys the launches their head form -- every group <= 96 members, PathArgs::grp_head)
     const bool perm_reg = q > 1024 && q <= 4096 && !sw().OEM_NO_SYMCOOP.set && !sw().OEM_NO_COOP.set && !sw().OEM_SYMCOOP_NO_GENERAL.set;
     const bool perm_large = q > 4096 && !o->accelerate && !o->compute_loss && !scale_factor && !sw().OEM_NO_SYM.set && !sw().OEM_NO_FUSED.set;
     if (!g_in_permuted_call && (perm_reg || perm_large) && nbatch == 1 && !wide && !ex && !lmax_xy_dev && xx && (sem == OEMGPU_SEM_DENSE || sem == SEM_XTX) &&
         o->ngroups > 0) {
         bool any_group_penalty = false;
         for (int k = 0; k < npen; ++k) any_group_penalty |= pen_is_grp(o->penalty[k]);
-        const std::vector<int> perm = any_group_penalty ? group_run_permutation(o, q, perm_reg ? q : 32) : std::vector<int>();
+        const std::vector<int> perm = any_group_penalty ? group_run_permutation(o, q, perm_reg ? q : 96) : std::vector<int>();
         if (!perm.empty()) {
             // the permuted problem in a buffer of its own (xx2 | xy2 | stats2 | perm), the options with their per-coordinate arrays permuted
             const size_t nd = (size_t)q * q + q + stats_len(p) + 8;
@@ -826,7 +828,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     a.sinv = scale_factor ? (const double *)(dblob + o_sinv) : nullptr;
     a.gid = (const int *)(dblob + o_gid); a.gstart = (const int *)(dblob + o_gst); a.gidx = (const int *)(dblob + o_gix);
     a.gzero = (const int *)(dblob + o_gz); a.gw = (const double *)(dblob + o_gw);
-    a.grp_head = P.grp_head ? 1 : 0;
+    a.grp_head = P.grp_head;
     a.grun = P.grp_head ? (const int *)(dblob + o_grun) : nullptr; a.gwc = P.grp_head ? (const double *)(dblob + o_gwc) : nullptr;
     a.beta = dout; a.lambda_out = dout + nb; a.loss = a.lambda_out + nk; a.d_out = a.loss + nk;
     double *dstats = a.d_out + D_OUT_LEN;

@@ -113,7 +113,7 @@ struct PathArgs {
     const int *gidx;         // members by group, increasing
     const double *gw;        // ngroups weights
     const int *gzero;        // ngroups: unique_groups[g] == 0
-    // grp_head (the launch engines on the packed triangle, path_large.hip: sympk_head_kernel<true>): every group is a run of <= 32
+    // grp_head = 1, 2, 3 (the launch engines on the packed triangle, path_large.hip: sympk_head_kernel<HB>): every group is a run of <= 32 HB
     // neighbouring coordinates and nothing needs a sum over all coordinates -- the group operators then run in the head of the (head, product)
     // pairs like the element-wise ones.  Per coordinate: grun[2 j] = its group's first coordinate, grun[2 j + 1] = one past its last |
     // (unique_groups[g] == 0) << 30 -- (1, 0): in no group --, gwc[j] = the group's weight

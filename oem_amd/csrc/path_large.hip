@@ -1249,24 +1249,29 @@ __global__ __launch_bounds__(256) void sympk_sum_kernel(const double *__restrict
 // Element-wise penalties: the slot sum IS the head of oem_symfused_kernel -- state, "still moving" words of the previous launch, the
 // replicated transition, the operator on the workgroup's 32 coordinates, beta_{t+1} into B[par ^ 1] (which the product kernel of
 // this iteration then reads), the workgroup's "still moving" word.  One (head, product) pair of launches per iteration.
-// GRP (PathArgs::grp_head: every group a run of <= 32 neighbouring coordinates, no Nesterov step, no loss, no scale.factor): the group operators
-// as well (ref src/oem_dense.h:193-315).  A group of one of the workgroup's coordinates lies inside the window of the 32 coordinates before
-// them, themselves and the 32 behind them: the workgroup forms u of the whole window (three slot sums instead of one -- the partial vectors
-// are 4 MB against the product's 270 -- threads (ch, l), ch = 0 / 1 / 2, take the coordinate l of the own / the lower / the upper block),
+// GRP (PathArgs::grp_head = HB: every group a run of <= 32 HB neighbouring coordinates, no Nesterov step, no loss, no scale.factor): the group
+// operators as well (ref src/oem_dense.h:193-315).  A group of one of the workgroup's coordinates lies inside the window of the 32 HB coordinates
+// before them, themselves and the 32 HB behind them: the workgroup forms u of the whole window (2 HB + 1 slot sums instead of one -- the partial
+// vectors are 4 MB against the product's 270 -- thread row ch takes coordinate l of one block of the window),
 // puts it through LDS and every own coordinate sums the squares of ITS group in member order.  A group that straddles two workgroups is summed by
 // both, from the same numbers in the same order.  Everything else -- state, flags, the blocks of zeros -- is the element-wise head's.
-template <bool GRP>
+// HB = 1, 2, 3 blocks of 32 coordinates on either side of the own one: groups of <= 32 HB members (HB = 0: the element-wise head).
+template <int HB>
 __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__restrict__ S, double *__restrict__ B, const double *__restrict__ P,
                                                           int *__restrict__ flags, int *__restrict__ fdone, int par, double d, int nblk, int qpad, int *__restrict__ nz32)
 {
-    __shared__ double sh[GRP ? 3 : 1][8][SPK_HC];
-    __shared__ double Ush[GRP ? 3 * SPK_HC : 1];
+    constexpr bool GRP = HB > 0;
+    constexpr int NWB = 2 * HB + 1;                                 // blocks of the window
+    static_assert(NWB <= 8, "one thread row (ch) per block of the window");
+    __shared__ double sh[NWB][8][SPK_HC];
+    __shared__ double Ush[NWB * SPK_HC];
     const int q = A.p, nl = A.nl, tid = threadIdx.x, l = tid & (SPK_HC - 1), ch = tid / SPK_HC, c0 = blockIdx.x * SPK_HC, cm = c0 + l;
     const bool own = ch == 0 && cm < q;
-    // the window coordinate of this thread (GRP; ch >= 3: none) -- or its own one
-    const int wslot = ch == 1 ? 0 : ch == 0 ? 1 : 2;                // block of the window: 0 lower, 1 own, 2 upper
-    const int cw = GRP ? c0 + SPK_HC * (wslot - 1) + l : cm;
-    const bool wok = GRP ? (ch < 3 && cw >= 0 && cw < q) : own;
+    // the window coordinate of this thread (GRP; ch >= NWB: none) -- or its own one.  Thread row 0 takes the own block (HB of the window),
+    // rows 1 .. HB the blocks below it, rows HB + 1 .. 2 HB those above
+    const int wslot = ch == 0 ? HB : (ch <= HB ? ch - 1 : ch);
+    const int cw = GRP ? c0 + SPK_HC * (wslot - HB) + l : cm;
+    const bool wok = GRP ? (ch < NWB && cw >= 0 && cw < q) : own;
     const SState st = S[par];
     const double *__restrict__ bin = B + (size_t)par * qpad;
     double *__restrict__ bout = B + (size_t)(par ^ 1) * qpad;
@@ -1285,13 +1290,13 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
     if constexpr (!GRP) g = spk_slot_sum(P, nblk, qpad, cm, ch, sh[0], l);
     else {
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            int cb = c0 + SPK_HC * (b - 1) + l;
+        for (int b = 0; b < NWB; ++b) {
+            int cb = c0 + SPK_HC * (b - HB) + l;
             cb = cb < 0 ? 0 : (cb < qpad ? cb : qpad - 1);          // (beyond the vector: read somewhere, never used)
             sh[b][ch][l] = spk_chunk_sum(P, nblk, qpad, cb, ch);
         }
         __syncthreads();
-        g = spk_chunk_tree(sh[wslot], l);
+        g = spk_chunk_tree(sh[wslot < NWB ? wslot : 0], l);
     }
     if (st.done) {                                                  // the launch after the last one: make both copies agree
         if (blockIdx.x == 0 && tid == 0) { S[par ^ 1].done = 1; *fdone = 1; }
@@ -1339,10 +1344,10 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
     double bn;
     if (GRP && K.kind >= K_GRP) {                                   // (wave-uniform: the penalty is the state's)
         const double uu = (K.kind == K_SGL) ? soft1(u, pfc * K.L1, 1.0) : u;
-        if (ch < 3) Ush[SPK_HC * wslot + l] = wok ? uu : 0.0;
+        if (ch < NWB) Ush[SPK_HC * wslot + l] = wok ? uu : 0.0;
         __syncthreads();
         double s2 = 0.0;
-        for (int m = gs; m < ge; ++m) { const double x = Ush[m - (c0 - SPK_HC)]; s2 += x * x; }      // member order (a run: ascending coordinates)
+        for (int m = gs; m < ge; ++m) { const double x = Ush[m - (c0 - SPK_HC * HB)]; s2 += x * x; }      // member order (a run: ascending coordinates)
         double fg = 1.0;
         if (ge < gs) fg = 0.0;                                      // (in no group: its coefficient stays 0, as path_update has it)
         else if (!gz) {
@@ -1835,7 +1840,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
 
     // ---- element-wise penalties at every other q > 1024: (head, product) pairs over the packed triangle
     // (... and group operators whose groups are runs of <= 32 neighbouring coordinates, PathArgs::grp_head: the same pairs, sympk_head_kernel<true>)
-    const bool grp_head = a.grp_head && a.ngroups > 0 && !a.accelerate && !a.compute_loss && !a.sinv;
+    const bool grp_head = a.grp_head > 0 && a.grp_head <= 3 && a.ngroups > 0 && !a.accelerate && !a.compute_loss && !a.sinv;
     if (spk && (elementwise || grp_head) && spk_qpad / SPK_HC <= FMAXB && !sw().OEM_NO_FUSED.set) {
         spk_pack();
         int *flags = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad);
@@ -1846,8 +1851,9 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
         auto enq = [&](int count) {
             for (int k = 0; k < count; ++k) {
                 const int par = k & 1;
-                if (grp_head) hipLaunchKernelGGL(sympk_head_kernel<true>, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, a, SS, spk_B, spk_P, flags, fdone, par, d, spk_nb, spk_qpad, nz32);
-                else hipLaunchKernelGGL(sympk_head_kernel<false>, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, a, SS, spk_B, spk_P, flags, fdone, par, d, spk_nb, spk_qpad, nz32);
+                void (*hk)(PathArgs, SState *, double *, const double *, int *, int *, int, double, int, int, int *) =
+                    !grp_head ? sympk_head_kernel<0> : a.grp_head == 1 ? sympk_head_kernel<1> : a.grp_head == 2 ? sympk_head_kernel<2> : sympk_head_kernel<3>;
+                hipLaunchKernelGGL(hk, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, a, SS, spk_B, spk_P, flags, fdone, par, d, spk_nb, spk_qpad, nz32);
                 hipLaunchKernelGGL(sympk_gemv_kernel, dim3(spk_nt), dim3(256), 0, s, a.sympk, q, spk_qpad, spk_B + (size_t)(par ^ 1) * spk_qpad, spk_P, fdone,
                                    (const int *)(nz32 + (size_t)(par ^ 1) * (spk_qpad / SPK_HC)));
             }

@@ -92,8 +92,8 @@ def test_group_operators_in_the_head_of_the_packed_triangle_pairs(oa, p, layout,
     order of sizes (they straddle the workgroups' 32-coordinate blocks), group 0 unpenalised, weights, penalty factors, every group kind
     with a lasso beside them; 'scattered': the same sizes dealt at random over the coordinates of an odd ragged q -- reordered into runs
     first (api.hip: group_run_permutation, beyond 4096 where every group has <= 32 members); 'launches below 4096': what the register
-    engine's second attempt runs (OEM_NO_SYMCOOP=1).  Against the oracle; the same bits run to run; a group of 40 members takes the
-    update-kernel form and agrees with the oracle as well."""
+    engine's second attempt runs (OEM_NO_SYMCOOP=1).  Against the oracle; the same bits run to run; groups of 40 and (scattered) 90 members on
+    the wider windows, groups of 120 on the update-kernel form."""
     import torch
     rng = np.random.default_rng(900 + p)
     xtx, xty = _gram_problem(p, p + p // 2, 5100 + p)
@@ -121,11 +121,15 @@ def test_group_operators_in_the_head_of_the_packed_triangle_pairs(oa, p, layout,
     f2 = oa.oem_xtx(xd, xty, **kw)
     assert all(np.array_equal(np.asarray(f["beta"][k]), np.asarray(f2["beta"][k])) for k in range(len(kw["penalty"])))
     if layout == "runs":
-        big = np.minimum(np.arange(p) // 40, p // 40 - 1) + 1        # groups of 40 (the last one larger): the update-kernel form
-        kwb = dict(penalty=["grp.lasso"], groups=big, nlambda=3, lambda_min_ratio=0.1, tol=1e-9, maxit=400)
-        fb = oa.oem_xtx(xd, xty, **kwb)
-        rb = orc.fit_xtx(xtx, xty, native=True, unique_groups=np.unique(big), d_override=fb["d"], **kwb)
-        _same_path(fb, rb, 0, (p, "groups of 40"))
+        # larger groups: <= 64 / <= 96 members widen the window to two / three blocks on either side (sympk_head_kernel<2>, <3>); 120: the update-kernel form
+        for size in (40, 90, 120):
+            big = rng.permutation(np.arange(p) // size + 1) if size == 90 else np.arange(p) // size + 1
+            kwb = dict(penalty=["grp.lasso", "grp.scad"], groups=big, nlambda=3, lambda_min_ratio=0.1, tol=1e-9, maxit=400)
+            fb = oa.oem_xtx(xd, xty, **kwb)
+            assert oa.last_path_engine()[0] == "launches"
+            rb = orc.fit_xtx(xtx, xty, native=True, unique_groups=np.unique(big), d_override=fb["d"], **kwb)
+            for k in range(2):
+                _same_path(fb, rb, k, (p, "groups of %d" % size, kwb["penalty"][k]))
 
 
 def test_xtx_beyond_4096_streams_the_packed_lower_triangle(oa, monkeypatch):

@@ -582,8 +582,8 @@ def test_random_packed_triangle_engine(oa, seed):
               tol=float(10.0 ** rng.uniform(-9, -7)), maxit=int(rng.choice([60, 300])), penalty_factor=pf)
     if seed % 2:
         # a group penalty beside them: groups of <= hi members dealt at random over the coordinates.  hi <= 32: reordered into runs, the group
-        # operators in the head of the pairs (sympk_head_kernel<true>); hi = 50: as they are, on the update-kernel form
-        hi = int(rng.choice([6, 32, 50]))
+        # operators in the head of the pairs (sympk_head_kernel<1>); 50, 96: the wider windows (<2>, <3>); 130: as they are, on the update-kernel form
+        hi = int(rng.choice([6, 32, 50, 96, 130]))
         sizes = []
         while sum(sizes) < p:
             sizes.append(int(rng.integers(1, hi + 1)))
