@@ -707,7 +707,8 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     const bool user = o->lambda_user && o->nlambda_user > 0;
     // (beyond 4096 the same reordering where it buys the launches their head form -- every group <= 96 members, PathArgs::grp_head)
     const bool perm_reg = q > 1024 && q <= 4096 && !sw().OEM_NO_SYMCOOP.set && !sw().OEM_NO_COOP.set && !sw().OEM_SYMCOOP_NO_GENERAL.set;
-    const bool perm_large = q > 4096 && !o->accelerate && !o->compute_loss && !scale_factor && !sw().OEM_NO_SYM.set && !sw().OEM_NO_FUSED.set;
+    // (... and below 4096 when the register engine is switched off: the launches are what runs)
+    const bool perm_large = q > 1024 && !perm_reg && !o->accelerate && !o->compute_loss && !scale_factor && !sw().OEM_NO_SYM.set && !sw().OEM_NO_FUSED.set;
     if (!g_in_permuted_call && (perm_reg || perm_large) && nbatch == 1 && !wide && !ex && !lmax_xy_dev && xx && (sem == OEMGPU_SEM_DENSE || sem == SEM_XTX) &&
         o->ngroups > 0) {
         bool any_group_penalty = false;
