@@ -515,7 +515,7 @@ def test_groups_larger_than_an_owners_slice_stay_on_the_register_resident_engine
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("p", [1100, 2048, 3500, 4096])
+@pytest.mark.parametrize("p", [1100, 3500, 4096])          # (2048: the one-exchange engine's boundary has tests of its own; 16 s of engine-against-engine here)
 def test_register_resident_engine_general_form(oa, p, monkeypatch):
     """the same engine with what needs more than a coordinate of its own (path_symcoop_kernel<NT, GEN = true>): group operators --
     the owners' slices cut at group boundaries, every group a run of <= 32 neighbouring coordinates (ragged runs of 1-12, ids in no
