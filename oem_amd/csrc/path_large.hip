@@ -1256,9 +1256,18 @@ __global__ __launch_bounds__(256) void sympk_sum_kernel(const double *__restrict
 // puts it through LDS and every own coordinate sums the squares of ITS group in member order.  A group that straddles two workgroups is summed by
 // both, from the same numbers in the same order.  Everything else -- state, flags, the blocks of zeros -- is the element-wise head's.
 // HB = 1, 2, 3 blocks of 32 coordinates on either side of the own one: groups of <= 32 HB members (HB = 0: the element-wise head).
-template <int HB>
+// GEN (gen != null): the two options that need a sum over ALL coordinates, with the sum taken one launch later like the stop rule --
+//   Nesterov's step (ref src/oem_dense.h:529, 633-651): every workgroup leaves its part of the restart test sum_j (beta_j - T(u)_j)(T(u)_j - beta_prev_j)
+//       in gen[parity][workgroup]; the next head adds the parts in workgroup order (every workgroup the same sum) and so knows the sequence's
+//       member of ITS iteration -- exactly when it needs it; the candidate successor travels in gen's state words;
+//   compute.loss (ref :759-770, Gram identity): when a lambda ends, g = XX beta of the finished iterate is in hand -- the workgroups' parts of
+//       beta'(g - 2 XY) go to gen, the NEXT head's workgroup 0 adds them and writes the loss (the launch behind the last one as well: the done word
+//       is then raised by that launch).
+// gen: [2][FMAXB] restart parts | [2][FMAXB] loss parts | [2][4] state words {akn, index of the pending loss or -1}
+template <int HB, bool GEN>
 __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__restrict__ S, double *__restrict__ B, const double *__restrict__ P,
-                                                          int *__restrict__ flags, int *__restrict__ fdone, int par, double d, int nblk, int qpad, int *__restrict__ nz32)
+                                                          int *__restrict__ flags, int *__restrict__ fdone, int par, double d, int nblk, int qpad, int *__restrict__ nz32,
+                                                          double *__restrict__ gen)
 {
     constexpr bool GRP = HB > 0;
     constexpr int NWB = 2 * HB + 1;                                 // blocks of the window
@@ -1279,6 +1288,18 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
 #pragma unroll
     for (int k = 0; k < FMAXB / 256; ++k) { const int t = tid + 256 * k; fl[k] = flags[par * FMAXB + (t < (int)gridDim.x ? t : 0)]; }
     const double bo = wok ? bin[cw] : 0.0, xyc = wok ? A.xy[cw] : 0.0, pfc = wok ? A.pf[cw] : 0.0;
+    // GEN: the parts of the previous launch (restart test, loss) and its state words, asked for with everything else
+    __shared__ double gsh[8];
+    double ap[FMAXB / 256], lp[FMAXB / 256], akn_prev = 1.0;
+    int loss_k = -1;
+    if constexpr (GEN) {
+#pragma unroll
+        for (int k = 0; k < FMAXB / 256; ++k) {
+            const int t = tid + 256 * k, tc = t < (int)gridDim.x ? t : 0;
+            ap[k] = gen[(size_t)par * FMAXB + tc]; lp[k] = gen[(size_t)(2 + par) * FMAXB + tc];
+        }
+        akn_prev = gen[4 * FMAXB + 4 * par]; loss_k = (int)gen[4 * FMAXB + 4 * par + 1];
+    }
     int gs = 1, ge = 0;
     bool gz = false;
     double gwc = 0.0;
@@ -1298,9 +1319,28 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
         __syncthreads();
         g = spk_chunk_tree(sh[wslot < NWB ? wslot : 0], l);
     }
+    // GEN: the loss of the lambda that ended in the previous launch (workgroup 0: the parts in workgroup order)
+    double atot = 0.0;
+    if constexpr (GEN) {
+        if (A.compute_loss && loss_k >= 0 && blockIdx.x == 0) {     // (uniform in the workgroup)
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < FMAXB / 256; ++k) t += (tid + 256 * k < (int)gridDim.x) ? lp[k] : 0.0;
+            t = block_sum(t, gsh);
+            if (tid == 0) A.loss[loss_k] = A.stats[2] + A.stats[3] * t;
+        }
+    }
     if (st.done) {                                                  // the launch after the last one: make both copies agree
-        if (blockIdx.x == 0 && tid == 0) { S[par ^ 1].done = 1; *fdone = 1; }
+        if (blockIdx.x == 0 && tid == 0) { S[par ^ 1].done = 1; *fdone = 1; if (GEN) gen[4 * FMAXB + 4 * (par ^ 1) + 1] = -1.0; }
         return;
+    }
+    if constexpr (GEN) {
+        if (A.accelerate) {                                         // the restart test of the previous iteration: every workgroup the same sum
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < FMAXB / 256; ++k) t += (tid + 256 * k < (int)gridDim.x) ? ap[k] : 0.0;
+            atot = block_sum(t, gsh);
+        }
     }
     int f = 0;
 #pragma unroll
@@ -1328,11 +1368,20 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
         nx.pp = pp; nx.i = i; nx.it = it + 1; nx.done = done_now ? 1 : 0; nx.fresh = 0; nx.pen = pen; nx.lam = lam;
         if (advanced) sym_successor(A, pp, i, pen, nx.pen_next, nx.lam_next);
         S[par ^ 1] = nx;
-        if (finalize) { A.niter[kfin] = niter_fin; A.loss[kfin] = 1e99; }
+        if (finalize) { A.niter[kfin] = niter_fin; if (!(GEN && A.compute_loss)) A.loss[kfin] = 1e99; }
     }
     if (finalize && own) A.beta[kfin * q + cm] = bo;
+    const bool want_loss = GEN && A.compute_loss != 0;
+    if constexpr (GEN) {
+        if (want_loss && finalize) {                                // (uniform) this workgroup's part of beta'(XX beta - 2 XY) of the finished iterate: g IS XX beta
+            const double lt = block_sum(own ? bo * (g - 2.0 * xyc) : 0.0, gsh);
+            if (tid == 0) gen[(size_t)(2 + (par ^ 1)) * FMAXB + blockIdx.x] = lt;
+        }
+        if (blockIdx.x == 0 && tid == 0) gen[4 * FMAXB + 4 * (par ^ 1) + 1] = (want_loss && finalize) ? (double)kfin : -1.0;
+    }
     if (done_now) {
-        if (blockIdx.x == 0 && tid == 0) *fdone = 1;                // (the products behind this launch return at once)
+        // (the products behind this launch return at once; a pending loss is written by the NEXT head, which then raises the word)
+        if (blockIdx.x == 0 && tid == 0 && !want_loss) *fdone = 1;
         return;
     }
     const PenK K = pen_consts(pen, lam / st.scaley, d, A.alpha, A.gamma, A.tau);
@@ -1367,6 +1416,16 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
         const double num = big ? u : (mid ? shrink(gm1 * u, K.gamma * tp) : shrink(u, tp));
         bn = cdiv(num, mid ? dsc : K.D, mid ? rdsc : rD);
     } else bn = cdiv(u, d, rd);
+    if constexpr (GEN) {
+        if (A.accelerate) {                                         // ref src/oem_dense.h:633-651 (the sequence restarts at a penalty's cold start, not between lambdas)
+            const double ak = fresh ? 1.0 : (atot > 0.0 ? 1.0 : akn_prev);
+            const double akn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * ak * ak)), ratio = (ak - 1.0) / akn;
+            const double upd = bn, diff = upd - b0;
+            bn = upd + ratio * diff;
+            const double at = block_sum(own ? (bn - upd) * diff : 0.0, gsh);
+            if (tid == 0) { gen[(size_t)(par ^ 1) * FMAXB + blockIdx.x] = at; if (blockIdx.x == 0) gen[4 * FMAXB + 4 * (par ^ 1)] = akn; }
+        }
+    }
     const double c = fabs(bn), qo = fabs(b0);
     const bool cn = c > 1e-13, qn = qo > 1e-13;
     const bool moving = own && ((cn != qn) || (cn && qn && fabs(bn - b0) > A.tol * qo));
@@ -1405,7 +1464,8 @@ size_t sympk_doubles(int q)
     if (q <= 1024) return 0;
     const size_t nblk = (size_t)spk_nblk(q), qpad = nblk * SYM_TB;
     // blocks | partial vectors P[NBLK][qpad] | B[2][qpad] | flags[2][FMAXB] ints | SState[2] | done word | nz32[2][qpad / 32] ints
-    return spk_ntile(q) * SPK_TILE + nblk * qpad + 2 * qpad + FMAXB + 16 + 8 + qpad / 32 + 8;
+    // ... | gen: the head's parts of the sums over all coordinates [4][FMAXB] + its state words [2][4] (sympk_head_kernel<.., true>)
+    return spk_ntile(q) * SPK_TILE + nblk * qpad + 2 * qpad + FMAXB + 16 + 8 + qpad / 32 + 8 + 4 * FMAXB + 16;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1735,7 +1795,7 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     bool spk_packed = false;
     auto spk_pack = [&]() {                               // before the first product (never inside a graph capture)
         if (spk_packed) return;
-        (void)hipMemsetAsync(spk_B, 0, sizeof(double) * (2 * (size_t)spk_qpad + FMAXB + 16 + 8 + spk_qpad / 32 + 8), s);
+        (void)hipMemsetAsync(spk_B, 0, sizeof(double) * (2 * (size_t)spk_qpad + FMAXB + 16 + 8 + spk_qpad / 32 + 8 + 4 * FMAXB + 16), s);
         hipLaunchKernelGGL(sympk_pack_kernel, dim3(spk_nt), dim3(256), 0, s, a.xx, q, a.sympk);
         spk_packed = true;
     };
@@ -1840,20 +1900,25 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
 
     // ---- element-wise penalties at every other q > 1024: (head, product) pairs over the packed triangle
     // (... and group operators whose groups are runs of <= 32 neighbouring coordinates, PathArgs::grp_head: the same pairs, sympk_head_kernel<true>)
-    const bool grp_head = a.grp_head > 0 && a.grp_head <= 3 && a.ngroups > 0 && !a.accelerate && !a.compute_loss && !a.sinv;
-    if (spk && (elementwise || grp_head) && spk_qpad / SPK_HC <= FMAXB && !sw().OEM_NO_FUSED.set) {
+    // (... and Nesterov's step / compute.loss: their sums over all coordinates are taken one launch later, sympk_head_kernel<.., true>)
+    const bool grp_head = a.grp_head > 0 && a.grp_head <= 3 && a.ngroups > 0 && !a.sinv;
+    const bool head_gen = a.accelerate || a.compute_loss;
+    if (spk && !a.sinv && (a.ngroups == 0 || grp_head) && spk_qpad / SPK_HC <= FMAXB && !sw().OEM_NO_FUSED.set) {
         spk_pack();
         int *flags = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad);
         SState *SS = reinterpret_cast<SState *>(spk_B + 2 * (size_t)spk_qpad + FMAXB);
         int *fdone = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad + FMAXB + 16);
         int *nz32 = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad + FMAXB + 16 + 8);      // [2][qpad / 32]: which 32-coordinate pieces of B[parity] hold a non-zero
+        double *gen = spk_B + 2 * (size_t)spk_qpad + FMAXB + 16 + 8 + spk_qpad / 32 + 8;          // the head's parts of the sums over all coordinates (zeroed with B)
         hipLaunchKernelGGL(sym_init_kernel, dim3(1), dim3(1), 0, s, SS, a);
         auto enq = [&](int count) {
             for (int k = 0; k < count; ++k) {
                 const int par = k & 1;
-                void (*hk)(PathArgs, SState *, double *, const double *, int *, int *, int, double, int, int, int *) =
-                    !grp_head ? sympk_head_kernel<0> : a.grp_head == 1 ? sympk_head_kernel<1> : a.grp_head == 2 ? sympk_head_kernel<2> : sympk_head_kernel<3>;
-                hipLaunchKernelGGL(hk, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, a, SS, spk_B, spk_P, flags, fdone, par, d, spk_nb, spk_qpad, nz32);
+                const int hb = grp_head ? a.grp_head : 0;
+                void (*hk)(PathArgs, SState *, double *, const double *, int *, int *, int, double, int, int, int *, double *) =
+                    head_gen ? (hb == 0 ? sympk_head_kernel<0, true> : hb == 1 ? sympk_head_kernel<1, true> : hb == 2 ? sympk_head_kernel<2, true> : sympk_head_kernel<3, true>)
+                             : (hb == 0 ? sympk_head_kernel<0, false> : hb == 1 ? sympk_head_kernel<1, false> : hb == 2 ? sympk_head_kernel<2, false> : sympk_head_kernel<3, false>);
+                hipLaunchKernelGGL(hk, dim3(spk_qpad / SPK_HC), dim3(256), 0, s, a, SS, spk_B, spk_P, flags, fdone, par, d, spk_nb, spk_qpad, nz32, head_gen ? gen : (double *)nullptr);
                 hipLaunchKernelGGL(sympk_gemv_kernel, dim3(spk_nt), dim3(256), 0, s, a.sympk, q, spk_qpad, spk_B + (size_t)(par ^ 1) * spk_qpad, spk_P, fdone,
                                    (const int *)(nz32 + (size_t)(par ^ 1) * (spk_qpad / SPK_HC)));
             }
