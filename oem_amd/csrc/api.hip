@@ -586,10 +586,10 @@ static int plan_paths(const PlanIn &in, PathPlan &P)
     a.pen_split = P.pen_split; a.pen_lo = 0; a.pen_hi = npen;
     a.nbatch = nbatch;
 
-    // the launch engines at q > 1024 (the packed triangle): groups that are runs of <= 96 neighbouring coordinates, no scale.factor
+    // the launch engines at q > 1024 (the packed triangle): groups that are runs of <= 96 neighbouring coordinates
     // -- the group operators run in the head of the (head, product) pairs (path_large.hip), one launch fewer per iteration
     // and no single-workgroup update kernel (q = 8,192: 65 -> 52 us per iteration)
-    if (!wide && any_grp && q > 1024 && nbatch == 1 && !P.loss_post && !in.has_scale && (int)G.gidx.size() <= q) {
+    if (!wide && any_grp && q > 1024 && nbatch == 1 && (int)G.gidx.size() <= q) {
         bool ok = true;
         int longest = 0;
         for (int g = 0; g < og.ngroups && ok; ++g) {
@@ -708,7 +708,7 @@ int run_paths(oemgpu_ctx *c, Bump &B, const double *xx, const double *xy, const 
     // (beyond 4096 the same reordering where it buys the launches their head form -- every group <= 96 members, PathArgs::grp_head)
     const bool perm_reg = q > 1024 && q <= 4096 && !sw().OEM_NO_SYMCOOP.set && !sw().OEM_NO_COOP.set && !sw().OEM_SYMCOOP_NO_GENERAL.set;
     // (... and below 4096 when the register engine is switched off: the launches are what runs)
-    const bool perm_large = q > 1024 && !perm_reg && !scale_factor && !sw().OEM_NO_SYM.set && !sw().OEM_NO_FUSED.set;
+    const bool perm_large = q > 1024 && !perm_reg && !sw().OEM_NO_SYM.set && !sw().OEM_NO_FUSED.set;
     if (!g_in_permuted_call && (perm_reg || perm_large) && nbatch == 1 && !wide && !ex && !lmax_xy_dev && xx && (sem == OEMGPU_SEM_DENSE || sem == SEM_XTX) &&
         o->ngroups > 0) {
         bool any_group_penalty = false;

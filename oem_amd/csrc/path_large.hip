@@ -1288,6 +1288,7 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
 #pragma unroll
     for (int k = 0; k < FMAXB / 256; ++k) { const int t = tid + 256 * k; fl[k] = flags[par * FMAXB + (t < (int)gridDim.x ? t : 0)]; }
     const double bo = wok ? bin[cw] : 0.0, xyc = wok ? A.xy[cw] : 0.0, pfc = wok ? A.pf[cw] : 0.0;
+    const double sinvc = (A.sinv && own) ? A.sinv[cm] : 1.0;      // oem.xtx's scale.factor: the iterate is rescaled IN PLACE when a lambda ends (ref src/oem_xtx.h:576-581, quirk Q5)
     // GEN: the parts of the previous launch (restart test, loss) and its state words, asked for with everything else
     __shared__ double gsh[8];
     double ap[FMAXB / 256], lp[FMAXB / 256], akn_prev = 1.0;
@@ -1363,14 +1364,17 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
             it = 0;
         }
     }
+    // scale.factor: the next lambda starts from beta / s, whose product is not the one in hand -- this launch publishes the rescaled iterate
+    // (no operator, not an iteration, marked "moving" so that nobody takes the round for a converged one) and the path goes on from there
+    const bool resc = A.sinv != nullptr && finalize && !done_now && !fresh;
     if (blockIdx.x == 0 && tid == 0) {
         SState nx = st;
-        nx.pp = pp; nx.i = i; nx.it = it + 1; nx.done = done_now ? 1 : 0; nx.fresh = 0; nx.pen = pen; nx.lam = lam;
+        nx.pp = pp; nx.i = i; nx.it = resc ? 0 : it + 1; nx.done = done_now ? 1 : 0; nx.fresh = 0; nx.pen = pen; nx.lam = lam;
         if (advanced) sym_successor(A, pp, i, pen, nx.pen_next, nx.lam_next);
         S[par ^ 1] = nx;
         if (finalize) { A.niter[kfin] = niter_fin; if (!(GEN && A.compute_loss)) A.loss[kfin] = 1e99; }
     }
-    if (finalize && own) A.beta[kfin * q + cm] = bo;
+    if (finalize && own) A.beta[kfin * q + cm] = bo * sinvc;
     const bool want_loss = GEN && A.compute_loss != 0;
     if constexpr (GEN) {
         if (want_loss && finalize) {                                // (uniform) this workgroup's part of beta'(XX beta - 2 XY) of the finished iterate: g IS XX beta
@@ -1426,9 +1430,10 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
             if (tid == 0) { gen[(size_t)(par ^ 1) * FMAXB + blockIdx.x] = at; if (blockIdx.x == 0) gen[4 * FMAXB + 4 * (par ^ 1)] = akn; }
         }
     }
+    if (resc) bn = bo * sinvc;
     const double c = fabs(bn), qo = fabs(b0);
     const bool cn = c > 1e-13, qn = qo > 1e-13;
-    const bool moving = own && ((cn != qn) || (cn && qn && fabs(bn - b0) > A.tol * qo));
+    const bool moving = own && (resc || (cn != qn) || (cn && qn && fabs(bn - b0) > A.tol * qo));
     if (own) bout[cm] = bn;
     const unsigned long long nzb = __ballot(own && bn != 0.0);       // (wave 0 holds this workgroup's 32 coordinates)
     const int mv = __syncthreads_or(moving ? 1 : 0);
@@ -1901,9 +1906,9 @@ int run_path_large(hipStream_t s, const PathArgs &a, double *host_scratch)
     // ---- element-wise penalties at every other q > 1024: (head, product) pairs over the packed triangle
     // (... and group operators whose groups are runs of <= 32 neighbouring coordinates, PathArgs::grp_head: the same pairs, sympk_head_kernel<true>)
     // (... and Nesterov's step / compute.loss: their sums over all coordinates are taken one launch later, sympk_head_kernel<.., true>)
-    const bool grp_head = a.grp_head > 0 && a.grp_head <= 3 && a.ngroups > 0 && !a.sinv;
+    const bool grp_head = a.grp_head > 0 && a.grp_head <= 3 && a.ngroups > 0;
     const bool head_gen = a.accelerate || a.compute_loss;
-    if (spk && !a.sinv && (a.ngroups == 0 || grp_head) && spk_qpad / SPK_HC <= FMAXB && !sw().OEM_NO_FUSED.set) {
+    if (spk && (a.ngroups == 0 || grp_head) && spk_qpad / SPK_HC <= FMAXB && !sw().OEM_NO_FUSED.set) {
         spk_pack();
         int *flags = reinterpret_cast<int *>(spk_B + 2 * (size_t)spk_qpad);
         SState *SS = reinterpret_cast<SState *>(spk_B + 2 * (size_t)spk_qpad + FMAXB);
