@@ -135,8 +135,9 @@ def test_group_operators_in_the_head_of_the_packed_triangle_pairs(oa, p, layout,
 def test_xtx_beyond_4096_streams_the_packed_lower_triangle(oa, monkeypatch):
     """q > 4096 (round 6): every product is ONE sweep over a packed copy of the lower triangle of XX (path_large.hip: sympk_*, 4 q^2 bytes
     where the row-streaming kernel reads 8 q^2; ref src/oem_xtx.h:378-381, src/oem_dense.h:508-512).  q = 6,145: a ragged last block
-    and rows that are only 8-byte aligned (q odd).  Element-wise penalties take the (head, product) pairs; lasso + grp.lasso in the
-    parametrised test above the product + slot sum + update kernel form.  Against the oracle, run to run (fixed summation order:
+    and rows that are only 8-byte aligned (q odd).  Element-wise penalties take the (head, product) pairs, and so do lasso + grp.lasso in the
+    parametrised test above (group operators in the head; groups of more than 96 members: the product + slot sum + update kernel form, see
+    test_group_operators_in_the_head_of_the_packed_triangle_pairs).  Against the oracle, run to run (fixed summation order:
     the same bits), and against the row-streaming kernels (OEM_NO_SYM=1) on the same problem."""
     import torch
     p = 6145
@@ -158,7 +159,7 @@ def test_xtx_beyond_4096_streams_the_packed_lower_triangle(oa, monkeypatch):
     assert abs(h["d"] - f["d"]) <= 1e-13 * f["d"]
     for k in range(4):
         _same_path(f, h, k, ("row-streaming", kw["penalty"][k]), tol=1e-12)
-    # the three-launch form (the whole of u in one place: here `scale.factor`) at the same ragged size
+    # `scale.factor` (the rescale round in the head of the pairs) at the same ragged size
     sf = np.linspace(0.5, 2.0, p)
     kw2 = dict(penalty=["lasso"], nlambda=3, lambda_min_ratio=0.1, tol=1e-9, maxit=400, scale_factor=sf)
     f2 = oa.oem_xtx(xd, xty, **kw2)

@@ -567,7 +567,7 @@ def test_random_wide_resident_in_the_accumulator_file(oa, seed, monkeypatch):
 def test_random_packed_triangle_engine(oa, seed):
     """oem.xtx at a random 4096 < p <= 4500 (the first sizes beyond the register engines: a ragged last block, odd sizes with rows that are
     only 8-byte aligned) on the packed lower triangle (path_large.hip: sympk_*): random element-wise penalty mixes -- the (head, product)
-    pairs -- or a group penalty in the call -- product, slot sum, update kernel --, penalty factors and maxit, against the oracle
+    pairs -- or group penalties in the call -- their operators in the same head, or product, slot sum, update kernel for large groups --, penalty factors and maxit, against the oracle
     (d handed over, as in the config-4 tests: the comparison is the path's)"""
     from scipy.sparse.linalg import eigsh
     rng = np.random.default_rng(9900 + seed)
