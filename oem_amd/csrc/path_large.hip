@@ -1093,9 +1093,10 @@ __global__ __launch_bounds__(256, OEM_SYM_MINWG) void oem_symfused_kernel(PathAr
 // (the ragged last block row / column is zero-filled by the pack, which also takes rows that are only 8-byte aligned: q odd).
 // The arithmetic of a block is oem_symfused_kernel's (both products from one read, fixed summation order, partial vectors by slot);
 // the slots are summed by a kernel of its own -- a workgroup's head would re-read as many bytes of partials as its block has at
-// NBLK = 64 -- which for element-wise penalties is also the operator, the stop rule's "still moving" words and the replicated
-// lambda / penalty bookkeeping (sympk_head_kernel: oem_symfused_kernel's head, 32 coordinates per workgroup); everything else gets
-// g = XX beta from sympk_sum_kernel and runs path_update_kernel / lanczos_update_kernel unchanged.
+// NBLK = 64 -- which is also the operator, the stop rule's "still moving" words and the replicated lambda / penalty bookkeeping
+// (sympk_head_kernel: oem_symfused_kernel's head, 32 coordinates per workgroup -- element-wise operators, group operators whose groups
+// have <= 96 members, Nesterov's step, compute.loss, scale.factor); groups of more than 96 members and the Lanczos steps get
+// g = XX beta from sympk_sum_kernel and run path_update_kernel / lanczos_update_kernel unchanged.
 // bytes per product: 4 q^2 + 512 q read + 8 q NBLK written and read again (q = 8,192: 272.6 + 4.2 + 4.2 MB).
 // ------------------------------------------------------------------------------------------------
 static const int SPK_TILE = SYM_TB * SYM_TB;             // doubles of a packed block (128 KiB)
