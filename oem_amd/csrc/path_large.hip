@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(256) void sympk_sum_kernel(const double *__restrict
 //   compute.loss (ref :759-770, Gram identity): when a lambda ends, g = XX beta of the finished iterate is in hand -- the workgroups' parts of
 //       beta'(g - 2 XY) go to gen, the NEXT head's workgroup 0 adds them and writes the loss (the launch behind the last one as well: the done word
 //       is then raised by that launch).
-// gen: [2][FMAXB] restart parts | [2][FMAXB] loss parts | [2][4] state words {akn, index of the pending loss or -1}
+// gen: [2][FMAXB] restart parts | [2][FMAXB] loss parts | [2][4] state words {akn, 1 + index of the pending loss or 0}
 template <int HB, bool GEN>
 __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__restrict__ S, double *__restrict__ B, const double *__restrict__ P,
                                                           int *__restrict__ flags, int *__restrict__ fdone, int par, double d, int nblk, int qpad, int *__restrict__ nz32,
@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
             const int t = tid + 256 * k, tc = t < (int)gridDim.x ? t : 0;
             ap[k] = gen[(size_t)par * FMAXB + tc]; lp[k] = gen[(size_t)(2 + par) * FMAXB + tc];
         }
-        akn_prev = gen[4 * FMAXB + 4 * par]; loss_k = (int)gen[4 * FMAXB + 4 * par + 1];
+        akn_prev = gen[4 * FMAXB + 4 * par]; loss_k = (int)gen[4 * FMAXB + 4 * par + 1] - 1;      // (the word holds index + 1: the area starts zeroed = nothing pending)
     }
     int gs = 1, ge = 0;
     bool gz = false;
@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
         }
     }
     if (st.done) {                                                  // the launch after the last one: make both copies agree
-        if (blockIdx.x == 0 && tid == 0) { S[par ^ 1].done = 1; *fdone = 1; if (GEN) gen[4 * FMAXB + 4 * (par ^ 1) + 1] = -1.0; }
+        if (blockIdx.x == 0 && tid == 0) { S[par ^ 1].done = 1; *fdone = 1; if (GEN) gen[4 * FMAXB + 4 * (par ^ 1) + 1] = 0.0; }
         return;
     }
     if constexpr (GEN) {
@@ -1382,7 +1382,7 @@ __global__ __launch_bounds__(256) void sympk_head_kernel(PathArgs A, SState *__r
             const double lt = block_sum(own ? bo * (g - 2.0 * xyc) : 0.0, gsh);
             if (tid == 0) gen[(size_t)(2 + (par ^ 1)) * FMAXB + blockIdx.x] = lt;
         }
-        if (blockIdx.x == 0 && tid == 0) gen[4 * FMAXB + 4 * (par ^ 1) + 1] = (want_loss && finalize) ? (double)kfin : -1.0;
+        if (blockIdx.x == 0 && tid == 0) gen[4 * FMAXB + 4 * (par ^ 1) + 1] = (want_loss && finalize) ? (double)(kfin + 1) : 0.0;
     }
     if (done_now) {
         // (the products behind this launch return at once; a pending loss is written by the NEXT head, which then raises the word)
