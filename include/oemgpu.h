@@ -324,7 +324,9 @@ int oemgpu_selftest_wcoop_sizing(int32_t n, int32_t p, int32_t npen, int32_t num
 
 /* Host-only self-check of the engine PLAN (pure arithmetic, runs without a GPU): what api.hip: plan_paths decides for a call with
  * these sizes and options on a device of num_cu CUs -- *engine = the OEMGPU_ENGINE_* of the first attempt (+ 256 where the cooperating
- * engine is planned with every instance on ONE XCD: run time still asks the device for its layout) -- and whether the
+ * engine is planned with every instance on ONE XCD: run time still asks the device for its layout; + 512 k, k = 1, 2, 3, where the
+ * launch engines would run group operators in the head of their (head, product) pairs with k blocks of 32 coordinates on either side of
+ * a workgroup's own: every group a run of <= 32 k neighbouring coordinates) -- and whether the
  * buffers the callers size hold what the launch will carve: *frame_bytes (outputs + parameter blob + engine workspace) against
  * *reserved_bytes, and for p >= n (wide_n > 0 rows, no Gram matrix) the persistent engine's exchange buffers against the scratch
  * (*scratch_need_doubles <= *scratch_have_doubles).  p: columns of x; q: dimension of beta (p + 1 with big.oem's intercept);

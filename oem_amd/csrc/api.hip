@@ -1117,7 +1117,7 @@ int oemgpu_selftest_plan(int32_t p, int32_t q, int32_t semantics, int32_t interc
     in.has_scale = has_scale != 0; in.wide_n = (int)wide_n;
     PathPlan P;
     if (int rc = plan_paths(in, P)) return rc;
-    *engine = P.engine | (P.one_xcd ? 256 : 0);       // (bit 8: OEMGPU_ENGINE_COOP planned with every instance on one XCD)
+    *engine = P.engine | (P.one_xcd ? 256 : 0) | (P.grp_head << 9);      // (bit 8: OEMGPU_ENGINE_COOP planned with every instance on one XCD; bits 9-10: PathArgs::grp_head, what the launches would do with the groups)
     // the frame run_paths carves (outputs | blob slot | work) against what every caller reserves for it (paths_ws_bytes); the blob
     // slot is bounded by the reservation's first two terms, which this adds back as the groups' and lambdas' actual sizes
     const int nl = nl_of(o);

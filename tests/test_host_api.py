@@ -251,6 +251,7 @@ def _plan(p, pens, sem=_SEM_DENSE, intercept=0, groups=None, has_scale=False, nb
                                       C.byref(res), C.byref(need), C.byref(have))
     assert rc == 0, (p, pens, sem, L.lib().oemgpu_last_error().decode())
     _plan.one_xcd = bool(eng.value & 256)                         # (the cooperating engine planned with every instance on one XCD)
+    _plan.grp_head = (eng.value >> 9) & 3                         # (the launch engines' head form for group operators: window blocks on either side, 0 = update kernel)
     return _ENGINES[eng.value & 255], frame.value, res.value, need.value, have.value
 
 
@@ -433,6 +434,12 @@ def test_the_plan_names_one_engine_and_a_workspace_that_fits_at_every_size():
     assert _plan(4096, ["lasso"], sem=_SEM_XTX)[0] == "symcoop" and _plan(4096, ["lasso"], sem=_SEM_XTX, has_scale=True)[0] == "symcoop"      # config 4 (scale.factor: on the register-resident engine since round 5)
     assert _plan(257 - 1, ["lasso"], sem=_SEM_BIG, intercept=1)[0] == "coop"                                              # config 5: q = 257 (from 209 on)
     assert _plan(2048, ["lasso"])[0] == "rowcoop" and _plan(2048, ["grp.lasso"], groups=_RUNS4)[0] == "symcoop" and _plan(4097, ["lasso"])[0] == "launches"
+    # the launch engines beyond 4096 (and behind the register engines below): group operators in the head of the (head, product) pairs for groups
+    # of <= 96 members that are runs -- one, two or three 32-coordinate blocks on either side of a workgroup's own --, the update kernel beyond
+    for q, grp, level in ((5000, _RUNS4, 1), (8192, lambda n: np.arange(n) // 32 + 1, 1), (8192, _RUNS50, 2), (6145, lambda n: np.arange(n) // 96 + 1, 3),
+                          (8192, lambda n: np.arange(n) // 120 + 1, 0), (5000, _SCATTER, 0), (3000, _RUNS50, 2)):
+        assert _plan(q, ["grp.lasso", "lasso"], groups=grp, accelerate=True, compute_loss=True)[0] in ("launches", "symcoop") and _plan.grp_head == level, (q, level, _plan.grp_head)
+    assert _plan(5000, ["lasso"])[0] == "launches" and _plan.grp_head == 0
     # groups of more than 32 members stay on the register engine (their norms summed over several owners' slices)
     for q in (1025, 1536, 3000, 4096):
         assert _plan(q, ["grp.lasso"], groups=_RUNS50)[0] == "symcoop" and _plan(q, ["grp.mcp"], groups=_RUNS7, accelerate=True)[0] == "symcoop", q
